@@ -1,0 +1,212 @@
+/*
+ * snvc_hip.h -- C ABI of libsnvc_hip.so, the MI355X (gfx950) implementation of SNVC's
+ * cost-volume / voxel-resampling / 3D-CNN hot path.
+ *
+ * The reference has no C FFI: its native boundary is three pybind11 modules taking
+ * at::Tensor.  The entry points below are what those modules'
+ * bodies would call once tensors have been checked and unwrapped, in the reference's own
+ * raw-pointer launcher style (snvc/extension/roiaware_pool3d/src/roiaware_pool3d.cpp:19-27):
+ * plain device pointers + sizes + a stream, no allocation (except where stated), no
+ * synchronisation, int status return (0 = ok).  Each declaration cites the reference
+ * interface it replaces.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - tensors are contiguous in the layout given (NCDHW family, W fastest), exactly the
+ *     layout the reference's .contiguous().data<T>() hands its kernels;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call is
+ *     asynchronous on that stream;
+ *   - sizes are int64_t, indices inside the kernels are 64-bit (the reference overflows
+ *     32-bit indices at N*2C*D*H*W >= 2^31, BuildCostVolume_cuda.cu:70-82);
+ *   - status codes: see snvc_status; snvc_last_error_string() gives the text of the last
+ *     failing call on the calling thread.
+ */
+#ifndef SNVC_HIP_H
+#define SNVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNVC_API __attribute__((visibility("default")))
+
+typedef enum {
+    SNVC_OK = 0,
+    SNVC_ERR_INVALID_ARGUMENT = 1, /* shapes / flags the kernels cannot honour */
+    SNVC_ERR_UNSUPPORTED = 2,      /* valid request outside the instantiated kernel set */
+    SNVC_ERR_HIP = 3               /* a HIP runtime call or launch failed */
+} snvc_status;
+
+typedef enum { SNVC_F32 = 0, SNVC_F64 = 1 } snvc_dtype;
+
+SNVC_API const char *snvc_last_error_string(void);
+/* Version of this ABI; bumped on any signature change. */
+SNVC_API int snvc_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * a1 / a2  build_cost_volume
+ * replaces: build_cost_volume_cuda.build_cost_volume_forward / _backward
+ *           (snvc/extension/build_cost_volume/src/BuildCostVolume.cpp:13-48,
+ *            launchers BuildCostVolume_cuda.cu:208-303)
+ *   left,right [N,C,Hi,Wi]   shift [N,D] (>= 0, same dtype)   out [N,2C,D,Hi/ds,Wi/ds]
+ *   Hi and Wi must be multiples of ds (the reference silently mis-strides otherwise).
+ * backward: grad [N,2C,D,H,W] -> grad_left, grad_right [N,C,H*ds,W*ds]; both outputs are
+ *   fully written (no pre-zeroing needed); deterministic gather, no atomics.
+ * ---------------------------------------------------------------------------------- */
+SNVC_API int snvc_cost_volume_forward(const void *left, const void *right, const void *shift,
+                                      void *out, int64_t N, int64_t C, int64_t Hi, int64_t Wi,
+                                      int64_t D, int64_t downsample, int dtype, void *stream);
+SNVC_API int snvc_cost_volume_backward(const void *grad, const void *shift, void *grad_left,
+                                       void *grad_right, int64_t N, int64_t C, int64_t H,
+                                       int64_t W, int64_t D, int64_t downsample, int dtype,
+                                       void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a3  feature -> voxel resampling
+ * replaces: VernierScale._sample_2d_feat(aggregate="concat")  (snvc/models/vernier.py:323-349):
+ *   coordinate normalisation (:335-338) + 2x F.grid_sample(bilinear, zeros, align_corners=False)
+ *   (:339-340) + torch.cat (:346), in one pass.
+ *   left,right [N,F,Hf,Wf]   l_pts,r_pts [N,2,V] RoI-pixel (x row, y row)
+ *   res_x = cfg.resolution[1], res_y = cfg.resolution[0]   out [N,2F,V] (V = nh*nw*nl)
+ *   The coordinate tensors are NOT modified (the reference normalises them in place).
+ * ---------------------------------------------------------------------------------- */
+SNVC_API int snvc_voxel_gather_forward(const float *left, const float *right, const float *l_pts,
+                                       const float *r_pts, float *out, int64_t N, int64_t F,
+                                       int64_t Hf, int64_t Wf, int64_t V, float res_x,
+                                       float res_y, void *stream);
+/* adjoint of the above w.r.t. the feature maps (bilinear scatter); grad_left/right [N,F,Hf,Wf]
+ * are fully written; deterministic order is NOT guaranteed (float atomics), like
+ * grid_sampler_2d_backward on GPUs. */
+SNVC_API int snvc_voxel_gather_backward(const float *grad_out, const float *l_pts,
+                                        const float *r_pts, float *grad_left, float *grad_right,
+                                        int64_t N, int64_t F, int64_t Hf, int64_t Wf, int64_t V,
+                                        float res_x, float res_y, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a4-a7  3D convolution / transposed convolution with fused epilogue
+ * replaces: nn.Conv3d / nn.ConvTranspose3d (+ eval-mode BatchNorm3d or a per-channel affine)
+ *   (+ residual add) (+ ReLU / Sigmoid) as composed by convbn_3d, hourglass,
+ *   get_hg_down_sample / get_hg_up_sample, hourglass_downsample_16
+ *   (snvc/models/submodule.py:32-50,85-268) and VernierScale._init_3d_net /
+ *   predict_3d_heatmaps (snvc/models/vernier.py:249-295,414-438).
+ *
+ *   y = epilogue( conv(x, w) ),   epilogue(v) for output channel c:
+ *       v = v * scale[c] + bias[c]           (scale/bias may be NULL: identity)
+ *       if (flags & SNVC_EPI_ADD_PRE)  v += residual
+ *       if (flags & SNVC_EPI_RELU)     v = max(v, 0)
+ *       if (flags & SNVC_EPI_SIGMOID)  v = 1 / (1 + exp(-v))
+ *       if (flags & SNVC_EPI_ADD_POST) v += residual
+ *
+ *   x [N,Cin,Din,Hin,Win]  y [N,Cout,Dout,Hout,Wout]  residual like y.
+ *   Batch strides (in elements) let x / y / residual be channel slices of larger buffers
+ *   (the torch.cat of vernier.py:433 is built in place that way); 0 = dense.
+ *   Cubic kernels only, as on the path: ksize in {1,3,5,7}, stride in {1,2}, dilation in {1,2}
+ *   with pad = dilation*(ksize-1)/2 ("same" for stride 1); transposed: ksize 3, stride 2,
+ *   pad 1, output_padding 1 (Dout = 2*Din).
+ *   Arithmetic: fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+ * ---------------------------------------------------------------------------------- */
+enum {
+    SNVC_EPI_RELU = 1,
+    SNVC_EPI_ADD_PRE = 2,
+    SNVC_EPI_ADD_POST = 4,
+    SNVC_EPI_SIGMOID = 8
+};
+
+typedef struct {
+    int32_t N, Cin, Din, Hin, Win;
+    int32_t Cout, Dout, Hout, Wout;
+    int32_t ksize, stride, dilation, pad;
+    int32_t transposed; /* 0: Conv3d, 1: ConvTranspose3d(k3,s2,p1,op1) */
+    int32_t flags;      /* SNVC_EPI_* */
+    int32_t reserved;
+    int64_t x_batch_stride, y_batch_stride, res_batch_stride; /* elements; 0 = dense */
+} snvc_conv3d_desc;
+
+/* Number of floats of the packed-weight buffer for this layer. */
+SNVC_API int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *desc_host);
+/* Re-lays nn.Conv3d weights [Cout,Cin,k,k,k] (or nn.ConvTranspose3d weights [Cin,Cout,3,3,3]
+ * when desc.transposed) into the kernel's streaming order.  Run once per layer. */
+SNVC_API int snvc_conv3d_pack_weights(const snvc_conv3d_desc *desc_host, const float *weight,
+                                      float *packed, void *stream);
+SNVC_API int snvc_conv3d_forward(const snvc_conv3d_desc *desc_host, const float *x,
+                                 const float *packed_weight, const float *scale,
+                                 const float *bias, const float *residual, float *y,
+                                 void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Normalisation statistics for GroupNorm / train-mode BatchNorm3d
+ * replaces: nn.GroupNorm(32, C) / nn.BatchNorm3d(C).train() inside convbn_3d
+ *           (snvc/models/submodule.py:49,135,146,206)
+ *   x [N,C,S] (S = D*H*W).  Statistics are taken over `groups` contiguous channel groups per
+ *   sample (GroupNorm: per_sample = 1) or over the whole batch per channel (BatchNorm:
+ *   per_sample = 0, groups = C).  Outputs: scale[N or 1][C], shift[N or 1][C] such that
+ *   y = x * scale + shift reproduces (x - mean) * rsqrt(var + eps) * gamma + beta (biased var);
+ *   mean_out / var_out (may be NULL) receive the statistics [N or 1][groups].
+ *   workspace: at least snvc_norm_workspace_bytes() bytes.
+ * ---------------------------------------------------------------------------------- */
+SNVC_API int64_t snvc_norm_workspace_bytes(int64_t N, int64_t C, int64_t groups);
+SNVC_API int snvc_norm_stats(const float *x, const float *gamma, const float *beta,
+                             float *scale, float *shift, float *mean_out, float *var_out,
+                             void *workspace, int64_t N, int64_t C, int64_t S,
+                             int64_t x_batch_stride, int64_t groups, int per_sample, float eps,
+                             void *stream);
+/* y = epilogue(x * scale[n?][c] + shift[n?][c]) with the SNVC_EPI_* flags; in-place allowed. */
+SNVC_API int snvc_affine_act(const float *x, const float *scale, const float *shift,
+                             const float *residual, float *y, int64_t N, int64_t C, int64_t S,
+                             int64_t x_batch_stride, int64_t y_batch_stride,
+                             int64_t res_batch_stride, int per_sample, int flags, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small fused element-wise steps of predict_3d_heatmaps
+ * ---------------------------------------------------------------------------------- */
+/* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half
+ *   (snvc/models/vernier.py:433): out[n,c,s] = feat[n,c,s] * occ[n,0,s]; out may be a channel
+ *   slice of the concat buffer (out_batch_stride). */
+SNVC_API int snvc_mul_broadcast(const float *feat, const float *occ, float *out, int64_t N,
+                                int64_t C, int64_t S, int64_t out_batch_stride, void *stream);
+/* replaces: AvgPool3d((4,1,1),(4,1,1)) + reshape to BEV (vernier.py:289,436-438):
+ *   x [N,C,D,H*W] -> y [N,C,D/4,H*W] (== [N, C*D/4, H, W] after a free reshape). */
+SNVC_API int snvc_avgpool_depth4(const float *x, float *y, int64_t N, int64_t C, int64_t D,
+                                 int64_t HW, void *stream);
+/* replaces: disparityregression.forward (snvc/models/submodule.py:81-83):
+ *   out[n,h,w] = sum_d x[n,d,h,w] * depth[d]. */
+SNVC_API int snvc_disparity_regression(const float *x, const float *depth, float *out, int64_t N,
+                                       int64_t D, int64_t HW, void *stream);
+/* replaces: np.argmax over the flattened heatmap (snvc/models/vernier.py:683-693, :570-572):
+ *   x [R, L] -> idx [R] int64 (first maximum, numpy semantics; NaN counts as maximal like numpy),
+ *   val [R] (may be NULL). */
+SNVC_API int snvc_argmax_rows(const float *x, int64_t *idx, float *val, int64_t R, int64_t L,
+                              void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * a10  roiaware_pool3d
+ * replaces: roiaware_pool3d_cuda.forward / backward / points_in_boxes_gpu / points_in_boxes_cpu
+ *   (snvc/extension/roiaware_pool3d/src/roiaware_pool3d.cpp:29-177; kernels
+ *    roiaware_pool3d_kernel.cu:39-336).  Same contract: the caller pre-zeroes argmax,
+ *   pts_idx_of_voxels, pooled (roiaware_pool3d_utils.py:124-126) and grad_in (:142).
+ *   rois [B,7]  pts [P,3]  feat [P,C]  argmax/pooled [B,ox,oy,oz,C]
+ *   pts_idx_of_voxels [B,ox,oy,oz,max_pts] (slot 0 = count).  pool_method 0 max / 1 avg.
+ *   workspace: B*P int32 (the reference cudaMalloc's it per call, :203-205,228).
+ * ---------------------------------------------------------------------------------- */
+SNVC_API int snvc_roiaware_pool3d_forward(const float *rois, const float *pts, const float *feat,
+                                          int32_t *argmax, int32_t *pts_idx_of_voxels,
+                                          float *pooled, int32_t *workspace, int B, int P, int C,
+                                          int max_pts, int ox, int oy, int oz, int pool_method,
+                                          void *stream);
+SNVC_API int snvc_roiaware_pool3d_backward(const int32_t *pts_idx_of_voxels, const int32_t *argmax,
+                                           const float *grad_out, float *grad_in, int B, int C,
+                                           int max_pts, int ox, int oy, int oz, int pool_method,
+                                           void *stream);
+/* boxes [Bs,T,7], pts [Bs,M,3], out [Bs,M] pre-filled with -1 by the caller. */
+SNVC_API int snvc_points_in_boxes_gpu(const float *boxes, const float *pts, int32_t *out, int Bs,
+                                      int T, int M, void *stream);
+/* HOST pointers (the reference op is a CPU function): boxes [T,7], pts [M,3], out [T,M]. */
+SNVC_API int snvc_points_in_boxes_cpu(const float *boxes_host, const float *pts_host,
+                                      int32_t *out_host, int T, int M);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNVC_HIP_H */

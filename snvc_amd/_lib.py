@@ -1,0 +1,87 @@
+"""ctypes binding of ``libsnvc_hip.so`` (the C ABI declared in ``include/snvc_hip.h``).
+
+The product path has no fallback: if the shared library is missing or a call fails, a
+``RuntimeError`` is raised.  Nothing here (or anywhere under ``snvc_amd``) imports ``oracle``.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnvc_hip.so")
+_lib = None
+
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_p = ctypes.c_void_p
+c_int = ctypes.c_int
+
+
+class Conv3dDesc(ctypes.Structure):
+    """Mirror of ``snvc_conv3d_desc`` (include/snvc_hip.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "N", "Cin", "Din", "Hin", "Win", "Cout", "Dout", "Hout", "Wout",
+        "ksize", "stride", "dilation", "pad", "transposed", "flags", "reserved")] + [
+        (n, ctypes.c_int64) for n in ("x_batch_stride", "y_batch_stride", "res_batch_stride")]
+
+
+EPI_RELU, EPI_ADD_PRE, EPI_ADD_POST, EPI_SIGMOID = 1, 2, 4, 8
+F32, F64 = 0, 1
+
+# name -> (restype, argtypes); kept next to the header so the symbol test can walk it
+SIGNATURES = {
+    "snvc_last_error_string": (ctypes.c_char_p, []),
+    "snvc_abi_version": (c_int, []),
+    "snvc_cost_volume_forward": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    "snvc_cost_volume_backward": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    "snvc_voxel_gather_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
+    "snvc_voxel_gather_backward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
+    "snvc_conv3d_packed_weight_count": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
+    "snvc_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p]),
+    "snvc_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "snvc_norm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "snvc_norm_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_p]),
+    "snvc_affine_act": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "snvc_mul_broadcast": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_disparity_regression": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p]),
+    "snvc_argmax_rows": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
+    "snvc_roiaware_pool3d_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
+    "snvc_roiaware_pool3d_backward": (c_int, [c_p, c_p, c_p, c_p] + [c_int] * 7 + [c_p]),
+    "snvc_points_in_boxes_gpu": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
+    "snvc_points_in_boxes_cpu": (c_int, [c_p, c_p, c_p, c_int, c_int]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into snvc_amd/libsnvc_hip.so (hipcc, no GPU needed)."""
+    cmd = ["make", "-s", "-j8", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C snvc_amd/csrc`). "
+                "snvc_amd has no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        if handle.snvc_abi_version() != 1:
+            raise RuntimeError("libsnvc_hip.so ABI version mismatch; rebuild it")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().snvc_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError(f"{what or 'snvc_hip'} failed (status {rc}): {msg}")

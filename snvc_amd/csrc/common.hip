@@ -1,0 +1,19 @@
+#include "common.hpp"
+
+#include <cstring>
+
+namespace snvc {
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace snvc
+
+extern "C" {
+const char *snvc_last_error_string(void) { return snvc::g_err; }
+int snvc_abi_version(void) { return 1; }
+}

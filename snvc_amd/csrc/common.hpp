@@ -1,0 +1,37 @@
+// Shared host-side helpers for libsnvc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "snvc_hip.h"
+
+namespace snvc {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+inline int fail(int code, const char *msg) {
+    set_error("%s", msg);
+    return code;
+}
+
+// Called after every launch: hipGetLastError is a host-side query (no device sync).
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return SNVC_ERR_HIP;
+    }
+    return SNVC_OK;
+}
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename T>
+__host__ __device__ inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+}  // namespace snvc

@@ -1,0 +1,588 @@
+// 3D convolution / transposed convolution with fused epilogue for gfx950
+// (SURVEY.md section 8 rows a4-a7).
+//
+// What the reference does: nn.Conv3d / nn.ConvTranspose3d through cuDNN, then separate
+// BatchNorm3d, residual-add and ReLU kernels (snvc/models/submodule.py:32-50,85-268;
+// snvc/models/vernier.py:249-295,414-438).
+//
+// What this file does instead -- a direct (im2col-free) convolution shaped for CDNA4:
+//   * GEMM view per workgroup:  Y^T[Cout x voxels] = W[Cout x (Cin*taps)] * X[(Cin*taps) x voxels].
+//     The MFMA's A operand is the weight (rows = output channels), the B operand is the
+//     activation (columns = 32 consecutive output voxels along W).  With NCDHW tensors this
+//     orientation makes every operand access unit-stride: B fragments are 32 consecutive
+//     floats of an LDS row, and each accumulator register is a 128-byte contiguous run of one
+//     output channel, so the epilogue stores whole cache lines without a transpose.
+//   * v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-exact FMA chain (no reduced
+//     precision anywhere); one VGPR per operand per lane.
+//   * The input tile (+halo) of KC input channels is staged once in LDS and re-used by all
+//     k^3 taps: a tap is only a constant LDS address offset.  Zero padding is materialised in
+//     LDS, so the inner loop has no bounds checks.
+//   * Weights are pre-packed (snvc_conv3d_pack_weights) into the exact order the waves
+//     stream them, fragment by fragment, from L2.
+//   * Epilogue fused in registers: per-channel affine (folded eval BatchNorm), residual add
+//     before or after the activation, ReLU / Sigmoid, channel-sliced output (builds the
+//     torch.cat of vernier.py:433 in place).
+//   * ConvTranspose3d(k3,s2,p1,op1) is computed as 8 parity-class sub-convolutions over the
+//     INPUT grid (27 taps per 8 outputs; no zero insertion): a workgroup owns one
+//     (depth-parity, height-parity) class, keeps both width parities in registers and
+//     stores them interleaved as 8-byte pairs.
+//   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs (round-robin dispatch) each get a
+//     contiguous run of tiles so that halo re-reads hit that XCD's L2.
+#include "common.hpp"
+
+namespace snvc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float *x;
+    const float *wp;
+    const float *scale;
+    const float *bias;
+    const float *res;
+    float *y;
+    int Cin, Din, Hin, Win;
+    int Cout, Dout, Hout, Wout;
+    int tiles_d, tiles_h, tiles_w;
+    int nchunks, flags;
+    int64_t x_bs, y_bs, r_bs;
+};
+
+__device__ __forceinline__ float epilogue_f(float v, float res, int flags) {
+    if (flags & SNVC_EPI_ADD_PRE) v += res;
+    if (flags & SNVC_EPI_RELU) v = v > 0.0f ? v : 0.0f;
+    if (flags & SNVC_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    if (flags & SNVC_EPI_ADD_POST) v += res;
+    return v;
+}
+
+// Bijective XCD-aware remap (cdna guide T1): blocks b and b+8 share an XCD; give each XCD a
+// contiguous range of logical tiles.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n >> 3, r = n & 7, xcd = b & 7, k = b >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+// ------------------------------------------------------------------------------------ conv
+template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_>
+struct ConvCfg {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, DIL = DIL_, MI = MI_, TD = TD_, TH = TH_, KC = KC_;
+    static constexpr int TW = 32;
+    static constexpr int PAD = DIL * (KS - 1) / 2;
+    static constexpr int IN_D = (TD - 1) * STRIDE + (KS - 1) * DIL + 1;
+    static constexpr int IN_H = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
+    static constexpr int IN_W = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
+    static constexpr int CH = IN_D * IN_H * IN_W;  // floats per staged channel
+    static constexpr int TILE = KC * CH;
+    static constexpr int NB = TD * TH / 4;         // 32-voxel rows per wave (4 waves)
+    static constexpr int KP = KC / 2;              // MFMA k-steps per chunk
+    static constexpr int TAPS = KS * KS * KS;
+    static constexpr int LDS_BYTES = TILE * 4;
+    static_assert(TD * TH % 4 == 0, "rows must split over 4 waves");
+    static_assert(KC % 2 == 0, "KC must be even (MFMA K = 2)");
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(256, 2)
+conv3d_mfma_kernel(const ConvArgs a) {
+    constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH;
+    constexpr int KC = Cfg::KC, KP = Cfg::KP, NB = Cfg::NB, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W;
+    constexpr int CH = Cfg::CH, TILE = Cfg::TILE, TAPS = Cfg::TAPS, PAD = Cfg::PAD;
+    constexpr int UNR = KS <= 3 ? KS : 1;  // small kernels: fully unrolled taps; k5/k7: kd,kh loops stay rolled
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
+    const int cg = blockIdx.y;  // group of 32*MI output channels
+    const int64_t n = blockIdx.z;
+    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 32;
+    const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+
+    f32x16 acc[NB][MI];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][m][r] = 0.0f;
+
+    const int64_t in_hw = (int64_t)a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const float *xn = a.x + n * a.x_bs;
+    const float *wp = a.wp + (int64_t)cg * a.nchunks * TAPS * KP * 64 * MI + lane * MI;
+    // B-fragment base: lane&31 = voxel column, lane>>5 = k within the k-pair
+    const int bbase = (lane >> 5) * CH + (lane & 31) * S;
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        __syncthreads();  // everyone is done reading the previous tile
+        // ---- stage KC channels of the input tile (zero padded) into LDS
+        const int c0 = chunk * KC;
+        constexpr int ITER = (TILE + 255) / 256;
+#pragma unroll 8
+        for (int it = 0; it < ITER; ++it) {
+            const int e = it * 256 + tid;
+            if (e < TILE) {
+                const int kc = e / CH, rem = e - kc * CH;
+                const int dd = rem / (IN_H * IN_W), rem2 = rem - dd * (IN_H * IN_W);
+                const int hh = rem2 / IN_W, ww = rem2 - hh * IN_W;
+                const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww, gc = c0 + kc;
+                float v = 0.0f;
+                if (gc < a.Cin && (unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Hin &&
+                    (unsigned)gw < (unsigned)a.Win)
+                    v = xn[gc * in_dhw + gd * in_hw + (int64_t)gh * a.Win + gw];
+                lds[e] = v;
+            }
+        }
+        __syncthreads();
+        // ---- k^3 taps x KP k-steps on the staged tile
+        const float *wc = wp + (int64_t)chunk * TAPS * KP * 64 * MI;
+#pragma unroll UNR
+        for (int kd = 0; kd < KS; ++kd) {
+#pragma unroll UNR
+            for (int kh = 0; kh < KS; ++kh) {
+                const float *wrow = wc + (int64_t)((kd * KS + kh) * KS) * KP * 64 * MI;
+                const int tap_base = bbase + (kd * DIL * IN_H + kh * DIL) * IN_W;
+#pragma unroll
+                for (int kw = 0; kw < KS; ++kw) {
+#pragma unroll
+                    for (int kp = 0; kp < KP; ++kp) {
+                        float af[MI];
+#pragma unroll
+                        for (int m = 0; m < MI; ++m) af[m] = wrow[(kw * KP + kp) * 64 * MI + m];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int row = wave * NB + nb;
+                            const int dd = row / TH, hh = row % TH;
+                            const float bf = lds[tap_base + kp * 2 * CH + (dd * S * IN_H + hh * S) * IN_W + kw * DIL];
+#pragma unroll
+                            for (int m = 0; m < MI; ++m)
+                                acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf, acc[nb][m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: acc[nb][m][r] = Y[cout = cg*32*MI + m*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
+    //                                 [voxel = (od0+dd, oh0+hh, ow0 + (lane&31))]
+    const int ow = ow0 + (lane & 31);
+    const int64_t out_hw = (int64_t)a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
+    float *yn = a.y + n * a.y_bs;
+    const float *rn = a.res ? a.res + n * a.r_bs : nullptr;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int od = od0 + row / TH, oh = oh0 + row % TH;
+        const bool vox_ok = od < a.Dout && oh < a.Hout && ow < a.Wout;
+        const int64_t sp = od * out_hw + (int64_t)oh * a.Wout + ow;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * 32 * MI + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (vox_ok && co < a.Cout) {
+                    float v = acc[nb][m][r];
+                    if (a.scale) v = v * a.scale[co] + a.bias[co];
+                    const float rv = rn ? rn[co * out_dhw + sp] : 0.0f;
+                    yn[co * out_dhw + sp] = epilogue_f(v, rv, a.flags);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ deconv
+// ConvTranspose3d(k=3, s=2, p=1, op=1): out[o] = sum_i sum_t x[i] * w[t], o = 2i - 1 + t.
+// Per dimension, output parity 0 uses tap 1 at input offset 0; parity 1 uses tap 2 at offset 0
+// and tap 0 at offset +1.
+template <int MI_, int TD_, int TH_, int KC_>
+struct DeconvCfg {
+    static constexpr int MI = MI_, TD = TD_, TH = TH_, KC = KC_;
+    static constexpr int IN_D = TD + 1, IN_H = TH + 1, IN_W = 33;
+    static constexpr int CH = IN_D * IN_H * IN_W;
+    static constexpr int TILE = KC * CH;
+    static constexpr int NB = TD * TH / 4;
+    static constexpr int KP = KC / 2;
+    static constexpr int LDS_BYTES = TILE * 4;
+    static_assert(TD * TH % 4 == 0, "rows must split over 4 waves");
+};
+
+__host__ __device__ constexpr int deconv_class_ntaps(int pd, int ph) { return (pd ? 2 : 1) * (ph ? 2 : 1) * 3; }
+__host__ __device__ constexpr int deconv_class_offset(int cls) {  // cls = pd*2 + ph
+    return cls == 0 ? 0 : cls == 1 ? 3 : cls == 2 ? 9 : 15;
+}
+
+template <class Cfg, int PD, int PH>
+__device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds, int tile, int cg, int64_t n) {
+    constexpr int MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, KP = Cfg::KP, NB = Cfg::NB;
+    constexpr int IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, CH = Cfg::CH, TILE = Cfg::TILE;
+    constexpr int ND = PD ? 2 : 1, NH = PH ? 2 : 1;
+    constexpr int CLS_OFF = deconv_class_offset(PD * 2 + PH);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, td = tile / (a.tiles_w * a.tiles_h);
+    const int id0 = td * TD, ih0 = th * TH, iw0 = tw * 32;
+
+    f32x16 acc[2][NB][MI];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int m = 0; m < MI; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][nb][m][r] = 0.0f;
+
+    const int64_t in_hw = (int64_t)a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const float *xn = a.x + n * a.x_bs;
+    const float *wp = a.wp + (int64_t)cg * a.nchunks * 27 * KP * 64 * MI + lane * MI;
+    const int bbase = (lane >> 5) * CH + (lane & 31);
+
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        __syncthreads();
+        const int c0 = chunk * KC;
+        constexpr int ITER = (TILE + 255) / 256;
+#pragma unroll 8
+        for (int it = 0; it < ITER; ++it) {
+            const int e = it * 256 + tid;
+            if (e < TILE) {
+                const int kc = e / CH, rem = e - kc * CH;
+                const int dd = rem / (IN_H * IN_W), rem2 = rem - dd * (IN_H * IN_W);
+                const int hh = rem2 / IN_W, ww = rem2 - hh * IN_W;
+                const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww, gc = c0 + kc;
+                float v = 0.0f;
+                if (gc < a.Cin && gd < a.Din && gh < a.Hin && gw < a.Win)
+                    v = xn[gc * in_dhw + gd * in_hw + (int64_t)gh * a.Win + gw];
+                lds[e] = v;
+            }
+        }
+        __syncthreads();
+        const float *wc = wp + ((int64_t)chunk * 27 + CLS_OFF) * KP * 64 * MI;
+        int tix = 0;  // running tap index inside this class (matches the packing order)
+#pragma unroll
+        for (int jd = 0; jd < ND; ++jd) {
+            const int dld = (PD && jd == 1) ? 1 : 0;  // input offset (+1 for tap 0)
+#pragma unroll
+            for (int jh = 0; jh < NH; ++jh) {
+                const int dlh = (PH && jh == 1) ? 1 : 0;
+#pragma unroll
+                for (int jw = 0; jw < 3; ++jw, ++tix) {
+                    // jw = 0: width parity 0 (tap 1, offset 0); 1: parity 1 (tap 2, offset 0);
+                    // 2: parity 1 (tap 0, offset +1)
+                    const int pw = jw == 0 ? 0 : 1;
+                    const int dlw = jw == 2 ? 1 : 0;
+#pragma unroll
+                    for (int kp = 0; kp < KP; ++kp) {
+                        float af[MI];
+#pragma unroll
+                        for (int m = 0; m < MI; ++m) af[m] = wc[(tix * KP + kp) * 64 * MI + m];
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) {
+                            const int row = wave * NB + nb;
+                            const int dd = row / TH, hh = row % TH;
+                            const float bf = lds[bbase + kp * 2 * CH + ((dd + dld) * IN_H + hh + dlh) * IN_W + dlw];
+#pragma unroll
+                            for (int m = 0; m < MI; ++m)
+                                acc[pw][nb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf, acc[pw][nb][m], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // epilogue: outputs (2*id + PD, 2*ih + PH, 2*iw + {0,1}) -> one 8-byte store per lane
+    const int iw = iw0 + (lane & 31);
+    const int64_t out_hw = (int64_t)a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
+    float *yn = a.y + n * a.y_bs;
+    const float *rn = a.res ? a.res + n * a.r_bs : nullptr;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int id = id0 + row / TH, ih = ih0 + row % TH;
+        const bool vox_ok = id < a.Din && ih < a.Hin && iw < a.Win;
+        const int64_t sp = (int64_t)(2 * id + PD) * out_hw + (int64_t)(2 * ih + PH) * a.Wout + 2 * iw;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cg * 32 * MI + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (vox_ok && co < a.Cout) {
+                    float v0 = acc[0][nb][m][r], v1 = acc[1][nb][m][r];
+                    if (a.scale) {
+                        const float sc = a.scale[co], bi = a.bias[co];
+                        v0 = v0 * sc + bi;
+                        v1 = v1 * sc + bi;
+                    }
+                    float r0 = 0.0f, r1 = 0.0f;
+                    if (rn) {
+                        const float2 rr = *reinterpret_cast<const float2 *>(rn + co * out_dhw + sp);
+                        r0 = rr.x; r1 = rr.y;
+                    }
+                    *reinterpret_cast<float2 *>(yn + co * out_dhw + sp) =
+                        make_float2(epilogue_f(v0, r0, a.flags), epilogue_f(v1, r1, a.flags));
+                }
+            }
+        }
+    }
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(256, 2)
+deconv3d_mfma_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+    // heaviest class first (12 taps), lightest last: blockIdx.x = cls_order * ntiles + tile
+    const int slot = blockIdx.x / ntiles;
+    const int tile = xcd_remap(blockIdx.x - slot * ntiles, ntiles);
+    const int cg = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    switch (slot) {  // wave-uniform
+        case 0: deconv_class_body<Cfg, 1, 1>(a, lds, tile, cg, n); break;
+        case 1: deconv_class_body<Cfg, 1, 0>(a, lds, tile, cg, n); break;
+        case 2: deconv_class_body<Cfg, 0, 1>(a, lds, tile, cg, n); break;
+        default: deconv_class_body<Cfg, 0, 0>(a, lds, tile, cg, n); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------ packing
+// Conv:    packed[cg][chunk][tap][kp][half][i][m] = W[co = cg*32*MI + m*32 + i][ci = chunk*KC + 2kp + half][tap]
+// Deconv:  same with tap enumerated class by class (see deconv_class_body) and
+//          W indexed [ci][co][tap] (nn.ConvTranspose3d layout).
+__global__ void pack_conv_weights_kernel(const float *__restrict__ w, float *__restrict__ packed,
+                                         int Cout, int Cin, int taps, int MI, int KC, int nchunks,
+                                         int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int KP = KC / 2;
+    int64_t r = i;
+    const int m = (int)(r % MI); r /= MI;
+    const int ii = (int)(r % 32); r /= 32;
+    const int half = (int)(r % 2); r /= 2;
+    const int kp = (int)(r % KP); r /= KP;
+    const int tap = (int)(r % taps); r /= taps;
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int cg = (int)r;
+    const int co = cg * 32 * MI + m * 32 + ii, ci = chunk * KC + 2 * kp + half;
+    packed[i] = (co < Cout && ci < Cin) ? w[((int64_t)co * Cin + ci) * taps + tap] : 0.0f;
+}
+
+__device__ __forceinline__ int deconv_tap_of_slot(int slot) {
+    // slot in [0,27): class-major order used by deconv_class_body
+    int cls, t;
+    if (slot < 3) { cls = 0; t = slot; } else if (slot < 9) { cls = 1; t = slot - 3; }
+    else if (slot < 15) { cls = 2; t = slot - 9; } else { cls = 3; t = slot - 15; }
+    const int pd = cls >> 1, ph = cls & 1;
+    const int nh = ph ? 2 : 1;
+    const int jw = t % 3, jh = (t / 3) % nh, jd = t / (3 * nh);
+    const int kd = pd ? (jd == 0 ? 2 : 0) : 1;
+    const int kh = ph ? (jh == 0 ? 2 : 0) : 1;
+    const int kw = jw == 0 ? 1 : (jw == 1 ? 2 : 0);
+    return (kd * 3 + kh) * 3 + kw;
+}
+
+__global__ void pack_deconv_weights_kernel(const float *__restrict__ w, float *__restrict__ packed,
+                                           int Cout, int Cin, int MI, int KC, int nchunks, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int KP = KC / 2;
+    int64_t r = i;
+    const int m = (int)(r % MI); r /= MI;
+    const int ii = (int)(r % 32); r /= 32;
+    const int half = (int)(r % 2); r /= 2;
+    const int kp = (int)(r % KP); r /= KP;
+    const int slot = (int)(r % 27); r /= 27;
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int cg = (int)r;
+    const int co = cg * 32 * MI + m * 32 + ii, ci = chunk * KC + 2 * kp + half;
+    packed[i] = (co < Cout && ci < Cin) ? w[((int64_t)ci * Cout + co) * 27 + deconv_tap_of_slot(slot)] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------ dispatch
+struct Plan {
+    int MI, KC, TD, TH;  // tile choice
+    int groups, nchunks;
+    int tiles_d, tiles_h, tiles_w;
+    int kind;  // index into the instantiation table
+};
+
+enum Kind {
+    K1_M1, K1_M2,
+    K3_M1, K3_M2,
+    K3S2_M1, K3S2_M2,
+    K5_M1, K5_M2,
+    K5D2_M1, K5D2_M2,
+    K7_M1, K7_M2,
+    DC_M1, DC_M2,
+    KIND_NONE
+};
+
+//                       KS S  D  MI TD TH KC
+using CfgK1M1   = ConvCfg<1, 1, 1, 1, 4, 8, 8>;
+using CfgK1M2   = ConvCfg<1, 1, 1, 2, 4, 4, 8>;
+using CfgK3M1   = ConvCfg<3, 1, 1, 1, 4, 8, 4>;
+using CfgK3M2   = ConvCfg<3, 1, 1, 2, 4, 4, 4>;
+using CfgK3S2M1 = ConvCfg<3, 2, 1, 1, 2, 4, 4>;
+using CfgK3S2M2 = ConvCfg<3, 2, 1, 2, 2, 4, 4>;
+using CfgK5M1   = ConvCfg<5, 1, 1, 1, 4, 8, 4>;
+using CfgK5M2   = ConvCfg<5, 1, 1, 2, 4, 4, 4>;
+using CfgK5D2M1 = ConvCfg<5, 1, 2, 1, 4, 8, 2>;
+using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2>;
+using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 8, 2>;
+using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2>;
+using CfgDCM1   = DeconvCfg<1, 2, 4, 8>;
+using CfgDCM2   = DeconvCfg<2, 2, 4, 8>;
+
+template <class Cfg>
+constexpr Plan plan_of(int kind) { return Plan{Cfg::MI, Cfg::KC, Cfg::TD, Cfg::TH, 0, 0, 0, 0, 0, kind}; }
+
+int make_plan(const snvc_conv3d_desc &d, Plan &p) {
+    if (d.N < 0 || d.Cin <= 0 || d.Cout <= 0 || d.Din <= 0 || d.Hin <= 0 || d.Win <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: sizes must be positive");
+    const bool wide = d.Cout > 32;  // MI = 2 handles 64 output channels per workgroup
+    if (d.transposed) {
+        if (d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.dilation != 1)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: transposed conv supports k3,s2,p1,op1 only");
+        if (d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win)
+            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: transposed output must be 2x the input");
+        p = wide ? plan_of<CfgDCM2>(DC_M2) : plan_of<CfgDCM1>(DC_M1);
+        p.tiles_d = ceil_div(d.Din, p.TD); p.tiles_h = ceil_div(d.Hin, p.TH); p.tiles_w = ceil_div(d.Win, 32);
+    } else {
+        if (d.pad != d.dilation * (d.ksize - 1) / 2)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: pad must equal dilation*(ksize-1)/2");
+        const int eff = d.dilation * (d.ksize - 1) + 1;
+        const int eD = (d.Din + 2 * d.pad - eff) / d.stride + 1, eH = (d.Hin + 2 * d.pad - eff) / d.stride + 1,
+                  eW = (d.Win + 2 * d.pad - eff) / d.stride + 1;
+        if (d.Dout != eD || d.Hout != eH || d.Wout != eW)
+            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: output size does not match the convolution arithmetic");
+        const int key = d.ksize * 100 + d.stride * 10 + d.dilation;
+        switch (key) {
+            case 111: p = wide ? plan_of<CfgK1M2>(K1_M2) : plan_of<CfgK1M1>(K1_M1); break;
+            case 311: p = wide ? plan_of<CfgK3M2>(K3_M2) : plan_of<CfgK3M1>(K3_M1); break;
+            case 321: p = wide ? plan_of<CfgK3S2M2>(K3S2_M2) : plan_of<CfgK3S2M1>(K3S2_M1); break;
+            case 511: p = wide ? plan_of<CfgK5M2>(K5_M2) : plan_of<CfgK5M1>(K5_M1); break;
+            case 512: p = wide ? plan_of<CfgK5D2M2>(K5D2_M2) : plan_of<CfgK5D2M1>(K5D2_M1); break;
+            case 711: p = wide ? plan_of<CfgK7M2>(K7_M2) : plan_of<CfgK7M1>(K7_M1); break;
+            default:
+                return fail(SNVC_ERR_UNSUPPORTED,
+                            "snvc_conv3d: (ksize,stride,dilation) not in {(1,1,1),(3,1,1),(3,2,1),(5,1,1),(5,1,2),(7,1,1)}");
+        }
+        p.tiles_d = ceil_div(d.Dout, p.TD); p.tiles_h = ceil_div(d.Hout, p.TH); p.tiles_w = ceil_div(d.Wout, 32);
+    }
+    p.groups = ceil_div(d.Cout, 32 * p.MI);
+    p.nchunks = ceil_div(d.Cin, p.KC);
+    if (p.groups > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: too many channel groups or samples");
+    return SNVC_OK;
+}
+
+template <class Cfg>
+void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done && Cfg::LDS_BYTES > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_mfma_kernel<Cfg>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        attr_done = true;
+    }
+    conv3d_mfma_kernel<Cfg><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+}
+
+template <class Cfg>
+void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    deconv3d_mfma_kernel<Cfg><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+}
+
+}  // namespace
+}  // namespace snvc
+
+extern "C" {
+
+int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
+    using namespace snvc;
+    Plan p;
+    if (!d || make_plan(*d, p) != SNVC_OK) return -1;
+    const int64_t taps = d->transposed ? 27 : (int64_t)d->ksize * d->ksize * d->ksize;
+    return (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
+}
+
+int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, float *packed, void *stream) {
+    using namespace snvc;
+    Plan p;
+    if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_pack_weights: null desc");
+    int rc = make_plan(*d, p);
+    if (rc) return rc;
+    if (!weight || !packed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_pack_weights: null pointer");
+    const int64_t total = snvc_conv3d_packed_weight_count(d);
+    const unsigned blocks = (unsigned)ceil_div<int64_t>(total, 256);
+    if (d->transposed)
+        pack_deconv_weights_kernel<<<blocks, 256, 0, as_stream(stream)>>>(weight, packed, d->Cout, d->Cin, p.MI, p.KC,
+                                                                           p.nchunks, total);
+    else
+        pack_conv_weights_kernel<<<blocks, 256, 0, as_stream(stream)>>>(weight, packed, d->Cout, d->Cin,
+                                                                         d->ksize * d->ksize * d->ksize, p.MI, p.KC,
+                                                                         p.nchunks, total);
+    return check_launch("snvc_conv3d_pack_weights");
+}
+
+int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *packed_weight,
+                        const float *scale, const float *bias, const float *residual, float *y,
+                        void *stream) {
+    using namespace snvc;
+    Plan p;
+    if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: null desc");
+    int rc = make_plan(*d, p);
+    if (rc) return rc;
+    if (d->N == 0) return SNVC_OK;
+    if (!x || !packed_weight || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: null pointer");
+    if ((scale == nullptr) != (bias == nullptr))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: scale and bias must both be given or both be NULL");
+    if ((d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) && !residual)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: residual flag without residual pointer");
+    if ((d->flags & SNVC_EPI_ADD_PRE) && (d->flags & SNVC_EPI_ADD_POST))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: ADD_PRE and ADD_POST are exclusive");
+    if (d->transposed && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 7))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: transposed y / residual must be 8-byte aligned");
+    const int64_t in_sz = (int64_t)d->Cin * d->Din * d->Hin * d->Win, out_sz = (int64_t)d->Cout * d->Dout * d->Hout * d->Wout;
+    if ((int64_t)d->Cin * d->Din * d->Hin * d->Win >= ((int64_t)1 << 40))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: sample too large");
+
+    ConvArgs a;
+    a.x = x; a.wp = packed_weight; a.scale = scale; a.bias = bias;
+    a.res = (d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) ? residual : nullptr;
+    a.y = y;
+    a.Cin = d->Cin; a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
+    a.Cout = d->Cout; a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;
+    a.tiles_d = p.tiles_d; a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w;
+    a.nchunks = p.nchunks; a.flags = d->flags;
+    a.x_bs = d->x_batch_stride ? d->x_batch_stride : in_sz;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
+    a.r_bs = d->res_batch_stride ? d->res_batch_stride : out_sz;
+
+    const int64_t ntiles = (int64_t)p.tiles_d * p.tiles_h * p.tiles_w;
+    const int64_t gx = d->transposed ? ntiles * 4 : ntiles;
+    if (gx >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: too many tiles");
+    dim3 grid((unsigned)gx, (unsigned)p.groups, (unsigned)d->N);
+    hipStream_t st = as_stream(stream);
+    switch (p.kind) {
+        case K1_M1: launch_conv<CfgK1M1>(a, grid, st); break;
+        case K1_M2: launch_conv<CfgK1M2>(a, grid, st); break;
+        case K3_M1: launch_conv<CfgK3M1>(a, grid, st); break;
+        case K3_M2: launch_conv<CfgK3M2>(a, grid, st); break;
+        case K3S2_M1: launch_conv<CfgK3S2M1>(a, grid, st); break;
+        case K3S2_M2: launch_conv<CfgK3S2M2>(a, grid, st); break;
+        case K5_M1: launch_conv<CfgK5M1>(a, grid, st); break;
+        case K5_M2: launch_conv<CfgK5M2>(a, grid, st); break;
+        case K5D2_M1: launch_conv<CfgK5D2M1>(a, grid, st); break;
+        case K5D2_M2: launch_conv<CfgK5D2M2>(a, grid, st); break;
+        case K7_M1: launch_conv<CfgK7M1>(a, grid, st); break;
+        case K7_M2: launch_conv<CfgK7M2>(a, grid, st); break;
+        case DC_M1: launch_deconv<CfgDCM1>(a, grid, st); break;
+        case DC_M2: launch_deconv<CfgDCM2>(a, grid, st); break;
+        default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: no kernel");
+    }
+    return check_launch("snvc_conv3d_forward");
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// Plane-sweep concat cost volume for gfx950.
+//
+// Semantics follow the reference kernels
+//   forward  snvc/extension/build_cost_volume/src/BuildCostVolume_cuda.cu:15-98
+//   backward snvc/extension/build_cost_volume/src/BuildCostVolume_cuda.cu:101-205
+// but the decomposition is new:
+//   * forward is a pure HBM-write stream: one workgroup walks whole (n, c, d) output planes
+//     (H*W contiguous floats), plane decode on the scalar unit, 16-byte stores, and the
+//     small left/right feature planes are re-read from L2;
+//   * backward is a deterministic GATHER (one thread per input pixel, d ascending) instead
+//     of the reference's float atomics with D-way contention, and writes every output
+//     element, so no zero-fill pass is needed.
+// Every product / sum is rounded on its own (fp contract off), in the order the reference
+// writes them, which makes the results bit-identical to oracle/cost_volume_ref.c.
+#include "common.hpp"
+
+namespace snvc {
+namespace {
+
+#pragma clang fp contract(off)
+
+// bilinear_interpolate (BuildCostVolume_cuda.cu:15-61) specialised to what the forward can
+// reach: y = ih integral, x gated to [0, img_w - 1].  The y_high row is still read and
+// multiplied by its zero weight, like the reference, so non-finite inputs propagate alike.
+template <typename T>
+__device__ __forceinline__ T sample_right(const T *__restrict__ plane, int img_h, int img_w,
+                                          int ih, T x) {
+    int y_lo = ih, y_hi;
+    if (y_lo >= img_h - 1) { y_hi = y_lo = img_h - 1; } else { y_hi = y_lo + 1; }
+    int x_lo = (int)x, x_hi;
+    if (x_lo >= img_w - 1) { x_hi = x_lo = img_w - 1; x = (T)x_lo; } else { x_hi = x_lo + 1; }
+    const T ly = (T)0, lx = x - (T)x_lo;
+    const T hy = (T)1 - ly, hx = (T)1 - lx;
+    const T v1 = plane[(int64_t)y_lo * img_w + x_lo], v2 = plane[(int64_t)y_lo * img_w + x_hi];
+    const T v3 = plane[(int64_t)y_hi * img_w + x_lo], v4 = plane[(int64_t)y_hi * img_w + x_hi];
+    const T w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+}
+
+template <typename T>
+__device__ __forceinline__ T right_value(const T *__restrict__ rplane, int img_h, int img_w,
+                                         int ih, int iw, T neg_shift) {
+    const T x = (T)iw + neg_shift;  // BuildCostVolume_cuda.cu:88,91
+    if (x >= (T)0 && x <= (T)(img_w - 1)) return sample_right(rplane, img_h, img_w, ih, x);
+    return (T)0;
+}
+
+// Generic forward: any dtype, any downsample.  One thread per output element of a plane.
+template <typename T>
+__global__ void __launch_bounds__(256)
+cost_volume_fwd_generic(const T *__restrict__ left, const T *__restrict__ right,
+                        const T *__restrict__ shift, T *__restrict__ out, int C, int D, int H,
+                        int W, int ds, int64_t planes) {
+    const int img_h = H * ds, img_w = W * ds;
+    const int hw = H * W;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e < hw;
+    const int h = live ? e / W : 0, w = live ? e - h * W : 0;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {  // p = (n*2C + c2)*D + d, uniform
+        const int d = (int)(p % D);
+        const int64_t nc2 = p / D;
+        const int c2 = (int)(nc2 % (2 * C));
+        const int64_t n = nc2 / (2 * C);
+        if (!live) continue;
+        T v;
+        if (c2 < C) {
+            v = left[((n * C + c2) * img_h + (int64_t)h * ds) * img_w + (int64_t)w * ds];
+        } else {
+            const T *rplane = right + (n * C + (c2 - C)) * (int64_t)img_h * img_w;
+            v = right_value(rplane, img_h, img_w, h * ds, w * ds, -shift[n * D + d]);
+        }
+        out[p * hw + e] = v;
+    }
+}
+
+// Fast forward: fp32, downsample 1, W % 4 == 0 -> one 16-byte store per lane.
+__global__ void __launch_bounds__(256)
+cost_volume_fwd_f32x4(const float *__restrict__ left, const float *__restrict__ right,
+                      const float *__restrict__ shift, float *__restrict__ out, int C, int D,
+                      int H, int W, int64_t planes) {
+    const int hw4 = (H * W) >> 2;
+    const int e4 = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e4 < hw4;
+    const int e = e4 << 2;
+    const int h = live ? e / W : 0, w = live ? e - h * W : 0;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
+        const int d = (int)(p % D);
+        const int64_t nc2 = p / D;
+        const int c2 = (int)(nc2 % (2 * C));
+        const int64_t n = nc2 / (2 * C);
+        if (!live) continue;
+        float4 v;
+        if (c2 < C) {
+            v = *reinterpret_cast<const float4 *>(left + (n * C + c2) * (int64_t)H * W + e);
+        } else {
+            const float *rplane = right + (n * C + (c2 - C)) * (int64_t)H * W;
+            const float ns = -shift[n * D + d];
+            v.x = right_value(rplane, H, W, h, w + 0, ns);
+            v.y = right_value(rplane, H, W, h, w + 1, ns);
+            v.z = right_value(rplane, H, W, h, w + 2, ns);
+            v.w = right_value(rplane, H, W, h, w + 3, ns);
+        }
+        *reinterpret_cast<float4 *>(out + p * (int64_t)H * W + e) = v;
+    }
+}
+
+// Backward gather.  One thread per element (n, c, iy, ix) of grad_left / grad_right
+// [N,C,H*ds,W*ds].  For grad_right the thread visits, for every d, the few output columns w
+// whose sample position x = w*ds - shift has x_low == ix or x_high == ix, recomputing the
+// reference's gate / clamp / weight arithmetic for each candidate (BuildCostVolume_cuda.cu:
+// 101-150,178-202), and adds g*w1 / g*w2 in (d, w, tap) order.  Taps 3,4 carry weight
+// ly*hx = 0 < 1e-10 and are never added (:199-202).
+template <typename T>
+__global__ void __launch_bounds__(256)
+cost_volume_bwd_gather(const T *__restrict__ grad, const T *__restrict__ shift,
+                       T *__restrict__ grad_left, T *__restrict__ grad_right, int C, int D, int H,
+                       int W, int ds, int64_t total) {
+    const int img_h = H * ds, img_w = W * ds;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ix = (int)(idx % img_w);
+    const int iy = (int)((idx / img_w) % img_h);
+    const int64_t nc = idx / ((int64_t)img_w * img_h);
+    const int c = (int)(nc % C);
+    const int64_t n = nc / C;
+    T acc_l = (T)0, acc_r = (T)0;
+    if (iy % ds == 0) {
+        const int h = iy / ds;
+        const int64_t hw = (int64_t)H * W;
+        const T *gl = grad + ((n * 2 * C + c) * (int64_t)D) * hw + (int64_t)h * W;
+        const T *gr = gl + (int64_t)C * D * hw;
+        const bool on_lattice = (ix % ds == 0);
+        const int wl = ix / ds;
+        for (int d = 0; d < D; ++d) {
+            const T s = shift[n * D + d];
+            const T neg_shift = -s;
+            if (on_lattice) acc_l = acc_l + gl[(int64_t)d * hw + wl];
+            // candidate columns: w*ds - s within (ix - 1, ix + 1), widened by one column
+            // on each side to absorb rounding of the float expression
+            const T centre = ((T)ix + s) / (T)ds;
+            int w0 = (int)floor((double)centre - 1.0 / ds) - 1;
+            int w1 = (int)floor((double)centre + 1.0 / ds) + 1;
+            if (w0 < 0) w0 = 0;
+            if (w1 > W - 1) w1 = W - 1;
+            for (int w = w0; w <= w1; ++w) {
+                const int iw = w * ds;
+                T x = (T)iw + neg_shift;
+                if (!(x >= (T)0 && x <= (T)(img_w - 1))) continue;
+                int x_lo = (int)x, x_hi;
+                if (x_lo >= img_w - 1) { x_hi = x_lo = img_w - 1; x = (T)x_lo; } else { x_hi = x_lo + 1; }
+                if (x_lo != ix && x_hi != ix) continue;
+                const T lx = x - (T)x_lo;
+                const T hy = (T)1, hx = (T)1 - lx;
+                const T wt1 = hy * hx, wt2 = hy * lx;
+                const T g = gr[(int64_t)d * hw + w];
+                const T g1 = g * wt1, g2 = g * wt2;
+                if (x_lo == ix && (double)wt1 >= 1e-10) acc_r = acc_r + g1;
+                if (x_hi == ix && (double)wt2 >= 1e-10) acc_r = acc_r + g2;
+            }
+        }
+    }
+    grad_left[idx] = acc_l;
+    grad_right[idx] = acc_r;
+}
+
+template <typename T>
+int launch_forward(const void *left, const void *right, const void *shift, void *out, int64_t N,
+                   int64_t C, int64_t Hi, int64_t Wi, int64_t D, int64_t ds, hipStream_t st) {
+    const int64_t H = Hi / ds, W = Wi / ds;
+    const int64_t planes = N * 2 * C * D;
+    if (planes == 0 || H * W == 0) return SNVC_OK;  // BuildCostVolume_cuda.cu:235-238
+    const unsigned gy = (unsigned)(planes < 65535 ? planes : 65535);
+    if (sizeof(T) == 4 && ds == 1 && (W % 4) == 0 &&
+        ((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        dim3 grid((unsigned)ceil_div<int64_t>(H * W / 4, 256), gy);
+        cost_volume_fwd_f32x4<<<grid, 256, 0, st>>>((const float *)left, (const float *)right,
+                                                    (const float *)shift, (float *)out, (int)C,
+                                                    (int)D, (int)H, (int)W, planes);
+    } else {
+        dim3 grid((unsigned)ceil_div<int64_t>(H * W, 256), gy);
+        cost_volume_fwd_generic<T><<<grid, 256, 0, st>>>((const T *)left, (const T *)right,
+                                                         (const T *)shift, (T *)out, (int)C, (int)D,
+                                                         (int)H, (int)W, (int)ds, planes);
+    }
+    return check_launch("snvc_cost_volume_forward");
+}
+
+template <typename T>
+int launch_backward(const void *grad, const void *shift, void *gl, void *gr, int64_t N, int64_t C,
+                    int64_t H, int64_t W, int64_t D, int64_t ds, hipStream_t st) {
+    const int64_t total = N * C * H * ds * W * ds;
+    if (total == 0) return SNVC_OK;
+    const int64_t blocks = ceil_div<int64_t>(total, 256);
+    cost_volume_bwd_gather<T><<<dim3((unsigned)blocks), 256, 0, st>>>(
+        (const T *)grad, (const T *)shift, (T *)gl, (T *)gr, (int)C, (int)D, (int)H, (int)W, (int)ds,
+        total);
+    return check_launch("snvc_cost_volume_backward");
+}
+
+}  // namespace
+}  // namespace snvc
+
+extern "C" {
+
+int snvc_cost_volume_forward(const void *left, const void *right, const void *shift, void *out,
+                             int64_t N, int64_t C, int64_t Hi, int64_t Wi, int64_t D,
+                             int64_t downsample, int dtype, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || Hi < 0 || Wi < 0 || D < 0 || downsample < 1)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_cost_volume_forward: negative size or downsample < 1");
+    if (Hi % downsample || Wi % downsample)
+        return fail(SNVC_ERR_INVALID_ARGUMENT,
+                    "snvc_cost_volume_forward: H and W must be multiples of downsample");
+    if (Hi * Wi >= (int64_t)1 << 31)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_cost_volume_forward: feature plane exceeds 2^31 elements");
+    if (N * 2 * C * D * (Hi / downsample) * (Wi / downsample) > 0 && (!left || !right || !shift || !out))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_cost_volume_forward: null pointer");
+    if (dtype == SNVC_F32)
+        return launch_forward<float>(left, right, shift, out, N, C, Hi, Wi, D, downsample, as_stream(stream));
+    if (dtype == SNVC_F64)
+        return launch_forward<double>(left, right, shift, out, N, C, Hi, Wi, D, downsample, as_stream(stream));
+    return fail(SNVC_ERR_UNSUPPORTED, "snvc_cost_volume_forward: dtype must be f32 or f64 (AT_DISPATCH_FLOATING_TYPES)");
+}
+
+int snvc_cost_volume_backward(const void *grad, const void *shift, void *grad_left, void *grad_right,
+                              int64_t N, int64_t C, int64_t H, int64_t W, int64_t D,
+                              int64_t downsample, int dtype, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || H < 0 || W < 0 || D < 0 || downsample < 1)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_cost_volume_backward: negative size or downsample < 1");
+    if (H * downsample * W * downsample >= (int64_t)1 << 31)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_cost_volume_backward: feature plane exceeds 2^31 elements");
+    if (N * C * H * W > 0 && (!grad_left || !grad_right || (D > 0 && (!grad || !shift))))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_cost_volume_backward: null pointer");
+    if (dtype == SNVC_F32)
+        return launch_backward<float>(grad, shift, grad_left, grad_right, N, C, H, W, D, downsample, as_stream(stream));
+    if (dtype == SNVC_F64)
+        return launch_backward<double>(grad, shift, grad_left, grad_right, N, C, H, W, D, downsample, as_stream(stream));
+    return fail(SNVC_ERR_UNSUPPORTED, "snvc_cost_volume_backward: dtype must be f32 or f64");
+}
+
+}  // extern "C"

@@ -1,0 +1,344 @@
+// HBM-bound glue steps of the 3D trunk and the
+// normalisation statistics for GroupNorm / train-mode BatchNorm (row a4).
+// All kernels stream with 16-byte accesses when the row length allows it and fall back to
+// scalar lanes otherwise; none of them re-reads its input.
+#include "common.hpp"
+
+#include <cfloat>
+
+namespace snvc {
+namespace {
+
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ float epilogue(float v, float res, int flags) {
+    if (flags & SNVC_EPI_ADD_PRE) v = v + res;
+    if (flags & SNVC_EPI_RELU) v = v > 0.0f ? v : 0.0f;  // NaN -> 0 differs from torch only for NaN inputs
+    if (flags & SNVC_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+    if (flags & SNVC_EPI_ADD_POST) v = v + res;
+    return v;
+}
+
+// out[n,c,s] = feat[n,c,s] * occ[n,s]
+__global__ void __launch_bounds__(256)
+mul_broadcast_kernel(const float *__restrict__ feat, const float *__restrict__ occ,
+                     float *__restrict__ out, int64_t C, int64_t S, int64_t out_bs) {
+    const int64_t n = blockIdx.z, c = blockIdx.y;
+    const float *f = feat + (n * C + c) * S;
+    const float *o = occ + n * S;
+    float *y = out + n * out_bs + c * S;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool vec = ((S & 3) == 0) && ((((uintptr_t)f | (uintptr_t)o | (uintptr_t)y) & 15) == 0);
+    if (vec) {
+        const int64_t S4 = S >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S4; i += stride) {
+            const float4 a = reinterpret_cast<const float4 *>(f)[i];
+            const float4 b = reinterpret_cast<const float4 *>(o)[i];
+            reinterpret_cast<float4 *>(y)[i] = make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += stride) y[i] = f[i] * o[i];
+    }
+}
+
+// AvgPool3d((4,1,1)): y[p, dq, i] = ((x[4dq]+x[4dq+1])+x[4dq+2])+x[4dq+3]) / 4, p = n*C + c
+__global__ void __launch_bounds__(256)
+avgpool_depth4_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t D, int64_t HW) {
+    const int64_t p = blockIdx.z, dq = blockIdx.y, Dq = D / 4;
+    const float *a = x + (p * D + dq * 4) * HW;
+    float *o = y + (p * Dq + dq) * HW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool vec = ((HW & 3) == 0) && ((((uintptr_t)a | (uintptr_t)o) & 15) == 0);
+    if (vec) {
+        const int64_t n4 = HW >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const float4 v0 = reinterpret_cast<const float4 *>(a)[i];
+            const float4 v1 = reinterpret_cast<const float4 *>(a + HW)[i];
+            const float4 v2 = reinterpret_cast<const float4 *>(a + 2 * HW)[i];
+            const float4 v3 = reinterpret_cast<const float4 *>(a + 3 * HW)[i];
+            float4 r;
+            r.x = (((v0.x + v1.x) + v2.x) + v3.x) / 4.0f;
+            r.y = (((v0.y + v1.y) + v2.y) + v3.y) / 4.0f;
+            r.z = (((v0.z + v1.z) + v2.z) + v3.z) / 4.0f;
+            r.w = (((v0.w + v1.w) + v2.w) + v3.w) / 4.0f;
+            reinterpret_cast<float4 *>(o)[i] = r;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride)
+            o[i] = (((a[i] + a[HW + i]) + a[2 * HW + i]) + a[3 * HW + i]) / 4.0f;
+    }
+}
+
+// out[n,i] = sum_d x[n,d,i] * depth[d], d ascending (torch.sum over dim 1 of a product)
+__global__ void __launch_bounds__(256)
+disparity_regression_kernel(const float *__restrict__ x, const float *__restrict__ depth,
+                            float *__restrict__ out, int64_t D, int64_t HW) {
+    const int64_t n = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    const float *p = x + n * D * HW + i;
+    float acc = 0.0f;
+    for (int64_t d = 0; d < D; ++d) acc = acc + p[d * HW] * depth[d];
+    out[n * HW + i] = acc;
+}
+
+// Row-wise first-maximum argmax, numpy semantics (a NaN is treated as the maximum and the
+// first NaN wins).  One 256-thread workgroup per row: strided scan, wave shuffle reduction,
+// then a 4-entry LDS combine.
+__device__ __forceinline__ bool better(float va, int64_t ia, float vb, int64_t ib) {
+    // true if (va, ia) should replace (vb, ib)
+    const bool a_nan = va != va, b_nan = vb != vb;
+    if (a_nan || b_nan) {
+        if (a_nan && b_nan) return ia < ib;
+        return a_nan;
+    }
+    if (va > vb) return true;
+    if (va < vb) return false;
+    return ia < ib;
+}
+
+__global__ void __launch_bounds__(256)
+argmax_rows_kernel(const float *__restrict__ x, int64_t *__restrict__ idx, float *__restrict__ val,
+                   int64_t L) {
+    const int64_t r = blockIdx.x;
+    const float *row = x + r * L;
+    float bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int64_t i = threadIdx.x; i < L; i += blockDim.x) {
+        const float v = row[i];
+        if (bi == INT64_MAX || better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(bv, off, 64);
+        const int64_t oi = __shfl_down(bi, off, 64);
+        if (oi != INT64_MAX && (bi == INT64_MAX || better(ov, oi, bv, bi))) { bv = ov; bi = oi; }
+    }
+    __shared__ float sv[4];
+    __shared__ int64_t si[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (si[k] != INT64_MAX && (bi == INT64_MAX || better(sv[k], si[k], bv, bi))) { bv = sv[k]; bi = si[k]; }
+        idx[r] = bi;
+        if (val) val[r] = bv;
+    }
+}
+
+// ---------------------------------------------------------------------------- norm statistics
+// Pass 1: partial (sum, sum of squares) in fp64 per (row, split); a "row" is one contiguous
+// run of `len` floats: (n, group) for GroupNorm; (n, c) for BatchNorm (combined over n later).
+__global__ void __launch_bounds__(256)
+norm_partial_kernel(const float *__restrict__ x, double *__restrict__ partial, int64_t rows_per_n,
+                    int64_t len, int64_t x_bs, int splits) {
+    const int64_t row = blockIdx.y;
+    const int split = blockIdx.x;
+    const int64_t n = row / rows_per_n, g = row % rows_per_n;
+    const float *p = x + n * x_bs + g * len;
+    const int64_t chunk = ceil_div<int64_t>(len, splits);
+    const int64_t lo = split * chunk, hi = (lo + chunk < len) ? lo + chunk : len;
+    double s = 0.0, ss = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const double v = (double)p[i];
+        s += v;
+        ss += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        ss += __shfl_down(ss, off, 64);
+    }
+    __shared__ double sh[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh[2 * wave] = s; sh[2 * wave + 1] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { s += sh[2 * k]; ss += sh[2 * k + 1]; }
+        partial[(row * splits + split) * 2 + 0] = s;
+        partial[(row * splits + split) * 2 + 1] = ss;
+    }
+}
+
+// Pass 2: one thread per (n or 0, channel): fold partials -> mean/var of its group -> scale/shift.
+__global__ void norm_finalize_kernel(const double *__restrict__ partial, const float *__restrict__ gamma,
+                                     const float *__restrict__ beta, float *__restrict__ scale,
+                                     float *__restrict__ shift, float *__restrict__ mean_out,
+                                     float *__restrict__ var_out, int64_t N, int64_t C, int64_t S,
+                                     int64_t groups, int per_sample, int splits, float eps) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t outer = per_sample ? N : 1;
+    if (t >= outer * C) return;
+    const int64_t n = t / C, c = t % C;
+    const int64_t cpg = C / groups, g = c / cpg;
+    double s = 0.0, ss = 0.0, count;
+    if (per_sample) {
+        const int64_t row = n * groups + g;
+        for (int k = 0; k < splits; ++k) { s += partial[(row * splits + k) * 2]; ss += partial[(row * splits + k) * 2 + 1]; }
+        count = (double)cpg * (double)S;
+    } else {  // batch statistics: groups == C, fold over the batch
+        for (int64_t b = 0; b < N; ++b) {
+            const int64_t row = b * C + c;
+            for (int k = 0; k < splits; ++k) { s += partial[(row * splits + k) * 2]; ss += partial[(row * splits + k) * 2 + 1]; }
+        }
+        count = (double)N * (double)S;
+    }
+    const double mean = s / count;
+    double var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+    scale[t] = (float)(rstd * ga);
+    shift[t] = (float)(be - mean * rstd * ga);
+    if (c % cpg == 0) {
+        if (mean_out) mean_out[n * groups + g] = (float)mean;
+        if (var_out) var_out[n * groups + g] = (float)var;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+affine_act_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                  const float *__restrict__ shift, const float *__restrict__ res,
+                  float *__restrict__ y, int64_t C, int64_t S, int64_t x_bs, int64_t y_bs,
+                  int64_t r_bs, int per_sample, int flags) {
+    const int64_t n = blockIdx.z, c = blockIdx.y;
+    const float sc = scale ? scale[(per_sample ? n * C : 0) + c] : 1.0f;
+    const float sh = shift ? shift[(per_sample ? n * C : 0) + c] : 0.0f;
+    const float *a = x + n * x_bs + c * S;
+    const float *r = res ? res + n * r_bs + c * S : nullptr;
+    float *o = y + n * y_bs + c * S;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const bool vec = ((S & 3) == 0) && ((((uintptr_t)a | (uintptr_t)o | (uintptr_t)r) & 15) == 0);
+    if (vec) {
+        const int64_t S4 = S >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S4; i += stride) {
+            const float4 v = reinterpret_cast<const float4 *>(a)[i];
+            float4 q = make_float4(0, 0, 0, 0);
+            if (r) q = reinterpret_cast<const float4 *>(r)[i];
+            float4 w;
+            w.x = epilogue(v.x * sc + sh, q.x, flags);
+            w.y = epilogue(v.y * sc + sh, q.y, flags);
+            w.z = epilogue(v.z * sc + sh, q.z, flags);
+            w.w = epilogue(v.w * sc + sh, q.w, flags);
+            reinterpret_cast<float4 *>(o)[i] = w;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += stride)
+            o[i] = epilogue(a[i] * sc + sh, r ? r[i] : 0.0f, flags);
+    }
+}
+
+constexpr int kNormSplits = 32;
+
+inline unsigned stream_blocks(int64_t items, int64_t outer) {
+    // enough workgroups to fill 256 CUs x 8 without over-subscribing tiny rows
+    int64_t b = ceil_div<int64_t>(items, 256 * 4);
+    const int64_t cap = ceil_div<int64_t>(2048, outer > 0 ? outer : 1);
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+}  // namespace snvc
+
+extern "C" {
+
+int snvc_mul_broadcast(const float *feat, const float *occ, float *out, int64_t N, int64_t C,
+                       int64_t S, int64_t out_batch_stride, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_mul_broadcast: negative size");
+    if (N == 0 || C == 0 || S == 0) return SNVC_OK;
+    if (!feat || !occ || !out) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_mul_broadcast: null pointer");
+    if (C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_mul_broadcast: C or N > 65535");
+    if (out_batch_stride == 0) out_batch_stride = C * S;
+    dim3 grid(stream_blocks(S / 4 + 1, N * C), (unsigned)C, (unsigned)N);
+    mul_broadcast_kernel<<<grid, 256, 0, as_stream(stream)>>>(feat, occ, out, C, S, out_batch_stride);
+    return check_launch("snvc_mul_broadcast");
+}
+
+int snvc_avgpool_depth4(const float *x, float *y, int64_t N, int64_t C, int64_t D, int64_t HW,
+                        void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || D < 0 || HW < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_avgpool_depth4: negative size");
+    const int64_t Dq = D / 4;  // floor, like AvgPool3d without ceil_mode
+    if (N * C == 0 || Dq == 0 || HW == 0) return SNVC_OK;
+    if (!x || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_avgpool_depth4: null pointer");
+    if (Dq > 65535 || N * C > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_avgpool_depth4: grid too large");
+    dim3 grid(stream_blocks(HW / 4 + 1, N * C * Dq), (unsigned)Dq, (unsigned)(N * C));
+    avgpool_depth4_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, y, D, HW);
+    return check_launch("snvc_avgpool_depth4");
+}
+
+int snvc_disparity_regression(const float *x, const float *depth, float *out, int64_t N, int64_t D,
+                              int64_t HW, void *stream) {
+    using namespace snvc;
+    if (N < 0 || D < 0 || HW < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_disparity_regression: negative size");
+    if (N == 0 || HW == 0) return SNVC_OK;
+    if (!out || (D > 0 && (!x || !depth))) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_disparity_regression: null pointer");
+    if (N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_disparity_regression: N > 65535");
+    dim3 grid((unsigned)ceil_div<int64_t>(HW, 256), (unsigned)N);
+    disparity_regression_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, depth, out, D, HW);
+    return check_launch("snvc_disparity_regression");
+}
+
+int snvc_argmax_rows(const float *x, int64_t *idx, float *val, int64_t R, int64_t L, void *stream) {
+    using namespace snvc;
+    if (R < 0 || L < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_argmax_rows: negative size");
+    if (R == 0) return SNVC_OK;
+    if (L == 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_argmax_rows: attempt to get argmax of an empty sequence");
+    if (!x || !idx) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_argmax_rows: null pointer");
+    argmax_rows_kernel<<<dim3((unsigned)R), 256, 0, as_stream(stream)>>>(x, idx, val, L);
+    return check_launch("snvc_argmax_rows");
+}
+
+int64_t snvc_norm_workspace_bytes(int64_t N, int64_t C, int64_t groups) {
+    const int64_t rows = N * (groups > C ? groups : C);
+    return rows * snvc::kNormSplits * 2 * (int64_t)sizeof(double);
+}
+
+int snvc_norm_stats(const float *x, const float *gamma, const float *beta, float *scale, float *shift,
+                    float *mean_out, float *var_out, void *workspace, int64_t N, int64_t C, int64_t S,
+                    int64_t x_batch_stride, int64_t groups, int per_sample, float eps, void *stream) {
+    using namespace snvc;
+    if (N <= 0 || C <= 0 || S <= 0 || groups <= 0 || C % groups)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_norm_stats: sizes must be positive and C divisible by groups");
+    if (!per_sample && groups != C)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_norm_stats: batch statistics need groups == C");
+    if (!x || !scale || !shift || !workspace) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_norm_stats: null pointer");
+    if (x_batch_stride == 0) x_batch_stride = C * S;
+    const int64_t rows_per_n = groups, len = (C / groups) * S, rows = N * rows_per_n;
+    if (rows > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_norm_stats: N*groups > 65535");
+    dim3 grid(kNormSplits, (unsigned)rows);
+    norm_partial_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, (double *)workspace, rows_per_n, len,
+                                                             x_batch_stride, kNormSplits);
+    int rc = check_launch("snvc_norm_stats(partial)");
+    if (rc) return rc;
+    const int64_t t = (per_sample ? N : 1) * C;
+    norm_finalize_kernel<<<dim3((unsigned)ceil_div<int64_t>(t, 128)), 128, 0, as_stream(stream)>>>(
+        (const double *)workspace, gamma, beta, scale, shift, mean_out, var_out, N, C, S, groups, per_sample,
+        kNormSplits, eps);
+    return check_launch("snvc_norm_stats(finalize)");
+}
+
+int snvc_affine_act(const float *x, const float *scale, const float *shift, const float *residual,
+                    float *y, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                    int64_t y_batch_stride, int64_t res_batch_stride, int per_sample, int flags,
+                    void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_affine_act: negative size");
+    if (N == 0 || C == 0 || S == 0) return SNVC_OK;
+    if (!x || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_affine_act: null pointer");
+    if ((flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) && !residual)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_affine_act: residual flag without residual pointer");
+    if (C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_affine_act: C or N > 65535");
+    if (!(flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))) residual = nullptr;
+    if (x_batch_stride == 0) x_batch_stride = C * S;
+    if (y_batch_stride == 0) y_batch_stride = C * S;
+    if (res_batch_stride == 0) res_batch_stride = C * S;
+    dim3 grid(stream_blocks(S / 4 + 1, N * C), (unsigned)C, (unsigned)N);
+    affine_act_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, scale, shift, residual, y, C, S, x_batch_stride,
+                                                           y_batch_stride, res_batch_stride, per_sample, flags);
+    return check_launch("snvc_affine_act");
+}
+
+}  // extern "C"

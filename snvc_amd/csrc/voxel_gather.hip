@@ -1,0 +1,155 @@
+// Feature -> voxel resampling for gfx950.
+//
+// Replaces VernierScale._sample_2d_feat (snvc/models/vernier.py:323-349): the reference
+// normalises the projected coordinates (two element-wise passes per side, :335-338), runs
+// F.grid_sample twice (:339-340) and then copies both results again for torch.cat (:346).
+// Here one kernel does all of it: each thread owns one voxel, derives the 4 bilinear taps
+// and weights of both cameras once, then walks the 2F channels writing coalesced rows of
+// the concatenated [N,2F,V] output.  The feature maps (<= 1 MB per side) stay in L2; the
+// kernel is bound by the output write.
+//
+// Arithmetic mirrors ATen's CPU grid_sampler_2d for (bilinear, zeros, align_corners=False)
+// -- aten/src/ATen/native/cpu/GridSamplerKernel.cpp: unnormalise = (g + 1) * (size / 2) - 0.5,
+// w = x - floor(x), e = 1 - w, n = y - floor(y), s = 1 - n, weights nw = s*e, ne = s*w,
+// sw = n*e, se = n*w, out-of-range taps contribute 0 -- with every operation rounded on its
+// own (fp contract off), so it is bit-identical to oracle/numpy_ref.py:sample_2d_feat.
+#include "common.hpp"
+
+namespace snvc {
+namespace {
+
+#pragma clang fp contract(off)
+
+struct Taps {
+    int off[4];    // element offsets inside one feature plane, -1 = out of range
+    float wt[4];   // nw, ne, sw, se
+};
+
+__device__ __forceinline__ Taps make_taps(float px, float py, float res_x, float res_y, int Hf,
+                                          int Wf) {
+    // vernier.py:335-338: p / res * 2 - 1 (three separately rounded fp32 ops)
+    const float gx = px / res_x * 2.0f - 1.0f;
+    const float gy = py / res_y * 2.0f - 1.0f;
+    const float x = (gx + 1.0f) * ((float)Wf / 2.0f) - 0.5f;
+    const float y = (gy + 1.0f) * ((float)Hf / 2.0f) - 0.5f;
+    const float xf = floorf(x), yf = floorf(y);
+    const float w = x - xf, e = 1.0f - w, n = y - yf, s = 1.0f - n;
+    Taps t;
+    t.wt[0] = s * e; t.wt[1] = s * w; t.wt[2] = n * e; t.wt[3] = n * w;
+    // float -> int conversion only after a range test (NaN / huge coordinates give no taps)
+    const bool finite_range = (xf >= -2.0f && xf <= (float)Wf + 1.0f && yf >= -2.0f && yf <= (float)Hf + 1.0f);
+    const int x0 = finite_range ? (int)xf : -2, y0 = finite_range ? (int)yf : -2;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < Wf, vx1 = x1 >= 0 && x1 < Wf;
+    const bool vy0 = y0 >= 0 && y0 < Hf, vy1 = y1 >= 0 && y1 < Hf;
+    t.off[0] = (vx0 && vy0) ? y0 * Wf + x0 : -1;
+    t.off[1] = (vx1 && vy0) ? y0 * Wf + x1 : -1;
+    t.off[2] = (vx0 && vy1) ? y1 * Wf + x0 : -1;
+    t.off[3] = (vx1 && vy1) ? y1 * Wf + x1 : -1;
+    return t;
+}
+
+__device__ __forceinline__ float apply_taps(const float *__restrict__ plane, const Taps &t) {
+    const float a = t.off[0] >= 0 ? plane[t.off[0]] : 0.0f;
+    const float b = t.off[1] >= 0 ? plane[t.off[1]] : 0.0f;
+    const float c = t.off[2] >= 0 ? plane[t.off[2]] : 0.0f;
+    const float d = t.off[3] >= 0 ? plane[t.off[3]] : 0.0f;
+    return a * t.wt[0] + b * t.wt[1] + c * t.wt[2] + d * t.wt[3];
+}
+
+__global__ void __launch_bounds__(256)
+voxel_gather_fwd(const float *__restrict__ left, const float *__restrict__ right,
+                 const float *__restrict__ l_pts, const float *__restrict__ r_pts,
+                 float *__restrict__ out, int F, int Hf, int Wf, int64_t V, float res_x,
+                 float res_y) {
+    const int64_t n = blockIdx.y;
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float *lp = l_pts + n * 2 * V, *rp = r_pts + n * 2 * V;
+    const Taps tl = make_taps(lp[v], lp[V + v], res_x, res_y, Hf, Wf);
+    const Taps tr = make_taps(rp[v], rp[V + v], res_x, res_y, Hf, Wf);
+    const int plane = Hf * Wf;
+    const float *lf = left + n * F * plane, *rf = right + n * F * plane;
+    float *o = out + n * 2 * F * V + v;
+#pragma unroll 4
+    for (int c = 0; c < F; ++c) o[(int64_t)c * V] = apply_taps(lf + (int64_t)c * plane, tl);
+    o += (int64_t)F * V;
+#pragma unroll 4
+    for (int c = 0; c < F; ++c) o[(int64_t)c * V] = apply_taps(rf + (int64_t)c * plane, tr);
+}
+
+__global__ void __launch_bounds__(256)
+voxel_gather_bwd(const float *__restrict__ grad_out, const float *__restrict__ l_pts,
+                 const float *__restrict__ r_pts, float *__restrict__ grad_left,
+                 float *__restrict__ grad_right, int F, int Hf, int Wf, int64_t V, float res_x,
+                 float res_y) {
+    const int64_t n = blockIdx.y;
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float *lp = l_pts + n * 2 * V, *rp = r_pts + n * 2 * V;
+    const Taps tl = make_taps(lp[v], lp[V + v], res_x, res_y, Hf, Wf);
+    const Taps tr = make_taps(rp[v], rp[V + v], res_x, res_y, Hf, Wf);
+    const int plane = Hf * Wf;
+    const float *g = grad_out + n * 2 * F * V + v;
+    float *gl = grad_left + n * F * plane, *gr = grad_right + n * F * plane;
+    for (int c = 0; c < F; ++c) {
+        const float gv = g[(int64_t)c * V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tl.off[k] >= 0) atomicAdd(gl + (int64_t)c * plane + tl.off[k], gv * tl.wt[k]);
+    }
+    g += (int64_t)F * V;
+    for (int c = 0; c < F; ++c) {
+        const float gv = g[(int64_t)c * V];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tr.off[k] >= 0) atomicAdd(gr + (int64_t)c * plane + tr.off[k], gv * tr.wt[k]);
+    }
+}
+
+}  // namespace
+}  // namespace snvc
+
+extern "C" {
+
+int snvc_voxel_gather_forward(const float *left, const float *right, const float *l_pts,
+                              const float *r_pts, float *out, int64_t N, int64_t F, int64_t Hf,
+                              int64_t Wf, int64_t V, float res_x, float res_y, void *stream) {
+    using namespace snvc;
+    if (N < 0 || F < 0 || Hf < 0 || Wf < 0 || V < 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward: negative size");
+    if (N == 0 || F == 0 || V == 0) return SNVC_OK;
+    if (Hf * Wf >= (int64_t)1 << 30 || N > 65535)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_voxel_gather_forward: feature plane or batch too large");
+    if (!left || !right || !l_pts || !r_pts || !out)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward: null pointer");
+    dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
+    voxel_gather_fwd<<<grid, 256, 0, as_stream(stream)>>>(left, right, l_pts, r_pts, out, (int)F,
+                                                          (int)Hf, (int)Wf, V, res_x, res_y);
+    return check_launch("snvc_voxel_gather_forward");
+}
+
+int snvc_voxel_gather_backward(const float *grad_out, const float *l_pts, const float *r_pts,
+                               float *grad_left, float *grad_right, int64_t N, int64_t F, int64_t Hf,
+                               int64_t Wf, int64_t V, float res_x, float res_y, void *stream) {
+    using namespace snvc;
+    if (N < 0 || F < 0 || Hf < 0 || Wf < 0 || V < 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_backward: negative size");
+    if (Hf * Wf >= (int64_t)1 << 30 || N > 65535)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_voxel_gather_backward: feature plane or batch too large");
+    const size_t bytes = sizeof(float) * (size_t)(N * F * Hf * Wf);
+    if (bytes) {
+        if (!grad_left || !grad_right)
+            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_backward: null pointer");
+        if (hipMemsetAsync(grad_left, 0, bytes, as_stream(stream)) != hipSuccess ||
+            hipMemsetAsync(grad_right, 0, bytes, as_stream(stream)) != hipSuccess)
+            return fail(SNVC_ERR_HIP, "snvc_voxel_gather_backward: hipMemsetAsync failed");
+    }
+    if (N == 0 || F == 0 || V == 0) return SNVC_OK;
+    dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
+    voxel_gather_bwd<<<grid, 256, 0, as_stream(stream)>>>(grad_out, l_pts, r_pts, grad_left, grad_right,
+                                                          (int)F, (int)Hf, (int)Wf, V, res_x, res_y);
+    return check_launch("snvc_voxel_gather_backward");
+}
+
+}  // extern "C"

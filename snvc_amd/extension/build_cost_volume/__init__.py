@@ -1,0 +1,41 @@
+"""Drop-in for ``snvc.extension.build_cost_volume`` (reference __init__.py:1-26).
+
+``build_cost_volume(left, right, shift, downsample)`` -> ``[N, 2C, D, H/ds, W/ds]``; the left
+half of the channel axis repeats the left feature for every plane, the right half holds the
+right feature shifted by ``shift[n, d]`` pixels with linear interpolation (a CONCAT volume, no
+correlation: BuildCostVolume_cuda.cu:81-96).  Backward returns ``(gL, gR, None, None)``.
+"""
+import types
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ... import ops
+
+# Stands where the reference's pybind module sits (BuildCostVolume.cpp:44-48): same two names.
+build_cost_volume_cuda = types.SimpleNamespace(
+    build_cost_volume_forward=ops.cost_volume_forward,
+    build_cost_volume_backward=ops.cost_volume_backward,
+)
+
+
+class _BuildCostVolume(Function):
+    @staticmethod
+    def forward(ctx, left, right, shift, downsample):
+        ctx.save_for_backward(shift)
+        ctx.downsample = downsample
+        # reference __init__.py:12 (forces a device->host sync there too)
+        assert torch.all(shift >= 0.)
+        return build_cost_volume_cuda.build_cost_volume_forward(left, right, shift, downsample)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        shift, = ctx.saved_tensors
+        grad_left, grad_right = build_cost_volume_cuda.build_cost_volume_backward(
+            grad_output, shift, ctx.downsample)
+        return grad_left, grad_right, None, None
+
+
+build_cost_volume = _BuildCostVolume.apply

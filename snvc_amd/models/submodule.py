@@ -1,0 +1,367 @@
+"""Drop-in for the 3D building blocks of ``snvc.models.submodule``.
+
+Same constructors, same module tree and therefore the same ``state_dict`` keys as the
+reference (``load_state_dict(strict=True)`` of a reference checkpoint works,
+tools/inference_agnostic.py:452), but ``forward`` runs hand-written HIP kernels:
+
+  reference (submodule.py)                         here
+  ------------------------------------------------ ------------------------------------------
+  convbn_3d                     :32-50             ConvBN3d(nn.Sequential): ONE fused launch
+                                                   conv + folded BatchNorm (+ReLU/+residual)
+  hourglass                     :85-168            6 fused launches (4 conv, 2 deconv)
+  get_hg_down_sample            :170-181           Sequential(ConvBN3d, ReLU) -> 1 launch
+  get_hg_up_sample              :197-208           ConvBN3d over ConvTranspose3d -> 1 launch
+  hourglass_downsample_16       :223-268           12 fused launches, skips added in the epilogue
+  disparityregression           :76-83             1 reduction kernel
+
+The nn.Conv3d / nn.BatchNorm3d / nn.GroupNorm children only HOLD parameters; their own
+``forward`` is never called.  GroupNorm and train-mode BatchNorm need statistics of the conv
+output, so they take three launches (conv, statistics, normalise+activation).
+
+The 2D helpers at the bottom (convbn, hourglass2d, ...) are stock torch.nn compositions: the
+BEV neck that follows the path is out of scope for hand-written kernels (SURVEY.md section 8f,
+row N1) and runs on PyTorch-ROCm's own kernels.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..ops import EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID
+
+
+def _no_autograd(x: torch.Tensor, mod: nn.Module):
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
+        raise NotImplementedError(
+            "snvc_amd 3D convolutions are forward-only in this release: call under torch.no_grad() "
+            "(the reference's inference loop does, tools/inference_agnostic.py:366). "
+            "Training backward (dgrad/wgrad kernels) is the next row of the build plan.")
+
+
+def _first_arg(k):
+    return k[0] if isinstance(k, (tuple, list)) else k
+
+
+def _cubic(v, what):
+    if isinstance(v, (tuple, list)):
+        if len(set(v)) != 1:
+            raise NotImplementedError(f"non-cubic {what} {tuple(v)} is not on the hot path")
+        return int(v[0])
+    return int(v)
+
+
+class _Plan:
+    """Packed weights + folded affine for one conv(+norm) pair, rebuilt when parameters change."""
+
+    def __init__(self):
+        self.key = None
+        self.layer: Optional[ops.Conv3dLayer] = None
+        self.scale = None
+        self.bias = None
+
+
+def _conv_geometry(conv: nn.Module):
+    transposed = isinstance(conv, nn.ConvTranspose3d)
+    k = _cubic(conv.kernel_size, "kernel")
+    s = _cubic(conv.stride, "stride")
+    p = _cubic(conv.padding, "padding")
+    d = _cubic(conv.dilation, "dilation")
+    if conv.bias is not None:
+        raise NotImplementedError("conv bias is not on the path (all 3D convs use bias=False)")
+    if conv.groups != 1:
+        raise NotImplementedError("grouped 3D convolutions are not on the path")
+    if transposed and _cubic(conv.output_padding, "output_padding") != 1:
+        raise NotImplementedError("ConvTranspose3d on the path always has output_padding=1")
+    return k, s, p, d, transposed
+
+
+def _get_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device)
+    if plan.layer is None or plan.key != key:
+        k, s, p, d, transposed = _conv_geometry(conv)
+        plan.layer = ops.Conv3dLayer(w.detach(), k, s, p, d, transposed)
+        plan.key = key
+    return plan.layer
+
+
+def _folded_bn(bn: nn.BatchNorm3d, plan: _Plan):
+    """Eval-mode BatchNorm3d as y = x*scale + bias (fp64 fold, cast once)."""
+    key = (bn.weight._version if bn.weight is not None else -1, bn.bias._version if bn.bias is not None else -1,
+           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_mean.device)
+    if plan.scale is None or getattr(plan, "bn_key", None) != key:
+        var = bn.running_var.detach().double()
+        mean = bn.running_mean.detach().double()
+        g = bn.weight.detach().double() if bn.weight is not None else torch.ones_like(var)
+        b = bn.bias.detach().double() if bn.bias is not None else torch.zeros_like(var)
+        sc = g / torch.sqrt(var + bn.eps)
+        plan.scale = sc.float().contiguous()
+        plan.bias = (b - mean * sc).float().contiguous()
+        plan.bn_key = key
+    return plan.scale, plan.bias
+
+
+def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,
+                 residual: Optional[torch.Tensor] = None, residual_after_act=False, out=None,
+                 plan: Optional[_Plan] = None) -> torch.Tensor:
+    """act(norm(conv(x)) [+ residual]) [+ residual] on the HIP kernels.
+
+    ``residual_after_act=False``: relu(norm(conv(x)) + residual)   (hourglass skips, submodule.py:154,162)
+    ``residual_after_act=True`` : relu(norm(conv(x))) + residual   (vernier.py:418-419)
+    """
+    owner = norm if norm is not None else conv
+    _no_autograd(x, conv)
+    if plan is None:  # one plan per device (replicas made by nn.DataParallel share __dict__ entries)
+        plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(x.device, _Plan())
+    if conv.weight.device != x.device:
+        raise RuntimeError(f"conv3d weight is on {conv.weight.device} but the input is on {x.device}")
+    layer = _get_layer(conv, plan)
+    flags = (EPI_RELU if relu else 0) | (EPI_SIGMOID if sigmoid else 0)
+    if residual is not None:
+        flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
+    if norm is None:
+        return layer(x, None, None, residual, flags, out)
+    if isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None):
+        scale, bias = _folded_bn(norm, plan)
+        return layer(x, scale, bias, residual, flags, out)
+    # statistics of the conv output are needed first: conv -> stats -> normalise (+res, +act)
+    raw = layer(x, None, None, None, 0, None)
+    c = raw.size(1)
+    if isinstance(norm, nn.GroupNorm):
+        scale, shift, _, _ = ops.norm_stats(raw, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
+        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=out if out is not None else raw)
+    if isinstance(norm, nn.BatchNorm3d):
+        scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, c, False, norm.eps)
+        if norm.training and norm.track_running_stats and norm.running_mean is not None:
+            with torch.no_grad():  # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
+                cnt = raw.numel() / c
+                norm.num_batches_tracked += 1
+                m = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked)
+                norm.running_mean.mul_(1 - m).add_(mean[0], alpha=m)
+                norm.running_var.mul_(1 - m).add_(var[0] * (cnt / max(cnt - 1, 1)), alpha=m)
+        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=out if out is not None else raw)
+    raise NotImplementedError(f"norm layer {type(owner).__name__} is not on the path")
+
+
+class ConvBN3d(nn.Sequential):
+    """``Sequential(Conv3d | ConvTranspose3d, BatchNorm3d | GroupNorm)`` -- the object convbn_3d
+    returns in the reference (keys ``0.weight``, ``1.weight``, ``1.bias``, ``1.running_mean``, ...)."""
+
+    def forward(self, x):
+        return self.fused(x)
+
+    def fused(self, x, **kw):
+        return fused_conv3d(self[0], self[1], x, **kw)
+
+
+class HipConv3d(nn.Conv3d):
+    """A bare nn.Conv3d(bias=False) (classifier, fg_cls_head[2], part_reg_head[2]) on the HIP kernel."""
+
+    def forward(self, x):
+        return self.fused(x)
+
+    def fused(self, x, **kw):
+        return fused_conv3d(self, None, x, **kw)
+
+
+def convbn_3d(in_planes, out_planes, kernel_size, stride, pad, dilation=1, gn=False, groups=32):
+    """reference submodule.py:32-50"""
+    return ConvBN3d(nn.Conv3d(in_planes, out_planes, kernel_size=kernel_size, padding=pad, dilation=dilation,
+                              stride=stride, bias=False),
+                    nn.BatchNorm3d(out_planes) if not gn else nn.GroupNorm(groups, out_planes))
+
+
+def _deconvbn_3d(cin, cout, gn):
+    return ConvBN3d(nn.ConvTranspose3d(cin, cout, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                    nn.BatchNorm3d(cout) if not gn else nn.GroupNorm(32, cout))
+
+
+class ConvBNReLU3d(nn.Sequential):
+    """``Sequential(convbn_3d(...), ReLU(inplace=True))``: the ReLU is folded into the conv epilogue."""
+
+    def forward(self, x):
+        return self[0].fused(x, relu=True)
+
+    def fused(self, x, **kw):
+        kw.setdefault("relu", True)
+        return self[0].fused(x, **kw)
+
+
+class disparityregression(nn.Module):
+    """reference submodule.py:76-83 (its constructor builds an unused .cuda() buffer; not kept)."""
+
+    def __init__(self, maxdisp=None, cfg=None):
+        super().__init__()
+        self.maxdisp = maxdisp
+
+    def forward(self, x, depth):
+        return ops.disparity_regression(x, depth)
+
+
+class hourglass(nn.Module):
+    """reference submodule.py:85-168"""
+
+    def __init__(self, inplanes, gn=False):
+        super().__init__()
+        c = inplanes
+        self.conv1 = ConvBNReLU3d(convbn_3d(c, c * 2, kernel_size=3, stride=2, pad=1, gn=gn), nn.ReLU(inplace=True))
+        self.conv2 = convbn_3d(c * 2, c * 2, kernel_size=3, stride=1, pad=1, gn=gn)
+        self.conv3 = ConvBNReLU3d(convbn_3d(c * 2, c * 2, kernel_size=3, stride=2, pad=1, gn=gn), nn.ReLU(inplace=True))
+        self.conv4 = ConvBNReLU3d(convbn_3d(c * 2, c * 2, kernel_size=3, stride=1, pad=1, gn=gn), nn.ReLU(inplace=True))
+        self.conv5 = _deconvbn_3d(c * 2, c * 2, gn)
+        self.conv6 = _deconvbn_3d(c * 2, c, gn)
+
+    def forward(self, x, presqu, postsqu, residual=None, out=None):
+        """Returns (out, pre, post).  ``residual``/``out`` (extension): fold the caller's
+        ``x + hourglass(x)[0]`` (vernier.py:370,421) into the last deconvolution's epilogue."""
+        o = self.conv1(x)                                                   # 1/2 res, ReLU fused
+        pre = self.conv2.fused(o, relu=True, residual=postsqu)              # relu(bn(conv) [+ postsqu]) :153-156
+        o = self.conv4(self.conv3(pre))                                     # 1/4 res
+        post = self.conv5.fused(o, relu=True, residual=presqu if presqu is not None else pre)  # :161-164
+        o = self.conv6.fused(post, residual=residual, out=out)              # :166
+        return o, pre, post
+
+
+def get_hg_down_sample(channel_in, channel_out, gn, downsample=True):
+    """reference submodule.py:170-181"""
+    return ConvBNReLU3d(convbn_3d(channel_in, channel_out, kernel_size=3, stride=2 if downsample else 1, pad=1, gn=gn),
+                        nn.ReLU(inplace=True))
+
+
+def get_hg_up_sample(channel_in, channel_out, gn):
+    """reference submodule.py:197-208"""
+    return _deconvbn_3d(channel_in, channel_out, gn)
+
+
+class hourglass_downsample_16(nn.Module):
+    """reference submodule.py:223-268"""
+
+    def __init__(self, inplanes, gn=False):
+        super().__init__()
+        c = inplanes
+        self.conv1 = get_hg_down_sample(c, c * 2, gn)
+        self.conv2 = get_hg_down_sample(c * 2, c * 2, gn, False)
+        self.conv3 = get_hg_down_sample(c * 2, c * 2, gn)
+        self.conv4 = get_hg_down_sample(c * 2, c * 2, gn, False)
+        self.conv5 = get_hg_down_sample(c * 2, c * 2, gn)
+        self.conv6 = get_hg_down_sample(c * 2, c * 2, gn, False)
+        self.conv7 = get_hg_down_sample(c * 2, c * 2, gn)
+        self.conv8 = get_hg_down_sample(c * 2, c * 2, gn, False)
+        self.conv9 = get_hg_up_sample(c * 2, c * 2, gn)
+        self.conv10 = get_hg_up_sample(c * 2, c * 2, gn)
+        self.conv11 = get_hg_up_sample(c * 2, c * 2, gn)
+        self.conv12 = get_hg_up_sample(c * 2, c, gn)
+
+    def forward(self, x, residual=None, out=None):
+        o2 = self.conv2(self.conv1(x))
+        o4 = self.conv4(self.conv3(o2))
+        o6 = self.conv6(self.conv5(o4))
+        o8 = self.conv8(self.conv7(o6))
+        i10 = self.conv9.fused(o8, residual=o6)     # out_conv9 + out_conv6   :258-259
+        i11 = self.conv10.fused(i10, residual=o4)   # out_conv10 + out_conv4  :261-262
+        i12 = self.conv11.fused(i11, residual=o2)   # out_conv11 + out_conv2  :264-266
+        return self.conv12.fused(i12, residual=residual, out=out)
+
+
+# ------------------------------------------------------------------------------------------
+# 2D BEV neck: stock PyTorch-ROCm (out of scope for hand-written kernels)
+# ------------------------------------------------------------------------------------------
+def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation, gn=False, groups=32):
+    """reference submodule.py:11-29"""
+    return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
+                                   padding=dilation if dilation > 1 else pad, dilation=dilation, bias=False),
+                         nn.BatchNorm2d(out_planes) if not gn else nn.GroupNorm(groups, out_planes))
+
+
+def _deconvbn_2d(cin, cout, gn):
+    return nn.Sequential(nn.ConvTranspose2d(cin, cout, kernel_size=3, padding=1, output_padding=1, stride=2, bias=False),
+                         nn.BatchNorm2d(cout) if not gn else nn.GroupNorm(32, cout))
+
+
+def get_hg_down_sample_2d(channel_in, channel_out, gn, downsample=True):
+    return nn.Sequential(convbn(channel_in, channel_out, kernel_size=3, stride=2 if downsample else 1, pad=1,
+                                dilation=1, gn=gn), nn.ReLU(inplace=True))
+
+
+def get_hg_up_sample_2d(channel_in, channel_out, gn):
+    return _deconvbn_2d(channel_in, channel_out, gn)
+
+
+class hourglass2d(nn.Module):
+    """reference submodule.py:317-361"""
+
+    def __init__(self, inplanes, gn=False):
+        super().__init__()
+        c = inplanes
+        self.conv1 = nn.Sequential(convbn(c, c * 2, 3, 2, 1, 1, gn=gn), nn.ReLU(inplace=True))
+        self.conv2 = convbn(c * 2, c * 2, 3, 1, 1, 1, gn=gn)
+        self.conv3 = nn.Sequential(convbn(c * 2, c * 2, 3, 2, 1, 1, gn=gn), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(convbn(c * 2, c * 2, 3, 1, 1, 1, gn=gn), nn.ReLU(inplace=True))
+        self.conv5 = _deconvbn_2d(c * 2, c * 2, gn)
+        self.conv6 = _deconvbn_2d(c * 2, c, gn)
+
+    def forward(self, x, presqu, postsqu):
+        out = self.conv1(x)
+        pre = self.conv2(out)
+        pre = F.relu(pre + postsqu, inplace=True) if postsqu is not None else F.relu(pre, inplace=True)
+        out = self.conv4(self.conv3(pre))
+        post = F.relu(self.conv5(out) + (presqu if presqu is not None else pre), inplace=True)
+        return self.conv6(post), pre, post
+
+
+class hourglass2d_downsample_16(nn.Module):
+    """reference submodule.py:270-315"""
+
+    def __init__(self, inplanes, gn=False):
+        super().__init__()
+        c = inplanes
+        self.conv1 = get_hg_down_sample_2d(c, c * 2, gn)
+        self.conv2 = get_hg_down_sample_2d(c * 2, c * 2, gn, False)
+        self.conv3 = get_hg_down_sample_2d(c * 2, c * 2, gn)
+        self.conv4 = get_hg_down_sample_2d(c * 2, c * 2, gn, False)
+        self.conv5 = get_hg_down_sample_2d(c * 2, c * 2, gn)
+        self.conv6 = get_hg_down_sample_2d(c * 2, c * 2, gn, False)
+        self.conv7 = get_hg_down_sample_2d(c * 2, c * 2, gn)
+        self.conv8 = get_hg_down_sample_2d(c * 2, c * 2, gn, False)
+        self.conv9 = get_hg_up_sample_2d(c * 2, c * 2, gn)
+        self.conv10 = get_hg_up_sample_2d(c * 2, c * 2, gn)
+        self.conv11 = get_hg_up_sample_2d(c * 2, c * 2, gn)
+        self.conv12 = get_hg_up_sample_2d(c * 2, c, gn)
+
+    def forward(self, x):
+        o2 = self.conv2(self.conv1(x))
+        o4 = self.conv4(self.conv3(o2))
+        o6 = self.conv6(self.conv5(o4))
+        o8 = self.conv8(self.conv7(o6))
+        o10 = self.conv10(self.conv9(o8) + o6)
+        o11 = self.conv11(o10 + o4)
+        return self.conv12(o11 + o2)
+
+
+class BasicBlock2d(nn.Module):
+    """snvc/models/hrnet.py:25-54 (used by the coordinate head, vernier.py:68-93)"""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes, momentum=0.1)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=1, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes, momentum=0.1)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        residual = x if self.downsample is None else self.downsample(x)
+        return self.relu(out + residual)
+
+
+def basicdownsample(in_planes, out_planes):
+    """snvc/models/hrnet.py:56-69"""
+    return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size=1, stride=2, bias=False),
+                         nn.BatchNorm2d(out_planes))

@@ -1,0 +1,195 @@
+"""Drop-in for the 3D trunk of ``snvc.models.vernier.VernierScale`` (``BEV_type3``).
+
+Module tree, attribute names and state-dict keys equal the reference's (vernier.py:249-313), so a
+reference checkpoint loads with ``strict=True``.  What changes is how ``forward`` executes:
+
+  reference (vernier.py)                              here
+  --------------------------------------------------- -----------------------------------------
+  _sample_2d_feat: 4 normalisation passes,            ONE gather kernel writing the concatenated
+    2 grid_sample, 1 torch.cat           :323-349       [N,2F,nh,nw,nl] volume
+  predict_3d_heatmaps 3D part: ~45 cuDNN / elementwise 22 fused conv launches + 3 small kernels;
+    kernels                              :414-438       residual adds, ReLU, Sigmoid and the
+                                                        torch.cat of :433 live in conv epilogues
+  2D neck + heads (conv5, hm1, hm2, coord_head)        unchanged: stock PyTorch-ROCm
+                                         :440-450
+
+The HRNet backbone is outside the path.  ``get_feat_extraction`` is the
+same hook the reference uses (vernier.py:837-839): assign a factory to it or
+pass ``feat_net=`` to the constructor.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .submodule import (BasicBlock2d, ConvBNReLU3d, HipConv3d, basicdownsample, convbn, convbn_3d, hourglass,
+                        hourglass2d, hourglass2d_downsample_16, hourglass_downsample_16)
+
+
+def get_feat_extraction(cfg, is_train=False, **kwargs):
+    """Factory hook for the 2D backbone (reference vernier.py:835-839 builds HRNet here)."""
+    if getattr(cfg, "name", None) == "identity":
+        return nn.Identity()
+    raise NotImplementedError(
+        "the 2D backbone (HRNet) is outside the MI355X hot path; set "
+        "snvc_amd.models.vernier.get_feat_extraction to the reference's factory, or pass feat_net=...")
+
+
+class VernierScale(nn.Module):
+    def __init__(self, cfg, is_train=False, feat_net=None):
+        super().__init__()
+        self.cfg = cfg
+        self.is_train = is_train
+        if cfg.vernier_type != "BEV_type3":
+            raise NotImplementedError("only vernier_type='BEV_type3' (the released V-A model) is on the path")
+        self._init_3d_net()
+        self._init_grid()
+        self._init_coord_head()
+        if getattr(self.cfg, "use_bbox_head", False):
+            raise NotImplementedError("use_bbox_head (FCmodel) is off by default and outside the path")
+        for m in self.modules():  # reference vernier.py:38-54
+            if isinstance(m, (nn.Conv3d, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm3d, nn.BatchNorm2d)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        self.feat_net = feat_net if feat_net is not None else get_feat_extraction(
+            cfg=getattr(self.cfg, self.cfg.backbone), is_train=self.is_train)
+
+    # ------------------------------------------------------------------ construction
+    def _init_coord_head(self):
+        """reference vernier.py:68-93"""
+        num_chan = self.cfg.num_parts
+        modules = [BasicBlock2d(num_chan + 2, num_chan * 2, stride=2,
+                                downsample=basicdownsample(num_chan + 2, num_chan * 2))]
+        num_ds = int(4 - np.log2(192 / self.cfg.grid_resolution[2]))
+        for _ in range(num_ds):
+            modules.append(BasicBlock2d(num_chan * 2, num_chan * 2, stride=2,
+                                        downsample=basicdownsample(num_chan * 2, num_chan * 2)))
+        modules.append(nn.Conv2d(num_chan * 2, num_chan * 2, kernel_size=(6, 4)))
+        modules.append(nn.Sigmoid())
+        self.coord_head = nn.Sequential(*modules)
+
+    def _init_grid(self):
+        """reference vernier.py:99-114"""
+        map_height, map_width = self.cfg.grid_resolution[2], self.cfg.grid_resolution[1]
+        x_map = np.tile(np.linspace(0, 1, map_width), (map_height, 1)).reshape(1, 1, map_height, map_width)
+        z_map = np.tile(np.linspace(0, 1, map_height).reshape(map_height, 1), (1, map_width))
+        z_map = z_map.reshape(1, 1, map_height, map_width)
+        self.coor_maps = torch.from_numpy(np.concatenate([x_map, z_map], axis=1).astype(np.float32))
+        self.xrange = self.cfg.x_range[1] - self.cfg.x_range[0]
+        self.zrange = self.cfg.z_range[1] - self.cfg.z_range[0]
+
+    def _init_3d_net(self):
+        """reference vernier.py:249-313 (BEV_type3 branch)"""
+        dim = self.cfg.hrfeat.output_channel
+        gn = self.cfg.gn
+        num_parts = getattr(self.cfg, "num_parts", 9)
+        relu = lambda: nn.ReLU(inplace=True)  # noqa: E731
+        self.vimg_feat = ConvBNReLU3d(convbn_3d(2 * dim, dim, 1, 1, 0, gn=gn), relu())
+        self.conv1 = ConvBNReLU3d(convbn_3d(2 * dim, dim, 7, 1, 3, gn=gn), relu())
+        self.conv2 = ConvBNReLU3d(convbn_3d(dim, dim, 5, 1, 2, gn=gn), relu())
+        self.conv3 = ConvBNReLU3d(convbn_3d(dim, dim, 5, 1, 4, dilation=2, gn=gn), relu())
+        self.conv4 = ConvBNReLU3d(convbn_3d(2 * dim, dim, 3, 1, 1, gn=gn), relu())
+        self.small = self.cfg.n_sample_w <= 16
+        self.hg_conv3d = hourglass(dim, gn=gn) if self.small else hourglass_downsample_16(dim, gn=gn)
+        self.fg_cls_head = nn.Sequential(convbn_3d(dim, dim, 3, 1, 1, gn=gn), relu(),
+                                         HipConv3d(dim, 1, 3, 1, 1, bias=False), nn.Sigmoid())
+        if getattr(self.cfg, "use_part_reg_head", False):
+            self.part_reg_head = nn.Sequential(convbn_3d(dim, dim, 3, 1, 1, gn=gn), relu(),
+                                               HipConv3d(dim, 27, 1, 1, 0, bias=False))
+        self.pool_3d = nn.AvgPool3d((4, 1, 1), stride=(4, 1, 1))
+        if self.cfg.grid_resolution[0] == 32:
+            dim_height = 256
+        elif self.cfg.grid_resolution[0] == 16:
+            dim_height = 128
+        else:
+            raise NotImplementedError
+        self.conv5 = nn.Sequential(convbn(dim_height, 64, 3, 1, 1, 1, gn=gn), relu())
+        self.hm1 = hourglass2d(64, gn=gn) if self.small else hourglass2d_downsample_16(64, gn=gn)
+        self.hm2 = nn.Conv2d(64, num_parts, 3, 1, 1, bias=False)
+
+    # ------------------------------------------------------------------ a3: feature -> voxel
+    def _sample_2d_feat(self, left, right, l_pts, r_pts, aggregate="concat"):
+        """reference vernier.py:323-349.  The reference normalises ``l_pts`` / ``r_pts`` IN PLACE
+        through a view (:335-338); this implementation leaves the caller's tensors untouched."""
+        if aggregate != "concat":
+            raise NotImplementedError('only aggregate="concat" is used by construct_voxel (vernier.py:351-360)')
+        nh, nw, nl = self.cfg.n_sample_h, self.cfg.n_sample_w, self.cfg.n_sample_l
+        if l_pts.size(2) != nh * nw * nl:
+            raise RuntimeError("grid projection does not have nh*nw*nl points")
+        vox = ops.voxel_gather_forward(left, right, l_pts, r_pts, self.cfg.resolution)
+        return vox.view(left.size(0), 2 * left.size(1), nh, nw, nl)
+
+    def construct_voxel(self, left, right, grid_proj_left, grid_proj_right):
+        """reference vernier.py:351-360"""
+        return self._sample_2d_feat(left, right, grid_proj_left, grid_proj_right)
+
+    # ------------------------------------------------------------------ a7: 3D trunk
+    def trunk_3d(self, voxel):
+        """reference vernier.py:415-438 -> (voxel_BEV [N, F*nh/4, nw, nl], occupancy [N,1,nh,nw,nl], offset)."""
+        n, c2 = voxel.size(0), voxel.size(1)
+        f = c2 // 2
+        img = self.vimg_feat(voxel)                                             # :415
+        v = self.conv1(voxel)                                                   # :417
+        v = self.conv2.fused(v, residual=v, residual_after_act=True)            # conv2(v) + v   :418
+        v = self.conv3.fused(v, residual=v, residual_after_act=True)            # conv3(v) + v   :419
+        cat = torch.empty((n, 2 * f) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+        if self.small:                                                          # :420-423, written into cat[:, :F]
+            v, _, _ = self.hg_conv3d(v, None, None, residual=v, out=cat[:, :f])
+        else:
+            v = self.hg_conv3d(v, residual=v, out=cat[:, :f])
+        t = self.fg_cls_head[0].fused(v, relu=True)                             # :427
+        occ = self.fg_cls_head[2].fused(t, sigmoid=True)
+        offset = None
+        if hasattr(self, "part_reg_head"):                                      # :428-431
+            offset = self.part_reg_head[2](self.part_reg_head[0].fused(v, relu=True))
+        ops.mul_broadcast(img, occ, out=cat[:, f:])                             # cat([v, img*occ])  :433
+        v = self.conv4(cat)                                                     # :435
+        v = ops.avgpool_depth4(v)                                               # :436
+        return v.view(n, -1, v.size(3), v.size(4)), occ, offset                 # :437-438
+
+    def heads_2d(self, voxel_BEV):
+        """reference vernier.py:440-450 (stock PyTorch-ROCm)"""
+        voxel_BEV = self.conv5(voxel_BEV)
+        if self.small:
+            heatmap_feats = self.hm1(voxel_BEV, None, None)[0].permute(0, 1, 3, 2)
+        else:
+            heatmap_feats = self.hm1(voxel_BEV).permute(0, 1, 3, 2)
+        heatmaps = self.hm2(heatmap_feats)
+        num_sample = len(heatmaps)
+        coor_maps = self.coor_maps.repeat(num_sample, 1, 1, 1).to(heatmaps.device)
+        augmented_maps = torch.cat([heatmaps, coor_maps], dim=1)
+        coordinates = self.coord_head(augmented_maps).view(num_sample, -1, 2)
+        return heatmaps, coordinates
+
+    def predict_3d_heatmaps(self, voxel, depth=None):
+        """reference vernier.py:362-458 -> (heatmaps, occupancy, offset, coordinates, bbox)"""
+        if depth is not None:
+            raise NotImplementedError
+        voxel_BEV, occupancy, offset = self.trunk_3d(voxel)
+        heatmaps, coordinates = self.heads_2d(voxel_BEV)
+        return heatmaps, occupancy.squeeze(1), offset, coordinates, None
+
+    def forward(self, left_roi, right_roi, grid_proj_left, grid_proj_right, meta_data=None, test=False):
+        """reference vernier.py:460-555"""
+        if test:
+            raise NotImplementedError("test=True is the reference's matplotlib self-check (vernier.py:479-550)")
+        left_feat = self.feat_net(left_roi)
+        right_feat = self.feat_net(right_roi)
+        voxels = self.construct_voxel(left_feat, right_feat, grid_proj_left, grid_proj_right)
+        ncf, occupancy, part_offsets, coordinates, bboxes = self.predict_3d_heatmaps(voxels)
+        return {"ncf": ncf, "occupancy": occupancy, "coordinates": coordinates}
+
+    # ------------------------------------------------------------------ a12: index extraction
+    def ncf_argmax(self, ncf):
+        """np.argmax(ncf.reshape(N, parts, -1), axis=2) of ncf_to_update_2d / ncf_to_offset
+        (reference vernier.py:570-572,693) on the device; returns (int64 indices, confidences)."""
+        n, p = ncf.shape[0], ncf.shape[1]
+        idx, val = ops.argmax_rows(ncf.reshape(n * p, -1))
+        return idx.view(n, p), val.view(n, p)
+
+
+def get_model(cfgs, is_train=False):
+    """reference vernier.py:841-842"""
+    return VernierScale(cfgs, is_train)

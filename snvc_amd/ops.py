@@ -1,0 +1,401 @@
+"""Tensor-level wrappers over the C ABI (``include/snvc_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream.  Every function
+  * requires its tensors on a GPU (``RuntimeError("... Not implemented on the CPU")`` otherwise,
+    the message the reference's dispatcher gives, BuildCostVolume.cpp:26,41),
+  * makes inputs contiguous like the reference launchers do (BuildCostVolume_cuda.cu:243-245),
+  * allocates outputs with the input's dtype/device (at::empty / at::zeros there),
+  * launches on ``torch.cuda.current_stream()`` without synchronising.
+"""
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, Conv3dDesc,
+                   check)
+
+__all__ = [
+    "cost_volume_forward", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
+    "Conv3dLayer", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
+    "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
+    "points_in_boxes_gpu", "points_in_boxes_cpu",
+    "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID",
+]
+
+
+def _gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: Not implemented on the CPU")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _dtype_tag(t: torch.Tensor, what: str) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.float64:
+        return F64
+    raise RuntimeError(f'"{what}" not implemented for {t.dtype}')  # AT_DISPATCH_FLOATING_TYPES
+
+
+# ------------------------------------------------------------------------------ cost volume
+def cost_volume_forward(left, right, shift, downsample: int):
+    """build_cost_volume_forward (BuildCostVolume_cuda.cu:208-256)."""
+    _gpu(left, "left"); _gpu(right, "right"); _gpu(shift, "shift")
+    if left.dim() != 4 or tuple(left.shape) != tuple(right.shape):
+        raise RuntimeError("Left image and right image should match their size.")
+    if shift.dim() != 2 or left.size(0) != shift.size(0):
+        raise RuntimeError("Image and shift should of same batch.")
+    tag = _dtype_tag(left, "BuildCostVolume_forward")
+    if right.dtype != left.dtype or shift.dtype != left.dtype:
+        raise RuntimeError("left, right and shift must share one dtype")
+    downsample = int(downsample)
+    if downsample < 1:
+        raise RuntimeError("downsample must be >= 1")
+    n, c, hi, wi = left.shape
+    d = shift.size(1)
+    if hi % downsample or wi % downsample:
+        raise RuntimeError("feature height and width must be multiples of downsample")
+    out = torch.empty((n, 2 * c, d, hi // downsample, wi // downsample), dtype=left.dtype, device=left.device)
+    if out.numel() == 0:
+        return out
+    left, right, shift = left.contiguous(), right.contiguous(), shift.contiguous()
+    with torch.cuda.device(left.device):
+        check(_lib.lib().snvc_cost_volume_forward(_ptr(left), _ptr(right), _ptr(shift), _ptr(out), n, c, hi, wi, d,
+                                                  downsample, tag, _stream(left)), "build_cost_volume_forward")
+    return out
+
+
+def cost_volume_backward(grad, shift, downsample: int):
+    """build_cost_volume_backward (BuildCostVolume_cuda.cu:259-303) -> (grad_left, grad_right)."""
+    _gpu(grad, "grad"); _gpu(shift, "shift")
+    tag = _dtype_tag(grad, "BuildCostVolume_backward")
+    if shift.dtype != grad.dtype:
+        raise RuntimeError("grad and shift must share one dtype")
+    downsample = int(downsample)
+    n, c2, _, h, w = grad.shape
+    c, d = c2 // 2, shift.size(1)
+    if grad.numel() != n * c * 2 * d * h * w:
+        raise RuntimeError("grad shape is wrong")
+    gl = torch.empty((n, c, h * downsample, w * downsample), dtype=grad.dtype, device=grad.device)
+    gr = torch.empty_like(gl)
+    if gl.numel() == 0:
+        return gl, gr
+    grad, shift = grad.contiguous(), shift.contiguous()
+    with torch.cuda.device(grad.device):
+        check(_lib.lib().snvc_cost_volume_backward(_ptr(grad), _ptr(shift), _ptr(gl), _ptr(gr), n, c, h, w, d,
+                                                   downsample, tag, _stream(grad)), "build_cost_volume_backward")
+    return gl, gr
+
+
+# ------------------------------------------------------------------------------ voxel gather
+def _check_gather(left, right, l_pts, r_pts):
+    for t, nm in ((left, "left"), (right, "right"), (l_pts, "grid_proj_left"), (r_pts, "grid_proj_right")):
+        _gpu(t, nm)
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"{nm} must be float32")
+    if left.dim() != 4 or tuple(left.shape) != tuple(right.shape):
+        raise RuntimeError("left and right feature maps must have the same [N,F,H,W] shape")
+    if l_pts.dim() != 3 or l_pts.size(1) != 2 or tuple(l_pts.shape) != tuple(r_pts.shape) or l_pts.size(0) != left.size(0):
+        raise RuntimeError("grid projections must be [N,2,V] for the same batch as the features")
+
+
+def voxel_gather_forward(left, right, l_pts, r_pts, resolution) -> torch.Tensor:
+    """_sample_2d_feat(aggregate='concat') (vernier.py:323-349) -> [N, 2F, V]."""
+    _check_gather(left, right, l_pts, r_pts)
+    n, f, hf, wf = left.shape
+    v = l_pts.size(2)
+    out = torch.empty((n, 2 * f, v), dtype=torch.float32, device=left.device)
+    if out.numel() == 0:
+        return out
+    left, right, l_pts, r_pts = left.contiguous(), right.contiguous(), l_pts.contiguous(), r_pts.contiguous()
+    with torch.cuda.device(left.device):
+        check(_lib.lib().snvc_voxel_gather_forward(_ptr(left), _ptr(right), _ptr(l_pts), _ptr(r_pts), _ptr(out), n, f,
+                                                   hf, wf, v, float(resolution[1]), float(resolution[0]),
+                                                   _stream(left)), "voxel_gather_forward")
+    return out
+
+
+def voxel_gather_backward(grad_out, l_pts, r_pts, feat_shape, resolution):
+    n, f, hf, wf = feat_shape
+    _gpu(grad_out, "grad_out")
+    v = l_pts.size(2)
+    gl = torch.empty((n, f, hf, wf), dtype=torch.float32, device=grad_out.device)
+    gr = torch.empty_like(gl)
+    grad_out, l_pts, r_pts = grad_out.contiguous(), l_pts.contiguous(), r_pts.contiguous()
+    with torch.cuda.device(grad_out.device):
+        check(_lib.lib().snvc_voxel_gather_backward(_ptr(grad_out), _ptr(l_pts), _ptr(r_pts), _ptr(gl), _ptr(gr), n, f,
+                                                    hf, wf, v, float(resolution[1]), float(resolution[0]),
+                                                    _stream(grad_out)), "voxel_gather_backward")
+    return gl, gr
+
+
+# ------------------------------------------------------------------------------ conv3d
+def _dense_inner(t: torch.Tensor) -> bool:
+    """True if dims 1.. are laid out densely (dim 0 may have any stride): a channel slice of a
+    contiguous [N, Ctot, D, H, W] buffer qualifies."""
+    exp = 1
+    for size, stride in zip(reversed(t.shape[1:]), reversed(t.stride()[1:])):
+        if size != 1 and stride != exp:
+            return False
+        exp *= size
+    return True
+
+
+def _batch_stride(t: torch.Tensor) -> int:
+    return t.stride(0) if t.size(0) > 1 else math.prod(t.shape[1:])
+
+
+class Conv3dLayer:
+    """One Conv3d / ConvTranspose3d layer prepared for the HIP kernel: geometry, packed weights.
+
+    Geometry follows nn.Conv3d(cin, cout, k, stride, pad, dilation, bias=False) as built by
+    convbn_3d (submodule.py:41-48) or nn.ConvTranspose3d(cin, cout, 3, padding=1,
+    output_padding=1, stride=2, bias=False) (submodule.py:127-134,198-205).
+    """
+
+    def __init__(self, weight: torch.Tensor, ksize: int, stride: int, pad: int, dilation: int, transposed: bool):
+        _gpu(weight, "weight")
+        if weight.dtype != torch.float32:
+            raise RuntimeError("conv3d weights must be float32")
+        self.transposed = bool(transposed)
+        if transposed:
+            self.cin, self.cout = weight.shape[0], weight.shape[1]
+        else:
+            self.cout, self.cin = weight.shape[0], weight.shape[1]
+        if tuple(weight.shape[2:]) != (ksize,) * 3:
+            raise RuntimeError("only cubic kernels are on the path")
+        self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
+        self.device = weight.device
+        probe = self._desc(1, (16, 16, 32), 0)
+        count = _lib.lib().snvc_conv3d_packed_weight_count(ctypes.byref(probe))
+        if count < 0:
+            check(1, "snvc_conv3d_packed_weight_count")
+        self.packed = torch.empty(count, dtype=torch.float32, device=weight.device)
+        with torch.cuda.device(weight.device):
+            check(_lib.lib().snvc_conv3d_pack_weights(ctypes.byref(probe), _ptr(weight.detach().contiguous()),
+                                                      _ptr(self.packed), _stream(weight)), "snvc_conv3d_pack_weights")
+
+    def out_spatial(self, in_spatial):
+        if self.transposed:
+            return tuple(2 * s for s in in_spatial)
+        eff = self.dilation * (self.ksize - 1) + 1
+        return tuple((s + 2 * self.pad - eff) // self.stride + 1 for s in in_spatial)
+
+    def _desc(self, n, in_spatial, flags, x_bs=0, y_bs=0, r_bs=0) -> Conv3dDesc:
+        d = Conv3dDesc()
+        d.N, d.Cin = n, self.cin
+        d.Din, d.Hin, d.Win = in_spatial
+        d.Cout = self.cout
+        d.Dout, d.Hout, d.Wout = self.out_spatial(in_spatial)
+        d.ksize, d.stride, d.dilation, d.pad = self.ksize, self.stride, self.dilation, self.pad
+        d.transposed = 1 if self.transposed else 0
+        d.flags = flags
+        d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = x_bs, y_bs, r_bs
+        return d
+
+    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None):
+        """y = epilogue(conv(x)); x / out / residual may be channel slices of larger buffers."""
+        _gpu(x, "x")
+        if x.dtype != torch.float32 or x.dim() != 5 or x.size(1) != self.cin:
+            raise RuntimeError(f"conv3d input must be float32 [N,{self.cin},D,H,W], got {tuple(x.shape)} {x.dtype}")
+        if not _dense_inner(x):
+            x = x.contiguous()
+        n = x.size(0)
+        in_sp = tuple(x.shape[2:])
+        out_shape = (n, self.cout) + self.out_spatial(in_sp)
+        if min(out_shape[2:]) < 1:
+            raise RuntimeError("conv3d output would be empty")
+        if out is None:
+            out = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+        else:
+            if tuple(out.shape) != out_shape or out.dtype != torch.float32 or not _dense_inner(out):
+                raise RuntimeError("conv3d `out` must be a float32 channel-dense view of the output shape")
+        if residual is not None:
+            if tuple(residual.shape) != out_shape:
+                raise RuntimeError("residual must have the output's shape")
+            if not _dense_inner(residual):
+                residual = residual.contiguous()
+        if n == 0:
+            return out
+        d = self._desc(n, in_sp, flags, _batch_stride(x), _batch_stride(out),
+                       _batch_stride(residual) if residual is not None else 0)
+        with torch.cuda.device(x.device):
+            check(_lib.lib().snvc_conv3d_forward(ctypes.byref(d), _ptr(x), _ptr(self.packed), _ptr(scale), _ptr(bias),
+                                                 _ptr(residual), _ptr(out), _stream(x)), "snvc_conv3d_forward")
+        return out
+
+
+# ------------------------------------------------------------------------------ norm / elementwise
+def norm_stats(x, gamma, beta, groups: int, per_sample: bool, eps: float):
+    """(scale, shift, mean, var) for GroupNorm (per_sample) or batch-stat BatchNorm."""
+    _gpu(x, "x")
+    if not _dense_inner(x):
+        x = x.contiguous()
+    n, c = x.shape[0], x.shape[1]
+    s = x[0, 0].numel()
+    outer = n if per_sample else 1
+    scale = torch.empty((outer, c), dtype=torch.float32, device=x.device)
+    shift = torch.empty_like(scale)
+    mean = torch.empty((outer, groups), dtype=torch.float32, device=x.device)
+    var = torch.empty_like(mean)
+    ws = torch.empty(_lib.lib().snvc_norm_workspace_bytes(n, c, groups), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_norm_stats(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift), _ptr(mean),
+                                         _ptr(var), _ptr(ws), n, c, s, _batch_stride(x), groups,
+                                         1 if per_sample else 0, float(eps), _stream(x)), "snvc_norm_stats")
+    return scale, shift, mean, var
+
+
+def affine_act(x, scale, shift, residual=None, flags=0, per_sample=False, out=None):
+    _gpu(x, "x")
+    if not _dense_inner(x):
+        x = x.contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    elif not _dense_inner(out) or tuple(out.shape) != tuple(x.shape):
+        raise RuntimeError("affine_act `out` must be a channel-dense view of x's shape")
+    if residual is not None and not _dense_inner(residual):
+        residual = residual.contiguous()
+    n, c = x.shape[0], x.shape[1]
+    s = x[0, 0].numel() if n else 0
+    if x.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_affine_act(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, c, s,
+                                         _batch_stride(x), _batch_stride(out),
+                                         _batch_stride(residual) if residual is not None else 0,
+                                         1 if per_sample else 0, flags, _stream(x)), "snvc_affine_act")
+    return out
+
+
+def mul_broadcast(feat, occ, out=None):
+    """out[n,c,...] = feat[n,c,...] * occ[n,0,...] (second half of the cat in vernier.py:433)."""
+    _gpu(feat, "feat"); _gpu(occ, "occ")
+    feat, occ = feat.contiguous(), occ.contiguous()
+    n, c = feat.shape[0], feat.shape[1]
+    s = feat[0, 0].numel() if n else 0
+    if occ.numel() != n * s:
+        raise RuntimeError("occupancy must be [N,1,D,H,W] matching the feature volume")
+    if out is None:
+        out = torch.empty_like(feat)
+    elif not _dense_inner(out) or tuple(out.shape) != tuple(feat.shape):
+        raise RuntimeError("mul_broadcast `out` must be a channel-dense view of feat's shape")
+    if feat.numel() == 0:
+        return out
+    with torch.cuda.device(feat.device):
+        check(_lib.lib().snvc_mul_broadcast(_ptr(feat), _ptr(occ), _ptr(out), n, c, s, _batch_stride(out),
+                                            _stream(feat)), "snvc_mul_broadcast")
+    return out
+
+
+def avgpool_depth4(x):
+    """AvgPool3d((4,1,1),(4,1,1)) (vernier.py:289) on [N,C,D,H,W] -> [N,C,D//4,H,W]."""
+    _gpu(x, "x")
+    x = x.contiguous()
+    n, c, d, h, w = x.shape
+    y = torch.empty((n, c, d // 4, h, w), dtype=torch.float32, device=x.device)
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_avgpool_depth4(_ptr(x), _ptr(y), n, c, d, h * w, _stream(x)), "snvc_avgpool_depth4")
+    return y
+
+
+def disparity_regression(x, depth):
+    """disparityregression.forward (submodule.py:81-83): [N,D,H,W] x [D] -> [N,H,W]."""
+    _gpu(x, "x"); _gpu(depth, "depth")
+    x, depth = x.contiguous(), depth.contiguous()
+    n, d, h, w = x.shape
+    if depth.numel() != d:
+        raise RuntimeError("depth must have one entry per disparity plane")
+    out = torch.empty((n, h, w), dtype=torch.float32, device=x.device)
+    if out.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_disparity_regression(_ptr(x), _ptr(depth), _ptr(out), n, d, h * w, _stream(x)),
+              "snvc_disparity_regression")
+    return out
+
+
+def argmax_rows(x2d) -> Tuple[torch.Tensor, torch.Tensor]:
+    """np.argmax(ncf.reshape(N, P, -1), axis=2) (vernier.py:693) on the GPU -> (int64 idx, max)."""
+    _gpu(x2d, "x")
+    x2d = x2d.contiguous()
+    r, l = x2d.shape
+    idx = torch.empty(r, dtype=torch.int64, device=x2d.device)
+    val = torch.empty(r, dtype=torch.float32, device=x2d.device)
+    if r == 0:
+        return idx, val
+    with torch.cuda.device(x2d.device):
+        check(_lib.lib().snvc_argmax_rows(_ptr(x2d), _ptr(idx), _ptr(val), r, l, _stream(x2d)), "snvc_argmax_rows")
+    return idx, val
+
+
+# ------------------------------------------------------------------------------ roiaware_pool3d
+def roiaware_pool3d_forward(rois, pts, pts_feature, argmax, pts_idx_of_voxels, pooled_features, pool_method: int):
+    """roiaware_pool3d_cuda.forward (roiaware_pool3d.cpp:29-66): outputs are pre-zeroed by the caller."""
+    for t, nm in ((rois, "rois"), (pts, "pts"), (pts_feature, "pts_feature"), (argmax, "argmax"),
+                  (pts_idx_of_voxels, "pts_idx_of_voxels"), (pooled_features, "pooled_features")):
+        _gpu(t, nm)
+        if not t.is_contiguous():
+            raise RuntimeError(f"{nm} must be contiguous")
+    b, p, c = rois.size(0), pts.size(0), pts_feature.size(1)
+    _, ox, oy, oz, max_pts = pts_idx_of_voxels.shape
+    if not (ox < 256 and oy < 256 and oz < 256):
+        raise AssertionError("we encode index with 8bit")  # roiaware_pool3d.cpp:53
+    ws = torch.empty((max(b * p, 1),), dtype=torch.int32, device=rois.device)
+    with torch.cuda.device(rois.device):
+        check(_lib.lib().snvc_roiaware_pool3d_forward(_ptr(rois), _ptr(pts), _ptr(pts_feature), _ptr(argmax),
+                                                      _ptr(pts_idx_of_voxels), _ptr(pooled_features), _ptr(ws), b, p,
+                                                      c, max_pts, ox, oy, oz, int(pool_method), _stream(rois)),
+              "roiaware_pool3d forward")
+    return 1
+
+
+def roiaware_pool3d_backward(pts_idx_of_voxels, argmax, grad_out, grad_in, pool_method: int):
+    for t, nm in ((pts_idx_of_voxels, "pts_idx_of_voxels"), (argmax, "argmax"), (grad_out, "grad_out"), (grad_in, "grad_in")):
+        _gpu(t, nm)
+        if not t.is_contiguous():
+            raise RuntimeError(f"{nm} must be contiguous")
+    b, ox, oy, oz, max_pts = pts_idx_of_voxels.shape
+    c = grad_out.size(4)
+    with torch.cuda.device(grad_out.device):
+        check(_lib.lib().snvc_roiaware_pool3d_backward(_ptr(pts_idx_of_voxels), _ptr(argmax), _ptr(grad_out),
+                                                       _ptr(grad_in), b, c, max_pts, ox, oy, oz, int(pool_method),
+                                                       _stream(grad_out)), "roiaware_pool3d backward")
+    return 1
+
+
+def points_in_boxes_gpu(boxes, pts, box_idx_of_points):
+    for t, nm in ((boxes, "boxes"), (pts, "pts"), (box_idx_of_points, "box_idx_of_points")):
+        _gpu(t, nm)
+        if not t.is_contiguous():
+            raise RuntimeError(f"{nm} must be contiguous")
+    bs, t_, m = boxes.size(0), boxes.size(1), pts.size(1)
+    with torch.cuda.device(boxes.device):
+        check(_lib.lib().snvc_points_in_boxes_gpu(_ptr(boxes), _ptr(pts), _ptr(box_idx_of_points), bs, t_, m,
+                                                  _stream(boxes)), "points_in_boxes_gpu")
+    return 1
+
+
+def points_in_boxes_cpu(boxes, pts, pts_indices):
+    """Host op in the reference too (roiaware_pool3d.cpp:137-168): CPU tensors in, CPU tensor out."""
+    for t, nm in ((boxes, "boxes"), (pts, "pts"), (pts_indices, "pts_indices")):
+        if t.is_cuda:
+            raise RuntimeError(f"{nm} must be a CPU tensor")
+        if not t.is_contiguous():
+            raise RuntimeError(f"{nm} must be contiguous")
+    check(_lib.lib().snvc_points_in_boxes_cpu(ctypes.c_void_p(boxes.data_ptr()), ctypes.c_void_p(pts.data_ptr()),
+                                              ctypes.c_void_p(pts_indices.data_ptr()), boxes.size(0), pts.size(0)),
+          "points_in_boxes_cpu")
+    return 1
