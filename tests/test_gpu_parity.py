@@ -423,7 +423,8 @@ def _roi_scene(seed, B=5, P=3000, C=6):
     rois[0, 6] = 0.0
     rois[1, 6] = np.pi / 2
     pts = r.uniform(-7, 7, (P, 3)).astype(np.float32)
-    pts[:200] = rois[0, :3] + r.uniform(-0.05, 0.05, (200, 3)).astype(np.float32)   # >127 points in one voxel
+    # >127 points inside ONE voxel of box 0 (heading 0): centre + 1/8 of the extents, tiny jitter
+    pts[:200] = rois[0, :3] + 0.125 * rois[0, 3:6] + r.uniform(-0.01, 0.01, (200, 3)).astype(np.float32)
     feat = r.standard_normal((P, C)).astype(np.float32)
     feat[10:20] = feat[10]                                                          # argmax ties
     return rois, pts, feat
