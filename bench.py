@@ -227,14 +227,14 @@ def _breakdown(model, left, right, shift, build_cost_volume):
 
     with torch.no_grad():
         t, vol = timed(lambda: build_cost_volume(left, right, shift, 1))
-        print(f"[breakdown] build_cost_volume      {t:8.3f} ms  {STEP_BYTES / t / 1e9:8.1f} GB/s", file=sys.stderr)
+        print(f"[breakdown] build_cost_volume      {t:8.3f} ms  {STEP_BYTES / (t * 1e-3) / 1e9:8.1f} GB/s", file=sys.stderr)
         t, v1 = timed(lambda: model.conv1(vol))
-        print(f"[breakdown] conv1 k3 64->32        {t:8.3f} ms  {CONV1_FLOP / t / 1e9:8.1f} TFLOP/s", file=sys.stderr)
+        print(f"[breakdown] conv1 k3 64->32        {t:8.3f} ms  {CONV1_FLOP / (t * 1e-3) / 1e12:8.1f} TFLOP/s", file=sys.stderr)
         del vol
         t, v2 = timed(lambda: model.conv2(v1))
-        print(f"[breakdown] conv2 k3 32->32        {t:8.3f} ms  {CONV1_FLOP / 2 / t / 1e9:8.1f} TFLOP/s", file=sys.stderr)
+        print(f"[breakdown] conv2 k3 32->32        {t:8.3f} ms  {CONV1_FLOP / 2 / (t * 1e-3) / 1e12:8.1f} TFLOP/s", file=sys.stderr)
         t, _ = timed(lambda: model.hg_conv3d(v2, None, None, residual=v2))
-        print(f"[breakdown] hourglass(32)          {t:8.3f} ms  {377.6e9 / t / 1e9:8.1f} TFLOP/s", file=sys.stderr)
+        print(f"[breakdown] hourglass(32)          {t:8.3f} ms  {377.6e9 / (t * 1e-3) / 1e12:8.1f} TFLOP/s", file=sys.stderr)
         t, _ = timed(lambda: model.classifier(v2))
         print(f"[breakdown] classifier 1x1x1       {t:8.3f} ms", file=sys.stderr)
 

@@ -46,6 +46,7 @@ struct ConvArgs {
     int Cout, Dout, Hout, Wout;
     int tiles_d, tiles_h, tiles_w;
     int nchunks, flags;
+    int vec;  // 1: 16-byte aligned rows (Win % 4 == 0, aligned base and strides) -> float4 staging
     int64_t x_bs, y_bs, r_bs;
 };
 
@@ -65,32 +66,179 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return base + k;
 }
 
+// ------------------------------------------------------------------------------------ staging
+// The LDS image of one chunk is [KC][IN_D][IN_H][IN_WV] floats.  IN_WV is the tile's input row
+// widened to 16-byte-aligned global columns: column 0 of the image is global column
+// (first output column)*STRIDE - LPAD with LPAD = PAD rounded up to a multiple of 4, so that a
+// row is RQ = IN_WV/4 aligned float4 pieces, each either entirely inside [0, Win) or entirely
+// padding when Win % 4 == 0.  Item i (= 16-byte piece i) lands at LDS float 4*i: lanes write
+// consecutive 16-byte slots (no bank conflicts) and the geometry of an item -- its global
+// offset and whether it is padding -- does not depend on the channel chunk, so it is computed
+// ONCE per thread and kept in registers.  Loads are unconditional (padding items read offset 0
+// and are zeroed by a select): no branches, no per-item waits; the whole chunk is in flight at
+// once, and it is issued one chunk AHEAD of its use (register prefetch).
+template <int KC_, int IN_D_, int IN_H_, int IN_WV_>
+struct Stager {
+    static constexpr int KC = KC_, IN_D = IN_D_, IN_H = IN_H_, IN_WV = IN_WV_;
+    static constexpr int RQ = IN_WV / 4;
+    static constexpr int ROWS = KC * IN_D * IN_H;
+    static constexpr int ITEMS = ROWS * RQ;
+    static constexpr int NIT = (ITEMS + 255) / 256;
+    static constexpr int CH = IN_D * IN_H * IN_WV;   // floats per channel
+    static constexpr int TILE = KC * CH;             // floats per chunk image
+    static_assert(IN_WV % 4 == 0, "image rows are whole float4 pieces");
+    static_assert(NIT <= 32, "validity mask is one 32-bit register");
+
+    unsigned off[NIT];   // float offset of the piece relative to (sample base + c0*in_dhw)
+    unsigned kcs;        // 2 bits per item would not fit every config: kc is recomputed when needed
+    unsigned vmask;      // bit it: piece is inside the tensor (else padding -> zeros)
+
+    __device__ __forceinline__ void init(int tid, int id0, int ih0, int ix0, int Din, int Hin, int Win,
+                                         int in_hw, int in_dhw) {
+        vmask = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            const int row = i / RQ, q = i - row * RQ;
+            const int kc = row / (IN_D * IN_H), r2 = row - kc * (IN_D * IN_H);
+            const int dd = r2 / IN_H, hh = r2 - dd * IN_H;
+            const int gd = id0 + dd, gh = ih0 + hh, gw = ix0 + 4 * q;
+            const bool ok = i < ITEMS && (unsigned)gd < (unsigned)Din && (unsigned)gh < (unsigned)Hin &&
+                            (unsigned)gw < (unsigned)Win;
+            off[it] = ok ? (unsigned)(kc * in_dhw + gd * in_hw + gh * Win + gw) : 0u;
+            vmask |= (ok ? 1u : 0u) << it;
+        }
+    }
+
+    // channels [c0, c0+KC) -> registers.  cin_left = Cin - c0 (items of channels >= Cin are zeros).
+    __device__ __forceinline__ void load(const float *__restrict__ xc, int tid, int cin_left, float4 (&v)[NIT]) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const float4 t = *reinterpret_cast<const float4 *>(xc + off[it]);
+            bool ok = (vmask >> it) & 1u;
+            if (cin_left < KC) ok = ok && ((it * 256 + tid) / (RQ * IN_D * IN_H) < cin_left);
+            v[it] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    __device__ __forceinline__ void store(float *__restrict__ buf, int tid, const float4 (&v)[NIT]) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<float4 *>(buf)[i] = v[it];
+        }
+    }
+
+    // Fallback for tensors whose rows are not 16-byte aligned (Win % 4 != 0, odd strides):
+    // same LDS image, one float at a time, synchronous, still branch-free per element.
+    static __device__ __forceinline__ void stage_scalar(const float *__restrict__ xc, float *__restrict__ buf,
+                                                        int tid, int id0, int ih0, int ix0, int Din, int Hin,
+                                                        int Win, int in_hw, int in_dhw, int cin_left) {
+        constexpr int BATCH = 8;
+        for (int e0 = 0; e0 < TILE; e0 += 256 * BATCH) {
+            float v[BATCH];
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) {
+                const int e = e0 + b * 256 + tid;
+                const int kc = e / CH, rem = e - kc * CH;
+                const int dd = rem / (IN_H * IN_WV), rem2 = rem - dd * (IN_H * IN_WV);
+                const int hh = rem2 / IN_WV, ww = rem2 - hh * IN_WV;
+                const int gd = id0 + dd, gh = ih0 + hh, gw = ix0 + ww;
+                const bool ok = e < TILE && kc < cin_left && (unsigned)gd < (unsigned)Din &&
+                                (unsigned)gh < (unsigned)Hin && (unsigned)gw < (unsigned)Win;
+                const float t = xc[ok ? (kc * in_dhw + gd * in_hw + gh * Win + gw) : 0];
+                v[b] = ok ? t : 0.0f;
+            }
+#pragma unroll
+            for (int b = 0; b < BATCH; ++b) {
+                const int e = e0 + b * 256 + tid;
+                if (e < TILE) buf[e] = v[b];
+            }
+        }
+    }
+};
+
+// Epilogue shared by conv and deconv: acc register r of lane l is output channel
+// cbase + (r&3) + 8*(r>>2) + 4*(l>>5); scale / bias for the lane's 16 channels are fetched
+// together, residual values are fetched as one batch per accumulator (clamped addresses, no
+// branches) and the stores are predicated.
+struct ChanAffine {
+    float sc[16], bi[16];
+};
+
+__device__ __forceinline__ void load_affine(const ConvArgs &a, int cbase, int lane, ChanAffine &f) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        co = co < a.Cout ? co : a.Cout - 1;
+        f.sc[r] = a.scale ? a.scale[co] : 1.0f;
+        f.bi[r] = a.scale ? a.bias[co] : 0.0f;
+    }
+}
+
 // ------------------------------------------------------------------------------------ conv
-template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_>
+template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_, bool DB_>
 struct ConvCfg {
     static constexpr int KS = KS_, STRIDE = STRIDE_, DIL = DIL_, MI = MI_, TD = TD_, TH = TH_, KC = KC_;
+    static constexpr bool DB = DB_;                 // double-buffered LDS image (one barrier per chunk)
     static constexpr int TW = 32;
     static constexpr int PAD = DIL * (KS - 1) / 2;
+    static constexpr int LPAD = (PAD + 3) / 4 * 4;  // left halo rounded to a 16-byte boundary
+    static constexpr int XOFF = LPAD - PAD;         // image column of the tile's first needed input
     static constexpr int IN_D = (TD - 1) * STRIDE + (KS - 1) * DIL + 1;
     static constexpr int IN_H = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
     static constexpr int IN_W = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
-    static constexpr int CH = IN_D * IN_H * IN_W;  // floats per staged channel
-    static constexpr int TILE = KC * CH;
-    static constexpr int NB = TD * TH / 4;         // 32-voxel rows per wave (4 waves)
-    static constexpr int KP = KC / 2;              // MFMA k-steps per chunk
+    static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;
+    using St = Stager<KC, IN_D, IN_H, IN_WV>;
+    static constexpr int CH = St::CH, TILE = St::TILE;
+    static constexpr int NB = TD * TH / 4;          // 32-voxel rows per wave (4 waves)
+    static constexpr int KP = KC / 2;               // MFMA k-steps per chunk
     static constexpr int TAPS = KS * KS * KS;
-    static constexpr int LDS_BYTES = TILE * 4;
+    static constexpr int LDS_BYTES = TILE * 4 * (DB ? 2 : 1);
     static_assert(TD * TH % 4 == 0, "rows must split over 4 waves");
     static_assert(KC % 2 == 0, "KC must be even (MFMA K = 2)");
 };
 
 template <class Cfg>
+__device__ __forceinline__ void conv_compute_chunk(const float *__restrict__ buf, const float *__restrict__ wc,
+                                                   int bbase, int wave, f32x16 (&acc)[Cfg::NB][Cfg::MI]) {
+    constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, MI = Cfg::MI, TH = Cfg::TH, KP = Cfg::KP;
+    constexpr int NB = Cfg::NB, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, CH = Cfg::CH;
+    constexpr int UNR = KS <= 3 ? KS : 1;  // small kernels: fully unrolled taps; k5/k7: kd,kh loops stay rolled
+#pragma unroll UNR
+    for (int kd = 0; kd < KS; ++kd) {
+#pragma unroll UNR
+        for (int kh = 0; kh < KS; ++kh) {
+            const float *wrow = wc + (int64_t)((kd * KS + kh) * KS) * KP * 64 * MI;
+            const int tap_base = bbase + (kd * DIL * IN_H + kh * DIL) * IN_WV;
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+#pragma unroll
+                for (int kp = 0; kp < KP; ++kp) {
+                    float af[MI];
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) af[m] = wrow[(kw * KP + kp) * 64 * MI + m];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int row = wave * NB + nb;
+                        const int dd = row / TH, hh = row % TH;
+                        const float bf = buf[tap_base + kp * 2 * CH + (dd * S * IN_H + hh * S) * IN_WV + kw * DIL];
+#pragma unroll
+                        for (int m = 0; m < MI; ++m)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf, acc[nb][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <class Cfg>
 __global__ void __launch_bounds__(256, 2)
 conv3d_mfma_kernel(const ConvArgs a) {
-    constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH;
-    constexpr int KC = Cfg::KC, KP = Cfg::KP, NB = Cfg::NB, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W;
-    constexpr int CH = Cfg::CH, TILE = Cfg::TILE, TAPS = Cfg::TAPS, PAD = Cfg::PAD;
-    constexpr int UNR = KS <= 3 ? KS : 1;  // small kernels: fully unrolled taps; k5/k7: kd,kh loops stay rolled
+    constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, KP = Cfg::KP, NB = Cfg::NB;
+    constexpr int CH = Cfg::CH, TILE = Cfg::TILE, TAPS = Cfg::TAPS, PAD = Cfg::PAD, LPAD = Cfg::LPAD, XOFF = Cfg::XOFF;
+    using St = typename Cfg::St;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -100,7 +248,7 @@ conv3d_mfma_kernel(const ConvArgs a) {
     const int cg = blockIdx.y;  // group of 32*MI output channels
     const int64_t n = blockIdx.z;
     const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 32;
-    const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+    const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, ix0 = ow0 * S - LPAD;
 
     f32x16 acc[NB][MI];
 #pragma unroll
@@ -110,86 +258,71 @@ conv3d_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nb][m][r] = 0.0f;
 
-    const int64_t in_hw = (int64_t)a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     const float *xn = a.x + n * a.x_bs;
     const float *wp = a.wp + (int64_t)cg * a.nchunks * TAPS * KP * 64 * MI + lane * MI;
     // B-fragment base: lane&31 = voxel column, lane>>5 = k within the k-pair
-    const int bbase = (lane >> 5) * CH + (lane & 31) * S;
+    const int bbase = (lane >> 5) * CH + (lane & 31) * S + XOFF;
 
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        __syncthreads();  // everyone is done reading the previous tile
-        // ---- stage KC channels of the input tile (zero padded) into LDS
-        const int c0 = chunk * KC;
-        constexpr int ITER = (TILE + 255) / 256;
-#pragma unroll 8
-        for (int it = 0; it < ITER; ++it) {
-            const int e = it * 256 + tid;
-            if (e < TILE) {
-                const int kc = e / CH, rem = e - kc * CH;
-                const int dd = rem / (IN_H * IN_W), rem2 = rem - dd * (IN_H * IN_W);
-                const int hh = rem2 / IN_W, ww = rem2 - hh * IN_W;
-                const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww, gc = c0 + kc;
-                float v = 0.0f;
-                if (gc < a.Cin && (unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Hin &&
-                    (unsigned)gw < (unsigned)a.Win)
-                    v = xn[gc * in_dhw + gd * in_hw + (int64_t)gh * a.Win + gw];
-                lds[e] = v;
+    if (a.vec) {
+        St st;
+        st.init(tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+        float4 pre[St::NIT];
+        st.load(xn, tid, a.Cin, pre);
+        st.store(lds, tid, pre);
+        __syncthreads();
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            const bool more = chunk + 1 < a.nchunks;
+            float *cur = lds + (Cfg::DB ? (chunk & 1) * TILE : 0);
+            if (more) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
+            conv_compute_chunk<Cfg>(cur, wp + (int64_t)chunk * TAPS * KP * 64 * MI, bbase, wave, acc);
+            if (Cfg::DB) {
+                if (more) st.store(lds + ((chunk + 1) & 1) * TILE, tid, pre);
+                __syncthreads();
+            } else {
+                __syncthreads();
+                if (more) st.store(lds, tid, pre);
+                __syncthreads();
             }
         }
-        __syncthreads();
-        // ---- k^3 taps x KP k-steps on the staged tile
-        const float *wc = wp + (int64_t)chunk * TAPS * KP * 64 * MI;
-#pragma unroll UNR
-        for (int kd = 0; kd < KS; ++kd) {
-#pragma unroll UNR
-            for (int kh = 0; kh < KS; ++kh) {
-                const float *wrow = wc + (int64_t)((kd * KS + kh) * KS) * KP * 64 * MI;
-                const int tap_base = bbase + (kd * DIL * IN_H + kh * DIL) * IN_W;
-#pragma unroll
-                for (int kw = 0; kw < KS; ++kw) {
-#pragma unroll
-                    for (int kp = 0; kp < KP; ++kp) {
-                        float af[MI];
-#pragma unroll
-                        for (int m = 0; m < MI; ++m) af[m] = wrow[(kw * KP + kp) * 64 * MI + m];
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const int row = wave * NB + nb;
-                            const int dd = row / TH, hh = row % TH;
-                            const float bf = lds[tap_base + kp * 2 * CH + (dd * S * IN_H + hh * S) * IN_W + kw * DIL];
-#pragma unroll
-                            for (int m = 0; m < MI; ++m)
-                                acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf, acc[nb][m], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+    } else {
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            __syncthreads();
+            St::stage_scalar(xn + (int64_t)chunk * KC * in_dhw, lds, tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw,
+                             in_dhw, a.Cin - chunk * KC);
+            __syncthreads();
+            conv_compute_chunk<Cfg>(lds, wp + (int64_t)chunk * TAPS * KP * 64 * MI, bbase, wave, acc);
         }
     }
 
-    // ---- epilogue: acc[nb][m][r] = Y[cout = cg*32*MI + m*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)]
-    //                                 [voxel = (od0+dd, oh0+hh, ow0 + (lane&31))]
+    // ---- epilogue
     const int ow = ow0 + (lane & 31);
     const int64_t out_hw = (int64_t)a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
     float *yn = a.y + n * a.y_bs;
     const float *rn = a.res ? a.res + n * a.r_bs : nullptr;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int row = wave * NB + nb;
-        const int od = od0 + row / TH, oh = oh0 + row % TH;
-        const bool vox_ok = od < a.Dout && oh < a.Hout && ow < a.Wout;
-        const int64_t sp = od * out_hw + (int64_t)oh * a.Wout + ow;
+    for (int m = 0; m < MI; ++m) {
+        const int cbase = cg * 32 * MI + m * 32;
+        ChanAffine f;
+        load_affine(a, cbase, lane, f);
 #pragma unroll
-        for (int m = 0; m < MI; ++m) {
+        for (int nb = 0; nb < NB; ++nb) {
+            const int row = wave * NB + nb;
+            const int od = od0 + row / TH, oh = oh0 + row % TH;
+            const bool vox_ok = od < a.Dout && oh < a.Hout && ow < a.Wout;
+            const int64_t sp = vox_ok ? od * out_hw + (int64_t)oh * a.Wout + ow : 0;
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = cg * 32 * MI + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (vox_ok && co < a.Cout) {
-                    float v = acc[nb][m][r];
-                    if (a.scale) v = v * a.scale[co] + a.bias[co];
-                    const float rv = rn ? rn[co * out_dhw + sp] : 0.0f;
-                    yn[co * out_dhw + sp] = epilogue_f(v, rv, a.flags);
-                }
+                int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                co = co < a.Cout ? co : a.Cout - 1;
+                rv[r] = rn ? rn[co * out_dhw + sp] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v = epilogue_f(acc[nb][m][r] * f.sc[r] + f.bi[r], rv[r], a.flags);
+                if (vox_ok && co < a.Cout) yn[co * out_dhw + sp] = v;
             }
         }
     }
@@ -202,26 +335,63 @@ conv3d_mfma_kernel(const ConvArgs a) {
 template <int MI_, int TD_, int TH_, int KC_>
 struct DeconvCfg {
     static constexpr int MI = MI_, TD = TD_, TH = TH_, KC = KC_;
-    static constexpr int IN_D = TD + 1, IN_H = TH + 1, IN_W = 33;
-    static constexpr int CH = IN_D * IN_H * IN_W;
-    static constexpr int TILE = KC * CH;
+    static constexpr int IN_D = TD + 1, IN_H = TH + 1, IN_WV = 36;   // 33 needed columns -> 9 float4 pieces
+    using St = Stager<KC, IN_D, IN_H, IN_WV>;
+    static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int NB = TD * TH / 4;
     static constexpr int KP = KC / 2;
-    static constexpr int LDS_BYTES = TILE * 4;
+    static constexpr int LDS_BYTES = TILE * 4 * 2;                   // double buffered
     static_assert(TD * TH % 4 == 0, "rows must split over 4 waves");
 };
 
-__host__ __device__ constexpr int deconv_class_ntaps(int pd, int ph) { return (pd ? 2 : 1) * (ph ? 2 : 1) * 3; }
 __host__ __device__ constexpr int deconv_class_offset(int cls) {  // cls = pd*2 + ph
     return cls == 0 ? 0 : cls == 1 ? 3 : cls == 2 ? 9 : 15;
 }
 
 template <class Cfg, int PD, int PH>
+__device__ __forceinline__ void deconv_compute_chunk(const float *__restrict__ buf, const float *__restrict__ wc,
+                                                     int bbase, int wave, f32x16 (&acc)[2][Cfg::NB][Cfg::MI]) {
+    constexpr int MI = Cfg::MI, TH = Cfg::TH, KP = Cfg::KP, NB = Cfg::NB, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV;
+    constexpr int CH = Cfg::CH, ND = PD ? 2 : 1, NH = PH ? 2 : 1;
+    int tix = 0;  // running tap index inside this class (matches the packing order)
+#pragma unroll
+    for (int jd = 0; jd < ND; ++jd) {
+        const int dld = (PD && jd == 1) ? 1 : 0;  // input offset (+1 for tap 0)
+#pragma unroll
+        for (int jh = 0; jh < NH; ++jh) {
+            const int dlh = (PH && jh == 1) ? 1 : 0;
+#pragma unroll
+            for (int jw = 0; jw < 3; ++jw, ++tix) {
+                // jw = 0: width parity 0 (tap 1, offset 0); 1: parity 1 (tap 2, offset 0);
+                // 2: parity 1 (tap 0, offset +1)
+                const int pw = jw == 0 ? 0 : 1;
+                const int dlw = jw == 2 ? 1 : 0;
+#pragma unroll
+                for (int kp = 0; kp < KP; ++kp) {
+                    float af[MI];
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) af[m] = wc[(tix * KP + kp) * 64 * MI + m];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const int row = wave * NB + nb;
+                        const int dd = row / TH, hh = row % TH;
+                        const float bf = buf[bbase + kp * 2 * CH + ((dd + dld) * IN_H + hh + dlh) * IN_WV + dlw];
+#pragma unroll
+                        for (int m = 0; m < MI; ++m)
+                            acc[pw][nb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf, acc[pw][nb][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <class Cfg, int PD, int PH>
 __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds, int tile, int cg, int64_t n) {
     constexpr int MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, KP = Cfg::KP, NB = Cfg::NB;
-    constexpr int IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, CH = Cfg::CH, TILE = Cfg::TILE;
-    constexpr int ND = PD ? 2 : 1, NH = PH ? 2 : 1;
+    constexpr int CH = Cfg::CH, TILE = Cfg::TILE;
     constexpr int CLS_OFF = deconv_class_offset(PD * 2 + PH);
+    using St = typename Cfg::St;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % a.tiles_h, td = tile / (a.tiles_w * a.tiles_h);
     const int id0 = td * TD, ih0 = th * TH, iw0 = tw * 32;
@@ -236,61 +406,33 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[p][nb][m][r] = 0.0f;
 
-    const int64_t in_hw = (int64_t)a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     const float *xn = a.x + n * a.x_bs;
-    const float *wp = a.wp + (int64_t)cg * a.nchunks * 27 * KP * 64 * MI + lane * MI;
+    const float *wp = a.wp + ((int64_t)cg * a.nchunks * 27 + CLS_OFF) * KP * 64 * MI + lane * MI;
     const int bbase = (lane >> 5) * CH + (lane & 31);
 
-    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    if (a.vec) {
+        St st;
+        st.init(tid, id0, ih0, iw0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+        float4 pre[St::NIT];
+        st.load(xn, tid, a.Cin, pre);
+        st.store(lds, tid, pre);
         __syncthreads();
-        const int c0 = chunk * KC;
-        constexpr int ITER = (TILE + 255) / 256;
-#pragma unroll 8
-        for (int it = 0; it < ITER; ++it) {
-            const int e = it * 256 + tid;
-            if (e < TILE) {
-                const int kc = e / CH, rem = e - kc * CH;
-                const int dd = rem / (IN_H * IN_W), rem2 = rem - dd * (IN_H * IN_W);
-                const int hh = rem2 / IN_W, ww = rem2 - hh * IN_W;
-                const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww, gc = c0 + kc;
-                float v = 0.0f;
-                if (gc < a.Cin && gd < a.Din && gh < a.Hin && gw < a.Win)
-                    v = xn[gc * in_dhw + gd * in_hw + (int64_t)gh * a.Win + gw];
-                lds[e] = v;
-            }
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            const bool more = chunk + 1 < a.nchunks;
+            if (more) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
+            deconv_compute_chunk<Cfg, PD, PH>(lds + (chunk & 1) * TILE, wp + (int64_t)chunk * 27 * KP * 64 * MI, bbase,
+                                              wave, acc);
+            if (more) st.store(lds + ((chunk + 1) & 1) * TILE, tid, pre);
+            __syncthreads();
         }
-        __syncthreads();
-        const float *wc = wp + ((int64_t)chunk * 27 + CLS_OFF) * KP * 64 * MI;
-        int tix = 0;  // running tap index inside this class (matches the packing order)
-#pragma unroll
-        for (int jd = 0; jd < ND; ++jd) {
-            const int dld = (PD && jd == 1) ? 1 : 0;  // input offset (+1 for tap 0)
-#pragma unroll
-            for (int jh = 0; jh < NH; ++jh) {
-                const int dlh = (PH && jh == 1) ? 1 : 0;
-#pragma unroll
-                for (int jw = 0; jw < 3; ++jw, ++tix) {
-                    // jw = 0: width parity 0 (tap 1, offset 0); 1: parity 1 (tap 2, offset 0);
-                    // 2: parity 1 (tap 0, offset +1)
-                    const int pw = jw == 0 ? 0 : 1;
-                    const int dlw = jw == 2 ? 1 : 0;
-#pragma unroll
-                    for (int kp = 0; kp < KP; ++kp) {
-                        float af[MI];
-#pragma unroll
-                        for (int m = 0; m < MI; ++m) af[m] = wc[(tix * KP + kp) * 64 * MI + m];
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) {
-                            const int row = wave * NB + nb;
-                            const int dd = row / TH, hh = row % TH;
-                            const float bf = lds[bbase + kp * 2 * CH + ((dd + dld) * IN_H + hh + dlh) * IN_W + dlw];
-#pragma unroll
-                            for (int m = 0; m < MI; ++m)
-                                acc[pw][nb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf, acc[pw][nb][m], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+    } else {
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            __syncthreads();
+            St::stage_scalar(xn + (int64_t)chunk * KC * in_dhw, lds, tid, id0, ih0, iw0, a.Din, a.Hin, a.Win, in_hw,
+                             in_dhw, a.Cin - chunk * KC);
+            __syncthreads();
+            deconv_compute_chunk<Cfg, PD, PH>(lds, wp + (int64_t)chunk * 27 * KP * 64 * MI, bbase, wave, acc);
         }
     }
 
@@ -300,31 +442,29 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
     float *yn = a.y + n * a.y_bs;
     const float *rn = a.res ? a.res + n * a.r_bs : nullptr;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int row = wave * NB + nb;
-        const int id = id0 + row / TH, ih = ih0 + row % TH;
-        const bool vox_ok = id < a.Din && ih < a.Hin && iw < a.Win;
-        const int64_t sp = (int64_t)(2 * id + PD) * out_hw + (int64_t)(2 * ih + PH) * a.Wout + 2 * iw;
+    for (int m = 0; m < MI; ++m) {
+        const int cbase = cg * 32 * MI + m * 32;
+        ChanAffine f;
+        load_affine(a, cbase, lane, f);
 #pragma unroll
-        for (int m = 0; m < MI; ++m) {
+        for (int nb = 0; nb < NB; ++nb) {
+            const int row = wave * NB + nb;
+            const int id = id0 + row / TH, ih = ih0 + row % TH;
+            const bool vox_ok = id < a.Din && ih < a.Hin && iw < a.Win;
+            const int64_t sp = vox_ok ? (int64_t)(2 * id + PD) * out_hw + (int64_t)(2 * ih + PH) * a.Wout + 2 * iw : 0;
+            float2 rv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = cg * 32 * MI + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (vox_ok && co < a.Cout) {
-                    float v0 = acc[0][nb][m][r], v1 = acc[1][nb][m][r];
-                    if (a.scale) {
-                        const float sc = a.scale[co], bi = a.bias[co];
-                        v0 = v0 * sc + bi;
-                        v1 = v1 * sc + bi;
-                    }
-                    float r0 = 0.0f, r1 = 0.0f;
-                    if (rn) {
-                        const float2 rr = *reinterpret_cast<const float2 *>(rn + co * out_dhw + sp);
-                        r0 = rr.x; r1 = rr.y;
-                    }
-                    *reinterpret_cast<float2 *>(yn + co * out_dhw + sp) =
-                        make_float2(epilogue_f(v0, r0, a.flags), epilogue_f(v1, r1, a.flags));
-                }
+                int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                co = co < a.Cout ? co : a.Cout - 1;
+                rv[r] = rn ? *reinterpret_cast<const float2 *>(rn + co * out_dhw + sp) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float v0 = epilogue_f(acc[0][nb][m][r] * f.sc[r] + f.bi[r], rv[r].x, a.flags);
+                const float v1 = epilogue_f(acc[1][nb][m][r] * f.sc[r] + f.bi[r], rv[r].y, a.flags);
+                if (vox_ok && co < a.Cout) *reinterpret_cast<float2 *>(yn + co * out_dhw + sp) = make_float2(v0, v1);
             }
         }
     }
@@ -420,19 +560,19 @@ enum Kind {
     KIND_NONE
 };
 
-//                       KS S  D  MI TD TH KC
-using CfgK1M1   = ConvCfg<1, 1, 1, 1, 4, 8, 8>;
-using CfgK1M2   = ConvCfg<1, 1, 1, 2, 4, 4, 8>;
-using CfgK3M1   = ConvCfg<3, 1, 1, 1, 4, 8, 4>;
-using CfgK3M2   = ConvCfg<3, 1, 1, 2, 4, 4, 4>;
-using CfgK3S2M1 = ConvCfg<3, 2, 1, 1, 2, 4, 4>;
-using CfgK3S2M2 = ConvCfg<3, 2, 1, 2, 2, 4, 4>;
-using CfgK5M1   = ConvCfg<5, 1, 1, 1, 4, 8, 4>;
-using CfgK5M2   = ConvCfg<5, 1, 1, 2, 4, 4, 4>;
-using CfgK5D2M1 = ConvCfg<5, 1, 2, 1, 4, 8, 2>;
-using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2>;
-using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 8, 2>;
-using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2>;
+//                       KS S  D  MI TD TH KC  DB      LDS image (x2 when double buffered)
+using CfgK1M1   = ConvCfg<1, 1, 1, 1, 4, 8, 8, true>;   // 32 KB
+using CfgK1M2   = ConvCfg<1, 1, 1, 2, 4, 4, 8, true>;   // 16 KB
+using CfgK3M1   = ConvCfg<3, 1, 1, 1, 4, 8, 4, true>;   // 37.5 KB
+using CfgK3M2   = ConvCfg<3, 1, 1, 2, 4, 4, 4, true>;   // 22.5 KB
+using CfgK3S2M1 = ConvCfg<3, 2, 1, 1, 2, 4, 4, false>;  // 47.8 KB
+using CfgK3S2M2 = ConvCfg<3, 2, 1, 2, 2, 4, 4, false>;  // 47.8 KB
+using CfgK5M1   = ConvCfg<5, 1, 1, 1, 4, 8, 2, true>;   // 30 KB
+using CfgK5M2   = ConvCfg<5, 1, 1, 2, 4, 4, 2, true>;   // 20 KB
+using CfgK5D2M1 = ConvCfg<5, 1, 2, 1, 4, 8, 2, false>;  // 60 KB
+using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2, false>;  // 45 KB
+using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 8, 2, false>;  // 43.8 KB
+using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false>;  // 31.3 KB
 using CfgDCM1   = DeconvCfg<1, 2, 4, 8>;
 using CfgDCM2   = DeconvCfg<2, 2, 4, 8>;
 
@@ -491,6 +631,7 @@ void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
 
 template <class Cfg>
 void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    static_assert(Cfg::LDS_BYTES <= 48 * 1024, "deconv image must fit the default dynamic LDS limit");
     deconv3d_mfma_kernel<Cfg><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 
@@ -545,8 +686,8 @@ int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *
     if (d->transposed && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 7))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: transposed y / residual must be 8-byte aligned");
     const int64_t in_sz = (int64_t)d->Cin * d->Din * d->Hin * d->Win, out_sz = (int64_t)d->Cout * d->Dout * d->Hout * d->Wout;
-    if ((int64_t)d->Cin * d->Din * d->Hin * d->Win >= ((int64_t)1 << 40))
-        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: sample too large");
+    if (in_sz + (int64_t)8 * d->Din * d->Hin * d->Win >= ((int64_t)1 << 31))  // 32-bit in-sample offsets
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: one sample must stay below 2^31 elements");
 
     ConvArgs a;
     a.x = x; a.wp = packed_weight; a.scale = scale; a.bias = bias;
@@ -559,6 +700,7 @@ int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *
     a.x_bs = d->x_batch_stride ? d->x_batch_stride : in_sz;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : out_sz;
+    a.vec = (d->Win % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (a.x_bs % 4 == 0);
 
     const int64_t ntiles = (int64_t)p.tiles_d * p.tiles_h * p.tiles_w;
     const int64_t gx = d->transposed ? ntiles * 4 : ntiles;

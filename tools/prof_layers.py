@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Runs ONE layer of the cfg2 step a few times so that a rocprofv3 pass stays small.
+
+    rocprofv3 --pmc ... -- python tools/prof_layers.py conv1 --reps 3
+Layers: cost_volume, conv1 (k3 64->32), conv2 (k3 32->32), hg (hourglass), classifier, gather, trunk.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("layer")
+ap.add_argument("--reps", type=int, default=3)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+
+from snvc_amd.extension.build_cost_volume import build_cost_volume  # noqa: E402
+from snvc_amd.models.stereo_volume import GlobalStack  # noqa: E402
+
+model = GlobalStack(bench.C)
+model.load_state_dict(bench.seeded_state(model))
+model.eval().to(dev)
+left, right, shift = bench.make_inputs(0, dev)
+with torch.no_grad():
+    if args.layer == "cost_volume":
+        fn = lambda: build_cost_volume(left, right, shift, 1)  # noqa: E731
+    else:
+        vol = build_cost_volume(left, right, shift, 1)
+        if args.layer == "conv1":
+            fn = lambda: model.conv1(vol)  # noqa: E731
+        else:
+            v1 = model.conv1(vol)
+            del vol
+            if args.layer == "conv2":
+                fn = lambda: model.conv2(v1)  # noqa: E731
+            else:
+                v2 = model.conv2(v1)
+                if args.layer == "hg":
+                    fn = lambda: model.hg_conv3d(v2, None, None, residual=v2)  # noqa: E731
+                elif args.layer == "classifier":
+                    fn = lambda: model.classifier(v2)  # noqa: E731
+                else:
+                    raise SystemExit("unknown layer")
+    for _ in range(args.reps):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(args.reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    print(f"{args.layer}: {a.elapsed_time(b) / args.reps:.3f} ms")
