@@ -30,6 +30,8 @@
 //     contiguous run of tiles so that halo re-reads hit that XCD's L2.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace snvc {
 namespace {
 
@@ -158,6 +160,33 @@ struct Stager {
     }
 };
 
+// Packed weights of one chunk are a contiguous run of WF floats in exactly the order the
+// fragments are consumed, so staging them is a linear float4 copy global -> registers -> LDS,
+// prefetched together with the input image.  Keeping the A fragments in LDS (and not in
+// per-wave global loads) leaves the vector-memory queue to the prefetch alone: the MFMA loop
+// only ever waits on LDS reads (lgkmcnt), and the one vmcnt wait sits at the END of a chunk.
+template <int WF_>
+struct WeightStager {
+    static constexpr int WF = WF_;
+    static constexpr int ITEMS = WF / 4;
+    static constexpr int NIT = (ITEMS + 255) / 256;
+    static_assert(WF % 4 == 0, "weight chunk is whole float4 pieces");
+    static __device__ __forceinline__ void load(const float *__restrict__ wc, int tid, float4 (&v)[NIT]) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            v[it] = reinterpret_cast<const float4 *>(wc)[(ITEMS % 256 == 0 || i < ITEMS) ? i : 0];
+        }
+    }
+    static __device__ __forceinline__ void store(float *__restrict__ wbuf, int tid, const float4 (&v)[NIT]) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<float4 *>(wbuf)[i] = v[it];
+        }
+    }
+};
+
 // Epilogue shared by conv and deconv: acc register r of lane l is output channel
 // cbase + (r&3) + 8*(r>>2) + 4*(l>>5); scale / bias for the lane's 16 channels are fetched
 // together, residual values are fetched as one batch per accumulator (clamped addresses, no
@@ -177,8 +206,15 @@ __device__ __forceinline__ void load_affine(const ConvArgs &a, int cbase, int la
 }
 
 // ------------------------------------------------------------------------------------ conv
-template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_, bool DB_>
+template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_, bool DB_, int OCC_ = 2, int KDG_ = 0>
 struct ConvCfg {
+    // A chunk (KC input channels) is consumed in NPH phases of KDG kernel depth-slices each; the
+    // weights of ONE phase are resident in LDS at a time (double buffered), the input image of the
+    // whole chunk stays resident across its phases.
+    static constexpr int KDG = KDG_ == 0 ? KS_ : KDG_;
+    static constexpr int NPH = KS_ / KDG;
+    static_assert(KS_ % KDG == 0, "phases must tile the kernel depth");
+    static constexpr int OCC = OCC_;                // minimum waves per SIMD requested from the register allocator
     static constexpr int KS = KS_, STRIDE = STRIDE_, DIL = DIL_, MI = MI_, TD = TD_, TH = TH_, KC = KC_;
     static constexpr bool DB = DB_;                 // double-buffered LDS image (one barrier per chunk)
     static constexpr int TW = 32;
@@ -194,22 +230,27 @@ struct ConvCfg {
     static constexpr int NB = TD * TH / 4;          // 32-voxel rows per wave (4 waves)
     static constexpr int KP = KC / 2;               // MFMA k-steps per chunk
     static constexpr int TAPS = KS * KS * KS;
-    static constexpr int LDS_BYTES = TILE * 4 * (DB ? 2 : 1);
+    static constexpr int WF = KDG * KS * KS * KP * 64 * MI;   // packed weight floats per phase
+    using Ws = WeightStager<WF>;
+    static constexpr int IMG_BUFS = DB ? 2 : 1;
+    static constexpr int LDS_BYTES = (TILE * IMG_BUFS + WF * 2) * 4;   // images, then two weight buffers
     static_assert(TD * TH % 4 == 0, "rows must split over 4 waves");
     static_assert(KC % 2 == 0, "KC must be even (MFMA K = 2)");
 };
 
 template <class Cfg>
-__device__ __forceinline__ void conv_compute_chunk(const float *__restrict__ buf, const float *__restrict__ wc,
+__device__ __forceinline__ void conv_compute_phase(const float *__restrict__ img, const float *__restrict__ wl,
                                                    int bbase, int wave, f32x16 (&acc)[Cfg::NB][Cfg::MI]) {
+    // img: staged input image, already advanced to this phase's first depth slice;
+    // wl : staged weights of this phase + lane*MI.  Both in LDS.
     constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, MI = Cfg::MI, TH = Cfg::TH, KP = Cfg::KP;
-    constexpr int NB = Cfg::NB, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, CH = Cfg::CH;
-    constexpr int UNR = KS <= 3 ? KS : 1;  // small kernels: fully unrolled taps; k5/k7: kd,kh loops stay rolled
-#pragma unroll UNR
-    for (int kd = 0; kd < KS; ++kd) {
+    constexpr int NB = Cfg::NB, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, CH = Cfg::CH, KDG = Cfg::KDG;
+    constexpr int UNR = KS <= 3 ? KS : 1;  // k3: fully unrolled taps; k5/k7: the kh loop stays rolled
+#pragma unroll
+    for (int kd = 0; kd < KDG; ++kd) {
 #pragma unroll UNR
         for (int kh = 0; kh < KS; ++kh) {
-            const float *wrow = wc + (int64_t)((kd * KS + kh) * KS) * KP * 64 * MI;
+            const float *wrow = wl + ((kd * KS + kh) * KS) * KP * 64 * MI;
             const int tap_base = bbase + (kd * DIL * IN_H + kh * DIL) * IN_WV;
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
@@ -222,7 +263,7 @@ __device__ __forceinline__ void conv_compute_chunk(const float *__restrict__ buf
                     for (int nb = 0; nb < NB; ++nb) {
                         const int row = wave * NB + nb;
                         const int dd = row / TH, hh = row % TH;
-                        const float bf = buf[tap_base + kp * 2 * CH + (dd * S * IN_H + hh * S) * IN_WV + kw * DIL];
+                        const float bf = img[tap_base + kp * 2 * CH + (dd * S * IN_H + hh * S) * IN_WV + kw * DIL];
 #pragma unroll
                         for (int m = 0; m < MI; ++m)
                             acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf, acc[nb][m], 0, 0, 0);
@@ -234,10 +275,10 @@ __device__ __forceinline__ void conv_compute_chunk(const float *__restrict__ buf
 }
 
 template <class Cfg>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_mfma_kernel(const ConvArgs a) {
-    constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, KP = Cfg::KP, NB = Cfg::NB;
-    constexpr int CH = Cfg::CH, TILE = Cfg::TILE, TAPS = Cfg::TAPS, PAD = Cfg::PAD, LPAD = Cfg::LPAD, XOFF = Cfg::XOFF;
+    constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB;
+    constexpr int CH = Cfg::CH, TILE = Cfg::TILE, PAD = Cfg::PAD, LPAD = Cfg::LPAD, XOFF = Cfg::XOFF;
     using St = typename Cfg::St;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -260,38 +301,59 @@ conv3d_mfma_kernel(const ConvArgs a) {
 
     const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     const float *xn = a.x + n * a.x_bs;
-    const float *wp = a.wp + (int64_t)cg * a.nchunks * TAPS * KP * 64 * MI + lane * MI;
     // B-fragment base: lane&31 = voxel column, lane>>5 = k within the k-pair
     const int bbase = (lane >> 5) * CH + (lane & 31) * S + XOFF;
 
+    constexpr int WF = Cfg::WF, NPH = Cfg::NPH, KDG = Cfg::KDG, DIL = Cfg::DIL;
+    constexpr int SLICE = KDG * DIL * Cfg::IN_H * Cfg::IN_WV;   // image floats per phase step (depth advance)
+    using Ws = typename Cfg::Ws;
+    float *const wlds = lds + TILE * Cfg::IMG_BUFS;          // two weight buffers behind the image(s)
+    // packed weights of this channel group: [chunk][phase] blocks of WF floats
+    const float *wg = a.wp + (int64_t)cg * a.nchunks * NPH * WF;
+    const int nphase = a.nchunks * NPH;
     if (a.vec) {
         St st;
         st.init(tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
-        float4 pre[St::NIT];
+        float4 pre[St::NIT], wpre[Ws::NIT];
         st.load(xn, tid, a.Cin, pre);
+        Ws::load(wg, tid, wpre);
         st.store(lds, tid, pre);
+        Ws::store(wlds, tid, wpre);
         __syncthreads();
-        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-            const bool more = chunk + 1 < a.nchunks;
-            float *cur = lds + (Cfg::DB ? (chunk & 1) * TILE : 0);
-            if (more) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
-            conv_compute_chunk<Cfg>(cur, wp + (int64_t)chunk * TAPS * KP * 64 * MI, bbase, wave, acc);
+        int chunk = 0, ph = 0;
+        for (int p = 0; p < nphase; ++p) {
+            const bool more = p + 1 < nphase;
+            const bool last_of_chunk = ph == NPH - 1;
+            const bool new_img = more && last_of_chunk;       // the next phase starts a new chunk
+            if (more) Ws::load(wg + (int64_t)(p + 1) * WF, tid, wpre);
+            if (new_img) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
+            const float *img = lds + (Cfg::DB ? (chunk & 1) * TILE : 0) + ph * SLICE;
+            conv_compute_phase<Cfg>(img, wlds + (p & 1) * WF + lane * MI, bbase, wave, acc);
+            if (more) Ws::store(wlds + ((p + 1) & 1) * WF, tid, wpre);
             if (Cfg::DB) {
-                if (more) st.store(lds + ((chunk + 1) & 1) * TILE, tid, pre);
+                if (new_img) st.store(lds + ((chunk + 1) & 1) * TILE, tid, pre);
                 __syncthreads();
             } else {
                 __syncthreads();
-                if (more) st.store(lds, tid, pre);
-                __syncthreads();
+                if (new_img) {            // uniform: the single image may only be overwritten once all
+                    st.store(lds, tid, pre);   // waves have finished reading it
+                    __syncthreads();
+                }
             }
+            if (last_of_chunk) { ph = 0; ++chunk; } else { ++ph; }
         }
     } else {
-        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        for (int p = 0; p < nphase; ++p) {
+            const int chunk = p / NPH, ph = p - chunk * NPH;
             __syncthreads();
-            St::stage_scalar(xn + (int64_t)chunk * KC * in_dhw, lds, tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw,
-                             in_dhw, a.Cin - chunk * KC);
+            if (ph == 0)
+                St::stage_scalar(xn + (int64_t)chunk * KC * in_dhw, lds, tid, id0, ih0, ix0, a.Din, a.Hin, a.Win,
+                                 in_hw, in_dhw, a.Cin - chunk * KC);
+            float4 wpre[Ws::NIT];
+            Ws::load(wg + (int64_t)p * WF, tid, wpre);
+            Ws::store(wlds, tid, wpre);
             __syncthreads();
-            conv_compute_chunk<Cfg>(lds, wp + (int64_t)chunk * TAPS * KP * 64 * MI, bbase, wave, acc);
+            conv_compute_phase<Cfg>(lds + ph * SLICE, wlds + lane * MI, bbase, wave, acc);
         }
     }
 
@@ -340,13 +402,16 @@ struct DeconvCfg {
     static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int NB = TD * TH / 4;
     static constexpr int KP = KC / 2;
-    static constexpr int LDS_BYTES = TILE * 4 * 2;                   // double buffered
+    static constexpr int WF_MAX = 12 * KP * 64 * MI;                 // heaviest parity class: 12 taps
+    static constexpr int BUF = TILE + WF_MAX;
+    static constexpr int LDS_BYTES = BUF * 4 * 2;                    // double buffered
     static_assert(TD * TH % 4 == 0, "rows must split over 4 waves");
 };
 
 __host__ __device__ constexpr int deconv_class_offset(int cls) {  // cls = pd*2 + ph
     return cls == 0 ? 0 : cls == 1 ? 3 : cls == 2 ? 9 : 15;
 }
+__host__ __device__ constexpr int deconv_class_ntaps(int cls) { return cls == 0 ? 3 : cls == 3 ? 12 : 6; }
 
 template <class Cfg, int PD, int PH>
 __device__ __forceinline__ void deconv_compute_chunk(const float *__restrict__ buf, const float *__restrict__ wc,
@@ -408,22 +473,35 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
 
     const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     const float *xn = a.x + n * a.x_bs;
-    const float *wp = a.wp + ((int64_t)cg * a.nchunks * 27 + CLS_OFF) * KP * 64 * MI + lane * MI;
+    constexpr int WF = deconv_class_ntaps(PD * 2 + PH) * KP * 64 * MI;   // this class's weight floats per chunk
+    constexpr int WSTRIDE = 27 * KP * 64 * MI;                            // all classes, per chunk
+    constexpr int BUF = Cfg::BUF;
+    using Ws = WeightStager<WF>;
+    const float *wg = a.wp + ((int64_t)cg * a.nchunks * 27 + CLS_OFF) * KP * 64 * MI;
     const int bbase = (lane >> 5) * CH + (lane & 31);
 
     if (a.vec) {
         St st;
         st.init(tid, id0, ih0, iw0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
-        float4 pre[St::NIT];
+        float4 pre[St::NIT], wpre[Ws::NIT];
         st.load(xn, tid, a.Cin, pre);
+        Ws::load(wg, tid, wpre);
         st.store(lds, tid, pre);
+        Ws::store(lds + TILE, tid, wpre);
         __syncthreads();
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             const bool more = chunk + 1 < a.nchunks;
-            if (more) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
-            deconv_compute_chunk<Cfg, PD, PH>(lds + (chunk & 1) * TILE, wp + (int64_t)chunk * 27 * KP * 64 * MI, bbase,
-                                              wave, acc);
-            if (more) st.store(lds + ((chunk + 1) & 1) * TILE, tid, pre);
+            const float *cur = lds + (chunk & 1) * BUF;
+            if (more) {
+                st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
+                Ws::load(wg + (int64_t)(chunk + 1) * WSTRIDE, tid, wpre);
+            }
+            deconv_compute_chunk<Cfg, PD, PH>(cur, cur + TILE + lane * MI, bbase, wave, acc);
+            if (more) {
+                float *nxt = lds + ((chunk + 1) & 1) * BUF;
+                st.store(nxt, tid, pre);
+                Ws::store(nxt + TILE, tid, wpre);
+            }
             __syncthreads();
         }
     } else {
@@ -431,8 +509,11 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
             __syncthreads();
             St::stage_scalar(xn + (int64_t)chunk * KC * in_dhw, lds, tid, id0, ih0, iw0, a.Din, a.Hin, a.Win, in_hw,
                              in_dhw, a.Cin - chunk * KC);
+            float4 wpre[Ws::NIT];
+            Ws::load(wg + (int64_t)chunk * WSTRIDE, tid, wpre);
+            Ws::store(lds + TILE, tid, wpre);
             __syncthreads();
-            deconv_compute_chunk<Cfg, PD, PH>(lds, wp + (int64_t)chunk * 27 * KP * 64 * MI, bbase, wave, acc);
+            deconv_compute_chunk<Cfg, PD, PH>(lds, lds + TILE + lane * MI, bbase, wave, acc);
         }
     }
 
@@ -551,7 +632,7 @@ struct Plan {
 
 enum Kind {
     K1_M1, K1_M2,
-    K3_M1, K3_M2,
+    K3_M1, K3_M2, K3_M1v0, K3_M1v2, K3_M1v3, K3_M1v4,
     K3S2_M1, K3S2_M2,
     K5_M1, K5_M2,
     K5D2_M1, K5D2_M2,
@@ -560,21 +641,25 @@ enum Kind {
     KIND_NONE
 };
 
-//                       KS S  D  MI TD TH KC  DB      LDS image (x2 when double buffered)
-using CfgK1M1   = ConvCfg<1, 1, 1, 1, 4, 8, 8, true>;   // 32 KB
-using CfgK1M2   = ConvCfg<1, 1, 1, 2, 4, 4, 8, true>;   // 16 KB
-using CfgK3M1   = ConvCfg<3, 1, 1, 1, 4, 8, 4, true>;   // 37.5 KB
-using CfgK3M2   = ConvCfg<3, 1, 1, 2, 4, 4, 4, true>;   // 22.5 KB
-using CfgK3S2M1 = ConvCfg<3, 2, 1, 1, 2, 4, 4, false>;  // 47.8 KB
-using CfgK3S2M2 = ConvCfg<3, 2, 1, 2, 2, 4, 4, false>;  // 47.8 KB
-using CfgK5M1   = ConvCfg<5, 1, 1, 1, 4, 8, 2, true>;   // 30 KB
-using CfgK5M2   = ConvCfg<5, 1, 1, 2, 4, 4, 2, true>;   // 20 KB
-using CfgK5D2M1 = ConvCfg<5, 1, 2, 1, 4, 8, 2, false>;  // 60 KB
-using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2, false>;  // 45 KB
-using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 8, 2, false>;  // 43.8 KB
-using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false>;  // 31.3 KB
-using CfgDCM1   = DeconvCfg<1, 2, 4, 8>;
-using CfgDCM2   = DeconvCfg<2, 2, 4, 8>;
+//                       KS S  D  MI TD TH KC  DB   OCC KDG
+using CfgK1M1   = ConvCfg<1, 1, 1, 1, 4, 4, 8, true>;
+using CfgK1M2   = ConvCfg<1, 1, 1, 2, 4, 4, 8, true>;
+using CfgK3M1   = ConvCfg<3, 1, 1, 1, 4, 4, 4, true>;
+using CfgK3M1v0 = ConvCfg<3, 1, 1, 1, 4, 8, 4, true>;
+using CfgK3M1v2 = ConvCfg<3, 1, 1, 1, 4, 4, 4, true, 3>;
+using CfgK3M1v3 = ConvCfg<3, 1, 1, 1, 4, 4, 4, true, 2, 1>;
+using CfgK3M1v4 = ConvCfg<3, 1, 1, 1, 4, 4, 4, true, 3, 1>;
+using CfgK3M2   = ConvCfg<3, 1, 1, 2, 4, 4, 4, true>;
+using CfgK3S2M1 = ConvCfg<3, 2, 1, 1, 2, 4, 2, false>;
+using CfgK3S2M2 = ConvCfg<3, 2, 1, 2, 2, 4, 2, false>;
+using CfgK5M1   = ConvCfg<5, 1, 1, 1, 4, 4, 2, true, 2, 1>;
+using CfgK5M2   = ConvCfg<5, 1, 1, 2, 4, 4, 2, true, 2, 1>;
+using CfgK5D2M1 = ConvCfg<5, 1, 2, 1, 4, 4, 2, false, 2, 1>;
+using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2, false, 2, 1>;
+using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 4, 2, false, 2, 1>;
+using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false, 2, 1>;
+using CfgDCM1   = DeconvCfg<1, 2, 4, 4>;
+using CfgDCM2   = DeconvCfg<2, 2, 4, 4>;
 
 template <class Cfg>
 constexpr Plan plan_of(int kind) { return Plan{Cfg::MI, Cfg::KC, Cfg::TD, Cfg::TH, 0, 0, 0, 0, 0, kind}; }
@@ -601,7 +686,17 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
         const int key = d.ksize * 100 + d.stride * 10 + d.dilation;
         switch (key) {
             case 111: p = wide ? plan_of<CfgK1M2>(K1_M2) : plan_of<CfgK1M1>(K1_M1); break;
-            case 311: p = wide ? plan_of<CfgK3M2>(K3_M2) : plan_of<CfgK3M1>(K3_M1); break;
+            case 311: {
+                p = wide ? plan_of<CfgK3M2>(K3_M2) : plan_of<CfgK3M1>(K3_M1);
+                const char *v = getenv("SNVC_K3M1_VARIANT");  // development knob (tile / occupancy sweep)
+                if (!wide && v) {
+                    if (v[0] == '0') p = plan_of<CfgK3M1v0>(K3_M1v0);
+                    if (v[0] == '2') p = plan_of<CfgK3M1v2>(K3_M1v2);
+                    if (v[0] == '3') p = plan_of<CfgK3M1v3>(K3_M1v3);
+                    if (v[0] == '4') p = plan_of<CfgK3M1v4>(K3_M1v4);
+                }
+                break;
+            }
             case 321: p = wide ? plan_of<CfgK3S2M2>(K3S2_M2) : plan_of<CfgK3S2M1>(K3S2_M1); break;
             case 511: p = wide ? plan_of<CfgK5M2>(K5_M2) : plan_of<CfgK5M1>(K5_M1); break;
             case 512: p = wide ? plan_of<CfgK5D2M2>(K5D2_M2) : plan_of<CfgK5D2M1>(K5D2_M1); break;
@@ -631,7 +726,12 @@ void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
 
 template <class Cfg>
 void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    static_assert(Cfg::LDS_BYTES <= 48 * 1024, "deconv image must fit the default dynamic LDS limit");
+    static bool attr_done = false;
+    if (!attr_done && Cfg::LDS_BYTES > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&deconv3d_mfma_kernel<Cfg>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        attr_done = true;
+    }
     deconv3d_mfma_kernel<Cfg><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 
@@ -711,6 +811,10 @@ int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *
         case K1_M1: launch_conv<CfgK1M1>(a, grid, st); break;
         case K1_M2: launch_conv<CfgK1M2>(a, grid, st); break;
         case K3_M1: launch_conv<CfgK3M1>(a, grid, st); break;
+        case K3_M1v0: launch_conv<CfgK3M1v0>(a, grid, st); break;
+        case K3_M1v2: launch_conv<CfgK3M1v2>(a, grid, st); break;
+        case K3_M1v3: launch_conv<CfgK3M1v3>(a, grid, st); break;
+        case K3_M1v4: launch_conv<CfgK3M1v4>(a, grid, st); break;
         case K3_M2: launch_conv<CfgK3M2>(a, grid, st); break;
         case K3S2_M1: launch_conv<CfgK3S2M1>(a, grid, st); break;
         case K3S2_M2: launch_conv<CfgK3S2M2>(a, grid, st); break;
