@@ -36,6 +36,7 @@ namespace snvc {
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native 16-byte vector (keeps staging arrays in registers)
 
 struct ConvArgs {
     const float *x;
@@ -112,22 +113,27 @@ struct Stager {
         }
     }
 
-    // channels [c0, c0+KC) -> registers.  cin_left = Cin - c0 (items of channels >= Cin are zeros).
-    __device__ __forceinline__ void load(const float *__restrict__ xc, int tid, int cin_left, float4 (&v)[NIT]) const {
+    // channels [c0, c0+KC) -> registers.  Only ISSUES the loads (padding pieces read offset 0);
+    // nothing here consumes the data, so the wave does not wait for it.
+    __device__ __forceinline__ void load(const float *__restrict__ xc, f32x4 (&v)[NIT]) const {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const float4 t = *reinterpret_cast<const float4 *>(xc + off[it]);
-            bool ok = (vmask >> it) & 1u;
-            if (cin_left < KC) ok = ok && ((it * 256 + tid) / (RQ * IN_D * IN_H) < cin_left);
-            v[it] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const f32x4 *>(xc + off[it]);
     }
 
-    __device__ __forceinline__ void store(float *__restrict__ buf, int tid, const float4 (&v)[NIT]) const {
+    // registers -> LDS image; padding pieces and channels >= Cin (cin_left = Cin - c0 < KC) become
+    // zeros here, by a select on the way out.
+    __device__ __forceinline__ void store(float *__restrict__ buf, int tid, int cin_left, const f32x4 (&v)[NIT]) const {
+        unsigned m = vmask;
+        if (cin_left < KC) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if ((it * 256 + tid) / (RQ * IN_D * IN_H) >= cin_left) m &= ~(1u << it);
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = it * 256 + tid;
-            if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<float4 *>(buf)[i] = v[it];
+            const f32x4 z = ((m >> it) & 1u) ? v[it] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<f32x4 *>(buf)[i] = z;
         }
     }
 
@@ -171,18 +177,18 @@ struct WeightStager {
     static constexpr int ITEMS = WF / 4;
     static constexpr int NIT = (ITEMS + 255) / 256;
     static_assert(WF % 4 == 0, "weight chunk is whole float4 pieces");
-    static __device__ __forceinline__ void load(const float *__restrict__ wc, int tid, float4 (&v)[NIT]) {
+    static __device__ __forceinline__ void load(const float *__restrict__ wc, int tid, f32x4 (&v)[NIT]) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = it * 256 + tid;
-            v[it] = reinterpret_cast<const float4 *>(wc)[(ITEMS % 256 == 0 || i < ITEMS) ? i : 0];
+            v[it] = reinterpret_cast<const f32x4 *>(wc)[(ITEMS % 256 == 0 || i < ITEMS) ? i : 0];
         }
     }
-    static __device__ __forceinline__ void store(float *__restrict__ wbuf, int tid, const float4 (&v)[NIT]) {
+    static __device__ __forceinline__ void store(float *__restrict__ wbuf, int tid, const f32x4 (&v)[NIT]) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = it * 256 + tid;
-            if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<float4 *>(wbuf)[i] = v[it];
+            if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<f32x4 *>(wbuf)[i] = v[it];
         }
     }
 };
@@ -314,10 +320,10 @@ conv3d_mfma_kernel(const ConvArgs a) {
     if (a.vec) {
         St st;
         st.init(tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
-        float4 pre[St::NIT], wpre[Ws::NIT];
-        st.load(xn, tid, a.Cin, pre);
+        f32x4 pre[St::NIT], wpre[Ws::NIT];
+        st.load(xn, pre);
         Ws::load(wg, tid, wpre);
-        st.store(lds, tid, pre);
+        st.store(lds, tid, a.Cin, pre);
         Ws::store(wlds, tid, wpre);
         __syncthreads();
         int chunk = 0, ph = 0;
@@ -326,17 +332,17 @@ conv3d_mfma_kernel(const ConvArgs a) {
             const bool last_of_chunk = ph == NPH - 1;
             const bool new_img = more && last_of_chunk;       // the next phase starts a new chunk
             if (more) Ws::load(wg + (int64_t)(p + 1) * WF, tid, wpre);
-            if (new_img) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
+            if (new_img) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, pre);
             const float *img = lds + (Cfg::DB ? (chunk & 1) * TILE : 0) + ph * SLICE;
             conv_compute_phase<Cfg>(img, wlds + (p & 1) * WF + lane * MI, bbase, wave, acc);
             if (more) Ws::store(wlds + ((p + 1) & 1) * WF, tid, wpre);
             if (Cfg::DB) {
-                if (new_img) st.store(lds + ((chunk + 1) & 1) * TILE, tid, pre);
+                if (new_img) st.store(lds + ((chunk + 1) & 1) * TILE, tid, a.Cin - (chunk + 1) * KC, pre);
                 __syncthreads();
             } else {
                 __syncthreads();
                 if (new_img) {            // uniform: the single image may only be overwritten once all
-                    st.store(lds, tid, pre);   // waves have finished reading it
+                    st.store(lds, tid, a.Cin - (chunk + 1) * KC, pre);   // waves have finished reading it
                     __syncthreads();
                 }
             }
@@ -349,7 +355,7 @@ conv3d_mfma_kernel(const ConvArgs a) {
             if (ph == 0)
                 St::stage_scalar(xn + (int64_t)chunk * KC * in_dhw, lds, tid, id0, ih0, ix0, a.Din, a.Hin, a.Win,
                                  in_hw, in_dhw, a.Cin - chunk * KC);
-            float4 wpre[Ws::NIT];
+            f32x4 wpre[Ws::NIT];
             Ws::load(wg + (int64_t)p * WF, tid, wpre);
             Ws::store(wlds, tid, wpre);
             __syncthreads();
@@ -483,23 +489,23 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
     if (a.vec) {
         St st;
         st.init(tid, id0, ih0, iw0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
-        float4 pre[St::NIT], wpre[Ws::NIT];
-        st.load(xn, tid, a.Cin, pre);
+        f32x4 pre[St::NIT], wpre[Ws::NIT];
+        st.load(xn, pre);
         Ws::load(wg, tid, wpre);
-        st.store(lds, tid, pre);
+        st.store(lds, tid, a.Cin, pre);
         Ws::store(lds + TILE, tid, wpre);
         __syncthreads();
         for (int chunk = 0; chunk < a.nchunks; ++chunk) {
             const bool more = chunk + 1 < a.nchunks;
             const float *cur = lds + (chunk & 1) * BUF;
             if (more) {
-                st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
+                st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, pre);
                 Ws::load(wg + (int64_t)(chunk + 1) * WSTRIDE, tid, wpre);
             }
             deconv_compute_chunk<Cfg, PD, PH>(cur, cur + TILE + lane * MI, bbase, wave, acc);
             if (more) {
                 float *nxt = lds + ((chunk + 1) & 1) * BUF;
-                st.store(nxt, tid, pre);
+                st.store(nxt, tid, a.Cin - (chunk + 1) * KC, pre);
                 Ws::store(nxt + TILE, tid, wpre);
             }
             __syncthreads();
@@ -509,7 +515,7 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
             __syncthreads();
             St::stage_scalar(xn + (int64_t)chunk * KC * in_dhw, lds, tid, id0, ih0, iw0, a.Din, a.Hin, a.Win, in_hw,
                              in_dhw, a.Cin - chunk * KC);
-            float4 wpre[Ws::NIT];
+            f32x4 wpre[Ws::NIT];
             Ws::load(wg + (int64_t)chunk * WSTRIDE, tid, wpre);
             Ws::store(lds + TILE, tid, wpre);
             __syncthreads();
