@@ -1,0 +1,134 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol that
+include/snvc_hip.h declares, argument validation happens before any device work, the product
+modules have the reference's state-dict keys, CPU tensors are refused (no CPU fallback), and the
+one host-side op (points_in_boxes_cpu) matches the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_cases as GC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from snvc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def test_every_declared_symbol_is_exported(L):
+    from snvc_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "snvc_hip.h")).read()
+    declared = set(re.findall(r"SNVC_API\s+[\w\s\*]+?\b(snvc_\w+)\s*\(", hdr))
+    assert len(declared) == 20, sorted(declared)
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert L.snvc_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    from snvc_amd._lib import Conv3dDesc
+    assert ctypes.sizeof(Conv3dDesc) == 16 * 4 + 3 * 8
+    assert Conv3dDesc.x_batch_stride.offset == 64
+
+
+def test_argument_validation_needs_no_gpu(L):
+    from snvc_amd._lib import Conv3dDesc
+    err = lambda: L.snvc_last_error_string().decode()  # noqa: E731
+    assert L.snvc_cost_volume_forward(None, None, None, None, 1, 1, 3, 4, 1, 2, 0, None) == 1
+    assert "multiples of downsample" in err()
+    assert L.snvc_cost_volume_forward(None, None, None, None, 1, 1, 4, 4, 1, 1, 7, None) == 2 or "null" in err()
+    assert L.snvc_cost_volume_forward(None, None, None, None, 0, 3, 4, 4, 5, 1, 0, None) == 0     # empty -> ok
+    assert L.snvc_argmax_rows(None, None, None, 3, 0, None) == 1 and "empty sequence" in err()
+    assert L.snvc_roiaware_pool3d_forward(None, None, None, None, None, None, None, 1, 1, 1, 128, 256, 4, 4, 0, None) == 1
+    assert "< 256" in err()
+    d = Conv3dDesc()
+    d.N, d.Cin, d.Din, d.Hin, d.Win = 1, 8, 4, 4, 32
+    d.Cout, d.Dout, d.Hout, d.Wout = 32, 4, 4, 32
+    d.ksize, d.stride, d.dilation, d.pad = 3, 1, 1, 1
+    assert L.snvc_conv3d_packed_weight_count(ctypes.byref(d)) == 1 * 2 * 27 * 2 * 64 * 1   # groups*chunks*taps*KP*64*MI
+    d.ksize, d.pad = 9, 4
+    assert L.snvc_conv3d_packed_weight_count(ctypes.byref(d)) == -1 and "not in" in err()
+    d.ksize, d.pad, d.Dout = 3, 1, 5
+    assert L.snvc_conv3d_packed_weight_count(ctypes.byref(d)) == -1 and "convolution arithmetic" in err()
+    d.Dout, d.transposed = 4, 1
+    assert L.snvc_conv3d_packed_weight_count(ctypes.byref(d)) == -1 and "transposed" in err()
+
+
+def test_no_cpu_fallback():
+    from snvc_amd import ops
+    from snvc_amd.extension.build_cost_volume import build_cost_volume
+    from snvc_amd.models import submodule as S
+    z = torch.zeros(1, 2, 4, 8)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        build_cost_volume(z, z, torch.zeros(1, 3), 1)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.voxel_gather_forward(z, z, torch.zeros(1, 2, 5), torch.zeros(1, 2, 5), (8, 8))
+    m = S.convbn_3d(4, 32, 3, 1, 1).eval()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        m(torch.zeros(1, 4, 4, 4, 8))
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        ops.argmax_rows(torch.zeros(2, 5))
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "snvc_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, f)
+
+
+def test_state_dict_keys_equal_the_reference(tmp_path):
+    """oracle.torch_ref's keys were checked against the imported reference by make_golden.py."""
+    import types
+    from oracle import torch_ref as T
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    from snvc_amd.models.vernier import VernierScale
+
+    def keys(m):
+        return [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+
+    for gn in (False, True):
+        assert keys(S.hourglass(32, gn)) == keys(T.hourglass(32, gn))
+        assert keys(S.hourglass_downsample_16(32, gn)) == keys(T.hourglass_downsample_16(32, gn))
+        assert keys(S.convbn_3d(64, 32, 7, 1, 3, gn=gn)) == keys(T.convbn_3d(64, 32, 7, 1, 3, gn=gn))
+        assert keys(GlobalStack(32, gn)) == keys(T.GlobalStack(32, gn))
+        for grid in ((16, 16, 24), (32, 128, 192)):
+            cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=gn, grid_resolution=list(grid),
+                                        resolution=(64, 64), x_range=(-1, 1), z_range=(-1, 1), num_parts=9)
+            cfg.hrfeat = types.SimpleNamespace(output_channel=32, name="identity")
+            cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
+            assert keys(VernierScale(cfg)) == keys(T.VernierTrunk(32, grid, gn))
+    # documented example keys
+    k = dict(keys(VernierScale(cfg)))
+    assert k["conv1.0.0.weight"] == (32, 64, 7, 7, 7)
+    assert k["hg_conv3d.conv1.0.0.weight"] == (64, 32, 3, 3, 3)
+    assert k["hg_conv3d.conv9.0.weight"] == (64, 64, 3, 3, 3)
+    assert k["hg_conv3d.conv12.0.weight"] == (64, 32, 3, 3, 3)       # ConvTranspose: [Cin, Cout, ...]
+    assert k["fg_cls_head.2.weight"] == (1, 32, 3, 3, 3)
+
+
+def test_points_in_boxes_cpu_host_op(L):
+    from oracle import native as O
+    from snvc_amd.extension.roiaware_pool3d import roiaware_pool3d_utils as U
+    r = np.random.default_rng(5)
+    boxes = np.concatenate([r.uniform(-3, 3, (6, 3)), r.uniform(1, 4, (6, 3)), r.uniform(-3.2, 3.2, (6, 1))], 1).astype(np.float32)
+    pts = r.uniform(-5, 5, (2000, 3)).astype(np.float32)
+    exp = O.points_in_boxes_cpu(pts, boxes)
+    assert np.array_equal(U.points_in_boxes_cpu(pts, boxes), exp) and exp.sum() > 20
+    got = U.points_in_boxes_cpu(torch.from_numpy(pts), torch.from_numpy(boxes))
+    assert isinstance(got, torch.Tensor) and np.array_equal(got.numpy(), exp)
+    idmap = U.points_in_boxes_cpu_idmap(pts, boxes)
+    assert idmap.shape == (2000,) and idmap.max() >= 0 and idmap.min() == -1
+    assert U.points_in_boxes_cpu_idmap(pts, boxes[:0]).tolist() == [-1] * 2000
