@@ -1,0 +1,88 @@
+"""World-size-2 gloo test of the multi-GPU host logic (CPU): batch sharding with no data-path
+collective, output gather, flat-bucket gradient all-reduce, one-time parameter broadcast."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from snvc_amd import parallel as P
+        assert P.world() == (rank, world)
+        # 5 "crops" over 2 ranks: rank 0 gets 3, rank 1 gets 2 (uneven shard)
+        crops = torch.arange(5 * 3, dtype=torch.float32).view(5, 3)
+        extra = torch.arange(5)
+        mine, mine_extra = P.shard([crops, extra])
+        lo, hi = P.shard_range(5, rank, world)
+        assert (lo, hi) == ((0, 3) if rank == 0 else (3, 5))
+        assert torch.equal(mine, crops[lo:hi]) and torch.equal(mine_extra, extra[lo:hi])
+        # per-rank "inference": no collective; then gather the small outputs
+        out_local = mine * 2 + rank * 0            # independent units
+        full = P.gather_outputs(out_local, 5)
+        assert torch.equal(full, crops * 2)
+        # gradient all-reduce: one flat bucket
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+        if rank == 1:
+            for p in net.parameters():
+                p.data.add_(1.0)
+        P.broadcast_parameters(net, src=0)
+        ref = [p.detach().clone() for p in net.parameters()]
+        loss = net(mine).pow(2).sum()
+        loss.backward()
+        local = [p.grad.clone() for p in net.parameters()]
+        moved = P.all_reduce_gradients(net.parameters(), average=False)
+        assert moved == sum(p.numel() for p in net.parameters()) * 4
+        # reference: gradient of the full-batch loss on one process
+        net2 = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.Linear(4, 2))
+        for p, r in zip(net2.parameters(), ref):
+            p.data.copy_(r)
+        net2(crops).pow(2).sum().backward()
+        for p, p2, l in zip(net.parameters(), net2.parameters(), local):
+            assert torch.allclose(p.grad, p2.grad, rtol=1e-5, atol=1e-5)
+            assert not torch.allclose(l, p2.grad)          # the local gradient alone is different
+        q.put((rank, "ok"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_grad_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_shard_range_partitions_exactly():
+    from snvc_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)
