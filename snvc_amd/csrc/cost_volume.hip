@@ -104,6 +104,82 @@ cost_volume_fwd_f32x4(const float *__restrict__ left, const float *__restrict__ 
     }
 }
 
+// Branch-free twin of right_value() for an LDS slab of `rows` (1 or 2) rows of width img_w: the gate
+// becomes a select, so the four elements of a float4 issue their LDS reads together.  For lanes
+// that pass the gate the arithmetic is operation-for-operation the same as sample_right().
+__device__ __forceinline__ float right_value_lds(const float *__restrict__ slab, int rows, int img_w, int iw,
+                                                 float neg_shift) {
+    const float x0 = (float)iw + neg_shift;
+    const bool ok = x0 >= 0.0f && x0 <= (float)(img_w - 1);
+    float x = ok ? x0 : 0.0f;
+    int x_lo = (int)x, x_hi;
+    if (x_lo >= img_w - 1) { x_hi = x_lo = img_w - 1; x = (float)x_lo; } else { x_hi = x_lo + 1; }
+    const int y_hi = rows - 1;                       // row below (same row on the last image row)
+    const float ly = 0.0f, lx = x - (float)x_lo;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const float v1 = slab[x_lo], v2 = slab[x_hi];
+    const float v3 = slab[y_hi * img_w + x_lo], v4 = slab[y_hi * img_w + x_hi];
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    const float val = w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+    return ok ? val : 0.0f;
+}
+
+// Fast forward v2: fp32, downsample 1, W % 4 == 0.  A workgroup owns RB consecutive rows of one
+// (n, c) feature plane: the right rows (+ the row below, whose zero-weight taps the reference still
+// loads) are staged ONCE in LDS, the left float4 of every thread stays in a register, and the
+// workgroup then walks a range of disparity planes writing, per plane, RB*W contiguous floats of
+// the left half and of the right half.  Gathers hit LDS instead of L1/L2, the shift is a scalar
+// load, and all vector-memory traffic is the two 16-byte stores per thread per plane.
+__global__ void __launch_bounds__(512)
+cost_volume_fwd_rows(const float *__restrict__ left, const float *__restrict__ right,
+                     const float *__restrict__ shift, float *__restrict__ out, int C, int D, int H, int W,
+                     int RB, int hblocks, int dchunk) {
+    extern __shared__ __attribute__((aligned(16))) float rrows[];   // [(RB+1)][W]
+    const int W4 = W >> 2;
+    const int hb = blockIdx.x % hblocks;
+    const int64_t nc = blockIdx.x / hblocks;            // n*C + c
+    const int c = (int)(nc % C);
+    const int64_t n = nc / C;
+    const int h0 = hb * RB;
+    const float *rplane = right + nc * (int64_t)H * W;
+    // stage rows h0 .. h0+RB (clamped to H-1) of the right plane
+    for (int i = threadIdx.x; i < (RB + 1) * W4; i += blockDim.x) {
+        const int r = i / W4, q = i - r * W4;
+        int gh = h0 + r;
+        gh = gh < H ? gh : H - 1;
+        reinterpret_cast<float4 *>(rrows)[i] = reinterpret_cast<const float4 *>(rplane + (int64_t)gh * W)[q];
+    }
+    const int row = threadIdx.x / W4, q = threadIdx.x - row * W4;
+    const int h = h0 + row;
+    const bool live = row < RB && h < H;
+    float4 lv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) lv = reinterpret_cast<const float4 *>(left + nc * (int64_t)H * W + (int64_t)h * W)[q];
+    __syncthreads();
+    if (!live) return;
+    // image seen by sample_right: rows [row, row+1] of the LDS slab act as rows [h, min(h+1,H-1)]
+    const float *slab = rrows + row * W;
+    const int slab_h = (h >= H - 1) ? 1 : 2;            // y_hi == y_lo on the last image row
+    const int w = q << 2;
+    const int d0 = blockIdx.y * dchunk;
+    const int d1 = d0 + dchunk < D ? d0 + dchunk : D;
+    const int64_t plane = (int64_t)H * W;
+    float *oL = out + ((n * 2 * C + c) * (int64_t)D + d0) * plane + (int64_t)h * W + w;
+    float *oR = oL + (int64_t)C * D * plane;
+#pragma unroll 2
+    for (int d = d0; d < d1; ++d) {
+        const float ns = -shift[n * D + d];
+        float4 v;
+        v.x = right_value_lds(slab, slab_h, W, w + 0, ns);
+        v.y = right_value_lds(slab, slab_h, W, w + 1, ns);
+        v.z = right_value_lds(slab, slab_h, W, w + 2, ns);
+        v.w = right_value_lds(slab, slab_h, W, w + 3, ns);
+        *reinterpret_cast<float4 *>(oL) = lv;
+        *reinterpret_cast<float4 *>(oR) = v;
+        oL += plane;
+        oR += plane;
+    }
+}
+
 // Backward gather.  One thread per element (n, c, iy, ix) of grad_left / grad_right
 // [N,C,H*ds,W*ds].  For grad_right the thread visits, for every d, the few output columns w
 // whose sample position x = w*ds - shift has x_low == ix or x_high == ix, recomputing the
@@ -170,8 +246,33 @@ int launch_forward(const void *left, const void *right, const void *shift, void 
     const int64_t planes = N * 2 * C * D;
     if (planes == 0 || H * W == 0) return SNVC_OK;  // BuildCostVolume_cuda.cu:235-238
     const unsigned gy = (unsigned)(planes < 65535 ? planes : 65535);
-    if (sizeof(T) == 4 && ds == 1 && (W % 4) == 0 &&
-        ((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const bool fast = sizeof(T) == 4 && ds == 1 && (W % 4) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right) |
+                        reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    const int64_t W4 = W / 4;
+    if (fast && W4 <= 512 && N * C * H < ((int64_t)1 << 30)) {
+        // rows per workgroup: prefer RB*W*4 bytes to be a multiple of 128 (every workgroup then writes
+        // whole cache lines per plane), with RB*W/4 threads <= 512
+        int RB = 0;
+        for (int r = 1; r <= 8 && r * W4 <= 512 && r <= H; ++r)
+            if ((r * W * 4) % 128 == 0) RB = r;
+        if (RB == 0) {
+            RB = (int)(256 / W4);
+            if (RB > 8) RB = 8;
+            if (RB < 1) RB = 1;
+        }
+        if (RB > H) RB = (int)H;
+        const int threads = (int)ceil_div<int64_t>(RB * W4, 64) * 64;
+        const int hblocks = (int)ceil_div<int64_t>(H, RB);
+        // enough workgroups to fill the chip without shortening the per-thread plane walk too much
+        int dsplit = 1;
+        while (N * C * hblocks * dsplit < 2048 && D / (dsplit * 2) >= 8) dsplit *= 2;
+        const int dchunk = (int)ceil_div<int64_t>(D, dsplit);
+        dim3 grid((unsigned)(N * C * hblocks), (unsigned)ceil_div<int64_t>(D, dchunk));
+        const size_t lds = (size_t)(RB + 1) * W * sizeof(float);
+        cost_volume_fwd_rows<<<grid, threads, lds, st>>>((const float *)left, (const float *)right, (const float *)shift,
+                                                     (float *)out, (int)C, (int)D, (int)H, (int)W, RB, hblocks, dchunk);
+    } else if (fast) {
         dim3 grid((unsigned)ceil_div<int64_t>(H * W / 4, 256), gy);
         cost_volume_fwd_f32x4<<<grid, 256, 0, st>>>((const float *)left, (const float *)right,
                                                     (const float *)shift, (float *)out, (int)C,
