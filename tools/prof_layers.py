@@ -28,7 +28,32 @@ model.load_state_dict(bench.seeded_state(model))
 model.eval().to(dev)
 left, right, shift = bench.make_inputs(0, dev)
 with torch.no_grad():
-    if args.layer == "cost_volume":
+    if args.layer in ("gather", "trunk"):
+        import types
+        from snvc_amd.models.vernier import VernierScale
+        grid = (32, 128, 192)
+        n = 4 if args.layer == "gather" else 1
+        cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False, grid_resolution=list(grid),
+                                    resolution=(256, 256), x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
+        cfg.hrfeat = types.SimpleNamespace(output_channel=32, name="identity")
+        cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
+        vs = VernierScale(cfg)
+        vs.load_state_dict(bench.seeded_state(vs))
+        vs.eval().to(dev)
+        r = np.random.default_rng(7)
+        v = grid[0] * grid[1] * grid[2]
+        lf = torch.from_numpy(r.standard_normal((n, 32, 64, 64)).astype(np.float32)).to(dev)
+        rf = torch.from_numpy(r.standard_normal((n, 32, 64, 64)).astype(np.float32)).to(dev)
+        # smooth projections (a plane sweep across the crop) + 6 % outside, like real grids
+        base = np.linspace(-8, 264, v, dtype=np.float32)
+        gl = torch.from_numpy(np.stack([np.stack([base, base[::-1]])] * n).copy()).to(dev)
+        gr = torch.from_numpy(np.stack([np.stack([base[::-1], base])] * n).copy()).to(dev)
+        if args.layer == "gather":
+            fn = lambda: vs.construct_voxel(lf, rf, gl, gr)  # noqa: E731
+        else:
+            vox = vs.construct_voxel(lf, rf, gl, gr)
+            fn = lambda: vs.trunk_3d(vox)  # noqa: E731
+    elif args.layer == "cost_volume":
         fn = lambda: build_cost_volume(left, right, shift, 1)  # noqa: E731
     else:
         vol = build_cost_volume(left, right, shift, 1)
