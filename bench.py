@@ -167,6 +167,15 @@ def main():
 
     conv1_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     achieved = CONV1_FLOP / (conv1_ms * 1e-3) / 1e12
+    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
+    # process; they are collected by separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950
+    # correction applied) and committed in profiles/r1/traffic.json.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1", "traffic.json")) as fh:
+            traffic = json.load(fh)["conv1_k3_64to32_cfg2"]["hbm_bytes_corrected"]
+    except Exception:
+        pass
 
     if args.breakdown and rank == 0:
         _breakdown(model, left, right, shift, build_cost_volume)
@@ -200,7 +209,8 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": "profiles/r1/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                 "flop_per_launch": CONV1_FLOP,
                 "avg_launch_ms": conv1_ms,
             },
