@@ -575,6 +575,48 @@ deconv3d_mfma_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------ 1x1x1, tiny Cout
+// The classifier (C -> 1, kernel 1) would waste 31/32 of an MFMA tile and is bound by reading its
+// input once: a streaming kernel does it -- each lane owns 4 consecutive voxels (16-byte loads of
+// every input channel, channel stride = D*H*W), weights in scalar registers, fused epilogue.
+template <int COUT>
+__global__ void __launch_bounds__(256)
+pointwise_small_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
+                       const float *__restrict__ bias, const float *__restrict__ res, float *__restrict__ y,
+                       int Cin, int64_t S, int64_t x_bs, int64_t y_bs, int64_t r_bs, int flags) {
+    const int64_t n = blockIdx.y;
+    const float *xn = x + n * x_bs;
+    float *yn = y + n * y_bs;
+    const float *rn = res ? res + n * r_bs : nullptr;
+    const int64_t S4 = S >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 acc[COUT];
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int ci = 0; ci < Cin; ++ci) {
+            const f32x4 v = reinterpret_cast<const f32x4 *>(xn + ci * S)[i];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                const float wv = w[co * Cin + ci];   // uniform -> scalar load
+                acc[co] += v * wv;
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float sc = scale ? scale[co] : 1.0f, bi = scale ? bias[co] : 0.0f;
+            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rn) r = reinterpret_cast<const f32x4 *>(rn + co * S)[i];
+            f32x4 o;
+            o.x = epilogue_f(acc[co].x * sc + bi, r.x, flags);
+            o.y = epilogue_f(acc[co].y * sc + bi, r.y, flags);
+            o.z = epilogue_f(acc[co].z * sc + bi, r.z, flags);
+            o.w = epilogue_f(acc[co].w * sc + bi, r.w, flags);
+            reinterpret_cast<f32x4 *>(yn + co * S)[i] = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ packing
 // Conv:    packed[cg][chunk][tap][kp][half][i][m] = W[co = cg*32*MI + m*32 + i][ci = chunk*KC + 2kp + half][tap]
 // Deconv:  same with tap enumerated class by class (see deconv_class_body) and
@@ -751,7 +793,10 @@ int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
     Plan p;
     if (!d || make_plan(*d, p) != SNVC_OK) return -1;
     const int64_t taps = d->transposed ? 27 : (int64_t)d->ksize * d->ksize * d->ksize;
-    return (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
+    int64_t count = (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
+    // 1x1x1 layers with <= 2 output channels also keep their raw [Cout][Cin] weights (streaming kernel)
+    if (!d->transposed && d->ksize == 1 && d->Cout <= 2) count += (int64_t)d->Cout * d->Cin;
+    return count;
 }
 
 int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, float *packed, void *stream) {
@@ -761,7 +806,13 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
     int rc = make_plan(*d, p);
     if (rc) return rc;
     if (!weight || !packed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_pack_weights: null pointer");
-    const int64_t total = snvc_conv3d_packed_weight_count(d);
+    int64_t total = snvc_conv3d_packed_weight_count(d);
+    if (!d->transposed && d->ksize == 1 && d->Cout <= 2) {   // raw copy behind the MFMA packing
+        total -= (int64_t)d->Cout * d->Cin;
+        if (hipMemcpyAsync(packed + total, weight, sizeof(float) * d->Cout * d->Cin, hipMemcpyDeviceToDevice,
+                           as_stream(stream)) != hipSuccess)
+            return fail(SNVC_ERR_HIP, "snvc_conv3d_pack_weights: hipMemcpyAsync failed");
+    }
     const unsigned blocks = (unsigned)ceil_div<int64_t>(total, 256);
     if (d->transposed)
         pack_deconv_weights_kernel<<<blocks, 256, 0, as_stream(stream)>>>(weight, packed, d->Cout, d->Cin, p.MI, p.KC,
@@ -808,6 +859,22 @@ int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : out_sz;
     a.vec = (d->Win % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (a.x_bs % 4 == 0);
 
+    // 1x1x1 convolution to <= 2 channels: HBM-bound streaming kernel (raw weights ride at the end of
+    // the packed buffer, see snvc_conv3d_pack_weights)
+    const int64_t S = (int64_t)d->Dout * d->Hout * d->Wout;
+    if (!d->transposed && d->ksize == 1 && d->stride == 1 && d->Cout <= 2 && (S % 4) == 0 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0 &&
+        a.x_bs % 4 == 0 && a.y_bs % 4 == 0 && a.r_bs % 4 == 0) {
+        const float *wraw = packed_weight + snvc_conv3d_packed_weight_count(d) - (int64_t)d->Cout * d->Cin;
+        int64_t blocks = ceil_div<int64_t>(S / 4, 256);
+        if (blocks > 4096) blocks = 4096;
+        dim3 g((unsigned)blocks, (unsigned)d->N);
+        if (d->Cout == 1)
+            pointwise_small_kernel<1><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
+        else
+            pointwise_small_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
+        return check_launch("snvc_conv3d_forward(pointwise)");
+    }
     const int64_t ntiles = (int64_t)p.tiles_d * p.tiles_h * p.tiles_w;
     const int64_t gx = d->transposed ? ntiles * 4 : ntiles;
     if (gx >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: too many tiles");
