@@ -159,6 +159,35 @@ SNVC_API int snvc_affine_act(const float *x, const float *scale, const float *sh
                              int64_t res_batch_stride, int per_sample, int flags, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Training backward of the 3D stack (BASELINE.json configs[3]; reference: torch autograd through
+ * nn.Conv3d / nn.ConvTranspose3d / nn.BatchNorm3d / ReLU as composed in snvc/models/submodule.py).
+ *   data gradient  : the forward kernels themselves -- a stride-1 Conv3d's dgrad is a Conv3d with the
+ *                    taps flipped and channels transposed, a stride-2 Conv3d's dgrad is a
+ *                    ConvTranspose3d(k3,s2,p1,op1) with the SAME weight memory, and vice versa.
+ *   weight gradient: snvc_conv3d_wgrad (deterministic: per-partition slabs + fixed-order sum).
+ *   epilogue       : forward was v = raw*scale + shift; [v += res]; y = act(v); [y += res].
+ *                    snvc_act_backward_reduce gives, per (n, c), sum(g) and sum(g*raw) in fp64 with
+ *                    g = gy*act'(v) (what BatchNorm / GroupNorm backward need);
+ *                    snvc_act_backward_apply writes draw = coef_g*g + coef_raw*raw + coef_const
+ *                    (per channel, or per (n, c) when per_sample) and optionally g itself.
+ * ---------------------------------------------------------------------------------- */
+SNVC_API int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *desc_host);
+SNVC_API int snvc_conv3d_wgrad(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
+                               void *workspace, void *stream);
+SNVC_API int64_t snvc_act_backward_workspace_bytes(int64_t N, int64_t C);
+SNVC_API int snvc_act_backward_reduce(const float *raw, const float *gy, const float *residual,
+                                      const float *scale, const float *shift, double *sums,
+                                      void *workspace, int64_t N, int64_t C, int64_t S,
+                                      int64_t raw_batch_stride, int64_t gy_batch_stride,
+                                      int64_t res_batch_stride, int per_sample, int flags, void *stream);
+SNVC_API int snvc_act_backward_apply(const float *raw, const float *gy, const float *residual,
+                                     const float *scale, const float *shift, const float *coef_g,
+                                     const float *coef_raw, const float *coef_const, float *draw,
+                                     float *g_out, int64_t N, int64_t C, int64_t S,
+                                     int64_t raw_batch_stride, int64_t gy_batch_stride,
+                                     int64_t res_batch_stride, int per_sample, int flags, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Small fused element-wise steps of predict_3d_heatmaps
  * ---------------------------------------------------------------------------------- */
 /* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half

@@ -113,11 +113,20 @@ struct Stager {
         }
     }
 
-    // channels [c0, c0+KC) -> registers.  Only ISSUES the loads (padding pieces read offset 0);
-    // nothing here consumes the data, so the wave does not wait for it.
-    __device__ __forceinline__ void load(const float *__restrict__ xc, f32x4 (&v)[NIT]) const {
+    // channels [c0, c0+KC) -> registers.  Only ISSUES the loads (padding pieces read offset 0, and so
+    // do pieces of channels >= Cin when the last chunk is partial: nothing outside the tensor is ever
+    // touched); nothing here consumes the data, so the wave does not wait for it.
+    __device__ __forceinline__ void load(const float *__restrict__ xc, int tid, int cin_left, f32x4 (&v)[NIT]) const {
+        if (cin_left >= KC) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const f32x4 *>(xc + off[it]);
+            for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const f32x4 *>(xc + off[it]);
+        } else {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const bool chan_ok = (it * 256 + tid) / (RQ * IN_D * IN_H) < cin_left;
+                v[it] = *reinterpret_cast<const f32x4 *>(xc + (chan_ok ? off[it] : 0u));
+            }
+        }
     }
 
     // registers -> LDS image; padding pieces and channels >= Cin (cin_left = Cin - c0 < KC) become
@@ -321,7 +330,7 @@ conv3d_mfma_kernel(const ConvArgs a) {
         St st;
         st.init(tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
         f32x4 pre[St::NIT], wpre[Ws::NIT];
-        st.load(xn, pre);
+        st.load(xn, tid, a.Cin, pre);
         Ws::load(wg, tid, wpre);
         st.store(lds, tid, a.Cin, pre);
         Ws::store(wlds, tid, wpre);
@@ -332,7 +341,7 @@ conv3d_mfma_kernel(const ConvArgs a) {
             const bool last_of_chunk = ph == NPH - 1;
             const bool new_img = more && last_of_chunk;       // the next phase starts a new chunk
             if (more) Ws::load(wg + (int64_t)(p + 1) * WF, tid, wpre);
-            if (new_img) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, pre);
+            if (new_img) st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
             const float *img = lds + (Cfg::DB ? (chunk & 1) * TILE : 0) + ph * SLICE;
             conv_compute_phase<Cfg>(img, wlds + (p & 1) * WF + lane * MI, bbase, wave, acc);
             if (more) Ws::store(wlds + ((p + 1) & 1) * WF, tid, wpre);
@@ -490,7 +499,7 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
         St st;
         st.init(tid, id0, ih0, iw0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
         f32x4 pre[St::NIT], wpre[Ws::NIT];
-        st.load(xn, pre);
+        st.load(xn, tid, a.Cin, pre);
         Ws::load(wg, tid, wpre);
         st.store(lds, tid, a.Cin, pre);
         Ws::store(lds + TILE, tid, wpre);
@@ -499,7 +508,7 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
             const bool more = chunk + 1 < a.nchunks;
             const float *cur = lds + (chunk & 1) * BUF;
             if (more) {
-                st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, pre);
+                st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
                 Ws::load(wg + (int64_t)(chunk + 1) * WSTRIDE, tid, wpre);
             }
             deconv_compute_chunk<Cfg, PD, PH>(cur, cur + TILE + lane * MI, bbase, wave, acc);

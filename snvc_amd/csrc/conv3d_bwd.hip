@@ -1,0 +1,261 @@
+// Weight gradient of the 3D convolutions for gfx950 (training step, BASELINE.json configs[3]).
+//
+// Reference: torch autograd through nn.Conv3d / nn.ConvTranspose3d (cuDNN wgrad) as composed by
+// convbn_3d / hourglass (snvc/models/submodule.py:32-50,85-168).
+//
+//   dW[cg][cx][t] = sum_n sum_o  G[n,cg,o] * X[n,cx, o*stride - pad + t*dil]
+//
+// G lives on the SMALL grid (the conv's output gradient), X on the BIG grid (the conv's input);
+// for a ConvTranspose3d the caller swaps roles (G := the deconv's input, X := its output
+// gradient) and the result is directly in nn.ConvTranspose3d's [Cin][Cout][k^3] layout.
+//
+// GEMM view per tap: M = 32 channels of G, N = 32 channels of X, K = voxels.  With
+// v_mfma_f32_32x32x2_f32 the lane index runs over CHANNELS for both operands and the two
+// K-slots are two adjacent voxels, so LDS tiles are kept channel-major with an ODD row stride:
+// the 32 lanes of a half-wave read one voxel of 32 different channels from 32 different banks.
+// A workgroup owns one (G-channel block, X-channel block) pair and one spatial partition; its 4
+// waves split the (up to 28) taps, each wave keeping 7 accumulators of 32x32 in registers across
+// ALL tiles of the partition.  Partials go to a slab [partition][...] that a second kernel sums
+// in a fixed order: the result is deterministic (no float atomics).
+#include "common.hpp"
+
+namespace snvc {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+    const float *x;   // big grid  [N, Cx, Di, Hi, Wi]
+    const float *g;   // small grid [N, Cg, Do, Ho, Wo]
+    float *partial;   // [P][pairs][taps_pad][32][32]
+    int N, Cx, Di, Hi, Wi;
+    int Cg, Do, Ho, Wo;
+    int tiles_h, tiles_w;       // tiles per (n, od) plane
+    int64_t ntiles;             // N * Do * tiles_h * tiles_w
+    int P;                      // spatial partitions (gridDim.x)
+    int cx_blocks;              // pairs = cg_blocks * cx_blocks, blockIdx.y = cgb * cx_blocks + cxb
+    int64_t x_bs, g_bs;
+};
+
+template <int KS_, int STRIDE_, int DIL_, int TH_>
+struct WgradCfg {
+    static constexpr int KS = KS_, STRIDE = STRIDE_, DIL = DIL_;
+    static constexpr int PAD = DIL * (KS - 1) / 2;
+    static constexpr int TAPS = KS * KS * KS;
+    static constexpr int NT = (TAPS + 3) / 4;          // taps per wave
+    static constexpr int TH = TH_, TW = 32;            // output tile: 1 x TH x 32 voxels = 32*TH K-slots
+    static constexpr int IN_D = (KS - 1) * DIL + 1;
+    static constexpr int IN_H = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
+    static constexpr int IN_W = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
+    static constexpr int XV = IN_D * IN_H * IN_W;      // staged X voxels per channel
+    static constexpr int XS = XV | 1;                  // odd row stride
+    static constexpr int GV = TH * TW;
+    static constexpr int GS = GV + 1;                  // odd
+    static constexpr int LDS_FLOATS = 32 * XS + 32 * GS;
+    static_assert(NT <= 7, "at most 28 taps per workgroup");
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(256, 2)
+conv3d_wgrad_kernel(const WgradArgs a) {
+    constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, PAD = Cfg::PAD, TAPS = Cfg::TAPS, NT = Cfg::NT;
+    constexpr int IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, XV = Cfg::XV, XS = Cfg::XS, GV = Cfg::GV, GS = Cfg::GS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *xl = lds;             // [32][XS]
+    float *gl = lds + 32 * XS;   // [32][GS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cgb = blockIdx.y / a.cx_blocks, cxb = blockIdx.y - cgb * a.cx_blocks;
+    const int cg0 = cgb * 32, cx0 = cxb * 32;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // per-wave tap table: tap = wave + 4*t  ->  LDS offset of its window inside the staged X tile
+    int tap_off[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = wave + 4 * t;
+        const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
+        tap_off[t] = tap < TAPS ? (kd * DIL * IN_H + kh * DIL) * IN_W + kw * DIL : 0;
+    }
+
+    const int64_t in_hw = (int64_t)a.Hi * a.Wi, in_dhw = in_hw * a.Di;
+    const int64_t out_hw = (int64_t)a.Ho * a.Wo, out_dhw = out_hw * a.Do;
+    const int ch = lane & 31, half = lane >> 5;
+    const float *xrow = xl + ch * XS, *grow = gl + ch * GS;
+
+    for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += a.P) {
+        const int tw = (int)(tile % a.tiles_w);
+        const int th = (int)((tile / a.tiles_w) % a.tiles_h);
+        const int od = (int)((tile / ((int64_t)a.tiles_w * a.tiles_h)) % a.Do);
+        const int64_t n = tile / ((int64_t)a.tiles_w * a.tiles_h * a.Do);
+        const int oh0 = th * Cfg::TH, ow0 = tw * 32;
+        const int id0 = od * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+        const float *xn = a.x + n * a.x_bs + (int64_t)cx0 * in_dhw;
+        const float *gn = a.g + n * a.g_bs + (int64_t)cg0 * out_dhw;
+        __syncthreads();   // previous tile fully consumed
+        // ---- stage X: 32 channels x XV voxels (zero padded), branch-free
+        for (int e0 = 0; e0 < 32 * XV; e0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int e = e0 + b * 256 + tid;
+                const int c = e / XV, rem = e - c * XV;
+                const int dd = rem / (IN_H * IN_W), rem2 = rem - dd * (IN_H * IN_W);
+                const int hh = rem2 / IN_W, ww = rem2 - hh * IN_W;
+                const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww;
+                const bool ok = e < 32 * XV && cx0 + c < a.Cx && (unsigned)gd < (unsigned)a.Di &&
+                                (unsigned)gh < (unsigned)a.Hi && (unsigned)gw < (unsigned)a.Wi;
+                const float t = xn[ok ? (c * in_dhw + gd * in_hw + (int64_t)gh * a.Wi + gw) : 0];
+                v[b] = ok ? t : 0.0f;
+            }
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int e = e0 + b * 256 + tid;
+                if (e < 32 * XV) { const int c = e / XV; xl[c * XS + (e - c * XV)] = v[b]; }
+            }
+        }
+        // ---- stage G: 32 channels x GV voxels
+#pragma unroll
+        for (int b = 0; b < (32 * GV) / 256; ++b) {
+            const int e = b * 256 + tid;
+            const int c = e / GV, rem = e - c * GV;
+            const int hh = rem / 32, ww = rem - hh * 32;
+            const int gh = oh0 + hh, gw = ow0 + ww;
+            const bool ok = cg0 + c < a.Cg && gh < a.Ho && gw < a.Wo;
+            const float t = gn[ok ? (c * out_dhw + od * out_hw + (int64_t)gh * a.Wo + gw) : 0];
+            gl[c * GS + rem] = ok ? t : 0.0f;
+        }
+        __syncthreads();
+        // ---- 32 K-steps (2 voxels each) x NT taps
+#pragma unroll 4
+        for (int kk = 0; kk < GV / 2; ++kk) {
+            const int v = 2 * kk + half;           // output voxel inside the tile: hh = v / 32, j = v % 32
+            const int hh = v >> 5, j = v & 31;
+            const float af = grow[v];
+            const int xbase = (hh * S) * IN_W + j * S;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float bf = xrow[xbase + tap_off[t]];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial slab: [p][pair][tap][cg 32][cx 32]
+    float *pp = a.partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (4 * NT) * 1024;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = wave + 4 * t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;   // cg
+            pp[(tap * 32 + row) * 32 + ch] = acc[t][r];            // col = cx = lane & 31
+        }
+    }
+}
+
+// dw[cg][cx][tap] = sum_p partial[p][pair][tap][cg%32][cx%32], p ascending
+__global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, int Cg, int Cx,
+                                    int taps, int taps_pad, int cx_blocks, int pairs, int P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)Cg * Cx * taps;
+    if (i >= total) return;
+    const int tap = (int)(i % taps);
+    const int cx = (int)((i / taps) % Cx);
+    const int cg = (int)(i / ((int64_t)taps * Cx));
+    const int pair = (cg >> 5) * cx_blocks + (cx >> 5);
+    const float *src = partial + ((int64_t)pair * taps_pad + tap) * 1024 + (cg & 31) * 32 + (cx & 31);
+    const int64_t pstride = (int64_t)pairs * taps_pad * 1024;
+    float s = 0.0f;
+    for (int p = 0; p < P; ++p) s += src[p * pstride];
+    dw[i] = s;
+}
+
+template <class Cfg>
+void launch_wgrad(const WgradArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int bytes = Cfg::LDS_FLOATS * 4;
+    static bool attr_done = false;
+    if (!attr_done && bytes > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<Cfg>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        attr_done = true;
+    }
+    conv3d_wgrad_kernel<Cfg><<<grid, 256, bytes, st>>>(a);
+}
+
+constexpr int kWgradPartitions = 512;   // 2 workgroups per CU
+
+}  // namespace
+}  // namespace snvc
+
+extern "C" {
+
+int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *d) {
+    using namespace snvc;
+    if (!d) return -1;
+    const int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
+    const int64_t taps_pad = (taps + 3) / 4 * 4;
+    const int64_t pairs = (int64_t)ceil_div(d->Cout, 32) * ceil_div(d->Cin, 32);
+    return (int64_t)kWgradPartitions * pairs * taps_pad * 1024 * (int64_t)sizeof(float);
+}
+
+// desc describes the FORWARD Conv3d (x = its input on the big grid, g = gradient of its output on
+// the small grid, dw [Cout][Cin][k^3]).  For a ConvTranspose3d(k3,s2,p1,op1) pass the equivalent
+// stride-2 convolution with roles swapped: x := gradient of the deconv's output, g := the deconv's
+// input, desc = {Cin := deconv Cout, Cout := deconv Cin, big grid, small grid, k3, s2, p1}: dw is
+// then in nn.ConvTranspose3d's [Cin][Cout][27] layout.
+int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g, float *dw, void *workspace,
+                      void *stream) {
+    using namespace snvc;
+    if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_wgrad: null desc");
+    if (d->transposed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_wgrad: describe the equivalent strided convolution (see header)");
+    if (d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_wgrad: sizes must be positive");
+    if (d->pad != d->dilation * (d->ksize - 1) / 2) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: pad must equal dilation*(ksize-1)/2");
+    const int eff = d->dilation * (d->ksize - 1) + 1;
+    if (d->Dout != (d->Din + 2 * d->pad - eff) / d->stride + 1 || d->Hout != (d->Hin + 2 * d->pad - eff) / d->stride + 1 ||
+        d->Wout != (d->Win + 2 * d->pad - eff) / d->stride + 1)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_wgrad: output size does not match the convolution arithmetic");
+    if (!x || !g || !dw || !workspace) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_wgrad: null pointer");
+    const int64_t in_sz = (int64_t)d->Cin * d->Din * d->Hin * d->Win, out_sz = (int64_t)d->Cout * d->Dout * d->Hout * d->Wout;
+    if (in_sz >= ((int64_t)1 << 31) || out_sz >= ((int64_t)1 << 31))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: one sample must stay below 2^31 elements");
+
+    WgradArgs a;
+    a.x = x; a.g = g; a.partial = (float *)workspace;
+    a.N = d->N; a.Cx = d->Cin; a.Di = d->Din; a.Hi = d->Hin; a.Wi = d->Win;
+    a.Cg = d->Cout; a.Do = d->Dout; a.Ho = d->Hout; a.Wo = d->Wout;
+    const int th = d->stride == 1 ? 2 : 1;   // rows per tile (see the WgradCfg instantiations below)
+    a.tiles_h = ceil_div(d->Hout, th); a.tiles_w = ceil_div(d->Wout, 32);
+    a.ntiles = (int64_t)d->N * d->Dout * a.tiles_h * a.tiles_w;
+    a.P = kWgradPartitions;
+    a.cx_blocks = ceil_div(d->Cin, 32);
+    a.x_bs = d->x_batch_stride ? d->x_batch_stride : in_sz;
+    a.g_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
+    const int pairs = ceil_div(d->Cout, 32) * a.cx_blocks;
+    if (pairs > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: too many channel pairs");
+    dim3 grid(kWgradPartitions, (unsigned)pairs);
+    hipStream_t st = as_stream(stream);
+    const int key = d->ksize * 100 + d->stride * 10 + d->dilation;
+    switch (key) {
+        case 111: launch_wgrad<WgradCfg<1, 1, 1, 2>>(a, grid, st); break;
+        case 311: launch_wgrad<WgradCfg<3, 1, 1, 2>>(a, grid, st); break;
+        case 321: launch_wgrad<WgradCfg<3, 2, 1, 1>>(a, grid, st); break;
+        default:
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: (ksize,stride,dilation) must be (1,1,1), (3,1,1) or (3,2,1) in this release");
+    }
+    int rc = check_launch("snvc_conv3d_wgrad");
+    if (rc) return rc;
+    const int taps = d->ksize * d->ksize * d->ksize, taps_pad = (taps + 3) / 4 * 4;
+    const int64_t total = (int64_t)d->Cout * d->Cin * taps;
+    wgrad_reduce_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>(
+        (const float *)workspace, dw, d->Cout, d->Cin, taps, taps_pad, a.cx_blocks, pairs, kWgradPartitions);
+    return check_launch("snvc_conv3d_wgrad(reduce)");
+}
+
+}  // extern "C"

@@ -227,6 +227,90 @@ affine_act_kernel(const float *__restrict__ x, const float *__restrict__ scale,
     }
 }
 
+
+// ---------------------------------------------------------------------------- backward of the fused epilogue
+// Forward (per element, channel c):  v = raw*sc + sh;  [v += res];  y = act(v);  [y += res]
+// g = dL/dv = gy * act'(v).  Training BatchNorm / GroupNorm additionally need, per statistics
+// group, sum(g) and sum(g*raw) -- accumulated here in fp64 exactly like the forward statistics.
+__device__ __forceinline__ float act_grad(float raw, float gy, float res, float sc, float sh, int flags) {
+    float v = raw * sc + sh;
+    if (flags & SNVC_EPI_ADD_PRE) v = v + res;
+    float g = gy;
+    if (flags & SNVC_EPI_RELU) g = v > 0.0f ? g : 0.0f;
+    if (flags & SNVC_EPI_SIGMOID) { const float s = 1.0f / (1.0f + expf(-v)); g = g * (s * (1.0f - s)); }
+    return g;
+}
+
+__global__ void __launch_bounds__(256)
+act_bwd_partial_kernel(const float *__restrict__ raw, const float *__restrict__ gy, const float *__restrict__ res,
+                       const float *__restrict__ scale, const float *__restrict__ shift, double *__restrict__ partial,
+                       int64_t C, int64_t S, int64_t raw_bs, int64_t gy_bs, int64_t r_bs, int per_sample, int flags,
+                       int splits) {
+    const int64_t row = blockIdx.y;            // n*C + c
+    const int split = blockIdx.x;
+    const int64_t n = row / C, c = row % C;
+    const float sc = scale ? scale[(per_sample ? n * C : 0) + c] : 1.0f;
+    const float sh = shift ? shift[(per_sample ? n * C : 0) + c] : 0.0f;
+    const float *a = raw + n * raw_bs + c * S, *b = gy + n * gy_bs + c * S;
+    const float *r = res ? res + n * r_bs + c * S : nullptr;
+    const int64_t chunk = ceil_div<int64_t>(S, splits);
+    const int64_t lo = split * chunk, hi = (lo + chunk < S) ? lo + chunk : S;
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float g = act_grad(a[i], b[i], r ? r[i] : 0.0f, sc, sh, flags);
+        s0 += (double)g;
+        s1 += (double)g * (double)a[i];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off, 64);
+        s1 += __shfl_down(s1, off, 64);
+    }
+    __shared__ double shm[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { shm[2 * wave] = s0; shm[2 * wave + 1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) { s0 += shm[2 * k]; s1 += shm[2 * k + 1]; }
+        partial[(row * splits + split) * 2 + 0] = s0;
+        partial[(row * splits + split) * 2 + 1] = s1;
+    }
+}
+
+// sums[row][2] = fold of the splits (row = n*C + c), fixed order
+__global__ void act_bwd_fold_kernel(const double *__restrict__ partial, double *__restrict__ sums, int64_t rows,
+                                    int splits) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < splits; ++k) { s0 += partial[(row * splits + k) * 2]; s1 += partial[(row * splits + k) * 2 + 1]; }
+    sums[row * 2] = s0;
+    sums[row * 2 + 1] = s1;
+}
+
+// draw = A*g + B*raw + Cc per (n?, c);  g_out (optional) = g
+__global__ void __launch_bounds__(256)
+act_bwd_apply_kernel(const float *__restrict__ raw, const float *__restrict__ gy, const float *__restrict__ res,
+                     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ A,
+                     const float *__restrict__ B, const float *__restrict__ Cc, float *__restrict__ draw,
+                     float *__restrict__ g_out, int64_t C, int64_t S, int64_t raw_bs, int64_t gy_bs, int64_t r_bs,
+                     int per_sample, int flags) {
+    const int64_t n = blockIdx.z, c = blockIdx.y;
+    const int64_t pc = (per_sample ? n * C : 0) + c;
+    const float sc = scale ? scale[pc] : 1.0f, sh = shift ? shift[pc] : 0.0f;
+    const float ca = A[pc], cb = B ? B[pc] : 0.0f, cc = Cc ? Cc[pc] : 0.0f;
+    const float *a = raw + n * raw_bs + c * S, *b = gy + n * gy_bs + c * S;
+    const float *r = res ? res + n * r_bs + c * S : nullptr;
+    float *o = draw + (n * C + c) * S;
+    float *go = g_out ? g_out + (n * C + c) * S : nullptr;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += stride) {
+        const float x = a[i];
+        const float g = act_grad(x, b[i], r ? r[i] : 0.0f, sc, sh, flags);
+        o[i] = ca * g + cb * x + cc;
+        if (go) go[i] = g;
+    }
+}
+
 constexpr int kNormSplits = 32;
 
 inline unsigned stream_blocks(int64_t items, int64_t outer) {
@@ -318,6 +402,55 @@ int snvc_norm_stats(const float *x, const float *gamma, const float *beta, float
         (const double *)workspace, gamma, beta, scale, shift, mean_out, var_out, N, C, S, groups, per_sample,
         kNormSplits, eps);
     return check_launch("snvc_norm_stats(finalize)");
+}
+
+int64_t snvc_act_backward_workspace_bytes(int64_t N, int64_t C) {
+    return N * C * snvc::kNormSplits * 2 * (int64_t)sizeof(double);
+}
+
+int snvc_act_backward_reduce(const float *raw, const float *gy, const float *residual, const float *scale,
+                             const float *shift, double *sums, void *workspace, int64_t N, int64_t C, int64_t S,
+                             int64_t raw_batch_stride, int64_t gy_batch_stride, int64_t res_batch_stride,
+                             int per_sample, int flags, void *stream) {
+    using namespace snvc;
+    if (N <= 0 || C <= 0 || S <= 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_reduce: sizes must be positive");
+    if (!raw || !gy || !sums || !workspace) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_reduce: null pointer");
+    if ((flags & SNVC_EPI_ADD_PRE) && !residual) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_reduce: ADD_PRE needs the residual");
+    if (N * C > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_act_backward_reduce: N*C > 65535");
+    if (!(flags & SNVC_EPI_ADD_PRE)) residual = nullptr;
+    if (raw_batch_stride == 0) raw_batch_stride = C * S;
+    if (gy_batch_stride == 0) gy_batch_stride = C * S;
+    if (res_batch_stride == 0) res_batch_stride = C * S;
+    dim3 grid(kNormSplits, (unsigned)(N * C));
+    act_bwd_partial_kernel<<<grid, 256, 0, as_stream(stream)>>>(raw, gy, residual, scale, shift, (double *)workspace, C, S,
+                                                                raw_batch_stride, gy_batch_stride, res_batch_stride,
+                                                                per_sample, flags, kNormSplits);
+    int rc = check_launch("snvc_act_backward_reduce(partial)");
+    if (rc) return rc;
+    act_bwd_fold_kernel<<<dim3((unsigned)ceil_div<int64_t>(N * C, 128)), 128, 0, as_stream(stream)>>>(
+        (const double *)workspace, sums, N * C, kNormSplits);
+    return check_launch("snvc_act_backward_reduce(fold)");
+}
+
+int snvc_act_backward_apply(const float *raw, const float *gy, const float *residual, const float *scale,
+                            const float *shift, const float *coef_g, const float *coef_raw, const float *coef_const,
+                            float *draw, float *g_out, int64_t N, int64_t C, int64_t S, int64_t raw_batch_stride,
+                            int64_t gy_batch_stride, int64_t res_batch_stride, int per_sample, int flags, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_apply: negative size");
+    if (N == 0 || C == 0 || S == 0) return SNVC_OK;
+    if (!raw || !gy || !coef_g || !draw) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_apply: null pointer");
+    if ((flags & SNVC_EPI_ADD_PRE) && !residual) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_apply: ADD_PRE needs the residual");
+    if (C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_act_backward_apply: C or N > 65535");
+    if (!(flags & SNVC_EPI_ADD_PRE)) residual = nullptr;
+    if (raw_batch_stride == 0) raw_batch_stride = C * S;
+    if (gy_batch_stride == 0) gy_batch_stride = C * S;
+    if (res_batch_stride == 0) res_batch_stride = C * S;
+    dim3 grid(stream_blocks(S, N * C), (unsigned)C, (unsigned)N);
+    act_bwd_apply_kernel<<<grid, 256, 0, as_stream(stream)>>>(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const,
+                                                              draw, g_out, C, S, raw_batch_stride, gy_batch_stride,
+                                                              res_batch_stride, per_sample, flags);
+    return check_launch("snvc_act_backward_apply");
 }
 
 int snvc_affine_act(const float *x, const float *scale, const float *shift, const float *residual,

@@ -32,14 +32,6 @@ from .. import ops
 from ..ops import EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID
 
 
-def _no_autograd(x: torch.Tensor, mod: nn.Module):
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
-        raise NotImplementedError(
-            "snvc_amd 3D convolutions are forward-only in this release: call under torch.no_grad() "
-            "(the reference's inference loop does, tools/inference_agnostic.py:366). "
-            "Training backward (dgrad/wgrad kernels) is the next row of the build plan.")
-
-
 def _first_arg(k):
     return k[0] if isinstance(k, (tuple, list)) else k
 
@@ -103,35 +95,28 @@ def _folded_bn(bn: nn.BatchNorm3d, plan: _Plan):
     return plan.scale, plan.bias
 
 
-def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,
-                 residual: Optional[torch.Tensor] = None, residual_after_act=False, out=None,
-                 plan: Optional[_Plan] = None) -> torch.Tensor:
-    """act(norm(conv(x)) [+ residual]) [+ residual] on the HIP kernels.
-
-    ``residual_after_act=False``: relu(norm(conv(x)) + residual)   (hourglass skips, submodule.py:154,162)
-    ``residual_after_act=True`` : relu(norm(conv(x))) + residual   (vernier.py:418-419)
-    """
-    owner = norm if norm is not None else conv
-    _no_autograd(x, conv)
-    if plan is None:  # one plan per device (replicas made by nn.DataParallel share __dict__ entries)
-        plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(x.device, _Plan())
-    if conv.weight.device != x.device:
-        raise RuntimeError(f"conv3d weight is on {conv.weight.device} but the input is on {x.device}")
-    layer = _get_layer(conv, plan)
-    flags = (EPI_RELU if relu else 0) | (EPI_SIGMOID if sigmoid else 0)
-    if residual is not None:
-        flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
+def _norm_forward(layer, norm, plan, x, residual, flags, out, keep_raw):
+    """Shared forward: returns (y, raw, scale, shift, mean, var, per_sample).  `raw` is the conv
+    output before the affine/activation (None when the single fused launch was used)."""
     if norm is None:
-        return layer(x, None, None, residual, flags, out)
+        if keep_raw and (flags or residual is not None):
+            raw = layer(x, None, None, None, 0, None)
+            return ops.affine_act(raw, None, None, residual, flags, out=out), raw, None, None, None, None, False
+        y = layer(x, None, None, residual, flags, out)
+        return y, (y if keep_raw else None), None, None, None, None, False
     if isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None):
         scale, bias = _folded_bn(norm, plan)
-        return layer(x, scale, bias, residual, flags, out)
+        if keep_raw:
+            raw = layer(x, None, None, None, 0, None)
+            return ops.affine_act(raw, scale, bias, residual, flags, out=out), raw, scale, bias, None, None, False
+        return layer(x, scale, bias, residual, flags, out), None, scale, bias, None, None, False
     # statistics of the conv output are needed first: conv -> stats -> normalise (+res, +act)
     raw = layer(x, None, None, None, 0, None)
     c = raw.size(1)
+    dst = out if out is not None else (None if keep_raw else raw)
     if isinstance(norm, nn.GroupNorm):
-        scale, shift, _, _ = ops.norm_stats(raw, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
-        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=out if out is not None else raw)
+        scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
+        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=dst), raw, scale, shift, mean, var, True
     if isinstance(norm, nn.BatchNorm3d):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, c, False, norm.eps)
         if norm.training and norm.track_running_stats and norm.running_mean is not None:
@@ -141,8 +126,152 @@ def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *,
                 m = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked)
                 norm.running_mean.mul_(1 - m).add_(mean[0], alpha=m)
                 norm.running_var.mul_(1 - m).add_(var[0] * (cnt / max(cnt - 1, 1)), alpha=m)
-        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=out if out is not None else raw)
-    raise NotImplementedError(f"norm layer {type(owner).__name__} is not on the path")
+        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst), raw, scale, shift, mean, var, False
+    raise NotImplementedError(f"norm layer {type(norm).__name__} is not on the path")
+
+
+def _dgrad_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
+    """The data gradient of a layer is another layer of the same kernel family:
+    Conv3d stride 1  -> Conv3d with taps flipped and channels transposed;
+    Conv3d(k3,s2,p1) -> ConvTranspose3d(k3,s2,p1,op1) over the SAME weight memory;
+    ConvTranspose3d  -> Conv3d(k3,s2,p1) over the SAME weight memory."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device)
+    if getattr(plan, "dgrad", None) is None or plan.dgrad_key != key:
+        k, s, p, d, transposed = _conv_geometry(conv)
+        wd = w.detach()
+        if transposed:
+            plan.dgrad = ops.Conv3dLayer(wd, 3, 2, 1, 1, False)
+        elif s == 1:
+            plan.dgrad = ops.Conv3dLayer(wd.transpose(0, 1).flip(2, 3, 4).contiguous(), k, 1, p, d, False)
+        elif s == 2 and k == 3 and p == 1 and d == 1:
+            plan.dgrad = ops.Conv3dLayer(wd, 3, 2, 1, 1, True)
+        else:
+            raise NotImplementedError("dgrad of this strided convolution is not on the path")
+        plan.dgrad_key = key
+    return plan.dgrad
+
+
+class _ConvNormActFn(torch.autograd.Function):
+    """Differentiable fused layer: forward = conv (+norm) (+residual) (+activation) on the HIP
+    kernels, backward = HIP epilogue-backward reductions, dgrad (forward kernels) and wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, conv, norm, flags, plan):
+        layer = _get_layer(conv, plan)
+        y, raw, scale, shift, mean, var, per_sample = _norm_forward(layer, norm, plan, x, residual, flags, None, True)
+        ctx.conv, ctx.norm, ctx.flags, ctx.plan, ctx.per_sample = conv, norm, flags, plan, per_sample
+        ctx.has_res = residual is not None
+        ctx.train_stats = mean is not None
+        res_saved = residual if (residual is not None and (flags & EPI_ADD_PRE)) else None
+        ctx.save_for_backward(x, raw, scale, shift, mean, var, res_saved)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, raw, scale, shift, mean, var, res = ctx.saved_tensors
+        conv, norm, flags, plan = ctx.conv, ctx.norm, ctx.flags, ctx.plan
+        gy = gy.contiguous()
+        n, c = raw.shape[0], raw.shape[1]
+        s = raw[0, 0].numel()
+        dev = raw.device
+        needs = ctx.needs_input_grad
+        act_flags = flags & (EPI_RELU | EPI_SIGMOID | EPI_ADD_PRE)
+        dgamma = dbeta = None
+        if norm is None:
+            coef_g = torch.ones(c, device=dev)
+            coef_raw = coef_const = None
+            per_sample = False
+        else:
+            per_sample = ctx.per_sample
+            sums = ops.act_backward_reduce(raw, gy, res, scale, shift, act_flags, per_sample)   # [n, c, 2] fp64
+            gam = norm.weight.detach().double() if norm.weight is not None else torch.ones(c, device=dev, dtype=torch.float64)
+            if isinstance(norm, nn.GroupNorm):
+                groups = norm.num_groups
+                cpg = c // groups
+                mu = mean.double().repeat_interleave(cpg, dim=1)                       # [n, c]
+                rstd = torch.rsqrt(var.double() + norm.eps).repeat_interleave(cpg, dim=1)
+                sg, sgr = sums[..., 0], sums[..., 1]
+                sgx = rstd * (sgr - mu * sg)                                          # sum g * xhat per (n, c)
+                p1 = (gam * sg).view(n, groups, cpg).sum(2).repeat_interleave(cpg, dim=1)
+                p2 = (gam * sgx).view(n, groups, cpg).sum(2).repeat_interleave(cpg, dim=1)
+                m = float(cpg * s)
+                a_ = rstd * gam
+                b_ = -rstd * rstd * p2 / m
+                c_ = -rstd * p1 / m - b_ * mu
+                dgamma, dbeta = sgx.sum(0), sg.sum(0)
+            else:
+                sg, sgr = sums[..., 0].sum(0), sums[..., 1].sum(0)                    # [c]
+                if ctx.train_stats:
+                    mu, rstd = mean[0].double(), torch.rsqrt(var[0].double() + norm.eps)
+                    sgx = rstd * (sgr - mu * sg)
+                    m = float(n * s)
+                    a_ = gam * rstd
+                    b_ = -gam * rstd * rstd * sgx / m
+                    c_ = -gam * rstd * sg / m - b_ * mu
+                else:   # frozen statistics: a plain per-channel affine
+                    mu, rstd = norm.running_mean.double(), torch.rsqrt(norm.running_var.double() + norm.eps)
+                    sgx = rstd * (sgr - mu * sg)
+                    a_, b_, c_ = gam * rstd, None, None
+                dgamma, dbeta = sgx, sg
+            coef_g = a_.float().contiguous()
+            coef_raw = b_.float().contiguous() if b_ is not None else None
+            coef_const = c_.float().contiguous() if c_ is not None else None
+            if norm.weight is None:
+                dgamma = dbeta = None
+        want_g = ctx.has_res and bool(flags & EPI_ADD_PRE) and needs[4]
+        if norm is None and not act_flags:
+            draw, g_out = gy, gy
+        else:
+            draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
+                                                 per_sample, want_g)
+        gres = None
+        if ctx.has_res and needs[4]:
+            gres = g_out if (flags & EPI_ADD_PRE) else gy
+        # data and weight gradients
+        k, st, p, d, transposed = _conv_geometry(conv)
+        gx = _dgrad_layer(conv, plan)(draw) if needs[0] else None
+        gw = None
+        if needs[1]:
+            if transposed:   # roles swapped, see snvc_conv3d_wgrad
+                gw = ops.conv3d_wgrad(draw, x, 3, 2, 1, 1)
+            else:
+                gw = ops.conv3d_wgrad(x, draw, k, st, p, d)
+        dg = dgamma.float() if (dgamma is not None and needs[2]) else None
+        db = dbeta.float() if (dbeta is not None and needs[3]) else None
+        return gx, gw, dg, db, gres, None, None, None, None
+
+
+def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,
+                 residual: Optional[torch.Tensor] = None, residual_after_act=False, out=None,
+                 plan: Optional[_Plan] = None) -> torch.Tensor:
+    """act(norm(conv(x)) [+ residual]) [+ residual] on the HIP kernels.
+
+    ``residual_after_act=False``: relu(norm(conv(x)) + residual)   (hourglass skips, submodule.py:154,162)
+    ``residual_after_act=True`` : relu(norm(conv(x))) + residual   (vernier.py:418-419)
+
+    Under autograd (training, BASELINE.json configs[3]) the layer is a differentiable
+    ``torch.autograd.Function`` whose backward also runs on the HIP kernels.
+    """
+    if plan is None:  # one plan per device (replicas made by nn.DataParallel share __dict__ entries)
+        plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(x.device, _Plan())
+    if conv.weight.device != x.device:
+        raise RuntimeError(f"conv3d weight is on {conv.weight.device} but the input is on {x.device}")
+    flags = (EPI_RELU if relu else 0) | (EPI_SIGMOID if sigmoid else 0)
+    if residual is not None:
+        flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
+    tracked = [x, conv.weight] + ([norm.weight, norm.bias] if norm is not None and getattr(norm, "weight", None) is not None else [])
+    if residual is not None:
+        tracked.append(residual)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tracked):
+        gamma = norm.weight if norm is not None else None
+        beta = norm.bias if norm is not None else None
+        if out is not None:
+            raise NotImplementedError("`out=` (in-place concat slices) is an inference-only fusion")
+        return _ConvNormActFn.apply(x, conv.weight, gamma, beta, residual, conv, norm, flags, plan)
+    layer = _get_layer(conv, plan)
+    return _norm_forward(layer, norm, plan, x, residual, flags, out, False)[0]
 
 
 class ConvBN3d(nn.Sequential):

@@ -19,7 +19,7 @@ from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, C
 
 __all__ = [
     "cost_volume_forward", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
-    "Conv3dLayer", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
+    "Conv3dLayer", "conv3d_wgrad", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
     "points_in_boxes_gpu", "points_in_boxes_cpu",
     "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID",
@@ -233,6 +233,63 @@ class Conv3dLayer:
             check(_lib.lib().snvc_conv3d_forward(ctypes.byref(d), _ptr(x), _ptr(self.packed), _ptr(scale), _ptr(bias),
                                                  _ptr(residual), _ptr(out), _stream(x)), "snvc_conv3d_forward")
         return out
+
+
+def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: int) -> torch.Tensor:
+    """dW[cg][cx][k^3] = sum over batch and voxels of g_small[cg] * x_big[cx] (shifted by the tap):
+    weight gradient of Conv3d(x_big -> g_small's shape); see snvc_conv3d_wgrad for the
+    ConvTranspose3d usage (roles swapped).  Deterministic."""
+    _gpu(x_big, "x"); _gpu(g_small, "g")
+    if not _dense_inner(x_big):
+        x_big = x_big.contiguous()
+    if not _dense_inner(g_small):
+        g_small = g_small.contiguous()
+    d = Conv3dDesc()
+    d.N, d.Cin = x_big.shape[0], x_big.shape[1]
+    d.Din, d.Hin, d.Win = x_big.shape[2:]
+    d.Cout = g_small.shape[1]
+    d.Dout, d.Hout, d.Wout = g_small.shape[2:]
+    d.ksize, d.stride, d.dilation, d.pad = ksize, stride, dilation, pad
+    d.transposed, d.flags = 0, 0
+    d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = _batch_stride(x_big), _batch_stride(g_small), 0
+    nbytes = _lib.lib().snvc_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x_big.device)
+    dw = torch.empty((d.Cout, d.Cin, ksize, ksize, ksize), dtype=torch.float32, device=x_big.device)
+    with torch.cuda.device(x_big.device):
+        check(_lib.lib().snvc_conv3d_wgrad(ctypes.byref(d), _ptr(x_big), _ptr(g_small), _ptr(dw), _ptr(ws),
+                                           _stream(x_big)), "snvc_conv3d_wgrad")
+    return dw
+
+
+def act_backward_reduce(raw, gy, residual, scale, shift, flags: int, per_sample: bool) -> torch.Tensor:
+    """Per (n, c): [sum(g), sum(g*raw)] in fp64, g = gy * act'(raw*scale + shift [+ residual])."""
+    n, c = raw.shape[0], raw.shape[1]
+    s = raw[0, 0].numel()
+    sums = torch.empty((n, c, 2), dtype=torch.float64, device=raw.device)
+    ws = torch.empty(_lib.lib().snvc_act_backward_workspace_bytes(n, c), dtype=torch.uint8, device=raw.device)
+    with torch.cuda.device(raw.device):
+        check(_lib.lib().snvc_act_backward_reduce(_ptr(raw), _ptr(gy), _ptr(residual), _ptr(scale), _ptr(shift),
+                                                  _ptr(sums), _ptr(ws), n, c, s, _batch_stride(raw), _batch_stride(gy),
+                                                  _batch_stride(residual) if residual is not None else 0,
+                                                  1 if per_sample else 0, flags, _stream(raw)),
+              "snvc_act_backward_reduce")
+    return sums
+
+
+def act_backward_apply(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const, flags: int, per_sample: bool,
+                       want_g: bool):
+    """draw = coef_g*g + coef_raw*raw + coef_const (per channel or per (n,c)); optionally also g."""
+    n, c = raw.shape[0], raw.shape[1]
+    s = raw[0, 0].numel()
+    draw = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
+    g_out = torch.empty(raw.shape, dtype=torch.float32, device=raw.device) if want_g else None
+    with torch.cuda.device(raw.device):
+        check(_lib.lib().snvc_act_backward_apply(_ptr(raw), _ptr(gy), _ptr(residual), _ptr(scale), _ptr(shift),
+                                                 _ptr(coef_g), _ptr(coef_raw), _ptr(coef_const), _ptr(draw), _ptr(g_out),
+                                                 n, c, s, _batch_stride(raw), _batch_stride(gy),
+                                                 _batch_stride(residual) if residual is not None else 0,
+                                                 1 if per_sample else 0, flags, _stream(raw)), "snvc_act_backward_apply")
+    return draw, g_out
 
 
 # ------------------------------------------------------------------------------ norm / elementwise
