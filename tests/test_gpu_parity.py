@@ -187,6 +187,16 @@ def test_voxel_gather_vs_torch_ref_edge_cases():
     check(got[m].numpy(), exp[m].numpy(), 1e-6, "gather edge cases")
 
 
+def test_voxel_gather_bit_exact_vs_numpy_oracle():
+    from oracle import numpy_ref as NR
+    from snvc_amd import ops
+    grid, gn, n, fh, fw, seed = GC.TRUNK_CASES["G1"]
+    lf, rf, gpl, gpr = GC.trunk_inputs(n, 32, fh, fw, grid, seed + 1)
+    exp = NR.sample_2d_feat(lf.numpy(), rf.numpy(), gpl.numpy(), gpr.numpy(), GC.RESOLUTION)
+    got = ops.voxel_gather_forward(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()), GC.RESOLUTION).cpu().numpy()
+    assert np.array_equal(got, exp), np.abs(got - exp).max()
+
+
 def test_voxel_gather_backward_adjoint():
     from snvc_amd import ops
     r = np.random.default_rng(10)
