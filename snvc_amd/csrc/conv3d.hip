@@ -724,7 +724,8 @@ constexpr Plan plan_of(int kind) { return Plan{Cfg::MI, Cfg::KC, Cfg::TD, Cfg::T
 int make_plan(const snvc_conv3d_desc &d, Plan &p) {
     if (d.N < 0 || d.Cin <= 0 || d.Cout <= 0 || d.Din <= 0 || d.Hin <= 0 || d.Win <= 0)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: sizes must be positive");
-    const bool wide = d.Cout > 32;  // MI = 2 handles 64 output channels per workgroup
+    const char *force = getenv("SNVC_FORCE_MI1");   // development knob
+    const bool wide = d.Cout > 32 && !(force && force[0] == '1');  // MI = 2 handles 64 output channels per workgroup
     if (d.transposed) {
         if (d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.dilation != 1)
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: transposed conv supports k3,s2,p1,op1 only");
