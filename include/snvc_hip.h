@@ -85,6 +85,22 @@ SNVC_API int snvc_voxel_gather_backward(const float *grad_out, const float *l_pt
                                         float res_x, float res_y, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * a11  projection of the 3D sampling grid into the RoI crops (producer of a3's coordinates)
+ * replaces: refinementDataset._init_3d_grid / _to_cam / _generate_grid_proj
+ *   (snvc/dataset/KITTIRefinement_dataset.py:267-282,828-868) + Calibration.project_rect_to_image
+ *   (snvc/dataset/kitti_util.py:282-293) + affine_transform (snvc/utils/img_proc.py:71-74),
+ *   which run in numpy float64 on the host and are then copied to the device.
+ *   samples [N,7] (h,w,l,x,y,z,ry) f64, P_left / P_right [3,4] f64, trans_l / trans_r [N,2,3] f64
+ *   (all DEVICE pointers), ranges_host = {x_min,x_max,y_min,y_max,z_min,z_max} (HOST pointer),
+ *   grid (nh,nw,nl) -> out_l, out_r [N,2,V] f32 (x row, y row; V = nh*nw*nl, index (ih*nw+iw)*nl+il),
+ *   grid_cam [N,V,3] f64 camera-frame points (may be NULL).
+ * ---------------------------------------------------------------------------------- */
+SNVC_API int snvc_grid_projection(const double *samples, const double *P_left, const double *P_right,
+                                  const double *trans_l, const double *trans_r,
+                                  const double *ranges_host, int nh, int nw, int nl, float *out_l,
+                                  float *out_r, double *grid_cam, int N, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * a4-a7  3D convolution / transposed convolution with fused epilogue
  * replaces: nn.Conv3d / nn.ConvTranspose3d (+ eval-mode BatchNorm3d or a per-channel affine)
  *   (+ residual add) (+ ReLU / Sigmoid) as composed by convbn_3d, hourglass,

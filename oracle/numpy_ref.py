@@ -54,3 +54,39 @@ def sample_2d_feat(left, right, l_pts, r_pts, resolution):
                 acc = term if acc is None else (acc + term).astype(f32)
             out[b, side * f:(side + 1) * f] = acc
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# a11: the host-side producer of the path's coordinates
+# --------------------------------------------------------------------------------------------
+def init_3d_grid(x_range, y_range, z_range, grid_resolution):
+    """refinementDataset._init_3d_grid (snvc/dataset/KITTIRefinement_dataset.py:267-282):
+    grid_3d [3, nh, nw, nl] float64, voxel order (ih*nw + iw)*nl + il."""
+    nh, nw, nl = grid_resolution
+    x_pts = np.linspace(x_range[0], x_range[1], nw)
+    y_pts = np.linspace(y_range[0], y_range[1], nh)
+    z_pts = np.linspace(z_range[0], z_range[1], nl)
+    gx, gy, gz = np.meshgrid(x_pts, y_pts, z_pts, indexing="xy")
+    return np.concatenate([gx[None], gy[None], gz[None]])
+
+
+def grid_projection(samples, P_left, P_right, trans_l, trans_r, grid_3d):
+    """refinementDataset._to_cam + _generate_grid_proj (KITTIRefinement_dataset.py:828-868) with
+    Calibration.project_rect_to_image (dataset/kitti_util.py:282-293) and affine_transform
+    (utils/img_proc.py:71-74).  samples [N,7] = (h,w,l,x,y,z,ry); P_* [3,4]; trans_* [N,2,3].
+    Returns (coord_l [N,2,V] f32, coord_r [N,2,V] f32, grid_cam [N,V,3] f64)."""
+    pts = grid_3d.reshape(3, -1)
+    cl, cr, g3 = [], [], []
+    for i, s in enumerate(samples):
+        ry = s[6] + 0.5 * np.pi
+        rot = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+        x, y, z = s[3:6]
+        cam = (rot @ pts + np.array([[x], [y - s[0] * 0.5], [z]])).T          # [V,3]
+        g3.append(cam[None])
+        hom = np.hstack([cam, np.ones((len(cam), 1))])
+        for P, tr, dst in ((P_left, trans_l[i], cl), (P_right, trans_r[i], cr)):
+            p2 = hom @ P.T
+            uv = p2[:, :2] / p2[:, 2:3]
+            h2 = np.concatenate([uv, np.ones((len(uv), 1))], axis=1)
+            dst.append((tr @ h2.T).astype(np.float32)[None])
+    return np.concatenate(cl), np.concatenate(cr), np.concatenate(g3)

@@ -36,6 +36,7 @@ SIGNATURES = {
     "snvc_cost_volume_backward": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
     "snvc_voxel_gather_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
     "snvc_voxel_gather_backward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
+    "snvc_grid_projection": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_p, c_p, c_int, c_p]),
     "snvc_conv3d_packed_weight_count": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
     "snvc_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p]),
     "snvc_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -29,7 +29,10 @@ REF = os.environ.get("SNVC_REFERENCE", "/root/reference")
 
 sys.dont_write_bytecode = True
 os.environ.setdefault("MPLBACKEND", "Agg")
-sys.modules.setdefault("cv2", types.ModuleType("cv2"))  # only used inside functions never called here
+# modules the reference imports at module scope but never touches on the code paths used here
+for _m in ("cv2", "torchvision", "torchvision.transforms", "imageio", "numba", "mayavi", "mayavi.mlab"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
 sys.path.insert(0, REF)
 
 import snvc.models.submodule as ref_sub  # noqa: E402
@@ -190,6 +193,29 @@ with torch.no_grad():
         yr = ref_parts.classifier(v + v1)
         check(yr, ours(vol), name)
         out[f"global/{name}"] = yr.numpy()
+
+# ------------------------------------------------------------- a11: grid projection producer
+import snvc.dataset.KITTIRefinement_dataset as ref_ds  # noqa: E402
+import snvc.dataset.kitti_util as ref_ku  # noqa: E402
+from oracle import numpy_ref as NR  # noqa: E402
+
+gp = GC.grid_proj_case()
+dummy = types.SimpleNamespace(cfg=types.SimpleNamespace(x_range=gp["x_range"], y_range=gp["y_range"],
+                                                        z_range=gp["z_range"], grid_resolution=gp["grid"]))
+ref_ds.refinementDataset._init_3d_grid(dummy)
+assert np.array_equal(dummy.grid_3d, NR.init_3d_grid(gp["x_range"], gp["y_range"], gp["z_range"], gp["grid"]))
+dummy._to_cam = lambda pts, sample: ref_ds.refinementDataset._to_cam(dummy, pts, sample)
+calib_l = ref_ku.Calibration(gp["P_left"], np.eye(3, 4), np.eye(3))
+calib_r = ref_ku.Calibration(gp["P_right"], np.eye(3, 4), np.eye(3))
+meta = {"trans_l": gp["trans_l"], "trans_r": gp["trans_r"]}
+cl, cr, g3 = ref_ds.refinementDataset._generate_grid_proj(dummy, gp["samples"], calib_l, calib_r, meta)
+ol, orr, og = NR.grid_projection(gp["samples"], gp["P_left"], gp["P_right"], gp["trans_l"], gp["trans_r"], dummy.grid_3d)
+assert cl.dtype == np.float32 and cl.shape == ol.shape
+assert np.array_equal(cl, ol) and np.array_equal(cr, orr) and np.array_equal(g3, og), "grid projection restatement differs"
+out["gridproj/left_sub"] = cl[:, :, ::37]
+out["gridproj/right_sub"] = cr[:, :, ::37]
+out["gridproj/sum"] = np.array([cl.astype(np.float64).sum(), cr.astype(np.float64).sum(), np.abs(cl).astype(np.float64).sum()])
+out["gridproj/grid3d_sub"] = g3[:, ::97]
 
 path = os.path.join(HERE, "reference_outputs.npz")
 np.savez_compressed(path, **out)

@@ -70,3 +70,27 @@ def trunk_inputs(n, f, fh, fw, grid, seed):
 
 def load_golden():
     return np.load(GOLDEN_NPZ)
+
+
+def grid_proj_case():
+    """a11: synthetic KITTI-like calibration + three box proposals + RoI-crop affines."""
+    P2 = np.array([7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01,
+                   0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01,
+                   0.0, 0.0, 1.0, 2.745884e-03]).reshape(3, 4)
+    P3 = P2.copy()
+    P3[0, 3] = -3.395242e+02
+    P3[1, 3] = 2.199936e+00
+    samples = np.array([[1.52, 1.63, 3.88, 2.10, 1.65, 14.2, -1.52],
+                        [1.60, 1.70, 4.10, -6.30, 1.80, 28.7, 0.31],
+                        [1.45, 1.58, 3.60, 0.40, 1.55, 8.9, 1.62]])
+    r = np.random.default_rng(777)
+    trans_l = np.zeros((3, 2, 3))
+    trans_r = np.zeros((3, 2, 3))
+    for t in (trans_l, trans_r):
+        t[:, 0, 0] = r.uniform(1.5, 3.0, 3)
+        t[:, 1, 1] = r.uniform(1.5, 3.0, 3)
+        t[:, 0, 2] = r.uniform(-1500, -200, 3)
+        t[:, 1, 2] = r.uniform(-500, -100, 3)
+        t[:, 0, 1] = r.uniform(-0.01, 0.01, 3)
+    return dict(P_left=P2, P_right=P3, samples=samples, trans_l=trans_l, trans_r=trans_r,
+                x_range=(-1.6, 1.6), y_range=(-0.8, 0.8), z_range=(-2.4, 2.4), grid=(16, 32, 48))

@@ -213,6 +213,38 @@ def test_voxel_gather_backward_adjoint():
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
 
 
+def test_grid_projection_vs_oracle_and_golden(G):
+    """a11: grid points -> camera frame -> P2/P3 -> crop affine, on the device, against the numpy
+    restatement (itself bit-equal to the reference's methods, make_golden.py) and the golden samples."""
+    import types
+    from oracle import numpy_ref as NR
+    from snvc_amd.geometry import GridProjector
+    gp = GC.grid_proj_case()
+    cfg = types.SimpleNamespace(x_range=gp["x_range"], y_range=gp["y_range"], z_range=gp["z_range"],
+                                grid_resolution=gp["grid"])
+    proj = GridProjector(cfg)
+    cl, cr, g3 = proj.generate(gp["samples"], gp["P_left"], gp["P_right"], gp["trans_l"], gp["trans_r"], dev(),
+                               with_grid_3d=True)
+    el, er, eg = NR.grid_projection(gp["samples"], gp["P_left"], gp["P_right"], gp["trans_l"], gp["trans_r"],
+                                    NR.init_3d_grid(gp["x_range"], gp["y_range"], gp["z_range"], gp["grid"]))
+    cl, cr, g3 = cl.cpu().numpy(), cr.cpu().numpy(), g3.cpu().numpy()
+    assert cl.dtype == np.float32 and cl.shape == el.shape == (3, 2, 16 * 32 * 48)
+    # fp64 pipeline rounded to fp32 once: equal except where the fp64 value sits on a float32 tie
+    for got, exp in ((cl, el), (cr, er)):
+        np.testing.assert_allclose(got, exp, rtol=0, atol=2e-4)      # pixels
+        assert (got == exp).mean() > 0.9999
+    np.testing.assert_allclose(g3, eg, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(cl[:, :, ::37], G["gridproj/left_sub"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(cr[:, :, ::37], G["gridproj/right_sub"], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(g3[:, ::97], G["gridproj/grid3d_sub"], rtol=1e-13, atol=1e-13)
+    # and it plugs straight into the gather (same tensors the dataset would have produced)
+    from snvc_amd import ops
+    lf = torch.randn(3, 8, 16, 16, device=dev())
+    a = ops.voxel_gather_forward(lf, lf, torch.from_numpy(cl).to(dev()), torch.from_numpy(cr).to(dev()), (64, 64))
+    b = ops.voxel_gather_forward(lf, lf, torch.from_numpy(el).to(dev()), torch.from_numpy(er).to(dev()), (64, 64))
+    assert (a - b).abs().max().item() < 1e-3
+
+
 # =============================================================================== a4
 @pytest.mark.parametrize("name", list(GC.CONV_CASES))
 def test_convbn_3d_vs_golden(name, G):

@@ -31,3 +31,19 @@ def test_numpy_gather_matches_golden():
     lf, rf, gpl, gpr = GC.trunk_inputs(n, 32, fh, fw, grid, seed + 1)
     vox = NR.sample_2d_feat(lf.numpy(), rf.numpy(), gpl.numpy(), gpr.numpy(), GC.RESOLUTION).reshape(n, 64, *grid)
     np.testing.assert_allclose(vox[:, ::7, ::3, ::5, ::5], G["trunk/G1/voxel_sub"], rtol=0, atol=2e-6)
+
+
+def test_grid_projection_oracle_matches_reference_golden():
+    """oracle.numpy_ref.grid_projection was asserted bit-equal to the reference's _init_3d_grid /
+    _to_cam / _generate_grid_proj by make_golden.py; here against the committed samples."""
+    G = GC.load_golden()
+    gp = GC.grid_proj_case()
+    g = NR.init_3d_grid(gp["x_range"], gp["y_range"], gp["z_range"], gp["grid"])
+    assert g.shape == (3, 16, 32, 48) and g[0, 0, :, 0].tolist() == np.linspace(-1.6, 1.6, 32).tolist()
+    cl, cr, g3 = NR.grid_projection(gp["samples"], gp["P_left"], gp["P_right"], gp["trans_l"], gp["trans_r"], g)
+    assert cl.dtype == np.float32 and cl.shape == (3, 2, 16 * 32 * 48)
+    np.testing.assert_allclose(cl[:, :, ::37], G["gridproj/left_sub"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(cr[:, :, ::37], G["gridproj/right_sub"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(g3[:, ::97], G["gridproj/grid3d_sub"], rtol=1e-13, atol=1e-13)
+    s = G["gridproj/sum"]
+    assert abs(cl.astype(np.float64).sum() - s[0]) <= 1e-7 * s[2]
