@@ -38,15 +38,21 @@ struct WgradArgs {
     int64_t x_bs, g_bs;
 };
 
-template <int KS_, int STRIDE_, int DIL_, int TH_>
+// A workgroup covers a CHUNK of taps: KDG kernel depth-slices x KHG kernel rows x all KS columns
+// (<= 28 taps = 7 per wave); blockIdx.z enumerates the chunks, so 5^3 and 7^3 kernels only widen
+// the grid, not the register or LDS footprint.
+template <int KS_, int STRIDE_, int DIL_, int TH_, int KDG_, int KHG_>
 struct WgradCfg {
-    static constexpr int KS = KS_, STRIDE = STRIDE_, DIL = DIL_;
+    static constexpr int KS = KS_, STRIDE = STRIDE_, DIL = DIL_, KDG = KDG_, KHG = KHG_;
     static constexpr int PAD = DIL * (KS - 1) / 2;
     static constexpr int TAPS = KS * KS * KS;
-    static constexpr int NT = (TAPS + 3) / 4;          // taps per wave
+    static constexpr int CHUNK_TAPS = KDG * KHG * KS;
+    static constexpr int NT = (CHUNK_TAPS + 3) / 4;    // taps per wave
+    static constexpr int CH_D = KS / KDG, CH_H = (KS + KHG - 1) / KHG;   // chunks along kd / kh
     static constexpr int TH = TH_, TW = 32;            // output tile: 1 x TH x 32 voxels = 32*TH K-slots
-    static constexpr int IN_D = (KS - 1) * DIL + 1;
-    static constexpr int IN_H = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
+    static constexpr int IN_D = (KDG - 1) * DIL + 1;
+    static constexpr int IN_H = (TH - 1) * STRIDE + (KHG - 1) * DIL + 1;
+    static_assert(KS % KDG == 0, "depth chunks must tile the kernel");
     static constexpr int IN_W = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     static constexpr int XV = IN_D * IN_H * IN_W;      // staged X voxels per channel
     static constexpr int XS = XV | 1;                  // odd row stride
@@ -59,7 +65,8 @@ struct WgradCfg {
 template <class Cfg>
 __global__ void __launch_bounds__(256, 2)
 conv3d_wgrad_kernel(const WgradArgs a) {
-    constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, PAD = Cfg::PAD, TAPS = Cfg::TAPS, NT = Cfg::NT;
+    constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, PAD = Cfg::PAD, NT = Cfg::NT;
+    constexpr int KDG = Cfg::KDG, KHG = Cfg::KHG;
     constexpr int IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, XV = Cfg::XV, XS = Cfg::XS, GV = Cfg::GV, GS = Cfg::GS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *xl = lds;             // [32][XS]
@@ -75,13 +82,19 @@ conv3d_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    // per-wave tap table: tap = wave + 4*t  ->  LDS offset of its window inside the staged X tile
-    int tap_off[NT];
+    // this workgroup's tap chunk: kernel depth-slices [kd0, kd0+KDG), rows [kh0, kh0+khn), all columns
+    const int kd0 = (blockIdx.z / Cfg::CH_H) * KDG, kh0 = (blockIdx.z % Cfg::CH_H) * KHG;
+    const int khn = KS - kh0 < KHG ? KS - kh0 : KHG;
+    const int chunk_taps = KDG * khn * KS;
+    // per-wave tap table: local tap = wave + 4*t -> LDS offset of its window inside the staged X tile
+    int tap_off[NT], tap_glob[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tap = wave + 4 * t;
-        const int kd = tap / (KS * KS), kh = (tap / KS) % KS, kw = tap % KS;
-        tap_off[t] = tap < TAPS ? (kd * DIL * IN_H + kh * DIL) * IN_W + kw * DIL : 0;
+        const int lt = wave + 4 * t;
+        const int kw = lt % KS, kh = (lt / KS) % khn, kd = lt / (KS * khn);
+        const bool ok = lt < chunk_taps;
+        tap_off[t] = ok ? (kd * DIL * IN_H + kh * DIL) * IN_W + kw * DIL : 0;
+        tap_glob[t] = ok ? ((kd0 + kd) * KS + kh0 + kh) * KS + kw : -1;
     }
 
     const int64_t in_hw = (int64_t)a.Hi * a.Wi, in_dhw = in_hw * a.Di;
@@ -95,7 +108,7 @@ conv3d_wgrad_kernel(const WgradArgs a) {
         const int od = (int)((tile / ((int64_t)a.tiles_w * a.tiles_h)) % a.Do);
         const int64_t n = tile / ((int64_t)a.tiles_w * a.tiles_h * a.Do);
         const int oh0 = th * Cfg::TH, ow0 = tw * 32;
-        const int id0 = od * S - PAD, ih0 = oh0 * S - PAD, iw0 = ow0 * S - PAD;
+        const int id0 = od * S - PAD + kd0 * DIL, ih0 = oh0 * S - PAD + kh0 * DIL, iw0 = ow0 * S - PAD;
         const float *xn = a.x + n * a.x_bs + (int64_t)cx0 * in_dhw;
         const float *gn = a.g + n * a.g_bs + (int64_t)cg0 * out_dhw;
         __syncthreads();   // previous tile fully consumed
@@ -147,15 +160,15 @@ conv3d_wgrad_kernel(const WgradArgs a) {
         }
     }
 
-    // ---- partial slab: [p][pair][tap][cg 32][cx 32]
-    float *pp = a.partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (4 * NT) * 1024;
+    // ---- partial slab: [p][pair][tap (global index)][cg 32][cx 32]
+    float *pp = a.partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (int64_t)Cfg::TAPS * 1024;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int tap = wave + 4 * t;
+        if (tap_glob[t] < 0) continue;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;   // cg
-            pp[(tap * 32 + row) * 32 + ch] = acc[t][r];            // col = cx = lane & 31
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;           // cg
+            pp[((int64_t)tap_glob[t] * 32 + row) * 32 + ch] = acc[t][r];  // col = cx = lane & 31
         }
     }
 }
@@ -190,6 +203,7 @@ void launch_wgrad(const WgradArgs &a, dim3 grid, hipStream_t st) {
 }
 
 constexpr int kWgradPartitions = 512;   // 2 workgroups per CU
+#define SNVC_CFG(...) WgradCfg<__VA_ARGS__>
 
 }  // namespace
 }  // namespace snvc
@@ -200,9 +214,8 @@ int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *d) {
     using namespace snvc;
     if (!d) return -1;
     const int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
-    const int64_t taps_pad = (taps + 3) / 4 * 4;
     const int64_t pairs = (int64_t)ceil_div(d->Cout, 32) * ceil_div(d->Cin, 32);
-    return (int64_t)kWgradPartitions * pairs * taps_pad * 1024 * (int64_t)sizeof(float);
+    return (int64_t)kWgradPartitions * pairs * taps * 1024 * (int64_t)sizeof(float);
 }
 
 // desc describes the FORWARD Conv3d (x = its input on the big grid, g = gradient of its output on
@@ -239,22 +252,32 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
     a.g_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
     const int pairs = ceil_div(d->Cout, 32) * a.cx_blocks;
     if (pairs > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: too many channel pairs");
-    dim3 grid(kWgradPartitions, (unsigned)pairs);
     hipStream_t st = as_stream(stream);
     const int key = d->ksize * 100 + d->stride * 10 + d->dilation;
-    switch (key) {
-        case 111: launch_wgrad<WgradCfg<1, 1, 1, 2>>(a, grid, st); break;
-        case 311: launch_wgrad<WgradCfg<3, 1, 1, 2>>(a, grid, st); break;
-        case 321: launch_wgrad<WgradCfg<3, 2, 1, 1>>(a, grid, st); break;
-        default:
-            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: (ksize,stride,dilation) must be (1,1,1), (3,1,1) or (3,2,1) in this release");
+#define SNVC_WGRAD_CASE(CFG)                                                                  \
+    {                                                                                         \
+        using C_ = CFG;                                                                       \
+        dim3 grid(kWgradPartitions, (unsigned)pairs, (unsigned)(C_::CH_D * C_::CH_H));        \
+        launch_wgrad<C_>(a, grid, st);                                                        \
     }
+    switch (key) {  //                            KS S  D  TH KDG KHG
+        case 111: SNVC_WGRAD_CASE(SNVC_CFG(1, 1, 1, 2, 1, 1)) break;
+        case 311: SNVC_WGRAD_CASE(SNVC_CFG(3, 1, 1, 2, 3, 3)) break;
+        case 321: SNVC_WGRAD_CASE(SNVC_CFG(3, 2, 1, 1, 3, 3)) break;
+        case 511: SNVC_WGRAD_CASE(SNVC_CFG(5, 1, 1, 2, 1, 5)) break;
+        case 512: SNVC_WGRAD_CASE(SNVC_CFG(5, 1, 2, 2, 1, 5)) break;
+        case 711: SNVC_WGRAD_CASE(SNVC_CFG(7, 1, 1, 2, 1, 4)) break;
+        default:
+            return fail(SNVC_ERR_UNSUPPORTED,
+                        "snvc_conv3d_wgrad: (ksize,stride,dilation) not in {(1,1,1),(3,1,1),(3,2,1),(5,1,1),(5,1,2),(7,1,1)}");
+    }
+#undef SNVC_WGRAD_CASE
     int rc = check_launch("snvc_conv3d_wgrad");
     if (rc) return rc;
-    const int taps = d->ksize * d->ksize * d->ksize, taps_pad = (taps + 3) / 4 * 4;
+    const int taps = d->ksize * d->ksize * d->ksize;
     const int64_t total = (int64_t)d->Cout * d->Cin * taps;
     wgrad_reduce_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>(
-        (const float *)workspace, dw, d->Cout, d->Cin, taps, taps_pad, a.cx_blocks, pairs, kWgradPartitions);
+        (const float *)workspace, dw, d->Cout, d->Cin, taps, taps, a.cx_blocks, pairs, kWgradPartitions);
     return check_launch("snvc_conv3d_wgrad(reduce)");
 }
 

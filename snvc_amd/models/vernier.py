@@ -26,6 +26,24 @@ from .submodule import (BasicBlock2d, ConvBNReLU3d, HipConv3d, basicdownsample, 
                         hourglass2d, hourglass2d_downsample_16, hourglass_downsample_16)
 
 
+class _VoxelGatherFn(torch.autograd.Function):
+    """Differentiable feature->voxel gather (gradients w.r.t. the two feature maps; the projected
+    coordinates get none, as in the reference where they come from the data loader)."""
+
+    @staticmethod
+    def forward(ctx, left, right, l_pts, r_pts, resolution):
+        ctx.save_for_backward(l_pts, r_pts)
+        ctx.feat_shape, ctx.resolution = tuple(left.shape), tuple(resolution)
+        return ops.voxel_gather_forward(left, right, l_pts, r_pts, resolution)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad):
+        l_pts, r_pts = ctx.saved_tensors
+        gl, gr = ops.voxel_gather_backward(grad.contiguous(), l_pts, r_pts, ctx.feat_shape, ctx.resolution)
+        return gl, gr, None, None, None
+
+
 def get_feat_extraction(cfg, is_train=False, **kwargs):
     """Factory hook for the 2D backbone (reference vernier.py:835-839 builds HRNet here)."""
     if getattr(cfg, "name", None) == "identity":
@@ -118,7 +136,10 @@ class VernierScale(nn.Module):
         nh, nw, nl = self.cfg.n_sample_h, self.cfg.n_sample_w, self.cfg.n_sample_l
         if l_pts.size(2) != nh * nw * nl:
             raise RuntimeError("grid projection does not have nh*nw*nl points")
-        vox = ops.voxel_gather_forward(left, right, l_pts, r_pts, self.cfg.resolution)
+        if torch.is_grad_enabled() and (left.requires_grad or right.requires_grad):
+            vox = _VoxelGatherFn.apply(left, right, l_pts, r_pts, tuple(self.cfg.resolution))
+        else:
+            vox = ops.voxel_gather_forward(left, right, l_pts, r_pts, self.cfg.resolution)
         return vox.view(left.size(0), 2 * left.size(1), nh, nw, nl)
 
     def construct_voxel(self, left, right, grid_proj_left, grid_proj_right):
@@ -130,24 +151,33 @@ class VernierScale(nn.Module):
         """reference vernier.py:415-438 -> (voxel_BEV [N, F*nh/4, nw, nl], occupancy [N,1,nh,nw,nl], offset)."""
         n, c2 = voxel.size(0), voxel.size(1)
         f = c2 // 2
+        training_graph = torch.is_grad_enabled() and (voxel.requires_grad or any(p.requires_grad for p in self.parameters()))
         img = self.vimg_feat(voxel)                                             # :415
         v = self.conv1(voxel)                                                   # :417
         v = self.conv2.fused(v, residual=v, residual_after_act=True)            # conv2(v) + v   :418
         v = self.conv3.fused(v, residual=v, residual_after_act=True)            # conv3(v) + v   :419
-        cat = torch.empty((n, 2 * f) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
-        if self.small:                                                          # :420-423, written into cat[:, :F]
-            v, _, _ = self.hg_conv3d(v, None, None, residual=v, out=cat[:, :f])
+        # inference: the torch.cat of :433 is built in place (producers write channel slices);
+        # under autograd the slices become ordinary tensors and the glue ops are torch's own
+        cat = None if training_graph else torch.empty((n, 2 * f) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)
+        dst = None if training_graph else cat[:, :f]
+        if self.small:                                                          # :420-423
+            v, _, _ = self.hg_conv3d(v, None, None, residual=v, out=dst)
         else:
-            v = self.hg_conv3d(v, residual=v, out=cat[:, :f])
+            v = self.hg_conv3d(v, residual=v, out=dst)
         t = self.fg_cls_head[0].fused(v, relu=True)                             # :427
         occ = self.fg_cls_head[2].fused(t, sigmoid=True)
         offset = None
         if hasattr(self, "part_reg_head"):                                      # :428-431
             offset = self.part_reg_head[2](self.part_reg_head[0].fused(v, relu=True))
-        ops.mul_broadcast(img, occ, out=cat[:, f:])                             # cat([v, img*occ])  :433
-        v = self.conv4(cat)                                                     # :435
-        v = ops.avgpool_depth4(v)                                               # :436
-        return v.view(n, -1, v.size(3), v.size(4)), occ, offset                 # :437-438
+        if training_graph:
+            cat = torch.cat([v, img * occ], dim=1)                              # :433
+            v = self.conv4(cat)                                                 # :435
+            v = torch.nn.functional.avg_pool3d(v, (4, 1, 1), (4, 1, 1))         # :436
+        else:
+            ops.mul_broadcast(img, occ, out=cat[:, f:])                         # cat([v, img*occ])  :433
+            v = self.conv4(cat)                                                 # :435
+            v = ops.avgpool_depth4(v)                                           # :436
+        return v.reshape(n, -1, v.size(3), v.size(4)), occ, offset              # :437-438
 
     def heads_2d(self, voxel_BEV):
         """reference vernier.py:440-450 (stock PyTorch-ROCm)"""

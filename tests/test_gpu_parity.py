@@ -328,7 +328,8 @@ def _grads(module, inputs, loss_fn):
     for t in inputs:
         t.grad = None
     loss_fn().backward()
-    return [t.grad.detach().cpu() for t in inputs], {k: v.grad.detach().cpu() for k, v in module.named_parameters()}
+    return [t.grad.detach().cpu() for t in inputs], {k: (v.grad.detach().cpu() if v.grad is not None else None)
+                                                      for k, v in module.named_parameters()}
 
 
 @pytest.mark.parametrize("case", ["k3_bn_train", "k3_bn_eval", "k3s2_bn_train", "deconv_bn_train", "k3_gn", "k1_plain"])
@@ -532,6 +533,46 @@ def test_global_pair_end_to_end_vs_oracle():
         got = ours.forward_pair(torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()),
                                 torch.from_numpy(s).to(dev()), 1).cpu().numpy()
     check(got, exp, 1e-4, "pair")
+
+
+@pytest.mark.parametrize("gn", [False, True])
+def test_training_step_vernier_trunk_vs_torch_autograd(gn):
+    """Local (V-A) model: gather + 3D trunk (7^3, 5^3, dilated 5^3 convs, hourglass, heads' inputs)
+    forward+backward in train mode against torch-CPU autograd: every 3D-trunk parameter gradient and
+    the gradients w.r.t. the two feature maps."""
+    from oracle import torch_ref as T
+    from snvc_amd.models.vernier import VernierScale
+    grid = (16, 16, 24)
+    ref = T.VernierTrunk(32, grid, gn)
+    ours = VernierScale(_cfg(grid, gn))
+    sd = T.seeded_state_dict(ref, 91)
+    ref.load_state_dict(sd); ours.load_state_dict(sd)
+    ref.train(); ours.train()
+    ours = ours.to(dev())
+    lf, rf, gpl, gpr = GC.trunk_inputs(2, 32, 16, 16, grid, 92)
+    w_occ = GC.randn((2, 1) + grid, 93)
+
+    def loss_ref(l, r):
+        bev, occ, _ = ref.trunk_3d(T.sample_2d_feat(l, r, gpl, gpr, GC.RESOLUTION, grid))
+        return bev.pow(2).mean() + (occ * w_occ).mean()
+
+    def loss_ours(l, r):
+        bev, occ, _ = ours.trunk_3d(ours.construct_voxel(l, r, gpl.to(dev()), gpr.to(dev())))
+        return bev.pow(2).mean() + (occ * w_occ.to(dev())).mean()
+
+    lr_, rr_ = lf.clone().requires_grad_(), rf.clone().requires_grad_()
+    (gl_r, gr_r), gp_r = _grads(ref, [lr_, rr_], lambda: loss_ref(lr_, rr_))
+    lo, ro = lf.to(dev()).requires_grad_(), rf.to(dev()).requires_grad_()
+    (gl_o, gr_o), gp_o = _grads(ours, [lo, ro], lambda: loss_ours(lo, ro))
+
+    def l2(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    assert l2(gl_o.numpy(), gl_r.numpy()) < 2e-3 and l2(gr_o.numpy(), gr_r.numpy()) < 2e-3
+    trunk = [k for k in gp_r if gp_r[k] is not None and k.split(".")[0] in
+             ("vimg_feat", "conv1", "conv2", "conv3", "conv4", "hg_conv3d", "fg_cls_head")]
+    assert len(trunk) >= 30
+    for k in trunk:
+        assert l2(gp_o[k].numpy(), gp_r[k].numpy()) < 2e-3, (k, l2(gp_o[k].numpy(), gp_r[k].numpy()))
 
 
 # =============================================================================== a9 + glue
