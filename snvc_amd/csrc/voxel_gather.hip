@@ -204,6 +204,49 @@ voxel_gather_bwd(const float *__restrict__ grad_out, const float *__restrict__ l
     }
 }
 
+
+// Backward, privatised: nearby voxels project onto the same few feature pixels, so plain global
+// float atomics collide heavily (64 lanes -> 1 address on a coherent projection).  A workgroup
+// therefore owns CPB channel planes of one (sample, camera) and a large run of voxels, accumulates
+// into an LDS copy of those planes with LDS atomics, and flushes only the touched pixels to global
+// memory with one atomic each.  Taps are recomputed per channel group (cheap ALU) instead of being
+// stored.  Summation order is not deterministic (like grid_sampler_2d_backward on any GPU).
+template <int CPB>
+__global__ void __launch_bounds__(256)
+voxel_gather_bwd_lds(const float *__restrict__ grad_out, const float *__restrict__ l_pts,
+                     const float *__restrict__ r_pts, float *__restrict__ grad_left,
+                     float *__restrict__ grad_right, int F, int Hf, int Wf, int64_t V, int64_t vchunk,
+                     float res_x, float res_y) {
+    extern __shared__ float acc[];   // [CPB][Hf*Wf]
+    const int plane = Hf * Wf;
+    const int64_t n = blockIdx.z >> 1;
+    const int side = blockIdx.z & 1;
+    const int c0 = blockIdx.y * CPB;
+    for (int i = threadIdx.x; i < CPB * plane; i += blockDim.x) acc[i] = 0.0f;
+    __syncthreads();
+    const float *pts = (side == 0 ? l_pts : r_pts) + n * 2 * V;
+    const float *g = grad_out + (n * 2 * F + (int64_t)side * F + c0) * V;
+    const int64_t v0 = (int64_t)blockIdx.x * vchunk;
+    const int64_t v1 = v0 + vchunk < V ? v0 + vchunk : V;
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += blockDim.x) {
+        const Taps t = make_taps(pts[v], pts[V + v], res_x, res_y, Hf, Wf);
+#pragma unroll
+        for (int c = 0; c < CPB; ++c) {
+            if (c0 + c >= F) break;
+            const float gv = g[(int64_t)c * V + v];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t.off[k] >= 0) atomicAdd(&acc[c * plane + t.off[k]], gv * t.wt[k]);
+        }
+    }
+    __syncthreads();
+    float *dst = (side == 0 ? grad_left : grad_right) + (n * F + c0) * (int64_t)plane;
+    for (int i = threadIdx.x; i < CPB * plane; i += blockDim.x) {
+        const float a = acc[i];
+        if (a != 0.0f && c0 + i / plane < F) atomicAdd(dst + i, a);
+    }
+}
+
 }  // namespace
 }  // namespace snvc
 
@@ -252,9 +295,19 @@ int snvc_voxel_gather_backward(const float *grad_out, const float *l_pts, const 
             return fail(SNVC_ERR_HIP, "snvc_voxel_gather_backward: hipMemsetAsync failed");
     }
     if (N == 0 || F == 0 || V == 0) return SNVC_OK;
-    dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
-    voxel_gather_bwd<<<grid, 256, 0, as_stream(stream)>>>(grad_out, l_pts, r_pts, grad_left, grad_right,
-                                                          (int)F, (int)Hf, (int)Wf, V, res_x, res_y);
+    constexpr int CPB = 2;
+    if ((int64_t)CPB * Hf * Wf * 4 <= 64 * 1024 && 2 * N <= 65535) {
+        // ~64k voxels per workgroup: the flush (<= CPB*Hf*Wf atomics) is amortised over >= 8x as many LDS adds
+        int64_t vchunk = 65536;
+        if (vchunk > V) vchunk = V;
+        dim3 grid((unsigned)ceil_div<int64_t>(V, vchunk), (unsigned)ceil_div<int64_t>(F, CPB), (unsigned)(2 * N));
+        voxel_gather_bwd_lds<CPB><<<grid, 256, (size_t)CPB * Hf * Wf * 4, as_stream(stream)>>>(
+            grad_out, l_pts, r_pts, grad_left, grad_right, (int)F, (int)Hf, (int)Wf, V, vchunk, res_x, res_y);
+    } else {
+        dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
+        voxel_gather_bwd<<<grid, 256, 0, as_stream(stream)>>>(grad_out, l_pts, r_pts, grad_left, grad_right,
+                                                              (int)F, (int)Hf, (int)Wf, V, res_x, res_y);
+    }
     return check_launch("snvc_voxel_gather_backward");
 }
 
