@@ -58,6 +58,10 @@ SNVC_API int snvc_abi_version(void);
 SNVC_API int snvc_cost_volume_forward(const void *left, const void *right, const void *shift,
                                       void *out, int64_t N, int64_t C, int64_t Hi, int64_t Wi,
                                       int64_t D, int64_t downsample, int dtype, void *stream);
+/* Right (warped) half only: out [N,C,D,Hi/ds,Wi/ds] = out_full[:, C:].  fp32. */
+SNVC_API int snvc_cost_volume_forward_right(const float *right, const float *shift, float *out,
+                                            int64_t N, int64_t C, int64_t Hi, int64_t Wi, int64_t D,
+                                            int64_t downsample, void *stream);
 SNVC_API int snvc_cost_volume_backward(const void *grad, const void *shift, void *grad_left,
                                        void *grad_right, int64_t N, int64_t C, int64_t H,
                                        int64_t W, int64_t D, int64_t downsample, int dtype,
@@ -150,6 +154,17 @@ SNVC_API int snvc_conv3d_forward(const snvc_conv3d_desc *desc_host, const float 
                                  const float *packed_weight, const float *scale,
                                  const float *bias, const float *residual, float *y,
                                  void *stream);
+/* Same, plus `depth_planes` [N,Cout,3,Hout,Wout] (may be NULL) added to the convolution result BEFORE
+ * the affine: plane 0 for output depth 0, plane 2 for the last output depth, plane 1 in between.
+ * This is the factored first convolution over a concat cost volume: its left half repeats the left
+ * feature for every disparity plane (BuildCostVolume_cuda.cu:86), so that half of
+ * conv(volume) is independent of d except at the two zero-padded ends -- three 2D planes, computed
+ * by this same kernel on the left feature stacked 3 deep -- and only the right half of the volume
+ * needs the full 3D convolution (and needs to exist at all). */
+SNVC_API int snvc_conv3d_forward_ex(const snvc_conv3d_desc *desc_host, const float *x,
+                                    const float *packed_weight, const float *scale,
+                                    const float *bias, const float *residual,
+                                    const float *depth_planes, float *y, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Normalisation statistics for GroupNorm / train-mode BatchNorm3d

@@ -33,6 +33,7 @@ SIGNATURES = {
     "snvc_last_error_string": (ctypes.c_char_p, []),
     "snvc_abi_version": (c_int, []),
     "snvc_cost_volume_forward": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    "snvc_cost_volume_forward_right": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_cost_volume_backward": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
     "snvc_voxel_gather_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
     "snvc_voxel_gather_backward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
@@ -40,6 +41,7 @@ SIGNATURES = {
     "snvc_conv3d_packed_weight_count": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
     "snvc_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p]),
     "snvc_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "snvc_conv3d_forward_ex": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_norm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "snvc_norm_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_p]),
     "snvc_affine_act": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),

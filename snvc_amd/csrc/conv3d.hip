@@ -44,6 +44,7 @@ struct ConvArgs {
     const float *scale;
     const float *bias;
     const float *res;
+    const float *plane;   // optional [N][Cout][3][Hout][Wout] depth-class planes added before the affine
     float *y;
     int Cin, Din, Hin, Win;
     int Cout, Dout, Hout, Wout;
@@ -388,17 +389,23 @@ conv3d_mfma_kernel(const ConvArgs a) {
             const int od = od0 + row / TH, oh = oh0 + row % TH;
             const bool vox_ok = od < a.Dout && oh < a.Hout && ow < a.Wout;
             const int64_t sp = vox_ok ? od * out_hw + (int64_t)oh * a.Wout + ow : 0;
-            float rv[16];
+            float rv[16], pv[16];
+            // depth class of this output plane for the factored first convolution (see
+            // snvc_conv3d_forward_ex): 0 = first plane, 2 = last plane, 1 = interior
+            const int cls = od == 0 ? 0 : (od >= a.Dout - 1 ? 2 : 1);
+            const int64_t psp = vox_ok ? (int64_t)cls * out_hw + (int64_t)oh * a.Wout + ow : 0;
+            const float *pn = a.plane ? a.plane + n * (int64_t)a.Cout * 3 * out_hw : nullptr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 co = co < a.Cout ? co : a.Cout - 1;
                 rv[r] = rn ? rn[co * out_dhw + sp] : 0.0f;
+                pv[r] = pn ? pn[co * 3 * out_hw + psp] : 0.0f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float v = epilogue_f(acc[nb][m][r] * f.sc[r] + f.bi[r], rv[r], a.flags);
+                const float v = epilogue_f((acc[nb][m][r] + pv[r]) * f.sc[r] + f.bi[r], rv[r], a.flags);
                 if (vox_ok && co < a.Cout) yn[co * out_dhw + sp] = v;
             }
         }
@@ -837,6 +844,12 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
 int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *packed_weight,
                         const float *scale, const float *bias, const float *residual, float *y,
                         void *stream) {
+    return snvc_conv3d_forward_ex(d, x, packed_weight, scale, bias, residual, nullptr, y, stream);
+}
+
+int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const float *packed_weight,
+                           const float *scale, const float *bias, const float *residual,
+                           const float *depth_planes, float *y, void *stream) {
     using namespace snvc;
     Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: null desc");
@@ -850,6 +863,8 @@ int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: residual flag without residual pointer");
     if ((d->flags & SNVC_EPI_ADD_PRE) && (d->flags & SNVC_EPI_ADD_POST))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: ADD_PRE and ADD_POST are exclusive");
+    if (depth_planes && (d->transposed || d->stride != 1 || d->Dout < 2 || (d->ksize == 1 && d->Cout <= 2)))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_ex: depth planes need a stride-1 Conv3d with Dout >= 2");
     if (d->transposed && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 7))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: transposed y / residual must be 8-byte aligned");
     const int64_t in_sz = (int64_t)d->Cin * d->Din * d->Hin * d->Win, out_sz = (int64_t)d->Cout * d->Dout * d->Hout * d->Wout;
@@ -859,6 +874,7 @@ int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *
     ConvArgs a;
     a.x = x; a.wp = packed_weight; a.scale = scale; a.bias = bias;
     a.res = (d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) ? residual : nullptr;
+    a.plane = depth_planes;
     a.y = y;
     a.Cin = d->Cin; a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
     a.Cout = d->Cout; a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;

@@ -130,6 +130,7 @@ __device__ __forceinline__ float right_value_lds(const float *__restrict__ slab,
 // workgroup then walks a range of disparity planes writing, per plane, RB*W contiguous floats of
 // the left half and of the right half.  Gathers hit LDS instead of L1/L2, the shift is a scalar
 // load, and all vector-memory traffic is the two 16-byte stores per thread per plane.
+template <bool WITH_LEFT>
 __global__ void __launch_bounds__(512)
 cost_volume_fwd_rows(const float *__restrict__ left, const float *__restrict__ right,
                      const float *__restrict__ shift, float *__restrict__ out, int C, int D, int H, int W,
@@ -153,7 +154,7 @@ cost_volume_fwd_rows(const float *__restrict__ left, const float *__restrict__ r
     const int h = h0 + row;
     const bool live = row < RB && h < H;
     float4 lv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) lv = reinterpret_cast<const float4 *>(left + nc * (int64_t)H * W + (int64_t)h * W)[q];
+    if (WITH_LEFT && live) lv = reinterpret_cast<const float4 *>(left + nc * (int64_t)H * W + (int64_t)h * W)[q];
     __syncthreads();
     if (!live) return;
     // image seen by sample_right: rows [row, row+1] of the LDS slab act as rows [h, min(h+1,H-1)]
@@ -163,8 +164,9 @@ cost_volume_fwd_rows(const float *__restrict__ left, const float *__restrict__ r
     const int d0 = blockIdx.y * dchunk;
     const int d1 = d0 + dchunk < D ? d0 + dchunk : D;
     const int64_t plane = (int64_t)H * W;
-    float *oL = out + ((n * 2 * C + c) * (int64_t)D + d0) * plane + (int64_t)h * W + w;
-    float *oR = oL + (int64_t)C * D * plane;
+    // WITH_LEFT: out is the full [N,2C,D,H,W] volume; otherwise only its right half [N,C,D,H,W]
+    float *oL = out + ((n * (WITH_LEFT ? 2 : 1) * C + c) * (int64_t)D + d0) * plane + (int64_t)h * W + w;
+    float *oR = WITH_LEFT ? oL + (int64_t)C * D * plane : oL;
 #pragma unroll 2
     for (int d = d0; d < d1; ++d) {
         const float ns = -shift[n * D + d];
@@ -173,7 +175,7 @@ cost_volume_fwd_rows(const float *__restrict__ left, const float *__restrict__ r
         v.y = right_value_lds(slab, slab_h, W, w + 1, ns);
         v.z = right_value_lds(slab, slab_h, W, w + 2, ns);
         v.w = right_value_lds(slab, slab_h, W, w + 3, ns);
-        *reinterpret_cast<float4 *>(oL) = lv;
+        if (WITH_LEFT) *reinterpret_cast<float4 *>(oL) = lv;
         *reinterpret_cast<float4 *>(oR) = v;
         oL += plane;
         oR += plane;
@@ -249,6 +251,8 @@ int launch_forward(const void *left, const void *right, const void *shift, void 
     const bool fast = sizeof(T) == 4 && ds == 1 && (W % 4) == 0 &&
                       ((reinterpret_cast<uintptr_t>(left) | reinterpret_cast<uintptr_t>(right) |
                         reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (!left && !(fast && W / 4 <= 512 && N * C * H < ((int64_t)1 << 30)))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_cost_volume_forward_right: needs fp32, downsample 1, W % 4 == 0, W <= 2048");
     const int64_t W4 = W / 4;
     if (fast && W4 <= 512 && N * C * H < ((int64_t)1 << 30)) {
         // rows per workgroup: prefer RB*W*4 bytes to be a multiple of 128 (every workgroup then writes
@@ -270,8 +274,14 @@ int launch_forward(const void *left, const void *right, const void *shift, void 
         const int dchunk = (int)ceil_div<int64_t>(D, dsplit);
         dim3 grid((unsigned)(N * C * hblocks), (unsigned)ceil_div<int64_t>(D, dchunk));
         const size_t lds = (size_t)(RB + 1) * W * sizeof(float);
-        cost_volume_fwd_rows<<<grid, threads, lds, st>>>((const float *)left, (const float *)right, (const float *)shift,
-                                                     (float *)out, (int)C, (int)D, (int)H, (int)W, RB, hblocks, dchunk);
+        if (left)
+            cost_volume_fwd_rows<true><<<grid, threads, lds, st>>>((const float *)left, (const float *)right,
+                                                                   (const float *)shift, (float *)out, (int)C, (int)D,
+                                                                   (int)H, (int)W, RB, hblocks, dchunk);
+        else
+            cost_volume_fwd_rows<false><<<grid, threads, lds, st>>>(nullptr, (const float *)right, (const float *)shift,
+                                                                    (float *)out, (int)C, (int)D, (int)H, (int)W, RB,
+                                                                    hblocks, dchunk);
     } else if (fast) {
         dim3 grid((unsigned)ceil_div<int64_t>(H * W / 4, 256), gy);
         cost_volume_fwd_f32x4<<<grid, 256, 0, st>>>((const float *)left, (const float *)right,
@@ -321,6 +331,16 @@ int snvc_cost_volume_forward(const void *left, const void *right, const void *sh
     if (dtype == SNVC_F64)
         return launch_forward<double>(left, right, shift, out, N, C, Hi, Wi, D, downsample, as_stream(stream));
     return fail(SNVC_ERR_UNSUPPORTED, "snvc_cost_volume_forward: dtype must be f32 or f64 (AT_DISPATCH_FLOATING_TYPES)");
+}
+
+int snvc_cost_volume_forward_right(const float *right, const float *shift, float *out, int64_t N, int64_t C,
+                                   int64_t Hi, int64_t Wi, int64_t D, int64_t downsample, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || Hi < 0 || Wi < 0 || D < 0 || downsample != 1)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_cost_volume_forward_right: downsample must be 1 and sizes non-negative");
+    if (N * C * D * Hi * Wi == 0) return SNVC_OK;
+    if (!right || !shift || !out) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_cost_volume_forward_right: null pointer");
+    return launch_forward<float>(nullptr, right, shift, out, N, C, Hi, Wi, D, 1, as_stream(stream));
 }
 
 int snvc_cost_volume_backward(const void *grad, const void *shift, void *grad_left, void *grad_right,

@@ -17,7 +17,8 @@ import torch
 import torch.nn as nn
 
 from ..extension.build_cost_volume import build_cost_volume
-from .submodule import ConvBNReLU3d, HipConv3d, convbn_3d, hourglass
+from .. import ops
+from .submodule import ConvBNReLU3d, HipConv3d, _folded_bn, _Plan, convbn_3d, hourglass
 
 
 class GlobalStack(nn.Module):
@@ -39,6 +40,53 @@ class GlobalStack(nn.Module):
         v, _, _ = self.hg_conv3d(v, None, None, residual=v)   # v + hourglass(v)[0], add fused in the epilogue
         return self.classifier(v)
 
-    def forward_pair(self, left, right, shift, downsample=1):
-        """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts."""
-        return self.forward(build_cost_volume(left, right, shift, downsample))
+    def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None):
+        """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
+
+        ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT
+        volume: its left half repeats the left feature on every disparity plane
+        (BuildCostVolume_cuda.cu:86), so the left half of conv1(volume) does not depend on d except
+        at the two zero-padded ends.  It is computed once as three depth-class planes (this same
+        conv kernel on the left feature stacked 3 deep with conv1's left-half weights) and added in
+        the epilogue of the 3D convolution over the RIGHT half only -- which is also the only half
+        of the volume that has to be built.  Same result (fp32 summation order aside), half of
+        conv1's work and of the volume's HBM traffic.  ``factored=False`` materialises the full volume
+        through ``build_cost_volume`` exactly like the reference would.
+        ``timing``: optional (start_event, end_event) recorded on the current stream around the first
+        3D convolution (the dominant kernel; used by bench.py for the roofline figure)."""
+        conv, bn = self.conv1[0][0], self.conv1[0][1]
+        usable = (factored and downsample == 1 and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
+                  and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)
+        if not usable:
+            vol = build_cost_volume(left, right, shift, downsample)
+            if timing is None:
+                return self.forward(vol)
+            timing[0].record()
+            v = self.conv1(vol)
+            timing[1].record()
+            del vol
+            v = self.conv2(v)
+            v, _, _ = self.hg_conv3d(v, None, None, residual=v)
+            return self.classifier(v)
+        assert torch.all(shift >= 0.)            # same contract as build_cost_volume (reference __init__.py:12)
+        c = left.size(1)
+        w = conv.weight
+        plans = conv.__dict__.setdefault("_snvc_factored", {})
+        key = (w.data_ptr(), w._version, w.device)
+        if plans.get("key") != key:
+            wl, wr = w.detach()[:, :c].contiguous(), w.detach()[:, c:].contiguous()
+            plans.update(key=key, left=ops.Conv3dLayer(wl, 3, 1, 1, 1, False), right=ops.Conv3dLayer(wr, 3, 1, 1, 1, False),
+                         plan=_Plan())
+        scale, bias = _folded_bn(bn, plans["plan"])
+        left3 = left.unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()       # [N,C,3,H,W]
+        planes = plans["left"](left3)                                           # depth classes: first / interior / last
+        vol_r = ops.cost_volume_forward_right(right, shift)                     # [N,C,D,H,W]
+        if timing is not None:
+            timing[0].record()
+        v = plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, None, depth_planes=planes)
+        if timing is not None:
+            timing[1].record()
+        del vol_r
+        v = self.conv2(v)
+        v, _, _ = self.hg_conv3d(v, None, None, residual=v)
+        return self.classifier(v)

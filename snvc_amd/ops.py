@@ -18,7 +18,7 @@ from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, C
                    check)
 
 __all__ = [
-    "cost_volume_forward", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
+    "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
     "Conv3dLayer", "conv3d_wgrad", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
     "points_in_boxes_gpu", "points_in_boxes_cpu",
@@ -72,6 +72,23 @@ def cost_volume_forward(left, right, shift, downsample: int):
     with torch.cuda.device(left.device):
         check(_lib.lib().snvc_cost_volume_forward(_ptr(left), _ptr(right), _ptr(shift), _ptr(out), n, c, hi, wi, d,
                                                   downsample, tag, _stream(left)), "build_cost_volume_forward")
+    return out
+
+
+def cost_volume_forward_right(right, shift):
+    """Right (warped) half of build_cost_volume at downsample 1: [N,C,D,H,W] == full[:, C:]."""
+    _gpu(right, "right"); _gpu(shift, "shift")
+    if right.dtype != torch.float32 or shift.dtype != torch.float32:
+        raise RuntimeError("cost_volume_forward_right is fp32 only")
+    n, c, h, w = right.shape
+    d = shift.size(1)
+    out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=right.device)
+    if out.numel() == 0:
+        return out
+    right, shift = right.contiguous(), shift.contiguous()
+    with torch.cuda.device(right.device):
+        check(_lib.lib().snvc_cost_volume_forward_right(_ptr(right), _ptr(shift), _ptr(out), n, c, h, w, d, 1,
+                                                        _stream(right)), "snvc_cost_volume_forward_right")
     return out
 
 
@@ -203,8 +220,9 @@ class Conv3dLayer:
         d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = x_bs, y_bs, r_bs
         return d
 
-    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None):
-        """y = epilogue(conv(x)); x / out / residual may be channel slices of larger buffers."""
+    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None, depth_planes=None):
+        """y = epilogue(conv(x)); x / out / residual may be channel slices of larger buffers.
+        depth_planes [N,Cout,3,H,W]: see snvc_conv3d_forward_ex."""
         _gpu(x, "x")
         if x.dtype != torch.float32 or x.dim() != 5 or x.size(1) != self.cin:
             raise RuntimeError(f"conv3d input must be float32 [N,{self.cin},D,H,W], got {tuple(x.shape)} {x.dtype}")
@@ -229,9 +247,13 @@ class Conv3dLayer:
             return out
         d = self._desc(n, in_sp, flags, _batch_stride(x), _batch_stride(out),
                        _batch_stride(residual) if residual is not None else 0)
+        if depth_planes is not None:
+            if tuple(depth_planes.shape) != (n, self.cout, 3) + out_shape[3:] or not depth_planes.is_contiguous():
+                raise RuntimeError("depth_planes must be a contiguous [N,Cout,3,H,W] tensor")
         with torch.cuda.device(x.device):
-            check(_lib.lib().snvc_conv3d_forward(ctypes.byref(d), _ptr(x), _ptr(self.packed), _ptr(scale), _ptr(bias),
-                                                 _ptr(residual), _ptr(out), _stream(x)), "snvc_conv3d_forward")
+            check(_lib.lib().snvc_conv3d_forward_ex(ctypes.byref(d), _ptr(x), _ptr(self.packed), _ptr(scale), _ptr(bias),
+                                                    _ptr(residual), _ptr(depth_planes), _ptr(out), _stream(x)),
+                  "snvc_conv3d_forward")
         return out
 
 

@@ -528,11 +528,22 @@ def test_global_pair_end_to_end_vs_oracle():
     s = (np.linspace(0, D - 1, D) + 0.5 * (np.arange(D) % 2)).astype(np.float32)[None]
     ref = seeded(T.GlobalStack(C), 42)
     ours = seeded(GlobalStack(C), 42).to(dev())
+    dl, dr, dsh = torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()), torch.from_numpy(s).to(dev())
     with torch.no_grad():
-        exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, 1))).numpy()
-        got = ours.forward_pair(torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()),
-                                torch.from_numpy(s).to(dev()), 1).cpu().numpy()
-    check(got, exp, 1e-4, "pair")
+        vol_ref = O.cost_volume_forward(L, R, s, 1)
+        exp = ref(torch.from_numpy(vol_ref)).numpy()
+        got_fact = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()                   # factored first conv
+        got_full = ours.forward_pair(dl, dr, dsh, 1, factored=False).cpu().numpy()   # materialised volume
+        # the right-half builder is the full builder's right half, bit for bit
+        from snvc_amd import ops
+        assert np.array_equal(ops.cost_volume_forward_right(dr, dsh).cpu().numpy(), vol_ref[:, C:])
+        # first layer alone: factored == full convolution over the concat volume
+        full1 = ours.conv1(torch.from_numpy(vol_ref).to(dev())).cpu().numpy()
+    check(got_full, exp, 1e-4, "pair (materialised)")
+    check(got_fact, exp, 1e-4, "pair (factored)")
+    check(got_fact, got_full, 2e-5, "factored vs materialised")
+    exp1 = ref.conv1(torch.from_numpy(vol_ref)).detach().numpy()
+    check(full1, exp1, 2e-5, "conv1")
 
 
 @pytest.mark.parametrize("gn", [False, True])

@@ -53,6 +53,17 @@ with torch.no_grad():
         else:
             vox = vs.construct_voxel(lf, rf, gl, gr)
             fn = lambda: vs.trunk_3d(vox)  # noqa: E731
+    elif args.layer == "pair":
+        fn = lambda: model.forward_pair(left, right, shift, 1)  # noqa: E731
+    elif args.layer == "conv1_factored":
+        from snvc_amd import ops
+        model.forward_pair(left, right, shift, 1)                     # builds the factored plans
+        plans = model.conv1[0][0].__dict__["_snvc_factored"]
+        from snvc_amd.models.submodule import _folded_bn
+        scale, bias = _folded_bn(model.conv1[0][1], plans["plan"])
+        planes = plans["left"](left.unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous())
+        vol_r = ops.cost_volume_forward_right(right, shift)
+        fn = lambda: plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, None, depth_planes=planes)  # noqa: E731
     elif args.layer == "cost_volume":
         fn = lambda: build_cost_volume(left, right, shift, 1)  # noqa: E731
     else:
