@@ -586,6 +586,42 @@ def test_training_step_vernier_trunk_vs_torch_autograd(gn):
         assert l2(gp_o[k].numpy(), gp_r[k].numpy()) < 2e-3, (k, l2(gp_o[k].numpy(), gp_r[k].numpy()))
 
 
+def test_empty_and_ragged_inputs():
+    """Edge cases: empty batches / zero voxels / zero points, W not a multiple of the 32-voxel tile
+    or of 4, single-plane depth, and a conv whose last channel chunk is partial on the LAST sample
+    of the allocation (no read may leave the tensor)."""
+    import torch.nn.functional as F
+    from snvc_amd import ops
+    from snvc_amd.extension.roiaware_pool3d import roiaware_pool3d_utils as U
+    from snvc_amd.models import submodule as S
+    d = dev()
+    with torch.no_grad():
+        conv = S.HipConv3d(5, 32, 3, 1, 1, bias=False).to(d)
+        assert conv(torch.zeros(0, 5, 4, 4, 8, device=d)).shape == (0, 32, 4, 4, 8)
+        for shape in ((1, 5, 1, 1, 1), (1, 5, 2, 3, 33), (2, 5, 3, 5, 7)):
+            x = torch.randn(shape, device=d)
+            ref = F.conv3d(x.cpu(), conv.weight.cpu(), None, 1, 1)
+            check(conv(x).cpu().numpy(), ref.numpy(), TIGHT, f"ragged conv {shape}")
+        # channel count 1 (dgrad of the classifier): Cin smaller than every staging chunk
+        c1 = S.HipConv3d(1, 32, 1, 1, 0, bias=False).to(d)
+        x = torch.randn(3, 1, 4, 4, 32, device=d)
+        check(c1(x).cpu().numpy(), F.conv3d(x.cpu(), c1.weight.cpu()).numpy(), TIGHT, "Cin=1")
+        assert ops.voxel_gather_forward(torch.zeros(2, 4, 5, 5, device=d), torch.zeros(2, 4, 5, 5, device=d),
+                                        torch.zeros(2, 2, 0, device=d), torch.zeros(2, 2, 0, device=d), (8, 8)).shape == (2, 8, 0)
+        assert ops.avgpool_depth4(torch.zeros(1, 2, 3, 4, 4, device=d)).shape == (1, 2, 0, 4, 4)
+        idx, val = ops.argmax_rows(torch.zeros(0, 7, device=d))
+        assert idx.shape == (0,)
+        with pytest.raises(RuntimeError, match="empty sequence"):
+            ops.argmax_rows(torch.zeros(3, 0, device=d))
+    pool = U.RoIAwarePool3d((2, 2, 2), 8)
+    rois = torch.tensor([[0, 0, 0, 2, 2, 2, 0.0]], device=d)
+    out = pool(rois, torch.zeros(0, 3, device=d), torch.zeros(0, 4, device=d), "max")     # no points
+    assert out.shape == (1, 2, 2, 2, 4) and float(out.abs().sum()) == 0.0
+    out = pool(rois[:0], torch.zeros(5, 3, device=d), torch.zeros(5, 4, device=d), "avg")  # no boxes
+    assert out.shape == (0, 2, 2, 2, 4)
+    assert U.points_in_boxes_gpu(torch.zeros(1, 0, 3, device=d), torch.zeros(1, 2, 7, device=d)).shape == (1, 0)
+
+
 # =============================================================================== a9 + glue
 def test_small_ops():
     from snvc_amd import ops
