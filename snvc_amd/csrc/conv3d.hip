@@ -45,6 +45,8 @@ struct ConvArgs {
     const float *bias;
     const float *res;
     const float *plane;   // optional [N][Cout][3][Hout][Wout] depth-class planes added before the affine
+    const float *wp_wino; // Winograd-packed weights of a k3/s1 layer (behind the direct packing)
+    int nchunks_wino;
     float *y;
     int Cin, Din, Hin, Win;
     int Cout, Dout, Hout, Wout;
@@ -412,6 +414,169 @@ conv3d_mfma_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------ conv k3: Winograd F(2,3) along W
+// For the 3x3x3 / stride-1 convolutions (all of cfg2's 3D FLOPs outside the hourglass resampling
+// layers) the W dimension is computed with the 1-D Winograd minimal-filtering algorithm F(2,3):
+// two adjacent outputs from four inputs with 4 multiplications instead of 6,
+//     V = B^T d   : V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3      (d = x[2t-1 .. 2t+2])
+//     U = G g     : U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2   (precomputed at pack time)
+//     m_p = sum over (cin, kd, kh) of U_p * V_p                          (the MFMA contraction)
+//     y[2t] = m0+m1+m2,  y[2t+1] = m1-m2-m3
+// so a (cin-pair, kd, kh) step issues 4 MFMAs for 64 output voxels where the direct form issues 6:
+// 2/3 of the matrix-core work, still exact fp32 arithmetic (error of F(2,3) in fp32 ~1e-7 relative;
+// cuDNN, the reference's backend, picks the same family of algorithms under its autotuner,
+// tools/inference_agnostic.py:18).  The input transform costs nothing extra in memory: the LDS image
+// is the same raw tile the direct kernel stages, and V is formed in registers right after the
+// fragment reads (one 8-byte and two 4-byte LDS reads + 4 VALU ops per 4 MFMAs).  A lane owns output
+// pair t of a 64-voxel row, so the epilogue stores 8 bytes per lane, 256 contiguous bytes per
+// half-wave.
+template <int TD_, int TH_, int KC_>
+struct WinoCfg {
+    static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1;
+    static constexpr int TW = 64, LPAD = 4, XOFF = 3;
+    static constexpr int IN_D = TD + 2, IN_H = TH + 2, IN_W = TW + 2;
+    static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;   // 72
+    using St = Stager<KC, IN_D, IN_H, IN_WV>;
+    static constexpr int CH = St::CH, TILE = St::TILE;
+    static constexpr int NB = TD * TH / 4;
+    static constexpr int KP = KC / 2;
+    static constexpr int WF = 9 * 4 * KP * 64;               // packed floats per chunk: [tap9][pos][kp][lane]
+    using Ws = WeightStager<WF>;
+    static constexpr int LDS_BYTES = (TILE * 2 + WF * 2) * 4;
+    static_assert(TD * TH % 4 == 0, "rows must split over 4 waves");
+    static_assert(CH % 2 == 0 && IN_WV % 2 == 0, "8-byte LDS reads need even strides");
+};
+
+template <class Cfg>
+__device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img, const float *__restrict__ wl,
+                                                   int bbase, int wave, f32x16 (&acc)[4][Cfg::NB]) {
+    constexpr int TH = Cfg::TH, KP = Cfg::KP, NB = Cfg::NB, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, CH = Cfg::CH;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+            for (int kp = 0; kp < KP; ++kp) {
+                float af[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) af[p] = wl[(((kd * 3 + kh) * 4 + p) * KP + kp) * 64];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int row = wave * NB + nb;
+                    const int dd = row / TH, hh = row % TH;
+                    const float *px = img + bbase + kp * 2 * CH + ((dd + kd) * IN_H + hh + kh) * IN_WV;
+                    const float d0 = px[0];
+                    const float2 d12 = *reinterpret_cast<const float2 *>(px + 1);   // 8-byte aligned by construction
+                    const float d3 = px[3];
+                    const float v0 = d0 - d12.y, v1 = d12.x + d12.y, v2 = d12.y - d12.x, v3 = d12.x - d3;
+                    acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], v0, acc[0][nb], 0, 0, 0);
+                    acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], v1, acc[1][nb], 0, 0, 0);
+                    acc[2][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], v2, acc[2][nb], 0, 0, 0);
+                    acc[3][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], v3, acc[3][nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
+template <class Cfg>
+__global__ void __launch_bounds__(256, 2)
+conv3d_wino_kernel(const ConvArgs a) {
+    constexpr int TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB, CH = Cfg::CH, TILE = Cfg::TILE, WF = Cfg::WF;
+    using St = typename Cfg::St;
+    using Ws = typename Cfg::Ws;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
+    const int cg = blockIdx.y;   // 32 output channels
+    const int64_t n = blockIdx.z;
+    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 64;
+    const int id0 = od0 - 1, ih0 = oh0 - 1, ix0 = ow0 - Cfg::LPAD;
+
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][nb][r] = 0.0f;
+
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const float *xn = a.x + n * a.x_bs;
+    // B-fragment base: lane&31 = output pair t (inputs 2t-1..2t+2 = image columns 2t+3..2t+6), lane>>5 = k
+    const int bbase = (lane >> 5) * CH + 2 * (lane & 31) + Cfg::XOFF;
+    float *const wlds = lds + 2 * TILE;
+    const float *wg = a.wp_wino + (int64_t)cg * a.nchunks_wino * WF;
+    const int nchunks = a.nchunks_wino;
+
+    St st;
+    st.init(tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+    f32x4 pre[St::NIT], wpre[Ws::NIT];
+    st.load(xn, tid, a.Cin, pre);
+    Ws::load(wg, tid, wpre);
+    st.store(lds, tid, a.Cin, pre);
+    Ws::store(wlds, tid, wpre);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) {
+            Ws::load(wg + (int64_t)(chunk + 1) * WF, tid, wpre);
+            st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
+        }
+        wino_compute_chunk<Cfg>(lds + (chunk & 1) * TILE, wlds + (chunk & 1) * WF + lane, bbase, wave, acc);
+        if (more) {
+            Ws::store(wlds + ((chunk + 1) & 1) * WF, tid, wpre);
+            st.store(lds + ((chunk + 1) & 1) * TILE, tid, a.Cin - (chunk + 1) * KC, pre);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: output transform, then the shared affine / residual / activation
+    const int ow = ow0 + 2 * (lane & 31);
+    const int64_t out_hw = (int64_t)a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
+    float *yn = a.y + n * a.y_bs;
+    const float *rn = a.res ? a.res + n * a.r_bs : nullptr;
+    const float *pn = a.plane ? a.plane + n * (int64_t)a.Cout * 3 * out_hw : nullptr;
+    const int cbase = cg * 32;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int od = od0 + row / TH, oh = oh0 + row % TH;
+        const bool vox_ok = od < a.Dout && oh < a.Hout && ow < a.Wout;   // Wout is even: ow+1 is in range too
+        const int64_t sp = vox_ok ? od * out_hw + (int64_t)oh * a.Wout + ow : 0;
+        const int cls = od == 0 ? 0 : (od >= a.Dout - 1 ? 2 : 1);
+        const int64_t psp = vox_ok ? (int64_t)cls * out_hw + (int64_t)oh * a.Wout + ow : 0;
+        // four accumulator registers (= 4 consecutive output channels) at a time keeps the live set small
+#pragma unroll
+        for (int rb = 0; rb < 16; rb += 4) {
+            float2 rv[4], pv[4];
+            float sc[4], bi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb + q;
+                int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                co = co < a.Cout ? co : a.Cout - 1;
+                sc[q] = a.scale ? a.scale[co] : 1.0f;
+                bi[q] = a.scale ? a.bias[co] : 0.0f;
+                rv[q] = rn ? *reinterpret_cast<const float2 *>(rn + co * out_dhw + sp) : make_float2(0.f, 0.f);
+                pv[q] = pn ? *reinterpret_cast<const float2 *>(pn + co * 3 * out_hw + psp) : make_float2(0.f, 0.f);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb + q;
+                const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
+                const float y0 = (m0 + m1) + m2, y1 = (m1 - m2) - m3;
+                const float v0 = epilogue_f((y0 + pv[q].x) * sc[q] + bi[q], rv[q].x, a.flags);
+                const float v1 = epilogue_f((y1 + pv[q].y) * sc[q] + bi[q], rv[q].y, a.flags);
+                if (vox_ok && co < a.Cout) *reinterpret_cast<float2 *>(yn + co * out_dhw + sp) = make_float2(v0, v1);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ deconv
 // ConvTranspose3d(k=3, s=2, p=1, op=1): out[o] = sum_i sum_t x[i] * w[t], o = 2i - 1 + t.
 // Per dimension, output parity 0 uses tap 1 at input offset 0; parity 1 uses tap 2 at offset 0
@@ -686,6 +851,31 @@ __global__ void pack_deconv_weights_kernel(const float *__restrict__ w, float *_
     packed[i] = (co < Cout && ci < Cin) ? w[((int64_t)ci * Cout + co) * 27 + deconv_tap_of_slot(slot)] : 0.0f;
 }
 
+// Winograd packing (k3, s1): packed[cg][chunk][tap9 = kd*3+kh][pos][kp][half][i] = U_pos of the three kw taps of
+// W[co = cg*32 + i][ci = chunk*KC + 2kp + half][kd][kh][:]
+__global__ void pack_wino_weights_kernel(const float *__restrict__ w, float *__restrict__ packed, int Cout, int Cin,
+                                         int KC, int nchunks, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int KP = KC / 2;
+    int64_t r = i;
+    const int ii = (int)(r % 32); r /= 32;
+    const int half = (int)(r % 2); r /= 2;
+    const int kp = (int)(r % KP); r /= KP;
+    const int pos = (int)(r % 4); r /= 4;
+    const int tap9 = (int)(r % 9); r /= 9;
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int cg = (int)r;
+    const int co = cg * 32 + ii, ci = chunk * KC + 2 * kp + half;
+    float u = 0.0f;
+    if (co < Cout && ci < Cin) {
+        const float *g = w + (((int64_t)co * Cin + ci) * 9 + tap9) * 3;
+        const float g0 = g[0], g1 = g[1], g2 = g[2];
+        u = pos == 0 ? g0 : pos == 1 ? ((g0 + g1) + g2) * 0.5f : pos == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+    }
+    packed[i] = u;
+}
+
 // ------------------------------------------------------------------------------------ dispatch
 struct Plan {
     int MI, KC, TD, TH;  // tile choice
@@ -722,6 +912,7 @@ using CfgK5D2M1 = ConvCfg<5, 1, 2, 1, 4, 4, 2, false, 2, 1>;
 using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2, false, 2, 1>;
 using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 4, 2, false, 2, 1>;
 using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false, 2, 1>;
+using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64 voxels, 2 input channels per chunk
 using CfgDCM1   = DeconvCfg<1, 2, 4, 4>;
 using CfgDCM2   = DeconvCfg<2, 2, 4, 4>;
 
@@ -789,6 +980,21 @@ void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
     conv3d_mfma_kernel<Cfg><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 
+inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
+    if (d.transposed || d.ksize != 3 || d.stride != 1 || d.dilation != 1) return 0;
+    return (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, CfgWino::KC) * CfgWino::WF;
+}
+
+void launch_wino(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done && CfgWino::LDS_BYTES > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wino_kernel<CfgWino>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, CfgWino::LDS_BYTES);
+        attr_done = true;
+    }
+    conv3d_wino_kernel<CfgWino><<<grid, 256, CfgWino::LDS_BYTES, st>>>(a);
+}
+
 template <class Cfg>
 void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
     static bool attr_done = false;
@@ -811,6 +1017,7 @@ int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
     if (!d || make_plan(*d, p) != SNVC_OK) return -1;
     const int64_t taps = d->transposed ? 27 : (int64_t)d->ksize * d->ksize * d->ksize;
     int64_t count = (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
+    count += wino_packed_count(*d);   // k3/s1 layers also carry the Winograd-transformed weights
     // 1x1x1 layers with <= 2 output channels also keep their raw [Cout][Cin] weights (streaming kernel)
     if (!d->transposed && d->ksize == 1 && d->Cout <= 2) count += (int64_t)d->Cout * d->Cin;
     return count;
@@ -829,6 +1036,14 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
         if (hipMemcpyAsync(packed + total, weight, sizeof(float) * d->Cout * d->Cin, hipMemcpyDeviceToDevice,
                            as_stream(stream)) != hipSuccess)
             return fail(SNVC_ERR_HIP, "snvc_conv3d_pack_weights: hipMemcpyAsync failed");
+    }
+    const int64_t wino = wino_packed_count(*d);
+    if (wino) {
+        total -= wino;
+        pack_wino_weights_kernel<<<(unsigned)ceil_div<int64_t>(wino, 256), 256, 0, as_stream(stream)>>>(
+            weight, packed + total, d->Cout, d->Cin, CfgWino::KC, ceil_div(d->Cin, CfgWino::KC), wino);
+        int rcw = check_launch("snvc_conv3d_pack_weights(winograd)");
+        if (rcw) return rcw;
     }
     const unsigned blocks = (unsigned)ceil_div<int64_t>(total, 256);
     if (d->transposed)
@@ -875,6 +1090,7 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
     a.x = x; a.wp = packed_weight; a.scale = scale; a.bias = bias;
     a.res = (d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) ? residual : nullptr;
     a.plane = depth_planes;
+    a.wp_wino = nullptr; a.nchunks_wino = 0;
     a.y = y;
     a.Cin = d->Cin; a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
     a.Cout = d->Cout; a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;
@@ -900,6 +1116,26 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
         else
             pointwise_small_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
         return check_launch("snvc_conv3d_forward(pointwise)");
+    }
+    // k3 / stride 1: Winograd F(2,3) along W when the rows allow 8-byte pair stores and 16-byte staging
+    {
+        const int64_t wino = wino_packed_count(*d);
+        const char *nw = getenv("SNVC_NO_WINOGRAD");   // development knob: force the direct kernel
+        const bool pair_ok = (d->Wout % 2 == 0) && a.vec && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
+                             ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
+                               reinterpret_cast<uintptr_t>(depth_planes)) & 7) == 0;
+        if (wino && pair_ok && !(nw && nw[0] == '1')) {
+            a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
+            a.nchunks_wino = ceil_div(d->Cin, CfgWino::KC);
+            a.tiles_d = ceil_div(d->Dout, CfgWino::TD); a.tiles_h = ceil_div(d->Hout, CfgWino::TH);
+            a.tiles_w = ceil_div(d->Wout, 64);
+            const int64_t nt = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
+            if (nt < ((int64_t)1 << 31)) {
+                dim3 gridw((unsigned)nt, (unsigned)ceil_div(d->Cout, 32), (unsigned)d->N);
+                launch_wino(a, gridw, as_stream(stream));
+                return check_launch("snvc_conv3d_forward(winograd)");
+            }
+        }
     }
     const int64_t ntiles = (int64_t)p.tiles_d * p.tiles_h * p.tiles_w;
     const int64_t gx = d->transposed ? ntiles * 4 : ntiles;
