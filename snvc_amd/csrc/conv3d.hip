@@ -52,6 +52,7 @@ struct ConvArgs {
     int Cout, Dout, Hout, Wout;
     int tiles_d, tiles_h, tiles_w;
     int nchunks, flags;
+    int njobs, groups;   // Winograd kernel: jobs = tiles x channel groups x samples
     int vec;  // 1: 16-byte aligned rows (Win % 4 == 0, aligned base and strides) -> float4 staging
     int64_t x_bs, y_bs, r_bs;
 };
@@ -149,6 +150,22 @@ struct Stager {
         }
     }
 
+    // The same store, one piece at a time (for kernels that interleave it with their MFMA stream).
+    __device__ __forceinline__ unsigned store_mask(int tid, int cin_left) const {
+        unsigned m = vmask;
+        if (cin_left < KC) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if ((it * 256 + tid) / (RQ * IN_D * IN_H) >= cin_left) m &= ~(1u << it);
+        }
+        return m;
+    }
+    static __device__ __forceinline__ void store_one(float *__restrict__ buf, int tid, int it, unsigned m, const f32x4 &v) {
+        const int i = it * 256 + tid;
+        const f32x4 z = ((m >> it) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<f32x4 *>(buf)[i] = z;
+    }
+
     // Fallback for tensors whose rows are not 16-byte aligned (Win % 4 != 0, odd strides):
     // same LDS image, one float at a time, synchronous, still branch-free per element.
     static __device__ __forceinline__ void stage_scalar(const float *__restrict__ xc, float *__restrict__ buf,
@@ -198,10 +215,11 @@ struct WeightStager {
     }
     static __device__ __forceinline__ void store(float *__restrict__ wbuf, int tid, const f32x4 (&v)[NIT]) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = it * 256 + tid;
-            if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<f32x4 *>(wbuf)[i] = v[it];
-        }
+        for (int it = 0; it < NIT; ++it) store_one(wbuf, tid, it, v[it]);
+    }
+    static __device__ __forceinline__ void store_one(float *__restrict__ wbuf, int tid, int it, const f32x4 &v) {
+        const int i = it * 256 + tid;
+        if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<f32x4 *>(wbuf)[i] = v;
     }
 };
 
@@ -447,39 +465,194 @@ struct WinoCfg {
     static_assert(CH % 2 == 0 && IN_WV % 2 == 0, "8-byte LDS reads need even strides");
 };
 
+// One (kd, kh, k-pair) step = 4 weight fragments (positions 0..3) + NB raw input quadruples.
+template <int NB>
+struct WinoStep {
+    float a[4];
+    float d0[NB], d3[NB];
+    float2 d12[NB];
+};
+
 template <class Cfg>
-__device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img, const float *__restrict__ wl,
-                                                   int bbase, int wave, f32x16 (&acc)[4][Cfg::NB]) {
+__device__ __forceinline__ void wino_load_step(const float *__restrict__ img, const float *__restrict__ wl, int bbase,
+                                               int wave, int step, WinoStep<Cfg::NB> &o) {
     constexpr int TH = Cfg::TH, KP = Cfg::KP, NB = Cfg::NB, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, CH = Cfg::CH;
+    const int kp = step % KP, tap9 = step / KP;         // compile-time after unrolling
+    const int kd = tap9 / 3, kh = tap9 % 3;
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd) {
+    for (int p = 0; p < 4; ++p) o.a[p] = wl[((tap9 * 4 + p) * KP + kp) * 64];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int dd = row / TH, hh = row % TH;
+        const float *px = img + bbase + kp * 2 * CH + ((dd + kd) * IN_H + hh + kh) * IN_WV;
+        o.d0[nb] = px[0];
+        o.d12[nb] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(px + 1, 8));
+        o.d3[nb] = px[3];
+    }
+}
+
+// `mid(s)` runs between steps s and s+1: the kernel uses it to retire the NEXT chunk's prefetch
+// (registers -> the idle LDS buffers) a piece at a time in the shadow of the MFMAs, so that a chunk
+// ends with a bare barrier instead of a vmcnt wait + a burst of LDS writes.
+template <class Cfg, class Mid>
+__device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img, const float *__restrict__ wl,
+                                                   int bbase, int wave, f32x16 (&acc)[4][Cfg::NB], Mid &&mid) {
+    constexpr int NB = Cfg::NB, NS = 9 * Cfg::KP;
+    // software pipeline: the LDS reads of step s+1 are issued before the MFMAs of step s
+    WinoStep<NB> cur, nxt;
+    wino_load_step<Cfg>(img, wl, bbase, wave, 0, cur);
 #pragma unroll
-            for (int kp = 0; kp < KP; ++kp) {
-                float af[4];
+    for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) wino_load_step<Cfg>(img, wl, bbase, wave, s + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) af[p] = wl[(((kd * 3 + kh) * 4 + p) * KP + kp) * 64];
+        for (int nb = 0; nb < NB; ++nb) {
+            const float d1 = cur.d12[nb].x, d2 = cur.d12[nb].y;
+            const float v0 = cur.d0[nb] - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - cur.d3[nb];
+            acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0], v0, acc[0][nb], 0, 0, 0);
+            acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1], v1, acc[1][nb], 0, 0, 0);
+            acc[2][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[2], v2, acc[2][nb], 0, 0, 0);
+            acc[3][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[3], v3, acc[3][nb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mid(s);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < NS) cur = nxt;
+    }
+}
+
+// A job = one output tile of one 32-channel group of one sample; one workgroup per job.
+struct WinoJob {
+    int od0, oh0, ow0, cg;
+    int64_t n;
+};
+
+__device__ __forceinline__ WinoJob wino_decode_job(const ConvArgs &a, int v, int total, int TD, int TH) {
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+    const int j = xcd_remap(v, total);
+    const int t = j % ntiles, g = j / ntiles;
+    WinoJob o;
+    o.ow0 = (t % a.tiles_w) * 64;
+    o.oh0 = ((t / a.tiles_w) % a.tiles_h) * TH;
+    o.od0 = (t / (a.tiles_w * a.tiles_h)) * TD;
+    o.cg = g % a.groups;
+    o.n = g / a.groups;
+    return o;
+}
+
+// Epilogue of one job.  Vector-memory loads and stores retire through ONE in-order counter (vmcnt), so
+// a load issued after a store cannot be consumed before that store has been acknowledged by the
+// memory system -- a load -> store -> load -> store chain costs a full write round trip per link
+// (measured: 40k cycles per job when the residual / affine loads were interleaved with the stores).
+// Hence: per-channel scale and bias come in through LDS (fetched by 64 threads at the start of the
+// job, parked during its first chunk; lgkmcnt), every vector load of the job (residual or depth-class planes, both row blocks) is issued before
+// the first store, and the stores are then fire-and-forget.
+// Results are formed IN PLACE (y0 -> acc[0], y1 -> acc[1]) so no extra registers are held while the
+// second row block's addends are fetched.
+// Addresses are a wave-uniform channel base (SGPR pair) + one 32-bit per-lane byte offset per row
+// block (the host routes layers with more than 2^27 output voxels per channel elsewhere).
+template <class Cfg, bool RES, bool PLANE>
+__device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[4][Cfg::NB],
+                                              const float *__restrict__ aff, int lane, int wave) {
+    constexpr int NB = Cfg::NB, TH = Cfg::TH;
+    const int ow = job.ow0 + 2 * (lane & 31);
+    const int out_hw = a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
+    const int cbase = __builtin_amdgcn_readfirstlane(job.cg * 32);
+    const int half = lane >> 5;                     // accumulator register r of this lane is channel
+                                                    //   cbase + (r&3) + 8*(r>>2) + 4*half
+    // Cout % 32 == 0 (host): every channel of the group exists, no channel predicates anywhere
+    const int hoff = 4 * half;
+    const bool relu = (a.flags & SNVC_EPI_RELU) != 0, add_pre = (a.flags & SNVC_EPI_ADD_PRE) != 0,
+               add_post = (a.flags & SNVC_EPI_ADD_POST) != 0;
+    const int64_t cs = (int64_t)out_dhw * 4, ps = (int64_t)out_hw * 12;   // channel strides in bytes
+    char *const yb = reinterpret_cast<char *>(a.y + job.n * a.y_bs) + cbase * cs;
+    const char *const rb = RES ? reinterpret_cast<const char *>(a.res + job.n * a.r_bs) + cbase * cs : nullptr;
+    const char *const pb =
+        PLANE ? reinterpret_cast<const char *>(a.plane + job.n * (int64_t)a.Cout * 3 * out_hw) + cbase * ps : nullptr;
+
+    // output transform first, in place (y0 -> acc[0], y1 -> acc[1]): half of the accumulator registers
+    // are free for the rest of the epilogue
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const int row = wave * NB + nb;
-                    const int dd = row / TH, hh = row % TH;
-                    const float *px = img + bbase + kp * 2 * CH + ((dd + kd) * IN_H + hh + kh) * IN_WV;
-                    const float d0 = px[0];
-                    const float2 d12 = *reinterpret_cast<const float2 *>(px + 1);   // 8-byte aligned by construction
-                    const float d3 = px[3];
-                    const float v0 = d0 - d12.y, v1 = d12.x + d12.y, v2 = d12.y - d12.x, v3 = d12.x - d3;
-                    acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], v0, acc[0][nb], 0, 0, 0);
-                    acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], v1, acc[1][nb], 0, 0, 0);
-                    acc[2][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], v2, acc[2][nb], 0, 0, 0);
-                    acc[3][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], v3, acc[3][nb], 0, 0, 0);
-                }
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
+            acc[0][nb][r] = (m0 + m1) + m2;
+            acc[1][nb][r] = (m1 - m2) - m3;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    unsigned voff[NB];
+    bool ok[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int od = job.od0 + row / TH, oh = job.oh0 + row % TH;
+        // Wout is even: ow+1 is in range too
+        ok[nb] = od < a.Dout && oh < a.Hout && ow < a.Wout;
+        const int sp = ok[nb] ? od * out_hw + oh * a.Wout + ow : 0;
+        voff[nb] = 4u * (unsigned)(hoff * out_dhw + sp);
+        const int cls = od == 0 ? 0 : (od >= a.Dout - 1 ? 2 : 1);
+        const unsigned poff = 4u * (unsigned)(hoff * 3 * out_hw + (ok[nb] ? cls * out_hw + oh * a.Wout + ow : 0));
+        // addends are fetched eight channels at a time (loads behind loads cost nothing; only a load
+        // behind a STORE would wait for the write to be acknowledged)
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+            float2 rv[RES ? 8 : 1], pv[PLANE ? 8 : 1];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cl = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);     // channel within the group
+                if (RES) rv[q] = *reinterpret_cast<const float2 *>(rb + cl * cs + voff[nb]);
+                if (PLANE) pv[q] = *reinterpret_cast<const float2 *>(pb + cl * ps + poff);
             }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = r0 + q;
+                const float sc = aff[(r & 3) + 8 * (r >> 2) + 4 * half], bi = aff[32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                float y0 = acc[0][nb][r], y1 = acc[1][nb][r];
+                if (PLANE) { y0 += pv[q].x; y1 += pv[q].y; }
+                y0 = y0 * sc + bi;
+                y1 = y1 * sc + bi;
+                if (RES) { y0 = add_pre ? y0 + rv[q].x : y0; y1 = add_pre ? y1 + rv[q].y : y1; }
+                const float t0 = y0 > 0.0f ? y0 : 0.0f, t1 = y1 > 0.0f ? y1 : 0.0f;
+                y0 = relu ? t0 : y0;
+                y1 = relu ? t1 : y1;
+                if (RES) { y0 = add_post ? y0 + rv[q].x : y0; y1 = add_post ? y1 + rv[q].y : y1; }
+                acc[0][nb][r] = y0;
+                acc[1][nb][r] = y1;
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the next batch's address math / loads out of this one
+        }
+    }
+    // Stores are issue-bound (a wave-wide store instruction costs several hundred cycles of the
+    // CU's store path whatever its width), so neighbouring lanes trade halves first: the even lane
+    // of a pair ends up with 4 consecutive outputs of channel c, the odd lane with the same 4
+    // outputs of channel c+1, and each issues ONE 16-byte store where it had two 8-byte ones.
+    const bool odd = (lane & 1) != 0;
+    const unsigned adj = odd ? (unsigned)cs - 8u : 0u;     // odd lane: next channel, two outputs to the left
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const unsigned vo = voff[nb] + adj;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const int cl = (r & 3) + 8 * (r >> 2);
+            const float ya0 = acc[0][nb][r], ya1 = acc[1][nb][r], yb0 = acc[0][nb][r + 1], yb1 = acc[1][nb][r + 1];
+            const float s0 = odd ? ya0 : yb0, s1 = odd ? ya1 : yb1;
+            // quad_perm [1,0,3,2]: swap with the neighbouring lane (both lanes of a pair share ok[nb])
+            const float g0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xF, 0xF, true));
+            const float g1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xF, 0xF, true));
+            f32x4 o;
+            o[0] = odd ? g0 : ya0;
+            o[1] = odd ? g1 : ya1;
+            o[2] = odd ? yb0 : g0;
+            o[3] = odd ? yb1 : g1;
+            if (ok[nb]) *reinterpret_cast<f32x4 *>(yb + cl * cs + vo) = o;
         }
     }
 }
 
-template <class Cfg>
+template <class Cfg, bool RES, bool PLANE>
 __global__ void __launch_bounds__(256, 2)
 conv3d_wino_kernel(const ConvArgs a) {
     constexpr int TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB, CH = Cfg::CH, TILE = Cfg::TILE, WF = Cfg::WF;
@@ -487,13 +660,7 @@ conv3d_wino_kernel(const ConvArgs a) {
     using Ws = typename Cfg::Ws;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
-    const int t = xcd_remap(blockIdx.x, ntiles);
-    const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
-    const int cg = blockIdx.y;   // 32 output channels
-    const int64_t n = blockIdx.z;
-    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 64;
-    const int id0 = od0 - 1, ih0 = oh0 - 1, ix0 = ow0 - Cfg::LPAD;
+    const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, TD, TH);
 
     f32x16 acc[4][NB];
 #pragma unroll
@@ -504,77 +671,57 @@ conv3d_wino_kernel(const ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[p][nb][r] = 0.0f;
 
     const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
-    const float *xn = a.x + n * a.x_bs;
+    const float *xn = a.x + job.n * a.x_bs;
     // B-fragment base: lane&31 = output pair t (inputs 2t-1..2t+2 = image columns 2t+3..2t+6), lane>>5 = k
     const int bbase = (lane >> 5) * CH + 2 * (lane & 31) + Cfg::XOFF;
     float *const wlds = lds + 2 * TILE;
-    const float *wg = a.wp_wino + (int64_t)cg * a.nchunks_wino * WF;
+    float *const aff = wlds + 2 * WF;      // scale | bias of this job's 32 channels
     const int nchunks = a.nchunks_wino;
+    const float *wg = a.wp_wino + (int64_t)job.cg * nchunks * WF;
+    constexpr int NS = 9 * Cfg::KP;
+    // prefetch pieces are retired over the last steps of a chunk (weights first: they were requested
+    // first); the first FIRST steps (>= 2.5k cycles of MFMAs) cover the global-memory latency.
+    // Measured on cfg2 conv2: FIRST = 2 -> 1.92 ms, 3 -> 1.88, 5 -> 1.85, 7 -> 1.85.
+    constexpr int NPIECE = Ws::NIT + St::NIT;
+    constexpr int FIRST = NS > 5 ? 5 : NS - 1;
 
     St st;
-    st.init(tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+    st.init(tid, job.od0 - 1, job.oh0 - 1, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
     f32x4 pre[St::NIT], wpre[Ws::NIT];
     st.load(xn, tid, a.Cin, pre);
     Ws::load(wg, tid, wpre);
+    if (tid < 64) {
+        float v = tid < 32 ? 1.0f : 0.0f;
+        if (a.scale) v = (tid < 32 ? a.scale : a.bias)[job.cg * 32 + (tid & 31)];   // Cout % 32 == 0 (host)
+        aff[tid] = v;
+    }
     st.store(lds, tid, a.Cin, pre);
     Ws::store(wlds, tid, wpre);
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         const bool more = chunk + 1 < nchunks;
+        const int cin_left = a.Cin - (chunk + 1) * KC;
         if (more) {
             Ws::load(wg + (int64_t)(chunk + 1) * WF, tid, wpre);
-            st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, a.Cin - (chunk + 1) * KC, pre);
+            st.load(xn + (int64_t)(chunk + 1) * KC * in_dhw, tid, cin_left, pre);
         }
-        wino_compute_chunk<Cfg>(lds + (chunk & 1) * TILE, wlds + (chunk & 1) * WF + lane, bbase, wave, acc);
-        if (more) {
-            Ws::store(wlds + ((chunk + 1) & 1) * WF, tid, wpre);
-            st.store(lds + ((chunk + 1) & 1) * TILE, tid, a.Cin - (chunk + 1) * KC, pre);
-        }
+        float *const wnext = wlds + ((chunk + 1) & 1) * WF;
+        float *const inext = lds + ((chunk + 1) & 1) * TILE;
+        const unsigned m = st.store_mask(tid, cin_left);
+        wino_compute_chunk<Cfg>(lds + (chunk & 1) * TILE, wlds + (chunk & 1) * WF + lane, bbase, wave, acc, [&](int s) {
+            if (!more) return;
+#pragma unroll
+            for (int piece = 0; piece < NPIECE; ++piece) {
+                // piece -> step: spread over steps FIRST..NS-1 (several per step when NPIECE > NS)
+                const int at = FIRST + piece * (NS - FIRST) / NPIECE;
+                if (at != s) continue;
+                if (piece < Ws::NIT) Ws::store_one(wnext, tid, piece, wpre[piece]);
+                else st.store_one(inext, tid, piece - Ws::NIT, m, pre[piece - Ws::NIT]);
+            }
+        });
         __syncthreads();
     }
-
-    // ---- epilogue: output transform, then the shared affine / residual / activation
-    const int ow = ow0 + 2 * (lane & 31);
-    const int64_t out_hw = (int64_t)a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
-    float *yn = a.y + n * a.y_bs;
-    const float *rn = a.res ? a.res + n * a.r_bs : nullptr;
-    const float *pn = a.plane ? a.plane + n * (int64_t)a.Cout * 3 * out_hw : nullptr;
-    const int cbase = cg * 32;
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int row = wave * NB + nb;
-        const int od = od0 + row / TH, oh = oh0 + row % TH;
-        const bool vox_ok = od < a.Dout && oh < a.Hout && ow < a.Wout;   // Wout is even: ow+1 is in range too
-        const int64_t sp = vox_ok ? od * out_hw + (int64_t)oh * a.Wout + ow : 0;
-        const int cls = od == 0 ? 0 : (od >= a.Dout - 1 ? 2 : 1);
-        const int64_t psp = vox_ok ? (int64_t)cls * out_hw + (int64_t)oh * a.Wout + ow : 0;
-        // four accumulator registers (= 4 consecutive output channels) at a time keeps the live set small
-#pragma unroll
-        for (int rb = 0; rb < 16; rb += 4) {
-            float2 rv[4], pv[4];
-            float sc[4], bi[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = rb + q;
-                int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                co = co < a.Cout ? co : a.Cout - 1;
-                sc[q] = a.scale ? a.scale[co] : 1.0f;
-                bi[q] = a.scale ? a.bias[co] : 0.0f;
-                rv[q] = rn ? *reinterpret_cast<const float2 *>(rn + co * out_dhw + sp) : make_float2(0.f, 0.f);
-                pv[q] = pn ? *reinterpret_cast<const float2 *>(pn + co * 3 * out_hw + psp) : make_float2(0.f, 0.f);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = rb + q;
-                const int co = cbase + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
-                const float y0 = (m0 + m1) + m2, y1 = (m1 - m2) - m3;
-                const float v0 = epilogue_f((y0 + pv[q].x) * sc[q] + bi[q], rv[q].x, a.flags);
-                const float v1 = epilogue_f((y1 + pv[q].y) * sc[q] + bi[q], rv[q].y, a.flags);
-                if (vox_ok && co < a.Cout) *reinterpret_cast<float2 *>(yn + co * out_dhw + sp) = make_float2(v0, v1);
-            }
-        }
-    }
+    wino_epilogue<Cfg, RES, PLANE>(a, job, acc, aff, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------ deconv
@@ -985,14 +1132,23 @@ inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
     return (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, CfgWino::KC) * CfgWino::WF;
 }
 
-void launch_wino(const ConvArgs &a, dim3 grid, hipStream_t st) {
+template <bool RES, bool PLANE>
+void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int BYTES = CfgWino::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
     static bool attr_done = false;
-    if (!attr_done && CfgWino::LDS_BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wino_kernel<CfgWino>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, CfgWino::LDS_BYTES);
+    if (!attr_done && BYTES > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wino_kernel<CfgWino, RES, PLANE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
         attr_done = true;
     }
-    conv3d_wino_kernel<CfgWino><<<grid, 256, CfgWino::LDS_BYTES, st>>>(a);
+    conv3d_wino_kernel<CfgWino, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
+}
+
+void launch_wino(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    if (a.res && a.plane) launch_wino_variant<true, true>(a, grid, st);
+    else if (a.res) launch_wino_variant<true, false>(a, grid, st);
+    else if (a.plane) launch_wino_variant<false, true>(a, grid, st);
+    else launch_wino_variant<false, false>(a, grid, st);
 }
 
 template <class Cfg>
@@ -1124,15 +1280,21 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
         const bool pair_ok = (d->Wout % 2 == 0) && a.vec && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
                              ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
                                reinterpret_cast<uintptr_t>(depth_planes)) & 7) == 0;
-        if (wino && pair_ok && !(nw && nw[0] == '1')) {
+        // the Winograd epilogue addresses outputs as (uniform channel base) + 32-bit lane byte offset and
+        // assumes whole 32-channel groups; it has no Sigmoid
+        const bool epi_ok = (int64_t)d->Dout * d->Hout * d->Wout < ((int64_t)1 << 27) &&
+                            d->Cout % 32 == 0 && !(d->flags & SNVC_EPI_SIGMOID) &&
+                            d->Wout % 4 == 0 && a.y_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+        if (wino && pair_ok && epi_ok && !(nw && nw[0] == '1')) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, CfgWino::KC);
             a.tiles_d = ceil_div(d->Dout, CfgWino::TD); a.tiles_h = ceil_div(d->Hout, CfgWino::TH);
             a.tiles_w = ceil_div(d->Wout, 64);
-            const int64_t nt = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
-            if (nt < ((int64_t)1 << 31)) {
-                dim3 gridw((unsigned)nt, (unsigned)ceil_div(d->Cout, 32), (unsigned)d->N);
-                launch_wino(a, gridw, as_stream(stream));
+            a.groups = ceil_div(d->Cout, 32);
+            const int64_t nj = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w * a.groups * d->N;
+            if (nj < ((int64_t)1 << 31)) {
+                a.njobs = (int)nj;
+                launch_wino(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 return check_launch("snvc_conv3d_forward(winograd)");
             }
         }

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Steady-state timing of single conv layers (development tool).  The shader clock ramps from
+~2.1 to ~2.4 GHz over the first tens of milliseconds of load (tools/probes/mfma_clock_probe.hip),
+so each case is warmed for ~100 ms first and the median / minimum of per-launch events is printed."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from snvc_amd.models import submodule as S  # noqa: E402
+
+CASES = {
+    "conv1": (64, 32, 3, 1, 1, (192, 96, 312), False),
+    "conv2": (32, 32, 3, 1, 1, (192, 96, 312), False),
+    "hg_s2": (32, 64, 3, 2, 1, (192, 96, 312), False),
+    "hg_c2": (64, 64, 3, 1, 1, (96, 48, 156), False),
+    "hg_s2b": (64, 64, 3, 2, 1, (96, 48, 156), False),
+    "hg_c4": (64, 64, 3, 1, 1, (48, 24, 78), False),
+    "dc5": (64, 64, 3, 2, 1, (48, 24, 78), True),
+    "dc6": (64, 32, 3, 2, 1, (96, 48, 156), True),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="*", default=list(CASES))
+    ap.add_argument("--reps", type=int, default=60)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    with torch.no_grad():
+        for name in args.cases:
+            cin, cout, k, s, p, shape, tr = CASES[name]
+            m = (S._deconvbn_3d(cin, cout, False) if tr else S.convbn_3d(cin, cout, k, s, p)).to(dev).eval()
+            x = torch.randn((1, cin) + shape, device=dev)
+            y = m.fused(x, relu=True)
+            vox = x[0, 0].numel() if tr else y[0, 0].numel()
+            gf = 2.0 * vox * cin * cout * 27 / 1e9
+            for _ in range(40):
+                m.fused(x, relu=True)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
+            for a, b in ev:
+                a.record(); m.fused(x, relu=True); b.record()
+            torch.cuda.synchronize()
+            t = sorted(a.elapsed_time(b) for a, b in ev)
+            med, mn = t[len(t) // 2], t[0]
+            print(f"{name:7s} {cin:3d}->{cout:3d} {'deconv' if tr else 'k3s%d' % s:6s} {shape}: median {med:7.3f} ms "
+                  f"({gf / med:6.1f} TF)  min {mn:7.3f} ms ({gf / mn:6.1f} TF)", flush=True)
+            del m, x, y
+
+
+if __name__ == "__main__":
+    main()
