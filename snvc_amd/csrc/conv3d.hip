@@ -52,6 +52,7 @@ struct ConvArgs {
     int Cout, Dout, Hout, Wout;
     int tiles_d, tiles_h, tiles_w;
     int nchunks, flags;
+    int fast_epi;        // the launch qualifies for the fast epilogues (see the toolkit comment)
     int njobs, groups;   // Winograd kernel: jobs = tiles x channel groups x samples
     int vec;  // 1: 16-byte aligned rows (Win % 4 == 0, aligned base and strides) -> float4 staging
     int64_t x_bs, y_bs, r_bs;
@@ -84,15 +85,19 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // ONCE per thread and kept in registers.  Loads are unconditional (padding items read offset 0
 // and are zeroed by a select): no branches, no per-item waits; the whole chunk is in flight at
 // once, and it is issued one chunk AHEAD of its use (register prefetch).
-template <int KC_, int IN_D_, int IN_H_, int IN_WV_>
+template <int KC_, int IN_D_, int IN_H_, int IN_WV_, int PIECE_ = 4>
 struct Stager {
-    static constexpr int KC = KC_, IN_D = IN_D_, IN_H = IN_H_, IN_WV = IN_WV_;
-    static constexpr int RQ = IN_WV / 4;
+    // PIECE = floats per staged piece: 4 (16-byte pieces; rows with Win % 4 == 0) or 2 (8-byte pieces
+    // for rows that are only 8-byte aligned, e.g. the W = 78 level of the cfg2 hourglass)
+    static constexpr int KC = KC_, IN_D = IN_D_, IN_H = IN_H_, IN_WV = IN_WV_, PIECE = PIECE_;
+    static constexpr int RQ = IN_WV / PIECE;
     static constexpr int ROWS = KC * IN_D * IN_H;
     static constexpr int ITEMS = ROWS * RQ;
     static constexpr int NIT = (ITEMS + 255) / 256;
     static constexpr int CH = IN_D * IN_H * IN_WV;   // floats per channel
     static constexpr int TILE = KC * CH;             // floats per chunk image
+    typedef float Vec __attribute__((ext_vector_type(PIECE)));
+    static_assert(PIECE == 4 || PIECE == 2, "pieces are 16 or 8 bytes");
     static_assert(IN_WV % 4 == 0, "image rows are whole float4 pieces");
     static_assert(NIT <= 32, "validity mask is one 32-bit register");
 
@@ -109,7 +114,7 @@ struct Stager {
             const int row = i / RQ, q = i - row * RQ;
             const int kc = row / (IN_D * IN_H), r2 = row - kc * (IN_D * IN_H);
             const int dd = r2 / IN_H, hh = r2 - dd * IN_H;
-            const int gd = id0 + dd, gh = ih0 + hh, gw = ix0 + 4 * q;
+            const int gd = id0 + dd, gh = ih0 + hh, gw = ix0 + PIECE * q;
             const bool ok = i < ITEMS && (unsigned)gd < (unsigned)Din && (unsigned)gh < (unsigned)Hin &&
                             (unsigned)gw < (unsigned)Win;
             off[it] = ok ? (unsigned)(kc * in_dhw + gd * in_hw + gh * Win + gw) : 0u;
@@ -120,34 +125,25 @@ struct Stager {
     // channels [c0, c0+KC) -> registers.  Only ISSUES the loads (padding pieces read offset 0, and so
     // do pieces of channels >= Cin when the last chunk is partial: nothing outside the tensor is ever
     // touched); nothing here consumes the data, so the wave does not wait for it.
-    __device__ __forceinline__ void load(const float *__restrict__ xc, int tid, int cin_left, f32x4 (&v)[NIT]) const {
+    __device__ __forceinline__ void load(const float *__restrict__ xc, int tid, int cin_left, Vec (&v)[NIT]) const {
         if (cin_left >= KC) {
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const f32x4 *>(xc + off[it]);
+            for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const Vec *>(xc + off[it]);
         } else {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const bool chan_ok = (it * 256 + tid) / (RQ * IN_D * IN_H) < cin_left;
-                v[it] = *reinterpret_cast<const f32x4 *>(xc + (chan_ok ? off[it] : 0u));
+                v[it] = *reinterpret_cast<const Vec *>(xc + (chan_ok ? off[it] : 0u));
             }
         }
     }
 
     // registers -> LDS image; padding pieces and channels >= Cin (cin_left = Cin - c0 < KC) become
     // zeros here, by a select on the way out.
-    __device__ __forceinline__ void store(float *__restrict__ buf, int tid, int cin_left, const f32x4 (&v)[NIT]) const {
-        unsigned m = vmask;
-        if (cin_left < KC) {
+    __device__ __forceinline__ void store(float *__restrict__ buf, int tid, int cin_left, const Vec (&v)[NIT]) const {
+        const unsigned m = store_mask(tid, cin_left);
 #pragma unroll
-            for (int it = 0; it < NIT; ++it)
-                if ((it * 256 + tid) / (RQ * IN_D * IN_H) >= cin_left) m &= ~(1u << it);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = it * 256 + tid;
-            const f32x4 z = ((m >> it) & 1u) ? v[it] : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<f32x4 *>(buf)[i] = z;
-        }
+        for (int it = 0; it < NIT; ++it) store_one(buf, tid, it, m, v[it]);
     }
 
     // The same store, one piece at a time (for kernels that interleave it with their MFMA stream).
@@ -160,10 +156,11 @@ struct Stager {
         }
         return m;
     }
-    static __device__ __forceinline__ void store_one(float *__restrict__ buf, int tid, int it, unsigned m, const f32x4 &v) {
+    static __device__ __forceinline__ void store_one(float *__restrict__ buf, int tid, int it, unsigned m, const Vec &v) {
         const int i = it * 256 + tid;
-        const f32x4 z = ((m >> it) & 1u) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<f32x4 *>(buf)[i] = z;
+        Vec z = v;
+        if (!((m >> it) & 1u)) z = Vec(0.0f);
+        if (ITEMS % 256 == 0 || i < ITEMS) reinterpret_cast<Vec *>(buf)[i] = z;
     }
 
     // Fallback for tensors whose rows are not 16-byte aligned (Win % 4 != 0, odd strides):
@@ -238,6 +235,72 @@ __device__ __forceinline__ void load_affine(const ConvArgs &a, int cbase, int la
         co = co < a.Cout ? co : a.Cout - 1;
         f.sc[r] = a.scale ? a.scale[co] : 1.0f;
         f.bi[r] = a.scale ? a.bias[co] : 0.0f;
+    }
+}
+
+// ---- fast epilogue toolkit (whole 32-channel groups, 16-byte aligned rows, no Sigmoid; the host
+// sets ConvArgs::fast_epi when a launch qualifies, everything else takes the generic epilogues).
+// Two measured facts shape it:
+//  * vector loads and stores retire through one in-order counter (vmcnt): a load issued behind a
+//    store is not usable before that store has been acknowledged, so a load/store/load/store chain
+//    costs a write round trip per link (40k cycles per workgroup in the first Winograd epilogue).
+//    All loads of the epilogue are therefore issued before its first store, results are formed IN
+//    PLACE in the accumulator registers, and the stores go out at the end, fire-and-forget.
+//  * stores are issue-bound: a wave-wide store instruction occupies the CU's store path for several
+//    hundred cycles whatever its width (32 x 8-byte stores per lane: 18k cycles), so lanes trade
+//    values first (DPP, no LDS) until each owns 4 consecutive outputs of one channel = one 16-byte
+//    store where it had four 4-byte or two 8-byte ones.
+__device__ __forceinline__ float dpp_xor1(float v) {   // value of lane ^ 1 (quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_xor2(float v) {   // value of lane ^ 2 (quad_perm [2,3,0,1])
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+// Registers a0..a3 of lanes 4j..4j+3 form a 4x4 block (register = channel c+k, lane = voxel 4j+i);
+// afterwards lane 4j+i holds channel c+i, voxels 4j..4j+3 in (a0..a3).  Two butterfly stages.
+__device__ __forceinline__ void quad_transpose(float &a0, float &a1, float &a2, float &a3, bool odd, bool hi) {
+    {
+        const float s01 = odd ? a0 : a1, s23 = odd ? a2 : a3;
+        const float g01 = dpp_xor1(s01), g23 = dpp_xor1(s23);
+        a0 = odd ? g01 : a0; a1 = odd ? a1 : g01;
+        a2 = odd ? g23 : a2; a3 = odd ? a3 : g23;
+    }
+    {
+        const float s02 = hi ? a0 : a2, s13 = hi ? a1 : a3;
+        const float g02 = dpp_xor2(s02), g13 = dpp_xor2(s13);
+        a0 = hi ? g02 : a0; a2 = hi ? a2 : g02;
+        a1 = hi ? g13 : a1; a3 = hi ? a3 : g13;
+    }
+}
+
+__device__ __forceinline__ float act_f(float y, float r, bool add_pre, bool relu, bool add_post) {
+    y = add_pre ? y + r : y;
+    const float t = y > 0.0f ? y : 0.0f;
+    y = relu ? t : y;
+    return add_post ? y + r : y;
+}
+
+// Lane owns the output PAIR (v0[r], v1[r]) at columns (2*col, 2*col+1) of channel
+// c(r) = (r&3) + 8*(r>>2) + 4*(lane>>5) -- the layout of the Winograd and transposed-convolution
+// kernels.  Even lanes end up with columns 4k..4k+3 of channel c(r), odd lanes with the same columns
+// of c(r+1).  base: channel-group base (wave-uniform), cs: channel stride in bytes, vo: this lane's
+// byte offset of its pair inside channel 4*(lane>>5).
+__device__ __forceinline__ void store_pairs_x4(char *base, int64_t cs, unsigned vo, bool ok, const f32x16 &v0,
+                                               const f32x16 &v1, int lane) {
+    const bool odd = (lane & 1) != 0;
+    const unsigned off = vo + (odd ? (unsigned)cs - 8u : 0u);   // odd lane: next channel, one pair to the left
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const int cl = (r & 3) + 8 * (r >> 2);
+        const float s0 = odd ? v0[r] : v0[r + 1], s1 = odd ? v1[r] : v1[r + 1];
+        const float g0 = dpp_xor1(s0), g1 = dpp_xor1(s1);
+        f32x4 o;
+        o[0] = odd ? g0 : v0[r];
+        o[1] = odd ? g1 : v1[r];
+        o[2] = odd ? v0[r + 1] : g0;
+        o[3] = odd ? v1[r + 1] : g1;
+        if (ok) *reinterpret_cast<f32x4 *>(base + cl * cs + off) = o;
     }
 }
 
@@ -350,7 +413,8 @@ conv3d_mfma_kernel(const ConvArgs a) {
     if (a.vec) {
         St st;
         st.init(tid, id0, ih0, ix0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
-        f32x4 pre[St::NIT], wpre[Ws::NIT];
+        typename St::Vec pre[St::NIT];
+        f32x4 wpre[Ws::NIT];
         st.load(xn, tid, a.Cin, pre);
         Ws::load(wg, tid, wpre);
         st.store(lds, tid, a.Cin, pre);
@@ -448,13 +512,13 @@ conv3d_mfma_kernel(const ConvArgs a) {
 // fragment reads (one 8-byte and two 4-byte LDS reads + 4 VALU ops per 4 MFMAs).  A lane owns output
 // pair t of a 64-voxel row, so the epilogue stores 8 bytes per lane, 256 contiguous bytes per
 // half-wave.
-template <int TD_, int TH_, int KC_>
+template <int TD_, int TH_, int KC_, int PIECE_ = 4>
 struct WinoCfg {
-    static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1;
+    static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1, PIECE = PIECE_;
     static constexpr int TW = 64, LPAD = 4, XOFF = 3;
     static constexpr int IN_D = TD + 2, IN_H = TH + 2, IN_W = TW + 2;
     static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;   // 72
-    using St = Stager<KC, IN_D, IN_H, IN_WV>;
+    using St = Stager<KC, IN_D, IN_H, IN_WV, PIECE>;
     static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int NB = TD * TH / 4;
     static constexpr int KP = KC / 2;
@@ -625,29 +689,16 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
             __builtin_amdgcn_sched_barrier(0);   // keep the next batch's address math / loads out of this one
         }
     }
-    // Stores are issue-bound (a wave-wide store instruction costs several hundred cycles of the
-    // CU's store path whatever its width), so neighbouring lanes trade halves first: the even lane
-    // of a pair ends up with 4 consecutive outputs of channel c, the odd lane with the same 4
-    // outputs of channel c+1, and each issues ONE 16-byte store where it had two 8-byte ones.
-    const bool odd = (lane & 1) != 0;
-    const unsigned adj = odd ? (unsigned)cs - 8u : 0u;     // odd lane: next channel, two outputs to the left
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const unsigned vo = voff[nb] + adj;
+        if constexpr (Cfg::PIECE == 4) {
+            store_pairs_x4(yb, cs, voff[nb], ok[nb], acc[0][nb], acc[1][nb], lane);
+        } else {   // rows only 8-byte aligned: one pair per store
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const int cl = (r & 3) + 8 * (r >> 2);
-            const float ya0 = acc[0][nb][r], ya1 = acc[1][nb][r], yb0 = acc[0][nb][r + 1], yb1 = acc[1][nb][r + 1];
-            const float s0 = odd ? ya0 : yb0, s1 = odd ? ya1 : yb1;
-            // quad_perm [1,0,3,2]: swap with the neighbouring lane (both lanes of a pair share ok[nb])
-            const float g0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xF, 0xF, true));
-            const float g1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xF, 0xF, true));
-            f32x4 o;
-            o[0] = odd ? g0 : ya0;
-            o[1] = odd ? g1 : ya1;
-            o[2] = odd ? yb0 : g0;
-            o[3] = odd ? yb1 : g1;
-            if (ok[nb]) *reinterpret_cast<f32x4 *>(yb + cl * cs + vo) = o;
+            for (int r = 0; r < 16; ++r)
+                if (ok[nb])
+                    *reinterpret_cast<float2 *>(yb + ((r & 3) + 8 * (r >> 2)) * cs + voff[nb]) =
+                        make_float2(acc[0][nb][r], acc[1][nb][r]);
         }
     }
 }
@@ -687,7 +738,8 @@ conv3d_wino_kernel(const ConvArgs a) {
 
     St st;
     st.init(tid, job.od0 - 1, job.oh0 - 1, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
-    f32x4 pre[St::NIT], wpre[Ws::NIT];
+    typename St::Vec pre[St::NIT];
+        f32x4 wpre[Ws::NIT];
     st.load(xn, tid, a.Cin, pre);
     Ws::load(wg, tid, wpre);
     if (tid < 64) {
@@ -728,11 +780,11 @@ conv3d_wino_kernel(const ConvArgs a) {
 // ConvTranspose3d(k=3, s=2, p=1, op=1): out[o] = sum_i sum_t x[i] * w[t], o = 2i - 1 + t.
 // Per dimension, output parity 0 uses tap 1 at input offset 0; parity 1 uses tap 2 at offset 0
 // and tap 0 at offset +1.
-template <int MI_, int TD_, int TH_, int KC_>
+template <int MI_, int TD_, int TH_, int KC_, int PIECE_ = 4>
 struct DeconvCfg {
-    static constexpr int MI = MI_, TD = TD_, TH = TH_, KC = KC_;
+    static constexpr int MI = MI_, TD = TD_, TH = TH_, KC = KC_, PIECE = PIECE_;
     static constexpr int IN_D = TD + 1, IN_H = TH + 1, IN_WV = 36;   // 33 needed columns -> 9 float4 pieces
-    using St = Stager<KC, IN_D, IN_H, IN_WV>;
+    using St = Stager<KC, IN_D, IN_H, IN_WV, PIECE>;
     static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int NB = TD * TH / 4;
     static constexpr int KP = KC / 2;
@@ -785,7 +837,66 @@ __device__ __forceinline__ void deconv_compute_chunk(const float *__restrict__ b
     }
 }
 
-template <class Cfg, int PD, int PH>
+// Fast epilogue of one parity class (toolkit comment above): lane holds the output pair
+// (2*iw, 2*iw+1) of row (2*id+PD, 2*ih+PH) for 16 channels.
+template <class Cfg, int PD, int PH, bool RES>
+__device__ __forceinline__ void deconv_epilogue_fast(const ConvArgs &a, f32x16 (&acc)[2][Cfg::NB][Cfg::MI], int id0,
+                                                     int ih0, int iw0, int cg, int64_t n, int lane, int wave) {
+    constexpr int MI = Cfg::MI, TH = Cfg::TH, NB = Cfg::NB;
+    const int iw = iw0 + (lane & 31), half = lane >> 5;
+    const int out_hw = a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
+    const int64_t cs = (int64_t)out_dhw * 4;
+    const bool relu = (a.flags & SNVC_EPI_RELU) != 0, add_pre = (a.flags & SNVC_EPI_ADD_PRE) != 0,
+               add_post = (a.flags & SNVC_EPI_ADD_POST) != 0;
+    unsigned voff[NB];
+    bool ok[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int id = id0 + row / TH, ih = ih0 + row % TH;
+        ok[nb] = id < a.Din && ih < a.Hin && iw < a.Win;      // Win is even (host): the pair lane shares it
+        const int sp = ok[nb] ? (2 * id + PD) * out_hw + (2 * ih + PH) * a.Wout + 2 * iw : 0;
+        voff[nb] = 4u * (unsigned)(4 * half * out_dhw + sp);
+    }
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+        const int cbase = __builtin_amdgcn_readfirstlane((cg * MI + m) * 32);
+        const char *const rb = RES ? reinterpret_cast<const char *>(a.res + n * a.r_bs) + cbase * cs : nullptr;
+        ChanAffine f;
+        load_affine(a, cbase, lane, f);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                float2 rv[RES ? 8 : 1];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int cl = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
+                    if (RES) rv[q] = *reinterpret_cast<const float2 *>(rb + cl * cs + voff[nb]);
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int r = r0 + q;
+                    acc[0][nb][m][r] = act_f(acc[0][nb][m][r] * f.sc[r] + f.bi[r], RES ? rv[q].x : 0.0f, add_pre, relu, add_post);
+                    acc[1][nb][m][r] = act_f(acc[1][nb][m][r] * f.sc[r] + f.bi[r], RES ? rv[q].y : 0.0f, add_pre, relu, add_post);
+                }
+                // one batch of loads in flight at a time (register pressure): pin this batch's results
+                // before the next batch's loads may be issued
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    asm volatile("" : "+v"(acc[0][nb][m][r0 + q]), "+v"(acc[1][nb][m][r0 + q])::"memory");
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+        const int cbase = __builtin_amdgcn_readfirstlane((cg * MI + m) * 32);
+        char *const yb = reinterpret_cast<char *>(a.y + n * a.y_bs) + cbase * cs;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) store_pairs_x4(yb, cs, voff[nb], ok[nb], acc[0][nb][m], acc[1][nb][m], lane);
+    }
+}
+
+template <class Cfg, int EPI, int PD, int PH>   // EPI: 0 generic epilogue, 1 fast, 2 fast with residual
 __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds, int tile, int cg, int64_t n) {
     constexpr int MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, KP = Cfg::KP, NB = Cfg::NB;
     constexpr int CH = Cfg::CH, TILE = Cfg::TILE;
@@ -817,7 +928,8 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
     if (a.vec) {
         St st;
         st.init(tid, id0, ih0, iw0, a.Din, a.Hin, a.Win, in_hw, in_dhw);
-        f32x4 pre[St::NIT], wpre[Ws::NIT];
+        typename St::Vec pre[St::NIT];
+        f32x4 wpre[Ws::NIT];
         st.load(xn, tid, a.Cin, pre);
         Ws::load(wg, tid, wpre);
         st.store(lds, tid, a.Cin, pre);
@@ -851,7 +963,10 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
         }
     }
 
-    // epilogue: outputs (2*id + PD, 2*ih + PH, 2*iw + {0,1}) -> one 8-byte store per lane
+    if constexpr (EPI != 0) {
+        deconv_epilogue_fast<Cfg, PD, PH, EPI == 2>(a, acc, id0, ih0, iw0, cg, n, lane, wave);
+    } else {
+    // generic epilogue: outputs (2*id + PD, 2*ih + PH, 2*iw + {0,1}) -> one 8-byte store per lane
     const int iw = iw0 + (lane & 31);
     const int64_t out_hw = (int64_t)a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
     float *yn = a.y + n * a.y_bs;
@@ -883,9 +998,10 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
             }
         }
     }
+    }
 }
 
-template <class Cfg>
+template <class Cfg, int EPI>
 __global__ void __launch_bounds__(256, 2)
 deconv3d_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -896,10 +1012,10 @@ deconv3d_mfma_kernel(const ConvArgs a) {
     const int cg = blockIdx.y;
     const int64_t n = blockIdx.z;
     switch (slot) {  // wave-uniform
-        case 0: deconv_class_body<Cfg, 1, 1>(a, lds, tile, cg, n); break;
-        case 1: deconv_class_body<Cfg, 1, 0>(a, lds, tile, cg, n); break;
-        case 2: deconv_class_body<Cfg, 0, 1>(a, lds, tile, cg, n); break;
-        default: deconv_class_body<Cfg, 0, 0>(a, lds, tile, cg, n); break;
+        case 0: deconv_class_body<Cfg, EPI, 1, 1>(a, lds, tile, cg, n); break;
+        case 1: deconv_class_body<Cfg, EPI, 1, 0>(a, lds, tile, cg, n); break;
+        case 2: deconv_class_body<Cfg, EPI, 0, 1>(a, lds, tile, cg, n); break;
+        default: deconv_class_body<Cfg, EPI, 0, 0>(a, lds, tile, cg, n); break;
     }
 }
 
@@ -1060,8 +1176,11 @@ using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2, false, 2, 1>;
 using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 4, 2, false, 2, 1>;
 using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false, 2, 1>;
 using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64 voxels, 2 input channels per chunk
+using CfgWino8  = WinoCfg<2, 4, 2, 2>;       // the same for rows that are only 8-byte aligned (W % 4 == 2)
 using CfgDCM1   = DeconvCfg<1, 2, 4, 4>;
 using CfgDCM2   = DeconvCfg<2, 2, 4, 4>;
+using CfgDCM1v8 = DeconvCfg<1, 2, 4, 4, 2>;
+using CfgDCM2v8 = DeconvCfg<2, 2, 4, 4, 2>;
 
 template <class Cfg>
 constexpr Plan plan_of(int kind) { return Plan{Cfg::MI, Cfg::KC, Cfg::TD, Cfg::TH, 0, 0, 0, 0, 0, kind}; }
@@ -1132,34 +1251,46 @@ inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
     return (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, CfgWino::KC) * CfgWino::WF;
 }
 
-template <bool RES, bool PLANE>
+template <class Cfg, bool RES, bool PLANE>
 void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    constexpr int BYTES = CfgWino::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
+    constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
     static bool attr_done = false;
     if (!attr_done && BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wino_kernel<CfgWino, RES, PLANE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wino_kernel<Cfg, RES, PLANE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
         attr_done = true;
     }
-    conv3d_wino_kernel<CfgWino, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
+    conv3d_wino_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
 }
 
+template <class Cfg>
 void launch_wino(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    if (a.res && a.plane) launch_wino_variant<true, true>(a, grid, st);
-    else if (a.res) launch_wino_variant<true, false>(a, grid, st);
-    else if (a.plane) launch_wino_variant<false, true>(a, grid, st);
-    else launch_wino_variant<false, false>(a, grid, st);
+    if (a.res && a.plane) launch_wino_variant<Cfg, true, true>(a, grid, st);
+    else if (a.res) launch_wino_variant<Cfg, true, false>(a, grid, st);
+    else if (a.plane) launch_wino_variant<Cfg, false, true>(a, grid, st);
+    else launch_wino_variant<Cfg, false, false>(a, grid, st);
+}
+
+template <class Cfg, int EPI>
+void launch_deconv_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done && Cfg::LDS_BYTES > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&deconv3d_mfma_kernel<Cfg, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        attr_done = true;
+    }
+    deconv3d_mfma_kernel<Cfg, EPI><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 
 template <class Cfg>
 void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done && Cfg::LDS_BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&deconv3d_mfma_kernel<Cfg>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        attr_done = true;
+    // the pair exchange of the fast epilogue needs an even input width (both lanes of a pair in range)
+    if (a.fast_epi && a.Win % 2 == 0) {
+        if (a.res) launch_deconv_variant<Cfg, 2>(a, grid, st);
+        else launch_deconv_variant<Cfg, 1>(a, grid, st);
+    } else {
+        launch_deconv_variant<Cfg, 0>(a, grid, st);
     }
-    deconv3d_mfma_kernel<Cfg><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 
 }  // namespace
@@ -1256,6 +1387,16 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : out_sz;
     a.vec = (d->Win % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (a.x_bs % 4 == 0);
+    const bool vec8 = (d->Win % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0) && (a.x_bs % 2 == 0);
+    // fast epilogues: (wave-uniform channel base) + 32-bit lane byte offsets, whole 32-channel groups, no
+    // Sigmoid; 16-byte stores when the output rows allow them
+    const char *ne = getenv("SNVC_NO_FAST_EPILOGUE");   // development knob
+    const bool fast_common = (int64_t)d->Dout * d->Hout * d->Wout < ((int64_t)1 << 27) && d->Cout % 32 == 0 &&
+                             !(d->flags & SNVC_EPI_SIGMOID) && !(ne && ne[0] == '1');
+    const bool epi16 = d->Wout % 4 == 0 && a.y_bs % 4 == 0 && a.r_bs % 4 == 0 &&
+                       ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
+                         reinterpret_cast<uintptr_t>(depth_planes)) & 15) == 0;
+    a.fast_epi = fast_common && epi16;
 
     // 1x1x1 convolution to <= 2 channels: HBM-bound streaming kernel (raw weights ride at the end of
     // the packed buffer, see snvc_conv3d_pack_weights)
@@ -1277,15 +1418,11 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
     {
         const int64_t wino = wino_packed_count(*d);
         const char *nw = getenv("SNVC_NO_WINOGRAD");   // development knob: force the direct kernel
-        const bool pair_ok = (d->Wout % 2 == 0) && a.vec && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
+        const bool pair_ok = (d->Wout % 2 == 0) && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
                              ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
                                reinterpret_cast<uintptr_t>(depth_planes)) & 7) == 0;
-        // the Winograd epilogue addresses outputs as (uniform channel base) + 32-bit lane byte offset and
-        // assumes whole 32-channel groups; it has no Sigmoid
-        const bool epi_ok = (int64_t)d->Dout * d->Hout * d->Wout < ((int64_t)1 << 27) &&
-                            d->Cout % 32 == 0 && !(d->flags & SNVC_EPI_SIGMOID) &&
-                            d->Wout % 4 == 0 && a.y_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-        if (wino && pair_ok && epi_ok && !(nw && nw[0] == '1')) {
+        const bool wide = a.vec && epi16;   // 16-byte staging and stores; else 8-byte ones (pair_ok)
+        if (wino && pair_ok && fast_common && (wide || vec8) && !(nw && nw[0] == '1')) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, CfgWino::KC);
             a.tiles_d = ceil_div(d->Dout, CfgWino::TD); a.tiles_h = ceil_div(d->Hout, CfgWino::TH);
@@ -1294,7 +1431,8 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
             const int64_t nj = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w * a.groups * d->N;
             if (nj < ((int64_t)1 << 31)) {
                 a.njobs = (int)nj;
-                launch_wino(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                if (wide) launch_wino<CfgWino>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                else launch_wino<CfgWino8>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 return check_launch("snvc_conv3d_forward(winograd)");
             }
         }
@@ -1321,8 +1459,14 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
         case K5D2_M2: launch_conv<CfgK5D2M2>(a, grid, st); break;
         case K7_M1: launch_conv<CfgK7M1>(a, grid, st); break;
         case K7_M2: launch_conv<CfgK7M2>(a, grid, st); break;
-        case DC_M1: launch_deconv<CfgDCM1>(a, grid, st); break;
-        case DC_M2: launch_deconv<CfgDCM2>(a, grid, st); break;
+        case DC_M1:
+            if (!a.vec && vec8) { a.vec = 1; launch_deconv<CfgDCM1v8>(a, grid, st); }
+            else launch_deconv<CfgDCM1>(a, grid, st);
+            break;
+        case DC_M2:
+            if (!a.vec && vec8) { a.vec = 1; launch_deconv<CfgDCM2v8>(a, grid, st); }
+            else launch_deconv<CfgDCM2>(a, grid, st);
+            break;
         default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: no kernel");
     }
     return check_launch("snvc_conv3d_forward");
