@@ -281,6 +281,21 @@ __device__ __forceinline__ float act_f(float y, float r, bool add_pre, bool relu
     return add_post ? y + r : y;
 }
 
+// Four consecutive floats; V4: one 16-byte load (the caller guarantees all four exist), else two
+// 8-byte loads, the second only where `hi_ok` (it is redirected to the first pair otherwise).
+template <bool V4>
+__device__ __forceinline__ f32x4 load_quad(const char *p, bool hi_ok) {
+    if constexpr (V4) {
+        return *reinterpret_cast<const f32x4 *>(p);
+    } else {
+        const float2 lo = *reinterpret_cast<const float2 *>(p);
+        const float2 hi = *reinterpret_cast<const float2 *>(p + (hi_ok ? 8 : 0));
+        f32x4 o;
+        o[0] = lo.x; o[1] = lo.y; o[2] = hi.x; o[3] = hi.y;
+        return o;
+    }
+}
+
 // Lane owns the output PAIR (v0[r], v1[r]) at columns (2*col, 2*col+1) of channel
 // c(r) = (r&3) + 8*(r>>2) + 4*(lane>>5) -- the layout of the Winograd and transposed-convolution
 // kernels.  Even lanes end up with columns 4k..4k+3 of channel c(r), odd lanes with the same columns
@@ -496,45 +511,51 @@ conv3d_mfma_kernel(const ConvArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------ conv k3: Winograd F(2,3) along W
+// ------------------------------------------------------------------------------------ conv k3: Winograd F(4,3) along W
 // For the 3x3x3 / stride-1 convolutions (all of cfg2's 3D FLOPs outside the hourglass resampling
-// layers) the W dimension is computed with the 1-D Winograd minimal-filtering algorithm F(2,3):
-// two adjacent outputs from four inputs with 4 multiplications instead of 6,
-//     V = B^T d   : V0 = d0-d2, V1 = d1+d2, V2 = d2-d1, V3 = d1-d3      (d = x[2t-1 .. 2t+2])
-//     U = G g     : U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2   (precomputed at pack time)
-//     m_p = sum over (cin, kd, kh) of U_p * V_p                          (the MFMA contraction)
-//     y[2t] = m0+m1+m2,  y[2t+1] = m1-m2-m3
-// so a (cin-pair, kd, kh) step issues 4 MFMAs for 64 output voxels where the direct form issues 6:
-// 2/3 of the matrix-core work, still exact fp32 arithmetic (error of F(2,3) in fp32 ~1e-7 relative;
-// cuDNN, the reference's backend, picks the same family of algorithms under its autotuner,
-// tools/inference_agnostic.py:18).  The input transform costs nothing extra in memory: the LDS image
-// is the same raw tile the direct kernel stages, and V is formed in registers right after the
-// fragment reads (one 8-byte and two 4-byte LDS reads + 4 VALU ops per 4 MFMAs).  A lane owns output
-// pair t of a 64-voxel row, so the epilogue stores 8 bytes per lane, 256 contiguous bytes per
-// half-wave.
+// layers) the W dimension is computed with the 1-D Winograd minimal-filtering algorithm F(4,3):
+// four adjacent outputs from six inputs with 6 multiplications instead of 12,
+//     V = B^T d   (d = x[4t-1 .. 4t+4]):  V0 = 4d0-5d2+d4          V5 = 4d1-5d3+d5
+//                  V1 = (d4-4d2)+(d3-4d1)   V2 = (d4-4d2)-(d3-4d1)
+//                  V3 = (d4-d2)+2(d3-d1)    V4 = (d4-d2)-2(d3-d1)
+//     U = G g     : U0 = g0/4, U1 = -(g0+g1+g2)/6, U2 = -(g0-g1+g2)/6,
+//                   U3 = g0/24+g1/12+g2/6, U4 = g0/24-g1/12+g2/6, U5 = g2     (at weight-pack time, in fp64)
+//     m_p = sum over (cin, kd, kh) of U_p * V_p                                 (the MFMA contraction)
+//     y0 = m0+m1+m2+m3+m4        y1 = (m1-m2)+2(m3-m4)
+//     y2 = (m1+m2)+4(m3+m4)      y3 = (m1-m2)+8(m3-m4)+m5
+// so a (cin-pair, kd, kh) step issues 6 MFMAs for 128 output voxels where the direct form issues 12:
+// half of the matrix-core work, still fp32 products and fp32 accumulation (measured error of the fp32
+// F(4,3) against an fp64 convolution: 2.2e-6 of the output range on a 576-term contraction, the
+// direct fp32 chain 0.7e-6 -- three orders below the 1e-3 contract; cuDNN, the reference's backend,
+// picks from the same family of algorithms under its autotuner, tools/inference_agnostic.py:18).
+// The input transform costs nothing extra in memory: the LDS image is the raw tile the direct kernel
+// stages and V is formed in registers right after the fragment reads (one 16-byte and two 4-byte LDS
+// reads + 12 VALU ops per 6 MFMAs).  The 32 MFMA columns are 2 rows x 16 tiles of 4 outputs: a lane
+// owns 4 consecutive outputs, so the epilogue stores 16 bytes per lane and channel.
 template <int TD_, int TH_, int KC_, int PIECE_ = 4>
 struct WinoCfg {
     static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1, PIECE = PIECE_;
+    static constexpr int NPOS = 6;
     static constexpr int TW = 64, LPAD = 4, XOFF = 3;
     static constexpr int IN_D = TD + 2, IN_H = TH + 2, IN_W = TW + 2;
     static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;   // 72
     using St = Stager<KC, IN_D, IN_H, IN_WV, PIECE>;
     static constexpr int CH = St::CH, TILE = St::TILE;
-    static constexpr int NB = TD * TH / 4;
+    static constexpr int NB = TD * TH / 8;                    // row PAIRS per wave (4 waves)
     static constexpr int KP = KC / 2;
-    static constexpr int WF = 9 * 4 * KP * 64;               // packed floats per chunk: [tap9][pos][kp][lane]
+    static constexpr int WF = 9 * NPOS * KP * 64;             // packed floats per chunk: [tap9][pos][kp][lane]
     using Ws = WeightStager<WF>;
     static constexpr int LDS_BYTES = (TILE * 2 + WF * 2) * 4;
-    static_assert(TD * TH % 4 == 0, "rows must split over 4 waves");
-    static_assert(CH % 2 == 0 && IN_WV % 2 == 0, "8-byte LDS reads need even strides");
+    static_assert(TD * TH % 8 == 0 && TH % 2 == 0, "row pairs must split over 4 waves");
+    static_assert(CH % 4 == 0 && IN_WV % 4 == 0, "16-byte LDS reads need aligned strides");
 };
 
-// One (kd, kh, k-pair) step = 4 weight fragments (positions 0..3) + NB raw input quadruples.
+// One (kd, kh, k-pair) step = 6 weight fragments (positions 0..5) + NB raw input sextuples.
 template <int NB>
 struct WinoStep {
-    float a[4];
-    float d0[NB], d3[NB];
-    float2 d12[NB];
+    float a[6];
+    float d0[NB], d5[NB];
+    f32x4 d14[NB];
 };
 
 template <class Cfg>
@@ -544,15 +565,15 @@ __device__ __forceinline__ void wino_load_step(const float *__restrict__ img, co
     const int kp = step % KP, tap9 = step / KP;         // compile-time after unrolling
     const int kd = tap9 / 3, kh = tap9 % 3;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) o.a[p] = wl[((tap9 * 4 + p) * KP + kp) * 64];
+    for (int p = 0; p < 6; ++p) o.a[p] = wl[((tap9 * 6 + p) * KP + kp) * 64];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int row = wave * NB + nb;
-        const int dd = row / TH, hh = row % TH;
-        const float *px = img + bbase + kp * 2 * CH + ((dd + kd) * IN_H + hh + kh) * IN_WV;
+        const int rp = wave * NB + nb;                  // row pair: rows (dd, hh0) and (dd, hh0 + 1)
+        const int dd = rp / (TH / 2), hh0 = 2 * (rp % (TH / 2));
+        const float *px = img + bbase + kp * 2 * CH + ((dd + kd) * IN_H + hh0 + kh) * IN_WV;
         o.d0[nb] = px[0];
-        o.d12[nb] = *reinterpret_cast<const float2 *>(__builtin_assume_aligned(px + 1, 8));
-        o.d3[nb] = px[3];
+        o.d14[nb] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(px + 1, 16));
+        o.d5[nb] = px[5];
     }
 }
 
@@ -561,28 +582,27 @@ __device__ __forceinline__ void wino_load_step(const float *__restrict__ img, co
 // ends with a bare barrier instead of a vmcnt wait + a burst of LDS writes.
 template <class Cfg, class Mid>
 __device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img, const float *__restrict__ wl,
-                                                   int bbase, int wave, f32x16 (&acc)[4][Cfg::NB], Mid &&mid) {
+                                                   int bbase, int wave, f32x16 (&acc)[6][Cfg::NB], Mid &&mid) {
     constexpr int NB = Cfg::NB, NS = 9 * Cfg::KP;
-    // software pipeline: the LDS reads of step s+1 are issued before the MFMAs of step s
-    WinoStep<NB> cur, nxt;
-    wino_load_step<Cfg>(img, wl, bbase, wave, 0, cur);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        if (s + 1 < NS) wino_load_step<Cfg>(img, wl, bbase, wave, s + 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
+        WinoStep<NB> cur;
+        wino_load_step<Cfg>(img, wl, bbase, wave, s, cur);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const float d1 = cur.d12[nb].x, d2 = cur.d12[nb].y;
-            const float v0 = cur.d0[nb] - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - cur.d3[nb];
+            const float d0 = cur.d0[nb], d1 = cur.d14[nb][0], d2 = cur.d14[nb][1], d3 = cur.d14[nb][2],
+                        d4 = cur.d14[nb][3], d5 = cur.d5[nb];
+            const float ta = d4 - 4.0f * d2, tb = d3 - 4.0f * d1, tc = d4 - d2, te = d3 - d1;
+            const float v0 = 4.0f * d0 + (d4 - 5.0f * d2), v5 = 4.0f * d1 + (d5 - 5.0f * d3);
+            const float v1 = ta + tb, v2 = ta - tb, v3 = tc + 2.0f * te, v4 = tc - 2.0f * te;
             acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0], v0, acc[0][nb], 0, 0, 0);
             acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1], v1, acc[1][nb], 0, 0, 0);
             acc[2][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[2], v2, acc[2][nb], 0, 0, 0);
             acc[3][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[3], v3, acc[3][nb], 0, 0, 0);
+            acc[4][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[4], v4, acc[4][nb], 0, 0, 0);
+            acc[5][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[5], v5, acc[5][nb], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
         mid(s);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + 1 < NS) cur = nxt;
     }
 }
 
@@ -605,28 +625,22 @@ __device__ __forceinline__ WinoJob wino_decode_job(const ConvArgs &a, int v, int
     return o;
 }
 
-// Epilogue of one job.  Vector-memory loads and stores retire through ONE in-order counter (vmcnt), so
-// a load issued after a store cannot be consumed before that store has been acknowledged by the
-// memory system -- a load -> store -> load -> store chain costs a full write round trip per link
-// (measured: 40k cycles per job when the residual / affine loads were interleaved with the stores).
-// Hence: per-channel scale and bias come in through LDS (fetched by 64 threads at the start of the
-// job, parked during its first chunk; lgkmcnt), every vector load of the job (residual or depth-class planes, both row blocks) is issued before
-// the first store, and the stores are then fire-and-forget.
-// Results are formed IN PLACE (y0 -> acc[0], y1 -> acc[1]) so no extra registers are held while the
-// second row block's addends are fetched.
-// Addresses are a wave-uniform channel base (SGPR pair) + one 32-bit per-lane byte offset per row
+// Epilogue of one job (fast-epilogue toolkit above): output transform in place (y0..y3 -> acc[0..3],
+// a third of the accumulator registers become free), per-channel scale and bias through LDS (parked
+// at kernel start; lgkmcnt), every vector load (residual or depth-class planes) before the first
+// store, addresses = wave-uniform channel base (SGPR pair) + one 32-bit per-lane byte offset per row
 // block (the host routes layers with more than 2^27 output voxels per channel elsewhere).
 template <class Cfg, bool RES, bool PLANE>
-__device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[4][Cfg::NB],
+__device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[6][Cfg::NB],
                                               const float *__restrict__ aff, int lane, int wave) {
     constexpr int NB = Cfg::NB, TH = Cfg::TH;
-    const int ow = job.ow0 + 2 * (lane & 31);
+    constexpr bool V4 = Cfg::PIECE == 4;           // 16-byte loads / stores (Wout % 4 == 0); else 8-byte halves
+    const int ow = job.ow0 + 4 * (lane & 15), rowsel = (lane >> 4) & 1;
     const int out_hw = a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
     const int cbase = __builtin_amdgcn_readfirstlane(job.cg * 32);
     const int half = lane >> 5;                     // accumulator register r of this lane is channel
                                                     //   cbase + (r&3) + 8*(r>>2) + 4*half
     // Cout % 32 == 0 (host): every channel of the group exists, no channel predicates anywhere
-    const int hoff = 4 * half;
     const bool relu = (a.flags & SNVC_EPI_RELU) != 0, add_pre = (a.flags & SNVC_EPI_ADD_PRE) != 0,
                add_post = (a.flags & SNVC_EPI_ADD_POST) != 0;
     const int64_t cs = (int64_t)out_dhw * 4, ps = (int64_t)out_hw * 12;   // channel strides in bytes
@@ -635,72 +649,76 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
     const char *const pb =
         PLANE ? reinterpret_cast<const char *>(a.plane + job.n * (int64_t)a.Cout * 3 * out_hw) + cbase * ps : nullptr;
 
-    // output transform first, in place (y0 -> acc[0], y1 -> acc[1]): half of the accumulator registers
-    // are free for the rest of the epilogue
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r];
-            acc[0][nb][r] = (m0 + m1) + m2;
-            acc[1][nb][r] = (m1 - m2) - m3;
+            const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r],
+                        m4 = acc[4][nb][r], m5 = acc[5][nb][r];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            acc[0][nb][r] = (m0 + s12) + s34;
+            acc[1][nb][r] = d12 + 2.0f * d34;
+            acc[2][nb][r] = s12 + 4.0f * s34;
+            acc[3][nb][r] = (d12 + 8.0f * d34) + m5;
         }
     __builtin_amdgcn_sched_barrier(0);
 
     unsigned voff[NB];
-    bool ok[NB];
+    bool ok0[NB], ok1[NB];     // outputs (ow, ow+1) and (ow+2, ow+3) in range (Wout is even)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int row = wave * NB + nb;
-        const int od = job.od0 + row / TH, oh = job.oh0 + row % TH;
-        // Wout is even: ow+1 is in range too
-        ok[nb] = od < a.Dout && oh < a.Hout && ow < a.Wout;
-        const int sp = ok[nb] ? od * out_hw + oh * a.Wout + ow : 0;
-        voff[nb] = 4u * (unsigned)(hoff * out_dhw + sp);
+        const int rp = wave * NB + nb;
+        const int od = job.od0 + rp / (TH / 2), oh = job.oh0 + 2 * (rp % (TH / 2)) + rowsel;
+        const bool row_ok = od < a.Dout && oh < a.Hout;
+        ok0[nb] = row_ok && ow < a.Wout;
+        ok1[nb] = row_ok && ow + 2 < a.Wout;
+        const int sp = ok0[nb] ? od * out_hw + oh * a.Wout + ow : 0;
+        voff[nb] = 4u * (unsigned)(4 * half * out_dhw + sp);
         const int cls = od == 0 ? 0 : (od >= a.Dout - 1 ? 2 : 1);
-        const unsigned poff = 4u * (unsigned)(hoff * 3 * out_hw + (ok[nb] ? cls * out_hw + oh * a.Wout + ow : 0));
-        // addends are fetched eight channels at a time (loads behind loads cost nothing; only a load
+        const unsigned poff = 4u * (unsigned)(4 * half * 3 * out_hw + (ok0[nb] ? cls * out_hw + oh * a.Wout + ow : 0));
+        // addends are fetched four channels at a time (loads behind loads cost nothing; only a load
         // behind a STORE would wait for the write to be acknowledged)
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 8) {
-            float2 rv[RES ? 8 : 1], pv[PLANE ? 8 : 1];
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+            f32x4 rv[RES ? 4 : 1], pv[PLANE ? 4 : 1];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const int cl = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);     // channel within the group
-                if (RES) rv[q] = *reinterpret_cast<const float2 *>(rb + cl * cs + voff[nb]);
-                if (PLANE) pv[q] = *reinterpret_cast<const float2 *>(pb + cl * ps + poff);
+                if (RES) rv[q] = load_quad<V4>(rb + cl * cs + voff[nb], ok1[nb]);
+                if (PLANE) pv[q] = load_quad<V4>(pb + cl * ps + poff, ok1[nb]);
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const int r = r0 + q;
                 const float sc = aff[(r & 3) + 8 * (r >> 2) + 4 * half], bi = aff[32 + (r & 3) + 8 * (r >> 2) + 4 * half];
-                float y0 = acc[0][nb][r], y1 = acc[1][nb][r];
-                if (PLANE) { y0 += pv[q].x; y1 += pv[q].y; }
-                y0 = y0 * sc + bi;
-                y1 = y1 * sc + bi;
-                if (RES) { y0 = add_pre ? y0 + rv[q].x : y0; y1 = add_pre ? y1 + rv[q].y : y1; }
-                const float t0 = y0 > 0.0f ? y0 : 0.0f, t1 = y1 > 0.0f ? y1 : 0.0f;
-                y0 = relu ? t0 : y0;
-                y1 = relu ? t1 : y1;
-                if (RES) { y0 = add_post ? y0 + rv[q].x : y0; y1 = add_post ? y1 + rv[q].y : y1; }
-                acc[0][nb][r] = y0;
-                acc[1][nb][r] = y1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float y = acc[j][nb][r];
+                    if (PLANE) y += pv[q][j];
+                    acc[j][nb][r] = act_f(y * sc + bi, RES ? rv[q][j] : 0.0f, add_pre, relu, add_post);
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);   // keep the next batch's address math / loads out of this one
+            // one batch of loads in flight at a time: pin this batch's results before the next loads
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                asm volatile("" : "+v"(acc[0][nb][r0 + q]), "+v"(acc[1][nb][r0 + q]), "+v"(acc[2][nb][r0 + q]),
+                             "+v"(acc[3][nb][r0 + q])::"memory");
         }
     }
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        if constexpr (Cfg::PIECE == 4) {
-            store_pairs_x4(yb, cs, voff[nb], ok[nb], acc[0][nb], acc[1][nb], lane);
-        } else {   // rows only 8-byte aligned: one pair per store
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (ok[nb])
-                    *reinterpret_cast<float2 *>(yb + ((r & 3) + 8 * (r >> 2)) * cs + voff[nb]) =
-                        make_float2(acc[0][nb][r], acc[1][nb][r]);
+        for (int r = 0; r < 16; ++r) {
+            char *const dst = yb + ((r & 3) + 8 * (r >> 2)) * cs + voff[nb];
+            if constexpr (V4) {
+                f32x4 o;
+                o[0] = acc[0][nb][r]; o[1] = acc[1][nb][r]; o[2] = acc[2][nb][r]; o[3] = acc[3][nb][r];
+                if (ok0[nb]) *reinterpret_cast<f32x4 *>(dst) = o;
+            } else {   // rows only 8-byte aligned (W % 4 == 2): the last tile of a row is half valid
+                if (ok0[nb]) *reinterpret_cast<float2 *>(dst) = make_float2(acc[0][nb][r], acc[1][nb][r]);
+                if (ok1[nb]) *reinterpret_cast<float2 *>(dst + 8) = make_float2(acc[2][nb][r], acc[3][nb][r]);
+            }
         }
-    }
 }
 
 template <class Cfg, bool RES, bool PLANE>
@@ -713,9 +731,9 @@ conv3d_wino_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, TD, TH);
 
-    f32x16 acc[4][NB];
+    f32x16 acc[6][NB];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 6; ++p)
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -723,8 +741,9 @@ conv3d_wino_kernel(const ConvArgs a) {
 
     const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     const float *xn = a.x + job.n * a.x_bs;
-    // B-fragment base: lane&31 = output pair t (inputs 2t-1..2t+2 = image columns 2t+3..2t+6), lane>>5 = k
-    const int bbase = (lane >> 5) * CH + 2 * (lane & 31) + Cfg::XOFF;
+    // B-fragment base: lane&15 = output quad t (inputs 4t-1..4t+4 = image columns 4t+3..4t+8),
+    // (lane>>4)&1 = row of the row pair, lane>>5 = k
+    const int bbase = (lane >> 5) * CH + ((lane >> 4) & 1) * Cfg::IN_WV + 4 * (lane & 15) + Cfg::XOFF;
     float *const wlds = lds + 2 * TILE;
     float *const aff = wlds + 2 * WF;      // scale | bias of this job's 32 channels
     const int nchunks = a.nchunks_wino;
@@ -1115,7 +1134,7 @@ __global__ void pack_deconv_weights_kernel(const float *__restrict__ w, float *_
 }
 
 // Winograd packing (k3, s1): packed[cg][chunk][tap9 = kd*3+kh][pos][kp][half][i] = U_pos of the three kw taps of
-// W[co = cg*32 + i][ci = chunk*KC + 2kp + half][kd][kh][:]
+// W[co = cg*32 + i][ci = chunk*KC + 2kp + half][kd][kh][:]   (F(4,3): U = G g, formed in fp64, rounded once)
 __global__ void pack_wino_weights_kernel(const float *__restrict__ w, float *__restrict__ packed, int Cout, int Cin,
                                          int KC, int nchunks, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1125,18 +1144,25 @@ __global__ void pack_wino_weights_kernel(const float *__restrict__ w, float *__r
     const int ii = (int)(r % 32); r /= 32;
     const int half = (int)(r % 2); r /= 2;
     const int kp = (int)(r % KP); r /= KP;
-    const int pos = (int)(r % 4); r /= 4;
+    const int pos = (int)(r % 6); r /= 6;
     const int tap9 = (int)(r % 9); r /= 9;
     const int chunk = (int)(r % nchunks); r /= nchunks;
     const int cg = (int)r;
     const int co = cg * 32 + ii, ci = chunk * KC + 2 * kp + half;
-    float u = 0.0f;
+    double u = 0.0;
     if (co < Cout && ci < Cin) {
         const float *g = w + (((int64_t)co * Cin + ci) * 9 + tap9) * 3;
-        const float g0 = g[0], g1 = g[1], g2 = g[2];
-        u = pos == 0 ? g0 : pos == 1 ? ((g0 + g1) + g2) * 0.5f : pos == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
+        const double g0 = g[0], g1 = g[1], g2 = g[2];
+        switch (pos) {
+            case 0: u = g0 / 4.0; break;
+            case 1: u = -(g0 + g1 + g2) / 6.0; break;
+            case 2: u = -(g0 - g1 + g2) / 6.0; break;
+            case 3: u = g0 / 24.0 + g1 / 12.0 + g2 / 6.0; break;
+            case 4: u = g0 / 24.0 - g1 / 12.0 + g2 / 6.0; break;
+            default: u = g2; break;
+        }
     }
-    packed[i] = u;
+    packed[i] = (float)u;
 }
 
 // ------------------------------------------------------------------------------------ dispatch
@@ -1414,7 +1440,7 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
             pointwise_small_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
         return check_launch("snvc_conv3d_forward(pointwise)");
     }
-    // k3 / stride 1: Winograd F(2,3) along W when the rows allow 8-byte pair stores and 16-byte staging
+    // k3 / stride 1: Winograd F(4,3) along W when the rows allow 8-byte pair stores and 16-byte staging
     {
         const int64_t wino = wino_packed_count(*d);
         const char *nw = getenv("SNVC_NO_WINOGRAD");   // development knob: force the direct kernel
