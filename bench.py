@@ -15,7 +15,7 @@ data-path collective): weak scaling.
 
 One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel, the first 3x3x3
 convolution (factored: 32->32 over the warped half of the volume, 318 GFLOP per launch; Winograd
-F(2,3) along W on the fp32 MFMA pipe), timed with
+F(4,3) along W on the fp32 MFMA pipe), timed with
 events on the launch stream inside the timed loop; `materialized` repeats the measurement with the
 full concat volume built and convolved (64->32, 636 GFLOP).  `cpu_baseline` times the CPU oracle (C cost volume + torch-CPU stack) on a bounded
 sample on rank 0 at N=1.
@@ -36,7 +36,7 @@ import torch  # noqa: E402
 C, H, W, D = 32, 96, 312, 192
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 CONV1_FLOP = 2.0 * D * H * W * (2 * C) * C * 27           # algorithmic FLOP of the dominant launch
-WINO_EXECUTED = (4.0 / 6.0) * (320.0 / 312.0)                   # F(2,3) MFMA share x 64-wide tile padding of W=312
+WINO_EXECUTED = (6.0 / 12.0) * (320.0 / 312.0)                  # F(4,3) MFMA share x 64-wide tile padding of W=312
 STEP_FLOP = 1332.0e9                                      # SURVEY.md section 8(d), cfg2 3D stack
 STEP_BYTES = 1479.9e6                                     # cost-volume build, algorithmic bytes
 
@@ -208,7 +208,7 @@ def main():
             },
             "roofline": {
                 "kernel": "conv3d_wino_kernel<2x4x64 tile, KC2, planes>: first conv over the right half of the volume, "
-                          "32->32 on 192x96x312, + depth-class planes (Winograd F(2,3) along W, exact fp32 MFMA)",
+                          "32->32 on 192x96x312, + depth-class planes (Winograd F(4,3) along W, exact fp32 MFMA)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS,
@@ -218,8 +218,8 @@ def main():
                 "traffic_source": "profiles/r1/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                 "flop_per_launch": dom_flop,
                 "avg_launch_ms": conv_ms,
-                # `achieved` prices the ALGORITHMIC multiply-adds of the convolution (contract); F(2,3)
-                # issues 4 MFMAs where the direct form needs 6, so the matrix pipe executes 2/3 of them
+                # `achieved` prices the ALGORITHMIC multiply-adds of the convolution (contract); F(4,3)
+                # issues 6 MFMAs where the direct form needs 12, so the matrix pipe executes half of them
                 # and `frac` may exceed 1.  The pipe's own utilisation is mfma_pipe_frac.
                 "executed_flop_per_launch": dom_flop * WINO_EXECUTED,
                 "mfma_pipe_frac": achieved * WINO_EXECUTED / PEAK_F32_MFMA_TFLOPS,

@@ -32,6 +32,9 @@
 
 #include <cstdlib>
 
+#ifndef WINO_EXP
+#define WINO_EXP 0
+#endif
 namespace snvc {
 namespace {
 
@@ -571,9 +574,13 @@ __device__ __forceinline__ void wino_load_step(const float *__restrict__ img, co
         const int rp = wave * NB + nb;                  // row pair: rows (dd, hh0) and (dd, hh0 + 1)
         const int dd = rp / (TH / 2), hh0 = 2 * (rp % (TH / 2));
         const float *px = img + bbase + kp * 2 * CH + ((dd + kd) * IN_H + hh0 + kh) * IN_WV;
+#if WINO_EXP == 2
+        o.d0[nb] = (float)step; o.d14[nb] = f32x4{1.f, 2.f, (float)nb, 4.f}; o.d5[nb] = 3.f; (void)px;
+#else
         o.d0[nb] = px[0];
         o.d14[nb] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(px + 1, 16));
         o.d5[nb] = px[5];
+#endif
     }
 }
 
@@ -584,17 +591,33 @@ template <class Cfg, class Mid>
 __device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img, const float *__restrict__ wl,
                                                    int bbase, int wave, f32x16 (&acc)[6][Cfg::NB], Mid &&mid) {
     constexpr int NB = Cfg::NB, NS = 9 * Cfg::KP;
+    constexpr bool PIPE = false;   // explicit one-step-ahead fragment reads measured slower (2.93 -> 3.05 ms on cfg2 conv1)
+    WinoStep<NB> cur, nxt;
+    if (PIPE) wino_load_step<Cfg>(img, wl, bbase, wave, 0, cur);
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        WinoStep<NB> cur;
-        wino_load_step<Cfg>(img, wl, bbase, wave, s, cur);
+        if (PIPE) {
+            if (s + 1 < NS) wino_load_step<Cfg>(img, wl, bbase, wave, s + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            wino_load_step<Cfg>(img, wl, bbase, wave, s, cur);
+        }
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             const float d0 = cur.d0[nb], d1 = cur.d14[nb][0], d2 = cur.d14[nb][1], d3 = cur.d14[nb][2],
                         d4 = cur.d14[nb][3], d5 = cur.d5[nb];
-            const float ta = d4 - 4.0f * d2, tb = d3 - 4.0f * d1, tc = d4 - d2, te = d3 - d1;
-            const float v0 = 4.0f * d0 + (d4 - 5.0f * d2), v5 = 4.0f * d1 + (d5 - 5.0f * d3);
-            const float v1 = ta + tb, v2 = ta - tb, v3 = tc + 2.0f * te, v4 = tc - 2.0f * te;
+            const float ta = __builtin_fmaf(-4.0f, d2, d4), tb = __builtin_fmaf(-4.0f, d1, d3), tc = d4 - d2, te = d3 - d1;
+#if WINO_EXP == 1
+            const float v0 = d0, v5 = d5;
+#else
+            const float v0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+            const float v5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+#endif
+#if WINO_EXP == 1
+            const float v1 = d1, v2 = d2, v3 = d3, v4 = d4; (void)ta; (void)tb; (void)tc; (void)te;
+#else
+            const float v1 = ta + tb, v2 = ta - tb, v3 = __builtin_fmaf(2.0f, te, tc), v4 = __builtin_fmaf(-2.0f, te, tc);
+#endif
             acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0], v0, acc[0][nb], 0, 0, 0);
             acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1], v1, acc[1][nb], 0, 0, 0);
             acc[2][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[2], v2, acc[2][nb], 0, 0, 0);
@@ -602,7 +625,12 @@ __device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img
             acc[4][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[4], v4, acc[4][nb], 0, 0, 0);
             acc[5][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[5], v5, acc[5][nb], 0, 0, 0);
         }
+        if (PIPE) __builtin_amdgcn_sched_barrier(0);
         mid(s);
+        if (PIPE) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 1 < NS) cur = nxt;
+        }
     }
 }
 
@@ -790,6 +818,80 @@ conv3d_wino_kernel(const ConvArgs a) {
                 else st.store_one(inext, tid, piece - Ws::NIT, m, pre[piece - Ws::NIT]);
             }
         });
+        __syncthreads();
+    }
+    wino_epilogue<Cfg, RES, PLANE>(a, job, acc, aff, lane, wave);
+}
+
+// The same convolution with the chunks staged by LDS-DMA (`global_load_lds_dwordx4`: global -> LDS
+// without a register hop).  That frees the 28 prefetch registers and the LDS write pass, which is what
+// lets a wave carry TWO row pairs (12 accumulators = 192 registers): 108 MFMAs between barriers
+// instead of 54, and a 4x4x64 tile whose halo is 2.25x instead of 3x.  A DMA wave-instruction writes
+// 64 x 16 bytes to consecutive LDS addresses (wave-uniform base in M0), exactly the Stager's
+// item order; padding pieces and channels beyond Cin read a 16-byte zero constant instead.
+// `__syncthreads()` drains the DMA (hipcc emits vmcnt(0) in front of the barrier while one is in
+// flight), so chunk c+1 lands while chunk c is multiplied and is visible after the chunk's barrier.
+__device__ const float g_zero16[4] __attribute__((aligned(16))) = {0.0f, 0.0f, 0.0f, 0.0f};
+
+template <class Cfg, bool RES, bool PLANE>
+__global__ void __launch_bounds__(256, 2)
+conv3d_wino_dma_kernel(const ConvArgs a) {
+    constexpr int TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB, CH = Cfg::CH, TILE = Cfg::TILE, WF = Cfg::WF;
+    using St = typename Cfg::St;
+    static_assert(Cfg::PIECE == 4, "LDS-DMA moves 16-byte pieces");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, TD, TH);
+
+    f32x16 acc[6][NB];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][nb][r] = 0.0f;
+
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const float *xn = a.x + job.n * a.x_bs;
+    const int bbase = (lane >> 5) * CH + ((lane >> 4) & 1) * Cfg::IN_WV + 4 * (lane & 15) + Cfg::XOFF;
+    float *const wlds = lds + 2 * TILE;
+    float *const aff = wlds + 2 * WF;      // scale | bias of this job's 32 channels
+    const int nchunks = a.nchunks_wino;
+    const float *wg = a.wp_wino + (int64_t)job.cg * nchunks * WF;
+
+    St st;
+    st.init(tid, job.od0 - 1, job.oh0 - 1, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+    constexpr int WITEMS = WF / 4, WNIT = (WITEMS + 255) / 256;
+    const int wbase = tid & ~63;           // first item of this wave in a 256-item round
+    auto issue = [&](int chunk, int b) {
+        const float *xc = xn + (int64_t)chunk * KC * in_dhw;
+        const float *wc = wg + (int64_t)chunk * WF;
+        const unsigned m = st.store_mask(tid, a.Cin - chunk * KC);
+        float *const ibuf = lds + b * TILE, *const wbuf = wlds + b * WF;
+#pragma unroll
+        for (int it = 0; it < WNIT; ++it) {
+            const int i = it * 256 + tid;
+            if (WITEMS % 256 == 0 || i < WITEMS)
+                __builtin_amdgcn_global_load_lds(wc + 4 * i, wbuf + 4 * (it * 256 + wbase), 16, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < St::NIT; ++it) {
+            const int i = it * 256 + tid;
+            const float *src = ((m >> it) & 1u) ? xc + st.off[it] : g_zero16;
+            if (St::ITEMS % 256 == 0 || i < St::ITEMS)
+                __builtin_amdgcn_global_load_lds(src, ibuf + 4 * (it * 256 + wbase), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    if (tid < 64) {
+        float v = tid < 32 ? 1.0f : 0.0f;
+        if (a.scale) v = (tid < 32 ? a.scale : a.bias)[job.cg * 32 + (tid & 31)];   // Cout % 32 == 0 (host)
+        aff[tid] = v;
+    }
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk + 1 < nchunks) issue(chunk + 1, (chunk + 1) & 1);
+        wino_compute_chunk<Cfg>(lds + (chunk & 1) * TILE, wlds + (chunk & 1) * WF + lane, bbase, wave, acc, [](int) {});
         __syncthreads();
     }
     wino_epilogue<Cfg, RES, PLANE>(a, job, acc, aff, lane, wave);
@@ -1202,6 +1304,7 @@ using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2, false, 2, 1>;
 using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 4, 2, false, 2, 1>;
 using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false, 2, 1>;
 using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64 voxels, 2 input channels per chunk
+using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per wave: large layers
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;       // the same for rows that are only 8-byte aligned (W % 4 == 2)
 using CfgDCM1   = DeconvCfg<1, 2, 4, 4>;
 using CfgDCM2   = DeconvCfg<2, 2, 4, 4>;
@@ -1287,6 +1390,26 @@ void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
         attr_done = true;
     }
     conv3d_wino_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
+}
+
+template <class Cfg, bool RES, bool PLANE>
+void launch_wino_dma_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
+    static bool attr_done = false;
+    if (!attr_done && BYTES > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        attr_done = true;
+    }
+    conv3d_wino_dma_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
+}
+
+template <class Cfg>
+void launch_wino_dma(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    if (a.res && a.plane) launch_wino_dma_variant<Cfg, true, true>(a, grid, st);
+    else if (a.res) launch_wino_dma_variant<Cfg, true, false>(a, grid, st);
+    else if (a.plane) launch_wino_dma_variant<Cfg, false, true>(a, grid, st);
+    else launch_wino_dma_variant<Cfg, false, false>(a, grid, st);
 }
 
 template <class Cfg>
@@ -1451,13 +1574,21 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
         if (wino && pair_ok && fast_common && (wide || vec8) && !(nw && nw[0] == '1')) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, CfgWino::KC);
-            a.tiles_d = ceil_div(d->Dout, CfgWino::TD); a.tiles_h = ceil_div(d->Hout, CfgWino::TH);
             a.tiles_w = ceil_div(d->Wout, 64);
             a.groups = ceil_div(d->Cout, 32);
+            // large layers: the LDS-DMA kernel with the 4x4x64 tile (two row pairs per wave) once it has
+            // enough jobs to keep the tail of the launch short; otherwise the 2x4x64 register-staged one
+            const char *bv = getenv("SNVC_WINO_BIG");   // development knob: 0 = never, 1 = always (when legal)
+            const int64_t nj_big = (int64_t)ceil_div(d->Dout, CfgWinoBig::TD) * ceil_div(d->Hout, CfgWinoBig::TH) *
+                                   a.tiles_w * a.groups * d->N;
+            const bool big = wide && (bv ? bv[0] == '1' : nj_big >= 8 * 2 * (int64_t)device_cu_count());
+            a.tiles_d = ceil_div(d->Dout, big ? CfgWinoBig::TD : CfgWino::TD);
+            a.tiles_h = ceil_div(d->Hout, big ? CfgWinoBig::TH : CfgWino::TH);
             const int64_t nj = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w * a.groups * d->N;
             if (nj < ((int64_t)1 << 31)) {
                 a.njobs = (int)nj;
-                if (wide) launch_wino<CfgWino>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                if (big) launch_wino_dma<CfgWinoBig>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                else if (wide) launch_wino<CfgWino>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 else launch_wino<CfgWino8>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 return check_launch("snvc_conv3d_forward(winograd)");
             }
