@@ -535,21 +535,24 @@ conv3d_mfma_kernel(const ConvArgs a) {
 // stages and V is formed in registers right after the fragment reads (one 16-byte and two 4-byte LDS
 // reads + 12 VALU ops per 6 MFMAs).  The 32 MFMA columns are 2 rows x 16 tiles of 4 outputs: a lane
 // owns 4 consecutive outputs, so the epilogue stores 16 bytes per lane and channel.
-template <int TD_, int TH_, int KC_, int PIECE_ = 4>
+template <int TD_, int TH_, int KC_, int PIECE_ = 4, int TW_ = 64>
 struct WinoCfg {
     static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1, PIECE = PIECE_;
     static constexpr int NPOS = 6;
-    static constexpr int TW = 64, LPAD = 4, XOFF = 3;
+    // The 32 MFMA columns are RPB rows x (TW/4) quads: 2 rows x 64 outputs, or 4 rows x 32 outputs for
+    // layers whose width fills 64-wide tiles badly (W = 156 -> 3 x 64 is 81 % full, 5 x 32 is 97 %).
+    static constexpr int TW = TW_, QUADS = TW / 4, RPB = 32 / QUADS, LPAD = 4, XOFF = 3;
+    static_assert(TW == 64 || TW == 32, "tile width");
     static constexpr int IN_D = TD + 2, IN_H = TH + 2, IN_W = TW + 2;
     static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;   // 72
     using St = Stager<KC, IN_D, IN_H, IN_WV, PIECE>;
     static constexpr int CH = St::CH, TILE = St::TILE;
-    static constexpr int NB = TD * TH / 8;                    // row PAIRS per wave (4 waves)
+    static constexpr int NB = TD * TH / (4 * RPB);            // row BLOCKS (RPB rows) per wave (4 waves)
     static constexpr int KP = KC / 2;
     static constexpr int WF = 9 * NPOS * KP * 64;             // packed floats per chunk: [tap9][pos][kp][lane]
     using Ws = WeightStager<WF>;
     static constexpr int LDS_BYTES = (TILE * 2 + WF * 2) * 4;
-    static_assert(TD * TH % 8 == 0 && TH % 2 == 0, "row pairs must split over 4 waves");
+    static_assert(TD * TH % (4 * RPB) == 0 && TH % RPB == 0, "row blocks must split over 4 waves");
     static_assert(CH % 4 == 0 && IN_WV % 4 == 0, "16-byte LDS reads need aligned strides");
 };
 
@@ -571,8 +574,8 @@ __device__ __forceinline__ void wino_load_step(const float *__restrict__ img, co
     for (int p = 0; p < 6; ++p) o.a[p] = wl[((tap9 * 6 + p) * KP + kp) * 64];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int rp = wave * NB + nb;                  // row pair: rows (dd, hh0) and (dd, hh0 + 1)
-        const int dd = rp / (TH / 2), hh0 = 2 * (rp % (TH / 2));
+        const int rp = wave * NB + nb;                  // row block: rows (dd, hh0 .. hh0 + RPB - 1)
+        const int dd = rp / (TH / Cfg::RPB), hh0 = Cfg::RPB * (rp % (TH / Cfg::RPB));
         const float *px = img + bbase + kp * 2 * CH + ((dd + kd) * IN_H + hh0 + kh) * IN_WV;
 #if WINO_EXP == 2
         o.d0[nb] = (float)step; o.d14[nb] = f32x4{1.f, 2.f, (float)nb, 4.f}; o.d5[nb] = 3.f; (void)px;
@@ -640,12 +643,12 @@ struct WinoJob {
     int64_t n;
 };
 
-__device__ __forceinline__ WinoJob wino_decode_job(const ConvArgs &a, int v, int total, int TD, int TH) {
+__device__ __forceinline__ WinoJob wino_decode_job(const ConvArgs &a, int v, int total, int TD, int TH, int TW) {
     const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
     const int j = xcd_remap(v, total);
     const int t = j % ntiles, g = j / ntiles;
     WinoJob o;
-    o.ow0 = (t % a.tiles_w) * 64;
+    o.ow0 = (t % a.tiles_w) * TW;
     o.oh0 = ((t / a.tiles_w) % a.tiles_h) * TH;
     o.od0 = (t / (a.tiles_w * a.tiles_h)) * TD;
     o.cg = g % a.groups;
@@ -663,7 +666,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
                                               const float *__restrict__ aff, int lane, int wave) {
     constexpr int NB = Cfg::NB, TH = Cfg::TH;
     constexpr bool V4 = Cfg::PIECE == 4;           // 16-byte loads / stores (Wout % 4 == 0); else 8-byte halves
-    const int ow = job.ow0 + 4 * (lane & 15), rowsel = (lane >> 4) & 1;
+    const int ow = job.ow0 + 4 * (lane & (Cfg::QUADS - 1)), rowsel = (lane & 31) / Cfg::QUADS;
     const int out_hw = a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
     const int cbase = __builtin_amdgcn_readfirstlane(job.cg * 32);
     const int half = lane >> 5;                     // accumulator register r of this lane is channel
@@ -696,7 +699,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int rp = wave * NB + nb;
-        const int od = job.od0 + rp / (TH / 2), oh = job.oh0 + 2 * (rp % (TH / 2)) + rowsel;
+        const int od = job.od0 + rp / (TH / Cfg::RPB), oh = job.oh0 + Cfg::RPB * (rp % (TH / Cfg::RPB)) + rowsel;
         const bool row_ok = od < a.Dout && oh < a.Hout;
         ok0[nb] = row_ok && ow < a.Wout;
         ok1[nb] = row_ok && ow + 2 < a.Wout;
@@ -757,7 +760,7 @@ conv3d_wino_kernel(const ConvArgs a) {
     using Ws = typename Cfg::Ws;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, TD, TH);
+    const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, TD, TH, Cfg::TW);
 
     f32x16 acc[6][NB];
 #pragma unroll
@@ -771,7 +774,7 @@ conv3d_wino_kernel(const ConvArgs a) {
     const float *xn = a.x + job.n * a.x_bs;
     // B-fragment base: lane&15 = output quad t (inputs 4t-1..4t+4 = image columns 4t+3..4t+8),
     // (lane>>4)&1 = row of the row pair, lane>>5 = k
-    const int bbase = (lane >> 5) * CH + ((lane >> 4) & 1) * Cfg::IN_WV + 4 * (lane & 15) + Cfg::XOFF;
+    const int bbase = (lane >> 5) * CH + ((lane & 31) / Cfg::QUADS) * Cfg::IN_WV + 4 * (lane & (Cfg::QUADS - 1)) + Cfg::XOFF;
     float *const wlds = lds + 2 * TILE;
     float *const aff = wlds + 2 * WF;      // scale | bias of this job's 32 channels
     const int nchunks = a.nchunks_wino;
@@ -841,7 +844,7 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
     static_assert(Cfg::PIECE == 4, "LDS-DMA moves 16-byte pieces");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, TD, TH);
+    const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, TD, TH, Cfg::TW);
 
     f32x16 acc[6][NB];
 #pragma unroll
@@ -853,7 +856,7 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
 
     const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     const float *xn = a.x + job.n * a.x_bs;
-    const int bbase = (lane >> 5) * CH + ((lane >> 4) & 1) * Cfg::IN_WV + 4 * (lane & 15) + Cfg::XOFF;
+    const int bbase = (lane >> 5) * CH + ((lane & 31) / Cfg::QUADS) * Cfg::IN_WV + 4 * (lane & (Cfg::QUADS - 1)) + Cfg::XOFF;
     float *const wlds = lds + 2 * TILE;
     float *const aff = wlds + 2 * WF;      // scale | bias of this job's 32 channels
     const int nchunks = a.nchunks_wino;
@@ -1305,7 +1308,9 @@ using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 4, 2, false, 2, 1>;
 using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false, 2, 1>;
 using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64 voxels, 2 input channels per chunk
 using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per wave: large layers
-using CfgWino8  = WinoCfg<2, 4, 2, 2>;       // the same for rows that are only 8-byte aligned (W % 4 == 2)
+using CfgWino8  = WinoCfg<2, 4, 2, 2>;
+using CfgWinoN  = WinoCfg<4, 4, 2, 4, 32>;   // 32-wide tile (4 rows x 8 quads per MFMA column block): narrow layers
+using CfgWinoN8 = WinoCfg<4, 4, 2, 2, 32>;       // the same for rows that are only 8-byte aligned (W % 4 == 2)
 using CfgDCM1   = DeconvCfg<1, 2, 4, 4>;
 using CfgDCM2   = DeconvCfg<2, 2, 4, 4>;
 using CfgDCM1v8 = DeconvCfg<1, 2, 4, 4, 2>;
@@ -1574,22 +1579,31 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
         if (wino && pair_ok && fast_common && (wide || vec8) && !(nw && nw[0] == '1')) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, CfgWino::KC);
-            a.tiles_w = ceil_div(d->Wout, 64);
             a.groups = ceil_div(d->Cout, 32);
-            // large layers: the LDS-DMA kernel with the 4x4x64 tile (two row pairs per wave) once it has
-            // enough jobs to keep the tail of the launch short; otherwise the 2x4x64 register-staged one
-            const char *bv = getenv("SNVC_WINO_BIG");   // development knob: 0 = never, 1 = always (when legal)
+            // tile choice: 32-wide when 64-wide tiles would be badly filled (W = 156: 81 % vs 97 %); among the
+            // 64-wide ones the LDS-DMA kernel with the 4x4x64 tile (two row blocks per wave) once a layer has
+            // enough jobs to keep the tail of the launch short, else the 2x4x64 register-staged one
+            const double fill64 = (double)d->Wout / (ceil_div(d->Wout, 64) * 64);
+            const double fill32 = (double)d->Wout / (ceil_div(d->Wout, 32) * 32);
+            const char *tv = getenv("SNVC_WINO_TILE");   // development knob: "big", "std", "narrow"
+            bool narrow = fill32 > 1.1 * fill64;
             const int64_t nj_big = (int64_t)ceil_div(d->Dout, CfgWinoBig::TD) * ceil_div(d->Hout, CfgWinoBig::TH) *
-                                   a.tiles_w * a.groups * d->N;
-            const bool big = wide && (bv ? bv[0] == '1' : nj_big >= 8 * 2 * (int64_t)device_cu_count());
-            a.tiles_d = ceil_div(d->Dout, big ? CfgWinoBig::TD : CfgWino::TD);
-            a.tiles_h = ceil_div(d->Hout, big ? CfgWinoBig::TH : CfgWino::TH);
+                                   ceil_div(d->Wout, 64) * a.groups * d->N;
+            bool big = !narrow && wide && nj_big >= 8 * 2 * (int64_t)device_cu_count();
+            if (tv) { narrow = tv[0] == 'n'; big = tv[0] == 'b' && wide; }
+            const int TDc = (big || narrow) ? 4 : 2, THc = 4, TWc = narrow ? 32 : 64;
+            a.tiles_d = ceil_div(d->Dout, TDc);
+            a.tiles_h = ceil_div(d->Hout, THc);
+            a.tiles_w = ceil_div(d->Wout, TWc);
             const int64_t nj = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w * a.groups * d->N;
             if (nj < ((int64_t)1 << 31)) {
                 a.njobs = (int)nj;
-                if (big) launch_wino_dma<CfgWinoBig>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
-                else if (wide) launch_wino<CfgWino>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
-                else launch_wino<CfgWino8>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                const dim3 g((unsigned)nj, 1, 1);
+                if (big) launch_wino_dma<CfgWinoBig>(a, g, as_stream(stream));
+                else if (narrow && wide) launch_wino<CfgWinoN>(a, g, as_stream(stream));
+                else if (narrow) launch_wino<CfgWinoN8>(a, g, as_stream(stream));
+                else if (wide) launch_wino<CfgWino>(a, g, as_stream(stream));
+                else launch_wino<CfgWino8>(a, g, as_stream(stream));
                 return check_launch("snvc_conv3d_forward(winograd)");
             }
         }
