@@ -391,7 +391,77 @@ __device__ __forceinline__ void conv_compute_phase(const float *__restrict__ img
     }
 }
 
-template <class Cfg>
+// Fast epilogue of the direct kernel (toolkit comment above).  A lane holds ONE output voxel of 16
+// channels per accumulator; 4x4 register/lane transposes (DPP) turn every 4 registers x 4 lanes into
+// "lane = channel, registers = 4 consecutive voxels", i.e. one 16-byte store per lane where the
+// generic epilogue issues four 4-byte ones.  No depth-class planes here (host).
+template <class Cfg, bool RES>
+__device__ __forceinline__ void conv_epilogue_fast(const ConvArgs &a, f32x16 (&acc)[Cfg::NB][Cfg::MI], int od0, int oh0,
+                                                   int ow0, int cg, int64_t n, int lane, int wave) {
+    constexpr int MI = Cfg::MI, TH = Cfg::TH, NB = Cfg::NB;
+    const int half = lane >> 5, li = lane & 3, lj = (lane & 31) >> 2;
+    const bool odd = (lane & 1) != 0, hi = (lane & 2) != 0;
+    const int out_hw = a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
+    const int64_t cs = (int64_t)out_dhw * 4;
+    const bool relu = (a.flags & SNVC_EPI_RELU) != 0, add_pre = (a.flags & SNVC_EPI_ADD_PRE) != 0,
+               add_post = (a.flags & SNVC_EPI_ADD_POST) != 0;
+    const int ow = ow0 + 4 * lj;
+    unsigned voff[NB];
+    bool ok[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int od = od0 + row / TH, oh = oh0 + row % TH;
+        ok[nb] = od < a.Dout && oh < a.Hout && ow < a.Wout;     // Wout % 4 == 0 (host): all four voxels exist
+        const int sp = ok[nb] ? od * out_hw + oh * a.Wout + ow : 0;
+        voff[nb] = 4u * (unsigned)((4 * half + li) * out_dhw + sp);
+    }
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+        const int cbase = __builtin_amdgcn_readfirstlane((cg * MI + m) * 32);
+        const char *const rb = RES ? reinterpret_cast<const char *>(a.res + n * a.r_bs) + cbase * cs : nullptr;
+        float sc[4], bi[4];     // this lane's channel of each register quad: cbase + 8q + 4*half + li
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc[q] = a.scale ? a.scale[cbase + 8 * q + 4 * half + li] : 1.0f;
+            bi[q] = a.scale ? a.bias[cbase + 8 * q + 4 * half + li] : 0.0f;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4 rv[RES ? 4 : 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (RES) rv[q] = *reinterpret_cast<const f32x4 *>(rb + 8 * q * cs + voff[nb]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0 = acc[nb][m][4 * q], v1 = acc[nb][m][4 * q + 1], v2 = acc[nb][m][4 * q + 2], v3 = acc[nb][m][4 * q + 3];
+                quad_transpose(v0, v1, v2, v3, odd, hi);
+                acc[nb][m][4 * q] = act_f(v0 * sc[q] + bi[q], RES ? rv[q][0] : 0.0f, add_pre, relu, add_post);
+                acc[nb][m][4 * q + 1] = act_f(v1 * sc[q] + bi[q], RES ? rv[q][1] : 0.0f, add_pre, relu, add_post);
+                acc[nb][m][4 * q + 2] = act_f(v2 * sc[q] + bi[q], RES ? rv[q][2] : 0.0f, add_pre, relu, add_post);
+                acc[nb][m][4 * q + 3] = act_f(v3 * sc[q] + bi[q], RES ? rv[q][3] : 0.0f, add_pre, relu, add_post);
+            }
+            // one batch of loads in flight at a time: pin this batch's results before the next loads
+#pragma unroll
+            for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(acc[nb][m][r])::"memory");
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+        const int cbase = __builtin_amdgcn_readfirstlane((cg * MI + m) * 32);
+        char *const yb = reinterpret_cast<char *>(a.y + n * a.y_bs) + cbase * cs;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 o;
+                o[0] = acc[nb][m][4 * q]; o[1] = acc[nb][m][4 * q + 1]; o[2] = acc[nb][m][4 * q + 2]; o[3] = acc[nb][m][4 * q + 3];
+                if (ok[nb]) *reinterpret_cast<f32x4 *>(yb + 8 * q * cs + voff[nb]) = o;
+            }
+    }
+}
+
+template <class Cfg, int EPI = 0>   // EPI: 0 generic epilogue, 1 fast, 2 fast with residual
 __global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_mfma_kernel(const ConvArgs a) {
     constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB;
@@ -476,6 +546,10 @@ conv3d_mfma_kernel(const ConvArgs a) {
     }
 
     // ---- epilogue
+    if constexpr (EPI != 0) {
+        conv_epilogue_fast<Cfg, EPI == 2>(a, acc, od0, oh0, ow0, cg, n, lane, wave);
+        return;
+    }
     const int ow = ow0 + (lane & 31);
     const int64_t out_hw = (int64_t)a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
     float *yn = a.y + n * a.y_bs;
@@ -1369,15 +1443,28 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
     return SNVC_OK;
 }
 
-template <class Cfg>
-void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
+template <class Cfg, int EPI>
+void launch_conv_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done && Cfg::LDS_BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_mfma_kernel<Cfg>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_mfma_kernel<Cfg, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         attr_done = true;
     }
-    conv3d_mfma_kernel<Cfg><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+    conv3d_mfma_kernel<Cfg, EPI><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+}
+
+// FAST: also build the fast-epilogue variants of this configuration (the ones on a measured path)
+template <class Cfg, bool FAST = false>
+void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    if constexpr (FAST) {
+        if (a.fast_epi && !a.plane) {
+            if (a.res) launch_conv_variant<Cfg, 2>(a, grid, st);
+            else launch_conv_variant<Cfg, 1>(a, grid, st);
+            return;
+        }
+    }
+    launch_conv_variant<Cfg, 0>(a, grid, st);
 }
 
 inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
@@ -1622,13 +1709,13 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
         case K3_M1v3: launch_conv<CfgK3M1v3>(a, grid, st); break;
         case K3_M1v4: launch_conv<CfgK3M1v4>(a, grid, st); break;
         case K3_M2: launch_conv<CfgK3M2>(a, grid, st); break;
-        case K3S2_M1: launch_conv<CfgK3S2M1>(a, grid, st); break;
-        case K3S2_M2: launch_conv<CfgK3S2M2>(a, grid, st); break;
-        case K5_M1: launch_conv<CfgK5M1>(a, grid, st); break;
+        case K3S2_M1: launch_conv<CfgK3S2M1, true>(a, grid, st); break;
+        case K3S2_M2: launch_conv<CfgK3S2M2, true>(a, grid, st); break;
+        case K5_M1: launch_conv<CfgK5M1, true>(a, grid, st); break;
         case K5_M2: launch_conv<CfgK5M2>(a, grid, st); break;
         case K5D2_M1: launch_conv<CfgK5D2M1>(a, grid, st); break;
         case K5D2_M2: launch_conv<CfgK5D2M2>(a, grid, st); break;
-        case K7_M1: launch_conv<CfgK7M1>(a, grid, st); break;
+        case K7_M1: launch_conv<CfgK7M1, true>(a, grid, st); break;
         case K7_M2: launch_conv<CfgK7M2>(a, grid, st); break;
         case DC_M1:
             if (!a.vec && vec8) { a.vec = 1; launch_deconv<CfgDCM1v8>(a, grid, st); }
