@@ -287,6 +287,35 @@ def test_conv3d_epilogue_variants_and_slices():
             assert torch.all(big_out[:, 0] == 7.0) and torch.all(big_out[:, 1 + cout:] == 7.0)
 
 
+@pytest.mark.parametrize("mode", ["default", "big", "std", "narrow", "direct"])
+@pytest.mark.parametrize("W", [72, 78, 156])
+def test_k3_kernel_variants_vs_torch(mode, W, monkeypatch):
+    """Every 3x3x3 / stride-1 kernel the dispatcher can pick -- Winograd F(4,3) with the 2x4x64
+    register-staged tile, the 4x4x64 LDS-DMA tile, the 4x4x32 tile, their 8-byte-row versions
+    (W % 4 == 2) and the direct kernel -- against torch's fp32 convolution, with the fused epilogue
+    forms (BN affine + residual before / after ReLU) and tile-ragged D and H."""
+    import torch.nn.functional as F
+    from snvc_amd.models import submodule as S
+    if mode == "direct":
+        monkeypatch.setenv("SNVC_NO_WINOGRAD", "1")
+    elif mode != "default":
+        monkeypatch.setenv("SNVC_WINO_TILE", mode)
+    r = np.random.default_rng(31 + W)
+    for cin, cout, shape in ((32, 32, (5, 7, W)), (6, 64, (2, 9, W))):
+        m = seeded(S.convbn_3d(cin, cout, 3, 1, 1), 40 + cin)
+        x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32))
+        with torch.no_grad():
+            ref = F.batch_norm(F.conv3d(x, m[0].weight, None, 1, 1), m[1].running_mean, m[1].running_var,
+                               m[1].weight, m[1].bias, False, 0.0, m[1].eps)
+            res = torch.from_numpy(r.standard_normal(tuple(ref.shape)).astype(np.float32))
+            m = m.to(dev())
+            check(m(x.to(dev())).cpu().numpy(), ref.numpy(), TIGHT, f"{mode} W={W} conv+bn")
+            y = m.fused(x.to(dev()), relu=True, residual=res.to(dev()))
+            check(y.cpu().numpy(), F.relu(ref + res).numpy(), TIGHT, f"{mode} W={W} relu(conv+res)")
+            y = m.fused(x.to(dev()), relu=True, residual=res.to(dev()), residual_after_act=True)
+            check(y.cpu().numpy(), (F.relu(ref) + res).numpy(), TIGHT, f"{mode} W={W} relu(conv)+res")
+
+
 def test_deconv_vs_torch():
     import torch.nn.functional as F
     from snvc_amd.models import submodule as S
@@ -516,8 +545,11 @@ def test_global_stack_vs_golden(name, G):
     check(y, G[f"global/{name}"], 1e-4, name)
 
 
-def test_global_pair_end_to_end_vs_oracle():
+@pytest.mark.parametrize("tile", ["default", "big", "narrow"])
+def test_global_pair_end_to_end_vs_oracle(tile, monkeypatch):
     """cost-volume build + 3D CNN forward (the benchmarked unit) against C oracle + torch-CPU."""
+    if tile != "default":
+        monkeypatch.setenv("SNVC_WINO_TILE", tile)   # depth-class planes through every Winograd tile form
     from oracle import native as O
     from oracle import torch_ref as T
     from snvc_amd.models.stereo_volume import GlobalStack

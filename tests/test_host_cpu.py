@@ -55,7 +55,8 @@ def test_argument_validation_needs_no_gpu(L):
     d.N, d.Cin, d.Din, d.Hin, d.Win = 1, 8, 4, 4, 32
     d.Cout, d.Dout, d.Hout, d.Wout = 32, 4, 4, 32
     d.ksize, d.stride, d.dilation, d.pad = 3, 1, 1, 1
-    assert L.snvc_conv3d_packed_weight_count(ctypes.byref(d)) == 1 * 2 * 27 * 2 * 64 * 1   # groups*chunks*taps*KP*64*MI
+    # direct packing groups*chunks*taps*KP*64*MI + Winograd F(4,3) packing groups*chunks(KC=2)*9*6*KP*64
+    assert L.snvc_conv3d_packed_weight_count(ctypes.byref(d)) == 1 * 2 * 27 * 2 * 64 * 1 + 1 * 4 * 9 * 6 * 1 * 64
     d.ksize, d.pad = 9, 4
     assert L.snvc_conv3d_packed_weight_count(ctypes.byref(d)) == -1 and "not in" in err()
     d.ksize, d.pad, d.Dout = 3, 1, 5
