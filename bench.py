@@ -174,7 +174,7 @@ def main():
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r1", "traffic.json")) as fh:
-            traffic = json.load(fh).get("conv1_right_wino_k3_32to32_cfg2", {}).get("hbm_bytes_corrected")
+            traffic = json.load(fh).get("conv1_right_wino43_dma_k3_32to32_cfg2", {}).get("hbm_bytes_corrected")
     except Exception:
         pass
 
@@ -207,8 +207,8 @@ def main():
                 "step_cost_volume_mb_algorithmic": STEP_BYTES / 1e6,
             },
             "roofline": {
-                "kernel": "conv3d_wino_kernel<2x4x64 tile, KC2, planes>: first conv over the right half of the volume, "
-                          "32->32 on 192x96x312, + depth-class planes (Winograd F(4,3) along W, exact fp32 MFMA)",
+                "kernel": "conv3d_wino_dma_kernel<4x4x64 tile, KC2, planes>: first conv over the right half of the volume, "
+                          "32->32 on 192x96x312, + depth-class planes (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_F32_MFMA_TFLOPS,
