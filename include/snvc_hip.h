@@ -125,7 +125,7 @@ SNVC_API int snvc_grid_projection(const double *samples, const double *P_left, c
  *   Cubic kernels only, as on the path: ksize in {1,3,5,7}, stride in {1,2}, dilation in {1,2}
  *   with pad = dilation*(ksize-1)/2 ("same" for stride 1); transposed: ksize 3, stride 2,
  *   pad 1, output_padding 1 (Dout = 2*Din).
- *   Arithmetic: fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+ *   Arithmetic: fp32 in, fp32 products and accumulation on v_mfma_f32_32x32x2_f32; see desc.algo.
  * ---------------------------------------------------------------------------------- */
 enum {
     SNVC_EPI_RELU = 1,
@@ -134,13 +134,19 @@ enum {
     SNVC_EPI_SIGMOID = 8
 };
 
+/* desc.algo: which arithmetic the stride-1 k3 / k5 / k7 layers may use.
+ *   SNVC_ALGO_AUTO   : fastest form inside the 1e-3 contract -- Winograd F(4,k) along W where the layer
+ *                      qualifies (fp32 products and sums; measured 2e-6 (k3) .. 1e-4 (k7) of the output range)
+ *   SNVC_ALGO_DIRECT : the direct kernels only (an exact fp32 FMA chain per output) */
+enum { SNVC_ALGO_AUTO = 0, SNVC_ALGO_DIRECT = 1 };
+
 typedef struct {
     int32_t N, Cin, Din, Hin, Win;
     int32_t Cout, Dout, Hout, Wout;
     int32_t ksize, stride, dilation, pad;
     int32_t transposed; /* 0: Conv3d, 1: ConvTranspose3d(k3,s2,p1,op1) */
     int32_t flags;      /* SNVC_EPI_* */
-    int32_t reserved;
+    int32_t algo;       /* SNVC_ALGO_* */
     int64_t x_batch_stride, y_batch_stride, res_batch_stride; /* elements; 0 = dense */
 } snvc_conv3d_desc;
 

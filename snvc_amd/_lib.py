@@ -21,7 +21,7 @@ class Conv3dDesc(ctypes.Structure):
     """Mirror of ``snvc_conv3d_desc`` (include/snvc_hip.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         "N", "Cin", "Din", "Hin", "Win", "Cout", "Dout", "Hout", "Wout",
-        "ksize", "stride", "dilation", "pad", "transposed", "flags", "reserved")] + [
+        "ksize", "stride", "dilation", "pad", "transposed", "flags", "algo")] + [
         (n, ctypes.c_int64) for n in ("x_batch_stride", "y_batch_stride", "res_batch_stride")]
 
 

@@ -29,6 +29,7 @@
 //   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs (round-robin dispatch) each get a
 //     contiguous run of tiles so that halo re-reads hit that XCD's L2.
 #include "common.hpp"
+#include "wino_tables.hpp"
 
 #include <cstdlib>
 
@@ -612,7 +613,7 @@ conv3d_mfma_kernel(const ConvArgs a) {
 template <int TD_, int TH_, int KC_, int PIECE_ = 4, int TW_ = 64>
 struct WinoCfg {
     static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1, PIECE = PIECE_;
-    static constexpr int NPOS = 6;
+    static constexpr int KS = 3, NPOS = 6;
     // The 32 MFMA columns are RPB rows x (TW/4) quads: 2 rows x 64 outputs, or 4 rows x 32 outputs for
     // layers whose width fills 64-wide tiles badly (W = 156 -> 3 x 64 is 81 % full, 5 x 32 is 97 %).
     static constexpr int TW = TW_, QUADS = TW / 4, RPB = 32 / QUADS, LPAD = 4, XOFF = 3;
@@ -730,13 +731,144 @@ __device__ __forceinline__ WinoJob wino_decode_job(const ConvArgs &a, int v, int
     return o;
 }
 
+// ------------------------------------------------------------------------------------ conv k5 / k7: Winograd F(4,5) / F(4,7) along W
+// The local model's first layers (7x7x7 64->32 and 5x5x5 32->32 on the whole voxel grid) carry two
+// thirds of its FLOPs.  Along W they use F(4,KS): 4 outputs from KS+3 inputs with KS+3 multiplications
+// instead of 4*KS (k5: 8 vs 20, k7: 10 vs 28).  The Cook-Toom matrices come from
+// tools/gen_wino_tables.py (exact rationals, symmetric point sets 0, +-1, +-2, +-1/2 (, +-3), inf);
+// the fp32 algorithm differs from an fp64 convolution by 3e-6 (k5) / 3e-5 (k7) of the output range
+// on a 448-term contraction.  B^T rows of a +-p pair are (even part) +- (odd part), so the input
+// transform is 27 (k5) / 40 (k7) VALU operations per step of 8 / 10 MFMAs.
+template <int KS> struct WinoTables;
+template <> struct WinoTables<5> {
+    static constexpr int P = 8;
+    static constexpr double bt(int r, int c) { return wino::BT5[r][c]; }
+    static constexpr double at(int r, int c) { return wino::AT5[r][c]; }
+    static constexpr double g(int r, int c) { return wino::G5[r][c]; }
+};
+template <> struct WinoTables<7> {
+    static constexpr int P = 10;
+    static constexpr double bt(int r, int c) { return wino::BT7[r][c]; }
+    static constexpr double at(int r, int c) { return wino::AT7[r][c]; }
+    static constexpr double g(int r, int c) { return wino::G7[r][c]; }
+};
+
+// v = B^T d.  Row 0 and row P-1 are plain dot products; rows (2j+1, 2j+2) share an even-column part E
+// and an odd-column part O:  v[2j+1] = E + O,  v[2j+2] = E - O.
+template <int KS>
+__device__ __forceinline__ void wino_input_transform(const float (&d)[WinoTables<KS>::P], float (&v)[WinoTables<KS>::P]) {
+    using T = WinoTables<KS>;
+    constexpr int P = T::P;
+    {
+        float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            if (T::bt(0, c) != 0.0) s0 = __builtin_fmaf((float)T::bt(0, c), d[c], s0);
+            if (T::bt(P - 1, c) != 0.0) s1 = __builtin_fmaf((float)T::bt(P - 1, c), d[c], s1);
+        }
+        v[0] = s0;
+        v[P - 1] = s1;
+    }
+#pragma unroll
+    for (int j = 0; 2 * j + 2 < P - 1; ++j) {
+        float e = 0.0f, o = 0.0f;
+#pragma unroll
+        for (int c = 0; c < P; ++c) {
+            if (T::bt(2 * j + 1, c) == 0.0) continue;
+            if (c % 2 == 0) e = __builtin_fmaf((float)T::bt(2 * j + 1, c), d[c], e);
+            else o = __builtin_fmaf((float)T::bt(2 * j + 1, c), d[c], o);
+        }
+        v[2 * j + 1] = e + o;
+        v[2 * j + 2] = e - o;
+    }
+}
+
+// y = A^T m (4 outputs), with the same pair structure: s = m+ + m-, t = m+ - m-.
+template <int KS>
+__device__ __forceinline__ void wino_output_transform(const float (&m)[WinoTables<KS>::P], float (&y)[4]) {
+    using T = WinoTables<KS>;
+    constexpr int P = T::P;
+    y[0] = m[0]; y[1] = 0.0f; y[2] = 0.0f; y[3] = m[P - 1];
+#pragma unroll
+    for (int j = 0; 2 * j + 2 < P - 1; ++j) {
+        const float sj = m[2 * j + 1] + m[2 * j + 2], tj = m[2 * j + 1] - m[2 * j + 2];
+        y[0] = __builtin_fmaf((float)T::at(0, 2 * j + 1), sj, y[0]);
+        y[1] = __builtin_fmaf((float)T::at(1, 2 * j + 1), tj, y[1]);
+        y[2] = __builtin_fmaf((float)T::at(2, 2 * j + 1), sj, y[2]);
+        y[3] = __builtin_fmaf((float)T::at(3, 2 * j + 1), tj, y[3]);
+    }
+}
+
+// Tile 4 x 4 x 32 voxels x 32 channels (a wave = one depth slice: 4 rows x 8 quads), KC = 2 channels
+// per chunk, one kernel depth-slice (kd) of weights resident at a time (double buffered), the input
+// image single-buffered; everything staged by LDS-DMA (no prefetch registers: the 8 or 10 position
+// accumulators take 128 / 160 of them).
+// Dilation 2 (the local model's third convolution, k5): in D and H the taps are simply two rows apart;
+// along W the convolution splits into two independent dense ones over the even and the odd columns
+// (polyphase), so a "quad" is 4 outputs of ONE parity, 2 columns apart, its 8 inputs are every other
+// element of four 16-byte reads, and the epilogue first re-interleaves the two parities between
+// neighbouring lanes so that every lane again owns 4 consecutive outputs.
+template <int KS_, int KC_, int DIL_ = 1>
+struct WinoKCfg {
+    static constexpr int KS = KS_, KC = KC_, DIL = DIL_, MI = 1, TD = 4, TH = 4, PIECE = 4;
+    static constexpr int NPOS = WinoTables<KS>::P;
+    static constexpr int TW = 32, QUADS = 8, RPB = 4, NB = 1;
+    static constexpr int PAD = DIL * (KS - 1) / 2, LPAD = 4, XOFF = LPAD - PAD;
+    static constexpr int IN_D = TD + DIL * (KS - 1), IN_H = TH + DIL * (KS - 1), IN_W = TW + DIL * (KS - 1);
+    static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;
+    static_assert(DIL == 1 || (DIL == 2 && XOFF == 0 && NPOS == 8), "dilation 2 is built for k5");
+    using St = Stager<KC, IN_D, IN_H, IN_WV, 4>;
+    static constexpr int CH = St::CH, TILE = St::TILE;
+    static constexpr int KP = KC / 2;
+    static constexpr int WF = KS * NPOS * KP * 64;            // packed floats per (chunk, kd): [kh][pos][kp][lane]
+    static constexpr int LDS_BYTES = (TILE + 2 * WF) * 4;
+    static_assert(DIL == 2 || (XOFF + 4 * (QUADS - 1) + NPOS <= IN_WV && XOFF + NPOS <= 12),
+                  "three 16-byte reads cover a quad's inputs");
+    static_assert(DIL == 1 || 8 * 3 + 16 <= IN_WV, "four 16-byte reads cover a dilated quad's inputs");
+};
+
+template <class Cfg>
+__device__ __forceinline__ void winok_compute_phase(const float *__restrict__ img, const float *__restrict__ wl, int bbase,
+                                                    int lane, f32x16 (&acc)[Cfg::NPOS][1]) {
+    constexpr int KS = Cfg::KS, P = Cfg::NPOS, KP = Cfg::KP, IN_WV = Cfg::IN_WV, CH = Cfg::CH, XOFF = Cfg::XOFF;
+    constexpr int DIL = Cfg::DIL;
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh) {
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            float af[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) af[q] = wl[((kh * P + q) * KP + kp) * 64];
+            const float *px = img + bbase + kp * 2 * CH + kh * DIL * IN_WV;
+            float d[P], v[P];
+            if constexpr (DIL == 1) {
+                f32x4 t[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) t[j] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(px + 4 * j, 16));
+#pragma unroll
+                for (int i = 0; i < P; ++i) d[i] = t[(XOFF + i) / 4][(XOFF + i) % 4];
+            } else {   // inputs 2i + parity of the 16 floats at px (px already points at this quad pair)
+                f32x4 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(px + 4 * j, 16));
+                const bool odd = (lane & 1) != 0;
+#pragma unroll
+                for (int i = 0; i < P; ++i) d[i] = odd ? t[(2 * i + 1) / 4][(2 * i + 1) % 4] : t[(2 * i) / 4][(2 * i) % 4];
+            }
+            wino_input_transform<KS>(d, v);
+#pragma unroll
+            for (int q = 0; q < P; ++q) acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q], v[q], acc[q][0], 0, 0, 0);
+        }
+    }
+}
+
 // Epilogue of one job (fast-epilogue toolkit above): output transform in place (y0..y3 -> acc[0..3],
 // a third of the accumulator registers become free), per-channel scale and bias through LDS (parked
 // at kernel start; lgkmcnt), every vector load (residual or depth-class planes) before the first
 // store, addresses = wave-uniform channel base (SGPR pair) + one 32-bit per-lane byte offset per row
 // block (the host routes layers with more than 2^27 output voxels per channel elsewhere).
 template <class Cfg, bool RES, bool PLANE>
-__device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[6][Cfg::NB],
+__device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[Cfg::NPOS][Cfg::NB],
                                               const float *__restrict__ aff, int lane, int wave) {
     constexpr int NB = Cfg::NB, TH = Cfg::TH;
     constexpr bool V4 = Cfg::PIECE == 4;           // 16-byte loads / stores (Wout % 4 == 0); else 8-byte halves
@@ -758,13 +890,31 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r],
-                        m4 = acc[4][nb][r], m5 = acc[5][nb][r];
-            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-            acc[0][nb][r] = (m0 + s12) + s34;
-            acc[1][nb][r] = d12 + 2.0f * d34;
-            acc[2][nb][r] = s12 + 4.0f * s34;
-            acc[3][nb][r] = (d12 + 8.0f * d34) + m5;
+            if constexpr (Cfg::KS == 3) {
+                const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r],
+                            m4 = acc[4][nb][r], m5 = acc[5][nb][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                acc[0][nb][r] = (m0 + s12) + s34;
+                acc[1][nb][r] = d12 + 2.0f * d34;
+                acc[2][nb][r] = s12 + 4.0f * s34;
+                acc[3][nb][r] = (d12 + 8.0f * d34) + m5;
+            } else {
+                float m[Cfg::NPOS], y[4];
+#pragma unroll
+                for (int q = 0; q < Cfg::NPOS; ++q) m[q] = acc[q][nb][r];
+                wino_output_transform<Cfg::KS>(m, y);
+                if constexpr (Cfg::DIL == 2) {
+                    // even lane: outputs o, o+2, o+4, o+6; its odd neighbour: o+1, o+3, o+5, o+7.  Afterwards the
+                    // even lane owns o .. o+3 and the odd lane o+4 .. o+7 (its usual 4 consecutive columns).
+                    const bool odd = (lane & 1) != 0;
+                    const float s0 = odd ? y[0] : y[2], s1 = odd ? y[1] : y[3];
+                    const float g0 = dpp_xor1(s0), g1 = dpp_xor1(s1);
+                    const float a0 = odd ? g0 : y[0], a1 = odd ? y[2] : g0, a2 = odd ? g1 : y[1], a3 = odd ? y[3] : g1;
+                    y[0] = a0; y[1] = a1; y[2] = a2; y[3] = a3;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j][nb][r] = y[j];
+            }
         }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -972,6 +1122,86 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
         __syncthreads();
     }
     wino_epilogue<Cfg, RES, PLANE>(a, job, acc, aff, lane, wave);
+}
+
+// k5 / k7 Winograd kernel (WinoKCfg above).  Phase p = (chunk, kd): weights of phase p+1 are DMA'd
+// while phase p is multiplied; the input image of the next chunk is DMA'd after the chunk's last
+// phase (single buffer: that load is exposed to this workgroup and hidden by the co-resident one; a
+// chunk is 7 x 70 = 490 MFMAs per wave for k7).
+template <class Cfg, bool RES>
+__global__ void __launch_bounds__(256, 2)
+conv3d_winok_kernel(const ConvArgs a) {
+    constexpr int KS = Cfg::KS, KC = Cfg::KC, CH = Cfg::CH, TILE = Cfg::TILE, WF = Cfg::WF, P = Cfg::NPOS;
+    using St = typename Cfg::St;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, Cfg::TD, Cfg::TH, Cfg::TW);
+
+    f32x16 acc[P][1];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][0][r] = 0.0f;
+
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const float *xn = a.x + job.n * a.x_bs;
+    // B-fragment base: lane&7 = output quad t, (lane&31)>>3 = row of the wave's depth slice, lane>>5 = k;
+    // a quad's inputs x[4t-PAD .. 4t+3+PAD] sit at image columns 4t+XOFF .. inside three 16-byte reads at 4t
+    // (dilation 2: lanes 2q and 2q+1 are the even / odd parity of the 8 outputs at 8q, both read at 8q)
+    const int bbase = (lane >> 5) * CH + (wave * Cfg::IN_H + ((lane & 31) >> 3)) * Cfg::IN_WV +
+                      (Cfg::DIL == 2 ? 8 * ((lane & 7) >> 1) : 4 * (lane & 7));
+    float *const wlds = lds + TILE;
+    float *const aff = wlds + 2 * WF;
+    const int nchunks = a.nchunks_wino, nphase = nchunks * KS;
+    const float *wg = a.wp_wino + (int64_t)job.cg * nphase * WF;
+    constexpr int SLICE = Cfg::DIL * Cfg::IN_H * Cfg::IN_WV;     // image floats per kernel depth step
+
+    St st;
+    st.init(tid, job.od0 - Cfg::PAD, job.oh0 - Cfg::PAD, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+    constexpr int WITEMS = WF / 4, WNIT = (WITEMS + 255) / 256;
+    const int wbase = tid & ~63;
+    auto issue_w = [&](int ph, int b) {
+        const float *wc = wg + (int64_t)ph * WF;
+        float *const wbuf = wlds + b * WF;
+#pragma unroll
+        for (int it = 0; it < WNIT; ++it) {
+            const int i = it * 256 + tid;
+            if (WITEMS % 256 == 0 || i < WITEMS)
+                __builtin_amdgcn_global_load_lds(wc + 4 * i, wbuf + 4 * (it * 256 + wbase), 16, 0, 0);
+        }
+    };
+    auto issue_img = [&](int chunk) {
+        const float *xc = xn + (int64_t)chunk * KC * in_dhw;
+        const unsigned m = st.store_mask(tid, a.Cin - chunk * KC);
+#pragma unroll
+        for (int it = 0; it < St::NIT; ++it) {
+            const int i = it * 256 + tid;
+            const float *src = ((m >> it) & 1u) ? xc + st.off[it] : g_zero16;
+            if (St::ITEMS % 256 == 0 || i < St::ITEMS)
+                __builtin_amdgcn_global_load_lds(src, lds + 4 * (it * 256 + wbase), 16, 0, 0);
+        }
+    };
+    issue_img(0);
+    issue_w(0, 0);
+    if (tid < 64) {
+        float v = tid < 32 ? 1.0f : 0.0f;
+        if (a.scale) v = (tid < 32 ? a.scale : a.bias)[job.cg * 32 + (tid & 31)];   // Cout % 32 == 0 (host)
+        aff[tid] = v;
+    }
+    __syncthreads();
+    int ph = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int kd = 0; kd < KS; ++kd, ++ph) {
+            if (ph + 1 < nphase) issue_w(ph + 1, (ph + 1) & 1);
+            winok_compute_phase<Cfg>(lds + kd * SLICE, wlds + (ph & 1) * WF + lane, bbase, lane, acc);
+            __syncthreads();
+        }
+        if (chunk + 1 < nchunks) {
+            issue_img(chunk + 1);
+            __syncthreads();
+        }
+    }
+    wino_epilogue<Cfg, RES, false>(a, job, acc, aff, lane, wave);
 }
 
 // ------------------------------------------------------------------------------------ deconv
@@ -1344,6 +1574,39 @@ __global__ void pack_wino_weights_kernel(const float *__restrict__ w, float *__r
     packed[i] = (float)u;
 }
 
+// F(4,KS) packing (k5 / k7, s1): packed[cg][chunk][kd][kh][pos][kp][half][i] = (G g)_pos of the KS kw taps of
+// W[co = cg*32 + i][ci = chunk*KC + 2kp + half][kd][kh][:]
+template <int KS>
+__global__ void pack_winok_weights_kernel(const float *__restrict__ w, float *__restrict__ packed, int Cout, int Cin,
+                                          int KC, int nchunks, int64_t total) {
+    using T = WinoTables<KS>;
+    constexpr int P = T::P;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int KP = KC / 2;
+    int64_t r = i;
+    const int ii = (int)(r % 32); r /= 32;
+    const int half = (int)(r % 2); r /= 2;
+    const int kp = (int)(r % KP); r /= KP;
+    const int pos = (int)(r % P); r /= P;
+    const int kh = (int)(r % KS); r /= KS;
+    const int kd = (int)(r % KS); r /= KS;
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int cg = (int)r;
+    const int co = cg * 32 + ii, ci = chunk * KC + 2 * kp + half;
+    double u = 0.0;
+    if (co < Cout && ci < Cin) {
+        const float *g = w + ((((int64_t)co * Cin + ci) * KS + kd) * KS + kh) * KS;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            if (q != pos) continue;
+#pragma unroll
+            for (int k = 0; k < KS; ++k) u += T::g(q, k) * (double)g[k];
+        }
+    }
+    packed[i] = (float)u;
+}
+
 // ------------------------------------------------------------------------------------ dispatch
 struct Plan {
     int MI, KC, TD, TH;  // tile choice
@@ -1385,6 +1648,9 @@ using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;
 using CfgWinoN  = WinoCfg<4, 4, 2, 4, 32>;   // 32-wide tile (4 rows x 8 quads per MFMA column block): narrow layers
 using CfgWinoN8 = WinoCfg<4, 4, 2, 2, 32>;       // the same for rows that are only 8-byte aligned (W % 4 == 2)
+using CfgWinoK5 = WinoKCfg<5, 2>;
+using CfgWinoK7 = WinoKCfg<7, 2>;
+using CfgWinoK5D2 = WinoKCfg<5, 2, 2>;
 using CfgDCM1   = DeconvCfg<1, 2, 4, 4>;
 using CfgDCM2   = DeconvCfg<2, 2, 4, 4>;
 using CfgDCM1v8 = DeconvCfg<1, 2, 4, 4, 2>;
@@ -1468,8 +1734,30 @@ void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
 }
 
 inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
-    if (d.transposed || d.ksize != 3 || d.stride != 1 || d.dilation != 1) return 0;
-    return (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, CfgWino::KC) * CfgWino::WF;
+    if (d.transposed || d.stride != 1 || !(d.dilation == 1 || (d.dilation == 2 && d.ksize == 5))) return 0;
+    const int64_t gc = (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, 2);     // groups x chunks (KC = 2 everywhere)
+    if (d.ksize == 3) return gc * CfgWino::WF;
+    if (d.ksize == 5) return gc * 5 * CfgWinoK5::WF;
+    if (d.ksize == 7) return gc * 7 * CfgWinoK7::WF;
+    return 0;
+}
+
+template <class Cfg, bool RES>
+void launch_winok_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
+    static bool attr_done = false;
+    if (!attr_done && BYTES > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_winok_kernel<Cfg, RES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+        attr_done = true;
+    }
+    conv3d_winok_kernel<Cfg, RES><<<grid, 256, BYTES, st>>>(a);
+}
+
+template <class Cfg>
+void launch_winok(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    if (a.res) launch_winok_variant<Cfg, true>(a, grid, st);
+    else launch_winok_variant<Cfg, false>(a, grid, st);
 }
 
 template <class Cfg, bool RES, bool PLANE>
@@ -1568,8 +1856,14 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
     const int64_t wino = wino_packed_count(*d);
     if (wino) {
         total -= wino;
-        pack_wino_weights_kernel<<<(unsigned)ceil_div<int64_t>(wino, 256), 256, 0, as_stream(stream)>>>(
-            weight, packed + total, d->Cout, d->Cin, CfgWino::KC, ceil_div(d->Cin, CfgWino::KC), wino);
+        const unsigned wb = (unsigned)ceil_div<int64_t>(wino, 256);
+        const int nck = ceil_div(d->Cin, 2);
+        if (d->ksize == 3)
+            pack_wino_weights_kernel<<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino);
+        else if (d->ksize == 5)
+            pack_winok_weights_kernel<5><<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino);
+        else
+            pack_winok_weights_kernel<7><<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino);
         int rcw = check_launch("snvc_conv3d_pack_weights(winograd)");
         if (rcw) return rcw;
     }
@@ -1655,15 +1949,35 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
             pointwise_small_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
         return check_launch("snvc_conv3d_forward(pointwise)");
     }
+    // k5 / k7, stride 1, no dilation: Winograd F(4,KS) along W (LDS-DMA staged: 16-byte rows only)
+    if (!d->transposed && (d->ksize == 5 || d->ksize == 7) && d->stride == 1 &&
+        (d->dilation == 1 || (d->dilation == 2 && d->ksize == 5)) && a.vec && a.fast_epi && !depth_planes) {
+        const char *nw = getenv("SNVC_NO_WINOGRAD");
+        if (!(nw && nw[0] == '1') && d->algo != SNVC_ALGO_DIRECT) {
+            const int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
+            a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
+            a.nchunks_wino = ceil_div(d->Cin, 2);
+            a.groups = ceil_div(d->Cout, 32);
+            a.tiles_d = ceil_div(d->Dout, 4); a.tiles_h = ceil_div(d->Hout, 4); a.tiles_w = ceil_div(d->Wout, 32);
+            const int64_t nj = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w * a.groups * d->N;
+            if (nj < ((int64_t)1 << 31)) {
+                a.njobs = (int)nj;
+                if (d->ksize == 5 && d->dilation == 2) launch_winok<CfgWinoK5D2>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                else if (d->ksize == 5) launch_winok<CfgWinoK5>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                else launch_winok<CfgWinoK7>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                return check_launch("snvc_conv3d_forward(winograd k5/k7)");
+            }
+        }
+    }
     // k3 / stride 1: Winograd F(4,3) along W when the rows allow 8-byte pair stores and 16-byte staging
     {
-        const int64_t wino = wino_packed_count(*d);
+        const int64_t wino = d->ksize == 3 ? wino_packed_count(*d) : 0;
         const char *nw = getenv("SNVC_NO_WINOGRAD");   // development knob: force the direct kernel
         const bool pair_ok = (d->Wout % 2 == 0) && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
                              ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
                                reinterpret_cast<uintptr_t>(depth_planes)) & 7) == 0;
         const bool wide = a.vec && epi16;   // 16-byte staging and stores; else 8-byte ones (pair_ok)
-        if (wino && pair_ok && fast_common && (wide || vec8) && !(nw && nw[0] == '1')) {
+        if (wino && pair_ok && fast_common && (wide || vec8) && !(nw && nw[0] == '1') && d->algo != SNVC_ALGO_DIRECT) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, CfgWino::KC);
             a.groups = ceil_div(d->Cout, 32);

@@ -220,9 +220,9 @@ class Conv3dLayer:
         d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = x_bs, y_bs, r_bs
         return d
 
-    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None, depth_planes=None):
+    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None, depth_planes=None, exact=False):
         """y = epilogue(conv(x)); x / out / residual may be channel slices of larger buffers.
-        depth_planes [N,Cout,3,H,W]: see snvc_conv3d_forward_ex."""
+        depth_planes [N,Cout,3,H,W]: see snvc_conv3d_forward_ex.  exact=True: SNVC_ALGO_DIRECT (no Winograd)."""
         _gpu(x, "x")
         if x.dtype != torch.float32 or x.dim() != 5 or x.size(1) != self.cin:
             raise RuntimeError(f"conv3d input must be float32 [N,{self.cin},D,H,W], got {tuple(x.shape)} {x.dtype}")
@@ -247,6 +247,7 @@ class Conv3dLayer:
             return out
         d = self._desc(n, in_sp, flags, _batch_stride(x), _batch_stride(out),
                        _batch_stride(residual) if residual is not None else 0)
+        d.algo = 1 if exact else 0
         if depth_planes is not None:
             if tuple(depth_planes.shape) != (n, self.cout, 3) + out_shape[3:] or not depth_planes.is_contiguous():
                 raise RuntimeError("depth_planes must be a contiguous [N,Cout,3,H,W] tensor")

@@ -56,6 +56,14 @@ for _ in range(args.reps):
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / args.reps
 assert torch.isfinite(bev).all()
+if F == 32 and grid[0] == 32:   # the 2D BEV neck + heads that follow the path
+    with torch.no_grad():
+        m.heads_2d(bev); torch.cuda.synchronize()
+        a.record()
+        for _ in range(args.reps):
+            hm, co = m.heads_2d(bev)
+        b.record(); torch.cuda.synchronize()
+    print(f"{args.cfg}: 2D neck + heads: {a.elapsed_time(b) / args.reps / n:.2f} ms/crop")
 print(f"{args.cfg}: grid {grid} F={F} crops/call={n}: {ms / n:.2f} ms/crop = {1e3 * n / ms:.1f} crops/s/GPU, "
       f"{gflop * n / ms:.1f} TFLOP/s ({100 * gflop * n / ms / 157.3:.0f}% of fp32 MFMA), "
       f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
