@@ -175,6 +175,114 @@ voxel_gather_fwd_x4(const float *__restrict__ left, const float *__restrict__ ri
     }
 }
 
+// ---- channels-last forward path ----
+// The plain kernel issues 4 gather loads per channel per camera (256 per voxel at F = 32) and is bound by
+// load-instruction issue, not by HBM (L1 hit rate 99 %).  With the feature maps re-laid [pixel][F] (a 2 x
+// N x F x Hf x Wf float workspace, <= 4 MB on the path) one 16-byte load fetches 4 channels of a tap:
+// 64 loads per voxel instead of 256, same taps, same weights, same separately rounded
+// a*nw + b*ne + c*sw + d*se per channel, so the result stays bit-identical.
+__global__ void __launch_bounds__(256)
+features_to_channels_last(const float *__restrict__ left, const float *__restrict__ right, float *__restrict__ ws,
+                          int F, int plane) {
+    // grid: (pixel blocks, N, 2 sides); LDS tile [64 pixels][F+1]
+    extern __shared__ float tile[];
+    const int side = blockIdx.z;
+    const int64_t n = blockIdx.y;
+    const float *src = (side == 0 ? left : right) + n * F * (int64_t)plane;
+    float *dst = ws + ((int64_t)side * gridDim.y + n) * F * (int64_t)plane;
+    const int p0 = blockIdx.x * 64;
+    for (int i = threadIdx.x; i < 64 * F; i += blockDim.x) {
+        const int c = i / 64, p = i % 64;                       // coalesced along pixels
+        tile[p * (F + 1) + c] = p0 + p < plane ? src[(int64_t)c * plane + p0 + p] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * F; i += blockDim.x) {
+        const int p = i / F, c = i % F;                         // coalesced along channels
+        if (p0 + p < plane) dst[(int64_t)(p0 + p) * F + c] = tile[p * (F + 1) + c];
+    }
+}
+
+__device__ __forceinline__ void gather_side_cl(const float *__restrict__ feat_cl, const Taps &t, int F, int64_t V,
+                                               float *__restrict__ o) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 *pa = reinterpret_cast<const f4 *>(feat_cl + (int64_t)(t.off[0] < 0 ? 0 : t.off[0]) * F);
+    const f4 *pb = reinterpret_cast<const f4 *>(feat_cl + (int64_t)(t.off[1] < 0 ? 0 : t.off[1]) * F);
+    const f4 *pc = reinterpret_cast<const f4 *>(feat_cl + (int64_t)(t.off[2] < 0 ? 0 : t.off[2]) * F);
+    const f4 *pd = reinterpret_cast<const f4 *>(feat_cl + (int64_t)(t.off[3] < 0 ? 0 : t.off[3]) * F);
+    const bool va = t.off[0] >= 0, vb = t.off[1] >= 0, vc = t.off[2] >= 0, vd = t.off[3] >= 0;
+#pragma unroll 4
+    for (int c4 = 0; c4 < F / 4; ++c4) {
+        const f4 a4 = pa[c4], b4 = pb[c4], c4v = pc[c4], d4 = pd[c4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = va ? a4[j] : 0.0f, b = vb ? b4[j] : 0.0f, c = vc ? c4v[j] : 0.0f, d = vd ? d4[j] : 0.0f;
+            o[(int64_t)(4 * c4 + j) * V] = a * t.wt[0] + b * t.wt[1] + c * t.wt[2] + d * t.wt[3];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+voxel_gather_fwd_cl(const float *__restrict__ ws, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
+                    float *__restrict__ out, int F, int Hf, int Wf, int64_t V, float res_x, float res_y) {
+    const int64_t n = blockIdx.y;
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const float *lp = l_pts + n * 2 * V, *rp = r_pts + n * 2 * V;
+    const Taps tl = make_taps(lp[v], lp[V + v], res_x, res_y, Hf, Wf);
+    const Taps tr = make_taps(rp[v], rp[V + v], res_x, res_y, Hf, Wf);
+    const int64_t fp = (int64_t)F * Hf * Wf;
+    const float *lf = ws + n * fp, *rf = ws + ((int64_t)gridDim.y + n) * fp;
+    float *o = out + n * 2 * F * V + v;
+    gather_side_cl(lf, tl, F, V, o);
+    gather_side_cl(rf, tr, F, V, o + (int64_t)F * V);
+}
+
+// Four consecutive voxels per thread on the channels-last maps: a wave writes 1 KB contiguous per channel
+// row (8 whole cache lines) instead of 256 B, which is what the HBM write stream wants.
+__global__ void __launch_bounds__(256)
+voxel_gather_fwd_cl_x4(const float *__restrict__ ws, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
+                       float *__restrict__ out, int F, int Hf, int Wf, int64_t V, float res_x, float res_y) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int64_t n = blockIdx.y;
+    const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (v >= V) return;
+    const int64_t fp = (int64_t)F * Hf * Wf;
+    float *o = out + n * 2 * F * V + v;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const float *pts = (side == 0 ? l_pts : r_pts) + n * 2 * V;
+        const float *feat = ws + ((int64_t)side * gridDim.y + n) * fp;
+        const f4 px = *reinterpret_cast<const f4 *>(pts + v);
+        const f4 py = *reinterpret_cast<const f4 *>(pts + V + v);
+        Taps t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = make_taps(px[k], py[k], res_x, res_y, Hf, Wf);
+#pragma unroll 2
+        for (int c4 = 0; c4 < F / 4; ++c4) {
+            f4 res[4];   // res[j] = channel 4*c4+j of the 4 voxels
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f4 a4 = reinterpret_cast<const f4 *>(feat + (int64_t)(t[k].off[0] < 0 ? 0 : t[k].off[0]) * F)[c4];
+                const f4 b4 = reinterpret_cast<const f4 *>(feat + (int64_t)(t[k].off[1] < 0 ? 0 : t[k].off[1]) * F)[c4];
+                const f4 c4v = reinterpret_cast<const f4 *>(feat + (int64_t)(t[k].off[2] < 0 ? 0 : t[k].off[2]) * F)[c4];
+                const f4 d4 = reinterpret_cast<const f4 *>(feat + (int64_t)(t[k].off[3] < 0 ? 0 : t[k].off[3]) * F)[c4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = t[k].off[0] >= 0 ? a4[j] : 0.0f, b = t[k].off[1] >= 0 ? b4[j] : 0.0f;
+                    const float c = t[k].off[2] >= 0 ? c4v[j] : 0.0f, d = t[k].off[3] >= 0 ? d4[j] : 0.0f;
+                    res[j][k] = a * t[k].wt[0] + b * t[k].wt[1] + c * t[k].wt[2] + d * t[k].wt[3];
+                }
+            }
+#pragma unroll
+            // non-temporal: the voxel tensor (0.2 GB per instance) is streamed out once and read by the next
+            // kernel from HBM anyway; measured 3.9 -> 5.0 TB/s
+            for (int j = 0; j < 4; ++j)
+                __builtin_nontemporal_store(res[j], reinterpret_cast<f4 *>(o + (int64_t)(4 * c4 + j) * V));
+        }
+        o += (int64_t)F * V;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 voxel_gather_bwd(const float *__restrict__ grad_out, const float *__restrict__ l_pts,
                  const float *__restrict__ r_pts, float *__restrict__ grad_left,
@@ -276,6 +384,38 @@ int snvc_voxel_gather_forward(const float *left, const float *right, const float
                                                               (int)Hf, (int)Wf, V, res_x, res_y);
     }
     return check_launch("snvc_voxel_gather_forward");
+}
+
+int64_t snvc_voxel_gather_workspace_floats(int64_t N, int64_t F, int64_t Hf, int64_t Wf) {
+    if (N < 0 || F < 0 || Hf < 0 || Wf < 0) return -1;
+    return 2 * N * F * Hf * Wf;
+}
+
+int snvc_voxel_gather_forward_ws(const float *left, const float *right, const float *l_pts, const float *r_pts,
+                                 float *out, float *workspace, int64_t N, int64_t F, int64_t Hf, int64_t Wf,
+                                 int64_t V, float res_x, float res_y, void *stream) {
+    using namespace snvc;
+    const bool cl_ok = workspace && F > 0 && F % 4 == 0 && F <= 256 && N > 0 && V > 0 && N <= 65535 &&
+                       Hf * Wf < ((int64_t)1 << 24) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    if (!cl_ok) return snvc_voxel_gather_forward(left, right, l_pts, r_pts, out, N, F, Hf, Wf, V, res_x, res_y, stream);
+    if (!left || !right || !l_pts || !r_pts || !out)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward_ws: null pointer");
+    const int plane = (int)(Hf * Wf);
+    dim3 tg((unsigned)ceil_div(plane, 64), (unsigned)N, 2);
+    features_to_channels_last<<<tg, 256, (size_t)64 * (F + 1) * sizeof(float), as_stream(stream)>>>(left, right, workspace,
+                                                                                                    (int)F, plane);
+    const char *x1 = getenv("SNVC_GATHER_X1");   // development knob: one voxel per thread
+    if (V % 4 == 0 && !(x1 && x1[0] == '1') &&
+        ((reinterpret_cast<uintptr_t>(l_pts) | reinterpret_cast<uintptr_t>(r_pts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        dim3 grid((unsigned)ceil_div<int64_t>(V / 4, 256), (unsigned)N);
+        voxel_gather_fwd_cl_x4<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf,
+                                                                    V, res_x, res_y);
+    } else {
+        dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
+        voxel_gather_fwd_cl<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V,
+                                                                 res_x, res_y);
+    }
+    return check_launch("snvc_voxel_gather_forward_ws");
 }
 
 int snvc_voxel_gather_backward(const float *grad_out, const float *l_pts, const float *r_pts,

@@ -136,9 +136,12 @@ def voxel_gather_forward(left, right, l_pts, r_pts, resolution) -> torch.Tensor:
         return out
     left, right, l_pts, r_pts = left.contiguous(), right.contiguous(), l_pts.contiguous(), r_pts.contiguous()
     with torch.cuda.device(left.device):
-        check(_lib.lib().snvc_voxel_gather_forward(_ptr(left), _ptr(right), _ptr(l_pts), _ptr(r_pts), _ptr(out), n, f,
-                                                   hf, wf, v, float(resolution[1]), float(resolution[0]),
-                                                   _stream(left)), "voxel_gather_forward")
+        # channels-last copy of both feature maps (<= 4 MB on the path): 4x fewer gather instructions, same bits
+        ws = torch.empty(_lib.lib().snvc_voxel_gather_workspace_floats(n, f, hf, wf), dtype=torch.float32,
+                         device=left.device) if f % 4 == 0 else None
+        check(_lib.lib().snvc_voxel_gather_forward_ws(_ptr(left), _ptr(right), _ptr(l_pts), _ptr(r_pts), _ptr(out),
+                                                      _ptr(ws), n, f, hf, wf, v, float(resolution[1]),
+                                                      float(resolution[0]), _stream(left)), "voxel_gather_forward")
     return out
 
 
