@@ -19,6 +19,8 @@
 // in a fixed order: the result is deterministic (no float atomics).
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace snvc {
 namespace {
 
@@ -36,18 +38,23 @@ struct WgradArgs {
     int P;                      // spatial partitions (gridDim.x)
     int cx_blocks;              // pairs = cg_blocks * cx_blocks, blockIdx.y = cgb * cx_blocks + cxb
     int64_t x_bs, g_bs;
+    int vec;   // 16-byte aligned rows on both grids: float4 staging with register prefetch
 };
 
 // A workgroup covers a CHUNK of taps: KDG kernel depth-slices x KHG kernel rows x all KS columns
 // (<= 28 taps = 7 per wave); blockIdx.z enumerates the chunks, so 5^3 and 7^3 kernels only widen
 // the grid, not the register or LDS footprint.
-template <int KS_, int STRIDE_, int DIL_, int TH_, int KDG_, int KHG_>
+// KSPLIT_: the 4 waves split the K-steps (voxel pairs) of a tile and each keeps ALL taps of the chunk (<= 10);
+// otherwise they split the chunk's taps (<= 7 each).  K-splitting has no padded tap slots (9 taps over 4 waves
+// would issue 12 MFMAs per K-step) and ends with a fixed-order reduction of the four waves through LDS.
+template <int KS_, int STRIDE_, int DIL_, int TH_, int KDG_, int KHG_, bool KSPLIT_ = false>
 struct WgradCfg {
+    static constexpr bool KSPLIT = KSPLIT_;
     static constexpr int KS = KS_, STRIDE = STRIDE_, DIL = DIL_, KDG = KDG_, KHG = KHG_;
     static constexpr int PAD = DIL * (KS - 1) / 2;
     static constexpr int TAPS = KS * KS * KS;
     static constexpr int CHUNK_TAPS = KDG * KHG * KS;
-    static constexpr int NT = (CHUNK_TAPS + 3) / 4;    // taps per wave
+    static constexpr int NT = KSPLIT_ ? CHUNK_TAPS : (CHUNK_TAPS + 3) / 4;    // taps per wave
     static constexpr int CH_D = KS / KDG, CH_H = (KS + KHG - 1) / KHG;   // chunks along kd / kh
     static constexpr int TH = TH_, TW = 32;            // output tile: 1 x TH x 32 voxels = 32*TH K-slots
     static constexpr int IN_D = (KDG - 1) * DIL + 1;
@@ -58,11 +65,18 @@ struct WgradCfg {
     static constexpr int XS = XV | 1;                  // odd row stride
     static constexpr int GV = TH * TW;
     static constexpr int GS = GV + 1;                  // odd
-    static constexpr int LDS_FLOATS = 32 * XS + 32 * GS;
-    static_assert(NT <= 7, "at most 28 taps per workgroup");
+    // vectorised staging (rows widened to 16-byte aligned global columns, like the forward Stager)
+    static constexpr int LPAD = 4, XOFF = LPAD - PAD;
+    static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;
+    static constexpr int XVV = IN_D * IN_H * IN_WV, XSV = XVV | 1;
+    static constexpr int RQ = IN_WV / 4, XITEMS = 32 * IN_D * IN_H * RQ, XNIT = (XITEMS + 255) / 256;
+    static constexpr int GITEMS = 32 * TH * 8, GNIT = (GITEMS + 255) / 256;
+    static constexpr int LDS_FLOATS = 32 * (XSV > XS ? XSV : XS) + 32 * GS;
+    static_assert(NT <= (KSPLIT_ ? 10 : 7), "accumulators per wave");
+    static_assert(PAD <= LPAD, "left halo fits the aligned margin");
 };
 
-template <class Cfg>
+template <class Cfg, bool VEC>
 __global__ void __launch_bounds__(256, 2)
 conv3d_wgrad_kernel(const WgradArgs a) {
     constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, PAD = Cfg::PAD, NT = Cfg::NT;
@@ -90,10 +104,10 @@ conv3d_wgrad_kernel(const WgradArgs a) {
     int tap_off[NT], tap_glob[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int lt = wave + 4 * t;
+        const int lt = Cfg::KSPLIT ? t : wave + 4 * t;
         const int kw = lt % KS, kh = (lt / KS) % khn, kd = lt / (KS * khn);
         const bool ok = lt < chunk_taps;
-        tap_off[t] = ok ? (kd * DIL * IN_H + kh * DIL) * IN_W + kw * DIL : 0;
+        tap_off[t] = ok ? (kd * DIL * IN_H + kh * DIL) * (VEC ? Cfg::IN_WV : IN_W) + kw * DIL : 0;
         tap_glob[t] = ok ? ((kd0 + kd) * KS + kh0 + kh) * KS + kw : -1;
     }
 
@@ -102,6 +116,103 @@ conv3d_wgrad_kernel(const WgradArgs a) {
     const int ch = lane & 31, half = lane >> 5;
     const float *xrow = xl + ch * XS, *grow = gl + ch * GS;
 
+    if constexpr (VEC) {
+        // ---- float4 staging with register prefetch: the element -> (channel, row, piece) decomposition of a
+        // staging item does not depend on the tile, so it is done once; per tile only the three range tests
+        // remain.  Tile t+1 is in registers while tile t is multiplied; LDS is single-buffered (70 KB).
+        constexpr int IN_WV = Cfg::IN_WV, XSV = Cfg::XSV, RQ = Cfg::RQ, XNIT = Cfg::XNIT, GNIT = Cfg::GNIT;
+        constexpr int ROWS = Cfg::IN_D * IN_H;
+        float *glv = lds + 32 * XSV;
+        const float *xrow_v = xl + ch * XSV, *grow_v = glv + ch * GS;
+        // one packed code per staging item: dd | hh << 4 | q << 8 | c << 16  (-1: item beyond the tile / channels)
+        int xcode[XNIT], gcode[GNIT];
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it) {
+            const int i = it * 256 + tid;
+            const int c = i / (ROWS * RQ), r = i - c * (ROWS * RQ);
+            const int row = r / RQ, q = r - row * RQ;
+            const int dd = row / IN_H, hh = row - dd * IN_H;
+            xcode[it] = (i < Cfg::XITEMS && cx0 + c < a.Cx) ? (dd | (hh << 4) | (q << 8) | (c << 16)) : -1;
+        }
+#pragma unroll
+        for (int it = 0; it < GNIT; ++it) {
+            const int i = it * 256 + tid;
+            const int c = i / (Cfg::TH * 8), r = i - c * (Cfg::TH * 8);
+            const int hh = r / 8, q = r - hh * 8;
+            gcode[it] = (i < Cfg::GITEMS && cg0 + c < a.Cg) ? (hh | (q << 8) | (c << 16)) : -1;
+        }
+        static_assert(Cfg::IN_D <= 16 && IN_H <= 16 && RQ <= 256, "packed staging code");
+        f32x4 xv[XNIT], gv[GNIT];
+        unsigned xok = 0, gok = 0;
+        auto load_tile = [&](int64_t tile) {
+            const int tw = (int)(tile % a.tiles_w);
+            const int th = (int)((tile / a.tiles_w) % a.tiles_h);
+            const int od = (int)((tile / ((int64_t)a.tiles_w * a.tiles_h)) % a.Do);
+            const int64_t n = tile / ((int64_t)a.tiles_w * a.tiles_h * a.Do);
+            const int oh0 = th * Cfg::TH, ow0 = tw * 32;
+            const int id0 = od * S - PAD + kd0 * DIL, ih0 = oh0 * S - PAD + kh0 * DIL, ix0 = ow0 * S - Cfg::LPAD;
+            const float *xn = a.x + n * a.x_bs + (int64_t)cx0 * in_dhw;
+            const float *gn = a.g + n * a.g_bs + (int64_t)cg0 * out_dhw;
+            const int64_t xorg = (int64_t)id0 * in_hw + (int64_t)ih0 * a.Wi + ix0;    // may be negative; used only when valid
+            const int64_t gorg = (int64_t)od * out_hw + (int64_t)oh0 * a.Wo + ow0;
+            xok = 0; gok = 0;
+#pragma unroll
+            for (int it = 0; it < XNIT; ++it) {
+                const int dd = xcode[it] & 15, hh = (xcode[it] >> 4) & 15, q = (xcode[it] >> 8) & 255, c = xcode[it] >> 16;
+                const bool ok = xcode[it] >= 0 && (unsigned)(id0 + dd) < (unsigned)a.Di &&
+                                (unsigned)(ih0 + hh) < (unsigned)a.Hi && (unsigned)(ix0 + 4 * q) < (unsigned)a.Wi;
+                const int64_t rel = c * in_dhw + dd * in_hw + (int64_t)hh * a.Wi + 4 * q;
+                xv[it] = *reinterpret_cast<const f32x4 *>(ok ? xn + xorg + rel : a.x);
+                xok |= (ok ? 1u : 0u) << it;
+            }
+#pragma unroll
+            for (int it = 0; it < GNIT; ++it) {
+                const int hh = gcode[it] & 255, q = (gcode[it] >> 8) & 255, c = gcode[it] >> 16;
+                const bool ok = gcode[it] >= 0 && oh0 + hh < a.Ho && ow0 + 4 * q < a.Wo;
+                gv[it] = *reinterpret_cast<const f32x4 *>(ok ? gn + gorg + c * out_dhw + (int64_t)hh * a.Wo + 4 * q : a.g);
+                gok |= (ok ? 1u : 0u) << it;
+            }
+        };
+        auto store_tile = [&]() {
+#pragma unroll
+            for (int it = 0; it < XNIT; ++it) {
+                if (Cfg::XITEMS % 256 != 0 && it * 256 + tid >= Cfg::XITEMS) continue;
+                const bool ok = (xok >> it) & 1u;
+                const int dd = xcode[it] & 15, hh = (xcode[it] >> 4) & 15, q = (xcode[it] >> 8) & 255, c = (xcode[it] >> 16) & 31;
+                const int dst = c * XSV + (dd * IN_H + hh) * IN_WV + 4 * q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xl[dst + j] = ok ? xv[it][j] : 0.0f;
+            }
+#pragma unroll
+            for (int it = 0; it < GNIT; ++it) {
+                if (Cfg::GITEMS % 256 != 0 && it * 256 + tid >= Cfg::GITEMS) continue;
+                const bool ok = (gok >> it) & 1u;
+                const int hh = gcode[it] & 255, q = (gcode[it] >> 8) & 255, c = (gcode[it] >> 16) & 31;
+                const int dst = c * GS + hh * 32 + 4 * q;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) glv[dst + j] = ok ? gv[it][j] : 0.0f;
+            }
+        };
+        int64_t tile = blockIdx.x;
+        if (tile < a.ntiles) load_tile(tile);
+        for (; tile < a.ntiles; tile += a.P) {
+            __syncthreads();   // previous tile fully consumed
+            store_tile();
+            __syncthreads();
+            if (tile + a.P < a.ntiles) load_tile(tile + a.P);   // in flight during the MFMAs below
+            for (int kk = Cfg::KSPLIT ? wave : 0; kk < GV / 2; kk += Cfg::KSPLIT ? 4 : 1) {
+                const int v = 2 * kk + half;
+                const int hh = v >> 5, j = v & 31;
+                const float af = grow_v[v];
+                const int xbase = (hh * S) * IN_WV + j * S + Cfg::XOFF;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float bf = xrow_v[xbase + tap_off[t]];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    } else {
     for (int64_t tile = blockIdx.x; tile < a.ntiles; tile += a.P) {
         const int tw = (int)(tile % a.tiles_w);
         const int th = (int)((tile / a.tiles_w) % a.tiles_h);
@@ -160,15 +271,48 @@ conv3d_wgrad_kernel(const WgradArgs a) {
         }
     }
 
+    }
+
     // ---- partial slab: [p][pair][tap (global index)][cg 32][cx 32]
     float *pp = a.partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (int64_t)Cfg::TAPS * 1024;
+    if constexpr (Cfg::KSPLIT) {
+        // the four waves hold partial sums of the SAME taps: add them in wave order through LDS (deterministic)
+        constexpr int TG = Cfg::LDS_FLOATS / 1024 < NT ? Cfg::LDS_FLOATS / 1024 : NT;   // taps per reduction round
+        static_assert(TG >= 1, "reduction buffer");
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (tap_glob[t] < 0) continue;
+        for (int t0 = 0; t0 < NT; t0 += TG) {
+            __syncthreads();   // staging LDS / previous round no longer read
+            for (int w = 0; w < 4; ++w) {
+                if (wave == w) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;           // cg
-            pp[((int64_t)tap_glob[t] * 32 + row) * 32 + ch] = acc[t][r];  // col = cx = lane & 31
+                    for (int t = t0; t < t0 + TG && t < NT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float *slot = lds + ((t - t0) * 16 + r) * 64 + lane;
+                            *slot = w == 0 ? acc[t][r] : *slot + acc[t][r];
+                        }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int t = t0; t < t0 + TG && t < NT; ++t) {
+                if (tap_glob[t] < 0) continue;
+                for (int i = tid; i < 1024; i += 256) {
+                    const int r = i >> 6, l = i & 63;
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+                    pp[((int64_t)tap_glob[t] * 32 + row) * 32 + (l & 31)] = lds[(t - t0) * 1024 + i];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (tap_glob[t] < 0) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * half;           // cg
+                pp[((int64_t)tap_glob[t] * 32 + row) * 32 + ch] = acc[t][r];  // col = cx = lane & 31
+            }
         }
     }
 }
@@ -190,16 +334,24 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__
     dw[i] = s;
 }
 
-template <class Cfg>
-void launch_wgrad(const WgradArgs &a, dim3 grid, hipStream_t st) {
+template <class Cfg, bool VEC>
+void launch_wgrad_variant(const WgradArgs &a, dim3 grid, hipStream_t st) {
     constexpr int bytes = Cfg::LDS_FLOATS * 4;
     static bool attr_done = false;
     if (!attr_done && bytes > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<Cfg>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<Cfg, VEC>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         attr_done = true;
     }
-    conv3d_wgrad_kernel<Cfg><<<grid, 256, bytes, st>>>(a);
+    conv3d_wgrad_kernel<Cfg, VEC><<<grid, 256, bytes, st>>>(a);
+}
+
+template <class Cfg>
+void launch_wgrad(const WgradArgs &a, dim3 grid, hipStream_t st) {
+    // the prefetching float4 path is built for the K-split configurations only (the tap-split ones have no
+    // registers left for the prefetch: 112 accumulator registers + 60 of staging spill)
+    if constexpr (Cfg::KSPLIT) launch_wgrad_variant<Cfg, true>(a, grid, st);
+    else launch_wgrad_variant<Cfg, false>(a, grid, st);
 }
 
 constexpr int kWgradPartitions = 512;   // 2 workgroups per CU
@@ -250,6 +402,9 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
     a.cx_blocks = ceil_div(d->Cin, 32);
     a.x_bs = d->x_batch_stride ? d->x_batch_stride : in_sz;
     a.g_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
+    const char *nv = getenv("SNVC_WGRAD_SCALAR");   // development knob: the scalar staging path
+    a.vec = d->Win % 4 == 0 && d->Wout % 4 == 0 && a.x_bs % 4 == 0 && a.g_bs % 4 == 0 &&
+            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0 && !(nv && nv[0] == '1');
     const int pairs = ceil_div(d->Cout, 32) * a.cx_blocks;
     if (pairs > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: too many channel pairs");
     hipStream_t st = as_stream(stream);
@@ -257,12 +412,17 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
 #define SNVC_WGRAD_CASE(CFG)                                                                  \
     {                                                                                         \
         using C_ = CFG;                                                                       \
+        a.tiles_h = ceil_div(d->Hout, C_::TH);                                                \
+        a.ntiles = (int64_t)d->N * d->Dout * a.tiles_h * a.tiles_w;                           \
         dim3 grid(kWgradPartitions, (unsigned)pairs, (unsigned)(C_::CH_D * C_::CH_H));        \
         launch_wgrad<C_>(a, grid, st);                                                        \
     }
     switch (key) {  //                            KS S  D  TH KDG KHG
         case 111: SNVC_WGRAD_CASE(SNVC_CFG(1, 1, 1, 2, 1, 1)) break;
-        case 311: SNVC_WGRAD_CASE(SNVC_CFG(3, 1, 1, 2, 3, 3)) break;
+        case 311:   // float4-staged, register-prefetched, K-split form when the rows are 16-byte aligned
+            if (a.vec) SNVC_WGRAD_CASE(SNVC_CFG(3, 1, 1, 2, 1, 3, true))
+            else SNVC_WGRAD_CASE(SNVC_CFG(3, 1, 1, 2, 3, 3))
+            break;
         case 321: SNVC_WGRAD_CASE(SNVC_CFG(3, 2, 1, 1, 3, 3)) break;
         case 511: SNVC_WGRAD_CASE(SNVC_CFG(5, 1, 1, 2, 1, 5)) break;
         case 512: SNVC_WGRAD_CASE(SNVC_CFG(5, 1, 2, 2, 1, 5)) break;
