@@ -613,7 +613,7 @@ conv3d_mfma_kernel(const ConvArgs a) {
 template <int TD_, int TH_, int KC_, int PIECE_ = 4, int TW_ = 64>
 struct WinoCfg {
     static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1, PIECE = PIECE_;
-    static constexpr int KS = 3, NPOS = 6;
+    static constexpr int KS = 3, NPOS = 6, STRIDE = 1;
     // The 32 MFMA columns are RPB rows x (TW/4) quads: 2 rows x 64 outputs, or 4 rows x 32 outputs for
     // layers whose width fills 64-wide tiles badly (W = 156 -> 3 x 64 is 81 % full, 5 x 32 is 97 %).
     static constexpr int TW = TW_, QUADS = TW / 4, RPB = 32 / QUADS, LPAD = 4, XOFF = 3;
@@ -810,7 +810,7 @@ __device__ __forceinline__ void wino_output_transform(const float (&m)[WinoTable
 // neighbouring lanes so that every lane again owns 4 consecutive outputs.
 template <int KS_, int KC_, int DIL_ = 1>
 struct WinoKCfg {
-    static constexpr int KS = KS_, KC = KC_, DIL = DIL_, MI = 1, TD = 4, TH = 4, PIECE = 4;
+    static constexpr int KS = KS_, KC = KC_, DIL = DIL_, STRIDE = 1, MI = 1, TD = 4, TH = 4, PIECE = 4;
     static constexpr int NPOS = WinoTables<KS>::P;
     static constexpr int TW = 32, QUADS = 8, RPB = 4, NB = 1;
     static constexpr int PAD = DIL * (KS - 1) / 2, LPAD = 4, XOFF = LPAD - PAD;
@@ -826,6 +826,67 @@ struct WinoKCfg {
                   "three 16-byte reads cover a quad's inputs");
     static_assert(DIL == 1 || 8 * 3 + 16 <= IN_WV, "four 16-byte reads cover a dilated quad's inputs");
 };
+
+// Stride-2 3x3x3 convolution (the hourglass down-sampling layers): in D and H the stride only changes
+// which input rows a tap reads; along W the layer splits into its two polyphase components,
+//     y[o] = g1 * xe[o]  +  ( g0 * xo[o-1] + g2 * xo[o] ),     xe[i] = x[2i], xo[i] = x[2i+1]:
+// a pointwise product on the even columns (4 MFMAs per 4 outputs, one shared weight fragment) and a
+// 2-tap stride-1 convolution on the odd ones, done with F(4,2) (5 MFMAs per 4 outputs instead of 8):
+// 9 MFMAs per quad and (cin pair, kd, kh) where the direct kernel issues 12.  The 12 floats
+// x[2o-4 .. 2o+7] of a quad come from three 16-byte LDS reads; xe and xo are their even / odd elements.
+template <int KC_>
+struct WinoS2Cfg {
+    static constexpr int KS = 3, KC = KC_, DIL = 1, STRIDE = 2, MI = 1, TD = 4, TH = 4, PIECE = 4;
+    static constexpr int NPOS = 9;                            // 4 even-phase + 5 F(4,2) positions
+    static constexpr int NA = 6;                              // weight fragments per step: g1, U0..U4
+    static constexpr int TW = 32, QUADS = 8, RPB = 4, NB = 1;
+    static constexpr int PAD = 1, LPAD = 4, XOFF = 3;
+    static constexpr int IN_D = 2 * TD + 1, IN_H = 2 * TH + 1, IN_W = 2 * (TW - 1) + 3;
+    static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;   // 68
+    using St = Stager<KC, IN_D, IN_H, IN_WV, 4>;
+    static constexpr int CH = St::CH, TILE = St::TILE;
+    static constexpr int KP = KC / 2;
+    static constexpr int WF = KS * NA * KP * 64;              // packed floats per (chunk, kd): [kh][frag][kp][lane]
+    static constexpr int LDS_BYTES = (TILE + 2 * WF) * 4;
+    static_assert(8 * (QUADS - 1) + 12 <= IN_WV, "three 16-byte reads cover a quad's inputs");
+};
+
+template <class Cfg>
+__device__ __forceinline__ void winos2_compute_phase(const float *__restrict__ img, const float *__restrict__ wl, int bbase,
+                                                     f32x16 (&acc)[9][1]) {
+    constexpr int KP = Cfg::KP, IN_WV = Cfg::IN_WV, CH = Cfg::CH, NA = Cfg::NA;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+            float af[NA];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) af[q] = wl[((kh * NA + q) * KP + kp) * 64];
+            const float *px = img + bbase + kp * 2 * CH + kh * IN_WV;
+            f32x4 t[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t[j] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(px + 4 * j, 16));
+            // element e of the 12 = x[2o - 4 + e]:  xe[o+j] = e 4+2j,  xo[o-1+i] = e 3+2i
+            const float e0 = t[1][0], e1 = t[1][2], e2 = t[2][0], e3 = t[2][2];
+            const float d0 = t[0][3], d1 = t[1][1], d2 = t[1][3], d3 = t[2][1], d4 = t[2][3];
+            // F(4,2) input transform (wino::BT2)
+            const float v0 = __builtin_fmaf(2.0f, d0 - d2, d3 - d1);
+            const float v1 = (d3 - d2) - 2.0f * d1;
+            const float v2 = __builtin_fmaf(2.0f, d1, __builtin_fmaf(-3.0f, d2, d3));
+            const float v3 = d3 - d1;
+            const float v4 = __builtin_fmaf(2.0f, d1 - d3, d4 - d2);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], e0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], e1, acc[1][0], 0, 0, 0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], e2, acc[2][0], 0, 0, 0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], e3, acc[3][0], 0, 0, 0);
+            acc[4][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], v0, acc[4][0], 0, 0, 0);
+            acc[5][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], v1, acc[5][0], 0, 0, 0);
+            acc[6][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], v2, acc[6][0], 0, 0, 0);
+            acc[7][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[4], v3, acc[7][0], 0, 0, 0);
+            acc[8][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[5], v4, acc[8][0], 0, 0, 0);
+        }
+    }
+}
 
 template <class Cfg>
 __device__ __forceinline__ void winok_compute_phase(const float *__restrict__ img, const float *__restrict__ wl, int bbase,
@@ -890,7 +951,14 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            if constexpr (Cfg::KS == 3) {
+            if constexpr (Cfg::STRIDE == 2) {   // even phase (positions 0..3) + A^T of F(4,2) (positions 4..8, wino::AT2)
+                const float m0 = acc[4][nb][r], m1 = acc[5][nb][r], m2 = acc[6][nb][r], m3 = acc[7][nb][r], m4 = acc[8][nb][r];
+                const float s12 = m1 + m2, d12 = m1 - m2;
+                acc[0][nb][r] += (m0 + s12) + m3;
+                acc[1][nb][r] += __builtin_fmaf(2.0f, m3, d12);
+                acc[2][nb][r] += __builtin_fmaf(4.0f, m3, s12);
+                acc[3][nb][r] += __builtin_fmaf(8.0f, m3, d12) + m4;
+            } else if constexpr (Cfg::KS == 3) {
                 const float m0 = acc[0][nb][r], m1 = acc[1][nb][r], m2 = acc[2][nb][r], m3 = acc[3][nb][r],
                             m4 = acc[4][nb][r], m5 = acc[5][nb][r];
                 const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
@@ -1148,8 +1216,10 @@ conv3d_winok_kernel(const ConvArgs a) {
     // B-fragment base: lane&7 = output quad t, (lane&31)>>3 = row of the wave's depth slice, lane>>5 = k;
     // a quad's inputs x[4t-PAD .. 4t+3+PAD] sit at image columns 4t+XOFF .. inside three 16-byte reads at 4t
     // (dilation 2: lanes 2q and 2q+1 are the even / odd parity of the 8 outputs at 8q, both read at 8q)
-    const int bbase = (lane >> 5) * CH + (wave * Cfg::IN_H + ((lane & 31) >> 3)) * Cfg::IN_WV +
-                      (Cfg::DIL == 2 ? 8 * ((lane & 7) >> 1) : 4 * (lane & 7));
+    // (stride 2: output row (wave, r) reads input rows 2*wave + kd, 2*r + kh; a quad's 12 inputs start at 8t)
+    const int bbase = (lane >> 5) * CH +
+                      Cfg::STRIDE * (wave * Cfg::IN_H + ((lane & 31) >> 3)) * Cfg::IN_WV +
+                      (Cfg::DIL == 2 ? 8 * ((lane & 7) >> 1) : 4 * Cfg::STRIDE * (lane & 7));
     float *const wlds = lds + TILE;
     float *const aff = wlds + 2 * WF;
     const int nchunks = a.nchunks_wino, nphase = nchunks * KS;
@@ -1157,7 +1227,8 @@ conv3d_winok_kernel(const ConvArgs a) {
     constexpr int SLICE = Cfg::DIL * Cfg::IN_H * Cfg::IN_WV;     // image floats per kernel depth step
 
     St st;
-    st.init(tid, job.od0 - Cfg::PAD, job.oh0 - Cfg::PAD, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+    st.init(tid, job.od0 * Cfg::STRIDE - Cfg::PAD, job.oh0 * Cfg::STRIDE - Cfg::PAD, job.ow0 * Cfg::STRIDE - Cfg::LPAD,
+            a.Din, a.Hin, a.Win, in_hw, in_dhw);
     constexpr int WITEMS = WF / 4, WNIT = (WITEMS + 255) / 256;
     const int wbase = tid & ~63;
     auto issue_w = [&](int ph, int b) {
@@ -1193,7 +1264,8 @@ conv3d_winok_kernel(const ConvArgs a) {
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         for (int kd = 0; kd < KS; ++kd, ++ph) {
             if (ph + 1 < nphase) issue_w(ph + 1, (ph + 1) & 1);
-            winok_compute_phase<Cfg>(lds + kd * SLICE, wlds + (ph & 1) * WF + lane, bbase, lane, acc);
+            if constexpr (Cfg::STRIDE == 2) winos2_compute_phase<Cfg>(lds + kd * SLICE, wlds + (ph & 1) * WF + lane, bbase, acc);
+            else winok_compute_phase<Cfg>(lds + kd * SLICE, wlds + (ph & 1) * WF + lane, bbase, lane, acc);
             __syncthreads();
         }
         if (chunk + 1 < nchunks) {
@@ -1607,6 +1679,31 @@ __global__ void pack_winok_weights_kernel(const float *__restrict__ w, float *__
     packed[i] = (float)u;
 }
 
+// Stride-2 k3 packing: packed[cg][chunk][kd][kh][frag][kp][half][i], frag 0 = g1 (even phase), frag 1..5 = G2 (g0, g2)
+__global__ void pack_winos2_weights_kernel(const float *__restrict__ w, float *__restrict__ packed, int Cout, int Cin,
+                                           int KC, int nchunks, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int KP = KC / 2;
+    int64_t r = i;
+    const int ii = (int)(r % 32); r /= 32;
+    const int half = (int)(r % 2); r /= 2;
+    const int kp = (int)(r % KP); r /= KP;
+    const int frag = (int)(r % 6); r /= 6;
+    const int kh = (int)(r % 3); r /= 3;
+    const int kd = (int)(r % 3); r /= 3;
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int cg = (int)r;
+    const int co = cg * 32 + ii, ci = chunk * KC + 2 * kp + half;
+    double u = 0.0;
+    if (co < Cout && ci < Cin) {
+        const float *g = w + ((((int64_t)co * Cin + ci) * 3 + kd) * 3 + kh) * 3;
+        if (frag == 0) u = g[1];
+        else u = wino::G2[frag - 1][0] * (double)g[0] + wino::G2[frag - 1][1] * (double)g[2];
+    }
+    packed[i] = (float)u;
+}
+
 // ------------------------------------------------------------------------------------ dispatch
 struct Plan {
     int MI, KC, TD, TH;  // tile choice
@@ -1648,6 +1745,7 @@ using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;
 using CfgWinoN  = WinoCfg<4, 4, 2, 4, 32>;   // 32-wide tile (4 rows x 8 quads per MFMA column block): narrow layers
 using CfgWinoN8 = WinoCfg<4, 4, 2, 2, 32>;       // the same for rows that are only 8-byte aligned (W % 4 == 2)
+using CfgWinoS2 = WinoS2Cfg<2>;
 using CfgWinoK5 = WinoKCfg<5, 2>;
 using CfgWinoK7 = WinoKCfg<7, 2>;
 using CfgWinoK5D2 = WinoKCfg<5, 2, 2>;
@@ -1734,6 +1832,8 @@ void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
 }
 
 inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
+    if (!d.transposed && d.stride == 2 && d.ksize == 3 && d.dilation == 1)
+        return (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, 2) * 3 * CfgWinoS2::WF;
     if (d.transposed || d.stride != 1 || !(d.dilation == 1 || (d.dilation == 2 && d.ksize == 5))) return 0;
     const int64_t gc = (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, 2);     // groups x chunks (KC = 2 everywhere)
     if (d.ksize == 3) return gc * CfgWino::WF;
@@ -1858,7 +1958,9 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
         total -= wino;
         const unsigned wb = (unsigned)ceil_div<int64_t>(wino, 256);
         const int nck = ceil_div(d->Cin, 2);
-        if (d->ksize == 3)
+        if (d->ksize == 3 && d->stride == 2)
+            pack_winos2_weights_kernel<<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino);
+        else if (d->ksize == 3)
             pack_wino_weights_kernel<<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino);
         else if (d->ksize == 5)
             pack_winok_weights_kernel<5><<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino);
@@ -1949,6 +2051,23 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
             pointwise_small_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
         return check_launch("snvc_conv3d_forward(pointwise)");
     }
+    // k3 / stride 2: polyphase + F(4,2) along W (LDS-DMA staged: 16-byte rows only)
+    if (!d->transposed && d->ksize == 3 && d->stride == 2 && d->dilation == 1 && a.vec && a.fast_epi && !depth_planes &&
+        d->algo != SNVC_ALGO_DIRECT) {
+        const char *nw = getenv("SNVC_NO_WINOGRAD");
+        if (!(nw && nw[0] == '1')) {
+            a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
+            a.nchunks_wino = ceil_div(d->Cin, 2);
+            a.groups = ceil_div(d->Cout, 32);
+            a.tiles_d = ceil_div(d->Dout, 4); a.tiles_h = ceil_div(d->Hout, 4); a.tiles_w = ceil_div(d->Wout, 32);
+            const int64_t nj = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w * a.groups * d->N;
+            if (nj < ((int64_t)1 << 31)) {
+                a.njobs = (int)nj;
+                launch_winok<CfgWinoS2>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                return check_launch("snvc_conv3d_forward(winograd stride 2)");
+            }
+        }
+    }
     // k5 / k7, stride 1, no dilation: Winograd F(4,KS) along W (LDS-DMA staged: 16-byte rows only)
     if (!d->transposed && (d->ksize == 5 || d->ksize == 7) && d->stride == 1 &&
         (d->dilation == 1 || (d->dilation == 2 && d->ksize == 5)) && a.vec && a.fast_epi && !depth_planes) {
@@ -1971,7 +2090,7 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
     }
     // k3 / stride 1: Winograd F(4,3) along W when the rows allow 8-byte pair stores and 16-byte staging
     {
-        const int64_t wino = d->ksize == 3 ? wino_packed_count(*d) : 0;
+        const int64_t wino = (d->ksize == 3 && d->stride == 1 && !d->transposed) ? wino_packed_count(*d) : 0;
         const char *nw = getenv("SNVC_NO_WINOGRAD");   // development knob: force the direct kernel
         const bool pair_ok = (d->Wout % 2 == 0) && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
                              ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
