@@ -288,6 +288,29 @@ def test_k5_k7_winograd_vs_torch(k, dil, W):
             check(y.cpu().numpy(), ref.numpy(), TIGHT, f"k{k} d{dil} W={W} direct kernel")
 
 
+@pytest.mark.parametrize("W", [40, 72, 44])
+def test_k3_stride2_winograd_vs_torch(W, monkeypatch):
+    """Stride-2 3x3x3 layers: the polyphase + F(4,2) kernel (output width % 4 == 0) and the direct kernel
+    (everything else, and desc.algo = SNVC_ALGO_DIRECT) against torch, batch 2, two channel groups, ragged tiles."""
+    import torch.nn.functional as F
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(70 + W)
+    for cin, cout, shape in ((32, 64, (10, 6, W)), (7, 32, (4, 8, W))):
+        m = seeded(S.convbn_3d(cin, cout, 3, 2, 1), 80 + cin)
+        x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32))
+        with torch.no_grad():
+            ref = F.batch_norm(F.conv3d(x, m[0].weight, None, 2, 1), m[1].running_mean, m[1].running_var,
+                               m[1].weight, m[1].bias, False, 0.0, m[1].eps)
+            res = torch.from_numpy(r.standard_normal(tuple(ref.shape)).astype(np.float32))
+            m = m.to(dev())
+            check(m(x.to(dev())).cpu().numpy(), ref.numpy(), TIGHT, f"s2 W={W} conv+bn")
+            y = m.fused(x.to(dev()), relu=True, residual=res.to(dev()))
+            check(y.cpu().numpy(), F.relu(ref + res).numpy(), TIGHT, f"s2 W={W} relu(conv+res)")
+            monkeypatch.setenv("SNVC_NO_WINOGRAD", "1")
+            check(m(x.to(dev())).cpu().numpy(), ref.numpy(), TIGHT, f"s2 W={W} direct")
+            monkeypatch.delenv("SNVC_NO_WINOGRAD")
+
+
 def test_conv3d_epilogue_variants_and_slices():
     """relu / sigmoid / residual-before / residual-after, batch > 1, channel-sliced in/out,
     Cout not a multiple of 32 (27 and 1), Cin not a multiple of the staging chunk."""
