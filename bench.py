@@ -207,7 +207,7 @@ def main():
                 "step_cost_volume_mb_algorithmic": STEP_BYTES / 1e6,
             },
             "roofline": {
-                "kernel": "conv3d_wino_dma_kernel<4x4x64 tile, KC2, planes>: first conv over the right half of the volume, "
+                "kernel": "conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, planes>: first conv over the right half of the volume, "
                           "32->32 on 192x96x312, + depth-class planes (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)",
                 "bound": "mfma",
                 "achieved": achieved,

@@ -610,8 +610,9 @@ conv3d_mfma_kernel(const ConvArgs a) {
 // stages and V is formed in registers right after the fragment reads (one 16-byte and two 4-byte LDS
 // reads + 12 VALU ops per 6 MFMAs).  The 32 MFMA columns are 2 rows x 16 tiles of 4 outputs: a lane
 // owns 4 consecutive outputs, so the epilogue stores 16 bytes per lane and channel.
-template <int TD_, int TH_, int KC_, int PIECE_ = 4, int TW_ = 64>
+template <int TD_, int TH_, int KC_, int PIECE_ = 4, int TW_ = 64, int OCC_ = 2>
 struct WinoCfg {
+    static constexpr int OCC = OCC_;   // workgroups per CU the register allocator is asked to allow
     static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1, PIECE = PIECE_;
     static constexpr int KS = 3, NPOS = 6, STRIDE = 1;
     // The 32 MFMA columns are RPB rows x (TW/4) quads: 2 rows x 64 outputs, or 4 rows x 32 outputs for
@@ -1129,7 +1130,7 @@ conv3d_wino_kernel(const ConvArgs a) {
 __device__ const float g_zero16[4] __attribute__((aligned(16))) = {0.0f, 0.0f, 0.0f, 0.0f};
 
 template <class Cfg, bool RES, bool PLANE>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_wino_dma_kernel(const ConvArgs a) {
     constexpr int TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB, CH = Cfg::CH, TILE = Cfg::TILE, WF = Cfg::WF;
     using St = typename Cfg::St;
@@ -1744,7 +1745,8 @@ using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64
 using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per wave: large layers
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;
 using CfgWinoN  = WinoCfg<4, 4, 2, 4, 32>;   // 32-wide tile (4 rows x 8 quads per MFMA column block): narrow layers
-using CfgWinoN8 = WinoCfg<4, 4, 2, 2, 32>;       // the same for rows that are only 8-byte aligned (W % 4 == 2)
+using CfgWinoN8 = WinoCfg<4, 4, 2, 2, 32>;
+using CfgWinoN3 = WinoCfg<4, 4, 2, 4, 32, 3>;   // the 32-wide tile LDS-DMA staged: <= 168 VGPRs, 3 workgroups per CU       // the same for rows that are only 8-byte aligned (W % 4 == 2)
 using CfgWinoS2 = WinoS2Cfg<2>;
 using CfgWinoK5 = WinoKCfg<5, 2>;
 using CfgWinoK7 = WinoKCfg<7, 2>;
@@ -2100,17 +2102,14 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, CfgWino::KC);
             a.groups = ceil_div(d->Cout, 32);
-            // tile choice: 32-wide when 64-wide tiles would be badly filled (W = 156: 81 % vs 97 %); among the
-            // 64-wide ones the LDS-DMA kernel with the 4x4x64 tile (two row blocks per wave) once a layer has
-            // enough jobs to keep the tail of the launch short, else the 2x4x64 register-staged one
-            const double fill64 = (double)d->Wout / (ceil_div(d->Wout, 64) * 64);
-            const double fill32 = (double)d->Wout / (ceil_div(d->Wout, 32) * 32);
-            const char *tv = getenv("SNVC_WINO_TILE");   // development knob: "big", "std", "narrow"
-            bool narrow = fill32 > 1.1 * fill64;
-            const int64_t nj_big = (int64_t)ceil_div(d->Dout, CfgWinoBig::TD) * ceil_div(d->Hout, CfgWinoBig::TH) *
-                                   ceil_div(d->Wout, 64) * a.groups * d->N;
-            bool big = !narrow && wide && nj_big >= 8 * 2 * (int64_t)device_cu_count();
-            if (tv) { narrow = tv[0] == 'n'; big = tv[0] == 'b' && wide; }
+            // tile choice.  Default: the 4x4x32 tile, LDS-DMA staged (137 VGPRs, 51 KB LDS: three workgroups per
+            // CU), or its register-staged 8-byte-row form when the rows are not 16-byte aligned.  Measured on cfg2:
+            // conv1 2.70 ms / conv2 1.40 ms / hg conv2 0.73 ms, against 2.82 / 1.45 / 0.89 for the 4x4x64 LDS-DMA
+            // tile ("big") and 2.93 / 1.52 / 0.91 for the 2x4x64 register-staged one ("std").  SNVC_WINO_TILE
+            // selects the other forms (development knob; the parity tests run all of them).
+            const char *tv = getenv("SNVC_WINO_TILE");   // "big", "std", "narrow" (register-staged 4x4x32)
+            const bool big = tv && tv[0] == 'b' && wide, stdt = tv && tv[0] == 's', nreg = tv && tv[0] == 'n';
+            const bool narrow = !big && !stdt;
             const int TDc = (big || narrow) ? 4 : 2, THc = 4, TWc = narrow ? 32 : 64;
             a.tiles_d = ceil_div(d->Dout, TDc);
             a.tiles_h = ceil_div(d->Hout, THc);
@@ -2120,6 +2119,7 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
                 a.njobs = (int)nj;
                 const dim3 g((unsigned)nj, 1, 1);
                 if (big) launch_wino_dma<CfgWinoBig>(a, g, as_stream(stream));
+                else if (narrow && wide && !nreg) launch_wino_dma<CfgWinoN3>(a, g, as_stream(stream));
                 else if (narrow && wide) launch_wino<CfgWinoN>(a, g, as_stream(stream));
                 else if (narrow) launch_wino<CfgWinoN8>(a, g, as_stream(stream));
                 else if (wide) launch_wino<CfgWino>(a, g, as_stream(stream));
