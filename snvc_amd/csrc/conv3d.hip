@@ -835,9 +835,10 @@ struct WinoKCfg {
 // 2-tap stride-1 convolution on the odd ones, done with F(4,2) (5 MFMAs per 4 outputs instead of 8):
 // 9 MFMAs per quad and (cin pair, kd, kh) where the direct kernel issues 12.  The 12 floats
 // x[2o-4 .. 2o+7] of a quad come from three 16-byte LDS reads; xe and xo are their even / odd elements.
-template <int KC_>
+template <int KC_, int STORE_PIECE_ = 4>
 struct WinoS2Cfg {
     static constexpr int KS = 3, KC = KC_, DIL = 1, STRIDE = 2, MI = 1, TD = 4, TH = 4, PIECE = 4;
+    static constexpr int STORE_PIECE = STORE_PIECE_;
     static constexpr int NPOS = 9;                            // 4 even-phase + 5 F(4,2) positions
     static constexpr int NA = 6;                              // weight fragments per step: g1, U0..U4
     static constexpr int TW = 32, QUADS = 8, RPB = 4, NB = 1;
@@ -924,6 +925,12 @@ __device__ __forceinline__ void winok_compute_phase(const float *__restrict__ im
     }
 }
 
+// Width of the epilogue's loads / stores in floats: a configuration may stage 16-byte pieces (input rows) and
+// still store 8-byte halves (output rows with W % 4 == 2), e.g. the stride-2 layer 156 -> 78.
+template <class Cfg, class = void> struct EpiloguePiece { static constexpr int value = Cfg::PIECE; };
+template <class Cfg> struct EpiloguePiece<Cfg, decltype((void)Cfg::STORE_PIECE)> { static constexpr int value = Cfg::STORE_PIECE; };
+template <class Cfg> constexpr int epilogue_piece() { return EpiloguePiece<Cfg>::value; }
+
 // Epilogue of one job (fast-epilogue toolkit above): output transform in place (y0..y3 -> acc[0..3],
 // a third of the accumulator registers become free), per-channel scale and bias through LDS (parked
 // at kernel start; lgkmcnt), every vector load (residual or depth-class planes) before the first
@@ -933,7 +940,7 @@ template <class Cfg, bool RES, bool PLANE>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[Cfg::NPOS][Cfg::NB],
                                               const float *__restrict__ aff, int lane, int wave) {
     constexpr int NB = Cfg::NB, TH = Cfg::TH;
-    constexpr bool V4 = Cfg::PIECE == 4;           // 16-byte loads / stores (Wout % 4 == 0); else 8-byte halves
+    constexpr bool V4 = epilogue_piece<Cfg>() == 4;   // 16-byte loads / stores (Wout % 4 == 0); else 8-byte halves
     const int ow = job.ow0 + 4 * (lane & (Cfg::QUADS - 1)), rowsel = (lane & 31) / Cfg::QUADS;
     const int out_hw = a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
     const int cbase = __builtin_amdgcn_readfirstlane(job.cg * 32);
@@ -1748,6 +1755,7 @@ using CfgWinoN  = WinoCfg<4, 4, 2, 4, 32>;   // 32-wide tile (4 rows x 8 quads p
 using CfgWinoN8 = WinoCfg<4, 4, 2, 2, 32>;
 using CfgWinoN3 = WinoCfg<4, 4, 2, 4, 32, 3>;   // the 32-wide tile LDS-DMA staged: <= 168 VGPRs, 3 workgroups per CU       // the same for rows that are only 8-byte aligned (W % 4 == 2)
 using CfgWinoS2 = WinoS2Cfg<2>;
+using CfgWinoS2v8 = WinoS2Cfg<2, 2>;   // output rows only 8-byte aligned
 using CfgWinoK5 = WinoKCfg<5, 2>;
 using CfgWinoK7 = WinoKCfg<7, 2>;
 using CfgWinoK5D2 = WinoKCfg<5, 2, 2>;
@@ -2053,11 +2061,13 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
             pointwise_small_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
         return check_launch("snvc_conv3d_forward(pointwise)");
     }
-    // k3 / stride 2: polyphase + F(4,2) along W (LDS-DMA staged: 16-byte rows only)
-    if (!d->transposed && d->ksize == 3 && d->stride == 2 && d->dilation == 1 && a.vec && a.fast_epi && !depth_planes &&
-        d->algo != SNVC_ALGO_DIRECT) {
+    // k3 / stride 2: polyphase + F(4,2) along W (LDS-DMA staged: 16-byte INPUT rows; output rows may be 8-byte ones)
+    {
+        const bool out8 = fast_common && (d->Wout % 2 == 0) && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
+                          ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res)) & 7) == 0;
         const char *nw = getenv("SNVC_NO_WINOGRAD");
-        if (!(nw && nw[0] == '1')) {
+        if (!d->transposed && d->ksize == 3 && d->stride == 2 && d->dilation == 1 && a.vec && (a.fast_epi || out8) &&
+            !depth_planes && d->algo != SNVC_ALGO_DIRECT && !(nw && nw[0] == '1')) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, 2);
             a.groups = ceil_div(d->Cout, 32);
@@ -2065,7 +2075,8 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
             const int64_t nj = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w * a.groups * d->N;
             if (nj < ((int64_t)1 << 31)) {
                 a.njobs = (int)nj;
-                launch_winok<CfgWinoS2>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                if (a.fast_epi) launch_winok<CfgWinoS2>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                else launch_winok<CfgWinoS2v8>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 return check_launch("snvc_conv3d_forward(winograd stride 2)");
             }
         }
