@@ -15,10 +15,11 @@ data-path collective): weak scaling.
 
 One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel, the first 3x3x3
 convolution (factored: 32->32 over the warped half of the volume, 318 GFLOP per launch; Winograd
-F(4,3) along W on the fp32 MFMA pipe), timed with
-events on the launch stream inside the timed loop; `materialized` repeats the measurement with the
-full concat volume built and convolved (64->32, 636 GFLOP).  `cpu_baseline` times the CPU oracle (C cost volume + torch-CPU stack) on a bounded
-sample on rank 0 at N=1.
+F(4,3) along W on the fp32 MFMA pipe), timed with events on the launch stream inside the timed
+loop: `achieved` prices the algorithmic FLOPs, `mfma_pipe_frac` the executed ones.  `materialized`
+repeats the measurement with the full concat volume built and convolved (64->32, 636 GFLOP).
+`cpu_baseline` times the CPU oracle (C cost volume + torch-CPU stack) on a bounded sample on rank 0
+at N=1.
 """
 import argparse
 import json
