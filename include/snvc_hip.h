@@ -217,6 +217,16 @@ SNVC_API int snvc_affine_act(const float *x, const float *scale, const float *sh
  *                    snvc_act_backward_apply writes draw = coef_g*g + coef_raw*raw + coef_const
  *                    (per channel, or per (n, c) when per_sample) and optionally g itself.
  * ---------------------------------------------------------------------------------- */
+/* Transposed layer + fused 1x1x1 head: y_head[n,0,:] = sum_c head_weight[c] * epilogue(conv(x, w))[n,c,:]; the
+ * Cout-channel tensor itself is never written.  This is the tail of the global model
+ * (stereo_volume.py: `v + hourglass(v)[0]` -> classifier Conv3d(C,1,1), the composition of vernier.py:366-371)
+ * when the layer's output has no other consumer.  Needs desc.transposed, Cout == 32, an even input width, no
+ * Sigmoid, a 16-byte aligned residual; returns SNVC_ERR_UNSUPPORTED otherwise (the caller then runs the two
+ * layers separately). */
+SNVC_API int snvc_conv3d_forward_head(const snvc_conv3d_desc *desc_host, const float *x,
+                                      const float *packed_weight, const float *scale, const float *bias,
+                                      const float *residual, const float *head_weight, float *y_head,
+                                      void *stream);
 SNVC_API int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *desc_host);
 SNVC_API int snvc_conv3d_wgrad(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
                                void *workspace, void *stream);

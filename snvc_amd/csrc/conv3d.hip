@@ -56,6 +56,8 @@ struct ConvArgs {
     int Cout, Dout, Hout, Wout;
     int tiles_d, tiles_h, tiles_w;
     int nchunks, flags;
+    const float *head_w; // fused 1x1x1 head (snvc_conv3d_forward_head): [Cout] weights, or nullptr
+    float *y_head;       //   its [N,1,Dout,Hout,Wout] output; `y` is then not written
     int fast_epi;        // the launch qualifies for the fast epilogues (see the toolkit comment)
     int njobs, groups;   // Winograd kernel: jobs = tiles x channel groups x samples
     int vec;  // 1: 16-byte aligned rows (Win % 4 == 0, aligned base and strides) -> float4 staging
@@ -1347,7 +1349,11 @@ __device__ __forceinline__ void deconv_compute_chunk(const float *__restrict__ b
 
 // Fast epilogue of one parity class (toolkit comment above): lane holds the output pair
 // (2*iw, 2*iw+1) of row (2*id+PD, 2*ih+PH) for 16 channels.
-template <class Cfg, int PD, int PH, bool RES>
+// HEAD: the layer's output feeds a 1x1x1 convolution to ONE channel and nothing else (the global model's
+// classifier after the hourglass, stereo_volume.py): the 32-channel dot product is formed here -- 16 channels
+// per lane, the other 16 in lane ^ 32 -- and only the single-channel result is stored (1/32 of the bytes; the
+// full-resolution tensor and the classifier's pass over it disappear).
+template <class Cfg, int PD, int PH, bool RES, bool HEAD = false>
 __device__ __forceinline__ void deconv_epilogue_fast(const ConvArgs &a, f32x16 (&acc)[2][Cfg::NB][Cfg::MI], int id0,
                                                      int ih0, int iw0, int cg, int64_t n, int lane, int wave) {
     constexpr int MI = Cfg::MI, TH = Cfg::TH, NB = Cfg::NB;
@@ -1395,16 +1401,40 @@ __device__ __forceinline__ void deconv_epilogue_fast(const ConvArgs &a, f32x16 (
                     asm volatile("" : "+v"(acc[0][nb][m][r0 + q]), "+v"(acc[1][nb][m][r0 + q])::"memory");
             }
     }
+    if constexpr (HEAD) {
+        static_assert(MI == 1, "the fused head covers one 32-channel group");
+        float hw[16];
 #pragma unroll
-    for (int m = 0; m < MI; ++m) {
-        const int cbase = __builtin_amdgcn_readfirstlane((cg * MI + m) * 32);
-        char *const yb = reinterpret_cast<char *>(a.y + n * a.y_bs) + cbase * cs;
+        for (int r = 0; r < 16; ++r) hw[r] = a.head_w[(r & 3) + 8 * (r >> 2) + 4 * half];
+        float *const yh = a.y_head + n * (int64_t)out_dhw;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) store_pairs_x4(yb, cs, voff[nb], ok[nb], acc[0][nb][m], acc[1][nb][m], lane);
+        for (int nb = 0; nb < NB; ++nb) {
+            float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                d0 = __builtin_fmaf(hw[r], acc[0][nb][0][r], d0);
+                d1 = __builtin_fmaf(hw[r], acc[1][nb][0][r], d1);
+            }
+            d0 += __shfl_xor(d0, 32);
+            d1 += __shfl_xor(d1, 32);
+            const int row = wave * NB + nb;
+            const int id = id0 + row / TH, ih = ih0 + row % TH;
+            if (ok[nb] && half == 0)
+                *reinterpret_cast<float2 *>(yh + (int64_t)(2 * id + PD) * out_hw + (2 * ih + PH) * a.Wout + 2 * iw) =
+                    make_float2(d0, d1);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+            const int cbase = __builtin_amdgcn_readfirstlane((cg * MI + m) * 32);
+            char *const yb = reinterpret_cast<char *>(a.y + n * a.y_bs) + cbase * cs;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) store_pairs_x4(yb, cs, voff[nb], ok[nb], acc[0][nb][m], acc[1][nb][m], lane);
+        }
     }
 }
 
-template <class Cfg, int EPI, int PD, int PH>   // EPI: 0 generic epilogue, 1 fast, 2 fast with residual
+template <class Cfg, int EPI, int PD, int PH>   // EPI: 0 generic epilogue, 1 fast, 2 fast with residual, 3 / 4 = 1 / 2 + fused head
 __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds, int tile, int cg, int64_t n) {
     constexpr int MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, KP = Cfg::KP, NB = Cfg::NB;
     constexpr int CH = Cfg::CH, TILE = Cfg::TILE;
@@ -1472,7 +1502,10 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
     }
 
     if constexpr (EPI != 0) {
-        deconv_epilogue_fast<Cfg, PD, PH, EPI == 2>(a, acc, id0, ih0, iw0, cg, n, lane, wave);
+        if constexpr (EPI >= 3 && Cfg::MI == 1)
+            deconv_epilogue_fast<Cfg, PD, PH, EPI == 4, true>(a, acc, id0, ih0, iw0, cg, n, lane, wave);
+        else
+            deconv_epilogue_fast<Cfg, PD, PH, EPI == 2>(a, acc, id0, ih0, iw0, cg, n, lane, wave);
     } else {
     // generic epilogue: outputs (2*id + PD, 2*ih + PH, 2*iw + {0,1}) -> one 8-byte store per lane
     const int iw = iw0 + (lane & 31);
@@ -1924,7 +1957,12 @@ void launch_deconv_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
 template <class Cfg>
 void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
     // the pair exchange of the fast epilogue needs an even input width (both lanes of a pair in range)
-    if (a.fast_epi && a.Win % 2 == 0) {
+    if (a.head_w) {   // validated by snvc_conv3d_forward_head: fast epilogue conditions hold, one channel group
+        if constexpr (Cfg::MI == 1) {
+            if (a.res) launch_deconv_variant<Cfg, 4>(a, grid, st);
+            else launch_deconv_variant<Cfg, 3>(a, grid, st);
+        }
+    } else if (a.fast_epi && a.Win % 2 == 0) {
         if (a.res) launch_deconv_variant<Cfg, 2>(a, grid, st);
         else launch_deconv_variant<Cfg, 1>(a, grid, st);
     } else {
@@ -1934,6 +1972,12 @@ void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
 
 }  // namespace
 }  // namespace snvc
+
+namespace snvc {
+int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *packed_weight, const float *scale,
+                        const float *bias, const float *residual, const float *depth_planes, float *y,
+                        const float *head_w, float *y_head, void *stream);
+}
 
 extern "C" {
 
@@ -1999,13 +2043,36 @@ int snvc_conv3d_forward(const snvc_conv3d_desc *d, const float *x, const float *
 int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const float *packed_weight,
                            const float *scale, const float *bias, const float *residual,
                            const float *depth_planes, float *y, void *stream) {
+    return snvc::conv3d_forward_impl(d, x, packed_weight, scale, bias, residual, depth_planes, y, nullptr, nullptr, stream);
+}
+
+int snvc_conv3d_forward_head(const snvc_conv3d_desc *d, const float *x, const float *packed_weight,
+                             const float *scale, const float *bias, const float *residual,
+                             const float *head_weight, float *y_head, void *stream) {
     using namespace snvc;
+    if (!d || !head_weight || !y_head) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward_head: null pointer");
+    if (!d->transposed || d->Cout != 32 || d->Win % 2 != 0 || (d->flags & SNVC_EPI_SIGMOID) ||
+        (int64_t)d->Dout * d->Hout * d->Wout >= ((int64_t)1 << 27) || (reinterpret_cast<uintptr_t>(y_head) & 7) ||
+        (reinterpret_cast<uintptr_t>(residual) & 15) || (d->res_batch_stride % 4) != 0)
+        return fail(SNVC_ERR_UNSUPPORTED,
+                    "snvc_conv3d_forward_head: needs a transposed layer with 32 output channels, an even input width, "
+                    "no Sigmoid, a 16-byte aligned residual and an 8-byte aligned head output");
+    return conv3d_forward_impl(d, x, packed_weight, scale, bias, residual, nullptr, nullptr, head_weight, y_head, stream);
+}
+
+}  // extern "C"
+
+namespace snvc {
+
+int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *packed_weight, const float *scale,
+                        const float *bias, const float *residual, const float *depth_planes, float *y,
+                        const float *head_w, float *y_head, void *stream) {
     Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: null desc");
     int rc = make_plan(*d, p);
     if (rc) return rc;
     if (d->N == 0) return SNVC_OK;
-    if (!x || !packed_weight || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: null pointer");
+    if (!x || !packed_weight || (!y && !head_w)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: null pointer");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: scale and bias must both be given or both be NULL");
     if ((d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) && !residual)
@@ -2024,6 +2091,8 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
     a.x = x; a.wp = packed_weight; a.scale = scale; a.bias = bias;
     a.res = (d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) ? residual : nullptr;
     a.plane = depth_planes;
+    a.head_w = head_w; a.y_head = y_head;
+    if (head_w && p.kind != DC_M1) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_head: layer is not a single-group transposed convolution");
     a.wp_wino = nullptr; a.nchunks_wino = 0;
     a.y = y;
     a.Cin = d->Cin; a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
@@ -2174,4 +2243,4 @@ int snvc_conv3d_forward_ex(const snvc_conv3d_desc *d, const float *x, const floa
     return check_launch("snvc_conv3d_forward");
 }
 
-}  // extern "C"
+}  // namespace snvc

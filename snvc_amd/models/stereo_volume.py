@@ -35,10 +35,14 @@ class GlobalStack(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    def _tail(self, v):
+        """v + hourglass(v)[0] -> classifier.  The residual add and (inference) the 1x1x1 classifier are folded
+        into the hourglass's last transposed convolution: the full-resolution C-channel tensor is never written."""
+        cost, _, _ = self.hg_conv3d(v, None, None, residual=v, head=self.classifier)
+        return cost
+
     def forward(self, volume):
-        v = self.conv2(self.conv1(volume))
-        v, _, _ = self.hg_conv3d(v, None, None, residual=v)   # v + hourglass(v)[0], add fused in the epilogue
-        return self.classifier(v)
+        return self._tail(self.conv2(self.conv1(volume)))
 
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
@@ -65,9 +69,7 @@ class GlobalStack(nn.Module):
             v = self.conv1(vol)
             timing[1].record()
             del vol
-            v = self.conv2(v)
-            v, _, _ = self.hg_conv3d(v, None, None, residual=v)
-            return self.classifier(v)
+            return self._tail(self.conv2(v))
         assert torch.all(shift >= 0.)            # same contract as build_cost_volume (reference __init__.py:12)
         c = left.size(1)
         w = conv.weight
@@ -87,6 +89,4 @@ class GlobalStack(nn.Module):
         if timing is not None:
             timing[1].record()
         del vol_r
-        v = self.conv2(v)
-        v, _, _ = self.hg_conv3d(v, None, None, residual=v)
-        return self.classifier(v)
+        return self._tail(self.conv2(v))

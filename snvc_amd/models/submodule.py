@@ -249,7 +249,7 @@ class _ConvNormActFn(torch.autograd.Function):
 
 def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,
                  residual: Optional[torch.Tensor] = None, residual_after_act=False, out=None,
-                 plan: Optional[_Plan] = None) -> torch.Tensor:
+                 plan: Optional[_Plan] = None, head: Optional[nn.Module] = None) -> torch.Tensor:
     """act(norm(conv(x)) [+ residual]) [+ residual] on the HIP kernels.
 
     ``residual_after_act=False``: relu(norm(conv(x)) + residual)   (hourglass skips, submodule.py:154,162)
@@ -257,6 +257,11 @@ def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *,
 
     Under autograd (training, BASELINE.json configs[3]) the layer is a differentiable
     ``torch.autograd.Function`` whose backward also runs on the HIP kernels.
+
+    ``head``: a bias-free ``Conv3d(C, 1, kernel_size=1)`` applied to the result (extension).  When the layer is a
+    transposed convolution with 32 output channels and frozen statistics, the projection happens inside the
+    layer's epilogue and the C-channel tensor is never written (``snvc_conv3d_forward_head``); otherwise the two
+    layers run one after the other.  Returns ``head(result)``.
     """
     if plan is None:  # one plan per device (replicas made by nn.DataParallel share __dict__ entries)
         plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(x.device, _Plan())
@@ -273,8 +278,18 @@ def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *,
         beta = norm.bias if norm is not None else None
         if out is not None:
             raise NotImplementedError("`out=` (in-place concat slices) is an inference-only fusion")
-        return _ConvNormActFn.apply(x, conv.weight, gamma, beta, residual, conv, norm, flags, plan)
+        y = _ConvNormActFn.apply(x, conv.weight, gamma, beta, residual, conv, norm, flags, plan)
+        return head(y) if head is not None else y
     layer = _get_layer(conv, plan)
+    if head is not None:
+        if (out is None and not torch.is_grad_enabled() and head.weight.shape[0] == 1 and head.bias is None
+                and tuple(head.weight.shape[2:]) == (1, 1, 1)
+                and (norm is None or (isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None)))):
+            scale, bias = _folded_bn(norm, plan) if norm is not None else (None, None)
+            y = ops.conv3d_forward_head(layer, x, scale, bias, residual, flags, head.weight)
+            if y is not None:
+                return y
+        return head(_norm_forward(layer, norm, plan, x, residual, flags, out, False)[0])
     return _norm_forward(layer, norm, plan, x, residual, flags, out, False)[0]
 
 
@@ -346,14 +361,16 @@ class hourglass(nn.Module):
         self.conv5 = _deconvbn_3d(c * 2, c * 2, gn)
         self.conv6 = _deconvbn_3d(c * 2, c, gn)
 
-    def forward(self, x, presqu, postsqu, residual=None, out=None):
+    def forward(self, x, presqu, postsqu, residual=None, out=None, head=None):
         """Returns (out, pre, post).  ``residual``/``out`` (extension): fold the caller's
-        ``x + hourglass(x)[0]`` (vernier.py:370,421) into the last deconvolution's epilogue."""
+        ``x + hourglass(x)[0]`` (vernier.py:370,421) into the last deconvolution's epilogue.
+        ``head`` (extension): a 1x1x1 one-channel convolution applied to ``out`` inside that epilogue
+        (see fused_conv3d); ``out`` is then ``head(out)``."""
         o = self.conv1(x)                                                   # 1/2 res, ReLU fused
         pre = self.conv2.fused(o, relu=True, residual=postsqu)              # relu(bn(conv) [+ postsqu]) :153-156
         o = self.conv4(self.conv3(pre))                                     # 1/4 res
         post = self.conv5.fused(o, relu=True, residual=presqu if presqu is not None else pre)  # :161-164
-        o = self.conv6.fused(post, residual=residual, out=out)              # :166
+        o = self.conv6.fused(post, residual=residual, out=out, head=head)   # :166
         return o, pre, post
 
 

@@ -261,6 +261,34 @@ class Conv3dLayer:
         return out
 
 
+def conv3d_forward_head(layer: "Conv3dLayer", x, scale, bias, residual, flags, head_weight) -> Optional[torch.Tensor]:
+    """epilogue(deconv(x)) projected to one channel by ``head_weight`` [Cout] inside the layer's epilogue
+    (snvc_conv3d_forward_head); returns [N,1,D,H,W], or None when the layer does not qualify."""
+    if not layer.transposed or layer.cout != 32 or x.size(4) % 2 != 0:
+        return None
+    _gpu(x, "x")
+    if not _dense_inner(x):
+        x = x.contiguous()
+    n = x.size(0)
+    in_sp = tuple(x.shape[2:])
+    out_sp = layer.out_spatial(in_sp)
+    if residual is not None and (tuple(residual.shape) != (n, layer.cout) + out_sp or not _dense_inner(residual)
+                                 or residual.data_ptr() % 16 or _batch_stride(residual) % 4):
+        return None
+    out = torch.empty((n, 1) + out_sp, dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out
+    d = layer._desc(n, in_sp, flags, _batch_stride(x), 0, _batch_stride(residual) if residual is not None else 0)
+    hw = head_weight.detach().reshape(-1).contiguous()
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().snvc_conv3d_forward_head(ctypes.byref(d), _ptr(x), _ptr(layer.packed), _ptr(scale), _ptr(bias),
+                                                 _ptr(residual), _ptr(hw), _ptr(out), _stream(x))
+    if rc == 2:        # SNVC_ERR_UNSUPPORTED: run the two layers separately
+        return None
+    check(rc, "snvc_conv3d_forward_head")
+    return out
+
+
 def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: int) -> torch.Tensor:
     """dW[cg][cx][k^3] = sum over batch and voxels of g_small[cg] * x_big[cx] (shifted by the tap):
     weight gradient of Conv3d(x_big -> g_small's shape); see snvc_conv3d_wgrad for the

@@ -389,6 +389,42 @@ def test_deconv_vs_torch():
             check(y.cpu().numpy(), F.relu(ref + res).numpy(), TIGHT, "relu(deconv+res)")
 
 
+def test_deconv_fused_head_vs_separate_layers():
+    """snvc_conv3d_forward_head: bn(deconv(x)) + residual projected to one channel inside the epilogue
+    equals the two layers run one after the other (torch reference), and the fused path is really taken."""
+    import torch.nn.functional as F
+    from snvc_amd import ops
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(91)
+    m = seeded(S._deconvbn_3d(64, 32, gn=False), 92)
+    head = S.HipConv3d(32, 1, kernel_size=1, padding=0, stride=1, bias=False)
+    head.weight.data.copy_(torch.from_numpy(r.standard_normal((1, 32, 1, 1, 1)).astype(np.float32)))
+    hw_cpu = head.weight.detach().clone()
+    wt_cpu, bn_cpu = m[0].weight.detach().clone(), [t.detach().clone() for t in (m[1].running_mean, m[1].running_var, m[1].weight, m[1].bias)]
+    for shape in ((3, 5, 34), (4, 4, 8)):
+        x = torch.from_numpy(r.standard_normal((2, 64) + shape).astype(np.float32))
+        with torch.no_grad():
+            y = F.batch_norm(F.conv_transpose3d(x, wt_cpu, None, 2, 1, 1), bn_cpu[0], bn_cpu[1], bn_cpu[2], bn_cpu[3],
+                             False, 0.0, m[1].eps)
+            res = torch.from_numpy(r.standard_normal(tuple(y.shape)).astype(np.float32))
+            ref = F.conv3d(y + res, hw_cpu)
+            md, hd = m.to(dev()), head.to(dev())
+            plan = S._Plan()
+            layer = S._get_layer(md[0], plan)
+            sc, bi = S._folded_bn(md[1], plan)
+            fused = ops.conv3d_forward_head(layer, x.to(dev()), sc, bi, res.to(dev()), ops.EPI_ADD_PRE, hd.weight)
+            assert fused is not None, "the fused-head path must be taken for a 64->32 transposed layer"
+            check(fused.cpu().numpy(), ref.numpy(), TIGHT, f"fused head {shape}")
+            got = md.fused(x.to(dev()), residual=res.to(dev()), head=hd)
+            check(got.cpu().numpy(), ref.numpy(), TIGHT, f"fused_conv3d(head=) {shape}")
+            # a layer that does not qualify (64 output channels) silently runs the two layers separately
+            m64 = seeded(S._deconvbn_3d(64, 64, gn=False), 93).to(dev())
+            h64 = S.HipConv3d(64, 1, kernel_size=1, padding=0, stride=1, bias=False).to(dev())
+            a = m64.fused(x.to(dev()), head=h64)
+            b = h64(m64.fused(x.to(dev())))
+            assert torch.equal(a, b)
+
+
 def test_train_mode_batchnorm_matches_torch():
     from oracle import torch_ref as T
     from snvc_amd.models import submodule as S
