@@ -423,7 +423,10 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
             if (a.vec) SNVC_WGRAD_CASE(SNVC_CFG(3, 1, 1, 2, 1, 3, true))
             else SNVC_WGRAD_CASE(SNVC_CFG(3, 1, 1, 2, 3, 3))
             break;
-        case 321: SNVC_WGRAD_CASE(SNVC_CFG(3, 2, 1, 1, 3, 3)) break;
+        case 321:   // same form for the stride-2 layers (one output row per tile keeps it inside 256 VGPRs)
+            if (a.vec) SNVC_WGRAD_CASE(SNVC_CFG(3, 2, 1, 1, 1, 3, true))
+            else SNVC_WGRAD_CASE(SNVC_CFG(3, 2, 1, 1, 3, 3))
+            break;
         case 511: SNVC_WGRAD_CASE(SNVC_CFG(5, 1, 1, 2, 1, 5)) break;
         case 512: SNVC_WGRAD_CASE(SNVC_CFG(5, 1, 2, 2, 1, 5)) break;
         case 711: SNVC_WGRAD_CASE(SNVC_CFG(7, 1, 1, 2, 1, 4)) break;
