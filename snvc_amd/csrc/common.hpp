@@ -29,6 +29,16 @@ inline int check_launch(const char *what) {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Kernels that need more than 48 KB of dynamic LDS must say so once per device (one process may drive several).
+inline void allow_large_lds(const void *func, int bytes, unsigned &done_mask) {
+    if (bytes <= 48 * 1024) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    if (done_mask & (1u << dev)) return;
+    (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done_mask |= 1u << dev;
+}
+
 // Compute units of the current device, rounded down to whole XCD octets (persistent-grid sizing).
 inline int device_cu_count() {
     static int cached[16] = {0};

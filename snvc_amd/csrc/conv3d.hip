@@ -1852,12 +1852,8 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
 
 template <class Cfg, int EPI>
 void launch_conv_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done && Cfg::LDS_BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_mfma_kernel<Cfg, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        attr_done = true;
-    }
+    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
+    allow_large_lds(reinterpret_cast<const void *>(&conv3d_mfma_kernel<Cfg, EPI>), Cfg::LDS_BYTES, attr_done);
     conv3d_mfma_kernel<Cfg, EPI><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 
@@ -1888,12 +1884,8 @@ inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
 template <class Cfg, bool RES>
 void launch_winok_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
-    static bool attr_done = false;
-    if (!attr_done && BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_winok_kernel<Cfg, RES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-        attr_done = true;
-    }
+    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
+    allow_large_lds(reinterpret_cast<const void *>(&conv3d_winok_kernel<Cfg, RES>), BYTES, attr_done);
     conv3d_winok_kernel<Cfg, RES><<<grid, 256, BYTES, st>>>(a);
 }
 
@@ -1906,24 +1898,16 @@ void launch_winok(const ConvArgs &a, dim3 grid, hipStream_t st) {
 template <class Cfg, bool RES, bool PLANE>
 void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
-    static bool attr_done = false;
-    if (!attr_done && BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wino_kernel<Cfg, RES, PLANE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-        attr_done = true;
-    }
+    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
+    allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_kernel<Cfg, RES, PLANE>), BYTES, attr_done);
     conv3d_wino_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
 }
 
 template <class Cfg, bool RES, bool PLANE>
 void launch_wino_dma_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
-    static bool attr_done = false;
-    if (!attr_done && BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
-        attr_done = true;
-    }
+    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
+    allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE>), BYTES, attr_done);
     conv3d_wino_dma_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
 }
 
@@ -1945,12 +1929,8 @@ void launch_wino(const ConvArgs &a, dim3 grid, hipStream_t st) {
 
 template <class Cfg, int EPI>
 void launch_deconv_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    static bool attr_done = false;
-    if (!attr_done && Cfg::LDS_BYTES > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&deconv3d_mfma_kernel<Cfg, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        attr_done = true;
-    }
+    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
+    allow_large_lds(reinterpret_cast<const void *>(&deconv3d_mfma_kernel<Cfg, EPI>), Cfg::LDS_BYTES, attr_done);
     deconv3d_mfma_kernel<Cfg, EPI><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 

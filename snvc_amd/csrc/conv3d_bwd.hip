@@ -337,12 +337,8 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__
 template <class Cfg, bool VEC>
 void launch_wgrad_variant(const WgradArgs &a, dim3 grid, hipStream_t st) {
     constexpr int bytes = Cfg::LDS_FLOATS * 4;
-    static bool attr_done = false;
-    if (!attr_done && bytes > 48 * 1024) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<Cfg, VEC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        attr_done = true;
-    }
+    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
+    allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<Cfg, VEC>), bytes, attr_done);
     conv3d_wgrad_kernel<Cfg, VEC><<<grid, 256, bytes, st>>>(a);
 }
 
