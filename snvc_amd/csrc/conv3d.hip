@@ -1602,6 +1602,77 @@ pointwise_small_kernel(const float *__restrict__ x, const float *__restrict__ w,
     }
 }
 
+// ------------------------------------------------------------------------------------ 3x3x3 to ONE channel
+// The occupancy head of the local model ends in Conv3d(32, 1, 3) + Sigmoid over the whole voxel grid
+// (vernier.py:262-270): 27 x Cin multiply-adds per voxel, far too little for a 32-channel MFMA tile (the MFMA
+// kernel spent 0.35 ms per crop with 31/32 of its tile empty).  A VALU kernel does it: a workgroup owns
+// 4 x 8 x 32 output voxels, a thread one (h, w) column of 4 depths; 4 input channels at a time are staged in
+// LDS (6 x 10 x 34 tile each); for every (channel, kh, kw) a thread reads its 6 depth values once and feeds the
+// 3 kd taps of its 4 outputs (12 FMAs); weights come in through scalar loads (wave-uniform addresses).
+constexpr int K3C1_TD = 4, K3C1_TH = 8, K3C1_KC = 4;
+constexpr int K3C1_IND = K3C1_TD + 2, K3C1_INH = K3C1_TH + 2, K3C1_INW = 34;
+constexpr int K3C1_CH = K3C1_IND * K3C1_INH * K3C1_INW;
+
+__global__ void __launch_bounds__(256)
+conv3d_k3_cout1_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
+                       const float *__restrict__ bias, const float *__restrict__ res, float *__restrict__ y, int Cin,
+                       int D, int H, int W, int tiles_h, int tiles_w, int64_t x_bs, int64_t y_bs, int64_t r_bs, int flags) {
+    __shared__ float img[K3C1_KC * K3C1_CH];
+    const int tid = threadIdx.x, ww = tid & 31, hh = tid >> 5;
+    const int t = blockIdx.x;
+    const int tw = t % tiles_w, th = (t / tiles_w) % tiles_h, td = t / (tiles_w * tiles_h);
+    const int od0 = td * K3C1_TD, oh0 = th * K3C1_TH, ow0 = tw * 32;
+    const int64_t n = blockIdx.y;
+    const int64_t hw = (int64_t)H * W, dhw = hw * D;
+    const float *xn = x + n * x_bs;
+    float acc[K3C1_TD] = {0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < Cin; c0 += K3C1_KC) {
+        __syncthreads();   // previous channels consumed
+        for (int e = tid; e < K3C1_KC * K3C1_CH; e += 256) {
+            const int c = e / K3C1_CH, r = e - c * K3C1_CH;
+            const int dd = r / (K3C1_INH * K3C1_INW), r2 = r - dd * (K3C1_INH * K3C1_INW);
+            const int h2 = r2 / K3C1_INW, w2 = r2 - h2 * K3C1_INW;
+            const int gd = od0 - 1 + dd, gh = oh0 - 1 + h2, gw = ow0 - 1 + w2;
+            const bool ok = c0 + c < Cin && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            const float v = xn[ok ? (c0 + c) * dhw + gd * hw + (int64_t)gh * W + gw : 0];
+            img[e] = ok ? v : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < K3C1_KC; ++c) {
+            if (c0 + c >= Cin) break;                     // uniform
+            const float *wc = w + (int64_t)(c0 + c) * 27;  // [kd][kh][kw], wave-uniform -> scalar loads
+            const float *pc = img + c * K3C1_CH + hh * K3C1_INW + ww;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    float v[K3C1_IND];
+#pragma unroll
+                    for (int dd = 0; dd < K3C1_IND; ++dd) v[dd] = pc[(dd * K3C1_INH + kh) * K3C1_INW + kw];
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd) {
+                        const float wv = wc[(kd * 3 + kh) * 3 + kw];
+#pragma unroll
+                        for (int o = 0; o < K3C1_TD; ++o) acc[o] = __builtin_fmaf(wv, v[o + kd], acc[o]);
+                    }
+                }
+        }
+    }
+    const float sc = scale ? scale[0] : 1.0f, bi = scale ? bias[0] : 0.0f;
+    const int oh = oh0 + hh, ow = ow0 + ww;
+    if (oh < H && ow < W) {
+#pragma unroll
+        for (int o = 0; o < K3C1_TD; ++o) {
+            const int od = od0 + o;
+            if (od >= D) break;
+            const int64_t sp = od * hw + (int64_t)oh * W + ow;
+            const float r = res ? res[n * r_bs + sp] : 0.0f;
+            y[n * y_bs + sp] = epilogue_f(acc[o] * sc + bi, r, flags);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ packing
 // Conv:    packed[cg][chunk][tap][kp][half][i][m] = W[co = cg*32*MI + m*32 + i][ci = chunk*KC + 2kp + half][tap]
 // Deconv:  same with tap enumerated class by class (see deconv_class_body) and
@@ -1970,6 +2041,8 @@ int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
     count += wino_packed_count(*d);   // k3/s1 layers also carry the Winograd-transformed weights
     // 1x1x1 layers with <= 2 output channels also keep their raw [Cout][Cin] weights (streaming kernel)
     if (!d->transposed && d->ksize == 1 && d->Cout <= 2) count += (int64_t)d->Cout * d->Cin;
+    // 3x3x3 / stride-1 layers with ONE output channel too ([Cin][27], VALU kernel)
+    if (!d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1) count += (int64_t)d->Cin * 27;
     return count;
 }
 
@@ -1981,9 +2054,11 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
     if (rc) return rc;
     if (!weight || !packed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_pack_weights: null pointer");
     int64_t total = snvc_conv3d_packed_weight_count(d);
-    if (!d->transposed && d->ksize == 1 && d->Cout <= 2) {   // raw copy behind the MFMA packing
-        total -= (int64_t)d->Cout * d->Cin;
-        if (hipMemcpyAsync(packed + total, weight, sizeof(float) * d->Cout * d->Cin, hipMemcpyDeviceToDevice,
+    const bool k3c1 = !d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1;
+    if ((!d->transposed && d->ksize == 1 && d->Cout <= 2) || k3c1) {   // raw copy behind the MFMA packing
+        const int64_t nraw = k3c1 ? (int64_t)d->Cin * 27 : (int64_t)d->Cout * d->Cin;
+        total -= nraw;
+        if (hipMemcpyAsync(packed + total, weight, sizeof(float) * nraw, hipMemcpyDeviceToDevice,
                            as_stream(stream)) != hipSuccess)
             return fail(SNVC_ERR_HIP, "snvc_conv3d_pack_weights: hipMemcpyAsync failed");
     }
@@ -2109,6 +2184,17 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         else
             pointwise_small_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
         return check_launch("snvc_conv3d_forward(pointwise)");
+    }
+    // 3x3x3 / stride 1 to ONE channel: VALU kernel (raw weights ride at the end of the packed buffer)
+    if (!d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1 && !depth_planes) {
+        const float *wraw = packed_weight + snvc_conv3d_packed_weight_count(d) - (int64_t)d->Cin * 27;
+        const int th_ = ceil_div(d->Hout, K3C1_TH), tw_ = ceil_div(d->Wout, 32);
+        const int64_t nt = (int64_t)ceil_div(d->Dout, K3C1_TD) * th_ * tw_;
+        if (nt < ((int64_t)1 << 31) && d->N <= 65535) {
+            conv3d_k3_cout1_kernel<<<dim3((unsigned)nt, (unsigned)d->N), 256, 0, as_stream(stream)>>>(
+                x, wraw, scale, bias, a.res, y, d->Cin, d->Dout, d->Hout, d->Wout, th_, tw_, a.x_bs, a.y_bs, a.r_bs, d->flags);
+            return check_launch("snvc_conv3d_forward(k3 to one channel)");
+        }
     }
     // k3 / stride 2: polyphase + F(4,2) along W (LDS-DMA staged: 16-byte INPUT rows; output rows may be 8-byte ones)
     {
