@@ -389,6 +389,44 @@ def test_deconv_vs_torch():
             check(y.cpu().numpy(), F.relu(ref + res).numpy(), TIGHT, "relu(deconv+res)")
 
 
+def test_conv_kernels_randomised_shapes():
+    """Seeded sweep over layer kinds x ragged sizes x epilogue forms, every case against torch's fp32
+    convolution: catches tile-edge, batch-stride and dispatch mistakes that fixed shapes miss."""
+    import torch.nn.functional as F
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(2026)
+    kinds = [("k3", 3, 1, 1), ("k3s2", 3, 2, 1), ("k5", 5, 1, 1), ("k5d2", 5, 1, 2), ("k7", 7, 1, 1), ("deconv", 3, 2, 1), ("k1", 1, 1, 1)]
+    import os
+    for case in range(int(os.environ.get("SNVC_FUZZ_CASES", "42"))):
+        name, k, stride, dil = kinds[case % len(kinds)]
+        cin = int(r.choice([3, 8, 32, 33, 64]))
+        cout = int(r.choice([32, 64, 32, 27, 1]))
+        n = int(r.choice([1, 2]))
+        if name == "deconv":
+            shape = (int(r.integers(1, 5)), int(r.integers(1, 6)), int(r.choice([3, 6, 16, 34, 39])))
+            m = S._deconvbn_3d(cin, cout, gn=False)
+            ref_conv = lambda x, w: F.conv_transpose3d(x, w, None, 2, 1, 1)
+        else:
+            lo = 2 if stride == 2 else 1
+            shape = (int(r.integers(lo, 9)), int(r.integers(lo, 11)), int(r.choice([4, 8, 12, 20, 36, 37, 42, 70])))
+            pad = dil * (k - 1) // 2
+            m = S.convbn_3d(cin, cout, k, stride, pad, dilation=dil)
+            ref_conv = lambda x, w, s_=stride, p_=pad, d_=dil: F.conv3d(x, w, None, s_, p_, d_)
+        seeded(m, 300 + case)
+        x = torch.from_numpy(r.standard_normal((n, cin) + shape).astype(np.float32))
+        mode = int(r.integers(0, 3))      # 0: bn, 1: relu(bn + res), 2: relu(bn) + res
+        with torch.no_grad():
+            ref = F.batch_norm(ref_conv(x, m[0].weight), m[1].running_mean, m[1].running_var, m[1].weight, m[1].bias,
+                               False, 0.0, m[1].eps)
+            res = torch.from_numpy(r.standard_normal(tuple(ref.shape)).astype(np.float32))
+            exp = ref if mode == 0 else (F.relu(ref + res) if mode == 1 else F.relu(ref) + res)
+            m = m.to(dev())
+            xd, rd = x.to(dev()), res.to(dev())
+            got = m(xd) if mode == 0 else m.fused(xd, relu=True, residual=rd, residual_after_act=(mode == 2))
+        check(got.cpu().numpy(), exp.numpy(), WINO7 if k == 7 else TIGHT,
+              f"case {case}: {name} {cin}->{cout} n={n} {shape} mode {mode}")
+
+
 def test_deconv_fused_head_vs_separate_layers():
     """snvc_conv3d_forward_head: bn(deconv(x)) + residual projected to one channel inside the epilogue
     equals the two layers run one after the other (torch reference), and the fused path is really taken."""

@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("cfg", choices=["cfg3", "cfg5", "rel"])
 ap.add_argument("--crops", type=int, default=2)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--no-heads", action="store_true", help="skip timing the stock-PyTorch 2D neck (keeps MIOpen's find kernels out of a profile)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 grid, F, gflop = {"cfg3": ((96, 96, 96), 32, 1907.3), "cfg5": ((80, 160, 160), 64, 17652.9),
@@ -56,7 +57,7 @@ for _ in range(args.reps):
 b.record(); torch.cuda.synchronize()
 ms = a.elapsed_time(b) / args.reps
 assert torch.isfinite(bev).all()
-if F == 32 and grid[0] == 32:   # the 2D BEV neck + heads that follow the path
+if F == 32 and grid[0] == 32 and not args.no_heads:   # the 2D BEV neck + heads that follow the path
     with torch.no_grad():
         m.heads_2d(bev); torch.cuda.synchronize()
         a.record()
