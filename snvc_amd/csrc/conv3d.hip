@@ -1009,19 +1009,20 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
         voff[nb] = 4u * (unsigned)(4 * half * out_dhw + sp);
         const int cls = od == 0 ? 0 : (od >= a.Dout - 1 ? 2 : 1);
         const unsigned poff = 4u * (unsigned)(4 * half * 3 * out_hw + (ok0[nb] ? cls * out_hw + oh * a.Wout + ow : 0));
-        // addends are fetched four channels at a time (loads behind loads cost nothing; only a load
-        // behind a STORE would wait for the write to be acknowledged)
+        // addends are fetched EB channels at a time (every batch is one exposed memory round trip: as large
+        // as the registers allow -- after the output transform only 4 of the position accumulators are live)
+        constexpr int EB = (RES && PLANE) ? 4 : (Cfg::NPOS * NB >= 12 ? 8 : 16);
 #pragma unroll
-        for (int r0 = 0; r0 < 16; r0 += 4) {
-            f32x4 rv[RES ? 4 : 1], pv[PLANE ? 4 : 1];
+        for (int r0 = 0; r0 < 16; r0 += EB) {
+            f32x4 rv[RES ? EB : 1], pv[PLANE ? EB : 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < EB; ++q) {
                 const int cl = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);     // channel within the group
                 if (RES) rv[q] = load_quad<V4>(rb + cl * cs + voff[nb], ok1[nb]);
                 if (PLANE) pv[q] = load_quad<V4>(pb + cl * ps + poff, ok1[nb]);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < EB; ++q) {
                 const int r = r0 + q;
                 const float sc = aff[(r & 3) + 8 * (r >> 2) + 4 * half], bi = aff[32 + (r & 3) + 8 * (r >> 2) + 4 * half];
 #pragma unroll
@@ -1033,7 +1034,7 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
             }
             // one batch of loads in flight at a time: pin this batch's results before the next loads
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < EB; ++q)
                 asm volatile("" : "+v"(acc[0][nb][r0 + q]), "+v"(acc[1][nb][r0 + q]), "+v"(acc[2][nb][r0 + q]),
                              "+v"(acc[3][nb][r0 + q])::"memory");
         }
@@ -1378,18 +1379,21 @@ __device__ __forceinline__ void deconv_epilogue_fast(const ConvArgs &a, f32x16 (
         const char *const rb = RES ? reinterpret_cast<const char *>(a.res + n * a.r_bs) + cbase * cs : nullptr;
         ChanAffine f;
         load_affine(a, cbase, lane, f);
+        // residual batches: a whole accumulator (16 pairs) when the kernel has registers to spare (MI = 1), half
+        // of one otherwise; every batch is one exposed memory round trip, so fewer and larger is better
+        constexpr int RBATCH = MI == 1 ? 16 : 8;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r0 = 0; r0 < 16; r0 += 8) {
-                float2 rv[RES ? 8 : 1];
+            for (int r0 = 0; r0 < 16; r0 += RBATCH) {
+                float2 rv[RES ? RBATCH : 1];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < RBATCH; ++q) {
                     const int cl = ((r0 + q) & 3) + 8 * ((r0 + q) >> 2);
                     if (RES) rv[q] = *reinterpret_cast<const float2 *>(rb + cl * cs + voff[nb]);
                 }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < RBATCH; ++q) {
                     const int r = r0 + q;
                     acc[0][nb][m][r] = act_f(acc[0][nb][m][r] * f.sc[r] + f.bi[r], RES ? rv[q].x : 0.0f, add_pre, relu, add_post);
                     acc[1][nb][m][r] = act_f(acc[1][nb][m][r] * f.sc[r] + f.bi[r], RES ? rv[q].y : 0.0f, add_pre, relu, add_post);
@@ -1397,7 +1401,7 @@ __device__ __forceinline__ void deconv_epilogue_fast(const ConvArgs &a, f32x16 (
                 // one batch of loads in flight at a time (register pressure): pin this batch's results
                 // before the next batch's loads may be issued
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
+                for (int q = 0; q < RBATCH; ++q)
                     asm volatile("" : "+v"(acc[0][nb][m][r0 + q]), "+v"(acc[1][nb][m][r0 + q])::"memory");
             }
     }
