@@ -12,8 +12,8 @@
 //     orientation makes every operand access unit-stride: B fragments are 32 consecutive
 //     floats of an LDS row, and each accumulator register is a 128-byte contiguous run of one
 //     output channel, so the epilogue stores whole cache lines without a transpose.
-//   * v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate, bit-exact FMA chain (no reduced
-//     precision anywhere); one VGPR per operand per lane.
+//   * v_mfma_f32_32x32x2_f32: fp32 in, fp32 accumulate (no reduced precision anywhere; the
+//     direct kernels are an exact fp32 FMA chain per output); one VGPR per operand per lane.
 //   * The input tile (+halo) of KC input channels is staged once in LDS and re-used by all
 //     k^3 taps: a tap is only a constant LDS address offset.  Zero padding is materialised in
 //     LDS, so the inner loop has no bounds checks.
@@ -28,6 +28,17 @@
 //     stores them interleaved as 8-byte pairs.
 //   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs (round-robin dispatch) each get a
 //     contiguous run of tiles so that halo re-reads hit that XCD's L2.
+//
+// Kernel families in this file (the dispatcher in conv3d_forward_impl picks one per launch):
+//   conv3d_mfma_kernel      direct form, any k in {1,3,5,7}, stride 1/2, dilation 1/2; also what
+//                           desc.algo = SNVC_ALGO_DIRECT and training's k5/k7 layers run on
+//   conv3d_wino_kernel /    Winograd F(4,3) along W for k3 / stride 1 (register-staged, and LDS-DMA
+//   conv3d_wino_dma_kernel  staged: the default 4x4x32 tile at three workgroups per CU)
+//   conv3d_winok_kernel     F(4,5) / F(4,7) for k5 / k7 (also dilation 2 for k5, polyphase) and the
+//                           polyphase + F(4,2) form of k3 / stride 2
+//   deconv3d_mfma_kernel    ConvTranspose3d(k3,s2,p1,op1), one parity class per workgroup, optional
+//                           fused 1x1x1 head (snvc_conv3d_forward_head)
+//   pointwise_small_kernel, conv3d_k3_cout1_kernel   VALU kernels for layers with 1-2 output channels
 #include "common.hpp"
 #include "wino_tables.hpp"
 
