@@ -44,9 +44,6 @@
 
 #include <cstdlib>
 
-#ifndef WINO_EXP
-#define WINO_EXP 0
-#endif
 namespace snvc {
 namespace {
 
@@ -666,13 +663,9 @@ __device__ __forceinline__ void wino_load_step(const float *__restrict__ img, co
         const int rp = wave * NB + nb;                  // row block: rows (dd, hh0 .. hh0 + RPB - 1)
         const int dd = rp / (TH / Cfg::RPB), hh0 = Cfg::RPB * (rp % (TH / Cfg::RPB));
         const float *px = img + bbase + kp * 2 * CH + ((dd + kd) * IN_H + hh0 + kh) * IN_WV;
-#if WINO_EXP == 2
-        o.d0[nb] = (float)step; o.d14[nb] = f32x4{1.f, 2.f, (float)nb, 4.f}; o.d5[nb] = 3.f; (void)px;
-#else
         o.d0[nb] = px[0];
         o.d14[nb] = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(px + 1, 16));
         o.d5[nb] = px[5];
-#endif
     }
 }
 
@@ -699,17 +692,9 @@ __device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img
             const float d0 = cur.d0[nb], d1 = cur.d14[nb][0], d2 = cur.d14[nb][1], d3 = cur.d14[nb][2],
                         d4 = cur.d14[nb][3], d5 = cur.d5[nb];
             const float ta = __builtin_fmaf(-4.0f, d2, d4), tb = __builtin_fmaf(-4.0f, d1, d3), tc = d4 - d2, te = d3 - d1;
-#if WINO_EXP == 1
-            const float v0 = d0, v5 = d5;
-#else
             const float v0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
             const float v5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
-#endif
-#if WINO_EXP == 1
-            const float v1 = d1, v2 = d2, v3 = d3, v4 = d4; (void)ta; (void)tb; (void)tc; (void)te;
-#else
             const float v1 = ta + tb, v2 = ta - tb, v3 = __builtin_fmaf(2.0f, te, tc), v4 = __builtin_fmaf(-2.0f, te, tc);
-#endif
             acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[0], v0, acc[0][nb], 0, 0, 0);
             acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[1], v1, acc[1][nb], 0, 0, 0);
             acc[2][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[2], v2, acc[2][nb], 0, 0, 0);
