@@ -1542,8 +1542,10 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
     }
 }
 
+// The single-group form with a fast epilogue fits 128 VGPRs and 30 KB of LDS: four workgroups per CU (its chunks
+// are short, 12..48 MFMAs per wave, so resident waves are what hides the staging latency).
 template <class Cfg, int EPI>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (Cfg::MI == 1 && EPI != 0) ? 4 : 2)
 deconv3d_mfma_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
