@@ -1883,7 +1883,9 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: transposed conv supports k3,s2,p1,op1 only");
         if (d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win)
             return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: transposed output must be 2x the input");
-        p = wide ? plan_of<CfgDCM2>(DC_M2) : plan_of<CfgDCM1>(DC_M1);
+        // whole 32-channel groups run the single-group form (128 VGPRs: four workgroups per CU); the 64-channel
+        // form only remains for channel counts that are not multiples of 32
+        p = (wide && d.Cout % 32 != 0) ? plan_of<CfgDCM2>(DC_M2) : plan_of<CfgDCM1>(DC_M1);
         p.tiles_d = ceil_div(d.Din, p.TD); p.tiles_h = ceil_div(d.Hin, p.TH); p.tiles_w = ceil_div(d.Win, 32);
     } else {
         if (d.pad != d.dilation * (d.ksize - 1) / 2)
