@@ -1203,8 +1203,9 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
 // while phase p is multiplied; the input image of the next chunk is DMA'd after the chunk's last
 // phase (single buffer: that load is exposed to this workgroup and hidden by the co-resident one; a
 // chunk is 7 x 70 = 490 MFMAs per wave for k7).
+// (the plain k5 form fits 168 VGPRs and 41 KB of LDS: three workgroups per CU, 0.78 -> 0.72 ms on the local conv2)
 template <class Cfg, bool RES>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, (Cfg::KS == 5 && Cfg::DIL == 1) ? 3 : 2)
 conv3d_winok_kernel(const ConvArgs a) {
     constexpr int KS = Cfg::KS, KC = Cfg::KC, CH = Cfg::CH, TILE = Cfg::TILE, WF = Cfg::WF, P = Cfg::NPOS;
     using St = typename Cfg::St;

@@ -20,23 +20,28 @@ CASES = {
     "hg_c4": (64, 64, 3, 1, 1, (48, 24, 78), False),
     "dc5": (64, 64, 3, 2, 1, (48, 24, 78), True),
     "dc6": (64, 32, 3, 2, 1, (96, 48, 156), True),
+    # local model (released shape): cin, cout, k, stride, pad, shape, transposed[, dilation]
+    "l_k7": (64, 32, 7, 1, 3, (32, 128, 192), False),
+    "l_k5": (32, 32, 5, 1, 2, (32, 128, 192), False),
+    "l_k5d2": (32, 32, 5, 1, 4, (32, 128, 192), False, 2),
 }
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cases", nargs="*", default=list(CASES))
+    ap.add_argument("cases", nargs="*", default=[c for c in CASES if not c.startswith("l_")])
     ap.add_argument("--reps", type=int, default=60)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     with torch.no_grad():
         for name in args.cases:
-            cin, cout, k, s, p, shape, tr = CASES[name]
-            m = (S._deconvbn_3d(cin, cout, False) if tr else S.convbn_3d(cin, cout, k, s, p)).to(dev).eval()
+            cin, cout, k, s, p, shape, tr = CASES[name][:7]
+            dil = CASES[name][7] if len(CASES[name]) > 7 else 1
+            m = (S._deconvbn_3d(cin, cout, False) if tr else S.convbn_3d(cin, cout, k, s, p, dilation=dil)).to(dev).eval()
             x = torch.randn((1, cin) + shape, device=dev)
             y = m.fused(x, relu=True)
             vox = x[0, 0].numel() if tr else y[0, 0].numel()
-            gf = 2.0 * vox * cin * cout * 27 / 1e9
+            gf = 2.0 * vox * cin * cout * (27 if tr else k ** 3) / 1e9
             for _ in range(40):
                 m.fused(x, relu=True)
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.reps)]
