@@ -143,11 +143,29 @@ enum {
     SNVC_EPI_SIGMOID = 8
 };
 
-/* desc.algo: which arithmetic the stride-1 k3 / k5 / k7 layers may use.
+/* desc.algo: which arithmetic / kernel form a layer may use.  Low byte = the arithmetic:
  *   SNVC_ALGO_AUTO   : fastest form inside the 1e-3 contract -- Winograd F(4,k) along W where the layer
  *                      qualifies (fp32 products and sums; measured 2e-6 (k3) .. 1e-4 (k7) of the output range)
- *   SNVC_ALGO_DIRECT : the direct kernels only (an exact fp32 FMA chain per output) */
-enum { SNVC_ALGO_AUTO = 0, SNVC_ALGO_DIRECT = 1 };
+ *   SNVC_ALGO_DIRECT : the direct kernels only (an exact fp32 FMA chain per output)
+ * ORed on top, kernel-form selectors.  The dispatcher's own choice (none of them set) is the measured-fastest
+ * form; the selectors exist so that every instantiated form can be reached -- and parity-tested -- through the
+ * ABI rather than through process environment:
+ *   SNVC_ALGO_WINO_TILE_*      : k3 / stride-1 Winograd tile: 4x4x64 LDS-DMA staged (BIG), 2x4x64
+ *                                register staged (STD), 4x4x32 register staged (NARROW_REG); default is
+ *                                the 4x4x32 LDS-DMA staged tile at three workgroups per CU
+ *   SNVC_ALGO_GENERIC_EPILOGUE : scalar predicated epilogue instead of the 16-byte-store ones
+ *   SNVC_ALGO_SCALAR_STAGING   : snvc_conv3d_wgrad only: element-wise staging instead of the float4 form */
+enum {
+    SNVC_ALGO_AUTO = 0,
+    SNVC_ALGO_DIRECT = 1,
+    SNVC_ALGO_ARITH_MASK = 0xff,
+    SNVC_ALGO_WINO_TILE_BIG = 0x100,
+    SNVC_ALGO_WINO_TILE_STD = 0x200,
+    SNVC_ALGO_WINO_TILE_NARROW_REG = 0x300,
+    SNVC_ALGO_WINO_TILE_MASK = 0x300,
+    SNVC_ALGO_GENERIC_EPILOGUE = 0x400,
+    SNVC_ALGO_SCALAR_STAGING = 0x800
+};
 
 typedef struct {
     int32_t N, Cin, Din, Hin, Win;

@@ -26,6 +26,10 @@ class Conv3dDesc(ctypes.Structure):
 
 
 EPI_RELU, EPI_ADD_PRE, EPI_ADD_POST, EPI_SIGMOID = 1, 2, 4, 8
+# snvc_conv3d_desc.algo (include/snvc_hip.h): arithmetic in the low byte, kernel-form selectors above it
+ALGO_AUTO, ALGO_DIRECT = 0, 1
+ALGO_WINO_TILE_BIG, ALGO_WINO_TILE_STD, ALGO_WINO_TILE_NARROW_REG = 0x100, 0x200, 0x300
+ALGO_GENERIC_EPILOGUE, ALGO_SCALAR_STAGING = 0x400, 0x800
 F32, F64 = 0, 1
 
 # name -> (restype, argtypes); kept next to the header so the symbol test can walk it

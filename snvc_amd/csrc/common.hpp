@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -17,8 +18,17 @@ inline int fail(int code, const char *msg) {
     return code;
 }
 
+// Set by allow_large_lds when the attribute call failed (the launch that follows is skipped by its caller and
+// check_launch reports the failure, message already recorded by set_error).
+inline thread_local bool g_launch_aborted = false;
+
 // Called after every launch: hipGetLastError is a host-side query (no device sync).
 inline int check_launch(const char *what) {
+    if (g_launch_aborted) {
+        g_launch_aborted = false;
+        (void)hipGetLastError();
+        return SNVC_ERR_HIP;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         set_error("%s: %s", what, hipGetErrorString(e));
@@ -29,14 +39,22 @@ inline int check_launch(const char *what) {
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Kernels that need more than 48 KB of dynamic LDS must say so once per device (one process may drive several).
-inline void allow_large_lds(const void *func, int bytes, unsigned &done_mask) {
-    if (bytes <= 48 * 1024) return;
+// Kernels that need more than 48 KB of dynamic LDS must say so once per device (one process may drive several,
+// from several host threads: nn.DataParallel replicas).  `done_mask` has one bit per device; the bit is set only
+// after the attribute call succeeded, so a racing thread at worst repeats the (idempotent) call.
+inline bool allow_large_lds(const void *func, int bytes, std::atomic<unsigned> &done_mask) {
+    if (bytes <= 48 * 1024) return true;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
-    if (done_mask & (1u << dev)) return;
-    (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    done_mask |= 1u << dev;
+    if (done_mask.load(std::memory_order_acquire) & (1u << dev)) return true;
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize, %d): %s", bytes, hipGetErrorString(e));
+        g_launch_aborted = true;
+        return false;
+    }
+    done_mask.fetch_or(1u << dev, std::memory_order_release);
+    return true;
 }
 
 // Compute units of the current device, rounded down to whole XCD octets (persistent-grid sizing).

@@ -42,8 +42,6 @@
 #include "common.hpp"
 #include "wino_tables.hpp"
 
-#include <cstdlib>
-
 namespace snvc {
 namespace {
 
@@ -1829,7 +1827,7 @@ struct Plan {
 
 enum Kind {
     K1_M1, K1_M2,
-    K3_M1, K3_M2, K3_M1v0, K3_M1v2, K3_M1v3, K3_M1v4,
+    K3_M1, K3_M2,
     K3S2_M1, K3S2_M2,
     K5_M1, K5_M2,
     K5D2_M1, K5D2_M2,
@@ -1842,10 +1840,6 @@ enum Kind {
 using CfgK1M1   = ConvCfg<1, 1, 1, 1, 4, 4, 8, true>;
 using CfgK1M2   = ConvCfg<1, 1, 1, 2, 4, 4, 8, true>;
 using CfgK3M1   = ConvCfg<3, 1, 1, 1, 4, 4, 4, true>;
-using CfgK3M1v0 = ConvCfg<3, 1, 1, 1, 4, 8, 4, true>;
-using CfgK3M1v2 = ConvCfg<3, 1, 1, 1, 4, 4, 4, true, 3>;
-using CfgK3M1v3 = ConvCfg<3, 1, 1, 1, 4, 4, 4, true, 2, 1>;
-using CfgK3M1v4 = ConvCfg<3, 1, 1, 1, 4, 4, 4, true, 3, 1>;
 using CfgK3M2   = ConvCfg<3, 1, 1, 2, 4, 4, 4, true>;
 using CfgK3S2M1 = ConvCfg<3, 2, 1, 1, 2, 4, 2, false>;
 using CfgK3S2M2 = ConvCfg<3, 2, 1, 2, 2, 4, 2, false>;
@@ -1877,8 +1871,7 @@ constexpr Plan plan_of(int kind) { return Plan{Cfg::MI, Cfg::KC, Cfg::TD, Cfg::T
 int make_plan(const snvc_conv3d_desc &d, Plan &p) {
     if (d.N < 0 || d.Cin <= 0 || d.Cout <= 0 || d.Din <= 0 || d.Hin <= 0 || d.Win <= 0)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: sizes must be positive");
-    const char *force = getenv("SNVC_FORCE_MI1");   // development knob
-    const bool wide = d.Cout > 32 && !(force && force[0] == '1');  // MI = 2 handles 64 output channels per workgroup
+    const bool wide = d.Cout > 32;  // MI = 2 handles 64 output channels per workgroup
     if (d.transposed) {
         if (d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.dilation != 1)
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: transposed conv supports k3,s2,p1,op1 only");
@@ -1899,17 +1892,7 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
         const int key = d.ksize * 100 + d.stride * 10 + d.dilation;
         switch (key) {
             case 111: p = wide ? plan_of<CfgK1M2>(K1_M2) : plan_of<CfgK1M1>(K1_M1); break;
-            case 311: {
-                p = wide ? plan_of<CfgK3M2>(K3_M2) : plan_of<CfgK3M1>(K3_M1);
-                const char *v = getenv("SNVC_K3M1_VARIANT");  // development knob (tile / occupancy sweep)
-                if (!wide && v) {
-                    if (v[0] == '0') p = plan_of<CfgK3M1v0>(K3_M1v0);
-                    if (v[0] == '2') p = plan_of<CfgK3M1v2>(K3_M1v2);
-                    if (v[0] == '3') p = plan_of<CfgK3M1v3>(K3_M1v3);
-                    if (v[0] == '4') p = plan_of<CfgK3M1v4>(K3_M1v4);
-                }
-                break;
-            }
+            case 311: p = wide ? plan_of<CfgK3M2>(K3_M2) : plan_of<CfgK3M1>(K3_M1); break;
             case 321: p = wide ? plan_of<CfgK3S2M2>(K3S2_M2) : plan_of<CfgK3S2M1>(K3S2_M1); break;
             case 511: p = wide ? plan_of<CfgK5M2>(K5_M2) : plan_of<CfgK5M1>(K5_M1); break;
             case 512: p = wide ? plan_of<CfgK5D2M2>(K5D2_M2) : plan_of<CfgK5D2M1>(K5D2_M1); break;
@@ -1928,8 +1911,8 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
 
 template <class Cfg, int EPI>
 void launch_conv_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
-    allow_large_lds(reinterpret_cast<const void *>(&conv3d_mfma_kernel<Cfg, EPI>), Cfg::LDS_BYTES, attr_done);
+    static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_mfma_kernel<Cfg, EPI>), Cfg::LDS_BYTES, attr_done)) return;
     conv3d_mfma_kernel<Cfg, EPI><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 
@@ -1960,8 +1943,8 @@ inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
 template <class Cfg, bool RES>
 void launch_winok_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
-    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
-    allow_large_lds(reinterpret_cast<const void *>(&conv3d_winok_kernel<Cfg, RES>), BYTES, attr_done);
+    static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_winok_kernel<Cfg, RES>), BYTES, attr_done)) return;
     conv3d_winok_kernel<Cfg, RES><<<grid, 256, BYTES, st>>>(a);
 }
 
@@ -1974,16 +1957,16 @@ void launch_winok(const ConvArgs &a, dim3 grid, hipStream_t st) {
 template <class Cfg, bool RES, bool PLANE>
 void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
-    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
-    allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_kernel<Cfg, RES, PLANE>), BYTES, attr_done);
+    static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_kernel<Cfg, RES, PLANE>), BYTES, attr_done)) return;
     conv3d_wino_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
 }
 
 template <class Cfg, bool RES, bool PLANE>
 void launch_wino_dma_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
-    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
-    allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE>), BYTES, attr_done);
+    static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE>), BYTES, attr_done)) return;
     conv3d_wino_dma_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
 }
 
@@ -2005,8 +1988,8 @@ void launch_wino(const ConvArgs &a, dim3 grid, hipStream_t st) {
 
 template <class Cfg, int EPI>
 void launch_deconv_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
-    allow_large_lds(reinterpret_cast<const void *>(&deconv3d_mfma_kernel<Cfg, EPI>), Cfg::LDS_BYTES, attr_done);
+    static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
+    if (!allow_large_lds(reinterpret_cast<const void *>(&deconv3d_mfma_kernel<Cfg, EPI>), Cfg::LDS_BYTES, attr_done)) return;
     deconv3d_mfma_kernel<Cfg, EPI><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
 }
 
@@ -2166,9 +2149,9 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     const bool vec8 = (d->Win % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0) && (a.x_bs % 2 == 0);
     // fast epilogues: (wave-uniform channel base) + 32-bit lane byte offsets, whole 32-channel groups, no
     // Sigmoid; 16-byte stores when the output rows allow them
-    const char *ne = getenv("SNVC_NO_FAST_EPILOGUE");   // development knob
+    const bool direct_only = (d->algo & SNVC_ALGO_ARITH_MASK) == SNVC_ALGO_DIRECT;
     const bool fast_common = (int64_t)d->Dout * d->Hout * d->Wout < ((int64_t)1 << 27) && d->Cout % 32 == 0 &&
-                             !(d->flags & SNVC_EPI_SIGMOID) && !(ne && ne[0] == '1');
+                             !(d->flags & SNVC_EPI_SIGMOID) && !(d->algo & SNVC_ALGO_GENERIC_EPILOGUE);
     const bool epi16 = d->Wout % 4 == 0 && a.y_bs % 4 == 0 && a.r_bs % 4 == 0 &&
                        ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
                          reinterpret_cast<uintptr_t>(depth_planes)) & 15) == 0;
@@ -2205,9 +2188,8 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     {
         const bool out8 = fast_common && (d->Wout % 2 == 0) && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
                           ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res)) & 7) == 0;
-        const char *nw = getenv("SNVC_NO_WINOGRAD");
         if (!d->transposed && d->ksize == 3 && d->stride == 2 && d->dilation == 1 && a.vec && (a.fast_epi || out8) &&
-            !depth_planes && d->algo != SNVC_ALGO_DIRECT && !(nw && nw[0] == '1')) {
+            !depth_planes && !direct_only) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, 2);
             a.groups = ceil_div(d->Cout, 32);
@@ -2224,8 +2206,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     // k5 / k7, stride 1, no dilation: Winograd F(4,KS) along W (LDS-DMA staged: 16-byte rows only)
     if (!d->transposed && (d->ksize == 5 || d->ksize == 7) && d->stride == 1 &&
         (d->dilation == 1 || (d->dilation == 2 && d->ksize == 5)) && a.vec && a.fast_epi && !depth_planes) {
-        const char *nw = getenv("SNVC_NO_WINOGRAD");
-        if (!(nw && nw[0] == '1') && d->algo != SNVC_ALGO_DIRECT) {
+        if (!direct_only) {
             const int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, 2);
@@ -2244,22 +2225,22 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     // k3 / stride 1: Winograd F(4,3) along W when the rows allow 8-byte pair stores and 16-byte staging
     {
         const int64_t wino = (d->ksize == 3 && d->stride == 1 && !d->transposed) ? wino_packed_count(*d) : 0;
-        const char *nw = getenv("SNVC_NO_WINOGRAD");   // development knob: force the direct kernel
         const bool pair_ok = (d->Wout % 2 == 0) && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
                              ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
                                reinterpret_cast<uintptr_t>(depth_planes)) & 7) == 0;
         const bool wide = a.vec && epi16;   // 16-byte staging and stores; else 8-byte ones (pair_ok)
-        if (wino && pair_ok && fast_common && (wide || vec8) && !(nw && nw[0] == '1') && d->algo != SNVC_ALGO_DIRECT) {
+        if (wino && pair_ok && fast_common && (wide || vec8) && !direct_only) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, CfgWino::KC);
             a.groups = ceil_div(d->Cout, 32);
             // tile choice.  Default: the 4x4x32 tile, LDS-DMA staged (137 VGPRs, 51 KB LDS: three workgroups per
             // CU), or its register-staged 8-byte-row form when the rows are not 16-byte aligned.  Measured on cfg2:
             // conv1 2.70 ms / conv2 1.40 ms / hg conv2 0.73 ms, against 2.82 / 1.45 / 0.89 for the 4x4x64 LDS-DMA
-            // tile ("big") and 2.93 / 1.52 / 0.91 for the 2x4x64 register-staged one ("std").  SNVC_WINO_TILE
-            // selects the other forms (development knob; the parity tests run all of them).
-            const char *tv = getenv("SNVC_WINO_TILE");   // "big", "std", "narrow" (register-staged 4x4x32)
-            const bool big = tv && tv[0] == 'b' && wide, stdt = tv && tv[0] == 's', nreg = tv && tv[0] == 'n';
+            // tile (BIG) and 2.93 / 1.52 / 0.91 for the 2x4x64 register-staged one (STD).  desc.algo's
+            // SNVC_ALGO_WINO_TILE_* bits select the other forms (the parity tests run all of them).
+            const int tsel = d->algo & SNVC_ALGO_WINO_TILE_MASK;
+            const bool big = tsel == SNVC_ALGO_WINO_TILE_BIG && wide, stdt = tsel == SNVC_ALGO_WINO_TILE_STD,
+                       nreg = tsel == SNVC_ALGO_WINO_TILE_NARROW_REG;
             const bool narrow = !big && !stdt;
             const int TDc = (big || narrow) ? 4 : 2, THc = 4, TWc = narrow ? 32 : 64;
             a.tiles_d = ceil_div(d->Dout, TDc);
@@ -2288,10 +2269,6 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         case K1_M1: launch_conv<CfgK1M1>(a, grid, st); break;
         case K1_M2: launch_conv<CfgK1M2>(a, grid, st); break;
         case K3_M1: launch_conv<CfgK3M1>(a, grid, st); break;
-        case K3_M1v0: launch_conv<CfgK3M1v0>(a, grid, st); break;
-        case K3_M1v2: launch_conv<CfgK3M1v2>(a, grid, st); break;
-        case K3_M1v3: launch_conv<CfgK3M1v3>(a, grid, st); break;
-        case K3_M1v4: launch_conv<CfgK3M1v4>(a, grid, st); break;
         case K3_M2: launch_conv<CfgK3M2>(a, grid, st); break;
         case K3S2_M1: launch_conv<CfgK3S2M1, true>(a, grid, st); break;
         case K3S2_M2: launch_conv<CfgK3S2M2, true>(a, grid, st); break;

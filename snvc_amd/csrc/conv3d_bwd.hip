@@ -19,7 +19,6 @@
 // in a fixed order: the result is deterministic (no float atomics).
 #include "common.hpp"
 
-#include <cstdlib>
 
 namespace snvc {
 namespace {
@@ -337,8 +336,8 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__
 template <class Cfg, bool VEC>
 void launch_wgrad_variant(const WgradArgs &a, dim3 grid, hipStream_t st) {
     constexpr int bytes = Cfg::LDS_FLOATS * 4;
-    static unsigned attr_done = 0;   // one bit per device: the attribute is per device
-    allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<Cfg, VEC>), bytes, attr_done);
+    static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_kernel<Cfg, VEC>), bytes, attr_done)) return;
     conv3d_wgrad_kernel<Cfg, VEC><<<grid, 256, bytes, st>>>(a);
 }
 
@@ -398,9 +397,8 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
     a.cx_blocks = ceil_div(d->Cin, 32);
     a.x_bs = d->x_batch_stride ? d->x_batch_stride : in_sz;
     a.g_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
-    const char *nv = getenv("SNVC_WGRAD_SCALAR");   // development knob: the scalar staging path
     a.vec = d->Win % 4 == 0 && d->Wout % 4 == 0 && a.x_bs % 4 == 0 && a.g_bs % 4 == 0 &&
-            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0 && !(nv && nv[0] == '1');
+            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0 && !(d->algo & SNVC_ALGO_SCALAR_STAGING);
     const int pairs = ceil_div(d->Cout, 32) * a.cx_blocks;
     if (pairs > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: too many channel pairs");
     hipStream_t st = as_stream(stream);

@@ -15,8 +15,6 @@
 // own (fp contract off), so it is bit-identical to oracle/numpy_ref.py:sample_2d_feat.
 #include "common.hpp"
 
-#include <cstdlib>
-
 namespace snvc {
 namespace {
 
@@ -87,93 +85,6 @@ voxel_gather_fwd(const float *__restrict__ left, const float *__restrict__ right
     for (int c = 0; c < F; ++c) o[(int64_t)c * V] = apply_taps(rf + (int64_t)c * plane, tr);
 }
 
-
-// ---- fast forward path: 4 consecutive voxels per thread, 16-byte stores, 8-byte pair loads ----
-// The two taps of a bilinear row are adjacent floats, so one (possibly unaligned) 8-byte load
-// fetches both: 2 loads per channel per voxel instead of 4.  The pair always starts inside the row
-// (xs = clamp(x0, 0, Wf-2)); per tap a pair of bit masks says whether it takes the pair's .x, its .y
-// or nothing (out of range -> exactly 0, like padding_mode="zeros").  The arithmetic on the
-// selected values is the same a*nw + b*ne + c*sw + d*se, separately rounded.
-struct PairTaps {
-    int row0, row1;          // element offsets of the two pairs inside one feature plane
-    unsigned mx[4], my[4];   // per tap (nw, ne, sw, se): all-ones mask for pair.x / pair.y
-    float wt[4];
-};
-
-__device__ __forceinline__ PairTaps make_pair_taps(float px, float py, float res_x, float res_y, int Hf, int Wf) {
-    const float gx = px / res_x * 2.0f - 1.0f;
-    const float gy = py / res_y * 2.0f - 1.0f;
-    const float x = (gx + 1.0f) * ((float)Wf / 2.0f) - 0.5f;
-    const float y = (gy + 1.0f) * ((float)Hf / 2.0f) - 0.5f;
-    const float xf = floorf(x), yf = floorf(y);
-    const float w = x - xf, e = 1.0f - w, n = y - yf, s = 1.0f - n;
-    PairTaps t;
-    t.wt[0] = s * e; t.wt[1] = s * w; t.wt[2] = n * e; t.wt[3] = n * w;
-    const bool finite_range = (xf >= -2.0f && xf <= (float)Wf + 1.0f && yf >= -2.0f && yf <= (float)Hf + 1.0f);
-    const int x0 = finite_range ? (int)xf : -2, y0 = finite_range ? (int)yf : -2;
-    const int x1 = x0 + 1, y1 = y0 + 1;
-    const bool vx0 = x0 >= 0 && x0 < Wf, vx1 = x1 >= 0 && x1 < Wf;
-    const bool vy0 = y0 >= 0 && y0 < Hf, vy1 = y1 >= 0 && y1 < Hf;
-    int xs = x0 < 0 ? 0 : x0;
-    xs = xs > Wf - 2 ? Wf - 2 : xs;
-    const int ys0 = vy0 ? y0 : 0, ys1 = vy1 ? y1 : 0;
-    t.row0 = ys0 * Wf + xs;
-    t.row1 = ys1 * Wf + xs;
-    const unsigned ones = 0xFFFFFFFFu;
-    // tap at column x0 / x1 sits in .x if it equals xs, in .y if it equals xs + 1
-    t.mx[0] = (vx0 && vy0 && x0 == xs) ? ones : 0u;  t.my[0] = (vx0 && vy0 && x0 == xs + 1) ? ones : 0u;
-    t.mx[1] = (vx1 && vy0 && x1 == xs) ? ones : 0u;  t.my[1] = (vx1 && vy0 && x1 == xs + 1) ? ones : 0u;
-    t.mx[2] = (vx0 && vy1 && x0 == xs) ? ones : 0u;  t.my[2] = (vx0 && vy1 && x0 == xs + 1) ? ones : 0u;
-    t.mx[3] = (vx1 && vy1 && x1 == xs) ? ones : 0u;  t.my[3] = (vx1 && vy1 && x1 == xs + 1) ? ones : 0u;
-    return t;
-}
-
-struct __attribute__((packed, aligned(4))) Pair { float x, y; };
-
-__device__ __forceinline__ float apply_pair_taps(const float *__restrict__ plane, const PairTaps &t) {
-    const Pair p0 = *reinterpret_cast<const Pair *>(plane + t.row0);
-    const Pair p1 = *reinterpret_cast<const Pair *>(plane + t.row1);
-    const unsigned x0 = __float_as_uint(p0.x), y0 = __float_as_uint(p0.y);
-    const unsigned x1 = __float_as_uint(p1.x), y1 = __float_as_uint(p1.y);
-    const float a = __uint_as_float((x0 & t.mx[0]) | (y0 & t.my[0]));
-    const float b = __uint_as_float((x0 & t.mx[1]) | (y0 & t.my[1]));
-    const float c = __uint_as_float((x1 & t.mx[2]) | (y1 & t.my[2]));
-    const float d = __uint_as_float((x1 & t.mx[3]) | (y1 & t.my[3]));
-    return a * t.wt[0] + b * t.wt[1] + c * t.wt[2] + d * t.wt[3];
-}
-
-__global__ void __launch_bounds__(256)
-voxel_gather_fwd_x4(const float *__restrict__ left, const float *__restrict__ right,
-                    const float *__restrict__ l_pts, const float *__restrict__ r_pts,
-                    float *__restrict__ out, int F, int Hf, int Wf, int64_t V, float res_x, float res_y) {
-    const int64_t n = blockIdx.y;
-    const int64_t v = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (v >= V) return;
-    const int plane = Hf * Wf;
-    float *o = out + n * 2 * F * V + v;
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const float *pts = (side == 0 ? l_pts : r_pts) + n * 2 * V;
-        const float *feat = (side == 0 ? left : right) + n * F * plane;
-        const float4 px = *reinterpret_cast<const float4 *>(pts + v);
-        const float4 py = *reinterpret_cast<const float4 *>(pts + V + v);
-        const PairTaps t0 = make_pair_taps(px.x, py.x, res_x, res_y, Hf, Wf);
-        const PairTaps t1 = make_pair_taps(px.y, py.y, res_x, res_y, Hf, Wf);
-        const PairTaps t2 = make_pair_taps(px.z, py.z, res_x, res_y, Hf, Wf);
-        const PairTaps t3 = make_pair_taps(px.w, py.w, res_x, res_y, Hf, Wf);
-#pragma unroll 2
-        for (int c = 0; c < F; ++c) {
-            const float *pl = feat + (int64_t)c * plane;
-            float4 r;
-            r.x = apply_pair_taps(pl, t0);
-            r.y = apply_pair_taps(pl, t1);
-            r.z = apply_pair_taps(pl, t2);
-            r.w = apply_pair_taps(pl, t3);
-            *reinterpret_cast<float4 *>(o + (int64_t)c * V) = r;
-        }
-        o += (int64_t)F * V;
-    }
-}
 
 // ---- channels-last forward path ----
 // The plain kernel issues 4 gather loads per channel per camera (256 per voxel at F = 32) and is bound by
@@ -371,18 +282,9 @@ int snvc_voxel_gather_forward(const float *left, const float *right, const float
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_voxel_gather_forward: feature plane or batch too large");
     if (!left || !right || !l_pts || !r_pts || !out)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward: null pointer");
-    const bool fast = getenv("SNVC_GATHER_X4") && (V % 4 == 0) && Wf >= 2 &&
-                      ((reinterpret_cast<uintptr_t>(l_pts) | reinterpret_cast<uintptr_t>(r_pts) |
-                        reinterpret_cast<uintptr_t>(out)) & 15) == 0;
-    if (fast) {
-        dim3 grid((unsigned)ceil_div<int64_t>(V / 4, 256), (unsigned)N);
-        voxel_gather_fwd_x4<<<grid, 256, 0, as_stream(stream)>>>(left, right, l_pts, r_pts, out, (int)F, (int)Hf,
-                                                                 (int)Wf, V, res_x, res_y);
-    } else {
-        dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
-        voxel_gather_fwd<<<grid, 256, 0, as_stream(stream)>>>(left, right, l_pts, r_pts, out, (int)F,
-                                                              (int)Hf, (int)Wf, V, res_x, res_y);
-    }
+    dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
+    voxel_gather_fwd<<<grid, 256, 0, as_stream(stream)>>>(left, right, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V,
+                                                          res_x, res_y);
     return check_launch("snvc_voxel_gather_forward");
 }
 
@@ -404,8 +306,7 @@ int snvc_voxel_gather_forward_ws(const float *left, const float *right, const fl
     dim3 tg((unsigned)ceil_div(plane, 64), (unsigned)N, 2);
     features_to_channels_last<<<tg, 256, (size_t)64 * (F + 1) * sizeof(float), as_stream(stream)>>>(left, right, workspace,
                                                                                                     (int)F, plane);
-    const char *x1 = getenv("SNVC_GATHER_X1");   // development knob: one voxel per thread
-    if (V % 4 == 0 && !(x1 && x1[0] == '1') &&
+    if (V % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(l_pts) | reinterpret_cast<uintptr_t>(r_pts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
         dim3 grid((unsigned)ceil_div<int64_t>(V / 4, 256), (unsigned)N);
         voxel_gather_fwd_cl_x4<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf,

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from ..extension.build_cost_volume import build_cost_volume
 from .. import ops
-from .submodule import ConvBNReLU3d, HipConv3d, _folded_bn, _Plan, convbn_3d, hourglass
+from .submodule import _GENERATION, ConvBNReLU3d, HipConv3d, _folded_bn, _Plan, convbn_3d, hourglass
 
 
 class GlobalStack(nn.Module):
@@ -74,7 +74,7 @@ class GlobalStack(nn.Module):
         c = left.size(1)
         w = conv.weight
         plans = conv.__dict__.setdefault("_snvc_factored", {})
-        key = (w.data_ptr(), w._version, w.device)
+        key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
         if plans.get("key") != key:
             wl, wr = w.detach()[:, :c].contiguous(), w.detach()[:, c:].contiguous()
             plans.update(key=key, left=ops.Conv3dLayer(wl, 3, 1, 1, 1, False), right=ops.Conv3dLayer(wr, 3, 1, 1, 1, False),

@@ -44,6 +44,26 @@ def _cubic(v, what):
     return int(v)
 
 
+_GENERATION = [0]   # bumped by invalidate_plans(): part of every cache key
+
+
+def invalidate_plans(module: Optional[nn.Module] = None) -> None:
+    """Drop the packed-weight / folded-BatchNorm / dgrad / factored-conv caches.
+
+    The caches are keyed on ``(data_ptr, tensor._version, device)``.  Every in-place update that goes
+    through autograd-visible tensors (``optimizer.step()``, ``load_state_dict``, ``p.copy_()`` under
+    ``no_grad``, ``p.detach().mul_()``) bumps ``_version`` and invalidates them by itself.  Writes through
+    ``.data`` (``p.data.mul_(2)``, an EMA swap that assigns ``.data`` storage in place) do NOT bump it: after
+    such a write call this function -- for one module tree, or with no argument for every model of the
+    process (a generation counter in the keys)."""
+    if module is None:
+        _GENERATION[0] += 1
+        return
+    for m in module.modules():
+        m.__dict__.pop("_snvc_plans", None)
+        m.__dict__.pop("_snvc_factored", None)
+
+
 class _Plan:
     """Packed weights + folded affine for one conv(+norm) pair, rebuilt when parameters change."""
 
@@ -71,7 +91,7 @@ def _conv_geometry(conv: nn.Module):
 
 def _get_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.device)
+    key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
     if plan.layer is None or plan.key != key:
         k, s, p, d, transposed = _conv_geometry(conv)
         plan.layer = ops.Conv3dLayer(w.detach(), k, s, p, d, transposed)
@@ -82,7 +102,8 @@ def _get_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
 def _folded_bn(bn: nn.BatchNorm3d, plan: _Plan):
     """Eval-mode BatchNorm3d as y = x*scale + bias (fp64 fold, cast once)."""
     key = (bn.weight._version if bn.weight is not None else -1, bn.bias._version if bn.bias is not None else -1,
-           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_mean.device)
+           bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(), bn.running_mean.device,
+           _GENERATION[0])
     if plan.scale is None or getattr(plan, "bn_key", None) != key:
         var = bn.running_var.detach().double()
         mean = bn.running_mean.detach().double()
@@ -136,7 +157,7 @@ def _dgrad_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
     Conv3d(k3,s2,p1) -> ConvTranspose3d(k3,s2,p1,op1) over the SAME weight memory;
     ConvTranspose3d  -> Conv3d(k3,s2,p1) over the SAME weight memory."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.device)
+    key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
     if getattr(plan, "dgrad", None) is None or plan.dgrad_key != key:
         k, s, p, d, transposed = _conv_geometry(conv)
         wd = w.detach()
@@ -159,6 +180,11 @@ class _ConvNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv, norm, flags, plan):
         layer = _get_layer(conv, plan)
+        if layer.stride == 2 and not layer.transposed and any(int(s) % 2 for s in x.shape[2:]):
+            # the data gradient of Conv3d(k3,s2,p1) runs on the ConvTranspose3d(k3,s2,p1,op1) kernel, whose
+            # output is exactly 2x its input: an odd extent would come back one element too large
+            raise NotImplementedError("training through a stride-2 3D convolution needs even input extents "
+                                      f"(got {tuple(x.shape[2:])}); the reference's hourglasses require it too")
         # training keeps the k5 / k7 layers on the direct kernel (exact fp32 FMA chain): the F(4,7) forward is
         # 1e-4 off, inside the 1e-3 contract but enough to flip ReLU masks and blur gradient comparisons
         y, raw, scale, shift, mean, var, per_sample = _norm_forward(layer, norm, plan, x, residual, flags, None, True,

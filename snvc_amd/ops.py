@@ -7,8 +7,10 @@ PyTorch is plumbing here: it owns device memory and the HIP stream.  Every funct
   * allocates outputs with the input's dtype/device (at::empty / at::zeros there),
   * launches on ``torch.cuda.current_stream()`` without synchronising.
 """
+import contextlib
 import ctypes
 import math
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -19,11 +21,32 @@ from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, C
 
 __all__ = [
     "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
-    "Conv3dLayer", "conv3d_wgrad", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
+    "Conv3dLayer", "conv_variant", "conv3d_wgrad", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
     "points_in_boxes_gpu", "points_in_boxes_cpu",
     "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID",
 ]
+
+
+_variant = threading.local()
+
+
+@contextlib.contextmanager
+def conv_variant(algo_bits: int):
+    """Within the block every conv3d / wgrad launch of this thread carries ``algo_bits`` in
+    ``snvc_conv3d_desc.algo`` (the SNVC_ALGO_* kernel-form selectors of include/snvc_hip.h):
+    how the parity tests and the tuning scripts reach every instantiated kernel form."""
+    prev = getattr(_variant, "bits", 0)
+    _variant.bits = int(algo_bits)
+    try:
+        yield
+    finally:
+        _variant.bits = prev
+
+
+def _algo(exact: bool = False) -> int:
+    bits = getattr(_variant, "bits", 0)
+    return (bits | _lib.ALGO_DIRECT) if exact else bits
 
 
 def _gpu(t: torch.Tensor, name: str):
@@ -250,7 +273,7 @@ class Conv3dLayer:
             return out
         d = self._desc(n, in_sp, flags, _batch_stride(x), _batch_stride(out),
                        _batch_stride(residual) if residual is not None else 0)
-        d.algo = 1 if exact else 0
+        d.algo = _algo(exact)
         if depth_planes is not None:
             if tuple(depth_planes.shape) != (n, self.cout, 3) + out_shape[3:] or not depth_planes.is_contiguous():
                 raise RuntimeError("depth_planes must be a contiguous [N,Cout,3,H,W] tensor")
@@ -279,6 +302,7 @@ def conv3d_forward_head(layer: "Conv3dLayer", x, scale, bias, residual, flags, h
     if n == 0:
         return out
     d = layer._desc(n, in_sp, flags, _batch_stride(x), 0, _batch_stride(residual) if residual is not None else 0)
+    d.algo = _algo()
     hw = head_weight.detach().reshape(-1).contiguous()
     with torch.cuda.device(x.device):
         rc = _lib.lib().snvc_conv3d_forward_head(ctypes.byref(d), _ptr(x), _ptr(layer.packed), _ptr(scale), _ptr(bias),
@@ -304,7 +328,7 @@ def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: in
     d.Cout = g_small.shape[1]
     d.Dout, d.Hout, d.Wout = g_small.shape[2:]
     d.ksize, d.stride, d.dilation, d.pad = ksize, stride, dilation, pad
-    d.transposed, d.flags = 0, 0
+    d.transposed, d.flags, d.algo = 0, 0, _algo()
     d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = _batch_stride(x_big), _batch_stride(g_small), 0
     nbytes = _lib.lib().snvc_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x_big.device)

@@ -70,28 +70,40 @@ def gather_outputs(local: torch.Tensor, n_items: int) -> torch.Tensor:
 
 
 def all_reduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = True) -> int:
-    """Sums (averages) .grad of every parameter across ranks with ONE flat-bucket all-reduce.
+    """Sums (averages) .grad of every trainable parameter across ranks with ONE flat-bucket all-reduce.
+    The bucket covers EVERY ``requires_grad`` parameter in iteration order -- a parameter whose ``.grad`` is
+    None on this rank (an unused head, a skipped branch) contributes zeros and receives the reduced
+    value -- so the bucket has the same length and layout on all ranks whatever each rank's graph touched.
     Returns the number of bytes moved per rank (0 when single-process)."""
     rank, w = world()
-    grads = [p.grad for p in params if p.grad is not None]
-    if w == 1 or not grads:
+    plist = [p for p in params if p.requires_grad]
+    if w == 1 or not plist:
         return 0
-    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in plist])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat /= w
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+    for p in plist:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p).to(p.dtype)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
         off += n
     return flat.numel() * 4
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
-    """One-time parameter/buffer placement (DataParallel repeats this on every forward)."""
+    """One-time parameter/buffer placement (DataParallel repeats this on every forward).  The broadcast
+    writes into the parameters' storage without going through autograd, so the packed-weight caches of the
+    HIP layers are dropped explicitly afterwards."""
     _, w = world()
     if w == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.detach(), src=src)
+    from .models.submodule import invalidate_plans
+    invalidate_plans(module)

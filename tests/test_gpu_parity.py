@@ -1,9 +1,10 @@
 """GPU parity: the HIP path (through the C ABI in libsnvc_hip.so) against the CPU oracle and the
 golden vectors generated from the imported reference.  Run with ``pytest -m gpu`` on an MI355X.
 
-Tolerance: BASELINE.json's north_star asks for 1e-3 relative fp32; the checks below use
-REL = 1e-3 on max|err| / max|ref| as the contract and additionally report / bound the much
-tighter error the exact-fp32 MFMA path actually achieves.  Integer outputs are bit-exact.
+Tolerance: BASELINE.json's north_star asks for 1e-3 relative fp32.  `check` applies it twice -- on
+max|err| / max|ref| and ELEMENT BY ELEMENT (|err| <= 1e-3*|ref| + 1e-3*rms(ref) for >= 99.99 % of
+the elements, see `elementwise_tail`) -- and additionally bounds the much tighter error the
+exact-fp32 MFMA path actually achieves.  Integer outputs are bit-exact.
 """
 import numpy as np
 import pytest
@@ -28,11 +29,29 @@ def rel_err(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def elementwise_tail(a, b, rel=REL):
+    """north_star's "1e-3 relative", element by element: an element passes when
+    |err| <= rel*|ref| + rel*rms(ref) (the rms term is the absolute floor for elements near zero,
+    where a pure ratio is meaningless after ReLU / cancellation).  Returns (fraction failing, worst
+    |err| / (rel*|ref| + rel*rms))."""
+    a = np.asarray(a, dtype=np.float64).ravel()
+    b = np.asarray(b, dtype=np.float64).ravel()
+    rms = np.sqrt(np.mean(b * b)) if b.size else 0.0
+    bound = rel * np.abs(b) + rel * max(rms, 1e-30)
+    ratio = np.abs(a - b) / bound
+    return float((ratio > 1.0).mean()) if b.size else 0.0, float(ratio.max()) if b.size else 0.0
+
+
 def check(a, b, tol=TIGHT, what=""):
+    """Three criteria: (1) the contract on the max-normalised error, (2) the tighter bound the exact-fp32
+    path is expected to meet, (3) the ELEMENTWISE contract: at most 0.01 % of the elements may miss
+    1e-3*|ref| + 1e-3*rms(ref), and none by more than 10x."""
     assert a.shape == b.shape, (what, a.shape, b.shape)
     e = rel_err(a, b)
     assert e <= REL, f"{what}: rel err {e:.3e} breaks the 1e-3 contract"
     assert e <= tol, f"{what}: rel err {e:.3e} above the expected {tol:.1e}"
+    frac, worst = elementwise_tail(a, b)
+    assert frac <= 1e-4 and worst <= 10.0, f"{what}: elementwise 1e-3 criterion: {100 * frac:.4f} % of elements outside, worst {worst:.2f}x"
 
 
 @pytest.fixture(scope="module")
@@ -182,9 +201,17 @@ def test_voxel_gather_vs_torch_ref_edge_cases():
     gl, gr = torch.from_numpy(pts), torch.from_numpy(pts[:, :, ::-1].copy())
     exp = T.sample_2d_feat(lf, rf, gl, gr, res, grid).reshape(n, 2 * f, v)
     got = ops.voxel_gather_forward(lf.to(dev()), rf.to(dev()), gl.to(dev()), gr.to(dev()), res).cpu()
-    finite = torch.isfinite(exp)
-    assert torch.equal(torch.isfinite(got), finite) or True   # NaN coordinate: torch yields NaN or 0 by version
-    m = finite & torch.isfinite(got)
+    # Non-finite coordinates (NaN, 1e9): pinned to the oracle (oracle/numpy_ref.py, the restatement of ATen's CPU
+    # arithmetic): no tap is in range, the four weights are NaN, 0 * NaN = NaN -> the voxel's channels are NaN on
+    # that camera's half and finite on the other; the 1e9 coordinate gives finite weights times zero taps = 0.
+    from oracle import numpy_ref as NR
+    exp_np = NR.sample_2d_feat(lf.numpy(), rf.numpy(), gl.numpy(), gr.numpy(), res)
+    assert np.array_equal(got.numpy(), exp_np, equal_nan=True)
+    assert np.isnan(got.numpy()[1, :f, 0]).all() and np.isfinite(got.numpy()[1, f:, 0]).all()
+    assert (got.numpy()[0, :f, 3] == 0).all()
+    # and against torch's grid_sample wherever torch is finite
+    m = torch.isfinite(exp) & torch.isfinite(got)
+    assert m.float().mean() > 0.98
     check(got[m].numpy(), exp[m].numpy(), 1e-6, "gather edge cases")
 
 
@@ -289,7 +316,7 @@ def test_k5_k7_winograd_vs_torch(k, dil, W):
 
 
 @pytest.mark.parametrize("W", [40, 72, 44])
-def test_k3_stride2_winograd_vs_torch(W, monkeypatch):
+def test_k3_stride2_winograd_vs_torch(W):
     """Stride-2 3x3x3 layers: the polyphase + F(4,2) kernel (output width % 4 == 0) and the direct kernel
     (everything else, and desc.algo = SNVC_ALGO_DIRECT) against torch, batch 2, two channel groups, ragged tiles."""
     import torch.nn.functional as F
@@ -306,9 +333,11 @@ def test_k3_stride2_winograd_vs_torch(W, monkeypatch):
             check(m(x.to(dev())).cpu().numpy(), ref.numpy(), TIGHT, f"s2 W={W} conv+bn")
             y = m.fused(x.to(dev()), relu=True, residual=res.to(dev()))
             check(y.cpu().numpy(), F.relu(ref + res).numpy(), TIGHT, f"s2 W={W} relu(conv+res)")
-            monkeypatch.setenv("SNVC_NO_WINOGRAD", "1")
-            check(m(x.to(dev())).cpu().numpy(), ref.numpy(), TIGHT, f"s2 W={W} direct")
-            monkeypatch.delenv("SNVC_NO_WINOGRAD")
+            from snvc_amd import _lib, ops
+            with ops.conv_variant(_lib.ALGO_DIRECT):
+                check(m(x.to(dev())).cpu().numpy(), ref.numpy(), TIGHT, f"s2 W={W} direct")
+            with ops.conv_variant(_lib.ALGO_DIRECT | _lib.ALGO_GENERIC_EPILOGUE):
+                check(m(x.to(dev())).cpu().numpy(), ref.numpy(), TIGHT, f"s2 W={W} direct, generic epilogue")
 
 
 def test_conv3d_epilogue_variants_and_slices():
@@ -344,22 +373,21 @@ def test_conv3d_epilogue_variants_and_slices():
 
 @pytest.mark.parametrize("mode", ["default", "big", "std", "narrow", "direct"])
 @pytest.mark.parametrize("W", [72, 78, 156])
-def test_k3_kernel_variants_vs_torch(mode, W, monkeypatch):
+def test_k3_kernel_variants_vs_torch(mode, W):
     """Every 3x3x3 / stride-1 kernel the dispatcher can pick -- Winograd F(4,3) with the 2x4x64
     register-staged tile, the 4x4x64 LDS-DMA tile, the 4x4x32 tile, their 8-byte-row versions
     (W % 4 == 2) and the direct kernel -- against torch's fp32 convolution, with the fused epilogue
     forms (BN affine + residual before / after ReLU) and tile-ragged D and H."""
     import torch.nn.functional as F
     from snvc_amd.models import submodule as S
-    if mode == "direct":
-        monkeypatch.setenv("SNVC_NO_WINOGRAD", "1")
-    elif mode != "default":
-        monkeypatch.setenv("SNVC_WINO_TILE", mode)
+    from snvc_amd import _lib, ops
+    bits = {"default": 0, "big": _lib.ALGO_WINO_TILE_BIG, "std": _lib.ALGO_WINO_TILE_STD,
+            "narrow": _lib.ALGO_WINO_TILE_NARROW_REG, "direct": _lib.ALGO_DIRECT}[mode]
     r = np.random.default_rng(31 + W)
     for cin, cout, shape in ((32, 32, (5, 7, W)), (6, 64, (2, 9, W))):
         m = seeded(S.convbn_3d(cin, cout, 3, 1, 1), 40 + cin)
         x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32))
-        with torch.no_grad():
+        with torch.no_grad(), ops.conv_variant(bits):
             ref = F.batch_norm(F.conv3d(x, m[0].weight, None, 1, 1), m[1].running_mean, m[1].running_var,
                                m[1].weight, m[1].bias, False, 0.0, m[1].eps)
             res = torch.from_numpy(r.standard_normal(tuple(ref.shape)).astype(np.float32))
@@ -675,10 +703,12 @@ def test_global_stack_vs_golden(name, G):
 
 
 @pytest.mark.parametrize("tile", ["default", "big", "narrow"])
-def test_global_pair_end_to_end_vs_oracle(tile, monkeypatch):
+def test_global_pair_end_to_end_vs_oracle(tile):
     """cost-volume build + 3D CNN forward (the benchmarked unit) against C oracle + torch-CPU."""
-    if tile != "default":
-        monkeypatch.setenv("SNVC_WINO_TILE", tile)   # depth-class planes through every Winograd tile form
+    from snvc_amd import _lib, ops
+    # depth-class planes through every Winograd tile form
+    bits = {"default": 0, "big": _lib.ALGO_WINO_TILE_BIG, "std": _lib.ALGO_WINO_TILE_STD,
+            "narrow": _lib.ALGO_WINO_TILE_NARROW_REG}[tile]
     from oracle import native as O
     from oracle import torch_ref as T
     from snvc_amd.models.stereo_volume import GlobalStack
@@ -690,13 +720,12 @@ def test_global_pair_end_to_end_vs_oracle(tile, monkeypatch):
     ref = seeded(T.GlobalStack(C), 42)
     ours = seeded(GlobalStack(C), 42).to(dev())
     dl, dr, dsh = torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()), torch.from_numpy(s).to(dev())
-    with torch.no_grad():
+    with torch.no_grad(), ops.conv_variant(bits):
         vol_ref = O.cost_volume_forward(L, R, s, 1)
         exp = ref(torch.from_numpy(vol_ref)).numpy()
         got_fact = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()                   # factored first conv
         got_full = ours.forward_pair(dl, dr, dsh, 1, factored=False).cpu().numpy()   # materialised volume
         # the right-half builder is the full builder's right half, bit for bit
-        from snvc_amd import ops
         assert np.array_equal(ops.cost_volume_forward_right(dr, dsh).cpu().numpy(), vol_ref[:, C:])
         # first layer alone: factored == full convolution over the concat volume
         full1 = ours.conv1(torch.from_numpy(vol_ref).to(dev())).cpu().numpy()

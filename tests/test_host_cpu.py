@@ -133,3 +133,28 @@ def test_points_in_boxes_cpu_host_op(L):
     idmap = U.points_in_boxes_cpu_idmap(pts, boxes)
     assert idmap.shape == (2000,) and idmap.max() >= 0 and idmap.min() == -1
     assert U.points_in_boxes_cpu_idmap(pts, boxes[:0]).tolist() == [-1] * 2000
+    # idmap = the largest index among the containing boxes (what the reference's loop + max(0) yields)
+    exp_id = np.where(exp > 0, np.arange(len(boxes))[:, None], -1).max(0)
+    assert np.array_equal(idmap, exp_id) and idmap.dtype == np.int32
+
+
+def test_plan_caches_follow_parameter_updates():
+    """Folded-BatchNorm / packed-weight caches are keyed on tensor versions: autograd-visible in-place
+    updates invalidate them by themselves; `.data` writes need invalidate_plans()."""
+    from snvc_amd.models import submodule as S
+    bn = torch.nn.BatchNorm3d(4).eval()
+    plan = S._Plan()
+    sc0, _ = S._folded_bn(bn, plan)
+    sc0 = sc0.clone()
+    with torch.no_grad():
+        bn.weight.mul_(2.0)                       # bumps _version
+    sc1, _ = S._folded_bn(bn, plan)
+    assert torch.allclose(sc1, 2 * sc0)
+    bn.weight.data.mul_(2.0)                      # does NOT bump _version: stale until invalidated
+    assert torch.allclose(S._folded_bn(bn, plan)[0], 2 * sc0)
+    S.invalidate_plans()                          # generation counter: every cache of the process
+    assert torch.allclose(S._folded_bn(bn, plan)[0], 4 * sc0)
+    m = S.convbn_3d(4, 4, 3, 1, 1)
+    m[0].__dict__["_snvc_plans"] = {"cpu": S._Plan()}
+    S.invalidate_plans(m)                         # per-module form drops the per-device plan table
+    assert "_snvc_plans" not in m[0].__dict__

@@ -56,6 +56,21 @@ def _worker(rank, world, port, q):
         for p, p2, l in zip(net.parameters(), net2.parameters(), local):
             assert torch.allclose(p.grad, p2.grad, rtol=1e-5, atol=1e-5)
             assert not torch.allclose(l, p2.grad)          # the local gradient alone is different
+        # a parameter without a gradient on ONE rank only (an unused head): the bucket keeps the same layout
+        # on every rank, the missing gradient counts as zeros and comes back as the reduced value
+        head = torch.nn.Linear(2, 2)
+        P.broadcast_parameters(head, src=0)
+        for p in list(net.parameters()) + list(head.parameters()):
+            p.grad = None
+        y = net(mine)
+        (y.pow(2).sum() + (head(y).sum() if rank == 0 else 0.0)).backward()
+        assert (head.weight.grad is None) == (rank == 1)
+        params = list(net.parameters()) + list(head.parameters())
+        moved = P.all_reduce_gradients(params, average=False)
+        assert moved == sum(p.numel() for p in params) * 4
+        g = [torch.zeros_like(head.weight.grad) for _ in range(world)]
+        dist.all_gather(g, head.weight.grad)
+        assert torch.equal(g[0], g[1]) and g[0].abs().sum() > 0
         q.put((rank, "ok"))
     finally:
         dist.destroy_process_group()
