@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Headline benchmark: stereo-pairs/sec, cost-volume build + 3D CNN forward (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (starts N ranks itself when N > 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --mode train                    (cfg4: fwd + bwd + RCCL gradient all-reduce)
 
 Workload (N=1): BASELINE.json configs[1], "Global scene model: 1242x375, 192 disparities, full 3D
 hourglass fwd, batch=1 on 1 MI355X", synthesised as SURVEY.md section 8(d) cfg2:
@@ -13,19 +14,29 @@ random-init weights, fp32.  A step = one pair through build_cost_volume + the 3D
 resident in HBM.  Multi-GPU = one process per GPU, each with its own pair (batch sharding, no
 data-path collective): weak scaling.
 
-One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel, the first 3x3x3
-convolution (factored: 32->32 over the warped half of the volume, 318 GFLOP per launch; Winograd
-F(4,3) along W on the fp32 MFMA pipe), timed with events on the launch stream inside the timed
-loop: `achieved` prices the algorithmic FLOPs, `mfma_pipe_frac` the executed ones.  `materialized`
-repeats the measurement with the full concat volume built and convolved (64->32, 636 GFLOP).
-`cpu_baseline` times the CPU oracle (C cost volume + torch-CPU stack) on a bounded sample on rank 0
-at N=1.
+One JSON line on stdout (rank 0):
+  value / ms_per_step  the step through the fused entry point GlobalStack.forward_pair (factored first
+                       convolution); `materialized` repeats it through the reference's own operator API
+                       (build_cost_volume(...) then the modules) -- config.entry_points says which is which
+  roofline             dominant kernel (first 3x3x3 convolution), events on the launch stream inside the
+                       timed loop.  `frac` = EXECUTED MFMA flops / launch time / fp32-MFMA peak (<= 1: the
+                       Winograd F(4,3) kernel issues 6 of the direct form's 12 multiplies);
+                       `algorithmic_over_peak` prices the convolution's algorithmic flops instead
+  roofline_hbm         the cost-volume builders (HBM-write bound), same event timing
+  configs              the other BASELINE configs on this GPU (N=1 only): cfg3 96^3 crops, the released
+                       local shape, cfg5 high-res, cfg4 training step; each with its dominant kernel's
+                       executed pipe fraction; gather bandwidth on projected and on uniform coordinates
+  train                (every N) cfg4 step incl. the RCCL flat-bucket gradient all-reduce
+  cpu_baseline         CPU oracle (C/OpenMP cost volume + torch-CPU stack) on one full cfg2 pair, rank 0, N=1
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -36,10 +47,19 @@ import torch  # noqa: E402
 
 C, H, W, D = 32, 96, 312, 192
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-CONV1_FLOP = 2.0 * D * H * W * (2 * C) * C * 27           # algorithmic FLOP of the dominant launch
-WINO_EXECUTED = (6.0 / 12.0) * (320.0 / 312.0)                  # F(4,3) MFMA share x 64-wide tile padding of W=312
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/F16 dense (no sparsity)
+PEAK_HBM_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E
+CONV1_FLOP = 2.0 * D * H * W * (2 * C) * C * 27           # algorithmic FLOP of the materialised first conv
 STEP_FLOP = 1332.0e9                                      # SURVEY.md section 8(d), cfg2 3D stack
-STEP_BYTES = 1479.9e6                                     # cost-volume build, algorithmic bytes
+CV_BYTES = 4.0 * (2 * C * D * H * W + 2 * C * H * W + D)  # a1 algorithmic bytes per pair = 1479.9 MB
+CV_RIGHT_BYTES = 4.0 * (C * D * H * W + C * H * W + D)    # right half only
+
+
+def wino_executed_share(ksize, w, tile_w=32):
+    """Share of a layer's algorithmic multiply-adds the Winograd F(4,k)-along-W kernels put on the
+    matrix pipe: (k+3)/(4k) x the padding of W to whole tiles."""
+    pad = (-(-w // tile_w) * tile_w) / float(w)
+    return (ksize + 3.0) / (4.0 * ksize) * pad
 
 
 def make_inputs(rank, device, d=D):
@@ -63,14 +83,16 @@ def seeded_state(model, seed=2024):
             sd[k] = torch.from_numpy(g.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
         elif v.dim() == 1 and k.endswith("bias"):
             sd[k] = torch.from_numpy(g.uniform(-0.2, 0.2, tuple(v.shape)).astype(np.float32))
-        elif v.dim() == 5:
+        elif v.dim() >= 4:
             fan_in = int(np.prod(v.shape[1:]))
             sd[k] = torch.from_numpy((g.standard_normal(tuple(v.shape)) * np.sqrt(2.0 / fan_in)).astype(np.float32))
     return sd
 
 
-def cpu_baseline(d_sample=64, repeats=1):
-    """CPU oracle on cfg1 (D = 64 planes of the same pair): C cost volume + torch-CPU 3D stack."""
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(d_sample=D):
+    """CPU oracle on ONE FULL cfg2 pair (all 192 planes, measured, not scaled): C/OpenMP cost volume +
+    torch-CPU 3D stack, every host core."""
     from oracle import native as O
     from oracle import torch_ref as T
     cores = os.cpu_count() or 1
@@ -80,25 +102,203 @@ def cpu_baseline(d_sample=64, repeats=1):
     ref.load_state_dict(seeded_state(ref))
     ref.eval()
     ln, rn, sn = left.numpy(), right.numpy(), shift.numpy()
-    best = None
-    t_cv = t_cnn = 0.0
-    for _ in range(repeats):
-        t0 = time.perf_counter()
-        vol = O.cost_volume_forward(ln, rn, sn, 1)
-        t1 = time.perf_counter()
-        with torch.no_grad():
-            ref(torch.from_numpy(vol))
-        t2 = time.perf_counter()
-        if best is None or (t2 - t0) < best:
-            best, t_cv, t_cnn = t2 - t0, t1 - t0, t2 - t1
-    # scale the 64-plane time to a 192-plane pair (both stages are linear in D)
-    pairs_per_s = 1.0 / (best * D / d_sample)
+    t0 = time.perf_counter()
+    vol = O.cost_volume_forward(ln, rn, sn, 1)
+    t1 = time.perf_counter()
+    with torch.no_grad():
+        ref(torch.from_numpy(vol))
+    t2 = time.perf_counter()
+    scale = D / float(d_sample)
     return {
-        "value": pairs_per_s, "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
-        "sample": f"1 pair at D={d_sample} of {D} planes (cfg1 size), {best:.2f}s "
-                  f"(cost volume C oracle 1 thread {t_cv:.2f}s + torch-CPU 3D stack {cores} threads {t_cnn:.2f}s), "
-                  f"scaled x{D // d_sample} to a {D}-plane pair; torch {torch.__version__}",
+        "value": 1.0 / ((t2 - t0) * scale), "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
+        "sample": f"1 pair, {d_sample} of {D} disparity planes{'' if d_sample == D else ' (scaled)'}: {t2 - t0:.2f}s = "
+                  f"cost volume (C oracle, OpenMP, {cores} threads) {t1 - t0:.2f}s + 3D stack (torch-CPU {torch.__version__}, "
+                  f"{cores} threads) {t2 - t1:.2f}s",
     }
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def timed_ms(fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        out = fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps, out
+
+
+def projected_coordinates(n, grid, device, res=256.0):
+    """grid_proj_left / grid_proj_right as the data loader would produce them: GridProjector (the HIP
+    restatement of refinementDataset._generate_grid_proj) on KITTI-like calibration, car-sized boxes, and a
+    crop affine that maps each box's projected bounding rectangle (+20 %) onto the res x res RoI crop."""
+    from snvc_amd.geometry import GridProjector
+    P2 = np.array([7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01, 0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01,
+                   0.0, 0.0, 1.0, 2.745884e-03]).reshape(3, 4)
+    P3 = P2.copy()
+    P3[0, 3], P3[1, 3] = -3.395242e+02, 2.199936e+00
+    r = np.random.default_rng(99)
+    samples = np.stack([np.array([1.5 + 0.1 * r.random(), 1.6 + 0.1 * r.random(), 3.9 + 0.4 * r.random(),
+                                  r.uniform(-8, 8), 1.65, r.uniform(8, 40), r.uniform(-np.pi, np.pi)]) for _ in range(n)])
+    xr, yr, zr = (-1.6, 1.6), (-0.8, 0.8), (-2.4, 2.4)
+    tl, tr = np.zeros((n, 2, 3)), np.zeros((n, 2, 3))
+    for i, s in enumerate(samples):
+        ry = s[6] + 0.5 * np.pi
+        rot = np.array([[np.cos(ry), 0, np.sin(ry)], [0, 1, 0], [-np.sin(ry), 0, np.cos(ry)]])
+        corners = np.array([[x, y, z] for x in xr for y in yr for z in zr]).T
+        cam = rot @ corners + np.array([[s[3]], [s[4] - 0.5 * s[0]], [s[5]]])
+        for P, t in ((P2, tl), (P3, tr)):
+            uvw = P @ np.vstack([cam, np.ones((1, 8))])
+            uv = uvw[:2] / uvw[2:]
+            lo, hi = uv.min(1), uv.max(1)
+            ctr, ext = 0.5 * (lo + hi), 1.2 * (hi - lo)
+            t[i, 0, 0], t[i, 1, 1] = res / ext[0], res / ext[1]
+            t[i, 0, 2], t[i, 1, 2] = 0.5 * res - ctr[0] * t[i, 0, 0], 0.5 * res - ctr[1] * t[i, 1, 1]
+    cfg = types.SimpleNamespace(x_range=xr, y_range=yr, z_range=zr, grid_resolution=list(grid))
+    return GridProjector(cfg).generate(samples, P2, P3, tl, tr, device)
+
+
+def local_config(name, grid, F, crops, device, reps=3, heads=False):
+    """gather + 3D trunk of the local (V-A) model on `crops` RoI crops; returns the `configs` entry."""
+    from snvc_amd.models.vernier import VernierScale
+    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False,
+                                grid_resolution=[32, grid[1], 192], resolution=(256, 256),
+                                x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
+    cfg.hrfeat = types.SimpleNamespace(output_channel=F, name="identity")
+    cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
+    m = VernierScale(cfg)
+    m.load_state_dict(seeded_state(m))
+    m.eval().to(device)
+    r = np.random.default_rng(5)
+    v = grid[0] * grid[1] * grid[2]
+    lf = torch.from_numpy(r.standard_normal((crops, F, 64, 64)).astype(np.float32)).to(device)
+    rf = torch.from_numpy(r.standard_normal((crops, F, 64, 64)).astype(np.float32)).to(device)
+    # SURVEY 8(d): uniform coordinates in [-8, 264) px (~6 % outside the crop)
+    gl = torch.from_numpy(r.uniform(-8, 264, (crops, 2, v)).astype(np.float32)).to(device)
+    gr = torch.from_numpy(r.uniform(-8, 264, (crops, 2, v)).astype(np.float32)).to(device)
+    pl, pr = projected_coordinates(crops, grid, device)
+    gather_bytes = crops * (v * (16 + 8 * F) + 2 * F * 64 * 64 * 4)
+    conv1_flop = 2.0 * crops * v * (2 * F) * F * 343
+    out = {"grid": list(grid), "F": F, "crops_per_call": crops, "dtype": "f32"}
+    with torch.no_grad():
+        ms_u, vox = timed_ms(lambda: m.construct_voxel(lf, rf, gl, gr), reps)
+        ms_p, _ = timed_ms(lambda: m.construct_voxel(lf, rf, pl, pr), reps)
+        ms_c1, _ = timed_ms(lambda: m.conv1(vox), reps)
+        del vox
+        ms, res = timed_ms(lambda: m.trunk_3d(m.construct_voxel(lf, rf, pl, pr)), reps)
+        assert torch.isfinite(res[0]).all()
+        if heads:
+            ms_h, _ = timed_ms(lambda: m.heads_2d(res[0]), reps)
+            out["heads_2d_ms_per_crop"] = ms_h / crops
+    share = wino_executed_share(7, grid[2])
+    out.update({
+        "ms_per_crop": ms / crops, "crops_per_s": 1e3 * crops / ms,
+        "dominant_kernel": f"conv3d_winok_kernel<k7> {2 * F}->{F} (Winograd F(4,7) along W, fp32 MFMA)",
+        "dominant_ms": ms_c1, "dominant_gflop_algorithmic": conv1_flop / 1e9,
+        "dominant_pipe_frac": conv1_flop * share / (ms_c1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "gather_projected": {"ms": ms_p, "GBps": gather_bytes / (ms_p * 1e-3) / 1e9,
+                             "frac_hbm": gather_bytes / (ms_p * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                             "coords": "GridProjector on KITTI-like calibration, car-sized boxes"},
+        "gather_uniform": {"ms": ms_u, "GBps": gather_bytes / (ms_u * 1e-3) / 1e9,
+                           "frac_hbm": gather_bytes / (ms_u * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                           "coords": "uniform in [-8, 264) px (SURVEY 8d)"},
+        "gather_bytes_algorithmic": gather_bytes,
+    })
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
+class TrainStep:
+    """cfg4: build_cost_volume + GlobalStack forward (train-mode BatchNorm), loss = mean(cost^2), backward through
+    the HIP kernels, then the flat-bucket gradient all-reduce (RCCL when world > 1)."""
+
+    def __init__(self, rank, device):
+        from snvc_amd.models.stereo_volume import GlobalStack
+        self.model = GlobalStack(C)
+        self.model.load_state_dict(seeded_state(self.model))
+        self.model.train().to(device)
+        self.left, self.right, self.shift = make_inputs(rank, device)
+        self.left.requires_grad_()
+        self.right.requires_grad_()
+        self.ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self.nparam = sum(p.numel() for p in self.model.parameters())
+
+    def __call__(self):
+        from snvc_amd import parallel as P
+        for p in self.model.parameters():
+            p.grad = None
+        self.left.grad = self.right.grad = None
+        self.ev[0].record()
+        out = self.model.forward_pair(self.left, self.right, self.shift, 1)
+        loss = out.pow(2).mean()
+        self.ev[1].record()
+        loss.backward()
+        self.ev[2].record()
+        self.moved = P.all_reduce_gradients(self.model.parameters())
+        self.ev[3].record()
+        return loss
+
+    def phases_ms(self):
+        return [self.ev[i].elapsed_time(self.ev[i + 1]) for i in range(3)]
+
+
+def run_train(rank, world, device, dist, steps, warmup, barrier):
+    ts = TrainStep(rank, device)
+    for _ in range(warmup):
+        ts()
+    barrier()
+    acc = np.zeros(3)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = ts()
+        torch.cuda.synchronize()
+        acc += np.array(ts.phases_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss)
+    f, b, r = acc / steps
+    res = {
+        "workload": "cfg4: 1 pair/GPU at cfg2 size, train-mode BatchNorm, loss = mean(cost^2), fwd + bwd on the HIP "
+                    "kernels + flat-bucket gradient all-reduce",
+        "ms_per_step": 1e3 * elapsed / steps, "pairs_per_s": world * steps / elapsed,
+        "fwd_ms": f, "bwd_ms": b, "allreduce_us": 1e3 * r, "allreduce_bytes": ts.moved, "params": ts.nparam,
+        "step_tflops_algorithmic": 3 * STEP_FLOP / (elapsed / steps) / 1e12, "steps": steps,
+    }
+    del ts
+    torch.cuda.empty_cache()
+    return res
+
+
+# ------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) BEFORE anything in
+    this process touches the GPU (torch.cuda.device_count() does not initialise it), wait for them and exit
+    with the worst exit code.  Rank 0 inherits stdout, so the JSON line comes out as usual."""
+    ndev = torch.cuda.device_count()
+    if ndev < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible on this node")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
 
 
 def main():
@@ -106,14 +306,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer: the headline metric (+ extras); train: cfg4 step as the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `configs` / `train` legs")
     ap.add_argument("--breakdown", action="store_true", help="per-layer timing on stderr (extra untimed pass)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
@@ -125,14 +330,12 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        joined = dist.get_world_size()      # ranks that actually joined the RCCL group
+    else:
+        joined = 1
 
     from snvc_amd.extension.build_cost_volume import build_cost_volume
     from snvc_amd.models.stereo_volume import GlobalStack
-
-    model = GlobalStack(C)
-    model.load_state_dict(seeded_state(model))
-    model.eval().to(device)
-    left, right, shift = make_inputs(rank, device)
 
     def barrier():
         torch.cuda.synchronize()
@@ -140,10 +343,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.mode == "train":
+        tr = run_train(rank, world, device, dist, args.steps, args.warmup, barrier)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "stereo-pairs/sec (training step: cost-volume + 3D CNN fwd+bwd + gradient all-reduce)",
+                "value": tr["pairs_per_s"], "unit": "stereo-pairs/s", "n_gpus": joined, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": tr["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": tr["workload"], "sharding": f"batch x{world}; RCCL all-reduce of "
+                           f"{tr['allreduce_bytes']} gradient bytes per step"},
+                "train": tr}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    model = GlobalStack(C)
+    model.load_state_dict(seeded_state(model))
+    model.eval().to(device)
+    left, right, shift = make_inputs(rank, device)
+
     def run(factored):
-        """W warm-up + K timed steps; returns (seconds for the K steps, mean ms of the first-conv launch)."""
-        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        """W warm-up + K timed steps; returns (seconds for the K steps, mean ms of the first-conv launch,
+        mean ms of the cost-volume launch)."""
+        names = ("volume", "conv1")
+        ev = [{k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in names}
+              for _ in range(args.steps)]
         with torch.no_grad():
             for _ in range(args.warmup):
                 model.forward_pair(left, right, shift, 1, factored=factored)
@@ -151,7 +376,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(args.steps):
                 # events go to torch's current stream == the stream the kernels are launched on
-                out = model.forward_pair(left, right, shift, 1, factored=factored, timing=(ev0[i], ev1[i]))
+                out = model.forward_pair(left, right, shift, 1, factored=factored, timing=ev[i])
             barrier()
             elapsed = time.perf_counter() - t0
         if dist is not None:
@@ -159,35 +384,43 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert torch.isfinite(out).all()
-        return elapsed, float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+        mean = lambda k: float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in ev]))  # noqa: E731
+        return elapsed, mean("conv1"), mean("volume")
 
-    # Headline: factored first convolution (GlobalStack.forward_pair).  For transparency the same step
-    # with the concat volume fully materialised (build_cost_volume + conv1 over all 64 channels) is
-    # timed in the same process and reported alongside.
-    elapsed, conv_ms = run(True)
-    elapsed_mat, conv_ms_mat = run(False)
+    # Headline: factored first convolution (GlobalStack.forward_pair).  The same step through the reference's
+    # operator API (build_cost_volume + conv1 over all 64 channels) is timed in the same process.
+    elapsed, conv_ms, cvr_ms = run(True)
+    elapsed_mat, conv_ms_mat, cv_ms = run(False)
     dom_flop = CONV1_FLOP / 2                       # right half: 32 -> 32 channels, 27 taps
-    achieved = dom_flop / (conv_ms * 1e-3) / 1e12
-    achieved_mat = CONV1_FLOP / (conv_ms_mat * 1e-3) / 1e12
-    # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this
-    # process; they come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, gfx950 correction)
-    # committed in profiles/r1/traffic.json.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1", "traffic.json")) as fh:
-            traffic = json.load(fh).get("conv1_right_wino43_dma_k3_32to32_cfg2", {}).get("hbm_bytes_corrected")
-    except Exception:
-        pass
+    share = wino_executed_share(3, W)               # F(4,3): 6 of 12 multiplies x padding of W=312 to 320
+    exec_tflops = dom_flop * share / (conv_ms * 1e-3) / 1e12
+    alg_tflops = dom_flop / (conv_ms * 1e-3) / 1e12
+    alg_tflops_mat = CONV1_FLOP / (conv_ms_mat * 1e-3) / 1e12
+    # HBM bytes per launch: PMC counters cannot be read from inside this process; separate rocprofv3 --pmc
+    # passes (FETCH_SIZE, WRITE_SIZE, gfx950 correction) are committed under profiles/
+    traffic, traffic_src = None, None
+    for rel in ("profiles/r2/traffic.json", "profiles/r1/traffic.json"):
+        try:
+            with open(os.path.join(ROOT, rel)) as fh:
+                traffic = json.load(fh).get("conv1_right_wino43_dma_k3_32to32_cfg2", {}).get("hbm_bytes_corrected")
+            if traffic is not None:
+                traffic_src = rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                break
+        except Exception:
+            pass
 
     if args.breakdown and rank == 0:
         _breakdown(model, left, right, shift, build_cost_volume)
+    del model
+    torch.cuda.empty_cache()
 
+    line = None
     if rank == 0:
         line = {
             "metric": "stereo-pairs/sec (cost-volume build + 3D CNN fwd)",
             "value": world * args.steps / elapsed,
             "unit": "stereo-pairs/s",
-            "n_gpus": world,
+            "n_gpus": joined,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -199,42 +432,75 @@ def main():
             "config": {
                 "workload": "cfg2 global scene model: 1 pair/GPU, features [1,32,96,312] (1242x375 /4), "
                             "192 disparities -> concat volume [1,64,192,96,312] -> conv3d x2 + hourglass(32) + classifier",
-                "first_conv": "factored: the left half of the concat volume is d-invariant -> 3 depth-class planes + "
-                              "3D conv over the warped right half only; output identical to the materialised path "
-                              "(tests/test_gpu_parity.py::test_global_pair_end_to_end_vs_oracle)",
+                "entry_points": {
+                    "value": "GlobalStack.forward_pair(left, right, shift): fused entry point; the left half of the concat "
+                             "volume is d-invariant -> 3 depth-class planes + 3D conv over the warped right half only "
+                             "(identical output: tests/test_gpu_parity.py::test_global_pair_end_to_end_vs_oracle, "
+                             "tests/test_gpu_fullsize.py)",
+                    "materialized": "the reference's operator API: build_cost_volume(left, right, shift, 1) then the "
+                                    "modules (conv1 over all 64 channels)"},
                 "pairs_per_gpu_per_step": 1,
                 "sharding": f"batch x{world}, no collective",
                 "step_gflop_algorithmic": STEP_FLOP / 1e9,
-                "step_cost_volume_mb_algorithmic": STEP_BYTES / 1e6,
+                "step_cost_volume_mb_algorithmic": CV_BYTES / 1e6,
             },
             "roofline": {
                 "kernel": "conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, planes>: first conv over the right half of the volume, "
                           "32->32 on 192x96x312, + depth-class planes (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)",
                 "bound": "mfma",
-                "achieved": achieved,
+                # `achieved` = flops the kernel EXECUTES on the matrix pipe per second (F(4,3) issues 6 MFMAs where
+                # the direct form needs 12; W = 312 is padded to 320) -> frac <= 1 is the pipe's utilisation.
+                "achieved": exec_tflops,
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": traffic,
-                "traffic_source": "profiles/r1/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                "flop_per_launch": dom_flop,
+                "frac": exec_tflops / PEAK_F32_MFMA_TFLOPS,
+                "algorithmic_tflops": alg_tflops,
+                "algorithmic_over_peak": alg_tflops / PEAK_F32_MFMA_TFLOPS,
+                "flop_per_launch_algorithmic": dom_flop,
+                "flop_per_launch_executed": dom_flop * share,
                 "avg_launch_ms": conv_ms,
-                # `achieved` prices the ALGORITHMIC multiply-adds of the convolution (contract); F(4,3)
-                # issues 6 MFMAs where the direct form needs 12, so the matrix pipe executes half of them
-                # and `frac` may exceed 1.  The pipe's own utilisation is mfma_pipe_frac.
-                "executed_flop_per_launch": dom_flop * WINO_EXECUTED,
-                "mfma_pipe_frac": achieved * WINO_EXECUTED / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+            },
+            "roofline_hbm": {
+                "kernel": "cost_volume_fwd_rows: right (warped) half only, as the fused entry point builds it",
+                "bound": "hbm", "achieved": CV_RIGHT_BYTES / (cvr_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": CV_RIGHT_BYTES / (cvr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": CV_RIGHT_BYTES,
+                "avg_launch_ms": cvr_ms,
+                "full_volume": {"kernel": "cost_volume_fwd_rows: build_cost_volume, both halves (materialized leg)",
+                                "achieved": CV_BYTES / (cv_ms * 1e-3) / 1e9, "frac": CV_BYTES / (cv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                "bytes_per_launch": CV_BYTES, "avg_launch_ms": cv_ms},
             },
             "materialized": {
-                "note": "same step with the full concat volume built by build_cost_volume and conv1 over all 64 channels",
+                "note": "same step through the reference's operator API: build_cost_volume builds the full concat volume, "
+                        "conv1 runs over all 64 channels",
                 "value": world * args.steps / elapsed_mat,
                 "ms_per_step": 1e3 * elapsed_mat / args.steps,
-                "conv1_tflops": achieved_mat,
-                "conv1_frac": achieved_mat / PEAK_F32_MFMA_TFLOPS,
+                "conv1_ms": conv_ms_mat,
+                "conv1_tflops_algorithmic": alg_tflops_mat,
+                "conv1_pipe_frac": alg_tflops_mat * share / PEAK_F32_MFMA_TFLOPS,
                 "conv1_flop_per_launch": CONV1_FLOP,
             },
             "step_tflops_algorithmic": STEP_FLOP / (elapsed / args.steps) / 1e12,
         }
+
+    if not args.no_extras:
+        # cfg4 on every N: the one leg with a collective (RCCL all-reduce of the 3D stack's gradients)
+        tr = run_train(rank, world, device, dist, 3, 1, barrier)
+        if rank == 0:
+            line["train"] = tr
+        if world == 1:
+            cfgs = {}
+            for name, grid, F, crops, heads in (("cfg3_crops_96", (96, 96, 96), 32, 2, False),
+                                                ("released_32x128x192", (32, 128, 192), 32, 2, True),
+                                                ("cfg5_highres_80x160x160", (80, 160, 160), 64, 1, False)):
+                try:
+                    cfgs[name] = local_config(name, grid, F, crops, device, heads=heads)
+                except Exception as e:  # an extra must never take the headline down with it
+                    cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
+            cfgs["cfg4_train_step"] = {k: tr[k] for k in ("ms_per_step", "fwd_ms", "bwd_ms", "step_tflops_algorithmic")}
+            line["configs"] = cfgs
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
@@ -243,28 +509,17 @@ def main():
 
 
 def _breakdown(model, left, right, shift, build_cost_volume):
-    def timed(fn, n=5):
-        fn()
-        torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(n):
-            r = fn()
-        b.record()
-        torch.cuda.synchronize()
-        return a.elapsed_time(b) / n, r
-
     with torch.no_grad():
-        t, vol = timed(lambda: build_cost_volume(left, right, shift, 1))
-        print(f"[breakdown] build_cost_volume      {t:8.3f} ms  {STEP_BYTES / (t * 1e-3) / 1e9:8.1f} GB/s", file=sys.stderr)
-        t, v1 = timed(lambda: model.conv1(vol))
+        t, vol = timed_ms(lambda: build_cost_volume(left, right, shift, 1), 5)
+        print(f"[breakdown] build_cost_volume      {t:8.3f} ms  {CV_BYTES / (t * 1e-3) / 1e9:8.1f} GB/s", file=sys.stderr)
+        t, v1 = timed_ms(lambda: model.conv1(vol), 5)
         print(f"[breakdown] conv1 k3 64->32        {t:8.3f} ms  {CONV1_FLOP / (t * 1e-3) / 1e12:8.1f} TFLOP/s", file=sys.stderr)
         del vol
-        t, v2 = timed(lambda: model.conv2(v1))
+        t, v2 = timed_ms(lambda: model.conv2(v1), 5)
         print(f"[breakdown] conv2 k3 32->32        {t:8.3f} ms  {CONV1_FLOP / 2 / (t * 1e-3) / 1e12:8.1f} TFLOP/s", file=sys.stderr)
-        t, _ = timed(lambda: model.hg_conv3d(v2, None, None, residual=v2))
+        t, _ = timed_ms(lambda: model.hg_conv3d(v2, None, None, residual=v2), 5)
         print(f"[breakdown] hourglass(32)          {t:8.3f} ms  {377.6e9 / (t * 1e-3) / 1e12:8.1f} TFLOP/s", file=sys.stderr)
-        t, _ = timed(lambda: model.classifier(v2))
+        t, _ = timed_ms(lambda: model.classifier(v2), 5)
         print(f"[breakdown] classifier 1x1x1       {t:8.3f} ms", file=sys.stderr)
 
 

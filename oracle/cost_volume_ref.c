@@ -90,6 +90,8 @@ ORACLE_API int oracle_cost_volume_forward_##SUFFIX(                             
     if (ds < 1 || Hi % ds || Wi % ds) return -1;                                            \
     const int64_t H = Hi / ds, W = Wi / ds;                                                 \
     const int64_t img_h = H * ds, img_w = W * ds;                                           \
+    /* (n, c) planes are independent: OpenMP over them changes no bit of the result */     \
+    _Pragma("omp parallel for collapse(2) schedule(static)")                                \
     for (int64_t n = 0; n < N; ++n)                                                         \
     for (int64_t c = 0; c < C; ++c) {                                                       \
         const T *lplane = left + (n * C + c) * img_h * img_w;                               \
@@ -124,6 +126,8 @@ ORACLE_API int oracle_cost_volume_backward_##SUFFIX(                            
     const int64_t img_h = H * ds, img_w = W * ds;                                           \
     memset(gL, 0, sizeof(T) * (size_t)(N * C * img_h * img_w));                             \
     memset(gR, 0, sizeof(T) * (size_t)(N * C * img_h * img_w));                             \
+    /* each (n, c) pair owns its two gradient planes; the order inside a plane is fixed */  \
+    _Pragma("omp parallel for collapse(2) schedule(static)")                                \
     for (int64_t n = 0; n < N; ++n)                                                         \
     for (int64_t c = 0; c < C; ++c) {                                                       \
         T *glp = gL + (n * C + c) * img_h * img_w;                                          \

@@ -56,18 +56,26 @@ class GlobalStack(nn.Module):
         of the volume that has to be built.  Same result (fp32 summation order aside), half of
         conv1's work and of the volume's HBM traffic.  ``factored=False`` materialises the full volume
         through ``build_cost_volume`` exactly like the reference would.
-        ``timing``: optional (start_event, end_event) recorded on the current stream around the first
-        3D convolution (the dominant kernel; used by bench.py for the roofline figure)."""
+        ``timing``: optional dict ``{"volume": (start, end), "conv1": (start, end)}`` of events recorded on the
+        current stream around the cost-volume launch and the first 3D convolution (the dominant kernel); used by
+        bench.py for the roofline figures."""
+        def mark(name, which):
+            if timing is not None and name in timing:
+                timing[name][which].record()
+
         conv, bn = self.conv1[0][0], self.conv1[0][1]
         usable = (factored and downsample == 1 and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
                   and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)
         if not usable:
-            vol = build_cost_volume(left, right, shift, downsample)
             if timing is None:
-                return self.forward(vol)
-            timing[0].record()
+                return self.forward(build_cost_volume(left, right, shift, downsample))
+            assert torch.all(shift >= 0.)        # the wrapper's own check (a sync) stays outside the event pair
+            mark("volume", 0)
+            vol = ops.cost_volume_forward(left, right, shift, downsample)
+            mark("volume", 1)
+            mark("conv1", 0)
             v = self.conv1(vol)
-            timing[1].record()
+            mark("conv1", 1)
             del vol
             return self._tail(self.conv2(v))
         assert torch.all(shift >= 0.)            # same contract as build_cost_volume (reference __init__.py:12)
@@ -82,11 +90,11 @@ class GlobalStack(nn.Module):
         scale, bias = _folded_bn(bn, plans["plan"])
         left3 = left.unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()       # [N,C,3,H,W]
         planes = plans["left"](left3)                                           # depth classes: first / interior / last
+        mark("volume", 0)
         vol_r = ops.cost_volume_forward_right(right, shift)                     # [N,C,D,H,W]
-        if timing is not None:
-            timing[0].record()
+        mark("volume", 1)
+        mark("conv1", 0)
         v = plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, None, depth_planes=planes)
-        if timing is not None:
-            timing[1].record()
+        mark("conv1", 1)
         del vol_r
         return self._tail(self.conv2(v))

@@ -97,3 +97,193 @@ def test_global_pair_full_size_factored_equals_materialised(pair):
     assert a.shape == (1, 1, D, H, W) and torch.isfinite(a).all()
     err = (a - b).abs().max().item() / b.abs().max().item()
     assert err < 1e-4, err
+
+
+# ------------------------------------------------------------------------------------------------
+# Local (V-A) model at the released shape (32,128,192) and at a cfg3 crop (96,96,96): every layer kind
+# of trunk_3d checked at FULL size -- spot voxels against torch-CPU on input crops (so a wrong tile, a
+# 32-bit offset overflow or a grid-limit mistake cannot hide), Winograd == direct kernel over the whole
+# tensor, and the fused trunk against its own layer-by-layer evaluation.
+# ------------------------------------------------------------------------------------------------
+def _local_model(grid, F_=32):
+    import types
+    import bench
+    from snvc_amd.models.vernier import VernierScale
+    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False,
+                                grid_resolution=[32, grid[1], 192], resolution=(256, 256),
+                                x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
+    cfg.hrfeat = types.SimpleNamespace(output_channel=F_, name="identity")
+    cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
+    m = VernierScale(cfg)
+    m.load_state_dict(bench.seeded_state(m))
+    return m.eval().to(dev())
+
+
+def _spot_points(shape, tile=(4, 4, 32)):
+    """Corners, tile edges (last voxel of a tile / first of the next), the far corner and a few interior voxels."""
+    d, h, w = shape
+    pts = {(0, 0, 0), (d - 1, h - 1, w - 1), (0, h - 1, 0), (d - 1, 0, w - 1), (d // 2, h // 2, w // 2)}
+    pts |= {(tile[0] - 1, tile[1] - 1, tile[2] - 1), (tile[0], tile[1], tile[2]), (d - 1, h // 2, tile[2] * (w // tile[2]) - 1),
+            (d // 3, h - 1, w - tile[2]), (1, 2, w - 2), (d - 2, 1, 3)}
+    return [p for p in pts if all(0 <= c < s for c, s in zip(p, shape))]
+
+
+def _conv_at(x, weight, pt, k, dil, stride=1):
+    """torch-CPU value of conv3d(x, weight)[0, :, pt] from the input crop around pt ('same' padding)."""
+    r = dil * (k - 1) // 2
+    shape = x.shape[2:]
+    lo = [p * stride - r for p in pt]
+    hi = [l + 2 * r + 1 for l in lo]
+    sl = [slice(max(l, 0), min(h_, s)) for l, h_, s in zip(lo, hi, shape)]
+    crop = x[:, :, sl[0], sl[1], sl[2]].cpu()
+    pad = []
+    for l, h_, s in reversed(list(zip(lo, hi, shape))):   # F.pad wants (W_lo, W_hi, H_lo, H_hi, D_lo, D_hi)
+        pad += [max(-l, 0), max(h_ - s, 0)]
+    return F.conv3d(F.pad(crop, pad), weight, None, 1, 0, dil)[0, :, 0, 0, 0]
+
+
+def _check_layer_spots(seq, x, y, relu=True, residual=None, after_act=False, sigmoid=False, tol=2e-4, what=""):
+    """seq: ConvBN3d (conv + eval BatchNorm) or a bare conv; y = the HIP result for input x."""
+    conv, bn = (seq[0], seq[1]) if isinstance(seq, torch.nn.Sequential) else (seq, None)
+    k, dil = conv.kernel_size[0], conv.dilation[0]
+    w_cpu = conv.weight.detach().cpu()
+    for pt in _spot_points(tuple(y.shape[2:])):
+        ref = _conv_at(x, w_cpu, pt, k, dil)
+        if bn is not None:
+            ref = (ref - bn.running_mean.cpu()) / torch.sqrt(bn.running_var.cpu() + bn.eps) * bn.weight.detach().cpu() + bn.bias.detach().cpu()
+        res = residual[0, :, pt[0], pt[1], pt[2]].cpu() if residual is not None else None
+        if res is not None and not after_act:
+            ref = ref + res
+        if relu:
+            ref = torch.relu(ref)
+        if sigmoid:
+            ref = torch.sigmoid(ref)
+        if res is not None and after_act:
+            ref = ref + res
+        got = y[0, :, pt[0], pt[1], pt[2]].cpu()
+        scale = max(ref.abs().max().item(), 1.0)
+        assert (got - ref).abs().max().item() <= tol * scale, (what, pt, (got - ref).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("grid", [(32, 128, 192), (96, 96, 96)], ids=["released_32x128x192", "cfg3_crop_96"])
+def test_local_trunk_full_size(grid):
+    import bench
+    from snvc_amd import ops
+    from snvc_amd.models.submodule import _folded_bn, _get_layer, _Plan
+    m = _local_model(grid)
+    f = 32
+    r = np.random.default_rng(7)
+    lf = torch.from_numpy(r.standard_normal((1, f, 64, 64)).astype(np.float32)).to(dev())
+    rf = torch.from_numpy(r.standard_normal((1, f, 64, 64)).astype(np.float32)).to(dev())
+    pl, pr = bench.projected_coordinates(1, grid, dev())
+    v = grid[0] * grid[1] * grid[2]
+    with torch.no_grad():
+        # a3 at full size: the projected coordinates land inside the crop; gather == F.grid_sample on sampled voxels
+        inside = ((pl >= 0) & (pl <= 256)).all(dim=1).float().mean().item()
+        assert inside > 0.5, inside
+        vox = m.construct_voxel(lf, rf, pl, pr)
+        assert vox.shape == (1, 2 * f) + grid
+        idx = torch.from_numpy(r.integers(0, v, 4096)).to(dev())
+        for feat, pts, half in ((lf, pl, 0), (rf, pr, 1)):
+            g = (pts[0][:, idx] / 256.0 * 2 - 1).t().reshape(1, 1, -1, 2)
+            ref = F.grid_sample(feat, g, mode="bilinear", padding_mode="zeros", align_corners=False)[0, :, 0]   # [F, 4096]
+            got = vox.view(1, 2 * f, v)[0, half * f:(half + 1) * f][:, idx]
+            assert (got - ref).abs().max().item() < 1e-4
+        # every layer of trunk_3d (vernier.py:415-438), each checked against torch-CPU on crops of ITS OWN input
+        img = m.vimg_feat(vox)
+        _check_layer_spots(m.vimg_feat[0], vox, img, what="vimg_feat k1")
+        v1 = m.conv1(vox)
+        _check_layer_spots(m.conv1[0], vox, v1, tol=4e-4, what="conv1 k7 (Winograd F(4,7))")
+        plan = _Plan()
+        sc, bi = _folded_bn(m.conv1[0][1], plan)
+        v1d = _get_layer(m.conv1[0][0], plan)(vox, sc, bi, None, ops.EPI_RELU, None, exact=True)
+        _check_layer_spots(m.conv1[0], vox, v1d, tol=2e-5, what="conv1 k7 (direct)")
+        e = (v1 - v1d).abs().max().item() / v1d.abs().max().item()
+        assert e < 3e-4, f"k7 Winograd vs direct over the whole tensor: {e:.2e}"
+        del v1d
+        v2 = m.conv2.fused(v1, residual=v1, residual_after_act=True)
+        _check_layer_spots(m.conv2[0], v1, v2, residual=v1, after_act=True, what="conv2 k5")
+        v3 = m.conv3.fused(v2, residual=v2, residual_after_act=True)
+        _check_layer_spots(m.conv3[0], v2, v3, residual=v2, after_act=True, what="conv3 k5 dil2")
+        for conv_seq, x_in in ((m.conv2, v1), (m.conv3, v2)):
+            plan = _Plan()
+            sc, bi = _folded_bn(conv_seq[0][1], plan)
+            layer = _get_layer(conv_seq[0][0], plan)
+            a = layer(x_in, sc, bi, None, ops.EPI_RELU, None)
+            b = layer(x_in, sc, bi, None, ops.EPI_RELU, None, exact=True)
+            e = (a - b).abs().max().item() / b.abs().max().item()
+            assert e < 2e-5, f"k5 Winograd vs direct over the whole tensor: {e:.2e}"
+            del a, b
+        del v1, v2
+        hg = m.hg_conv3d(v3, residual=v3)                              # hourglass_downsample_16 + v  (:420-423)
+        # first / last layers of the hourglass on their own inputs
+        o1 = m.hg_conv3d.conv1(v3)
+        w1 = m.hg_conv3d.conv1[0][0].weight.detach().cpu()
+        bn1 = m.hg_conv3d.conv1[0][1]
+        for pt in _spot_points(tuple(o1.shape[2:]), tile=(2, 4, 32)):
+            ref = _conv_at(v3, w1, pt, 3, 1, stride=2)
+            ref = torch.relu((ref - bn1.running_mean.cpu()) / torch.sqrt(bn1.running_var.cpu() + bn1.eps) * bn1.weight.detach().cpu() + bn1.bias.detach().cpu())
+            got = o1[0, :, pt[0], pt[1], pt[2]].cpu()
+            assert (got - ref).abs().max().item() <= 2e-4 * max(ref.abs().max().item(), 1.0), ("hg conv1 s2", pt)
+        del o1
+        t = m.fg_cls_head[0].fused(hg, relu=True)
+        _check_layer_spots(m.fg_cls_head[0], hg, t, what="fg_cls_head[0] k3")
+        occ = m.fg_cls_head[2].fused(t, sigmoid=True)
+        _check_layer_spots(m.fg_cls_head[2], t, occ, relu=False, sigmoid=True, what="occupancy head k3 -> 1 channel")
+        cat = torch.cat([hg, img * occ], dim=1)
+        v4 = m.conv4(cat)
+        _check_layer_spots(m.conv4[0], cat, v4, what="conv4 k3 (Winograd F(4,3))")
+        bev_ref = F.avg_pool3d(v4, (4, 1, 1), (4, 1, 1)).reshape(1, -1, grid[1], grid[2])
+        del cat, t
+        # the fused trunk (in-place concat, fused residuals) reproduces the layer-by-layer evaluation
+        bev, occ2, _ = m.trunk_3d(vox)
+        assert bev.shape == bev_ref.shape and torch.isfinite(bev).all()
+        assert (bev - bev_ref).abs().max().item() <= 1e-5 * bev_ref.abs().max().item()
+        assert (occ2 - occ).abs().max().item() <= 1e-6
+
+
+def test_training_step_full_size_properties():
+    """cfg4 at full size (1 pair, cfg2 shapes, train-mode BatchNorm): finite gradients for every parameter and both
+    feature maps, equality of the step with the Winograd forms off (desc.algo = DIRECT), and the bilinear adjoint
+    identities <conv(x,w), g> = <x, dgrad(g)> = <w, wgrad(x,g)> of one full-size layer."""
+    import bench
+    from snvc_amd import _lib, ops
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+
+    def step(bits):
+        m = GlobalStack(C)
+        m.load_state_dict(bench.seeded_state(m))
+        m.train().to(dev())
+        left, right, shift = bench.make_inputs(0, dev())
+        left.requires_grad_(); right.requires_grad_()
+        with ops.conv_variant(bits):
+            out = m.forward_pair(left, right, shift, 1)
+            loss = out.pow(2).mean()
+            loss.backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        grads["left"], grads["right"] = left.grad.clone(), right.grad.clone()
+        return loss.item(), grads
+
+    l0, g0 = step(0)
+    l1, g1 = step(_lib.ALGO_DIRECT)
+    assert np.isfinite(l0) and abs(l0 - l1) <= 1e-4 * abs(l1)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all(), k
+        assert g0[k].abs().max().item() > 0, k
+        e = (g0[k] - g1[k]).abs().max().item() / max(g1[k].abs().max().item(), 1e-30)
+        assert e < 5e-3, (k, e)       # Winograd forward flips a few ReLU masks: bounded, not bit-equal
+    del g0, g1
+    torch.cuda.empty_cache()
+    conv = S.HipConv3d(C, C, 3, 1, 1, bias=False).to(dev())
+    torch.manual_seed(3)
+    torch.nn.init.normal_(conv.weight, std=0.05)
+    x = torch.randn(1, C, D, H, W, device=dev(), requires_grad=True)
+    y = conv(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    lhs = (y.detach().double() * g.double()).sum().item()
+    via_x = (x.detach().double() * x.grad.double()).sum().item()
+    via_w = (conv.weight.detach().double() * conv.weight.grad.double()).sum().item()
+    assert abs(lhs - via_x) <= 1e-5 * abs(lhs) + 1e-2, (lhs, via_x)
+    assert abs(lhs - via_w) <= 1e-5 * abs(lhs) + 1e-2, (lhs, via_w)
