@@ -284,6 +284,50 @@ SNVC_API int snvc_argmax_rows(const float *x, int64_t *idx, float *val, int64_t 
                               void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * fp16-storage mode of the local 3D trunk (BASELINE.json configs[4]: "High-res local model: ... 64ch, fp16
+ * with MFMA").  The reference has no half-precision path: its kernels dispatch float / double only
+ * (BuildCostVolume_cuda.cu:240) and VernierScale never calls .half().  These entry points run the same layers
+ * -- snvc/models/vernier.py:249-264,414-438 and snvc/models/submodule.py:223-268 -- with activations and weights
+ * stored as IEEE half, fp32 accumulation (v_mfma_f32_32x32x16_f16), fp32 epilogue, one rounding on the way out.
+ * Parity target: this library's own fp32 path (tolerances in tests/test_gpu_f16.py).
+ *
+ * Tensor layout "C8": [N][C/8][D][H][W][8] half -- the 8 consecutive channels of a voxel are one 16-byte piece
+ * (C a multiple of 8; pointers 16-byte aligned; batch strides in ELEMENTS, multiples of 8, 0 = dense).
+ * Channel slices at multiples of 8 channels are contiguous, so torch.cat on channels (vernier.py:433) is free.
+ * ---------------------------------------------------------------------------------- */
+/* NCDHW fp32 <-> C8 half (S = D*H*W).  C need not be a multiple of 8 here: missing channels are zero / dropped. */
+SNVC_API int snvc_f16_from_ncdhw(const float *x, void *y_c8, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                                 int64_t y_batch_stride, void *stream);
+SNVC_API int snvc_f16_to_ncdhw(const void *x_c8, float *y, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                               int64_t y_batch_stride, void *stream);
+/* replaces: _sample_2d_feat (vernier.py:323-349) with a C8 half result [N][2F/8][V][8]: same taps and the same
+ * separately rounded fp32 bilinear sum as snvc_voxel_gather_forward_ws, rounded to half once.  F % 8 == 0;
+ * workspace as for snvc_voxel_gather_forward_ws (required). */
+SNVC_API int snvc_voxel_gather_forward_f16(const float *left, const float *right, const float *l_pts,
+                                           const float *r_pts, void *out_c8, float *workspace, int64_t N, int64_t F,
+                                           int64_t Hf, int64_t Wf, int64_t V, float res_x, float res_y, void *stream);
+/* replaces: nn.Conv3d / nn.ConvTranspose3d (+ folded eval BatchNorm) (+ residual) (+ ReLU) as snvc_conv3d_forward
+ * does, on C8 half tensors.  desc as for snvc_conv3d_forward (Cin % 8 == 0; Cout % 32 == 0; the SNVC_EPI_* flags
+ * except SIGMOID; desc.algo ignored; batch strides in half elements).  scale / bias / the epilogue are fp32.
+ * Cout == 1 (k3, stride 1: the occupancy head, vernier.py:269-278): the single channel is written as an fp32
+ * plane y_f32 [N][1][D][H][W] and SNVC_EPI_SIGMOID is honoured; y_c8 is then unused. */
+SNVC_API int64_t snvc_f16_conv3d_packed_weight_bytes(const snvc_conv3d_desc *desc_host);
+/* weight: the fp32 nn.Conv3d [Cout,Cin,k,k,k] / nn.ConvTranspose3d [Cin,Cout,3,3,3] parameter; rounded to half. */
+SNVC_API int snvc_f16_conv3d_pack_weights(const snvc_conv3d_desc *desc_host, const float *weight, void *packed,
+                                          void *stream);
+SNVC_API int snvc_f16_conv3d_forward(const snvc_conv3d_desc *desc_host, const void *x_c8, const void *packed_weight,
+                                     const float *scale, const float *bias, const void *residual_c8, void *y_c8,
+                                     float *y_f32, void *stream);
+/* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half (vernier.py:433) on C8 tensors:
+ *   out[n,c,s] = half(float(feat[n,c,s]) * occ[n,0,s]), occ an fp32 plane [N][S]; C % 8 == 0. */
+SNVC_API int snvc_f16_mul_broadcast(const void *feat_c8, const float *occ, void *out_c8, int64_t N, int64_t C,
+                                    int64_t S, int64_t feat_batch_stride, int64_t out_batch_stride, void *stream);
+/* replaces: AvgPool3d((4,1,1),(4,1,1)) + reshape to BEV (vernier.py:289,436-438): C8 [N][C/8][D][HW][8] ->
+ *   fp32 [N,C,D/4,HW] (== [N, C*D/4, H, W] after a free reshape), the layout the 2D neck reads. */
+SNVC_API int snvc_f16_avgpool_depth4(const void *x_c8, float *y, int64_t N, int64_t C, int64_t D, int64_t HW,
+                                     int64_t x_batch_stride, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * a10  roiaware_pool3d
  * replaces: roiaware_pool3d_cuda.forward / backward / points_in_boxes_gpu / points_in_boxes_cpu
  *   (snvc/extension/roiaware_pool3d/src/roiaware_pool3d.cpp:29-177; kernels

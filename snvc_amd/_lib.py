@@ -61,6 +61,14 @@ SIGNATURES = {
     "snvc_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_disparity_regression": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p]),
     "snvc_argmax_rows": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
+    "snvc_f16_from_ncdhw": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_f16_to_ncdhw": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_voxel_gather_forward_f16": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
+    "snvc_f16_conv3d_packed_weight_bytes": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
+    "snvc_f16_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p]),
+    "snvc_f16_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "snvc_f16_mul_broadcast": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_f16_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_roiaware_pool3d_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "snvc_roiaware_pool3d_backward": (c_int, [c_p, c_p, c_p, c_p] + [c_int] * 7 + [c_p]),
     "snvc_points_in_boxes_gpu": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p]),

@@ -1,0 +1,557 @@
+// fp16-storage 3D convolution family for gfx950 (BASELINE.json configs[4]: "High-res local model ... 64ch,
+// fp16 with MFMA").  The layers are the local trunk's
+// (snvc/models/vernier.py:249-264: 1x1x1, 7x7x7, 5x5x5, dilated 5x5x5, 3x3x3) and the 16x hourglass's
+// (snvc/models/submodule.py:223-268: 3x3x3 stride 1 / stride 2, ConvTranspose3d(k3,s2,p1,op1)).
+// The reference has no fp16 path (its kernels dispatch float/double only and the model never calls .half()),
+// so this mode is an extension whose parity target is this library's own fp32 path (tests/test_gpu_f16.py).
+//
+// Storage: activations and weights are IEEE half in HBM, products accumulate in fp32 on
+// v_mfma_f32_32x32x16_f16, the per-channel affine / residual / ReLU run in fp32 on the accumulators and the
+// result is rounded to half once, on the way out.
+//
+// Layout "C8": [N][C/8][D][H][W][8] -- eight consecutive channels of one voxel are one 16-byte piece.  That
+// is the MFMA's own operand shape (a lane feeds 8 k-values = 8 channels of ONE voxel), so:
+//   * staging is a plain copy: the LDS image of a chunk is [channel group][IN_D][IN_H][IN_W] pieces, filled by
+//     LDS-DMA (global_load_lds_dwordx4, one piece per lane, padding pieces read a zero constant), with
+//     per-VOXEL granularity -- no alignment classes along W as in the fp32 NCDHW kernels;
+//   * a B fragment is ONE ds_read_b128 (32 consecutive voxels x 2 k-groups), conflict-free;
+//   * the epilogue stores 16-byte pieces, 512 contiguous bytes per half-wave: the rows of the weight matrix
+//     are permuted when packed so that accumulator register r of a lane is channel 16*(lane>>5) + r, i.e. a
+//     lane ends up with two whole 8-channel pieces of its voxel.
+// K = 16 per MFMA is either two channel groups of one tap (MODE 0: small kernels, two groups resident) or
+// two TAPS of one channel group (MODE 1: 5^3 / 7^3 / stride-2 layers, whose LDS image of a single group is
+// already 37-92 KB): lanes 32-63 then read the same image one tap further on, which is only a different
+// (precomputed) lane base address.
+// A fragments (weights) are NOT staged in LDS: a chunk of a 7^3 layer needs 343 KB of them.  Each wave streams
+// them from L2 in consumption order through a small register ring (they are packed exactly in that order), so
+// the chunk loop has no barrier besides the image hand-over and the LDS holds images only.
+#include "common.hpp"
+
+namespace snvc {
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ const unsigned g_zero16h[4] __attribute__((aligned(16))) = {0u, 0u, 0u, 0u};
+
+struct F16Args {
+    const _Float16 *x;
+    const _Float16 *wp;
+    const float *scale, *bias;
+    const _Float16 *res;
+    _Float16 *y;
+    float *y_f32;        // EPI 1: [N][1][Dout][Hout][Wout] fp32 plane of output channel 0
+    int CGin;            // input channel groups (Cin / 8, rounded up)
+    int Din, Hin, Win;
+    int Dout, Hout, Wout;      // dims of the OUTPUT TENSOR
+    int nd, nh, nw;            // output positions this launch computes per dim (== Dout.. except transposed classes)
+    int os, offd, offh, offw;  // output coordinate = position * os + off
+    int pad_lo;                // input coordinate = position * STRIDE + tap * DIL - pad_lo
+    int tiles_d, tiles_h, tiles_w;
+    int nchunks, flags;
+    int64_t x_bs, y_bs, r_bs, yf_bs;   // batch strides in elements
+};
+
+constexpr int F16_PF = 4;   // A-fragment register ring depth (k-steps ahead)
+
+template <int KD_, int KH_, int KW_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KCG_, int MODE_, bool DB_, int OCC_>
+struct F16Cfg {
+    static constexpr int KD = KD_, KH = KH_, KW = KW_, STRIDE = STRIDE_, DIL = DIL_, MI = MI_, TD = TD_, TH = TH_;
+    static constexpr int KCG = KCG_, MODE = MODE_, OCC = OCC_;
+    static constexpr bool DB = DB_;
+    static constexpr int IN_D = (TD - 1) * STRIDE + (KD - 1) * DIL + 1;
+    static constexpr int IN_H = (TH - 1) * STRIDE + (KH - 1) * DIL + 1;
+    static constexpr int IN_W = 31 * STRIDE + (KW - 1) * DIL + 1;
+    static constexpr int VOX = IN_D * IN_H * IN_W;          // pieces per channel-group image
+    static constexpr int GB = VOX * 16;                     // bytes per channel-group image
+    static constexpr int ITEMS = KCG * VOX;
+    static constexpr int NIT = (ITEMS + 255) / 256;
+    static constexpr int IMG_BYTES = NIT * 256 * 16;        // whole DMA rounds
+    static constexpr int LDS_BYTES = IMG_BYTES * (DB ? 2 : 1);
+    static constexpr int NB = TD * TH / 4;
+    static constexpr bool UNROLL_D = KD <= 3;
+    static constexpr int SEGS = UNROLL_D ? 1 : KD;          // runtime-looped kernel depth slices
+    static constexpr int TSEG = UNROLL_D ? KD * KH * KW : KH * KW;
+    static constexpr int NPS = (TSEG + 1) / 2;              // MODE 1: tap pairs per segment
+    static constexpr int NS = MODE == 0 ? TSEG * (KCG / 2) : NPS * KCG;   // k-steps per segment
+    static constexpr int STEPS = SEGS * NS;                 // k-steps per chunk
+    static constexpr int SEG_BYTES = DIL * IN_H * IN_W * 16;
+    static_assert(TD * TH % 4 == 0, "rows split over 4 waves");
+    static_assert(MODE == 1 || KCG % 2 == 0, "MODE 0 pairs channel groups");
+    static_assert(NIT <= 32, "validity mask is one register");
+    // voxel offset of tap t of a segment (kd = 0 for looped segments)
+    static constexpr int tapoff(int t) {
+        const int kd = UNROLL_D ? t / (KH * KW) : 0, kh = (t / KW) % KH, kw = t % KW;
+        return ((kd * DIL) * IN_H + kh * DIL) * IN_W + kw * DIL;
+    }
+};
+
+// MFMA row i of a 32-channel block holds output channel 16*((i>>2)&1) + 4*(i>>3) + (i&3): accumulator register r of
+// lane l (row (r&3) + 8*(r>>2) + 4*(l>>5)) is then channel 16*(l>>5) + r.
+__host__ __device__ constexpr int f16_row_channel(int i) { return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3); }
+
+__device__ __forceinline__ int xcd_remap16(int b, int n) {
+    const int q = n >> 3, r = n & 7, xcd = b & 7, k = b >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+template <class Cfg, int EPI>   // EPI 0: C8 half output (+affine, residual, ReLU); 1: fp32 plane of channel 0 (+Sigmoid)
+__global__ void __launch_bounds__(256, Cfg::OCC)
+conv3d_f16_kernel(const F16Args a) {
+    constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, NB = Cfg::NB, KCG = Cfg::KCG;
+    constexpr int IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, GB = Cfg::GB, NIT = Cfg::NIT, ITEMS = Cfg::ITEMS;
+    constexpr int PF = F16_PF;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+    const int t = xcd_remap16(blockIdx.x, ntiles);
+    const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
+    const int cb = blockIdx.y;              // block of 32*MI output channels
+    const int64_t n = blockIdx.z;
+    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 32;
+    const int id0 = od0 * S - a.pad_lo, ih0 = oh0 * S - a.pad_lo, iw0 = ow0 * S - a.pad_lo;
+
+    f32x16 acc[NB][MI];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nb][m][r] = 0.0f;
+
+    // ---- staging geometry: piece i of the image = (group, dd, hh, ww); its source offset (in pieces, relative to
+    // the chunk's first channel group) and validity do not depend on the chunk
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    unsigned off[NIT];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        const int g = i / VOX, r = i - g * VOX;
+        const int dd = r / (IN_H * IN_W), r2 = r - dd * (IN_H * IN_W);
+        const int hh = r2 / IN_W, ww = r2 - hh * IN_W;
+        const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww;
+        const bool ok = i < ITEMS && (unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Hin &&
+                        (unsigned)gw < (unsigned)a.Win;
+        off[it] = ok ? (unsigned)(g * in_dhw + gd * in_hw + gh * a.Win + gw) : 0u;
+        vmask |= (ok ? 1u : 0u) << it;
+    }
+    const _Float16 *xn = a.x + n * a.x_bs;
+    const int wbase = tid & ~63;
+    auto issue = [&](int chunk, int buf) {
+        const _Float16 *xc = xn + (int64_t)chunk * KCG * in_dhw * 8;
+        const int cg_left = a.CGin - chunk * KCG;
+        char *const ibuf = lds + buf * Cfg::IMG_BYTES;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            const bool ok = ((vmask >> it) & 1u) && (KCG == 1 || i / VOX < cg_left);
+            const void *src = ok ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
+            if (ITEMS % 256 == 0 || i < ITEMS)
+                __builtin_amdgcn_global_load_lds(static_cast<const float *>(src),
+                                                 reinterpret_cast<float *>(ibuf + (it * 256 + wbase) * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- B-fragment addressing (bytes inside an image).  Lane (l & 31) = output column; lanes 32..63 feed the
+    // second k-group: the next channel group (MODE 0) or the next tap (MODE 1) -- a constant added to the lane base.
+    const int lanebase = (lane & 31) * S * 16;
+    int rowoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        rowoff[nb] = ((row / TH) * S * IN_H + (row % TH) * S) * IN_W * 16;
+    }
+    constexpr int D_SAME = Cfg::DIL;
+    constexpr int D_ROW = Cfg::DIL * IN_W - (Cfg::KW - 1) * Cfg::DIL;
+    constexpr int D_SLICE = Cfg::DIL * IN_H * IN_W - (Cfg::KH - 1) * Cfg::DIL * IN_W - (Cfg::KW - 1) * Cfg::DIL;
+    const int b_grp = lanebase + half * GB;
+    const int b_same = lanebase + half * D_SAME * 16;
+    const int b_row = lanebase + half * D_ROW * 16;
+    const int b_slice = lanebase + half * D_SLICE * 16;
+    const int b_none = lanebase;
+
+    // ---- A fragments: [cout block][chunk][segment][k-step][m][lane] pieces, consumed in exactly that order
+    const int64_t steps_total = (int64_t)a.nchunks * Cfg::STEPS;
+    const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * MI) * 64 + lane;
+    h8 q[PF][MI];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+#pragma unroll
+        for (int m = 0; m < MI; ++m) q[i][m] = wq[m * 64];
+        wq += MI * 64;     // the packed buffer carries PF steps of zero padding behind the last block
+    }
+
+    auto compute = [&](const char *img) {
+#pragma unroll 1
+        for (int seg = 0; seg < Cfg::SEGS; ++seg) {
+            const char *simg = img + seg * Cfg::SEG_BYTES;
+#pragma unroll
+            for (int s = 0; s < Cfg::NS; ++s) {
+                int base, toff;
+                if constexpr (Cfg::MODE == 0) {
+                    const int tp = s / (KCG / 2), j = s % (KCG / 2);
+                    base = b_grp;
+                    toff = 2 * j * GB + Cfg::tapoff(tp) * 16;
+                } else {
+                    const int g = s / Cfg::NPS, p = s % Cfg::NPS;
+                    const int ta = 2 * p, tb = 2 * p + 1;
+                    toff = g * GB + Cfg::tapoff(ta) * 16;
+                    if (tb >= Cfg::TSEG) base = b_none;          // odd tap count: the pair's second half has zero weights
+                    else {
+                        const int delta = Cfg::tapoff(tb) - Cfg::tapoff(ta);
+                        base = delta == D_SAME ? b_same : (delta == D_ROW ? b_row : b_slice);
+                    }
+                }
+                h8 af[MI];
+#pragma unroll
+                for (int m = 0; m < MI; ++m) af[m] = q[0][m];
+#pragma unroll
+                for (int i = 0; i + 1 < PF; ++i)
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) q[i][m] = q[i + 1][m];
+#pragma unroll
+                for (int m = 0; m < MI; ++m) q[PF - 1][m] = wq[m * 64];
+                wq += MI * 64;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const h8 bf = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
+#pragma unroll
+                    for (int m = 0; m < MI; ++m)
+                        acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf, acc[nb][m], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if constexpr (Cfg::DB) {
+        issue(0, 0);
+        __syncthreads();
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            if (chunk + 1 < a.nchunks) issue(chunk + 1, (chunk + 1) & 1);
+            compute(lds + (chunk & 1) * Cfg::IMG_BYTES);
+            __syncthreads();     // drains the DMA of chunk+1 and retires every read of this chunk's buffer
+        }
+    } else {
+        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+            issue(chunk, 0);
+            __syncthreads();
+            compute(lds);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: lane = voxel (lane & 31) of row nb; registers r = channels 16*half + r of block m
+    const int out_hw = a.Hout * a.Wout;
+    const int64_t out_dhw = (int64_t)out_hw * a.Dout;
+    const int pw_ = ow0 + (lane & 31);
+    const bool relu = (a.flags & SNVC_EPI_RELU) != 0, add_pre = (a.flags & SNVC_EPI_ADD_PRE) != 0,
+               add_post = (a.flags & SNVC_EPI_ADD_POST) != 0;
+    int64_t sp[NB];
+    bool okv[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int pd = od0 + row / TH, ph = oh0 + row % TH;
+        okv[nb] = pd < a.nd && ph < a.nh && pw_ < a.nw;
+        sp[nb] = okv[nb] ? ((int64_t)(pd * a.os + a.offd) * out_hw + (ph * a.os + a.offh) * a.Wout + (pw_ * a.os + a.offw)) : 0;
+    }
+    if constexpr (EPI == 1) {
+        // one output channel (row 0 of block 0 = register 0 of the lanes with half == 0), Sigmoid, fp32 plane
+        const float sc = a.scale ? a.scale[0] : 1.0f, bi = a.scale ? a.bias[0] : 0.0f;
+        float *yp = a.y_f32 + n * a.yf_bs;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            float v = acc[nb][0][0] * sc + bi;
+            if (relu) v = v > 0.0f ? v : 0.0f;
+            if (a.flags & SNVC_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+            if (okv[nb] && half == 0) yp[sp[nb]] = v;
+        }
+    } else {
+        const _Float16 *rn = a.res ? a.res + n * a.r_bs : nullptr;
+        _Float16 *yn = a.y + n * a.y_bs;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+            const int c0 = (cb * MI + m) * 32 + 16 * half;          // first of this lane's 16 channels
+            f32x4 sc[4], bi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sc[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + c0 + 4 * k) : f32x4(1.0f);
+                bi[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.bias + c0 + 4 * k) : f32x4(0.0f);
+            }
+            const int64_t g0 = (int64_t)(c0 >> 3) * out_dhw;        // channel group of registers 0..7; 8..15 is the next
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                h8 rv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    rv[j] = rn ? *reinterpret_cast<const h8 *>(rn + ((g0 + j * out_dhw) + sp[nb]) * 8) : h8((_Float16)0.0f);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    h8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = 8 * j + e;
+                        float v = acc[nb][m][r] * sc[r >> 2][r & 3] + bi[r >> 2][r & 3];
+                        const float rr = (float)rv[j][e];
+                        if (add_pre) v += rr;
+                        if (relu) v = v > 0.0f ? v : 0.0f;
+                        if (add_post) v += rr;
+                        o[e] = (_Float16)v;
+                    }
+                    if (okv[nb]) *reinterpret_cast<h8 *>(yn + ((g0 + j * out_dhw) + sp[nb]) * 8) = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ weight packing
+struct PackArgs {
+    const float *w;
+    _Float16 *out;
+    int Cout, Cin, K;          // K = original cubic kernel size
+    int transposed, pd, ph, pw;  // transposed: parity class of this packing ([Cin][Cout][3][3][3] source)
+    int KD, KH, KW, KCG, MODE, MI, SEGS, TSEG, NPS, NS, unroll_d;
+    int nchunks, cblocks;
+    int64_t total;             // elements (halves)
+};
+
+__global__ void pack_f16_weights_kernel(const PackArgs p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.total) return;
+    int64_t r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int m = (int)(r % p.MI); r /= p.MI;
+    const int s = (int)(r % p.NS); r /= p.NS;
+    const int seg = (int)(r % p.SEGS); r /= p.SEGS;
+    const int chunk = (int)(r % p.nchunks); r /= p.nchunks;
+    const int cb = (int)r;
+    const int half = lane >> 5;
+    const int co = (cb * p.MI + m) * 32 + f16_row_channel(lane & 31);
+    int tap, g;
+    if (p.MODE == 0) { tap = s / (p.KCG / 2); g = 2 * (s % (p.KCG / 2)) + half; }
+    else { g = s / p.NPS; tap = 2 * (s % p.NPS) + half; }
+    const int ci = (chunk * p.KCG + g) * 8 + e;
+    float v = 0.0f;
+    if (tap < p.TSEG && co < p.Cout && ci < p.Cin) {
+        const int kd = p.unroll_d ? tap / (p.KH * p.KW) : seg, kh = (tap / p.KW) % p.KH, kw = tap % p.KW;
+        if (!p.transposed) {
+            v = p.w[((((int64_t)co * p.Cin + ci) * p.K + kd) * p.K + kh) * p.K + kw];
+        } else {
+            // parity class: per dim, parity 0 -> only box tap 0 exists (kernel index 1); parity 1 -> box tap 0 is
+            // kernel index 2 (input offset 0), box tap 1 is kernel index 0 (input offset +1)
+            const int par[3] = {p.pd, p.ph, p.pw}, b[3] = {kd, kh, kw};
+            int k3[3];
+            bool ok = true;
+            for (int d = 0; d < 3; ++d) {
+                if (par[d] == 0) { ok = ok && b[d] == 0; k3[d] = 1; }
+                else k3[d] = b[d] == 0 ? 2 : 0;
+            }
+            if (ok) v = p.w[((((int64_t)ci * p.Cout + co) * 3 + k3[0]) * 3 + k3[1]) * 3 + k3[2]];
+        }
+    }
+    p.out[i] = (_Float16)v;
+}
+
+// ------------------------------------------------------------------------------------ configurations
+//                        KD KH KW S  D  MI TD TH KCG MODE DB   OCC
+using F16K1   = F16Cfg<1, 1, 1, 1, 1, 2, 4, 4, 2, 0, true, 2>;
+using F16K3   = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 2, 0, true, 2>;
+using F16K3H  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 2, 0, true, 2>;     // one 32-channel block: the 1-channel head
+using F16K3S2 = F16Cfg<3, 3, 3, 2, 1, 2, 2, 4, 1, 1, false, 2>;
+using F16K5   = F16Cfg<5, 5, 5, 1, 1, 2, 4, 4, 1, 1, true, 2>;
+using F16K5D2 = F16Cfg<5, 5, 5, 1, 2, 2, 4, 4, 1, 1, false, 1>;
+using F16K7   = F16Cfg<7, 7, 7, 1, 1, 2, 4, 4, 1, 1, false, 2>;
+using F16DC   = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 0, true, 2>;      // one parity class of ConvTranspose3d(k3,s2,p1,op1)
+
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FNONE };
+
+struct F16Plan {
+    int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d;
+    int nchunks, cblocks;
+    int64_t block_halves;      // packed halves of one class (without padding)
+};
+
+template <class Cfg>
+F16Plan plan_from(int kind) {
+    F16Plan p{};
+    p.kind = kind; p.MI = Cfg::MI; p.KCG = Cfg::KCG; p.MODE = Cfg::MODE; p.TD = Cfg::TD; p.TH = Cfg::TH;
+    p.STEPS = Cfg::STEPS; p.SEGS = Cfg::SEGS; p.TSEG = Cfg::TSEG; p.NPS = Cfg::NPS; p.NS = Cfg::NS;
+    p.KD = Cfg::KD; p.KH = Cfg::KH; p.KW = Cfg::KW; p.unroll_d = Cfg::UNROLL_D ? 1 : 0;
+    return p;
+}
+
+int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p) {
+    if (d.N < 0 || d.Cin <= 0 || d.Cout <= 0 || d.Din <= 0 || d.Hin <= 0 || d.Win <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d: sizes must be positive");
+    if (d.Cin % 8 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: Cin must be a multiple of 8 (C8 layout)");
+    if (d.Cout != 1 && d.Cout % 32 != 0)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: Cout must be a multiple of 32, or 1 (fp32 plane output)");
+    if (d.transposed) {
+        if (d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.dilation != 1)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: transposed conv supports k3,s2,p1,op1 only");
+        if (d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win)
+            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d: transposed output must be 2x the input");
+        if (d.Cout == 1) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: transposed conv to one channel");
+        p = plan_from<F16DC>(FDC);
+    } else {
+        if (d.pad != d.dilation * (d.ksize - 1) / 2)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: pad must equal dilation*(ksize-1)/2");
+        const int eff = d.dilation * (d.ksize - 1) + 1;
+        if (d.Dout != (d.Din + 2 * d.pad - eff) / d.stride + 1 || d.Hout != (d.Hin + 2 * d.pad - eff) / d.stride + 1 ||
+            d.Wout != (d.Win + 2 * d.pad - eff) / d.stride + 1)
+            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d: output size does not match the convolution arithmetic");
+        const int key = d.ksize * 100 + d.stride * 10 + d.dilation;
+        if (d.Cout == 1) {
+            if (key != 311) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: one-channel output is built for k3/s1 only");
+            p = plan_from<F16K3H>(FK3H);
+        } else {
+            switch (key) {
+                case 111: p = plan_from<F16K1>(FK1); break;
+                case 311: p = plan_from<F16K3>(FK3); break;
+                case 321: p = plan_from<F16K3S2>(FK3S2); break;
+                case 511: p = plan_from<F16K5>(FK5); break;
+                case 512: p = plan_from<F16K5D2>(FK5D2); break;
+                case 711: p = plan_from<F16K7>(FK7); break;
+                default:
+                    return fail(SNVC_ERR_UNSUPPORTED,
+                                "snvc_f16_conv3d: (ksize,stride,dilation) not in {(1,1,1),(3,1,1),(3,2,1),(5,1,1),(5,1,2),(7,1,1)}");
+            }
+        }
+    }
+    p.nchunks = ceil_div(d.Cin / 8, p.KCG);
+    p.cblocks = ceil_div(d.Cout, 32 * p.MI);
+    p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * p.MI * 64 * 8;
+    if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: too many channel blocks or samples");
+    return SNVC_OK;
+}
+
+inline int64_t f16_class_stride(const F16Plan &p) { return p.block_halves + (int64_t)F16_PF * p.MI * 64 * 8; }
+
+template <class Cfg, int EPI>
+void launch_f16(const F16Args &a, dim3 grid, hipStream_t st) {
+    static std::atomic<unsigned> attr_done{0};
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_f16_kernel<Cfg, EPI>), Cfg::LDS_BYTES, attr_done)) return;
+    conv3d_f16_kernel<Cfg, EPI><<<grid, 256, Cfg::LDS_BYTES, st>>>(a);
+}
+
+}  // namespace
+}  // namespace snvc
+
+extern "C" {
+
+int64_t snvc_f16_conv3d_packed_weight_bytes(const snvc_conv3d_desc *d) {
+    using namespace snvc;
+    F16Plan p;
+    if (!d || make_f16_plan(*d, p) != SNVC_OK) return -1;
+    return 2 * f16_class_stride(p) * (d->transposed ? 8 : 1);
+}
+
+int snvc_f16_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, void *packed, void *stream) {
+    using namespace snvc;
+    F16Plan p;
+    if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_pack_weights: null desc");
+    int rc = make_f16_plan(*d, p);
+    if (rc) return rc;
+    if (!weight || !packed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_pack_weights: null pointer");
+    const int64_t bytes = snvc_f16_conv3d_packed_weight_bytes(d);
+    if (hipMemsetAsync(packed, 0, (size_t)bytes, as_stream(stream)) != hipSuccess)   // the ring's read-ahead padding
+        return fail(SNVC_ERR_HIP, "snvc_f16_conv3d_pack_weights: hipMemsetAsync failed");
+    const int classes = d->transposed ? 8 : 1;
+    for (int c = 0; c < classes; ++c) {
+        PackArgs a;
+        a.w = weight;
+        a.out = reinterpret_cast<_Float16 *>(packed) + c * f16_class_stride(p);
+        a.Cout = d->Cout; a.Cin = d->Cin; a.K = d->ksize;
+        a.transposed = d->transposed; a.pd = (c >> 2) & 1; a.ph = (c >> 1) & 1; a.pw = c & 1;
+        a.KD = p.KD; a.KH = p.KH; a.KW = p.KW; a.KCG = p.KCG; a.MODE = p.MODE; a.MI = p.MI; a.SEGS = p.SEGS;
+        a.TSEG = p.TSEG; a.NPS = p.NPS; a.NS = p.NS; a.unroll_d = p.unroll_d;
+        a.nchunks = p.nchunks; a.cblocks = p.cblocks; a.total = p.block_halves;
+        pack_f16_weights_kernel<<<(unsigned)ceil_div<int64_t>(a.total, 256), 256, 0, as_stream(stream)>>>(a);
+    }
+    return check_launch("snvc_f16_conv3d_pack_weights");
+}
+
+int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void *packed_weight, const float *scale,
+                            const float *bias, const void *residual, void *y, float *y_f32, void *stream) {
+    using namespace snvc;
+    F16Plan p;
+    if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_forward: null desc");
+    int rc = make_f16_plan(*d, p);
+    if (rc) return rc;
+    if (d->N == 0) return SNVC_OK;
+    const bool plane = d->Cout == 1;
+    if (!x || !packed_weight || (plane ? !y_f32 : !y))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_forward: null pointer");
+    if ((scale == nullptr) != (bias == nullptr))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_forward: scale and bias must both be given or both be NULL");
+    const int resflags = d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST);
+    if (resflags && (!residual || plane))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_forward: residual flag without a C8 residual");
+    if (resflags == (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_forward: ADD_PRE and ADD_POST are exclusive");
+    if (!plane && (d->flags & SNVC_EPI_SIGMOID))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: Sigmoid is built for the one-channel fp32 output only");
+    const int64_t in_sp = (int64_t)d->Din * d->Hin * d->Win, out_sp = (int64_t)d->Dout * d->Hout * d->Wout;
+    if ((int64_t)(d->Cin / 8 + 2) * in_sp >= ((int64_t)1 << 31) || out_sp >= ((int64_t)1 << 31))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: one sample must stay below 2^31 pieces");
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual) |
+         reinterpret_cast<uintptr_t>(packed_weight)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_forward: C8 tensors must be 16-byte aligned");
+    if ((d->x_batch_stride | d->y_batch_stride | d->res_batch_stride) % 8)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_forward: batch strides must be multiples of 8 elements");
+
+    F16Args a;
+    a.x = reinterpret_cast<const _Float16 *>(x);
+    a.scale = scale; a.bias = bias;
+    a.res = resflags ? reinterpret_cast<const _Float16 *>(residual) : nullptr;
+    a.y = reinterpret_cast<_Float16 *>(y); a.y_f32 = y_f32;
+    a.CGin = d->Cin / 8;
+    a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
+    a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;
+    a.nchunks = p.nchunks; a.flags = d->flags;
+    a.x_bs = d->x_batch_stride ? d->x_batch_stride : (int64_t)d->Cin * in_sp;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->Cout * out_sp;
+    a.r_bs = d->res_batch_stride ? d->res_batch_stride : (int64_t)d->Cout * out_sp;
+    a.yf_bs = out_sp;
+    hipStream_t st = as_stream(stream);
+    const int classes = d->transposed ? 8 : 1;
+    for (int c = 0; c < classes; ++c) {
+        a.wp = reinterpret_cast<const _Float16 *>(packed_weight) + c * f16_class_stride(p);
+        if (d->transposed) {
+            a.nd = d->Din; a.nh = d->Hin; a.nw = d->Win;
+            a.os = 2; a.offd = (c >> 2) & 1; a.offh = (c >> 1) & 1; a.offw = c & 1;
+            a.pad_lo = 0;
+        } else {
+            a.nd = d->Dout; a.nh = d->Hout; a.nw = d->Wout;
+            a.os = 1; a.offd = a.offh = a.offw = 0;
+            a.pad_lo = d->pad;
+        }
+        a.tiles_d = ceil_div(a.nd, p.TD); a.tiles_h = ceil_div(a.nh, p.TH); a.tiles_w = ceil_div(a.nw, 32);
+        const int64_t ntiles = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
+        if (ntiles >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: too many tiles");
+        dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)d->N);
+        switch (p.kind) {
+            case FK1: launch_f16<F16K1, 0>(a, grid, st); break;
+            case FK3: launch_f16<F16K3, 0>(a, grid, st); break;
+            case FK3H: launch_f16<F16K3H, 1>(a, grid, st); break;
+            case FK3S2: launch_f16<F16K3S2, 0>(a, grid, st); break;
+            case FK5: launch_f16<F16K5, 0>(a, grid, st); break;
+            case FK5D2: launch_f16<F16K5D2, 0>(a, grid, st); break;
+            case FK7: launch_f16<F16K7, 0>(a, grid, st); break;
+            case FDC: launch_f16<F16DC, 0>(a, grid, st); break;
+            default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: no kernel");
+        }
+        rc = check_launch("snvc_f16_conv3d_forward");
+        if (rc) return rc;
+    }
+    return SNVC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// Element-wise companions of the fp16-storage conv family (conv3d_f16.hip): layout conversion between the
+// reference's contiguous NCDHW fp32 tensors and the C8 half layout [N][C/8][S][8] (S = D*H*W), and the two
+// element-wise steps of predict_3d_heatmaps in that layout (snvc/models/vernier.py:433 and :289,436-438).
+// All of them are single-pass HBM streams: one 16-byte piece per thread on the C8 side, rows of one channel
+// coalesced across the wave on the NCDHW side.
+#include "common.hpp"
+
+namespace snvc {
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+__global__ void __launch_bounds__(256)
+ncdhw_f32_to_c8_kernel(const float *__restrict__ x, _Float16 *__restrict__ y, int C, int64_t S, int64_t x_bs, int64_t y_bs) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int g = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const float *xp = x + n * x_bs + (int64_t)g * 8 * S + s;
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (g * 8 + e < C) ? (_Float16)xp[(int64_t)e * S] : (_Float16)0.0f;
+    *reinterpret_cast<h8 *>(y + n * y_bs + ((int64_t)g * S + s) * 8) = o;
+}
+
+__global__ void __launch_bounds__(256)
+c8_to_ncdhw_f32_kernel(const _Float16 *__restrict__ x, float *__restrict__ y, int C, int64_t S, int64_t x_bs, int64_t y_bs) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int g = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const h8 v = *reinterpret_cast<const h8 *>(x + n * x_bs + ((int64_t)g * S + s) * 8);
+    float *yp = y + n * y_bs + (int64_t)g * 8 * S + s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (g * 8 + e < C) yp[(int64_t)e * S] = (float)v[e];
+}
+
+// out[n][g][s][:] = feat[n][g][s][:] * occ[n][s]   (occ: fp32 plane; product in fp32, rounded once)
+__global__ void __launch_bounds__(256)
+mul_broadcast_c8_kernel(const _Float16 *__restrict__ feat, const float *__restrict__ occ, _Float16 *__restrict__ out,
+                        int64_t S, int64_t f_bs, int64_t o_bs) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int g = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const h8 v = *reinterpret_cast<const h8 *>(feat + n * f_bs + ((int64_t)g * S + s) * 8);
+    const float w = occ[n * S + s];
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)v[e] * w);
+    *reinterpret_cast<h8 *>(out + n * o_bs + ((int64_t)g * S + s) * 8) = o;
+}
+
+// AvgPool3d((4,1,1)) of a C8 tensor [N][G][D][HW][8] into the fp32 NCDHW tensor [N][C][D/4][HW] the 2D neck reads
+__global__ void __launch_bounds__(256)
+avgpool_depth4_c8_kernel(const _Float16 *__restrict__ x, float *__restrict__ y, int C, int D, int64_t HW, int64_t x_bs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int D4 = D / 4;
+    if (i >= (int64_t)D4 * HW) return;
+    const int64_t hw = i % HW;
+    const int d4 = (int)(i / HW);
+    const int g = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const _Float16 *xp = x + n * x_bs + (((int64_t)g * D + 4 * d4) * HW + hw) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const h8 v = *reinterpret_cast<const h8 *>(xp + (int64_t)k * HW * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+    float *yp = y + ((n * C + (int64_t)g * 8) * D4 + d4) * HW + hw;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (g * 8 + e < C) yp[(int64_t)e * D4 * HW] = acc[e] * 0.25f;
+}
+
+inline bool grid_ok(int64_t S, int64_t G, int64_t N) { return ceil_div<int64_t>(S, 256) < ((int64_t)1 << 31) && G <= 65535 && N <= 65535; }
+
+}  // namespace
+}  // namespace snvc
+
+extern "C" {
+
+int snvc_f16_from_ncdhw(const float *x, void *y, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                        int64_t y_batch_stride, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_from_ncdhw: bad sizes");
+    if (N == 0 || S == 0) return SNVC_OK;
+    const int64_t G = ceil_div<int64_t>(C, 8);
+    if (!x || !y || (reinterpret_cast<uintptr_t>(y) & 15)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_from_ncdhw: null or unaligned pointer");
+    if (!grid_ok(S, G, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_from_ncdhw: tensor too large");
+    dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)G, (unsigned)N);
+    ncdhw_f32_to_c8_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, reinterpret_cast<_Float16 *>(y), (int)C, S,
+                                                               x_batch_stride ? x_batch_stride : C * S,
+                                                               y_batch_stride ? y_batch_stride : G * 8 * S);
+    return check_launch("snvc_f16_from_ncdhw");
+}
+
+int snvc_f16_to_ncdhw(const void *x, float *y, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                      int64_t y_batch_stride, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_to_ncdhw: bad sizes");
+    if (N == 0 || S == 0) return SNVC_OK;
+    const int64_t G = ceil_div<int64_t>(C, 8);
+    if (!x || !y || (reinterpret_cast<uintptr_t>(x) & 15)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_to_ncdhw: null or unaligned pointer");
+    if (!grid_ok(S, G, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_to_ncdhw: tensor too large");
+    dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)G, (unsigned)N);
+    c8_to_ncdhw_f32_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const _Float16 *>(x), y, (int)C, S,
+                                                               x_batch_stride ? x_batch_stride : G * 8 * S,
+                                                               y_batch_stride ? y_batch_stride : C * S);
+    return check_launch("snvc_f16_to_ncdhw");
+}
+
+int snvc_f16_mul_broadcast(const void *feat, const float *occ, void *out, int64_t N, int64_t C, int64_t S,
+                           int64_t feat_batch_stride, int64_t out_batch_stride, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || C % 8 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_mul_broadcast: bad sizes (C % 8 == 0)");
+    if (N == 0 || S == 0) return SNVC_OK;
+    if (!feat || !occ || !out || ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_mul_broadcast: null or unaligned pointer");
+    if (!grid_ok(S, C / 8, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_mul_broadcast: tensor too large");
+    dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)(C / 8), (unsigned)N);
+    mul_broadcast_c8_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const _Float16 *>(feat), occ,
+                                                                reinterpret_cast<_Float16 *>(out), S,
+                                                                feat_batch_stride ? feat_batch_stride : C * S,
+                                                                out_batch_stride ? out_batch_stride : C * S);
+    return check_launch("snvc_f16_mul_broadcast");
+}
+
+int snvc_f16_avgpool_depth4(const void *x, float *y, int64_t N, int64_t C, int64_t D, int64_t HW, int64_t x_batch_stride,
+                            void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || D < 0 || HW < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_avgpool_depth4: bad sizes");
+    const int64_t G = ceil_div<int64_t>(C, 8), out = (D / 4) * HW;
+    if (N == 0 || out == 0) return SNVC_OK;
+    if (!x || !y || (reinterpret_cast<uintptr_t>(x) & 15)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_avgpool_depth4: null or unaligned pointer");
+    if (!grid_ok(out, G, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_avgpool_depth4: tensor too large");
+    dim3 grid((unsigned)ceil_div<int64_t>(out, 256), (unsigned)G, (unsigned)N);
+    avgpool_depth4_c8_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const _Float16 *>(x), y, (int)C, (int)D, HW,
+                                                                 x_batch_stride ? x_batch_stride : G * 8 * D * HW);
+    return check_launch("snvc_f16_avgpool_depth4");
+}
+
+}  // extern "C"

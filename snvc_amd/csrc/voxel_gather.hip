@@ -194,6 +194,49 @@ voxel_gather_fwd_cl_x4(const float *__restrict__ ws, const float *__restrict__ l
     }
 }
 
+
+// fp16-storage output (conv3d_f16.hip's C8 layout [N][2F/8][V][8]; BASELINE.json configs[4]): same taps, same
+// separately rounded fp32 a*nw + b*ne + c*sw + d*se per channel as the kernels above, rounded to half once on
+// the way out.  One voxel per thread: a wave stores 1 KB contiguous per channel group (64 voxels x 16 bytes), and
+// the output stream is 4F + 16 bytes per voxel instead of 8F + 16.
+__global__ void __launch_bounds__(256)
+voxel_gather_fwd_cl_c8(const float *__restrict__ ws, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
+                       _Float16 *__restrict__ out, int F, int Hf, int Wf, int64_t V, float res_x, float res_y) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int64_t n = blockIdx.y;
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int64_t fp = (int64_t)F * Hf * Wf;
+    const int G = F / 8;
+    _Float16 *o = out + n * 2 * F * V + v * 8;
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const float *pts = (side == 0 ? l_pts : r_pts) + n * 2 * V;
+        const float *feat = ws + ((int64_t)side * gridDim.y + n) * fp;
+        const Taps t = make_taps(pts[v], pts[V + v], res_x, res_y, Hf, Wf);
+        const f4 *pa = reinterpret_cast<const f4 *>(feat + (int64_t)(t.off[0] < 0 ? 0 : t.off[0]) * F);
+        const f4 *pb = reinterpret_cast<const f4 *>(feat + (int64_t)(t.off[1] < 0 ? 0 : t.off[1]) * F);
+        const f4 *pc = reinterpret_cast<const f4 *>(feat + (int64_t)(t.off[2] < 0 ? 0 : t.off[2]) * F);
+        const f4 *pd = reinterpret_cast<const f4 *>(feat + (int64_t)(t.off[3] < 0 ? 0 : t.off[3]) * F);
+        const bool va = t.off[0] >= 0, vb = t.off[1] >= 0, vc = t.off[2] >= 0, vd = t.off[3] >= 0;
+#pragma unroll 2
+        for (int g = 0; g < G; ++g) {
+            h8 res;
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const f4 a4 = pa[2 * g + hq], b4 = pb[2 * g + hq], c4 = pc[2 * g + hq], d4 = pd[2 * g + hq];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = va ? a4[j] : 0.0f, b = vb ? b4[j] : 0.0f, c = vc ? c4[j] : 0.0f, d = vd ? d4[j] : 0.0f;
+                    res[4 * hq + j] = (_Float16)(a * t.wt[0] + b * t.wt[1] + c * t.wt[2] + d * t.wt[3]);
+                }
+            }
+            __builtin_nontemporal_store(res, reinterpret_cast<h8 *>(o + ((int64_t)(side * G + g) * V) * 8));
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 voxel_gather_bwd(const float *__restrict__ grad_out, const float *__restrict__ l_pts,
                  const float *__restrict__ r_pts, float *__restrict__ grad_left,
@@ -317,6 +360,29 @@ int snvc_voxel_gather_forward_ws(const float *left, const float *right, const fl
                                                                  res_x, res_y);
     }
     return check_launch("snvc_voxel_gather_forward_ws");
+}
+
+int snvc_voxel_gather_forward_f16(const float *left, const float *right, const float *l_pts, const float *r_pts,
+                                  void *out, float *workspace, int64_t N, int64_t F, int64_t Hf, int64_t Wf,
+                                  int64_t V, float res_x, float res_y, void *stream) {
+    using namespace snvc;
+    if (N < 0 || F <= 0 || F % 8 != 0 || F > 256 || Hf <= 0 || Wf <= 0 || V < 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward_f16: bad sizes (F % 8 == 0, F <= 256)");
+    if (N == 0 || V == 0) return SNVC_OK;
+    if (N > 65535 || Hf * Wf >= ((int64_t)1 << 24))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_voxel_gather_forward_f16: feature plane or batch too large");
+    if (!left || !right || !l_pts || !r_pts || !out || !workspace)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward_f16: null pointer");
+    if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward_f16: workspace and output must be 16-byte aligned");
+    const int plane = (int)(Hf * Wf);
+    dim3 tg((unsigned)ceil_div(plane, 64), (unsigned)N, 2);
+    features_to_channels_last<<<tg, 256, (size_t)64 * (F + 1) * sizeof(float), as_stream(stream)>>>(left, right, workspace,
+                                                                                                    (int)F, plane);
+    dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
+    voxel_gather_fwd_cl_c8<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, reinterpret_cast<_Float16 *>(out),
+                                                                (int)F, (int)Hf, (int)Wf, V, res_x, res_y);
+    return check_launch("snvc_voxel_gather_forward_f16");
 }
 
 int snvc_voxel_gather_backward(const float *grad_out, const float *l_pts, const float *r_pts,

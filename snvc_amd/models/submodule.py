@@ -61,6 +61,7 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
         return
     for m in module.modules():
         m.__dict__.pop("_snvc_plans", None)
+        m.__dict__.pop("_snvc_plans_f16", None)
         m.__dict__.pop("_snvc_factored", None)
 
 
@@ -319,6 +320,32 @@ def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *,
     return _norm_forward(layer, norm, plan, x, residual, flags, out, False)[0]
 
 
+def fused_conv3d_f16(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,
+                     residual: Optional[torch.Tensor] = None, residual_after_act=False, out=None) -> torch.Tensor:
+    """``fused_conv3d`` in the fp16-storage mode (inference only; BASELINE.json configs[4]): ``x`` / ``residual`` /
+    ``out`` are C8 half tensors (``ops.to_c8``), the parameters stay fp32 ``nn.Parameter``s and are rounded to half
+    when packed, BatchNorm must be in eval mode (folded into the fp32 epilogue).  A one-output-channel layer
+    (the occupancy head) returns its result as a float32 ``[N,1,D,H,W]`` tensor."""
+    if torch.is_grad_enabled() and (conv.weight.requires_grad and x.requires_grad):
+        raise NotImplementedError("the fp16-storage mode is inference only")
+    if norm is not None and not (isinstance(norm, nn.BatchNorm3d) and not norm.training and norm.running_mean is not None):
+        raise NotImplementedError("the fp16-storage mode needs eval-mode BatchNorm3d (GroupNorm / batch statistics: fp32 path)")
+    if conv.weight.device != x.device:
+        raise RuntimeError(f"conv3d weight is on {conv.weight.device} but the input is on {x.device}")
+    plan = conv.__dict__.setdefault("_snvc_plans_f16", {}).setdefault(x.device, _Plan())
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
+    if plan.layer is None or plan.key != key:
+        k, s, p, d, transposed = _conv_geometry(conv)
+        plan.layer = ops.Conv3dLayerF16(w.detach(), k, s, p, d, transposed)
+        plan.key = key
+    scale, bias = _folded_bn(norm, plan) if norm is not None else (None, None)
+    flags = (EPI_RELU if relu else 0) | (EPI_SIGMOID if sigmoid else 0)
+    if residual is not None:
+        flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
+    return plan.layer(x, scale, bias, residual, flags, out)
+
+
 class ConvBN3d(nn.Sequential):
     """``Sequential(Conv3d | ConvTranspose3d, BatchNorm3d | GroupNorm)`` -- the object convbn_3d
     returns in the reference (keys ``0.weight``, ``1.weight``, ``1.bias``, ``1.running_mean``, ...)."""
@@ -329,6 +356,9 @@ class ConvBN3d(nn.Sequential):
     def fused(self, x, **kw):
         return fused_conv3d(self[0], self[1], x, **kw)
 
+    def fused_f16(self, x, **kw):
+        return fused_conv3d_f16(self[0], self[1], x, **kw)
+
 
 class HipConv3d(nn.Conv3d):
     """A bare nn.Conv3d(bias=False) (classifier, fg_cls_head[2], part_reg_head[2]) on the HIP kernel."""
@@ -338,6 +368,9 @@ class HipConv3d(nn.Conv3d):
 
     def fused(self, x, **kw):
         return fused_conv3d(self, None, x, **kw)
+
+    def fused_f16(self, x, **kw):
+        return fused_conv3d_f16(self, None, x, **kw)
 
 
 def convbn_3d(in_planes, out_planes, kernel_size, stride, pad, dilation=1, gn=False, groups=32):
@@ -361,6 +394,10 @@ class ConvBNReLU3d(nn.Sequential):
     def fused(self, x, **kw):
         kw.setdefault("relu", True)
         return self[0].fused(x, **kw)
+
+    def fused_f16(self, x, **kw):
+        kw.setdefault("relu", True)
+        return self[0].fused_f16(x, **kw)
 
 
 class disparityregression(nn.Module):
@@ -397,6 +434,15 @@ class hourglass(nn.Module):
         o = self.conv4(self.conv3(pre))                                     # 1/4 res
         post = self.conv5.fused(o, relu=True, residual=presqu if presqu is not None else pre)  # :161-164
         o = self.conv6.fused(post, residual=residual, out=out, head=head)   # :166
+        return o, pre, post
+
+    def forward_f16(self, x, presqu=None, postsqu=None, residual=None, out=None):
+        """The same graph on C8 half tensors (fp16-storage mode)."""
+        o = self.conv1.fused_f16(x)
+        pre = self.conv2.fused_f16(o, relu=True, residual=postsqu)
+        o = self.conv4.fused_f16(self.conv3.fused_f16(pre))
+        post = self.conv5.fused_f16(o, relu=True, residual=presqu if presqu is not None else pre)
+        o = self.conv6.fused_f16(post, residual=residual, out=out)
         return o, pre, post
 
 
@@ -439,6 +485,17 @@ class hourglass_downsample_16(nn.Module):
         i11 = self.conv10.fused(i10, residual=o4)   # out_conv10 + out_conv4  :261-262
         i12 = self.conv11.fused(i11, residual=o2)   # out_conv11 + out_conv2  :264-266
         return self.conv12.fused(i12, residual=residual, out=out)
+
+    def forward_f16(self, x, residual=None, out=None):
+        """The same graph on C8 half tensors (fp16-storage mode)."""
+        o2 = self.conv2.fused_f16(self.conv1.fused_f16(x))
+        o4 = self.conv4.fused_f16(self.conv3.fused_f16(o2))
+        o6 = self.conv6.fused_f16(self.conv5.fused_f16(o4))
+        o8 = self.conv8.fused_f16(self.conv7.fused_f16(o6))
+        i10 = self.conv9.fused_f16(o8, residual=o6)
+        i11 = self.conv10.fused_f16(i10, residual=o4)
+        i12 = self.conv11.fused_f16(i11, residual=o2)
+        return self.conv12.fused_f16(i12, residual=residual, out=out)
 
 
 # ------------------------------------------------------------------------------------------

@@ -179,6 +179,40 @@ class VernierScale(nn.Module):
             v = ops.avgpool_depth4(v)                                           # :436
         return v.reshape(n, -1, v.size(3), v.size(4)), occ, offset              # :437-438
 
+    # ------------------------------------------------------------------ fp16-storage mode (BASELINE configs[4])
+    def construct_voxel_f16(self, left, right, grid_proj_left, grid_proj_right):
+        """``construct_voxel`` with a C8 half result ``[N, 2F/8, nh, nw, nl, 8]`` (``ops.to_c8`` layout): the fp32
+        feature maps are sampled exactly as in the fp32 path and rounded to half once."""
+        nh, nw, nl = self.cfg.n_sample_h, self.cfg.n_sample_w, self.cfg.n_sample_l
+        if grid_proj_left.size(2) != nh * nw * nl:
+            raise RuntimeError("grid projection does not have nh*nw*nl points")
+        vox = ops.voxel_gather_forward_f16(left, right, grid_proj_left, grid_proj_right, self.cfg.resolution)
+        return vox.view(left.size(0), 2 * left.size(1) // 8, nh, nw, nl, 8)
+
+    def trunk_3d_f16(self, voxel):
+        """``trunk_3d`` (reference vernier.py:415-438) with half storage: ``voxel`` is a C8 tensor; activations and
+        weights are half in HBM, accumulation and epilogues fp32.  Returns the same float32 tensors as ``trunk_3d``
+        (voxel_BEV, occupancy, offset)."""
+        if hasattr(self, "part_reg_head"):
+            raise NotImplementedError("part_reg_head is not built for the fp16-storage mode")
+        n, g2 = voxel.size(0), voxel.size(1)
+        g = g2 // 2
+        img = self.vimg_feat.fused_f16(voxel)                                   # :415
+        v = self.conv1.fused_f16(voxel)                                         # :417
+        v = self.conv2.fused_f16(v, residual=v, residual_after_act=True)        # :418
+        v = self.conv3.fused_f16(v, residual=v, residual_after_act=True)        # :419
+        cat = torch.empty((n, g2) + tuple(v.shape[2:]), dtype=v.dtype, device=v.device)   # the cat of :433, in place
+        if self.small:                                                          # :420-423
+            v, _, _ = self.hg_conv3d.forward_f16(v, residual=v, out=cat[:, :g])
+        else:
+            v = self.hg_conv3d.forward_f16(v, residual=v, out=cat[:, :g])
+        t = self.fg_cls_head[0].fused_f16(v, relu=True)                         # :427
+        occ = self.fg_cls_head[2].fused_f16(t, sigmoid=True)                    # float32 [N,1,nh,nw,nl]
+        ops.mul_broadcast_c8(img, occ, out=cat[:, g:])                          # :433
+        v = self.conv4.fused_f16(cat)                                           # :435
+        v = ops.avgpool_depth4_c8(v)                                            # :436 -> float32 [N,F,nh/4,nw,nl]
+        return v.reshape(n, -1, v.size(3), v.size(4)), occ, None                # :437-438
+
     def heads_2d(self, voxel_BEV):
         """reference vernier.py:440-450 (stock PyTorch-ROCm)"""
         voxel_BEV = self.conv5(voxel_BEV)
@@ -197,7 +231,10 @@ class VernierScale(nn.Module):
         """reference vernier.py:362-458 -> (heatmaps, occupancy, offset, coordinates, bbox)"""
         if depth is not None:
             raise NotImplementedError
-        voxel_BEV, occupancy, offset = self.trunk_3d(voxel)
+        if voxel.dtype == torch.float16:        # a C8 tensor from construct_voxel_f16: fp16-storage mode
+            voxel_BEV, occupancy, offset = self.trunk_3d_f16(voxel)
+        else:
+            voxel_BEV, occupancy, offset = self.trunk_3d(voxel)
         heatmaps, coordinates = self.heads_2d(voxel_BEV)
         return heatmaps, occupancy.squeeze(1), offset, coordinates, None
 
@@ -207,7 +244,10 @@ class VernierScale(nn.Module):
             raise NotImplementedError("test=True is the reference's matplotlib self-check (vernier.py:479-550)")
         left_feat = self.feat_net(left_roi)
         right_feat = self.feat_net(right_roi)
-        voxels = self.construct_voxel(left_feat, right_feat, grid_proj_left, grid_proj_right)
+        if getattr(self, "precision", "f32") == "f16" and not torch.is_grad_enabled():
+            voxels = self.construct_voxel_f16(left_feat, right_feat, grid_proj_left, grid_proj_right)
+        else:
+            voxels = self.construct_voxel(left_feat, right_feat, grid_proj_left, grid_proj_right)
         ncf, occupancy, part_offsets, coordinates, bboxes = self.predict_3d_heatmaps(voxels)
         return {"ncf": ncf, "occupancy": occupancy, "coordinates": coordinates}
 

@@ -21,7 +21,8 @@ from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, C
 
 __all__ = [
     "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
-    "Conv3dLayer", "conv_variant", "conv3d_wgrad", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
+    "Conv3dLayer", "conv_variant", "conv3d_wgrad", "Conv3dLayerF16", "to_c8", "from_c8", "voxel_gather_forward_f16",
+    "mul_broadcast_c8", "avgpool_depth4_c8", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
     "points_in_boxes_gpu", "points_in_boxes_cpu",
     "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID",
@@ -474,6 +475,172 @@ def argmax_rows(x2d) -> Tuple[torch.Tensor, torch.Tensor]:
     with torch.cuda.device(x2d.device):
         check(_lib.lib().snvc_argmax_rows(_ptr(x2d), _ptr(idx), _ptr(val), r, l, _stream(x2d)), "snvc_argmax_rows")
     return idx, val
+
+
+# ------------------------------------------------------------------------------ fp16-storage mode (C8 layout)
+# A C8 tensor is a torch.float16 tensor of shape [N, C/8, D, H, W, 8] (include/snvc_hip.h, "fp16-storage mode"):
+# channel c of voxel (d,h,w) is t[n, c // 8, d, h, w, c % 8].  t[:, g0:g1] is a channel slice (a view).
+def _c8_check(t: torch.Tensor, name: str):
+    _gpu(t, name)
+    if t.dtype != torch.float16 or t.dim() != 6 or t.size(5) != 8:
+        raise RuntimeError(f"{name} must be a C8 tensor: float16 [N, C/8, D, H, W, 8], got {tuple(t.shape)} {t.dtype}")
+    if not _dense_inner(t) or t.data_ptr() % 16:
+        raise RuntimeError(f"{name} must be dense below dim 0 and 16-byte aligned")
+
+
+def to_c8(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 [N,C,D,H,W] -> C8 half [N,ceil(C/8),D,H,W,8] (missing channels are zero)."""
+    _gpu(x, "x")
+    if x.dtype != torch.float32 or x.dim() != 5:
+        raise RuntimeError("to_c8 needs a float32 [N,C,D,H,W] tensor")
+    if not _dense_inner(x):
+        x = x.contiguous()
+    n, c = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])
+    if out is None:
+        out = torch.empty((n, (c + 7) // 8) + sp + (8,), dtype=torch.float16, device=x.device)
+    else:
+        _c8_check(out, "out")
+    if x.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_f16_from_ncdhw(_ptr(x), _ptr(out), n, c, math.prod(sp), _batch_stride(x), _batch_stride(out),
+                                             _stream(x)), "snvc_f16_from_ncdhw")
+    return out
+
+
+def from_c8(x: torch.Tensor, channels: Optional[int] = None) -> torch.Tensor:
+    """C8 half -> float32 [N,C,D,H,W] (C = channels or all 8*G)."""
+    _c8_check(x, "x")
+    n, g = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:5])
+    c = channels if channels is not None else 8 * g
+    y = torch.empty((n, c) + sp, dtype=torch.float32, device=x.device)
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_f16_to_ncdhw(_ptr(x), _ptr(y), n, c, math.prod(sp), _batch_stride(x), 0, _stream(x)),
+              "snvc_f16_to_ncdhw")
+    return y
+
+
+def voxel_gather_forward_f16(left, right, l_pts, r_pts, resolution) -> torch.Tensor:
+    """_sample_2d_feat(aggregate='concat') (vernier.py:323-349) with a C8 half result [N, 2F/8, V, 8]."""
+    _check_gather(left, right, l_pts, r_pts)
+    n, f, hf, wf = left.shape
+    if f % 8:
+        raise RuntimeError("the fp16-storage gather needs F % 8 == 0")
+    v = l_pts.size(2)
+    out = torch.empty((n, 2 * f // 8, v, 8), dtype=torch.float16, device=left.device)
+    if out.numel() == 0:
+        return out
+    left, right, l_pts, r_pts = left.contiguous(), right.contiguous(), l_pts.contiguous(), r_pts.contiguous()
+    with torch.cuda.device(left.device):
+        ws = torch.empty(_lib.lib().snvc_voxel_gather_workspace_floats(n, f, hf, wf), dtype=torch.float32, device=left.device)
+        check(_lib.lib().snvc_voxel_gather_forward_f16(_ptr(left), _ptr(right), _ptr(l_pts), _ptr(r_pts), _ptr(out),
+                                                       _ptr(ws), n, f, hf, wf, v, float(resolution[1]),
+                                                       float(resolution[0]), _stream(left)), "voxel_gather_forward_f16")
+    return out
+
+
+class Conv3dLayerF16:
+    """A Conv3d / ConvTranspose3d layer prepared for the fp16-storage kernels (snvc_f16_conv3d_*): same
+    geometry rules as Conv3dLayer; the fp32 parameter is rounded to half when packed."""
+
+    def __init__(self, weight: torch.Tensor, ksize: int, stride: int, pad: int, dilation: int, transposed: bool):
+        _gpu(weight, "weight")
+        if weight.dtype != torch.float32:
+            raise RuntimeError("conv3d weights must be float32 (they are rounded to half when packed)")
+        self.transposed = bool(transposed)
+        if transposed:
+            self.cin, self.cout = weight.shape[0], weight.shape[1]
+        else:
+            self.cout, self.cin = weight.shape[0], weight.shape[1]
+        if tuple(weight.shape[2:]) != (ksize,) * 3:
+            raise RuntimeError("only cubic kernels are on the path")
+        self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
+        probe = self._desc(1, (16, 16, 32), 0)
+        nbytes = _lib.lib().snvc_f16_conv3d_packed_weight_bytes(ctypes.byref(probe))
+        if nbytes < 0:
+            check(1, "snvc_f16_conv3d_packed_weight_bytes")
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        with torch.cuda.device(weight.device):
+            check(_lib.lib().snvc_f16_conv3d_pack_weights(ctypes.byref(probe), _ptr(weight.detach().contiguous()),
+                                                          _ptr(self.packed), _stream(weight)), "snvc_f16_conv3d_pack_weights")
+
+    out_spatial = Conv3dLayer.out_spatial
+    _desc = Conv3dLayer._desc
+
+    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None):
+        """y = epilogue(conv(x)) on C8 tensors.  Cout == 1: returns the fp32 plane [N,1,D,H,W] (Sigmoid allowed)."""
+        _c8_check(x, "x")
+        if x.size(1) * 8 != self.cin:
+            raise RuntimeError(f"conv3d input must have {self.cin} channels (C8), got {x.size(1) * 8}")
+        n = x.size(0)
+        in_sp = tuple(x.shape[2:5])
+        out_sp = self.out_spatial(in_sp)
+        if min(out_sp) < 1:
+            raise RuntimeError("conv3d output would be empty")
+        plane = self.cout == 1
+        y32 = None
+        if plane:
+            y32 = torch.empty((n, 1) + out_sp, dtype=torch.float32, device=x.device)
+            out = None
+        elif out is None:
+            out = torch.empty((n, self.cout // 8) + out_sp + (8,), dtype=torch.float16, device=x.device)
+        else:
+            _c8_check(out, "out")
+            if tuple(out.shape) != (n, self.cout // 8) + out_sp + (8,):
+                raise RuntimeError("conv3d `out` must be a C8 view of the output shape")
+        if residual is not None:
+            _c8_check(residual, "residual")
+            if tuple(residual.shape) != (n, self.cout // 8) + out_sp + (8,):
+                raise RuntimeError("residual must have the output's shape")
+        if n == 0:
+            return y32 if plane else out
+        d = self._desc(n, in_sp, flags, _batch_stride(x), _batch_stride(out) if out is not None else 0,
+                       _batch_stride(residual) if residual is not None else 0)
+        with torch.cuda.device(x.device):
+            check(_lib.lib().snvc_f16_conv3d_forward(ctypes.byref(d), _ptr(x), _ptr(self.packed), _ptr(scale), _ptr(bias),
+                                                     _ptr(residual), _ptr(out), _ptr(y32), _stream(x)),
+                  "snvc_f16_conv3d_forward")
+        return y32 if plane else out
+
+
+def mul_broadcast_c8(feat, occ, out=None):
+    """out[n,c,...] = feat[n,c,...] * occ[n,0,...] on C8 tensors (occ: float32 [N,1,D,H,W])."""
+    _c8_check(feat, "feat")
+    _gpu(occ, "occ")
+    occ = occ.contiguous()
+    n, g = feat.shape[0], feat.shape[1]
+    s = math.prod(feat.shape[2:5])
+    if occ.dtype != torch.float32 or occ.numel() != n * s:
+        raise RuntimeError("occupancy must be float32 [N,1,D,H,W] matching the feature volume")
+    if out is None:
+        out = torch.empty_like(feat)
+    else:
+        _c8_check(out, "out")
+        if tuple(out.shape) != tuple(feat.shape):
+            raise RuntimeError("mul_broadcast_c8 `out` must have feat's shape")
+    if feat.numel() == 0:
+        return out
+    with torch.cuda.device(feat.device):
+        check(_lib.lib().snvc_f16_mul_broadcast(_ptr(feat), _ptr(occ), _ptr(out), n, 8 * g, s, _batch_stride(feat),
+                                                _batch_stride(out), _stream(feat)), "snvc_f16_mul_broadcast")
+    return out
+
+
+def avgpool_depth4_c8(x):
+    """AvgPool3d((4,1,1),(4,1,1)) (vernier.py:289) of a C8 tensor -> float32 [N,C,D//4,H,W]."""
+    _c8_check(x, "x")
+    n, g, d, h, w, _ = x.shape
+    y = torch.empty((n, 8 * g, d // 4, h, w), dtype=torch.float32, device=x.device)
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_f16_avgpool_depth4(_ptr(x), _ptr(y), n, 8 * g, d, h * w, _batch_stride(x), _stream(x)),
+              "snvc_f16_avgpool_depth4")
+    return y
 
 
 # ------------------------------------------------------------------------------ roiaware_pool3d

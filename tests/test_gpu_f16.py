@@ -1,0 +1,255 @@
+"""fp16-storage mode (BASELINE.json configs[4], "High-res local model ... 64ch, fp16 with MFMA").
+
+The reference has no half-precision path ("its tolerance must be set vs the fp32 result"),
+so the parity targets are:
+  * per layer: torch's fp32 convolution of the SAME half-rounded inputs and weights (what an exact
+    fp16-storage / fp32-accumulate layer computes), elementwise |err| <= 1e-3*|ref| + 2e-4*rms(ref)
+    (the result's own rounding to half is 4.9e-4 relative; fp32 accumulation order is ~1e-5 of rms);
+  * gather: bit-equal to the fp32 gather rounded to half;
+  * whole trunk: this library's fp32 path on the same inputs and parameters, max|err| <= 2e-2 * rms(ref)
+    (20+ layers, each re-rounding its activations to half; measured values are printed).
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def h(t):
+    """round to half and back: what the kernels see"""
+    return t.half().float()
+
+
+def close_f16(got, ref, what, rtol=1e-3, arms=2e-4):
+    got, ref = got.double(), ref.double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    rms = ref.pow(2).mean().sqrt().item()
+    bound = rtol * ref.abs() + arms * max(rms, 1e-30)
+    ratio = ((got - ref).abs() / bound).max().item()
+    assert ratio <= 1.0, f"{what}: worst |err| / (1e-3|ref| + 2e-4 rms) = {ratio:.2f}"
+
+
+def seeded_bn(bn, g):
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(g.uniform(0.5, 1.5, bn.weight.shape).astype(np.float32)))
+        bn.bias.copy_(torch.from_numpy(g.uniform(-0.2, 0.2, bn.bias.shape).astype(np.float32)))
+        bn.running_mean.copy_(torch.from_numpy(g.uniform(-0.2, 0.2, bn.bias.shape).astype(np.float32)))
+        bn.running_var.copy_(torch.from_numpy(g.uniform(0.5, 1.5, bn.bias.shape).astype(np.float32)))
+
+
+def test_c8_layout_round_trip():
+    from snvc_amd import ops
+    x = torch.randn(2, 13, 3, 5, 7, device=dev())
+    c8 = ops.to_c8(x)
+    assert c8.shape == (2, 2, 3, 5, 7, 8) and c8.dtype == torch.float16
+    assert torch.equal(ops.from_c8(c8, 13), h(x))
+    assert torch.equal(c8[:, 1, ..., 5:], torch.zeros_like(c8[:, 1, ..., 5:]))       # channels 13..15 are zero
+    # element (n, c, d, h, w) sits at [n, c // 8, d, h, w, c % 8]
+    assert c8[1, 1, 2, 4, 6, 3].item() == x[1, 11, 2, 4, 6].half().item()
+    # channel slices are views: converting into a slice of a larger buffer
+    big = torch.zeros(2, 4, 3, 5, 7, 8, dtype=torch.float16, device=dev())
+    ops.to_c8(x, out=big[:, 1:3])
+    assert torch.equal(big[:, 1:3], c8) and big[:, 0].abs().sum() == 0 and big[:, 3].abs().sum() == 0
+
+
+KINDS = {  # name: (k, stride, dil, transposed)
+    "k1": (1, 1, 1, False), "k3": (3, 1, 1, False), "k3s2": (3, 2, 1, False), "k5": (5, 1, 1, False),
+    "k5d2": (5, 1, 2, False), "k7": (7, 1, 1, False), "deconv": (3, 2, 1, True),
+}
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("cin,cout,shape", [(64, 64, (5, 6, 37)), (16, 32, (4, 9, 33)), (128, 128, (2, 3, 40))])
+def test_f16_layer_vs_torch(kind, cin, cout, shape):
+    """Every layer kind of the fp16 family against torch's fp32 convolution of the half-rounded operands: BN affine,
+    ReLU, residual before / after the activation, batch 2, tile-ragged sizes, 1-2 chunks, 1-2 output blocks."""
+    from snvc_amd import ops
+    from snvc_amd.models import submodule as S
+    k, stride, dil, transposed = KINDS[kind]
+    if stride == 2 and not transposed:
+        shape = tuple(max(s, 3) for s in shape)
+    g = np.random.default_rng(1000 * list(KINDS).index(kind) + cin + cout)
+    pad = dil * (k - 1) // 2
+    m = S._deconvbn_3d(cin, cout, False) if transposed else S.convbn_3d(cin, cout, k, stride, pad, dilation=dil)
+    fan = cin * k ** 3
+    with torch.no_grad():
+        m[0].weight.copy_(torch.from_numpy((g.standard_normal(tuple(m[0].weight.shape)) * np.sqrt(2.0 / fan)).astype(np.float32)))
+    seeded_bn(m[1], g)
+    m.eval()
+    x = torch.from_numpy(g.standard_normal((2, cin) + shape).astype(np.float32))
+    with torch.no_grad():
+        wq = h(m[0].weight)
+        conv = (F.conv_transpose3d(h(x).double(), wq.double(), None, 2, 1, 1) if transposed
+                else F.conv3d(h(x).double(), wq.double(), None, stride, pad, dil))
+        ref = F.batch_norm(conv, m[1].running_mean.double(), m[1].running_var.double(), m[1].weight.double(),
+                           m[1].bias.double(), False, 0.0, m[1].eps)
+        res = torch.from_numpy(g.standard_normal(tuple(ref.shape)).astype(np.float32))
+        m = m.to(dev())
+        xc = ops.to_c8(x.to(dev()))
+        rc = ops.to_c8(res.to(dev()))
+        y = ops.from_c8(m.fused_f16(xc)).cpu()
+        close_f16(y, ref, f"{kind} conv+bn")
+        y = ops.from_c8(m.fused_f16(xc, relu=True, residual=rc)).cpu()
+        close_f16(y, F.relu(ref + h(res).double()), f"{kind} relu(conv+res)")
+        y = ops.from_c8(m.fused_f16(xc, relu=True, residual=rc, residual_after_act=True)).cpu()
+        close_f16(y, F.relu(ref) + h(res).double(), f"{kind} relu(conv)+res")
+        # output into a channel slice of a wider C8 buffer (the in-place torch.cat of vernier.py:433)
+        big = torch.full((2, cout // 8 + 2) + tuple(ref.shape[2:]) + (8,), 7.0, dtype=torch.float16, device=dev())
+        m.fused_f16(xc, relu=True, out=big[:, 1:1 + cout // 8])
+        close_f16(ops.from_c8(big[:, 1:1 + cout // 8]).cpu(), F.relu(ref), f"{kind} sliced out")
+        assert torch.all(big[:, 0] == 7.0) and torch.all(big[:, -1] == 7.0)
+
+
+def test_f16_one_channel_head_vs_torch():
+    """The occupancy head Conv3d(F, 1, 3) + Sigmoid (vernier.py:269-278): fp32 plane output."""
+    from snvc_amd import ops
+    from snvc_amd.models import submodule as S
+    g = np.random.default_rng(11)
+    for cin, shape in ((64, (5, 7, 41)), (32, (4, 4, 32))):
+        conv = S.HipConv3d(cin, 1, 3, 1, 1, bias=False)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy((g.standard_normal(tuple(conv.weight.shape)) * 0.05).astype(np.float32)))
+        x = torch.from_numpy(g.standard_normal((2, cin) + shape).astype(np.float32))
+        ref = torch.sigmoid(F.conv3d(h(x).double(), h(conv.weight.detach()).double(), None, 1, 1))
+        conv = conv.to(dev())
+        with torch.no_grad():
+            y = conv.fused_f16(ops.to_c8(x.to(dev())), sigmoid=True)
+        assert y.dtype == torch.float32 and y.shape == ref.shape
+        assert (y.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+def test_f16_gather_equals_rounded_fp32_gather():
+    from snvc_amd import ops
+    g = np.random.default_rng(3)
+    n, f, hf, wf, grid = 2, 32, 16, 16, (4, 8, 12)
+    v = grid[0] * grid[1] * grid[2]
+    lf = torch.from_numpy(g.standard_normal((n, f, hf, wf)).astype(np.float32)).to(dev())
+    rf = torch.from_numpy(g.standard_normal((n, f, hf, wf)).astype(np.float32)).to(dev())
+    pts = g.uniform(-6, 70, (n, 2, v)).astype(np.float32)
+    pts[0, 0, 0] = np.nan
+    gl, gr = torch.from_numpy(pts).to(dev()), torch.from_numpy(pts[:, :, ::-1].copy()).to(dev())
+    a = ops.voxel_gather_forward(lf, rf, gl, gr, (64, 64))                  # [N, 2F, V] fp32
+    b = ops.voxel_gather_forward_f16(lf, rf, gl, gr, (64, 64))             # [N, 2F/8, V, 8] half
+    exp = a.half().view(n, 2 * f // 8, 8, v).permute(0, 1, 3, 2)
+    assert torch.equal(torch.isnan(b), torch.isnan(exp))
+    assert torch.equal(torch.nan_to_num(b), torch.nan_to_num(exp))
+
+
+def test_f16_elementwise_vs_torch():
+    from snvc_amd import ops
+    x = torch.randn(2, 16, 8, 5, 9, device=dev())
+    occ = torch.rand(2, 1, 8, 5, 9, device=dev())
+    xc = ops.to_c8(x)
+    y = ops.from_c8(ops.mul_broadcast_c8(xc, occ))
+    assert torch.equal(y, h(h(x) * occ))
+    p = ops.avgpool_depth4_c8(xc)
+    ref = F.avg_pool3d(h(x), (4, 1, 1), (4, 1, 1))
+    assert p.shape == ref.shape and (p - ref).abs().max().item() < 1e-6
+
+
+def _model(grid, F_, seed=2024):
+    import bench
+    from snvc_amd.models.vernier import VernierScale
+    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False,
+                                grid_resolution=[32, grid[1], 192], resolution=(256, 256),
+                                x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
+    cfg.hrfeat = types.SimpleNamespace(output_channel=F_, name="identity")
+    cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
+    m = VernierScale(cfg)
+    m.load_state_dict(bench.seeded_state(m, seed))
+    return m.eval().to(dev())
+
+
+@pytest.mark.parametrize("grid,F_", [((16, 16, 24), 32), ((16, 32, 48), 32), ((16, 32, 32), 64)],
+                         ids=["hourglass", "hourglass16_F32", "hourglass16_F64"])
+def test_f16_trunk_vs_fp32_trunk(grid, F_):
+    """gather + 3D trunk in the fp16-storage mode against this library's fp32 path (same inputs, same parameters)."""
+    m = _model(grid, F_)
+    g = np.random.default_rng(17)
+    v = grid[0] * grid[1] * grid[2]
+    lf = torch.from_numpy(g.standard_normal((2, F_, 64, 64)).astype(np.float32)).to(dev())
+    rf = torch.from_numpy(g.standard_normal((2, F_, 64, 64)).astype(np.float32)).to(dev())
+    gl = torch.from_numpy(g.uniform(-8, 264, (2, 2, v)).astype(np.float32)).to(dev())
+    gr = torch.from_numpy(g.uniform(-8, 264, (2, 2, v)).astype(np.float32)).to(dev())
+    with torch.no_grad():
+        bev32, occ32, _ = m.trunk_3d(m.construct_voxel(lf, rf, gl, gr))
+        bev16, occ16, _ = m.trunk_3d_f16(m.construct_voxel_f16(lf, rf, gl, gr))
+    assert bev16.dtype == torch.float32 and bev16.shape == bev32.shape and occ16.shape == occ32.shape
+    rms = bev32.pow(2).mean().sqrt().item()
+    e_bev = (bev16 - bev32).abs().max().item() / rms
+    e_occ = (occ16 - occ32).abs().max().item()
+    print(f"fp16 trunk vs fp32 trunk {grid} F={F_}: bev max|err|/rms = {e_bev:.2e}, occupancy max|err| = {e_occ:.2e}")
+    assert e_bev <= 2e-2, e_bev
+    assert e_occ <= 5e-3, e_occ
+
+
+@pytest.mark.parametrize("name", ["G1", "G2"])
+def test_f16_model_switch_vs_golden(name):
+    """VernierScale.forward with ``model.precision = "f16"``: same dict, outputs near the REFERENCE's golden fp32
+    outputs (tests/golden/reference_outputs.npz) within the fp16-storage tolerance."""
+    import golden_cases as GC
+    from test_gpu_parity import _cfg, rel_err, seeded
+    from snvc_amd.models.vernier import VernierScale
+    G = GC.load_golden()
+    grid, gn, n, fh, fw, seed = GC.TRUNK_CASES[name]
+    m = seeded(VernierScale(_cfg(grid, gn)), seed).to(dev())
+    m.precision = "f16"
+    lf, rf, gpl, gpr = GC.trunk_inputs(n, 32, fh, fw, grid, seed + 1)
+    with torch.no_grad():
+        out = m(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()))
+    assert set(out) == {"ncf", "occupancy", "coordinates"}
+    for key, tol in (("occupancy", 5e-3), ("ncf", 2e-2), ("coordinates", 5e-3)):
+        e = rel_err(out[key].cpu().numpy(), G[f"trunk/{name}/{key}"])
+        print(f"f16 model vs reference golden {name}/{key}: {e:.2e}")
+        assert e <= tol, (key, e)
+
+
+def test_f16_cfg5_full_size():
+    """cfg5 at full size: grid (80,160,160), F = 64.  conv1 (7^3, 128 -> 64) against torch-CPU on input crops at
+    spot voxels (tile edges, corners), the trunk against the fp32 path, everything finite."""
+    from snvc_amd import ops
+    grid, F_ = (80, 160, 160), 64
+    m = _model(grid, F_)
+    g = np.random.default_rng(23)
+    v = grid[0] * grid[1] * grid[2]
+    lf = torch.from_numpy(g.standard_normal((1, F_, 64, 64)).astype(np.float32)).to(dev())
+    rf = torch.from_numpy(g.standard_normal((1, F_, 64, 64)).astype(np.float32)).to(dev())
+    gl = torch.from_numpy(g.uniform(-8, 264, (1, 2, v)).astype(np.float32)).to(dev())
+    gr = torch.from_numpy(g.uniform(-8, 264, (1, 2, v)).astype(np.float32)).to(dev())
+    with torch.no_grad():
+        vox = m.construct_voxel_f16(lf, rf, gl, gr)
+        assert vox.shape == (1, 16, 80, 160, 160, 8)
+        v1 = m.conv1.fused_f16(vox)
+        conv, bn = m.conv1[0][0], m.conv1[0][1]
+        wq = h(conv.weight.detach().cpu()).double()
+        sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().cpu().double()
+        bi = (bn.bias - bn.running_mean * bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().cpu().double()
+        d, hh, w = grid
+        for pt in [(0, 0, 0), (d - 1, hh - 1, w - 1), (3, 3, 31), (4, 4, 32), (40, 80, 95), (79, 0, 159), (17, 159, 128), (41, 77, 64)]:
+            lo = [p - 3 for p in pt]
+            sl = [slice(max(l, 0), min(l + 7, s)) for l, s in zip(lo, grid)]
+            crop = ops.from_c8(vox[:, :, sl[0], sl[1], sl[2]].contiguous()).cpu().double()
+            pad = []
+            for l, s in reversed(list(zip(lo, grid))):
+                pad += [max(-l, 0), max(l + 7 - s, 0)]
+            ref = torch.relu(F.conv3d(F.pad(crop, pad), wq)[0, :, 0, 0, 0] * sc + bi)
+            got = ops.from_c8(v1[:, :, pt[0]:pt[0] + 1, pt[1]:pt[1] + 1, pt[2]:pt[2] + 1].contiguous())[0, :, 0, 0, 0].cpu().double()
+            assert ((got - ref).abs() <= 1e-3 * ref.abs() + 2e-4 * max(ref.pow(2).mean().sqrt().item(), 1e-3)).all(), pt
+        del v1
+        bev16, occ16, _ = m.trunk_3d_f16(vox)
+        del vox
+        assert torch.isfinite(bev16).all() and torch.isfinite(occ16).all()
+        bev32, occ32, _ = m.trunk_3d(m.construct_voxel(lf, rf, gl, gr))
+        rms = bev32.pow(2).mean().sqrt().item()
+        e_bev = (bev16 - bev32).abs().max().item() / rms
+        e_occ = (occ16 - occ32).abs().max().item()
+        print(f"cfg5 fp16 vs fp32: bev max|err|/rms = {e_bev:.2e}, occupancy max|err| = {e_occ:.2e}")
+        assert e_bev <= 3e-2 and e_occ <= 1e-2

@@ -272,7 +272,11 @@ def test_training_step_full_size_properties():
         assert torch.isfinite(g0[k]).all(), k
         assert g0[k].abs().max().item() > 0, k
         e = (g0[k] - g1[k]).abs().max().item() / max(g1[k].abs().max().item(), 1e-30)
-        assert e < 5e-3, (k, e)       # Winograd forward flips a few ReLU masks: bounded, not bit-equal
+        # Not bit-equal: the two runs differ by ~2e-6 of the range per layer, which flips ~1e-5 of the 1e9 ReLU
+        # masks.  A parameter gradient sums over every voxel (flips average out: < 5e-3 of its max); a feature-map
+        # gradient at one pixel sums only ~1.7e5 terms, so ONE flipped mask moves it by ~0.25 % of its typical
+        # value and the worst of 1e6 pixels by ~1 % (measured 1.0e-2): bounded at 5e-2.
+        assert e < (5e-2 if k in ("left", "right") else 5e-3), (k, e)
     del g0, g1
     torch.cuda.empty_cache()
     conv = S.HipConv3d(C, C, 3, 1, 1, bias=False).to(dev())
