@@ -161,8 +161,9 @@ def projected_coordinates(n, grid, device, res=256.0):
     return GridProjector(cfg).generate(samples, P2, P3, tl, tr, device)
 
 
-def local_config(name, grid, F, crops, device, reps=3, heads=False):
-    """gather + 3D trunk of the local (V-A) model on `crops` RoI crops; returns the `configs` entry."""
+def local_config(name, grid, F, crops, device, reps=3, heads=False, precision="f32"):
+    """gather + 3D trunk of the local (V-A) model on `crops` RoI crops; returns the `configs` entry.
+    precision "f16": the fp16-storage mode (C8 half activations / weights, fp32 accumulate; BASELINE configs[4])."""
     from snvc_amd.models.vernier import VernierScale
     cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False,
                                 grid_resolution=[32, grid[1], 192], resolution=(256, 256),
@@ -180,25 +181,34 @@ def local_config(name, grid, F, crops, device, reps=3, heads=False):
     gl = torch.from_numpy(r.uniform(-8, 264, (crops, 2, v)).astype(np.float32)).to(device)
     gr = torch.from_numpy(r.uniform(-8, 264, (crops, 2, v)).astype(np.float32)).to(device)
     pl, pr = projected_coordinates(crops, grid, device)
-    gather_bytes = crops * (v * (16 + 8 * F) + 2 * F * 64 * 64 * 4)
+    f16 = precision == "f16"
+    gather_bytes = crops * (v * (16 + (4 if f16 else 8) * F) + 2 * F * 64 * 64 * 4)
     conv1_flop = 2.0 * crops * v * (2 * F) * F * 343
-    out = {"grid": list(grid), "F": F, "crops_per_call": crops, "dtype": "f32"}
+    out = {"grid": list(grid), "F": F, "crops_per_call": crops, "dtype": precision}
+    gather = m.construct_voxel_f16 if f16 else m.construct_voxel
+    trunk = m.trunk_3d_f16 if f16 else m.trunk_3d
+    conv1 = m.conv1.fused_f16 if f16 else m.conv1
     with torch.no_grad():
-        ms_u, vox = timed_ms(lambda: m.construct_voxel(lf, rf, gl, gr), reps)
-        ms_p, _ = timed_ms(lambda: m.construct_voxel(lf, rf, pl, pr), reps)
-        ms_c1, _ = timed_ms(lambda: m.conv1(vox), reps)
+        ms_u, vox = timed_ms(lambda: gather(lf, rf, gl, gr), reps)
+        ms_p, _ = timed_ms(lambda: gather(lf, rf, pl, pr), reps)
+        ms_c1, _ = timed_ms(lambda: conv1(vox), reps)
         del vox
-        ms, res = timed_ms(lambda: m.trunk_3d(m.construct_voxel(lf, rf, pl, pr)), reps)
+        ms, res = timed_ms(lambda: trunk(gather(lf, rf, pl, pr)), reps)
         assert torch.isfinite(res[0]).all()
         if heads:
             ms_h, _ = timed_ms(lambda: m.heads_2d(res[0]), reps)
             out["heads_2d_ms_per_crop"] = ms_h / crops
-    share = wino_executed_share(7, grid[2])
+    if f16:     # direct form: every algorithmic multiply-add is executed (+ the 50th tap of the 25 tap pairs per slice)
+        kernel = f"conv3d_f16_kernel<k7> {2 * F}->{F} (direct, v_mfma_f32_32x32x16_f16, C8 half storage)"
+        frac = conv1_flop / (ms_c1 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
+    else:
+        kernel = f"conv3d_winok_kernel<k7> {2 * F}->{F} (Winograd F(4,7) along W, fp32 MFMA)"
+        frac = conv1_flop * wino_executed_share(7, grid[2]) / (ms_c1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
     out.update({
         "ms_per_crop": ms / crops, "crops_per_s": 1e3 * crops / ms,
-        "dominant_kernel": f"conv3d_winok_kernel<k7> {2 * F}->{F} (Winograd F(4,7) along W, fp32 MFMA)",
+        "dominant_kernel": kernel,
         "dominant_ms": ms_c1, "dominant_gflop_algorithmic": conv1_flop / 1e9,
-        "dominant_pipe_frac": conv1_flop * share / (ms_c1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "dominant_pipe_frac": frac, "dominant_peak_tflops": PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS,
         "gather_projected": {"ms": ms_p, "GBps": gather_bytes / (ms_p * 1e-3) / 1e9,
                              "frac_hbm": gather_bytes / (ms_p * 1e-3) / 1e9 / PEAK_HBM_GBS,
                              "coords": "GridProjector on KITTI-like calibration, car-sized boxes"},
@@ -491,11 +501,12 @@ def main():
             line["train"] = tr
         if world == 1:
             cfgs = {}
-            for name, grid, F, crops, heads in (("cfg3_crops_96", (96, 96, 96), 32, 2, False),
-                                                ("released_32x128x192", (32, 128, 192), 32, 2, True),
-                                                ("cfg5_highres_80x160x160", (80, 160, 160), 64, 1, False)):
+            for name, grid, F, crops, heads, prec in (("cfg3_crops_96", (96, 96, 96), 32, 2, False, "f32"),
+                                                      ("released_32x128x192", (32, 128, 192), 32, 2, True, "f32"),
+                                                      ("cfg5_highres_80x160x160", (80, 160, 160), 64, 1, False, "f16"),
+                                                      ("cfg5_highres_80x160x160_f32", (80, 160, 160), 64, 1, False, "f32")):
                 try:
-                    cfgs[name] = local_config(name, grid, F, crops, device, heads=heads)
+                    cfgs[name] = local_config(name, grid, F, crops, device, heads=heads, precision=prec)
                 except Exception as e:  # an extra must never take the headline down with it
                     cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
             cfgs["cfg4_train_step"] = {k: tr[k] for k in ("ms_per_step", "fwd_ms", "bwd_ms", "step_tflops_algorithmic")}

@@ -44,6 +44,7 @@ struct F16Args {
     _Float16 *y;
     float *y_f32;        // EPI 1: [N][1][Dout][Hout][Wout] fp32 plane of output channel 0
     int CGin;            // input channel groups (Cin / 8, rounded up)
+    int Cout;
     int Din, Hin, Win;
     int Dout, Hout, Wout;      // dims of the OUTPUT TENSOR
     int nd, nh, nw;            // output positions this launch computes per dim (== Dout.. except transposed classes)
@@ -276,6 +277,7 @@ conv3d_f16_kernel(const F16Args a) {
         _Float16 *yn = a.y + n * a.y_bs;
 #pragma unroll
         for (int m = 0; m < MI; ++m) {
+            if ((cb * MI + m) * 32 >= a.Cout) break;                // Cout = 32 * odd: the last block is half empty
             const int c0 = (cb * MI + m) * 32 + 16 * half;          // first of this lane's 16 channels
             f32x4 sc[4], bi[4];
 #pragma unroll
@@ -513,6 +515,7 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     a.res = resflags ? reinterpret_cast<const _Float16 *>(residual) : nullptr;
     a.y = reinterpret_cast<_Float16 *>(y); a.y_f32 = y_f32;
     a.CGin = d->Cin / 8;
+    a.Cout = d->Cout;
     a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
     a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;
     a.nchunks = p.nchunks; a.flags = d->flags;
