@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("cfg", choices=["cfg3", "cfg5", "rel"])
 ap.add_argument("--crops", type=int, default=2)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--precision", choices=["f32", "f16"], default="f32", help="f16: the fp16-storage mode (C8 half tensors)")
 ap.add_argument("--no-heads", action="store_true", help="skip timing the stock-PyTorch 2D neck (keeps MIOpen's find kernels out of a profile)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -45,6 +46,8 @@ gr = torch.from_numpy(r.uniform(-8, 264, (n, 2, v)).astype(np.float32)).to(dev)
 
 def step():
     with torch.no_grad():
+        if args.precision == "f16":
+            return m.trunk_3d_f16(m.construct_voxel_f16(lf, rf, gl, gr))
         vox = m.construct_voxel(lf, rf, gl, gr)
         return m.trunk_3d(vox)
 
@@ -65,6 +68,6 @@ if F == 32 and grid[0] == 32 and not args.no_heads:   # the 2D BEV neck + heads 
             hm, co = m.heads_2d(bev)
         b.record(); torch.cuda.synchronize()
     print(f"{args.cfg}: 2D neck + heads: {a.elapsed_time(b) / args.reps / n:.2f} ms/crop")
-print(f"{args.cfg}: grid {grid} F={F} crops/call={n}: {ms / n:.2f} ms/crop = {1e3 * n / ms:.1f} crops/s/GPU, "
+print(f"{args.cfg} [{args.precision}]: grid {grid} F={F} crops/call={n}: {ms / n:.2f} ms/crop = {1e3 * n / ms:.1f} crops/s/GPU, "
       f"{gflop * n / ms:.1f} TFLOP/s ({100 * gflop * n / ms / 157.3:.0f}% of fp32 MFMA), "
       f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
