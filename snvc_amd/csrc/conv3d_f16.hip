@@ -47,24 +47,30 @@ struct F16Args {
     int Cout;
     int Din, Hin, Win;
     int Dout, Hout, Wout;      // dims of the OUTPUT TENSOR
-    int nd, nh, nw;            // output positions this launch computes per dim (== Dout.. except transposed classes)
-    int os, offd, offh, offw;  // output coordinate = position * os + off
-    int pad_lo;                // input coordinate = position * STRIDE + tap * DIL - pad_lo
+    int nd, nh, nw;            // output positions this launch computes per dim (== Dout.. except for parity classes)
+    int osd, osh, osw, offd, offh, offw;   // output coordinate = position * os + off
+    int pad_d, pad_h, pad_w;   // image coordinate = position * STRIDE + tap * DIL - pad
+    int isd, ish, iod, ioh;    // input coordinate (D, H) = image coordinate * is + io  (sub-grid classes; W is never scaled)
     int tiles_d, tiles_h, tiles_w;
     int nchunks, flags;
+    int N, cls_mode;           // blockIdx.z = class * N + n.  cls_mode 0: one class; 1: the 8 parity classes of a transposed
+                               // layer (own weights each); 2: the 4 (depth, height) sub-grids of a dilation-2 layer
+    int64_t cls_wstride;       // halves between the packed weights of consecutive classes (cls_mode 1)
     int64_t x_bs, y_bs, r_bs, yf_bs;   // batch strides in elements
 };
 
 constexpr int F16_PF = 4;   // A-fragment register ring depth (k-steps ahead)
 
-template <int KD_, int KH_, int KW_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KCG_, int MODE_, bool DB_, int OCC_>
+template <int KD_, int KH_, int KW_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KCG_, int MODE_, bool DB_, int OCC_,
+          int DILW_ = DIL_>
 struct F16Cfg {
-    static constexpr int KD = KD_, KH = KH_, KW = KW_, STRIDE = STRIDE_, DIL = DIL_, MI = MI_, TD = TD_, TH = TH_;
+    // DIL applies to D and H, DILW to W (they differ only for the sub-grid form of a dilated layer, see F16K5D2)
+    static constexpr int KD = KD_, KH = KH_, KW = KW_, STRIDE = STRIDE_, DIL = DIL_, DILW = DILW_, MI = MI_, TD = TD_, TH = TH_;
     static constexpr int KCG = KCG_, MODE = MODE_, OCC = OCC_;
     static constexpr bool DB = DB_;
     static constexpr int IN_D = (TD - 1) * STRIDE + (KD - 1) * DIL + 1;
     static constexpr int IN_H = (TH - 1) * STRIDE + (KH - 1) * DIL + 1;
-    static constexpr int IN_W = 31 * STRIDE + (KW - 1) * DIL + 1;
+    static constexpr int IN_W = 31 * STRIDE + (KW - 1) * DILW + 1;
     static constexpr int VOX = IN_D * IN_H * IN_W;          // pieces per channel-group image
     static constexpr int GB = VOX * 16;                     // bytes per channel-group image
     static constexpr int ITEMS = KCG * VOX;
@@ -85,7 +91,7 @@ struct F16Cfg {
     // voxel offset of tap t of a segment (kd = 0 for looped segments)
     static constexpr int tapoff(int t) {
         const int kd = UNROLL_D ? t / (KH * KW) : 0, kh = (t / KW) % KH, kw = t % KW;
-        return ((kd * DIL) * IN_H + kh * DIL) * IN_W + kw * DIL;
+        return ((kd * DIL) * IN_H + kh * DIL) * IN_W + kw * DILW;
     }
 };
 
@@ -101,7 +107,17 @@ __device__ __forceinline__ int xcd_remap16(int b, int n) {
 
 template <class Cfg, int EPI>   // EPI 0: C8 half output (+affine, residual, ReLU); 1: fp32 plane of channel 0 (+Sigmoid)
 __global__ void __launch_bounds__(256, Cfg::OCC)
-conv3d_f16_kernel(const F16Args a) {
+conv3d_f16_kernel(const F16Args a_) {
+    F16Args a = a_;
+    const int cls = blockIdx.z / a.N;
+    if (a.cls_mode == 1) {
+        a.offd = (cls >> 2) & 1; a.offh = (cls >> 1) & 1; a.offw = cls & 1;
+        a.wp += cls * a.cls_wstride;
+    } else if (a.cls_mode == 2) {
+        const int pd = (cls >> 1) & 1, ph = cls & 1;
+        a.offd = a.iod = pd; a.offh = a.ioh = ph;
+        a.nd = (a.Dout - pd + 1) / 2; a.nh = (a.Hout - ph + 1) / 2;
+    }
     constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, NB = Cfg::NB, KCG = Cfg::KCG;
     constexpr int IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, GB = Cfg::GB, NIT = Cfg::NIT, ITEMS = Cfg::ITEMS;
     constexpr int PF = F16_PF;
@@ -112,9 +128,10 @@ conv3d_f16_kernel(const F16Args a) {
     const int t = xcd_remap16(blockIdx.x, ntiles);
     const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
     const int cb = blockIdx.y;              // block of 32*MI output channels
-    const int64_t n = blockIdx.z;
+    const int64_t n = blockIdx.z - cls * a.N;
     const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 32;
-    const int id0 = od0 * S - a.pad_lo, ih0 = oh0 * S - a.pad_lo, iw0 = ow0 * S - a.pad_lo;
+    if (od0 >= a.nd || oh0 >= a.nh) return;      // a smaller class of an odd extent: whole tile outside (block-uniform)
+    const int id0 = od0 * S - a.pad_d, ih0 = oh0 * S - a.pad_h, iw0 = ow0 * S - a.pad_w;
 
     f32x16 acc[NB][MI];
 #pragma unroll
@@ -135,7 +152,7 @@ conv3d_f16_kernel(const F16Args a) {
         const int g = i / VOX, r = i - g * VOX;
         const int dd = r / (IN_H * IN_W), r2 = r - dd * (IN_H * IN_W);
         const int hh = r2 / IN_W, ww = r2 - hh * IN_W;
-        const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww;
+        const int gd = (id0 + dd) * a.isd + a.iod, gh = (ih0 + hh) * a.ish + a.ioh, gw = iw0 + ww;
         const bool ok = i < ITEMS && (unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Hin &&
                         (unsigned)gw < (unsigned)a.Win;
         off[it] = ok ? (unsigned)(g * in_dhw + gd * in_hw + gh * a.Win + gw) : 0u;
@@ -167,9 +184,9 @@ conv3d_f16_kernel(const F16Args a) {
         const int row = wave * NB + nb;
         rowoff[nb] = ((row / TH) * S * IN_H + (row % TH) * S) * IN_W * 16;
     }
-    constexpr int D_SAME = Cfg::DIL;
-    constexpr int D_ROW = Cfg::DIL * IN_W - (Cfg::KW - 1) * Cfg::DIL;
-    constexpr int D_SLICE = Cfg::DIL * IN_H * IN_W - (Cfg::KH - 1) * Cfg::DIL * IN_W - (Cfg::KW - 1) * Cfg::DIL;
+    constexpr int D_SAME = Cfg::DILW;
+    constexpr int D_ROW = Cfg::DIL * IN_W - (Cfg::KW - 1) * Cfg::DILW;
+    constexpr int D_SLICE = Cfg::DIL * IN_H * IN_W - (Cfg::KH - 1) * Cfg::DIL * IN_W - (Cfg::KW - 1) * Cfg::DILW;
     const int b_grp = lanebase + half * GB;
     const int b_same = lanebase + half * D_SAME * 16;
     const int b_row = lanebase + half * D_ROW * 16;
@@ -259,7 +276,7 @@ conv3d_f16_kernel(const F16Args a) {
         const int row = wave * NB + nb;
         const int pd = od0 + row / TH, ph = oh0 + row % TH;
         okv[nb] = pd < a.nd && ph < a.nh && pw_ < a.nw;
-        sp[nb] = okv[nb] ? ((int64_t)(pd * a.os + a.offd) * out_hw + (ph * a.os + a.offh) * a.Wout + (pw_ * a.os + a.offw)) : 0;
+        sp[nb] = okv[nb] ? ((int64_t)(pd * a.osd + a.offd) * out_hw + (ph * a.osh + a.offh) * a.Wout + (pw_ * a.osw + a.offw)) : 0;
     }
     if constexpr (EPI == 1) {
         // one output channel (row 0 of block 0 = register 0 of the lanes with half == 0), Sigmoid, fp32 plane
@@ -368,7 +385,9 @@ using F16K3   = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 2, 0, true, 2>;
 using F16K3H  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 2, 0, true, 2>;     // one 32-channel block: the 1-channel head
 using F16K3S2 = F16Cfg<3, 3, 3, 2, 1, 2, 2, 4, 1, 1, false, 2>;
 using F16K5   = F16Cfg<5, 5, 5, 1, 1, 2, 4, 4, 1, 1, true, 2>;
-using F16K5D2 = F16Cfg<5, 5, 5, 1, 2, 2, 4, 4, 1, 1, false, 1>;
+// dilation 2 = four independent (depth, height)-parity sub-grids, each a convolution with dilation (1,1,2): the image
+// of a tile is 8x8x40 pieces (41 KB) instead of 12x12x40 (92 KB: one workgroup per CU with its staging exposed)
+using F16K5D2 = F16Cfg<5, 5, 5, 1, 1, 2, 4, 4, 1, 1, false, 2, 2>;
 using F16K7   = F16Cfg<7, 7, 7, 1, 1, 2, 4, 4, 1, 1, false, 2>;
 using F16DC   = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 0, true, 2>;      // one parity class of ConvTranspose3d(k3,s2,p1,op1)
 
@@ -524,37 +543,42 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : (int64_t)d->Cout * out_sp;
     a.yf_bs = out_sp;
     hipStream_t st = as_stream(stream);
-    const int classes = d->transposed ? 8 : 1;
-    for (int c = 0; c < classes; ++c) {
-        a.wp = reinterpret_cast<const _Float16 *>(packed_weight) + c * f16_class_stride(p);
-        if (d->transposed) {
-            a.nd = d->Din; a.nh = d->Hin; a.nw = d->Win;
-            a.os = 2; a.offd = (c >> 2) & 1; a.offh = (c >> 1) & 1; a.offw = c & 1;
-            a.pad_lo = 0;
-        } else {
-            a.nd = d->Dout; a.nh = d->Hout; a.nw = d->Wout;
-            a.os = 1; a.offd = a.offh = a.offw = 0;
-            a.pad_lo = d->pad;
-        }
-        a.tiles_d = ceil_div(a.nd, p.TD); a.tiles_h = ceil_div(a.nh, p.TH); a.tiles_w = ceil_div(a.nw, 32);
-        const int64_t ntiles = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
-        if (ntiles >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: too many tiles");
-        dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)d->N);
-        switch (p.kind) {
-            case FK1: launch_f16<F16K1, 0>(a, grid, st); break;
-            case FK3: launch_f16<F16K3, 0>(a, grid, st); break;
-            case FK3H: launch_f16<F16K3H, 1>(a, grid, st); break;
-            case FK3S2: launch_f16<F16K3S2, 0>(a, grid, st); break;
-            case FK5: launch_f16<F16K5, 0>(a, grid, st); break;
-            case FK5D2: launch_f16<F16K5D2, 0>(a, grid, st); break;
-            case FK7: launch_f16<F16K7, 0>(a, grid, st); break;
-            case FDC: launch_f16<F16DC, 0>(a, grid, st); break;
-            default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: no kernel");
-        }
-        rc = check_launch("snvc_f16_conv3d_forward");
-        if (rc) return rc;
+    const bool subgrid = p.kind == FK5D2;      // (depth, height) parity classes share ONE packed weight block
+    const int classes = d->transposed ? 8 : (subgrid ? 4 : 1);
+    a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
+    a.N = d->N; a.cls_mode = d->transposed ? 1 : (subgrid ? 2 : 0); a.cls_wstride = f16_class_stride(p);
+    a.isd = a.ish = 1; a.iod = a.ioh = 0; a.offd = a.offh = a.offw = 0;
+    if (d->transposed) {
+        a.nd = d->Din; a.nh = d->Hin; a.nw = d->Win;
+        a.osd = a.osh = a.osw = 2;
+        a.pad_d = a.pad_h = a.pad_w = 0;
+    } else if (subgrid) {
+        a.nd = (d->Dout + 1) / 2; a.nh = (d->Hout + 1) / 2; a.nw = d->Wout;     // the largest class; the kernel trims the others
+        a.osd = a.osh = 2; a.osw = 1;
+        a.isd = a.ish = 2;
+        a.pad_d = a.pad_h = d->pad / 2; a.pad_w = d->pad;
+    } else {
+        a.nd = d->Dout; a.nh = d->Hout; a.nw = d->Wout;
+        a.osd = a.osh = a.osw = 1;
+        a.pad_d = a.pad_h = a.pad_w = d->pad;
     }
-    return SNVC_OK;
+    a.tiles_d = ceil_div(a.nd, p.TD); a.tiles_h = ceil_div(a.nh, p.TH); a.tiles_w = ceil_div(a.nw, 32);
+    const int64_t ntiles = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
+    if (ntiles >= ((int64_t)1 << 31) || (int64_t)d->N * classes > 65535)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: too many tiles or samples");
+    dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)(d->N * classes));
+    switch (p.kind) {
+        case FK1: launch_f16<F16K1, 0>(a, grid, st); break;
+        case FK3: launch_f16<F16K3, 0>(a, grid, st); break;
+        case FK3H: launch_f16<F16K3H, 1>(a, grid, st); break;
+        case FK3S2: launch_f16<F16K3S2, 0>(a, grid, st); break;
+        case FK5: launch_f16<F16K5, 0>(a, grid, st); break;
+        case FK5D2: launch_f16<F16K5D2, 0>(a, grid, st); break;
+        case FK7: launch_f16<F16K7, 0>(a, grid, st); break;
+        case FDC: launch_f16<F16DC, 0>(a, grid, st); break;
+        default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: no kernel");
+    }
+    return check_launch("snvc_f16_conv3d_forward");
 }
 
 }  // extern "C"
