@@ -328,6 +328,24 @@ SNVC_API int snvc_f16_avgpool_depth4(const void *x_c8, float *y, int64_t N, int6
                                      int64_t x_batch_stride, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * N3  plane-sweep volume -> 3D grid resampling (global model)
+ * The consumer of build_cost_volume is not in the public reference (snvc/models/__init__.py:1-2); its helpers are:
+ * project_rect_to_image / project_image_to_rect / project_disp_to_depth_new (snvc/utils/torch_utils.py:5-45) and
+ * disparityregression (snvc/models/submodule.py:76-83, snvc_disparity_regression above).  The resampling step is
+ * defined against 5-D F.grid_sample(mode="bilinear" (= trilinear), padding_mode="zeros"); PARITY UNPINNED by the
+ * reference -- the oracle is torch's own grid_sample.
+ *   x [N,C,D,H,W]   grid [N,V,3] = (gx -> W, gy -> H, gz -> D) in [-1,1]   out [N,C,V]
+ * ---------------------------------------------------------------------------------- */
+SNVC_API int snvc_volume_resample(const float *x, const float *grid, float *out, int64_t N, int64_t C, int64_t D,
+                                  int64_t H, int64_t W, int64_t V, int align_corners, int64_t x_batch_stride,
+                                  int64_t out_batch_stride, void *stream);
+/* replaces: project_rect_to_image (snvc/utils/torch_utils.py:37-45) + the normalisation of (u, v, z) to grid_sample's
+ *   cube: pts_rect [V,3] -> grid [V,3]; g = (value - origin) / span * 2 - 1 per axis.  P_host: HOST pointer, 12 floats
+ *   (the 3x4 projection matrix, row major). */
+SNVC_API int snvc_rect_to_psv_grid(const float *pts_rect, const float *P_host, float *grid, int64_t V, float u0,
+                                   float u_span, float v0, float v_span, float z0, float z_span, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * a10  roiaware_pool3d
  * replaces: roiaware_pool3d_cuda.forward / backward / points_in_boxes_gpu / points_in_boxes_cpu
  *   (snvc/extension/roiaware_pool3d/src/roiaware_pool3d.cpp:29-177; kernels

@@ -69,6 +69,8 @@ SIGNATURES = {
     "snvc_f16_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_f16_mul_broadcast": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_f16_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_volume_resample": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_i64, c_p]),
+    "snvc_rect_to_psv_grid": (c_int, [c_p, c_p, c_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_p]),
     "snvc_roiaware_pool3d_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p] + [c_int] * 8 + [c_p]),
     "snvc_roiaware_pool3d_backward": (c_int, [c_p, c_p, c_p, c_p] + [c_int] * 7 + [c_p]),
     "snvc_points_in_boxes_gpu": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p]),

@@ -22,7 +22,7 @@ from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, C
 __all__ = [
     "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
     "Conv3dLayer", "conv_variant", "conv3d_wgrad", "Conv3dLayerF16", "to_c8", "from_c8", "voxel_gather_forward_f16",
-    "mul_broadcast_c8", "avgpool_depth4_c8", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
+    "mul_broadcast_c8", "avgpool_depth4_c8", "volume_resample", "rect_to_psv_grid", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
     "points_in_boxes_gpu", "points_in_boxes_cpu",
     "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID",
@@ -475,6 +475,45 @@ def argmax_rows(x2d) -> Tuple[torch.Tensor, torch.Tensor]:
     with torch.cuda.device(x2d.device):
         check(_lib.lib().snvc_argmax_rows(_ptr(x2d), _ptr(idx), _ptr(val), r, l, _stream(x2d)), "snvc_argmax_rows")
     return idx, val
+
+
+# ------------------------------------------------------------------------------ N3: PSV -> 3D grid resampling
+def volume_resample(x, grid, align_corners: bool = False) -> torch.Tensor:
+    """F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros") for a 5-D input: x [N,C,D,H,W] float32,
+    grid [N,Do,Ho,Wo,3] (or [N,V,3]) with (gx -> W, gy -> H, gz -> D) -> [N,C,Do,Ho,Wo] (or [N,C,V])."""
+    _gpu(x, "x"); _gpu(grid, "grid")
+    if x.dtype != torch.float32 or grid.dtype != torch.float32 or x.dim() != 5 or grid.size(-1) != 3 or grid.size(0) != x.size(0):
+        raise RuntimeError("volume_resample needs float32 x [N,C,D,H,W] and grid [N,...,3]")
+    if not _dense_inner(x):
+        x = x.contiguous()
+    n, c, d, h, w = x.shape
+    out_sp = tuple(grid.shape[1:-1])
+    g = grid.reshape(n, -1, 3).contiguous()
+    v = g.size(1)
+    out = torch.empty((n, c, v), dtype=torch.float32, device=x.device)
+    if out.numel():
+        with torch.cuda.device(x.device):
+            check(_lib.lib().snvc_volume_resample(_ptr(x), _ptr(g), _ptr(out), n, c, d, h, w, v, 1 if align_corners else 0,
+                                                  _batch_stride(x), 0, _stream(x)), "snvc_volume_resample")
+    return out.view((n, c) + out_sp)
+
+
+def rect_to_psv_grid(pts_rect, P, origin, span) -> torch.Tensor:
+    """project_rect_to_image (snvc/utils/torch_utils.py:37-45) + normalisation: pts_rect [V,3] (GPU, float32), P a 3x4
+    projection matrix (host), origin / span = (u0, v0, z0) / (u_span, v_span, z_span) -> grid [V,3] in [-1,1]."""
+    import numpy as np
+    _gpu(pts_rect, "pts_rect")
+    pts = pts_rect.contiguous()
+    if pts.dtype != torch.float32 or pts.dim() != 2 or pts.size(1) != 3:
+        raise RuntimeError("pts_rect must be float32 [V,3]")
+    p = np.ascontiguousarray(np.asarray(P.cpu() if torch.is_tensor(P) else P, dtype=np.float32).reshape(12))
+    grid = torch.empty_like(pts)
+    if pts.numel():
+        with torch.cuda.device(pts.device):
+            check(_lib.lib().snvc_rect_to_psv_grid(_ptr(pts), p.ctypes.data_as(ctypes.c_void_p), _ptr(grid), pts.size(0),
+                                                   float(origin[0]), float(span[0]), float(origin[1]), float(span[1]),
+                                                   float(origin[2]), float(span[2]), _stream(pts)), "snvc_rect_to_psv_grid")
+    return grid
 
 
 # ------------------------------------------------------------------------------ fp16-storage mode (C8 layout)

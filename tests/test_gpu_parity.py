@@ -909,3 +909,55 @@ def test_points_in_boxes():
     assert np.array_equal(got.cpu().numpy(), exp) and (exp >= 0).sum() > 50
     exp_cpu = O.points_in_boxes_cpu(pts, rois)
     assert np.array_equal(U.points_in_boxes_cpu(pts, rois), exp_cpu)
+
+
+# =============================================================================== N3 (parity unpinned by the reference)
+@pytest.mark.parametrize("align", [False, True])
+def test_volume_resample_vs_grid_sample(align):
+    """PSV -> 3D grid resampling: defined against 5-D F.grid_sample (trilinear, zeros padding); the
+    reference ships only the helper math (snvc/utils/torch_utils.py:5-45), so torch's operator is the oracle."""
+    import torch.nn.functional as F
+    from snvc_amd import ops
+    r = np.random.default_rng(61)
+    x = torch.from_numpy(r.standard_normal((2, 5, 6, 7, 9)).astype(np.float32))
+    grid = r.uniform(-1.15, 1.15, (2, 3, 4, 11, 3)).astype(np.float32)
+    grid[0, 0, 0, :4] = [[-1, -1, -1], [1, 1, 1], [0, 0, 0], [1e9, 0, 0]]     # exact corners, centre, far outside
+    g = torch.from_numpy(grid)
+    exp = F.grid_sample(x, g, mode="bilinear", padding_mode="zeros", align_corners=align)
+    got = ops.volume_resample(x.to(dev()), g.to(dev()), align_corners=align).cpu()
+    assert got.shape == exp.shape == (2, 5, 3, 4, 11)
+    check(got.numpy(), exp.numpy(), 1e-6, f"volume_resample align_corners={align}")
+    # channel-sliced input (a view of a wider buffer) and a flat [N,V,3] grid
+    big = torch.zeros(2, 8, 6, 7, 9, device=dev())
+    big[:, 2:7] = x.to(dev())
+    got2 = ops.volume_resample(big[:, 2:7], g.reshape(2, -1, 3).to(dev()), align_corners=align).cpu()
+    assert torch.equal(got2.view_as(got), got)
+
+
+def test_psv_to_grid_chain_vs_torch():
+    """project_rect_to_image (torch_utils.py:37-45) + normalisation on the device, then the resampler, then
+    disparityregression (submodule.py:76-83) on the same volume: the global model's read-out steps chained."""
+    import torch.nn.functional as F
+    from snvc_amd import ops
+    r = np.random.default_rng(62)
+    P = np.array([7.215377e+02, 0.0, 6.095593e+02, 4.485728e+01, 0.0, 7.215377e+02, 1.728540e+02, 2.163791e-01,
+                  0.0, 0.0, 1.0, 2.745884e-03], dtype=np.float32).reshape(3, 4)
+    pts = np.stack([r.uniform(-20, 20, 500), r.uniform(-1, 3, 500), r.uniform(2, 60, 500)], 1).astype(np.float32)
+    origin, span = (0.0, 0.0, 2.0), (1247.0, 383.0, 58.0)
+    # the reference's helper, expression by expression
+    ph = torch.cat([torch.from_numpy(pts), torch.ones(500, 1)], dim=1)
+    p2 = torch.mm(ph, torch.from_numpy(P).t())
+    uv = torch.stack([p2[:, 0] / p2[:, 2], p2[:, 1] / p2[:, 2]], 1)
+    exp = torch.stack([(uv[:, 0] - origin[0]) / span[0] * 2 - 1, (uv[:, 1] - origin[1]) / span[1] * 2 - 1,
+                       (torch.from_numpy(pts)[:, 2] - origin[2]) / span[2] * 2 - 1], 1)
+    grid = ops.rect_to_psv_grid(torch.from_numpy(pts).to(dev()), P, origin, span)
+    assert np.abs(grid.cpu().numpy() - exp.numpy()).max() < 2e-6
+    cost = torch.from_numpy(r.standard_normal((1, 1, 12, 10, 14)).astype(np.float32))
+    feat = torch.from_numpy(r.standard_normal((1, 4, 12, 10, 14)).astype(np.float32))
+    vox = ops.volume_resample(feat.to(dev()), grid.view(1, -1, 3), align_corners=True).cpu()
+    ref = F.grid_sample(feat, grid.cpu().view(1, 1, 1, -1, 3), mode="bilinear", padding_mode="zeros", align_corners=True)
+    check(vox.numpy(), ref[:, :, 0, 0].numpy(), 1e-6, "psv -> grid")
+    depth = torch.linspace(2.0, 60.0, 12)
+    prob = torch.softmax(cost[:, 0], dim=1)
+    dm = ops.disparity_regression(prob.to(dev()), depth.to(dev())).cpu()
+    check(dm.numpy(), (prob * depth.view(1, -1, 1, 1)).sum(1).numpy(), 1e-6, "disparityregression")
