@@ -195,6 +195,103 @@ voxel_gather_fwd_cl_x4(const float *__restrict__ ws, const float *__restrict__ l
 }
 
 
+// ---- LDS-staged forward path (the default when the feature plane fits) ----
+// The channels-last kernels above read every bilinear tap through the vector L1: 1 KB of L1 traffic per voxel for
+// 256 output bytes at F = 32.  On coherent coordinates (neighbouring lanes hit the same pixel) that is invisible; on
+// real projections it is the bound (2.4-2.8 TB/s measured with GridProjector coordinates, 1.4 TB/s on uniform random
+// ones, against 5.1 TB/s on a degenerate line).  Here a workgroup owns a run of voxels and a slice of CS channels:
+// per camera it copies that channel slice of the WHOLE feature map into LDS ([pixel][CS] floats, 64 KB at 64x64x4;
+// LDS-DMA from the channels-last workspace), then resolves its taps with ds_read_b128 -- LDS serves 256 B/clk/CU
+// where the L1 serves 64, and its rate does not depend on how coherent the coordinates are.  Same taps, same
+// separately rounded a*nw + b*ne + c*sw + d*se: bit-identical to the other kernels.  Two workgroups fit a CU, so one
+// streams its outputs while the other refills.
+template <int CS, bool HALF>
+__global__ void __launch_bounds__(256)
+voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
+                     void *__restrict__ out_, int F, int Hf, int Wf, int64_t V, int64_t vrun, float res_x, float res_y) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    static_assert(HALF ? CS == 8 : CS == 4, "fp32 output: 4-channel slices; C8 half output: one 8-channel group");
+    constexpr int U = HALF ? 1 : 4;          // voxels per thread and step
+    extern __shared__ __attribute__((aligned(16))) float img[];
+    const int tid = threadIdx.x;
+    const int cs = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int plane = Hf * Wf;
+    const int64_t v0 = (int64_t)blockIdx.x * vrun;
+    const int64_t v1 = v0 + vrun < V ? v0 + vrun : V;
+    const int pieces = plane * (CS / 4);                      // 16-byte pieces of the slice
+#pragma unroll 1
+    for (int side = 0; side < 2; ++side) {
+        const float *feat = ws + ((int64_t)side * gridDim.z + n) * plane * F + cs * CS;
+        for (int i0 = 0; i0 < pieces; i0 += 256) {
+            const int i = i0 + tid;
+            const int px = i / (CS / 4), hq = i - px * (CS / 4);
+            if (i < pieces)
+                __builtin_amdgcn_global_load_lds(feat + (int64_t)px * F + 4 * hq, img + 4 * (i0 + (tid & ~63)), 16, 0, 0);
+        }
+        __syncthreads();       // drains the DMA: the slice is in LDS
+        const float *pts = (side == 0 ? l_pts : r_pts) + n * 2 * V;
+        for (int64_t v = v0 + (int64_t)tid * U; v < v1; v += 256 * U) {
+            float px[U], py[U];
+            if constexpr (U == 4) {
+                const f4 x4 = *reinterpret_cast<const f4 *>(pts + v), y4 = *reinterpret_cast<const f4 *>(pts + V + v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { px[k] = x4[k]; py[k] = y4[k]; }
+            } else {
+                px[0] = pts[v]; py[0] = pts[V + v];
+            }
+            if constexpr (!HALF) {
+                f4 res[4];       // res[j] = channel cs*4 + j of the 4 voxels
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const Taps t = make_taps(px[k], py[k], res_x, res_y, Hf, Wf);
+                    const f4 a4 = *reinterpret_cast<const f4 *>(img + 4 * (t.off[0] < 0 ? 0 : t.off[0]));
+                    const f4 b4 = *reinterpret_cast<const f4 *>(img + 4 * (t.off[1] < 0 ? 0 : t.off[1]));
+                    const f4 c4 = *reinterpret_cast<const f4 *>(img + 4 * (t.off[2] < 0 ? 0 : t.off[2]));
+                    const f4 d4 = *reinterpret_cast<const f4 *>(img + 4 * (t.off[3] < 0 ? 0 : t.off[3]));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = t.off[0] >= 0 ? a4[j] : 0.0f, b = t.off[1] >= 0 ? b4[j] : 0.0f;
+                        const float c = t.off[2] >= 0 ? c4[j] : 0.0f, d = t.off[3] >= 0 ? d4[j] : 0.0f;
+                        res[j][k] = a * t.wt[0] + b * t.wt[1] + c * t.wt[2] + d * t.wt[3];
+                    }
+                }
+                float *o = reinterpret_cast<float *>(out_) + (n * 2 * F + (int64_t)side * F + cs * 4) * V + v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(res[j], reinterpret_cast<f4 *>(o + (int64_t)j * V));
+            } else {
+                const Taps t = make_taps(px[0], py[0], res_x, res_y, Hf, Wf);
+                h8 res;
+#pragma unroll
+                for (int hq = 0; hq < 2; ++hq) {
+                    const f4 a4 = *reinterpret_cast<const f4 *>(img + 8 * (t.off[0] < 0 ? 0 : t.off[0]) + 4 * hq);
+                    const f4 b4 = *reinterpret_cast<const f4 *>(img + 8 * (t.off[1] < 0 ? 0 : t.off[1]) + 4 * hq);
+                    const f4 c4 = *reinterpret_cast<const f4 *>(img + 8 * (t.off[2] < 0 ? 0 : t.off[2]) + 4 * hq);
+                    const f4 d4 = *reinterpret_cast<const f4 *>(img + 8 * (t.off[3] < 0 ? 0 : t.off[3]) + 4 * hq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float a = t.off[0] >= 0 ? a4[j] : 0.0f, b = t.off[1] >= 0 ? b4[j] : 0.0f;
+                        const float c = t.off[2] >= 0 ? c4[j] : 0.0f, d = t.off[3] >= 0 ? d4[j] : 0.0f;
+                        res[4 * hq + j] = (_Float16)(a * t.wt[0] + b * t.wt[1] + c * t.wt[2] + d * t.wt[3]);
+                    }
+                }
+                _Float16 *o = reinterpret_cast<_Float16 *>(out_) + ((n * 2 * (F / 8) + (int64_t)side * (F / 8) + cs) * V + v) * 8;
+                __builtin_nontemporal_store(res, reinterpret_cast<h8 *>(o));
+            }
+        }
+        __syncthreads();       // every tap of this camera is resolved before the slice is overwritten
+    }
+}
+
+// voxels per workgroup: enough workgroups to fill the chip twice over, runs as long as that allows (the refill of the
+// slice is amortised over the run), whole 1024-voxel steps
+inline int64_t gather_run_length(int64_t V, int64_t slices, int64_t N) {
+    const int64_t want = ceil_div<int64_t>(4 * (int64_t)device_cu_count(), slices * N);     // workgroups along the voxel axis
+    int64_t run = ceil_div<int64_t>(ceil_div<int64_t>(V, want), 1024) * 1024;
+    return run < 1024 ? 1024 : run;
+}
+
 // fp16-storage output (conv3d_f16.hip's C8 layout [N][2F/8][V][8]; BASELINE.json configs[4]): same taps, same
 // separately rounded fp32 a*nw + b*ne + c*sw + d*se per channel as the kernels above, rounded to half once on
 // the way out.  One voxel per thread: a wave stores 1 KB contiguous per channel group (64 voxels x 16 bytes), and
@@ -349,8 +446,17 @@ int snvc_voxel_gather_forward_ws(const float *left, const float *right, const fl
     dim3 tg((unsigned)ceil_div(plane, 64), (unsigned)N, 2);
     features_to_channels_last<<<tg, 256, (size_t)64 * (F + 1) * sizeof(float), as_stream(stream)>>>(left, right, workspace,
                                                                                                     (int)F, plane);
-    if (V % 4 == 0 &&
-        ((reinterpret_cast<uintptr_t>(l_pts) | reinterpret_cast<uintptr_t>(r_pts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    const bool x4 = V % 4 == 0 &&
+        ((reinterpret_cast<uintptr_t>(l_pts) | reinterpret_cast<uintptr_t>(r_pts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (x4 && (int64_t)plane * 16 <= 72 * 1024 && V >= 4096) {     // LDS-staged 4-channel slices (two workgroups per CU)
+        const int64_t run = gather_run_length(V, F / 4, N);
+        static std::atomic<unsigned> attr_done{0};
+        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<4, false>), plane * 16, attr_done)) {
+            dim3 grid((unsigned)ceil_div<int64_t>(V, run), (unsigned)(F / 4), (unsigned)N);
+            voxel_gather_fwd_lds<4, false><<<grid, 256, (size_t)plane * 16, as_stream(stream)>>>(
+                workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run, res_x, res_y);
+        }
+    } else if (x4) {
         dim3 grid((unsigned)ceil_div<int64_t>(V / 4, 256), (unsigned)N);
         voxel_gather_fwd_cl_x4<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf,
                                                                     V, res_x, res_y);
@@ -379,9 +485,19 @@ int snvc_voxel_gather_forward_f16(const float *left, const float *right, const f
     dim3 tg((unsigned)ceil_div(plane, 64), (unsigned)N, 2);
     features_to_channels_last<<<tg, 256, (size_t)64 * (F + 1) * sizeof(float), as_stream(stream)>>>(left, right, workspace,
                                                                                                     (int)F, plane);
-    dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
-    voxel_gather_fwd_cl_c8<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, reinterpret_cast<_Float16 *>(out),
-                                                                (int)F, (int)Hf, (int)Wf, V, res_x, res_y);
+    if ((int64_t)plane * 32 <= 144 * 1024 && V >= 4096) {      // LDS-staged 8-channel groups (one workgroup per CU)
+        const int64_t run = gather_run_length(V, F / 8, N);
+        static std::atomic<unsigned> attr_done{0};
+        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<8, true>), plane * 32, attr_done)) {
+            dim3 grid((unsigned)ceil_div<int64_t>(V, run), (unsigned)(F / 8), (unsigned)N);
+            voxel_gather_fwd_lds<8, true><<<grid, 256, (size_t)plane * 32, as_stream(stream)>>>(
+                workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run, res_x, res_y);
+        }
+    } else {
+        dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
+        voxel_gather_fwd_cl_c8<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, reinterpret_cast<_Float16 *>(out),
+                                                                    (int)F, (int)Hf, (int)Wf, V, res_x, res_y);
+    }
     return check_launch("snvc_voxel_gather_forward_f16");
 }
 

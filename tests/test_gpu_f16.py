@@ -126,10 +126,11 @@ def test_f16_one_channel_head_vs_torch():
         assert (y.cpu().double() - ref).abs().max().item() < 2e-5
 
 
-def test_f16_gather_equals_rounded_fp32_gather():
+@pytest.mark.parametrize("grid", [(4, 8, 12), (16, 16, 24)], ids=["direct", "lds_staged"])
+def test_f16_gather_equals_rounded_fp32_gather(grid):
     from snvc_amd import ops
     g = np.random.default_rng(3)
-    n, f, hf, wf, grid = 2, 32, 16, 16, (4, 8, 12)
+    n, f, hf, wf = 2, 32, 16, 16
     v = grid[0] * grid[1] * grid[2]
     lf = torch.from_numpy(g.standard_normal((n, f, hf, wf)).astype(np.float32)).to(dev())
     rf = torch.from_numpy(g.standard_normal((n, f, hf, wf)).astype(np.float32)).to(dev())
