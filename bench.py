@@ -118,7 +118,7 @@ def cpu_baseline(d_sample=D):
 
 
 # ------------------------------------------------------------------------------------------ helpers
-def timed_ms(fn, reps=3, warm=1):
+def timed_ms(fn, reps=3, warm=2):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()

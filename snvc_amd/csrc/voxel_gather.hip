@@ -205,8 +205,8 @@ voxel_gather_fwd_cl_x4(const float *__restrict__ ws, const float *__restrict__ l
 // where the L1 serves 64, and its rate does not depend on how coherent the coordinates are.  Same taps, same
 // separately rounded a*nw + b*ne + c*sw + d*se: bit-identical to the other kernels.  Two workgroups fit a CU, so one
 // streams its outputs while the other refills.
-template <int CS, bool HALF>
-__global__ void __launch_bounds__(256)
+template <int CS, bool HALF, int BS>
+__global__ void __launch_bounds__(BS)
 voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
                      void *__restrict__ out_, int F, int Hf, int Wf, int64_t V, int64_t vrun, float res_x, float res_y) {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -224,23 +224,27 @@ voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_p
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
         const float *feat = ws + ((int64_t)side * gridDim.z + n) * plane * F + cs * CS;
-        for (int i0 = 0; i0 < pieces; i0 += 256) {
+        for (int i0 = 0; i0 < pieces; i0 += BS) {
             const int i = i0 + tid;
             const int px = i / (CS / 4), hq = i - px * (CS / 4);
             if (i < pieces)
                 __builtin_amdgcn_global_load_lds(feat + (int64_t)px * F + 4 * hq, img + 4 * (i0 + (tid & ~63)), 16, 0, 0);
         }
-        __syncthreads();       // drains the DMA: the slice is in LDS
         const float *pts = (side == 0 ? l_pts : r_pts) + n * 2 * V;
-        for (int64_t v = v0 + (int64_t)tid * U; v < v1; v += 256 * U) {
-            float px[U], py[U];
-            if constexpr (U == 4) {
-                const f4 x4 = *reinterpret_cast<const f4 *>(pts + v), y4 = *reinterpret_cast<const f4 *>(pts + V + v);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { px[k] = x4[k]; py[k] = y4[k]; }
-            } else {
-                px[0] = pts[v]; py[0] = pts[V + v];
+        // coordinates of the first step are fetched while the slice lands; every step fetches the next one's first
+        int64_t v = v0 + (int64_t)tid * U;
+        f4 cx = f4(0.0f), cy = f4(0.0f);
+        auto fetch = [&](int64_t vv) {
+            if (vv < v1) {
+                if constexpr (U == 4) { cx = *reinterpret_cast<const f4 *>(pts + vv); cy = *reinterpret_cast<const f4 *>(pts + V + vv); }
+                else { cx[0] = pts[vv]; cy[0] = pts[V + vv]; }
             }
+        };
+        fetch(v);
+        __syncthreads();       // drains the DMA: the slice is in LDS
+        for (; v < v1; v += BS * U) {
+            const f4 px = cx, py = cy;
+            fetch(v + BS * U);
             if constexpr (!HALF) {
                 f4 res[4];       // res[j] = channel cs*4 + j of the 4 voxels
 #pragma unroll
@@ -285,11 +289,11 @@ voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_p
 }
 
 // voxels per workgroup: enough workgroups to fill the chip twice over, runs as long as that allows (the refill of the
-// slice is amortised over the run), whole 1024-voxel steps
+// slice is amortised over the run), whole 4096-voxel steps
 inline int64_t gather_run_length(int64_t V, int64_t slices, int64_t N) {
     const int64_t want = ceil_div<int64_t>(4 * (int64_t)device_cu_count(), slices * N);     // workgroups along the voxel axis
-    int64_t run = ceil_div<int64_t>(ceil_div<int64_t>(V, want), 1024) * 1024;
-    return run < 1024 ? 1024 : run;
+    int64_t run = ceil_div<int64_t>(ceil_div<int64_t>(V, want), 4096) * 4096;
+    return run < 4096 ? 4096 : run;
 }
 
 // fp16-storage output (conv3d_f16.hip's C8 layout [N][2F/8][V][8]; BASELINE.json configs[4]): same taps, same
@@ -451,9 +455,9 @@ int snvc_voxel_gather_forward_ws(const float *left, const float *right, const fl
     if (x4 && (int64_t)plane * 16 <= 72 * 1024 && V >= 4096) {     // LDS-staged 4-channel slices (two workgroups per CU)
         const int64_t run = gather_run_length(V, F / 4, N);
         static std::atomic<unsigned> attr_done{0};
-        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<4, false>), plane * 16, attr_done)) {
+        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<4, false, 512>), plane * 16, attr_done)) {
             dim3 grid((unsigned)ceil_div<int64_t>(V, run), (unsigned)(F / 4), (unsigned)N);
-            voxel_gather_fwd_lds<4, false><<<grid, 256, (size_t)plane * 16, as_stream(stream)>>>(
+            voxel_gather_fwd_lds<4, false, 512><<<grid, 512, (size_t)plane * 16, as_stream(stream)>>>(
                 workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run, res_x, res_y);
         }
     } else if (x4) {
@@ -488,9 +492,9 @@ int snvc_voxel_gather_forward_f16(const float *left, const float *right, const f
     if ((int64_t)plane * 32 <= 144 * 1024 && V >= 4096) {      // LDS-staged 8-channel groups (one workgroup per CU)
         const int64_t run = gather_run_length(V, F / 8, N);
         static std::atomic<unsigned> attr_done{0};
-        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<8, true>), plane * 32, attr_done)) {
+        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<8, true, 1024>), plane * 32, attr_done)) {
             dim3 grid((unsigned)ceil_div<int64_t>(V, run), (unsigned)(F / 8), (unsigned)N);
-            voxel_gather_fwd_lds<8, true><<<grid, 256, (size_t)plane * 32, as_stream(stream)>>>(
+            voxel_gather_fwd_lds<8, true, 1024><<<grid, 1024, (size_t)plane * 32, as_stream(stream)>>>(
                 workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run, res_x, res_y);
         }
     } else {
