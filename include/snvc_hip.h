@@ -174,6 +174,11 @@ typedef struct {
     int32_t transposed; /* 0: Conv3d, 1: ConvTranspose3d(k3,s2,p1,op1) */
     int32_t flags;      /* SNVC_EPI_* */
     int32_t algo;       /* SNVC_ALGO_* */
+    int32_t ksize_d;    /* kernel extent along D: 0 = cubic (= ksize); 1 = depth-1 layer, i.e. an nn.Conv2d(k, stride,
+                           padding=(k-1)/2) of the 2D BEV neck (snvc/models/vernier.py:296-313, submodule.py:11-29,
+                           270-361) run on the [N,C,1,H,W] view of its NCHW tensors: Din = Dout = 1, k in {1,3}, stride
+                           in {1,2} applied to H and W only, weight [Cout,Cin,k,k] */
+    int32_t reserved;   /* 0 */
     int64_t x_batch_stride, y_batch_stride, res_batch_stride; /* elements; 0 = dense */
 } snvc_conv3d_desc;
 
@@ -273,6 +278,10 @@ SNVC_API int snvc_mul_broadcast(const float *feat, const float *occ, float *out,
  *   x [N,C,D,H*W] -> y [N,C,D/4,H*W] (== [N, C*D/4, H, W] after a free reshape). */
 SNVC_API int snvc_avgpool_depth4(const float *x, float *y, int64_t N, int64_t C, int64_t D,
                                  int64_t HW, void *stream);
+/* Zero-stuffing pass of the 2D up-sampling layers: x [R,H,W] -> y [R,2H,2W], y[r,2i,2j] = x[r,i,j], 0 elsewhere.
+ * nn.ConvTranspose2d(k3,s2,p1,op1) of the BEV neck (snvc/models/submodule.py:291-314) == the depth-1 k3 / stride-1
+ * convolution (desc.ksize_d = 1) of y with the flipped, channel-transposed kernel. */
+SNVC_API int snvc_zero_stuff2x(const float *x, float *y, int64_t R, int64_t H, int64_t W, void *stream);
 /* replaces: disparityregression.forward (snvc/models/submodule.py:81-83):
  *   out[n,h,w] = sum_d x[n,d,h,w] * depth[d]. */
 SNVC_API int snvc_disparity_regression(const float *x, const float *depth, float *out, int64_t N,

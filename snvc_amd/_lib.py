@@ -21,7 +21,7 @@ class Conv3dDesc(ctypes.Structure):
     """Mirror of ``snvc_conv3d_desc`` (include/snvc_hip.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         "N", "Cin", "Din", "Hin", "Win", "Cout", "Dout", "Hout", "Wout",
-        "ksize", "stride", "dilation", "pad", "transposed", "flags", "algo")] + [
+        "ksize", "stride", "dilation", "pad", "transposed", "flags", "algo", "ksize_d", "reserved")] + [
         (n, ctypes.c_int64) for n in ("x_batch_stride", "y_batch_stride", "res_batch_stride")]
 
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "snvc_act_backward_apply": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     "snvc_mul_broadcast": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_zero_stuff2x": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p]),
     "snvc_disparity_regression": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p]),
     "snvc_argmax_rows": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "snvc_f16_from_ncdhw": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
@@ -100,7 +101,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
-        if handle.snvc_abi_version() != 1:
+        if handle.snvc_abi_version() != 2:
             raise RuntimeError("libsnvc_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

@@ -332,22 +332,26 @@ __device__ __forceinline__ void store_pairs_x4(char *base, int64_t cs, unsigned 
 }
 
 // ------------------------------------------------------------------------------------ conv
-template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_, bool DB_, int OCC_ = 2, int KDG_ = 0>
+template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_, bool DB_, int OCC_ = 2, int KDG_ = 0, int KSD_ = KS_>
 struct ConvCfg {
+    // KSD: kernel extent along D.  KSD = KS for the cubic 3D layers; KSD = 1 (with TD = 1) is the depth-1 form that
+    // runs the 2D BEV neck's Conv2d layers on [N,C,1,H,W] views (desc.ksize_d = 1).
     // A chunk (KC input channels) is consumed in NPH phases of KDG kernel depth-slices each; the
     // weights of ONE phase are resident in LDS at a time (double buffered), the input image of the
     // whole chunk stays resident across its phases.
-    static constexpr int KDG = KDG_ == 0 ? KS_ : KDG_;
-    static constexpr int NPH = KS_ / KDG;
-    static_assert(KS_ % KDG == 0, "phases must tile the kernel depth");
+    static constexpr int KSD = KSD_;
+    static constexpr int KDG = KDG_ == 0 ? KSD_ : KDG_;
+    static constexpr int NPH = KSD_ / KDG;
+    static_assert(KSD_ % KDG == 0, "phases must tile the kernel depth");
     static constexpr int OCC = OCC_;                // minimum waves per SIMD requested from the register allocator
     static constexpr int KS = KS_, STRIDE = STRIDE_, DIL = DIL_, MI = MI_, TD = TD_, TH = TH_, KC = KC_;
     static constexpr bool DB = DB_;                 // double-buffered LDS image (one barrier per chunk)
     static constexpr int TW = 32;
     static constexpr int PAD = DIL * (KS - 1) / 2;
+    static constexpr int PAD_D = DIL * (KSD - 1) / 2;
     static constexpr int LPAD = (PAD + 3) / 4 * 4;  // left halo rounded to a 16-byte boundary
     static constexpr int XOFF = LPAD - PAD;         // image column of the tile's first needed input
-    static constexpr int IN_D = (TD - 1) * STRIDE + (KS - 1) * DIL + 1;
+    static constexpr int IN_D = (TD - 1) * STRIDE + (KSD - 1) * DIL + 1;
     static constexpr int IN_H = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
     static constexpr int IN_W = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;
@@ -355,7 +359,7 @@ struct ConvCfg {
     static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int NB = TD * TH / 4;          // 32-voxel rows per wave (4 waves)
     static constexpr int KP = KC / 2;               // MFMA k-steps per chunk
-    static constexpr int TAPS = KS * KS * KS;
+    static constexpr int TAPS = KSD * KS * KS;
     static constexpr int WF = KDG * KS * KS * KP * 64 * MI;   // packed weight floats per phase
     using Ws = WeightStager<WF>;
     static constexpr int IMG_BUFS = DB ? 2 : 1;
@@ -485,7 +489,7 @@ conv3d_mfma_kernel(const ConvArgs a) {
     const int cg = blockIdx.y;  // group of 32*MI output channels
     const int64_t n = blockIdx.z;
     const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 32;
-    const int id0 = od0 * S - PAD, ih0 = oh0 * S - PAD, ix0 = ow0 * S - LPAD;
+    const int id0 = od0 * S - Cfg::PAD_D, ih0 = oh0 * S - PAD, ix0 = ow0 * S - LPAD;
 
     f32x16 acc[NB][MI];
 #pragma unroll
@@ -1833,6 +1837,7 @@ enum Kind {
     K5D2_M1, K5D2_M2,
     K7_M1, K7_M2,
     DC_M1, DC_M2,
+    P1_M1, P1_M2, P1S2_M1, P1S2_M2, P3_M1, P3_M2, P3S2_M1, P3S2_M2,     // depth-1 (2D) layers
     KIND_NONE
 };
 
@@ -1849,6 +1854,16 @@ using CfgK5D2M1 = ConvCfg<5, 1, 2, 1, 4, 4, 2, false, 2, 1>;
 using CfgK5D2M2 = ConvCfg<5, 1, 2, 2, 4, 4, 2, false, 2, 1>;
 using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 4, 2, false, 2, 1>;
 using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false, 2, 1>;
+// depth-1 layers (Conv2d of the BEV neck on [N,C,1,H,W] views): tile 1 x 8 x 32
+//                        KS S  D  MI TD TH KC  DB   OCC KDG KSD
+using CfgP1M1   = ConvCfg<1, 1, 1, 1, 1, 8, 8, true, 2, 0, 1>;
+using CfgP1M2   = ConvCfg<1, 1, 1, 2, 1, 8, 8, true, 2, 0, 1>;
+using CfgP1S2M1 = ConvCfg<1, 2, 1, 1, 1, 8, 8, true, 2, 0, 1>;
+using CfgP1S2M2 = ConvCfg<1, 2, 1, 2, 1, 8, 8, true, 2, 0, 1>;
+using CfgP3M1   = ConvCfg<3, 1, 1, 1, 1, 8, 8, true, 2, 0, 1>;
+using CfgP3M2   = ConvCfg<3, 1, 1, 2, 1, 8, 8, true, 2, 0, 1>;
+using CfgP3S2M1 = ConvCfg<3, 2, 1, 1, 1, 8, 4, true, 2, 0, 1>;
+using CfgP3S2M2 = ConvCfg<3, 2, 1, 2, 1, 8, 4, true, 2, 0, 1>;
 using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64 voxels, 2 input channels per chunk
 using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per wave: large layers
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;
@@ -1881,7 +1896,26 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
         // form only remains for channel counts that are not multiples of 32
         p = (wide && d.Cout % 32 != 0) ? plan_of<CfgDCM2>(DC_M2) : plan_of<CfgDCM1>(DC_M1);
         p.tiles_d = ceil_div(d.Din, p.TD); p.tiles_h = ceil_div(d.Hin, p.TH); p.tiles_w = ceil_div(d.Win, 32);
+    } else if (d.ksize_d == 1) {
+        // depth-1 layer: nn.Conv2d(k, stride, padding=(k-1)/2) on an [N,C,1,H,W] view; the stride applies to H and W only
+        // (k = 1, stride 2 is BasicBlock's downsample path, hrnet.py:56-69)
+        if (d.Din != 1 || d.Dout != 1 || d.dilation != 1 || d.pad != (d.ksize - 1) / 2)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: ksize_d = 1 needs Din = Dout = 1, dilation 1, pad = (ksize-1)/2");
+        const int eH = (d.Hin + 2 * d.pad - d.ksize) / d.stride + 1, eW = (d.Win + 2 * d.pad - d.ksize) / d.stride + 1;
+        if (d.Hout != eH || d.Wout != eW)
+            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: output size does not match the convolution arithmetic");
+        const int key = d.ksize * 10 + d.stride;
+        switch (key) {
+            case 11: p = wide ? plan_of<CfgP1M2>(P1_M2) : plan_of<CfgP1M1>(P1_M1); break;
+            case 12: p = wide ? plan_of<CfgP1S2M2>(P1S2_M2) : plan_of<CfgP1S2M1>(P1S2_M1); break;
+            case 31: p = wide ? plan_of<CfgP3M2>(P3_M2) : plan_of<CfgP3M1>(P3_M1); break;
+            case 32: p = wide ? plan_of<CfgP3S2M2>(P3S2_M2) : plan_of<CfgP3S2M1>(P3S2_M1); break;
+            default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: depth-1 layers are built for ksize 1 and 3, stride 1 and 2");
+        }
+        p.tiles_d = 1; p.tiles_h = ceil_div(d.Hout, p.TH); p.tiles_w = ceil_div(d.Wout, 32);
     } else {
+        if (d.ksize_d != 0 && d.ksize_d != d.ksize)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: ksize_d must be 0 (cubic), ksize or 1");
         if (d.pad != d.dilation * (d.ksize - 1) / 2)
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: pad must equal dilation*(ksize-1)/2");
         const int eff = d.dilation * (d.ksize - 1) + 1;
@@ -2024,8 +2058,10 @@ int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
     using namespace snvc;
     Plan p;
     if (!d || make_plan(*d, p) != SNVC_OK) return -1;
-    const int64_t taps = d->transposed ? 27 : (int64_t)d->ksize * d->ksize * d->ksize;
+    const bool planar = d->ksize_d == 1;      // depth-1 layer: only the direct packing, no special forms
+    const int64_t taps = d->transposed ? 27 : (int64_t)(planar ? 1 : d->ksize) * d->ksize * d->ksize;
     int64_t count = (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
+    if (planar) return count;
     count += wino_packed_count(*d);   // k3/s1 layers also carry the Winograd-transformed weights
     // 1x1x1 layers with <= 2 output channels also keep their raw [Cout][Cin] weights (streaming kernel)
     if (!d->transposed && d->ksize == 1 && d->Cout <= 2) count += (int64_t)d->Cout * d->Cin;
@@ -2042,15 +2078,16 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
     if (rc) return rc;
     if (!weight || !packed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_pack_weights: null pointer");
     int64_t total = snvc_conv3d_packed_weight_count(d);
-    const bool k3c1 = !d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1;
-    if ((!d->transposed && d->ksize == 1 && d->Cout <= 2) || k3c1) {   // raw copy behind the MFMA packing
+    const bool planar = d->ksize_d == 1;
+    const bool k3c1 = !planar && !d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1;
+    if (!planar && ((!d->transposed && d->ksize == 1 && d->Cout <= 2) || k3c1)) {   // raw copy behind the MFMA packing
         const int64_t nraw = k3c1 ? (int64_t)d->Cin * 27 : (int64_t)d->Cout * d->Cin;
         total -= nraw;
         if (hipMemcpyAsync(packed + total, weight, sizeof(float) * nraw, hipMemcpyDeviceToDevice,
                            as_stream(stream)) != hipSuccess)
             return fail(SNVC_ERR_HIP, "snvc_conv3d_pack_weights: hipMemcpyAsync failed");
     }
-    const int64_t wino = wino_packed_count(*d);
+    const int64_t wino = planar ? 0 : wino_packed_count(*d);
     if (wino) {
         total -= wino;
         const unsigned wb = (unsigned)ceil_div<int64_t>(wino, 256);
@@ -2072,7 +2109,7 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
                                                                            p.nchunks, total);
     else
         pack_conv_weights_kernel<<<blocks, 256, 0, as_stream(stream)>>>(weight, packed, d->Cout, d->Cin,
-                                                                         d->ksize * d->ksize * d->ksize, p.MI, p.KC,
+                                                                         (planar ? 1 : d->ksize) * d->ksize * d->ksize, p.MI, p.KC,
                                                                          p.nchunks, total);
     return check_launch("snvc_conv3d_pack_weights");
 }
@@ -2122,7 +2159,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: residual flag without residual pointer");
     if ((d->flags & SNVC_EPI_ADD_PRE) && (d->flags & SNVC_EPI_ADD_POST))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: ADD_PRE and ADD_POST are exclusive");
-    if (depth_planes && (d->transposed || d->stride != 1 || d->Dout < 2 || (d->ksize == 1 && d->Cout <= 2)))
+    if (depth_planes && (d->transposed || d->stride != 1 || d->Dout < 2 || d->ksize_d == 1 || (d->ksize == 1 && d->Cout <= 2)))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_ex: depth planes need a stride-1 Conv3d with Dout >= 2");
     if (d->transposed && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 7))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: transposed y / residual must be 8-byte aligned");
@@ -2159,8 +2196,9 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
 
     // 1x1x1 convolution to <= 2 channels: HBM-bound streaming kernel (raw weights ride at the end of
     // the packed buffer, see snvc_conv3d_pack_weights)
+    const bool planar = d->ksize_d == 1;
     const int64_t S = (int64_t)d->Dout * d->Hout * d->Wout;
-    if (!d->transposed && d->ksize == 1 && d->stride == 1 && d->Cout <= 2 && (S % 4) == 0 &&
+    if (!planar && !d->transposed && d->ksize == 1 && d->stride == 1 && d->Cout <= 2 && (S % 4) == 0 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0 &&
         a.x_bs % 4 == 0 && a.y_bs % 4 == 0 && a.r_bs % 4 == 0) {
         const float *wraw = packed_weight + snvc_conv3d_packed_weight_count(d) - (int64_t)d->Cout * d->Cin;
@@ -2174,7 +2212,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         return check_launch("snvc_conv3d_forward(pointwise)");
     }
     // 3x3x3 / stride 1 to ONE channel: VALU kernel (raw weights ride at the end of the packed buffer)
-    if (!d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1 && !depth_planes) {
+    if (!planar && !d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1 && !depth_planes) {
         const float *wraw = packed_weight + snvc_conv3d_packed_weight_count(d) - (int64_t)d->Cin * 27;
         const int th_ = ceil_div(d->Hout, K3C1_TH), tw_ = ceil_div(d->Wout, 32);
         const int64_t nt = (int64_t)ceil_div(d->Dout, K3C1_TD) * th_ * tw_;
@@ -2188,7 +2226,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     {
         const bool out8 = fast_common && (d->Wout % 2 == 0) && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
                           ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res)) & 7) == 0;
-        if (!d->transposed && d->ksize == 3 && d->stride == 2 && d->dilation == 1 && a.vec && (a.fast_epi || out8) &&
+        if (!planar && !d->transposed && d->ksize == 3 && d->stride == 2 && d->dilation == 1 && a.vec && (a.fast_epi || out8) &&
             !depth_planes && !direct_only) {
             a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 27 * (p.KC / 2) * 64 * p.MI;
             a.nchunks_wino = ceil_div(d->Cin, 2);
@@ -2204,7 +2242,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         }
     }
     // k5 / k7, stride 1, no dilation: Winograd F(4,KS) along W (LDS-DMA staged: 16-byte rows only)
-    if (!d->transposed && (d->ksize == 5 || d->ksize == 7) && d->stride == 1 &&
+    if (!planar && !d->transposed && (d->ksize == 5 || d->ksize == 7) && d->stride == 1 &&
         (d->dilation == 1 || (d->dilation == 2 && d->ksize == 5)) && a.vec && a.fast_epi && !depth_planes) {
         if (!direct_only) {
             const int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
@@ -2224,7 +2262,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     }
     // k3 / stride 1: Winograd F(4,3) along W when the rows allow 8-byte pair stores and 16-byte staging
     {
-        const int64_t wino = (d->ksize == 3 && d->stride == 1 && !d->transposed) ? wino_packed_count(*d) : 0;
+        const int64_t wino = (!planar && d->ksize == 3 && d->stride == 1 && !d->transposed) ? wino_packed_count(*d) : 0;
         const bool pair_ok = (d->Wout % 2 == 0) && a.y_bs % 2 == 0 && a.r_bs % 2 == 0 &&
                              ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res) |
                                reinterpret_cast<uintptr_t>(depth_planes)) & 7) == 0;
@@ -2278,6 +2316,14 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         case K5D2_M2: launch_conv<CfgK5D2M2>(a, grid, st); break;
         case K7_M1: launch_conv<CfgK7M1, true>(a, grid, st); break;
         case K7_M2: launch_conv<CfgK7M2>(a, grid, st); break;
+        case P1_M1: launch_conv<CfgP1M1>(a, grid, st); break;
+        case P1_M2: launch_conv<CfgP1M2>(a, grid, st); break;
+        case P1S2_M1: launch_conv<CfgP1S2M1>(a, grid, st); break;
+        case P1S2_M2: launch_conv<CfgP1S2M2>(a, grid, st); break;
+        case P3_M1: launch_conv<CfgP3M1, true>(a, grid, st); break;
+        case P3_M2: launch_conv<CfgP3M2, true>(a, grid, st); break;
+        case P3S2_M1: launch_conv<CfgP3S2M1, true>(a, grid, st); break;
+        case P3S2_M2: launch_conv<CfgP3S2M2, true>(a, grid, st); break;
         case DC_M1:
             if (!a.vec && vec8) { a.vec = 1; launch_deconv<CfgDCM1v8>(a, grid, st); }
             else launch_deconv<CfgDCM1>(a, grid, st);

@@ -322,10 +322,37 @@ inline unsigned stream_blocks(int64_t items, int64_t outer) {
     return (unsigned)b;
 }
 
+
+// ConvTranspose2d(k3, s2, p1, op1) = Conv2d(k3, s1, p1) with the flipped, channel-transposed kernel over the
+// zero-stuffed input u[2i, 2j] = x[i, j] (u is [2H, 2W]; every other element 0).  The 2D BEV neck's four
+// up-sampling layers (snvc/models/submodule.py:291-314) run that way on the depth-1 conv kernel; this is the
+// stuffing pass: planes [R][H][W] -> [R][2H][2W], fully written.
+__global__ void __launch_bounds__(256)
+zero_stuff2x_kernel(const float *__restrict__ x, float *__restrict__ y, int H, int W, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ow = (int)(i % (2 * W));
+    const int oh = (int)((i / (2 * W)) % (2 * H));
+    const int64_t r = i / ((int64_t)4 * H * W);
+    y[i] = ((ow | oh) & 1) ? 0.0f : x[(r * H + (oh >> 1)) * W + (ow >> 1)];
+}
+
 }  // namespace
 }  // namespace snvc
 
 extern "C" {
+
+int snvc_zero_stuff2x(const float *x, float *y, int64_t R, int64_t H, int64_t W, void *stream) {
+    using namespace snvc;
+    if (R < 0 || H < 0 || W < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_zero_stuff2x: negative size");
+    const int64_t total = R * 4 * H * W;
+    if (total == 0) return SNVC_OK;
+    if (!x || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_zero_stuff2x: null pointer");
+    if (ceil_div<int64_t>(total, 256) >= ((int64_t)1 << 31) || 2 * W >= ((int64_t)1 << 30) || 2 * H >= ((int64_t)1 << 30))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_zero_stuff2x: tensor too large");
+    zero_stuff2x_kernel<<<(unsigned)ceil_div<int64_t>(total, 256), 256, 0, as_stream(stream)>>>(x, y, (int)H, (int)W, total);
+    return check_launch("snvc_zero_stuff2x");
+}
 
 int snvc_mul_broadcast(const float *feat, const float *occ, float *out, int64_t N, int64_t C,
                        int64_t S, int64_t out_batch_stride, void *stream) {

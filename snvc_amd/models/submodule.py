@@ -18,9 +18,9 @@ The nn.Conv3d / nn.BatchNorm3d / nn.GroupNorm children only HOLD parameters; the
 ``forward`` is never called.  GroupNorm and train-mode BatchNorm need statistics of the conv
 output, so they take three launches (conv, statistics, normalise+activation).
 
-The 2D helpers at the bottom (convbn, hourglass2d, ...) are stock torch.nn compositions: the
-BEV neck that follows the path is out of scope for hand-written kernels (SURVEY.md section 8f,
-row N1) and runs on PyTorch-ROCm's own kernels.
+The 2D helpers at the bottom (convbn, hourglass2d, ...) keep torch.nn's
+module tree; their inference forward runs on the depth-1 form of the same HIP conv kernels
+(``fused_conv2d`` / ``fused_deconv2d``), training and GroupNorm on the modules' own torch forward.
 """
 from typing import Optional
 
@@ -62,6 +62,7 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
     for m in module.modules():
         m.__dict__.pop("_snvc_plans", None)
         m.__dict__.pop("_snvc_plans_f16", None)
+        m.__dict__.pop("_snvc_plans2d", None)
         m.__dict__.pop("_snvc_factored", None)
 
 
@@ -499,8 +500,100 @@ class hourglass_downsample_16(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------
-# 2D BEV neck: stock PyTorch-ROCm (out of scope for hand-written kernels)
+# 2D BEV neck: same module tree / state-dict keys as the reference; inference with eval-mode
+# BatchNorm2d runs on the depth-1 form of the HIP conv kernels (an NCHW tensor IS an [N,C,1,H,W] tensor), with the
+# folded norm, the conv bias, residual adds, ReLU and Sigmoid in the conv epilogue.  Training and GroupNorm take
+# the modules' own torch forward.
 # ------------------------------------------------------------------------------------------
+def _hip_2d_ok(x: torch.Tensor, *norms) -> bool:
+    """The HIP path of the 2D neck: a float32 GPU tensor, no autograd graph, every norm an eval-mode BatchNorm2d."""
+    if not (x.is_cuda and x.dtype == torch.float32) or (torch.is_grad_enabled() and x.requires_grad):
+        return False
+    return all(n is None or (isinstance(n, nn.BatchNorm2d) and not n.training and n.running_mean is not None) for n in norms)
+
+
+def _plan2d(conv: nn.Module, device) -> _Plan:
+    return conv.__dict__.setdefault("_snvc_plans2d", {}).setdefault(device, _Plan())
+
+
+def _affine2d(conv, norm, plan: _Plan):
+    """(scale, bias) of the epilogue: folded eval BatchNorm2d and / or the conv's own bias."""
+    scale = bias = None
+    if norm is not None:
+        scale, bias = _folded_bn(norm, plan)
+    if conv.bias is not None:
+        key = (conv.bias._version, conv.bias.data_ptr(), None if scale is None else scale.data_ptr(), _GENERATION[0])
+        if getattr(plan, "cb_key", None) != key:
+            b = conv.bias.detach().float()
+            plan.cb = ((b * scale + bias) if scale is not None else b).contiguous()
+            plan.cs = scale if scale is not None else torch.ones_like(b)
+            plan.cb_key = key
+        scale, bias = plan.cs, plan.cb
+    return scale, bias
+
+
+def fused_conv2d(conv: nn.Conv2d, norm, x: torch.Tensor, *, relu=False, sigmoid=False, residual=None,
+                 residual_after_act=False) -> torch.Tensor:
+    """act(norm(conv(x)) [+ residual]) [+ residual] for the 2D neck (reference submodule.py:11-29, hrnet.py:25-69)
+    on the depth-1 HIP kernels.  conv: Conv2d(k in {1,3}, stride in {1,2}, padding=(k-1)/2) -- or a Conv2d whose
+    kernel covers its whole input (the coordinate head's last layer, vernier.py:87), run as a 1x1 layer."""
+    plan = _plan2d(conv, x.device)
+    w = conv.weight
+    kh, kw = conv.kernel_size
+    whole = (kh, kw) == tuple(x.shape[2:]) and tuple(conv.padding) == (0, 0) and (kh, kw) != (1, 1)
+    key = (w.data_ptr(), w._version, w.device, whole, _GENERATION[0])
+    if plan.layer is None or plan.key != key:
+        if conv.groups != 1 or tuple(conv.dilation) != (1, 1):
+            raise NotImplementedError("grouped / dilated Conv2d is not in the 2D neck")
+        if whole:      # one output pixel: a 1x1 layer over the flattened (c, h, w) input
+            plan.layer = ops.Conv3dLayer(w.detach().reshape(w.size(0), -1, 1, 1, 1), 1, 1, 0, 1, False, planar=True)
+        else:
+            k, st = kh, conv.stride[0]
+            if kh != kw or conv.stride[0] != conv.stride[1] or tuple(conv.padding) != ((k - 1) // 2,) * 2 or k not in (1, 3) or st not in (1, 2):
+                raise NotImplementedError(f"Conv2d geometry {conv} is not in the 2D neck")
+            plan.layer = ops.Conv3dLayer(w.detach(), k, st, (k - 1) // 2, 1, False, planar=True)
+        plan.key = key
+    scale, bias = _affine2d(conv, norm, plan)
+    flags = (EPI_RELU if relu else 0) | (EPI_SIGMOID if sigmoid else 0)
+    if residual is not None:
+        flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
+    x5 = x.reshape(x.size(0), -1, 1, 1, 1) if whole else x.unsqueeze(2)
+    r5 = residual.unsqueeze(2) if residual is not None else None
+    return plan.layer(x5, scale, bias, r5, flags).squeeze(2)
+
+
+def fused_deconv2d(conv: nn.ConvTranspose2d, norm, x: torch.Tensor, *, relu=False, residual=None) -> torch.Tensor:
+    """ConvTranspose2d(k3,s2,p1,op1) (+norm) (+residual) (+ReLU) (reference submodule.py:291-314): zero-stuffed input,
+    then the depth-1 k3 convolution with the flipped, channel-transposed kernel."""
+    if (tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding), tuple(conv.output_padding)) != ((3, 3), (2, 2), (1, 1), (1, 1)) \
+            or conv.groups != 1 or conv.bias is not None:
+        raise NotImplementedError("the 2D neck's up-sampling layers are ConvTranspose2d(k3,s2,p1,op1,bias=False)")
+    plan = _plan2d(conv, x.device)
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
+    if plan.layer is None or plan.key != key:
+        plan.layer = ops.Conv3dLayer(w.detach().transpose(0, 1).flip(2, 3).contiguous(), 3, 1, 1, 1, False, planar=True)
+        plan.key = key
+    scale, bias = _affine2d(conv, norm, plan)
+    flags = (EPI_RELU if relu else 0) | (EPI_ADD_PRE if residual is not None else 0)
+    up = ops.zero_stuff2x(x)
+    return plan.layer(up.unsqueeze(2), scale, bias, residual.unsqueeze(2) if residual is not None else None, flags).squeeze(2)
+
+
+def _cbr2d(seq, x, **kw):
+    """Sequential(convbn(...), ReLU) or a bare convbn Sequential(conv, norm) on the HIP path."""
+    if isinstance(seq[0], nn.Sequential):          # Sequential(convbn, ReLU)
+        kw.setdefault("relu", True)
+        seq = seq[0]
+    if isinstance(seq[0], nn.ConvTranspose2d):
+        return fused_deconv2d(seq[0], seq[1], x, **kw)
+    return fused_conv2d(seq[0], seq[1], x, **kw)
+
+
+def _norms2d(module):
+    return [m for m in module.modules() if isinstance(m, (nn.BatchNorm2d, nn.GroupNorm))]
+
+
 def convbn(in_planes, out_planes, kernel_size, stride, pad, dilation, gn=False, groups=32):
     """reference submodule.py:11-29"""
     return nn.Sequential(nn.Conv2d(in_planes, out_planes, kernel_size=kernel_size, stride=stride,
@@ -536,6 +629,12 @@ class hourglass2d(nn.Module):
         self.conv6 = _deconvbn_2d(c * 2, c, gn)
 
     def forward(self, x, presqu, postsqu):
+        if _hip_2d_ok(x, *_norms2d(self)):
+            out = _cbr2d(self.conv1, x)
+            pre = _cbr2d(self.conv2, out, relu=True, residual=postsqu)              # relu(bn(conv) [+ postsqu])
+            out = _cbr2d(self.conv4, _cbr2d(self.conv3, pre))
+            post = _cbr2d(self.conv5, out, relu=True, residual=presqu if presqu is not None else pre)
+            return _cbr2d(self.conv6, post), pre, post
         out = self.conv1(x)
         pre = self.conv2(out)
         pre = F.relu(pre + postsqu, inplace=True) if postsqu is not None else F.relu(pre, inplace=True)
@@ -564,6 +663,15 @@ class hourglass2d_downsample_16(nn.Module):
         self.conv12 = get_hg_up_sample_2d(c * 2, c, gn)
 
     def forward(self, x):
+        if _hip_2d_ok(x, *_norms2d(self)):
+            o2 = _cbr2d(self.conv2, _cbr2d(self.conv1, x))
+            o4 = _cbr2d(self.conv4, _cbr2d(self.conv3, o2))
+            o6 = _cbr2d(self.conv6, _cbr2d(self.conv5, o4))
+            o8 = _cbr2d(self.conv8, _cbr2d(self.conv7, o6))
+            i10 = _cbr2d(self.conv9, o8, residual=o6)        # the skip adds live in the up-sampling layers' epilogues
+            i11 = _cbr2d(self.conv10, i10, residual=o4)
+            i12 = _cbr2d(self.conv11, i11, residual=o2)
+            return _cbr2d(self.conv12, i12)
         o2 = self.conv2(self.conv1(x))
         o4 = self.conv4(self.conv3(o2))
         o6 = self.conv6(self.conv5(o4))
@@ -588,6 +696,10 @@ class BasicBlock2d(nn.Module):
         self.stride = stride
 
     def forward(self, x):
+        if _hip_2d_ok(x, *_norms2d(self)):
+            residual = x if self.downsample is None else fused_conv2d(self.downsample[0], self.downsample[1], x)
+            out = fused_conv2d(self.conv1, self.bn1, x, relu=True)
+            return fused_conv2d(self.conv2, self.bn2, out, relu=True, residual=residual)     # relu(bn2(conv2) + residual)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         residual = x if self.downsample is None else self.downsample(x)

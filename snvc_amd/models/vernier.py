@@ -10,8 +10,8 @@ reference checkpoint loads with ``strict=True``.  What changes is how ``forward`
   predict_3d_heatmaps 3D part: ~45 cuDNN / elementwise 22 fused conv launches + 3 small kernels;
     kernels                              :414-438       residual adds, ReLU, Sigmoid and the
                                                         torch.cat of :433 live in conv epilogues
-  2D neck + heads (conv5, hm1, hm2, coord_head)        unchanged: stock PyTorch-ROCm
-                                         :440-450
+  2D neck + heads (conv5, hm1, hm2, coord_head)        the same conv kernels in their depth-1 form
+                                         :440-450       (SURVEY 8f N1), fused norm/bias/res/act
 
 The HRNet backbone is outside the path.  ``get_feat_extraction`` is the
 same hook the reference uses (vernier.py:837-839): assign a factory to it or
@@ -214,17 +214,32 @@ class VernierScale(nn.Module):
         return v.reshape(n, -1, v.size(3), v.size(4)), occ, None                # :437-438
 
     def heads_2d(self, voxel_BEV):
-        """reference vernier.py:440-450 (stock PyTorch-ROCm)"""
-        voxel_BEV = self.conv5(voxel_BEV)
+        """reference vernier.py:440-450.  Inference with eval-mode BatchNorm runs every convolution of the neck
+        (conv5, hm1, hm2, the coordinate head's blocks and its last full-extent layer) on the depth-1 HIP kernels
+        with fused norm / bias / residual / ReLU / Sigmoid epilogues; otherwise the modules' torch forward."""
+        from .submodule import _hip_2d_ok, _norms2d, _cbr2d, fused_conv2d
+        hip = _hip_2d_ok(voxel_BEV, *_norms2d(self.conv5), *_norms2d(self.hm1), *_norms2d(self.coord_head))
+        voxel_BEV = _cbr2d(self.conv5, voxel_BEV) if hip else self.conv5(voxel_BEV)
         if self.small:
             heatmap_feats = self.hm1(voxel_BEV, None, None)[0].permute(0, 1, 3, 2)
         else:
             heatmap_feats = self.hm1(voxel_BEV).permute(0, 1, 3, 2)
-        heatmaps = self.hm2(heatmap_feats)
+        heatmaps = fused_conv2d(self.hm2, None, heatmap_feats.contiguous()) if hip else self.hm2(heatmap_feats)
         num_sample = len(heatmaps)
         coor_maps = self.coor_maps.repeat(num_sample, 1, 1, 1).to(heatmaps.device)
         augmented_maps = torch.cat([heatmaps, coor_maps], dim=1)
-        coordinates = self.coord_head(augmented_maps).view(num_sample, -1, 2)
+        last = self.coord_head[-2]
+        if hip and tuple(last.kernel_size) != (1, 1):
+            t = augmented_maps
+            for blk in self.coord_head[:-2]:
+                t = blk(t)                                                          # BasicBlock2d: HIP forward
+            if tuple(t.shape[2:]) == tuple(last.kernel_size):
+                coordinates = fused_conv2d(last, None, t.contiguous(), sigmoid=True)   # Conv2d((6,4)) + Sigmoid  :87-88
+            else:
+                coordinates = self.coord_head[-1](last(t))
+            coordinates = coordinates.reshape(num_sample, -1, 2)
+        else:
+            coordinates = self.coord_head(augmented_maps).view(num_sample, -1, 2)
         return heatmaps, coordinates
 
     def predict_3d_heatmaps(self, voxel, depth=None):

@@ -22,7 +22,7 @@ from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, C
 __all__ = [
     "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
     "Conv3dLayer", "conv_variant", "conv3d_wgrad", "Conv3dLayerF16", "to_c8", "from_c8", "voxel_gather_forward_f16",
-    "mul_broadcast_c8", "avgpool_depth4_c8", "volume_resample", "rect_to_psv_grid", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4",
+    "mul_broadcast_c8", "avgpool_depth4_c8", "volume_resample", "rect_to_psv_grid", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4", "zero_stuff2x",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
     "points_in_boxes_gpu", "points_in_boxes_cpu",
     "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID",
@@ -207,20 +207,26 @@ class Conv3dLayer:
     output_padding=1, stride=2, bias=False) (submodule.py:127-134,198-205).
     """
 
-    def __init__(self, weight: torch.Tensor, ksize: int, stride: int, pad: int, dilation: int, transposed: bool):
+    def __init__(self, weight: torch.Tensor, ksize: int, stride: int, pad: int, dilation: int, transposed: bool,
+                 planar: bool = False):
+        """planar=True: a depth-1 layer (desc.ksize_d = 1) -- an nn.Conv2d(k, stride, padding=(k-1)/2) of the 2D BEV
+        neck run on [N,C,1,H,W] views; ``weight`` is then [Cout,Cin,1,k,k] (or the Conv2d's own [Cout,Cin,k,k])."""
         _gpu(weight, "weight")
         if weight.dtype != torch.float32:
             raise RuntimeError("conv3d weights must be float32")
         self.transposed = bool(transposed)
+        self.planar = bool(planar)
+        if planar and weight.dim() == 4:
+            weight = weight.unsqueeze(2)
         if transposed:
             self.cin, self.cout = weight.shape[0], weight.shape[1]
         else:
             self.cout, self.cin = weight.shape[0], weight.shape[1]
-        if tuple(weight.shape[2:]) != (ksize,) * 3:
-            raise RuntimeError("only cubic kernels are on the path")
+        if tuple(weight.shape[2:]) != ((1, ksize, ksize) if planar else (ksize,) * 3):
+            raise RuntimeError("only cubic kernels (or depth-1 k x k ones with planar=True) are on the path")
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
         self.device = weight.device
-        probe = self._desc(1, (16, 16, 32), 0)
+        probe = self._desc(1, (1, 16, 32) if planar else (16, 16, 32), 0)
         count = _lib.lib().snvc_conv3d_packed_weight_count(ctypes.byref(probe))
         if count < 0:
             check(1, "snvc_conv3d_packed_weight_count")
@@ -233,6 +239,8 @@ class Conv3dLayer:
         if self.transposed:
             return tuple(2 * s for s in in_spatial)
         eff = self.dilation * (self.ksize - 1) + 1
+        if getattr(self, "planar", False):      # the stride and the padding apply to H and W only
+            return (in_spatial[0],) + tuple((s + 2 * self.pad - eff) // self.stride + 1 for s in in_spatial[1:])
         return tuple((s + 2 * self.pad - eff) // self.stride + 1 for s in in_spatial)
 
     def _desc(self, n, in_spatial, flags, x_bs=0, y_bs=0, r_bs=0) -> Conv3dDesc:
@@ -244,6 +252,7 @@ class Conv3dLayer:
         d.ksize, d.stride, d.dilation, d.pad = self.ksize, self.stride, self.dilation, self.pad
         d.transposed = 1 if self.transposed else 0
         d.flags = flags
+        d.ksize_d = 1 if getattr(self, "planar", False) else 0
         d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = x_bs, y_bs, r_bs
         return d
 
@@ -444,6 +453,18 @@ def avgpool_depth4(x):
         return y
     with torch.cuda.device(x.device):
         check(_lib.lib().snvc_avgpool_depth4(_ptr(x), _ptr(y), n, c, d, h * w, _stream(x)), "snvc_avgpool_depth4")
+    return y
+
+
+def zero_stuff2x(x):
+    """[N,C,H,W] -> [N,C,2H,2W] with y[..., 2i, 2j] = x[..., i, j] and zeros elsewhere (see snvc_zero_stuff2x)."""
+    _gpu(x, "x")
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    if y.numel():
+        with torch.cuda.device(x.device):
+            check(_lib.lib().snvc_zero_stuff2x(_ptr(x), _ptr(y), n * c, h, w, _stream(x)), "snvc_zero_stuff2x")
     return y
 
 

@@ -27,18 +27,18 @@ def test_every_declared_symbol_is_exported(L):
     from snvc_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "snvc_hip.h")).read()
     declared = set(re.findall(r"SNVC_API\s+[\w\s\*]+?\b(snvc_\w+)\s*\(", hdr))
-    assert len(declared) == 41, sorted(declared)
+    assert len(declared) == 42, sorted(declared)
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert L.snvc_abi_version() == 1
+    assert L.snvc_abi_version() == 2
 
 
 def test_struct_layout_matches_header():
     from snvc_amd._lib import Conv3dDesc
-    assert ctypes.sizeof(Conv3dDesc) == 16 * 4 + 3 * 8
-    assert Conv3dDesc.x_batch_stride.offset == 64
+    assert ctypes.sizeof(Conv3dDesc) == 18 * 4 + 3 * 8
+    assert Conv3dDesc.x_batch_stride.offset == 72
 
 
 def test_argument_validation_needs_no_gpu(L):
