@@ -275,6 +275,14 @@ class VernierScale(nn.Module):
         return idx.view(n, p), val.view(n, p)
 
 
+    # ------------------------------------------------------------------ N4: decode
+    def ncf_to_update_2d(self, ncf, samples, grid, filter_3d, arg_max="hard", coordinates=None):
+        """reference vernier.py:665-738 (see snvc_amd.decode.ncf_to_update_2d: max / argmax / range test on the device,
+        the 9-point pose fit on the host in float64 like the reference)."""
+        from .. import decode
+        return decode.ncf_to_update_2d(self.cfg, ncf, samples, grid, filter_3d, arg_max=arg_max, coordinates=coordinates)
+
+
 def get_model(cfgs, is_train=False):
     """reference vernier.py:841-842"""
     return VernierScale(cfgs, is_train)
