@@ -296,6 +296,27 @@ inline int64_t gather_run_length(int64_t V, int64_t slices, int64_t N) {
     return run < 4096 ? 4096 : run;
 }
 
+// aggregate="concat-atten" (snvc/models/vernier.py:341-344): the concatenated voxel features are multiplied by
+// clamp(cosine_similarity(left half, right half, dim=channels), 0).  One thread per voxel: pass 1 accumulates the two
+// squared norms, pass 2 the dot product of the normalised halves (torch >= 2.0: x / max(||x||, eps) . y / max(||y||, eps),
+// eps = 1e-8), pass 3 scales the 2F channels in place.  Rows of one channel are coalesced across the wave.
+__global__ void __launch_bounds__(256)
+voxel_atten_scale_kernel(float *__restrict__ vox, int F, int64_t V) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float *p = vox + (int64_t)blockIdx.y * 2 * F * V + v;
+    float nl = 0.0f, nr = 0.0f;
+    for (int c = 0; c < F; ++c) {
+        const float a = p[(int64_t)c * V], b = p[(int64_t)(F + c) * V];
+        nl += a * a; nr += b * b;
+    }
+    const float dl = fmaxf(sqrtf(nl), 1e-8f), dr = fmaxf(sqrtf(nr), 1e-8f);
+    float dot = 0.0f;
+    for (int c = 0; c < F; ++c) dot += (p[(int64_t)c * V] / dl) * (p[(int64_t)(F + c) * V] / dr);
+    const float w = dot > 0.0f ? dot : 0.0f;
+    for (int c = 0; c < 2 * F; ++c) p[(int64_t)c * V] *= w;
+}
+
 // fp16-storage output (conv3d_f16.hip's C8 layout [N][2F/8][V][8]; BASELINE.json configs[4]): same taps, same
 // separately rounded fp32 a*nw + b*ne + c*sw + d*se per channel as the kernels above, rounded to half once on
 // the way out.  One voxel per thread: a wave stores 1 KB contiguous per channel group (64 voxels x 16 bytes), and
@@ -503,6 +524,16 @@ int snvc_voxel_gather_forward_f16(const float *left, const float *right, const f
                                                                     (int)F, (int)Hf, (int)Wf, V, res_x, res_y);
     }
     return check_launch("snvc_voxel_gather_forward_f16");
+}
+
+int snvc_voxel_atten_scale(float *vox, int64_t N, int64_t F, int64_t V, void *stream) {
+    using namespace snvc;
+    if (N < 0 || F < 0 || V < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_atten_scale: negative size");
+    if (N == 0 || F == 0 || V == 0) return SNVC_OK;
+    if (!vox) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_atten_scale: null pointer");
+    if (N > 65535 || ceil_div<int64_t>(V, 256) >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_voxel_atten_scale: too large");
+    voxel_atten_scale_kernel<<<dim3((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N), 256, 0, as_stream(stream)>>>(vox, (int)F, V);
+    return check_launch("snvc_voxel_atten_scale");
 }
 
 int snvc_voxel_gather_backward(const float *grad_out, const float *l_pts, const float *r_pts,

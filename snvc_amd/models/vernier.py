@@ -131,8 +131,10 @@ class VernierScale(nn.Module):
     def _sample_2d_feat(self, left, right, l_pts, r_pts, aggregate="concat"):
         """reference vernier.py:323-349.  The reference normalises ``l_pts`` / ``r_pts`` IN PLACE
         through a view (:335-338); this implementation leaves the caller's tensors untouched."""
-        if aggregate != "concat":
-            raise NotImplementedError('only aggregate="concat" is used by construct_voxel (vernier.py:351-360)')
+        if aggregate not in ("concat", "concat-atten"):
+            raise NotImplementedError
+        if aggregate == "concat-atten" and torch.is_grad_enabled() and (left.requires_grad or right.requires_grad):
+            raise NotImplementedError('aggregate="concat-atten" is built for inference (construct_voxel uses "concat")')
         nh, nw, nl = self.cfg.n_sample_h, self.cfg.n_sample_w, self.cfg.n_sample_l
         if l_pts.size(2) != nh * nw * nl:
             raise RuntimeError("grid projection does not have nh*nw*nl points")
@@ -140,6 +142,8 @@ class VernierScale(nn.Module):
             vox = _VoxelGatherFn.apply(left, right, l_pts, r_pts, tuple(self.cfg.resolution))
         else:
             vox = ops.voxel_gather_forward(left, right, l_pts, r_pts, self.cfg.resolution)
+        if aggregate == "concat-atten":                       # :341-344
+            ops.voxel_atten_scale_(vox)
         return vox.view(left.size(0), 2 * left.size(1), nh, nw, nl)
 
     def construct_voxel(self, left, right, grid_proj_left, grid_proj_right):

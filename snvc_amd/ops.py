@@ -169,6 +169,18 @@ def voxel_gather_forward(left, right, l_pts, r_pts, resolution) -> torch.Tensor:
     return out
 
 
+def voxel_atten_scale_(vox):
+    """In place: vox [N,2F,V] *= clamp(cosine_similarity(left half, right half, dim=1), 0) (vernier.py:341-344)."""
+    _gpu(vox, "vox")
+    if vox.dtype != torch.float32 or vox.dim() != 3 or vox.size(1) % 2 or not vox.is_contiguous():
+        raise RuntimeError("voxel_atten_scale_ needs a contiguous float32 [N,2F,V] tensor")
+    n, c2, v = vox.shape
+    if vox.numel():
+        with torch.cuda.device(vox.device):
+            check(_lib.lib().snvc_voxel_atten_scale(_ptr(vox), n, c2 // 2, v, _stream(vox)), "snvc_voxel_atten_scale")
+    return vox
+
+
 def voxel_gather_backward(grad_out, l_pts, r_pts, feat_shape, resolution):
     n, f, hf, wf = feat_shape
     _gpu(grad_out, "grad_out")

@@ -961,3 +961,17 @@ def test_psv_to_grid_chain_vs_torch():
     prob = torch.softmax(cost[:, 0], dim=1)
     dm = ops.disparity_regression(prob.to(dev()), depth.to(dev())).cpu()
     check(dm.numpy(), (prob * depth.view(1, -1, 1, 1)).sum(1).numpy(), 1e-6, "disparityregression")
+
+
+def test_sample_2d_feat_concat_atten_vs_torch():
+    """aggregate="concat-atten" (vernier.py:341-344): concat * clamp(cosine_similarity(left, right, dim=1), 0)."""
+    import torch.nn.functional as F
+    from snvc_amd.models.vernier import VernierScale
+    grid, gn, n, fh, fw, seed = GC.TRUNK_CASES["G1"]
+    m = VernierScale(_cfg(grid, gn)).to(dev())
+    lf, rf, gpl, gpr = GC.trunk_inputs(n, 32, fh, fw, grid, seed + 1)
+    with torch.no_grad():
+        plain = m._sample_2d_feat(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev())).cpu()
+        got = m._sample_2d_feat(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()), aggregate="concat-atten").cpu()
+    att = F.cosine_similarity(plain[:, :32], plain[:, 32:], dim=1).unsqueeze(1)
+    check(got.numpy(), (plain * torch.clamp(att, 0.0)).numpy(), 2e-6, "concat-atten")
