@@ -822,6 +822,7 @@ struct WinoKCfg {
     static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int KP = KC / 2;
     static constexpr int WF = KS * NPOS * KP * 64;            // packed floats per (chunk, kd): [kh][pos][kp][lane]
+    static constexpr int WPH = 1;                              // kernel depth slices of weights resident at a time
     static constexpr int LDS_BYTES = (TILE + 2 * WF) * 4;
     static_assert(DIL == 2 || (XOFF + 4 * (QUADS - 1) + NPOS <= IN_WV && XOFF + NPOS <= 12),
                   "three 16-byte reads cover a quad's inputs");
@@ -849,7 +850,9 @@ struct WinoS2Cfg {
     static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int KP = KC / 2;
     static constexpr int WF = KS * NA * KP * 64;              // packed floats per (chunk, kd): [kh][frag][kp][lane]
-    static constexpr int LDS_BYTES = (TILE + 2 * WF) * 4;
+    // the weights of a WHOLE chunk (3 depth slices) are resident: one barrier per 81 MFMAs instead of one per 27
+    static constexpr int WPH = KS;
+    static constexpr int LDS_BYTES = (TILE + 2 * WPH * WF) * 4;
     static_assert(8 * (QUADS - 1) + 12 <= IN_WV, "three 16-byte reads cover a quad's inputs");
 };
 
@@ -1230,20 +1233,21 @@ conv3d_winok_kernel(const ConvArgs a) {
     const int bbase = (lane >> 5) * CH +
                       Cfg::STRIDE * (wave * Cfg::IN_H + ((lane & 31) >> 3)) * Cfg::IN_WV +
                       (Cfg::DIL == 2 ? 8 * ((lane & 7) >> 1) : 4 * Cfg::STRIDE * (lane & 7));
+    constexpr int WPH = Cfg::WPH, WBLK = WPH * WF;             // weights resident per phase: WPH kernel depth slices
     float *const wlds = lds + TILE;
-    float *const aff = wlds + 2 * WF;
-    const int nchunks = a.nchunks_wino, nphase = nchunks * KS;
-    const float *wg = a.wp_wino + (int64_t)job.cg * nphase * WF;
+    float *const aff = wlds + 2 * WBLK;
+    const int nchunks = a.nchunks_wino, nphase = nchunks * (KS / WPH);
+    const float *wg = a.wp_wino + (int64_t)job.cg * nphase * WBLK;
     constexpr int SLICE = Cfg::DIL * Cfg::IN_H * Cfg::IN_WV;     // image floats per kernel depth step
 
     St st;
     st.init(tid, job.od0 * Cfg::STRIDE - Cfg::PAD, job.oh0 * Cfg::STRIDE - Cfg::PAD, job.ow0 * Cfg::STRIDE - Cfg::LPAD,
             a.Din, a.Hin, a.Win, in_hw, in_dhw);
-    constexpr int WITEMS = WF / 4, WNIT = (WITEMS + 255) / 256;
+    constexpr int WITEMS = WBLK / 4, WNIT = (WITEMS + 255) / 256;
     const int wbase = tid & ~63;
     auto issue_w = [&](int ph, int b) {
-        const float *wc = wg + (int64_t)ph * WF;
-        float *const wbuf = wlds + b * WF;
+        const float *wc = wg + (int64_t)ph * WBLK;
+        float *const wbuf = wlds + b * WBLK;
 #pragma unroll
         for (int it = 0; it < WNIT; ++it) {
             const int i = it * 256 + tid;
@@ -1272,10 +1276,14 @@ conv3d_winok_kernel(const ConvArgs a) {
     __syncthreads();
     int ph = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        for (int kd = 0; kd < KS; ++kd, ++ph) {
+        for (int kd0 = 0; kd0 < KS; kd0 += WPH, ++ph) {
             if (ph + 1 < nphase) issue_w(ph + 1, (ph + 1) & 1);
-            if constexpr (Cfg::STRIDE == 2) winos2_compute_phase<Cfg>(lds + kd * SLICE, wlds + (ph & 1) * WF + lane, bbase, acc);
-            else winok_compute_phase<Cfg>(lds + kd * SLICE, wlds + (ph & 1) * WF + lane, bbase, lane, acc);
+#pragma unroll
+            for (int k = 0; k < WPH; ++k) {
+                const float *wl = wlds + (ph & 1) * WBLK + k * WF + lane;
+                if constexpr (Cfg::STRIDE == 2) winos2_compute_phase<Cfg>(lds + (kd0 + k) * SLICE, wl, bbase, acc);
+                else winok_compute_phase<Cfg>(lds + (kd0 + k) * SLICE, wl, bbase, lane, acc);
+            }
             __syncthreads();
         }
         if (chunk + 1 < nchunks) {
