@@ -75,7 +75,7 @@ struct WgradCfg {
     static_assert(PAD <= LPAD, "left halo fits the aligned margin");
 };
 
-template <class Cfg, bool VEC>
+template <class Cfg, int VEC>   // 0: scalar staging; 4 / 2: float4 X pieces and 16- / 8-byte G pieces (rows with Wo % 4 == 2)
 __global__ void __launch_bounds__(256, 2)
 conv3d_wgrad_kernel(const WgradArgs a) {
     constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, PAD = Cfg::PAD, NT = Cfg::NT;
@@ -106,7 +106,7 @@ conv3d_wgrad_kernel(const WgradArgs a) {
         const int lt = Cfg::KSPLIT ? t : wave + 4 * t;
         const int kw = lt % KS, kh = (lt / KS) % khn, kd = lt / (KS * khn);
         const bool ok = lt < chunk_taps;
-        tap_off[t] = ok ? (kd * DIL * IN_H + kh * DIL) * (VEC ? Cfg::IN_WV : IN_W) + kw * DIL : 0;
+        tap_off[t] = ok ? (kd * DIL * IN_H + kh * DIL) * (VEC != 0 ? Cfg::IN_WV : IN_W) + kw * DIL : 0;
         tap_glob[t] = ok ? ((kd0 + kd) * KS + kh0 + kh) * KS + kw : -1;
     }
 
@@ -115,11 +115,13 @@ conv3d_wgrad_kernel(const WgradArgs a) {
     const int ch = lane & 31, half = lane >> 5;
     const float *xrow = xl + ch * XS, *grow = gl + ch * GS;
 
-    if constexpr (VEC) {
+    if constexpr (VEC != 0) {
         // ---- float4 staging with register prefetch: the element -> (channel, row, piece) decomposition of a
         // staging item does not depend on the tile, so it is done once; per tile only the three range tests
         // remain.  Tile t+1 is in registers while tile t is multiplied; LDS is single-buffered (70 KB).
-        constexpr int IN_WV = Cfg::IN_WV, XSV = Cfg::XSV, RQ = Cfg::RQ, XNIT = Cfg::XNIT, GNIT = Cfg::GNIT;
+        constexpr int IN_WV = Cfg::IN_WV, XSV = Cfg::XSV, RQ = Cfg::RQ, XNIT = Cfg::XNIT;
+        constexpr int GP = VEC, GQ = 32 / GP, GITEMS = 32 * Cfg::TH * GQ, GNIT = (GITEMS + 255) / 256;   // G pieces of GP floats
+        typedef float GVec __attribute__((ext_vector_type(GP)));
         constexpr int ROWS = Cfg::IN_D * IN_H;
         float *glv = lds + 32 * XSV;
         const float *xrow_v = xl + ch * XSV, *grow_v = glv + ch * GS;
@@ -136,12 +138,13 @@ conv3d_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int it = 0; it < GNIT; ++it) {
             const int i = it * 256 + tid;
-            const int c = i / (Cfg::TH * 8), r = i - c * (Cfg::TH * 8);
-            const int hh = r / 8, q = r - hh * 8;
-            gcode[it] = (i < Cfg::GITEMS && cg0 + c < a.Cg) ? (hh | (q << 8) | (c << 16)) : -1;
+            const int c = i / (Cfg::TH * GQ), r = i - c * (Cfg::TH * GQ);
+            const int hh = r / GQ, q = r - hh * GQ;
+            gcode[it] = (i < GITEMS && cg0 + c < a.Cg) ? (hh | (q << 8) | (c << 16)) : -1;
         }
         static_assert(Cfg::IN_D <= 16 && IN_H <= 16 && RQ <= 256, "packed staging code");
-        f32x4 xv[XNIT], gv[GNIT];
+        f32x4 xv[XNIT];
+        GVec gv[GNIT];
         unsigned xok = 0, gok = 0;
         auto load_tile = [&](int64_t tile) {
             const int tw = (int)(tile % a.tiles_w);
@@ -167,8 +170,8 @@ conv3d_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int it = 0; it < GNIT; ++it) {
                 const int hh = gcode[it] & 255, q = (gcode[it] >> 8) & 255, c = gcode[it] >> 16;
-                const bool ok = gcode[it] >= 0 && oh0 + hh < a.Ho && ow0 + 4 * q < a.Wo;
-                gv[it] = *reinterpret_cast<const f32x4 *>(ok ? gn + gorg + c * out_dhw + (int64_t)hh * a.Wo + 4 * q : a.g);
+                const bool ok = gcode[it] >= 0 && oh0 + hh < a.Ho && ow0 + GP * q < a.Wo;
+                gv[it] = *reinterpret_cast<const GVec *>(ok ? gn + gorg + c * out_dhw + (int64_t)hh * a.Wo + GP * q : a.g);
                 gok |= (ok ? 1u : 0u) << it;
             }
         };
@@ -184,12 +187,12 @@ conv3d_wgrad_kernel(const WgradArgs a) {
             }
 #pragma unroll
             for (int it = 0; it < GNIT; ++it) {
-                if (Cfg::GITEMS % 256 != 0 && it * 256 + tid >= Cfg::GITEMS) continue;
+                if (GITEMS % 256 != 0 && it * 256 + tid >= GITEMS) continue;
                 const bool ok = (gok >> it) & 1u;
                 const int hh = gcode[it] & 255, q = (gcode[it] >> 8) & 255, c = (gcode[it] >> 16) & 31;
-                const int dst = c * GS + hh * 32 + 4 * q;
+                const int dst = c * GS + hh * 32 + GP * q;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) glv[dst + j] = ok ? gv[it][j] : 0.0f;
+                for (int j = 0; j < GP; ++j) glv[dst + j] = ok ? gv[it][j] : 0.0f;
             }
         };
         int64_t tile = blockIdx.x;
@@ -316,24 +319,34 @@ conv3d_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// dw[cg][cx][tap] = sum_p partial[p][pair][tap][cg%32][cx%32], p ascending
+// dw[cg][cx][tap] = sum_p partial[p][pair][tap][cg%32][cx%32].  One thread per element of a slab, in the slab's own
+// order (consecutive lanes read consecutive floats of every partition: the first version walked dw's order and
+// touched one cache line per lane and partition, 0.25 ms per layer); four running sums over p mod 4, combined in a
+// fixed order: deterministic.
 __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, int Cg, int Cx,
                                     int taps, int taps_pad, int cx_blocks, int pairs, int P) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t total = (int64_t)Cg * Cx * taps;
-    if (i >= total) return;
-    const int tap = (int)(i % taps);
-    const int cx = (int)((i / taps) % Cx);
-    const int cg = (int)(i / ((int64_t)taps * Cx));
-    const int pair = (cg >> 5) * cx_blocks + (cx >> 5);
-    const float *src = partial + ((int64_t)pair * taps_pad + tap) * 1024 + (cg & 31) * 32 + (cx & 31);
     const int64_t pstride = (int64_t)pairs * taps_pad * 1024;
-    float s = 0.0f;
-    for (int p = 0; p < P; ++p) s += src[p * pstride];
-    dw[i] = s;
+    if (i >= pstride) return;
+    const int cxl = (int)(i & 31), cgl = (int)((i >> 5) & 31);
+    const int tap = (int)((i >> 10) % taps_pad);
+    const int pair = (int)(i / ((int64_t)taps_pad * 1024));
+    const int cg = (pair / cx_blocks) * 32 + cgl, cx = (pair % cx_blocks) * 32 + cxl;
+    if (tap >= taps || cg >= Cg || cx >= Cx) return;
+    const float *src = partial + i;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int p = 0;
+    for (; p + 4 <= P; p += 4) {
+        s0 += src[(int64_t)p * pstride];
+        s1 += src[(int64_t)(p + 1) * pstride];
+        s2 += src[(int64_t)(p + 2) * pstride];
+        s3 += src[(int64_t)(p + 3) * pstride];
+    }
+    for (; p < P; ++p) s0 += src[(int64_t)p * pstride];
+    dw[((int64_t)cg * Cx + cx) * taps + tap] = (s0 + s1) + (s2 + s3);
 }
 
-template <class Cfg, bool VEC>
+template <class Cfg, int VEC>
 void launch_wgrad_variant(const WgradArgs &a, dim3 grid, hipStream_t st) {
     constexpr int bytes = Cfg::LDS_FLOATS * 4;
     static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
@@ -345,8 +358,12 @@ template <class Cfg>
 void launch_wgrad(const WgradArgs &a, dim3 grid, hipStream_t st) {
     // the prefetching float4 path is built for the K-split configurations only (the tap-split ones have no
     // registers left for the prefetch: 112 accumulator registers + 60 of staging spill)
-    if constexpr (Cfg::KSPLIT) launch_wgrad_variant<Cfg, true>(a, grid, st);
-    else launch_wgrad_variant<Cfg, false>(a, grid, st);
+    if constexpr (Cfg::KSPLIT) {
+        if (a.vec == 2) launch_wgrad_variant<Cfg, 2>(a, grid, st);
+        else launch_wgrad_variant<Cfg, 4>(a, grid, st);
+    } else {
+        launch_wgrad_variant<Cfg, 0>(a, grid, st);
+    }
 }
 
 constexpr int kWgradPartitions = 512;   // 2 workgroups per CU
@@ -397,8 +414,13 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
     a.cx_blocks = ceil_div(d->Cin, 32);
     a.x_bs = d->x_batch_stride ? d->x_batch_stride : in_sz;
     a.g_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
-    a.vec = d->Win % 4 == 0 && d->Wout % 4 == 0 && a.x_bs % 4 == 0 && a.g_bs % 4 == 0 &&
-            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0 && !(d->algo & SNVC_ALGO_SCALAR_STAGING);
+    // float4 staging of X needs 16-byte rows on the big grid; G rows may be 16- or 8-byte ones (the W = 78 level of the
+    // cfg2 hourglass: its two layers took the scalar path at 1.0 ms each)
+    const bool xv = d->Win % 4 == 0 && a.x_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    !(d->algo & SNVC_ALGO_SCALAR_STAGING);
+    const bool g4 = d->Wout % 4 == 0 && a.g_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0;
+    const bool g2 = d->Wout % 2 == 0 && a.g_bs % 2 == 0 && (reinterpret_cast<uintptr_t>(g) & 7) == 0;
+    a.vec = xv ? (g4 ? 4 : (g2 ? 2 : 0)) : 0;
     const int pairs = ceil_div(d->Cout, 32) * a.cx_blocks;
     if (pairs > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: too many channel pairs");
     hipStream_t st = as_stream(stream);
@@ -432,7 +454,7 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
     int rc = check_launch("snvc_conv3d_wgrad");
     if (rc) return rc;
     const int taps = d->ksize * d->ksize * d->ksize;
-    const int64_t total = (int64_t)d->Cout * d->Cin * taps;
+    const int64_t total = (int64_t)pairs * taps * 1024;
     wgrad_reduce_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>(
         (const float *)workspace, dw, d->Cout, d->Cin, taps, taps, a.cx_blocks, pairs, kWgradPartitions);
     return check_launch("snvc_conv3d_wgrad(reduce)");
