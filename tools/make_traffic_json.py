@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 --pmc CSVs of tools/pmc_r2.sh (gpurun_out/pmc_r2/<layer>_<tag>/.../p_counter_collection.csv)
+into profiles/r2/traffic.json and copies the per-layer CSV rows of the profiled kernel into profiles/r2/pmc/.
+HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE (KiB counters; the factor 2 is the gfx950 FETCH_SIZE correction of
+MI355X_MICROARCH.md's HBM section for 16-byte-per-lane streaming reads)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "pmc_r2")
+DST = os.path.join(ROOT, "profiles", "r2")
+KERNEL = {  # layer -> substring of the kernel whose LAST dispatch is reported
+    "conv1_factored": "conv3d_wino_dma_kernel", "cost_volume": "cost_volume_fwd_rows", "cost_volume_right": "cost_volume_fwd_rows",
+    "cost_volume_bwd": "cost_volume_bwd_rows_f32", "gather_proj": "voxel_gather_fwd_lds", "gather_uniform": "voxel_gather_fwd_lds",
+    "gather_f16": "voxel_gather_fwd_lds", "f16_k7": "conv3d_f16_kernel", "f16_k5": "conv3d_f16_kernel",
+}
+ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
+    "conv1_factored": 1472200704, "cost_volume": 1479869184, "cost_volume_right": 739934976, "cost_volume_bwd": 1479869184 + 2 * 3833856,
+    "gather_proj": 2 * (786432 * 272 + 2 * 32 * 4096 * 4), "gather_uniform": 2 * (786432 * 272 + 2 * 32 * 4096 * 4),
+    "gather_f16": 2048000 * (16 + 4 * 64) + 2 * 64 * 4096 * 4,
+    "f16_k7": 2 * 2048000 * (128 + 64), "f16_k5": 2 * 2048000 * (64 + 64),
+}
+
+
+def last_dispatch(path, needle):
+    rows = [r for r in csv.DictReader(open(path)) if needle in r.get("Kernel_Name", "")]
+    if not rows:
+        return {}, []
+    last = max(int(r["Dispatch_Id"]) for r in rows)
+    sel = [r for r in rows if int(r["Dispatch_Id"]) == last]
+    return {r["Counter_Name"]: float(r["Counter_Value"]) for r in sel}, sel
+
+
+out = {"note": __doc__.strip().split("\n")[-3:], "layers": {}}
+os.makedirs(os.path.join(DST, "pmc"), exist_ok=True)
+for layer, needle in KERNEL.items():
+    entry = {"kernel": needle}
+    for tag in ("fetch", "write", "sq", "sq2"):
+        files = glob.glob(os.path.join(SRC, f"{layer}_{tag}", "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        vals, sel = last_dispatch(files[0], needle)
+        entry.update(vals)
+        if sel:
+            with open(os.path.join(DST, "pmc", f"{layer}_{tag}.csv"), "w", newline="") as fh:
+                w = csv.DictWriter(fh, fieldnames=list(sel[0].keys()))
+                w.writeheader()
+                w.writerows(sel)
+    if "FETCH_SIZE" in entry and "WRITE_SIZE" in entry:
+        entry["hbm_bytes_corrected"] = 2 * entry["FETCH_SIZE"] * 1024 + entry["WRITE_SIZE"] * 1024
+        entry["algorithmic_bytes"] = ALGORITHMIC[layer]
+        entry["traffic_over_algorithmic"] = entry["hbm_bytes_corrected"] / ALGORITHMIC[layer]
+    if "SQ_INSTS_MFMA" in entry and "GRBM_GUI_ACTIVE" in entry:
+        cyc = 64 if layer == "conv1_factored" else 32          # v_mfma_f32_32x32x2_f32: 64 cycles/SIMD; 32x32x16_f16: 32
+        entry["mfma_pipe_frac"] = entry["SQ_INSTS_MFMA"] * cyc / (1024 * entry["GRBM_GUI_ACTIVE"] / 8)
+    if len(entry) > 1:
+        out["layers"][layer] = entry
+if "conv1_factored" in out["layers"]:
+    out["conv1_right_wino43_dma_k3_32to32_cfg2"] = out["layers"]["conv1_factored"]   # the key bench.py reads
+json.dump(out, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])

@@ -2,7 +2,9 @@
 """Runs ONE layer of the cfg2 step a few times so that a rocprofv3 pass stays small.
 
     rocprofv3 --pmc ... -- python tools/prof_layers.py conv1 --reps 3
-Layers: cost_volume, conv1 (k3 64->32), conv2 (k3 32->32), hg (hourglass), classifier, gather, trunk.
+Layers: cost_volume, cost_volume_right, cost_volume_bwd, conv1 (k3 64->32), conv1_factored, conv2 (k3 32->32), hg
+(hourglass), classifier, gather (degenerate line, r1), gather_proj / gather_uniform (GridProjector / uniform coordinates,
+2 crops of the released shape), gather_f16 (cfg5, C8 half), f16_k7 / f16_k5 (cfg5's dominant fp16 layers), trunk.
 """
 import argparse
 import os
@@ -53,6 +55,34 @@ with torch.no_grad():
         else:
             vox = vs.construct_voxel(lf, rf, gl, gr)
             fn = lambda: vs.trunk_3d(vox)  # noqa: E731
+    elif args.layer in ("gather_proj", "gather_uniform", "gather_f16"):
+        import types
+        from snvc_amd import ops
+        f16 = args.layer == "gather_f16"
+        grid, n, F = ((80, 160, 160), 1, 64) if f16 else ((32, 128, 192), 2, 32)
+        r = np.random.default_rng(5)
+        v = grid[0] * grid[1] * grid[2]
+        lf = torch.from_numpy(r.standard_normal((n, F, 64, 64)).astype(np.float32)).to(dev)
+        rf = torch.from_numpy(r.standard_normal((n, F, 64, 64)).astype(np.float32)).to(dev)
+        if args.layer == "gather_uniform":
+            gl = torch.from_numpy(r.uniform(-8, 264, (n, 2, v)).astype(np.float32)).to(dev)
+            gr = torch.from_numpy(r.uniform(-8, 264, (n, 2, v)).astype(np.float32)).to(dev)
+        else:
+            gl, gr = bench.projected_coordinates(n, grid, dev)
+        fn = (lambda: ops.voxel_gather_forward_f16(lf, rf, gl, gr, (256, 256))) if f16 else (lambda: ops.voxel_gather_forward(lf, rf, gl, gr, (256, 256)))  # noqa: E731
+    elif args.layer in ("f16_k7", "f16_k5"):
+        from snvc_amd.models import submodule as S
+        k, cin = (7, 128) if args.layer == "f16_k7" else (5, 64)
+        m = S.convbn_3d(cin, 64, k, 1, (k - 1) // 2).to(dev).eval()
+        xh = torch.randn((1, cin // 8, 80, 160, 160, 8), device=dev).half()
+        fn = lambda: m.fused_f16(xh, relu=True)  # noqa: E731
+    elif args.layer == "cost_volume_right":
+        from snvc_amd import ops
+        fn = lambda: ops.cost_volume_forward_right(right, shift)  # noqa: E731
+    elif args.layer == "cost_volume_bwd":
+        from snvc_amd import ops
+        g = torch.randn(1, 2 * bench.C, bench.D, bench.H, bench.W, device=dev)
+        fn = lambda: ops.cost_volume_backward(g, shift, 1)  # noqa: E731
     elif args.layer == "pair":
         fn = lambda: model.forward_pair(left, right, shift, 1)  # noqa: E731
     elif args.layer == "conv1_factored":
