@@ -92,6 +92,14 @@ SNVC_API int snvc_voxel_gather_forward_ws(const float *left, const float *right,
                                           const float *r_pts, float *out, float *workspace, int64_t N,
                                           int64_t F, int64_t Hf, int64_t Wf, int64_t V, float res_x,
                                           float res_y, void *stream);
+/* Deterministic form of the adjoint (training; VERDICT r1: the atomics above are order-dependent and collapse when many
+ * voxels project onto one pixel): voxels are grouped by their base pixel with a stable radix sort, every sum has one
+ * fixed order, no atomics -> bit-reproducible run to run.  workspace: snvc_voxel_gather_backward_workspace_bytes()
+ * bytes, 256-byte aligned.  Same result as snvc_voxel_gather_backward up to summation order. */
+SNVC_API int64_t snvc_voxel_gather_backward_workspace_bytes(int64_t N, int64_t F, int64_t Hf, int64_t Wf, int64_t V);
+SNVC_API int snvc_voxel_gather_backward_det(const float *grad_out, const float *l_pts, const float *r_pts,
+                                            float *grad_left, float *grad_right, void *workspace, int64_t N, int64_t F,
+                                            int64_t Hf, int64_t Wf, int64_t V, float res_x, float res_y, void *stream);
 /* replaces: the aggregate="concat-atten" branch of _sample_2d_feat (vernier.py:341-344), applied in place to the gather's
  * result vox [N,2F,V]: every channel of voxel v is multiplied by max(cosine_similarity(vox[:, :F, v], vox[:, F:, v]), 0). */
 SNVC_API int snvc_voxel_atten_scale(float *vox, int64_t N, int64_t F, int64_t V, void *stream);

@@ -42,6 +42,8 @@ SIGNATURES = {
     "snvc_voxel_gather_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
     "snvc_voxel_gather_workspace_floats": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "snvc_voxel_gather_forward_ws": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
+    "snvc_voxel_gather_backward_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64, c_i64]),
+    "snvc_voxel_gather_backward_det": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
     "snvc_voxel_atten_scale": (c_int, [c_p, c_i64, c_i64, c_i64, c_p]),
     "snvc_voxel_gather_backward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
     "snvc_grid_projection": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_int, c_int, c_int, c_p, c_p, c_p, c_int, c_p]),

@@ -181,7 +181,9 @@ def voxel_atten_scale_(vox):
     return vox
 
 
-def voxel_gather_backward(grad_out, l_pts, r_pts, feat_shape, resolution):
+def voxel_gather_backward(grad_out, l_pts, r_pts, feat_shape, resolution, deterministic: bool = True):
+    """Adjoint of voxel_gather_forward w.r.t. the two feature maps.  deterministic=True (default): the sorted,
+    atomics-free form (snvc_voxel_gather_backward_det, bit-reproducible); False: the float-atomics form."""
     n, f, hf, wf = feat_shape
     _gpu(grad_out, "grad_out")
     v = l_pts.size(2)
@@ -189,9 +191,18 @@ def voxel_gather_backward(grad_out, l_pts, r_pts, feat_shape, resolution):
     gr = torch.empty_like(gl)
     grad_out, l_pts, r_pts = grad_out.contiguous(), l_pts.contiguous(), r_pts.contiguous()
     with torch.cuda.device(grad_out.device):
-        check(_lib.lib().snvc_voxel_gather_backward(_ptr(grad_out), _ptr(l_pts), _ptr(r_pts), _ptr(gl), _ptr(gr), n, f,
-                                                    hf, wf, v, float(resolution[1]), float(resolution[0]),
-                                                    _stream(grad_out)), "voxel_gather_backward")
+        if deterministic:
+            nbytes = _lib.lib().snvc_voxel_gather_backward_workspace_bytes(n, f, hf, wf, v)
+            if nbytes < 0:
+                check(1, "snvc_voxel_gather_backward_workspace_bytes")
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=grad_out.device)
+            check(_lib.lib().snvc_voxel_gather_backward_det(_ptr(grad_out), _ptr(l_pts), _ptr(r_pts), _ptr(gl), _ptr(gr), _ptr(ws),
+                                                            n, f, hf, wf, v, float(resolution[1]), float(resolution[0]),
+                                                            _stream(grad_out)), "voxel_gather_backward_det")
+        else:
+            check(_lib.lib().snvc_voxel_gather_backward(_ptr(grad_out), _ptr(l_pts), _ptr(r_pts), _ptr(gl), _ptr(gr), n, f,
+                                                        hf, wf, v, float(resolution[1]), float(resolution[0]),
+                                                        _stream(grad_out)), "voxel_gather_backward")
     return gl, gr
 
 

@@ -241,6 +241,49 @@ def test_voxel_gather_backward_adjoint():
     assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
 
 
+@pytest.mark.parametrize("case", ["uniform", "coherent", "edges"])
+def test_voxel_gather_backward_deterministic(case):
+    """The sorted, atomics-free adjoint: equals torch autograd through F.grid_sample, equals the atomics form up to
+    summation order, and is BIT-IDENTICAL run to run -- also when every voxel lands on a handful of pixels (the
+    case that took the atomics form 77 ms) and with out-of-range / NaN coordinates."""
+    import torch.nn.functional as F
+    from snvc_amd import ops
+    r = np.random.default_rng({"uniform": 1, "coherent": 2, "edges": 3}[case])
+    n, f, hf, wf, v, res = 2, 32, 16, 16, 6000, (64, 64)
+    if case == "edges":
+        n, f, hf, wf, v, res = 1, 5, 7, 9, 333, (28, 36)
+    lf = torch.from_numpy(r.standard_normal((n, f, hf, wf)).astype(np.float32))
+    rf = torch.from_numpy(r.standard_normal((n, f, hf, wf)).astype(np.float32))
+    if case == "coherent":      # a short line: thousands of voxels per pixel
+        t = np.linspace(0, 1, v, dtype=np.float32)
+        pts = np.stack([np.stack([20 + 6 * t, 30 + 2 * t])] * n)
+    else:
+        pts = r.uniform(-0.1 * res[1], 1.1 * res[1], (n, 2, v)).astype(np.float32)
+    if case == "edges":
+        pts[0, 0, :5] = [0.0, res[1], -3.0, 1e9, np.nan]
+        pts[0, 1, :5] = [0.0, res[0], 14.0, 3.0, 5.0]
+    gl = torch.from_numpy(pts.astype(np.float32))
+    gr = torch.from_numpy(pts[:, :, ::-1].copy().astype(np.float32))
+    g = torch.from_numpy(r.standard_normal((n, 2 * f, v)).astype(np.float32))
+    dgl, dgr, dg = gl.to(dev()), gr.to(dev()), g.to(dev())
+    a = ops.voxel_gather_backward(dg, dgl, dgr, (n, f, hf, wf), res)
+    b = ops.voxel_gather_backward(dg, dgl, dgr, (n, f, hf, wf), res)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])                       # run-to-run bit identity
+    c = ops.voxel_gather_backward(dg, dgl, dgr, (n, f, hf, wf), res, deterministic=False)
+    # torch autograd (NaN coordinates give no gradient in both: weights are dropped with their voxel)
+    finite = torch.isfinite(gl).all(dim=1) & torch.isfinite(gr).all(dim=1)           # [n, v]
+    for side, (feat, p) in enumerate(((lf, gl), (rf, gr))):
+        x = feat.clone().requires_grad_()
+        pn = torch.nan_to_num(p, nan=-1e6)
+        grid = torch.stack([pn[:, 0] / res[1] * 2 - 1, pn[:, 1] / res[0] * 2 - 1], dim=-1).view(n, 1, v, 2)
+        out = F.grid_sample(x, grid, mode="bilinear", padding_mode="zeros", align_corners=False)[:, :, 0]   # [n, f, v]
+        (out * g[:, side * f:(side + 1) * f]).sum().backward()
+        ref = x.grad
+        scale = max(ref.abs().max().item(), 1.0)
+        assert (a[side].cpu() - ref).abs().max().item() <= 2e-5 * scale, (case, side)
+        assert (c[side].cpu() - ref).abs().max().item() <= 2e-4 * scale, (case, side)
+
+
 def test_grid_projection_vs_oracle_and_golden(G):
     """a11: grid points -> camera frame -> P2/P3 -> crop affine, on the device, against the numpy
     restatement (itself bit-equal to the reference's methods, make_golden.py) and the golden samples."""
