@@ -5,10 +5,11 @@
 //   1. every voxel gets the key of its BASE pixel (x0, y0) = floor of its sample position (all four bilinear taps
 //      hang off it), per (sample, camera) group;
 //   2. a stable radix sort (hipCUB) of (key, voxel) pairs groups the voxels by base pixel, voxel index ascending;
-//   3. one workgroup per base pixel walks its segment in that order, 64 voxels at a time: the gradient tile
-//      [64 voxels][F channels] goes through LDS, thread (channel, tap) adds its 64 products in voxel order ->
-//      A[group][base][tap][channel];
-//   4. grad[c, pixel] = A[base(pixel, nw)][nw] + A[..ne][ne] + A[..sw][sw] + A[..se][se], fixed order.
+//   3. every segment is cut into pieces of <= 1024 voxels (an exclusive scan of the piece counts gives each piece its
+//      slot, so one pixel that collects a million voxels becomes a thousand workgroups, not one); a workgroup walks its
+//      piece in sorted order, 64 voxels at a time: the gradient tile [64 voxels][F channels] goes through LDS, thread
+//      (channel, tap) adds its 64 products in voxel order -> P[slot][tap][channel];
+//   4. grad[c, pixel] = sum over the four taps (nw, ne, sw, se) of the slots of that tap's base pixel, slots ascending.
 // Every sum has one fixed order -> the result is bit-reproducible run to run, and the gradient volume is read once.
 // Weights are the forward kernel's own (same make_taps arithmetic, fp contract off).
 #include <hipcub/hipcub.hpp>
@@ -68,25 +69,52 @@ segment_starts_kernel(const unsigned *__restrict__ skeys, unsigned *__restrict__
     for (int64_t k = prev + 1; k <= cur; ++k) start[k] = (unsigned)i;
 }
 
-// One workgroup per base-pixel key.  tile[j][c]: gradient of channel c at the j-th voxel of the batch; thread
+constexpr int kPiece = 1024;     // voxels per workgroup of the segment pass
+
+// npieces[k] = ceil(len_k / kPiece) for base-pixel keys, 0 for a group's "no tap inside" bucket
+__global__ void __launch_bounds__(256)
+piece_counts_kernel(const unsigned *__restrict__ start, unsigned *__restrict__ npieces, unsigned nkeys, unsigned K) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > nkeys) return;
+    unsigned c = 0;
+    if (k < nkeys && k % (K + 1) != K) c = (start[k + 1] - start[k] + kPiece - 1) / kPiece;
+    npieces[k] = c;
+}
+
+// One workgroup per piece.  tile[j][c]: gradient of channel c at the j-th voxel of the batch; thread
 // (c, t) = (tid % FP, tid / FP) sums wt[j][t] * tile[j][c] over j ascending.
 template <int FP>   // channels handled per pass: 64 (256 threads = 64 channels x 4 taps)
 __global__ void __launch_bounds__(256)
-gather_bwd_segments_kernel(const float *__restrict__ grad_out, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
-                           const unsigned *__restrict__ start, const unsigned *__restrict__ svals, float *__restrict__ A,
-                           int N, int F, int Hf, int Wf, int64_t V, float res_x, float res_y) {
+gather_bwd_pieces_kernel(const float *__restrict__ grad_out, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
+                         const unsigned *__restrict__ start, const unsigned *__restrict__ slot0, const unsigned *__restrict__ svals,
+                         float *__restrict__ P, unsigned nkeys, int N, int F, int Hf, int Wf, int64_t V, float res_x, float res_y) {
     __shared__ float tile[64][FP + 1];
     __shared__ float wts[64][4];
     __shared__ unsigned vox[64];
+    __shared__ unsigned key_s;
+    const unsigned slot = blockIdx.x;
+    if (slot >= slot0[nkeys]) return;                      // the grid is an upper bound of the piece count (block-uniform exit)
+    const int tid = threadIdx.x;
+    if (tid == 0) {                                        // the key whose slot range [slot0[k], slot0[k+1]) holds this slot
+        unsigned lo = 0, hi = nkeys;                       // invariant: slot0[lo] <= slot < slot0[hi]
+        while (hi - lo > 1) {
+            const unsigned mid = (lo + hi) >> 1;
+            if (slot0[mid] <= slot) lo = mid; else hi = mid;
+        }
+        key_s = lo;
+    }
+    __syncthreads();
+    const unsigned gkey = key_s;
     const unsigned K = (unsigned)(Hf + 1) * (Wf + 1);
-    const int g = blockIdx.y, side = g / N, n = g - side * N;
-    const unsigned local = blockIdx.x;                    // base-pixel key inside the group, < K
-    const unsigned gkey = (unsigned)g * (K + 1) + local;
-    const unsigned s0 = start[gkey], s1 = start[gkey + 1];
-    const int tid = threadIdx.x, c_of = tid % FP, t_of = tid / FP;
+    const int g = (int)(gkey / (K + 1)), side = g / N, n = g - side * N;
+    const unsigned piece = slot - slot0[gkey];
+    const unsigned s0 = start[gkey] + piece * kPiece;
+    const unsigned send = start[gkey + 1];
+    const unsigned s1 = s0 + kPiece < send ? s0 + kPiece : send;
+    const int c_of = tid % FP, t_of = tid / FP;
     const float *pts = (side == 0 ? l_pts : r_pts) + (int64_t)n * 2 * V;
     const float *gbase = grad_out + ((int64_t)n * 2 * F + (int64_t)side * F) * V;
-    float *Ag = A + ((int64_t)g * K + local) * 4 * F;
+    float *Ps = P + (int64_t)slot * 4 * F;
     for (int c0 = 0; c0 < F; c0 += FP) {
         float acc = 0.0f;
         for (unsigned b = s0; b < s1; b += 64) {
@@ -109,14 +137,15 @@ gather_bwd_segments_kernel(const float *__restrict__ grad_out, const float *__re
             if (t_of < 4 && c0 + c_of < F)
                 for (int j = 0; j < cnt; ++j) acc += wts[j][t_of] * tile[j][c_of];
         }
-        if (t_of < 4 && c0 + c_of < F) Ag[t_of * F + c0 + c_of] = acc;
+        if (t_of < 4 && c0 + c_of < F) Ps[t_of * F + c0 + c_of] = acc;
     }
 }
 
-// grad[n, c, py, px] = sum over the four taps that can land on (py, px), in the order nw, ne, sw, se
+// grad[n, c, py, px] = sum over the four taps that can land on (py, px), in the order nw, ne, sw, se; per tap the
+// pieces of its base pixel in slot order
 __global__ void __launch_bounds__(256)
-gather_bwd_combine_kernel(const float *__restrict__ A, float *__restrict__ grad_left, float *__restrict__ grad_right, int N,
-                          int F, int Hf, int Wf) {
+gather_bwd_combine_kernel(const float *__restrict__ P, const unsigned *__restrict__ slot0, float *__restrict__ grad_left,
+                          float *__restrict__ grad_right, int N, int F, int Hf, int Wf) {
     const int plane = Hf * Wf;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (c, pixel) of one group
     if (i >= (int64_t)F * plane) return;
@@ -124,19 +153,19 @@ gather_bwd_combine_kernel(const float *__restrict__ A, float *__restrict__ grad_
     const int p = (int)(i % plane), c = (int)(i / plane);
     const int py = p / Wf, px = p - py * Wf;
     const unsigned K = (unsigned)(Hf + 1) * (Wf + 1);
-    const float *Ag = A + (int64_t)g * K * 4 * F;
     float s = 0.0f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int dy = t >> 1, dx = t & 1;                  // tap t of base (py - dy, px - dx) is this pixel
-        const unsigned local = (unsigned)(py - dy + 1) * (Wf + 1) + (unsigned)(px - dx + 1);
-        s += Ag[((int64_t)local * 4 + t) * F + c];
+        const unsigned gkey = (unsigned)g * (K + 1) + (unsigned)(py - dy + 1) * (Wf + 1) + (unsigned)(px - dx + 1);
+        for (unsigned j = slot0[gkey]; j < slot0[gkey + 1]; ++j) s += P[((int64_t)j * 4 + t) * F + c];
     }
     (side == 0 ? grad_left : grad_right)[((int64_t)n * F + c) * plane + p] = s;
 }
 
 struct BwdLayout {
-    int64_t M, nkeys, off_keys_in, off_keys_out, off_vals_in, off_vals_out, off_start, off_A, off_tmp, tmp_bytes, total;
+    int64_t M, nkeys, max_pieces, off_keys_in, off_keys_out, off_vals_in, off_vals_out, off_start, off_np, off_slot0, off_P, off_tmp,
+        tmp_bytes, total;
 };
 
 inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
@@ -145,20 +174,26 @@ int bwd_layout(int64_t N, int64_t F, int64_t Hf, int64_t Wf, int64_t V, BwdLayou
     L.M = 2 * N * V;
     const int64_t K = (Hf + 1) * (Wf + 1);
     L.nkeys = 2 * N * (K + 1);
-    if (L.nkeys >= ((int64_t)1 << 32) || V >= ((int64_t)1 << 32) || L.M >= ((int64_t)1 << 31))
+    if (L.nkeys >= ((int64_t)1 << 31) || V >= ((int64_t)1 << 32) || L.M >= ((int64_t)1 << 31))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_voxel_gather_backward_det: too many voxels or pixels for 32-bit keys");
     size_t tmp = 0;
     if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned *)nullptr, (unsigned *)nullptr, (const unsigned *)nullptr,
                                            (unsigned *)nullptr, (int)L.M, 0, 32) != hipSuccess)
         return fail(SNVC_ERR_HIP, "snvc_voxel_gather_backward_det: hipcub temp-storage query failed");
-    L.tmp_bytes = (int64_t)tmp;
+    size_t tmp2 = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, (const unsigned *)nullptr, (unsigned *)nullptr, (int)(L.nkeys + 1)) != hipSuccess)
+        return fail(SNVC_ERR_HIP, "snvc_voxel_gather_backward_det: hipcub temp-storage query failed");
+    L.tmp_bytes = (int64_t)(tmp > tmp2 ? tmp : tmp2);
+    L.max_pieces = L.M / kPiece + L.nkeys;          // sum of ceil(len / kPiece) <= M / kPiece + (number of keys)
     int64_t o = 0;
     L.off_keys_in = o; o += align256(L.M * 4);
     L.off_keys_out = o; o += align256(L.M * 4);
     L.off_vals_in = o; o += align256(L.M * 4);
     L.off_vals_out = o; o += align256(L.M * 4);
     L.off_start = o; o += align256((L.nkeys + 1) * 4);
-    L.off_A = o; o += align256(2 * N * K * 4 * F * 4);
+    L.off_np = o; o += align256((L.nkeys + 1) * 4);
+    L.off_slot0 = o; o += align256((L.nkeys + 1) * 4);
+    L.off_P = o; o += align256(L.max_pieces * 4 * F * 4);
     L.off_tmp = o; o += align256(L.tmp_bytes);
     L.total = o;
     return SNVC_OK;
@@ -203,8 +238,9 @@ int snvc_voxel_gather_backward_det(const float *grad_out, const float *l_pts, co
     char *ws = reinterpret_cast<char *>(workspace);
     unsigned *keys_in = reinterpret_cast<unsigned *>(ws + L.off_keys_in), *keys_out = reinterpret_cast<unsigned *>(ws + L.off_keys_out);
     unsigned *vals_in = reinterpret_cast<unsigned *>(ws + L.off_vals_in), *vals_out = reinterpret_cast<unsigned *>(ws + L.off_vals_out);
-    unsigned *start = reinterpret_cast<unsigned *>(ws + L.off_start);
-    float *A = reinterpret_cast<float *>(ws + L.off_A);
+    unsigned *start = reinterpret_cast<unsigned *>(ws + L.off_start), *npieces = reinterpret_cast<unsigned *>(ws + L.off_np);
+    unsigned *slot0 = reinterpret_cast<unsigned *>(ws + L.off_slot0);
+    float *P = reinterpret_cast<float *>(ws + L.off_P);
     const int G = (int)(2 * N);
     gather_bwd_keys_kernel<<<dim3((unsigned)ceil_div<int64_t>(V, 256), (unsigned)G), 256, 0, st>>>(l_pts, r_pts, keys_in, vals_in, (int)N,
                                                                                                  (int)Hf, (int)Wf, V, res_x, res_y);
@@ -217,9 +253,14 @@ int snvc_voxel_gather_backward_det(const float *grad_out, const float *l_pts, co
         return fail(SNVC_ERR_HIP, "snvc_voxel_gather_backward_det: radix sort failed");
     segment_starts_kernel<<<(unsigned)ceil_div<int64_t>(L.M + 1, 256), 256, 0, st>>>(keys_out, start, L.M, (unsigned)L.nkeys);
     const unsigned K = (unsigned)((Hf + 1) * (Wf + 1));
-    gather_bwd_segments_kernel<64><<<dim3(K, (unsigned)G), 256, 0, st>>>(grad_out, l_pts, r_pts, start, vals_out, A, (int)N, (int)F,
-                                                                        (int)Hf, (int)Wf, V, res_x, res_y);
-    gather_bwd_combine_kernel<<<dim3((unsigned)ceil_div<int64_t>(F * plane, 256), (unsigned)G), 256, 0, st>>>(A, grad_left, grad_right,
+    piece_counts_kernel<<<(unsigned)ceil_div<int64_t>(L.nkeys + 1, 256), 256, 0, st>>>(start, npieces, (unsigned)L.nkeys, K);
+    tmp = (size_t)L.tmp_bytes;
+    if (hipcub::DeviceScan::ExclusiveSum(ws + L.off_tmp, tmp, npieces, slot0, (int)(L.nkeys + 1), st) != hipSuccess)
+        return fail(SNVC_ERR_HIP, "snvc_voxel_gather_backward_det: scan failed");
+    gather_bwd_pieces_kernel<64><<<dim3((unsigned)L.max_pieces), 256, 0, st>>>(grad_out, l_pts, r_pts, start, slot0, vals_out, P,
+                                                                               (unsigned)L.nkeys, (int)N, (int)F, (int)Hf, (int)Wf, V, res_x,
+                                                                               res_y);
+    gather_bwd_combine_kernel<<<dim3((unsigned)ceil_div<int64_t>(F * plane, 256), (unsigned)G), 256, 0, st>>>(P, slot0, grad_left, grad_right,
                                                                                                               (int)N, (int)F, (int)Hf, (int)Wf);
     return check_launch("snvc_voxel_gather_backward_det");
 }
