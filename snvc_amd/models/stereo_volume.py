@@ -35,6 +35,20 @@ class GlobalStack(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    def _buffer(self, name, shape, device):
+        """Inference workspace: the three full-resolution intermediates (warped half-volume, conv1 / conv2 outputs,
+        0.74 GB each at cfg2) are kept across calls instead of going through the caching allocator every step -- with
+        GB-sized blocks that are split and re-merged, a steady-state step can land on a fresh hipMalloc (tens of ms).
+        They never escape ``forward`` / ``forward_pair`` (the result is the head's own small tensor)."""
+        ws = self.__dict__.setdefault("_snvc_ws", {})
+        key = (name, tuple(shape), device)
+        buf = ws.get(key)
+        if buf is None:
+            for k in [k for k in ws if k[0] == name]:
+                del ws[k]
+            buf = ws[key] = torch.empty(shape, dtype=torch.float32, device=device)
+        return buf
+
     def _tail(self, v):
         """v + hourglass(v)[0] -> classifier.  The residual add and (inference) the 1x1x1 classifier are folded
         into the hourglass's last transposed convolution: the full-resolution C-channel tensor is never written."""
@@ -42,7 +56,12 @@ class GlobalStack(nn.Module):
         return cost
 
     def forward(self, volume):
-        return self._tail(self.conv2(self.conv1(volume)))
+        if torch.is_grad_enabled() or not volume.is_cuda:
+            return self._tail(self.conv2(self.conv1(volume)))
+        n, c2 = volume.size(0), volume.size(1)
+        shape = (n, c2 // 2) + tuple(volume.shape[2:])
+        v = self.conv1.fused(volume, out=self._buffer("v1", shape, volume.device))
+        return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, volume.device)))
 
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
@@ -74,10 +93,16 @@ class GlobalStack(nn.Module):
             vol = ops.cost_volume_forward(left, right, shift, downsample)
             mark("volume", 1)
             mark("conv1", 0)
-            v = self.conv1(vol)
+            if torch.is_grad_enabled():
+                v = self.conv1(vol)
+                mark("conv1", 1)
+                del vol
+                return self._tail(self.conv2(v))
+            shape = (vol.size(0), vol.size(1) // 2) + tuple(vol.shape[2:])
+            v = self.conv1.fused(vol, out=self._buffer("v1", shape, vol.device))
             mark("conv1", 1)
             del vol
-            return self._tail(self.conv2(v))
+            return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, vol.device)))
         assert torch.all(shift >= 0.)            # same contract as build_cost_volume (reference __init__.py:12)
         c = left.size(1)
         w = conv.weight
@@ -91,10 +116,10 @@ class GlobalStack(nn.Module):
         left3 = left.unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()       # [N,C,3,H,W]
         planes = plans["left"](left3)                                           # depth classes: first / interior / last
         mark("volume", 0)
-        vol_r = ops.cost_volume_forward_right(right, shift)                     # [N,C,D,H,W]
+        shape = (left.size(0), c, shift.size(1)) + tuple(left.shape[2:])
+        vol_r = ops.cost_volume_forward_right(right, shift, out=self._buffer("vol_r", shape, left.device))   # [N,C,D,H,W]
         mark("volume", 1)
         mark("conv1", 0)
-        v = plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, None, depth_planes=planes)
+        v = plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, self._buffer("v1", shape, left.device), depth_planes=planes)
         mark("conv1", 1)
-        del vol_r
-        return self._tail(self.conv2(v))
+        return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, left.device)))

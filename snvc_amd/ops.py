@@ -99,14 +99,17 @@ def cost_volume_forward(left, right, shift, downsample: int):
     return out
 
 
-def cost_volume_forward_right(right, shift):
+def cost_volume_forward_right(right, shift, out=None):
     """Right (warped) half of build_cost_volume at downsample 1: [N,C,D,H,W] == full[:, C:]."""
     _gpu(right, "right"); _gpu(shift, "shift")
     if right.dtype != torch.float32 or shift.dtype != torch.float32:
         raise RuntimeError("cost_volume_forward_right is fp32 only")
     n, c, h, w = right.shape
     d = shift.size(1)
-    out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=right.device)
+    if out is None:
+        out = torch.empty((n, c, d, h, w), dtype=torch.float32, device=right.device)
+    elif tuple(out.shape) != (n, c, d, h, w) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("cost_volume_forward_right `out` must be a contiguous float32 [N,C,D,H,W] tensor")
     if out.numel() == 0:
         return out
     right, shift = right.contiguous(), shift.contiguous()
