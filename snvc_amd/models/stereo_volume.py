@@ -98,11 +98,11 @@ class GlobalStack(nn.Module):
                 mark("conv1", 1)
                 del vol
                 return self._tail(self.conv2(v))
-            shape = (vol.size(0), vol.size(1) // 2) + tuple(vol.shape[2:])
-            v = self.conv1.fused(vol, out=self._buffer("v1", shape, vol.device))
+            shape, device = (vol.size(0), vol.size(1) // 2) + tuple(vol.shape[2:]), vol.device
+            v = self.conv1.fused(vol, out=self._buffer("v1", shape, device))
             mark("conv1", 1)
             del vol
-            return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, vol.device)))
+            return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, device)))
         assert torch.all(shift >= 0.)            # same contract as build_cost_volume (reference __init__.py:12)
         c = left.size(1)
         w = conv.weight
