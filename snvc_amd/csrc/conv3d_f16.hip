@@ -59,7 +59,9 @@ struct F16Args {
     int64_t x_bs, y_bs, r_bs, yf_bs;   // batch strides in elements
 };
 
-constexpr int F16_PF = 4;   // A-fragment register ring depth (k-steps ahead)
+// A-fragment register ring depth (k-steps ahead).  Measured on cfg5 (k7 / k5 / k3 ms): 2: 9.70 / 1.92 / 0.91;
+// 4: 9.38 / 2.00 / 0.91; 6: 8.99 / 1.82 / 0.85 (242-246 VGPRs, no spills); 8: 8.89 / 1.83 / 0.86 with spills.
+constexpr int F16_PF = 6;
 
 template <int KD_, int KH_, int KW_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KCG_, int MODE_, bool DB_, int OCC_,
           int DILW_ = DIL_>
@@ -388,6 +390,7 @@ using F16K5   = F16Cfg<5, 5, 5, 1, 1, 2, 4, 4, 1, 1, true, 2>;
 // dilation 2 = four independent (depth, height)-parity sub-grids, each a convolution with dilation (1,1,2): the image
 // of a tile is 8x8x40 pieces (41 KB) instead of 12x12x40 (92 KB: one workgroup per CU with its staging exposed)
 using F16K5D2 = F16Cfg<5, 5, 5, 1, 1, 2, 4, 4, 1, 1, false, 2, 2>;
+// (a double-buffered image at one workgroup per CU: 14.3 ms against 9.0 on cfg5's conv1 -- two co-resident workgroups matter)
 using F16K7   = F16Cfg<7, 7, 7, 1, 1, 2, 4, 4, 1, 1, false, 2>;
 using F16DC   = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 0, true, 2>;      // one parity class of ConvTranspose3d(k3,s2,p1,op1)
 
