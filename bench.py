@@ -519,6 +519,18 @@ def main():
                 except Exception as e:  # an extra must never take the headline down with it
                     cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
             cfgs["cfg4_train_step"] = {k: tr[k] for k in ("ms_per_step", "fwd_ms", "bwd_ms", "step_tflops_algorithmic")}
+            try:        # its dominant kernel: the weight gradient of the first convolution (direct form: executed == algorithmic)
+                from snvc_amd import ops
+                xg = torch.randn(1, 2 * C, D, H, W, device=device)
+                gg = torch.randn(1, C, D, H, W, device=device)
+                ms_w, _ = timed_ms(lambda: ops.conv3d_wgrad(xg, gg, 3, 1, 1, 1), 3)
+                cfgs["cfg4_train_step"].update({
+                    "dominant_kernel": "conv3d_wgrad_kernel<k3,s1> 64->32 on 192x96x312 (deterministic MFMA weight gradient + partition reduce)",
+                    "dominant_ms": ms_w, "dominant_gflop_algorithmic": CONV1_FLOP / 1e9,
+                    "dominant_pipe_frac": CONV1_FLOP / (ms_w * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS})
+                del xg, gg
+            except Exception as e:
+                cfgs["cfg4_train_step"]["dominant_error"] = f"{type(e).__name__}: {e}"
             line["configs"] = cfgs
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
