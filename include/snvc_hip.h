@@ -67,6 +67,17 @@ SNVC_API int snvc_cost_volume_backward(const void *grad, const void *shift, void
                                        int64_t W, int64_t D, int64_t downsample, int dtype,
                                        void *stream);
 
+/* Training through the FACTORED first convolution (see snvc_conv3d_forward_ex): the two adjoints that have no
+ * counterpart in the materialised path.
+ *   snvc_cost_volume_backward_right : the warped half of snvc_cost_volume_backward alone -- grad_right_half [N,C,D,H,W]
+ *       (gradient of snvc_cost_volume_forward_right's output) -> grad_right [N,C,H,W]; fp32, downsample 1; same sum in the
+ *       same order as the full backward's right half (bit-identical).
+ *   snvc_depth_class_sums : adjoint of the depth-class planes: g [NC,D,HW] -> out [NC,3,HW] = (g[0], sum_{d=1..D-2} g[d],
+ *       g[D-1]), d ascending. */
+SNVC_API int snvc_cost_volume_backward_right(const float *grad_right_half, const float *shift, float *grad_right, int64_t N,
+                                             int64_t C, int64_t H, int64_t W, int64_t D, void *stream);
+SNVC_API int snvc_depth_class_sums(const float *g, float *out, int64_t NC, int64_t D, int64_t HW, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * a3  feature -> voxel resampling
  * replaces: VernierScale._sample_2d_feat(aggregate="concat")  (snvc/models/vernier.py:323-349):

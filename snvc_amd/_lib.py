@@ -39,6 +39,8 @@ SIGNATURES = {
     "snvc_cost_volume_forward": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
     "snvc_cost_volume_forward_right": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_cost_volume_backward": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    "snvc_cost_volume_backward_right": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_depth_class_sums": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p]),
     "snvc_voxel_gather_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
     "snvc_voxel_gather_workspace_floats": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "snvc_voxel_gather_forward_ws": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),

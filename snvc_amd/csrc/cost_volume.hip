@@ -254,6 +254,7 @@ cost_volume_bwd_gather(const T *__restrict__ grad, const T *__restrict__ shift,
 // above it and its predecessor below.
 struct __attribute__((packed, aligned(4))) Pair2 { float v[2]; };
 
+template <bool WITH_LEFT>   // false: `grad` is the right (warped) half only, [N,C,D,H,W]; grad_left is not written
 __global__ void __launch_bounds__(256)
 cost_volume_bwd_rows_f32(const float *__restrict__ grad, const float *__restrict__ shift, float *__restrict__ grad_left,
                          float *__restrict__ grad_right, int C, int D, int H, int W, int64_t total) {
@@ -267,12 +268,12 @@ cost_volume_bwd_rows_f32(const float *__restrict__ grad, const float *__restrict
     const int c = (int)(nc % C);
     const int64_t n = nc / C;
     const int64_t hw = (int64_t)H * W;
-    const float *gl = grad + ((n * 2 * C + c) * (int64_t)D) * hw + (int64_t)h * W;
-    const float *gr = gl + (int64_t)C * D * hw;
+    const float *gl = grad + ((n * (WITH_LEFT ? 2 : 1) * C + c) * (int64_t)D) * hw + (int64_t)h * W;
+    const float *gr = WITH_LEFT ? gl + (int64_t)C * D * hw : gl;
     const float *sh = shift + n * D;
     float acc_l = 0.0f, acc_r = 0.0f;
     auto one_plane = [&](float s, float glv, const Pair2 &q, int wq) {
-        acc_l = acc_l + glv;
+        if (WITH_LEFT) acc_l = acc_l + glv;
         const float neg_shift = -s;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -307,7 +308,7 @@ cost_volume_bwd_rows_f32(const float *__restrict__ grad, const float *__restrict
         for (int j = 0; j < PL; ++j) s[j] = sh[d + j];
 #pragma unroll
         for (int j = 0; j < PL; ++j) {
-            glv[j] = gl[(int64_t)(d + j) * hw + ix];
+            glv[j] = WITH_LEFT ? gl[(int64_t)(d + j) * hw + ix] : 0.0f;
             load_pair(d + j, s[j], q[j], wq[j]);
         }
 #pragma unroll
@@ -317,12 +318,30 @@ cost_volume_bwd_rows_f32(const float *__restrict__ grad, const float *__restrict
         Pair2 q;
         int wq;
         const float s = sh[d];
-        const float glv = gl[(int64_t)d * hw + ix];
+        const float glv = WITH_LEFT ? gl[(int64_t)d * hw + ix] : 0.0f;
         load_pair(d, s, q, wq);
         one_plane(s, glv, q, wq);
     }
-    grad_left[idx] = acc_l;
+    if (WITH_LEFT) grad_left[idx] = acc_l;
     grad_right[idx] = acc_r;
+}
+
+// Adjoint of the depth-class planes of the factored first convolution (snvc_conv3d_forward_ex): plane 0 was added to
+// output depth 0, plane 2 to the last depth, plane 1 to every depth in between, so
+//   out[n,c,0] = g[n,c,0],  out[n,c,2] = g[n,c,D-1],  out[n,c,1] = sum_{d=1..D-2} g[n,c,d]   (d ascending: one fixed order)
+__global__ void __launch_bounds__(256)
+depth_class_sums_kernel(const float *__restrict__ g, float *__restrict__ out, int D, int64_t HW4) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW4) return;
+    const int64_t nc = blockIdx.y;
+    const f4 *gp = reinterpret_cast<const f4 *>(g) + nc * D * HW4 + i;
+    f4 *op = reinterpret_cast<f4 *>(out) + nc * 3 * HW4 + i;
+    f4 mid = f4(0.0f);
+    for (int d = 1; d + 1 < D; ++d) mid = mid + gp[(int64_t)d * HW4];
+    op[0] = gp[0];
+    op[HW4] = mid;
+    op[2 * HW4] = gp[(int64_t)(D - 1) * HW4];
 }
 
 template <typename T>
@@ -388,7 +407,7 @@ int launch_backward(const void *grad, const void *shift, void *gl, void *gr, int
     const int64_t blocks = ceil_div<int64_t>(total, 256);
     if constexpr (sizeof(T) == 4) {
         if (ds == 1 && W >= 2 && blocks < ((int64_t)1 << 31)) {
-            cost_volume_bwd_rows_f32<<<dim3((unsigned)blocks), 256, 0, st>>>((const float *)grad, (const float *)shift, (float *)gl,
+            cost_volume_bwd_rows_f32<true><<<dim3((unsigned)blocks), 256, 0, st>>>((const float *)grad, (const float *)shift, (float *)gl,
                                                                           (float *)gr, (int)C, (int)D, (int)H, (int)W, total);
             return check_launch("snvc_cost_volume_backward");
         }
@@ -432,6 +451,33 @@ int snvc_cost_volume_forward_right(const float *right, const float *shift, float
     if (N * C * D * Hi * Wi == 0) return SNVC_OK;
     if (!right || !shift || !out) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_cost_volume_forward_right: null pointer");
     return launch_forward<float>(nullptr, right, shift, out, N, C, Hi, Wi, D, 1, as_stream(stream));
+}
+
+int snvc_cost_volume_backward_right(const float *grad_right_half, const float *shift, float *grad_right, int64_t N, int64_t C,
+                                    int64_t H, int64_t W, int64_t D, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || H < 0 || W < 0 || D < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_cost_volume_backward_right: negative size");
+    const int64_t total = N * C * H * W;
+    if (total == 0) return SNVC_OK;
+    if (W < 2 || H * W >= ((int64_t)1 << 31) || ceil_div<int64_t>(total, 256) >= ((int64_t)1 << 31))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_cost_volume_backward_right: needs 2 <= W and a plane below 2^31 elements");
+    if (!grad_right || (D > 0 && (!grad_right_half || !shift)))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_cost_volume_backward_right: null pointer");
+    cost_volume_bwd_rows_f32<false><<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, as_stream(stream)>>>(
+        grad_right_half, shift, nullptr, grad_right, (int)C, (int)D, (int)H, (int)W, total);
+    return check_launch("snvc_cost_volume_backward_right");
+}
+
+int snvc_depth_class_sums(const float *g, float *out, int64_t NC, int64_t D, int64_t HW, void *stream) {
+    using namespace snvc;
+    if (NC < 0 || D < 2 || HW < 0 || HW % 4 != 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_depth_class_sums: needs D >= 2 and H*W % 4 == 0");
+    if (NC == 0 || HW == 0) return SNVC_OK;
+    if (!g || !out || ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out)) & 15))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_depth_class_sums: null or unaligned pointer");
+    if (NC > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_depth_class_sums: N*C > 65535");
+    depth_class_sums_kernel<<<dim3((unsigned)ceil_div<int64_t>(HW / 4, 256), (unsigned)NC), 256, 0, as_stream(stream)>>>(g, out, (int)D, HW / 4);
+    return check_launch("snvc_depth_class_sums");
 }
 
 int snvc_cost_volume_backward(const void *grad, const void *shift, void *grad_left, void *grad_right,

@@ -18,7 +18,8 @@ import torch.nn as nn
 
 from ..extension.build_cost_volume import build_cost_volume
 from .. import ops
-from .submodule import _GENERATION, ConvBNReLU3d, HipConv3d, _folded_bn, _Plan, convbn_3d, hourglass
+from .submodule import (_GENERATION, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _folded_bn, _Plan, convbn_3d, hourglass,
+                        EPI_RELU)
 
 
 class GlobalStack(nn.Module):
@@ -83,6 +84,14 @@ class GlobalStack(nn.Module):
                 timing[name][which].record()
 
         conv, bn = self.conv1[0][0], self.conv1[0][1]
+        training_graph = torch.is_grad_enabled() and (left.requires_grad or right.requires_grad or conv.weight.requires_grad)
+        if (training_graph and factored and timing is None and downsample == 1 and left.dtype == torch.float32
+                and left.size(3) % 4 == 0 and (left.size(2) * left.size(3)) % 4 == 0 and shift.size(1) >= 2):
+            # training (cfg4): the same factoring with a backward pass (half the first layer's dgrad / wgrad, no 1.5 GB volume)
+            assert torch.all(shift >= 0.)
+            plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(left.device, _Plan())
+            v = _FactoredFirstConvFn.apply(left, right, shift, conv.weight, bn.weight, bn.bias, conv, bn, EPI_RELU, plan)
+            return self._tail(self.conv2(v))
         usable = (factored and downsample == 1 and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
                   and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)
         if not usable:

@@ -118,6 +118,33 @@ def _folded_bn(bn: nn.BatchNorm3d, plan: _Plan):
     return plan.scale, plan.bias
 
 
+def _norm_from_raw(raw, norm, plan, residual, flags, out=None):
+    """norm + residual + activation of an already computed conv output `raw` (kept for the backward pass):
+    returns (y, scale, shift, mean, var, per_sample)."""
+    if norm is None:
+        if flags or residual is not None:
+            return ops.affine_act(raw, None, None, residual, flags, out=out), None, None, None, None, False
+        return raw, None, None, None, None, False
+    if isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None):
+        scale, bias = _folded_bn(norm, plan)
+        return ops.affine_act(raw, scale, bias, residual, flags, out=out), scale, bias, None, None, False
+    c = raw.size(1)
+    if isinstance(norm, nn.GroupNorm):
+        scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
+        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=out), scale, shift, mean, var, True
+    if isinstance(norm, nn.BatchNorm3d):
+        scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, c, False, norm.eps)
+        if norm.training and norm.track_running_stats and norm.running_mean is not None:
+            with torch.no_grad():  # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
+                cnt = raw.numel() / c
+                norm.num_batches_tracked += 1
+                m = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked)
+                norm.running_mean.mul_(1 - m).add_(mean[0], alpha=m)
+                norm.running_var.mul_(1 - m).add_(var[0] * (cnt / max(cnt - 1, 1)), alpha=m)
+        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=out), scale, shift, mean, var, False
+    raise NotImplementedError(f"norm layer {type(norm).__name__} is not on the path")
+
+
 def _norm_forward(layer, norm, plan, x, residual, flags, out, keep_raw, exact=False):
     """Shared forward: returns (y, raw, scale, shift, mean, var, per_sample).  `raw` is the conv
     output before the affine/activation (None when the single fused launch was used)."""
@@ -203,63 +230,9 @@ class _ConvNormActFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, raw, scale, shift, mean, var, res = ctx.saved_tensors
         conv, norm, flags, plan = ctx.conv, ctx.norm, ctx.flags, ctx.plan
-        gy = gy.contiguous()
-        n, c = raw.shape[0], raw.shape[1]
-        s = raw[0, 0].numel()
-        dev = raw.device
         needs = ctx.needs_input_grad
-        act_flags = flags & (EPI_RELU | EPI_SIGMOID | EPI_ADD_PRE)
-        dgamma = dbeta = None
-        if norm is None:
-            coef_g = torch.ones(c, device=dev)
-            coef_raw = coef_const = None
-            per_sample = False
-        else:
-            per_sample = ctx.per_sample
-            sums = ops.act_backward_reduce(raw, gy, res, scale, shift, act_flags, per_sample)   # [n, c, 2] fp64
-            gam = norm.weight.detach().double() if norm.weight is not None else torch.ones(c, device=dev, dtype=torch.float64)
-            if isinstance(norm, nn.GroupNorm):
-                groups = norm.num_groups
-                cpg = c // groups
-                mu = mean.double().repeat_interleave(cpg, dim=1)                       # [n, c]
-                rstd = torch.rsqrt(var.double() + norm.eps).repeat_interleave(cpg, dim=1)
-                sg, sgr = sums[..., 0], sums[..., 1]
-                sgx = rstd * (sgr - mu * sg)                                          # sum g * xhat per (n, c)
-                p1 = (gam * sg).view(n, groups, cpg).sum(2).repeat_interleave(cpg, dim=1)
-                p2 = (gam * sgx).view(n, groups, cpg).sum(2).repeat_interleave(cpg, dim=1)
-                m = float(cpg * s)
-                a_ = rstd * gam
-                b_ = -rstd * rstd * p2 / m
-                c_ = -rstd * p1 / m - b_ * mu
-                dgamma, dbeta = sgx.sum(0), sg.sum(0)
-            else:
-                sg, sgr = sums[..., 0].sum(0), sums[..., 1].sum(0)                    # [c]
-                if ctx.train_stats:
-                    mu, rstd = mean[0].double(), torch.rsqrt(var[0].double() + norm.eps)
-                    sgx = rstd * (sgr - mu * sg)
-                    m = float(n * s)
-                    a_ = gam * rstd
-                    b_ = -gam * rstd * rstd * sgx / m
-                    c_ = -gam * rstd * sg / m - b_ * mu
-                else:   # frozen statistics: a plain per-channel affine
-                    mu, rstd = norm.running_mean.double(), torch.rsqrt(norm.running_var.double() + norm.eps)
-                    sgx = rstd * (sgr - mu * sg)
-                    a_, b_, c_ = gam * rstd, None, None
-                dgamma, dbeta = sgx, sg
-            coef_g = a_.float().contiguous()
-            coef_raw = b_.float().contiguous() if b_ is not None else None
-            coef_const = c_.float().contiguous() if c_ is not None else None
-            if norm.weight is None:
-                dgamma = dbeta = None
-        want_g = ctx.has_res and bool(flags & EPI_ADD_PRE) and needs[4]
-        if norm is None and not act_flags:
-            draw, g_out = gy, gy
-        else:
-            draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
-                                                 per_sample, want_g)
-        gres = None
-        if ctx.has_res and needs[4]:
-            gres = g_out if (flags & EPI_ADD_PRE) else gy
+        draw, gres, dg, db = _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, ctx.per_sample, ctx.train_stats,
+                                                ctx.has_res and needs[4], needs[2], needs[3])
         # data and weight gradients
         k, st, p, d, transposed = _conv_geometry(conv)
         dl = _dgrad_layer(conv, plan)
@@ -270,9 +243,126 @@ class _ConvNormActFn(torch.autograd.Function):
                 gw = ops.conv3d_wgrad(draw, x, 3, 2, 1, 1)
             else:
                 gw = ops.conv3d_wgrad(x, draw, k, st, p, d)
-        dg = dgamma.float() if (dgamma is not None and needs[2]) else None
-        db = dbeta.float() if (dbeta is not None and needs[3]) else None
         return gx, gw, dg, db, gres, None, None, None, None
+
+
+def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_sample, train_stats, want_res, want_gamma, want_beta):
+    """Backward of  y = act(norm(raw) [+ res]) [+ res]  given gy: returns (draw, gres, dgamma, dbeta) on the HIP
+    reduction / apply kernels (BatchNorm / GroupNorm backward coefficients in fp64)."""
+    gy = gy.contiguous()
+    n, c = raw.shape[0], raw.shape[1]
+    s = raw[0, 0].numel()
+    dev = raw.device
+    act_flags = flags & (EPI_RELU | EPI_SIGMOID | EPI_ADD_PRE)
+    dgamma = dbeta = None
+    if norm is None:
+        coef_g = torch.ones(c, device=dev)
+        coef_raw = coef_const = None
+        per_sample = False
+    else:
+        sums = ops.act_backward_reduce(raw, gy, res, scale, shift, act_flags, per_sample)   # [n, c, 2] fp64
+        gam = norm.weight.detach().double() if norm.weight is not None else torch.ones(c, device=dev, dtype=torch.float64)
+        if isinstance(norm, nn.GroupNorm):
+            groups = norm.num_groups
+            cpg = c // groups
+            mu = mean.double().repeat_interleave(cpg, dim=1)                       # [n, c]
+            rstd = torch.rsqrt(var.double() + norm.eps).repeat_interleave(cpg, dim=1)
+            sg, sgr = sums[..., 0], sums[..., 1]
+            sgx = rstd * (sgr - mu * sg)                                          # sum g * xhat per (n, c)
+            p1 = (gam * sg).view(n, groups, cpg).sum(2).repeat_interleave(cpg, dim=1)
+            p2 = (gam * sgx).view(n, groups, cpg).sum(2).repeat_interleave(cpg, dim=1)
+            m = float(cpg * s)
+            a_ = rstd * gam
+            b_ = -rstd * rstd * p2 / m
+            c_ = -rstd * p1 / m - b_ * mu
+            dgamma, dbeta = sgx.sum(0), sg.sum(0)
+        else:
+            sg, sgr = sums[..., 0].sum(0), sums[..., 1].sum(0)                    # [c]
+            if train_stats:
+                mu, rstd = mean[0].double(), torch.rsqrt(var[0].double() + norm.eps)
+                sgx = rstd * (sgr - mu * sg)
+                m = float(n * s)
+                a_ = gam * rstd
+                b_ = -gam * rstd * rstd * sgx / m
+                c_ = -gam * rstd * sg / m - b_ * mu
+            else:   # frozen statistics: a plain per-channel affine
+                mu, rstd = norm.running_mean.double(), torch.rsqrt(norm.running_var.double() + norm.eps)
+                sgx = rstd * (sgr - mu * sg)
+                a_, b_, c_ = gam * rstd, None, None
+            dgamma, dbeta = sgx, sg
+        coef_g = a_.float().contiguous()
+        coef_raw = b_.float().contiguous() if b_ is not None else None
+        coef_const = c_.float().contiguous() if c_ is not None else None
+        if norm.weight is None:
+            dgamma = dbeta = None
+    want_g = want_res and bool(flags & EPI_ADD_PRE)
+    if norm is None and not act_flags:
+        draw, g_out = gy, gy
+    else:
+        draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
+                                             per_sample, want_g)
+    gres = None
+    if want_res:
+        gres = g_out if (flags & EPI_ADD_PRE) else gy
+    dg = dgamma.float() if (dgamma is not None and want_gamma) else None
+    db = dbeta.float() if (dbeta is not None and want_beta) else None
+    return draw, gres, dg, db
+
+
+class _FactoredFirstConvFn(torch.autograd.Function):
+    """Differentiable first layer of the global stack over a CONCAT cost volume that is never built:
+        y = act(norm(conv3d(build_cost_volume(left, right, shift, 1), W)))          (k3, stride 1, 2C -> Cout)
+    The left half of the volume repeats the left feature on every disparity plane (BuildCostVolume_cuda.cu:86), so
+      forward : raw = conv3d(warped right half, W[:, C:]) + depth-class planes of conv3d(left stacked 3 deep, W[:, :C])
+      backward: the right half goes through the ordinary 3D dgrad / wgrad at HALF the channels and the right-only
+                cost-volume adjoint; the left half collapses to 2D work on the depth-class sums of the output gradient
+                (snvc_depth_class_sums): a 3-plane wgrad / dgrad instead of a D-plane one.
+    Same gradients as the materialised path up to summation order (tests: training step vs C oracle + torch autograd)."""
+
+    @staticmethod
+    def forward(ctx, left, right, shift, weight, gamma, beta, conv, norm, flags, plan):
+        c = left.size(1)
+        fac = conv.__dict__.setdefault("_snvc_factored_train", {})
+        key = (weight.data_ptr(), weight._version, weight.device, _GENERATION[0])
+        if fac.get("key") != key:
+            wd = weight.detach()
+            wl, wr = wd[:, :c].contiguous(), wd[:, c:].contiguous()
+            flip = lambda w: w.transpose(0, 1).flip(2, 3, 4).contiguous()   # noqa: E731  (dgrad of a stride-1 conv)
+            fac.clear()
+            fac.update(key=key, fl=ops.Conv3dLayer(wl, 3, 1, 1, 1, False), fr=ops.Conv3dLayer(wr, 3, 1, 1, 1, False),
+                       bl=ops.Conv3dLayer(flip(wl), 3, 1, 1, 1, False), br=ops.Conv3dLayer(flip(wr), 3, 1, 1, 1, False))
+        left3 = left.detach().unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()
+        planes = fac["fl"](left3)
+        vol_r = ops.cost_volume_forward_right(right.detach(), shift)
+        raw = fac["fr"](vol_r, None, None, None, 0, None, depth_planes=planes)
+        del vol_r
+        y, scale, shf, mean, var, per_sample = _norm_from_raw(raw, norm, plan, None, flags)
+        ctx.conv, ctx.norm, ctx.flags, ctx.per_sample, ctx.train_stats = conv, norm, flags, per_sample, mean is not None
+        ctx.save_for_backward(left3, right.detach(), shift, raw, scale, shf, mean, var)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        left3, right, shift, raw, scale, shf, mean, var = ctx.saved_tensors
+        conv, norm, flags = ctx.conv, ctx.norm, ctx.flags
+        needs = ctx.needs_input_grad
+        draw, _, dg, db = _epilogue_backward(raw, gy, None, scale, shf, mean, var, norm, flags, ctx.per_sample, ctx.train_stats,
+                                             False, needs[4], needs[5])
+        fac = conv.__dict__["_snvc_factored_train"]
+        dplanes = ops.depth_class_sums(draw)                                      # [N,Cout,3,H,W]
+        g_left = g_right = gw = None
+        if needs[3]:
+            vol_r = ops.cost_volume_forward_right(right, shift)                   # recomputed (0.17 ms) rather than kept (0.74 GB)
+            gw_r = ops.conv3d_wgrad(vol_r, draw, 3, 1, 1, 1)
+            del vol_r
+            gw_l = ops.conv3d_wgrad(left3, dplanes, 3, 1, 1, 1)
+            gw = torch.cat([gw_l, gw_r], dim=1)
+        if needs[0]:
+            g_left = fac["bl"](dplanes).sum(dim=2)                                # the three depth copies are one tensor
+        if needs[1]:
+            g_right = ops.cost_volume_backward_right(fac["br"](draw), shift)
+        return g_left, g_right, None, gw, dg, db, None, None, None, None
 
 
 def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,

@@ -20,7 +20,7 @@ from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, C
                    check)
 
 __all__ = [
-    "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "voxel_gather_forward", "voxel_gather_backward",
+    "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "cost_volume_backward_right", "depth_class_sums", "voxel_gather_forward", "voxel_gather_backward",
     "Conv3dLayer", "conv_variant", "conv3d_wgrad", "Conv3dLayerF16", "to_c8", "from_c8", "voxel_gather_forward_f16",
     "mul_broadcast_c8", "avgpool_depth4_c8", "volume_resample", "rect_to_psv_grid", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4", "zero_stuff2x",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
@@ -139,6 +139,32 @@ def cost_volume_backward(grad, shift, downsample: int):
         check(_lib.lib().snvc_cost_volume_backward(_ptr(grad), _ptr(shift), _ptr(gl), _ptr(gr), n, c, h, w, d,
                                                    downsample, tag, _stream(grad)), "build_cost_volume_backward")
     return gl, gr
+
+
+def cost_volume_backward_right(grad_r, shift):
+    """Adjoint of cost_volume_forward_right: grad_r [N,C,D,H,W] -> grad_right [N,C,H,W] (fp32, downsample 1)."""
+    _gpu(grad_r, "grad"); _gpu(shift, "shift")
+    if grad_r.dtype != torch.float32 or shift.dtype != torch.float32 or grad_r.dim() != 5:
+        raise RuntimeError("cost_volume_backward_right needs float32 [N,C,D,H,W]")
+    grad_r, shift = grad_r.contiguous(), shift.contiguous()
+    n, c, d, h, w = grad_r.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=grad_r.device)
+    with torch.cuda.device(grad_r.device):
+        check(_lib.lib().snvc_cost_volume_backward_right(_ptr(grad_r), _ptr(shift), _ptr(out), n, c, h, w, d, _stream(grad_r)),
+              "snvc_cost_volume_backward_right")
+    return out
+
+
+def depth_class_sums(g):
+    """g [N,C,D,H,W] -> [N,C,3,H,W]: (g[:, :, 0], g[:, :, 1:-1].sum(2), g[:, :, -1]) -- the adjoint of the depth-class
+    planes of the factored first convolution."""
+    _gpu(g, "g")
+    g = g.contiguous()
+    n, c, d, h, w = g.shape
+    out = torch.empty((n, c, 3, h, w), dtype=torch.float32, device=g.device)
+    with torch.cuda.device(g.device):
+        check(_lib.lib().snvc_depth_class_sums(_ptr(g), _ptr(out), n * c, d, h * w, _stream(g)), "snvc_depth_class_sums")
+    return out
 
 
 # ------------------------------------------------------------------------------ voxel gather
