@@ -346,6 +346,56 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ partial, float *__
     dw[((int64_t)cg * Cx + cx) * taps + tap] = (s0 + s1) + (s2 + s3);
 }
 
+
+// Weight gradient of a 1x1x1 convolution to <= 2 channels (the global model's classifier, Conv3d(C,1,1)):
+// dW[cg][cx] = sum over (n, voxels) of g[cg] * x[cx] -- C dot products over the whole grid, HBM-bound.  The MFMA kernel
+// above spends 0.8 ms on it at cfg2 (one 32x32 tile for a 1x32 result); here a workgroup owns (chunk of voxels, cx),
+// threads stride the chunk with float4 loads, a fixed-shape LDS tree adds the 256 partials, and a second kernel adds
+// the chunks in ascending order: deterministic.
+template <int CG>
+__global__ void __launch_bounds__(256)
+wgrad_k1_small_partial(const float *__restrict__ x, const float *__restrict__ g, float *__restrict__ partial, int Cx, int64_t S4,
+                       int64_t chunk4, int64_t x_bs, int64_t g_bs) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float red[CG][256];
+    const int cx = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int64_t v0 = (int64_t)blockIdx.x * chunk4, v1 = v0 + chunk4 < S4 ? v0 + chunk4 : S4;
+    const f4 *xp = reinterpret_cast<const f4 *>(x + n * x_bs + (int64_t)cx * S4 * 4);
+    const f4 *gp = reinterpret_cast<const f4 *>(g + n * g_bs);
+    float acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = 0.0f;
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += 256) {
+        const f4 xv = xp[v];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const f4 gv = gp[(int64_t)c * S4 + v];
+            acc[c] += (xv[0] * gv[0] + xv[1] * gv[1]) + (xv[2] * gv[2] + xv[3] * gv[3]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CG; ++c) red[c][threadIdx.x] = acc[c];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w)
+#pragma unroll
+            for (int c = 0; c < CG; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < CG)
+        partial[(((int64_t)n * gridDim.x + blockIdx.x) * Cx + cx) * CG + threadIdx.x] = red[threadIdx.x][0];
+}
+
+__global__ void wgrad_k1_small_final(const float *__restrict__ partial, float *__restrict__ dw, int Cx, int CG, int64_t slabs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (cx, cg)
+    if (i >= Cx * CG) return;
+    const int cx = i / CG, cg = i - cx * CG;
+    float s = 0.0f;
+    for (int64_t k = 0; k < slabs; ++k) s += partial[(k * Cx + cx) * CG + cg];
+    dw[(int64_t)cg * Cx + cx] = s;
+}
+
 template <class Cfg, int VEC>
 void launch_wgrad_variant(const WgradArgs &a, dim3 grid, hipStream_t st) {
     constexpr int bytes = Cfg::LDS_FLOATS * 4;
@@ -424,6 +474,23 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
     const int pairs = ceil_div(d->Cout, 32) * a.cx_blocks;
     if (pairs > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_wgrad: too many channel pairs");
     hipStream_t st = as_stream(stream);
+    {   // 1x1x1 to <= 2 channels: streaming dot products (see wgrad_k1_small_partial)
+        const int64_t S = (int64_t)d->Dout * d->Hout * d->Wout;
+        const int64_t chunk4 = 16384;                                 // 64k voxels per workgroup
+        const int64_t chunks = ceil_div<int64_t>(S / 4, chunk4);
+        if (d->ksize == 1 && d->stride == 1 && d->Cout <= 2 && S % 4 == 0 && a.x_bs % 4 == 0 && a.g_bs % 4 == 0 &&
+            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0 && d->Cin <= 65535 && d->N <= 65535 &&
+            chunks * d->N * d->Cin * d->Cout * 4 <= snvc_conv3d_wgrad_workspace_bytes(d)) {
+            dim3 grid((unsigned)chunks, (unsigned)d->Cin, (unsigned)d->N);
+            if (d->Cout == 1)
+                wgrad_k1_small_partial<1><<<grid, 256, 0, st>>>(x, g, (float *)workspace, d->Cin, S / 4, chunk4, a.x_bs, a.g_bs);
+            else
+                wgrad_k1_small_partial<2><<<grid, 256, 0, st>>>(x, g, (float *)workspace, d->Cin, S / 4, chunk4, a.x_bs, a.g_bs);
+            wgrad_k1_small_final<<<ceil_div(d->Cin * d->Cout, 64), 64, 0, st>>>((const float *)workspace, dw, d->Cin, d->Cout,
+                                                                               chunks * d->N);
+            return check_launch("snvc_conv3d_wgrad(k1 small)");
+        }
+    }
     const int key = d->ksize * 100 + d->stride * 10 + d->dilation;
 #define SNVC_WGRAD_CASE(CFG)                                                                  \
     {                                                                                         \
