@@ -396,6 +396,213 @@ __global__ void wgrad_k1_small_final(const float *__restrict__ partial, float *_
     dw[(int64_t)cg * Cx + cx] = s;
 }
 
+// ------------------------------------------------------------------------------------ Winograd-domain weight gradient
+// 3x3x3 / stride-1 layers (conv1, conv2, the hourglass's stride-1 layers: 80 % of the training step's wgrad FLOPs).
+// The forward runs F(4,3) along W:  y = A^T [ (G g) . (B^T d) ]  per quad of 4 outputs.  Its adjoint w.r.t. the taps is
+//     dU_p = sum over quads of (A dy)_p * (B^T d)_p        (6 products per quad and (cout, cin, kd, kh))
+//     dg   = G^T dU                                         (applied once, in the reduce kernel)
+// so a K-step of two quads (8 output voxels) costs 6 MFMAs per (kd, kh) where the direct form issues 12 (3 taps x 4
+// K-steps).  Both operands are transformed in registers right after their LDS reads (8 + 12 VALU per 6 MFMAs):
+//     (A dy): p0 = dy0, p1/p2 = (dy0+dy2) +- (dy1+dy3), p3/p4 = (dy0+4dy2) +- (2dy1+8dy3), p5 = dy3
+//     (B^T d): as in the forward kernel (conv3d.hip, 4.1c)
+// A workgroup (6 waves) owns one kernel depth slice kd of one (cout block, cin block) pair and a spatial partition:
+// wave = (kh, position half) keeps three dU_p accumulators (48 registers: three waves per SIMD) over all K-steps of a
+// tile; partial slabs [P][pair][kd][kh][p][32][32] are summed in a fixed order by wgrad_wino_reduce_kernel, which also
+// applies G^T: deterministic, fp32 throughout (measured against torch autograd in
+// tests/test_gpu_parity.py, same 1e-3 bound as the direct form; desc.algo = SNVC_ALGO_DIRECT keeps the direct form).
+struct WinoWgradCfg {
+    static constexpr int TH = 4, TW = 32, THREADS = 384;
+    static constexpr int IN_H = TH + 2, LPAD = 4, XOFF = 3;
+    static constexpr int IN_WV = 40;                       // image columns ow0-4 .. ow0+35
+    static constexpr int XVV = IN_H * IN_WV, XSV = XVV | 1;
+    static constexpr int GV = TH * TW, GS = GV + 1;
+    static constexpr int RQ = IN_WV / 4;
+    static constexpr int XITEMS = 32 * IN_H * RQ, XNIT = (XITEMS + THREADS - 1) / THREADS;      // 16-byte pieces
+    static constexpr int GITEMS = 32 * TH * 8, GNIT = (GITEMS + THREADS - 1) / THREADS;
+    static constexpr int LDS_FLOATS = 32 * XSV + 32 * GS;  // 47 KB
+    static constexpr int SLABS = 18;                       // (kh, p) per kernel depth slice
+};
+
+__global__ void __launch_bounds__(384, 3)
+conv3d_wgrad_wino_kernel(const WgradArgs a) {
+    using Cfg = WinoWgradCfg;
+    constexpr int IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, XSV = Cfg::XSV, GS = Cfg::GS, RQ = Cfg::RQ, T = Cfg::THREADS;
+    constexpr int XNIT = Cfg::XNIT, GNIT = Cfg::GNIT;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *xl = lds;                 // [32][XSV]
+    float *gl = lds + 32 * XSV;      // [32][GS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kh = wave >> 1, ph = wave & 1;            // this wave: kernel row kh, Winograd positions 3*ph .. 3*ph+2
+    const int cgb = blockIdx.y / a.cx_blocks, cxb = blockIdx.y - cgb * a.cx_blocks;
+    const int cg0 = cgb * 32, cx0 = cxb * 32;
+    const int kd = blockIdx.z;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+    const int64_t in_hw = (int64_t)a.Hi * a.Wi, in_dhw = in_hw * a.Di;
+    const int64_t out_hw = (int64_t)a.Ho * a.Wo, out_dhw = out_hw * a.Do;
+    const int ch = lane & 31, half = lane >> 5;
+    const float *xrow = xl + ch * XSV + kh * IN_WV + Cfg::XOFF, *grow = gl + ch * GS;
+
+    // staging: packed codes hh | q << 4 | c << 16 (-1: beyond the tile / the channels), as in the direct kernel's float4 path
+    int xcode[XNIT], gcode[GNIT];
+#pragma unroll
+    for (int it = 0; it < XNIT; ++it) {
+        const int i = it * T + tid;
+        const int c = i / (IN_H * RQ), r = i - c * (IN_H * RQ);
+        const int hh = r / RQ, q = r - hh * RQ;
+        xcode[it] = (i < Cfg::XITEMS && cx0 + c < a.Cx) ? (hh | (q << 4) | (c << 16)) : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < GNIT; ++it) {
+        const int i = it * T + tid;
+        const int c = i / (Cfg::TH * 8), r = i - c * (Cfg::TH * 8);
+        const int hh = r / 8, q = r - hh * 8;
+        gcode[it] = (i < Cfg::GITEMS && cg0 + c < a.Cg) ? (hh | (q << 4) | (c << 16)) : -1;
+    }
+    f32x4 xv[XNIT], gv[GNIT];
+    unsigned xok = 0, gok = 0;
+    auto load_tile = [&](int64_t tile) {
+        const int tw = (int)(tile % a.tiles_w);
+        const int th = (int)((tile / a.tiles_w) % a.tiles_h);
+        const int od = (int)((tile / ((int64_t)a.tiles_w * a.tiles_h)) % a.Do);
+        const int64_t n = tile / ((int64_t)a.tiles_w * a.tiles_h * a.Do);
+        const int oh0 = th * Cfg::TH, ow0 = tw * 32;
+        const int id = od - 1 + kd, ih0 = oh0 - 1, ix0 = ow0 - Cfg::LPAD;
+        const float *xn = a.x + n * a.x_bs + (int64_t)cx0 * in_dhw;
+        const float *gn = a.g + n * a.g_bs + (int64_t)cg0 * out_dhw;
+        const int64_t xorg = (int64_t)id * in_hw + (int64_t)ih0 * a.Wi + ix0;     // used only when valid
+        const int64_t gorg = (int64_t)od * out_hw + (int64_t)oh0 * a.Wo + ow0;
+        const bool d_ok = (unsigned)id < (unsigned)a.Di;
+        xok = 0; gok = 0;
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it) {
+            const int hh = xcode[it] & 15, q = (xcode[it] >> 4) & 255, c = xcode[it] >> 16;
+            const bool ok = xcode[it] >= 0 && d_ok && (unsigned)(ih0 + hh) < (unsigned)a.Hi && (unsigned)(ix0 + 4 * q) < (unsigned)a.Wi;
+            xv[it] = *reinterpret_cast<const f32x4 *>(ok ? xn + xorg + c * in_dhw + (int64_t)hh * a.Wi + 4 * q : a.x);
+            xok |= (ok ? 1u : 0u) << it;
+        }
+#pragma unroll
+        for (int it = 0; it < GNIT; ++it) {
+            const int hh = gcode[it] & 15, q = (gcode[it] >> 4) & 255, c = gcode[it] >> 16;
+            const bool ok = gcode[it] >= 0 && oh0 + hh < a.Ho && ow0 + 4 * q < a.Wo;
+            gv[it] = *reinterpret_cast<const f32x4 *>(ok ? gn + gorg + c * out_dhw + (int64_t)hh * a.Wo + 4 * q : a.g);
+            gok |= (ok ? 1u : 0u) << it;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it) {
+            if (Cfg::XITEMS % T != 0 && it * T + tid >= Cfg::XITEMS) continue;
+            const bool ok = (xok >> it) & 1u;
+            const int hh = xcode[it] & 15, q = (xcode[it] >> 4) & 255, c = (xcode[it] >> 16) & 31;
+            const int dst = c * XSV + hh * IN_WV + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xl[dst + j] = ok ? xv[it][j] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < GNIT; ++it) {
+            if (Cfg::GITEMS % T != 0 && it * T + tid >= Cfg::GITEMS) continue;
+            const bool ok = (gok >> it) & 1u;
+            const int hh = gcode[it] & 15, q = (gcode[it] >> 4) & 255, c = (gcode[it] >> 16) & 31;
+            const int dst = c * GS + hh * 32 + 4 * q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gl[dst + j] = ok ? gv[it][j] : 0.0f;
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < a.ntiles) load_tile(tile);
+    for (; tile < a.ntiles; tile += a.P) {
+        __syncthreads();   // previous tile fully consumed
+        store_tile();
+        __syncthreads();
+        if (tile + a.P < a.ntiles) load_tile(tile + a.P);   // in flight during the MFMAs below
+        // 16 K-steps of two quads (lanes 0-31: quad 2kk, lanes 32-63: quad 2kk+1); quad q = row q / 8, quad t = q % 8
+        if (ph == 0) {
+#pragma unroll 4
+            for (int kk = 0; kk < Cfg::TH * 4; ++kk) {
+                const int q = 2 * kk + half;
+                const float *gp = grow + 4 * q;                              // r * 32 + 4 * t == 4 * q
+                const float *xp = xrow + (q >> 3) * IN_WV + 4 * (q & 7);
+                const float dy0 = gp[0], dy1 = gp[1], dy2 = gp[2], dy3 = gp[3];
+                const float d0 = xp[0], d1 = xp[1], d2 = xp[2], d3 = xp[3], d4 = xp[4];
+                const float s02 = dy0 + dy2, s13 = dy1 + dy3;
+                const float e = __builtin_fmaf(-4.0f, d2, d4), f = __builtin_fmaf(-4.0f, d1, d3);
+                const float v0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy0, v0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(s02 + s13, e + f, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(s02 - s13, e - f, acc[2], 0, 0, 0);
+            }
+        } else {
+#pragma unroll 4
+            for (int kk = 0; kk < Cfg::TH * 4; ++kk) {
+                const int q = 2 * kk + half;
+                const float *gp = grow + 4 * q;
+                const float *xp = xrow + (q >> 3) * IN_WV + 4 * (q & 7);
+                const float dy0 = gp[0], dy1 = gp[1], dy2 = gp[2], dy3 = gp[3];
+                const float d1 = xp[1], d2 = xp[2], d3 = xp[3], d4 = xp[4], d5 = xp[5];
+                const float t02 = __builtin_fmaf(4.0f, dy2, dy0), t13 = __builtin_fmaf(8.0f, dy3, 2.0f * dy1);
+                const float c2 = d4 - d2, e2 = d3 - d1;
+                const float v5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(t02 + t13, __builtin_fmaf(2.0f, e2, c2), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(t02 - t13, __builtin_fmaf(-2.0f, e2, c2), acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy3, v5, acc[2], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial slab [partition][pair][kd][kh][pos][cg 32][cx 32]
+    float *pp = a.partial + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 3 + kd) * (int64_t)Cfg::SLABS * 1024 +
+                (int64_t)(kh * 6 + ph * 3) * 1024;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;            // cg
+            pp[(p * 32 + row) * 32 + ch] = acc[p][r];
+        }
+}
+
+// dw[cg][cx][kd][kh][kw] = sum_p G[p][kw] * (sum over partitions of the dU_p slabs); one thread per (pair, kd, kh, cg, cx)
+__global__ void wgrad_wino_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dw, int Cg, int Cx, int cx_blocks,
+                                         int pairs, int P) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_pair = 9 * 1024;                          // (kd, kh) x 32 x 32
+    if (i >= (int64_t)pairs * per_pair) return;
+    const int cxl = (int)(i & 31), cgl = (int)((i >> 5) & 31);
+    const int kdh = (int)((i >> 10) % 9);
+    const int pair = (int)(i / per_pair);
+    const int cg = (pair / cx_blocks) * 32 + cgl, cx = (pair % cx_blocks) * 32 + cxl;
+    if (cg >= Cg || cx >= Cx) return;
+    const int64_t pstride = (int64_t)pairs * 54 * 1024;
+    const float *src = partial + ((int64_t)pair * 54 + kdh * 6) * 1024 + cgl * 32 + cxl;
+    float u[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) {
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        const float *sp = src + p * 1024;
+        int k = 0;
+        for (; k + 4 <= P; k += 4) {
+            s0 += sp[(int64_t)k * pstride];
+            s1 += sp[(int64_t)(k + 1) * pstride];
+            s2 += sp[(int64_t)(k + 2) * pstride];
+            s3 += sp[(int64_t)(k + 3) * pstride];
+        }
+        for (; k < P; ++k) s0 += sp[(int64_t)k * pstride];
+        u[p] = (s0 + s1) + (s2 + s3);
+    }
+    // G^T (wino tables of F(4,3): U0 = g0/4, U1 = -(g0+g1+g2)/6, U2 = -(g0-g1+g2)/6, U3 = g0/24+g1/12+g2/6,
+    // U4 = g0/24-g1/12+g2/6, U5 = g2)
+    const float g0 = u[0] * 0.25f - (u[1] + u[2]) * (1.0f / 6.0f) + (u[3] + u[4]) * (1.0f / 24.0f);
+    const float g1 = (u[2] - u[1]) * (1.0f / 6.0f) + (u[3] - u[4]) * (1.0f / 12.0f);
+    const float g2 = -(u[1] + u[2]) * (1.0f / 6.0f) + (u[3] + u[4]) * (1.0f / 6.0f) + u[5];
+    float *o = dw + (((int64_t)cg * Cx + cx) * 9 + kdh) * 3;
+    o[0] = g0; o[1] = g1; o[2] = g2;
+}
+
 template <class Cfg, int VEC>
 void launch_wgrad_variant(const WgradArgs &a, dim3 grid, hipStream_t st) {
     constexpr int bytes = Cfg::LDS_FLOATS * 4;
@@ -427,7 +634,8 @@ extern "C" {
 int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *d) {
     using namespace snvc;
     if (!d) return -1;
-    const int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
+    int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
+    if (d->ksize == 3 && d->stride == 1 && d->dilation == 1) taps = 54;      // the Winograd-domain form: 9 (kd, kh) x 6 positions
     const int64_t pairs = (int64_t)ceil_div(d->Cout, 32) * ceil_div(d->Cin, 32);
     return (int64_t)kWgradPartitions * pairs * taps * 1024 * (int64_t)sizeof(float);
 }
@@ -492,6 +700,22 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
         }
     }
     const int key = d->ksize * 100 + d->stride * 10 + d->dilation;
+    if (key == 311 && a.vec == 4 && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
+        // Winograd-domain form (see conv3d_wgrad_wino_kernel): half the MFMAs of the direct form
+        a.tiles_h = ceil_div(d->Hout, WinoWgradCfg::TH);
+        a.ntiles = (int64_t)d->N * d->Dout * a.tiles_h * a.tiles_w;
+        a.P = device_cu_count() * 2 / 3 > kWgradPartitions ? kWgradPartitions : device_cu_count() * 2 / 3;   // x 3 depth slices = 2 per CU
+        static std::atomic<unsigned> attr_done{0};
+        constexpr int bytes = WinoWgradCfg::LDS_FLOATS * 4;
+        if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_wino_kernel), bytes, attr_done))
+            conv3d_wgrad_wino_kernel<<<dim3((unsigned)a.P, (unsigned)pairs, 3), WinoWgradCfg::THREADS, bytes, st>>>(a);
+        int rcw = check_launch("snvc_conv3d_wgrad(winograd)");
+        if (rcw) return rcw;
+        const int64_t total = (int64_t)pairs * 9 * 1024;
+        wgrad_wino_reduce_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>((const float *)workspace, dw, d->Cout,
+                                                                                                 d->Cin, a.cx_blocks, pairs, a.P);
+        return check_launch("snvc_conv3d_wgrad(winograd reduce)");
+    }
 #define SNVC_WGRAD_CASE(CFG)                                                                  \
     {                                                                                         \
         using C_ = CFG;                                                                       \
