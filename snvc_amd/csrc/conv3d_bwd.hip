@@ -412,10 +412,14 @@ __global__ void wgrad_k1_small_final(const float *__restrict__ partial, float *_
 // tests/test_gpu_parity.py, same 1e-3 bound as the direct form; desc.algo = SNVC_ALGO_DIRECT keeps the direct form).
 struct WinoWgradCfg {
     static constexpr int TH = 4, TW = 32, THREADS = 384;
-    static constexpr int IN_H = TH + 2, LPAD = 4, XOFF = 3;
+    static constexpr int IN_H = TH + 2, LPAD = 4;
     static constexpr int IN_WV = 40;                       // image columns ow0-4 .. ow0+35
-    static constexpr int XVV = IN_H * IN_WV, XSV = XVV | 1;
-    static constexpr int GV = TH * TW, GS = GV + 1;
+    // Channel strides are 4 * (odd) floats: rows stay 16-byte aligned (whole pieces are stored with one ds_write_b128, no
+    // bank conflicts -- the odd strides of the direct kernel force four 4-way conflicting ds_write_b32 per piece) and a
+    // lane's quad is ONE ds_read_b128 whose 16-lane groups cover all 64 banks (4 * ch * odd mod 64 is a permutation).
+    static constexpr int XVV = IN_H * IN_WV, XSV = XVV + 4;      // 244 = 4 * 61
+    static constexpr int GV = TH * TW, GS = GV + 4;              // 132 = 4 * 33
+    static_assert((XSV / 4) % 2 == 1 && (GS / 4) % 2 == 1 && XSV % 4 == 0 && GS % 4 == 0, "channel stride = 4 * odd");
     static constexpr int RQ = IN_WV / 4;
     static constexpr int XITEMS = 32 * IN_H * RQ, XNIT = (XITEMS + THREADS - 1) / THREADS;      // 16-byte pieces
     static constexpr int GITEMS = 32 * TH * 8, GNIT = (GITEMS + THREADS - 1) / THREADS;
@@ -446,7 +450,7 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
     const int64_t in_hw = (int64_t)a.Hi * a.Wi, in_dhw = in_hw * a.Di;
     const int64_t out_hw = (int64_t)a.Ho * a.Wo, out_dhw = out_hw * a.Do;
     const int ch = lane & 31, half = lane >> 5;
-    const float *xrow = xl + ch * XSV + kh * IN_WV + Cfg::XOFF, *grow = gl + ch * GS;
+    const float *xrow = xl + ch * XSV + kh * IN_WV, *grow = gl + ch * GS;
 
     // staging: packed codes hh | q << 4 | c << 16 (-1: beyond the tile / the channels), as in the direct kernel's float4 path
     int xcode[XNIT], gcode[GNIT];
@@ -501,8 +505,7 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
             const bool ok = (xok >> it) & 1u;
             const int hh = xcode[it] & 15, q = (xcode[it] >> 4) & 255, c = (xcode[it] >> 16) & 31;
             const int dst = c * XSV + hh * IN_WV + 4 * q;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) xl[dst + j] = ok ? xv[it][j] : 0.0f;
+            *reinterpret_cast<f32x4 *>(xl + dst) = ok ? xv[it] : f32x4(0.0f);
         }
 #pragma unroll
         for (int it = 0; it < GNIT; ++it) {
@@ -510,8 +513,7 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
             const bool ok = (gok >> it) & 1u;
             const int hh = gcode[it] & 15, q = (gcode[it] >> 4) & 255, c = (gcode[it] >> 16) & 31;
             const int dst = c * GS + hh * 32 + 4 * q;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gl[dst + j] = ok ? gv[it][j] : 0.0f;
+            *reinterpret_cast<f32x4 *>(gl + dst) = ok ? gv[it] : f32x4(0.0f);
         }
     };
     int64_t tile = blockIdx.x;
@@ -522,14 +524,17 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
         __syncthreads();
         if (tile + a.P < a.ntiles) load_tile(tile + a.P);   // in flight during the MFMAs below
         // 16 K-steps of two quads (lanes 0-31: quad 2kk, lanes 32-63: quad 2kk+1); quad q = row q / 8, quad t = q % 8
+        // (q = 2kk + half: row q >> 3 = kk >> 2 and quad q & 7 = 2 (kk & 3) + half, so everything but 4 * half is an immediate)
+        const float *gq = grow + 4 * half, *xq = xrow + 4 * half;
         if (ph == 0) {
 #pragma unroll 4
             for (int kk = 0; kk < Cfg::TH * 4; ++kk) {
-                const int q = 2 * kk + half;
-                const float *gp = grow + 4 * q;                              // r * 32 + 4 * t == 4 * q
-                const float *xp = xrow + (q >> 3) * IN_WV + 4 * (q & 7);
-                const float dy0 = gp[0], dy1 = gp[1], dy2 = gp[2], dy3 = gp[3];
-                const float d0 = xp[0], d1 = xp[1], d2 = xp[2], d3 = xp[3], d4 = xp[4];
+                // the quad's inputs x[4t-1 .. 4t+4] are image columns 4t+3 .. 4t+8: last float of piece t, piece t+1, first of t+2
+                const f32x4 dy = *reinterpret_cast<const f32x4 *>(gq + 8 * kk);                               // r * 32 + 4 * t == 4 * q
+                const float *xp = xq + (kk >> 2) * IN_WV + 8 * (kk & 3);
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xp), x1 = *reinterpret_cast<const f32x4 *>(xp + 4);
+                const float dy0 = dy[0], dy1 = dy[1], dy2 = dy[2], dy3 = dy[3];
+                const float d0 = x0[3], d1 = x1[0], d2 = x1[1], d3 = x1[2], d4 = x1[3];
                 const float s02 = dy0 + dy2, s13 = dy1 + dy3;
                 const float e = __builtin_fmaf(-4.0f, d2, d4), f = __builtin_fmaf(-4.0f, d1, d3);
                 const float v0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
@@ -540,11 +545,11 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
         } else {
 #pragma unroll 4
             for (int kk = 0; kk < Cfg::TH * 4; ++kk) {
-                const int q = 2 * kk + half;
-                const float *gp = grow + 4 * q;
-                const float *xp = xrow + (q >> 3) * IN_WV + 4 * (q & 7);
-                const float dy0 = gp[0], dy1 = gp[1], dy2 = gp[2], dy3 = gp[3];
-                const float d1 = xp[1], d2 = xp[2], d3 = xp[3], d4 = xp[4], d5 = xp[5];
+                const f32x4 dy = *reinterpret_cast<const f32x4 *>(gq + 8 * kk);
+                const float *xp = xq + (kk >> 2) * IN_WV + 8 * (kk & 3);
+                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xp + 4), x2 = *reinterpret_cast<const f32x4 *>(xp + 8);
+                const float dy0 = dy[0], dy1 = dy[1], dy2 = dy[2], dy3 = dy[3];
+                const float d1 = x1[0], d2 = x1[1], d3 = x1[2], d4 = x1[3], d5 = x2[0];
                 const float t02 = __builtin_fmaf(4.0f, dy2, dy0), t13 = __builtin_fmaf(8.0f, dy3, 2.0f * dy1);
                 const float c2 = d4 - d2, e2 = d3 - d1;
                 const float v5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
