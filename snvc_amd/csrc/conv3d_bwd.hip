@@ -38,6 +38,7 @@ struct WgradArgs {
     int cx_blocks;              // pairs = cg_blocks * cx_blocks, blockIdx.y = cgb * cx_blocks + cxb
     int64_t x_bs, g_bs;
     int vec;   // 16-byte aligned rows on both grids: float4 staging with register prefetch
+    int pairs, upx;     // Winograd form: 1-D grid of 8 * upx * 3 workgroups, see conv3d_wgrad_wino_kernel
 };
 
 // A workgroup covers a CHUNK of taps: KDG kernel depth-slices x KHG kernel rows x all KS columns
@@ -405,13 +406,15 @@ __global__ void wgrad_k1_small_final(const float *__restrict__ partial, float *_
 // K-steps).  Both operands are transformed in registers right after their LDS reads (8 + 12 VALU per 6 MFMAs):
 //     (A dy): p0 = dy0, p1/p2 = (dy0+dy2) +- (dy1+dy3), p3/p4 = (dy0+4dy2) +- (2dy1+8dy3), p5 = dy3
 //     (B^T d): as in the forward kernel (conv3d.hip, 4.1c)
-// A workgroup (6 waves) owns one kernel depth slice kd of one (cout block, cin block) pair and a spatial partition:
-// wave = (kh, position half) keeps three dU_p accumulators (48 registers: three waves per SIMD) over all K-steps of a
-// tile; partial slabs [P][pair][kd][kh][p][32][32] are summed in a fixed order by wgrad_wino_reduce_kernel, which also
-// applies G^T: deterministic, fp32 throughout (measured against torch autograd in
+// A workgroup (12 waves = the three waves per SIMD that 168 registers allow; a 6-wave workgroup lands 2,2,1,1 on the SIMDs
+// and a second one does not fit beside it -- measured: same time with one workgroup per CU forced) owns one kernel depth
+// slice kd of one (cout block, cin block) pair and a spatial partition: wave = (row half of the tile, kh, position half)
+// keeps three dU_p accumulators over its K-steps of every tile; the tile is double-buffered in LDS (one barrier per
+// tile: waves that finish their MFMAs store the next tile while the others still compute).  Partial slabs
+// [2P][pair][kd][kh][p][32][32] are summed in a fixed order by wgrad_wino_reduce_kernel, which also applies G^T: deterministic, fp32 throughout (measured against torch autograd in
 // tests/test_gpu_parity.py, same 1e-3 bound as the direct form; desc.algo = SNVC_ALGO_DIRECT keeps the direct form).
 struct WinoWgradCfg {
-    static constexpr int TH = 4, TW = 32, THREADS = 384;
+    static constexpr int TH = 4, TW = 32, THREADS = 768;
     static constexpr int IN_H = TH + 2, LPAD = 4;
     static constexpr int IN_WV = 40;                       // image columns ow0-4 .. ow0+35
     // Channel strides are 4 * (odd) floats: rows stay 16-byte aligned (whole pieces are stored with one ds_write_b128, no
@@ -423,23 +426,32 @@ struct WinoWgradCfg {
     static constexpr int RQ = IN_WV / 4;
     static constexpr int XITEMS = 32 * IN_H * RQ, XNIT = (XITEMS + THREADS - 1) / THREADS;      // 16-byte pieces
     static constexpr int GITEMS = 32 * TH * 8, GNIT = (GITEMS + THREADS - 1) / THREADS;
-    static constexpr int LDS_FLOATS = 32 * XSV + 32 * GS;  // 47 KB
+    static constexpr int BUF_FLOATS = 32 * XSV + 32 * GS;  // 47 KB
+    static constexpr int LDS_FLOATS = 2 * BUF_FLOATS;      // double-buffered
     static constexpr int SLABS = 18;                       // (kh, p) per kernel depth slice
 };
 
-__global__ void __launch_bounds__(384, 3)
+__global__ void __launch_bounds__(768, 1)
 conv3d_wgrad_wino_kernel(const WgradArgs a) {
     using Cfg = WinoWgradCfg;
     constexpr int IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, XSV = Cfg::XSV, GS = Cfg::GS, RQ = Cfg::RQ, T = Cfg::THREADS;
     constexpr int XNIT = Cfg::XNIT, GNIT = Cfg::GNIT;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *xl = lds;                 // [32][XSV]
-    float *gl = lds + 32 * XSV;      // [32][GS]
+    // buffer b: X [32][XSV] at lds + b * BUF_FLOATS, G [32][GS] behind it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kh = wave >> 1, ph = wave & 1;            // this wave: kernel row kh, Winograd positions 3*ph .. 3*ph+2
-    const int cgb = blockIdx.y / a.cx_blocks, cxb = blockIdx.y - cgb * a.cx_blocks;
+    const int kq = wave / 6, role = wave - 6 * kq;      // this wave: tile rows 2kq, 2kq+1,
+    const int kh = role >> 1, ph = role & 1;            // kernel row kh, Winograd positions 3*ph .. 3*ph+2
+    // 1-D grid, id -> (XCD id & 7, slot id >> 3), at most one workgroup per CU of each XCD: the three kd workgroups of a
+    // (pair, partition) unit sit on ONE XCD, units that are neighbours in depth (tiles run depth-fastest, partition = tile
+    // mod P) beside them: the dy tile is fetched into that L2 once for the three kd, and input slice od+1 read by kd = 2
+    // of one partition is read at the same time by kd = 1 / kd = 0 of the next two.  (With kd on blockIdx.z the loads
+    // alone took 1.48 ms of the layer's 2.45 ms: 6.3 GB over the fabric.)
+    const int slot = blockIdx.x >> 3;
+    const int kd = slot % 3, unit = (blockIdx.x & 7) * a.upx + slot / 3;
+    if (unit >= a.pairs * a.P) return;
+    const int pair = unit / a.P, part = unit - pair * a.P;
+    const int cgb = pair / a.cx_blocks, cxb = pair - cgb * a.cx_blocks;
     const int cg0 = cgb * 32, cx0 = cxb * 32;
-    const int kd = blockIdx.z;
 
     f32x16 acc[3];
 #pragma unroll
@@ -450,85 +462,104 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
     const int64_t in_hw = (int64_t)a.Hi * a.Wi, in_dhw = in_hw * a.Di;
     const int64_t out_hw = (int64_t)a.Ho * a.Wo, out_dhw = out_hw * a.Do;
     const int ch = lane & 31, half = lane >> 5;
-    const float *xrow = xl + ch * XSV + kh * IN_WV, *grow = gl + ch * GS;
+    const int xrow = ch * XSV + (kh + 2 * kq) * IN_WV + 4 * half, grow = 32 * XSV + ch * GS + 2 * kq * 32 + 4 * half;
 
-    // staging: packed codes hh | q << 4 | c << 16 (-1: beyond the tile / the channels), as in the direct kernel's float4 path
-    int xcode[XNIT], gcode[GNIT];
+    // staging: per item, tile-invariant: the 32-bit element offset from the tile's origin, the LDS offset, and the packed
+    // code hh | q << 4 for the border tests; bit `it` of xstat / gstat = the item exists (inside the tile's item count and
+    // the layer's channels).  Interior tiles (72% of cfg2's conv1) load with no per-item test or address arithmetic: a
+    // wave-uniform base plus the item's offset.
+    unsigned xoff[XNIT], goff[GNIT];
+    int xdst[XNIT], gdst[GNIT], xcode[XNIT], gcode[GNIT];
+    unsigned xstat = 0, gstat = 0;
 #pragma unroll
     for (int it = 0; it < XNIT; ++it) {
         const int i = it * T + tid;
         const int c = i / (IN_H * RQ), r = i - c * (IN_H * RQ);
         const int hh = r / RQ, q = r - hh * RQ;
-        xcode[it] = (i < Cfg::XITEMS && cx0 + c < a.Cx) ? (hh | (q << 4) | (c << 16)) : -1;
+        const bool ex = i < Cfg::XITEMS && cx0 + c < a.Cx;
+        xstat |= (ex ? 1u : 0u) << it;
+        xcode[it] = hh | (q << 4);
+        xoff[it] = ex ? (unsigned)(c * in_dhw + (int64_t)hh * a.Wi + 4 * q) : 0u;
+        xdst[it] = i < Cfg::XITEMS ? c * XSV + hh * IN_WV + 4 * q : -1;
     }
 #pragma unroll
     for (int it = 0; it < GNIT; ++it) {
         const int i = it * T + tid;
         const int c = i / (Cfg::TH * 8), r = i - c * (Cfg::TH * 8);
         const int hh = r / 8, q = r - hh * 8;
-        gcode[it] = (i < Cfg::GITEMS && cg0 + c < a.Cg) ? (hh | (q << 4) | (c << 16)) : -1;
+        const bool ex = i < Cfg::GITEMS && cg0 + c < a.Cg;
+        gstat |= (ex ? 1u : 0u) << it;
+        gcode[it] = hh | (q << 4);
+        goff[it] = ex ? (unsigned)(c * out_dhw + (int64_t)hh * a.Wo + 4 * q) : 0u;
+        gdst[it] = i < Cfg::GITEMS ? 32 * XSV + c * GS + hh * 32 + 4 * q : -1;
     }
     f32x4 xv[XNIT], gv[GNIT];
     unsigned xok = 0, gok = 0;
-    auto load_tile = [&](int64_t tile) {
-        const int tw = (int)(tile % a.tiles_w);
-        const int th = (int)((tile / a.tiles_w) % a.tiles_h);
-        const int od = (int)((tile / ((int64_t)a.tiles_w * a.tiles_h)) % a.Do);
-        const int64_t n = tile / ((int64_t)a.tiles_w * a.tiles_h * a.Do);
+    const unsigned tiles_dw = (unsigned)a.Do * a.tiles_w, tiles_dwh = tiles_dw * a.tiles_h;
+    auto load_tile = [&](unsigned tile) {
+        const unsigned n = tile / tiles_dwh, r0 = tile - n * tiles_dwh;           // depth fastest
+        const unsigned th = r0 / tiles_dw, r1 = r0 - th * tiles_dw;
+        const int tw = (int)(r1 / (unsigned)a.Do), od = (int)(r1 - tw * (unsigned)a.Do);
         const int oh0 = th * Cfg::TH, ow0 = tw * 32;
         const int id = od - 1 + kd, ih0 = oh0 - 1, ix0 = ow0 - Cfg::LPAD;
-        const float *xn = a.x + n * a.x_bs + (int64_t)cx0 * in_dhw;
-        const float *gn = a.g + n * a.g_bs + (int64_t)cg0 * out_dhw;
-        const int64_t xorg = (int64_t)id * in_hw + (int64_t)ih0 * a.Wi + ix0;     // used only when valid
-        const int64_t gorg = (int64_t)od * out_hw + (int64_t)oh0 * a.Wo + ow0;
+        const float *gb = a.g + n * a.g_bs + (int64_t)cg0 * out_dhw + (int64_t)od * out_hw + (int64_t)oh0 * a.Wo + ow0;
         const bool d_ok = (unsigned)id < (unsigned)a.Di;
-        xok = 0; gok = 0;
+        // the X origin may lie before the tensor on border tiles: it is only dereferenced through items that passed their tests
+        const float *xb = a.x + n * a.x_bs + (int64_t)cx0 * in_dhw + (int64_t)id * in_hw + (int64_t)ih0 * a.Wi + ix0;
+        const bool interior = d_ok && ih0 >= 0 && ih0 + IN_H <= a.Hi && ix0 >= 0 && ix0 + IN_WV <= a.Wi &&
+                              oh0 + Cfg::TH <= a.Ho && ow0 + 32 <= a.Wo;
+        if (interior) {
+            xok = xstat; gok = gstat;
+#pragma unroll
+            for (int it = 0; it < XNIT; ++it) xv[it] = *reinterpret_cast<const f32x4 *>(xb + xoff[it]);    // offset 0 (a valid
+#pragma unroll                                                                                             // element) where
+            for (int it = 0; it < GNIT; ++it) gv[it] = *reinterpret_cast<const f32x4 *>(gb + goff[it]);    // the item is absent
+        } else {
+            xok = 0; gok = 0;
+#pragma unroll
+            for (int it = 0; it < XNIT; ++it) {
+                const int hh = xcode[it] & 15, q = xcode[it] >> 4;
+                const bool ok = ((xstat >> it) & 1u) && d_ok && (unsigned)(ih0 + hh) < (unsigned)a.Hi &&
+                                (unsigned)(ix0 + 4 * q) < (unsigned)a.Wi;
+                xv[it] = *reinterpret_cast<const f32x4 *>(ok ? xb + xoff[it] : a.x);
+                xok |= (ok ? 1u : 0u) << it;
+            }
+#pragma unroll
+            for (int it = 0; it < GNIT; ++it) {
+                const int hh = gcode[it] & 15, q = gcode[it] >> 4;
+                const bool ok = ((gstat >> it) & 1u) && oh0 + hh < a.Ho && ow0 + 4 * q < a.Wo;
+                gv[it] = *reinterpret_cast<const f32x4 *>(ok ? gb + goff[it] : a.g);
+                gok |= (ok ? 1u : 0u) << it;
+            }
+        }
+    };
+    auto store_tile = [&](float *base) {
 #pragma unroll
         for (int it = 0; it < XNIT; ++it) {
-            const int hh = xcode[it] & 15, q = (xcode[it] >> 4) & 255, c = xcode[it] >> 16;
-            const bool ok = xcode[it] >= 0 && d_ok && (unsigned)(ih0 + hh) < (unsigned)a.Hi && (unsigned)(ix0 + 4 * q) < (unsigned)a.Wi;
-            xv[it] = *reinterpret_cast<const f32x4 *>(ok ? xn + xorg + c * in_dhw + (int64_t)hh * a.Wi + 4 * q : a.x);
-            xok |= (ok ? 1u : 0u) << it;
+            if (Cfg::XITEMS % T != 0 && xdst[it] < 0) continue;
+            *reinterpret_cast<f32x4 *>(base + xdst[it]) = ((xok >> it) & 1u) ? xv[it] : f32x4(0.0f);
         }
 #pragma unroll
         for (int it = 0; it < GNIT; ++it) {
-            const int hh = gcode[it] & 15, q = (gcode[it] >> 4) & 255, c = gcode[it] >> 16;
-            const bool ok = gcode[it] >= 0 && oh0 + hh < a.Ho && ow0 + 4 * q < a.Wo;
-            gv[it] = *reinterpret_cast<const f32x4 *>(ok ? gn + gorg + c * out_dhw + (int64_t)hh * a.Wo + 4 * q : a.g);
-            gok |= (ok ? 1u : 0u) << it;
+            if (Cfg::GITEMS % T != 0 && gdst[it] < 0) continue;
+            *reinterpret_cast<f32x4 *>(base + gdst[it]) = ((gok >> it) & 1u) ? gv[it] : f32x4(0.0f);
         }
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int it = 0; it < XNIT; ++it) {
-            if (Cfg::XITEMS % T != 0 && it * T + tid >= Cfg::XITEMS) continue;
-            const bool ok = (xok >> it) & 1u;
-            const int hh = xcode[it] & 15, q = (xcode[it] >> 4) & 255, c = (xcode[it] >> 16) & 31;
-            const int dst = c * XSV + hh * IN_WV + 4 * q;
-            *reinterpret_cast<f32x4 *>(xl + dst) = ok ? xv[it] : f32x4(0.0f);
-        }
-#pragma unroll
-        for (int it = 0; it < GNIT; ++it) {
-            if (Cfg::GITEMS % T != 0 && it * T + tid >= Cfg::GITEMS) continue;
-            const bool ok = (gok >> it) & 1u;
-            const int hh = gcode[it] & 15, q = (gcode[it] >> 4) & 255, c = (gcode[it] >> 16) & 31;
-            const int dst = c * GS + hh * 32 + 4 * q;
-            *reinterpret_cast<f32x4 *>(gl + dst) = ok ? gv[it] : f32x4(0.0f);
-        }
-    };
-    int64_t tile = blockIdx.x;
-    if (tile < a.ntiles) load_tile(tile);
-    for (; tile < a.ntiles; tile += a.P) {
-        __syncthreads();   // previous tile fully consumed
-        store_tile();
-        __syncthreads();
-        if (tile + a.P < a.ntiles) load_tile(tile + a.P);   // in flight during the MFMAs below
-        // 16 K-steps of two quads (lanes 0-31: quad 2kk, lanes 32-63: quad 2kk+1); quad q = row q / 8, quad t = q % 8
-        // (q = 2kk + half: row q >> 3 = kk >> 2 and quad q & 7 = 2 (kk & 3) + half, so everything but 4 * half is an immediate)
-        const float *gq = grow + 4 * half, *xq = xrow + 4 * half;
+    unsigned tile = part;              // ntiles < 2^31 (host-checked)
+    int buf = 0;
+    if (tile < a.ntiles) {
+        load_tile(tile);
+        store_tile(lds);
+        if (tile + a.P < a.ntiles) load_tile(tile + a.P);
+    }
+    __syncthreads();
+    for (; tile < a.ntiles; tile += a.P, buf ^= 1) {
+        // 8 K-steps of two quads (lanes 0-31: quad 2kk, lanes 32-63: quad 2kk+1) over this wave's two rows; quad q = row q / 8,
+        // quad t = q % 8 (q = 2kk + half: row kk >> 2 and quad 2 (kk & 3) + half, so everything but 4 * half is an immediate)
+        const float *gq = lds + buf * Cfg::BUF_FLOATS + grow, *xq = lds + buf * Cfg::BUF_FLOATS + xrow;
         if (ph == 0) {
-#pragma unroll 4
-            for (int kk = 0; kk < Cfg::TH * 4; ++kk) {
+#pragma unroll
+            for (int kk = 0; kk < Cfg::TH * 2; ++kk) {
                 // the quad's inputs x[4t-1 .. 4t+4] are image columns 4t+3 .. 4t+8: last float of piece t, piece t+1, first of t+2
                 const f32x4 dy = *reinterpret_cast<const f32x4 *>(gq + 8 * kk);                               // r * 32 + 4 * t == 4 * q
                 const float *xp = xq + (kk >> 2) * IN_WV + 8 * (kk & 3);
@@ -543,8 +574,8 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(s02 - s13, e - f, acc[2], 0, 0, 0);
             }
         } else {
-#pragma unroll 4
-            for (int kk = 0; kk < Cfg::TH * 4; ++kk) {
+#pragma unroll
+            for (int kk = 0; kk < Cfg::TH * 2; ++kk) {
                 const f32x4 dy = *reinterpret_cast<const f32x4 *>(gq + 8 * kk);
                 const float *xp = xq + (kk >> 2) * IN_WV + 8 * (kk & 3);
                 const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xp + 4), x2 = *reinterpret_cast<const f32x4 *>(xp + 8);
@@ -558,9 +589,15 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy3, v5, acc[2], 0, 0, 0);
             }
         }
+        // the other buffer was last read before the previous barrier: refill it, then start the loads of the tile after
+        if (tile + a.P < a.ntiles) {
+            store_tile(lds + (buf ^ 1) * Cfg::BUF_FLOATS);
+            if (tile + 2 * a.P < a.ntiles) load_tile(tile + 2 * a.P);
+        }
+        __syncthreads();
     }
-    // ---- partial slab [partition][pair][kd][kh][pos][cg 32][cx 32]
-    float *pp = a.partial + (((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * 3 + kd) * (int64_t)Cfg::SLABS * 1024 +
+    // ---- partial slab [partition * 2 + row half][pair][kd][kh][pos][cg 32][cx 32]
+    float *pp = a.partial + ((((int64_t)part * 2 + kq) * a.pairs + pair) * 3 + kd) * (int64_t)Cfg::SLABS * 1024 +
                 (int64_t)(kh * 6 + ph * 3) * 1024;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -705,20 +742,29 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
         }
     }
     const int key = d->ksize * 100 + d->stride * 10 + d->dilation;
-    if (key == 311 && a.vec == 4 && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
+    const int64_t wino_tiles = (int64_t)d->N * d->Dout * ceil_div(d->Hout, WinoWgradCfg::TH) * a.tiles_w;   // 32-bit tile counter
+    if (key == 311 && a.vec == 4 && wino_tiles < ((int64_t)1 << 30) && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
         // Winograd-domain form (see conv3d_wgrad_wino_kernel): half the MFMAs of the direct form
         a.tiles_h = ceil_div(d->Hout, WinoWgradCfg::TH);
         a.ntiles = (int64_t)d->N * d->Dout * a.tiles_h * a.tiles_w;
-        a.P = device_cu_count() * 2 / 3 > kWgradPartitions ? kWgradPartitions : device_cu_count() * 2 / 3;   // x 3 depth slices = 2 per CU
+        // one 12-wave workgroup per CU, one round: upx (pair, partition) units x 3 depth slices on each of the 8 XCDs
+        a.upx = device_cu_count() / 8 / 3;
+        if (a.upx < 1) a.upx = 1;
+        a.P = 8 * a.upx / pairs;
+        if (a.P < 1) a.P = 1;       // more pairs than units: the units take several rounds
+        if (a.P > kWgradPartitions / 2) a.P = kWgradPartitions / 2;
+        a.pairs = pairs;
+        if (a.P * pairs > 8 * a.upx) a.upx = ceil_div(a.P * pairs, 8);
+        const unsigned nwg = (unsigned)(8 * a.upx * 3);
         static std::atomic<unsigned> attr_done{0};
         constexpr int bytes = WinoWgradCfg::LDS_FLOATS * 4;
         if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_wino_kernel), bytes, attr_done))
-            conv3d_wgrad_wino_kernel<<<dim3((unsigned)a.P, (unsigned)pairs, 3), WinoWgradCfg::THREADS, bytes, st>>>(a);
+            conv3d_wgrad_wino_kernel<<<dim3(nwg), WinoWgradCfg::THREADS, bytes, st>>>(a);
         int rcw = check_launch("snvc_conv3d_wgrad(winograd)");
         if (rcw) return rcw;
         const int64_t total = (int64_t)pairs * 9 * 1024;
         wgrad_wino_reduce_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>((const float *)workspace, dw, d->Cout,
-                                                                                                 d->Cin, a.cx_blocks, pairs, a.P);
+                                                                                                 d->Cin, a.cx_blocks, pairs, 2 * a.P);
         return check_launch("snvc_conv3d_wgrad(winograd reduce)");
     }
 #define SNVC_WGRAD_CASE(CFG)                                                                  \
