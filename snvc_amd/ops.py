@@ -10,7 +10,6 @@ PyTorch is plumbing here: it owns device memory and the HIP stream.  Every funct
 import contextlib
 import ctypes
 import math
-import threading
 from typing import Optional, Tuple
 
 import torch
@@ -29,25 +28,26 @@ __all__ = [
 ]
 
 
-_variant = threading.local()
+_variant_bits = 0
 
 
 @contextlib.contextmanager
 def conv_variant(algo_bits: int):
-    """Within the block every conv3d / wgrad launch of this thread carries ``algo_bits`` in
+    """Within the block every conv3d / wgrad launch of this PROCESS carries ``algo_bits`` in
     ``snvc_conv3d_desc.algo`` (the SNVC_ALGO_* kernel-form selectors of include/snvc_hip.h):
-    how the parity tests and the tuning scripts reach every instantiated kernel form."""
-    prev = getattr(_variant, "bits", 0)
-    _variant.bits = int(algo_bits)
+    how the parity tests and the tuning scripts reach every instantiated kernel form.  Process-wide, not per thread:
+    autograd runs ``backward`` on its own worker thread, and a ``loss.backward()`` inside the block must see the bits."""
+    global _variant_bits
+    prev = _variant_bits
+    _variant_bits = int(algo_bits)
     try:
         yield
     finally:
-        _variant.bits = prev
+        _variant_bits = prev
 
 
 def _algo(exact: bool = False) -> int:
-    bits = getattr(_variant, "bits", 0)
-    return (bits | _lib.ALGO_DIRECT) if exact else bits
+    return (_variant_bits | _lib.ALGO_DIRECT) if exact else _variant_bits
 
 
 def _gpu(t: torch.Tensor, name: str):

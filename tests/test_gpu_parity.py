@@ -561,6 +561,40 @@ def _grads(module, inputs, loss_fn):
                                                       for k, v in module.named_parameters()}
 
 
+_WGRAD_CASES = {
+    # name: (N, Cin, Cout, (D, H, W) of the input, ksize, stride)
+    "k3 many tiles": (1, 32, 32, (10, 40, 96), 3, 1),         # 300 Winograd tiles over 80 partitions: first / steady / last tile of a partition
+    "k3 ragged": (2, 40, 24, (5, 10, 44), 3, 1),              # border tiles in H and W, channel blocks of 8 and 24, two samples
+    "k3 one tile": (1, 32, 64, (2, 4, 32), 3, 1),             # partitions without any tile
+    "k3 rows of 8 bytes": (1, 32, 32, (4, 6, 38), 3, 1),      # W % 4 != 0: the direct form with float2 pieces
+    "k3 odd width": (1, 32, 32, (3, 6, 37), 3, 1),            # scalar staging
+    "k3s2": (2, 32, 64, (6, 12, 40), 3, 2),
+    "k1": (1, 40, 32, (3, 5, 36), 1, 1),
+    "k1 to one channel": (2, 32, 1, (4, 6, 40), 1, 1),
+}
+
+
+@pytest.mark.parametrize("variant", ["auto", "direct"])
+@pytest.mark.parametrize("case", sorted(_WGRAD_CASES))
+def test_conv3d_wgrad_vs_float64(case, variant):
+    """snvc_conv3d_wgrad against the float64 weight gradient of F.conv3d on the CPU: the Winograd-domain form (auto, on
+    16-byte rows) and the direct form, on shapes that give a partition several tiles, none, and border tiles."""
+    import torch.nn.functional as F
+    from snvc_amd import _lib, ops
+    N, cin, cout, shp, k, st = _WGRAD_CASES[case]
+    r = np.random.default_rng(300 + sorted(_WGRAD_CASES).index(case))
+    x = torch.from_numpy(r.standard_normal((N, cin) + shp).astype(np.float32))
+    w = torch.zeros(cout, cin, k, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x.double(), w, stride=st, padding=k // 2)
+    g = torch.from_numpy(r.standard_normal(tuple(y.shape)).astype(np.float32))
+    (y * g.double()).sum().backward()
+    with ops.conv_variant(0 if variant == "auto" else _lib.ALGO_DIRECT):
+        dw = ops.conv3d_wgrad(x.to(dev()), g.to(dev()), k, st, k // 2, 1)
+        dw2 = ops.conv3d_wgrad(x.to(dev()), g.to(dev()), k, st, k // 2, 1)
+    assert torch.equal(dw, dw2), "the weight gradient is deterministic"
+    check(dw.cpu().numpy(), w.grad.float().numpy(), 2e-5 if variant == "auto" else 5e-6, f"wgrad {case} ({variant})")
+
+
 @pytest.mark.parametrize("case", ["k3_bn_train", "k3_bn_eval", "k3s2_bn_train", "deconv_bn_train", "k3_gn", "k1_plain"])
 def test_layer_backward_vs_torch_autograd(case):
     """fwd+bwd of one fused layer (conv/deconv + norm + residual + ReLU) against torch autograd on
