@@ -1140,6 +1140,31 @@ conv3d_wino_kernel(const ConvArgs a) {
 // flight), so chunk c+1 lands while chunk c is multiplied and is visible after the chunk's barrier.
 __device__ const float g_zero16[4] __attribute__((aligned(16))) = {0.0f, 0.0f, 0.0f, 0.0f};
 
+// LDS-DMA of one chunk of conv3d_wino_dma_kernel (weights -> wbuf, input rows -> ibuf) from the per-thread source
+// pointers xsrc[St::NIT] / wsrc[WNIT], which then advance to the next chunk; cin_left = channels from this chunk's first
+// one to the layer's last (an odd Cin leaves the last chunk half empty: those pieces read the zero constant).
+template <class Cfg>
+__device__ __forceinline__ void wino_dma_issue(const float **xsrc, const float **wsrc, unsigned vmask, int64_t xstep, int cin_left,
+                                               float *ibuf, float *wbuf, int tid) {
+    using St = typename Cfg::St;
+    constexpr int WITEMS = Cfg::WF / 4, WNIT = (WITEMS + 255) / 256;
+    const int wbase = tid & ~63;           // first item of this wave in a 256-item round
+#pragma unroll
+    for (int it = 0; it < WNIT; ++it) {
+        if (WITEMS % 256 == 0 || it * 256 + tid < WITEMS)
+            __builtin_amdgcn_global_load_lds(wsrc[it], wbuf + 4 * (it * 256 + wbase), 16, 0, 0);
+        wsrc[it] += Cfg::WF;
+    }
+#pragma unroll
+    for (int it = 0; it < St::NIT; ++it) {
+        const float *src = xsrc[it];
+        if (cin_left < Cfg::KC && (it * 256 + tid) / (St::RQ * Cfg::IN_D * Cfg::IN_H) >= cin_left) src = g_zero16;
+        if (St::ITEMS % 256 == 0 || it * 256 + tid < St::ITEMS)
+            __builtin_amdgcn_global_load_lds(src, ibuf + 4 * (it * 256 + wbase), 16, 0, 0);
+        if ((vmask >> it) & 1u) xsrc[it] += xstep;
+    }
+}
+
 template <class Cfg, bool RES, bool PLANE>
 __global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_wino_dma_kernel(const ConvArgs a) {
@@ -1169,27 +1194,17 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
     St st;
     st.init(tid, job.od0 - 1, job.oh0 - 1, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
     constexpr int WITEMS = WF / 4, WNIT = (WITEMS + 255) / 256;
-    const int wbase = tid & ~63;           // first item of this wave in a 256-item round
-    auto issue = [&](int chunk, int b) {
-        const float *xc = xn + (int64_t)chunk * KC * in_dhw;
-        const float *wc = wg + (int64_t)chunk * WF;
-        const unsigned m = st.store_mask(tid, a.Cin - chunk * KC);
-        float *const ibuf = lds + b * TILE, *const wbuf = wlds + b * WF;
+    // Per-thread DMA sources live in registers for the whole job and advance by one chunk per issue (chunks are issued in
+    // order): beside fp32 MFMAs a VALU instruction costs ~7 cycles of matrix-pipe time
+    // (profiles/r2/mfma_f32_issue_microbench.txt), and recomputing seven 64-bit addresses with their zero-fill selects
+    // was ~35 of them per chunk.  Padding pieces keep pointing at the zero constant.
+    const float *xsrc[St::NIT], *wsrc[WNIT];
 #pragma unroll
-        for (int it = 0; it < WNIT; ++it) {
-            const int i = it * 256 + tid;
-            if (WITEMS % 256 == 0 || i < WITEMS)
-                __builtin_amdgcn_global_load_lds(wc + 4 * i, wbuf + 4 * (it * 256 + wbase), 16, 0, 0);
-        }
+    for (int it = 0; it < St::NIT; ++it) xsrc[it] = ((st.vmask >> it) & 1u) ? xn + st.off[it] : g_zero16;
 #pragma unroll
-        for (int it = 0; it < St::NIT; ++it) {
-            const int i = it * 256 + tid;
-            const float *src = ((m >> it) & 1u) ? xc + st.off[it] : g_zero16;
-            if (St::ITEMS % 256 == 0 || i < St::ITEMS)
-                __builtin_amdgcn_global_load_lds(src, ibuf + 4 * (it * 256 + wbase), 16, 0, 0);
-        }
-    };
-    issue(0, 0);
+    for (int it = 0; it < WNIT; ++it) wsrc[it] = wg + 4 * (it * 256 + tid);
+    const int64_t xstep = (int64_t)KC * in_dhw;
+    wino_dma_issue<Cfg>(xsrc, wsrc, st.vmask, xstep, a.Cin, lds, wlds, tid);
     if (tid < 64) {
         float v = tid < 32 ? 1.0f : 0.0f;
         if (a.scale) v = (tid < 32 ? a.scale : a.bias)[job.cg * 32 + (tid & 31)];   // Cout % 32 == 0 (host)
@@ -1197,7 +1212,9 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
     }
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        if (chunk + 1 < nchunks) issue(chunk + 1, (chunk + 1) & 1);
+        if (chunk + 1 < nchunks)
+            wino_dma_issue<Cfg>(xsrc, wsrc, st.vmask, xstep, a.Cin - (chunk + 1) * KC, lds + ((chunk + 1) & 1) * TILE,
+                                wlds + ((chunk + 1) & 1) * WF, tid);
         wino_compute_chunk<Cfg>(lds + (chunk & 1) * TILE, wlds + (chunk & 1) * WF + lane, bbase, wave, acc, [](int) {});
         __syncthreads();
     }
