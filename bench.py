@@ -519,15 +519,19 @@ def main():
                 except Exception as e:  # an extra must never take the headline down with it
                     cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
             cfgs["cfg4_train_step"] = {k: tr[k] for k in ("ms_per_step", "fwd_ms", "bwd_ms", "step_tflops_algorithmic")}
-            try:        # its dominant kernel: the weight gradient of the first convolution (direct form: executed == algorithmic)
-                from snvc_amd import ops
-                xg = torch.randn(1, 2 * C, D, H, W, device=device)
+            try:        # its dominant launch: the Winograd-domain weight gradient of a 32->32 layer on the full grid
+                from snvc_amd import ops                     # (conv1's right half, conv2, the classifier: 3 per step)
+                xg = torch.randn(1, C, D, H, W, device=device)
                 gg = torch.randn(1, C, D, H, W, device=device)
                 ms_w, _ = timed_ms(lambda: ops.conv3d_wgrad(xg, gg, 3, 1, 1, 1), 3)
+                flop = CONV1_FLOP / 2                          # 32 of conv1's 64 input channels
                 cfgs["cfg4_train_step"].update({
-                    "dominant_kernel": "conv3d_wgrad_kernel<k3,s1> 64->32 on 192x96x312 (deterministic MFMA weight gradient + partition reduce)",
-                    "dominant_ms": ms_w, "dominant_gflop_algorithmic": CONV1_FLOP / 1e9,
-                    "dominant_pipe_frac": CONV1_FLOP / (ms_w * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS})
+                    "dominant_kernel": "conv3d_wgrad_wino_kernel 32->32 on 192x96x312 (Winograd-domain weight gradient, fp32 MFMA, "
+                                       "deterministic) + wgrad_wino_reduce_kernel",
+                    "dominant_ms": ms_w, "dominant_gflop_algorithmic": flop / 1e9,
+                    "dominant_tflops_algorithmic": flop / (ms_w * 1e-3) / 1e12,
+                    # executed on the matrix pipe: 6 of 12 multiply-adds, on 32-wide tiles (W = 312 -> 320)
+                    "dominant_pipe_frac": wino_executed_share(3, W) * flop / (ms_w * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS})
                 del xg, gg
             except Exception as e:
                 cfgs["cfg4_train_step"]["dominant_error"] = f"{type(e).__name__}: {e}"
