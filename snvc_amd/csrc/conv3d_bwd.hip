@@ -449,7 +449,7 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
     const int slot = blockIdx.x >> 3;
     const int kd = slot % 3, unit = (blockIdx.x & 7) * a.upx + slot / 3;
     if (unit >= a.pairs * a.P) return;
-    const int pair = unit / a.P, part = unit - pair * a.P;
+    const int part = unit / a.pairs, pair = unit - part * a.pairs;    // pairs of one partition share tiles: same XCD
     const int cgb = pair / a.cx_blocks, cxb = pair - cgb * a.cx_blocks;
     const int cg0 = cgb * 32, cx0 = cxb * 32;
 
@@ -605,6 +605,180 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;            // cg
             pp[(p * 32 + row) * 32 + ch] = acc[p][r];
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3x3 / stride-2 / pad-1 layers (and, with roles swapped, of the transposed layers) in the
+// 12-wave form of conv3d_wgrad_wino_kernel: a workgroup owns one kernel depth slice kd of one (cout block, cin block)
+// pair and a spatial partition, tiles of 2 output rows x 32 output columns double-buffered in LDS (input rows
+// 2*oh0-1 .. +4, columns 2*ow0-4 .. +63 as 17 aligned 16-byte pieces; channel strides 4 * odd floats).
+// wave = (kh, quarter of the tile's 16 output quads); a lane reads ITS channel's dy quad (one b128: 4 voxels) and the 12
+// input floats under it (three b128: columns 8t .. 8t+11 of row 2r+kh, of which 8t+3 .. 8t+11 are used) and issues the
+// 12 MFMAs (4 voxels x kw = 0,1,2) with no arithmetic in between: the direct tap-split kernel this replaces ran at
+// 26 % of the matrix pipe on these layers (one output row per tile, scalar LDS reads, 6 % of the cfg4 step each).
+// Partial slabs [4 P][pair][27 taps][32][32] in the layout of the direct kernel: summed by wgrad_reduce_kernel in a
+// fixed order (deterministic).  GP = floats per staged dy piece (4, or 2 for rows that are only 8-byte aligned: W = 78).
+struct S2WgradCfg {
+    static constexpr int TH = 2, THREADS = 768;
+    static constexpr int IN_H = 2 * TH + 1, IN_WV = 68, RQ = IN_WV / 4;       // 5 rows of 17 pieces
+    static constexpr int XSV = IN_H * IN_WV;                                  // 340 = 4 * 85
+    static constexpr int GS = TH * 32 + 4;                                    // 68 = 4 * 17
+    static_assert((XSV / 4) % 2 == 1 && (GS / 4) % 2 == 1 && XSV % 4 == 0, "channel stride = 4 * odd");
+    static constexpr int XITEMS = 32 * IN_H * RQ, XNIT = (XITEMS + THREADS - 1) / THREADS;
+    static constexpr int BUF_FLOATS = 32 * XSV + 32 * GS, LDS_FLOATS = 2 * BUF_FLOATS;     // 2 x 51 KB
+};
+
+template <int GP>
+__global__ void __launch_bounds__(768, 1)
+conv3d_wgrad_s2_kernel(const WgradArgs a) {
+    using Cfg = S2WgradCfg;
+    constexpr int IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, XSV = Cfg::XSV, GS = Cfg::GS, RQ = Cfg::RQ, T = Cfg::THREADS;
+    constexpr int XNIT = Cfg::XNIT, GQ = 32 / GP, GITEMS = 32 * Cfg::TH * GQ, GNIT = (GITEMS + T - 1) / T;
+    typedef float GVec __attribute__((ext_vector_type(GP)));
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kq = wave / 3, kh = wave - 3 * kq;        // this wave: kernel row kh, quads 4 kq .. 4 kq + 3 of the tile
+    const int slot = blockIdx.x >> 3;                   // XCD-grouped units as in conv3d_wgrad_wino_kernel
+    const int kd = slot % 3, unit = (blockIdx.x & 7) * a.upx + slot / 3;
+    if (unit >= a.pairs * a.P) return;
+    const int part = unit / a.pairs, pair = unit - part * a.pairs;    // pairs of one partition share tiles: same XCD
+    const int cgb = pair / a.cx_blocks, cxb = pair - cgb * a.cx_blocks;
+    const int cg0 = cgb * 32, cx0 = cxb * 32;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+
+    const int64_t in_hw = (int64_t)a.Hi * a.Wi, in_dhw = in_hw * a.Di;
+    const int64_t out_hw = (int64_t)a.Ho * a.Wo, out_dhw = out_hw * a.Do;
+    const int ch = lane & 31, half = lane >> 5;
+    // group j (0, 1) of this wave: output row r = kq >> 1, quad t = 4 (kq & 1) + 2 j + half
+    const int r = kq >> 1, t0 = 4 * (kq & 1) + half;
+    const int xrow = ch * XSV + (2 * r + kh) * IN_WV + 8 * t0, grow = 32 * XSV + ch * GS + r * 32 + 4 * t0;
+
+    unsigned xoff[XNIT], goff[GNIT];
+    int xdst[XNIT], gdst[GNIT], xcode[XNIT], gcode[GNIT];
+    unsigned xstat = 0, gstat = 0;
+#pragma unroll
+    for (int it = 0; it < XNIT; ++it) {
+        const int i = it * T + tid;
+        const int c = i / (IN_H * RQ), rr = i - c * (IN_H * RQ);
+        const int hh = rr / RQ, q = rr - hh * RQ;
+        const bool ex = i < Cfg::XITEMS && cx0 + c < a.Cx;
+        xstat |= (ex ? 1u : 0u) << it;
+        xcode[it] = hh | (q << 4);
+        xoff[it] = ex ? (unsigned)(c * in_dhw + (int64_t)hh * a.Wi + 4 * q) : 0u;
+        xdst[it] = i < Cfg::XITEMS ? c * XSV + hh * IN_WV + 4 * q : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < GNIT; ++it) {
+        const int i = it * T + tid;
+        const int c = i / (Cfg::TH * GQ), rr = i - c * (Cfg::TH * GQ);
+        const int hh = rr / GQ, q = rr - hh * GQ;
+        const bool ex = i < GITEMS && cg0 + c < a.Cg;
+        gstat |= (ex ? 1u : 0u) << it;
+        gcode[it] = hh | (q << 4);
+        goff[it] = ex ? (unsigned)(c * out_dhw + (int64_t)hh * a.Wo + GP * q) : 0u;
+        gdst[it] = i < GITEMS ? 32 * XSV + c * GS + hh * 32 + GP * q : -1;
+    }
+    f32x4 xv[XNIT];
+    GVec gv[GNIT];
+    unsigned xok = 0, gok = 0;
+    const unsigned tiles_dw = (unsigned)a.Do * a.tiles_w, tiles_dwh = tiles_dw * a.tiles_h;
+    auto load_tile = [&](unsigned tile) {
+        const unsigned n = tile / tiles_dwh, r0 = tile - n * tiles_dwh;           // depth fastest
+        const unsigned th = r0 / tiles_dw, r1 = r0 - th * tiles_dw;
+        const int tw = (int)(r1 / (unsigned)a.Do), od = (int)(r1 - tw * (unsigned)a.Do);
+        const int oh0 = th * Cfg::TH, ow0 = tw * 32;
+        const int id = 2 * od - 1 + kd, ih0 = 2 * oh0 - 1, ix0 = 2 * ow0 - 4;
+        const float *gb = a.g + n * a.g_bs + (int64_t)cg0 * out_dhw + (int64_t)od * out_hw + (int64_t)oh0 * a.Wo + ow0;
+        const bool d_ok = (unsigned)id < (unsigned)a.Di;
+        // the X origin may lie before the tensor on border tiles: it is only dereferenced through items that passed their tests
+        const float *xb = a.x + n * a.x_bs + (int64_t)cx0 * in_dhw + (int64_t)id * in_hw + (int64_t)ih0 * a.Wi + ix0;
+        const bool interior = d_ok && ih0 >= 0 && ih0 + IN_H <= a.Hi && ix0 >= 0 && ix0 + IN_WV <= a.Wi &&
+                              oh0 + Cfg::TH <= a.Ho && ow0 + 32 <= a.Wo;
+        if (interior) {
+            xok = xstat; gok = gstat;
+#pragma unroll
+            for (int it = 0; it < XNIT; ++it) xv[it] = *reinterpret_cast<const f32x4 *>(xb + xoff[it]);
+#pragma unroll
+            for (int it = 0; it < GNIT; ++it) gv[it] = *reinterpret_cast<const GVec *>(gb + goff[it]);
+        } else {
+            xok = 0; gok = 0;
+#pragma unroll
+            for (int it = 0; it < XNIT; ++it) {
+                const int hh = xcode[it] & 15, q = xcode[it] >> 4;
+                const bool ok = ((xstat >> it) & 1u) && d_ok && (unsigned)(ih0 + hh) < (unsigned)a.Hi &&
+                                (unsigned)(ix0 + 4 * q) < (unsigned)a.Wi;
+                xv[it] = *reinterpret_cast<const f32x4 *>(ok ? xb + xoff[it] : a.x);
+                xok |= (ok ? 1u : 0u) << it;
+            }
+#pragma unroll
+            for (int it = 0; it < GNIT; ++it) {
+                const int hh = gcode[it] & 15, q = gcode[it] >> 4;
+                const bool ok = ((gstat >> it) & 1u) && oh0 + hh < a.Ho && ow0 + GP * q < a.Wo;
+                gv[it] = *reinterpret_cast<const GVec *>(ok ? gb + goff[it] : a.g);
+                gok |= (ok ? 1u : 0u) << it;
+            }
+        }
+    };
+    auto store_tile = [&](float *base) {
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it) {
+            if (Cfg::XITEMS % T != 0 && xdst[it] < 0) continue;
+            *reinterpret_cast<f32x4 *>(base + xdst[it]) = ((xok >> it) & 1u) ? xv[it] : f32x4(0.0f);
+        }
+#pragma unroll
+        for (int it = 0; it < GNIT; ++it) {
+            if (GITEMS % T != 0 && gdst[it] < 0) continue;
+            *reinterpret_cast<GVec *>(base + gdst[it]) = ((gok >> it) & 1u) ? gv[it] : GVec(0.0f);
+        }
+    };
+    auto compute = [&](int buf) {
+        const float *gq = lds + buf * Cfg::BUF_FLOATS + grow, *xq = lds + buf * Cfg::BUF_FLOATS + xrow;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 dy = *reinterpret_cast<const f32x4 *>(gq + 8 * j);        // quads t0 + 2 j: 4 (t0 + 2 j) floats into the row
+            const float *xp = xq + 16 * j;                                        // 8 columns per quad
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xp), x1 = *reinterpret_cast<const f32x4 *>(xp + 4),
+                        x2 = *reinterpret_cast<const f32x4 *>(xp + 8);
+            // output ow = 4t + i reads input columns 8t + 2i + kw + 3 of the staged row (ix0 = 2 ow0 - 4, pad 1)
+            const float f[12] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], x2[0], x2[1], x2[2], x2[3]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy[i], f[2 * i + kw + 3], acc[kw], 0, 0, 0);
+        }
+    };
+    unsigned tile = part;              // ntiles < 2^30 (host-checked)
+    int buf = 0;
+    if (tile < a.ntiles) {
+        load_tile(tile);
+        store_tile(lds);
+        if (tile + a.P < a.ntiles) load_tile(tile + a.P);
+    }
+    __syncthreads();
+    for (; tile < a.ntiles; tile += a.P, buf ^= 1) {
+        compute(buf);
+        // the other buffer was last read before the previous barrier: refill it, then start the loads of the tile after
+        if (tile + a.P < a.ntiles) {
+            store_tile(lds + (buf ^ 1) * Cfg::BUF_FLOATS);
+            if (tile + 2 * a.P < a.ntiles) load_tile(tile + 2 * a.P);
+        }
+        __syncthreads();
+    }
+    // ---- partial slab [partition * 4 + kq][pair][tap (kd, kh, kw)][cg 32][cx 32]
+    float *pp = a.partial + ((((int64_t)part * 4 + kq) * a.pairs + pair) * 27 + (kd * 3 + kh) * 3) * 1024;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int row = (rr & 3) + 8 * (rr >> 2) + 4 * half;          // cg
+            pp[(kw * 32 + row) * 32 + ch] = acc[kw][rr];
         }
 }
 
@@ -766,6 +940,36 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
         wgrad_wino_reduce_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>((const float *)workspace, dw, d->Cout,
                                                                                                  d->Cin, a.cx_blocks, pairs, 2 * a.P);
         return check_launch("snvc_conv3d_wgrad(winograd reduce)");
+    }
+    const int64_t s2_tiles = (int64_t)d->N * d->Dout * ceil_div(d->Hout, S2WgradCfg::TH) * a.tiles_w;
+    if (key == 321 && (a.vec == 4 || a.vec == 2) && s2_tiles < ((int64_t)1 << 30) &&
+        (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
+        // 12-wave form (see conv3d_wgrad_s2_kernel); SNVC_ALGO_DIRECT keeps the tap-split kernel below
+        a.tiles_h = ceil_div(d->Hout, S2WgradCfg::TH);
+        a.ntiles = s2_tiles;
+        a.upx = device_cu_count() / 8 / 3;
+        if (a.upx < 1) a.upx = 1;
+        a.P = 8 * a.upx / pairs;
+        if (a.P < 1) a.P = 1;
+        if (a.P > kWgradPartitions / 4) a.P = kWgradPartitions / 4;
+        a.pairs = pairs;
+        if (a.P * pairs > 8 * a.upx) a.upx = ceil_div(a.P * pairs, 8);
+        const unsigned nwg = (unsigned)(8 * a.upx * 3);
+        constexpr int bytes = S2WgradCfg::LDS_FLOATS * 4;
+        static std::atomic<unsigned> attr4{0}, attr2{0};
+        if (a.vec == 4) {
+            if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_s2_kernel<4>), bytes, attr4))
+                conv3d_wgrad_s2_kernel<4><<<dim3(nwg), S2WgradCfg::THREADS, bytes, st>>>(a);
+        } else {
+            if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_s2_kernel<2>), bytes, attr2))
+                conv3d_wgrad_s2_kernel<2><<<dim3(nwg), S2WgradCfg::THREADS, bytes, st>>>(a);
+        }
+        int rcs = check_launch("snvc_conv3d_wgrad(stride 2)");
+        if (rcs) return rcs;
+        const int64_t total = (int64_t)pairs * 27 * 1024;
+        wgrad_reduce_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>((const float *)workspace, dw, d->Cout, d->Cin, 27,
+                                                                                            27, a.cx_blocks, pairs, 4 * a.P);
+        return check_launch("snvc_conv3d_wgrad(stride 2 reduce)");
     }
 #define SNVC_WGRAD_CASE(CFG)                                                                  \
     {                                                                                         \

@@ -569,6 +569,9 @@ _WGRAD_CASES = {
     "k3 rows of 8 bytes": (1, 32, 32, (4, 6, 38), 3, 1),      # W % 4 != 0: the direct form with float2 pieces
     "k3 odd width": (1, 32, 32, (3, 6, 37), 3, 1),            # scalar staging
     "k3s2": (2, 32, 64, (6, 12, 40), 3, 2),
+    "k3s2 many tiles": (1, 32, 32, (12, 40, 160), 3, 2),      # 180 tiles over 80 partitions, interior and border tiles
+    "k3s2 rows of 8 bytes": (1, 32, 64, (4, 12, 76), 3, 2),   # output rows of 38 floats: 8-byte dy pieces
+    "k3s2 odd extents": (1, 40, 24, (5, 9, 44), 3, 2),        # odd input depth / height, partial channel blocks
     "k1": (1, 40, 32, (3, 5, 36), 1, 1),
     "k1 to one channel": (2, 32, 1, (4, 6, 40), 1, 1),
 }
