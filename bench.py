@@ -199,6 +199,11 @@ def local_config(name, grid, F, crops, device, reps=3, heads=False, precision="f
         if heads:
             ms_h, _ = timed_ms(lambda: m.heads_2d(res[0]), reps)
             out["heads_2d_ms_per_crop"] = ms_h / crops
+            # everything after the backbone (gather + trunk + 2D neck + heads) through VernierScale.forward
+            del res
+            m.precision = precision
+            ms_e, _ = timed_ms(lambda: m(lf, rf, pl, pr), reps)
+            out["forward_ms_per_crop"] = ms_e / crops
     if f16:     # direct form: every algorithmic multiply-add is executed (+ the 50th tap of the 25 tap pairs per slice)
         kernel = f"conv3d_f16_kernel<k7> {2 * F}->{F} (direct, v_mfma_f32_32x32x16_f16, C8 half storage)"
         frac = conv1_flop / (ms_c1 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
@@ -512,6 +517,7 @@ def main():
             cfgs = {}
             for name, grid, F, crops, heads, prec in (("cfg3_crops_96", (96, 96, 96), 32, 2, False, "f32"),
                                                       ("released_32x128x192", (32, 128, 192), 32, 2, True, "f32"),
+                                                      ("released_32x128x192_f16", (32, 128, 192), 32, 2, True, "f16"),
                                                       ("cfg5_highres_80x160x160", (80, 160, 160), 64, 1, False, "f16"),
                                                       ("cfg5_highres_80x160x160_f32", (80, 160, 160), 64, 1, False, "f32")):
                 try:

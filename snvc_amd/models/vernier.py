@@ -230,7 +230,12 @@ class VernierScale(nn.Module):
             heatmap_feats = self.hm1(voxel_BEV).permute(0, 1, 3, 2)
         heatmaps = fused_conv2d(self.hm2, None, heatmap_feats.contiguous()) if hip else self.hm2(heatmap_feats)
         num_sample = len(heatmaps)
-        coor_maps = self.coor_maps.repeat(num_sample, 1, 1, 1).to(heatmaps.device)
+        # the coordinate maps are a plain attribute in the reference (not in the state dict): one device copy is kept,
+        # so that no host -> device copy sits in the middle of the neck (and of a captured graph)
+        cm = getattr(self, "_coor_maps_dev", None)
+        if cm is None or cm.device != heatmaps.device:
+            cm = self._coor_maps_dev = self.coor_maps.to(heatmaps.device)
+        coor_maps = cm.repeat(num_sample, 1, 1, 1)
         augmented_maps = torch.cat([heatmaps, coor_maps], dim=1)
         last = self.coord_head[-2]
         if hip and tuple(last.kernel_size) != (1, 1):

@@ -254,3 +254,33 @@ def test_f16_cfg5_full_size():
         e_occ = (occ16 - occ32).abs().max().item()
         print(f"cfg5 fp16 vs fp32: bev max|err|/rms = {e_bev:.2e}, occupancy max|err| = {e_occ:.2e}")
         assert e_bev <= 3e-2 and e_occ <= 1e-2
+
+
+def test_f16_released_shape_full_size_forward():
+    """The released local model's grid (32,128,192), F = 32, through VernierScale.forward in the fp16-storage mode
+    (gather -> 3D trunk in C8 half -> fp32 BEV neck + heads) against the fp32 mode of the same model on the same inputs."""
+    import types
+    import bench
+    from snvc_amd.models.vernier import VernierScale
+    grid = (32, 128, 192)
+    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False, grid_resolution=[32, 128, 192],
+                                resolution=(256, 256), x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
+    cfg.hrfeat = types.SimpleNamespace(output_channel=32, name="identity")
+    cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
+    m = VernierScale(cfg)
+    m.load_state_dict(bench.seeded_state(m, 5))
+    m.eval().to(dev())
+    g = np.random.default_rng(29)
+    lf = torch.from_numpy(g.standard_normal((2, 32, 64, 64)).astype(np.float32)).to(dev())
+    rf = torch.from_numpy(g.standard_normal((2, 32, 64, 64)).astype(np.float32)).to(dev())
+    pl, pr = bench.projected_coordinates(2, grid, dev())
+    with torch.no_grad():
+        ref = m(lf, rf, pl, pr)
+        m.precision = "f16"
+        out = m(lf, rf, pl, pr)
+    assert set(out) == set(ref) == {"ncf", "occupancy", "coordinates"}
+    for k, tol in (("occupancy", 1e-2), ("ncf", 3e-2), ("coordinates", 1e-2)):
+        assert out[k].shape == ref[k].shape and torch.isfinite(out[k]).all(), k
+        e = (out[k] - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-30)
+        print(f"released shape, fp16-storage vs fp32 forward, {k}: max|err|/max = {e:.2e}")
+        assert e <= tol, (k, e)
