@@ -1,0 +1,54 @@
+"""A cost volume that is built when somebody looks at it.
+
+The reference's call sequence is ``volume = build_cost_volume(left, right, shift, 1); cost = model(volume)``.  The left
+half of that CONCAT volume repeats the left feature on every disparity plane, and the first 3D convolution is the only
+consumer: ``GlobalStack.forward`` does not need the 1.48 GB tensor at all (models/stereo_volume.py::forward_pair builds
+only the warped right half and folds the left half into three depth-class planes -- DESIGN 4.1b).  ``LazyCostVolume`` lets
+the reference's own operator API reach that path: ``build_cost_volume`` returns it under ``torch.no_grad()``; it has the
+volume's shape / dtype / device, ``GlobalStack.forward`` takes it apart again, and ANY other use -- an aten operator, a
+kernel of this library asking for ``data_ptr()``, printing -- builds the real volume first (once) and carries on with
+that: the observable values are those of the eager volume, bit for bit.
+"""
+import torch
+from torch.utils._pytree import tree_map
+
+
+class LazyCostVolume(torch.Tensor):
+    @staticmethod
+    def __new__(cls, left, right, shift, downsample, build):
+        n, c, h, w = left.shape
+        shape = (n, 2 * c, shift.shape[1], h // downsample, w // downsample)
+        r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=left.dtype, device=left.device, requires_grad=False)
+        r._sources = (left, right, shift, downsample)
+        r._build = build
+        r._real = None
+        return r
+
+    # ---- what GlobalStack.forward uses
+    @property
+    def is_materialized(self):
+        return self._real is not None
+
+    @property
+    def sources(self):
+        """(left, right, shift, downsample) as given to build_cost_volume."""
+        return self._sources
+
+    def materialize(self) -> torch.Tensor:
+        if self._real is None:
+            left, right, shift, ds = self._sources
+            self._real = self._build(left, right, shift, ds)
+        return self._real
+
+    # ---- everything else sees the real tensor
+    def data_ptr(self):
+        return self.materialize().data_ptr()
+
+    def __repr__(self):
+        return f"LazyCostVolume(shape={tuple(self.shape)}, materialized={self.is_materialized})"
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        def unwrap(t):
+            return t.materialize() if isinstance(t, LazyCostVolume) else t
+        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs or {}))

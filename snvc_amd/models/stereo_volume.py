@@ -16,7 +16,7 @@ blocks (``convbn_3d``, ``hourglass``) and the composition pattern of VernierScal
 import torch
 import torch.nn as nn
 
-from ..extension.build_cost_volume import build_cost_volume
+from ..extension.build_cost_volume import _BuildCostVolume, build_cost_volume  # noqa: F401  (re-exported)
 from .. import ops
 from .submodule import (_GENERATION, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _folded_bn, _Plan, convbn_3d, hourglass,
                         EPI_RELU)
@@ -57,6 +57,14 @@ class GlobalStack(nn.Module):
         return cost
 
     def forward(self, volume):
+        from ..lazy import LazyCostVolume
+        if isinstance(volume, LazyCostVolume):
+            # build_cost_volume's result that nobody has looked at yet: the reference's call sequence on the fused path
+            if not volume.is_materialized and not torch.is_grad_enabled() and not self.training:
+                left, right, shift, ds = volume.sources
+                if left.shape[1] * 2 == self.conv1[0][0].in_channels and left.shape[3] % 4 == 0:
+                    return self.forward_pair(left, right, shift, ds, shift_checked=True)
+            volume = volume.materialize()
         if torch.is_grad_enabled() or not volume.is_cuda:
             return self._tail(self.conv2(self.conv1(volume)))
         n, c2 = volume.size(0), volume.size(1)
@@ -64,7 +72,7 @@ class GlobalStack(nn.Module):
         v = self.conv1.fused(volume, out=self._buffer("v1", shape, volume.device))
         return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, volume.device)))
 
-    def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None):
+    def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
 
         ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT
@@ -96,7 +104,7 @@ class GlobalStack(nn.Module):
                   and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)
         if not usable:
             if timing is None:
-                return self.forward(build_cost_volume(left, right, shift, downsample))
+                return self.forward(_BuildCostVolume.apply(left, right, shift, downsample))      # the eager volume
             assert torch.all(shift >= 0.)        # the wrapper's own check (a sync) stays outside the event pair
             mark("volume", 0)
             vol = ops.cost_volume_forward(left, right, shift, downsample)
@@ -112,7 +120,8 @@ class GlobalStack(nn.Module):
             mark("conv1", 1)
             del vol
             return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, device)))
-        assert torch.all(shift >= 0.)            # same contract as build_cost_volume (reference __init__.py:12)
+        if not shift_checked:                    # a LazyCostVolume was checked when build_cost_volume made it
+            assert torch.all(shift >= 0.)        # same contract as build_cost_volume (reference __init__.py:12)
         c = left.size(1)
         w = conv.weight
         plans = conv.__dict__.setdefault("_snvc_factored", {})

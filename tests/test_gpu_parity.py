@@ -782,6 +782,60 @@ def test_global_stack_vs_golden(name, G):
     check(y, G[f"global/{name}"], 1e-4, name)
 
 
+def test_lazy_cost_volume_reference_call_sequence():
+    """``vol = build_cost_volume(l, r, s, 1); model(vol)`` under no_grad: ``vol`` is a LazyCostVolume with the volume's
+    shape / dtype / device; GlobalStack consumes it on the fused path (== forward_pair, bit for bit, nothing built);
+    any other use builds the real volume, whose values are the eager builder's, bit for bit."""
+    from snvc_amd import ops
+    from snvc_amd.extension.build_cost_volume import build_cost_volume
+    from snvc_amd.lazy import LazyCostVolume
+    from snvc_amd.models.stereo_volume import GlobalStack
+    C, H, W, D = 32, 8, 40, 8
+    r = np.random.default_rng(11)
+    L = torch.from_numpy(r.standard_normal((2, C, H, W)).astype(np.float32)).to(dev())
+    R = torch.from_numpy(r.standard_normal((2, C, H, W)).astype(np.float32)).to(dev())
+    S_ = torch.from_numpy(np.tile(np.linspace(0.0, 9.5, D, dtype=np.float32), (2, 1))).to(dev())
+    m = seeded(GlobalStack(C), 3).to(dev())
+    eager = ops.cost_volume_forward(L, R, S_, 1)
+    with torch.no_grad():
+        vol = build_cost_volume(L, R, S_, 1)
+        assert isinstance(vol, LazyCostVolume) and not vol.is_materialized
+        assert tuple(vol.shape) == tuple(eager.shape) and vol.dtype == eager.dtype and vol.device == eager.device
+        assert vol.is_cuda and vol.is_contiguous() and vol.size(1) == 2 * C and vol.dim() == 5
+        y_api = m(vol)                                   # the reference's call sequence
+        assert not vol.is_materialized                   # ... never built the volume
+        y_pair = m.forward_pair(L, R, S_, 1)
+        assert torch.equal(y_api, y_pair)
+        y_mat = m(eager)                                 # conv1 over the materialised 64 channels
+        check(y_api.cpu().numpy(), y_mat.cpu().numpy(), 1e-5, "fused path vs materialised volume")
+        # any other use: the real volume
+        vol2 = build_cost_volume(L, R, S_, 1)
+        s = (vol2 * 2.0).sum()                           # an aten operator
+        assert vol2.is_materialized and torch.equal(vol2.materialize(), eager) and s.item() == (eager * 2.0).sum().item()
+        vol3 = build_cost_volume(L, R, S_, 1)
+        assert torch.equal(vol3[:, C:], eager[:, C:]) and torch.equal(vol3.cpu(), eager.cpu())
+        vol4 = build_cost_volume(L, R, S_, 1)
+        y4 = m.conv1.fused(vol4)                         # a kernel of this library asking for the pointer
+        assert vol4.is_materialized and torch.equal(y4, m.conv1.fused(eager))
+        y5 = m(vol4)                                     # a materialised lazy volume: the materialised path
+        assert torch.equal(y5, y_mat)
+        m.train()
+        vol6 = build_cost_volume(L, R, S_, 1)            # train-mode BatchNorm: not the fused path
+        y6 = m(vol6)
+        assert vol6.is_materialized and torch.isfinite(y6).all()
+        m.eval()
+        with pytest.raises(AssertionError):
+            build_cost_volume(L, R, S_ - 1.0, 1)
+    # with autograd on: the eager autograd function, as before
+    Lg = L.clone().requires_grad_()
+    vol_g = build_cost_volume(Lg, R, S_, 1)
+    assert not isinstance(vol_g, LazyCostVolume) and vol_g.grad_fn is not None and torch.equal(vol_g, eager)
+    # other dtypes / downsample: eager
+    with torch.no_grad():
+        assert not isinstance(build_cost_volume(L.double(), R.double(), S_.double(), 1), LazyCostVolume)
+        assert not isinstance(build_cost_volume(L, R, S_, 2), LazyCostVolume)
+
+
 @pytest.mark.parametrize("tile", ["default", "big", "narrow"])
 def test_global_pair_end_to_end_vs_oracle(tile):
     """cost-volume build + 3D CNN forward (the benchmarked unit) against C oracle + torch-CPU."""
