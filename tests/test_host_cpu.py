@@ -158,3 +158,32 @@ def test_plan_caches_follow_parameter_updates():
     m[0].__dict__["_snvc_plans"] = {"cpu": S._Plan()}
     S.invalidate_plans(m)                         # per-module form drops the per-device plan table
     assert "_snvc_plans" not in m[0].__dict__
+
+
+def test_lazy_cost_volume_host_semantics():
+    """LazyCostVolume (snvc_amd/lazy.py) without a GPU: a stand-in builder shows that the wrapper carries the volume's
+    shape / dtype / device, builds once, and hands every operator, index and pointer request the built tensor."""
+    import torch
+    from snvc_amd.lazy import LazyCostVolume
+    calls = []
+
+    def build(left, right, shift, ds):
+        calls.append(1)
+        n, c, h, w = left.shape
+        d = shift.shape[1]
+        return torch.cat([left[:, :, None].expand(n, c, d, h, w), right[:, :, None].expand(n, c, d, h, w)], 1).contiguous()
+
+    left, right = torch.arange(24.0).reshape(1, 2, 3, 4), -torch.arange(24.0).reshape(1, 2, 3, 4)
+    shift = torch.zeros(1, 5)
+    v = LazyCostVolume(left, right, shift, 1, build)
+    assert tuple(v.shape) == (1, 4, 5, 3, 4) and v.dtype == torch.float32 and v.device == left.device and v.dim() == 5
+    assert v.is_contiguous() and not v.is_materialized and not calls and v.sources[0] is left
+    assert "materialized=False" in repr(v) and not calls
+    ref = build(left, right, shift, 1)
+    calls.clear()
+    assert torch.equal(v + 0.0, ref) and v.is_materialized and len(calls) == 1
+    assert torch.equal(v[:, 2:], ref[:, 2:]) and v.sum().item() == ref.sum().item() and len(calls) == 1     # built once
+    assert v.data_ptr() == v.materialize().data_ptr() != 0
+    w = LazyCostVolume(left, right, shift, 1, build)
+    assert w.data_ptr() != 0 and w.is_materialized                     # a pointer request builds it too
+    assert torch.equal(torch.relu(LazyCostVolume(left, right, shift, 1, build)), torch.relu(ref))
