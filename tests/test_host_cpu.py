@@ -187,3 +187,37 @@ def test_lazy_cost_volume_host_semantics():
     w = LazyCostVolume(left, right, shift, 1, build)
     assert w.data_ptr() != 0 and w.is_materialized                     # a pointer request builds it too
     assert torch.equal(torch.relu(LazyCostVolume(left, right, shift, 1, build)), torch.relu(ref))
+
+
+def test_install_as_snvc_redirects_the_reference_imports(tmp_path, monkeypatch):
+    """snvc_amd.install_as_snvc(): the reference's import lines give this package's modules; the rest of a `snvc`
+    checkout on sys.path stays the reference's own (a stand-in package tree here: the real one is not on the GPU box)."""
+    import importlib
+    import sys
+    root = tmp_path / "ref"
+    for pkg in ("snvc", "snvc/models", "snvc/extension", "snvc/extension/roiaware_pool3d", "snvc/utils"):
+        (root / pkg).mkdir(parents=True)
+        (root / pkg / "__init__.py").write_text("")
+    (root / "snvc/models/hrnet.py").write_text("def get_model(cfg, is_train=False, **kw):\n    return ('hrnet', cfg, is_train)\n")
+    (root / "snvc/models/vernier.py").write_text("raise ImportError('the reference module must not be imported')\n")
+    (root / "snvc/utils/misc.py").write_text("ANSWER = 42\n")
+    monkeypatch.syspath_prepend(str(root))
+    for name in [m for m in sys.modules if m == "snvc" or m.startswith("snvc.")]:
+        monkeypatch.delitem(sys.modules, name)
+    import snvc_amd
+    import snvc_amd.models.vernier as ours
+    saved = ours.get_feat_extraction
+    try:
+        snvc_amd.install_as_snvc()
+        from snvc.models.vernier import get_model, VernierScale          # noqa: F401  (the reference's import line)
+        from snvc.extension.build_cost_volume import build_cost_volume  # noqa: F401
+        from snvc.models.submodule import convbn_3d, hourglass           # noqa: F401
+        from snvc.extension.roiaware_pool3d.roiaware_pool3d_utils import RoIAwarePool3d  # noqa: F401
+        import snvc.models.vernier as v
+        assert v is ours and get_model is ours.get_model and build_cost_volume.__module__.startswith("snvc_amd")
+        assert importlib.import_module("snvc.utils.misc").ANSWER == 42          # everything else: the checkout's own
+        assert ours.get_feat_extraction("cfg", True) == ("hrnet", "cfg", True)  # backbone factory wired in
+    finally:
+        ours.get_feat_extraction = saved
+        for name in [m for m in sys.modules if m == "snvc" or m.startswith("snvc.")]:
+            sys.modules.pop(name, None)
