@@ -264,16 +264,46 @@ class VernierScale(nn.Module):
 
     def forward(self, left_roi, right_roi, grid_proj_left, grid_proj_right, meta_data=None, test=False):
         """reference vernier.py:460-555"""
-        if test:
-            raise NotImplementedError("test=True is the reference's matplotlib self-check (vernier.py:479-550)")
         left_feat = self.feat_net(left_roi)
         right_feat = self.feat_net(right_roi)
+        if test:
+            self.last_self_check = self._aggregation_self_check(left_feat, right_feat, grid_proj_left, grid_proj_right, meta_data)
         if getattr(self, "precision", "f32") == "f16" and not torch.is_grad_enabled():
             voxels = self.construct_voxel_f16(left_feat, right_feat, grid_proj_left, grid_proj_right)
         else:
             voxels = self.construct_voxel(left_feat, right_feat, grid_proj_left, grid_proj_right)
         ncf, occupancy, part_offsets, coordinates, bboxes = self.predict_3d_heatmaps(voxels)
         return {"ncf": ncf, "occupancy": occupancy, "coordinates": coordinates}
+
+    def _aggregation_self_check(self, left_feat, right_feat, grid_proj_left, grid_proj_right, meta_data, voxel=None):
+        """The numeric half of the reference's ``forward(test=True)`` (vernier.py:479-519; its matplotlib half is not
+        reproduced): one voxel (i, j, k) of sample 0 is re-projected on the host from ``meta_data['grid_3d']`` through
+        the sample's calibration objects and crop transforms, compared with the projected grid that was fed in, and the
+        voxel's aggregated feature is compared with the two feature maps at the ROUNDED pixel (nearest neighbour against
+        the kernel's bilinear sample, as in the reference: an eyeball check).  Returns / stores the numbers it prints."""
+        import numpy as np
+        nh, nw, nl = self.cfg.n_sample_h, self.cfg.n_sample_w, self.cfg.n_sample_l
+        i, j, k = voxel if voxel is not None else (np.random.randint(0, nh), np.random.randint(0, nw), np.random.randint(0, nl))
+        n, down = len(left_feat), 4.0
+        p3 = np.asarray(meta_data["grid_3d"][0]).reshape(nh, nw, nl, 3)[i, j, k].reshape(1, 3)
+
+        def to_crop(calib, trans):            # img_proc.affine_transform (:71-74) of the projected point
+            p2 = np.asarray(calib.project_rect_to_image(p3), dtype=np.float64).reshape(1, 2)
+            return (np.asarray(trans, dtype=np.float64) @ np.concatenate([p2, np.ones((1, 1))], axis=1).T).astype(np.float32) / down
+
+        cl = to_crop(meta_data["calib_left"][0], meta_data["trans_l"][0])
+        cr = to_crop(meta_data["calib_right"][0], meta_data["trans_r"][0])
+        gpl = meta_data["grid_proj_left"].reshape(n, 2, nh, nw, nl)[0, :, i, j, k].detach().cpu().numpy()
+        gpr = meta_data["grid_proj_right"].reshape(n, 2, nh, nw, nl)[0, :, i, j, k].detach().cpu().numpy()
+        voxels = self.construct_voxel(left_feat[:1], right_feat[:1], grid_proj_left[:1], grid_proj_right[:1])
+        xl, yl = int(np.round(cl[0, 0])), int(np.round(cl[1, 0]))
+        xr, yr = int(np.round(cr[0, 0])), int(np.round(cr[1, 0]))
+        f3d = voxels[0, :, i, j, k]
+        dif = torch.abs(f3d - torch.cat((left_feat[0, :, yl, xl], right_feat[0, :, yr, xr])))
+        out = {"voxel": (i, j, k), "projection_error_left": cl[:, 0] * down - gpl, "projection_error_right": cr[:, 0] * down - gpr,
+               "feature_abs_diff": dif.detach().cpu(), "voxel_feature": f3d.detach().cpu()}
+        print(out["projection_error_left"]); print(out["projection_error_right"]); print(dif); print(f3d)
+        return out
 
     # ------------------------------------------------------------------ a12: index extraction
     def ncf_argmax(self, ncf):

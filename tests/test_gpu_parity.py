@@ -772,6 +772,53 @@ def test_vernier_scale_vs_golden(name, G):
     assert safe.mean() > 0.5
 
 
+def test_vernier_forward_self_check():
+    """forward(test=True): the numeric half of the reference's aggregation self-check (vernier.py:479-519).  A pinhole
+    calibration stand-in projects the grid: the host re-projection of the checked voxel agrees with the projected grid that
+    was fed in, and the reported voxel feature is the aggregated one."""
+    from snvc_amd.models.vernier import VernierScale
+    name = list(GC.TRUNK_CASES)[0]
+    grid, gn, n, fh, fw, seed = GC.TRUNK_CASES[name]
+    m = seeded(VernierScale(_cfg(grid, gn)), seed).to(dev())
+    nh, nw, nl = grid
+    v = nh * nw * nl
+    r = np.random.default_rng(41)
+
+    class Calib:                                      # x = f X / Z + cx, y = f Y / Z + cy
+        def __init__(self, shift):
+            self.shift = shift
+
+        def project_rect_to_image(self, p):
+            p = np.asarray(p, dtype=np.float64)
+            return np.stack([8.0 * (p[:, 0] + self.shift) / p[:, 2] + 16.0, 8.0 * p[:, 1] / p[:, 2] + 12.0], axis=1)
+
+    # a 3D grid whose projections are integers in feature-map pixels times the down-sampling factor 4
+    px = r.integers(1, fw - 1, v).astype(np.float64)
+    py = r.integers(1, fh - 1, v).astype(np.float64)
+    z = r.uniform(4.0, 9.0, v)
+    g3 = np.stack([(4.0 * px - 16.0) * z / 8.0, (4.0 * py - 12.0) * z / 8.0, z], axis=1)
+    cal_l, cal_r = Calib(0.0), Calib(-0.5)
+    eye = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    gl = np.stack([cal_l.project_rect_to_image(g3).T] * n).astype(np.float32)            # [n, 2, v] in image pixels
+    gr = np.stack([cal_r.project_rect_to_image(g3).T] * n).astype(np.float32)
+    lf, rf, _, _ = GC.trunk_inputs(n, 32, fh, fw, grid, seed + 1)
+    gpl, gpr = torch.from_numpy(gl).to(dev()), torch.from_numpy(gr).to(dev())
+    meta = {"grid_3d": [g3], "calib_left": [cal_l], "calib_right": [cal_r], "trans_l": [eye], "trans_r": [eye],
+            "grid_proj_left": gpl.clone(), "grid_proj_right": gpr.clone()}
+    with torch.no_grad():
+        out = m(lf.to(dev()), rf.to(dev()), gpl, gpr, meta_data=meta, test=True)
+    assert set(out) == {"ncf", "occupancy", "coordinates"}
+    chk = m.last_self_check
+    assert np.abs(chk["projection_error_left"]).max() < 1e-3 and np.abs(chk["projection_error_right"]).max() < 1e-3
+    # the feature comparison is the reference's eyeball check (nearest pixel of x / 4 against the kernel's bilinear sample
+    # at x / 4 - 0.5): only its plumbing is asserted -- the voxel feature is construct_voxel's, the difference is finite
+    i, j, k = chk["voxel"]
+    with torch.no_grad():
+        vox = m.construct_voxel(lf.to(dev())[:1], rf.to(dev())[:1], gpl[:1], gpr[:1])
+    assert torch.equal(chk["voxel_feature"], vox[0, :, i, j, k].cpu()) and torch.isfinite(chk["feature_abs_diff"]).all()
+    assert chk["feature_abs_diff"].shape == (64,)
+
+
 @pytest.mark.parametrize("name", list(GC.GLOBAL_CASES))
 def test_global_stack_vs_golden(name, G):
     from snvc_amd.models.stereo_volume import GlobalStack
