@@ -288,6 +288,15 @@ SNVC_API int snvc_act_backward_apply(const float *raw, const float *gy, const fl
                                      int64_t raw_batch_stride, int64_t gy_batch_stride,
                                      int64_t res_batch_stride, int per_sample, int flags, void *stream);
 
+/* Train-mode BatchNorm backward coefficients from snvc_act_backward_reduce's sums [N, C, 2] (fp64), in fp64, one launch
+ * (replaces the ~15 per-channel tensor operations of torch autograd's native_batch_norm_backward on this path):
+ *   sg = sum_n sums[n,c,0], sgr = sum_n sums[n,c,1], rstd = 1/sqrt(var[c] + eps), sgx = rstd * (sgr - mean[c] * sg)
+ *   coef_g = gamma*rstd, coef_raw = -gamma*rstd^2*sgx/m, coef_const = -gamma*rstd*sg/m - coef_raw*mean   (m = count)
+ *   dgamma = sgx, dbeta = sg.    gamma may be NULL (= 1); mean / var are the batch statistics of the forward. */
+SNVC_API int snvc_bn_backward_coefs(const double *sums, const float *mean, const float *var, const float *gamma,
+                                    float *coef_g, float *coef_raw, float *coef_const, float *dgamma, float *dbeta,
+                                    int64_t N, int64_t C, double count, double eps, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * Small fused element-wise steps of predict_3d_heatmaps
  * ---------------------------------------------------------------------------------- */

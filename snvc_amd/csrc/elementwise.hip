@@ -338,6 +338,25 @@ act_bwd_apply_kernel(const float *__restrict__ raw, const float *__restrict__ gy
     }
 }
 
+// Train-mode BatchNorm backward coefficients (see snvc_bn_backward_coefs): one thread per channel, fp64.
+__global__ void bn_bwd_coefs_kernel(const double *__restrict__ sums, const float *__restrict__ mean, const float *__restrict__ var,
+                                    const float *__restrict__ gamma, float *__restrict__ coef_g, float *__restrict__ coef_raw,
+                                    float *__restrict__ coef_const, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                    int64_t N, int64_t C, double count, double eps) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sg = 0.0, sgr = 0.0;
+    for (int64_t n = 0; n < N; ++n) { sg += sums[(n * C + c) * 2]; sgr += sums[(n * C + c) * 2 + 1]; }
+    const double mu = (double)mean[c], rstd = 1.0 / sqrt((double)var[c] + eps), gam = gamma ? (double)gamma[c] : 1.0;
+    const double sgx = rstd * (sgr - mu * sg);
+    const double a = gam * rstd, b = -gam * rstd * rstd * sgx / count, cc = -gam * rstd * sg / count - b * mu;
+    coef_g[c] = (float)a;
+    coef_raw[c] = (float)b;
+    coef_const[c] = (float)cc;
+    if (dgamma) dgamma[c] = (float)sgx;
+    if (dbeta) dbeta[c] = (float)sg;
+}
+
 constexpr int kNormSplits = 32;
 
 inline unsigned stream_blocks(int64_t items, int64_t outer) {
@@ -514,6 +533,18 @@ int snvc_act_backward_apply(const float *raw, const float *gy, const float *resi
                                                               draw, g_out, C, S, raw_batch_stride, gy_batch_stride,
                                                               res_batch_stride, per_sample, flags);
     return check_launch("snvc_act_backward_apply");
+}
+
+int snvc_bn_backward_coefs(const double *sums, const float *mean, const float *var, const float *gamma, float *coef_g,
+                           float *coef_raw, float *coef_const, float *dgamma, float *dbeta, int64_t N, int64_t C, double count,
+                           double eps, void *stream) {
+    using namespace snvc;
+    if (N <= 0 || C <= 0 || !(count > 0.0)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_bn_backward_coefs: sizes must be positive");
+    if (!sums || !mean || !var || !coef_g || !coef_raw || !coef_const)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_bn_backward_coefs: null pointer");
+    bn_bwd_coefs_kernel<<<dim3((unsigned)ceil_div<int64_t>(C, 64)), 64, 0, as_stream(stream)>>>(
+        sums, mean, var, gamma, coef_g, coef_raw, coef_const, dgamma, dbeta, N, C, count, eps);
+    return check_launch("snvc_bn_backward_coefs");
 }
 
 int snvc_affine_act(const float *x, const float *scale, const float *shift, const float *residual,

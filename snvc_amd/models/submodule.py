@@ -277,6 +277,18 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
             c_ = -rstd * p1 / m - b_ * mu
             dgamma, dbeta = sgx.sum(0), sg.sum(0)
         else:
+            if train_stats and mean.dtype == torch.float32 and var.dtype == torch.float32:
+                # batch statistics: every coefficient in one launch (fp64 inside), instead of ~15 per-channel tensor ops
+                gw = norm.weight.detach().float().contiguous() if norm.weight is not None else None
+                coef_g, coef_raw, coef_const, dgamma, dbeta = ops.bn_backward_coefs(
+                    sums, mean[0].contiguous(), var[0].contiguous(), gw, float(n * s), float(norm.eps))
+                if norm.weight is None:
+                    dgamma = dbeta = None
+                want_g = want_res and bool(flags & EPI_ADD_PRE)
+                draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
+                                                     per_sample, want_g)
+                gres = (g_out if (flags & EPI_ADD_PRE) else gy) if want_res else None
+                return draw, gres, (dgamma if want_gamma else None), (dbeta if want_beta else None)
             sg, sgr = sums[..., 0].sum(0), sums[..., 1].sum(0)                    # [c]
             if train_stats:
                 mu, rstd = mean[0].double(), torch.rsqrt(var[0].double() + norm.eps)

@@ -21,7 +21,7 @@ from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, C
 __all__ = [
     "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "cost_volume_backward_right", "depth_class_sums", "voxel_gather_forward", "voxel_gather_backward",
     "Conv3dLayer", "conv_variant", "conv3d_wgrad", "Conv3dLayerF16", "to_c8", "from_c8", "voxel_gather_forward_f16",
-    "mul_broadcast_c8", "avgpool_depth4_c8", "volume_resample", "rect_to_psv_grid", "act_backward_reduce", "act_backward_apply", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4", "zero_stuff2x",
+    "mul_broadcast_c8", "avgpool_depth4_c8", "volume_resample", "rect_to_psv_grid", "act_backward_reduce", "act_backward_apply", "bn_backward_coefs", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4", "zero_stuff2x",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
     "points_in_boxes_gpu", "points_in_boxes_cpu",
     "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID",
@@ -399,6 +399,19 @@ def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: in
         check(_lib.lib().snvc_conv3d_wgrad(ctypes.byref(d), _ptr(x_big), _ptr(g_small), _ptr(dw), _ptr(ws),
                                            _stream(x_big)), "snvc_conv3d_wgrad")
     return dw
+
+
+def bn_backward_coefs(sums, mean, var, gamma, count: float, eps: float):
+    """Train-mode BatchNorm backward coefficients in one launch (snvc_bn_backward_coefs): sums [N, C, 2] fp64 from
+    act_backward_reduce, mean / var [C] the forward's batch statistics, gamma [C] or None.
+    Returns (coef_g, coef_raw, coef_const, dgamma, dbeta), float32 [C]."""
+    n, c = sums.shape[0], sums.shape[1]
+    out = torch.empty((5, c), dtype=torch.float32, device=sums.device)
+    with torch.cuda.device(sums.device):
+        check(_lib.lib().snvc_bn_backward_coefs(_ptr(sums), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(out[0]), _ptr(out[1]),
+                                               _ptr(out[2]), _ptr(out[3]), _ptr(out[4]), n, c, float(count), float(eps),
+                                               _stream(sums)), "snvc_bn_backward_coefs")
+    return out[0], out[1], out[2], out[3], out[4]
 
 
 def act_backward_reduce(raw, gy, residual, scale, shift, flags: int, per_sample: bool) -> torch.Tensor:
