@@ -272,6 +272,17 @@ SNVC_API int snvc_conv3d_forward_head(const snvc_conv3d_desc *desc_host, const f
                                       const float *packed_weight, const float *scale, const float *bias,
                                       const float *residual, const float *head_weight, float *y_head,
                                       void *stream);
+/* A layer AND the 1x1x1 projection of its own result in one launch: y as snvc_conv3d_forward writes it, and
+ * y_head[n,0,:] = sum_c head_weight[c] * y[n,c,:] ([N,1,D,H,W], 16-byte aligned).  Used for the `classifier(v)` term of
+ * the global model's folded tail (stereo_volume.py): with no activation behind the hourglass's last transposed layer
+ * (snvc/models/submodule.py:166), classifier(bn(deconv(post)) + v) = deconv'(post) + b' + classifier(v), where deconv' is
+ * a ConvTranspose3d to ONE channel (run by snvc_conv3d_forward: desc.transposed, Cout = 1) and classifier(v) comes out
+ * of the launch that produces v.  Built for 3x3x3 / stride-1 layers with 32 output channels on the default Winograd
+ * form, no residual; returns SNVC_ERR_UNSUPPORTED otherwise (the caller then projects y in a launch of its own). */
+SNVC_API int snvc_conv3d_forward_side_head(const snvc_conv3d_desc *desc_host, const float *x,
+                                           const float *packed_weight, const float *scale, const float *bias,
+                                           const float *residual, float *y, const float *head_weight,
+                                           float *y_head, void *stream);
 SNVC_API int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *desc_host);
 SNVC_API int snvc_conv3d_wgrad(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
                                void *workspace, void *stream);

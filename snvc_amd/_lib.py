@@ -10,6 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNVC_HIP_LIB") or os.path.join(_HERE, "libsnvc_hip.so")   # env: development override
 _lib = None
+_ABI = 3   # snvc_abi_version() this binding was written against
 
 c_i64 = ctypes.c_int64
 c_f32 = ctypes.c_float
@@ -54,6 +55,7 @@ SIGNATURES = {
     "snvc_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_conv3d_forward_ex": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_conv3d_forward_head": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "snvc_conv3d_forward_side_head": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_norm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "snvc_norm_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_p]),
     "snvc_affine_act": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
@@ -107,7 +109,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
-        if handle.snvc_abi_version() != 2:
+        if handle.snvc_abi_version() != _ABI:
             raise RuntimeError("libsnvc_hip.so ABI version mismatch; rebuild it")
         _lib = handle
     return _lib

@@ -40,6 +40,7 @@
 //                           fused 1x1x1 head (snvc_conv3d_forward_head)
 //   pointwise_small_kernel, conv3d_k3_cout1_kernel   VALU kernels for layers with 1-2 output channels
 #include "common.hpp"
+#include "conv3d_internal.hpp"
 #include "wino_tables.hpp"
 
 namespace snvc {
@@ -939,7 +940,11 @@ template <class Cfg> constexpr int epilogue_piece() { return EpiloguePiece<Cfg>:
 // at kernel start; lgkmcnt), every vector load (residual or depth-class planes) before the first
 // store, addresses = wave-uniform channel base (SGPR pair) + one 32-bit per-lane byte offset per row
 // block (the host routes layers with more than 2^27 output voxels per channel elsewhere).
-template <class Cfg, bool RES, bool PLANE>
+// HEAD (side head, snvc_conv3d_forward_side_head): besides y, the launch writes the 1x1x1 projection of its own
+// 32-channel result to one channel, y_head = sum_c head_w[c] * y[c] -- 16 channels per lane, the other 16 in
+// lane ^ 32 -- so that a later consumer of head(y) does not have to read y again (the global model's
+// `classifier(v)` term of the folded hourglass tail, models/stereo_volume.py).
+template <class Cfg, bool RES, bool PLANE, bool HEAD = false>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[Cfg::NPOS][Cfg::NB],
                                               const float *__restrict__ aff, int lane, int wave) {
     constexpr int NB = Cfg::NB, TH = Cfg::TH;
@@ -1038,6 +1043,24 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
             for (int q = 0; q < EB; ++q)
                 asm volatile("" : "+v"(acc[0][nb][r0 + q]), "+v"(acc[1][nb][r0 + q]), "+v"(acc[2][nb][r0 + q]),
                              "+v"(acc[3][nb][r0 + q])::"memory");
+        }
+    }
+    if constexpr (HEAD) {
+        static_assert(V4, "the side head stores 16-byte pieces");
+        float hw[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hw[r] = a.head_w[cbase + (r & 3) + 8 * (r >> 2) + 4 * half];
+        char *const yh = reinterpret_cast<char *>(a.y_head + job.n * (int64_t)out_dhw);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f32x4 dsum = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dsum[j] = __builtin_fmaf(hw[r], acc[j][nb][r], dsum[j]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dsum[j] += __shfl_xor(dsum[j], 32);
+            if (half == 0 && ok0[nb]) *reinterpret_cast<f32x4 *>(yh + voff[nb]) = dsum;   // half 0: voff = 4 * voxel
         }
     }
 #pragma unroll
@@ -1165,7 +1188,7 @@ __device__ __forceinline__ void wino_dma_issue(const float **xsrc, const float *
     }
 }
 
-template <class Cfg, bool RES, bool PLANE>
+template <class Cfg, bool RES, bool PLANE, bool HEAD = false>
 __global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_wino_dma_kernel(const ConvArgs a) {
     constexpr int TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB, CH = Cfg::CH, TILE = Cfg::TILE, WF = Cfg::WF;
@@ -1218,7 +1241,7 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
         wino_compute_chunk<Cfg>(lds + (chunk & 1) * TILE, wlds + (chunk & 1) * WF + lane, bbase, wave, acc, [](int) {});
         __syncthreads();
     }
-    wino_epilogue<Cfg, RES, PLANE>(a, job, acc, aff, lane, wave);
+    wino_epilogue<Cfg, RES, PLANE, HEAD>(a, job, acc, aff, lane, wave);
 }
 
 // k5 / k7 Winograd kernel (WinoKCfg above).  Phase p = (chunk, kd): weights of phase p+1 are DMA'd
@@ -2021,12 +2044,12 @@ void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     conv3d_wino_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
 }
 
-template <class Cfg, bool RES, bool PLANE>
+template <class Cfg, bool RES, bool PLANE, bool HEAD = false>
 void launch_wino_dma_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
     static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
-    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE>), BYTES, attr_done)) return;
-    conv3d_wino_dma_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE, HEAD>), BYTES, attr_done)) return;
+    conv3d_wino_dma_kernel<Cfg, RES, PLANE, HEAD><<<grid, 256, BYTES, st>>>(a);
 }
 
 template <class Cfg>
@@ -2092,6 +2115,8 @@ int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
     if (!d->transposed && d->ksize == 1 && d->Cout <= 2) count += (int64_t)d->Cout * d->Cin;
     // 3x3x3 / stride-1 layers with ONE output channel too ([Cin][27], VALU kernel)
     if (!d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1) count += (int64_t)d->Cin * 27;
+    // transposed layers to ONE channel as well ([Cin][1][27], VALU kernel of conv3d_small.hip)
+    if (d->transposed && d->Cout == 1) count += (int64_t)d->Cin * 27;
     return count;
 }
 
@@ -2104,7 +2129,8 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
     if (!weight || !packed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_pack_weights: null pointer");
     int64_t total = snvc_conv3d_packed_weight_count(d);
     const bool planar = d->ksize_d == 1;
-    const bool k3c1 = !planar && !d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1;
+    const bool k3c1 = !planar && ((!d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1) ||
+                                  (d->transposed && d->Cout == 1));
     if (!planar && ((!d->transposed && d->ksize == 1 && d->Cout <= 2) || k3c1)) {   // raw copy behind the MFMA packing
         const int64_t nraw = k3c1 ? (int64_t)d->Cin * 27 : (int64_t)d->Cout * d->Cin;
         total -= nraw;
@@ -2165,6 +2191,14 @@ int snvc_conv3d_forward_head(const snvc_conv3d_desc *d, const float *x, const fl
     return conv3d_forward_impl(d, x, packed_weight, scale, bias, residual, nullptr, nullptr, head_weight, y_head, stream);
 }
 
+int snvc_conv3d_forward_side_head(const snvc_conv3d_desc *d, const float *x, const float *packed_weight,
+                                  const float *scale, const float *bias, const float *residual, float *y,
+                                  const float *head_weight, float *y_head, void *stream) {
+    using namespace snvc;
+    if (!d || !y || !head_weight || !y_head) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward_side_head: null pointer");
+    return conv3d_forward_impl(d, x, packed_weight, scale, bias, residual, nullptr, y, head_weight, y_head, stream);
+}
+
 }  // extern "C"
 
 namespace snvc {
@@ -2197,7 +2231,11 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     a.res = (d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) ? residual : nullptr;
     a.plane = depth_planes;
     a.head_w = head_w; a.y_head = y_head;
-    if (head_w && p.kind != DC_M1) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_head: layer is not a single-group transposed convolution");
+    const bool side_head = head_w && y;   // snvc_conv3d_forward_side_head: y AND its one-channel projection
+    if (side_head && (d->transposed || d->ksize_d == 1 || d->ksize != 3 || d->stride != 1 || d->dilation != 1 || depth_planes))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_side_head: built for 3x3x3 / stride-1 Conv3d layers");
+    if (head_w && !side_head && p.kind != DC_M1)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_head: layer is not a single-group transposed convolution");
     a.wp_wino = nullptr; a.nchunks_wino = 0;
     a.y = y;
     a.Cin = d->Cin; a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
@@ -2246,6 +2284,12 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
                 x, wraw, scale, bias, a.res, y, d->Cin, d->Dout, d->Hout, d->Wout, th_, tw_, a.x_bs, a.y_bs, a.r_bs, d->flags);
             return check_launch("snvc_conv3d_forward(k3 to one channel)");
         }
+    }
+    // transposed layer to ONE channel (the folded hourglass tail + classifier): VALU kernel, raw weights as above
+    if (!planar && !head_w && deconv3d_cout1_qualifies(*d, x, y, a.res, a.x_bs, a.y_bs, a.r_bs)) {
+        const float *wraw = packed_weight + snvc_conv3d_packed_weight_count(d) - (int64_t)d->Cin * 27;
+        deconv3d_cout1_launch(*d, x, wraw, scale, bias, a.res, y, a.x_bs, a.y_bs, a.r_bs, as_stream(stream));
+        return check_launch("snvc_conv3d_forward(transposed to one channel)");
     }
     // k3 / stride 2: polyphase + F(4,2) along W (LDS-DMA staged: 16-byte INPUT rows; output rows may be 8-byte ones)
     {
@@ -2313,6 +2357,13 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
             if (nj < ((int64_t)1 << 31)) {
                 a.njobs = (int)nj;
                 const dim3 g((unsigned)nj, 1, 1);
+                if (side_head) {   // built for the default kernel form without addends (the global model's conv2)
+                    if (!(narrow && wide && !nreg) || a.res || a.plane || d->Cout != 32 || (reinterpret_cast<uintptr_t>(y_head) & 15))
+                        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_side_head: needs the default Winograd form, 32 output "
+                                                          "channels, no residual / depth planes and a 16-byte aligned y_head");
+                    launch_wino_dma_variant<CfgWinoN3, false, false, true>(a, g, as_stream(stream));
+                    return check_launch("snvc_conv3d_forward_side_head");
+                }
                 if (big) launch_wino_dma<CfgWinoBig>(a, g, as_stream(stream));
                 else if (narrow && wide && !nreg) launch_wino_dma<CfgWinoN3>(a, g, as_stream(stream));
                 else if (narrow && wide) launch_wino<CfgWinoN>(a, g, as_stream(stream));
@@ -2323,6 +2374,8 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
             }
         }
     }
+    if (side_head)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_side_head: built for 3x3x3 / stride-1 layers on the Winograd path");
     const int64_t ntiles = (int64_t)p.tiles_d * p.tiles_h * p.tiles_w;
     const int64_t gx = d->transposed ? ntiles * 4 : ntiles;
     if (gx >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: too many tiles");

@@ -50,11 +50,17 @@ class GlobalStack(nn.Module):
             buf = ws[key] = torch.empty(shape, dtype=torch.float32, device=device)
         return buf
 
-    def _tail(self, v):
-        """v + hourglass(v)[0] -> classifier.  The residual add and (inference) the 1x1x1 classifier are folded
-        into the hourglass's last transposed convolution: the full-resolution C-channel tensor is never written."""
-        cost, _, _ = self.hg_conv3d(v, None, None, residual=v, head=self.classifier)
+    def _tail(self, v, hv=None):
+        """v + hourglass(v)[0] -> classifier.  The hourglass's last transposed layer has no activation
+        (reference submodule.py:166), so at inference  classifier(bn(deconv(post)) + v) = deconv'(post) + b' +
+        classifier(v)  with deconv' a transposed layer to ONE channel (fused_conv3d): the full-resolution C-channel
+        tensor is never formed.  ``hv`` = classifier(v) when conv2's launch already produced it (side head)."""
+        cost, _, _ = self.hg_conv3d(v, None, None, residual=v, head=self.classifier, head_residual=hv)
         return cost
+
+    def _conv2_tail(self, v1, shape):
+        v, hv = self.conv2.fused(v1, out=self._buffer("v2", shape, v1.device), side_head=self.classifier)
+        return self._tail(v, hv)
 
     def forward(self, volume):
         from ..lazy import LazyCostVolume
@@ -70,7 +76,7 @@ class GlobalStack(nn.Module):
         n, c2 = volume.size(0), volume.size(1)
         shape = (n, c2 // 2) + tuple(volume.shape[2:])
         v = self.conv1.fused(volume, out=self._buffer("v1", shape, volume.device))
-        return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, volume.device)))
+        return self._conv2_tail(v, shape)
 
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
@@ -119,7 +125,7 @@ class GlobalStack(nn.Module):
             v = self.conv1.fused(vol, out=self._buffer("v1", shape, device))
             mark("conv1", 1)
             del vol
-            return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, device)))
+            return self._conv2_tail(v, shape)
         if not shift_checked:                    # a LazyCostVolume was checked when build_cost_volume made it
             assert torch.all(shift >= 0.)        # same contract as build_cost_volume (reference __init__.py:12)
         c = left.size(1)
@@ -140,4 +146,4 @@ class GlobalStack(nn.Module):
         mark("conv1", 0)
         v = plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, self._buffer("v1", shape, left.device), depth_planes=planes)
         mark("conv1", 1)
-        return self._tail(self.conv2.fused(v, out=self._buffer("v2", shape, left.device)))
+        return self._conv2_tail(v, shape)

@@ -46,6 +46,10 @@ def _cubic(v, what):
 
 _GENERATION = [0]   # bumped by invalidate_plans(): part of every cache key
 
+# How often each fused route was taken (tests assert on it: a silent regression to a slower or to a torch route shows)
+import collections
+_ROUTES = collections.Counter()
+
 
 def invalidate_plans(module: Optional[nn.Module] = None) -> None:
     """Drop the packed-weight / folded-BatchNorm / dgrad / factored-conv caches.
@@ -377,9 +381,55 @@ class _FactoredFirstConvFn(torch.autograd.Function):
         return g_left, g_right, None, gw, dg, db, None, None, None, None
 
 
+def _is_frozen_norm(norm) -> bool:
+    return norm is None or (isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None))
+
+
+def _is_channel_head(head, cin) -> bool:
+    """A bias-free Conv3d(cin, 1, kernel_size=1): the projection the head fusions are built for."""
+    return (isinstance(head, nn.Conv3d) and head.bias is None and tuple(head.weight.shape) == (1, cin, 1, 1, 1)
+            and head.weight.dtype == torch.float32)
+
+
+def _folded_head_layer(conv: nn.Module, norm: Optional[nn.Module], head: nn.Module, plan: _Plan):
+    """``head(norm(conv(x)))`` with NO activation in between is one layer to ONE channel:
+    W'[ci][tap] = sum_co h[co] * scale[co] * W[co, ci][tap],  b' = sum_co h[co] * shift[co]   (folded in fp64).
+    Returns (layer, one, bias) with ``one`` / ``bias`` the [1] scale / shift tensors of that layer's epilogue."""
+    w, hw = conv.weight, head.weight
+    bn_key = None
+    if norm is not None:
+        bn_key = (norm.weight._version if norm.weight is not None else -1, norm.bias._version if norm.bias is not None else -1,
+                  norm.running_mean._version, norm.running_var._version, norm.running_mean.data_ptr())
+    key = (w.data_ptr(), w._version, hw.data_ptr(), hw._version, bn_key, w.device, _GENERATION[0])
+    cached = getattr(plan, "folded_head", None)
+    if cached is None or cached[0] != key:
+        k, s, p, d, transposed = _conv_geometry(conv)
+        h = hw.detach().double().reshape(-1)
+        if norm is not None:
+            var, mean = norm.running_var.detach().double(), norm.running_mean.detach().double()
+            g = norm.weight.detach().double() if norm.weight is not None else torch.ones_like(var)
+            b = norm.bias.detach().double() if norm.bias is not None else torch.zeros_like(var)
+            sc = g / torch.sqrt(var + norm.eps)
+            sh = b - mean * sc
+        else:
+            sc, sh = torch.ones_like(h), torch.zeros_like(h)
+        hs = h * sc
+        wd = w.detach().double()
+        if transposed:      # [Cin, Cout, k, k, k] -> [Cin, 1, k, k, k]
+            wf = torch.einsum("iodhw,o->idhw", wd, hs).unsqueeze(1)
+        else:               # [Cout, Cin, k, k, k] -> [1, Cin, k, k, k]
+            wf = torch.einsum("oidhw,o->idhw", wd, hs).unsqueeze(0)
+        layer = ops.Conv3dLayer(wf.float().contiguous(), k, s, p, d, transposed)
+        one = torch.ones(1, dtype=torch.float32, device=w.device)
+        bias = (h * sh).sum().float().reshape(1)
+        cached = plan.folded_head = (key, layer, one, bias)
+    return cached[1], cached[2], cached[3]
+
+
 def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,
                  residual: Optional[torch.Tensor] = None, residual_after_act=False, out=None,
-                 plan: Optional[_Plan] = None, head: Optional[nn.Module] = None) -> torch.Tensor:
+                 plan: Optional[_Plan] = None, head: Optional[nn.Module] = None,
+                 head_residual: Optional[torch.Tensor] = None, side_head: Optional[nn.Module] = None):
     """act(norm(conv(x)) [+ residual]) [+ residual] on the HIP kernels.
 
     ``residual_after_act=False``: relu(norm(conv(x)) + residual)   (hourglass skips, submodule.py:154,162)
@@ -409,12 +459,30 @@ def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *,
         if out is not None:
             raise NotImplementedError("`out=` (in-place concat slices) is an inference-only fusion")
         y = _ConvNormActFn.apply(x, conv.weight, gamma, beta, residual, conv, norm, flags, plan)
+        if side_head is not None:
+            return y, side_head(y)
         return head(y) if head is not None else y
     layer = _get_layer(conv, plan)
+    if side_head is not None:
+        if head is not None:
+            raise NotImplementedError("`head` and `side_head` are exclusive")
+        if not torch.is_grad_enabled() and _is_frozen_norm(norm) and _is_channel_head(side_head, layer.cout):
+            scale, bias = _folded_bn(norm, plan) if norm is not None else (None, None)
+            y, hy = layer(x, scale, bias, residual, flags, out, side_head=side_head.weight)
+            _ROUTES["side_head" if hy is not None else "side_head_separate"] += 1
+        else:
+            y, hy = _norm_forward(layer, norm, plan, x, residual, flags, out, False)[0], None
+        return y, (hy if hy is not None else side_head(y))
     if head is not None:
-        if (out is None and not torch.is_grad_enabled() and head.weight.shape[0] == 1 and head.bias is None
-                and tuple(head.weight.shape[2:]) == (1, 1, 1)
-                and (norm is None or (isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None)))):
+        fusable = (out is None and not torch.is_grad_enabled() and _is_channel_head(head, layer.cout) and _is_frozen_norm(norm))
+        if fusable and not (flags & (EPI_RELU | EPI_SIGMOID)):
+            fl, one, fbias = _folded_head_layer(conv, norm, head, plan)
+            hres = None
+            if residual is not None:
+                hres = head_residual if head_residual is not None else head(residual)
+            _ROUTES["folded_head"] += 1
+            return fl(x, one, fbias, hres, EPI_ADD_PRE if hres is not None else 0)
+        if fusable:
             scale, bias = _folded_bn(norm, plan) if norm is not None else (None, None)
             y = ops.conv3d_forward_head(layer, x, scale, bias, residual, flags, head.weight)
             if y is not None:
@@ -527,16 +595,17 @@ class hourglass(nn.Module):
         self.conv5 = _deconvbn_3d(c * 2, c * 2, gn)
         self.conv6 = _deconvbn_3d(c * 2, c, gn)
 
-    def forward(self, x, presqu, postsqu, residual=None, out=None, head=None):
+    def forward(self, x, presqu, postsqu, residual=None, out=None, head=None, head_residual=None):
         """Returns (out, pre, post).  ``residual``/``out`` (extension): fold the caller's
         ``x + hourglass(x)[0]`` (vernier.py:370,421) into the last deconvolution's epilogue.
-        ``head`` (extension): a 1x1x1 one-channel convolution applied to ``out`` inside that epilogue
-        (see fused_conv3d); ``out`` is then ``head(out)``."""
+        ``head`` (extension): a 1x1x1 one-channel convolution applied to ``out`` (see fused_conv3d: conv6 has no
+        activation, so at inference conv6 + head fold into one transposed layer to one channel); ``out`` is then
+        ``head(out)``.  ``head_residual`` = ``head(residual)`` when the caller already has it."""
         o = self.conv1(x)                                                   # 1/2 res, ReLU fused
         pre = self.conv2.fused(o, relu=True, residual=postsqu)              # relu(bn(conv) [+ postsqu]) :153-156
         o = self.conv4(self.conv3(pre))                                     # 1/4 res
         post = self.conv5.fused(o, relu=True, residual=presqu if presqu is not None else pre)  # :161-164
-        o = self.conv6.fused(post, residual=residual, out=out, head=head)   # :166
+        o = self.conv6.fused(post, residual=residual, out=out, head=head, head_residual=head_residual)   # :166
         return o, pre, post
 
     def forward_f16(self, x, presqu=None, postsqu=None, residual=None, out=None):

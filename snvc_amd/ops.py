@@ -308,9 +308,12 @@ class Conv3dLayer:
         d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = x_bs, y_bs, r_bs
         return d
 
-    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None, depth_planes=None, exact=False):
+    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None, depth_planes=None, exact=False,
+                 side_head=None):
         """y = epilogue(conv(x)); x / out / residual may be channel slices of larger buffers.
-        depth_planes [N,Cout,3,H,W]: see snvc_conv3d_forward_ex.  exact=True: SNVC_ALGO_DIRECT (no Winograd)."""
+        depth_planes [N,Cout,3,H,W]: see snvc_conv3d_forward_ex.  exact=True: SNVC_ALGO_DIRECT (no Winograd).
+        side_head: a [Cout] (or [1,Cout,1,1,1]) weight -> returns ``(y, y_head)`` with ``y_head = sum_c side_head[c]*y[:, c]``
+        written by the same launch (snvc_conv3d_forward_side_head), or ``(y, None)`` when the layer does not qualify."""
         _gpu(x, "x")
         if x.dtype != torch.float32 or x.dim() != 5 or x.size(1) != self.cin:
             raise RuntimeError(f"conv3d input must be float32 [N,{self.cin},D,H,W], got {tuple(x.shape)} {x.dtype}")
@@ -340,10 +343,21 @@ class Conv3dLayer:
             if tuple(depth_planes.shape) != (n, self.cout, 3) + out_shape[3:] or not depth_planes.is_contiguous():
                 raise RuntimeError("depth_planes must be a contiguous [N,Cout,3,H,W] tensor")
         with torch.cuda.device(x.device):
+            if side_head is not None:
+                hw = side_head.detach().reshape(-1).contiguous()
+                if depth_planes is None and hw.numel() == self.cout and hw.dtype == torch.float32:
+                    y_head = torch.empty((n, 1) + out_shape[2:], dtype=torch.float32, device=x.device)
+                    rc = _lib.lib().snvc_conv3d_forward_side_head(ctypes.byref(d), _ptr(x), _ptr(self.packed), _ptr(scale),
+                                                                 _ptr(bias), _ptr(residual), _ptr(out), _ptr(hw), _ptr(y_head),
+                                                                 _stream(x))
+                    if rc == 0:
+                        return out, y_head
+                    if rc != 2:        # anything but SNVC_ERR_UNSUPPORTED is an error
+                        check(rc, "snvc_conv3d_forward_side_head")
             check(_lib.lib().snvc_conv3d_forward_ex(ctypes.byref(d), _ptr(x), _ptr(self.packed), _ptr(scale), _ptr(bias),
                                                     _ptr(residual), _ptr(depth_planes), _ptr(out), _stream(x)),
                   "snvc_conv3d_forward")
-        return out
+        return (out, None) if side_head is not None else out
 
 
 def conv3d_forward_head(layer: "Conv3dLayer", x, scale, bias, residual, flags, head_weight) -> Optional[torch.Tensor]:

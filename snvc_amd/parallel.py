@@ -69,30 +69,91 @@ def gather_outputs(local: torch.Tensor, n_items: int) -> torch.Tensor:
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
 
 
-def all_reduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = True) -> int:
-    """Sums (averages) .grad of every trainable parameter across ranks with ONE flat-bucket all-reduce.
+RS_AG_MIN_BYTES = 8 << 20      # buckets from this size on are reduced as reduce-scatter + all-gather (algorithm="auto")
+
+
+def _reduce_flat(flat: torch.Tensor, w: int, average: bool, algorithm: str) -> str:
+    """Sum (average) a flat fp32 bucket across ranks in place; returns the algorithm used.
+
+    "all_reduce": one RCCL all-reduce (latency-bound sizes: the 3D stack's 2.5 MB).
+    "rs_ag": reduce-scatter + all-gather over a bucket padded to a multiple of the world size -- every rank reduces and
+    scales only ITS 1/w of the bucket, and both halves are bandwidth-optimal collectives that RCCL spreads over all the
+    xGMI links of a rank (the 133.5 MB full-model case).  gloo (CPU tests) has no reduce-scatter."""
+    if algorithm == "auto":
+        algorithm = "rs_ag" if (flat.numel() * 4 >= RS_AG_MIN_BYTES and dist.get_backend() == "nccl") else "all_reduce"
+    if algorithm == "rs_ag":
+        n = flat.numel()
+        per = -(-n // w)
+        buf = flat if per * w == n else torch.cat([flat, flat.new_zeros(per * w - n)])
+        mine = torch.empty(per, dtype=flat.dtype, device=flat.device)
+        dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM)
+        if average:
+            mine /= w
+        dist.all_gather_into_tensor(buf, mine)
+        if buf is not flat:
+            flat.copy_(buf[:n])
+    elif algorithm == "all_reduce":
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if average:
+            flat /= w
+    else:
+        raise ValueError(f"unknown gradient reduction algorithm {algorithm!r}")
+    return algorithm
+
+
+def all_reduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = True, force: bool = False,
+                         algorithm: str = "auto") -> int:
+    """Sums (averages) .grad of every trainable parameter across ranks with ONE flat-bucket collective.
     The bucket covers EVERY ``requires_grad`` parameter in iteration order -- a parameter whose ``.grad`` is
-    None on this rank (an unused head, a skipped branch) contributes zeros and receives the reduced
-    value -- so the bucket has the same length and layout on all ranks whatever each rank's graph touched.
-    Returns the number of bytes moved per rank (0 when single-process)."""
+    None on this rank (an unused head, a skipped branch) contributes zeros -- followed by one "has a gradient" flag
+    per parameter, so the bucket has the same length and layout on all ranks whatever each rank's graph touched.
+    A parameter that received a gradient on SOME rank gets the reduced value everywhere; one that has none on ANY
+    rank keeps ``.grad = None`` (as DDP and a single process leave it: no weight decay / momentum on it).
+    ``force``: run the collective even in a one-rank group (exercises RCCL on a single GPU; the values do not change).
+    Returns the number of gradient bytes moved per rank (0 when nothing was exchanged)."""
     rank, w = world()
     plist = [p for p in params if p.requires_grad]
-    if w == 1 or not plist:
+    if not plist or (w == 1 and not (force and dist.is_available() and dist.is_initialized())):
         return 0
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in plist])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    dev = plist[0].device
+    mask = torch.tensor([0.0 if p.grad is None else 1.0 for p in plist], dtype=torch.float32, device=dev)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in plist] + [mask])
+    nmask = len(plist)
+    _reduce_flat(flat, w, False, algorithm)
+    has = flat[-nmask:].tolist()          # one small device -> host copy per step
     if average:
-        flat /= w
+        flat[:-nmask] /= w
     off = 0
-    for p in plist:
+    for p, h in zip(plist, has):
         n = p.numel()
-        g = flat[off:off + n].view_as(p).to(p.dtype)
-        if p.grad is None:
-            p.grad = g.clone()
-        else:
-            p.grad.copy_(g)
+        if h > 0.0:
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
         off += n
-    return flat.numel() * 4
+    return (flat.numel() - nmask) * 4
+
+
+def all_reduce_bucket(nbytes: int, device, algorithm: str = "auto", reps: int = 5):
+    """Times the gradient collective on a synthetic flat bucket of ``nbytes`` (2.6 MB for the 3D stack,
+    133.5 MB for the full model).  Returns (microseconds per call, algorithm used); needs an initialised group."""
+    rank, w = world()
+    flat = torch.ones(max(nbytes // 4, 1), dtype=torch.float32, device=device)
+    used = _reduce_flat(flat, w, True, algorithm)       # warm-up (communicator set-up)
+    if flat.is_cuda:
+        torch.cuda.synchronize(device)
+    import time
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _reduce_flat(flat, w, True, algorithm)
+    if flat.is_cuda:
+        torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / reps
+    if not torch.allclose(flat[:4], torch.ones(4, device=flat.device)):
+        raise RuntimeError("gradient collective changed an all-ones bucket under averaging")
+    return 1e6 * dt, used
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:

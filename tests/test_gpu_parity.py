@@ -69,7 +69,7 @@ def seeded(mod, seed):
 def test_library_loads_and_reports_errors():
     from snvc_amd import _lib
     L = _lib.lib()
-    assert L.snvc_abi_version() == 2
+    assert L.snvc_abi_version() == 3
     rc = L.snvc_cost_volume_forward(None, None, None, None, 1, 1, 3, 4, 1, 2, 0, None)
     assert rc == 1 and b"multiples of downsample" in L.snvc_last_error_string()
 
@@ -524,14 +524,99 @@ def test_deconv_fused_head_vs_separate_layers():
             fused = ops.conv3d_forward_head(layer, x.to(dev()), sc, bi, res.to(dev()), ops.EPI_ADD_PRE, hd.weight)
             assert fused is not None, "the fused-head path must be taken for a 64->32 transposed layer"
             check(fused.cpu().numpy(), ref.numpy(), TIGHT, f"fused head {shape}")
-            got = md.fused(x.to(dev()), residual=res.to(dev()), head=hd)
-            check(got.cpu().numpy(), ref.numpy(), TIGHT, f"fused_conv3d(head=) {shape}")
-            # a layer that does not qualify (64 output channels) silently runs the two layers separately
+            # with an activation between the layer and the head the in-epilogue projection is what fused_conv3d takes
+            got = md.fused(x.to(dev()), relu=True, residual=res.to(dev()), head=hd)
+            check(got.cpu().numpy(), F.conv3d(F.relu(y + res), hw_cpu).numpy(), TIGHT, f"fused_conv3d(relu, head=) {shape}")
+            # a layer that does not qualify for it (64 output channels) silently runs the two layers separately
             m64 = seeded(S._deconvbn_3d(64, 64, gn=False), 93).to(dev())
             h64 = S.HipConv3d(64, 1, kernel_size=1, padding=0, stride=1, bias=False).to(dev())
-            a = m64.fused(x.to(dev()), head=h64)
-            b = h64(m64.fused(x.to(dev())))
+            a = m64.fused(x.to(dev()), relu=True, head=h64)
+            b = h64(m64.fused(x.to(dev()), relu=True))
             assert torch.equal(a, b)
+
+
+def test_deconv_to_one_channel_vs_torch():
+    """ConvTranspose3d(Cin, 1, k3, s2, p1, op1): the VALU kernel of conv3d_small.hip (rows of whole 16-byte pieces) and
+    the MFMA kernel it falls back to, with every epilogue form, against torch."""
+    import torch.nn.functional as F
+    from snvc_amd import ops
+    r = np.random.default_rng(191)
+    for cin, shape in ((64, (3, 5, 36)), (5, (1, 1, 4)), (32, (4, 3, 156)), (16, (2, 3, 34)), (7, (2, 2, 5))):
+        w = torch.from_numpy(r.standard_normal((cin, 1, 3, 3, 3)).astype(np.float32))
+        x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32))
+        sc, bi = torch.tensor([1.7]), torch.tensor([-0.3])
+        with torch.no_grad():
+            raw = F.conv_transpose3d(x, w, None, 2, 1, 1)
+            res = torch.from_numpy(r.standard_normal(tuple(raw.shape)).astype(np.float32))
+            layer = ops.Conv3dLayer(w.to(dev()), 3, 2, 1, 1, True)
+            xd, rd = x.to(dev()), res.to(dev())
+            check(layer(xd).cpu().numpy(), raw.numpy(), TIGHT, f"deconv->1 {cin} {shape}")
+            y = layer(xd, sc.to(dev()), bi.to(dev()), rd, ops.EPI_ADD_PRE | ops.EPI_RELU)
+            check(y.cpu().numpy(), F.relu(raw * 1.7 - 0.3 + res).numpy(), TIGHT, f"relu(deconv->1 + res) {cin} {shape}")
+            y = layer(xd, sc.to(dev()), bi.to(dev()), rd, ops.EPI_ADD_POST | ops.EPI_SIGMOID)
+            check(y.cpu().numpy(), (torch.sigmoid(raw * 1.7 - 0.3) + res).numpy(), TIGHT, f"sigmoid(deconv->1) + res {cin} {shape}")
+            # a batch-strided input (channel slice of a larger buffer)
+            big = torch.from_numpy(r.standard_normal((2, cin + 3) + shape).astype(np.float32)).to(dev())
+            ref2 = F.conv_transpose3d(big[:, 3:].cpu(), w, None, 2, 1, 1)
+            check(layer(big[:, 3:]).cpu().numpy(), ref2.numpy(), TIGHT, f"deconv->1 slice {cin} {shape}")
+
+
+def test_folded_head_tail_vs_separate_layers():
+    """No activation between a layer with frozen statistics and a 1x1x1 head: fused_conv3d folds the pair into one
+    layer to ONE channel (head(bn(conv(x)) + res) = conv'(x) + b' + head(res)).  Transposed (the hourglass tail) and
+    plain layers, with and without a residual, with head(res) handed in; the route counter proves the path."""
+    import torch.nn.functional as F
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(291)
+    for kind, cin, cout, shape in (("deconv", 64, 32, (3, 5, 36)), ("deconv", 64, 64, (2, 3, 34)), ("k3", 32, 32, (4, 6, 40)),
+                                   ("k1", 16, 32, (3, 4, 8))):
+        m = S._deconvbn_3d(cin, cout, gn=False) if kind == "deconv" else S.convbn_3d(cin, cout, 3 if kind == "k3" else 1, 1,
+                                                                                      1 if kind == "k3" else 0)
+        seeded(m, 292)
+        head = S.HipConv3d(cout, 1, kernel_size=1, padding=0, stride=1, bias=False)
+        head.weight.data.copy_(torch.from_numpy(r.standard_normal((1, cout, 1, 1, 1)).astype(np.float32)))
+        x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32))
+        with torch.no_grad():
+            conv = (F.conv_transpose3d(x, m[0].weight, None, 2, 1, 1) if kind == "deconv"
+                    else F.conv3d(x, m[0].weight, None, 1, 1 if kind == "k3" else 0))
+            y = F.batch_norm(conv, m[1].running_mean, m[1].running_var, m[1].weight, m[1].bias, False, 0.0, m[1].eps)
+            res = torch.from_numpy(r.standard_normal(tuple(y.shape)).astype(np.float32))
+            ref0, ref1 = F.conv3d(y, head.weight), F.conv3d(y + res, head.weight)
+            md, hd, xd, rd = m.to(dev()), head.to(dev()), x.to(dev()), res.to(dev())
+            before = S._ROUTES["folded_head"]
+            check(md.fused(xd, head=hd).cpu().numpy(), ref0.numpy(), TIGHT, f"folded {kind} {cin}->{cout}")
+            check(md.fused(xd, residual=rd, head=hd).cpu().numpy(), ref1.numpy(), TIGHT, f"folded {kind} {cin}->{cout} + res")
+            check(md.fused(xd, residual=rd, head=hd, head_residual=hd(rd)).cpu().numpy(), ref1.numpy(), TIGHT,
+                  f"folded {kind} {cin}->{cout} + given head(res)")
+            assert S._ROUTES["folded_head"] == before + 3
+            # parameters change -> the folded layer is rebuilt
+            hd.weight.mul_(0.5)
+            check(md.fused(xd, residual=rd, head=hd).cpu().numpy(), 0.5 * ref1.numpy(), TIGHT, "folded head after an update")
+
+
+def test_side_head_vs_separate_projection():
+    """snvc_conv3d_forward_side_head: y is bit-identical to the plain launch and y_head = head(y); layers that do not
+    qualify get the projection from a launch of their own."""
+    import torch.nn.functional as F
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(391)
+    head = S.HipConv3d(32, 1, kernel_size=1, padding=0, stride=1, bias=False)
+    head.weight.data.copy_(torch.from_numpy(r.standard_normal((1, 32, 1, 1, 1)).astype(np.float32)))
+    m = S.ConvBNReLU3d(seeded(S.convbn_3d(32, 32, 3, 1, 1), 392), torch.nn.ReLU(inplace=True)).to(dev())
+    hd = head.to(dev())
+    for shape, n in (((5, 6, 40), 2), ((4, 4, 156), 1), ((3, 9, 36), 1)):
+        x = torch.from_numpy(r.standard_normal((n, 32) + shape).astype(np.float32)).to(dev())
+        with torch.no_grad():
+            plain = m.fused(x)
+            before = S._ROUTES["side_head"]
+            y, hy = m.fused(x, side_head=hd)
+            assert S._ROUTES["side_head"] == before + 1, "the side-head launch must be taken for a 32->32 k3 layer"
+            assert torch.equal(y, plain)
+            check(hy.cpu().numpy(), F.conv3d(plain.cpu(), head.weight.cpu()).numpy(), TIGHT, f"side head {shape}")
+    with torch.no_grad():   # rows of 8-byte pieces (W % 4 == 2) and 64 output channels: projection in its own launch
+        x = torch.from_numpy(r.standard_normal((1, 32, 4, 4, 38)).astype(np.float32)).to(dev())
+        y, hy = m.fused(x, side_head=hd)
+        assert torch.equal(y, m.fused(x)) and torch.equal(hy, hd(y))
 
 
 def test_train_mode_batchnorm_matches_torch():
@@ -910,6 +995,12 @@ def test_global_pair_end_to_end_vs_oracle(tile):
         assert np.array_equal(ops.cost_volume_forward_right(dr, dsh).cpu().numpy(), vol_ref[:, C:])
         # first layer alone: factored == full convolution over the concat volume
         full1 = ours.conv1(torch.from_numpy(vol_ref).to(dev())).cpu().numpy()
+    from snvc_amd.models import submodule as S
+    if tile == "default":   # the folded tail and conv2's side head are what forward_pair runs on
+        with torch.no_grad():
+            b_f, b_s = S._ROUTES["folded_head"], S._ROUTES["side_head"]
+            ours.forward_pair(dl, dr, dsh, 1)
+            assert (S._ROUTES["folded_head"], S._ROUTES["side_head"]) == (b_f + 1, b_s + 1)
     check(got_full, exp, 1e-4, "pair (materialised)")
     check(got_fact, exp, 1e-4, "pair (factored)")
     check(got_fact, got_full, 2e-5, "factored vs materialised")

@@ -71,6 +71,17 @@ def _worker(rank, world, port, q):
         g = [torch.zeros_like(head.weight.grad) for _ in range(world)]
         dist.all_gather(g, head.weight.grad)
         assert torch.equal(g[0], g[1]) and g[0].abs().sum() > 0
+        # a parameter without a gradient on ANY rank stays without one (as DDP / a single process leave it)
+        unused = torch.nn.Linear(2, 2)
+        for p in params:
+            p.grad = None
+        net(mine).pow(2).sum().backward()
+        P.all_reduce_gradients(params + list(unused.parameters()), average=True)
+        assert unused.weight.grad is None and unused.bias.grad is None and head.weight.grad is None
+        assert all(p.grad is not None for p in net.parameters())
+        # the synthetic-bucket timer runs on any backend (gloo has no reduce-scatter: "auto" stays on all_reduce)
+        us, used = P.all_reduce_bucket(1 << 16, "cpu", reps=2)
+        assert used == "all_reduce" and us > 0
         q.put((rank, "ok"))
     finally:
         dist.destroy_process_group()
