@@ -4,6 +4,7 @@
     python bench.py --gpus N --steps K --warmup W            (starts N ranks itself when N > 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --gpus N --mode train                    (cfg4: fwd + bwd + RCCL gradient all-reduce)
+    python bench.py --gpus N --config cfg3                   (BASELINE configs[2]: 64 RoI crops 96^3 sharded over N ranks)
 
 Workload (N=1): BASELINE.json configs[1], "Global scene model: 1242x375, 192 disparities, full 3D
 hourglass fwd, batch=1 on 1 MI355X", synthesised as SURVEY.md section 8(d) cfg2:
@@ -119,7 +120,7 @@ def cpu_baseline(d_sample=D):
 
 
 # ------------------------------------------------------------------------------------------ helpers
-def timed_ms(fn, reps=3, warm=2):
+def timed_ms(fn, reps=20, warm=10):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -162,18 +163,10 @@ def projected_coordinates(n, grid, device, res=256.0):
     return GridProjector(cfg).generate(samples, P2, P3, tl, tr, device)
 
 
-def local_config(name, grid, F, crops, device, reps=3, heads=False, precision="f32"):
+def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="f32"):
     """gather + 3D trunk of the local (V-A) model on `crops` RoI crops; returns the `configs` entry.
     precision "f16": the fp16-storage mode (C8 half activations / weights, fp32 accumulate; BASELINE configs[4])."""
-    from snvc_amd.models.vernier import VernierScale
-    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False,
-                                grid_resolution=[32, grid[1], 192], resolution=(256, 256),
-                                x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
-    cfg.hrfeat = types.SimpleNamespace(output_channel=F, name="identity")
-    cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
-    m = VernierScale(cfg)
-    m.load_state_dict(seeded_state(m))
-    m.eval().to(device)
+    m = local_model(grid, F, device)
     r = np.random.default_rng(5)
     v = grid[0] * grid[1] * grid[2]
     lf = torch.from_numpy(r.standard_normal((crops, F, 64, 64)).astype(np.float32)).to(device)
@@ -228,6 +221,79 @@ def local_config(name, grid, F, crops, device, reps=3, heads=False, precision="f
     return out
 
 
+def local_model(grid, F, device):
+    from snvc_amd.models.vernier import VernierScale
+    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False,
+                                grid_resolution=[32, grid[1], 192], resolution=(256, 256),
+                                x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
+    cfg.hrfeat = types.SimpleNamespace(output_channel=F, name="identity")
+    cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
+    m = VernierScale(cfg)
+    m.load_state_dict(seeded_state(m))
+    return m.eval().to(device)
+
+
+def run_cfg3(rank, world, device, dist, steps, warmup, barrier, total=64, per_call=8, gather=True):
+    """BASELINE configs[2]: `total` object-centric RoI crops (96^3 voxels, F = 32) sharded over the ranks on dim 0
+    (snvc_amd.parallel.shard: what replaces DataParallel's scatter, tools/inference_agnostic.py:472); every rank runs
+    feature->voxel gather + the 3D trunk on ITS crops, `per_call` at a time, with no data-path collective; the per-crop
+    occupancy volumes are optionally all-gathered at the end of a step (DataParallel's gather).  A step = all `total`
+    crops; crops/s is barrier to barrier, max over ranks."""
+    from snvc_amd import parallel as P
+    grid, F = (96, 96, 96), 32
+    m = local_model(grid, F, device)
+    v = grid[0] * grid[1] * grid[2]
+    lo, hi = P.shard_range(total, rank, world)
+
+    def crop_inputs(i):     # seeded per crop: every rank could draw any crop, each draws only its own
+        r = np.random.default_rng(4321 + i)
+        return (r.standard_normal((F, 64, 64)).astype(np.float32), r.standard_normal((F, 64, 64)).astype(np.float32),
+                r.uniform(-8, 264, (2, v)).astype(np.float32), r.uniform(-8, 264, (2, v)).astype(np.float32))
+    mine = [crop_inputs(i) for i in range(lo, hi)]
+    lf, rf, gl, gr = (torch.from_numpy(np.stack([c[k] for c in mine])).to(device) if mine else
+                      torch.empty((0,) + s_, device=device) for k, s_ in enumerate(((F, 64, 64), (F, 64, 64), (2, v), (2, v))))
+    del mine
+
+    def step():
+        occ = []
+        for a in range(0, hi - lo, per_call):
+            b = min(a + per_call, hi - lo)
+            bev, oc = m.trunk_3d(m.construct_voxel(lf[a:b], rf[a:b], gl[a:b], gr[a:b]))[:2]
+            occ.append(oc)
+        occ = torch.cat(occ) if occ else torch.empty((0,) + grid, device=device)
+        return P.gather_outputs(occ, total) if gather else occ
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            out = step()
+        gc.collect()
+        gc.disable()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gc.enable()
+    if dist is not None and world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all() and (not gather or out.shape[0] == total)
+    res = {"workload": f"cfg3: {total} RoI crops {grid[0]}x{grid[1]}x{grid[2]}, F={F} (voxel volume [n,64,96,96,96]), "
+                       f"feature->voxel gather + 3D trunk (BEV_type3), sharded on dim 0 over {world} rank(s), "
+                       f"{per_call} crops per call",
+           "crops_total": total, "crops_this_rank": hi - lo, "crops_per_call": per_call,
+           "crops_per_s": total * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+           "ms_per_crop_per_gpu": 1e3 * elapsed / steps / max(hi - lo, 1),
+           "step_tflops_algorithmic": total * 1907.3e9 / (elapsed / steps) / 1e12,
+           "outputs_gathered": "occupancy [64,96,96,96] all-gathered per step" if (gather and world > 1) else "none (one rank)",
+           "steps": steps}
+    del m, lf, rf, gl, gr, out
+    torch.cuda.empty_cache()
+    return res
+
+
 class TrainStep:
     """cfg4: build_cost_volume + GlobalStack forward (train-mode BatchNorm), loss = mean(cost^2), backward through
     the HIP kernels, then the flat-bucket gradient all-reduce (RCCL when world > 1)."""
@@ -254,7 +320,7 @@ class TrainStep:
         self.ev[1].record()
         loss.backward()
         self.ev[2].record()
-        self.moved = P.all_reduce_gradients(self.model.parameters())
+        self.moved = P.all_reduce_gradients(self.model.parameters(), force=True)   # one rank too: RCCL really runs
         self.ev[3].record()
         return loss
 
@@ -291,6 +357,14 @@ def run_train(rank, world, device, dist, steps, warmup, barrier):
         "fwd_ms": f, "bwd_ms": b, "allreduce_us": 1e3 * r, "allreduce_bytes": ts.moved, "params": ts.nparam,
         "step_tflops_algorithmic": 3 * STEP_FLOP / (elapsed / steps) / 1e12, "steps": steps,
     }
+    if dist is not None:
+        # the collective alone on synthetic buckets: the 3D stack's gradients and SURVEY.md 8(d)'s 133.5 MB full model,
+        # as one all-reduce and as reduce-scatter + all-gather (what `algorithm="auto"` picks from 8 MB on)
+        from snvc_amd import parallel as P
+        sizes = {"stack": ts.nparam * 4, "full_model_133p5MB": 133_500_000}
+        res["collective_us"] = {f"{k}_{algo}": P.all_reduce_bucket(nb, device, algorithm=algo, reps=5)[0]
+                                for k, nb in sizes.items() for algo in ("all_reduce", "rs_ag")}
+        res["collective_backend"] = f"{dist.get_backend()} x{dist.get_world_size()}"
     del ts
     torch.cuda.empty_cache()
     return res
@@ -327,6 +401,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer: the headline metric (+ extras); train: cfg4 step as the headline value")
+    ap.add_argument("--config", choices=["cfg2", "cfg3"], default="cfg2",
+                    help="cfg2: the headline (BASELINE configs[1]); cfg3: 64 RoI crops sharded over the ranks (configs[2])")
+    ap.add_argument("--crops", type=int, default=64, help="cfg3: crops per step over all ranks")
+    ap.add_argument("--crops-per-call", type=int, default=8)
+    ap.add_argument("--no-gather", action="store_true", help="cfg3: skip the all-gather of the occupancy volumes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the `configs` / `train` legs")
     ap.add_argument("--breakdown", action="store_true", help="per-layer timing on stderr (extra untimed pass)")
@@ -344,6 +423,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    rccl_note = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -352,13 +432,28 @@ def main():
         joined = dist.get_world_size()      # ranks that actually joined the RCCL group
     else:
         joined = 1
+        # one rank: still a real RCCL group, so that the gradient collective of the `train` leg runs through
+        # RCCL on this GPU (allreduce_bytes != 0) and the init path the N > 1 runs take is exercised
+        try:
+            import torch.distributed as dist_mod
+            if "MASTER_PORT" not in os.environ:
+                s_ = socket.socket()
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+                s_.close()
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist_mod.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            dist = dist_mod
+            rccl_note = "one-rank nccl (RCCL) group"
+        except Exception as e:      # never take the headline down
+            rccl_note = f"one-rank RCCL group failed: {type(e).__name__}: {e}"
 
     from snvc_amd.extension.build_cost_volume import build_cost_volume
     from snvc_amd.models.stereo_volume import GlobalStack
 
     def barrier():
         torch.cuda.synchronize()
-        if dist is not None:
+        if dist is not None and world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -373,6 +468,22 @@ def main():
                 "config": {"workload": tr["workload"], "sharding": f"batch x{world}; RCCL all-reduce of "
                            f"{tr['allreduce_bytes']} gradient bytes per step"},
                 "train": tr}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    if args.config == "cfg3":
+        c3 = run_cfg3(rank, world, device, dist, args.steps, args.warmup, barrier, args.crops, args.crops_per_call,
+                      not args.no_gather)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "RoI-crops/sec (feature->voxel gather + 3D trunk fwd, 96^3 crops)",
+                "value": c3["crops_per_s"], "unit": "RoI-crops/s", "n_gpus": joined, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": c3["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": c3["workload"], "sharding": f"{args.crops} crops on dim 0 over {world} rank(s), "
+                           "no data-path collective; " + c3["outputs_gathered"]},
+                "cfg3": c3}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -542,7 +653,7 @@ def main():
             line["train"] = tr
         if world == 1:
             cfgs = {}
-            for name, grid, F, crops, heads, prec in (("cfg3_crops_96", (96, 96, 96), 32, 2, False, "f32"),
+            for name, grid, F, crops, heads, prec in (("cfg3_crops_96", (96, 96, 96), 32, 8, False, "f32"),
                                                       ("released_32x128x192", (32, 128, 192), 32, 2, True, "f32"),
                                                       ("released_32x128x192_f16", (32, 128, 192), 32, 2, True, "f16"),
                                                       ("cfg5_highres_80x160x160", (80, 160, 160), 64, 1, False, "f16"),
@@ -551,6 +662,10 @@ def main():
                     cfgs[name] = local_config(name, grid, F, crops, device, heads=heads, precision=prec)
                 except Exception as e:  # an extra must never take the headline down with it
                     cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
+            try:        # BASELINE configs[2] as the N > 1 runs shard it (`--config cfg3`), here all 64 crops on one rank
+                cfgs["cfg3_64crops_sharded"] = run_cfg3(rank, world, device, dist, 2, 1, barrier)
+            except Exception as e:
+                cfgs["cfg3_64crops_sharded"] = {"error": f"{type(e).__name__}: {e}"}
             cfgs["cfg4_train_step"] = {k: tr[k] for k in ("ms_per_step", "fwd_ms", "bwd_ms", "step_tflops_algorithmic")}
             try:        # its dominant launch: the Winograd-domain weight gradient of a 32->32 layer on the full grid
                 from snvc_amd import ops                     # (conv1's right half, conv2, the classifier: 3 per step)
@@ -569,6 +684,14 @@ def main():
             except Exception as e:
                 cfgs["cfg4_train_step"]["dominant_error"] = f"{type(e).__name__}: {e}"
             line["configs"] = cfgs
+            g3 = cfgs.get("cfg3_crops_96", {}).get("gather_projected")
+            if g3:      # north_star's ">= 60 % HBM roofline on the warp/gather": the gather beside the cost-volume builders
+                line["roofline_hbm"]["gather"] = {
+                    "kernel": "voxel_gather_fwd_lds: _sample_2d_feat on 8 crops 96^3, F=32, GridProjector coordinates",
+                    "achieved": g3["GBps"], "frac": g3["frac_hbm"], "avg_launch_ms": g3["ms"],
+                    "bytes_per_launch": cfgs["cfg3_crops_96"]["gather_bytes_algorithmic"]}
+            if rccl_note:
+                line["train"]["rccl"] = rccl_note
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()

@@ -1047,9 +1047,9 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
     }
     if constexpr (HEAD) {
         static_assert(V4, "the side head stores 16-byte pieces");
-        float hw[16];
+        float hw[16];     // parked in LDS behind scale | bias at kernel start (a global load here is an exposed round trip)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hw[r] = a.head_w[cbase + (r & 3) + 8 * (r >> 2) + 4 * half];
+        for (int r = 0; r < 16; ++r) hw[r] = aff[64 + (r & 3) + 8 * (r >> 2) + 4 * half];
         char *const yh = reinterpret_cast<char *>(a.y_head + job.n * (int64_t)out_dhw);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -1232,6 +1232,8 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
         float v = tid < 32 ? 1.0f : 0.0f;
         if (a.scale) v = (tid < 32 ? a.scale : a.bias)[job.cg * 32 + (tid & 31)];   // Cout % 32 == 0 (host)
         aff[tid] = v;
+    } else if (HEAD && tid < 96) {
+        aff[tid] = a.head_w[job.cg * 32 + (tid - 64)];
     }
     __syncthreads();
     for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -2046,7 +2048,7 @@ void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
 
 template <class Cfg, bool RES, bool PLANE, bool HEAD = false>
 void launch_wino_dma_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
+    constexpr int BYTES = Cfg::LDS_BYTES + (HEAD ? 384 : 256);   // + (scale | bias [| head weights]) of 32 channels
     static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
     if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE, HEAD>), BYTES, attr_done)) return;
     conv3d_wino_dma_kernel<Cfg, RES, PLANE, HEAD><<<grid, 256, BYTES, st>>>(a);

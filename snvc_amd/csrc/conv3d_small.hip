@@ -52,24 +52,42 @@ deconv3d_cout1_kernel(const float *__restrict__ x, const float *__restrict__ w, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[a][b][j] = 0.0f;
 
-#pragma unroll 2
-    for (int c = 0; c < Cin; ++c) {
+    // Software pipeline: the 8 loads of channel c+1 are issued before channel c's 108 FMAs (the scheduler, left alone,
+    // sinks every load to its first use and waits for each one: 8 exposed round trips per channel, 122 us on cfg2).
+    struct Raw {
+        f32x4 v[2][2];
+        float nb[2][2];
+    };
+    auto issue = [&](int c, Raw &r) {
         const float *pc = p0 + c * in_dhw;
-        const float *wc = w + c * 27;   // wave-uniform: scalar loads
-        float X[2][2][5];
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 const float *pr = pc + (dd ? od : 0) + (hh ? oh : 0);
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(pr);
-                const float nb = pr[on];
+                r.v[dd][hh] = *reinterpret_cast<const f32x4 *>(pr);
+                r.nb[dd][hh] = pr[on];
+            }
+    };
+    Raw cur;
+    issue(0, cur);
+    for (int c = 0; c < Cin; ++c) {
+        Raw nxt;
+        issue(c + 1 < Cin ? c + 1 : c, nxt);     // the last iteration re-reads its own channel (no branch, discarded)
+        const float *wc = w + c * 27;            // wave-uniform: scalar loads
+        float wk[27];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) wk[k] = wc[k];
+        __builtin_amdgcn_sched_barrier(0);
+        float X[2][2][5];
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
                 const bool ok = (dd == 0 || d1) && (hh == 0 || h1);
-                X[dd][hh][0] = ok ? v[0] : 0.0f;
-                X[dd][hh][1] = ok ? v[1] : 0.0f;
-                X[dd][hh][2] = ok ? v[2] : 0.0f;
-                X[dd][hh][3] = ok ? v[3] : 0.0f;
-                X[dd][hh][4] = (ok && w1) ? nb : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) X[dd][hh][j] = ok ? cur.v[dd][hh][j] : 0.0f;
+                X[dd][hh][4] = (ok && w1) ? cur.nb[dd][hh] : 0.0f;
             }
 #pragma unroll
         for (int pd = 0; pd < 2; ++pd)
@@ -81,8 +99,8 @@ deconv3d_cout1_kernel(const float *__restrict__ x, const float *__restrict__ w, 
                     for (int jh = 0; jh <= ph; ++jh) {
                         // parity 0: (tap 1, offset 0); parity 1: j = 0 -> (tap 2, offset 0), j = 1 -> (tap 0, offset 1)
                         const int kd = pd ? (jd ? 0 : 2) : 1, kh = ph ? (jh ? 0 : 2) : 1;
-                        const float w0 = wc[(kd * 3 + kh) * 3 + 0], w1k = wc[(kd * 3 + kh) * 3 + 1],
-                                    w2 = wc[(kd * 3 + kh) * 3 + 2];
+                        const float w0 = wk[(kd * 3 + kh) * 3 + 0], w1k = wk[(kd * 3 + kh) * 3 + 1],
+                                    w2 = wk[(kd * 3 + kh) * 3 + 2];
                         const float(&r)[5] = X[jd][jh];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -91,6 +109,8 @@ deconv3d_cout1_kernel(const float *__restrict__ x, const float *__restrict__ w, 
                                 __builtin_fmaf(r[j + 1], w0, __builtin_fmaf(r[j], w2, acc[pd][ph][2 * j + 1]));
                         }
                     }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
 
     const float sc = scale ? scale[0] : 1.0f, bi = scale ? bias[0] : 0.0f;

@@ -40,15 +40,32 @@ class GlobalStack(nn.Module):
         """Inference workspace: the three full-resolution intermediates (warped half-volume, conv1 / conv2 outputs,
         0.74 GB each at cfg2) are kept across calls instead of going through the caching allocator every step -- with
         GB-sized blocks that are split and re-merged, a steady-state step can land on a fresh hipMalloc (tens of ms).
-        They never escape ``forward`` / ``forward_pair`` (the result is the head's own small tensor)."""
+        They never escape ``forward`` / ``forward_pair`` (the result is the head's own small tensor).
+        One buffer per (name, device): replicas on different devices keep their own.  Single-stream: the buffers
+        are not tracked by the caching allocator's stream bookkeeping, so calls on two streams of one device would
+        alias them.  ``release_workspace()`` / ``invalidate_plans(model)`` / ``train()`` give the memory back."""
         ws = self.__dict__.setdefault("_snvc_ws", {})
         key = (name, tuple(shape), device)
         buf = ws.get(key)
         if buf is None:
-            for k in [k for k in ws if k[0] == name]:
+            for k in [k for k in ws if k[0] == name and k[2] == device]:
                 del ws[k]
             buf = ws[key] = torch.empty(shape, dtype=torch.float32, device=device)
         return buf
+
+    def release_workspace(self):
+        """Drop the persistent inference workspace (2.2 GB at cfg2)."""
+        self.__dict__.pop("_snvc_ws", None)
+
+    def train(self, mode: bool = True):
+        if mode:
+            self.release_workspace()
+        return super().train(mode)
+
+    def __getstate__(self):          # copy.deepcopy / torch.save(model): the workspace is scratch, not state
+        state = self.__dict__.copy()
+        state.pop("_snvc_ws", None)
+        return state
 
     def _tail(self, v, hv=None):
         """v + hourglass(v)[0] -> classifier.  The hourglass's last transposed layer has no activation

@@ -64,10 +64,16 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
         _GENERATION[0] += 1
         return
     for m in module.modules():
-        m.__dict__.pop("_snvc_plans", None)
-        m.__dict__.pop("_snvc_plans_f16", None)
-        m.__dict__.pop("_snvc_plans2d", None)
-        m.__dict__.pop("_snvc_factored", None)
+        for name in CACHE_ATTRS:
+            m.__dict__.pop(name, None)
+
+
+# Every per-module cache this package hangs on a module's __dict__ (packed weights, folded norms, the factored first
+# convolution's split weights for inference and training, the persistent inference workspace, the device copy of the
+# coordinate maps).  invalidate_plans() drops exactly these; tests/test_host_cpu.py checks that no other `_snvc_*`
+# name is written anywhere in the package.
+CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans2d", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
+               "_snvc_coor_maps")
 
 
 class _Plan:
@@ -497,8 +503,10 @@ def fused_conv3d_f16(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor
     ``out`` are C8 half tensors (``ops.to_c8``), the parameters stay fp32 ``nn.Parameter``s and are rounded to half
     when packed, BatchNorm must be in eval mode (folded into the fp32 epilogue).  A one-output-channel layer
     (the occupancy head) returns its result as a float32 ``[N,1,D,H,W]`` tensor."""
-    if torch.is_grad_enabled() and (conv.weight.requires_grad and x.requires_grad):
-        raise NotImplementedError("the fp16-storage mode is inference only")
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in (conv, norm) if m is not None
+                                                           for p in m.parameters())):
+        raise NotImplementedError("the fp16-storage mode is inference only: call it under torch.no_grad() "
+                                  "(or freeze the parameters); nothing here has a backward pass")
     if norm is not None and not (isinstance(norm, nn.BatchNorm3d) and not norm.training and norm.running_mean is not None):
         raise NotImplementedError("the fp16-storage mode needs eval-mode BatchNorm3d (GroupNorm / batch statistics: fp32 path)")
     if conv.weight.device != x.device:
@@ -676,11 +684,21 @@ class hourglass_downsample_16(nn.Module):
 # folded norm, the conv bias, residual adds, ReLU and Sigmoid in the conv epilogue.  Training and GroupNorm take
 # the modules' own torch forward.
 # ------------------------------------------------------------------------------------------
-def _hip_2d_ok(x: torch.Tensor, *norms) -> bool:
-    """The HIP path of the 2D neck: a float32 GPU tensor, no autograd graph, every norm an eval-mode BatchNorm2d."""
-    if not (x.is_cuda and x.dtype == torch.float32) or (torch.is_grad_enabled() and x.requires_grad):
-        return False
-    return all(n is None or (isinstance(n, nn.BatchNorm2d) and not n.training and n.running_mean is not None) for n in norms)
+def _hip_2d_ok(x: torch.Tensor, *modules) -> bool:
+    """The HIP path of the 2D neck (kernels without a backward): a float32 GPU tensor, every norm of ``modules`` an
+    eval-mode BatchNorm2d, and NOTHING to differentiate -- autograd off, or neither the input nor any parameter of the
+    modules requires grad (a frozen trunk with trainable heads must keep the torch forward, or the heads would
+    silently get no gradient).  Every decision is counted in ``_ROUTES`` ("neck2d_hip" / "neck2d_torch")."""
+    if not x.is_cuda:
+        raise RuntimeError("2D neck input must be a GPU tensor: Not implemented on the CPU")
+    ok = x.dtype == torch.float32
+    if ok and torch.is_grad_enabled():
+        ok = not (x.requires_grad or any(p.requires_grad for m in modules for p in m.parameters()))
+    if ok:
+        ok = all(isinstance(n, nn.BatchNorm2d) and not n.training and n.running_mean is not None
+                 for m in modules for n in _norms2d(m))
+    _ROUTES["neck2d_hip" if ok else "neck2d_torch"] += 1
+    return ok
 
 
 def _plan2d(conv: nn.Module, device) -> _Plan:
@@ -800,7 +818,7 @@ class hourglass2d(nn.Module):
         self.conv6 = _deconvbn_2d(c * 2, c, gn)
 
     def forward(self, x, presqu, postsqu):
-        if _hip_2d_ok(x, *_norms2d(self)):
+        if _hip_2d_ok(x, self):
             out = _cbr2d(self.conv1, x)
             pre = _cbr2d(self.conv2, out, relu=True, residual=postsqu)              # relu(bn(conv) [+ postsqu])
             out = _cbr2d(self.conv4, _cbr2d(self.conv3, pre))
@@ -834,7 +852,7 @@ class hourglass2d_downsample_16(nn.Module):
         self.conv12 = get_hg_up_sample_2d(c * 2, c, gn)
 
     def forward(self, x):
-        if _hip_2d_ok(x, *_norms2d(self)):
+        if _hip_2d_ok(x, self):
             o2 = _cbr2d(self.conv2, _cbr2d(self.conv1, x))
             o4 = _cbr2d(self.conv4, _cbr2d(self.conv3, o2))
             o6 = _cbr2d(self.conv6, _cbr2d(self.conv5, o4))
@@ -867,7 +885,7 @@ class BasicBlock2d(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        if _hip_2d_ok(x, *_norms2d(self)):
+        if _hip_2d_ok(x, self):
             residual = x if self.downsample is None else fused_conv2d(self.downsample[0], self.downsample[1], x)
             out = fused_conv2d(self.conv1, self.bn1, x, relu=True)
             return fused_conv2d(self.conv2, self.bn2, out, relu=True, residual=residual)     # relu(bn2(conv2) + residual)

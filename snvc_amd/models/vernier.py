@@ -221,8 +221,8 @@ class VernierScale(nn.Module):
         """reference vernier.py:440-450.  Inference with eval-mode BatchNorm runs every convolution of the neck
         (conv5, hm1, hm2, the coordinate head's blocks and its last full-extent layer) on the depth-1 HIP kernels
         with fused norm / bias / residual / ReLU / Sigmoid epilogues; otherwise the modules' torch forward."""
-        from .submodule import _hip_2d_ok, _norms2d, _cbr2d, fused_conv2d
-        hip = _hip_2d_ok(voxel_BEV, *_norms2d(self.conv5), *_norms2d(self.hm1), *_norms2d(self.coord_head))
+        from .submodule import _hip_2d_ok, _cbr2d, fused_conv2d
+        hip = _hip_2d_ok(voxel_BEV, self.conv5, self.hm1, self.hm2, self.coord_head)
         voxel_BEV = _cbr2d(self.conv5, voxel_BEV) if hip else self.conv5(voxel_BEV)
         if self.small:
             heatmap_feats = self.hm1(voxel_BEV, None, None)[0].permute(0, 1, 3, 2)
@@ -232,9 +232,9 @@ class VernierScale(nn.Module):
         num_sample = len(heatmaps)
         # the coordinate maps are a plain attribute in the reference (not in the state dict): one device copy is kept,
         # so that no host -> device copy sits in the middle of the neck (and of a captured graph)
-        cm = getattr(self, "_coor_maps_dev", None)
+        cm = self.__dict__.get("_snvc_coor_maps")
         if cm is None or cm.device != heatmaps.device:
-            cm = self._coor_maps_dev = self.coor_maps.to(heatmaps.device)
+            cm = self.__dict__["_snvc_coor_maps"] = self.coor_maps.to(heatmaps.device)
         coor_maps = cm.repeat(num_sample, 1, 1, 1)
         augmented_maps = torch.cat([heatmaps, coor_maps], dim=1)
         last = self.coord_head[-2]

@@ -833,8 +833,14 @@ def test_vernier_scale_vs_golden(name, G):
     assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == ref_keys
     seeded(m, seed).to(dev())
     lf, rf, gpl, gpr = GC.trunk_inputs(n, 32, fh, fw, grid, seed + 1)
+    from snvc_amd.models import submodule as S
     with torch.no_grad():
+        hip0, torch0 = S._ROUTES["neck2d_hip"], S._ROUTES["neck2d_torch"]
         out = m(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()))
+        # the 2D neck + heads ran on the HIP kernels (eval BatchNorm) or, under GroupNorm, on the modules' torch forward:
+        # never a silent mix
+        hip1, torch1 = S._ROUTES["neck2d_hip"], S._ROUTES["neck2d_torch"]
+        assert (hip1 > hip0 and torch1 == torch0) if not gn else (torch1 > torch0 and hip1 == hip0)
         vox = m.construct_voxel(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()))
         bev, occ5, _ = m.trunk_3d(vox)
         idx, conf = m.ncf_argmax(out["ncf"])

@@ -79,6 +79,37 @@ def test_no_cpu_fallback():
         m(torch.zeros(1, 4, 4, 4, 8))
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         ops.argmax_rows(torch.zeros(2, 5))
+    # the 2D neck has no CPU route either (its torch forward is for autograd / GroupNorm on the GPU)
+    for blk, x in ((S.hourglass2d(4).eval(), torch.zeros(1, 4, 8, 8)), (S.BasicBlock2d(4, 4).eval(), torch.zeros(1, 4, 8, 8)),
+                   (S.hourglass2d_downsample_16(4).eval(), torch.zeros(1, 4, 16, 16))):
+        with torch.no_grad(), pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+            blk(x, None, None) if isinstance(blk, S.hourglass2d) else blk(x)
+
+
+def test_invalidate_plans_clears_every_cache():
+    """Every `_snvc_*` attribute the package writes on a module is one of submodule.CACHE_ATTRS, and
+    invalidate_plans(module) drops them all (a stale split-weight cache of the factored first convolution would keep
+    running old weights after a broadcast / `.data` swap)."""
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    written = set()
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "snvc_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                written |= set(re.findall(r"[\"\'](_snvc_\w+)[\"\']", open(os.path.join(dirpath, f)).read()))
+    assert written and written <= set(S.CACHE_ATTRS), written - set(S.CACHE_ATTRS)
+    m = GlobalStack(4)
+    for i, mod in enumerate(m.modules()):
+        for name in S.CACHE_ATTRS:
+            mod.__dict__[name] = {"stale": i}
+    S.invalidate_plans(m)
+    assert not any(k.startswith("_snvc_") for mod in m.modules() for k in mod.__dict__)
+    # the persistent inference workspace is scratch: not pickled / deep-copied, dropped by train()
+    import copy
+    m.__dict__["_snvc_ws"] = {("v1", (1,), "cpu"): torch.zeros(1)}
+    assert "_snvc_ws" not in copy.deepcopy(m).__dict__
+    m.train()
+    assert "_snvc_ws" not in m.__dict__
 
 
 def test_product_never_imports_the_oracle():
