@@ -1336,6 +1336,155 @@ conv3d_winok_kernel(const ConvArgs a) {
     wino_epilogue<Cfg, RES, false>(a, job, acc, aff, lane, wave);
 }
 
+// ------------------------------------------------------------------------------------ k3 / stride 2, slice-pipelined refill (r3)
+// conv3d_winok_kernel<WinoS2Cfg> refills its single-buffered 44 KB image once per 2-channel chunk, after the chunk's last
+// MFMA and in front of a barrier that drains the DMA: ~2 us of exposed refill per 2.2 us of MFMAs, which the second
+// resident workgroup can only partly fill (pipe 0.54-0.59).  A second image buffer would cost that second workgroup.
+// This form keeps ONE buffer and refills it SLICE BY SLICE as the depth phases release the slices:
+//   wave w owns output depth w and reads input depth 2w + kd, so phase kd = 0 reads depth slices {0,2,4,6}, kd = 2 reads
+//   {2,4,6,8} and kd = 1 reads {1,3,5,7}.  With the phases ordered A = kd 0, B = kd 2, C = kd 1:
+//     start of A(c): issue the weights of chunk c+1 and the ODD slices of chunk c (last read in C(c-1));
+//     start of B(c): issue slice 0 of chunk c+1 (only A reads it);
+//     start of C(c): issue slices 2, 4, 6 and then 8 of chunk c+1 (B was their last reader);
+//   so every slice has at least one full phase (27 MFMAs per wave = 1.7k cycles) of MFMAs between its issue and its first
+//   use, the odd ones two.  LDS-DMA stays in flight across s_barrier; a phase ends with a COUNTED `s_waitcnt vmcnt(N)`
+//   that only waits for the pieces the next phase reads, followed by s_barrier (hipcc's __syncthreads() would wait for
+//   vmcnt(0)).  vmcnt(N) guarantees everything but the wave's N youngest operations: N is the SMALLEST number of DMA
+//   instructions any wave issues after the pieces in question (waves that issued more just wait for a few of those too).
+// DMA instructions are whole: the LDS image is [depth slice][channel][640 floats] (a 9 x 68 channel plane padded from
+// 612 to 640 floats), so a slice is exactly 5 x 64 pieces of 16 bytes -- wave w issues instruction w of every slice,
+// wave dd % 4 also instruction 4 of slice dd -- and the 864-piece weight block of a chunk goes as 14 whole instructions
+// (the last one overlaps its predecessor by half: same bytes to the same place).  No lane predicates anywhere near a DMA
+// (a divergent `if` around one lets the compiler duplicate its neighbours into both arms, which changes the count).
+template <int STORE_PIECE_ = 4>
+struct WinoS2PipeCfg : WinoS2Cfg<2, STORE_PIECE_> {
+    using Base = WinoS2Cfg<2, STORE_PIECE_>;
+    static constexpr int PLANE = Base::IN_H * Base::IN_WV;      // 612 floats of a channel's rows in one depth slice
+    static constexpr int CH = 640;                               // channel stride inside a depth slice (padded)
+    static constexpr int DSLICE = Base::KC * CH;                 // 1280 floats = 320 pieces = 5 DMA instructions
+    static constexpr int WBLK = 3 * Base::WF;                    // 3456 floats = 864 pieces
+    static constexpr int LDS_BYTES = (Base::IN_D * DSLICE + 2 * WBLK) * 4;
+    static_assert(CH >= PLANE && CH % 4 == 0 && DSLICE == 5 * 256 && WBLK / 4 > 13 * 64 - 64 && WBLK / 4 <= 14 * 64, "piece maps");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_then_barrier() {
+    // all but the N youngest vector-memory operations of this wave (here: LDS-DMA instructions) have landed, then the
+    // workgroup barrier makes every wave's landed pieces visible; "memory": the compiler moves no LDS access across
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <class Cfg, bool RES>
+__global__ void __launch_bounds__(256, 2)
+conv3d_winos2_pipe_kernel(const ConvArgs a) {
+    constexpr int KC = Cfg::KC, WF = Cfg::WF, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, RQ = IN_WV / 4, IN_D = Cfg::IN_D;
+    constexpr int CHS = Cfg::CH, PLANE = Cfg::PLANE, DSLICE = Cfg::DSLICE, WBLK = Cfg::WBLK, WPIECES = WBLK / 4;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const WinoJob job = wino_decode_job(a, blockIdx.x, a.njobs, Cfg::TD, Cfg::TH, Cfg::TW);
+
+    f32x16 acc[9][1];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][0][r] = 0.0f;
+
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const float *xn = a.x + job.n * a.x_bs;
+    const int id0 = job.od0 * 2 - 1, ih0 = job.oh0 * 2 - 1, ix0 = job.ow0 * 2 - Cfg::LPAD;
+    // B fragments: lane>>5 = channel of the pair, (lane&31)>>3 = output row, lane&7 = quad; wave = output depth
+    const int bbase = (lane >> 5) * CHS + 2 * wave * DSLICE + 2 * ((lane & 31) >> 3) * IN_WV + 8 * (lane & 7);
+    float *const wlds = lds + IN_D * DSLICE;
+    float *const aff = wlds + 2 * WBLK;
+    const int nchunks = a.nchunks_wino;
+    const float *wg = a.wp_wino + (int64_t)job.cg * nchunks * WBLK;
+
+    // ---- piece maps (constant over slices and chunks).  Piece p of a slice = (channel kc = p / 160, then 16-byte piece
+    // r = p % 160 of that channel's padded plane: row r / 17, column piece r % 17; r >= 153 is padding).
+    // This thread moves piece 64*wave + lane of every slice and piece 256 + lane of the slices with dd % 4 == wave.
+    auto piece_geom = [&](int p, unsigned &off, bool &ok, bool &second) {
+        const int kc = p / (CHS / 4), r = p - kc * (CHS / 4), hh = r / RQ, q = r - hh * RQ;
+        const int gh = ih0 + hh, gw = ix0 + 4 * q;
+        second = kc != 0;
+        ok = r < PLANE / 4 && (unsigned)gh < (unsigned)a.Hin && (unsigned)gw < (unsigned)a.Win;
+        off = ok ? (unsigned)(kc * in_dhw + gh * a.Win + gw) : 0u;
+    };
+    unsigned off_a, off_b;
+    bool ok_a, ok_b, second_a, second_b;
+    piece_geom(64 * wave + lane, off_a, ok_a, second_a);
+    piece_geom(256 + lane, off_b, ok_b, second_b);
+    unsigned dmask = 0;      // depth slices inside the tensor (wave-uniform)
+#pragma unroll
+    for (int dd = 0; dd < IN_D; ++dd) dmask |= ((unsigned)(id0 + dd) < (unsigned)a.Din ? 1u : 0u) << dd;
+
+    auto issue_slice = [&](int chunk, int dd) {
+        const float *xc = xn + (int64_t)chunk * KC * in_dhw + (int64_t)(id0 + dd) * in_hw;
+        const bool dok = (dmask >> dd) & 1u;
+        const bool odd_tail = a.Cin - chunk * KC < KC;        // odd Cin: the last chunk's second channel is zeros
+        float *const dst = lds + dd * DSLICE;
+        const float *sa = (dok && ok_a && !(odd_tail && second_a)) ? xc + off_a : g_zero16;
+        __builtin_amdgcn_global_load_lds(sa, dst + 4 * (64 * wave), 16, 0, 0);
+        if (wave == (dd & 3)) {      // wave-uniform: a scalar branch, every lane of the wave takes part
+            const float *sb = (dok && ok_b && !(odd_tail && second_b)) ? xc + off_b : g_zero16;
+            __builtin_amdgcn_global_load_lds(sb, dst + 4 * 256, 16, 0, 0);
+        }
+    };
+    // weights: instructions 0..13 of 64 pieces; wave w issues w, w+4, w+8 and (w = 0: 12, w = 2: 13); instruction 13
+    // starts at piece WPIECES - 64 (overlapping 12)
+    auto issue_w = [&](int chunk) {
+        const float *wc = wg + (int64_t)chunk * WBLK;
+        float *const wbuf = wlds + (chunk & 1) * WBLK;
+#pragma unroll
+        for (int it = 0; it < 3; ++it)
+            __builtin_amdgcn_global_load_lds(wc + 4 * (it * 256 + tid), wbuf + 4 * (it * 256 + 64 * wave), 16, 0, 0);
+        if (wave == 0) __builtin_amdgcn_global_load_lds(wc + 4 * (768 + lane), wbuf + 4 * 768, 16, 0, 0);
+        if (wave == 2) __builtin_amdgcn_global_load_lds(wc + 4 * (WPIECES - 64 + lane), wbuf + 4 * (WPIECES - 64), 16, 0, 0);
+    };
+    // DMA instructions per wave.  weights: {4,3,4,3}.  slice dd: 1, +1 for wave dd % 4.
+    //   odd slices {1,3,5,7}: {4,6,4,6};  slice 0: {2,1,1,1};  slices {2,4,6}: {4,3,5,3};  slice 8: {2,1,1,1}
+    constexpr int AFTER_SLICE8_MORE = 3 + 4;      // min over waves of weights + odd slices   (end of A, next chunk exists)
+    constexpr int AFTER_SLICE8_LAST = 4;          // min over waves of the odd slices         (end of A, last chunk)
+    constexpr int AFTER_ODD = 1;                  // min over waves of slice 0                (end of B)
+    constexpr int AFTER_EVEN = 1;                 // min over waves of slice 8                (end of C)
+
+    // prologue: weights of chunk 0 and its EVEN slices (the odd ones are issued at the start of phase A like in every chunk)
+    issue_w(0);
+#pragma unroll
+    for (int dd = 0; dd < IN_D; dd += 2) issue_slice(0, dd);
+    if (tid < 64) {
+        float v = tid < 32 ? 1.0f : 0.0f;
+        if (a.scale) v = (tid < 32 ? a.scale : a.bias)[job.cg * 32 + (tid & 31)];   // Cout % 32 == 0 (host)
+        aff[tid] = v;
+    }
+    __syncthreads();       // drains the DMA (vmcnt(0)) and publishes aff
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        const float *wl = wlds + (chunk & 1) * WBLK + lane;
+        // ---- phase A: kd = 0 on slices {0,2,4,6}
+        if (more) issue_w(chunk + 1);
+#pragma unroll
+        for (int dd = 1; dd < IN_D; dd += 2) issue_slice(chunk, dd);
+        winos2_compute_phase<Cfg>(lds + 0 * DSLICE, wl + 0 * WF, bbase, acc);
+        // B reads slice 8 (issued last in C(chunk-1), or by the prologue): everything older than this phase's issues
+        if (more) wait_vmcnt_then_barrier<AFTER_SLICE8_MORE>(); else wait_vmcnt_then_barrier<AFTER_SLICE8_LAST>();
+        // ---- phase B: kd = 2 on slices {2,4,6,8}
+        if (more) issue_slice(chunk + 1, 0);
+        winos2_compute_phase<Cfg>(lds + 2 * DSLICE, wl + 2 * WF, bbase, acc);
+        // C reads the odd slices (issued at the start of A): all but slice 0 of the next chunk
+        if (more) wait_vmcnt_then_barrier<AFTER_ODD>(); else wait_vmcnt_then_barrier<0>();
+        // ---- phase C: kd = 1 on slices {1,3,5,7}
+        if (more) {
+#pragma unroll
+            for (int dd = 2; dd < IN_D; dd += 2) issue_slice(chunk + 1, dd);       // 2, 4, 6, then 8
+        }
+        winos2_compute_phase<Cfg>(lds + 1 * DSLICE, wl + 1 * WF, bbase, acc);
+        // A(chunk+1) reads slices {0,2,4,6} and the next weights: all but slice 8
+        if (more) wait_vmcnt_then_barrier<AFTER_EVEN>();
+    }
+    wino_epilogue<Cfg, RES, false>(a, job, acc, aff, lane, wave);
+}
+
 // ------------------------------------------------------------------------------------ deconv
 // ConvTranspose3d(k=3, s=2, p=1, op=1): out[o] = sum_i sum_t x[i] * w[t], o = 2i - 1 + t.
 // Per dimension, output parity 0 uses tap 1 at input offset 0; parity 1 uses tap 2 at offset 0
@@ -2033,6 +2182,20 @@ void launch_winok_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
 }
 
 template <class Cfg>
+void launch_winos2_pipe(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
+    if (a.res) {
+        static std::atomic<unsigned> attr_done{0};
+        if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_winos2_pipe_kernel<Cfg, true>), BYTES, attr_done)) return;
+        conv3d_winos2_pipe_kernel<Cfg, true><<<grid, 256, BYTES, st>>>(a);
+    } else {
+        static std::atomic<unsigned> attr_done{0};
+        if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_winos2_pipe_kernel<Cfg, false>), BYTES, attr_done)) return;
+        conv3d_winos2_pipe_kernel<Cfg, false><<<grid, 256, BYTES, st>>>(a);
+    }
+}
+
+template <class Cfg>
 void launch_winok(const ConvArgs &a, dim3 grid, hipStream_t st) {
     if (a.res) launch_winok_variant<Cfg, true>(a, grid, st);
     else launch_winok_variant<Cfg, false>(a, grid, st);
@@ -2306,8 +2469,12 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
             const int64_t nj = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w * a.groups * d->N;
             if (nj < ((int64_t)1 << 31)) {
                 a.njobs = (int)nj;
-                if (a.fast_epi) launch_winok<CfgWinoS2>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
-                else launch_winok<CfgWinoS2v8>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                // default: the slice-pipelined refill; SNVC_ALGO_WINO_TILE_STD selects the per-chunk refill form
+                const bool per_chunk = (d->algo & SNVC_ALGO_WINO_TILE_MASK) == SNVC_ALGO_WINO_TILE_STD;
+                if (per_chunk && a.fast_epi) launch_winok<CfgWinoS2>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                else if (per_chunk) launch_winok<CfgWinoS2v8>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                else if (a.fast_epi) launch_winos2_pipe<WinoS2PipeCfg<4>>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                else launch_winos2_pipe<WinoS2PipeCfg<2>>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 return check_launch("snvc_conv3d_forward(winograd stride 2)");
             }
         }

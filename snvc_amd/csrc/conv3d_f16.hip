@@ -393,8 +393,18 @@ using F16K5D2 = F16Cfg<5, 5, 5, 1, 1, 2, 4, 4, 1, 1, false, 2, 2>;
 // (a double-buffered image at one workgroup per CU: 14.3 ms against 9.0 on cfg5's conv1 -- two co-resident workgroups matter)
 using F16K7   = F16Cfg<7, 7, 7, 1, 1, 2, 4, 4, 1, 1, false, 2>;
 using F16DC   = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 0, true, 2>;      // one parity class of ConvTranspose3d(k3,s2,p1,op1)
+// r3: MI = 1 forms for layers with exactly 32 output channels (the released F = 32 model, vernier.py:249-264: every
+// trunk layer but the hourglass's inner ones).  The 64-channel forms above would multiply a second, all-zero weight
+// block (half of the MFMAs wasted: released-shape conv1 ran at 0.27 of the fp16 peak).  Same tiles and images; a wave
+// carries 4 accumulators instead of 8.
+using F16K1N   = F16Cfg<1, 1, 1, 1, 1, 1, 4, 4, 2, 0, true, 2>;
+using F16K3S2N = F16Cfg<3, 3, 3, 2, 1, 1, 2, 4, 1, 1, false, 2>;
+using F16K5N   = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, true, 2>;
+using F16K5D2N = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2>;
+using F16K7N   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2>;
+using F16DCN   = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 0, true, 2>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d;
@@ -423,7 +433,7 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p) {
         if (d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win)
             return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d: transposed output must be 2x the input");
         if (d.Cout == 1) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: transposed conv to one channel");
-        p = plan_from<F16DC>(FDC);
+        p = d.Cout == 32 ? plan_from<F16DCN>(FDCN) : plan_from<F16DC>(FDC);
     } else {
         if (d.pad != d.dilation * (d.ksize - 1) / 2)
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: pad must equal dilation*(ksize-1)/2");
@@ -436,13 +446,14 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p) {
             if (key != 311) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: one-channel output is built for k3/s1 only");
             p = plan_from<F16K3H>(FK3H);
         } else {
+            const bool narrow = d.Cout == 32;      // one 32-channel block: the MI = 1 forms
             switch (key) {
-                case 111: p = plan_from<F16K1>(FK1); break;
-                case 311: p = plan_from<F16K3>(FK3); break;
-                case 321: p = plan_from<F16K3S2>(FK3S2); break;
-                case 511: p = plan_from<F16K5>(FK5); break;
-                case 512: p = plan_from<F16K5D2>(FK5D2); break;
-                case 711: p = plan_from<F16K7>(FK7); break;
+                case 111: p = narrow ? plan_from<F16K1N>(FK1N) : plan_from<F16K1>(FK1); break;
+                case 311: p = narrow ? plan_from<F16K3H>(FK3N) : plan_from<F16K3>(FK3); break;
+                case 321: p = narrow ? plan_from<F16K3S2N>(FK3S2N) : plan_from<F16K3S2>(FK3S2); break;
+                case 511: p = narrow ? plan_from<F16K5N>(FK5N) : plan_from<F16K5>(FK5); break;
+                case 512: p = narrow ? plan_from<F16K5D2N>(FK5D2N) : plan_from<F16K5D2>(FK5D2); break;
+                case 711: p = narrow ? plan_from<F16K7N>(FK7N) : plan_from<F16K7>(FK7); break;
                 default:
                     return fail(SNVC_ERR_UNSUPPORTED,
                                 "snvc_f16_conv3d: (ksize,stride,dilation) not in {(1,1,1),(3,1,1),(3,2,1),(5,1,1),(5,1,2),(7,1,1)}");
@@ -546,7 +557,7 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : (int64_t)d->Cout * out_sp;
     a.yf_bs = out_sp;
     hipStream_t st = as_stream(stream);
-    const bool subgrid = p.kind == FK5D2;      // (depth, height) parity classes share ONE packed weight block
+    const bool subgrid = p.kind == FK5D2 || p.kind == FK5D2N;      // (depth, height) parity classes share ONE packed weight block
     const int classes = d->transposed ? 8 : (subgrid ? 4 : 1);
     a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
     a.N = d->N; a.cls_mode = d->transposed ? 1 : (subgrid ? 2 : 0); a.cls_wstride = f16_class_stride(p);
@@ -579,6 +590,13 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
         case FK5D2: launch_f16<F16K5D2, 0>(a, grid, st); break;
         case FK7: launch_f16<F16K7, 0>(a, grid, st); break;
         case FDC: launch_f16<F16DC, 0>(a, grid, st); break;
+        case FK1N: launch_f16<F16K1N, 0>(a, grid, st); break;
+        case FK3N: launch_f16<F16K3H, 0>(a, grid, st); break;
+        case FK3S2N: launch_f16<F16K3S2N, 0>(a, grid, st); break;
+        case FK5N: launch_f16<F16K5N, 0>(a, grid, st); break;
+        case FK5D2N: launch_f16<F16K5D2N, 0>(a, grid, st); break;
+        case FK7N: launch_f16<F16K7N, 0>(a, grid, st); break;
+        case FDCN: launch_f16<F16DCN, 0>(a, grid, st); break;
         default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: no kernel");
     }
     return check_launch("snvc_f16_conv3d_forward");

@@ -15,6 +15,8 @@
 // own (fp contract off), so it is bit-identical to oracle/numpy_ref.py:sample_2d_feat.
 #include "common.hpp"
 
+#include <cmath>
+
 namespace snvc {
 namespace {
 
@@ -25,11 +27,15 @@ struct Taps {
     float wt[4];   // nw, ne, sw, se
 };
 
+// POW2: res_x and res_y are powers of two and (res_x, res_y) hold their RECIPROCALS: p / 2^k and p * 2^-k are the same
+// real number rounded once, so the product is bit-identical to the division (subnormal results included) and costs
+// one instruction instead of the ~12 of a correctly rounded fp32 division (the path's crops are 256 x 256).
+template <bool POW2 = false>
 __device__ __forceinline__ Taps make_taps(float px, float py, float res_x, float res_y, int Hf,
                                           int Wf) {
     // vernier.py:335-338: p / res * 2 - 1 (three separately rounded fp32 ops)
-    const float gx = px / res_x * 2.0f - 1.0f;
-    const float gy = py / res_y * 2.0f - 1.0f;
+    const float gx = (POW2 ? px * res_x : px / res_x) * 2.0f - 1.0f;
+    const float gy = (POW2 ? py * res_y : py / res_y) * 2.0f - 1.0f;
     const float x = (gx + 1.0f) * ((float)Wf / 2.0f) - 0.5f;
     const float y = (gy + 1.0f) * ((float)Hf / 2.0f) - 0.5f;
     const float xf = floorf(x), yf = floorf(y);
@@ -205,22 +211,73 @@ voxel_gather_fwd_cl_x4(const float *__restrict__ ws, const float *__restrict__ l
 // where the L1 serves 64, and its rate does not depend on how coherent the coordinates are.  Same taps, same
 // separately rounded a*nw + b*ne + c*sw + d*se: bit-identical to the other kernels.  Two workgroups fit a CU, so one
 // streams its outputs while the other refills.
-template <int CS, bool HALF, int BS>
+// Taps of one voxel for the LDS kernels, written so that the x and y halves of the arithmetic pair up into packed fp32
+// instructions (v_pk_mul_f32 / v_pk_add_f32: two floats per lane per issue slot -- the kernel is VALU-issue bound:
+// profiles/r3/pmc_gather.txt, 88 % of the SIMD issue cycles): the same separately rounded operations as make_taps on
+// the same values.  The range test + conversion of make_taps becomes a clamp of floor(x) to [-2, size + 1] before the
+// conversion (fmax / fmin return the non-NaN operand: a NaN or far-away coordinate lands on -2 or size + 1, where both
+// of its columns / rows fail the bounds test exactly as they fail make_taps's finite_range test).  `a[k]` are FLOAT
+// indices into the LDS slice ([pixel][CS]); a tap outside the map points at the zero slot `zidx`.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct TapsLds {
+    int a[4];
+    float wt[4];   // nw, ne, sw, se
+};
+
+template <bool POW2, int CS>
+__device__ __forceinline__ TapsLds make_taps_lds(float px, float py, f2 res, f2 half_size, int Hf, int Wf, int zidx) {
+    const f2 p = {px, py};
+    const f2 g = (POW2 ? p * res : p / res) * 2.0f - 1.0f;          // vernier.py:335-338, three separately rounded ops
+    const f2 xy = (g + 1.0f) * half_size - 0.5f;
+    const f2 fl = {floorf(xy[0]), floorf(xy[1])};
+    const f2 wn = xy - fl, es = 1.0f - wn;                             // (w, n), (e, s)
+    const f2 ew = {es[0], wn[0]};
+    const f2 top = f2{es[1], es[1]} * ew, bot = f2{wn[1], wn[1]} * ew; // (s*e, s*w), (n*e, n*w)
+    TapsLds t;
+    t.wt[0] = top[0]; t.wt[1] = top[1]; t.wt[2] = bot[0]; t.wt[3] = bot[1];
+    const int x0 = (int)fminf(fmaxf(fl[0], -2.0f), (float)Wf + 1.0f);
+    const int y0 = (int)fminf(fmaxf(fl[1], -2.0f), (float)Hf + 1.0f);
+    const bool vx0 = (unsigned)x0 < (unsigned)Wf, vx1 = (unsigned)(x0 + 1) < (unsigned)Wf;
+    const bool vy0 = (unsigned)y0 < (unsigned)Hf, vy1 = (unsigned)(y0 + 1) < (unsigned)Hf;
+    const int base = (y0 * Wf + x0) * CS;
+    t.a[0] = (vx0 && vy0) ? base : zidx;
+    t.a[1] = (vx1 && vy0) ? base + CS : zidx;
+    t.a[2] = (vx0 && vy1) ? base + Wf * CS : zidx;
+    t.a[3] = (vx1 && vy1) ? base + Wf * CS + CS : zidx;
+    return t;
+}
+
+// r3: out-of-range taps point at a 16-byte ZERO slot behind the image instead of being zeroed by a select per loaded
+// value (+0.0 * w is what the select form computes too: same bits, 16 selects per voxel fewer); the coordinate
+// normalisation multiplies by the reciprocal when the crop resolution is a power of two (make_taps<POW2>); and the
+// channel slices of one voxel run are dispatched back to back on ONE XCD (blocks b and b + 8 share an XCD), so that the
+// run's coordinates are read from HBM once and from that XCD's L2 by the other slices.
+template <int CS, bool HALF, int BS, bool POW2>
 __global__ void __launch_bounds__(BS)
 voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
-                     void *__restrict__ out_, int F, int Hf, int Wf, int64_t V, int64_t vrun, float res_x, float res_y) {
+                     void *__restrict__ out_, int F, int Hf, int Wf, int64_t V, int64_t vrun, int nruns, float res_x,
+                     float res_y) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     static_assert(HALF ? CS == 8 : CS == 4, "fp32 output: 4-channel slices; C8 half output: one 8-channel group");
     constexpr int U = HALF ? 1 : 4;          // voxels per thread and step
     extern __shared__ __attribute__((aligned(16))) float img[];
     const int tid = threadIdx.x;
-    const int cs = blockIdx.y;
+    // block -> (voxel run, channel slice): XCD x = b % 8 owns the runs {x, x + 8, ...}; its blocks walk (run, slice)
+    // with the slice fastest.  Blocks beyond the last run of their XCD have nothing to do (grid = 8 * ceil(nruns/8) * slices).
+    const int nsl = F / CS;
+    const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+    const int cs = kk % nsl, run = (kk / nsl) * 8 + xcd;
+    if (run >= nruns) return;
     const int64_t n = blockIdx.z;
     const int plane = Hf * Wf;
-    const int64_t v0 = (int64_t)blockIdx.x * vrun;
+    const int64_t v0 = (int64_t)run * vrun;
     const int64_t v1 = v0 + vrun < V ? v0 + vrun : V;
     const int pieces = plane * (CS / 4);                      // 16-byte pieces of the slice
+    const int zidx = plane * CS;                              // float index of the zero slot
+    if (tid < CS / 4) reinterpret_cast<f4 *>(img)[pieces + tid] = f4(0.0f);
+    const f2 res2 = {res_x, res_y};
+    const f2 half_size = {(float)Wf / 2.0f, (float)Hf / 2.0f};
 #pragma unroll 1
     for (int side = 0; side < 2; ++side) {
         const float *feat = ws + ((int64_t)side * gridDim.z + n) * plane * F + cs * CS;
@@ -249,36 +306,30 @@ voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_p
                 f4 res[4];       // res[j] = channel cs*4 + j of the 4 voxels
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const Taps t = make_taps(px[k], py[k], res_x, res_y, Hf, Wf);
-                    const f4 a4 = *reinterpret_cast<const f4 *>(img + 4 * (t.off[0] < 0 ? 0 : t.off[0]));
-                    const f4 b4 = *reinterpret_cast<const f4 *>(img + 4 * (t.off[1] < 0 ? 0 : t.off[1]));
-                    const f4 c4 = *reinterpret_cast<const f4 *>(img + 4 * (t.off[2] < 0 ? 0 : t.off[2]));
-                    const f4 d4 = *reinterpret_cast<const f4 *>(img + 4 * (t.off[3] < 0 ? 0 : t.off[3]));
+                    const TapsLds t = make_taps_lds<POW2, CS>(px[k], py[k], res2, half_size, Hf, Wf, zidx);
+                    const f4 a4 = *reinterpret_cast<const f4 *>(img + t.a[0]);
+                    const f4 b4 = *reinterpret_cast<const f4 *>(img + t.a[1]);
+                    const f4 c4 = *reinterpret_cast<const f4 *>(img + t.a[2]);
+                    const f4 d4 = *reinterpret_cast<const f4 *>(img + t.a[3]);
+                    const f4 r = a4 * t.wt[0] + b4 * t.wt[1] + c4 * t.wt[2] + d4 * t.wt[3];     // 4 channels of voxel k
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float a = t.off[0] >= 0 ? a4[j] : 0.0f, b = t.off[1] >= 0 ? b4[j] : 0.0f;
-                        const float c = t.off[2] >= 0 ? c4[j] : 0.0f, d = t.off[3] >= 0 ? d4[j] : 0.0f;
-                        res[j][k] = a * t.wt[0] + b * t.wt[1] + c * t.wt[2] + d * t.wt[3];
-                    }
+                    for (int j = 0; j < 4; ++j) res[j][k] = r[j];
                 }
                 float *o = reinterpret_cast<float *>(out_) + (n * 2 * F + (int64_t)side * F + cs * 4) * V + v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(res[j], reinterpret_cast<f4 *>(o + (int64_t)j * V));
             } else {
-                const Taps t = make_taps(px[0], py[0], res_x, res_y, Hf, Wf);
+                const TapsLds t = make_taps_lds<POW2, CS>(px[0], py[0], res2, half_size, Hf, Wf, zidx);
                 h8 res;
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
-                    const f4 a4 = *reinterpret_cast<const f4 *>(img + 8 * (t.off[0] < 0 ? 0 : t.off[0]) + 4 * hq);
-                    const f4 b4 = *reinterpret_cast<const f4 *>(img + 8 * (t.off[1] < 0 ? 0 : t.off[1]) + 4 * hq);
-                    const f4 c4 = *reinterpret_cast<const f4 *>(img + 8 * (t.off[2] < 0 ? 0 : t.off[2]) + 4 * hq);
-                    const f4 d4 = *reinterpret_cast<const f4 *>(img + 8 * (t.off[3] < 0 ? 0 : t.off[3]) + 4 * hq);
+                    const f4 a4 = *reinterpret_cast<const f4 *>(img + t.a[0] + 4 * hq);
+                    const f4 b4 = *reinterpret_cast<const f4 *>(img + t.a[1] + 4 * hq);
+                    const f4 c4 = *reinterpret_cast<const f4 *>(img + t.a[2] + 4 * hq);
+                    const f4 d4 = *reinterpret_cast<const f4 *>(img + t.a[3] + 4 * hq);
+                    const f4 r = a4 * t.wt[0] + b4 * t.wt[1] + c4 * t.wt[2] + d4 * t.wt[3];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float a = t.off[0] >= 0 ? a4[j] : 0.0f, b = t.off[1] >= 0 ? b4[j] : 0.0f;
-                        const float c = t.off[2] >= 0 ? c4[j] : 0.0f, d = t.off[3] >= 0 ? d4[j] : 0.0f;
-                        res[4 * hq + j] = (_Float16)(a * t.wt[0] + b * t.wt[1] + c * t.wt[2] + d * t.wt[3]);
-                    }
+                    for (int j = 0; j < 4; ++j) res[4 * hq + j] = (_Float16)r[j];
                 }
                 _Float16 *o = reinterpret_cast<_Float16 *>(out_) + ((n * 2 * (F / 8) + (int64_t)side * (F / 8) + cs) * V + v) * 8;
                 __builtin_nontemporal_store(res, reinterpret_cast<h8 *>(o));
@@ -286,6 +337,36 @@ voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_p
         }
         __syncthreads();       // every tap of this camera is resolved before the slice is overwritten
     }
+}
+
+// True when x is a power of two whose reciprocal is a normal float (make_taps<POW2>).
+inline bool pow2_res(float x, float &inv) {
+    int e = 0;
+    if (!(x > 0.0f) || std::frexp(x, &e) != 0.5f || e < -100 || e > 100) return false;
+    inv = std::ldexp(1.0f, 1 - e);      // x = 0.5 * 2^e  ->  1 / x = 2^(1 - e)
+    return true;
+}
+
+template <int CS, bool HALF, int BS>
+int launch_gather_lds(const float *ws, const float *l_pts, const float *r_pts, void *out, int64_t N, int64_t F, int64_t Hf,
+                      int64_t Wf, int64_t V, int64_t run, float res_x, float res_y, hipStream_t st) {
+    const int plane = (int)(Hf * Wf);
+    const size_t lds = (size_t)plane * CS * 4 + (CS / 4) * 16;     // the slice + the zero slot
+    const int nruns = (int)ceil_div<int64_t>(V, run);
+    const dim3 grid((unsigned)(8 * ceil_div(nruns, 8) * (int)(F / CS)), 1, (unsigned)N);
+    float ix = 0.0f, iy = 0.0f;
+    if (pow2_res(res_x, ix) && pow2_res(res_y, iy)) {
+        static std::atomic<unsigned> attr_done{0};
+        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<CS, HALF, BS, true>), (int)lds, attr_done))
+            voxel_gather_fwd_lds<CS, HALF, BS, true><<<grid, BS, lds, st>>>(ws, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run,
+                                                                          nruns, ix, iy);
+    } else {
+        static std::atomic<unsigned> attr_done{0};
+        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<CS, HALF, BS, false>), (int)lds, attr_done))
+            voxel_gather_fwd_lds<CS, HALF, BS, false><<<grid, BS, lds, st>>>(ws, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run,
+                                                                           nruns, res_x, res_y);
+    }
+    return 0;
 }
 
 // voxels per workgroup: enough workgroups to fill the chip twice over, runs as long as that allows (the refill of the
@@ -475,12 +556,7 @@ int snvc_voxel_gather_forward_ws(const float *left, const float *right, const fl
         ((reinterpret_cast<uintptr_t>(l_pts) | reinterpret_cast<uintptr_t>(r_pts) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     if (x4 && (int64_t)plane * 16 <= 72 * 1024 && V >= 4096) {     // LDS-staged 4-channel slices (two workgroups per CU)
         const int64_t run = gather_run_length(V, F / 4, N);
-        static std::atomic<unsigned> attr_done{0};
-        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<4, false, 512>), plane * 16, attr_done)) {
-            dim3 grid((unsigned)ceil_div<int64_t>(V, run), (unsigned)(F / 4), (unsigned)N);
-            voxel_gather_fwd_lds<4, false, 512><<<grid, 512, (size_t)plane * 16, as_stream(stream)>>>(
-                workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run, res_x, res_y);
-        }
+        launch_gather_lds<4, false, 512>(workspace, l_pts, r_pts, out, N, F, Hf, Wf, V, run, res_x, res_y, as_stream(stream));
     } else if (x4) {
         dim3 grid((unsigned)ceil_div<int64_t>(V / 4, 256), (unsigned)N);
         voxel_gather_fwd_cl_x4<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf,
@@ -512,12 +588,7 @@ int snvc_voxel_gather_forward_f16(const float *left, const float *right, const f
                                                                                                     (int)F, plane);
     if ((int64_t)plane * 32 <= 144 * 1024 && V >= 4096) {      // LDS-staged 8-channel groups (one workgroup per CU)
         const int64_t run = gather_run_length(V, F / 8, N);
-        static std::atomic<unsigned> attr_done{0};
-        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<8, true, 1024>), plane * 32, attr_done)) {
-            dim3 grid((unsigned)ceil_div<int64_t>(V, run), (unsigned)(F / 8), (unsigned)N);
-            voxel_gather_fwd_lds<8, true, 1024><<<grid, 1024, (size_t)plane * 32, as_stream(stream)>>>(
-                workspace, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run, res_x, res_y);
-        }
+        launch_gather_lds<8, true, 1024>(workspace, l_pts, r_pts, out, N, F, Hf, Wf, V, run, res_x, res_y, as_stream(stream));
     } else {
         dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
         voxel_gather_fwd_cl_c8<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, reinterpret_cast<_Float16 *>(out),

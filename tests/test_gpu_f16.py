@@ -67,10 +67,12 @@ KINDS = {  # name: (k, stride, dil, transposed)
 
 
 @pytest.mark.parametrize("kind", list(KINDS))
-@pytest.mark.parametrize("cin,cout,shape", [(64, 64, (5, 6, 37)), (16, 32, (4, 9, 33)), (128, 128, (2, 3, 40))])
+@pytest.mark.parametrize("cin,cout,shape", [(64, 64, (5, 6, 37)), (16, 32, (4, 9, 33)), (128, 128, (2, 3, 40)),
+                                            (64, 32, (6, 5, 36)), (32, 96, (3, 4, 34))])
 def test_f16_layer_vs_torch(kind, cin, cout, shape):
     """Every layer kind of the fp16 family against torch's fp32 convolution of the half-rounded operands: BN affine,
-    ReLU, residual before / after the activation, batch 2, tile-ragged sizes, 1-2 chunks, 1-2 output blocks."""
+    ReLU, residual before / after the activation, batch 2, tile-ragged sizes, 1-2 chunks, 1-2 output blocks.  32 output
+    channels run the MI = 1 kernel forms, 64 / 128 the two-block forms, 96 a two-block form with a half-empty block."""
     from snvc_amd import ops
     from snvc_amd.models import submodule as S
     k, stride, dil, transposed = KINDS[kind]

@@ -225,6 +225,33 @@ def test_voxel_gather_bit_exact_vs_numpy_oracle():
     assert np.array_equal(got, exp), np.abs(got - exp).max()
 
 
+@pytest.mark.parametrize("res", [(28, 36), (64, 128), (256, 256)])
+def test_voxel_gather_lds_path_bit_exact_with_edge_coordinates(res):
+    """The LDS-staged kernel (V >= 4096, whole 16-byte rows) on both forms of the coordinate normalisation -- the
+    division (crop sizes that are not powers of two) and its reciprocal-multiply twin (powers of two) -- with exact
+    borders, far-outside, infinite and NaN coordinates (out-of-range taps read the zero slot), fp32 and C8-half
+    outputs: bit-identical to the numpy oracle (and to its result rounded to half)."""
+    from oracle import numpy_ref as NR
+    from snvc_amd import ops
+    r = np.random.default_rng(19)
+    n, f, hf, wf, v = 2, 16, 9, 11, 8192
+    lf = torch.from_numpy(r.standard_normal((n, f, hf, wf)).astype(np.float32))
+    rf = torch.from_numpy(r.standard_normal((n, f, hf, wf)).astype(np.float32))
+    lf[0, :, 0, 0] = np.inf                     # the pixel the select form used to park out-of-range taps on
+    pts = np.stack([r.uniform(-0.2 * res[1], 1.2 * res[1], (n, v)), r.uniform(-0.2 * res[0], 1.2 * res[0], (n, v))], 1).astype(np.float32)
+    pts[0, 0, :8] = [0.0, res[1], -2.0, 1e9, np.inf, -np.inf, np.nan, 0.5 * res[1]]
+    pts[0, 1, :8] = [0.0, res[0], 0.5 * res[0], 3.0, 1.0, 2.0, 3.0, np.nan]
+    pts[1, :, 100:200] = 1e-41                  # subnormal coordinates: x / 2^k and x * 2^-k round alike
+    gl, gr = torch.from_numpy(pts), torch.from_numpy(pts[:, :, ::-1].copy())
+    exp = NR.sample_2d_feat(lf.numpy(), rf.numpy(), gl.numpy(), gr.numpy(), res)
+    dl, dr, dgl, dgr = lf.to(dev()), rf.to(dev()), gl.to(dev()), gr.to(dev())
+    got = ops.voxel_gather_forward(dl, dr, dgl, dgr, res).cpu().numpy()
+    assert np.array_equal(got, exp, equal_nan=True)
+    half = ops.voxel_gather_forward_f16(dl, dr, dgl, dgr, res)          # [N, 2F/8, V, 8]
+    exp_h = torch.from_numpy(exp).half().reshape(n, 2 * f // 8, 8, v).permute(0, 1, 3, 2)
+    assert torch.equal(torch.nan_to_num(half.cpu().float(), nan=7.0), torch.nan_to_num(exp_h.float(), nan=7.0))
+
+
 def test_voxel_gather_backward_adjoint():
     from snvc_amd import ops
     r = np.random.default_rng(10)
@@ -358,17 +385,22 @@ def test_k5_k7_winograd_vs_torch(k, dil, W):
             check(y.cpu().numpy(), ref.numpy(), TIGHT, f"k{k} d{dil} W={W} direct kernel")
 
 
+@pytest.mark.parametrize("form", ["slice_pipelined", "per_chunk"])
 @pytest.mark.parametrize("W", [40, 72, 44])
-def test_k3_stride2_winograd_vs_torch(W):
-    """Stride-2 3x3x3 layers: the polyphase + F(4,2) kernel (output width % 4 == 0) and the direct kernel
-    (everything else, and desc.algo = SNVC_ALGO_DIRECT) against torch, batch 2, two channel groups, ragged tiles."""
+def test_k3_stride2_winograd_vs_torch(W, form):
+    """Stride-2 3x3x3 layers: the polyphase + F(4,2) kernels (output width % 4 == 0) -- the default slice-pipelined
+    refill (counted vmcnt waits) and the per-chunk refill form (SNVC_ALGO_WINO_TILE_STD) -- and the direct kernel
+    (everything else, and desc.algo = SNVC_ALGO_DIRECT) against torch, batch 2, two channel groups, ragged tiles,
+    odd channel counts (a half-empty last chunk), one and many chunks."""
     import torch.nn.functional as F
+    from snvc_amd import _lib, ops
     from snvc_amd.models import submodule as S
     r = np.random.default_rng(70 + W)
-    for cin, cout, shape in ((32, 64, (10, 6, W)), (7, 32, (4, 8, W))):
+    bits = _lib.ALGO_WINO_TILE_STD if form == "per_chunk" else 0
+    for cin, cout, shape in ((32, 64, (10, 6, W)), (7, 32, (4, 8, W)), (2, 32, (18, 10, W)), (64, 64, (6, 20, W))):
         m = seeded(S.convbn_3d(cin, cout, 3, 2, 1), 80 + cin)
         x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32))
-        with torch.no_grad():
+        with torch.no_grad(), ops.conv_variant(bits):
             ref = F.batch_norm(F.conv3d(x, m[0].weight, None, 2, 1), m[1].running_mean, m[1].running_var,
                                m[1].weight, m[1].bias, False, 0.0, m[1].eps)
             res = torch.from_numpy(r.standard_normal(tuple(ref.shape)).astype(np.float32))
@@ -837,10 +869,10 @@ def test_vernier_scale_vs_golden(name, G):
     with torch.no_grad():
         hip0, torch0 = S._ROUTES["neck2d_hip"], S._ROUTES["neck2d_torch"]
         out = m(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()))
-        # the 2D neck + heads ran on the HIP kernels (eval BatchNorm) or, under GroupNorm, on the modules' torch forward:
-        # never a silent mix
+        # eval BatchNorm: every block of the 2D neck + heads ran on the HIP kernels, none on torch's; GroupNorm: the neck
+        # takes the modules' torch forward (the coordinate head's BasicBlocks carry BatchNorm2d either way)
         hip1, torch1 = S._ROUTES["neck2d_hip"], S._ROUTES["neck2d_torch"]
-        assert (hip1 > hip0 and torch1 == torch0) if not gn else (torch1 > torch0 and hip1 == hip0)
+        assert (hip1 > hip0 and torch1 == torch0) if not gn else torch1 > torch0
         vox = m.construct_voxel(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()))
         bev, occ5, _ = m.trunk_3d(vox)
         idx, conf = m.ncf_argmax(out["ncf"])

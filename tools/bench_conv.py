@@ -31,8 +31,32 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", default=[c for c in CASES if not c.startswith("l_")])
     ap.add_argument("--reps", type=int, default=60)
+    ap.add_argument("--side-head", action="store_true",
+                    help="conv2 with and without the side head (snvc_conv3d_forward_side_head), interleaved in one process")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.side_head:
+        with torch.no_grad():
+            m = S.ConvBNReLU3d(S.convbn_3d(32, 32, 3, 1, 1), torch.nn.ReLU()).to(dev).eval()
+            head = S.HipConv3d(32, 1, kernel_size=1, padding=0, stride=1, bias=False).to(dev)
+            x = torch.randn((1, 32, 192, 96, 312), device=dev)
+            out = torch.empty_like(x)
+            fns = {"plain": lambda: m.fused(x, out=out), "side_head": lambda: m.fused(x, out=out, side_head=head),
+                   "plain+pointwise": lambda: head(m.fused(x, out=out))}
+            for f in fns.values():
+                for _ in range(10):
+                    f()
+            times = {k: [] for k in fns}
+            for _ in range(args.reps // 3):
+                for k, f in fns.items():
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record(); f(); b.record()
+                    torch.cuda.synchronize()
+                    times[k].append(a.elapsed_time(b))
+            for k, t in times.items():
+                t = sorted(t)
+                print(f"conv2 {k:16s}: median {t[len(t) // 2]:7.3f} ms  min {t[0]:7.3f} ms", flush=True)
+        return
     with torch.no_grad():
         for name in args.cases:
             cin, cout, k, s, p, shape, tr = CASES[name][:7]

@@ -55,11 +55,13 @@ with torch.no_grad():
         else:
             vox = vs.construct_voxel(lf, rf, gl, gr)
             fn = lambda: vs.trunk_3d(vox)  # noqa: E731
-    elif args.layer in ("gather_proj", "gather_uniform", "gather_f16"):
+    elif args.layer in ("gather_proj", "gather_uniform", "gather_f16", "gather_cfg3"):
         import types
         from snvc_amd import ops
         f16 = args.layer == "gather_f16"
         grid, n, F = ((80, 160, 160), 1, 64) if f16 else ((32, 128, 192), 2, 32)
+        if args.layer == "gather_cfg3":          # BASELINE configs[2]: 8 crops of 96^3 per GPU
+            grid, n, F = (96, 96, 96), 8, 32
         r = np.random.default_rng(5)
         v = grid[0] * grid[1] * grid[2]
         lf = torch.from_numpy(r.standard_normal((n, F, 64, 64)).astype(np.float32)).to(dev)
