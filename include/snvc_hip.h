@@ -162,7 +162,12 @@ enum {
     SNVC_EPI_RELU = 1,
     SNVC_EPI_ADD_PRE = 2,
     SNVC_EPI_ADD_POST = 4,
-    SNVC_EPI_SIGMOID = 8
+    SNVC_EPI_SIGMOID = 8,
+    /* y = AvgPool3d((4,1,1),(4,1,1))(epilogue(conv(x))) as a [N,Cout,Dout/4,Hout,Wout] tensor, the full-resolution
+     * result never written (snvc/models/vernier.py:289,436: the pool between the trunk's conv4 and the BEV reshape).
+     * Built for 3x3x3 / stride-1 Conv3d layers on the default Winograd form with Dout % 4 == 0 and no residual;
+     * SNVC_ERR_UNSUPPORTED otherwise (the caller then pools in a launch of its own: snvc_avgpool_depth4). */
+    SNVC_EPI_AVGPOOL_D4 = 16
 };
 
 /* desc.algo: which arithmetic / kernel form a layer may use.  Low byte = the arithmetic:

@@ -944,9 +944,42 @@ template <class Cfg> constexpr int epilogue_piece() { return EpiloguePiece<Cfg>:
 // 32-channel result to one channel, y_head = sum_c head_w[c] * y[c] -- 16 channels per lane, the other 16 in
 // lane ^ 32 -- so that a later consumer of head(y) does not have to read y again (the global model's
 // `classifier(v)` term of the folded hourglass tail, models/stereo_volume.py).
-template <class Cfg, bool RES, bool PLANE, bool HEAD = false>
+// XMODE 2 (SNVC_EPI_AVGPOOL_D4): AvgPool3d((4,1,1),(4,1,1)) of the layer's own result (snvc/models/vernier.py:289,436: the
+// pool between conv4 and the BEV reshape) folded in: a 4 x 4 x 32 tile holds exactly the four depths of one pooled plane,
+// one per wave, so the waves trade registers through the (now idle) LDS buffers -- wave w collects channels 8w .. 8w+3
+// (+4 for the upper half-wave) of all four depths, sums them in depth order, scales by 1/4 and stores the pooled
+// [N, C, D/4, H, W] tensor; the full-resolution result is never written.
+template <int W, class Cfg>
+__device__ __forceinline__ void wino_pool_store(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[Cfg::NPOS][Cfg::NB],
+                                                const f32x4 *__restrict__ X, int lane) {
+    const int half = lane >> 5, rowsel = (lane & 31) / Cfg::QUADS;
+    const int ow = job.ow0 + 4 * (lane & (Cfg::QUADS - 1)), oh = job.oh0 + rowsel;
+    const int out_hw = a.Hout * a.Wout;
+    const int64_t pooled_dhw = (int64_t)(a.Dout / 4) * out_hw;
+    const bool ok = oh < a.Hout && ow < a.Wout;
+    float *yb = a.y + job.n * a.y_bs + (int64_t)(job.cg * 32 + 8 * W + 4 * half) * pooled_dhw +
+                (ok ? (int64_t)(job.od0 / 4) * out_hw + oh * a.Wout + ow : 0);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        f32x4 v[4];
+#pragma unroll
+        for (int sw = 0; sw < 4; ++sw) {
+            if (sw == W) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[sw][j] = acc[j][0][4 * W + rr];
+            } else {
+                v[sw] = X[((W * 3 + (sw < W ? sw : sw - 1)) * 4 + rr) * 64 + lane];
+            }
+        }
+        const f32x4 sum = ((v[0] + v[1]) + v[2]) + v[3];
+        if (ok) *reinterpret_cast<f32x4 *>(yb + rr * pooled_dhw) = sum * 0.25f;
+    }
+}
+
+template <class Cfg, bool RES, bool PLANE, int XMODE = 0>
 __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &job, f32x16 (&acc)[Cfg::NPOS][Cfg::NB],
-                                              const float *__restrict__ aff, int lane, int wave) {
+                                              const float *__restrict__ aff, int lane, int wave, float *xch = nullptr) {
+    constexpr bool HEAD = XMODE == 1;
     constexpr int NB = Cfg::NB, TH = Cfg::TH;
     constexpr bool V4 = epilogue_piece<Cfg>() == 4;   // 16-byte loads / stores (Wout % 4 == 0); else 8-byte halves
     const int ow = job.ow0 + 4 * (lane & (Cfg::QUADS - 1)), rowsel = (lane & 31) / Cfg::QUADS;
@@ -1062,6 +1095,30 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
             for (int j = 0; j < 4; ++j) dsum[j] += __shfl_xor(dsum[j], 32);
             if (half == 0 && ok0[nb]) *reinterpret_cast<f32x4 *>(yh + voff[nb]) = dsum;   // half 0: voff = 4 * voxel
         }
+    }
+    if constexpr (XMODE == 2) {
+        static_assert(V4 && NB == 1 && Cfg::TD == 4 && Cfg::TH == Cfg::RPB, "one depth per wave, 16-byte stores");
+        f32x4 *const X = reinterpret_cast<f32x4 *>(xch);
+#pragma unroll
+        for (int dw = 0; dw < 4; ++dw) {
+            if (dw == wave) continue;                   // wave-uniform
+            const int slot = wave < dw ? wave : wave - 1;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = acc[j][0][4 * dw + rr];
+                X[((dw * 3 + slot) * 4 + rr) * 64 + lane] = o;
+            }
+        }
+        __syncthreads();
+        switch (wave) {
+            case 0: wino_pool_store<0, Cfg>(a, job, acc, X, lane); break;
+            case 1: wino_pool_store<1, Cfg>(a, job, acc, X, lane); break;
+            case 2: wino_pool_store<2, Cfg>(a, job, acc, X, lane); break;
+            default: wino_pool_store<3, Cfg>(a, job, acc, X, lane); break;
+        }
+        return;
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -1188,9 +1245,10 @@ __device__ __forceinline__ void wino_dma_issue(const float **xsrc, const float *
     }
 }
 
-template <class Cfg, bool RES, bool PLANE, bool HEAD = false>
+template <class Cfg, bool RES, bool PLANE, int XMODE = 0>
 __global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_wino_dma_kernel(const ConvArgs a) {
+    constexpr bool HEAD = XMODE == 1;
     constexpr int TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB, CH = Cfg::CH, TILE = Cfg::TILE, WF = Cfg::WF;
     using St = typename Cfg::St;
     static_assert(Cfg::PIECE == 4, "LDS-DMA moves 16-byte pieces");
@@ -1243,7 +1301,8 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
         wino_compute_chunk<Cfg>(lds + (chunk & 1) * TILE, wlds + (chunk & 1) * WF + lane, bbase, wave, acc, [](int) {});
         __syncthreads();
     }
-    wino_epilogue<Cfg, RES, PLANE, HEAD>(a, job, acc, aff, lane, wave);
+    static_assert(XMODE != 2 || 48 * 64 * 16 <= Cfg::LDS_BYTES, "the pooled epilogue trades 48 KB through the image / weight buffers");
+    wino_epilogue<Cfg, RES, PLANE, XMODE>(a, job, acc, aff, lane, wave, lds);
 }
 
 // k5 / k7 Winograd kernel (WinoKCfg above).  Phase p = (chunk, kd): weights of phase p+1 are DMA'd
@@ -1377,7 +1436,7 @@ __device__ __forceinline__ void wait_vmcnt_then_barrier() {
 template <class Cfg, bool RES>
 __global__ void __launch_bounds__(256, 2)
 conv3d_winos2_pipe_kernel(const ConvArgs a) {
-    constexpr int KC = Cfg::KC, WF = Cfg::WF, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, RQ = IN_WV / 4, IN_D = Cfg::IN_D;
+    constexpr int KC = Cfg::KC, WF = Cfg::WF, IN_WV = Cfg::IN_WV, RQ = IN_WV / 4, IN_D = Cfg::IN_D;
     constexpr int CHS = Cfg::CH, PLANE = Cfg::PLANE, DSLICE = Cfg::DSLICE, WBLK = Cfg::WBLK, WPIECES = WBLK / 4;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2036,7 +2095,7 @@ enum Kind {
     K5D2_M1, K5D2_M2,
     K7_M1, K7_M2,
     DC_M1, DC_M2,
-    P1_M1, P1_M2, P1S2_M1, P1S2_M2, P3_M1, P3_M2, P3S2_M1, P3S2_M2,     // depth-1 (2D) layers
+    P1_M1S, P1S2_M1S, P3_M1S, P3S2_M1S,                                  // depth-1 (2D) layers, 1 x 4 x 32 tiles
     KIND_NONE
 };
 
@@ -2055,14 +2114,18 @@ using CfgK7M1   = ConvCfg<7, 1, 1, 1, 4, 4, 2, false, 2, 1>;
 using CfgK7M2   = ConvCfg<7, 1, 1, 2, 4, 4, 2, false, 2, 1>;
 // depth-1 layers (Conv2d of the BEV neck on [N,C,1,H,W] views): tile 1 x 8 x 32
 //                        KS S  D  MI TD TH KC  DB   OCC KDG KSD
-using CfgP1M1   = ConvCfg<1, 1, 1, 1, 1, 8, 8, true, 2, 0, 1>;
-using CfgP1M2   = ConvCfg<1, 1, 1, 2, 1, 8, 8, true, 2, 0, 1>;
-using CfgP1S2M1 = ConvCfg<1, 2, 1, 1, 1, 8, 8, true, 2, 0, 1>;
-using CfgP1S2M2 = ConvCfg<1, 2, 1, 2, 1, 8, 8, true, 2, 0, 1>;
-using CfgP3M1   = ConvCfg<3, 1, 1, 1, 1, 8, 8, true, 2, 0, 1>;
-using CfgP3M2   = ConvCfg<3, 1, 1, 2, 1, 8, 8, true, 2, 0, 1>;
-using CfgP3S2M1 = ConvCfg<3, 2, 1, 1, 1, 8, 4, true, 2, 0, 1>;
-using CfgP3S2M2 = ConvCfg<3, 2, 1, 2, 1, 8, 4, true, 2, 0, 1>;
+// r3: the BEV neck's images are small (128 x 192 down to 8 x 12 pixels): on 1 x 8 x 32 tiles with 64 output channels per
+// workgroup a whole level is 2 .. 48 workgroups, each a serial chain of up to 1152 MFMAs per wave -- 85-100 us per layer
+// whatever its size (profiles/r3/heads_kernel_stats_v1.csv).  Depth-1 layers therefore always run one 32-channel group
+// per workgroup (MI = 1; the packing depends on MI and KC only), and on 1 x 4 x 32 tiles while that leaves the launch
+// under two workgroups per CU: 4x the workgroups, a quarter of the chain.
+// ... and with 16-32 input channels per chunk: a chunk costs one exposed global-memory round trip (~2-4 us on these
+// launches: 36 MFMAs per wave cannot cover it), so a 64-channel layer took 8 of them at KC = 8 (40-60 us per layer,
+// profiles/r3/heads_kernel_stats_v2.csv) and takes 4 at KC = 16.
+using CfgP1M1s   = ConvCfg<1, 1, 1, 1, 1, 4, 32, true, 2, 0, 1>;
+using CfgP1S2M1s = ConvCfg<1, 2, 1, 1, 1, 4, 16, true, 2, 0, 1>;
+using CfgP3M1s   = ConvCfg<3, 1, 1, 1, 1, 4, 16, true, 2, 0, 1>;
+using CfgP3S2M1s = ConvCfg<3, 2, 1, 1, 1, 4, 8, true, 2, 0, 1>;
 using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64 voxels, 2 input channels per chunk
 using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per wave: large layers
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;
@@ -2104,11 +2167,13 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
         if (d.Hout != eH || d.Wout != eW)
             return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: output size does not match the convolution arithmetic");
         const int key = d.ksize * 10 + d.stride;
+        // one 32-channel group per workgroup on 1 x 4 x 32 tiles whatever the layer (see CfgP*s above)
+        (void)wide;
         switch (key) {
-            case 11: p = wide ? plan_of<CfgP1M2>(P1_M2) : plan_of<CfgP1M1>(P1_M1); break;
-            case 12: p = wide ? plan_of<CfgP1S2M2>(P1S2_M2) : plan_of<CfgP1S2M1>(P1S2_M1); break;
-            case 31: p = wide ? plan_of<CfgP3M2>(P3_M2) : plan_of<CfgP3M1>(P3_M1); break;
-            case 32: p = wide ? plan_of<CfgP3S2M2>(P3S2_M2) : plan_of<CfgP3S2M1>(P3S2_M1); break;
+            case 11: p = plan_of<CfgP1M1s>(P1_M1S); break;
+            case 12: p = plan_of<CfgP1S2M1s>(P1S2_M1S); break;
+            case 31: p = plan_of<CfgP3M1s>(P3_M1S); break;
+            case 32: p = plan_of<CfgP3S2M1s>(P3S2_M1S); break;
             default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: depth-1 layers are built for ksize 1 and 3, stride 1 and 2");
         }
         p.tiles_d = 1; p.tiles_h = ceil_div(d.Hout, p.TH); p.tiles_w = ceil_div(d.Wout, 32);
@@ -2209,12 +2274,12 @@ void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     conv3d_wino_kernel<Cfg, RES, PLANE><<<grid, 256, BYTES, st>>>(a);
 }
 
-template <class Cfg, bool RES, bool PLANE, bool HEAD = false>
+template <class Cfg, bool RES, bool PLANE, int XMODE = 0>
 void launch_wino_dma_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
-    constexpr int BYTES = Cfg::LDS_BYTES + (HEAD ? 384 : 256);   // + (scale | bias [| head weights]) of 32 channels
+    constexpr int BYTES = Cfg::LDS_BYTES + (XMODE == 1 ? 384 : 256);   // + (scale | bias [| head weights]) of 32 channels
     static std::atomic<unsigned> attr_done{0};   // one bit per device: the attribute is per device
-    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE, HEAD>), BYTES, attr_done)) return;
-    conv3d_wino_dma_kernel<Cfg, RES, PLANE, HEAD><<<grid, 256, BYTES, st>>>(a);
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_wino_dma_kernel<Cfg, RES, PLANE, XMODE>), BYTES, attr_done)) return;
+    conv3d_wino_dma_kernel<Cfg, RES, PLANE, XMODE><<<grid, 256, BYTES, st>>>(a);
 }
 
 template <class Cfg>
@@ -2397,6 +2462,12 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     a.plane = depth_planes;
     a.head_w = head_w; a.y_head = y_head;
     const bool side_head = head_w && y;   // snvc_conv3d_forward_side_head: y AND its one-channel projection
+    const bool pooled = (d->flags & SNVC_EPI_AVGPOOL_D4) != 0;   // y is [N,Cout,Dout/4,Hout,Wout]
+    if (pooled && (side_head || head_w || d->transposed || d->ksize_d == 1 || d->ksize != 3 || d->stride != 1 || d->dilation != 1 ||
+                   depth_planes || d->Dout % 4 != 0 || d->Cout % 32 != 0 || (d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST | SNVC_EPI_SIGMOID)) ||
+                   (d->algo & SNVC_ALGO_ARITH_MASK) == SNVC_ALGO_DIRECT))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: SNVC_EPI_AVGPOOL_D4 is built for 3x3x3 / stride-1 Conv3d layers "
+                                          "with Dout % 4 == 0, whole 32-channel groups and no residual");
     if (side_head && (d->transposed || d->ksize_d == 1 || d->ksize != 3 || d->stride != 1 || d->dilation != 1 || depth_planes))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_side_head: built for 3x3x3 / stride-1 Conv3d layers");
     if (head_w && !side_head && p.kind != DC_M1)
@@ -2408,7 +2479,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     a.tiles_d = p.tiles_d; a.tiles_h = p.tiles_h; a.tiles_w = p.tiles_w;
     a.nchunks = p.nchunks; a.flags = d->flags;
     a.x_bs = d->x_batch_stride ? d->x_batch_stride : in_sz;
-    a.y_bs = d->y_batch_stride ? d->y_batch_stride : out_sz;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (pooled ? out_sz / 4 : out_sz);
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : out_sz;
     a.vec = (d->Win % 4 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (a.x_bs % 4 == 0);
     const bool vec8 = (d->Win % 2 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0) && (a.x_bs % 2 == 0);
@@ -2530,8 +2601,15 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
                     if (!(narrow && wide && !nreg) || a.res || a.plane || d->Cout != 32 || (reinterpret_cast<uintptr_t>(y_head) & 15))
                         return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_side_head: needs the default Winograd form, 32 output "
                                                           "channels, no residual / depth planes and a 16-byte aligned y_head");
-                    launch_wino_dma_variant<CfgWinoN3, false, false, true>(a, g, as_stream(stream));
+                    launch_wino_dma_variant<CfgWinoN3, false, false, 1>(a, g, as_stream(stream));
                     return check_launch("snvc_conv3d_forward_side_head");
+                }
+                if (pooled) {      // built for the default kernel form without addends (the local trunk's conv4)
+                    if (!(narrow && wide && !nreg) || a.res || a.plane)
+                        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: SNVC_EPI_AVGPOOL_D4 needs the default Winograd "
+                                                          "form and no residual / depth planes");
+                    launch_wino_dma_variant<CfgWinoN3, false, false, 2>(a, g, as_stream(stream));
+                    return check_launch("snvc_conv3d_forward(pooled)");
                 }
                 if (big) launch_wino_dma<CfgWinoBig>(a, g, as_stream(stream));
                 else if (narrow && wide && !nreg) launch_wino_dma<CfgWinoN3>(a, g, as_stream(stream));
@@ -2545,6 +2623,8 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     }
     if (side_head)
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_side_head: built for 3x3x3 / stride-1 layers on the Winograd path");
+    if (pooled)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: SNVC_EPI_AVGPOOL_D4 needs 16-byte aligned rows (the Winograd path)");
     const int64_t ntiles = (int64_t)p.tiles_d * p.tiles_h * p.tiles_w;
     const int64_t gx = d->transposed ? ntiles * 4 : ntiles;
     if (gx >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: too many tiles");
@@ -2563,14 +2643,10 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         case K5D2_M2: launch_conv<CfgK5D2M2>(a, grid, st); break;
         case K7_M1: launch_conv<CfgK7M1, true>(a, grid, st); break;
         case K7_M2: launch_conv<CfgK7M2>(a, grid, st); break;
-        case P1_M1: launch_conv<CfgP1M1>(a, grid, st); break;
-        case P1_M2: launch_conv<CfgP1M2>(a, grid, st); break;
-        case P1S2_M1: launch_conv<CfgP1S2M1>(a, grid, st); break;
-        case P1S2_M2: launch_conv<CfgP1S2M2>(a, grid, st); break;
-        case P3_M1: launch_conv<CfgP3M1, true>(a, grid, st); break;
-        case P3_M2: launch_conv<CfgP3M2, true>(a, grid, st); break;
-        case P3S2_M1: launch_conv<CfgP3S2M1, true>(a, grid, st); break;
-        case P3S2_M2: launch_conv<CfgP3S2M2, true>(a, grid, st); break;
+        case P1_M1S: launch_conv<CfgP1M1s>(a, grid, st); break;
+        case P1S2_M1S: launch_conv<CfgP1S2M1s>(a, grid, st); break;
+        case P3_M1S: launch_conv<CfgP3M1s, true>(a, grid, st); break;
+        case P3S2_M1S: launch_conv<CfgP3S2M1s, true>(a, grid, st); break;
         case DC_M1:
             if (!a.vec && vec8) { a.vec = 1; launch_deconv<CfgDCM1v8>(a, grid, st); }
             else launch_deconv<CfgDCM1>(a, grid, st);

@@ -497,6 +497,26 @@ def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *,
     return _norm_forward(layer, norm, plan, x, residual, flags, out, False)[0]
 
 
+def fused_conv3d_avgpool_d4(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False) -> torch.Tensor:
+    """``avg_pool3d(act(norm(conv(x))), (4,1,1), (4,1,1))`` (reference vernier.py:289,435-436: conv4 and the pool in front of the
+    BEV reshape).  With frozen statistics and nothing to differentiate the pool is part of the conv launch's epilogue
+    (``SNVC_EPI_AVGPOOL_D4``: the full-resolution tensor is never written); otherwise the layer and the pool run one
+    after the other."""
+    if not torch.is_grad_enabled() and x.is_cuda and _is_frozen_norm(norm):
+        plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(x.device, _Plan())
+        layer = _get_layer(conv, plan)
+        scale, bias = _folded_bn(norm, plan) if norm is not None else (None, None)
+        y = ops.conv3d_forward_avgpool_d4(layer, x, scale, bias, EPI_RELU if relu else 0)
+        if y is not None:
+            _ROUTES["conv_avgpool_fused"] += 1
+            return y
+    y = fused_conv3d(conv, norm, x, relu=relu)
+    if torch.is_grad_enabled() and y.requires_grad:
+        return F.avg_pool3d(y, (4, 1, 1), (4, 1, 1))
+    _ROUTES["conv_avgpool_separate"] += 1
+    return ops.avgpool_depth4(y)
+
+
 def fused_conv3d_f16(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,
                      residual: Optional[torch.Tensor] = None, residual_after_act=False, out=None) -> torch.Tensor:
     """``fused_conv3d`` in the fp16-storage mode (inference only; BASELINE.json configs[4]): ``x`` / ``residual`` /
@@ -681,21 +701,23 @@ class hourglass_downsample_16(nn.Module):
 # ------------------------------------------------------------------------------------------
 # 2D BEV neck: same module tree / state-dict keys as the reference; inference with eval-mode
 # BatchNorm2d runs on the depth-1 form of the HIP conv kernels (an NCHW tensor IS an [N,C,1,H,W] tensor), with the
-# folded norm, the conv bias, residual adds, ReLU and Sigmoid in the conv epilogue.  Training and GroupNorm take
-# the modules' own torch forward.
+# folded norm, the conv bias, residual adds, ReLU and Sigmoid in the conv epilogue; GroupNorm (cfg.gn) takes the 3D
+# layers' three-launch form (conv, statistics, normalise + residual + activation).  Anything with a gradient to
+# compute takes the modules' own torch forward.
 # ------------------------------------------------------------------------------------------
 def _hip_2d_ok(x: torch.Tensor, *modules) -> bool:
     """The HIP path of the 2D neck (kernels without a backward): a float32 GPU tensor, every norm of ``modules`` an
-    eval-mode BatchNorm2d, and NOTHING to differentiate -- autograd off, or neither the input nor any parameter of the
-    modules requires grad (a frozen trunk with trainable heads must keep the torch forward, or the heads would
-    silently get no gradient).  Every decision is counted in ``_ROUTES`` ("neck2d_hip" / "neck2d_torch")."""
+    eval-mode BatchNorm2d (folded into the conv epilogue) or a GroupNorm (conv -> statistics -> normalise + residual +
+    activation, three launches like the 3D layers), and NOTHING to differentiate -- autograd off, or neither the input
+    nor any parameter of the modules requires grad (a frozen trunk with trainable heads must keep the torch forward, or
+    the heads would silently get no gradient).  Every decision is counted in ``_ROUTES`` ("neck2d_hip" / "neck2d_torch")."""
     if not x.is_cuda:
         raise RuntimeError("2D neck input must be a GPU tensor: Not implemented on the CPU")
     ok = x.dtype == torch.float32
     if ok and torch.is_grad_enabled():
         ok = not (x.requires_grad or any(p.requires_grad for m in modules for p in m.parameters()))
     if ok:
-        ok = all(isinstance(n, nn.BatchNorm2d) and not n.training and n.running_mean is not None
+        ok = all(isinstance(n, nn.GroupNorm) or (isinstance(n, nn.BatchNorm2d) and not n.training and n.running_mean is not None)
                  for m in modules for n in _norms2d(m))
     _ROUTES["neck2d_hip" if ok else "neck2d_torch"] += 1
     return ok
@@ -708,7 +730,7 @@ def _plan2d(conv: nn.Module, device) -> _Plan:
 def _affine2d(conv, norm, plan: _Plan):
     """(scale, bias) of the epilogue: folded eval BatchNorm2d and / or the conv's own bias."""
     scale = bias = None
-    if norm is not None:
+    if isinstance(norm, nn.BatchNorm2d):
         scale, bias = _folded_bn(norm, plan)
     if conv.bias is not None:
         key = (conv.bias._version, conv.bias.data_ptr(), None if scale is None else scale.data_ptr(), _GENERATION[0])
@@ -748,7 +770,16 @@ def fused_conv2d(conv: nn.Conv2d, norm, x: torch.Tensor, *, relu=False, sigmoid=
         flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
     x5 = x.reshape(x.size(0), -1, 1, 1, 1) if whole else x.unsqueeze(2)
     r5 = residual.unsqueeze(2) if residual is not None else None
+    if isinstance(norm, nn.GroupNorm):
+        return _group_norm_2d(plan.layer(x5, scale, bias), norm, r5, flags).squeeze(2)
     return plan.layer(x5, scale, bias, r5, flags).squeeze(2)
+
+
+def _group_norm_2d(raw5, norm: nn.GroupNorm, r5, flags):
+    """GroupNorm of a conv output on the HIP kernels (reference submodule.py:11-29 with gn=True): per-(sample, group)
+    statistics in fp64, then normalise + affine + residual + activation in one pass, in place."""
+    scale, shift, _, _ = ops.norm_stats(raw5, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
+    return ops.affine_act(raw5, scale, shift, r5, flags, per_sample=True, out=raw5)
 
 
 def fused_deconv2d(conv: nn.ConvTranspose2d, norm, x: torch.Tensor, *, relu=False, residual=None) -> torch.Tensor:
@@ -766,7 +797,10 @@ def fused_deconv2d(conv: nn.ConvTranspose2d, norm, x: torch.Tensor, *, relu=Fals
     scale, bias = _affine2d(conv, norm, plan)
     flags = (EPI_RELU if relu else 0) | (EPI_ADD_PRE if residual is not None else 0)
     up = ops.zero_stuff2x(x)
-    return plan.layer(up.unsqueeze(2), scale, bias, residual.unsqueeze(2) if residual is not None else None, flags).squeeze(2)
+    r5 = residual.unsqueeze(2) if residual is not None else None
+    if isinstance(norm, nn.GroupNorm):
+        return _group_norm_2d(plan.layer(up.unsqueeze(2), scale, bias), norm, r5, flags).squeeze(2)
+    return plan.layer(up.unsqueeze(2), scale, bias, r5, flags).squeeze(2)
 
 
 def _cbr2d(seq, x, **kw):

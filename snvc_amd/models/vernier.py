@@ -179,8 +179,8 @@ class VernierScale(nn.Module):
             v = torch.nn.functional.avg_pool3d(v, (4, 1, 1), (4, 1, 1))         # :436
         else:
             ops.mul_broadcast(img, occ, out=cat[:, f:])                         # cat([v, img*occ])  :433
-            v = self.conv4(cat)                                                 # :435
-            v = ops.avgpool_depth4(v)                                           # :436
+            from .submodule import fused_conv3d_avgpool_d4
+            v = fused_conv3d_avgpool_d4(self.conv4[0][0], self.conv4[0][1], cat, relu=True)    # :435-436, one launch
         return v.reshape(n, -1, v.size(3), v.size(4)), occ, offset              # :437-438
 
     # ------------------------------------------------------------------ fp16-storage mode (BASELINE configs[4])

@@ -360,6 +360,32 @@ class Conv3dLayer:
         return (out, None) if side_head is not None else out
 
 
+def conv3d_forward_avgpool_d4(layer: "Conv3dLayer", x, scale, bias, flags) -> Optional[torch.Tensor]:
+    """AvgPool3d((4,1,1),(4,1,1)) of ``epilogue(conv(x))`` written by the layer's own launch (SNVC_EPI_AVGPOOL_D4): returns
+    [N,Cout,D/4,H,W], or None when the layer does not qualify (the caller then pools with ``avgpool_depth4``)."""
+    _gpu(x, "x")
+    if layer.transposed or layer.planar or layer.ksize != 3 or layer.stride != 1 or layer.dilation != 1:
+        return None
+    if x.dtype != torch.float32 or x.dim() != 5 or x.size(1) != layer.cin or x.size(2) % 4 != 0 or layer.cout % 32 != 0:
+        return None
+    if not _dense_inner(x):
+        x = x.contiguous()
+    n = x.size(0)
+    in_sp = tuple(x.shape[2:])
+    out = torch.empty((n, layer.cout, in_sp[0] // 4, in_sp[1], in_sp[2]), dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out
+    d = layer._desc(n, in_sp, flags | _lib.EPI_AVGPOOL_D4, _batch_stride(x), 0, 0)
+    d.algo = _algo()
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().snvc_conv3d_forward_ex(ctypes.byref(d), _ptr(x), _ptr(layer.packed), _ptr(scale), _ptr(bias), _ptr(None),
+                                               _ptr(None), _ptr(out), _stream(x))
+    if rc == 2:        # SNVC_ERR_UNSUPPORTED
+        return None
+    check(rc, "snvc_conv3d_forward(pooled)")
+    return out
+
+
 def conv3d_forward_head(layer: "Conv3dLayer", x, scale, bias, residual, flags, head_weight) -> Optional[torch.Tensor]:
     """epilogue(deconv(x)) projected to one channel by ``head_weight`` [Cout] inside the layer's epilogue
     (snvc_conv3d_forward_head); returns [N,1,D,H,W], or None when the layer does not qualify."""

@@ -97,7 +97,27 @@ def _routes():
     return S._ROUTES["neck2d_hip"], S._ROUTES["neck2d_torch"]
 
 
-@pytest.mark.parametrize("block", ["basic", "basic_down", "hg2d", "hg2d_skips", "hg2d_16"])
+def test_fused_conv2d_group_norm_vs_torch():
+    """cfg.gn: Conv2d / ConvTranspose2d + GroupNorm(32, C) (+ residual, + ReLU) on the HIP kernels against torch."""
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(1500)
+    for tr, cin, cout, stride, hw in ((False, 32, 64, 1, (12, 20)), (False, 64, 64, 2, (16, 24)), (True, 64, 32, 2, (6, 10))):
+        seq = S._deconvbn_2d(cin, cout, True) if tr else S.convbn(cin, cout, 3, stride, 1, 1, gn=True)
+        seq[0].weight.data.copy_(_t(r, tuple(seq[0].weight.shape)) * 0.1)
+        seq[1].weight.data.copy_(torch.from_numpy(r.uniform(0.5, 1.5, cout).astype(np.float32)))
+        seq[1].bias.data.copy_(torch.from_numpy(r.uniform(-0.2, 0.2, cout).astype(np.float32)))
+        x = _t(r, (2, cin) + hw)
+        with torch.no_grad():
+            ref = seq(x)
+            res = _t(r, tuple(ref.shape))
+            sd, xd, rd = seq.to(dev()), x.to(dev()), res.to(dev())
+            f = S.fused_deconv2d if tr else S.fused_conv2d
+            check(f(sd[0], sd[1], xd).cpu().numpy(), ref.numpy(), 5e-5, f"gn(conv) transposed={tr}")
+            check(f(sd[0], sd[1], xd, relu=True, residual=rd).cpu().numpy(), F.relu(ref + res).numpy(), 5e-5,
+                  f"relu(gn(conv) + res) transposed={tr}")
+
+
+@pytest.mark.parametrize("block", ["basic", "basic_down", "hg2d", "hg2d_skips", "hg2d_16", "hg2d_gn", "hg2d_16_gn"])
 def test_neck_blocks_vs_oracle_modules(block):
     """The blocks against the oracle's torch modules (pinned to the imported reference by make_golden.py) with the same
     seeded state dict; the HIP route must be the one taken under no_grad."""
@@ -110,6 +130,11 @@ def test_neck_blocks_vs_oracle_modules(block):
         ours = S.BasicBlock2d(16, 32, 2, S.basicdownsample(16, 32))
         ref = T.BasicBlock2d(16, 32, 2, T.basicdownsample(16, 32))
         x, extra = _t(r, (2, 16, 12, 8)), ()
+    elif block == "hg2d_gn":
+        ours, ref, x, extra = S.hourglass2d(32, gn=True), T.hourglass2d(32, gn=True), _t(r, (2, 32, 16, 24)), (None, None)
+    elif block == "hg2d_16_gn":
+        ours, ref, x, extra = (S.hourglass2d_downsample_16(32, gn=True), T.hourglass2d_downsample_16(32, gn=True),
+                               _t(r, (2, 32, 32, 48)), ())
     elif block == "hg2d":
         ours, ref, x, extra = S.hourglass2d(32), T.hourglass2d(32), _t(r, (2, 32, 16, 24)), (None, None)
     elif block == "hg2d_skips":

@@ -626,6 +626,28 @@ def test_folded_head_tail_vs_separate_layers():
             check(md.fused(xd, residual=rd, head=hd).cpu().numpy(), 0.5 * ref1.numpy(), TIGHT, "folded head after an update")
 
 
+def test_conv_avgpool_d4_fused_vs_separate():
+    """SNVC_EPI_AVGPOOL_D4: conv4 + AvgPool3d((4,1,1)) of the local trunk (vernier.py:289,435-436) in one launch against
+    torch; layers that do not qualify (W % 4 != 0, D % 4 != 0, GroupNorm) pool in a launch of their own."""
+    import torch.nn.functional as F
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(491)
+    for cin, cout, shape, fused in ((64, 32, (8, 6, 40), True), (32, 64, (4, 9, 156), True), (64, 32, (12, 5, 36), True),
+                                    (64, 32, (8, 6, 38), False), (64, 32, (6, 6, 40), False)):
+        m = seeded(S.convbn_3d(cin, cout, 3, 1, 1), 492).to(dev())
+        x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32))
+        with torch.no_grad():
+            ref = F.relu(F.batch_norm(F.conv3d(x, m[0].weight.cpu(), None, 1, 1), m[1].running_mean.cpu(), m[1].running_var.cpu(),
+                                      m[1].weight.cpu(), m[1].bias.cpu(), False, 0.0, m[1].eps))
+            if shape[0] % 4:
+                ref = ref[:, :, :shape[0] // 4 * 4]
+            exp = F.avg_pool3d(ref, (4, 1, 1), (4, 1, 1))
+            b_f, b_s = S._ROUTES["conv_avgpool_fused"], S._ROUTES["conv_avgpool_separate"]
+            got = S.fused_conv3d_avgpool_d4(m[0], m[1], x.to(dev()), relu=True)
+            assert (S._ROUTES["conv_avgpool_fused"], S._ROUTES["conv_avgpool_separate"]) == ((b_f + 1, b_s) if fused else (b_f, b_s + 1))
+        check(got.cpu().numpy(), exp.numpy(), TIGHT, f"conv + avgpool {cin}->{cout} {shape}")
+
+
 def test_side_head_vs_separate_projection():
     """snvc_conv3d_forward_side_head: y is bit-identical to the plain launch and y_head = head(y); layers that do not
     qualify get the projection from a launch of their own."""
@@ -869,10 +891,10 @@ def test_vernier_scale_vs_golden(name, G):
     with torch.no_grad():
         hip0, torch0 = S._ROUTES["neck2d_hip"], S._ROUTES["neck2d_torch"]
         out = m(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()))
-        # eval BatchNorm: every block of the 2D neck + heads ran on the HIP kernels, none on torch's; GroupNorm: the neck
-        # takes the modules' torch forward (the coordinate head's BasicBlocks carry BatchNorm2d either way)
+        # every block of the 2D neck + heads ran on the HIP kernels, none on torch's -- eval BatchNorm folded into the conv
+        # epilogues, GroupNorm as conv + statistics + normalise launches
         hip1, torch1 = S._ROUTES["neck2d_hip"], S._ROUTES["neck2d_torch"]
-        assert (hip1 > hip0 and torch1 == torch0) if not gn else torch1 > torch0
+        assert hip1 > hip0 and torch1 == torch0
         vox = m.construct_voxel(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()))
         bev, occ5, _ = m.trunk_3d(vox)
         idx, conf = m.ncf_argmax(out["ncf"])
