@@ -493,15 +493,17 @@ def main():
     model.eval().to(device)
     left, right, shift = make_inputs(rank, device)
 
-    def run(factored):
-        """W warm-up + K timed steps; returns (seconds for the K steps, mean ms of the first-conv launch,
-        mean ms of the cost-volume launch)."""
-        names = ("volume", "conv1")
+    def run(factored, sheared=True):
+        """W warm-up + K timed steps; returns (seconds for the K steps, mean ms of the "conv1" bracket, of the "volume"
+        bracket and of the "conv2" bracket).  sheared path: volume = Rq + the 2D convolution G + the 4-plane edge slab,
+        conv1 = the expand pass (0.74 GB write) + edge-plane copies; general path: volume = the right-half cost-volume
+        launch, conv1 = the first 3D convolution; conv2 = the second 3D convolution (+ side head) either way."""
+        names = ("volume", "conv1", "conv2")
         ev = [{k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in names}
               for _ in range(args.steps)]
         with torch.no_grad():
             for _ in range(args.warmup):
-                model.forward_pair(left, right, shift, 1, factored=factored)
+                model.forward_pair(left, right, shift, 1, factored=factored, sheared=sheared)
             # the cyclic garbage collector stays out of the timed region (as timeit does): a generation-2 pass over the
             # ~1e6 objects torch keeps alive costs ~35 ms, i.e. six steps, whenever its counter happens to trip
             gc.collect()
@@ -510,7 +512,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(args.steps):
                 # events go to torch's current stream == the stream the kernels are launched on
-                out = model.forward_pair(left, right, shift, 1, factored=factored, timing=ev[i])
+                out = model.forward_pair(left, right, shift, 1, factored=factored, timing=ev[i], sheared=sheared)
             barrier()
             elapsed = time.perf_counter() - t0
             gc.enable()
@@ -520,12 +522,18 @@ def main():
             elapsed = float(t.item())
         assert torch.isfinite(out).all()
         mean = lambda k: float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in ev]))  # noqa: E731
-        return elapsed, mean("conv1"), mean("volume")
+        return elapsed, mean("conv1"), mean("volume"), mean("conv2")
 
-    # Headline: factored first convolution (GlobalStack.forward_pair).  The same step through the reference's
-    # operator API (build_cost_volume + conv1 over all 64 channels) is timed in the same process.
-    elapsed, conv_ms, cvr_ms = run(True)
-    elapsed_mat, conv_ms_mat, cv_ms = run(False)
+    # Headline: GlobalStack.forward_pair.  cfg2's disparity planes are uniformly spaced (linspace(0, 95.5, 192): half-pixel
+    # steps), so the first convolution over the warped half runs as a 2D convolution along the shear (csrc/sheared_conv.hip).
+    # The same step on the general path (any shift array: factored first convolution over the built right half) and
+    # through the reference's operator API (build_cost_volume + conv1 over all 64 channels) is timed in the same process.
+    from snvc_amd.models import submodule as S_
+    routes0 = S_._ROUTES["sheared_first_conv"]
+    elapsed, expand_ms, shear_prep_ms, conv2_ms = run(True)
+    sheared_taken = S_._ROUTES["sheared_first_conv"] > routes0
+    elapsed_gen, conv_ms, cvr_ms, _ = run(True, sheared=False)
+    elapsed_mat, conv_ms_mat, cv_ms, _ = run(False)
 
     def run_reference_api():
         """the reference's call sequence, verbatim: volume = build_cost_volume(l, r, s, 1); cost = model(volume)"""
@@ -544,10 +552,12 @@ def main():
         assert torch.isfinite(out).all()
         return dt
     elapsed_api = run_reference_api()
-    dom_flop = CONV1_FLOP / 2                       # right half: 32 -> 32 channels, 27 taps
+    dom_flop = CONV1_FLOP / 2                       # a 32 -> 32 channel 3x3x3 layer on the full grid (conv2; conv1's right half)
     share = wino_executed_share(3, W)               # F(4,3): 6 of 12 multiplies x padding of W=312 to 320
-    exec_tflops = dom_flop * share / (conv_ms * 1e-3) / 1e12
-    alg_tflops = dom_flop / (conv_ms * 1e-3) / 1e12
+    dom_ms = conv2_ms if sheared_taken else conv_ms
+    exec_tflops = dom_flop * share / (dom_ms * 1e-3) / 1e12
+    alg_tflops = dom_flop / (dom_ms * 1e-3) / 1e12
+    V1_BYTES = 4.0 * C * D * H * W                  # the first layer's output, written once by the expand pass
     alg_tflops_mat = CONV1_FLOP / (conv_ms_mat * 1e-3) / 1e12
     # HBM bytes per launch: PMC counters cannot be read from inside this process; separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE, gfx950 correction) are committed under profiles/
@@ -586,10 +596,13 @@ def main():
                 "workload": "cfg2 global scene model: 1 pair/GPU, features [1,32,96,312] (1242x375 /4), "
                             "192 disparities -> concat volume [1,64,192,96,312] -> conv3d x2 + hourglass(32) + classifier",
                 "entry_points": {
-                    "value": "GlobalStack.forward_pair(left, right, shift): fused entry point; the left half of the concat "
-                             "volume is d-invariant -> 3 depth-class planes + 3D conv over the warped right half only "
-                             "(identical output: tests/test_gpu_parity.py::test_global_pair_end_to_end_vs_oracle, "
-                             "tests/test_gpu_fullsize.py)",
+                    "value": "GlobalStack.forward_pair(left, right, shift): fused entry point.  Left half of the concat volume: "
+                             "d-invariant -> 3 depth-class planes.  Warped right half: the disparity planes are uniformly "
+                             "spaced (shift = d/2), so it is a shear of one 2D image and conv1 over it is a 2D convolution "
+                             "evaluated along the shear (" + ("taken" if sheared_taken else "NOT taken") + "; csrc/sheared_conv.hip; "
+                             "tests/test_gpu_parity.py::test_sheared_first_conv_vs_oracle_and_general_path, tests/test_gpu_fullsize.py)",
+                    "general_shift": "the same entry point for ANY shift array (sheared=False): factored first convolution over "
+                                     "the built right half of the volume",
                     "reference_api": "model(build_cost_volume(left, right, shift, 1)): same kernels as `value` (lazy volume)",
                     "materialized": "the full concat volume built in HBM, then the modules (conv1 over all 64 channels)"},
                 "pairs_per_gpu_per_step": 1,
@@ -598,8 +611,11 @@ def main():
                 "step_cost_volume_mb_algorithmic": CV_BYTES / 1e6,
             },
             "roofline": {
-                "kernel": "conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, planes>: first conv over the right half of the volume, "
-                          "32->32 on 192x96x312, + depth-class planes (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)",
+                "kernel": ("conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, side head>: second 3D convolution, 32->32 on 192x96x312 "
+                           "+ the classifier's projection of its own result (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)"
+                           if sheared_taken else
+                           "conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, planes>: first conv over the right half of the volume, "
+                           "32->32 on 192x96x312, + depth-class planes (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)"),
                 "bound": "mfma",
                 # `achieved` = flops the kernel EXECUTES on the matrix pipe per second (F(4,3) issues 6 MFMAs where
                 # the direct form needs 12; W = 312 is padded to 320) -> frac <= 1 is the pipe's utilisation.
@@ -611,15 +627,20 @@ def main():
                 "algorithmic_over_peak": alg_tflops / PEAK_F32_MFMA_TFLOPS,
                 "flop_per_launch_algorithmic": dom_flop,
                 "flop_per_launch_executed": dom_flop * share,
-                "avg_launch_ms": conv_ms,
+                "avg_launch_ms": dom_ms,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
             },
             "roofline_hbm": {
-                "kernel": "cost_volume_fwd_rows: right (warped) half only, as the fused entry point builds it",
+                "kernel": "cost_volume_fwd_rows: right (warped) half only, as the general path builds it",
                 "bound": "hbm", "achieved": CV_RIGHT_BYTES / (cvr_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": CV_RIGHT_BYTES / (cvr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": CV_RIGHT_BYTES,
                 "avg_launch_ms": cvr_ms,
+                "sheared_expand": {"kernel": "sheared_expand_kernel + 2 edge-plane copies: conv1's result written along the shear "
+                                             "(the headline path's first layer: one 0.74 GB write stream)",
+                                   "achieved": V1_BYTES / (expand_ms * 1e-3) / 1e9, "frac": V1_BYTES / (expand_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "bytes_per_launch": V1_BYTES, "avg_launch_ms": expand_ms,
+                                   "prep_ms": shear_prep_ms, "prep": "Rq + depth-1 7x7 convolution (G, G') + 4-plane edge slab"},
                 "full_volume": {"kernel": "cost_volume_fwd_rows: build_cost_volume, both halves (materialized leg)",
                                 "achieved": CV_BYTES / (cv_ms * 1e-3) / 1e9, "frac": CV_BYTES / (cv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "bytes_per_launch": CV_BYTES, "avg_launch_ms": cv_ms},
@@ -631,6 +652,14 @@ def main():
                         "builds the real volume (tests/test_gpu_parity.py::test_lazy_cost_volume_reference_call_sequence)",
                 "value": world * args.steps / elapsed_api,
                 "ms_per_step": 1e3 * elapsed_api / args.steps,
+            },
+            "general_shift": {
+                "note": "same step on the path any shift array takes (forward_pair(..., sheared=False)): right half of the volume "
+                        "built (cost_volume_fwd_rows), factored first 3D convolution over it",
+                "value": world * args.steps / elapsed_gen,
+                "ms_per_step": 1e3 * elapsed_gen / args.steps,
+                "conv1_ms": conv_ms, "conv1_pipe_frac": dom_flop * share / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "volume_ms": cvr_ms,
             },
             "materialized": {
                 "note": "same step with the full concat volume built in HBM (what the reference does, and what this library "

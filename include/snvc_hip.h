@@ -290,6 +290,24 @@ SNVC_API int snvc_conv3d_forward_side_head(const snvc_conv3d_desc *desc_host, co
                                            const float *packed_weight, const float *scale, const float *bias,
                                            const float *residual, float *y, const float *head_weight,
                                            float *y_head, void *stream);
+/* ------------------------------------------------------------------------------------
+ * Sheared first convolution: the 3x3x3 convolution over the WARPED half of build_cost_volume's result when the
+ * disparity planes are uniformly spaced, shift[n][d] = (m0 + d) / q with q in {1, 2} (whole- / half-pixel steps; the
+ * plane-sweep volume of BASELINE.json configs[1] is q = 2, m0 = 0).  Then V[c][d][h][w] = Rq[c][h][q*w - d - m0] with
+ * Rq the reference's own interpolation of the right feature on the 1/q-pixel grid (BuildCostVolume_cuda.cu:15-98), and
+ * conv(V)[co][d][h][w] = G[co][h][q*w - d - m0] for a 2D convolution G of Rq (csrc/sheared_conv.hip has the algebra and
+ * the three borders that are not sheared).  The warped volume is never built and the layer's 318 GFLOP become 3.4.
+ *   snvc_sheared_upsample : out[n][c][h][i] = Rq[i - off] on a row of WU floats (zero outside 0 <= u <= q*(W-1))
+ *   snvc_conv3d_forward   : G / G' = the depth-1 7x7 convolution of that image (desc.ksize_d = 1, ksize = 7), 2*C
+ *                           output channels (C.. = the kernel without its kw = +1 taps, used at w = W-1)
+ *   snvc_sheared_expand   : y[n][co][d][h][w] = epilogue(scale*(G|G')[n][co][h][q*w - d - m0 + off] + planes[n][co][1][h][w])
+ *                           for the planes d = 1 .. D-2 (planes: the depth-class planes of snvc_conv3d_forward_ex, or NULL);
+ *                           the planes d = 0 and d = D-1 are the caller's (general kernels on a 4-plane slab). */
+SNVC_API int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, int64_t H, int64_t W, int q,
+                                   int64_t WU, int off, void *stream);
+SNVC_API int snvc_sheared_expand(const float *g, const float *planes, const float *scale, const float *bias, float *y,
+                                 int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off,
+                                 int flags, void *stream);
 SNVC_API int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *desc_host);
 SNVC_API int snvc_conv3d_wgrad(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
                                void *workspace, void *stream);

@@ -56,6 +56,8 @@ SIGNATURES = {
     "snvc_conv3d_forward_ex": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_conv3d_forward_head": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_conv3d_forward_side_head": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "snvc_sheared_upsample": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_p]),
+    "snvc_sheared_expand": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_int, c_p]),
     "snvc_norm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "snvc_norm_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_p]),
     "snvc_affine_act": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),

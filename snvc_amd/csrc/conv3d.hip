@@ -2095,7 +2095,7 @@ enum Kind {
     K5D2_M1, K5D2_M2,
     K7_M1, K7_M2,
     DC_M1, DC_M2,
-    P1_M1S, P1S2_M1S, P3_M1S, P3S2_M1S,                                  // depth-1 (2D) layers, 1 x 4 x 32 tiles
+    P1_M1S, P1S2_M1S, P3_M1S, P3S2_M1S, P7_M1S,                          // depth-1 (2D) layers, 1 x 4 x 32 tiles
     KIND_NONE
 };
 
@@ -2126,6 +2126,8 @@ using CfgP1M1s   = ConvCfg<1, 1, 1, 1, 1, 4, 32, true, 2, 0, 1>;
 using CfgP1S2M1s = ConvCfg<1, 2, 1, 1, 1, 4, 16, true, 2, 0, 1>;
 using CfgP3M1s   = ConvCfg<3, 1, 1, 1, 1, 4, 16, true, 2, 0, 1>;
 using CfgP3S2M1s = ConvCfg<3, 2, 1, 1, 1, 4, 8, true, 2, 0, 1>;
+// 7 x 7, stride 1: the sheared first convolution of the global model (sheared_conv.hip: a 3 x 7 kernel embedded in 7 x 7)
+using CfgP7M1s   = ConvCfg<7, 1, 1, 1, 1, 4, 4, true, 2, 0, 1>;
 using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64 voxels, 2 input channels per chunk
 using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per wave: large layers
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;
@@ -2174,7 +2176,8 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
             case 12: p = plan_of<CfgP1S2M1s>(P1S2_M1S); break;
             case 31: p = plan_of<CfgP3M1s>(P3_M1S); break;
             case 32: p = plan_of<CfgP3S2M1s>(P3S2_M1S); break;
-            default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: depth-1 layers are built for ksize 1 and 3, stride 1 and 2");
+            case 71: p = plan_of<CfgP7M1s>(P7_M1S); break;
+            default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: depth-1 layers are built for ksize 1 and 3 (stride 1 and 2) and ksize 7 (stride 1)");
         }
         p.tiles_d = 1; p.tiles_h = ceil_div(d.Hout, p.TH); p.tiles_w = ceil_div(d.Wout, 32);
     } else {
@@ -2647,6 +2650,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         case P1S2_M1S: launch_conv<CfgP1S2M1s>(a, grid, st); break;
         case P3_M1S: launch_conv<CfgP3M1s, true>(a, grid, st); break;
         case P3S2_M1S: launch_conv<CfgP3S2M1s, true>(a, grid, st); break;
+        case P7_M1S: launch_conv<CfgP7M1s>(a, grid, st); break;
         case DC_M1:
             if (!a.vec && vec8) { a.vec = 1; launch_deconv<CfgDCM1v8>(a, grid, st); }
             else launch_deconv<CfgDCM1>(a, grid, st);

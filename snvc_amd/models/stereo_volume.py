@@ -18,8 +18,8 @@ import torch.nn as nn
 
 from ..extension.build_cost_volume import _BuildCostVolume, build_cost_volume  # noqa: F401  (re-exported)
 from .. import ops
-from .submodule import (_GENERATION, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _folded_bn, _Plan, convbn_3d, hourglass,
-                        EPI_RELU)
+from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _folded_bn, _Plan, convbn_3d,
+                        hourglass, EPI_RELU)
 
 
 class GlobalStack(nn.Module):
@@ -75,8 +75,12 @@ class GlobalStack(nn.Module):
         cost, _, _ = self.hg_conv3d(v, None, None, residual=v, head=self.classifier, head_residual=hv)
         return cost
 
-    def _conv2_tail(self, v1, shape):
+    def _conv2_tail(self, v1, shape, timing=None):
+        if timing is not None and "conv2" in timing:
+            timing["conv2"][0].record()
         v, hv = self.conv2.fused(v1, out=self._buffer("v2", shape, v1.device), side_head=self.classifier)
+        if timing is not None and "conv2" in timing:
+            timing["conv2"][1].record()
         return self._tail(v, hv)
 
     def forward(self, volume):
@@ -95,7 +99,41 @@ class GlobalStack(nn.Module):
         v = self.conv1.fused(volume, out=self._buffer("v1", shape, volume.device))
         return self._conv2_tail(v, shape)
 
-    def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False):
+    @staticmethod
+    def _shift_structure(shift):
+        """One device -> host round trip (it replaces the `assert torch.all(shift >= 0)` sync of the reference's wrapper):
+        (all shifts >= 0, (q, m0) or None).  (q, m0): every row of ``shift`` is (m0 + d) / q for d = 0..D-1 with q in {1, 2}
+        -- uniformly spaced whole- or half-pixel disparity planes -- exactly, in fp32."""
+        d = shift.size(1)
+        s = shift.detach().float()
+        ar = torch.arange(d, dtype=torch.float32, device=shift.device)
+        s00 = s[:1, :1]
+        flags = torch.stack([(s >= 0).all(), (s == s00 + ar).all(), (s == s00 + 0.5 * ar).all()]).float()
+        nonneg, u1, u2, first = torch.cat([flags, s00.reshape(1)]).tolist()
+        q = 1 if u1 else (2 if u2 else 0)
+        m0 = first * q
+        if q == 0 or d < 4 or m0 != int(m0) or not (0 <= m0 < 1 << 20):
+            return bool(nonneg), None
+        return bool(nonneg), (q, int(m0))
+
+    def _sheared_layer(self, plans, wr, q):
+        """The depth-1 7x7 layer that computes G and G' (csrc/sheared_conv.hip): K[kh][t] = sum over (kd, kw) with
+        q*kw - kd = t of the right-half weights, folded in fp64; output channels C.. carry the kernel without its kw = +1 taps."""
+        cache = plans.setdefault("sheared", {})
+        if q not in cache:
+            w = wr.detach().double()                                       # [Cout, C, kd, kh, kw]
+            cout, c = w.shape[0], w.shape[1]
+            k = torch.zeros((2, cout, c, 7, 7), dtype=torch.float64, device=w.device)
+            for kd in (-1, 0, 1):
+                for kw in (-1, 0, 1):
+                    t = q * kw - kd
+                    k[0, :, :, 2:5, t + 3] += w[:, :, kd + 1, :, kw + 1]
+                    if kw != 1:
+                        k[1, :, :, 2:5, t + 3] += w[:, :, kd + 1, :, kw + 1]
+            cache[q] = ops.Conv3dLayer(k.reshape(2 * cout, c, 7, 7).float().contiguous(), 7, 1, 3, 1, False, planar=True)
+        return cache[q]
+
+    def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
 
         ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT
@@ -107,6 +145,12 @@ class GlobalStack(nn.Module):
         of the volume that has to be built.  Same result (fp32 summation order aside), half of
         conv1's work and of the volume's HBM traffic.  ``factored=False`` materialises the full volume
         through ``build_cost_volume`` exactly like the reference would.
+        ``sheared=True`` (with ``factored``): when the disparity planes are uniformly spaced by a whole or half pixel --
+        ``shift[n, d] = (m0 + d) / q``, q in {1, 2}, what a plane sweep over disparities is (BASELINE.json configs[1]:
+        linspace(0, 95.5, 192)) -- the warped half is a shear of ONE 2D image and conv1 over it is a 2D convolution
+        evaluated along the shear (csrc/sheared_conv.hip): the warped volume is not built at all and conv1's 318 GFLOP
+        become 3.4.  Any other shift array (checked on the device, same sync as the reference's assert) takes the
+        general factored path.
         ``timing``: optional dict ``{"volume": (start, end), "conv1": (start, end)}`` of events recorded on the
         current stream around the cost-volume launch and the first 3D convolution (the dominant kernel); used by
         bench.py for the roofline figures."""
@@ -143,8 +187,12 @@ class GlobalStack(nn.Module):
             mark("conv1", 1)
             del vol
             return self._conv2_tail(v, shape)
-        if not shift_checked:                    # a LazyCostVolume was checked when build_cost_volume made it
-            assert torch.all(shift >= 0.)        # same contract as build_cost_volume (reference __init__.py:12)
+        structure = None
+        if sheared and left.size(0) > 0 and shift.size(1) >= 4 and shift.dtype == torch.float32:
+            nonneg, structure = self._shift_structure(shift)
+            assert nonneg                        # same contract as build_cost_volume (reference __init__.py:12)
+        elif not shift_checked:                  # a LazyCostVolume was checked when build_cost_volume made it
+            assert torch.all(shift >= 0.)
         c = left.size(1)
         w = conv.weight
         plans = conv.__dict__.setdefault("_snvc_factored", {})
@@ -156,11 +204,31 @@ class GlobalStack(nn.Module):
         scale, bias = _folded_bn(bn, plans["plan"])
         left3 = left.unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()       # [N,C,3,H,W]
         planes = plans["left"](left3)                                           # depth classes: first / interior / last
-        mark("volume", 0)
         shape = (left.size(0), c, shift.size(1)) + tuple(left.shape[2:])
+        if structure is not None:
+            q, m0 = structure
+            d, wd = shift.size(1), left.size(3)
+            off = 4
+            wu = (off + q * (wd - 1) + 1 + 3 + 3) // 4 * 4
+            mark("volume", 0)
+            rq = ops.sheared_upsample(right, q, wu, off)                                          # [N,C,H,WU]
+            g = self._sheared_layer(plans, w.detach()[:, c:], q)(rq.unsqueeze(2)).squeeze(2)      # [N,2C,H,WU]: G | G'
+            slab = torch.tensor([0, 1, d - 2, d - 1], device=shift.device)
+            vol4 = ops.cost_volume_forward_right(right, shift.index_select(1, slab))              # planes 0, 1, D-2, D-1
+            edge = plans["right"](vol4, scale, bias, None, ops.EPI_RELU, None, depth_planes=planes)
+            mark("volume", 1)
+            mark("conv1", 0)
+            v = self._buffer("v1", shape, left.device)
+            ops.sheared_expand(g, planes, scale, bias, v, q, m0, off, ops.EPI_RELU)               # planes 1 .. D-2
+            v[:, :, 0].copy_(edge[:, :, 0])
+            v[:, :, d - 1].copy_(edge[:, :, 3])
+            mark("conv1", 1)
+            _ROUTES["sheared_first_conv"] += 1
+            return self._conv2_tail(v, shape, timing)
+        mark("volume", 0)
         vol_r = ops.cost_volume_forward_right(right, shift, out=self._buffer("vol_r", shape, left.device))   # [N,C,D,H,W]
         mark("volume", 1)
         mark("conv1", 0)
         v = plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, self._buffer("v1", shape, left.device), depth_planes=planes)
         mark("conv1", 1)
-        return self._conv2_tail(v, shape)
+        return self._conv2_tail(v, shape, timing)

@@ -360,6 +360,36 @@ class Conv3dLayer:
         return (out, None) if side_head is not None else out
 
 
+def sheared_upsample(right, q: int, wu: int, off: int):
+    """Rq on a padded grid (snvc_sheared_upsample): right [N,C,H,W] -> [N,C,H,wu], element i = Rq[i - off]."""
+    _gpu(right, "right")
+    if right.dtype != torch.float32 or right.dim() != 4:
+        raise RuntimeError("sheared_upsample needs a float32 [N,C,H,W] tensor")
+    right = right.contiguous()
+    n, c, h, w = right.shape
+    out = torch.empty((n, c, h, wu), dtype=torch.float32, device=right.device)
+    with torch.cuda.device(right.device):
+        check(_lib.lib().snvc_sheared_upsample(_ptr(right), _ptr(out), n, c, h, w, int(q), int(wu), int(off), _stream(right)),
+              "snvc_sheared_upsample")
+    return out
+
+
+def sheared_expand(g, planes, scale, bias, out, q: int, m0: int, off: int, flags: int = 0):
+    """out[n,co,d,h,w] = epilogue(scale*(G | G')[n,co,h,q*w-d-m0+off] + planes[n,co,1,h,w] + bias) for d = 1 .. D-2
+    (snvc_sheared_expand); g [N,2C,H,WG], planes [N,C,3,H,W] or None, out [N,C,D,H,W] (contiguous, written in place)."""
+    _gpu(g, "g"); _gpu(out, "out")
+    n, c, d, h, w = out.shape
+    if (g.dtype != torch.float32 or out.dtype != torch.float32 or tuple(g.shape[:3]) != (n, 2 * c, h) or not g.is_contiguous()
+            or not out.is_contiguous()):
+        raise RuntimeError("sheared_expand needs contiguous float32 g [N,2C,H,WG] and out [N,C,D,H,W]")
+    if planes is not None and (tuple(planes.shape) != (n, c, 3, h, w) or not planes.is_contiguous()):
+        raise RuntimeError("planes must be a contiguous [N,C,3,H,W] tensor")
+    with torch.cuda.device(out.device):
+        check(_lib.lib().snvc_sheared_expand(_ptr(g), _ptr(planes), _ptr(scale), _ptr(bias), _ptr(out), n, c, d, h, w, int(q), int(m0),
+                                             g.size(3), int(off), int(flags), _stream(out)), "snvc_sheared_expand")
+    return out
+
+
 def conv3d_forward_avgpool_d4(layer: "Conv3dLayer", x, scale, bias, flags) -> Optional[torch.Tensor]:
     """AvgPool3d((4,1,1),(4,1,1)) of ``epilogue(conv(x))`` written by the layer's own launch (SNVC_EPI_AVGPOOL_D4): returns
     [N,Cout,D/4,H,W], or None when the layer does not qualify (the caller then pools with ``avgpool_depth4``)."""

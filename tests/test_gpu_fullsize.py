@@ -84,18 +84,32 @@ def test_conv3d_full_size_crops_and_linearity():
 
 
 def test_global_pair_full_size_factored_equals_materialised(pair):
-    """The benchmarked step at full size: factored first convolution vs the materialised concat volume."""
+    """The benchmarked step at full size: the sheared first convolution (uniform disparity planes) and the general factored
+    first convolution, both against the materialised concat volume; the first layer's output of the two compared directly."""
     from snvc_amd.models.stereo_volume import GlobalStack
     import bench
     m = GlobalStack(C)
     m.load_state_dict(bench.seeded_state(m))
     m.eval().to(dev())
     dl, dr, ds = (torch.from_numpy(a).to(dev()) for a in pair)
+    from snvc_amd.models import submodule as S
     with torch.no_grad():
-        a = m.forward_pair(dl, dr, ds, 1, factored=True)
+        before = S._ROUTES["sheared_first_conv"]
+        s = m.forward_pair(dl, dr, ds, 1)                           # cfg2's shifts are d / 2: the sheared first convolution
+        assert S._ROUTES["sheared_first_conv"] == before + 1
+        v1s = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+        probe_s = v1s[0, ::7, ::5, ::9, ::11].clone()               # the first layer itself, strided over the whole volume,
+        edge_s = [v1s[0, :, 0].clone(), v1s[0, :, D - 1].clone(), v1s[0, :, :, :, W - 1].clone(), v1s[0, :, :, :, 0].clone()]
+        a = m.forward_pair(dl, dr, ds, 1, factored=True, sheared=False)
+        v1g = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+        assert torch.allclose(probe_s, v1g[0, ::7, ::5, ::9, ::11], rtol=1e-4, atol=1e-5)
+        for e, g in zip(edge_s, (v1g[0, :, 0], v1g[0, :, D - 1], v1g[0, :, :, :, W - 1], v1g[0, :, :, :, 0])):   # and its four borders whole
+            assert torch.allclose(e, g, rtol=1e-4, atol=1e-5), (e - g).abs().max()
         b = m.forward_pair(dl, dr, ds, 1, factored=False)
     assert a.shape == (1, 1, D, H, W) and torch.isfinite(a).all()
     err = (a - b).abs().max().item() / b.abs().max().item()
+    assert err < 1e-4, err
+    err = (s - b).abs().max().item() / b.abs().max().item()
     assert err < 1e-4, err
 
 

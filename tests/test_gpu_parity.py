@@ -1068,6 +1068,48 @@ def test_global_pair_end_to_end_vs_oracle(tile):
     check(full1, exp1, 2e-5, "conv1")
 
 
+@pytest.mark.parametrize("q,m0", [(2, 0), (2, 3), (1, 0), (1, 2)])
+def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
+    """Uniformly spaced disparity planes, shift[d] = (m0 + d) / q: forward_pair takes the sheared first convolution
+    (csrc/sheared_conv.hip: no warped volume, conv1 as a 2D convolution along the shear) -- against the C oracle's cost
+    volume + the torch-CPU stack, and against the general factored path on the same inputs; every border (d = 0, D-1,
+    w = 0, W-1, x < 0 gate, planes of the left half) is inside these small shapes.  Any other shift array keeps the
+    general path (route counter)."""
+    from oracle import native as O
+    from oracle import torch_ref as T
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    r = np.random.default_rng(141 + 10 * q + m0)
+    C, H, W, D = 32, 8, 40, 12
+    L = r.standard_normal((2, C, H, W)).astype(np.float32)
+    R = r.standard_normal((2, C, H, W)).astype(np.float32)
+    s = np.tile(((m0 + np.arange(D)) / q).astype(np.float32)[None], (2, 1))
+    ref = seeded(T.GlobalStack(C), 142)
+    ours = seeded(GlobalStack(C), 142).to(dev())
+    dl, dr, dsh = torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()), torch.from_numpy(s).to(dev())
+    with torch.no_grad():
+        exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, 1))).numpy()
+        before = S._ROUTES["sheared_first_conv"]
+        got = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()
+        assert S._ROUTES["sheared_first_conv"] == before + 1
+        general = ours.forward_pair(dl, dr, dsh, 1, sheared=False).cpu().numpy()
+        assert S._ROUTES["sheared_first_conv"] == before + 1
+        # first layer alone (before conv2 / the hourglass smooth anything over): the sheared planes against the general ones
+        v_sheared = ours.__dict__["_snvc_ws"]
+        ours.forward_pair(dl, dr, dsh, 1)
+        v1s = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+        ours.forward_pair(dl, dr, dsh, 1, sheared=False)
+        v1g = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+        # a shift array that is not uniformly spaced: general path
+        dsh2 = dsh.clone()
+        dsh2[0, 5] += 0.25
+        ours.forward_pair(dl, dr, dsh2, 1)
+        assert S._ROUTES["sheared_first_conv"] == before + 2
+    check(v1s.cpu().numpy(), v1g.cpu().numpy(), TIGHT, f"first layer, sheared vs general q={q} m0={m0}")
+    check(got, exp, 1e-4, f"pair (sheared) vs oracle q={q} m0={m0}")
+    check(got, general, 2e-5, f"sheared vs general path q={q} m0={m0}")
+
+
 @pytest.mark.parametrize("gn", [False, True])
 def test_training_step_vernier_trunk_vs_torch_autograd(gn):
     """Local (V-A) model: gather + 3D trunk (7^3, 5^3, dilated 5^3 convs, hourglass, heads' inputs)
