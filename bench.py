@@ -521,7 +521,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert torch.isfinite(out).all()
-        mean = lambda k: float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in ev]))  # noqa: E731
+        def mean(k):
+            try:
+                return float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in ev]))
+            except (RuntimeError, ValueError):      # a bracket this path does not record
+                return float("nan")
         return elapsed, mean("conv1"), mean("volume"), mean("conv2")
 
     # Headline: GlobalStack.forward_pair.  cfg2's disparity planes are uniformly spaced (linspace(0, 95.5, 192): half-pixel
@@ -561,16 +565,21 @@ def main():
     alg_tflops_mat = CONV1_FLOP / (conv_ms_mat * 1e-3) / 1e12
     # HBM bytes per launch: PMC counters cannot be read from inside this process; separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE, gfx950 correction) are committed under profiles/
-    traffic, traffic_src = None, None
-    for rel in ("profiles/r2/traffic.json", "profiles/r1/traffic.json"):
+    traffic, traffic_src, traffic_conv2 = None, None, None
+    for rel in ("profiles/r3/traffic.json", "profiles/r2/traffic.json", "profiles/r1/traffic.json"):
         try:
             with open(os.path.join(ROOT, rel)) as fh:
-                traffic = json.load(fh).get("conv1_right_wino43_dma_k3_32to32_cfg2", {}).get("hbm_bytes_corrected")
-            if traffic is not None:
+                tj = json.load(fh)
+            if traffic_conv2 is None:
+                traffic_conv2 = tj.get("layers", {}).get("conv2_side", {}).get("hbm_bytes_corrected")
+            if traffic is None:
+                traffic = tj.get("conv1_right_wino43_dma_k3_32to32_cfg2", {}).get("hbm_bytes_corrected")
+            if traffic is not None and traffic_src is None:
                 traffic_src = rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-                break
         except Exception:
             pass
+    if sheared_taken and traffic_conv2 is not None:
+        traffic_src = "profiles/r3/traffic.json, layer conv2_side (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
 
     if args.breakdown and rank == 0:
         _breakdown(model, left, right, shift, build_cost_volume)
@@ -628,7 +637,7 @@ def main():
                 "flop_per_launch_algorithmic": dom_flop,
                 "flop_per_launch_executed": dom_flop * share,
                 "avg_launch_ms": dom_ms,
-                "traffic": traffic,
+                "traffic": traffic if not sheared_taken else traffic_conv2,
                 "traffic_source": traffic_src,
             },
             "roofline_hbm": {

@@ -207,7 +207,8 @@ typedef struct {
                            padding=(k-1)/2) of the 2D BEV neck (snvc/models/vernier.py:296-313, submodule.py:11-29,
                            270-361) run on the [N,C,1,H,W] view of its NCHW tensors: Din = Dout = 1, k in {1,3}, stride
                            in {1,2} applied to H and W only, weight [Cout,Cin,k,k] */
-    int32_t reserved;   /* 0 */
+    int32_t ksize_h;    /* kernel extent along H of a depth-1 layer: 0 = ksize; 3 with ksize = 7 is the 3 x 7 layer of the
+                           sheared first convolution (weight [Cout,Cin,3,7], padding (1,3)); anything else unsupported */
     int64_t x_batch_stride, y_batch_stride, res_batch_stride; /* elements; 0 = dense */
 } snvc_conv3d_desc;
 
@@ -297,17 +298,19 @@ SNVC_API int snvc_conv3d_forward_side_head(const snvc_conv3d_desc *desc_host, co
  * Rq the reference's own interpolation of the right feature on the 1/q-pixel grid (BuildCostVolume_cuda.cu:15-98), and
  * conv(V)[co][d][h][w] = G[co][h][q*w - d - m0] for a 2D convolution G of Rq (csrc/sheared_conv.hip has the algebra and
  * the three borders that are not sheared).  The warped volume is never built and the layer's 318 GFLOP become 3.4.
- *   snvc_sheared_upsample : out[n][c][h][i] = Rq[i - off] on a row of WU floats (zero outside 0 <= u <= q*(W-1))
- *   snvc_conv3d_forward   : G / G' = the depth-1 7x7 convolution of that image (desc.ksize_d = 1, ksize = 7), 2*C
- *                           output channels (C.. = the kernel without its kw = +1 taps, used at w = W-1)
- *   snvc_sheared_expand   : y[n][co][d][h][w] = epilogue(scale*(G|G')[n][co][h][q*w - d - m0 + off] + planes[n][co][1][h][w])
- *                           for the planes d = 1 .. D-2 (planes: the depth-class planes of snvc_conv3d_forward_ex, or NULL);
- *                           the planes d = 0 and d = D-1 are the caller's (general kernels on a 4-plane slab). */
+ *   snvc_sheared_upsample : out[n][c][h][i] = Rq[i - off] on a row of WU floats (zero outside 0 <= u <= q*(W-1); off may
+ *                           be negative: a window of Rq)
+ *   snvc_conv3d_forward   : G = the depth-1 3 x 7 convolution of that image (desc.ksize_d = 1, ksize_h = 3, ksize = 7); G' =
+ *                           the same with the kernel stripped of its kw = +1 taps, over the window the last column reads
+ *   snvc_sheared_expand   : y[n][co][d][h][w] = epilogue(scale*G[n][co][h][q*w - d - m0 + off] + planes[n][co][1][h][w]),
+ *                           G'[..][q*(W-1) - d - m0 + off2] in place of G at w = W-1, for the planes d = 1 .. D-2 (planes: the
+ *                           depth-class planes of snvc_conv3d_forward_ex, or NULL); the planes d = 0 and d = D-1 are the
+ *                           caller's (general kernels on a 4-plane slab). */
 SNVC_API int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, int64_t H, int64_t W, int q,
                                    int64_t WU, int off, void *stream);
-SNVC_API int snvc_sheared_expand(const float *g, const float *planes, const float *scale, const float *bias, float *y,
-                                 int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off,
-                                 int flags, void *stream);
+SNVC_API int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale,
+                                 const float *bias, float *y, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q,
+                                 int m0, int64_t WG, int off, int64_t WG2, int off2, int flags, void *stream);
 SNVC_API int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *desc_host);
 SNVC_API int snvc_conv3d_wgrad(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
                                void *workspace, void *stream);

@@ -22,7 +22,7 @@ class Conv3dDesc(ctypes.Structure):
     """Mirror of ``snvc_conv3d_desc`` (include/snvc_hip.h)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         "N", "Cin", "Din", "Hin", "Win", "Cout", "Dout", "Hout", "Wout",
-        "ksize", "stride", "dilation", "pad", "transposed", "flags", "algo", "ksize_d", "reserved")] + [
+        "ksize", "stride", "dilation", "pad", "transposed", "flags", "algo", "ksize_d", "ksize_h")] + [
         (n, ctypes.c_int64) for n in ("x_batch_stride", "y_batch_stride", "res_batch_stride")]
 
 
@@ -57,7 +57,8 @@ SIGNATURES = {
     "snvc_conv3d_forward_head": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_conv3d_forward_side_head": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_sheared_upsample": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_p]),
-    "snvc_sheared_expand": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_int, c_p]),
+    "snvc_sheared_expand": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_i64, c_int,
+                                    c_int, c_p]),
     "snvc_norm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "snvc_norm_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_p]),
     "snvc_affine_act": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),

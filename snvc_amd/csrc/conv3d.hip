@@ -333,8 +333,12 @@ __device__ __forceinline__ void store_pairs_x4(char *base, int64_t cs, unsigned 
 }
 
 // ------------------------------------------------------------------------------------ conv
-template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_, bool DB_, int OCC_ = 2, int KDG_ = 0, int KSD_ = KS_>
+template <int KS_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KC_, bool DB_, int OCC_ = 2, int KDG_ = 0, int KSD_ = KS_,
+          int KSH_ = KS_>
 struct ConvCfg {
+    // KSH: kernel extent along H (= KS except for the 3 x 7 depth-1 layer of the sheared first convolution, desc.ksize_h)
+    static constexpr int KSH = KSH_;
+    static constexpr int PAD_H = DIL_ * (KSH_ - 1) / 2;
     // KSD: kernel extent along D.  KSD = KS for the cubic 3D layers; KSD = 1 (with TD = 1) is the depth-1 form that
     // runs the 2D BEV neck's Conv2d layers on [N,C,1,H,W] views (desc.ksize_d = 1).
     // A chunk (KC input channels) is consumed in NPH phases of KDG kernel depth-slices each; the
@@ -353,15 +357,15 @@ struct ConvCfg {
     static constexpr int LPAD = (PAD + 3) / 4 * 4;  // left halo rounded to a 16-byte boundary
     static constexpr int XOFF = LPAD - PAD;         // image column of the tile's first needed input
     static constexpr int IN_D = (TD - 1) * STRIDE + (KSD - 1) * DIL + 1;
-    static constexpr int IN_H = (TH - 1) * STRIDE + (KS - 1) * DIL + 1;
+    static constexpr int IN_H = (TH - 1) * STRIDE + (KSH - 1) * DIL + 1;
     static constexpr int IN_W = (TW - 1) * STRIDE + (KS - 1) * DIL + 1;
     static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;
     using St = Stager<KC, IN_D, IN_H, IN_WV>;
     static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int NB = TD * TH / 4;          // 32-voxel rows per wave (4 waves)
     static constexpr int KP = KC / 2;               // MFMA k-steps per chunk
-    static constexpr int TAPS = KSD * KS * KS;
-    static constexpr int WF = KDG * KS * KS * KP * 64 * MI;   // packed weight floats per phase
+    static constexpr int TAPS = KSD * KSH * KS;
+    static constexpr int WF = KDG * KSH * KS * KP * 64 * MI;  // packed weight floats per phase
     using Ws = WeightStager<WF>;
     static constexpr int IMG_BUFS = DB ? 2 : 1;
     static constexpr int LDS_BYTES = (TILE * IMG_BUFS + WF * 2) * 4;   // images, then two weight buffers
@@ -376,12 +380,13 @@ __device__ __forceinline__ void conv_compute_phase(const float *__restrict__ img
     // wl : staged weights of this phase + lane*MI.  Both in LDS.
     constexpr int KS = Cfg::KS, S = Cfg::STRIDE, DIL = Cfg::DIL, MI = Cfg::MI, TH = Cfg::TH, KP = Cfg::KP;
     constexpr int NB = Cfg::NB, IN_H = Cfg::IN_H, IN_WV = Cfg::IN_WV, CH = Cfg::CH, KDG = Cfg::KDG;
-    constexpr int UNR = KS <= 3 ? KS : 1;  // k3: fully unrolled taps; k5/k7: the kh loop stays rolled
+    constexpr int KSH = Cfg::KSH;
+    constexpr int UNR = KS <= 3 ? KSH : 1;  // k3: fully unrolled taps; k5/k7: the kh loop stays rolled
 #pragma unroll
     for (int kd = 0; kd < KDG; ++kd) {
 #pragma unroll UNR
-        for (int kh = 0; kh < KS; ++kh) {
-            const float *wrow = wl + ((kd * KS + kh) * KS) * KP * 64 * MI;
+        for (int kh = 0; kh < KSH; ++kh) {
+            const float *wrow = wl + ((kd * KSH + kh) * KS) * KP * 64 * MI;
             const int tap_base = bbase + (kd * DIL * IN_H + kh * DIL) * IN_WV;
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
@@ -479,7 +484,7 @@ template <class Cfg, int EPI = 0>   // EPI: 0 generic epilogue, 1 fast, 2 fast w
 __global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_mfma_kernel(const ConvArgs a) {
     constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, KC = Cfg::KC, NB = Cfg::NB;
-    constexpr int CH = Cfg::CH, TILE = Cfg::TILE, PAD = Cfg::PAD, LPAD = Cfg::LPAD, XOFF = Cfg::XOFF;
+    constexpr int CH = Cfg::CH, TILE = Cfg::TILE, LPAD = Cfg::LPAD, XOFF = Cfg::XOFF;
     using St = typename Cfg::St;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -490,7 +495,7 @@ conv3d_mfma_kernel(const ConvArgs a) {
     const int cg = blockIdx.y;  // group of 32*MI output channels
     const int64_t n = blockIdx.z;
     const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 32;
-    const int id0 = od0 * S - Cfg::PAD_D, ih0 = oh0 * S - PAD, ix0 = ow0 * S - LPAD;
+    const int id0 = od0 * S - Cfg::PAD_D, ih0 = oh0 * S - Cfg::PAD_H, ix0 = ow0 * S - LPAD;
 
     f32x16 acc[NB][MI];
 #pragma unroll
@@ -2126,8 +2131,8 @@ using CfgP1M1s   = ConvCfg<1, 1, 1, 1, 1, 4, 32, true, 2, 0, 1>;
 using CfgP1S2M1s = ConvCfg<1, 2, 1, 1, 1, 4, 16, true, 2, 0, 1>;
 using CfgP3M1s   = ConvCfg<3, 1, 1, 1, 1, 4, 16, true, 2, 0, 1>;
 using CfgP3S2M1s = ConvCfg<3, 2, 1, 1, 1, 4, 8, true, 2, 0, 1>;
-// 7 x 7, stride 1: the sheared first convolution of the global model (sheared_conv.hip: a 3 x 7 kernel embedded in 7 x 7)
-using CfgP7M1s   = ConvCfg<7, 1, 1, 1, 1, 4, 4, true, 2, 0, 1>;
+// 3 (H) x 7 (W), stride 1: the sheared first convolution of the global model (sheared_conv.hip; desc.ksize_h = 3, ksize = 7)
+using CfgP7M1s   = ConvCfg<7, 1, 1, 1, 1, 4, 8, true, 2, 0, 1, 3>;
 using CfgWino   = WinoCfg<2, 4, 2>;          // k3/s1 fast path: 2 x 4 rows x 64 voxels, 2 input channels per chunk
 using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per wave: large layers
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;
@@ -2165,7 +2170,12 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
         // (k = 1, stride 2 is BasicBlock's downsample path, hrnet.py:56-69)
         if (d.Din != 1 || d.Dout != 1 || d.dilation != 1 || d.pad != (d.ksize - 1) / 2)
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: ksize_d = 1 needs Din = Dout = 1, dilation 1, pad = (ksize-1)/2");
-        const int eH = (d.Hin + 2 * d.pad - d.ksize) / d.stride + 1, eW = (d.Win + 2 * d.pad - d.ksize) / d.stride + 1;
+        const int kh_ = d.ksize_h ? d.ksize_h : d.ksize;      // kernel extent along H (its padding is (ksize_h-1)/2)
+        if (kh_ != d.ksize && !(d.ksize == 7 && kh_ == 3 && d.stride == 1))
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: ksize_h != ksize is built for the 3 x 7 depth-1 layer only");
+        if (d.ksize == 7 && kh_ != 3)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: depth-1 ksize 7 is built as the 3 x 7 layer (ksize_h = 3)");
+        const int eH = (d.Hin + 2 * ((kh_ - 1) / 2) - kh_) / d.stride + 1, eW = (d.Win + 2 * d.pad - d.ksize) / d.stride + 1;
         if (d.Hout != eH || d.Wout != eW)
             return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: output size does not match the convolution arithmetic");
         const int key = d.ksize * 10 + d.stride;
@@ -2177,12 +2187,14 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
             case 31: p = plan_of<CfgP3M1s>(P3_M1S); break;
             case 32: p = plan_of<CfgP3S2M1s>(P3S2_M1S); break;
             case 71: p = plan_of<CfgP7M1s>(P7_M1S); break;
-            default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: depth-1 layers are built for ksize 1 and 3 (stride 1 and 2) and ksize 7 (stride 1)");
+            default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: depth-1 layers are built for ksize 1 and 3 (stride 1 and 2) and 3 x 7 (stride 1)");
         }
         p.tiles_d = 1; p.tiles_h = ceil_div(d.Hout, p.TH); p.tiles_w = ceil_div(d.Wout, 32);
     } else {
         if (d.ksize_d != 0 && d.ksize_d != d.ksize)
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: ksize_d must be 0 (cubic), ksize or 1");
+        if (d.ksize_h != 0 && d.ksize_h != d.ksize)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: ksize_h != ksize needs a depth-1 layer (ksize_d = 1)");
         if (d.pad != d.dilation * (d.ksize - 1) / 2)
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: pad must equal dilation*(ksize-1)/2");
         const int eff = d.dilation * (d.ksize - 1) + 1;
@@ -2340,7 +2352,7 @@ int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
     Plan p;
     if (!d || make_plan(*d, p) != SNVC_OK) return -1;
     const bool planar = d->ksize_d == 1;      // depth-1 layer: only the direct packing, no special forms
-    const int64_t taps = d->transposed ? 27 : (int64_t)(planar ? 1 : d->ksize) * d->ksize * d->ksize;
+    const int64_t taps = d->transposed ? 27 : (int64_t)(planar ? 1 : d->ksize) * (planar && d->ksize_h ? d->ksize_h : d->ksize) * d->ksize;
     int64_t count = (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
     if (planar) return count;
     count += wino_packed_count(*d);   // k3/s1 layers also carry the Winograd-transformed weights
@@ -2393,7 +2405,7 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
                                                                            p.nchunks, total);
     else
         pack_conv_weights_kernel<<<blocks, 256, 0, as_stream(stream)>>>(weight, packed, d->Cout, d->Cin,
-                                                                         (planar ? 1 : d->ksize) * d->ksize * d->ksize, p.MI, p.KC,
+                                                                         (planar ? 1 : d->ksize) * (planar && d->ksize_h ? d->ksize_h : d->ksize) * d->ksize, p.MI, p.KC,
                                                                          p.nchunks, total);
     return check_launch("snvc_conv3d_pack_weights");
 }

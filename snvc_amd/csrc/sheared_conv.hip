@@ -14,8 +14,8 @@
 // kd = -1 taps at d = 0 and the kd = +1 taps at d = D-1, and the zero padding in w removes the kw = +1 taps at w = W-1
 // (the kw = -1 taps at w = 0 read u < 0, which is zero in Rq as well).  The host (models/stereo_volume.py) therefore
 //   1. builds Rq on a padded grid                                      (sheared_upsample_kernel, here)
-//   2. runs ONE depth-1 7x7 convolution for G (all columns) and G' (kernel without its kw = +1 taps, for w = W-1),
-//      stacked as 2*Cout output channels                               (conv3d.hip, desc.ksize_d = 1, ksize = 7)
+//   2. runs the depth-1 3 x 7 convolution twice: G over all columns, and G' (the kernel without its kw = +1 taps, used
+//      at w = W-1) over the window of D + 6 columns that column reads    (conv3d.hip, desc.ksize_d = 1, ksize_h = 3, ksize = 7)
 //   3. expands v1[co][d][h][w] = act(scale * (G or G')[co][h][q*w - d - m0] + planes[co][interior][h][w] + bias) for
 //      the planes 1 .. D-2 -- a pure 0.74 GB write stream              (sheared_expand_kernel, here)
 //   4. computes the planes d = 0 and d = D-1 with the general kernels on a 4-plane slab {0, 1, D-2, D-1}.
@@ -53,9 +53,9 @@ sheared_upsample_kernel(const float *__restrict__ r, float *__restrict__ out, in
 // moving from plane d to d + q shifts it down by one: one 4-byte LDS read per thread and plane.
 template <int Q>
 __global__ void __launch_bounds__(512)
-sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ planes, const float *__restrict__ scale,
-                      const float *__restrict__ bias, float *__restrict__ y, int C, int D, int H, int W, int m0, int WG, int off,
-                      int RB, int flags) {
+sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gcol, const float *__restrict__ planes,
+                      const float *__restrict__ scale, const float *__restrict__ bias, float *__restrict__ y, int C, int D, int H,
+                      int W, int m0, int WG, int off, int WG2, int off2, int RB, int flags) {
     extern __shared__ float lds[];
     const int quads = W >> 2;
     const int tid = threadIdx.x;
@@ -66,15 +66,15 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ pla
     const int LW = (WG + Q - 1) / Q + 4;                 // elements per phase array of a row (+ slack for the window start)
     float *const phase = lds;                            // [RB][Q][LW]
     float *const lastcol = lds + RB * Q * LW;            // [RB][D]: G' at the last column, per plane
-    const float *gn = g + (n * 2 * C + co) * (int64_t)H * WG, *gc = gn + (int64_t)C * H * WG;
+    const float *gn = g + (n * C + co) * (int64_t)H * WG, *gc = gcol + (n * C + co) * (int64_t)H * WG2;
     for (int e = tid; e < rows * WG; e += blockDim.x) {
         const int r = e / WG, i = e - r * WG;
         phase[(r * Q + (i % Q)) * LW + i / Q] = gn[(int64_t)(h0 + r) * WG + i];
     }
     for (int e = tid; e < rows * D; e += blockDim.x) {
         const int r = e / D, d = e - r * D;
-        const int i = Q * (W - 1) - d - m0 + off;
-        lastcol[r * D + d] = (i >= 0 && i < WG) ? gc[(int64_t)(h0 + r) * WG + i] : 0.0f;
+        const int i = Q * (W - 1) - d - m0 + off2;
+        lastcol[r * D + d] = (i >= 0 && i < WG2) ? gc[(int64_t)(h0 + r) * WG2 + i] : 0.0f;
     }
     __syncthreads();
     if (tid >= rows * quads) return;
@@ -129,8 +129,8 @@ extern "C" {
 int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, int64_t H, int64_t W, int q, int64_t WU,
                           int off, void *stream) {
     using namespace snvc;
-    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || (q != 1 && q != 2) || off < 0 || WU < off + q * (W - 1) + 1)
-        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_upsample: bad sizes (q in {1,2}, WU >= off + q*(W-1) + 1)");
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || (q != 1 && q != 2) || WU <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_upsample: bad sizes (q in {1,2})");
     if (N == 0) return SNVC_OK;
     if (!right || !out) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_upsample: null pointer");
     const int64_t rows = N * C * H, total = rows * WU;
@@ -140,16 +140,17 @@ int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, 
     return check_launch("snvc_sheared_upsample");
 }
 
-int snvc_sheared_expand(const float *g, const float *planes, const float *scale, const float *bias, float *y, int64_t N,
-                        int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int flags, void *stream) {
+int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale, const float *bias, float *y,
+                        int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2,
+                        int off2, int flags, void *stream) {
     using namespace snvc;
-    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || W % 4 != 0 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || off < 0)
+    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || W % 4 != 0 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || WG2 <= 0)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: bad sizes (W % 4 == 0, q in {1,2}, D >= 2)");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: scale and bias must both be given or both be NULL");
     if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand: only SNVC_EPI_RELU");
     if (N == 0 || D == 2) return SNVC_OK;
-    if (!g || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: null pointer");
+    if (!g || !gcol || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: null pointer");
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(planes)) & 15)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: y and planes must be 16-byte aligned");
     const int quads = (int)(W / 4);
@@ -165,12 +166,12 @@ int snvc_sheared_expand(const float *g, const float *planes, const float *scale,
     static std::atomic<unsigned> attr1{0}, attr2{0};
     if (q == 1) {
         if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<1>), (int)lds, attr1)) return check_launch("snvc_sheared_expand");
-        sheared_expand_kernel<1><<<grid, threads, lds, as_stream(stream)>>>(g, planes, scale, bias, y, (int)C, (int)D, (int)H, (int)W, m0,
-                                                                          (int)WG, off, RB, flags);
+        sheared_expand_kernel<1><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, (int)C, (int)D, (int)H, (int)W,
+                                                                          m0, (int)WG, off, (int)WG2, off2, RB, flags);
     } else {
         if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<2>), (int)lds, attr2)) return check_launch("snvc_sheared_expand");
-        sheared_expand_kernel<2><<<grid, threads, lds, as_stream(stream)>>>(g, planes, scale, bias, y, (int)C, (int)D, (int)H, (int)W, m0,
-                                                                          (int)WG, off, RB, flags);
+        sheared_expand_kernel<2><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, (int)C, (int)D, (int)H, (int)W,
+                                                                          m0, (int)WG, off, (int)WG2, off2, RB, flags);
     }
     return check_launch("snvc_sheared_expand");
 }

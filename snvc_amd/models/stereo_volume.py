@@ -116,21 +116,21 @@ class GlobalStack(nn.Module):
             return bool(nonneg), None
         return bool(nonneg), (q, int(m0))
 
-    def _sheared_layer(self, plans, wr, q):
-        """The depth-1 7x7 layer that computes G and G' (csrc/sheared_conv.hip): K[kh][t] = sum over (kd, kw) with
-        q*kw - kd = t of the right-half weights, folded in fp64; output channels C.. carry the kernel without its kw = +1 taps."""
+    def _sheared_layers(self, plans, wr, q):
+        """The depth-1 3 x 7 layers that compute G and G' (csrc/sheared_conv.hip): K[kh][t] = sum over (kd, kw) with
+        q*kw - kd = t of the right-half weights, folded in fp64; G' is the kernel without its kw = +1 taps."""
         cache = plans.setdefault("sheared", {})
         if q not in cache:
             w = wr.detach().double()                                       # [Cout, C, kd, kh, kw]
             cout, c = w.shape[0], w.shape[1]
-            k = torch.zeros((2, cout, c, 7, 7), dtype=torch.float64, device=w.device)
+            k = torch.zeros((2, cout, c, 3, 7), dtype=torch.float64, device=w.device)
             for kd in (-1, 0, 1):
                 for kw in (-1, 0, 1):
                     t = q * kw - kd
-                    k[0, :, :, 2:5, t + 3] += w[:, :, kd + 1, :, kw + 1]
+                    k[0, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
                     if kw != 1:
-                        k[1, :, :, 2:5, t + 3] += w[:, :, kd + 1, :, kw + 1]
-            cache[q] = ops.Conv3dLayer(k.reshape(2 * cout, c, 7, 7).float().contiguous(), 7, 1, 3, 1, False, planar=True)
+                        k[1, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
+            cache[q] = tuple(ops.Conv3dLayer(k[i].float().contiguous(), 7, 1, 3, 1, False, planar=True, ksize_h=3) for i in range(2))
         return cache[q]
 
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True):
@@ -186,7 +186,7 @@ class GlobalStack(nn.Module):
             v = self.conv1.fused(vol, out=self._buffer("v1", shape, device))
             mark("conv1", 1)
             del vol
-            return self._conv2_tail(v, shape)
+            return self._conv2_tail(v, shape, timing)
         structure = None
         if sheared and left.size(0) > 0 and shift.size(1) >= 4 and shift.dtype == torch.float32:
             nonneg, structure = self._shift_structure(shift)
@@ -210,16 +210,21 @@ class GlobalStack(nn.Module):
             d, wd = shift.size(1), left.size(3)
             off = 4
             wu = (off + q * (wd - 1) + 1 + 3 + 3) // 4 * 4
+            # the last column reads G' at u = q*(W-1) - d - m0, d = 1 .. D-2: a window of Rq with 3 columns of context each side
+            u_lo = q * (wd - 1) - (d - 2) - m0 - 3
+            off_col = 4 - u_lo
+            wu_col = (d + 6 + 4 + 3) // 4 * 4
+            lay_g, lay_col = self._sheared_layers(plans, w.detach()[:, c:], q)
             mark("volume", 0)
-            rq = ops.sheared_upsample(right, q, wu, off)                                          # [N,C,H,WU]
-            g = self._sheared_layer(plans, w.detach()[:, c:], q)(rq.unsqueeze(2)).squeeze(2)      # [N,2C,H,WU]: G | G'
+            g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)             # [N,C,H,WU]
+            gcol = lay_col(ops.sheared_upsample(right, q, wu_col, off_col).unsqueeze(2)).squeeze(2)   # [N,C,H,WU2]
             slab = torch.tensor([0, 1, d - 2, d - 1], device=shift.device)
             vol4 = ops.cost_volume_forward_right(right, shift.index_select(1, slab))              # planes 0, 1, D-2, D-1
             edge = plans["right"](vol4, scale, bias, None, ops.EPI_RELU, None, depth_planes=planes)
             mark("volume", 1)
             mark("conv1", 0)
             v = self._buffer("v1", shape, left.device)
-            ops.sheared_expand(g, planes, scale, bias, v, q, m0, off, ops.EPI_RELU)               # planes 1 .. D-2
+            ops.sheared_expand(g, gcol, planes, scale, bias, v, q, m0, off, off_col, ops.EPI_RELU)    # planes 1 .. D-2
             v[:, :, 0].copy_(edge[:, :, 0])
             v[:, :, d - 1].copy_(edge[:, :, 3])
             mark("conv1", 1)

@@ -260,9 +260,11 @@ class Conv3dLayer:
     """
 
     def __init__(self, weight: torch.Tensor, ksize: int, stride: int, pad: int, dilation: int, transposed: bool,
-                 planar: bool = False):
+                 planar: bool = False, ksize_h: int = 0):
         """planar=True: a depth-1 layer (desc.ksize_d = 1) -- an nn.Conv2d(k, stride, padding=(k-1)/2) of the 2D BEV
-        neck run on [N,C,1,H,W] views; ``weight`` is then [Cout,Cin,1,k,k] (or the Conv2d's own [Cout,Cin,k,k])."""
+        neck run on [N,C,1,H,W] views; ``weight`` is then [Cout,Cin,1,k,k] (or the Conv2d's own [Cout,Cin,k,k]).
+        ksize_h (planar only): kernel extent along H when it differs from ``ksize`` (desc.ksize_h; the 3 x 7 layer of the
+        sheared first convolution: weight [Cout,Cin,3,7], padding (1,3))."""
         _gpu(weight, "weight")
         if weight.dtype != torch.float32:
             raise RuntimeError("conv3d weights must be float32")
@@ -274,8 +276,9 @@ class Conv3dLayer:
             self.cin, self.cout = weight.shape[0], weight.shape[1]
         else:
             self.cout, self.cin = weight.shape[0], weight.shape[1]
-        if tuple(weight.shape[2:]) != ((1, ksize, ksize) if planar else (ksize,) * 3):
-            raise RuntimeError("only cubic kernels (or depth-1 k x k ones with planar=True) are on the path")
+        self.ksize_h = int(ksize_h) if planar else 0
+        if tuple(weight.shape[2:]) != ((1, self.ksize_h or ksize, ksize) if planar else (ksize,) * 3):
+            raise RuntimeError("only cubic kernels (or depth-1 k x k / ksize_h x k ones with planar=True) are on the path")
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
         self.device = weight.device
         probe = self._desc(1, (1, 16, 32) if planar else (16, 16, 32), 0)
@@ -292,7 +295,9 @@ class Conv3dLayer:
             return tuple(2 * s for s in in_spatial)
         eff = self.dilation * (self.ksize - 1) + 1
         if getattr(self, "planar", False):      # the stride and the padding apply to H and W only
-            return (in_spatial[0],) + tuple((s + 2 * self.pad - eff) // self.stride + 1 for s in in_spatial[1:])
+            kh = getattr(self, "ksize_h", 0) or self.ksize
+            return (in_spatial[0], (in_spatial[1] + 2 * ((kh - 1) // 2) - kh) // self.stride + 1,
+                    (in_spatial[2] + 2 * self.pad - eff) // self.stride + 1)
         return tuple((s + 2 * self.pad - eff) // self.stride + 1 for s in in_spatial)
 
     def _desc(self, n, in_spatial, flags, x_bs=0, y_bs=0, r_bs=0) -> Conv3dDesc:
@@ -305,6 +310,7 @@ class Conv3dLayer:
         d.transposed = 1 if self.transposed else 0
         d.flags = flags
         d.ksize_d = 1 if getattr(self, "planar", False) else 0
+        d.ksize_h = getattr(self, "ksize_h", 0)
         d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = x_bs, y_bs, r_bs
         return d
 
@@ -374,19 +380,23 @@ def sheared_upsample(right, q: int, wu: int, off: int):
     return out
 
 
-def sheared_expand(g, planes, scale, bias, out, q: int, m0: int, off: int, flags: int = 0):
-    """out[n,co,d,h,w] = epilogue(scale*(G | G')[n,co,h,q*w-d-m0+off] + planes[n,co,1,h,w] + bias) for d = 1 .. D-2
-    (snvc_sheared_expand); g [N,2C,H,WG], planes [N,C,3,H,W] or None, out [N,C,D,H,W] (contiguous, written in place)."""
-    _gpu(g, "g"); _gpu(out, "out")
+def sheared_expand(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int, off_col: int, flags: int = 0):
+    """out[n,co,d,h,w] = epilogue(scale*G[n,co,h,q*w-d-m0+off] + planes[n,co,1,h,w] + bias) for d = 1 .. D-2, with G' (``gcol``,
+    indexed with ``off_col``) in place of G at w = W-1 (snvc_sheared_expand); g [N,C,H,WG], gcol [N,C,H,WG2], planes
+    [N,C,3,H,W] or None, out [N,C,D,H,W] (contiguous, written in place)."""
+    _gpu(g, "g"); _gpu(gcol, "gcol"); _gpu(out, "out")
     n, c, d, h, w = out.shape
-    if (g.dtype != torch.float32 or out.dtype != torch.float32 or tuple(g.shape[:3]) != (n, 2 * c, h) or not g.is_contiguous()
-            or not out.is_contiguous()):
-        raise RuntimeError("sheared_expand needs contiguous float32 g [N,2C,H,WG] and out [N,C,D,H,W]")
+    for t in (g, gcol):
+        if t.dtype != torch.float32 or tuple(t.shape[:3]) != (n, c, h) or not t.is_contiguous():
+            raise RuntimeError("sheared_expand needs contiguous float32 g / gcol [N,C,H,*]")
+    if out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("sheared_expand needs a contiguous float32 out [N,C,D,H,W]")
     if planes is not None and (tuple(planes.shape) != (n, c, 3, h, w) or not planes.is_contiguous()):
         raise RuntimeError("planes must be a contiguous [N,C,3,H,W] tensor")
     with torch.cuda.device(out.device):
-        check(_lib.lib().snvc_sheared_expand(_ptr(g), _ptr(planes), _ptr(scale), _ptr(bias), _ptr(out), n, c, d, h, w, int(q), int(m0),
-                                             g.size(3), int(off), int(flags), _stream(out)), "snvc_sheared_expand")
+        check(_lib.lib().snvc_sheared_expand(_ptr(g), _ptr(gcol), _ptr(planes), _ptr(scale), _ptr(bias), _ptr(out), n, c, d, h, w,
+                                             int(q), int(m0), g.size(3), int(off), gcol.size(3), int(off_col), int(flags),
+                                             _stream(out)), "snvc_sheared_expand")
     return out
 
 

@@ -102,9 +102,9 @@ def test_global_pair_full_size_factored_equals_materialised(pair):
         edge_s = [v1s[0, :, 0].clone(), v1s[0, :, D - 1].clone(), v1s[0, :, :, :, W - 1].clone(), v1s[0, :, :, :, 0].clone()]
         a = m.forward_pair(dl, dr, ds, 1, factored=True, sheared=False)
         v1g = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
-        assert torch.allclose(probe_s, v1g[0, ::7, ::5, ::9, ::11], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(probe_s, v1g[0, ::7, ::5, ::9, ::11], rtol=1e-4, atol=1e-4)
         for e, g in zip(edge_s, (v1g[0, :, 0], v1g[0, :, D - 1], v1g[0, :, :, :, W - 1], v1g[0, :, :, :, 0])):   # and its four borders whole
-            assert torch.allclose(e, g, rtol=1e-4, atol=1e-5), (e - g).abs().max()
+            assert torch.allclose(e, g, rtol=1e-4, atol=1e-4), (e - g).abs().max()   # 864-term fp32 sums in two orders, values up to ~5
         b = m.forward_pair(dl, dr, ds, 1, factored=False)
     assert a.shape == (1, 1, D, H, W) and torch.isfinite(a).all()
     err = (a - b).abs().max().item() / b.abs().max().item()

@@ -10,19 +10,28 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "pmc_r2")
-DST = os.path.join(ROOT, "profiles", "r2")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r2"          # python tools/make_traffic_json.py r3
+SRC = os.path.join(ROOT, "gpurun_out", f"pmc_{ROUND}")
+DST = os.path.join(ROOT, "profiles", ROUND)
 KERNEL = {  # layer -> substring of the kernel whose LAST dispatch is reported
     "conv1_factored": "conv3d_wino_dma_kernel", "cost_volume": "cost_volume_fwd_rows", "cost_volume_right": "cost_volume_fwd_rows",
     "cost_volume_bwd": "cost_volume_bwd_rows_f32", "gather_proj": "voxel_gather_fwd_lds", "gather_uniform": "voxel_gather_fwd_lds",
     "gather_f16": "voxel_gather_fwd_lds", "f16_k7": "conv3d_f16_kernel", "f16_k5": "conv3d_f16_kernel",
+    # r3
+    "conv2_side": "conv3d_wino_dma_kernel", "hg_s2": "conv3d_winos2_pipe_kernel", "sheared": "sheared_expand_kernel",
+    "gather_cfg3": "voxel_gather_fwd_lds", "f16_k7_32": "conv3d_f16_kernel",
 }
 ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     "conv1_factored": 1472200704, "cost_volume": 1479869184, "cost_volume_right": 739934976, "cost_volume_bwd": 1479869184 + 2 * 3833856,
     "gather_proj": 2 * (786432 * 272 + 2 * 32 * 4096 * 4), "gather_uniform": 2 * (786432 * 272 + 2 * 32 * 4096 * 4),
     "gather_f16": 2048000 * (16 + 4 * 64) + 2 * 64 * 4096 * 4,
     "f16_k7": 2 * 2048000 * (128 + 64), "f16_k5": 2 * 2048000 * (64 + 64),
+    # r3: conv2 reads and writes one 32-channel volume (+ the 1-channel projection); hg conv1 reads 32 channels at full and
+    # writes 64 at half resolution; the expand pass writes one 32-channel volume; 8 crops of 96^3
+    "conv2_side": 2 * 735902208 + 22996944, "hg_s2": 735902208 + 183975552, "sheared": 735902208,
+    "gather_cfg3": 8 * (884736 * 272 + 2 * 32 * 4096 * 4), "f16_k7_32": 2 * 786432 * 2 * (64 + 32),
 }
+F32_MFMA_LAYERS = ("conv1_factored", "conv2_side", "hg_s2")
 
 
 def last_dispatch(path, needle):
@@ -54,7 +63,7 @@ for layer, needle in KERNEL.items():
         entry["algorithmic_bytes"] = ALGORITHMIC[layer]
         entry["traffic_over_algorithmic"] = entry["hbm_bytes_corrected"] / ALGORITHMIC[layer]
     if "SQ_INSTS_MFMA" in entry and "GRBM_GUI_ACTIVE" in entry:
-        cyc = 64 if layer == "conv1_factored" else 32          # v_mfma_f32_32x32x2_f32: 64 cycles/SIMD; 32x32x16_f16: 32
+        cyc = 64 if layer in F32_MFMA_LAYERS else 32          # v_mfma_f32_32x32x2_f32: 64 cycles/SIMD; 32x32x16_f16: 32
         entry["mfma_pipe_frac"] = entry["SQ_INSTS_MFMA"] * cyc / (1024 * entry["GRBM_GUI_ACTIVE"] / 8)
     if len(entry) > 1:
         out["layers"][layer] = entry

@@ -78,6 +78,21 @@ with torch.no_grad():
         m = S.convbn_3d(cin, 64, k, 1, (k - 1) // 2).to(dev).eval()
         xh = torch.randn((1, cin // 8, 80, 160, 160, 8), device=dev).half()
         fn = lambda: m.fused_f16(xh, relu=True)  # noqa: E731
+    elif args.layer == "conv2_side":        # r3 dominant kernel: conv2 + the classifier's projection of its own result
+        from snvc_amd.models import submodule as S
+        v1 = torch.randn(1, bench.C, bench.D, bench.H, bench.W, device=dev)
+        out = torch.empty_like(v1)
+        fn = lambda: model.conv2.fused(v1, out=out, side_head=model.classifier)  # noqa: E731
+    elif args.layer == "hg_s2":             # hourglass conv1: k3 / stride 2, 32 -> 64 (slice-pipelined refill)
+        v2 = torch.randn(1, bench.C, bench.D, bench.H, bench.W, device=dev)
+        fn = lambda: model.hg_conv3d.conv1(v2)  # noqa: E731
+    elif args.layer == "sheared":           # the sheared first convolution: Rq, G | G', edge slab, expand, copies
+        fn = lambda: model.forward_pair(left, right, shift, 1)  # noqa: E731
+    elif args.layer == "f16_k7_32":         # released shape, fp16 storage, MI = 1 form (64 -> 32)
+        from snvc_amd.models import submodule as S
+        m = S.convbn_3d(64, 32, 7, 1, 3).to(dev).eval()
+        xh = torch.randn((2, 8, 32, 128, 192, 8), device=dev).half()
+        fn = lambda: m.fused_f16(xh, relu=True)  # noqa: E731
     elif args.layer == "cost_volume_right":
         from snvc_amd import ops
         fn = lambda: ops.cost_volume_forward_right(right, shift)  # noqa: E731
