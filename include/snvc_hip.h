@@ -301,11 +301,12 @@ SNVC_API int snvc_conv3d_forward_side_head(const snvc_conv3d_desc *desc_host, co
  *   snvc_sheared_upsample : out[n][c][h][i] = Rq[i - off] on a row of WU floats (zero outside 0 <= u <= q*(W-1); off may
  *                           be negative: a window of Rq)
  *   snvc_conv3d_forward   : G = the depth-1 3 x 7 convolution of that image (desc.ksize_d = 1, ksize_h = 3, ksize = 7); G' =
- *                           the same with the kernel stripped of its kw = +1 taps, over the window the last column reads
- *   snvc_sheared_expand   : y[n][co][d][h][w] = epilogue(scale*G[n][co][h][q*w - d - m0 + off] + planes[n][co][1][h][w]),
- *                           G'[..][q*(W-1) - d - m0 + off2] in place of G at w = W-1, for the planes d = 1 .. D-2 (planes: the
- *                           depth-class planes of snvc_conv3d_forward_ex, or NULL); the planes d = 0 and d = D-1 are the
- *                           caller's (general kernels on a 4-plane slab). */
+ *                           the same with the kernel stripped of its kw = +1 taps, over the window the last column reads;
+ *                           both for the three depth classes (first plane d = 0: kernel without its kd = -1 taps; interior;
+ *                           last plane d = D-1: without kd = +1), stacked class-major as 3*C output channels
+ *   snvc_sheared_expand   : y[n][co][d][h][w] = epilogue(scale*G[n][cls(d)][co][h][q*w - d - m0 + off] + planes[n][co][cls(d)][h][w]),
+ *                           G'[..][q*(W-1) - d - m0 + off2] in place of G at w = W-1; g [N][3][C][H][WG], gcol [N][3][C][H][WG2],
+ *                           planes = the depth-class planes of snvc_conv3d_forward_ex (or NULL). */
 SNVC_API int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, int64_t H, int64_t W, int q,
                                    int64_t WU, int off, void *stream);
 SNVC_API int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale,

@@ -728,13 +728,17 @@ struct WinoJob {
 __device__ __forceinline__ WinoJob wino_decode_job(const ConvArgs &a, int v, int total, int TD, int TH, int TW) {
     const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
     const int j = xcd_remap(v, total);
-    const int t = j % ntiles, g = j / ntiles;
+    // channel group fastest: the groups of one tile run back to back on one XCD, so the tile's input is read from HBM
+    // once and from that XCD's L2 by the other groups (r3: hg conv1, 2 groups, read 2.1x its algorithmic bytes when the
+    // groups were whole passes over the volume apart -- profiles/r3/traffic.json)
+    const int cg = j % a.groups, rest = j / a.groups;
+    const int t = rest % ntiles;
     WinoJob o;
     o.ow0 = (t % a.tiles_w) * TW;
     o.oh0 = ((t / a.tiles_w) % a.tiles_h) * TH;
     o.od0 = (t / (a.tiles_w * a.tiles_h)) * TD;
-    o.cg = g % a.groups;
-    o.n = g / a.groups;
+    o.cg = cg;
+    o.n = rest / ntiles;
     return o;
 }
 

@@ -16,9 +16,10 @@
 //   1. builds Rq on a padded grid                                      (sheared_upsample_kernel, here)
 //   2. runs the depth-1 3 x 7 convolution twice: G over all columns, and G' (the kernel without its kw = +1 taps, used
 //      at w = W-1) over the window of D + 6 columns that column reads    (conv3d.hip, desc.ksize_d = 1, ksize_h = 3, ksize = 7)
-//   3. expands v1[co][d][h][w] = act(scale * (G or G')[co][h][q*w - d - m0] + planes[co][interior][h][w] + bias) for
-//      the planes 1 .. D-2 -- a pure 0.74 GB write stream              (sheared_expand_kernel, here)
-//   4. computes the planes d = 0 and d = D-1 with the general kernels on a 4-plane slab {0, 1, D-2, D-1}.
+//      -- each for the three depth classes (first plane: kernel without kd = -1; interior; last plane: without kd = +1),
+//      stacked as 3*Cout output channels
+//   3. expands v1[co][d][h][w] = act(scale * (G or G')[class(d)][co][h][q*w - d - m0] + planes[co][class(d)][h][w] + bias)
+//      -- a pure 0.74 GB write stream                                   (sheared_expand_kernel, here)
 // `planes` are the depth-class planes of the LEFT half of the concat volume (snvc_conv3d_forward_ex); the result equals
 // the factored path's (tests/test_gpu_parity.py::test_sheared_first_conv_*), fp32 summation order aside.
 #include "common.hpp"
@@ -66,7 +67,8 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
     const int LW = (WG + Q - 1) / Q + 4;                 // elements per phase array of a row (+ slack for the window start)
     float *const phase = lds;                            // [RB][Q][LW]
     float *const lastcol = lds + RB * Q * LW;            // [RB][D]: G' at the last column, per plane
-    const float *gn = g + (n * C + co) * (int64_t)H * WG, *gc = gcol + (n * C + co) * (int64_t)H * WG2;
+    // g / gcol are [N][3][C][H][*]: depth class 0 = first plane (no kd = -1 taps), 1 = interior, 2 = last plane (no kd = +1)
+    const float *gn = g + ((n * 3 + 1) * C + co) * (int64_t)H * WG, *gc = gcol + ((n * 3 + 1) * C + co) * (int64_t)H * WG2;
     for (int e = tid; e < rows * WG; e += blockDim.x) {
         const int r = e / WG, i = e - r * WG;
         phase[(r * Q + (i % Q)) * LW + i / Q] = gn[(int64_t)(h0 + r) * WG + i];
@@ -98,6 +100,30 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
         const int d = 1 + p;                  // first plane of the chain that starts at d = 1 + p
 #pragma unroll
         for (int k = 0; k < 4; ++k) win[p][k] = load(Q * (w0 + k) - d - m0 + off);
+    }
+    // the two end planes: their own G / G' (depth classes 0 and 2) and planes of the left half, read straight from L2
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int d = e ? D - 1 : 0, cls = e ? 2 : 0;
+        const float *ge = g + ((n * 3 + cls) * C + co) * (int64_t)H * WG + (int64_t)(h0 + r) * WG;
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = Q * (w0 + k) - d - m0 + off;
+            o[k] = (i >= 0 && i < WG) ? ge[i] : 0.0f;
+        }
+        if (last) {
+            const int i = Q * (W - 1) - d - m0 + off2;
+            o[3] = (i >= 0 && i < WG2) ? gcol[((n * 3 + cls) * C + co) * (int64_t)H * WG2 + (int64_t)(h0 + r) * WG2 + i] : 0.0f;
+        }
+        f32x4 pe = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (planes) pe = *reinterpret_cast<const f32x4 *>(planes + (((n * C + co) * 3 + cls) * (int64_t)H + h0 + r) * W + w0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float v = (o[k] + pe[k]) * sc + bi;
+            o[k] = relu ? (v > 0.0f ? v : 0.0f) : v;
+        }
+        *reinterpret_cast<f32x4 *>(yp + (int64_t)d * plane_sz) = o;
     }
     for (int d0 = 1; d0 < D - 1; d0 += Q) {
 #pragma unroll
@@ -149,7 +175,7 @@ int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, 
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: scale and bias must both be given or both be NULL");
     if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand: only SNVC_EPI_RELU");
-    if (N == 0 || D == 2) return SNVC_OK;
+    if (N == 0) return SNVC_OK;
     if (!g || !gcol || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: null pointer");
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(planes)) & 15)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: y and planes must be 16-byte aligned");

@@ -123,15 +123,29 @@ class GlobalStack(nn.Module):
         if q not in cache:
             w = wr.detach().double()                                       # [Cout, C, kd, kh, kw]
             cout, c = w.shape[0], w.shape[1]
-            k = torch.zeros((2, cout, c, 3, 7), dtype=torch.float64, device=w.device)
-            for kd in (-1, 0, 1):
-                for kw in (-1, 0, 1):
-                    t = q * kw - kd
-                    k[0, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
-                    if kw != 1:
-                        k[1, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
-            cache[q] = tuple(ops.Conv3dLayer(k[i].float().contiguous(), 7, 1, 3, 1, False, planar=True, ksize_h=3) for i in range(2))
+            k = torch.zeros((2, 3, cout, c, 3, 7), dtype=torch.float64, device=w.device)     # [all | last column][depth class]
+            for cls, kds in enumerate(((0, 1), (-1, 0, 1), (-1, 0))):        # first plane: no kd = -1; interior; last: no kd = +1
+                for kd in kds:
+                    for kw in (-1, 0, 1):
+                        t = q * kw - kd
+                        k[0, cls, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
+                        if kw != 1:
+                            k[1, cls, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
+            cache[q] = tuple(ops.Conv3dLayer(k[i].reshape(3 * cout, c, 3, 7).float().contiguous(), 7, 1, 3, 1, False, planar=True,
+                                             ksize_h=3) for i in range(2))
         return cache[q]
+
+    @staticmethod
+    def _left_planes_layer(plans, wl):
+        """The three depth-class planes of the LEFT half of conv1(volume) as ONE depth-1 3x3 convolution of the left feature
+        with 3*Cout output channels (channel co*3 + cls = the kd taps that class sees, summed in fp64): [N,3C,1,H,W] is
+        the [N,C,3,H,W] tensor snvc_conv3d_forward_ex takes.  (r1-r2 ran the 3D kernel on the feature stacked 3 deep: a
+        one-tile-deep launch whose time is one workgroup's whole channel loop, 50 us.)"""
+        if "left2d" not in plans:
+            w = wl.detach().double()                                       # [Cout, C, kd, kh, kw]
+            k = torch.stack([w[:, :, 1:].sum(2), w.sum(2), w[:, :, :2].sum(2)], dim=1)      # [Cout, 3, C, kh, kw]
+            plans["left2d"] = ops.Conv3dLayer(k.reshape(-1, w.shape[1], 3, 3).float().contiguous(), 3, 1, 1, 1, False, planar=True)
+        return plans["left2d"]
 
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
@@ -198,35 +212,30 @@ class GlobalStack(nn.Module):
         plans = conv.__dict__.setdefault("_snvc_factored", {})
         key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
         if plans.get("key") != key:
-            wl, wr = w.detach()[:, :c].contiguous(), w.detach()[:, c:].contiguous()
-            plans.update(key=key, left=ops.Conv3dLayer(wl, 3, 1, 1, 1, False), right=ops.Conv3dLayer(wr, 3, 1, 1, 1, False),
-                         plan=_Plan())
+            wr = w.detach()[:, c:].contiguous()
+            plans.clear()
+            plans.update(key=key, right=ops.Conv3dLayer(wr, 3, 1, 1, 1, False), plan=_Plan())
         scale, bias = _folded_bn(bn, plans["plan"])
-        left3 = left.unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()       # [N,C,3,H,W]
-        planes = plans["left"](left3)                                           # depth classes: first / interior / last
+        planes = self._left_planes_layer(plans, w.detach()[:, :c])(left.unsqueeze(2))       # [N,3C,1,H,W] ...
+        planes = planes.view(left.size(0), c, 3, left.size(2), left.size(3))                 # ... = [N,C,3,H,W]: first / interior / last
         shape = (left.size(0), c, shift.size(1)) + tuple(left.shape[2:])
         if structure is not None:
             q, m0 = structure
             d, wd = shift.size(1), left.size(3)
             off = 4
             wu = (off + q * (wd - 1) + 1 + 3 + 3) // 4 * 4
-            # the last column reads G' at u = q*(W-1) - d - m0, d = 1 .. D-2: a window of Rq with 3 columns of context each side
-            u_lo = q * (wd - 1) - (d - 2) - m0 - 3
+            # the last column reads G' at u = q*(W-1) - d - m0, d = 0 .. D-1: a window of Rq with 3 columns of context each side
+            u_lo = q * (wd - 1) - (d - 1) - m0 - 3
             off_col = 4 - u_lo
             wu_col = (d + 6 + 4 + 3) // 4 * 4
             lay_g, lay_col = self._sheared_layers(plans, w.detach()[:, c:], q)
             mark("volume", 0)
-            g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)             # [N,C,H,WU]
-            gcol = lay_col(ops.sheared_upsample(right, q, wu_col, off_col).unsqueeze(2)).squeeze(2)   # [N,C,H,WU2]
-            slab = torch.tensor([0, 1, d - 2, d - 1], device=shift.device)
-            vol4 = ops.cost_volume_forward_right(right, shift.index_select(1, slab))              # planes 0, 1, D-2, D-1
-            edge = plans["right"](vol4, scale, bias, None, ops.EPI_RELU, None, depth_planes=planes)
+            g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)             # [N,3C,H,WU]
+            gcol = lay_col(ops.sheared_upsample(right, q, wu_col, off_col).unsqueeze(2)).squeeze(2)   # [N,3C,H,WU2]
             mark("volume", 1)
             mark("conv1", 0)
             v = self._buffer("v1", shape, left.device)
-            ops.sheared_expand(g, gcol, planes, scale, bias, v, q, m0, off, off_col, ops.EPI_RELU)    # planes 1 .. D-2
-            v[:, :, 0].copy_(edge[:, :, 0])
-            v[:, :, d - 1].copy_(edge[:, :, 3])
+            ops.sheared_expand(g, gcol, planes, scale, bias, v, q, m0, off, off_col, ops.EPI_RELU)
             mark("conv1", 1)
             _ROUTES["sheared_first_conv"] += 1
             return self._conv2_tail(v, shape, timing)

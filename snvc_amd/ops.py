@@ -381,14 +381,14 @@ def sheared_upsample(right, q: int, wu: int, off: int):
 
 
 def sheared_expand(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int, off_col: int, flags: int = 0):
-    """out[n,co,d,h,w] = epilogue(scale*G[n,co,h,q*w-d-m0+off] + planes[n,co,1,h,w] + bias) for d = 1 .. D-2, with G' (``gcol``,
-    indexed with ``off_col``) in place of G at w = W-1 (snvc_sheared_expand); g [N,C,H,WG], gcol [N,C,H,WG2], planes
-    [N,C,3,H,W] or None, out [N,C,D,H,W] (contiguous, written in place)."""
+    """out[n,co,d,h,w] = epilogue(scale*G[n,cls(d),co,h,q*w-d-m0+off] + planes[n,co,cls(d),h,w] + bias), with G' (``gcol``,
+    indexed with ``off_col``) in place of G at w = W-1 (snvc_sheared_expand); g [N,3C,H,WG], gcol [N,3C,H,WG2] (depth classes
+    first / interior / last stacked class-major), planes [N,C,3,H,W] or None, out [N,C,D,H,W] (contiguous, written in place)."""
     _gpu(g, "g"); _gpu(gcol, "gcol"); _gpu(out, "out")
     n, c, d, h, w = out.shape
     for t in (g, gcol):
-        if t.dtype != torch.float32 or tuple(t.shape[:3]) != (n, c, h) or not t.is_contiguous():
-            raise RuntimeError("sheared_expand needs contiguous float32 g / gcol [N,C,H,*]")
+        if t.dtype != torch.float32 or tuple(t.shape[:3]) != (n, 3 * c, h) or not t.is_contiguous():
+            raise RuntimeError("sheared_expand needs contiguous float32 g / gcol [N,3C,H,*] (depth classes stacked class-major)")
     if out.dtype != torch.float32 or not out.is_contiguous():
         raise RuntimeError("sheared_expand needs a contiguous float32 out [N,C,D,H,W]")
     if planes is not None and (tuple(planes.shape) != (n, c, 3, h, w) or not planes.is_contiguous()):
