@@ -649,7 +649,7 @@ def main():
                                              "(the headline path's first layer: one 0.74 GB write stream)",
                                    "achieved": V1_BYTES / (expand_ms * 1e-3) / 1e9, "frac": V1_BYTES / (expand_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                    "bytes_per_launch": V1_BYTES, "avg_launch_ms": expand_ms,
-                                   "prep_ms": shear_prep_ms, "prep": "Rq + depth-1 7x7 convolution (G, G') + 4-plane edge slab"},
+                                   "prep_ms": shear_prep_ms, "prep": "Rq on two grids + the depth-1 3x7 convolutions G (all columns) and G' (last column), 3 depth classes each"},
                 "full_volume": {"kernel": "cost_volume_fwd_rows: build_cost_volume, both halves (materialized leg)",
                                 "achieved": CV_BYTES / (cv_ms * 1e-3) / 1e9, "frac": CV_BYTES / (cv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "bytes_per_launch": CV_BYTES, "avg_launch_ms": cv_ms},
