@@ -326,8 +326,12 @@ cost_volume_bwd_rows_f32(const float *__restrict__ grad, const float *__restrict
     // the pair (w, w + 1), w = ix + floor(s); the 8-byte load is kept inside the row (W >= 2): a shifted pair still
     // holds every in-row candidate, and a column that is not a candidate can never match
     auto load_pair = [&](int d, float s, Pair2 &q, int &wq) {
-        int st = ix + (int)s;
+        // floor(s), made safe for any float (negative, huge, NaN: fmaxf / fminf return the non-NaN operand): for s < 0 the two
+        // candidates are still ix + floor(s) and the column after it, and whatever falls outside the row cannot match
+        const int fs = (int)fminf(fmaxf(floorf(s), -(float)W - 2.0f), (float)W + 2.0f);
+        int st = ix + fs;
         st = st > W - 2 ? W - 2 : st;
+        st = st < 0 ? 0 : st;
         wq = st;
         q = *reinterpret_cast<const Pair2 *>(gr + (int64_t)d * hw + st);
     };

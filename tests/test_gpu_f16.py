@@ -215,6 +215,41 @@ def test_f16_model_switch_vs_golden(name):
         assert e <= tol, (key, e)
 
 
+def _spot_check_f16_layer(layer, x_c8, y_c8, pts, k, stride, dil, transposed):
+    """Output voxels `pts` of relu(bn(conv(x))) (what ``fused_f16`` of a ConvBNReLU3d / the plain affine of a ConvBN3d gives)
+    against torch-CPU float64 on the half-rounded weights and the input crop each voxel reads (zero-padded at the borders)."""
+    from snvc_amd import ops
+    conv, bn = (layer[0][0], layer[0][1]) if isinstance(layer[0], torch.nn.Sequential) else (layer[0], layer[1])
+    relu = isinstance(layer[0], torch.nn.Sequential)
+    wq = h(conv.weight.detach().cpu()).double()
+    sc = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().cpu().double()
+    bi = (bn.bias - bn.running_mean * bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().cpu().double()
+    in_sp = tuple(x_c8.shape[2:5])
+    for pt in pts:
+        if transposed:          # contributors i of output o: 2i - 1 + k = o  ->  i in [o//2 - 1, o//2 + 1]
+            lo, ext = [p // 2 - 1 for p in pt], 3
+        else:
+            pad_ = dil * (k - 1) // 2
+            lo, ext = [p * stride - pad_ for p in pt], dil * (k - 1) + 1
+        sl = [slice(max(l, 0), min(l + ext, s_)) for l, s_ in zip(lo, in_sp)]
+        crop = ops.from_c8(x_c8[:, :, sl[0], sl[1], sl[2]].contiguous()).cpu().double()
+        pad = []
+        for l, s_ in reversed(list(zip(lo, in_sp))):
+            pad += [max(-l, 0), max(l + ext - s_, 0)]
+        crop = F.pad(crop, pad)
+        if transposed:
+            full = F.conv_transpose3d(crop, wq, None, 2, 1, 1)                         # 6^3 outputs for inputs lo .. lo+2
+            raw = full[0, :, pt[0] - 2 * lo[0], pt[1] - 2 * lo[1], pt[2] - 2 * lo[2]]
+        else:
+            raw = F.conv3d(crop, wq, None, 1, 0, dil)[0, :, 0, 0, 0]
+        ref = raw * sc + bi
+        if relu:
+            ref = torch.relu(ref)
+        got = ops.from_c8(y_c8[:, :, pt[0]:pt[0] + 1, pt[1]:pt[1] + 1, pt[2]:pt[2] + 1].contiguous())[0, :, 0, 0, 0].cpu().double()
+        tol = 1e-3 * ref.abs() + 2e-4 * max(ref.pow(2).mean().sqrt().item(), 1e-3)
+        assert ((got - ref).abs() <= tol).all(), (k, stride, dil, transposed, pt, (got - ref).abs().max().item())
+
+
 def test_f16_cfg5_full_size():
     """cfg5 at full size: grid (80,160,160), F = 64.  conv1 (7^3, 128 -> 64) against torch-CPU on input crops at
     spot voxels (tile edges, corners), the trunk against the fp32 path, everything finite."""
@@ -246,7 +281,16 @@ def test_f16_cfg5_full_size():
             ref = torch.relu(F.conv3d(F.pad(crop, pad), wq)[0, :, 0, 0, 0] * sc + bi)
             got = ops.from_c8(v1[:, :, pt[0]:pt[0] + 1, pt[1]:pt[1] + 1, pt[2]:pt[2] + 1].contiguous())[0, :, 0, 0, 0].cpu().double()
             assert ((got - ref).abs() <= 1e-3 * ref.abs() + 2e-4 * max(ref.pow(2).mean().sqrt().item(), 1e-3)).all(), pt
-        del v1
+        # r3: the other layer kinds at the same full size -- k5 (conv2), dilated k5 (conv3, sub-grid classes), stride 2 and
+        # transposed (the 16x hourglass's first and last layers) -- spot voxels against torch-CPU on input crops
+        pts = [(0, 0, 0), (d - 1, hh - 1, w - 1), (3, 3, 31), (4, 4, 32), (40, 80, 95), (79, 0, 159), (17, 159, 128), (41, 77, 64)]
+        _spot_check_f16_layer(m.conv2, v1, m.conv2.fused_f16(v1), pts, 5, 1, 1, False)
+        _spot_check_f16_layer(m.conv3, v1, m.conv3.fused_f16(v1), pts, 5, 1, 2, False)
+        s2 = m.hg_conv3d.conv1.fused_f16(v1)                                            # 64 -> 128 at half resolution
+        _spot_check_f16_layer(m.hg_conv3d.conv1, v1, s2, [(p[0] // 2, p[1] // 2, p[2] // 2) for p in pts], 3, 2, 1, False)
+        up = m.hg_conv3d.conv12.fused_f16(s2)                                           # 128 -> 64 back at full resolution
+        _spot_check_f16_layer(m.hg_conv3d.conv12, s2, up, pts + [(1, 1, 1), (78, 158, 158), (5, 4, 33)], 3, 2, 1, True)
+        del v1, s2, up
         bev16, occ16, _ = m.trunk_3d_f16(vox)
         del vox
         assert torch.isfinite(bev16).all() and torch.isfinite(occ16).all()

@@ -131,6 +131,25 @@ def test_cost_volume_backward_bit_exact(N, C, H, W, D, ds, dtype):
     assert np.array_equal(gR.cpu().numpy(), eR), np.abs(gR.cpu().numpy() - eR).max()
 
 
+def test_cost_volume_backward_any_shift_matches_the_oracle():
+    """The C-ABI backward entry points take any shift array (the `shift >= 0` assert lives in the Python wrapper of the
+    forward only, reference __init__.py:12): negative, fractional-negative, huge and NaN shifts through the fp32 / ds = 1
+    two-candidate kernel give the oracle's bits (that kernel used to assume shift >= 0)."""
+    from oracle import native as O
+    from snvc_amd import ops
+    r = np.random.default_rng(77)
+    N, C, H, W, D = 2, 3, 4, 16, 10
+    g = r.standard_normal((N, 2 * C, D, H, W)).astype(np.float32)
+    s = r.uniform(-6, 6, (N, D)).astype(np.float32)
+    s[0, :6] = [-0.5, -1.0, -2.75, -30.0, 1e9, -1e9]
+    s[1, 0] = np.nan
+    eL, eR = O.cost_volume_backward(g, s, 1)
+    gL, gR = ops.cost_volume_backward(torch.from_numpy(g).to(dev()), torch.from_numpy(s).to(dev()), 1)
+    assert np.array_equal(gL.cpu().numpy(), eL) and np.array_equal(gR.cpu().numpy(), eR, equal_nan=True)
+    gR2 = ops.cost_volume_backward_right(torch.from_numpy(g[:, C:].copy()).to(dev()), torch.from_numpy(s).to(dev()))
+    assert np.array_equal(gR2.cpu().numpy(), eR, equal_nan=True)
+
+
 def test_cost_volume_known_answers():
     """The hand-derived KATs of tests/test_oracle_cost_volume.py, straight on the HIP kernel."""
     from snvc_amd.extension.build_cost_volume import build_cost_volume
