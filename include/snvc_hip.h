@@ -312,6 +312,25 @@ SNVC_API int snvc_sheared_upsample(const float *right, float *out, int64_t N, in
 SNVC_API int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale,
                                  const float *bias, float *y, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q,
                                  int m0, int64_t WG, int off, int64_t WG2, int off2, int flags, void *stream);
+/* Backward of the sheared first convolution (training, BASELINE.json configs[3]); dy = the gradient of the layer's RAW
+ * result (the caller applies the norm / activation backward first, snvc_act_backward_*).
+ *   snvc_sheared_reduce            : adjoint of snvc_sheared_expand: dg [N][3][C][H][WG] / dgcol [N][3][C][H][WG2] = the
+ *                                    sums of dy along each shear line, per depth class; every element written; deterministic
+ *   snvc_sheared_wgrad             : dK[co][c][kh][t] = sum_{n,h,i} dy[n][co][h][i] * x[n][c][h+kh-1][i+t-3] of the depth-1
+ *                                    3 x 7 layer (x [N][C][H][WU], dy [N][CO][H][WU], C <= 32; dk [CO][C][3][7]) on the matrix
+ *                                    pipe, partial sums in `workspace` (snvc_sheared_wgrad_workspace_bytes) reduced in a
+ *                                    fixed order.  The 3D gradient is dW[kd][kh][kw] = sum over classes holding kd of
+ *                                    dK_cls[kh][q*kw - kd + 3] (+ the last-column window's, kw <= 0)
+ *   snvc_sheared_upsample_backward : adjoint of snvc_sheared_upsample: dright[j] = dRq[q*j] (+ (dRq[2j-1] + dRq[2j+1]) / 2 for
+ *                                    q = 2), drq [N][C][H][WU] with element i = dRq[i - off]
+ * The input gradient dRq itself is snvc_conv3d_forward of dg with the flipped / transposed 3 x 7 kernel. */
+SNVC_API int snvc_sheared_reduce(const float *dy, float *dg, float *dgcol, int64_t N, int64_t C, int64_t D, int64_t H,
+                                 int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2, int off2, void *stream);
+SNVC_API int64_t snvc_sheared_wgrad_workspace_bytes(int64_t N, int64_t CO, int64_t H, int64_t WU);
+SNVC_API int snvc_sheared_wgrad(const float *x, const float *dy, float *dk, void *workspace, int64_t N, int64_t C,
+                                int64_t CO, int64_t H, int64_t WU, void *stream);
+SNVC_API int snvc_sheared_upsample_backward(const float *drq, float *dright, int64_t N, int64_t C, int64_t H, int64_t W,
+                                            int q, int64_t WU, int off, void *stream);
 SNVC_API int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *desc_host);
 SNVC_API int snvc_conv3d_wgrad(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
                                void *workspace, void *stream);

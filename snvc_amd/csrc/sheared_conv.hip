@@ -147,6 +147,153 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
     }
 }
 
+// ------------------------------------------------------------------------------------ backward (training, cfg4)
+// Adjoint of sheared_expand_kernel w.r.t. G and G' (scale = 1: the caller applies the norm's backward first):
+//     dG[n][cls][co][h][i]  = sum over (d in class cls, w <= W-2) with Q*w - d - m0 + off  == i of dy[n][co][d][h][w]
+//     dG'[n][cls][co][h][i] = sum over (d in class cls)           with Q*(W-1) - d - m0 + off2 == i of dy[n][co][d][h][W-1]
+// One workgroup per (n, co, h) row.  Thread t owns the Q slots i = Q*t + p; at a fixed plane d exactly one phase p is
+// hit, at column w = t + c(d): consecutive threads read consecutive columns (coalesced), every dy element is read once and
+// every sum runs in ascending d: deterministic, no atomics.
+template <int Q>
+__global__ void __launch_bounds__(256)
+sheared_reduce_kernel(const float *__restrict__ dy, float *__restrict__ dg, float *__restrict__ dgcol, int C, int D, int H, int W,
+                      int m0, int WG, int off, int WG2, int off2) {
+    const int h = blockIdx.x, co = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int64_t plane_sz = (int64_t)H * W;
+    const float *row = dy + ((n * C + co) * (int64_t)D) * plane_sz + (int64_t)h * W;
+    auto gout = [&](int cls) { return dg + (((n * 3 + cls) * C + co) * (int64_t)H + h) * WG; };
+    auto cout_ = [&](int cls) { return dgcol + (((n * 3 + cls) * C + co) * (int64_t)H + h) * WG2; };
+    const int nslots = (WG + Q - 1) / Q;
+    for (int t = threadIdx.x; t < nslots; t += blockDim.x) {
+        float acc[Q], first[Q], lastp[Q];
+#pragma unroll
+        for (int p = 0; p < Q; ++p) acc[p] = first[p] = lastp[p] = 0.0f;
+        // plane d hits phase p(d) = (off - m0 - d) mod Q of this thread, at column w = t + (p + d + m0 - off) / Q
+        for (int d = 0; d < D; ++d) {
+            const int e = off - m0 - d;
+            const int p = ((e % Q) + Q) % Q;
+            const int w = t + (p - e) / Q;                      // (p - e) is a multiple of Q
+            const float v = ((unsigned)w < (unsigned)(W - 1)) ? row[(int64_t)d * plane_sz + w] : 0.0f;
+#pragma unroll
+            for (int pp = 0; pp < Q; ++pp) {
+                if (pp != p) continue;
+                if (d == 0) first[pp] = v;
+                else if (d == D - 1) lastp[pp] = v;
+                else acc[pp] = acc[pp] + v;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < Q; ++p) {
+            const int i = Q * t + p;
+            if (i < WG) { gout(0)[i] = first[p]; gout(1)[i] = acc[p]; gout(2)[i] = lastp[p]; }
+        }
+    }
+    // last column: slot i2 = Q*(W-1) - d - m0 + off2 receives dy[d][h][W-1]
+    for (int i = threadIdx.x; i < WG2; i += blockDim.x) {
+        const int d = Q * (W - 1) - m0 + off2 - i;
+        const float v = ((unsigned)d < (unsigned)D) ? row[(int64_t)d * plane_sz + (W - 1)] : 0.0f;
+        cout_(0)[i] = d == 0 ? v : 0.0f;
+        cout_(1)[i] = (d > 0 && d < D - 1) ? v : 0.0f;
+        cout_(2)[i] = (d == D - 1 && d != 0) ? v : 0.0f;
+    }
+}
+
+// Weight gradient of the depth-1 3 x 7 convolution  y[co][h][i] = sum_{c,kh,t} K[co][c][kh][t] * x[c][h+kh-1][i+t-3]:
+//     dK[co][c][kh][t] = sum_{n,h,i} dy[n][co][h][i] * x[n][c][h+kh-1][i+t-3]
+// on the matrix pipe: per tap a 32 x 32 (co x c) tile contracted over the positions (h, i), two positions per
+// v_mfma_f32_32x32x2_f32.  A workgroup owns one row h and a range of columns, its four waves split the 21 taps (6,5,5,5
+// accumulators), tiles of 64 columns go through LDS (dy [32][65], x [32][3][71]: odd strides, conflict-free column reads).
+// Partial sums per workgroup go to a workspace; sheared_wgrad_reduce_kernel adds them in a fixed order (deterministic).
+constexpr int SW_IC = 64, SW_XS = SW_IC + 7, SW_YS = SW_IC + 1;
+__global__ void __launch_bounds__(256)
+sheared_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ ws, int C, int CO, int H, int WU,
+                     int col_chunks, int chunk_cols) {
+    __shared__ float ylds[32 * SW_YS];
+    __shared__ float xlds[32 * 3 * SW_XS];
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x / col_chunks, cc = blockIdx.x - h * col_chunks;
+    const int g = blockIdx.y;                      // 32-channel group of dy
+    const int64_t n = blockIdx.z;
+    const int ntap = wave == 0 ? 6 : 5;            // taps wave, wave + 4, ... of the 21
+    f32x16 acc[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    const float *xn = x + n * (int64_t)C * H * WU;
+    const float *yn = dy + (n * CO + g * 32) * (int64_t)H * WU + (int64_t)h * WU;
+    const int i_begin = cc * chunk_cols, i_end = (i_begin + chunk_cols) < WU ? (i_begin + chunk_cols) : WU;
+    for (int i0 = i_begin; i0 < i_end; i0 += SW_IC) {
+        __syncthreads();
+        for (int e = tid; e < 32 * SW_IC; e += 256) {
+            const int co = e / SW_IC, ii = e - co * SW_IC, i = i0 + ii;
+            ylds[co * SW_YS + ii] = (i < i_end && co < CO - g * 32) ? yn[(int64_t)co * H * WU + i] : 0.0f;
+        }
+        for (int e = tid; e < 32 * 3 * (SW_IC + 6); e += 256) {
+            const int c = e / (3 * (SW_IC + 6)), r = e - c * 3 * (SW_IC + 6), kh = r / (SW_IC + 6), ii = r - kh * (SW_IC + 6);
+            const int hh = h + kh - 1, i = i0 + ii - 3;
+            const bool ok = c < C && (unsigned)hh < (unsigned)H && (unsigned)i < (unsigned)WU;
+            xlds[(c * 3 + kh) * SW_XS + ii] = ok ? xn[((int64_t)c * H + hh) * WU + i] : 0.0f;
+        }
+        __syncthreads();
+        const int col = lane & 31, k = lane >> 5;
+#pragma unroll 4
+        for (int ii = 0; ii < SW_IC; ii += 2) {
+            const float af = ylds[col * SW_YS + ii + k];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                if (a < ntap) {
+                    const int tap = wave + 4 * a, kh = tap / 7, t = tap - kh * 7;
+                    const float bf = xlds[(col * 3 + kh) * SW_XS + ii + k + t];
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[a], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partials: ws[((n * groups + g) * nwg + wg)][tap][co_local][c]
+    const int nwg = gridDim.x;
+    float *wp = ws + ((((n * gridDim.y + g) * nwg + blockIdx.x) * 21) * (int64_t)1024);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        if (a < ntap) {
+            const int tap = wave + 4 * a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                wp[(tap * 32 + co) * 32 + (lane & 31)] = acc[a][r];
+            }
+        }
+    }
+}
+
+// dK[g*32 + co][c][kh][t] = sum over (n, workgroup) of the partials, in that order
+__global__ void __launch_bounds__(256)
+sheared_wgrad_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dk, int C, int CO, int N, int groups, int nwg) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;          // (g, tap, co, c)
+    if (idx >= groups * 21 * 1024) return;
+    const int c = idx & 31, co = (idx >> 5) & 31, tap = (idx >> 10) % 21, g = idx / (21 * 1024);
+    float s = 0.0f;
+    for (int n = 0; n < N; ++n)
+        for (int w = 0; w < nwg; ++w) s = s + ws[((((int64_t)n * groups + g) * nwg + w) * 21 + tap) * 1024 + co * 32 + c];
+    if (g * 32 + co < CO && c < C) dk[((int64_t)(g * 32 + co) * C + c) * 21 + tap] = s;
+}
+
+// Adjoint of sheared_upsample_kernel: dR[j] = sum_u dRq[u] * dRq[u]/dR[j]   (u = Q*j exactly; u = 2j +- 1 with weight 1/2)
+__global__ void __launch_bounds__(256)
+sheared_upsample_bwd_kernel(const float *__restrict__ drq, float *__restrict__ dr, int W, int q, int WU, int off, int64_t rows) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * W) return;
+    const int64_t row = idx / W;
+    const int j = (int)(idx - row * W);
+    const float *g = drq + row * WU;
+    auto at = [&](int u) { const int i = u + off; return (u >= 0 && u <= q * (W - 1) && i >= 0 && i < WU) ? g[i] : 0.0f; };
+    float v = at(q * j);
+    if (q == 2) v = v + (0.5f * at(2 * j - 1) + 0.5f * at(2 * j + 1));
+    dr[idx] = v;
+}
+
 }  // namespace
 }  // namespace snvc
 
@@ -200,6 +347,67 @@ int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, 
                                                                           m0, (int)WG, off, (int)WG2, off2, RB, flags);
     }
     return check_launch("snvc_sheared_expand");
+}
+
+int snvc_sheared_reduce(const float *dy, float *dg, float *dgcol, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q,
+                        int m0, int64_t WG, int off, int64_t WG2, int off2, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W < 2 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || WG2 <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_reduce: bad sizes (q in {1,2}, D >= 2, W >= 2)");
+    if (N == 0) return SNVC_OK;
+    if (!dy || !dg || !dgcol) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_reduce: null pointer");
+    if (C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_reduce: too many channels or samples");
+    const dim3 grid((unsigned)H, (unsigned)C, (unsigned)N);
+    if (q == 1)
+        sheared_reduce_kernel<1><<<grid, 256, 0, as_stream(stream)>>>(dy, dg, dgcol, (int)C, (int)D, (int)H, (int)W, m0, (int)WG, off,
+                                                                     (int)WG2, off2);
+    else
+        sheared_reduce_kernel<2><<<grid, 256, 0, as_stream(stream)>>>(dy, dg, dgcol, (int)C, (int)D, (int)H, (int)W, m0, (int)WG, off,
+                                                                     (int)WG2, off2);
+    return check_launch("snvc_sheared_reduce");
+}
+
+static void sheared_wgrad_geometry(int64_t WU, int &col_chunks, int &chunk_cols) {
+    using snvc::ceil_div;
+    col_chunks = WU > 320 ? 2 : 1;                                     // two workgroups per row on the wide grid
+    chunk_cols = (int)((ceil_div<int64_t>(WU, col_chunks) + snvc::SW_IC - 1) / snvc::SW_IC * snvc::SW_IC);
+}
+
+int64_t snvc_sheared_wgrad_workspace_bytes(int64_t N, int64_t CO, int64_t H, int64_t WU) {
+    if (N < 0 || CO <= 0 || H <= 0 || WU <= 0) return -1;
+    int cc, cols;
+    sheared_wgrad_geometry(WU, cc, cols);
+    return N * ((CO + 31) / 32) * H * cc * 21 * 1024 * (int64_t)sizeof(float);
+}
+
+int snvc_sheared_wgrad(const float *x, const float *dy, float *dk, void *workspace, int64_t N, int64_t C, int64_t CO, int64_t H,
+                       int64_t WU, void *stream) {
+    using namespace snvc;
+    if (N <= 0 || C <= 0 || C > 32 || CO <= 0 || H <= 0 || WU <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_wgrad: bad sizes (1 <= C <= 32)");
+    if (!x || !dy || !dk || !workspace) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_wgrad: null pointer");
+    int cc, cols;
+    sheared_wgrad_geometry(WU, cc, cols);
+    const int groups = (int)((CO + 31) / 32), nwg = (int)(H * cc);
+    if (N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_wgrad: too many samples");
+    sheared_wgrad_kernel<<<dim3((unsigned)nwg, (unsigned)groups, (unsigned)N), 256, 0, as_stream(stream)>>>(
+        x, dy, static_cast<float *>(workspace), (int)C, (int)CO, (int)H, (int)WU, cc, cols);
+    sheared_wgrad_reduce_kernel<<<(unsigned)ceil_div(groups * 21 * 1024, 256), 256, 0, as_stream(stream)>>>(
+        static_cast<const float *>(workspace), dk, (int)C, (int)CO, (int)N, groups, nwg);
+    return check_launch("snvc_sheared_wgrad");
+}
+
+int snvc_sheared_upsample_backward(const float *drq, float *dright, int64_t N, int64_t C, int64_t H, int64_t W, int q, int64_t WU,
+                                   int off, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || (q != 1 && q != 2) || WU <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_upsample_backward: bad sizes (q in {1,2})");
+    if (N == 0) return SNVC_OK;
+    if (!drq || !dright) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_upsample_backward: null pointer");
+    const int64_t rows = N * C * H, total = rows * W;
+    sheared_upsample_bwd_kernel<<<(unsigned)ceil_div<int64_t>(total, 256), 256, 0, as_stream(stream)>>>(drq, dright, (int)W, q, (int)WU,
+                                                                                                         off, rows);
+    return check_launch("snvc_sheared_upsample_backward");
 }
 
 }  // extern "C"

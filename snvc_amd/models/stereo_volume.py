@@ -18,8 +18,8 @@ import torch.nn as nn
 
 from ..extension.build_cost_volume import _BuildCostVolume, build_cost_volume  # noqa: F401  (re-exported)
 from .. import ops
-from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _folded_bn, _Plan, convbn_3d,
-                        hourglass, EPI_RELU)
+from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _ShearedFirstConvFn, _folded_bn, _Plan,
+                        convbn_3d, hourglass, sheared_geometry, sheared_kernels, EPI_RELU)
 
 
 class GlobalStack(nn.Module):
@@ -121,16 +121,8 @@ class GlobalStack(nn.Module):
         q*kw - kd = t of the right-half weights, folded in fp64; G' is the kernel without its kw = +1 taps."""
         cache = plans.setdefault("sheared", {})
         if q not in cache:
-            w = wr.detach().double()                                       # [Cout, C, kd, kh, kw]
-            cout, c = w.shape[0], w.shape[1]
-            k = torch.zeros((2, 3, cout, c, 3, 7), dtype=torch.float64, device=w.device)     # [all | last column][depth class]
-            for cls, kds in enumerate(((0, 1), (-1, 0, 1), (-1, 0))):        # first plane: no kd = -1; interior; last: no kd = +1
-                for kd in kds:
-                    for kw in (-1, 0, 1):
-                        t = q * kw - kd
-                        k[0, cls, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
-                        if kw != 1:
-                            k[1, cls, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
+            k = sheared_kernels(wr, q)                                     # [all | last column][depth class][Cout,C,3,7]
+            cout, c = k.shape[2], k.shape[3]
             cache[q] = tuple(ops.Conv3dLayer(k[i].reshape(3 * cout, c, 3, 7).float().contiguous(), 7, 1, 3, 1, False, planar=True,
                                              ksize_h=3) for i in range(2))
         return cache[q]
@@ -177,8 +169,17 @@ class GlobalStack(nn.Module):
         if (training_graph and factored and timing is None and downsample == 1 and left.dtype == torch.float32
                 and left.size(3) % 4 == 0 and (left.size(2) * left.size(3)) % 4 == 0 and shift.size(1) >= 2):
             # training (cfg4): the same factoring with a backward pass (half the first layer's dgrad / wgrad, no 1.5 GB volume)
-            assert torch.all(shift >= 0.)
+            structure = None
+            if sheared and left.size(0) > 0 and shift.size(1) >= 4 and shift.dtype == torch.float32 and left.size(1) <= 32:
+                nonneg, structure = self._shift_structure(shift)
+                assert nonneg
+            else:
+                assert torch.all(shift >= 0.)
             plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(left.device, _Plan())
+            if structure is not None:      # uniformly spaced planes: the sheared 2D form, forward and backward
+                v = _ShearedFirstConvFn.apply(left, right, conv.weight, bn.weight, bn.bias, conv, bn, EPI_RELU, plan, structure[0],
+                                              structure[1], shift.size(1))
+                return self._tail(self.conv2(v))
             v = _FactoredFirstConvFn.apply(left, right, shift, conv.weight, bn.weight, bn.bias, conv, bn, EPI_RELU, plan)
             return self._tail(self.conv2(v))
         usable = (factored and downsample == 1 and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
@@ -221,13 +222,7 @@ class GlobalStack(nn.Module):
         shape = (left.size(0), c, shift.size(1)) + tuple(left.shape[2:])
         if structure is not None:
             q, m0 = structure
-            d, wd = shift.size(1), left.size(3)
-            off = 4
-            wu = (off + q * (wd - 1) + 1 + 3 + 3) // 4 * 4
-            # the last column reads G' at u = q*(W-1) - d - m0, d = 0 .. D-1: a window of Rq with 3 columns of context each side
-            u_lo = q * (wd - 1) - (d - 1) - m0 - 3
-            off_col = 4 - u_lo
-            wu_col = (d + 6 + 4 + 3) // 4 * 4
+            off, wu, off_col, wu_col = sheared_geometry(q, m0, shift.size(1), left.size(3))
             lay_g, lay_col = self._sheared_layers(plans, w.detach()[:, c:], q)
             mark("volume", 0)
             g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)             # [N,3C,H,WU]

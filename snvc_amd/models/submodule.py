@@ -331,6 +331,23 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
     return draw, gres, dg, db
 
 
+def _flip3d(w):
+    """Weights of the dgrad of a stride-1 convolution: channel roles swapped, every axis flipped."""
+    return w.transpose(0, 1).flip(2, 3, 4).contiguous()
+
+
+def _first_conv_train_cache(conv, weight, c):
+    """Packed layers of the factored first convolution's training functions, rebuilt when the weight changes: ``fl`` / ``bl``
+    = the left half's forward / dgrad layers (the general and the sheared function add their right-half layers lazily)."""
+    fac = conv.__dict__.setdefault("_snvc_factored_train", {})
+    key = (weight.data_ptr(), weight._version, weight.device, _GENERATION[0])
+    if fac.get("key") != key:
+        wl = weight.detach()[:, :c].contiguous()
+        fac.clear()
+        fac.update(key=key, fl=ops.Conv3dLayer(wl, 3, 1, 1, 1, False), bl=ops.Conv3dLayer(_flip3d(wl), 3, 1, 1, 1, False))
+    return fac
+
+
 class _FactoredFirstConvFn(torch.autograd.Function):
     """Differentiable first layer of the global stack over a CONCAT cost volume that is never built:
         y = act(norm(conv3d(build_cost_volume(left, right, shift, 1), W)))          (k3, stride 1, 2C -> Cout)
@@ -344,15 +361,10 @@ class _FactoredFirstConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, left, right, shift, weight, gamma, beta, conv, norm, flags, plan):
         c = left.size(1)
-        fac = conv.__dict__.setdefault("_snvc_factored_train", {})
-        key = (weight.data_ptr(), weight._version, weight.device, _GENERATION[0])
-        if fac.get("key") != key:
-            wd = weight.detach()
-            wl, wr = wd[:, :c].contiguous(), wd[:, c:].contiguous()
-            flip = lambda w: w.transpose(0, 1).flip(2, 3, 4).contiguous()   # noqa: E731  (dgrad of a stride-1 conv)
-            fac.clear()
-            fac.update(key=key, fl=ops.Conv3dLayer(wl, 3, 1, 1, 1, False), fr=ops.Conv3dLayer(wr, 3, 1, 1, 1, False),
-                       bl=ops.Conv3dLayer(flip(wl), 3, 1, 1, 1, False), br=ops.Conv3dLayer(flip(wr), 3, 1, 1, 1, False))
+        fac = _first_conv_train_cache(conv, weight, c)
+        if "fr" not in fac:
+            wr = weight.detach()[:, c:].contiguous()
+            fac.update(fr=ops.Conv3dLayer(wr, 3, 1, 1, 1, False), br=ops.Conv3dLayer(_flip3d(wr), 3, 1, 1, 1, False))
         left3 = left.detach().unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()
         planes = fac["fl"](left3)
         vol_r = ops.cost_volume_forward_right(right.detach(), shift)
@@ -385,6 +397,114 @@ class _FactoredFirstConvFn(torch.autograd.Function):
         if needs[1]:
             g_right = ops.cost_volume_backward_right(fac["br"](draw), shift)
         return g_left, g_right, None, gw, dg, db, None, None, None, None
+
+
+SHEAR_CLASS_KDS = ((0, 1), (-1, 0, 1), (-1, 0))     # kd taps the first plane / the interior planes / the last plane see
+
+
+def sheared_kernels(wr: torch.Tensor, q: int) -> torch.Tensor:
+    """The 3 x 7 kernels of the sheared first convolution (csrc/sheared_conv.hip), folded in fp64 from the right-half weights
+    wr [Cout,C,3,3,3]: K[v][cls][co][c][kh][t + 3] = sum over (kd in class cls, kw) with q*kw - kd = t of wr[co,c,kd,kh,kw];
+    v = 0: all kw (columns w <= W-2), v = 1: without the kw = +1 taps (the last column)."""
+    w = wr.detach().double()
+    k = torch.zeros((2, 3, w.shape[0], w.shape[1], 3, 7), dtype=torch.float64, device=w.device)
+    for cls, kds in enumerate(SHEAR_CLASS_KDS):
+        for kd in kds:
+            for kw in (-1, 0, 1):
+                t = q * kw - kd
+                k[0, cls, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
+                if kw != 1:
+                    k[1, cls, :, :, :, t + 3] += w[:, :, kd + 1, :, kw + 1]
+    return k
+
+
+def sheared_geometry(q: int, m0: int, d: int, w: int):
+    """(off, wu, off_col, wu_col): where Rq sits on the padded grid G is computed on, and the window of Rq (3 columns of
+    context each side) the last output column's G' reads at u = q*(W-1) - d - m0, d = 0 .. D-1."""
+    off = 4
+    wu = (off + q * (w - 1) + 1 + 3 + 3) // 4 * 4
+    u_lo = q * (w - 1) - (d - 1) - m0 - 3
+    return off, wu, 4 - u_lo, (d + 6 + 4 + 3) // 4 * 4
+
+
+class _ShearedFirstConvFn(torch.autograd.Function):
+    """``_FactoredFirstConvFn`` for uniformly spaced disparity planes, shift[n][d] = (m0 + d) / q with q in {1, 2}: the warped
+    half of the volume is a shear of ONE image Rq and the 3D convolution over it a 2D 3 x 7 convolution G evaluated along the
+    shear (csrc/sheared_conv.hip).  Neither the warped volume nor any 3D product over it exists in either direction:
+      forward : raw = expand(G, G') + depth-class planes of the left half
+      backward: dG / dG' = the sums of draw along the shear lines (snvc_sheared_reduce); the weight gradient is the 3 x 7 one
+                of the 2D layer (snvc_sheared_wgrad) scattered back onto the 27 taps; the input gradient is the 2D layer's
+                dgrad (flipped kernel) followed by the adjoint of the half-pixel interpolation.  Left half as in
+                ``_FactoredFirstConvFn``.
+    Same gradients as the general path up to summation order (tests/test_gpu_parity.py)."""
+
+    @staticmethod
+    def forward(ctx, left, right, weight, gamma, beta, conv, norm, flags, plan, q, m0, depth):
+        c = left.size(1)
+        fac = _first_conv_train_cache(conv, weight, c)
+        if ("shear", q) not in fac:
+            k = sheared_kernels(weight.detach()[:, c:], q)                       # [2,3,Cout,C,3,7]
+            cout = k.shape[2]
+            planar = lambda t: ops.Conv3dLayer(t.float().contiguous(), 7, 1, 3, 1, False, planar=True, ksize_h=3)   # noqa: E731
+            fwd = tuple(planar(k[v].reshape(3 * cout, c, 3, 7)) for v in range(2))
+            # dgrad of a stride-1 layer: the same layer with the kernel flipped and the channel roles swapped
+            bwd = tuple(planar(k[v].reshape(3 * cout, c, 3, 7).transpose(0, 1).flip(2, 3)) for v in range(2))
+            # dW[kd][kw] gathers dK[v][cls][t = q*kw - kd]
+            scatter = torch.zeros((2, 3, 7, 3, 3), dtype=torch.float32)
+            for cls, kds in enumerate(SHEAR_CLASS_KDS):
+                for kd in kds:
+                    for kw in (-1, 0, 1):
+                        scatter[0, cls, q * kw - kd + 3, kd + 1, kw + 1] = 1.0
+                        if kw != 1:
+                            scatter[1, cls, q * kw - kd + 3, kd + 1, kw + 1] = 1.0
+            fac[("shear", q)] = (fwd, bwd, scatter.to(weight.device))
+        fwd = fac[("shear", q)][0]
+        n, h, w = left.size(0), left.size(2), left.size(3)
+        off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
+        left3 = left.detach().unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()
+        planes = fac["fl"](left3)
+        rd = right.detach()
+        g = fwd[0](ops.sheared_upsample(rd, q, wu, off).unsqueeze(2)).squeeze(2)
+        gcol = fwd[1](ops.sheared_upsample(rd, q, wu_col, off_col).unsqueeze(2)).squeeze(2)
+        raw = torch.empty((n, weight.size(0), depth, h, w), dtype=torch.float32, device=left.device)
+        ops.sheared_expand(g, gcol, planes, None, None, raw, q, m0, off, off_col, 0)
+        del g, gcol
+        y, scale, shf, mean, var, per_sample = _norm_from_raw(raw, norm, plan, None, flags)
+        ctx.conv, ctx.norm, ctx.flags, ctx.per_sample, ctx.train_stats = conv, norm, flags, per_sample, mean is not None
+        ctx.q, ctx.m0 = q, m0
+        ctx.save_for_backward(left3, rd, raw, scale, shf, mean, var)
+        _ROUTES["sheared_first_conv_train"] += 1
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        left3, right, raw, scale, shf, mean, var = ctx.saved_tensors
+        conv, norm, flags, q, m0 = ctx.conv, ctx.norm, ctx.flags, ctx.q, ctx.m0
+        needs = ctx.needs_input_grad
+        draw, _, dg, db = _epilogue_backward(raw, gy, None, scale, shf, mean, var, norm, flags, ctx.per_sample, ctx.train_stats,
+                                             False, needs[3], needs[4])
+        fac = conv.__dict__["_snvc_factored_train"]
+        _, bwd, scatter = fac[("shear", q)]
+        depth, w = draw.size(2), draw.size(4)
+        off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
+        dplanes = ops.depth_class_sums(draw)                                      # [N,Cout,3,H,W]
+        g_left = g_right = gw = None
+        if needs[1] or needs[2]:
+            d_g, d_gcol = ops.sheared_reduce(draw, q, m0, wu, off, wu_col, off_col)
+        if needs[2]:
+            cout = draw.size(1)
+            dk = torch.stack([ops.sheared_wgrad(ops.sheared_upsample(right, q, wu, off), d_g),
+                              ops.sheared_wgrad(ops.sheared_upsample(right, q, wu_col, off_col), d_gcol)])   # [2,3*Cout,C,3,7]
+            gw_r = torch.einsum("vsockt,vstdw->ocdkw", dk.view(2, 3, cout, -1, 3, 7), scatter)
+            gw_l = ops.conv3d_wgrad(left3, dplanes, 3, 1, 1, 1)
+            gw = torch.cat([gw_l, gw_r], dim=1)
+        if needs[0]:
+            g_left = fac["bl"](dplanes).sum(dim=2)                                # the three depth copies are one tensor
+        if needs[1]:
+            g_right = ops.sheared_upsample_backward(bwd[0](d_g.unsqueeze(2)).squeeze(2), q, w, off)
+            g_right = g_right + ops.sheared_upsample_backward(bwd[1](d_gcol.unsqueeze(2)).squeeze(2), q, w, off_col)
+        return g_left, g_right, gw, dg, db, None, None, None, None, None, None, None
 
 
 def _is_frozen_norm(norm) -> bool:

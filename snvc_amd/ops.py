@@ -400,6 +400,52 @@ def sheared_expand(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int,
     return out
 
 
+def sheared_reduce(dy, q: int, m0: int, wg: int, off: int, wg_col: int, off_col: int):
+    """Adjoint of ``sheared_expand`` (snvc_sheared_reduce): dy [N,C,D,H,W] -> (dg [N,3C,H,wg], dgcol [N,3C,H,wg_col]), the sums
+    of dy along each shear line per depth class (class-major); every element is written, the sums are deterministic."""
+    _gpu(dy, "dy")
+    if dy.dtype != torch.float32 or dy.dim() != 5 or not dy.is_contiguous():
+        raise RuntimeError("sheared_reduce needs a contiguous float32 [N,C,D,H,W] gradient")
+    n, c, d, h, w = dy.shape
+    dg = torch.empty((n, 3 * c, h, wg), dtype=torch.float32, device=dy.device)
+    dgcol = torch.empty((n, 3 * c, h, wg_col), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        check(_lib.lib().snvc_sheared_reduce(_ptr(dy), _ptr(dg), _ptr(dgcol), n, c, d, h, w, int(q), int(m0), int(wg), int(off),
+                                             int(wg_col), int(off_col), _stream(dy)), "snvc_sheared_reduce")
+    return dg, dgcol
+
+
+def sheared_wgrad(x, dy):
+    """Weight gradient of the depth-1 3x7 layer (snvc_sheared_wgrad): x [N,C,H,WU], dy [N,CO,H,WU] -> dK [CO,C,3,7]."""
+    _gpu(x, "x"); _gpu(dy, "dy")
+    if (x.dtype != torch.float32 or dy.dtype != torch.float32 or x.dim() != 4 or dy.dim() != 4 or not x.is_contiguous()
+            or not dy.is_contiguous() or x.size(0) != dy.size(0) or tuple(x.shape[2:]) != tuple(dy.shape[2:])):
+        raise RuntimeError("sheared_wgrad needs contiguous float32 x [N,C,H,WU] and dy [N,CO,H,WU]")
+    n, c, h, wu = x.shape
+    co = dy.size(1)
+    dk = torch.empty((co, c, 3, 7), dtype=torch.float32, device=x.device)
+    nbytes = _lib.lib().snvc_sheared_wgrad_workspace_bytes(n, co, h, wu)
+    if nbytes < 0:
+        raise RuntimeError("snvc_sheared_wgrad_workspace_bytes: bad sizes")
+    ws = torch.empty((max(nbytes, 4) + 3) // 4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_sheared_wgrad(_ptr(x), _ptr(dy), _ptr(dk), _ptr(ws), n, c, co, h, wu, _stream(x)), "snvc_sheared_wgrad")
+    return dk
+
+
+def sheared_upsample_backward(drq, q: int, w: int, off: int):
+    """Adjoint of ``sheared_upsample`` (snvc_sheared_upsample_backward): drq [N,C,H,WU] (element i = dRq[i - off]) -> [N,C,H,w]."""
+    _gpu(drq, "drq")
+    if drq.dtype != torch.float32 or drq.dim() != 4 or not drq.is_contiguous():
+        raise RuntimeError("sheared_upsample_backward needs a contiguous float32 [N,C,H,WU] tensor")
+    n, c, h, wu = drq.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=drq.device)
+    with torch.cuda.device(drq.device):
+        check(_lib.lib().snvc_sheared_upsample_backward(_ptr(drq), _ptr(out), n, c, h, int(w), int(q), wu, int(off), _stream(drq)),
+              "snvc_sheared_upsample_backward")
+    return out
+
+
 def conv3d_forward_avgpool_d4(layer: "Conv3dLayer", x, scale, bias, flags) -> Optional[torch.Tensor]:
     """AvgPool3d((4,1,1),(4,1,1)) of ``epilogue(conv(x))`` written by the layer's own launch (SNVC_EPI_AVGPOOL_D4): returns
     [N,Cout,D/4,H,W], or None when the layer does not qualify (the caller then pools with ``avgpool_depth4``)."""

@@ -1129,6 +1129,107 @@ def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
     check(got, general, 2e-5, f"sheared vs general path q={q} m0={m0}")
 
 
+@pytest.mark.parametrize("q,m0", [(2, 0), (2, 3), (1, 0), (1, 2)])
+def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0):
+    """Training (cfg4) with uniformly spaced disparity planes: the first layer runs sheared in BOTH directions
+    (_ShearedFirstConvFn: snvc_sheared_reduce / snvc_sheared_wgrad / the 3 x 7 dgrad / snvc_sheared_upsample_backward).
+    Every parameter gradient and the feature gradients against the C oracle's cost volume + torch-CPU autograd, and
+    against the general factored function on the same inputs."""
+    from oracle import native as O
+    from oracle import torch_ref as T
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    r = np.random.default_rng(181 + 10 * q + m0)
+    C, H, W, D = 32, 8, 40, 12
+    L = r.standard_normal((2, C, H, W)).astype(np.float32)
+    R = r.standard_normal((2, C, H, W)).astype(np.float32)
+    s = np.tile(((m0 + np.arange(D)) / q).astype(np.float32)[None], (2, 1))
+    ref, ours = T.GlobalStack(C), GlobalStack(C)
+    sd = T.seeded_state_dict(ref, 182)
+    ref.load_state_dict(sd); ours.load_state_dict(sd)
+    ref.train(); ours.train()
+    ours = ours.to(dev())
+
+    class CV(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, l, rr):
+            return torch.from_numpy(O.cost_volume_forward(l.detach().numpy(), rr.detach().numpy(), s, 1))
+
+        @staticmethod
+        def backward(ctx, g):
+            gl, gr = O.cost_volume_backward(g.contiguous().numpy(), s, 1)
+            return torch.from_numpy(gl), torch.from_numpy(gr)
+
+    lr, rr = torch.from_numpy(L).requires_grad_(), torch.from_numpy(R).requires_grad_()
+    (gl_r, gr_r), gp_r = _grads(ref, [lr, rr], lambda: ref(CV.apply(lr, rr)).pow(2).mean())
+    lo, ro = torch.from_numpy(L).to(dev()).requires_grad_(), torch.from_numpy(R).to(dev()).requires_grad_()
+    sh = torch.from_numpy(s).to(dev())
+    before = S._ROUTES["sheared_first_conv_train"]
+    (gl_o, gr_o), gp_o = _grads(ours, [lo, ro], lambda: ours.forward_pair(lo, ro, sh, 1).pow(2).mean())
+    assert S._ROUTES["sheared_first_conv_train"] == before + 1
+    # the same step on the general factored function (the running statistics move a second time: gradients only)
+    lg, rg = torch.from_numpy(L).to(dev()).requires_grad_(), torch.from_numpy(R).to(dev()).requires_grad_()
+    (gl_g, gr_g), gp_g = _grads(ours, [lg, rg], lambda: ours.forward_pair(lg, rg, sh, 1, sheared=False).pow(2).mean())
+    assert S._ROUTES["sheared_first_conv_train"] == before + 1
+
+    def l2(a, b):
+        return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    assert l2(gl_o.numpy(), gl_r.numpy()) < 1e-3 and l2(gr_o.numpy(), gr_r.numpy()) < 1e-3
+    assert l2(gl_o.numpy(), gl_g.numpy()) < 1e-3 and l2(gr_o.numpy(), gr_g.numpy()) < 1e-3
+    assert set(gp_o) == set(gp_r)
+    for k in gp_r:
+        check(gp_o[k].numpy(), gp_r[k].numpy(), 1e-3, f"d {k} (vs torch)")
+        check(gp_o[k].numpy(), gp_g[k].numpy(), 1e-3, f"d {k} (vs general)")
+
+
+@pytest.mark.parametrize("q,m0", [(2, 0), (2, 5), (1, 1)])
+def test_sheared_backward_entry_points_vs_numpy(q, m0):
+    """snvc_sheared_reduce is the exact adjoint of snvc_sheared_expand (bit-exact against a numpy scatter in the same order
+    for the one-term slots, 1e-5 for the sums), snvc_sheared_wgrad against an fp64 correlation, snvc_sheared_upsample_backward
+    against the transpose of the interpolation matrix."""
+    from snvc_amd import ops
+    from snvc_amd.models.submodule import sheared_geometry
+    r = np.random.default_rng(191 + q + m0)
+    N, C, D, H, W = 2, 5, 9, 3, 21
+    off, wu, off_col, wu_col = sheared_geometry(q, m0, D, W)
+    dy = r.standard_normal((N, C, D, H, W)).astype(np.float32)
+    dg, dgc = ops.sheared_reduce(torch.from_numpy(dy).to(dev()), q, m0, wu, off, wu_col, off_col)
+    exp_g = np.zeros((N, 3, C, H, wu), np.float64)
+    exp_c = np.zeros((N, 3, C, H, wu_col), np.float64)
+    for d in range(D):
+        cls = 0 if d == 0 else (2 if d == D - 1 else 1)
+        for w in range(W - 1):
+            if 0 <= q * w - d - m0 + off < wu:           # further left than the kernel's reach: G is zero there, nothing to sum
+                exp_g[:, cls, :, :, q * w - d - m0 + off] += dy[:, :, d, :, w]
+        exp_c[:, cls, :, :, q * (W - 1) - d - m0 + off_col] += dy[:, :, d, :, W - 1]
+    check(dg.cpu().numpy().reshape(exp_g.shape), exp_g.astype(np.float32), 1e-5, "dG")
+    check(dgc.cpu().numpy().reshape(exp_c.shape), exp_c.astype(np.float32), 0, "dG'")
+
+    # 3 x 7 weight gradient (CO = 40: one full and one ragged channel group; C < 32)
+    CO, WU = 40, 2 * 64 + 20
+    x = r.standard_normal((N, C, H, WU)).astype(np.float32)
+    gy = r.standard_normal((N, CO, H, WU)).astype(np.float32)
+    dk = ops.sheared_wgrad(torch.from_numpy(x).to(dev()), torch.from_numpy(gy).to(dev())).cpu().numpy()
+    xp = np.pad(x.astype(np.float64), ((0, 0), (0, 0), (1, 1), (3, 3)))
+    exp = np.zeros((CO, C, 3, 7))
+    for kh in range(3):
+        for t in range(7):
+            exp[:, :, kh, t] = np.einsum("nohi,nchi->oc", gy.astype(np.float64), xp[:, :, kh:kh + H, t:t + WU])
+    check(dk, exp.astype(np.float32), 1e-5, "dK")
+
+    # adjoint of the upsampling: <upsample(R), G> == <R, upsample_backward(G)> and against the dense transpose
+    R = r.standard_normal((N, C, H, W)).astype(np.float32)
+    G = r.standard_normal((N, C, H, wu)).astype(np.float32)
+    up = ops.sheared_upsample(torch.from_numpy(R).to(dev()), q, wu, off).cpu().numpy().astype(np.float64)
+    M = np.zeros((wu, W))                                    # up[i] = sum_j M[i][j] R[j]
+    for j in range(W):
+        e = np.zeros((1, 1, 1, W), np.float32); e[..., j] = 1
+        M[:, j] = ops.sheared_upsample(torch.from_numpy(e).to(dev()), q, wu, off).cpu().numpy().reshape(-1)
+    back = ops.sheared_upsample_backward(torch.from_numpy(G).to(dev()), q, W, off).cpu().numpy()
+    check(back, (G.astype(np.float64) @ M).astype(np.float32), 1e-6, "upsample backward")
+    assert abs((up * G).sum() - (back.astype(np.float64) * R).sum()) < 1e-3
+
+
 @pytest.mark.parametrize("gn", [False, True])
 def test_training_step_vernier_trunk_vs_torch_autograd(gn):
     """Local (V-A) model: gather + 3D trunk (7^3, 5^3, dilated 5^3 convs, hourglass, heads' inputs)
