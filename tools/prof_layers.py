@@ -93,6 +93,16 @@ with torch.no_grad():
         m = S.convbn_3d(64, 32, 7, 1, 3).to(dev).eval()
         xh = torch.randn((2, 8, 32, 128, 192, 8), device=dev).half()
         fn = lambda: m.fused_f16(xh, relu=True)  # noqa: E731
+    elif args.layer in ("wgrad_conv2", "wgrad_s2", "wgrad_hg"):     # cfg4: weight gradients of conv2 (k3 s1 32->32), of the
+        from snvc_amd import ops                                     # hourglass's stride-2 layer and of its 64->64 layer
+        if args.layer == "wgrad_conv2":
+            xb = torch.randn(1, bench.C, bench.D, bench.H, bench.W, device=dev); gs = torch.randn_like(xb); st = 1
+        elif args.layer == "wgrad_hg":
+            xb = torch.randn(1, 2 * bench.C, bench.D // 2, bench.H // 2, bench.W // 2, device=dev); gs = torch.randn_like(xb); st = 1
+        else:
+            xb = torch.randn(1, bench.C, bench.D, bench.H, bench.W, device=dev)
+            gs = torch.randn(1, 2 * bench.C, bench.D // 2, bench.H // 2, bench.W // 2, device=dev); st = 2
+        fn = lambda: ops.conv3d_wgrad(xb, gs, 3, st, 1, 1)  # noqa: E731
     elif args.layer == "cost_volume_right":
         from snvc_amd import ops
         fn = lambda: ops.cost_volume_forward_right(right, shift)  # noqa: E731
