@@ -324,6 +324,30 @@ SNVC_API int snvc_sheared_expand(const float *g, const float *gcol, const float 
  *   snvc_sheared_upsample_backward : adjoint of snvc_sheared_upsample: dright[j] = dRq[q*j] (+ (dRq[2j-1] + dRq[2j+1]) / 2 for
  *                                    q = 2), drq [N][C][H][WU] with element i = dRq[i - off]
  * The input gradient dRq itself is snvc_conv3d_forward of dg with the flipped / transposed 3 x 7 kernel. */
+/* Train-mode BatchNorm around the sheared layer WITHOUT storing the layer's raw result (the 736 MB tensor of cfg4):
+ *   snvc_sheared_expand_stats    : batch statistics of raw = expand(g, gcol) + planes, computed while walking the same values
+ *                                  snvc_sheared_expand writes: scale / shift [C] for y = relu(scale*raw + shift) (gamma / beta
+ *                                  may be NULL), mean / var [C] (may be NULL); fp64 sums, deterministic
+ *   snvc_sheared_backward_reduce : everything the layer's backward needs from gy = dL/dy, in ONE pass over it; raw is recomputed
+ *                                  from g / gcol / planes.  With g' = gy where scale*raw + shift > 0 (else 0):
+ *                                    sums   [N][C][2] fp64 = (sum g', sum g'*raw)     -> snvc_bn_backward_coefs
+ *                                    line   [2][N][3][C][H][WG]  sums of g' (0) and of raw (1) along every shear line, per depth
+ *                                                                class, columns w <= W-2 (the layout of snvc_sheared_reduce's dg)
+ *                                    lastc  [2][N][3][C][H][WG2] g' and raw of column W-1 by slot (dgcol's layout)
+ *                                    colsum [2][N][C][3][H][W]   sums of g' and of raw over each depth class (the left half's planes)
+ *                                  The BatchNorm backward is linear, draw = A*g' + B*raw + Cc per channel, so
+ *                                  dg = A*line[0] + B*line[1] + Cc*(terms per line), and likewise dgcol and the planes: the
+ *                                  caller combines 8 MB of sums; draw itself (736 MB) is never formed.  W % 8 == 0, W <= 512. */
+SNVC_API int64_t snvc_sheared_stats_workspace_bytes(int64_t N, int64_t C, int64_t H);
+SNVC_API int snvc_sheared_expand_stats(const float *g, const float *gcol, const float *planes, const float *gamma,
+                                       const float *beta, float *scale, float *shift, float *mean, float *var,
+                                       void *workspace, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0,
+                                       int64_t WG, int off, int64_t WG2, int off2, float eps, void *stream);
+SNVC_API int64_t snvc_sheared_backward_workspace_bytes(int64_t N, int64_t C, int64_t H);
+SNVC_API int snvc_sheared_backward_reduce(const float *g, const float *gcol, const float *planes, const float *scale,
+                                          const float *shift, const float *gy, float *line, float *colsum, float *lastc,
+                                          double *sums, void *workspace, int64_t N, int64_t C, int64_t D, int64_t H,
+                                          int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2, int off2, void *stream);
 SNVC_API int snvc_sheared_reduce(const float *dy, float *dg, float *dgcol, int64_t N, int64_t C, int64_t D, int64_t H,
                                  int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2, int off2, void *stream);
 SNVC_API int64_t snvc_sheared_wgrad_workspace_bytes(int64_t N, int64_t CO, int64_t H, int64_t WU);

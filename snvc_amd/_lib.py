@@ -57,6 +57,12 @@ SIGNATURES = {
     "snvc_conv3d_forward_head": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_conv3d_forward_side_head": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_sheared_upsample": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_p]),
+    "snvc_sheared_stats_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "snvc_sheared_expand_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int,
+                                          c_i64, c_int, c_i64, c_int, ctypes.c_float, c_p]),
+    "snvc_sheared_backward_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
+    "snvc_sheared_backward_reduce": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                             c_int, c_int, c_i64, c_int, c_i64, c_int, c_p]),
     "snvc_sheared_reduce": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_i64, c_int, c_p]),
     "snvc_sheared_wgrad_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     "snvc_sheared_wgrad": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),

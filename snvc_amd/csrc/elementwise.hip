@@ -3,6 +3,7 @@
 // All kernels stream with 16-byte accesses when the row length allows it and fall back to
 // scalar lanes otherwise; none of them re-reads its input.
 #include "common.hpp"
+#include "elementwise_internal.hpp"
 
 #include <cfloat>
 
@@ -384,6 +385,14 @@ zero_stuff2x_kernel(const float *__restrict__ x, float *__restrict__ y, int H, i
 }
 
 }  // namespace
+}  // namespace snvc
+
+namespace snvc {
+void launch_norm_finalize(const double *partial, const float *gamma, const float *beta, float *scale, float *shift, float *mean,
+                          float *var, int64_t N, int64_t C, int64_t S, int splits, float eps, hipStream_t st) {
+    norm_finalize_kernel<<<dim3((unsigned)ceil_div<int64_t>(C, 128)), 128, 0, st>>>(partial, gamma, beta, scale, shift, mean, var, N, C, S, C, 0,
+                                                                                   splits, eps);
+}
 }  // namespace snvc
 
 extern "C" {

@@ -23,6 +23,7 @@
 // `planes` are the depth-class planes of the LEFT half of the concat volume (snvc_conv3d_forward_ex); the result equals
 // the factored path's (tests/test_gpu_parity.py::test_sheared_first_conv_*), fp32 summation order aside.
 #include "common.hpp"
+#include "elementwise_internal.hpp"
 
 namespace snvc {
 namespace {
@@ -52,11 +53,16 @@ sheared_upsample_kernel(const float *__restrict__ r, float *__restrict__ out, in
 // Window: the thread's four values G[i0 + q*k], k = 0..3, with i0 = q*4*quad - d - m0 + off.  For q = 2 the even- and the
 // odd-indexed elements of a G row are kept as two LDS arrays, so a window is 4 CONSECUTIVE elements of one of them and
 // moving from plane d to d + q shifts it down by one: one 4-byte LDS read per thread and plane.
-template <int Q>
+// MODE 0 writes y; MODE 1 (training: train-mode BatchNorm needs the statistics of the layer's raw result before it can write
+// anything) walks the same values and leaves the workgroup's fp64 (sum, sum of squares) in stats[(n*C + co) * gridDim.x + blockIdx.x]
+// -- the raw result is never stored: MODE 0 then writes act(scale * raw + shift) directly, and the backward pass
+// (sheared_bwd_kernel) recomputes raw from G the same way.
+template <int Q, int MODE>
 __global__ void __launch_bounds__(512)
 sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gcol, const float *__restrict__ planes,
-                      const float *__restrict__ scale, const float *__restrict__ bias, float *__restrict__ y, int C, int D, int H,
-                      int W, int m0, int WG, int off, int WG2, int off2, int RB, int flags) {
+                      const float *__restrict__ scale, const float *__restrict__ bias, float *__restrict__ y,
+                      double *__restrict__ stats, int C, int D, int H, int W, int m0, int WG, int off, int WG2, int off2, int RB,
+                      int flags) {
     extern __shared__ float lds[];
     const int quads = W >> 2;
     const int tid = threadIdx.x;
@@ -79,7 +85,8 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
         lastcol[r * D + d] = (i >= 0 && i < WG2) ? gc[(int64_t)(h0 + r) * WG2 + i] : 0.0f;
     }
     __syncthreads();
-    if (tid >= rows * quads) return;
+    double st0 = 0.0, st1 = 0.0;
+    if (tid < rows * quads) {
     const int r = tid / quads, qd = tid - r * quads, w0 = 4 * qd;
     const float sc = scale ? scale[co] : 1.0f, bi = scale ? bias[co] : 0.0f;
     f32x4 pl = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -123,7 +130,12 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
             float v = (o[k] + pe[k]) * sc + bi;
             o[k] = relu ? (v > 0.0f ? v : 0.0f) : v;
         }
-        *reinterpret_cast<f32x4 *>(yp + (int64_t)d * plane_sz) = o;
+        if (MODE == 0) {
+            *reinterpret_cast<f32x4 *>(yp + (int64_t)d * plane_sz) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { st0 += (double)o[k]; st1 += (double)o[k] * (double)o[k]; }
+        }
     }
     for (int d0 = 1; d0 < D - 1; d0 += Q) {
 #pragma unroll
@@ -139,10 +151,28 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
                 float v = (o[k] + pl[k]) * sc + bi;
                 o[k] = relu ? (v > 0.0f ? v : 0.0f) : v;
             }
-            *reinterpret_cast<f32x4 *>(yp + (int64_t)d * plane_sz) = o;      // plain store: conv2 reads the tail from the caches
+            if (MODE == 0) {
+                *reinterpret_cast<f32x4 *>(yp + (int64_t)d * plane_sz) = o;      // plain store: conv2 reads the tail from the caches
+            } else {
+                st0 += ((double)o[0] + (double)o[1]) + ((double)o[2] + (double)o[3]);
+                st1 += ((double)o[0] * (double)o[0] + (double)o[1] * (double)o[1]) + ((double)o[2] * (double)o[2] + (double)o[3] * (double)o[3]);
+            }
             // next plane of this chain is d + Q: every index drops by Q, i.e. by ONE element of the chain's phase array
             win[p][3] = win[p][2]; win[p][2] = win[p][1]; win[p][1] = win[p][0];
             win[p][0] = load(Q * w0 - (d + Q) - m0 + off);
+        }
+    }
+    }   // active threads
+    if (MODE == 1) {
+        for (int o = 32; o > 0; o >>= 1) { st0 += __shfl_down(st0, o, 64); st1 += __shfl_down(st1, o, 64); }
+        __shared__ double red[16];
+        const int wave = tid >> 6, nw = (int)(blockDim.x >> 6);
+        if ((tid & 63) == 0) { red[2 * wave] = st0; red[2 * wave + 1] = st1; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int k = 1; k < nw; ++k) { st0 += red[2 * k]; st1 += red[2 * k + 1]; }
+            double *o = stats + (((int64_t)n * C + co) * gridDim.x + blockIdx.x) * 2;
+            o[0] = st0; o[1] = st1;
         }
     }
 }
@@ -197,6 +227,253 @@ sheared_reduce_kernel(const float *__restrict__ dy, float *__restrict__ dg, floa
         cout_(1)[i] = (d > 0 && d < D - 1) ? v : 0.0f;
         cout_(2)[i] = (d == D - 1 && d != 0) ? v : 0.0f;
     }
+}
+
+// Backward of  y = relu(scale * raw + shift)  through the sheared layer in ONE pass over gy (train-mode BatchNorm, cfg4).
+// raw is not stored: it is recomputed from G / G' / planes exactly as sheared_expand_kernel forms it.  The BatchNorm backward
+//     draw = A * g + B * raw + Cc      (g = gy where scale*raw + shift > 0; A, B, Cc per channel from sum(g), sum(g*raw))
+// is LINEAR in (g, raw, 1), and the layer's own backward only needs sums of draw -- along the shear lines (dG, dG') and over
+// the depth classes (the left half's planes) -- so this kernel accumulates those sums of g and of raw separately, plus the
+// per-channel fp64 (sum g, sum g*raw); the host combines them with the coefficients on 8 MB instead of 736.
+//   line[q][n][cls][co][h][i]   q = 0: g, 1: raw;  sum over (d in cls, w <= W-2) with Q*w - d - m0 + off == i
+//   colsum[q][n][co][cls][h][w] sum over d in cls
+//   lastc[q][n][cls][co][h][i2] the value at (d, W-1) with Q*(W-1) - d - m0 + off2 == i2
+// One wave per image row, lane = 8 consecutive columns, walking d.  A shear line's running sum moves one column to the right
+// per plane of its parity chain: it lives in a window of 8 registers that shifts by one per step, the value leaving lane l
+// enters lane l+1 (one __shfl_up per step), the one leaving the row's last lane is final.  Every sum has one fixed order.
+template <int Q>
+__global__ void __launch_bounds__(256)
+sheared_bwd_kernel(const float *__restrict__ g, const float *__restrict__ gcol, const float *__restrict__ planes,
+                   const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ gy,
+                   float *__restrict__ line, float *__restrict__ colsum, float *__restrict__ lastc, double *__restrict__ partial,
+                   int N, int C, int D, int H, int W, int m0, int WG, int off, int WG2, int off2) {
+    constexpr int RB = 4;                                    // rows (waves) per workgroup
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int h0 = blockIdx.x * RB, h = h0 + wave;
+    const int rows = (H - h0) < RB ? (H - h0) : RB;
+    const int LW = (WG + Q - 1) / Q + 4;
+    float *const phase = lds;                                // [RB][Q][LW]   G (interior class) as phase arrays
+    float *const lastg = phase + RB * Q * LW;                // [RB][D]       G' at the last column, per plane
+    float *const lineb = lastg + RB * D;                     // [RB][2][WG]   line sums being built
+    float *const lcb = lineb + RB * 2 * WG;                  // [RB][2][WG2]  last-column values by slot
+    const int64_t CH = (int64_t)C * H;
+    const float *gn = g + ((n * 3 + 1) * C + co) * (int64_t)H * WG, *gc = gcol + ((n * 3 + 1) * C + co) * (int64_t)H * WG2;
+    for (int e = tid; e < rows * WG; e += 256) {
+        const int r = e / WG, i = e - r * WG;
+        phase[(r * Q + (i % Q)) * LW + i / Q] = gn[(int64_t)(h0 + r) * WG + i];
+    }
+    for (int e = tid; e < rows * D; e += 256) {
+        const int r = e / D, d = e - r * D;
+        const int i = Q * (W - 1) - d - m0 + off2;
+        lastg[r * D + d] = (i >= 0 && i < WG2) ? gc[(int64_t)(h0 + r) * WG2 + i] : 0.0f;
+    }
+    for (int e = tid; e < RB * 2 * WG; e += 256) lineb[e] = 0.0f;
+    for (int e = tid; e < RB * 2 * WG2; e += 256) lcb[e] = 0.0f;
+    __syncthreads();
+    const int nT = W >> 3;                                   // active lanes per row
+    const bool act = lane < nT && h < H;
+    const bool lastlane = lane == nT - 1;
+    const int w0 = 8 * lane;
+    const float sc = scale[co], sh = shift[co];
+    const int64_t plane_sz = (int64_t)H * W;
+    const float *gyp = gy + ((n * C + co) * (int64_t)D) * plane_sz + (int64_t)(act ? h : 0) * W + (act ? w0 : 0);
+    const int64_t lrow = (int64_t)H * WG, crow = (int64_t)H * WG2;
+    const int64_t line_q = (int64_t)N * 3 * CH * WG, lc_q = (int64_t)N * 3 * CH * WG2, col_q = (int64_t)N * C * 3 * plane_sz;
+    double s0 = 0.0, s1 = 0.0;
+    auto gload = [&](int i) -> float { return (i >= 0 && i < WG) ? phase[(wave * Q + (i % Q)) * LW + i / Q] : 0.0f; };
+    // g and raw of plane d at this lane's 8 columns; rawv in: G part, out: raw
+    auto grad8 = [&](const f32x4 a, const f32x4 b, float (&rawv)[8], const float (&pl)[8], float (&gg)[8]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float x = rawv[k] + pl[k];
+            const float v = x * sc + sh;                     // the same two roundings as the forward (fp contract is off)
+            const float gyk = k < 4 ? a[k] : b[k - 4];
+            gg[k] = v > 0.0f ? gyk : 0.0f;
+            rawv[k] = x;
+            s0 += (double)gg[k];
+            s1 += (double)gg[k] * (double)x;
+        }
+    };
+    // ---- the two end planes (depth classes 0 and 2): single terms everywhere
+#pragma unroll 1
+    for (int e = 0; e < 2; ++e) {
+        const int d = e ? D - 1 : 0, cls = e ? 2 : 0;
+        if (act) {
+            const float *ge = g + ((n * 3 + cls) * C + co) * lrow + (int64_t)h * WG;
+            float rawv[8], pl[8], gg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = Q * (w0 + k) - d - m0 + off;
+                rawv[k] = (i >= 0 && i < WG) ? ge[i] : 0.0f;
+            }
+            if (lastlane) {
+                const int i = Q * (W - 1) - d - m0 + off2;
+                rawv[7] = (i >= 0 && i < WG2) ? gcol[((n * 3 + cls) * C + co) * crow + (int64_t)h * WG2 + i] : 0.0f;
+            }
+            const float *pp = planes + (((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) pl[k] = pp[k];
+            grad8(*reinterpret_cast<const f32x4 *>(gyp + (int64_t)d * plane_sz), *reinterpret_cast<const f32x4 *>(gyp + (int64_t)d * plane_sz + 4),
+                  rawv, pl, gg);
+            float *cs = colsum + (((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cs[k] = gg[k];
+                cs[col_q + k] = rawv[k];
+                const int i = Q * (w0 + k) - d - m0 + off;
+                if (lastlane && k == 7) {
+                    const int i2 = Q * (W - 1) - d - m0 + off2;
+                    if (i2 >= 0 && i2 < WG2) { lcb[(wave * 2 + 0) * WG2 + i2] = gg[k]; lcb[(wave * 2 + 1) * WG2 + i2] = rawv[k]; }
+                } else if (i >= 0 && i < WG) {
+                    lineb[(wave * 2 + 0) * WG + i] = gg[k];
+                    lineb[(wave * 2 + 1) * WG + i] = rawv[k];
+                }
+            }
+        }
+        __syncthreads();
+        for (int e2 = tid; e2 < rows * 2 * WG; e2 += 256) {       // coalesced rows out, zeros included; then clear
+            const int r = e2 / (2 * WG), rem = e2 - r * 2 * WG, qn = rem / WG, i = rem - qn * WG;
+            line[qn * line_q + ((n * 3 + cls) * C + co) * lrow + (int64_t)(h0 + r) * WG + i] = lineb[e2];
+            lineb[e2] = 0.0f;
+        }
+        for (int e2 = tid; e2 < rows * 2 * WG2; e2 += 256) {
+            const int r = e2 / (2 * WG2), rem = e2 - r * 2 * WG2, qn = rem / WG2, i = rem - qn * WG2;
+            lastc[qn * lc_q + ((n * 3 + cls) * C + co) * crow + (int64_t)(h0 + r) * WG2 + i] = lcb[e2];
+            lcb[e2] = 0.0f;
+        }
+        __syncthreads();
+    }
+    // ---- interior planes d = 1 .. D-2 (depth class 1)
+    float pl[8], cg[8], cr[8], wing[Q][8], lg[Q][8], lr[Q][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { pl[k] = 0.0f; cg[k] = 0.0f; cr[k] = 0.0f; }
+    if (act) {
+        const float *pp = planes + (((n * C + co) * 3 + 1) * (int64_t)H + h) * W + w0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pl[k] = pp[k];
+    }
+#pragma unroll
+    for (int p = 0; p < Q; ++p)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            wing[p][k] = gload(Q * (w0 + k) - (1 + p) - m0 + off);
+            lg[p][k] = 0.0f;
+            lr[p][k] = 0.0f;
+        }
+    // gy of the NEXT block of 4 planes is requested before this block is processed (~60 KB in flight per CU)
+    constexpr int PB = 4;
+    static_assert(PB % Q == 0, "a block is whole parity chains");
+    f32x4 cur[PB][2], nxt[PB][2];
+    auto fetch = [&](int d, f32x4 (&dst)[2]) {
+        if (act && d < D - 1) {
+            dst[0] = *reinterpret_cast<const f32x4 *>(gyp + (int64_t)d * plane_sz);
+            dst[1] = *reinterpret_cast<const f32x4 *>(gyp + (int64_t)d * plane_sz + 4);
+        } else {
+            dst[0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            dst[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < PB; ++j) fetch(1 + j, cur[j]);
+    for (int d0 = 1; d0 < D - 1; d0 += PB) {
+#pragma unroll
+        for (int j = 0; j < PB; ++j) fetch(d0 + PB + j, nxt[j]);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int p = j % Q;                              // d0 - 1 is a multiple of PB: the chain of plane d0 + j
+            const int d = d0 + j;
+            if (d >= D - 1) break;
+            float rawv[8], gg[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rawv[k] = wing[p][k];
+            if (lastlane) rawv[7] = lastg[wave * D + d];
+            if (act) {
+                grad8(cur[j][0], cur[j][1], rawv, pl, gg);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { gg[k] = 0.0f; rawv[k] = 0.0f; }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cg[k] = cg[k] + gg[k];
+                cr[k] = cr[k] + rawv[k];
+            }
+            if (lastlane) {                                   // column W-1 belongs to G', not to a shear line of G
+                const int i2 = Q * (W - 1) - d - m0 + off2;
+                if (i2 >= 0 && i2 < WG2) { lcb[(wave * 2 + 0) * WG2 + i2] = gg[7]; lcb[(wave * 2 + 1) * WG2 + i2] = rawv[7]; }
+                gg[7] = 0.0f; rawv[7] = 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                lg[p][k] = lg[p][k] + gg[k];
+                lr[p][k] = lr[p][k] + rawv[k];
+            }
+            // the line at k = 7 moves on to the next lane (or is complete); everything shifts by one element
+            const float og = lg[p][7], orr = lr[p][7];
+            if (lastlane) {
+                const int i = Q * (w0 + 7) - d - m0 + off;
+                if (i >= 0 && i < WG) { lineb[(wave * 2 + 0) * WG + i] = og; lineb[(wave * 2 + 1) * WG + i] = orr; }
+            }
+            const float ig = __shfl_up(og, 1, 64), ir = __shfl_up(orr, 1, 64);
+#pragma unroll
+            for (int k = 7; k > 0; --k) { lg[p][k] = lg[p][k - 1]; lr[p][k] = lr[p][k - 1]; wing[p][k] = wing[p][k - 1]; }
+            lg[p][0] = lane == 0 ? 0.0f : ig;
+            lr[p][0] = lane == 0 ? 0.0f : ir;
+            wing[p][0] = gload(Q * w0 - (d + Q) - m0 + off);
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) { cur[j][0] = nxt[j][0]; cur[j][1] = nxt[j][1]; }
+    }
+    if (act) {
+        // lines still inside the windows: chain p stands at its next plane d = dn(p), element k is slot Q*(w0+k) - dn - m0 + off
+#pragma unroll
+        for (int p = 0; p < Q; ++p) {
+            int dn = 1 + p;
+            while (dn < D - 1) dn += Q;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int i = Q * (w0 + k) - dn - m0 + off;
+                if (i >= 0 && i < WG) {
+                    lineb[(wave * 2 + 0) * WG + i] = lg[p][k];
+                    lineb[(wave * 2 + 1) * WG + i] = lr[p][k];
+                }
+            }
+        }
+        float *cs = colsum + (((n * C + co) * 3 + 1) * (int64_t)H + h) * W + w0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { cs[k] = cg[k]; cs[col_q + k] = cr[k]; }
+    }
+    __syncthreads();
+    for (int e2 = tid; e2 < rows * 2 * WG; e2 += 256) {
+        const int r = e2 / (2 * WG), rem = e2 - r * 2 * WG, qn = rem / WG, i = rem - qn * WG;
+        line[qn * line_q + ((n * 3 + 1) * C + co) * lrow + (int64_t)(h0 + r) * WG + i] = lineb[e2];
+    }
+    for (int e2 = tid; e2 < rows * 2 * WG2; e2 += 256) {
+        const int r = e2 / (2 * WG2), rem = e2 - r * 2 * WG2, qn = rem / WG2, i = rem - qn * WG2;
+        lastc[qn * lc_q + ((n * 3 + 1) * C + co) * crow + (int64_t)(h0 + r) * WG2 + i] = lcb[e2];
+    }
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_down(s0, o, 64); s1 += __shfl_down(s1, o, 64); }
+    __shared__ double red[8];
+    if (lane == 0) { red[2 * wave] = s0; red[2 * wave + 1] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < 4; ++k) { s0 += red[2 * k]; s1 += red[2 * k + 1]; }
+        double *o = partial + (((int64_t)n * C + co) * gridDim.x + blockIdx.x) * 2;
+        o[0] = s0; o[1] = s1;
+    }
+}
+
+// sums[n*C + c][2] = the workgroups' partials in a fixed order
+__global__ void sheared_fold_kernel(const double *__restrict__ partial, double *__restrict__ sums, int64_t rows, int splits) {
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < splits; ++k) { a += partial[(row * splits + k) * 2]; b += partial[(row * splits + k) * 2 + 1]; }
+    sums[row * 2] = a;
+    sums[row * 2 + 1] = b;
 }
 
 // Weight gradient of the depth-1 3 x 7 convolution  y[co][h][i] = sum_{c,kh,t} K[co][c][kh][t] * x[c][h+kh-1][i+t-3]:
@@ -313,6 +590,14 @@ int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, 
     return check_launch("snvc_sheared_upsample");
 }
 
+// Launch geometry of sheared_expand_kernel, shared by the forward statistics pass
+static int sheared_expand_rows(int64_t N, int64_t C, int64_t H, int quads) {
+    int RB = 512 / quads;                       // rows per workgroup: as many as 512 threads cover ...
+    if (RB > 8) RB = 8;
+    while (RB > 1 && snvc::ceil_div<int64_t>(H, RB) * C * N < 4 * 256) RB = (RB + 1) / 2;      // ... while the chip stays covered
+    return RB;
+}
+
 int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale, const float *bias, float *y,
                         int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2,
                         int off2, int flags, void *stream) {
@@ -328,9 +613,7 @@ int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, 
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: y and planes must be 16-byte aligned");
     const int quads = (int)(W / 4);
     if (quads > 512 || C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand: row too wide or too many channels");
-    int RB = 512 / quads;                       // rows per workgroup: as many as 512 threads cover ...
-    if (RB > 8) RB = 8;
-    while (RB > 1 && ceil_div<int64_t>(H, RB) * C * N < 4 * 256) RB = (RB + 1) / 2;      // ... while the chip stays covered
+    const int RB = sheared_expand_rows(N, C, H, quads);
     const int threads = ceil_div(RB * quads, 64) * 64;
     const int LW = (int)((WG + q - 1) / q) + 4;
     const size_t lds = sizeof(float) * ((size_t)RB * q * LW + (size_t)RB * D);
@@ -338,15 +621,91 @@ int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, 
     const dim3 grid((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N);
     static std::atomic<unsigned> attr1{0}, attr2{0};
     if (q == 1) {
-        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<1>), (int)lds, attr1)) return check_launch("snvc_sheared_expand");
-        sheared_expand_kernel<1><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, (int)C, (int)D, (int)H, (int)W,
-                                                                          m0, (int)WG, off, (int)WG2, off2, RB, flags);
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<1, 0>), (int)lds, attr1)) return check_launch("snvc_sheared_expand");
+        sheared_expand_kernel<1, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
+                                                                             (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
     } else {
-        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<2>), (int)lds, attr2)) return check_launch("snvc_sheared_expand");
-        sheared_expand_kernel<2><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, (int)C, (int)D, (int)H, (int)W,
-                                                                          m0, (int)WG, off, (int)WG2, off2, RB, flags);
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<2, 0>), (int)lds, attr2)) return check_launch("snvc_sheared_expand");
+        sheared_expand_kernel<2, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
+                                                                             (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
     }
     return check_launch("snvc_sheared_expand");
+}
+
+int64_t snvc_sheared_stats_workspace_bytes(int64_t N, int64_t C, int64_t H) {
+    if (N < 0 || C <= 0 || H <= 0) return -1;
+    return (N * C * H * 2 + 2 * N * C) * (int64_t)sizeof(double) + 16;     // one partial pair per (n, c, row block <= H)
+}
+
+int snvc_sheared_expand_stats(const float *g, const float *gcol, const float *planes, const float *gamma, const float *beta,
+                              float *scale, float *shift, float *mean, float *var, void *workspace, int64_t N, int64_t C, int64_t D,
+                              int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2, int off2, float eps,
+                              void *stream) {
+    using namespace snvc;
+    if (N <= 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || W % 4 != 0 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || WG2 <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_stats: bad sizes (W % 4 == 0, q in {1,2}, D >= 2)");
+    if (!g || !gcol || !scale || !shift || !workspace) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_stats: null pointer");
+    if (reinterpret_cast<uintptr_t>(planes) & 15) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_stats: planes must be 16-byte aligned");
+    const int quads = (int)(W / 4);
+    if (quads > 512 || C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_stats: row too wide or too many channels");
+    const int RB = sheared_expand_rows(N, C, H, quads);
+    const int threads = ceil_div(RB * quads, 64) * 64;
+    const int LW = (int)((WG + q - 1) / q) + 4;
+    const size_t lds = sizeof(float) * ((size_t)RB * q * LW + (size_t)RB * D);
+    if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_stats: rows do not fit the LDS");
+    const dim3 grid((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N);
+    double *partial = static_cast<double *>(workspace);
+    static std::atomic<unsigned> attr1{0}, attr2{0};
+    if (q == 1) {
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<1, 1>), (int)lds, attr1)) return check_launch("snvc_sheared_expand_stats");
+        sheared_expand_kernel<1, 1><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, nullptr, nullptr, nullptr, partial, (int)C, (int)D,
+                                                                             (int)H, (int)W, m0, (int)WG, off, (int)WG2, off2, RB, 0);
+    } else {
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<2, 1>), (int)lds, attr2)) return check_launch("snvc_sheared_expand_stats");
+        sheared_expand_kernel<2, 1><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, nullptr, nullptr, nullptr, partial, (int)C, (int)D,
+                                                                             (int)H, (int)W, m0, (int)WG, off, (int)WG2, off2, RB, 0);
+    }
+    int rc = check_launch("snvc_sheared_expand_stats(partial)");
+    if (rc) return rc;
+    launch_norm_finalize(partial, gamma, beta, scale, shift, mean, var, N, C, D * H * W, (int)grid.x, eps, as_stream(stream));
+    return check_launch("snvc_sheared_expand_stats(finalize)");
+}
+
+int64_t snvc_sheared_backward_workspace_bytes(int64_t N, int64_t C, int64_t H) {
+    if (N < 0 || C <= 0 || H <= 0) return -1;
+    return N * C * ((H + 3) / 4) * 2 * (int64_t)sizeof(double) + 16;
+}
+
+int snvc_sheared_backward_reduce(const float *g, const float *gcol, const float *planes, const float *scale, const float *shift,
+                                 const float *gy, float *line, float *colsum, float *lastc, double *sums, void *workspace, int64_t N,
+                                 int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2, int off2,
+                                 void *stream) {
+    using namespace snvc;
+    if (N <= 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || W % 8 != 0 || W > 512 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || WG2 <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_backward_reduce: bad sizes (W % 8 == 0, W <= 512, q in {1,2}, D >= 2)");
+    if (!g || !gcol || !planes || !scale || !shift || !gy || !line || !colsum || !lastc || !sums || !workspace)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_backward_reduce: null pointer");
+    if (reinterpret_cast<uintptr_t>(gy) & 15) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_backward_reduce: gy must be 16-byte aligned");
+    if (C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_backward_reduce: too many channels or samples");
+    const int LW = (int)((WG + q - 1) / q) + 4;
+    const size_t lds = sizeof(float) * (4 * ((size_t)q * LW + D + 2 * WG + 2 * WG2));
+    if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_backward_reduce: rows do not fit the LDS");
+    const dim3 grid((unsigned)ceil_div<int64_t>(H, 4), (unsigned)C, (unsigned)N);
+    double *partial = static_cast<double *>(workspace);
+    static std::atomic<unsigned> attr1{0}, attr2{0};
+    if (q == 1) {
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_bwd_kernel<1>), (int)lds, attr1)) return check_launch("snvc_sheared_backward_reduce");
+        sheared_bwd_kernel<1><<<grid, 256, lds, as_stream(stream)>>>(g, gcol, planes, scale, shift, gy, line, colsum, lastc, partial, (int)N, (int)C,
+                                                                   (int)D, (int)H, (int)W, m0, (int)WG, off, (int)WG2, off2);
+    } else {
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_bwd_kernel<2>), (int)lds, attr2)) return check_launch("snvc_sheared_backward_reduce");
+        sheared_bwd_kernel<2><<<grid, 256, lds, as_stream(stream)>>>(g, gcol, planes, scale, shift, gy, line, colsum, lastc, partial, (int)N, (int)C,
+                                                                   (int)D, (int)H, (int)W, m0, (int)WG, off, (int)WG2, off2);
+    }
+    int rc = check_launch("snvc_sheared_backward_reduce");
+    if (rc) return rc;
+    sheared_fold_kernel<<<(unsigned)ceil_div<int64_t>(N * C, 128), 128, 0, as_stream(stream)>>>(partial, sums, N * C, (int)grid.x);
+    return check_launch("snvc_sheared_backward_reduce(fold)");
 }
 
 int snvc_sheared_reduce(const float *dy, float *dg, float *dgcol, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q,

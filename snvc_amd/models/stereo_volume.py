@@ -18,8 +18,8 @@ import torch.nn as nn
 
 from ..extension.build_cost_volume import _BuildCostVolume, build_cost_volume  # noqa: F401  (re-exported)
 from .. import ops
-from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _ShearedFirstConvFn, _folded_bn, _Plan,
-                        convbn_3d, hourglass, sheared_geometry, sheared_kernels, EPI_RELU)
+from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _ShearedFirstConvBNFn,
+                        _ShearedFirstConvFn, _folded_bn, _Plan, convbn_3d, hourglass, sheared_geometry, sheared_kernels, EPI_RELU)
 
 
 class GlobalStack(nn.Module):
@@ -139,7 +139,8 @@ class GlobalStack(nn.Module):
             plans["left2d"] = ops.Conv3dLayer(k.reshape(-1, w.shape[1], 3, 3).float().contiguous(), 3, 1, 1, 1, False, planar=True)
         return plans["left2d"]
 
-    def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True):
+    def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True,
+                     fused_bn=True):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
 
         ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT
@@ -176,6 +177,12 @@ class GlobalStack(nn.Module):
             else:
                 assert torch.all(shift >= 0.)
             plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(left.device, _Plan())
+            if (structure is not None and isinstance(bn, nn.BatchNorm3d) and bn.training and left.size(3) % 8 == 0
+                    and left.size(3) <= 512 and fused_bn):
+                # ... with train-mode BatchNorm + ReLU folded around it: neither the raw result nor its gradient is ever stored
+                v = _ShearedFirstConvBNFn.apply(left, right, conv.weight, bn.weight, bn.bias, conv, bn, plan, structure[0], structure[1],
+                                                shift.size(1))
+                return self._tail(self.conv2(v))
             if structure is not None:      # uniformly spaced planes: the sheared 2D form, forward and backward
                 v = _ShearedFirstConvFn.apply(left, right, conv.weight, bn.weight, bn.bias, conv, bn, EPI_RELU, plan, structure[0],
                                               structure[1], shift.size(1))

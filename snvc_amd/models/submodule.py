@@ -427,6 +427,38 @@ def sheared_geometry(q: int, m0: int, d: int, w: int):
     return off, wu, 4 - u_lo, (d + 6 + 4 + 3) // 4 * 4
 
 
+def _sheared_train_layers(fac, weight, c, q):
+    """(forward layers G | G', their dgrad layers, the [2,3,7,3,3] scatter of the 3 x 7 weight gradient onto the 27 taps) of the
+    sheared first convolution, cached with the layer's other training plans."""
+    if ("shear", q) not in fac:
+        k = sheared_kernels(weight.detach()[:, c:], q)                       # [2,3,Cout,C,3,7]
+        cout = k.shape[2]
+        planar = lambda t: ops.Conv3dLayer(t.float().contiguous(), 7, 1, 3, 1, False, planar=True, ksize_h=3)   # noqa: E731
+        fwd = tuple(planar(k[v].reshape(3 * cout, c, 3, 7)) for v in range(2))
+        # dgrad of a stride-1 layer: the same layer with the kernel flipped and the channel roles swapped
+        bwd = tuple(planar(k[v].reshape(3 * cout, c, 3, 7).transpose(0, 1).flip(2, 3)) for v in range(2))
+        # dW[kd][kw] gathers dK[v][cls][t = q*kw - kd]
+        scatter = torch.zeros((2, 3, 7, 3, 3), dtype=torch.float32)
+        for cls, kds in enumerate(SHEAR_CLASS_KDS):
+            for kd in kds:
+                for kw in (-1, 0, 1):
+                    scatter[0, cls, q * kw - kd + 3, kd + 1, kw + 1] = 1.0
+                    if kw != 1:
+                        scatter[1, cls, q * kw - kd + 3, kd + 1, kw + 1] = 1.0
+        fac[("shear", q)] = (fwd, bwd, scatter.to(weight.device))
+    return fac[("shear", q)]
+
+
+def _bn_track(norm, mean, var, cnt):
+    """nn.BatchNorm3d's bookkeeping in train mode: momentum update of the running statistics with the unbiased variance."""
+    if norm.training and norm.track_running_stats and norm.running_mean is not None:
+        with torch.no_grad():
+            norm.num_batches_tracked += 1
+            m = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked)
+            norm.running_mean.mul_(1 - m).add_(mean[0], alpha=m)
+            norm.running_var.mul_(1 - m).add_(var[0] * (cnt / max(cnt - 1, 1)), alpha=m)
+
+
 class _ShearedFirstConvFn(torch.autograd.Function):
     """``_FactoredFirstConvFn`` for uniformly spaced disparity planes, shift[n][d] = (m0 + d) / q with q in {1, 2}: the warped
     half of the volume is a shear of ONE image Rq and the 3D convolution over it a 2D 3 x 7 convolution G evaluated along the
@@ -442,23 +474,7 @@ class _ShearedFirstConvFn(torch.autograd.Function):
     def forward(ctx, left, right, weight, gamma, beta, conv, norm, flags, plan, q, m0, depth):
         c = left.size(1)
         fac = _first_conv_train_cache(conv, weight, c)
-        if ("shear", q) not in fac:
-            k = sheared_kernels(weight.detach()[:, c:], q)                       # [2,3,Cout,C,3,7]
-            cout = k.shape[2]
-            planar = lambda t: ops.Conv3dLayer(t.float().contiguous(), 7, 1, 3, 1, False, planar=True, ksize_h=3)   # noqa: E731
-            fwd = tuple(planar(k[v].reshape(3 * cout, c, 3, 7)) for v in range(2))
-            # dgrad of a stride-1 layer: the same layer with the kernel flipped and the channel roles swapped
-            bwd = tuple(planar(k[v].reshape(3 * cout, c, 3, 7).transpose(0, 1).flip(2, 3)) for v in range(2))
-            # dW[kd][kw] gathers dK[v][cls][t = q*kw - kd]
-            scatter = torch.zeros((2, 3, 7, 3, 3), dtype=torch.float32)
-            for cls, kds in enumerate(SHEAR_CLASS_KDS):
-                for kd in kds:
-                    for kw in (-1, 0, 1):
-                        scatter[0, cls, q * kw - kd + 3, kd + 1, kw + 1] = 1.0
-                        if kw != 1:
-                            scatter[1, cls, q * kw - kd + 3, kd + 1, kw + 1] = 1.0
-            fac[("shear", q)] = (fwd, bwd, scatter.to(weight.device))
-        fwd = fac[("shear", q)][0]
+        fwd = _sheared_train_layers(fac, weight, c, q)[0]
         n, h, w = left.size(0), left.size(2), left.size(3)
         off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
         left3 = left.detach().unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()
@@ -485,26 +501,123 @@ class _ShearedFirstConvFn(torch.autograd.Function):
         draw, _, dg, db = _epilogue_backward(raw, gy, None, scale, shf, mean, var, norm, flags, ctx.per_sample, ctx.train_stats,
                                              False, needs[3], needs[4])
         fac = conv.__dict__["_snvc_factored_train"]
-        _, bwd, scatter = fac[("shear", q)]
         depth, w = draw.size(2), draw.size(4)
         off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
         dplanes = ops.depth_class_sums(draw)                                      # [N,Cout,3,H,W]
-        g_left = g_right = gw = None
+        d_g = d_gcol = None
         if needs[1] or needs[2]:
             d_g, d_gcol = ops.sheared_reduce(draw, q, m0, wu, off, wu_col, off_col)
-        if needs[2]:
-            cout = draw.size(1)
-            dk = torch.stack([ops.sheared_wgrad(ops.sheared_upsample(right, q, wu, off), d_g),
-                              ops.sheared_wgrad(ops.sheared_upsample(right, q, wu_col, off_col), d_gcol)])   # [2,3*Cout,C,3,7]
-            gw_r = torch.einsum("vsockt,vstdw->ocdkw", dk.view(2, 3, cout, -1, 3, 7), scatter)
-            gw_l = ops.conv3d_wgrad(left3, dplanes, 3, 1, 1, 1)
-            gw = torch.cat([gw_l, gw_r], dim=1)
-        if needs[0]:
-            g_left = fac["bl"](dplanes).sum(dim=2)                                # the three depth copies are one tensor
-        if needs[1]:
-            g_right = ops.sheared_upsample_backward(bwd[0](d_g.unsqueeze(2)).squeeze(2), q, w, off)
-            g_right = g_right + ops.sheared_upsample_backward(bwd[1](d_gcol.unsqueeze(2)).squeeze(2), q, w, off_col)
+        g_left, g_right, gw = _sheared_backward_tail(fac, q, m0, depth, w, left3, right, d_g, d_gcol, dplanes, needs[0], needs[1], needs[2])
         return g_left, g_right, gw, dg, db, None, None, None, None, None, None, None
+
+
+def _sheared_backward_tail(fac, q, m0, depth, w, left3, right, d_g, d_gcol, dplanes, need_left, need_right, need_weight):
+    """From the gradients of G / G' (d_g [N,3C,H,WG], d_gcol [N,3C,H,WG2]) and of the left half's depth-class planes to the
+    gradients of the two features and of the layer's 3x3x3 weight."""
+    _, bwd, scatter = fac[("shear", q)]
+    off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
+    g_left = g_right = gw = None
+    if need_weight:
+        cout = dplanes.size(1)
+        dk = torch.stack([ops.sheared_wgrad(ops.sheared_upsample(right, q, wu, off), d_g),
+                          ops.sheared_wgrad(ops.sheared_upsample(right, q, wu_col, off_col), d_gcol)])   # [2,3*Cout,C,3,7]
+        gw_r = torch.einsum("vsockt,vstdw->ocdkw", dk.view(2, 3, cout, -1, 3, 7), scatter)
+        gw_l = ops.conv3d_wgrad(left3, dplanes, 3, 1, 1, 1)
+        gw = torch.cat([gw_l, gw_r], dim=1)
+    if need_left:
+        g_left = fac["bl"](dplanes).sum(dim=2)                                    # the three depth copies are one tensor
+    if need_right:
+        g_right = ops.sheared_upsample_backward(bwd[0](d_g.unsqueeze(2)).squeeze(2), q, w, off)
+        g_right = g_right + ops.sheared_upsample_backward(bwd[1](d_gcol.unsqueeze(2)).squeeze(2), q, w, off_col)
+    return g_left, g_right, gw
+
+
+def _sheared_term_counts(q, m0, depth, w, device):
+    """How many elements of the layer's result lie on each shear line / in each last-column slot / depth class (per class):
+    the multiplicity of the BatchNorm backward's constant term in the sums of ``_ShearedFirstConvBNFn.backward``."""
+    key = (q, m0, depth, w, str(device))
+    hit = _SHEAR_COUNTS.get(key)
+    if hit is None:
+        import numpy as np
+        off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
+        line, col = np.zeros((3, wu), np.float32), np.zeros((3, wu_col), np.float32)
+        d = np.arange(depth)
+        cls = np.where(d == 0, 0, np.where(d == depth - 1, 2, 1))
+        i = q * np.arange(w - 1)[None, :] - d[:, None] - m0 + off                    # [D, W-1]
+        ok = (i >= 0) & (i < wu)
+        np.add.at(line, (np.broadcast_to(cls[:, None], i.shape)[ok], i[ok]), 1.0)
+        i2 = q * (w - 1) - d - m0 + off_col
+        ok2 = (i2 >= 0) & (i2 < wu_col)
+        np.add.at(col, (cls[ok2], i2[ok2]), 1.0)
+        per_class = np.array([1.0, max(depth - 2, 0), 1.0], np.float32)
+        hit = _SHEAR_COUNTS[key] = tuple(torch.from_numpy(a).to(device) for a in (line, col, per_class))
+    return hit
+
+
+_SHEAR_COUNTS = {}
+
+
+class _ShearedFirstConvBNFn(torch.autograd.Function):
+    """``_ShearedFirstConvFn`` for the layer as the reference builds it -- train-mode BatchNorm3d + ReLU -- WITHOUT the layer's
+    raw result ever being stored or its gradient formed (two 736 MB tensors on cfg4):
+      forward : batch statistics while walking the values the expansion is about to write (snvc_sheared_expand_stats), then
+                y = relu(scale * expand(G, G') + planes ... ) written once
+      backward: ONE pass over gy (snvc_sheared_backward_reduce) recomputes raw from G, masks gy and leaves per-channel fp64 sums
+                plus the sums of the masked gradient and of raw along the shear lines and over the depth classes; the BatchNorm
+                backward draw = A*g + B*raw + Cc is linear, so dG, dG' and the planes' gradients are combinations of those sums.
+    Gradients equal ``_ShearedFirstConvFn``'s up to summation order (tests/test_gpu_parity.py)."""
+
+    @staticmethod
+    def forward(ctx, left, right, weight, gamma, beta, conv, norm, plan, q, m0, depth):
+        c = left.size(1)
+        fac = _first_conv_train_cache(conv, weight, c)
+        fwd = _sheared_train_layers(fac, weight, c, q)[0]
+        n, h, w = left.size(0), left.size(2), left.size(3)
+        off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
+        left3 = left.detach().unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()
+        planes = fac["fl"](left3)
+        rd = right.detach()
+        g = fwd[0](ops.sheared_upsample(rd, q, wu, off).unsqueeze(2)).squeeze(2)
+        gcol = fwd[1](ops.sheared_upsample(rd, q, wu_col, off_col).unsqueeze(2)).squeeze(2)
+        shape = (n, weight.size(0), depth, h, w)
+        gam = gamma.detach() if gamma is not None else None
+        bet = beta.detach() if beta is not None else None
+        scale, shift, mean, var = ops.sheared_expand_stats(g, gcol, planes, gam, bet, shape, q, m0, off, off_col, norm.eps)
+        _bn_track(norm, mean, var, float(n * depth * h * w))
+        y = torch.empty(shape, dtype=torch.float32, device=left.device)
+        ops.sheared_expand(g, gcol, planes, scale, shift, y, q, m0, off, off_col, EPI_RELU)
+        ctx.conv, ctx.norm, ctx.q, ctx.m0 = conv, norm, q, m0
+        ctx.save_for_backward(left3, rd, g, gcol, planes, scale, shift, mean, var)
+        _ROUTES["sheared_first_conv_train"] += 1
+        _ROUTES["sheared_first_conv_train_fused_bn"] += 1
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        left3, right, g, gcol, planes, scale, shift, mean, var = ctx.saved_tensors
+        conv, norm, q, m0 = ctx.conv, ctx.norm, ctx.q, ctx.m0
+        needs = ctx.needs_input_grad
+        gy = gy.contiguous()
+        n, c, depth, h, w = gy.shape
+        off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
+        line, colsum, lastc, sums = ops.sheared_backward_reduce(g, gcol, planes, scale, shift, gy, q, m0, off, off_col)
+        gw_ = norm.weight.detach().float().contiguous() if norm.weight is not None else None
+        a_, b_, c_, dgamma, dbeta = ops.bn_backward_coefs(sums, mean[0].contiguous(), var[0].contiguous(), gw_,
+                                                          float(n * depth * h * w), float(norm.eps))
+        if norm.weight is None:
+            dgamma = dbeta = None
+        cnt_line, cnt_col, cnt_cls = _sheared_term_counts(q, m0, depth, w, gy.device)
+        ch = lambda t: t.view(1, 1, c, 1, 1)                                       # noqa: E731  [N,3,C,H,*] layouts
+        combine = lambda t, cnt: (ch(a_) * t[0].view(n, 3, c, h, -1) + ch(b_) * t[1].view(n, 3, c, h, -1)          # noqa: E731
+                                  + ch(c_) * cnt.view(1, 3, 1, 1, -1)).view(n, 3 * c, h, -1)
+        d_g, d_gcol = combine(line, cnt_line), combine(lastc, cnt_col)
+        pc = lambda t: t.view(1, c, 1, 1, 1)                                       # noqa: E731  [N,C,3,H,W] layout
+        dplanes = pc(a_) * colsum[0] + pc(b_) * colsum[1] + pc(c_) * cnt_cls.view(1, 1, 3, 1, 1)
+        fac = conv.__dict__["_snvc_factored_train"]
+        g_left, g_right, gw = _sheared_backward_tail(fac, q, m0, depth, w, left3, right, d_g, d_gcol, dplanes.contiguous(),
+                                                     needs[0], needs[1], needs[2])
+        return g_left, g_right, gw, (dgamma if needs[3] else None), (dbeta if needs[4] else None), None, None, None, None, None, None
 
 
 def _is_frozen_norm(norm) -> bool:

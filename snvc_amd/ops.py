@@ -400,6 +400,48 @@ def sheared_expand(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int,
     return out
 
 
+def sheared_expand_stats(g, gcol, planes, gamma, beta, shape, q: int, m0: int, off: int, off_col: int, eps: float):
+    """Batch statistics of the sheared layer's raw result without storing it (snvc_sheared_expand_stats): returns
+    (scale, shift, mean, var), each [1, C], for ``y = relu(scale * raw + shift)``; ``shape`` = (N, C, D, H, W) of the result."""
+    _gpu(g, "g"); _gpu(gcol, "gcol"); _gpu(planes, "planes")
+    n, c, d, h, w = shape
+    for t in (g, gcol):
+        if t.dtype != torch.float32 or tuple(t.shape[:3]) != (n, 3 * c, h) or not t.is_contiguous():
+            raise RuntimeError("sheared_expand_stats needs contiguous float32 g / gcol [N,3C,H,*]")
+    if tuple(planes.shape) != (n, c, 3, h, w) or not planes.is_contiguous():
+        raise RuntimeError("planes must be a contiguous [N,C,3,H,W] tensor")
+    scale = torch.empty((1, c), dtype=torch.float32, device=g.device)
+    shift, mean, var = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
+    ws = torch.empty(_lib.lib().snvc_sheared_stats_workspace_bytes(n, c, h), dtype=torch.uint8, device=g.device)
+    with torch.cuda.device(g.device):
+        check(_lib.lib().snvc_sheared_expand_stats(_ptr(g), _ptr(gcol), _ptr(planes), _ptr(gamma), _ptr(beta), _ptr(scale), _ptr(shift),
+                                                   _ptr(mean), _ptr(var), _ptr(ws), n, c, d, h, w, int(q), int(m0), g.size(3), int(off),
+                                                   gcol.size(3), int(off_col), float(eps), _stream(g)), "snvc_sheared_expand_stats")
+    return scale, shift, mean, var
+
+
+def sheared_backward_reduce(g, gcol, planes, scale, shift, gy, q: int, m0: int, off: int, off_col: int):
+    """One pass over ``gy`` = dL/d relu(scale*raw + shift) of the sheared layer (snvc_sheared_backward_reduce): returns
+    (line [2,N,3C,H,WG], colsum [2,N,C,3,H,W], lastc [2,N,3C,H,WG2], sums [N,C,2] fp64) -- index 0: sums of the masked gradient,
+    1: of the recomputed raw result -- from which the caller forms dG, dG', the depth-class planes and the BatchNorm terms."""
+    _gpu(gy, "gy")
+    if gy.dtype != torch.float32 or gy.dim() != 5 or not gy.is_contiguous():
+        raise RuntimeError("sheared_backward_reduce needs a contiguous float32 [N,C,D,H,W] gradient")
+    n, c, d, h, w = gy.shape
+    wg, wg2 = g.size(3), gcol.size(3)
+    dev = gy.device
+    line = torch.empty((2, n, 3 * c, h, wg), dtype=torch.float32, device=dev)
+    colsum = torch.empty((2, n, c, 3, h, w), dtype=torch.float32, device=dev)
+    lastc = torch.empty((2, n, 3 * c, h, wg2), dtype=torch.float32, device=dev)
+    sums = torch.empty((n, c, 2), dtype=torch.float64, device=dev)
+    ws = torch.empty(_lib.lib().snvc_sheared_backward_workspace_bytes(n, c, h), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().snvc_sheared_backward_reduce(_ptr(g), _ptr(gcol), _ptr(planes), _ptr(scale), _ptr(shift), _ptr(gy), _ptr(line),
+                                                      _ptr(colsum), _ptr(lastc), _ptr(sums), _ptr(ws), n, c, d, h, w, int(q), int(m0), wg,
+                                                      int(off), wg2, int(off_col), _stream(gy)), "snvc_sheared_backward_reduce")
+    return line, colsum, lastc, sums
+
+
 def sheared_reduce(dy, q: int, m0: int, wg: int, off: int, wg_col: int, off_col: int):
     """Adjoint of ``sheared_expand`` (snvc_sheared_reduce): dy [N,C,D,H,W] -> (dg [N,3C,H,wg], dgcol [N,3C,H,wg_col]), the sums
     of dy along each shear line per depth class (class-major); every element is written, the sums are deterministic."""

@@ -1129,12 +1129,14 @@ def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
     check(got, general, 2e-5, f"sheared vs general path q={q} m0={m0}")
 
 
+@pytest.mark.parametrize("fused_bn", [True, False])
 @pytest.mark.parametrize("q,m0", [(2, 0), (2, 3), (1, 0), (1, 2)])
-def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0):
+def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0, fused_bn):
     """Training (cfg4) with uniformly spaced disparity planes: the first layer runs sheared in BOTH directions
     (_ShearedFirstConvFn: snvc_sheared_reduce / snvc_sheared_wgrad / the 3 x 7 dgrad / snvc_sheared_upsample_backward).
     Every parameter gradient and the feature gradients against the C oracle's cost volume + torch-CPU autograd, and
-    against the general factored function on the same inputs."""
+    against the general factored function on the same inputs.  ``fused_bn``: the train-mode BatchNorm + ReLU folded around the
+    layer (_ShearedFirstConvBNFn: snvc_sheared_expand_stats / snvc_sheared_backward_reduce, no raw result, no raw gradient)."""
     from oracle import native as O
     from oracle import torch_ref as T
     from snvc_amd.models import submodule as S
@@ -1164,9 +1166,13 @@ def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0):
     (gl_r, gr_r), gp_r = _grads(ref, [lr, rr], lambda: ref(CV.apply(lr, rr)).pow(2).mean())
     lo, ro = torch.from_numpy(L).to(dev()).requires_grad_(), torch.from_numpy(R).to(dev()).requires_grad_()
     sh = torch.from_numpy(s).to(dev())
-    before = S._ROUTES["sheared_first_conv_train"]
-    (gl_o, gr_o), gp_o = _grads(ours, [lo, ro], lambda: ours.forward_pair(lo, ro, sh, 1).pow(2).mean())
+    before, before_bn = S._ROUTES["sheared_first_conv_train"], S._ROUTES["sheared_first_conv_train_fused_bn"]
+    (gl_o, gr_o), gp_o = _grads(ours, [lo, ro], lambda: ours.forward_pair(lo, ro, sh, 1, fused_bn=fused_bn).pow(2).mean())
     assert S._ROUTES["sheared_first_conv_train"] == before + 1
+    assert S._ROUTES["sheared_first_conv_train_fused_bn"] == before_bn + (1 if fused_bn else 0)
+    for (k, a), (_, b) in zip(ours.state_dict().items(), ref.state_dict().items()):     # BatchNorm bookkeeping after ONE step
+        if "running" in k:
+            check(a.cpu().numpy(), b.numpy(), 1e-4, k)
     # the same step on the general factored function (the running statistics move a second time: gradients only)
     lg, rg = torch.from_numpy(L).to(dev()).requires_grad_(), torch.from_numpy(R).to(dev()).requires_grad_()
     (gl_g, gr_g), gp_g = _grads(ours, [lg, rg], lambda: ours.forward_pair(lg, rg, sh, 1, sheared=False).pow(2).mean())
@@ -1180,6 +1186,55 @@ def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0):
     for k in gp_r:
         check(gp_o[k].numpy(), gp_r[k].numpy(), 1e-3, f"d {k} (vs torch)")
         check(gp_o[k].numpy(), gp_g[k].numpy(), 1e-3, f"d {k} (vs general)")
+
+
+@pytest.mark.parametrize("q,m0", [(2, 0), (2, 5), (1, 1)])
+def test_sheared_fused_batchnorm_entry_points_vs_numpy(q, m0):
+    """snvc_sheared_expand_stats against the statistics of the expanded tensor, and snvc_sheared_backward_reduce against the
+    same sums formed in numpy from the expanded tensor and a random gy: per-channel fp64 sums, shear-line sums, last-column
+    slots and depth-class sums of both the masked gradient and raw.  Two samples, a ragged row block (H = 6), W = 24."""
+    from snvc_amd import ops
+    from snvc_amd.models.submodule import sheared_geometry
+    r = np.random.default_rng(211 + q + m0)
+    N, C, D, H, W = 2, 3, 10, 6, 24
+    off, wu, off_col, wu_col = sheared_geometry(q, m0, D, W)
+    g = torch.from_numpy(r.standard_normal((N, 3 * C, H, wu)).astype(np.float32)).to(dev())
+    gcol = torch.from_numpy(r.standard_normal((N, 3 * C, H, wu_col)).astype(np.float32)).to(dev())
+    planes = torch.from_numpy(r.standard_normal((N, C, 3, H, W)).astype(np.float32)).to(dev())
+    gamma = torch.from_numpy(r.uniform(0.5, 1.5, C).astype(np.float32)).to(dev())
+    beta = torch.from_numpy(r.standard_normal(C).astype(np.float32)).to(dev())
+    raw_t = torch.empty((N, C, D, H, W), device=dev())
+    ops.sheared_expand(g, gcol, planes, None, None, raw_t, q, m0, off, off_col, 0)
+    raw = raw_t.cpu().numpy().astype(np.float64)
+    scale, shift, mean, var = ops.sheared_expand_stats(g, gcol, planes, gamma, beta, (N, C, D, H, W), q, m0, off, off_col, 1e-5)
+    mu, vr = raw.mean((0, 2, 3, 4)), raw.var((0, 2, 3, 4))
+    np.testing.assert_allclose(mean.cpu().numpy()[0], mu, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(var.cpu().numpy()[0], vr, rtol=1e-6)
+    sc = gamma.cpu().numpy() / np.sqrt(vr + 1e-5)
+    np.testing.assert_allclose(scale.cpu().numpy()[0], sc, rtol=2e-6)
+    np.testing.assert_allclose(shift.cpu().numpy()[0], beta.cpu().numpy() - mu * sc, rtol=0, atol=2e-6)
+
+    gy = r.standard_normal((N, C, D, H, W)).astype(np.float32)
+    line, colsum, lastc, sums = ops.sheared_backward_reduce(g, gcol, planes, scale, shift, torch.from_numpy(gy).to(dev()), q, m0, off, off_col)
+    rawf = raw_t.cpu().numpy()
+    v = rawf * scale.cpu().numpy()[0][None, :, None, None, None] + shift.cpu().numpy()[0][None, :, None, None, None]
+    gm = np.where(v > 0, gy, 0).astype(np.float64)
+    exp_sums = np.stack([gm.sum((2, 3, 4)), (gm * raw).sum((2, 3, 4))], -1)
+    np.testing.assert_allclose(sums.cpu().numpy(), exp_sums, rtol=1e-9, atol=1e-9)
+    cls_of = lambda d: 0 if d == 0 else (2 if d == D - 1 else 1)          # noqa: E731
+    e_line, e_last, e_col = np.zeros((2, N, 3, C, H, wu)), np.zeros((2, N, 3, C, H, wu_col)), np.zeros((2, N, C, 3, H, W))
+    for qi, src in enumerate((gm, raw)):
+        for d in range(D):
+            cls = cls_of(d)
+            e_col[qi, :, :, cls] += src[:, :, d]
+            for w in range(W - 1):
+                i = q * w - d - m0 + off
+                if 0 <= i < wu:
+                    e_line[qi, :, cls, :, :, i] += src[:, :, d, :, w]
+            e_last[qi, :, cls, :, :, q * (W - 1) - d - m0 + off_col] += src[:, :, d, :, W - 1]
+    check(line.cpu().numpy().reshape(e_line.shape), e_line.astype(np.float32), 1e-5, "line sums")
+    check(lastc.cpu().numpy().reshape(e_last.shape), e_last.astype(np.float32), 0, "last-column slots")
+    check(colsum.cpu().numpy(), e_col.astype(np.float32), 1e-5, "depth-class sums")
 
 
 @pytest.mark.parametrize("q,m0", [(2, 0), (2, 5), (1, 1)])
