@@ -212,12 +212,51 @@ def _dgrad_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
     return plan.dgrad
 
 
+class _GradBox:
+    """Where a skip connection's gradient waits for the layer whose data gradient it is added to (see _SkipTap)."""
+    __slots__ = ("grad", "consumed")
+
+    def __init__(self):
+        self.grad, self.consumed = None, False
+
+
+class _SkipTap(torch.autograd.Function):
+    """``x`` used twice -- by a convolution and, further down, as a skip connection -- makes autograd add two gradients of x's
+    size (0.38 ms for the 736 MB tensor of cfg4).  The skip branch goes through this identity instead: its gradient is parked in
+    ``box`` and the convolution's own backward adds it in the epilogue of its data-gradient kernel (_ConvNormActFn, ``grad_box``).
+    The skip's consumer lies downstream of that convolution, so its backward always runs first; if it ever did not, the
+    tap raises instead of losing a gradient."""
+
+    @staticmethod
+    def forward(ctx, x, box):
+        ctx.box = box
+        return x.view_as(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if ctx.box.consumed:
+            raise RuntimeError("_SkipTap: the convolution's backward ran before the skip connection's")
+        ctx.box.grad = g if ctx.box.grad is None else ctx.box.grad + g
+        return None, None
+
+
+def skip_box(x: torch.Tensor) -> Optional[_GradBox]:
+    """A box for the gradient of x's skip-connection use, or None outside HIP training.  Order of use: make the box, run the
+    convolution with ``grad_box=box``, THEN route the skip through ``_SkipTap.apply(x, box)``: autograd runs ready nodes
+    newest first, so the tap (made after the convolution's node) hands its gradient over before the convolution's backward."""
+    if torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype == torch.float32:
+        return _GradBox()
+    return None
+
+
 class _ConvNormActFn(torch.autograd.Function):
     """Differentiable fused layer: forward = conv (+norm) (+residual) (+activation) on the HIP
     kernels, backward = HIP epilogue-backward reductions, dgrad (forward kernels) and wgrad."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, conv, norm, flags, plan):
+    def forward(ctx, x, weight, gamma, beta, residual, conv, norm, flags, plan, grad_box=None):
+        ctx.grad_box = grad_box
         layer = _get_layer(conv, plan)
         if layer.stride == 2 and not layer.transposed and any(int(s) % 2 for s in x.shape[2:]):
             # the data gradient of Conv3d(k3,s2,p1) runs on the ConvTranspose3d(k3,s2,p1,op1) kernel, whose
@@ -246,14 +285,23 @@ class _ConvNormActFn(torch.autograd.Function):
         # data and weight gradients
         k, st, p, d, transposed = _conv_geometry(conv)
         dl = _dgrad_layer(conv, plan)
-        gx = dl(draw, exact=dl.ksize >= 5) if needs[0] else None
+        extra = None
+        if ctx.grad_box is not None:        # the gradient of x's other use (a skip connection): added by the dgrad kernel's epilogue
+            extra, ctx.grad_box.grad, ctx.grad_box.consumed = ctx.grad_box.grad, None, True
+            if extra is not None and not needs[0]:
+                raise RuntimeError("a skip connection's gradient was parked for a layer whose input needs no gradient")
+            if extra is not None:
+                extra = extra.contiguous()
+        gx = None
+        if needs[0]:
+            gx = dl(draw, None, None, extra, EPI_ADD_POST if extra is not None else 0, None, exact=dl.ksize >= 5)
         gw = None
         if needs[1]:
             if transposed:   # roles swapped, see snvc_conv3d_wgrad
                 gw = ops.conv3d_wgrad(draw, x, 3, 2, 1, 1)
             else:
                 gw = ops.conv3d_wgrad(x, draw, k, st, p, d)
-        return gx, gw, dg, db, gres, None, None, None, None
+        return gx, gw, dg, db, gres, None, None, None, None, None
 
 
 def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_sample, train_stats, want_res, want_gamma, want_beta):
@@ -668,7 +716,8 @@ def _folded_head_layer(conv: nn.Module, norm: Optional[nn.Module], head: nn.Modu
 def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,
                  residual: Optional[torch.Tensor] = None, residual_after_act=False, out=None,
                  plan: Optional[_Plan] = None, head: Optional[nn.Module] = None,
-                 head_residual: Optional[torch.Tensor] = None, side_head: Optional[nn.Module] = None):
+                 head_residual: Optional[torch.Tensor] = None, side_head: Optional[nn.Module] = None,
+                 grad_box: Optional[_GradBox] = None):
     """act(norm(conv(x)) [+ residual]) [+ residual] on the HIP kernels.
 
     ``residual_after_act=False``: relu(norm(conv(x)) + residual)   (hourglass skips, submodule.py:154,162)
@@ -697,10 +746,12 @@ def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *,
         beta = norm.bias if norm is not None else None
         if out is not None:
             raise NotImplementedError("`out=` (in-place concat slices) is an inference-only fusion")
-        y = _ConvNormActFn.apply(x, conv.weight, gamma, beta, residual, conv, norm, flags, plan)
+        y = _ConvNormActFn.apply(x, conv.weight, gamma, beta, residual, conv, norm, flags, plan, grad_box)
         if side_head is not None:
             return y, side_head(y)
         return head(y) if head is not None else y
+    if grad_box is not None:
+        raise RuntimeError("grad_box was given to a layer that runs outside autograd: the skip connection's gradient would be lost")
     layer = _get_layer(conv, plan)
     if side_head is not None:
         if head is not None:
@@ -862,10 +913,18 @@ class hourglass(nn.Module):
         ``head`` (extension): a 1x1x1 one-channel convolution applied to ``out`` (see fused_conv3d: conv6 has no
         activation, so at inference conv6 + head fold into one transposed layer to one channel); ``out`` is then
         ``head(out)``.  ``head_residual`` = ``head(residual)`` when the caller already has it."""
-        o = self.conv1(x)                                                   # 1/2 res, ReLU fused
+        # training: the two skip connections (x -> conv6's residual when the caller folds it, pre -> conv5's residual) hand their
+        # gradients to conv1's / conv3's data-gradient kernels instead of to an autograd add (_SkipTap)
+        box_x = skip_box(x) if residual is x else None
+        o = self.conv1.fused(x, grad_box=box_x)                             # 1/2 res, ReLU fused
+        if box_x is not None:
+            residual = _SkipTap.apply(x, box_x)
         pre = self.conv2.fused(o, relu=True, residual=postsqu)              # relu(bn(conv) [+ postsqu]) :153-156
-        o = self.conv4(self.conv3(pre))                                     # 1/4 res
-        post = self.conv5.fused(o, relu=True, residual=presqu if presqu is not None else pre)  # :161-164
+        box_pre = skip_box(pre) if presqu is None else None
+        o = self.conv3.fused(pre, grad_box=box_pre)
+        pre_skip = _SkipTap.apply(pre, box_pre) if box_pre is not None else pre
+        o = self.conv4(o)                                                   # 1/4 res
+        post = self.conv5.fused(o, relu=True, residual=presqu if presqu is not None else pre_skip)  # :161-164
         o = self.conv6.fused(post, residual=residual, out=out, head=head, head_residual=head_residual)   # :166
         return o, pre, post
 
