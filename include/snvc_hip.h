@@ -291,6 +291,15 @@ SNVC_API int snvc_conv3d_forward_side_head(const snvc_conv3d_desc *desc_host, co
                                            const float *packed_weight, const float *scale, const float *bias,
                                            const float *residual, float *y, const float *head_weight,
                                            float *y_head, void *stream);
+/* Convolution + the batch statistics of its own result in one launch (train-mode BatchNorm, cfg4): the 3x3x3 Winograd
+ * kernels (stride 1 and 2, their default forms) leave per-workgroup fp64 (sum, sum of squares) of the raw result beside y, a
+ * fold adds them in a fixed order and scale / shift [Cout] (for y' = scale*y + shift; gamma / beta may be NULL) and mean / var
+ * [Cout] (may be NULL) come back as from snvc_norm_stats -- which would read the tensor once more.  desc.flags must be 0.
+ * SNVC_ERR_UNSUPPORTED (nothing launched) when the layer does not take one of those kernel forms. */
+SNVC_API int64_t snvc_conv3d_stats_workspace_bytes(const snvc_conv3d_desc *desc_host);
+SNVC_API int snvc_conv3d_forward_stats(const snvc_conv3d_desc *desc_host, const float *x, const float *packed_weight, float *y,
+                                       const float *gamma, const float *beta, float *scale, float *shift, float *mean,
+                                       float *var, void *workspace, float eps, void *stream);
 /* ------------------------------------------------------------------------------------
  * Sheared first convolution: the 3x3x3 convolution over the WARPED half of build_cost_volume's result when the
  * disparity planes are uniformly spaced, shift[n][d] = (m0 + d) / q with q in {1, 2} (whole- / half-pixel steps; the

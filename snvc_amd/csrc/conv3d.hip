@@ -41,6 +41,7 @@
 //   pointwise_small_kernel, conv3d_k3_cout1_kernel   VALU kernels for layers with 1-2 output channels
 #include "common.hpp"
 #include "conv3d_internal.hpp"
+#include "elementwise_internal.hpp"
 #include "wino_tables.hpp"
 
 namespace snvc {
@@ -66,6 +67,7 @@ struct ConvArgs {
     const float *head_w; // fused 1x1x1 head (snvc_conv3d_forward_head): [Cout] weights, or nullptr
     float *y_head;       //   its [N,1,Dout,Hout,Wout] output; `y` is then not written
     int fast_epi;        // the launch qualifies for the fast epilogues (see the toolkit comment)
+    double *stats;       // XMODE 3: per job [32 channels][sum, sum of squares] of the raw result (train-mode BatchNorm), or nullptr
     int njobs, groups;   // Winograd kernel: jobs = tiles x channel groups x samples
     int vec;  // 1: 16-byte aligned rows (Win % 4 == 0, aligned base and strides) -> float4 staging
     int64_t x_bs, y_bs, r_bs;
@@ -722,6 +724,7 @@ __device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img
 // A job = one output tile of one 32-channel group of one sample; one workgroup per job.
 struct WinoJob {
     int od0, oh0, ow0, cg;
+    int id;              // (n * tiles + tile) * groups + cg: the job's slot in per-job outputs (ConvArgs::stats)
     int64_t n;
 };
 
@@ -738,6 +741,7 @@ __device__ __forceinline__ WinoJob wino_decode_job(const ConvArgs &a, int v, int
     o.oh0 = ((t / a.tiles_w) % a.tiles_h) * TH;
     o.od0 = (t / (a.tiles_w * a.tiles_h)) * TD;
     o.cg = cg;
+    o.id = j;
     o.n = rest / ntiles;
     return o;
 }
@@ -1087,6 +1091,37 @@ __device__ __forceinline__ void wino_epilogue(const ConvArgs &a, const WinoJob &
                              "+v"(acc[3][nb][r0 + q])::"memory");
         }
     }
+    if constexpr (XMODE == 3) {
+        // Batch statistics of the layer's result, taken while it is still in registers (train-mode BatchNorm reads the
+        // tensor once less): every lane's fp32 (sum, sum of squares) of its <= 4*NB in-range values per channel go through
+        // the idle LDS buffers, 64 threads add them in fp64 in a fixed order -> stats[job][channel][2].
+        float *const P = xch;                       // [16 registers x 2][256 threads]
+        const int tid = wave * 64 + lane;
+        __syncthreads();                            // every wave is done with the image / weight buffers
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float su = 0.0f, sq = 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float v0 = ok0[nb] ? acc[0][nb][r] : 0.0f, v1 = ok0[nb] ? acc[1][nb][r] : 0.0f;
+                const float v2 = ok1[nb] ? acc[2][nb][r] : 0.0f, v3 = ok1[nb] ? acc[3][nb][r] : 0.0f;
+                su += (v0 + v1) + (v2 + v3);
+                sq += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            }
+            P[(2 * r) * 256 + tid] = su;
+            P[(2 * r + 1) * 256 + tid] = sq;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int ch = tid >> 1, q = tid & 1;                       // channel (r & 3) + 8 * (r >> 2) + 4 * half
+            const int r = (ch & 3) + 4 * (ch >> 3), hf = (ch >> 2) & 1;
+            const float *src = P + (2 * r + q) * 256 + hf * 32;
+            double t = 0.0;
+            for (int w = 0; w < 4; ++w)
+                for (int l = 0; l < 32; ++l) t += (double)src[w * 64 + ((l + tid) & 31)];   // skewed: no bank conflicts
+            a.stats[(int64_t)job.id * 64 + tid] = t;
+        }
+    }
     if constexpr (HEAD) {
         static_assert(V4, "the side head stores 16-byte pieces");
         float hw[16];     // parked in LDS behind scale | bias at kernel start (a global load here is an exposed round trip)
@@ -1311,6 +1346,7 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
         __syncthreads();
     }
     static_assert(XMODE != 2 || 48 * 64 * 16 <= Cfg::LDS_BYTES, "the pooled epilogue trades 48 KB through the image / weight buffers");
+    static_assert(XMODE != 3 || 32 * 256 * 4 <= Cfg::LDS_BYTES, "the statistics epilogue trades 32 KB through the image / weight buffers");
     wino_epilogue<Cfg, RES, PLANE, XMODE>(a, job, acc, aff, lane, wave, lds);
 }
 
@@ -1442,7 +1478,7 @@ __device__ __forceinline__ void wait_vmcnt_then_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <class Cfg, bool RES>
+template <class Cfg, bool RES, int XMODE = 0>
 __global__ void __launch_bounds__(256, 2)
 conv3d_winos2_pipe_kernel(const ConvArgs a) {
     constexpr int KC = Cfg::KC, WF = Cfg::WF, IN_WV = Cfg::IN_WV, RQ = IN_WV / 4, IN_D = Cfg::IN_D;
@@ -1550,7 +1586,8 @@ conv3d_winos2_pipe_kernel(const ConvArgs a) {
         // A(chunk+1) reads slices {0,2,4,6} and the next weights: all but slice 8
         if (more) wait_vmcnt_then_barrier<AFTER_EVEN>();
     }
-    wino_epilogue<Cfg, RES, false>(a, job, acc, aff, lane, wave);
+    static_assert(XMODE != 3 || 32 * 256 * 4 <= Cfg::LDS_BYTES, "the statistics epilogue trades 32 KB through the image buffer");
+    wino_epilogue<Cfg, RES, false, XMODE>(a, job, acc, aff, lane, wave, lds);
 }
 
 // ------------------------------------------------------------------------------------ deconv
@@ -2285,6 +2322,14 @@ void launch_winok(const ConvArgs &a, dim3 grid, hipStream_t st) {
     else launch_winok_variant<Cfg, false>(a, grid, st);
 }
 
+template <class Cfg>
+void launch_winos2_pipe_stats(const ConvArgs &a, dim3 grid, hipStream_t st) {
+    constexpr int BYTES = Cfg::LDS_BYTES + 256;
+    static std::atomic<unsigned> attr_done{0};
+    if (!allow_large_lds(reinterpret_cast<const void *>(&conv3d_winos2_pipe_kernel<Cfg, false, 3>), BYTES, attr_done)) return;
+    conv3d_winos2_pipe_kernel<Cfg, false, 3><<<grid, 256, BYTES, st>>>(a);
+}
+
 template <class Cfg, bool RES, bool PLANE>
 void launch_wino_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
     constexpr int BYTES = Cfg::LDS_BYTES + 256;   // + (scale | bias) of 32 channels
@@ -2346,7 +2391,36 @@ void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
 namespace snvc {
 int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *packed_weight, const float *scale,
                         const float *bias, const float *residual, const float *depth_planes, float *y,
-                        const float *head_w, float *y_head, void *stream);
+                        const float *head_w, float *y_head, void *stream, double *stats = nullptr);
+
+namespace {
+// stats[((n * tiles + t) * groups + cg)][32][2] -> partial[(n * C + c)][2]: one workgroup per (n, c), fixed-order tree
+__global__ void __launch_bounds__(256)
+conv_stats_fold_kernel(const double *__restrict__ stats, double *__restrict__ partial, int C, int groups, int tiles) {
+    const int c = blockIdx.x, cg = c >> 5, ch = c & 31;
+    const int64_t n = blockIdx.y;
+    double s0 = 0.0, s1 = 0.0;
+    for (int t = threadIdx.x; t < tiles; t += 256) {
+        const double *p = stats + (((n * tiles + t) * groups + cg) * 32 + ch) * 2;
+        s0 += p[0];
+        s1 += p[1];
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s0;
+    sh[1][threadIdx.x] = s1;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) { sh[0][threadIdx.x] += sh[0][threadIdx.x + w]; sh[1][threadIdx.x] += sh[1][threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[(n * C + c) * 2] = sh[0][0];
+        partial[(n * C + c) * 2 + 1] = sh[1][0];
+    }
+}
+// the Winograd tiling of the layers the statistics epilogue is built for (the dispatcher's default forms)
+inline int64_t stats_tiles(const snvc_conv3d_desc &d) { return (int64_t)ceil_div(d.Dout, 4) * ceil_div(d.Hout, 4) * ceil_div(d.Wout, 32); }
+}  // namespace
 }
 
 extern "C" {
@@ -2448,13 +2522,44 @@ int snvc_conv3d_forward_side_head(const snvc_conv3d_desc *d, const float *x, con
     return conv3d_forward_impl(d, x, packed_weight, scale, bias, residual, nullptr, y, head_weight, y_head, stream);
 }
 
+int64_t snvc_conv3d_stats_workspace_bytes(const snvc_conv3d_desc *d) {
+    using namespace snvc;
+    if (!d || d->N < 0 || d->Cout <= 0 || d->Dout <= 0 || d->Hout <= 0 || d->Wout <= 0) return -1;
+    const int64_t groups = ceil_div(d->Cout, 32);
+    return (d->N * stats_tiles(*d) * groups * 64 + d->N * (int64_t)d->Cout * 2) * (int64_t)sizeof(double);
+}
+
+int snvc_conv3d_forward_stats(const snvc_conv3d_desc *d, const float *x, const float *packed_weight, float *y, const float *gamma,
+                              const float *beta, float *scale, float *shift, float *mean, float *var, void *workspace, float eps,
+                              void *stream) {
+    using namespace snvc;
+    if (!d || !y || !scale || !shift || !workspace) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward_stats: null pointer");
+    if (d->N <= 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward_stats: empty batch");
+    if (d->flags || d->transposed || d->ksize_d == 1 || d->ksize != 3 || d->dilation != 1 || (d->stride != 1 && d->stride != 2) ||
+        d->Cout % 32 != 0)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_stats: built for 3x3x3 Conv3d layers (stride 1 or 2) with whole "
+                                          "32-channel groups and no epilogue");
+    double *stats = static_cast<double *>(workspace);
+    int rc = conv3d_forward_impl(d, x, packed_weight, nullptr, nullptr, nullptr, nullptr, y, nullptr, nullptr, stream, stats);
+    if (rc) return rc;
+    const int groups = d->Cout / 32;
+    const int64_t tiles = stats_tiles(*d);
+    double *partial = stats + d->N * tiles * groups * 64;
+    conv_stats_fold_kernel<<<dim3((unsigned)d->Cout, (unsigned)d->N), 256, 0, as_stream(stream)>>>(stats, partial, d->Cout, groups, (int)tiles);
+    rc = check_launch("snvc_conv3d_forward_stats(fold)");
+    if (rc) return rc;
+    launch_norm_finalize(partial, gamma, beta, scale, shift, mean, var, d->N, d->Cout, (int64_t)d->Dout * d->Hout * d->Wout, 1, eps,
+                         as_stream(stream));
+    return check_launch("snvc_conv3d_forward_stats(finalize)");
+}
+
 }  // extern "C"
 
 namespace snvc {
 
 int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *packed_weight, const float *scale,
                         const float *bias, const float *residual, const float *depth_planes, float *y,
-                        const float *head_w, float *y_head, void *stream) {
+                        const float *head_w, float *y_head, void *stream, double *stats) {
     Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward: null desc");
     int rc = make_plan(*d, p);
@@ -2480,6 +2585,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     a.res = (d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) ? residual : nullptr;
     a.plane = depth_planes;
     a.head_w = head_w; a.y_head = y_head;
+    a.stats = stats;
     const bool side_head = head_w && y;   // snvc_conv3d_forward_side_head: y AND its one-channel projection
     const bool pooled = (d->flags & SNVC_EPI_AVGPOOL_D4) != 0;   // y is [N,Cout,Dout/4,Hout,Wout]
     if (pooled && (side_head || head_w || d->transposed || d->ksize_d == 1 || d->ksize != 3 || d->stride != 1 || d->dilation != 1 ||
@@ -2561,6 +2667,12 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
                 a.njobs = (int)nj;
                 // default: the slice-pipelined refill; SNVC_ALGO_WINO_TILE_STD selects the per-chunk refill form
                 const bool per_chunk = (d->algo & SNVC_ALGO_WINO_TILE_MASK) == SNVC_ALGO_WINO_TILE_STD;
+                if (stats) {        // the default form with 16-byte output rows carries the statistics epilogue
+                    if (per_chunk || !a.fast_epi || a.res)
+                        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_stats: this stride-2 layer does not take the default kernel form");
+                    launch_winos2_pipe_stats<WinoS2PipeCfg<4>>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+                    return check_launch("snvc_conv3d_forward_stats(winograd stride 2)");
+                }
                 if (per_chunk && a.fast_epi) launch_winok<CfgWinoS2>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 else if (per_chunk) launch_winok<CfgWinoS2v8>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 else if (a.fast_epi) launch_winos2_pipe<WinoS2PipeCfg<4>>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
@@ -2623,6 +2735,12 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
                     launch_wino_dma_variant<CfgWinoN3, false, false, 1>(a, g, as_stream(stream));
                     return check_launch("snvc_conv3d_forward_side_head");
                 }
+                if (stats) {       // the default kernel form without addends carries the statistics epilogue
+                    if (!(narrow && wide && !nreg) || a.res || a.plane)
+                        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_stats: this layer does not take the default Winograd form");
+                    launch_wino_dma_variant<CfgWinoN3, false, false, 3>(a, g, as_stream(stream));
+                    return check_launch("snvc_conv3d_forward_stats(winograd)");
+                }
                 if (pooled) {      // built for the default kernel form without addends (the local trunk's conv4)
                     if (!(narrow && wide && !nreg) || a.res || a.plane)
                         return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: SNVC_EPI_AVGPOOL_D4 needs the default Winograd "
@@ -2640,6 +2758,8 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
             }
         }
     }
+    if (stats)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_stats: the layer's rows do not allow the Winograd forms that carry the statistics epilogue");
     if (side_head)
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_side_head: built for 3x3x3 / stride-1 layers on the Winograd path");
     if (pooled)

@@ -171,6 +171,16 @@ def _norm_forward(layer, norm, plan, x, residual, flags, out, keep_raw, exact=Fa
             return ops.affine_act(raw, scale, bias, residual, flags, out=out), raw, scale, bias, None, None, False
         return layer(x, scale, bias, residual, flags, out, exact=exact), None, scale, bias, None, None, False
     # statistics of the conv output are needed first: conv -> stats -> normalise (+res, +act)
+    if isinstance(norm, nn.BatchNorm3d) and not exact:
+        # the 3x3x3 Winograd kernels take the batch statistics in their own epilogue (one read of the tensor less)
+        got = layer.forward_stats(x, norm.weight.detach() if norm.weight is not None else None,
+                                  norm.bias.detach() if norm.bias is not None else None, norm.eps)
+        if got is not None:
+            raw, scale, shift, mean, var = got
+            _ROUTES["conv_stats_epilogue"] += 1
+            _bn_track(norm, mean, var, raw.numel() / raw.size(1))
+            dst = out if out is not None else (None if keep_raw else raw)
+            return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst), raw, scale, shift, mean, var, False
     raw = layer(x, None, None, None, 0, None, exact=exact)
     c = raw.size(1)
     dst = out if out is not None else (None if keep_raw else raw)

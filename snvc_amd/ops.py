@@ -365,6 +365,37 @@ class Conv3dLayer:
                   "snvc_conv3d_forward")
         return (out, None) if side_head is not None else out
 
+    def forward_stats(self, x, gamma, beta, eps: float):
+        """raw = conv(x) together with the batch statistics of raw, taken in the convolution's own epilogue
+        (snvc_conv3d_forward_stats): returns (raw, scale, shift, mean, var) with the [1, C] shapes of ``norm_stats``, or None
+        when the layer does not take a kernel form that carries the statistics epilogue (nothing was launched)."""
+        _gpu(x, "x")
+        if (self.planar or self.transposed or self.ksize != 3 or self.dilation != 1 or self.stride not in (1, 2) or self.cout % 32
+                or x.dtype != torch.float32 or x.dim() != 5 or x.size(1) != self.cin or x.size(0) == 0 or _algo() != 0):
+            return None
+        if not _dense_inner(x):
+            x = x.contiguous()
+        n, in_sp = x.size(0), tuple(x.shape[2:])
+        out_shape = (n, self.cout) + self.out_spatial(in_sp)
+        if min(out_shape[2:]) < 1:
+            return None
+        out = torch.empty(out_shape, dtype=torch.float32, device=x.device)
+        d = self._desc(n, in_sp, 0, _batch_stride(x), _batch_stride(out), 0)
+        d.algo = _algo()
+        nbytes = _lib.lib().snvc_conv3d_stats_workspace_bytes(ctypes.byref(d))
+        if nbytes < 0:
+            return None
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        scale = torch.empty((1, self.cout), dtype=torch.float32, device=x.device)
+        shift, mean, var = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().snvc_conv3d_forward_stats(ctypes.byref(d), _ptr(x), _ptr(self.packed), _ptr(out), _ptr(gamma), _ptr(beta),
+                                                      _ptr(scale), _ptr(shift), _ptr(mean), _ptr(var), _ptr(ws), float(eps), _stream(x))
+        if rc == 2:            # SNVC_ERR_UNSUPPORTED: the caller runs the convolution and the statistics pass separately
+            return None
+        check(rc, "snvc_conv3d_forward_stats")
+        return out, scale, shift, mean, var
+
 
 def sheared_upsample(right, q: int, wu: int, off: int):
     """Rq on a padded grid (snvc_sheared_upsample): right [N,C,H,W] -> [N,C,H,wu], element i = Rq[i - off]."""

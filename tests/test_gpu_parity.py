@@ -1129,6 +1129,33 @@ def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
     check(got, general, 2e-5, f"sheared vs general path q={q} m0={m0}")
 
 
+@pytest.mark.parametrize("case", ["k3s1_32", "k3s1_64_ragged", "k3s2_32_64", "k3s2_ragged", "unsupported_w78"])
+def test_conv_statistics_epilogue_vs_separate_pass(case):
+    """snvc_conv3d_forward_stats: the convolution result is bit-identical to the plain launch and the batch statistics taken in
+    its epilogue equal snvc_norm_stats' over that tensor (fp64 sums in a different order: 1e-6), for tile-ragged extents, two
+    samples and two channel groups; a layer whose rows do not allow the carrying kernel forms reports that it did nothing."""
+    from snvc_amd import ops
+    cin, cout, stride, shape = {"k3s1_32": (32, 32, 1, (8, 8, 64)), "k3s1_64_ragged": (6, 64, 1, (5, 7, 72)),
+                                "k3s2_32_64": (32, 64, 2, (8, 16, 128)), "k3s2_ragged": (4, 32, 2, (10, 14, 72)),
+                                "unsupported_w78": (8, 32, 1, (4, 4, 78))}[case]
+    r = np.random.default_rng(231)
+    w = torch.from_numpy((0.1 * r.standard_normal((cout, cin, 3, 3, 3))).astype(np.float32)).to(dev())
+    x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32)).to(dev())
+    gamma = torch.from_numpy(r.uniform(0.5, 1.5, cout).astype(np.float32)).to(dev())
+    beta = torch.from_numpy(r.standard_normal(cout).astype(np.float32)).to(dev())
+    layer = ops.Conv3dLayer(w, 3, stride, 1, 1, False)
+    got = layer.forward_stats(x, gamma, beta, 1e-5)
+    if case.startswith("unsupported"):
+        assert got is None
+        return
+    raw, scale, shift, mean, var = got
+    ref = layer(x)
+    assert torch.equal(raw, ref)
+    s2, h2, m2, v2 = ops.norm_stats(ref, gamma, beta, cout, False, 1e-5)
+    for a_, b_, what in ((scale, s2, "scale"), (shift, h2, "shift"), (mean, m2, "mean"), (var, v2, "var")):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=2e-6, atol=2e-7, err_msg=what)
+
+
 @pytest.mark.parametrize("fused_bn", [True, False])
 @pytest.mark.parametrize("q,m0", [(2, 0), (2, 3), (1, 0), (1, 2)])
 def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0, fused_bn):
@@ -1167,7 +1194,9 @@ def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0, fused_bn):
     lo, ro = torch.from_numpy(L).to(dev()).requires_grad_(), torch.from_numpy(R).to(dev()).requires_grad_()
     sh = torch.from_numpy(s).to(dev())
     before, before_bn = S._ROUTES["sheared_first_conv_train"], S._ROUTES["sheared_first_conv_train_fused_bn"]
+    before_stats = S._ROUTES["conv_stats_epilogue"]
     (gl_o, gr_o), gp_o = _grads(ours, [lo, ro], lambda: ours.forward_pair(lo, ro, sh, 1, fused_bn=fused_bn).pow(2).mean())
+    assert S._ROUTES["conv_stats_epilogue"] >= before_stats + 3      # conv2 and the hourglass's 16-byte-row layers
     assert S._ROUTES["sheared_first_conv_train"] == before + 1
     assert S._ROUTES["sheared_first_conv_train_fused_bn"] == before_bn + (1 if fused_bn else 0)
     for (k, a), (_, b) in zip(ours.state_dict().items(), ref.state_dict().items()):     # BatchNorm bookkeeping after ONE step
