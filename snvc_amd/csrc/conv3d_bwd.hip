@@ -847,13 +847,36 @@ constexpr int kWgradPartitions = 512;   // 2 workgroups per CU
 
 extern "C" {
 
+// Spatial partitions and units per XCD of the two 12-wave forms: one workgroup per CU and (pair, partition, kd) unit, one round
+static void wgrad_units(int pairs, int cap, int &P, int &upx) {
+    upx = snvc::device_cu_count() / 8 / 3;
+    if (upx < 1) upx = 1;
+    P = 8 * upx / pairs;
+    if (P < 1) P = 1;           // more pairs than units: the units take several rounds
+    if (P > cap) P = cap;
+    if (P * pairs > 8 * upx) upx = snvc::ceil_div(P * pairs, 8);
+}
+
+// Partial slabs [partitions][pairs][taps][32][32] of the form the layer takes; which of a key's forms runs depends on the
+// operands' alignment, known only at launch, so the size is the largest of the key's candidates -- each with the partition
+// count its launch really uses (r1-r2 reserved 512 partitions for every form: 6x too much for the 12-wave forms).
 int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *d) {
     using namespace snvc;
-    if (!d) return -1;
-    int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
-    if (d->ksize == 3 && d->stride == 1 && d->dilation == 1) taps = 54;      // the Winograd-domain form: 9 (kd, kh) x 6 positions
+    if (!d || d->Cin <= 0 || d->Cout <= 0) return -1;
+    const int64_t taps = (int64_t)d->ksize * d->ksize * d->ksize;
     const int64_t pairs = (int64_t)ceil_div(d->Cout, 32) * ceil_div(d->Cin, 32);
-    return (int64_t)kWgradPartitions * pairs * taps * 1024 * (int64_t)sizeof(float);
+    int64_t slabs = (int64_t)kWgradPartitions * taps;                        // tap-split / K-split forms
+    if (pairs <= 65535) {
+        int P, upx;
+        if (d->ksize == 3 && d->stride == 1 && d->dilation == 1) {            // Winograd-domain form: 2P row-half slabs x 54
+            wgrad_units((int)pairs, kWgradPartitions / 2, P, upx);
+            if ((int64_t)2 * P * 54 > slabs) slabs = (int64_t)2 * P * 54;
+        } else if (d->ksize == 3 && d->stride == 2 && d->dilation == 1) {     // stride-2 form: 4P slabs x 27
+            wgrad_units((int)pairs, kWgradPartitions / 4, P, upx);
+            if ((int64_t)4 * P * 27 > slabs) slabs = (int64_t)4 * P * 27;
+        }
+    }
+    return slabs * pairs * 1024 * (int64_t)sizeof(float);
 }
 
 // desc describes the FORWARD Conv3d (x = its input on the big grid, g = gradient of its output on
@@ -922,13 +945,8 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
         a.tiles_h = ceil_div(d->Hout, WinoWgradCfg::TH);
         a.ntiles = (int64_t)d->N * d->Dout * a.tiles_h * a.tiles_w;
         // one 12-wave workgroup per CU, one round: upx (pair, partition) units x 3 depth slices on each of the 8 XCDs
-        a.upx = device_cu_count() / 8 / 3;
-        if (a.upx < 1) a.upx = 1;
-        a.P = 8 * a.upx / pairs;
-        if (a.P < 1) a.P = 1;       // more pairs than units: the units take several rounds
-        if (a.P > kWgradPartitions / 2) a.P = kWgradPartitions / 2;
+        wgrad_units(pairs, kWgradPartitions / 2, a.P, a.upx);
         a.pairs = pairs;
-        if (a.P * pairs > 8 * a.upx) a.upx = ceil_div(a.P * pairs, 8);
         const unsigned nwg = (unsigned)(8 * a.upx * 3);
         static std::atomic<unsigned> attr_done{0};
         constexpr int bytes = WinoWgradCfg::LDS_FLOATS * 4;
@@ -947,13 +965,8 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
         // 12-wave form (see conv3d_wgrad_s2_kernel); SNVC_ALGO_DIRECT keeps the tap-split kernel below
         a.tiles_h = ceil_div(d->Hout, S2WgradCfg::TH);
         a.ntiles = s2_tiles;
-        a.upx = device_cu_count() / 8 / 3;
-        if (a.upx < 1) a.upx = 1;
-        a.P = 8 * a.upx / pairs;
-        if (a.P < 1) a.P = 1;
-        if (a.P > kWgradPartitions / 4) a.P = kWgradPartitions / 4;
+        wgrad_units(pairs, kWgradPartitions / 4, a.P, a.upx);
         a.pairs = pairs;
-        if (a.P * pairs > 8 * a.upx) a.upx = ceil_div(a.P * pairs, 8);
         const unsigned nwg = (unsigned)(8 * a.upx * 3);
         constexpr int bytes = S2WgradCfg::LDS_FLOATS * 4;
         static std::atomic<unsigned> attr4{0}, attr2{0};

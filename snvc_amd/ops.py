@@ -574,6 +574,27 @@ def conv3d_forward_head(layer: "Conv3dLayer", x, scale, bias, residual, flags, h
     return out
 
 
+_WORKSPACES = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    """Scratch for the kernels that reduce per-workgroup partials (weight gradients): one buffer per (device, stream), grown
+    when a layer needs more -- the launches that use it are ordered on that stream, so layers can share it and a training
+    step allocates nothing here after its first pass."""
+    if nbytes < 0:
+        raise RuntimeError("workspace size query failed")
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WORKSPACES[key] = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=device)
+    return ws
+
+
+def release_workspaces() -> None:
+    """Drop the cached scratch buffers (e.g. before handing the device's memory to something else)."""
+    _WORKSPACES.clear()
+
+
 def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: int) -> torch.Tensor:
     """dW[cg][cx][k^3] = sum over batch and voxels of g_small[cg] * x_big[cx] (shifted by the tap):
     weight gradient of Conv3d(x_big -> g_small's shape); see snvc_conv3d_wgrad for the
@@ -591,8 +612,7 @@ def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: in
     d.ksize, d.stride, d.dilation, d.pad = ksize, stride, dilation, pad
     d.transposed, d.flags, d.algo = 0, 0, _algo()
     d.x_batch_stride, d.y_batch_stride, d.res_batch_stride = _batch_stride(x_big), _batch_stride(g_small), 0
-    nbytes = _lib.lib().snvc_conv3d_wgrad_workspace_bytes(ctypes.byref(d))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=x_big.device)
+    ws = _workspace(_lib.lib().snvc_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), x_big.device)
     dw = torch.empty((d.Cout, d.Cin, ksize, ksize, ksize), dtype=torch.float32, device=x_big.device)
     with torch.cuda.device(x_big.device):
         check(_lib.lib().snvc_conv3d_wgrad(ctypes.byref(d), _ptr(x_big), _ptr(g_small), _ptr(dw), _ptr(ws),
