@@ -686,7 +686,7 @@ def main():
 
     if not args.no_extras:
         # cfg4 on every N: the one leg with a collective (RCCL all-reduce of the 3D stack's gradients)
-        tr = run_train(rank, world, device, dist, 3, 1, barrier)
+        tr = run_train(rank, world, device, dist, 10, 3, barrier)
         if rank == 0:
             line["train"] = tr
         if world == 1:
