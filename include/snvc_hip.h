@@ -316,6 +316,11 @@ SNVC_API int snvc_conv3d_forward_stats(const snvc_conv3d_desc *desc_host, const 
  *   snvc_sheared_expand   : y[n][co][d][h][w] = epilogue(scale*G[n][cls(d)][co][h][q*w - d - m0 + off] + planes[n][co][cls(d)][h][w]),
  *                           G'[..][q*(W-1) - d - m0 + off2] in place of G at w = W-1; g [N][3][C][H][WG], gcol [N][3][C][H][WG2],
  *                           planes = the depth-class planes of snvc_conv3d_forward_ex (or NULL). */
+/* Structure of a float32 shift array [N][D] in one launch: out4 = { all >= 0, every row == shift[0][0] + d (q = 1),
+ * every row == shift[0][0] + d/2 (q = 2), shift[0][0] } (flags as 1.0 / 0.0, exact fp32 comparisons).  The caller reads the four
+ * floats back: the same single device -> host sync as the reference wrapper's `assert torch.all(shift >= 0)`
+ * (snvc/extension/build_cost_volume/__init__.py:12), which it replaces. */
+SNVC_API int snvc_shift_structure(const float *shift, float *out4, int64_t N, int64_t D, void *stream);
 SNVC_API int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, int64_t H, int64_t W, int q,
                                    int64_t WU, int off, void *stream);
 SNVC_API int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale,

@@ -177,6 +177,31 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
     }
 }
 
+// Structure of a shift array in one launch (the host reads 4 floats back: the one device -> host sync that replaces the
+// `assert torch.all(shift >= 0)` of the reference's wrapper, snvc/extension/build_cost_volume/__init__.py:12):
+//   out = { all shift >= 0,  every row == shift[0][0] + d,  every row == shift[0][0] + d/2,  shift[0][0] }
+// compared exactly in fp32 (s0 + d and s0 + 0.5*d are formed as the host would form them: one rounding each).
+__global__ void __launch_bounds__(256)
+shift_structure_kernel(const float *__restrict__ shift, float *__restrict__ out, int64_t total, int D) {
+    __shared__ int flags[3];
+    if (threadIdx.x < 3) flags[threadIdx.x] = 1;
+    __syncthreads();
+    const float s0 = shift[0];
+    bool nonneg = true, whole = true, half_ = true;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        const float v = shift[i], d = (float)(int)(i % D);
+        nonneg = nonneg && v >= 0.0f;                 // NaN fails, as torch.all(shift >= 0) does
+        whole = whole && v == s0 + d;
+        half_ = half_ && v == s0 + 0.5f * d;
+    }
+    if (!nonneg) flags[0] = 0;
+    if (!whole) flags[1] = 0;
+    if (!half_) flags[2] = 0;
+    __syncthreads();
+    if (threadIdx.x < 3) out[threadIdx.x] = (float)flags[threadIdx.x];
+    if (threadIdx.x == 3) out[3] = s0;
+}
+
 // ------------------------------------------------------------------------------------ backward (training, cfg4)
 // Adjoint of sheared_expand_kernel w.r.t. G and G' (scale = 1: the caller applies the norm's backward first):
 //     dG[n][cls][co][h][i]  = sum over (d in class cls, w <= W-2) with Q*w - d - m0 + off  == i of dy[n][co][d][h][w]
@@ -706,6 +731,15 @@ int snvc_sheared_backward_reduce(const float *g, const float *gcol, const float 
     if (rc) return rc;
     sheared_fold_kernel<<<(unsigned)ceil_div<int64_t>(N * C, 128), 128, 0, as_stream(stream)>>>(partial, sums, N * C, (int)grid.x);
     return check_launch("snvc_sheared_backward_reduce(fold)");
+}
+
+int snvc_shift_structure(const float *shift, float *out4, int64_t N, int64_t D, void *stream) {
+    using namespace snvc;
+    if (N <= 0 || D <= 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_shift_structure: sizes must be positive");
+    if (!shift || !out4) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_shift_structure: null pointer");
+    if (D >= (1 << 24)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_shift_structure: D must stay exactly representable in fp32");
+    shift_structure_kernel<<<1, 256, 0, as_stream(stream)>>>(shift, out4, N * D, (int)D);
+    return check_launch("snvc_shift_structure");
 }
 
 int snvc_sheared_reduce(const float *dy, float *dg, float *dgcol, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q,

@@ -105,11 +105,7 @@ class GlobalStack(nn.Module):
         (all shifts >= 0, (q, m0) or None).  (q, m0): every row of ``shift`` is (m0 + d) / q for d = 0..D-1 with q in {1, 2}
         -- uniformly spaced whole- or half-pixel disparity planes -- exactly, in fp32."""
         d = shift.size(1)
-        s = shift.detach().float()
-        ar = torch.arange(d, dtype=torch.float32, device=shift.device)
-        s00 = s[:1, :1]
-        flags = torch.stack([(s >= 0).all(), (s == s00 + ar).all(), (s == s00 + 0.5 * ar).all()]).float()
-        nonneg, u1, u2, first = torch.cat([flags, s00.reshape(1)]).tolist()
+        nonneg, u1, u2, first = ops.shift_structure(shift.detach())         # one launch (r3 first form: 12 torch kernels, 60 us)
         q = 1 if u1 else (2 if u2 else 0)
         m0 = first * q
         if q == 0 or d < 4 or m0 != int(m0) or not (0 <= m0 < 1 << 20):

@@ -397,6 +397,21 @@ class Conv3dLayer:
         return out, scale, shift, mean, var
 
 
+def shift_structure(shift):
+    """(all shifts >= 0, rows == s0 + d, rows == s0 + d/2, s0) of a float32 [N, D] shift array: one launch and one 16-byte
+    device -> host copy (snvc_shift_structure)."""
+    _gpu(shift, "shift")
+    if shift.dtype != torch.float32 or shift.dim() != 2 or shift.numel() == 0:
+        raise RuntimeError("shift_structure needs a non-empty float32 [N, D] tensor")
+    shift = shift.contiguous()
+    out = torch.empty(4, dtype=torch.float32, device=shift.device)
+    with torch.cuda.device(shift.device):
+        check(_lib.lib().snvc_shift_structure(_ptr(shift), _ptr(out), shift.size(0), shift.size(1), _stream(shift)),
+              "snvc_shift_structure")
+    nonneg, u1, u2, first = out.tolist()
+    return bool(nonneg), bool(u1), bool(u2), first
+
+
 def sheared_upsample(right, q: int, wu: int, off: int):
     """Rq on a padded grid (snvc_sheared_upsample): right [N,C,H,W] -> [N,C,H,wu], element i = Rq[i - off]."""
     _gpu(right, "right")

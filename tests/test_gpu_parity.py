@@ -1087,6 +1087,26 @@ def test_global_pair_end_to_end_vs_oracle(tile):
     check(full1, exp1, 2e-5, "conv1")
 
 
+def test_shift_structure_flags():
+    """snvc_shift_structure: the one-launch replacement of the wrapper's `assert torch.all(shift >= 0)` also classifies the
+    array (whole- / half-pixel uniform spacing, exactly in fp32)."""
+    from snvc_amd import ops
+    D = 192
+    ar = np.arange(D, dtype=np.float32)
+    mk = lambda rows: torch.from_numpy(np.stack(rows).astype(np.float32)).to(dev())      # noqa: E731
+    assert ops.shift_structure(mk([ar / 2, ar / 2])) == (True, False, True, 0.0)                 # cfg2: linspace(0, 95.5, 192)
+    assert ops.shift_structure(mk([3 + ar])) == (True, True, False, 3.0)
+    assert ops.shift_structure(mk([1.5 + ar / 2] * 3)) == (True, False, True, 1.5)
+    assert ops.shift_structure(mk([ar / 2, ar / 2 + 0.25]))[:3] == (True, False, False)          # rows differ
+    bad = ar / 2
+    bad[77] = np.nextafter(bad[77], np.float32(1e9))
+    assert ops.shift_structure(mk([bad]))[:3] == (True, False, False)                            # one ulp off: general path
+    assert ops.shift_structure(mk([ar - 1]))[:2] == (False, True)                                # negative shift: the wrapper's assert
+    nan = ar.copy(); nan[5] = np.nan
+    assert ops.shift_structure(mk([nan]))[0] is False
+    assert ops.shift_structure(mk([np.linspace(0, 5, D)]))[:3] == (True, False, False)
+
+
 @pytest.mark.parametrize("q,m0", [(2, 0), (2, 3), (1, 0), (1, 2)])
 def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
     """Uniformly spaced disparity planes, shift[d] = (m0 + d) / q: forward_pair takes the sheared first convolution
