@@ -104,8 +104,11 @@ class GlobalStack(nn.Module):
         """One device -> host round trip (it replaces the `assert torch.all(shift >= 0)` sync of the reference's wrapper):
         (all shifts >= 0, (q, m0) or None).  (q, m0): every row of ``shift`` is (m0 + d) / q for d = 0..D-1 with q in {1, 2}
         -- uniformly spaced whole- or half-pixel disparity planes -- exactly, in fp32."""
-        d = shift.size(1)
-        nonneg, u1, u2, first = ops.shift_structure(shift.detach())         # one launch (r3 first form: 12 torch kernels, 60 us)
+        return GlobalStack._shift_structure_end(ops.shift_structure_begin(shift.detach()), shift.size(1))
+
+    @staticmethod
+    def _shift_structure_end(ticket, d):
+        nonneg, u1, u2, first = ops.shift_structure_result(ticket)          # one launch (r3 first form: 12 torch kernels, 60 us)
         q = 1 if u1 else (2 if u2 else 0)
         m0 = first * q
         if q == 0 or d < 4 or m0 != int(m0) or not (0 <= m0 < 1 << 20):
@@ -205,10 +208,14 @@ class GlobalStack(nn.Module):
             mark("conv1", 1)
             del vol
             return self._conv2_tail(v, shape, timing)
-        structure = None
+        # The one device -> host sync of the step (the wrapper's `assert shift >= 0`, here also the shift array's spacing) is
+        # STARTED first and awaited only after everything that does not need its answer has been queued: the left half's
+        # planes, and -- speculatively, for the spacing the previous call saw -- the sheared layer's two small 2D convolutions.
+        # The host then waits while the GPU still has work, and queues the big layers while those run (r3: the wait sat in
+        # front of six small launches whose launch latency the GPU then had to sit through, ~0.1 ms of a 4 ms step).
+        ticket = None
         if sheared and left.size(0) > 0 and shift.size(1) >= 4 and shift.dtype == torch.float32:
-            nonneg, structure = self._shift_structure(shift)
-            assert nonneg                        # same contract as build_cost_volume (reference __init__.py:12)
+            ticket = ops.shift_structure_begin(shift.detach())
         elif not shift_checked:                  # a LazyCostVolume was checked when build_cost_volume made it
             assert torch.all(shift >= 0.)
         c = left.size(1)
@@ -223,13 +230,28 @@ class GlobalStack(nn.Module):
         planes = self._left_planes_layer(plans, w.detach()[:, :c])(left.unsqueeze(2))       # [N,3C,1,H,W] ...
         planes = planes.view(left.size(0), c, 3, left.size(2), left.size(3))                 # ... = [N,C,3,H,W]: first / interior / last
         shape = (left.size(0), c, shift.size(1)) + tuple(left.shape[2:])
-        if structure is not None:
-            q, m0 = structure
+
+        def sheared_inputs(q, m0):
             off, wu, off_col, wu_col = sheared_geometry(q, m0, shift.size(1), left.size(3))
             lay_g, lay_col = self._sheared_layers(plans, w.detach()[:, c:], q)
-            mark("volume", 0)
             g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)             # [N,3C,H,WU]
             gcol = lay_col(ops.sheared_upsample(right, q, wu_col, off_col).unsqueeze(2)).squeeze(2)   # [N,3C,H,WU2]
+            return g, gcol, off, off_col
+
+        structure, guess, ready = None, None, None
+        if ticket is not None:
+            guess = plans.get("spacing_seen")    # (q, m0, D, W) of the previous call: a guess, checked below
+            mark("volume", 0)
+            if guess is not None and guess[2:] == (shift.size(1), left.size(3)):
+                ready = sheared_inputs(guess[0], guess[1])
+            nonneg, structure = self._shift_structure_end(ticket, shift.size(1))
+            assert nonneg                        # same contract as build_cost_volume (reference __init__.py:12)
+            plans["spacing_seen"] = structure + (shift.size(1), left.size(3)) if structure is not None else None
+        if structure is not None:
+            q, m0 = structure
+            if ready is None or guess[:2] != structure:
+                ready = sheared_inputs(q, m0)    # first call, or the spacing changed: the guess is dropped
+            g, gcol, off, off_col = ready
             mark("volume", 1)
             mark("conv1", 0)
             v = self._buffer("v1", shape, left.device)

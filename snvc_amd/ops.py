@@ -403,12 +403,36 @@ def shift_structure(shift):
     _gpu(shift, "shift")
     if shift.dtype != torch.float32 or shift.dim() != 2 or shift.numel() == 0:
         raise RuntimeError("shift_structure needs a non-empty float32 [N, D] tensor")
+    return shift_structure_result(shift_structure_begin(shift))
+
+
+_PINNED4 = {}
+
+
+def shift_structure_begin(shift):
+    """Launches snvc_shift_structure and the 16-byte copy of its result to pinned host memory; returns a ticket for
+    ``shift_structure_result``.  Work queued between the two calls overlaps the host's wait (``GlobalStack.forward_pair``
+    queues the launches that do not depend on the answer first)."""
+    _gpu(shift, "shift")
+    if shift.dtype != torch.float32 or shift.dim() != 2 or shift.numel() == 0:
+        raise RuntimeError("shift_structure needs a non-empty float32 [N, D] tensor")
     shift = shift.contiguous()
     out = torch.empty(4, dtype=torch.float32, device=shift.device)
+    key = (shift.device, torch.cuda.current_stream(shift.device).cuda_stream)
+    host = _PINNED4.get(key)
+    if host is None:
+        host = _PINNED4[key] = (torch.empty(4, dtype=torch.float32).pin_memory(), torch.cuda.Event())
     with torch.cuda.device(shift.device):
         check(_lib.lib().snvc_shift_structure(_ptr(shift), _ptr(out), shift.size(0), shift.size(1), _stream(shift)),
               "snvc_shift_structure")
-    nonneg, u1, u2, first = out.tolist()
+        host[0].copy_(out, non_blocking=True)
+        host[1].record()
+    return host
+
+
+def shift_structure_result(ticket):
+    ticket[1].synchronize()
+    nonneg, u1, u2, first = ticket[0].tolist()
     return bool(nonneg), bool(u1), bool(u2), first
 
 

@@ -1144,6 +1144,15 @@ def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
         dsh2[0, 5] += 0.25
         ours.forward_pair(dl, dr, dsh2, 1)
         assert S._ROUTES["sheared_first_conv"] == before + 2
+        # the spacing changes between calls: the launches queued for the previous call's spacing are dropped, not used
+        q3, m3 = (1, 1) if q == 2 else (2, 1)
+        s3 = torch.from_numpy(np.tile(((m3 + np.arange(D)) / q3).astype(np.float32)[None], (2, 1))).to(dev())
+        ours.forward_pair(dl, dr, dsh, 1)                                   # spacing (q, m0) is now the guess
+        other = ours.forward_pair(dl, dr, s3, 1).cpu().numpy()
+        other_general = ours.forward_pair(dl, dr, s3, 1, sheared=False).cpu().numpy()
+        back = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()              # and back again
+        check(other, other_general, 2e-5, "spacing changed between calls")
+        assert np.array_equal(back, got)
     check(v1s.cpu().numpy(), v1g.cpu().numpy(), TIGHT, f"first layer, sheared vs general q={q} m0={m0}")
     check(got, exp, 1e-4, f"pair (sheared) vs oracle q={q} m0={m0}")
     check(got, general, 2e-5, f"sheared vs general path q={q} m0={m0}")
