@@ -48,6 +48,14 @@ def build_cost_volume(left, right, shift, downsample):
                not (left.requires_grad or right.requires_grad))
     if not lazy_ok:
         return _BuildCostVolume.apply(left, right, shift, downsample)
-    assert torch.all(shift >= 0.)            # reference __init__.py:12, at the same point of the call sequence
     from ...lazy import LazyCostVolume
-    return LazyCostVolume(left, right, shift, downsample, build_cost_volume_cuda.build_cost_volume_forward)
+    from ... import ops
+    spacing = "unknown"
+    if shift.dtype == torch.float32 and shift.numel() > 0:
+        # reference __init__.py:12, at the same point of the call sequence and with the same single sync; the launch also
+        # classifies the array's spacing, which GlobalStack.forward_pair would otherwise sync for a second time
+        nonneg, spacing = ops.shift_spacing_result(ops.shift_structure_begin(shift.detach()), shift.size(1))
+        assert nonneg
+    else:
+        assert torch.all(shift >= 0.)
+    return LazyCostVolume(left, right, shift, downsample, build_cost_volume_cuda.build_cost_volume_forward, spacing)

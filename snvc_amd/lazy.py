@@ -15,14 +15,21 @@ from torch.utils._pytree import tree_map
 
 class LazyCostVolume(torch.Tensor):
     @staticmethod
-    def __new__(cls, left, right, shift, downsample, build):
+    def __new__(cls, left, right, shift, downsample, build, spacing="unknown"):
         n, c, h, w = left.shape
         shape = (n, 2 * c, shift.shape[1], h // downsample, w // downsample)
         r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=left.dtype, device=left.device, requires_grad=False)
         r._sources = (left, right, shift, downsample)
         r._build = build
         r._real = None
+        r._spacing = spacing
         return r
+
+    @property
+    def spacing(self):
+        """What build_cost_volume's one look at the shift array found: (q, m0) for uniformly spaced planes (m0 + d) / q,
+        None for any other array, "unknown" if it did not classify it."""
+        return self._spacing
 
     # ---- what GlobalStack.forward uses
     @property

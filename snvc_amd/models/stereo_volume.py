@@ -90,7 +90,7 @@ class GlobalStack(nn.Module):
             if not volume.is_materialized and not torch.is_grad_enabled() and not self.training:
                 left, right, shift, ds = volume.sources
                 if left.shape[1] * 2 == self.conv1[0][0].in_channels and left.shape[3] % 4 == 0:
-                    return self.forward_pair(left, right, shift, ds, shift_checked=True)
+                    return self.forward_pair(left, right, shift, ds, shift_checked=True, spacing=volume.spacing)
             volume = volume.materialize()
         if torch.is_grad_enabled() or not volume.is_cuda:
             return self._tail(self.conv2(self.conv1(volume)))
@@ -108,12 +108,7 @@ class GlobalStack(nn.Module):
 
     @staticmethod
     def _shift_structure_end(ticket, d):
-        nonneg, u1, u2, first = ops.shift_structure_result(ticket)          # one launch (r3 first form: 12 torch kernels, 60 us)
-        q = 1 if u1 else (2 if u2 else 0)
-        m0 = first * q
-        if q == 0 or d < 4 or m0 != int(m0) or not (0 <= m0 < 1 << 20):
-            return bool(nonneg), None
-        return bool(nonneg), (q, int(m0))
+        return ops.shift_spacing_result(ticket, d)     # one launch (r3 first form: 12 torch kernels, 60 us)
 
     def _sheared_layers(self, plans, wr, q):
         """The depth-1 3 x 7 layers that compute G and G' (csrc/sheared_conv.hip): K[kh][t] = sum over (kd, kw) with
@@ -139,7 +134,7 @@ class GlobalStack(nn.Module):
         return plans["left2d"]
 
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True,
-                     fused_bn=True):
+                     fused_bn=True, spacing="unknown"):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
 
         ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT
@@ -214,7 +209,10 @@ class GlobalStack(nn.Module):
         # The host then waits while the GPU still has work, and queues the big layers while those run (r3: the wait sat in
         # front of six small launches whose launch latency the GPU then had to sit through, ~0.1 ms of a 4 ms step).
         ticket = None
-        if sheared and left.size(0) > 0 and shift.size(1) >= 4 and shift.dtype == torch.float32:
+        known = shift_checked and spacing != "unknown"       # build_cost_volume already looked (LazyCostVolume.spacing)
+        if known and not sheared:
+            spacing = None
+        if not known and sheared and left.size(0) > 0 and shift.size(1) >= 4 and shift.dtype == torch.float32:
             ticket = ops.shift_structure_begin(shift.detach())
         elif not shift_checked:                  # a LazyCostVolume was checked when build_cost_volume made it
             assert torch.all(shift >= 0.)
@@ -238,7 +236,7 @@ class GlobalStack(nn.Module):
             gcol = lay_col(ops.sheared_upsample(right, q, wu_col, off_col).unsqueeze(2)).squeeze(2)   # [N,3C,H,WU2]
             return g, gcol, off, off_col
 
-        structure, guess, ready = None, None, None
+        structure, guess, ready = (spacing if known else None), None, None
         if ticket is not None:
             guess = plans.get("spacing_seen")    # (q, m0, D, W) of the previous call: a guess, checked below
             mark("volume", 0)
@@ -250,6 +248,7 @@ class GlobalStack(nn.Module):
         if structure is not None:
             q, m0 = structure
             if ready is None or guess[:2] != structure:
+                mark("volume", 0)
                 ready = sheared_inputs(q, m0)    # first call, or the spacing changed: the guess is dropped
             g, gcol, off, off_col = ready
             mark("volume", 1)

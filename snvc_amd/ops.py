@@ -436,6 +436,17 @@ def shift_structure_result(ticket):
     return bool(nonneg), bool(u1), bool(u2), first
 
 
+def shift_spacing_result(ticket, d: int):
+    """(all shifts >= 0, (q, m0) or None): (q, m0) when every row of the shift array is (m0 + d) / q for d = 0..D-1 with q in
+    {1, 2} -- uniformly spaced whole- or half-pixel disparity planes -- exactly, in fp32 (the sheared first convolution)."""
+    nonneg, u1, u2, first = shift_structure_result(ticket)
+    q = 1 if u1 else (2 if u2 else 0)
+    m0 = first * q
+    if q == 0 or d < 4 or m0 != int(m0) or not (0 <= m0 < 1 << 20):
+        return nonneg, None
+    return nonneg, (q, int(m0))
+
+
 def sheared_upsample(right, q: int, wu: int, off: int):
     """Rq on a padded grid (snvc_sheared_upsample): right [N,C,H,W] -> [N,C,H,wu], element i = Rq[i - off]."""
     _gpu(right, "right")

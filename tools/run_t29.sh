@@ -1,3 +1,2 @@
-python -m pytest tests -m gpu -x -q -k "sheared or shift_structure or global_pair or lazy or fullsize" > gpurun_out/r3_t29_tests.log 2>&1; tail -4 gpurun_out/r3_t29_tests.log
-python bench.py --no-extras > gpurun_out/r3_t29_bench.json 2>/dev/null; tail -1 gpurun_out/r3_t29_bench.json | head -c 250; echo
-python bench.py --no-extras > gpurun_out/r3_t29_bench2.json 2>/dev/null; tail -1 gpurun_out/r3_t29_bench2.json | head -c 250; echo
+python -m pytest tests -m gpu -x -q > gpurun_out/r3_t29_tests.log 2>&1; tail -4 gpurun_out/r3_t29_tests.log
+python bench.py > gpurun_out/r3_t29_bench.json 2>/dev/null; tail -1 gpurun_out/r3_t29_bench.json | head -c 250; echo
