@@ -192,6 +192,12 @@ def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="
         if heads:
             ms_h, _ = timed_ms(lambda: m.heads_2d(res[0]), reps)
             out["heads_2d_ms_per_crop"] = ms_h / crops
+            # the neck is ~36 small launches whose time barely depends on the crops in the call (0.95 ms for 1 or 2 crops):
+            # the same call on 8 crops (BASELINE configs[2]'s crops per GPU) beside it
+            bev8 = res[0].repeat((8 + crops - 1) // crops, 1, 1, 1)[:8].contiguous()
+            ms_h8, _ = timed_ms(lambda: m.heads_2d(bev8), reps)
+            out["heads_2d_ms_per_crop_at_8_crops"] = ms_h8 / 8
+            del bev8
             # everything after the backbone (gather + trunk + 2D neck + heads) through VernierScale.forward
             del res
             m.precision = precision

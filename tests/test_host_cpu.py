@@ -252,3 +252,62 @@ def test_install_as_snvc_redirects_the_reference_imports(tmp_path, monkeypatch):
         ours.get_feat_extraction = saved
         for name in [m for m in sys.modules if m == "snvc" or m.startswith("snvc.")]:
             sys.modules.pop(name, None)
+
+
+@pytest.mark.parametrize("q,m0", [(2, 0), (2, 3), (1, 0), (1, 2)])
+def test_sheared_first_convolution_algebra_on_the_cpu(q, m0):
+    """The identity behind csrc/sheared_conv.hip, checked without a GPU: for shift[d] = (m0 + d) / q the 3x3x3 convolution
+    over the WARPED half of the oracle's cost volume equals the depth-1 3x7 convolutions G / G' of the interpolated right
+    feature (kernels from ``sheared_kernels``: three depth classes, all columns | last column) read along the shear with
+    ``sheared_geometry``'s offsets -- every border included (d = 0, D-1, w = 0, W-1, samples left of the image)."""
+    import torch.nn.functional as F
+    from oracle import native as O
+    from snvc_amd.models.submodule import sheared_geometry, sheared_kernels
+    r = np.random.default_rng(7 + 10 * q + m0)
+    C, CO, D, H, W = 3, 4, 9, 5, 12
+    L = r.standard_normal((1, C, H, W)).astype(np.float32)
+    R = r.standard_normal((1, C, H, W)).astype(np.float32)
+    shift = ((m0 + np.arange(D)) / q).astype(np.float32)[None]
+    wr = torch.from_numpy(r.standard_normal((CO, C, 3, 3, 3))).double()
+    vol_r = torch.from_numpy(O.cost_volume_forward(L, R, shift, 1)[:, C:]).double()          # the warped half [1,C,D,H,W]
+    ref = F.conv3d(vol_r, wr, padding=1)[0].numpy()
+    # Rq on the padded grid, exactly as snvc_sheared_upsample lays it out
+    off, wu, off_col, wu_col = sheared_geometry(q, m0, D, W)
+
+    def rq(width, o):
+        out = np.zeros((C, H, width))
+        for i in range(width):
+            u = i - o
+            if 0 <= u <= q * (W - 1):
+                j = u // q
+                out[:, :, i] = R[0, :, :, j] if u % q == 0 else 0.5 * R[0, :, :, j] + 0.5 * R[0, :, :, j + 1]
+        return torch.from_numpy(out)[None]
+
+    k = sheared_kernels(wr, q)                                                                 # [2,3,CO,C,3,7]
+    g = [F.conv2d(rq(wu, off), k[0, cls], padding=(1, 3))[0].numpy() for cls in range(3)]
+    gc = [F.conv2d(rq(wu_col, off_col), k[1, cls], padding=(1, 3))[0].numpy() for cls in range(3)]
+    got = np.zeros_like(ref)
+    for d in range(D):
+        cls = 0 if d == 0 else (2 if d == D - 1 else 1)
+        for w in range(W - 1):
+            i = q * w - d - m0 + off
+            if 0 <= i < wu:
+                got[:, d, :, w] = g[cls][:, :, i]
+        got[:, d, :, W - 1] = gc[cls][:, :, q * (W - 1) - d - m0 + off_col]
+    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def test_sheared_term_counts_cover_every_element():
+    """The multiplicities the fused BatchNorm backward multiplies its constant term with: every element of the layer's
+    [D, W] plane lies on exactly one shear line (columns < W-1, minus the lines left of the padded grid, where G is zero) or
+    in one last-column slot, and in one depth class."""
+    from snvc_amd.models.submodule import _sheared_term_counts, sheared_geometry
+    for q, m0, D, W in ((2, 0, 192, 312), (1, 3, 12, 40), (2, 5, 9, 24)):
+        line, col, per_class = _sheared_term_counts(q, m0, D, W, torch.device("cpu"))
+        off, wu, off_col, wu_col = sheared_geometry(q, m0, D, W)
+        dropped = sum(1 for d in range(D) for w in range(W - 1) if not 0 <= q * w - d - m0 + off < wu)
+        assert line.shape == (3, wu) and col.shape == (3, wu_col)
+        assert int(line.sum()) == D * (W - 1) - dropped
+        assert int(col.sum()) == D and float(col.max()) == 1.0
+        assert per_class.tolist() == [1.0, float(D - 2), 1.0]
+        assert int(line[0].sum()) + int(line[2].sum()) <= 2 * (W - 1)
