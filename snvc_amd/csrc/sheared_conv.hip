@@ -311,6 +311,7 @@ sheared_bwd_kernel(const float *__restrict__ g, const float *__restrict__ gcol, 
     auto gload = [&](int i) -> float { return (i >= 0 && i < WG) ? phase[(wave * Q + (i % Q)) * LW + i / Q] : 0.0f; };
     // g and raw of plane d at this lane's 8 columns; rawv in: G part, out: raw
     auto grad8 = [&](const f32x4 a, const f32x4 b, float (&rawv)[8], const float (&pl)[8], float (&gg)[8]) {
+        float p0 = 0.0f, p1 = 0.0f;                          // this plane's 8 terms in fp32, then fp64 across planes and lanes
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float x = rawv[k] + pl[k];
@@ -318,9 +319,11 @@ sheared_bwd_kernel(const float *__restrict__ g, const float *__restrict__ gcol, 
             const float gyk = k < 4 ? a[k] : b[k - 4];
             gg[k] = v > 0.0f ? gyk : 0.0f;
             rawv[k] = x;
-            s0 += (double)gg[k];
-            s1 += (double)gg[k] * (double)x;
+            p0 = p0 + gg[k];
+            p1 = p1 + gg[k] * x;
         }
+        s0 += (double)p0;
+        s1 += (double)p1;
     };
     // ---- the two end planes (depth classes 0 and 2): single terms everywhere
 #pragma unroll 1

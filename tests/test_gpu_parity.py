@@ -1278,7 +1278,7 @@ def test_sheared_fused_batchnorm_entry_points_vs_numpy(q, m0):
     v = rawf * scale.cpu().numpy()[0][None, :, None, None, None] + shift.cpu().numpy()[0][None, :, None, None, None]
     gm = np.where(v > 0, gy, 0).astype(np.float64)
     exp_sums = np.stack([gm.sum((2, 3, 4)), (gm * raw).sum((2, 3, 4))], -1)
-    np.testing.assert_allclose(sums.cpu().numpy(), exp_sums, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(sums.cpu().numpy(), exp_sums, rtol=2e-6, atol=2e-5)
     cls_of = lambda d: 0 if d == 0 else (2 if d == D - 1 else 1)          # noqa: E731
     e_line, e_last, e_col = np.zeros((2, N, 3, C, H, wu)), np.zeros((2, N, 3, C, H, wu_col)), np.zeros((2, N, C, 3, H, W))
     for qi, src in enumerate((gm, raw)):
