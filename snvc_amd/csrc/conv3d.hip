@@ -67,6 +67,7 @@ struct ConvArgs {
     const float *head_w; // fused 1x1x1 head (snvc_conv3d_forward_head): [Cout] weights, or nullptr
     float *y_head;       //   its [N,1,Dout,Hout,Wout] output; `y` is then not written
     int fast_epi;        // the launch qualifies for the fast epilogues (see the toolkit comment)
+    int dc_planar;       // deconv3d_mfma_kernel: depth-1 layer, only the classes (pd = 0, ph) are launched (2 * ntiles workgroups)
     double *stats;       // XMODE 3: per job [32 channels][sum, sum of squares] of the raw result (train-mode BatchNorm), or nullptr
     int njobs, groups;   // Winograd kernel: jobs = tiles x channel groups x samples
     int vec;  // 1: 16-byte aligned rows (Win % 4 == 0, aligned base and strides) -> float4 staging
@@ -1861,6 +1862,11 @@ deconv3d_mfma_kernel(const ConvArgs a) {
     const int tile = xcd_remap(blockIdx.x - slot * ntiles, ntiles);
     const int cg = blockIdx.y;
     const int64_t n = blockIdx.z;
+    if (a.dc_planar) {   // depth-1 layer: the two classes of depth parity 0 (output plane 0 is the only one)
+        if (slot == 0) deconv_class_body<Cfg, EPI, 0, 1>(a, lds, tile, cg, n);
+        else deconv_class_body<Cfg, EPI, 0, 0>(a, lds, tile, cg, n);
+        return;
+    }
     switch (slot) {  // wave-uniform
         case 0: deconv_class_body<Cfg, EPI, 1, 1>(a, lds, tile, cg, n); break;
         case 1: deconv_class_body<Cfg, EPI, 1, 0>(a, lds, tile, cg, n); break;
@@ -2140,7 +2146,7 @@ enum Kind {
     K5_M1, K5_M2,
     K5D2_M1, K5D2_M2,
     K7_M1, K7_M2,
-    DC_M1, DC_M2,
+    DC_M1, DC_M2, DCP_M1,
     P1_M1S, P1S2_M1S, P3_M1S, P3S2_M1S, P7_M1S,                          // depth-1 (2D) layers, 1 x 4 x 32 tiles
     KIND_NONE
 };
@@ -2189,6 +2195,10 @@ using CfgDCM1   = DeconvCfg<1, 2, 4, 4>;
 using CfgDCM2   = DeconvCfg<2, 2, 4, 4>;
 using CfgDCM1v8 = DeconvCfg<1, 2, 4, 4, 2>;
 using CfgDCM2v8 = DeconvCfg<2, 2, 4, 4, 2>;
+// depth-1 transposed layer (nn.ConvTranspose2d(k3,s2,p1,op1) of the 2D neck on [N,C,1,H,W] views): 1 x 8 x 32 input tiles,
+// only the two depth-parity-0 classes exist (their taps are the kd = 1 plane of the embedded 3x3x3 kernel)
+using CfgDCP    = DeconvCfg<1, 1, 8, 4>;
+using CfgDCPv8  = DeconvCfg<1, 1, 8, 4, 2>;
 
 template <class Cfg>
 constexpr Plan plan_of(int kind) { return Plan{Cfg::MI, Cfg::KC, Cfg::TD, Cfg::TH, 0, 0, 0, 0, 0, kind}; }
@@ -2200,12 +2210,19 @@ int make_plan(const snvc_conv3d_desc &d, Plan &p) {
     if (d.transposed) {
         if (d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.dilation != 1)
             return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d: transposed conv supports k3,s2,p1,op1 only");
+        if (d.ksize_d == 1) {   // depth-1 form: [N,C,1,H,W] -> [N,C,1,2H,2W]; the weight is the 2D kernel on the kd = 1 plane of a 3x3x3 one
+            if (d.Din != 1 || d.Dout != 1 || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win || (d.ksize_h != 0 && d.ksize_h != 3))
+                return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: a depth-1 transposed layer maps [1,H,W] to [1,2H,2W]");
+            p = plan_of<CfgDCP>(DCP_M1);
+            p.tiles_d = 1; p.tiles_h = ceil_div(d.Hin, p.TH); p.tiles_w = ceil_div(d.Win, 32);
+        } else {
         if (d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win)
             return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d: transposed output must be 2x the input");
         // whole 32-channel groups run the single-group form (128 VGPRs: four workgroups per CU); the 64-channel
         // form only remains for channel counts that are not multiples of 32
         p = (wide && d.Cout % 32 != 0) ? plan_of<CfgDCM2>(DC_M2) : plan_of<CfgDCM1>(DC_M1);
         p.tiles_d = ceil_div(d.Din, p.TD); p.tiles_h = ceil_div(d.Hin, p.TH); p.tiles_w = ceil_div(d.Win, 32);
+        }
     } else if (d.ksize_d == 1) {
         // depth-1 layer: nn.Conv2d(k, stride, padding=(k-1)/2) on an [N,C,1,H,W] view; the stride applies to H and W only
         // (k = 1, stride 2 is BasicBlock's downsample path, hrnet.py:56-69)
@@ -2586,6 +2603,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     a.plane = depth_planes;
     a.head_w = head_w; a.y_head = y_head;
     a.stats = stats;
+    a.dc_planar = (d->transposed && d->ksize_d == 1) ? 1 : 0;
     const bool side_head = head_w && y;   // snvc_conv3d_forward_side_head: y AND its one-channel projection
     const bool pooled = (d->flags & SNVC_EPI_AVGPOOL_D4) != 0;   // y is [N,Cout,Dout/4,Hout,Wout]
     if (pooled && (side_head || head_w || d->transposed || d->ksize_d == 1 || d->ksize != 3 || d->stride != 1 || d->dilation != 1 ||
@@ -2765,7 +2783,7 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
     if (pooled)
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: SNVC_EPI_AVGPOOL_D4 needs 16-byte aligned rows (the Winograd path)");
     const int64_t ntiles = (int64_t)p.tiles_d * p.tiles_h * p.tiles_w;
-    const int64_t gx = d->transposed ? ntiles * 4 : ntiles;
+    const int64_t gx = d->transposed ? ntiles * (a.dc_planar ? 2 : 4) : ntiles;
     if (gx >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: too many tiles");
     dim3 grid((unsigned)gx, (unsigned)p.groups, (unsigned)d->N);
     hipStream_t st = as_stream(stream);
@@ -2794,6 +2812,10 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         case DC_M2:
             if (!a.vec && vec8) { a.vec = 1; launch_deconv<CfgDCM2v8>(a, grid, st); }
             else launch_deconv<CfgDCM2>(a, grid, st);
+            break;
+        case DCP_M1:
+            if (!a.vec && vec8) { a.vec = 1; launch_deconv<CfgDCPv8>(a, grid, st); }
+            else launch_deconv<CfgDCP>(a, grid, st);
             break;
         default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward: no kernel");
     }

@@ -1085,8 +1085,9 @@ def _group_norm_2d(raw5, norm: nn.GroupNorm, r5, flags):
 
 
 def fused_deconv2d(conv: nn.ConvTranspose2d, norm, x: torch.Tensor, *, relu=False, residual=None) -> torch.Tensor:
-    """ConvTranspose2d(k3,s2,p1,op1) (+norm) (+residual) (+ReLU) (reference submodule.py:291-314): zero-stuffed input,
-    then the depth-1 k3 convolution with the flipped, channel-transposed kernel."""
+    """ConvTranspose2d(k3,s2,p1,op1) (+norm) (+residual) (+ReLU) (reference submodule.py:291-314) on the depth-1 form of the
+    parity-class transposed kernel (r2-r3 first form: zero-stuffed input + a k3 convolution with the flipped kernel, i.e.
+    four times the multiply-adds and one more launch; kept as ``ops.zero_stuff2x`` for the tests)."""
     if (tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding), tuple(conv.output_padding)) != ((3, 3), (2, 2), (1, 1), (1, 1)) \
             or conv.groups != 1 or conv.bias is not None:
         raise NotImplementedError("the 2D neck's up-sampling layers are ConvTranspose2d(k3,s2,p1,op1,bias=False)")
@@ -1094,15 +1095,14 @@ def fused_deconv2d(conv: nn.ConvTranspose2d, norm, x: torch.Tensor, *, relu=Fals
     w = conv.weight
     key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
     if plan.layer is None or plan.key != key:
-        plan.layer = ops.Conv3dLayer(w.detach().transpose(0, 1).flip(2, 3).contiguous(), 3, 1, 1, 1, False, planar=True)
+        plan.layer = ops.Conv3dLayer(w.detach().contiguous(), 3, 2, 1, 1, True, planar=True)
         plan.key = key
     scale, bias = _affine2d(conv, norm, plan)
     flags = (EPI_RELU if relu else 0) | (EPI_ADD_PRE if residual is not None else 0)
-    up = ops.zero_stuff2x(x)
     r5 = residual.unsqueeze(2) if residual is not None else None
     if isinstance(norm, nn.GroupNorm):
-        return _group_norm_2d(plan.layer(up.unsqueeze(2), scale, bias), norm, r5, flags).squeeze(2)
-    return plan.layer(up.unsqueeze(2), scale, bias, r5, flags).squeeze(2)
+        return _group_norm_2d(plan.layer(x.unsqueeze(2), scale, bias), norm, r5, flags).squeeze(2)
+    return plan.layer(x.unsqueeze(2), scale, bias, r5, flags).squeeze(2)
 
 
 def _cbr2d(seq, x, **kw):

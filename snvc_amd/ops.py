@@ -272,12 +272,20 @@ class Conv3dLayer:
         self.planar = bool(planar)
         if planar and weight.dim() == 4:
             weight = weight.unsqueeze(2)
+        if planar and transposed:
+            # nn.ConvTranspose2d(k3,s2,p1,op1) [Cin,Cout,3,3]: the kd = 1 plane of a 3x3x3 transposed kernel; the depth-1
+            # form of the parity-class kernel launches only the two classes whose taps lie on that plane
+            if tuple(weight.shape[2:]) != (1, 3, 3) or (ksize, stride, pad, dilation) != (3, 2, 1, 1):
+                raise RuntimeError("a depth-1 transposed layer is ConvTranspose2d(k3,s2,p1,op1): weight [Cin,Cout,3,3]")
+            w3 = torch.zeros(weight.shape[:2] + (3, 3, 3), dtype=torch.float32, device=weight.device)
+            w3[:, :, 1] = weight[:, :, 0]
+            weight = w3
         if transposed:
             self.cin, self.cout = weight.shape[0], weight.shape[1]
         else:
             self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.ksize_h = int(ksize_h) if planar else 0
-        if tuple(weight.shape[2:]) != ((1, self.ksize_h or ksize, ksize) if planar else (ksize,) * 3):
+        if tuple(weight.shape[2:]) != ((1, self.ksize_h or ksize, ksize) if (planar and not transposed) else (ksize,) * 3):
             raise RuntimeError("only cubic kernels (or depth-1 k x k / ksize_h x k ones with planar=True) are on the path")
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
         self.device = weight.device
@@ -291,6 +299,8 @@ class Conv3dLayer:
                                                       _ptr(self.packed), _stream(weight)), "snvc_conv3d_pack_weights")
 
     def out_spatial(self, in_spatial):
+        if self.transposed and getattr(self, "planar", False):
+            return (in_spatial[0], 2 * in_spatial[1], 2 * in_spatial[2])
         if self.transposed:
             return tuple(2 * s for s in in_spatial)
         eff = self.dilation * (self.ksize - 1) + 1

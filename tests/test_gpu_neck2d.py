@@ -78,7 +78,7 @@ def test_zero_stuff_and_fused_deconv2d_vs_torch():
     exp = torch.zeros(2, 5, 14, 18, device=dev())
     exp[:, :, ::2, ::2] = x
     assert torch.equal(up, exp)
-    for cin, cout, hw in ((64, 64, (6, 10)), (64, 32, (12, 17)), (8, 5, (1, 1)), (128, 64, (3, 2))):
+    for cin, cout, hw in ((64, 64, (6, 10)), (64, 32, (12, 17)), (8, 5, (1, 1)), (128, 64, (3, 2)), (64, 64, (64, 96)), (32, 48, (20, 44))):
         seq = seeded(S._deconvbn_2d(cin, cout, False), 31)
         x = _t(r, (2, cin) + hw)
         with torch.no_grad():
