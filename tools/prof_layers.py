@@ -30,7 +30,7 @@ model.load_state_dict(bench.seeded_state(model))
 model.eval().to(dev)
 left, right, shift = bench.make_inputs(0, dev)
 with torch.no_grad():
-    if args.layer in ("gather", "trunk"):
+    if args.layer in ("gather", "trunk", "trunk_f16"):
         import types
         from snvc_amd.models.vernier import VernierScale
         grid = (32, 128, 192)
@@ -52,6 +52,9 @@ with torch.no_grad():
         gr = torch.from_numpy(np.stack([np.stack([base[::-1], base])] * n).copy()).to(dev)
         if args.layer == "gather":
             fn = lambda: vs.construct_voxel(lf, rf, gl, gr)  # noqa: E731
+        elif args.layer == "trunk_f16":      # released shape, fp16-storage mode: gather (C8 half) + trunk, 2 crops per call
+            lf2, rf2, gl2, gr2 = (torch.cat([t, t]) for t in (lf, rf, gl, gr))
+            fn = lambda: vs.trunk_3d_f16(vs.construct_voxel_f16(lf2, rf2, gl2, gr2))  # noqa: E731
         else:
             vox = vs.construct_voxel(lf, rf, gl, gr)
             fn = lambda: vs.trunk_3d(vox)  # noqa: E731
