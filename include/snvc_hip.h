@@ -181,7 +181,8 @@ enum {
  *                                register staged (STD), 4x4x32 register staged (NARROW_REG); default is
  *                                the 4x4x32 LDS-DMA staged tile at three workgroups per CU.  On a k3 /
  *                                stride-2 layer STD selects the per-chunk image refill form; the default there
- *                                is the slice-pipelined refill (counted vmcnt waits, conv3d.hip)
+ *                                is the slice-pipelined refill (counted vmcnt waits, conv3d.hip).  On a depth-1 k3 /
+ *                                stride-1 layer BIG forces the 1x16x32 Winograd form that large calls take by themselves
  *   SNVC_ALGO_GENERIC_EPILOGUE : scalar predicated epilogue instead of the 16-byte-store ones
  *   SNVC_ALGO_SCALAR_STAGING   : snvc_conv3d_wgrad only: element-wise staging instead of the float4 form */
 enum {

@@ -631,22 +631,24 @@ conv3d_mfma_kernel(const ConvArgs a) {
 // stages and V is formed in registers right after the fragment reads (one 16-byte and two 4-byte LDS
 // reads + 12 VALU ops per 6 MFMAs).  The 32 MFMA columns are 2 rows x 16 tiles of 4 outputs: a lane
 // owns 4 consecutive outputs, so the epilogue stores 16 bytes per lane and channel.
-template <int TD_, int TH_, int KC_, int PIECE_ = 4, int TW_ = 64, int OCC_ = 2>
+template <int TD_, int TH_, int KC_, int PIECE_ = 4, int TW_ = 64, int OCC_ = 2, int KSD_ = 3>
 struct WinoCfg {
     static constexpr int OCC = OCC_;   // workgroups per CU the register allocator is asked to allow
     static constexpr int TD = TD_, TH = TH_, KC = KC_, MI = 1, PIECE = PIECE_;
     static constexpr int KS = 3, NPOS = 6, STRIDE = 1;
+    static constexpr int KSD = KSD_;   // kernel extent along D: 3, or 1 for the depth-1 (2D neck) layers: 3 (kd, kh) taps instead of 9
     // The 32 MFMA columns are RPB rows x (TW/4) quads: 2 rows x 64 outputs, or 4 rows x 32 outputs for
     // layers whose width fills 64-wide tiles badly (W = 156 -> 3 x 64 is 81 % full, 5 x 32 is 97 %).
     static constexpr int TW = TW_, QUADS = TW / 4, RPB = 32 / QUADS, LPAD = 4, XOFF = 3;
     static_assert(TW == 64 || TW == 32, "tile width");
-    static constexpr int IN_D = TD + 2, IN_H = TH + 2, IN_W = TW + 2;
+    static constexpr int IN_D = TD + KSD - 1, IN_H = TH + 2, IN_W = TW + 2;
     static constexpr int IN_WV = (XOFF + IN_W + 3) / 4 * 4;   // 72
     using St = Stager<KC, IN_D, IN_H, IN_WV, PIECE>;
     static constexpr int CH = St::CH, TILE = St::TILE;
     static constexpr int NB = TD * TH / (4 * RPB);            // row BLOCKS (RPB rows) per wave (4 waves)
     static constexpr int KP = KC / 2;
-    static constexpr int WF = 9 * NPOS * KP * 64;             // packed floats per chunk: [tap9][pos][kp][lane]
+    static constexpr int NTAP = KSD * 3;                      // (kd, kh) taps
+    static constexpr int WF = NTAP * NPOS * KP * 64;          // packed floats per chunk: [tap9][pos][kp][lane]
     using Ws = WeightStager<WF>;
     static constexpr int LDS_BYTES = (TILE * 2 + WF * 2) * 4;
     static_assert(TD * TH % (4 * RPB) == 0 && TH % RPB == 0, "row blocks must split over 4 waves");
@@ -686,7 +688,7 @@ __device__ __forceinline__ void wino_load_step(const float *__restrict__ img, co
 template <class Cfg, class Mid>
 __device__ __forceinline__ void wino_compute_chunk(const float *__restrict__ img, const float *__restrict__ wl,
                                                    int bbase, int wave, f32x16 (&acc)[6][Cfg::NB], Mid &&mid) {
-    constexpr int NB = Cfg::NB, NS = 9 * Cfg::KP;
+    constexpr int NB = Cfg::NB, NS = Cfg::NTAP * Cfg::KP;
     constexpr bool PIPE = false;   // explicit one-step-ahead fragment reads measured slower (2.93 -> 3.05 ms on cfg2 conv1)
     WinoStep<NB> cur, nxt;
     if (PIPE) wino_load_step<Cfg>(img, wl, bbase, wave, 0, cur);
@@ -1208,7 +1210,7 @@ conv3d_wino_kernel(const ConvArgs a) {
     float *const aff = wlds + 2 * WF;      // scale | bias of this job's 32 channels
     const int nchunks = a.nchunks_wino;
     const float *wg = a.wp_wino + (int64_t)job.cg * nchunks * WF;
-    constexpr int NS = 9 * Cfg::KP;
+    constexpr int NS = Cfg::NTAP * Cfg::KP;
     // prefetch pieces are retired over the last steps of a chunk (weights first: they were requested
     // first); the first FIRST steps (>= 2.5k cycles of MFMAs) cover the global-memory latency.
     // Measured on cfg2 conv2: FIRST = 2 -> 1.92 ms, 3 -> 1.88, 5 -> 1.85, 7 -> 1.85.
@@ -1216,7 +1218,7 @@ conv3d_wino_kernel(const ConvArgs a) {
     constexpr int FIRST = NS > 5 ? 5 : NS - 1;
 
     St st;
-    st.init(tid, job.od0 - 1, job.oh0 - 1, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+    st.init(tid, job.od0 - Cfg::KSD / 2, job.oh0 - 1, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
     typename St::Vec pre[St::NIT];
         f32x4 wpre[Ws::NIT];
     st.load(xn, tid, a.Cin, pre);
@@ -1318,7 +1320,7 @@ conv3d_wino_dma_kernel(const ConvArgs a) {
     const float *wg = a.wp_wino + (int64_t)job.cg * nchunks * WF;
 
     St st;
-    st.init(tid, job.od0 - 1, job.oh0 - 1, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
+    st.init(tid, job.od0 - Cfg::KSD / 2, job.oh0 - 1, job.ow0 - Cfg::LPAD, a.Din, a.Hin, a.Win, in_hw, in_dhw);
     constexpr int WITEMS = WF / 4, WNIT = (WITEMS + 255) / 256;
     // Per-thread DMA sources live in registers for the whole job and advance by one chunk per issue (chunks are issued in
     // order): beside fp32 MFMAs a VALU instruction costs ~7 cycles of matrix-pipe time
@@ -2044,7 +2046,7 @@ __global__ void pack_deconv_weights_kernel(const float *__restrict__ w, float *_
 // Winograd packing (k3, s1): packed[cg][chunk][tap9 = kd*3+kh][pos][kp][half][i] = U_pos of the three kw taps of
 // W[co = cg*32 + i][ci = chunk*KC + 2kp + half][kd][kh][:]   (F(4,3): U = G g, formed in fp64, rounded once)
 __global__ void pack_wino_weights_kernel(const float *__restrict__ w, float *__restrict__ packed, int Cout, int Cin,
-                                         int KC, int nchunks, int64_t total) {
+                                         int KC, int nchunks, int64_t total, int ntap = 9) {   // ntap = 3: depth-1 layer [Cout][Cin][1][3][3]
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int KP = KC / 2;
@@ -2053,13 +2055,13 @@ __global__ void pack_wino_weights_kernel(const float *__restrict__ w, float *__r
     const int half = (int)(r % 2); r /= 2;
     const int kp = (int)(r % KP); r /= KP;
     const int pos = (int)(r % 6); r /= 6;
-    const int tap9 = (int)(r % 9); r /= 9;
+    const int tap9 = (int)(r % ntap); r /= ntap;
     const int chunk = (int)(r % nchunks); r /= nchunks;
     const int cg = (int)r;
     const int co = cg * 32 + ii, ci = chunk * KC + 2 * kp + half;
     double u = 0.0;
     if (co < Cout && ci < Cin) {
-        const float *g = w + (((int64_t)co * Cin + ci) * 9 + tap9) * 3;
+        const float *g = w + (((int64_t)co * Cin + ci) * ntap + tap9) * 3;
         const double g0 = g[0], g1 = g[1], g2 = g[2];
         switch (pos) {
             case 0: u = g0 / 4.0; break;
@@ -2185,7 +2187,8 @@ using CfgWinoBig = WinoCfg<4, 4, 2>;        // LDS-DMA staged, two row pairs per
 using CfgWino8  = WinoCfg<2, 4, 2, 2>;
 using CfgWinoN  = WinoCfg<4, 4, 2, 4, 32>;   // 32-wide tile (4 rows x 8 quads per MFMA column block): narrow layers
 using CfgWinoN8 = WinoCfg<4, 4, 2, 2, 32>;
-using CfgWinoN3 = WinoCfg<4, 4, 2, 4, 32, 3>;   // the 32-wide tile LDS-DMA staged: <= 168 VGPRs, 3 workgroups per CU       // the same for rows that are only 8-byte aligned (W % 4 == 2)
+using CfgWinoN3 = WinoCfg<4, 4, 2, 4, 32, 3>;
+using CfgWinoP  = WinoCfg<1, 16, 2, 4, 32, 3, 1>;   // depth-1 (2D neck) layers: 1 x 16 x 32 tile, 3 taps per chunk, 20 KB of LDS   // the 32-wide tile LDS-DMA staged: <= 168 VGPRs, 3 workgroups per CU       // the same for rows that are only 8-byte aligned (W % 4 == 2)
 using CfgWinoS2 = WinoS2Cfg<2>;
 using CfgWinoS2v8 = WinoS2Cfg<2, 2>;   // output rows only 8-byte aligned
 using CfgWinoK5 = WinoKCfg<5, 2>;
@@ -2300,7 +2303,18 @@ void launch_conv(const ConvArgs &a, dim3 grid, hipStream_t st) {
     launch_conv_variant<Cfg, 0>(a, grid, st);
 }
 
+// depth-1 k3 / stride-1 layers big enough for the 1 x 16 x 32 Winograd tile (the small levels of the neck stay on the direct
+// 1 x 4 x 32 form: a handful of workgroups either way)
+// (every depth-1 k3 / stride-1 layer CARRIES the Winograd weights: what is packed depends on the layer, never on the extents
+// of the probe it was packed with)
+inline bool planar_wino_weights(const snvc_conv3d_desc &d) {
+    return d.ksize_d == 1 && !d.transposed && d.ksize == 3 && (d.ksize_h == 0 || d.ksize_h == 3) && d.stride == 1 && d.dilation == 1;
+}
+inline bool planar_wino_layer(const snvc_conv3d_desc &d) { return planar_wino_weights(d) && d.Hout >= 32 && d.Wout >= 32; }
+
 inline int64_t wino_packed_count(const snvc_conv3d_desc &d) {
+    if (d.ksize_d == 1)
+        return planar_wino_weights(d) ? (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, 2) * CfgWinoP::WF : 0;
     if (!d.transposed && d.stride == 2 && d.ksize == 3 && d.dilation == 1)
         return (int64_t)ceil_div(d.Cout, 32) * ceil_div(d.Cin, 2) * 3 * CfgWinoS2::WF;
     if (d.transposed || d.stride != 1 || !(d.dilation == 1 || (d.dilation == 2 && d.ksize == 5))) return 0;
@@ -2449,7 +2463,7 @@ int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
     const bool planar = d->ksize_d == 1;      // depth-1 layer: only the direct packing, no special forms
     const int64_t taps = d->transposed ? 27 : (int64_t)(planar ? 1 : d->ksize) * (planar && d->ksize_h ? d->ksize_h : d->ksize) * d->ksize;
     int64_t count = (int64_t)p.groups * p.nchunks * taps * (p.KC / 2) * 64 * p.MI;
-    if (planar) return count;
+    if (planar) return count + wino_packed_count(*d);
     count += wino_packed_count(*d);   // k3/s1 layers also carry the Winograd-transformed weights
     // 1x1x1 layers with <= 2 output channels also keep their raw [Cout][Cin] weights (streaming kernel)
     if (!d->transposed && d->ksize == 1 && d->Cout <= 2) count += (int64_t)d->Cout * d->Cin;
@@ -2478,12 +2492,14 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
                            as_stream(stream)) != hipSuccess)
             return fail(SNVC_ERR_HIP, "snvc_conv3d_pack_weights: hipMemcpyAsync failed");
     }
-    const int64_t wino = planar ? 0 : wino_packed_count(*d);
+    const int64_t wino = wino_packed_count(*d);
     if (wino) {
         total -= wino;
         const unsigned wb = (unsigned)ceil_div<int64_t>(wino, 256);
         const int nck = ceil_div(d->Cin, 2);
-        if (d->ksize == 3 && d->stride == 2)
+        if (planar)
+            pack_wino_weights_kernel<<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino, 3);
+        else if (d->ksize == 3 && d->stride == 2)
             pack_winos2_weights_kernel<<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino);
         else if (d->ksize == 3)
             pack_wino_weights_kernel<<<wb, 256, 0, as_stream(stream)>>>(weight, packed + total, d->Cout, d->Cin, 2, nck, wino);
@@ -2716,6 +2732,24 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
                 else launch_winok<CfgWinoK7>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
                 return check_launch("snvc_conv3d_forward(winograd k5/k7)");
             }
+        }
+    }
+    // depth-1 k3 / stride 1 (the 2D neck's larger levels) on 16-byte rows: the same Winograd kernel on 1 x 16 x 32 tiles with
+    // 3 taps per chunk instead of 9 (half the MFMAs of the direct depth-1 form)
+    if (planar && planar_wino_layer(*d) && a.vec && epi16 && fast_common && !direct_only && !depth_planes && !head_w && !pooled && !stats) {
+        const int th_ = ceil_div(d->Hout, CfgWinoP::TH), tw_ = ceil_div(d->Wout, CfgWinoP::TW), groups_ = ceil_div(d->Cout, 32);
+        const int64_t nj = (int64_t)th_ * tw_ * groups_ * d->N;
+        // a job is a serial chain of Cin / 2 chunks: below two jobs per CU the direct form's 4x smaller tiles (4x the
+        // workgroups) finish sooner (2 crops of the released shape: heads 0.46 vs 0.44 ms/crop; 8 crops: 0.164 vs 0.196)
+        const bool forced = (d->algo & SNVC_ALGO_WINO_TILE_MASK) == SNVC_ALGO_WINO_TILE_BIG;     // tests reach the form on small inputs
+        if ((forced || nj >= 2 * device_cu_count()) && nj < ((int64_t)1 << 31)) {
+            a.wp_wino = packed_weight + (int64_t)p.groups * p.nchunks * 9 * (p.KC / 2) * 64 * p.MI;
+            a.nchunks_wino = ceil_div(d->Cin, CfgWinoP::KC);
+            a.groups = groups_;
+            a.tiles_d = 1; a.tiles_h = th_; a.tiles_w = tw_;
+            a.njobs = (int)nj;
+            launch_wino_dma<CfgWinoP>(a, dim3((unsigned)nj, 1, 1), as_stream(stream));
+            return check_launch("snvc_conv3d_forward(depth-1 winograd)");
         }
     }
     // k3 / stride 1: Winograd F(4,3) along W when the rows allow 8-byte pair stores and 16-byte staging

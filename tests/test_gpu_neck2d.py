@@ -24,7 +24,10 @@ def _bn_eval(y, bn):
 
 
 @pytest.mark.parametrize("k,stride", [(1, 1), (1, 2), (3, 1), (3, 2)])
-@pytest.mark.parametrize("cin,cout,hw", [(32, 64, (24, 40)), (9, 32, (6, 4)), (64, 27, (13, 34)), (256, 64, (16, 24))])
+@pytest.mark.parametrize("cin,cout,hw", [(32, 64, (24, 40)), (9, 32, (6, 4)), (64, 27, (13, 34)), (256, 64, (16, 24)),
+                                         # >= 32 x 32 with 16-byte rows and whole channel groups: k3 / stride 1 takes the depth-1
+                                         # Winograd form (1 x 16 x 32 tiles: ragged in H and W here, odd channel count)
+                                         (64, 64, (40, 72)), (7, 32, (33, 36)), (256, 64, (64, 96))])
 def test_fused_conv2d_vs_torch(k, stride, cin, cout, hw):
     from snvc_amd.models import submodule as S
     r = np.random.default_rng(1000 + 10 * k + stride + cin)
@@ -46,6 +49,16 @@ def test_fused_conv2d_vs_torch(k, stride, cin, cout, hw):
         check(S.fused_conv2d(conv, bn, xd, relu=True, residual=rd, residual_after_act=True).cpu().numpy(),
               (F.relu(ref) + res).numpy(), TIGHT, "relu(bn(conv)) + res")
         check(S.fused_conv2d(conv, bn, xd, sigmoid=True).cpu().numpy(), torch.sigmoid(ref).numpy(), TIGHT, "sigmoid(bn(conv))")
+        if k == 3 and stride == 1 and min(hw) >= 32:
+            # the depth-1 Winograd form (taken by itself from two jobs per CU on; forced here): bit-different from the direct form
+            from snvc_amd import _lib, ops
+            direct = S.fused_conv2d(conv, bn, xd, relu=True, residual=rd)
+            with ops.conv_variant(_lib.ALGO_WINO_TILE_BIG):
+                wino = S.fused_conv2d(conv, bn, xd, relu=True, residual=rd)
+                check(wino.cpu().numpy(), F.relu(ref + res).numpy(), TIGHT, "relu(bn(conv) + res), depth-1 Winograd")
+                check(S.fused_conv2d(conv, None, xd).cpu().numpy(), raw.numpy(), TIGHT, "conv, depth-1 Winograd")
+            if cout % 32 == 0 and hw[1] % 4 == 0:
+                assert not torch.equal(wino, direct), "the forced form is a different kernel"
 
 
 def test_fused_conv2d_bias_and_whole_extent_layer():
