@@ -1660,9 +1660,10 @@ __device__ __forceinline__ void deconv_compute_chunk(const float *__restrict__ b
 // classifier after the hourglass, stereo_volume.py): the 32-channel dot product is formed here -- 16 channels
 // per lane, the other 16 in lane ^ 32 -- and only the single-channel result is stored (1/32 of the bytes; the
 // full-resolution tensor and the classifier's pass over it disappear).
-template <class Cfg, int PD, int PH, bool RES, bool HEAD = false>
+template <class Cfg, int PD, int PH, bool RES, bool HEAD = false, bool STATS = false>
 __device__ __forceinline__ void deconv_epilogue_fast(const ConvArgs &a, f32x16 (&acc)[2][Cfg::NB][Cfg::MI], int id0,
-                                                     int ih0, int iw0, int cg, int64_t n, int lane, int wave) {
+                                                     int ih0, int iw0, int cg, int64_t n, int lane, int wave,
+                                                     float *xch = nullptr) {
     constexpr int MI = Cfg::MI, TH = Cfg::TH, NB = Cfg::NB;
     const int iw = iw0 + (lane & 31), half = lane >> 5;
     const int out_hw = a.Hout * a.Wout, out_dhw = out_hw * a.Dout;
@@ -1710,6 +1711,39 @@ __device__ __forceinline__ void deconv_epilogue_fast(const ConvArgs &a, f32x16 (
                 for (int q = 0; q < RBATCH; ++q)
                     asm volatile("" : "+v"(acc[0][nb][m][r0 + q]), "+v"(acc[1][nb][m][r0 + q])::"memory");
             }
+    }
+    if constexpr (STATS) {
+        // Batch statistics of the layer's result while it is in registers (train-mode BatchNorm, as wino_epilogue's XMODE 3):
+        // fp32 (sum, sum of squares) of a lane's <= 2*NB in-range values per channel, added over the 32 lanes of its half-wave
+        // with xor shuffles, over the four waves through 1 KB of LDS, in fp64 -> a.stats[workgroup slot][32 channels][2].
+        static_assert(MI == 1, "one 32-channel group per workgroup");
+        float *const P = xch;                       // [4 waves][64]: channel (r, half) x (sum | sum of squares)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float su = 0.0f, sq = 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float v0 = ok[nb] ? acc[0][nb][0][r] : 0.0f, v1 = ok[nb] ? acc[1][nb][0][r] : 0.0f;
+                su += v0 + v1;
+                sq += v0 * v0 + v1 * v1;
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) { su += __shfl_xor(su, o); sq += __shfl_xor(sq, o); }
+            if ((lane & 31) == 0) {
+                const int ch = (r & 3) + 8 * (r >> 2) + 4 * half;
+                P[wave * 64 + 2 * ch] = su;
+                P[wave * 64 + 2 * ch + 1] = sq;
+            }
+        }
+        __syncthreads();
+        const int tid = wave * 64 + lane;
+        if (tid < 64) {
+            double t = 0.0;
+            for (int w = 0; w < 4; ++w) t += (double)P[w * 64 + tid];
+            const int64_t slot = ((n * gridDim.x + blockIdx.x) * gridDim.y + cg);
+            a.stats[slot * 64 + tid] = t;
+        }
     }
     if constexpr (HEAD) {
         static_assert(MI == 1, "the fused head covers one 32-channel group");
@@ -1812,7 +1846,9 @@ __device__ __forceinline__ void deconv_class_body(const ConvArgs &a, float *lds,
     }
 
     if constexpr (EPI != 0) {
-        if constexpr (EPI >= 3 && Cfg::MI == 1)
+        if constexpr (EPI == 5 && Cfg::MI == 1)
+            deconv_epilogue_fast<Cfg, PD, PH, false, false, true>(a, acc, id0, ih0, iw0, cg, n, lane, wave, lds);
+        else if constexpr (EPI >= 3 && Cfg::MI == 1)
             deconv_epilogue_fast<Cfg, PD, PH, EPI == 4, true>(a, acc, id0, ih0, iw0, cg, n, lane, wave);
         else
             deconv_epilogue_fast<Cfg, PD, PH, EPI == 2>(a, acc, id0, ih0, iw0, cg, n, lane, wave);
@@ -2403,7 +2439,9 @@ void launch_deconv_variant(const ConvArgs &a, dim3 grid, hipStream_t st) {
 template <class Cfg>
 void launch_deconv(const ConvArgs &a, dim3 grid, hipStream_t st) {
     // the pair exchange of the fast epilogue needs an even input width (both lanes of a pair in range)
-    if (a.head_w) {   // validated by snvc_conv3d_forward_head: fast epilogue conditions hold, one channel group
+    if (a.stats) {    // validated by conv3d_forward_impl: fast epilogue conditions, one channel group per workgroup, no addends
+        if constexpr (Cfg::MI == 1) launch_deconv_variant<Cfg, 5>(a, grid, st);
+    } else if (a.head_w) {   // validated by snvc_conv3d_forward_head: fast epilogue conditions hold, one channel group
         if constexpr (Cfg::MI == 1) {
             if (a.res) launch_deconv_variant<Cfg, 4>(a, grid, st);
             else launch_deconv_variant<Cfg, 3>(a, grid, st);
@@ -2450,7 +2488,11 @@ conv_stats_fold_kernel(const double *__restrict__ stats, double *__restrict__ pa
     }
 }
 // the Winograd tiling of the layers the statistics epilogue is built for (the dispatcher's default forms)
-inline int64_t stats_tiles(const snvc_conv3d_desc &d) { return (int64_t)ceil_div(d.Dout, 4) * ceil_div(d.Hout, 4) * ceil_div(d.Wout, 32); }
+inline int64_t stats_tiles(const snvc_conv3d_desc &d) {
+    if (d.transposed)   // four parity classes of 2 x 4 x 32 INPUT tiles (DeconvCfg<1, 2, 4, 4>), one workgroup slot each
+        return 4 * (int64_t)ceil_div(d.Din, 2) * ceil_div(d.Hin, 4) * ceil_div(d.Win, 32);
+    return (int64_t)ceil_div(d.Dout, 4) * ceil_div(d.Hout, 4) * ceil_div(d.Wout, 32);
+}
 }  // namespace
 }
 
@@ -2568,10 +2610,10 @@ int snvc_conv3d_forward_stats(const snvc_conv3d_desc *d, const float *x, const f
     using namespace snvc;
     if (!d || !y || !scale || !shift || !workspace) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward_stats: null pointer");
     if (d->N <= 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_forward_stats: empty batch");
-    if (d->flags || d->transposed || d->ksize_d == 1 || d->ksize != 3 || d->dilation != 1 || (d->stride != 1 && d->stride != 2) ||
-        d->Cout % 32 != 0)
-        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_stats: built for 3x3x3 Conv3d layers (stride 1 or 2) with whole "
-                                          "32-channel groups and no epilogue");
+    if (d->flags || d->ksize_d == 1 || d->ksize != 3 || d->dilation != 1 || (d->stride != 1 && d->stride != 2) || d->Cout % 32 != 0 ||
+        (d->transposed && d->stride != 2))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_stats: built for 3x3x3 Conv3d layers (stride 1 or 2) and "
+                                          "ConvTranspose3d(k3,s2,p1,op1) with whole 32-channel groups and no epilogue");
     double *stats = static_cast<double *>(workspace);
     int rc = conv3d_forward_impl(d, x, packed_weight, nullptr, nullptr, nullptr, nullptr, y, nullptr, nullptr, stream, stats);
     if (rc) return rc;
@@ -2810,8 +2852,8 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
             }
         }
     }
-    if (stats)
-        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_stats: the layer's rows do not allow the Winograd forms that carry the statistics epilogue");
+    if (stats && !(p.kind == DC_M1 && a.vec && a.fast_epi && d->Win % 2 == 0 && !a.res && !head_w))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_stats: the layer's rows do not allow the kernel forms that carry the statistics epilogue");
     if (side_head)
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_conv3d_forward_side_head: built for 3x3x3 / stride-1 layers on the Winograd path");
     if (pooled)

@@ -380,7 +380,7 @@ class Conv3dLayer:
         (snvc_conv3d_forward_stats): returns (raw, scale, shift, mean, var) with the [1, C] shapes of ``norm_stats``, or None
         when the layer does not take a kernel form that carries the statistics epilogue (nothing was launched)."""
         _gpu(x, "x")
-        if (self.planar or self.transposed or self.ksize != 3 or self.dilation != 1 or self.stride not in (1, 2) or self.cout % 32
+        if (self.planar or self.ksize != 3 or self.dilation != 1 or self.stride not in (1, 2) or (self.transposed and self.stride != 2) or self.cout % 32
                 or x.dtype != torch.float32 or x.dim() != 5 or x.size(1) != self.cin or x.size(0) == 0 or _algo() != 0):
             return None
         if not _dense_inner(x):

@@ -1158,7 +1158,7 @@ def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
     check(got, general, 2e-5, f"sheared vs general path q={q} m0={m0}")
 
 
-@pytest.mark.parametrize("case", ["k3s1_32", "k3s1_64_ragged", "k3s2_32_64", "k3s2_ragged", "unsupported_w78"])
+@pytest.mark.parametrize("case", ["k3s1_32", "k3s1_64_ragged", "k3s2_32_64", "k3s2_ragged", "deconv_64_32", "deconv_ragged", "unsupported_w78"])
 def test_conv_statistics_epilogue_vs_separate_pass(case):
     """snvc_conv3d_forward_stats: the convolution result is bit-identical to the plain launch and the batch statistics taken in
     its epilogue equal snvc_norm_stats' over that tensor (fp64 sums in a different order: 1e-6), for tile-ragged extents, two
@@ -1166,13 +1166,16 @@ def test_conv_statistics_epilogue_vs_separate_pass(case):
     from snvc_amd import ops
     cin, cout, stride, shape = {"k3s1_32": (32, 32, 1, (8, 8, 64)), "k3s1_64_ragged": (6, 64, 1, (5, 7, 72)),
                                 "k3s2_32_64": (32, 64, 2, (8, 16, 128)), "k3s2_ragged": (4, 32, 2, (10, 14, 72)),
+                                "deconv_64_32": (64, 32, 2, (4, 8, 64)), "deconv_ragged": (6, 64, 2, (3, 5, 36)),
                                 "unsupported_w78": (8, 32, 1, (4, 4, 78))}[case]
+    transposed = case.startswith("deconv")
     r = np.random.default_rng(231)
-    w = torch.from_numpy((0.1 * r.standard_normal((cout, cin, 3, 3, 3))).astype(np.float32)).to(dev())
+    wshape = (cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3)
+    w = torch.from_numpy((0.1 * r.standard_normal(wshape)).astype(np.float32)).to(dev())
     x = torch.from_numpy(r.standard_normal((2, cin) + shape).astype(np.float32)).to(dev())
     gamma = torch.from_numpy(r.uniform(0.5, 1.5, cout).astype(np.float32)).to(dev())
     beta = torch.from_numpy(r.standard_normal(cout).astype(np.float32)).to(dev())
-    layer = ops.Conv3dLayer(w, 3, stride, 1, 1, False)
+    layer = ops.Conv3dLayer(w, 3, stride, 1, 1, transposed)
     got = layer.forward_stats(x, gamma, beta, 1e-5)
     if case.startswith("unsupported"):
         assert got is None
