@@ -319,3 +319,42 @@ def test_training_step_full_size_properties():
     assert e <= 5e-5, e
     via_w = (conv.weight.detach().double() * dw_wino.double()).sum().item()
     assert abs(lhs - via_w) <= 4 * tol_w, (lhs, via_w, tol_w)
+
+
+def test_training_step_full_size_sheared_vs_general():
+    """cfg4 at full size: the step through the sheared first layer with the train-mode BatchNorm folded around it
+    (_ShearedFirstConvBNFn: no raw result, no raw gradient, statistics in the kernels' epilogues) against the same step on the
+    general factored function (``sheared=False``: warped half built, 3D weight / data gradients, separate statistics passes):
+    same loss, every parameter gradient and both feature gradients within the bounds of the DIRECT-vs-Winograd comparison
+    above (the two paths differ by fp32 summation order, which flips ~1e-5 of the ReLU masks)."""
+    import bench
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+
+    def step(sheared):
+        m = GlobalStack(C)
+        m.load_state_dict(bench.seeded_state(m))
+        m.train().to(dev())
+        left, right, shift = bench.make_inputs(0, dev())
+        left.requires_grad_(); right.requires_grad_()
+        before = S._ROUTES["sheared_first_conv_train_fused_bn"]
+        out = m.forward_pair(left, right, shift, 1, sheared=sheared)
+        loss = out.pow(2).mean()
+        loss.backward()
+        assert S._ROUTES["sheared_first_conv_train_fused_bn"] == before + (1 if sheared else 0)
+        grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        grads["left"], grads["right"] = left.grad.clone(), right.grad.clone()
+        stats = {k: v.detach().clone() for k, v in m.state_dict().items() if "running" in k}
+        return loss.item(), grads, stats
+
+    l0, g0, s0 = step(True)
+    torch.cuda.empty_cache()
+    l1, g1, s1 = step(False)
+    assert np.isfinite(l0) and abs(l0 - l1) <= 1e-4 * abs(l1)
+    for k in g0:
+        assert torch.isfinite(g0[k]).all(), k
+        e = (g0[k] - g1[k]).abs().max().item() / max(g1[k].abs().max().item(), 1e-30)
+        assert e < (5e-2 if k in ("left", "right") else 5e-3), (k, e)
+    for k in s0:        # BatchNorm bookkeeping moved the same way on both paths
+        e = (s0[k] - s1[k]).abs().max().item() / max(s1[k].abs().max().item(), 1e-30)
+        assert e < 1e-4, (k, e)
