@@ -499,7 +499,7 @@ def main():
     model.eval().to(device)
     left, right, shift = make_inputs(rank, device)
 
-    def run(factored, sheared=True):
+    def run(factored, sheared=True, commuted=True):
         """W warm-up + K timed steps; returns (seconds for the K steps, mean ms of the "conv1" bracket, of the "volume"
         bracket and of the "conv2" bracket).  sheared path: volume = Rq + the 2D convolution G + the 4-plane edge slab,
         conv1 = the expand pass (0.74 GB write) + edge-plane copies; general path: volume = the right-half cost-volume
@@ -518,7 +518,7 @@ def main():
             t0 = time.perf_counter()
             for i in range(args.steps):
                 # events go to torch's current stream == the stream the kernels are launched on
-                out = model.forward_pair(left, right, shift, 1, factored=factored, timing=ev[i], sheared=sheared)
+                out = model.forward_pair(left, right, shift, 1, factored=factored, timing=ev[i], sheared=sheared, commuted=commuted)
             barrier()
             elapsed = time.perf_counter() - t0
             gc.enable()
@@ -542,7 +542,8 @@ def main():
     routes0 = S_._ROUTES["sheared_first_conv"]
     elapsed, expand_ms, shear_prep_ms, conv2_ms = run(True)
     sheared_taken = S_._ROUTES["sheared_first_conv"] > routes0
-    elapsed_gen, conv_ms, cvr_ms, _ = run(True, sheared=False)
+    elapsed_gen, warp_expand_ms, warp_prep_ms, _ = run(True, sheared=False)                  # any shift array: warp after convolution
+    elapsed_built, conv_ms, cvr_ms, _ = run(True, sheared=False, commuted=False)              # right half built + 3D convolution over it
     elapsed_mat, conv_ms_mat, cv_ms, _ = run(False)
 
     def run_reference_api():
@@ -616,8 +617,11 @@ def main():
                              "spaced (shift = d/2), so it is a shear of one 2D image and conv1 over it is a 2D convolution "
                              "evaluated along the shear (" + ("taken" if sheared_taken else "NOT taken") + "; csrc/sheared_conv.hip; "
                              "tests/test_gpu_parity.py::test_sheared_first_conv_vs_oracle_and_general_path, tests/test_gpu_fullsize.py)",
-                    "general_shift": "the same entry point for ANY shift array (sheared=False): factored first convolution over "
-                                     "the built right half of the volume",
+                    "general_shift": "the same entry point for ANY shift array (sheared=False): interpolation along w commutes with "
+                                     "the convolution -- three 2D convolutions of the right feature + three interpolations per "
+                                     "output voxel (snvc_warped_expand); the warped volume is not built either",
+                    "built_right_half": "forward_pair(..., sheared=False, commuted=False): right half of the volume built, factored "
+                                        "first 3D convolution over it (r2's path)",
                     "reference_api": "model(build_cost_volume(left, right, shift, 1)): same kernels as `value` (lazy volume)",
                     "materialized": "the full concat volume built in HBM, then the modules (conv1 over all 64 channels)"},
                 "pairs_per_gpu_per_step": 1,
@@ -669,10 +673,17 @@ def main():
                 "ms_per_step": 1e3 * elapsed_api / args.steps,
             },
             "general_shift": {
-                "note": "same step on the path any shift array takes (forward_pair(..., sheared=False)): right half of the volume "
-                        "built (cost_volume_fwd_rows), factored first 3D convolution over it",
+                "note": "same step on the path any shift array takes (forward_pair(..., sheared=False)): warp after convolution "
+                        "(csrc/sheared_conv.hip: three depth-1 convolutions of the right feature + snvc_warped_expand)",
                 "value": world * args.steps / elapsed_gen,
                 "ms_per_step": 1e3 * elapsed_gen / args.steps,
+                "expand_ms": warp_expand_ms, "prep_ms": warp_prep_ms,
+            },
+            "built_right_half": {
+                "note": "same step with the right half of the volume built (cost_volume_fwd_rows) and the factored first 3D "
+                        "convolution over it (forward_pair(..., sheared=False, commuted=False))",
+                "value": world * args.steps / elapsed_built,
+                "ms_per_step": 1e3 * elapsed_built / args.steps,
                 "conv1_ms": conv_ms, "conv1_pipe_frac": dom_flop * share / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "volume_ms": cvr_ms,
             },

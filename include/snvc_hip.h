@@ -317,6 +317,17 @@ SNVC_API int snvc_conv3d_forward_stats(const snvc_conv3d_desc *desc_host, const 
  *   snvc_sheared_expand   : y[n][co][d][h][w] = epilogue(scale*G[n][cls(d)][co][h][q*w - d - m0 + off] + planes[n][co][cls(d)][h][w]),
  *                           G'[..][q*(W-1) - d - m0 + off2] in place of G at w = W-1; g [N][3][C][H][WG], gcol [N][3][C][H][WG2],
  *                           planes = the depth-class planes of snvc_conv3d_forward_ex (or NULL). */
+/* The same first convolution for an ARBITRARY shift array (shift >= 0): linear interpolation along w commutes with the
+ * convolution, so conv3d(warped half)[co][d][h][w] = sum_kd lerp(P_kd[co][h][:], w - shift[d+kd-1]) with P_kd = the depth-1 3x3
+ * convolution of the right feature with the layer's kd slice -- three 2D convolutions computed once and three
+ * interpolations per output voxel; the two places where the reference is not "interpolate the zero-extended signal" are
+ * corrected exactly (csrc/sheared_conv.hip: q = the kw = +1 taps alone, for the zero padding at w = W-1; e = the (c, kh)
+ * contraction of the image's first column per (kd, kw), for the gate x >= 0).  The warped volume is never built.
+ *   y[n][co][d][h][w] = epilogue(scale * (sum_kd ...) + planes[n][co][cls(d)][h][w] ...)
+ *   p, q [N][3][C][H][W], e [N][3][3][C][H][4] (column 0 used), planes [N][C][3][H][W] or NULL, shift [N][D] float32. */
+SNVC_API int snvc_warped_expand(const float *p, const float *q, const float *e, const float *planes, const float *shift,
+                                const float *scale, const float *bias, float *y, int64_t N, int64_t C, int64_t D, int64_t H,
+                                int64_t W, int flags, void *stream);
 /* Structure of a float32 shift array [N][D] in one launch: out4 = { all >= 0, every row == shift[0][0] + d (q = 1),
  * every row == shift[0][0] + d/2 (q = 2), shift[0][0] } (flags as 1.0 / 0.0, exact fp32 comparisons).  The caller reads the four
  * floats back: the same single device -> host sync as the reference wrapper's `assert torch.all(shift >= 0)`

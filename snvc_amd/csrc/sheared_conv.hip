@@ -202,6 +202,134 @@ shift_structure_kernel(const float *__restrict__ shift, float *__restrict__ out,
     if (threadIdx.x == 3) out[3] = s0;
 }
 
+// ------------------------------------------------------------------------------------ any shift array: warp AFTER the convolution
+// For an ARBITRARY shift array the warped half is still a per-plane horizontal resampling of ONE image, V[c][d][h][w'] =
+// lerp(R0[c][h][:], w' - s_d) (R0 = the right feature, zero outside the image; BuildCostVolume_cuda.cu:63-98), and a linear
+// interpolation along w commutes with a convolution along (c, h, w).  So
+//     conv3d(V)[co][d][h][w] = sum_{kd, 0 <= d+kd-1 < D}  lerp(P_kd[co][h][:], w - s_{d+kd-1}),     P_kd = conv2d(R0, Wt[:, :, kd])
+// -- three 2D convolutions of the feature, computed ONCE, and three interpolations per output voxel instead of 27 x C
+// multiply-adds -- up to the two places where the reference is NOT "interpolate the zero-extended signal":
+//   (a) zero padding of the 3D convolution on the right: at w = W-1 the kw = +1 tap reads V[W] = 0, while P_kd there includes
+//       lerp(R0, W - s) != 0.  Q_kd[co][h][j] = sum_{c,kh} Wt[co][c][kd][kh][kw=+1] R0[c][h+kh-1][j] (the same depth-1 launch,
+//       kernels with only their centre column set) gives that term exactly: out[W-1] -= lerp(Q_kd, W - s).
+//   (b) the left edge, two single-column terms around w = m = floor(s), both multiples of E[kd][kw][co][h] = the (c, kh)
+//       contraction of the image's FIRST column with the kw taps (a depth-1 launch on a 4-column slab): the correlation at
+//       column -1, P_kd[-1] = E[kd][+1], which zero-extended rows lack; and the gate x >= 0 (BuildCostVolume_cuda.cu:88): for a
+//       fractional s the sample at w' = m has x = -frac(s) < 0 and is ZERO in the reference while the zero-extended
+//       interpolation gives (1 - frac(s)) * R[0]; it feeds the outputs w = m + 1 - kw through one kw tap each.
+// The interpolation's right edge needs nothing: for x in (W-2, W-1] the zero-extended lerp is the reference's clamped one.
+// Same values as the 3D convolution over the built volume up to fp32 summation order (tests: random shift arrays against
+// that path and against the oracle).  p / q: [N][3 kd][C][H][W]; e: [N][3 kd][3 kw][C][H][4] (column 0 used).
+// Inner loop without a data-dependent branch: the border terms are folded into the staged rows.
+//   rows F (the f-term reads them): P_kd zero-extended, with the one column the zero extension gets wrong set right: F[-1] = E2
+//   rows G (the g-term reads them for a fractional shift): F with the gated sample's share removed, G[-1] = 0, G[0] = P[0] - E1,
+//          G[1] = P[1] - E0  (for a whole-pixel shift the g-term reads F: nothing is gated)
+//   ta[kd][row][dd] = the last column's (a) term f * Q0[W-m-1] + g * Qg[W-m] of plane dd (Qg[0] = 0 for a fractional shift),
+//          tabulated once per workgroup: no global load inside the walk
+__global__ void __launch_bounds__(512)
+warped_expand_kernel(const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
+                     const float *__restrict__ planes, const float *__restrict__ shift, const float *__restrict__ scale,
+                     const float *__restrict__ bias, float *__restrict__ y, int C, int D, int H, int W, int RB, int flags) {
+    // rows [2 (F | G)][3 kd][RB][LW], each with W + 4 zeros in front and 4 behind: the interpolation reads columns
+    // w - m - 1 .. w - m + 3 (0 <= m <= W) without a bounds test
+    extern __shared__ float lds[];
+    const int quads = W >> 2, LW = 2 * W + 8, Z = W + 4;
+    const int tid = threadIdx.x;
+    const int co = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int h0 = blockIdx.x * RB;
+    const int rows = (H - h0) < RB ? (H - h0) : RB;
+    const int64_t hw = (int64_t)H * W;
+    float *const rowsG = lds + 3 * RB * LW;
+    float *const ta = rowsG + 3 * RB * LW;              // [3][RB][D]
+    const float *sh = shift + n * D;
+    for (int i = tid; i < 3 * rows * (LW >> 2); i += blockDim.x) {
+        const int row = i / (LW >> 2), pc = i - row * (LW >> 2);          // piece pc of LDS row (kd, r)
+        const int kd = row / rows, r = row - kd * rows, col = 4 * pc - Z;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (col >= 0 && col < W) v = *reinterpret_cast<const f32x4 *>(p + (((n * 3 + kd) * C + co) * (int64_t)H + h0 + r) * W + col);
+        f32x4 g4 = v;
+        const float *er = e + (((n * 3 + kd) * 3) * C + co) * (int64_t)H * 4 + (int64_t)(h0 + r) * 4;     // E[kd][kw][co][h][0], kw stride C*H*4
+        const int64_t kws = (int64_t)C * H * 4;
+        if (col == -4) { v[3] = er[2 * kws]; g4[3] = 0.0f; }              // column -1
+        if (col == 0) { g4[0] = v[0] - er[kws]; g4[1] = v[1] - er[0]; }   // columns 0, 1
+        *reinterpret_cast<f32x4 *>(lds + (kd * RB + r) * LW + 4 * pc) = v;
+        *reinterpret_cast<f32x4 *>(rowsG + (kd * RB + r) * LW + 4 * pc) = g4;
+    }
+    for (int i = tid; i < 3 * rows * D; i += blockDim.x) {
+        const int kd = i / (rows * D), r = (i / D) % rows, dd = i % D;
+        const float s = sh[dd];
+        float t = 0.0f;
+        if (s <= (float)W) {
+            const float mf = __builtin_floorf(s), f = s - mf, g = 1.0f - f;
+            const int m = (int)mf, i0 = W - m - 1;
+            const float *qr = q + (((n * 3 + kd) * C + co) * (int64_t)H + h0 + r) * W;
+            const float a0 = (unsigned)i0 < (unsigned)W ? qr[i0] : 0.0f;
+            float a1 = (unsigned)(i0 + 1) < (unsigned)W ? qr[i0 + 1] : 0.0f;
+            if (i0 + 1 == 0 && f > 0.0f) a1 = 0.0f;                       // Qg[0]: the gated sample's share
+            t = f * a0 + g * a1;
+        }
+        ta[(kd * RB + r) * D + dd] = t;
+    }
+    __syncthreads();
+    if (tid >= rows * quads) return;
+    const int r = tid / quads, qd = tid - r * quads, w0 = 4 * qd, h = h0 + r;
+    const bool last = qd == quads - 1;
+    const float sc = scale ? scale[co] : 1.0f, bi = scale ? bias[co] : 0.0f;
+    const bool relu = (flags & SNVC_EPI_RELU) != 0;
+    f32x4 pl[3];
+#pragma unroll
+    for (int cls = 0; cls < 3; ++cls) {
+        pl[cls] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (planes) pl[cls] = *reinterpret_cast<const f32x4 *>(planes + (((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w0);
+    }
+    float *yp = y + ((n * C + co) * (int64_t)D) * hw + (int64_t)h * W + w0;
+    const int lane_off = r * LW + Z + w0 - 4;           // + kd * RB * LW - m, rounded down to a piece: the quad's window
+    const float *tar = ta + r * D;
+    // the shifts of planes d-1, d, d+1 ride in scalar registers; the next one is requested an iteration ahead.  +inf marks
+    // "no such plane" (zero padding in depth) and takes the same exit as a shift beyond the image
+    const float none = __builtin_inff();
+    float sk[3] = {none, sh[0], D > 1 ? sh[1] : none};
+    for (int d = 0; d < D; ++d) {
+        const float snext = d + 2 < D ? sh[d + 2] : none;
+        f32x4 o = d == 0 ? pl[0] : (d == D - 1 ? pl[2] : pl[1]);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            // wave-uniform, and SAID so: m, f and the alignment pick below live in scalar registers, every branch on them is scalar
+            const float s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sk[kd])));
+            if (!(s <= (float)W)) continue;             // no plane, or every sample left of the image
+            const float mf = __builtin_floorf(s), f = s - mf, g = 1.0f - f;
+            const int m = (int)mf;
+            // out[w] += f * F[w - m - 1] + g * Gsel[w - m]: the window F[w0 - m - 1 .. w0 - m + 3] starts (3 - m) & 3 floats past a
+            // 16-byte boundary that is the same for every lane: three aligned 16-byte reads per row and a wave-uniform pick
+            const int a = (3 - m) & 3, mb = m + a - 3;  // mb = 4 * (m / 4)
+            const float *fr = lds + kd * RB * LW + lane_off - mb;
+            const float *gr = (f > 0.0f ? rowsG : lds) + kd * RB * LW + lane_off - mb;
+            const f32x4 FA = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(fr, 16));
+            const f32x4 FB = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(fr + 4, 16));
+            const f32x4 GA = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(gr, 16));
+            const f32x4 GB = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(gr + 4, 16));
+            // the eight floats read hold window element i (column w0 - m - 1 + i) at position a + i: F needs i = 0..3, G i = 1..4
+            float fv[4], gv[4];
+            if (a == 0) { fv[0] = FA[0]; fv[1] = FA[1]; fv[2] = FA[2]; fv[3] = FA[3]; gv[0] = GA[1]; gv[1] = GA[2]; gv[2] = GA[3]; gv[3] = GB[0]; }
+            else if (a == 1) { fv[0] = FA[1]; fv[1] = FA[2]; fv[2] = FA[3]; fv[3] = FB[0]; gv[0] = GA[2]; gv[1] = GA[3]; gv[2] = GB[0]; gv[3] = GB[1]; }
+            else if (a == 2) { fv[0] = FA[2]; fv[1] = FA[3]; fv[2] = FB[0]; fv[3] = FB[1]; gv[0] = GA[3]; gv[1] = GB[0]; gv[2] = GB[1]; gv[3] = GB[2]; }
+            else { fv[0] = FA[3]; fv[1] = FB[0]; fv[2] = FB[1]; fv[3] = FB[2]; gv[0] = GB[0]; gv[1] = GB[1]; gv[2] = GB[2]; gv[3] = GB[3]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += f * fv[k] + g * gv[k];
+            const float tl = tar[kd * RB * D + d + kd - 1];
+            o[3] -= last ? tl : 0.0f;                   // (a): the kw = +1 tap of the last column reads the zero padding
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = o[k] * sc + bi;
+            o[k] = relu ? (t > 0.0f ? t : 0.0f) : t;
+        }
+        *reinterpret_cast<f32x4 *>(yp + (int64_t)d * hw) = o;
+        sk[0] = sk[1]; sk[1] = sk[2]; sk[2] = snext;
+    }
+}
+
 // ------------------------------------------------------------------------------------ backward (training, cfg4)
 // Adjoint of sheared_expand_kernel w.r.t. G and G' (scale = 1: the caller applies the norm's backward first):
 //     dG[n][cls][co][h][i]  = sum over (d in class cls, w <= W-2) with Q*w - d - m0 + off  == i of dy[n][co][d][h][w]
@@ -734,6 +862,33 @@ int snvc_sheared_backward_reduce(const float *g, const float *gcol, const float 
     if (rc) return rc;
     sheared_fold_kernel<<<(unsigned)ceil_div<int64_t>(N * C, 128), 128, 0, as_stream(stream)>>>(partial, sums, N * C, (int)grid.x);
     return check_launch("snvc_sheared_backward_reduce(fold)");
+}
+
+int snvc_warped_expand(const float *p, const float *q, const float *e, const float *planes, const float *shift, const float *scale,
+                       const float *bias, float *y, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int flags, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || D < 1 || H <= 0 || W <= 0 || W % 4 != 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand: bad sizes (W % 4 == 0)");
+    if ((scale == nullptr) != (bias == nullptr))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand: scale and bias must both be given or both be NULL");
+    if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand: only SNVC_EPI_RELU");
+    if (N == 0) return SNVC_OK;
+    if (!p || !q || !e || !shift || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand: null pointer");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(p)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand: p, y and planes must be 16-byte aligned");
+    const int quads = (int)(W / 4);
+    if (quads > 512 || C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand: row too wide or too many channels");
+    int RB = 512 / quads;
+    if (RB > 8) RB = 8;
+    while (RB > 1 && ceil_div<int64_t>(H, RB) * C * N < 4 * 256) RB = (RB + 1) / 2;
+    const int threads = ceil_div(RB * quads, 64) * 64;
+    const size_t lds = sizeof(float) * (2 * 3 * (size_t)RB * (2 * W + 8) + 3 * (size_t)RB * D);
+    if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand: rows do not fit the LDS");
+    static std::atomic<unsigned> attr{0};
+    if (!allow_large_lds(reinterpret_cast<const void *>(&warped_expand_kernel), (int)lds, attr)) return check_launch("snvc_warped_expand");
+    warped_expand_kernel<<<dim3((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N), threads, lds, as_stream(stream)>>>(
+        p, q, e, planes, shift, scale, bias, y, (int)C, (int)D, (int)H, (int)W, RB, flags);
+    return check_launch("snvc_warped_expand");
 }
 
 int snvc_shift_structure(const float *shift, float *out4, int64_t N, int64_t D, void *stream) {

@@ -133,8 +133,26 @@ class GlobalStack(nn.Module):
             plans["left2d"] = ops.Conv3dLayer(k.reshape(-1, w.shape[1], 3, 3).float().contiguous(), 3, 1, 1, 1, False, planar=True)
         return plans["left2d"]
 
+    @staticmethod
+    def _commuted_layers(plans, wr):
+        """The depth-1 layers of the warp-after-convolution form of the first layer (csrc/sheared_conv.hip, any shift array):
+        P_kd = conv2d(right, W[:, :, kd]); Q_kd = the kw = +1 taps alone (on the centre column); E[kd][kw] = the (c, kh)
+        contraction with the kw taps, applied to the image's first column."""
+        if "commuted" not in plans:
+            w = wr.detach()                                                   # [Cout, C, kd, kh, kw]
+            cout, c = w.shape[0], w.shape[1]
+            wk = w.permute(2, 0, 1, 3, 4).contiguous()                        # [kd, Cout, C, kh, kw]
+            kq = torch.zeros_like(wk)
+            kq[..., 1] = wk[..., 2]
+            ke = torch.zeros((3, 3, cout, c, 3, 3), dtype=w.dtype, device=w.device)
+            for kw in range(3):
+                ke[:, kw, :, :, :, 1] = wk[..., kw]
+            mk = lambda t: ops.Conv3dLayer(t.reshape(-1, c, 3, 3).contiguous(), 3, 1, 1, 1, False, planar=True)   # noqa: E731
+            plans["commuted"] = (mk(wk), mk(kq), mk(ke))
+        return plans["commuted"]
+
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True,
-                     fused_bn=True, spacing="unknown"):
+                     fused_bn=True, spacing="unknown", commuted=True):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
 
         ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT
@@ -257,6 +275,21 @@ class GlobalStack(nn.Module):
             ops.sheared_expand(g, gcol, planes, scale, bias, v, q, m0, off, off_col, ops.EPI_RELU)
             mark("conv1", 1)
             _ROUTES["sheared_first_conv"] += 1
+            return self._conv2_tail(v, shape, timing)
+        if commuted and shift.dtype == torch.float32 and left.size(3) <= 2048:
+            # any other shift array: interpolation along w commutes with the convolution -- three 2D convolutions of the right
+            # feature, three interpolations per output voxel, the warped volume is not built either (csrc/sheared_conv.hip)
+            lay_p, lay_q, lay_e = self._commuted_layers(plans, w.detach()[:, c:])
+            mark("volume", 0)
+            r5 = right.unsqueeze(2)
+            p_, q_ = lay_p(r5).squeeze(2), lay_q(r5).squeeze(2)
+            e_ = lay_e(right[:, :, :, :4].contiguous().unsqueeze(2)).squeeze(2)
+            mark("volume", 1)
+            mark("conv1", 0)
+            v = self._buffer("v1", shape, left.device)
+            ops.warped_expand(p_, q_, e_, planes, shift, scale, bias, v, ops.EPI_RELU)
+            mark("conv1", 1)
+            _ROUTES["commuted_first_conv"] += 1
             return self._conv2_tail(v, shape, timing)
         mark("volume", 0)
         vol_r = ops.cost_volume_forward_right(right, shift, out=self._buffer("vol_r", shape, left.device))   # [N,C,D,H,W]

@@ -407,6 +407,29 @@ class Conv3dLayer:
         return out, scale, shift, mean, var
 
 
+def warped_expand(p, q, e, planes, shift, scale, bias, out, flags: int = 0):
+    """First convolution over the warped half for ANY shift array, warp after convolution (snvc_warped_expand):
+    p, q [N,3C,H,W] (kd-major stacks of the depth-1 convolutions of the right feature: all taps | the kw = +1 taps alone),
+    e [N,9C,H,4] ((kd, kw)-major, the first image column), planes [N,C,3,H,W] or None, shift [N,D] float32,
+    out [N,C,D,H,W] written in place."""
+    _gpu(p, "p"); _gpu(q, "q"); _gpu(e, "e"); _gpu(out, "out"); _gpu(shift, "shift")
+    n, c, d, h, w = out.shape
+    for t, ch, ww in ((p, 3 * c, w), (q, 3 * c, w), (e, 9 * c, 4)):
+        if t.dtype != torch.float32 or tuple(t.shape) != (n, ch, h, ww) or not t.is_contiguous():
+            raise RuntimeError("warped_expand needs contiguous float32 p / q [N,3C,H,W] and e [N,9C,H,4]")
+    if out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("warped_expand needs a contiguous float32 out [N,C,D,H,W]")
+    if shift.dtype != torch.float32 or tuple(shift.shape) != (n, d):
+        raise RuntimeError("warped_expand needs a float32 shift [N,D]")
+    if planes is not None and (tuple(planes.shape) != (n, c, 3, h, w) or not planes.is_contiguous()):
+        raise RuntimeError("planes must be a contiguous [N,C,3,H,W] tensor")
+    shift = shift.contiguous()
+    with torch.cuda.device(out.device):
+        check(_lib.lib().snvc_warped_expand(_ptr(p), _ptr(q), _ptr(e), _ptr(planes), _ptr(shift), _ptr(scale), _ptr(bias), _ptr(out),
+                                            n, c, d, h, w, int(flags), _stream(out)), "snvc_warped_expand")
+    return out
+
+
 def shift_structure(shift):
     """(all shifts >= 0, rows == s0 + d, rows == s0 + d/2, s0) of a float32 [N, D] shift array: one launch and one 16-byte
     device -> host copy (snvc_shift_structure)."""

@@ -100,13 +100,25 @@ def test_global_pair_full_size_factored_equals_materialised(pair):
         v1s = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
         probe_s = v1s[0, ::7, ::5, ::9, ::11].clone()               # the first layer itself, strided over the whole volume,
         edge_s = [v1s[0, :, 0].clone(), v1s[0, :, D - 1].clone(), v1s[0, :, :, :, W - 1].clone(), v1s[0, :, :, :, 0].clone()]
-        a = m.forward_pair(dl, dr, ds, 1, factored=True, sheared=False)
+        a = m.forward_pair(dl, dr, ds, 1, factored=True, sheared=False, commuted=False)
         v1g = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
         assert torch.allclose(probe_s, v1g[0, ::7, ::5, ::9, ::11], rtol=1e-4, atol=1e-4)
         for e, g in zip(edge_s, (v1g[0, :, 0], v1g[0, :, D - 1], v1g[0, :, :, :, W - 1], v1g[0, :, :, :, 0])):   # and its four borders whole
             assert torch.allclose(e, g, rtol=1e-4, atol=1e-4), (e - g).abs().max()   # 864-term fp32 sums in two orders, values up to ~5
+        probe_g = v1g[0, ::7, ::5, ::9, ::11].clone()
+        edge_g = [v1g[0, :, 0].clone(), v1g[0, :, D - 1].clone(), v1g[0, :, :, :, W - 1].clone(), v1g[0, :, :, :, 0].clone()]
+        # the form any OTHER shift array takes (warp after convolution), here on cfg2's own shifts at full size
+        before_c = S._ROUTES["commuted_first_conv"]
+        cmt = m.forward_pair(dl, dr, ds, 1, sheared=False)
+        assert S._ROUTES["commuted_first_conv"] == before_c + 1
+        v1c = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+        assert torch.allclose(probe_g, v1c[0, ::7, ::5, ::9, ::11], rtol=1e-4, atol=1e-4)
+        for e, g in zip(edge_g, (v1c[0, :, 0], v1c[0, :, D - 1], v1c[0, :, :, :, W - 1], v1c[0, :, :, :, 0])):
+            assert torch.allclose(e, g, rtol=1e-4, atol=1e-4), (e - g).abs().max()
         b = m.forward_pair(dl, dr, ds, 1, factored=False)
     assert a.shape == (1, 1, D, H, W) and torch.isfinite(a).all()
+    err = (cmt - b).abs().max().item() / b.abs().max().item()
+    assert err < 1e-4, err
     err = (a - b).abs().max().item() / b.abs().max().item()
     assert err < 1e-4, err
     err = (s - b).abs().max().item() / b.abs().max().item()

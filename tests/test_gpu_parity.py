@@ -1087,6 +1087,47 @@ def test_global_pair_end_to_end_vs_oracle(tile):
     check(full1, exp1, 2e-5, "conv1")
 
 
+@pytest.mark.parametrize("case", ["random", "whole_pixels", "beyond_the_image", "ragged_rows"])
+def test_commuted_first_conv_any_shift_vs_oracle_and_built_volume(case):
+    """Any shift array (inference): the first convolution over the warped half as three interpolations of three 2D convolutions
+    (snvc_warped_expand, csrc/sheared_conv.hip) -- against the C oracle's cost volume + the torch-CPU stack and against the path
+    that builds the right half and runs the 3D convolution over it; first layer alone at the exact-fp32 tolerance.  Two samples
+    with different, non-monotone shift rows: fractional, whole, zero, and larger than the image width."""
+    from oracle import native as O
+    from oracle import torch_ref as T
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    r = np.random.default_rng(161 + len(case))
+    C, D = 32, 12
+    H, W = (12, 44) if case == "ragged_rows" else (8, 40)      # 12 rows over row blocks of 8 (the hourglass needs multiples of 4)
+    L = r.standard_normal((2, C, H, W)).astype(np.float32)
+    R = r.standard_normal((2, C, H, W)).astype(np.float32)
+    s = r.uniform(0, 20, (2, D))
+    if case == "whole_pixels":
+        s = np.floor(s)
+    elif case == "beyond_the_image":
+        s[:, ::2] = r.uniform(W - 2, W + 3, (2, (D + 1) // 2))
+        s[0, 1], s[1, 3] = float(W), float(W - 1)
+    else:
+        s[0, 2], s[1, 5], s[0, 7], s[1, 0] = 0.0, 3.0, 0.25, 19.999
+    s = s.astype(np.float32)
+    ref = seeded(T.GlobalStack(C), 162)
+    ours = seeded(GlobalStack(C), 162).to(dev())
+    dl, dr, dsh = torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()), torch.from_numpy(s).to(dev())
+    with torch.no_grad():
+        exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, 1))).numpy()
+        before = S._ROUTES["commuted_first_conv"]
+        got = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()
+        assert S._ROUTES["commuted_first_conv"] == before + 1
+        v1c = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+        built = ours.forward_pair(dl, dr, dsh, 1, commuted=False).cpu().numpy()
+        assert S._ROUTES["commuted_first_conv"] == before + 1
+        v1b = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+    check(v1c.cpu().numpy(), v1b.cpu().numpy(), TIGHT, f"first layer, warp after convolution vs built volume ({case})")
+    check(got, exp, 1e-4, f"pair vs oracle ({case})")
+    check(got, built, 2e-5, f"pair, warp after convolution vs built volume ({case})")
+
+
 def test_shift_structure_flags():
     """snvc_shift_structure: the one-launch replacement of the wrapper's `assert torch.all(shift >= 0)` also classifies the
     array (whole- / half-pixel uniform spacing, exactly in fp32)."""
@@ -1131,13 +1172,13 @@ def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
         before = S._ROUTES["sheared_first_conv"]
         got = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()
         assert S._ROUTES["sheared_first_conv"] == before + 1
-        general = ours.forward_pair(dl, dr, dsh, 1, sheared=False).cpu().numpy()
+        general = ours.forward_pair(dl, dr, dsh, 1, sheared=False, commuted=False).cpu().numpy()      # right half built
         assert S._ROUTES["sheared_first_conv"] == before + 1
         # first layer alone (before conv2 / the hourglass smooth anything over): the sheared planes against the general ones
         v_sheared = ours.__dict__["_snvc_ws"]
         ours.forward_pair(dl, dr, dsh, 1)
         v1s = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
-        ours.forward_pair(dl, dr, dsh, 1, sheared=False)
+        ours.forward_pair(dl, dr, dsh, 1, sheared=False, commuted=False)
         v1g = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
         # a shift array that is not uniformly spaced: general path
         dsh2 = dsh.clone()
@@ -1149,7 +1190,7 @@ def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
         s3 = torch.from_numpy(np.tile(((m3 + np.arange(D)) / q3).astype(np.float32)[None], (2, 1))).to(dev())
         ours.forward_pair(dl, dr, dsh, 1)                                   # spacing (q, m0) is now the guess
         other = ours.forward_pair(dl, dr, s3, 1).cpu().numpy()
-        other_general = ours.forward_pair(dl, dr, s3, 1, sheared=False).cpu().numpy()
+        other_general = ours.forward_pair(dl, dr, s3, 1, sheared=False, commuted=False).cpu().numpy()
         back = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()              # and back again
         check(other, other_general, 2e-5, "spacing changed between calls")
         assert np.array_equal(back, got)

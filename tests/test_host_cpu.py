@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported(L):
     from snvc_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "snvc_hip.h")).read()
     declared = set(re.findall(r"SNVC_API\s+[\w\s\*]+?\b(snvc_\w+)\s*\(", hdr))
-    assert len(declared) == 62, sorted(declared)
+    assert len(declared) == 63, sorted(declared)
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
@@ -311,3 +311,73 @@ def test_sheared_term_counts_cover_every_element():
         assert int(col.sum()) == D and float(col.max()) == 1.0
         assert per_class.tolist() == [1.0, float(D - 2), 1.0]
         assert int(line[0].sum()) + int(line[2].sum()) <= 2 * (W - 1)
+
+
+def _warped_first_conv_reference(R, wr, shift, D):
+    """csrc/sheared_conv.hip's warp-after-convolution identity in plain fp64 numpy/torch (the arithmetic of warped_expand_kernel):
+    returns conv3d(warped half of the volume, wr) for an arbitrary shift array [D]."""
+    import torch.nn.functional as F
+    C, H, W = R.shape
+    CO = wr.shape[0]
+    Rt = torch.from_numpy(R)[None].double()
+    P = [F.conv2d(Rt, wr[:, :, kd], padding=1)[0].numpy() for kd in range(3)]                    # [CO,H,W]
+    kq = [torch.zeros_like(wr[:, :, 0]) for _ in range(3)]
+    for kd in range(3):
+        kq[kd][:, :, :, 1] = wr[:, :, kd, :, 2]                                                  # the kw = +1 taps on the centre column
+    Q = [F.conv2d(Rt, kq[kd], padding=1)[0].numpy() for kd in range(3)]
+    E = np.zeros((3, 3, CO, H))
+    col0 = F.pad(Rt[:, :, :, :1], (0, 0, 1, 1))                                                   # first column, padded in h
+    for kd in range(3):
+        for kw in range(3):
+            E[kd, kw] = F.conv2d(col0, wr[:, :, kd, :, kw:kw + 1])[0, :, :, 0].numpy()
+
+    def z(a, j):            # zero-extended read
+        return a[:, :, j] if 0 <= j < W else np.zeros(a.shape[:2])
+
+    out = np.zeros((CO, D, H, W))
+    for d in range(D):
+        for kd in range(3):
+            dd = d + kd - 1
+            if not 0 <= dd < D:
+                continue
+            s = float(shift[dd]); m = int(np.floor(s)); f = s - m; g = 1.0 - f
+            for w in range(W):
+                out[:, d, :, w] += f * z(P[kd], w - m - 1) + g * z(P[kd], w - m)
+            out[:, d, :, W - 1] -= f * z(Q[kd], W - m - 1) + g * z(Q[kd], W - m)
+            if m <= W:
+                add = [g * E[kd, 2], f * E[kd, 2], 0.0 * E[kd, 2]]
+                if f > 0:
+                    if m - 1 != W - 1:
+                        add[0] = add[0] - g * E[kd, 2]
+                    add[1] = add[1] - g * E[kd, 1]
+                    add[2] = add[2] - g * E[kd, 0]
+                for j in range(3):
+                    w = m - 1 + j
+                    if 0 <= w < W:
+                        out[:, d, :, w] += add[j]
+    return out
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_warp_after_convolution_algebra_on_the_cpu(seed):
+    """For ANY shift array the 3x3x3 convolution over the warped half equals three interpolations of three 2D convolutions of the
+    right feature plus two border terms (csrc/sheared_conv.hip, warped_expand_kernel): checked in fp64 against F.conv3d over the
+    oracle's cost volume for random fractional / integer / zero / beyond-the-image shifts, all borders included."""
+    import torch.nn.functional as F
+    from oracle import native as O
+    r = np.random.default_rng(50 + seed)
+    C, CO, D, H, W = 3, 4, 10, 5, 12
+    L = r.standard_normal((1, C, H, W)).astype(np.float32)
+    R = r.standard_normal((1, C, H, W)).astype(np.float32)
+    shift = r.uniform(0, W + 2, D)
+    shift[::3] = np.floor(shift[::3])                 # whole-pixel planes
+    shift[1] = 0.0
+    shift[2] = float(W)                               # every sample left of the image
+    shift[4] = W - 1 + 0.5
+    shift[5] = 0.25
+    shift = shift.astype(np.float32)[None]
+    wr = torch.from_numpy(r.standard_normal((CO, C, 3, 3, 3))).double()
+    vol_r = torch.from_numpy(O.cost_volume_forward(L, R, shift, 1)[:, C:]).double()
+    ref = F.conv3d(vol_r, wr, padding=1)[0].numpy()
+    got = _warped_first_conv_reference(R[0].astype(np.float64), wr, shift[0].astype(np.float64), D)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)      # the oracle interpolates in fp32: ~1e-7 of the values
