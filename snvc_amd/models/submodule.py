@@ -72,7 +72,7 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
 # convolution's split weights for inference and training, the persistent inference workspace, the device copy of the
 # coordinate maps).  invalidate_plans() drops exactly these; tests/test_host_cpu.py checks that no other `_snvc_*`
 # name is written anywhere in the package.
-CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans2d", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
+CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans2d", "_snvc_plans2d_t", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
                "_snvc_coor_maps")
 
 
@@ -1046,14 +1046,22 @@ def _affine2d(conv, norm, plan: _Plan):
 
 
 def fused_conv2d(conv: nn.Conv2d, norm, x: torch.Tensor, *, relu=False, sigmoid=False, residual=None,
-                 residual_after_act=False) -> torch.Tensor:
+                 residual_after_act=False, transposed_input=False) -> torch.Tensor:
     """act(norm(conv(x)) [+ residual]) [+ residual] for the 2D neck (reference submodule.py:11-29, hrnet.py:25-69)
     on the depth-1 HIP kernels.  conv: Conv2d(k in {1,3}, stride in {1,2}, padding=(k-1)/2) -- or a Conv2d whose
-    kernel covers its whole input (the coordinate head's last layer, vernier.py:87), run as a 1x1 layer."""
+    kernel covers its whole input (the coordinate head's last layer, vernier.py:87), run as a 1x1 layer.
+    ``transposed_input``: returns ``conv(x.transpose(2, 3))`` as a transposed VIEW of the convolution of x itself with the
+    kernel's two spatial axes swapped (a convolution commutes with swapping H and W if its kernel is swapped too): the
+    copy that ``permute(0, 1, 3, 2).contiguous()`` would make of the C-channel input is not made (vernier.py:441-442)."""
     plan = _plan2d(conv, x.device)
     w = conv.weight
     kh, kw = conv.kernel_size
     whole = (kh, kw) == tuple(x.shape[2:]) and tuple(conv.padding) == (0, 0) and (kh, kw) != (1, 1)
+    if transposed_input:
+        if whole or kh != kw or residual is not None or isinstance(norm, nn.GroupNorm):
+            return fused_conv2d(conv, norm, x.transpose(2, 3).contiguous(), relu=relu, sigmoid=sigmoid, residual=residual,
+                                residual_after_act=residual_after_act)
+        plan = conv.__dict__.setdefault("_snvc_plans2d_t", {}).setdefault(x.device, _Plan())
     key = (w.data_ptr(), w._version, w.device, whole, _GENERATION[0])
     if plan.layer is None or plan.key != key:
         if conv.groups != 1 or tuple(conv.dilation) != (1, 1):
@@ -1064,7 +1072,8 @@ def fused_conv2d(conv: nn.Conv2d, norm, x: torch.Tensor, *, relu=False, sigmoid=
             k, st = kh, conv.stride[0]
             if kh != kw or conv.stride[0] != conv.stride[1] or tuple(conv.padding) != ((k - 1) // 2,) * 2 or k not in (1, 3) or st not in (1, 2):
                 raise NotImplementedError(f"Conv2d geometry {conv} is not in the 2D neck")
-            plan.layer = ops.Conv3dLayer(w.detach(), k, st, (k - 1) // 2, 1, False, planar=True)
+            wk = w.detach().transpose(2, 3).contiguous() if transposed_input else w.detach()
+            plan.layer = ops.Conv3dLayer(wk, k, st, (k - 1) // 2, 1, False, planar=True)
         plan.key = key
     scale, bias = _affine2d(conv, norm, plan)
     flags = (EPI_RELU if relu else 0) | (EPI_SIGMOID if sigmoid else 0)
@@ -1074,7 +1083,8 @@ def fused_conv2d(conv: nn.Conv2d, norm, x: torch.Tensor, *, relu=False, sigmoid=
     r5 = residual.unsqueeze(2) if residual is not None else None
     if isinstance(norm, nn.GroupNorm):
         return _group_norm_2d(plan.layer(x5, scale, bias), norm, r5, flags).squeeze(2)
-    return plan.layer(x5, scale, bias, r5, flags).squeeze(2)
+    y = plan.layer(x5, scale, bias, r5, flags).squeeze(2)
+    return y.transpose(2, 3) if transposed_input else y
 
 
 def _group_norm_2d(raw5, norm: nn.GroupNorm, r5, flags):

@@ -224,18 +224,18 @@ class VernierScale(nn.Module):
         from .submodule import _hip_2d_ok, _cbr2d, fused_conv2d
         hip = _hip_2d_ok(voxel_BEV, self.conv5, self.hm1, self.hm2, self.coord_head)
         voxel_BEV = _cbr2d(self.conv5, voxel_BEV) if hip else self.conv5(voxel_BEV)
-        if self.small:
-            heatmap_feats = self.hm1(voxel_BEV, None, None)[0].permute(0, 1, 3, 2)
+        feats = self.hm1(voxel_BEV, None, None)[0] if self.small else self.hm1(voxel_BEV)
+        if hip:      # hm2(feats.permute(0, 1, 3, 2)) without copying the 64-channel tensor: swapped kernel, transposed view out
+            heatmaps = fused_conv2d(self.hm2, None, feats, transposed_input=True)
         else:
-            heatmap_feats = self.hm1(voxel_BEV).permute(0, 1, 3, 2)
-        heatmaps = fused_conv2d(self.hm2, None, heatmap_feats.contiguous()) if hip else self.hm2(heatmap_feats)
+            heatmaps = self.hm2(feats.permute(0, 1, 3, 2))
         num_sample = len(heatmaps)
         # the coordinate maps are a plain attribute in the reference (not in the state dict): one device copy is kept,
         # so that no host -> device copy sits in the middle of the neck (and of a captured graph)
         cm = self.__dict__.get("_snvc_coor_maps")
         if cm is None or cm.device != heatmaps.device:
             cm = self.__dict__["_snvc_coor_maps"] = self.coor_maps.to(heatmaps.device)
-        coor_maps = cm.repeat(num_sample, 1, 1, 1)
+        coor_maps = cm.expand(num_sample, -1, -1, -1) if cm.size(0) == 1 else cm.repeat(num_sample, 1, 1, 1)
         augmented_maps = torch.cat([heatmaps, coor_maps], dim=1)
         last = self.coord_head[-2]
         if hip and tuple(last.kernel_size) != (1, 1):

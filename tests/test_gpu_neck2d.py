@@ -61,6 +61,24 @@ def test_fused_conv2d_vs_torch(k, stride, cin, cout, hw):
                 assert not torch.equal(wino, direct), "the forced form is a different kernel"
 
 
+def test_fused_conv2d_transposed_input_is_a_swapped_kernel():
+    """hm2(feats.permute(0, 1, 3, 2)) (vernier.py:441-442) without the copy: the convolution of feats with the kernel's
+    spatial axes swapped, returned as a transposed view."""
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(1150)
+    for cin, cout, hw, bias in ((64, 9, (24, 16), False), (16, 32, (13, 40), True)):
+        conv = torch.nn.Conv2d(cin, cout, 3, 1, 1, bias=bias)
+        conv.weight.data.copy_(_t(r, tuple(conv.weight.shape)) * 0.1)
+        if bias:
+            conv.bias.data.copy_(_t(r, (cout,)))
+        x = _t(r, (2, cin) + hw)
+        with torch.no_grad():
+            ref = F.conv2d(x.permute(0, 1, 3, 2), conv.weight, conv.bias, 1, 1)
+            got = S.fused_conv2d(conv.to(dev()), None, x.to(dev()), transposed_input=True)
+        assert tuple(got.shape) == tuple(ref.shape)
+        check(got.cpu().numpy(), ref.numpy(), TIGHT, f"conv(x^T) {cin}->{cout}")
+
+
 def test_fused_conv2d_bias_and_whole_extent_layer():
     """Conv2d with its own bias (hm2, the coordinate head's last layer) and the (6,4) kernel that covers its whole input
     (vernier.py:87-88), run as a 1x1 layer over the flattened input, + Sigmoid."""
