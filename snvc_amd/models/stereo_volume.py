@@ -199,7 +199,7 @@ class GlobalStack(nn.Module):
                 v = _ShearedFirstConvFn.apply(left, right, conv.weight, bn.weight, bn.bias, conv, bn, EPI_RELU, plan, structure[0],
                                               structure[1], shift.size(1))
                 return self._tail(self.conv2(v))
-            v = _FactoredFirstConvFn.apply(left, right, shift, conv.weight, bn.weight, bn.bias, conv, bn, EPI_RELU, plan)
+            v = _FactoredFirstConvFn.apply(left, right, shift, conv.weight, bn.weight, bn.bias, conv, bn, EPI_RELU, plan, commuted)
             return self._tail(self.conv2(v))
         usable = (factored and downsample == 1 and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
                   and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)

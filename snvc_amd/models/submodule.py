@@ -417,7 +417,7 @@ class _FactoredFirstConvFn(torch.autograd.Function):
     Same gradients as the materialised path up to summation order (tests: training step vs C oracle + torch autograd)."""
 
     @staticmethod
-    def forward(ctx, left, right, shift, weight, gamma, beta, conv, norm, flags, plan):
+    def forward(ctx, left, right, shift, weight, gamma, beta, conv, norm, flags, plan, commuted=True):
         c = left.size(1)
         fac = _first_conv_train_cache(conv, weight, c)
         if "fr" not in fac:
@@ -425,9 +425,31 @@ class _FactoredFirstConvFn(torch.autograd.Function):
             fac.update(fr=ops.Conv3dLayer(wr, 3, 1, 1, 1, False), br=ops.Conv3dLayer(_flip3d(wr), 3, 1, 1, 1, False))
         left3 = left.detach().unsqueeze(2).expand(-1, -1, 3, -1, -1).contiguous()
         planes = fac["fl"](left3)
-        vol_r = ops.cost_volume_forward_right(right.detach(), shift)
-        raw = fac["fr"](vol_r, None, None, None, 0, None, depth_planes=planes)
-        del vol_r
+        rd = right.detach()
+        if commuted and shift.dtype == torch.float32 and rd.size(3) % 4 == 0 and rd.size(3) <= 2048:
+            # forward: warp AFTER the convolution (csrc/sheared_conv.hip, any shift array): three depth-1 convolutions of the
+            # right feature + three interpolations per voxel instead of the volume build and the 3D convolution over it
+            if "commuted" not in fac:
+                w = weight.detach()[:, c:]
+                cout = w.size(0)
+                wk = w.permute(2, 0, 1, 3, 4).contiguous()
+                kq = torch.zeros_like(wk)
+                kq[..., 1] = wk[..., 2]
+                ke = torch.zeros((3, 3, cout, c, 3, 3), dtype=w.dtype, device=w.device)
+                for kw in range(3):
+                    ke[:, kw, :, :, :, 1] = wk[..., kw]
+                mk = lambda t: ops.Conv3dLayer(t.reshape(-1, c, 3, 3).contiguous(), 3, 1, 1, 1, False, planar=True)   # noqa: E731
+                fac["commuted"] = (mk(wk), mk(kq), mk(ke))
+            lp, lq, le = fac["commuted"]
+            r5 = rd.unsqueeze(2)
+            raw = torch.empty((rd.size(0), weight.size(0), shift.size(1)) + tuple(rd.shape[2:]), dtype=torch.float32, device=rd.device)
+            ops.warped_expand(lp(r5).squeeze(2), lq(r5).squeeze(2), le(rd[:, :, :, :4].contiguous().unsqueeze(2)).squeeze(2), planes,
+                              shift.detach().float().contiguous(), None, None, raw, 0)
+            _ROUTES["commuted_first_conv_train"] += 1
+        else:
+            vol_r = ops.cost_volume_forward_right(rd, shift)
+            raw = fac["fr"](vol_r, None, None, None, 0, None, depth_planes=planes)
+            del vol_r
         y, scale, shf, mean, var, per_sample = _norm_from_raw(raw, norm, plan, None, flags)
         ctx.conv, ctx.norm, ctx.flags, ctx.per_sample, ctx.train_stats = conv, norm, flags, per_sample, mean is not None
         ctx.save_for_backward(left3, right.detach(), shift, raw, scale, shf, mean, var)
@@ -454,7 +476,7 @@ class _FactoredFirstConvFn(torch.autograd.Function):
             g_left = fac["bl"](dplanes).sum(dim=2)                                # the three depth copies are one tensor
         if needs[1]:
             g_right = ops.cost_volume_backward_right(fac["br"](draw), shift)
-        return g_left, g_right, None, gw, dg, db, None, None, None, None
+        return g_left, g_right, None, gw, dg, db, None, None, None, None, None
 
 
 SHEAR_CLASS_KDS = ((0, 1), (-1, 0, 1), (-1, 0))     # kd taps the first plane / the interior planes / the last plane see

@@ -842,7 +842,10 @@ def test_training_step_global_stack_vs_torch_autograd():
     (gl_r, gr_r), gp_r = _grads(ref, [lr, rr], lambda: ref(CV.apply(lr, rr)).pow(2).mean())
     lo, ro = torch.from_numpy(L).to(dev()).requires_grad_(), torch.from_numpy(R).to(dev()).requires_grad_()
     sh = torch.from_numpy(s).to(dev())
+    from snvc_amd.models import submodule as S
+    before_c = S._ROUTES["commuted_first_conv_train"]
     (gl_o, gr_o), gp_o = _grads(ours, [lo, ro], lambda: ours.forward_pair(lo, ro, sh, 1).pow(2).mean())
+    assert S._ROUTES["commuted_first_conv_train"] == before_c + 1      # non-uniform shifts: the first layer's forward warps after the convolution
     # feature gradients pass through ~10 ReLUs: a mask bit that flips on a pre-activation of ~1e-7
     # perturbs a small neighbourhood, so they are compared in the L2 sense
     def l2(a, b):
@@ -1277,7 +1280,7 @@ def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0, fused_bn):
             check(a.cpu().numpy(), b.numpy(), 1e-4, k)
     # the same step on the general factored function (the running statistics move a second time: gradients only)
     lg, rg = torch.from_numpy(L).to(dev()).requires_grad_(), torch.from_numpy(R).to(dev()).requires_grad_()
-    (gl_g, gr_g), gp_g = _grads(ours, [lg, rg], lambda: ours.forward_pair(lg, rg, sh, 1, sheared=False).pow(2).mean())
+    (gl_g, gr_g), gp_g = _grads(ours, [lg, rg], lambda: ours.forward_pair(lg, rg, sh, 1, sheared=False, commuted=False).pow(2).mean())
     assert S._ROUTES["sheared_first_conv_train"] == before + 1
 
     def l2(a, b):
