@@ -144,13 +144,7 @@ def _norm_from_raw(raw, norm, plan, residual, flags, out=None):
         return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=out), scale, shift, mean, var, True
     if isinstance(norm, nn.BatchNorm3d):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, c, False, norm.eps)
-        if norm.training and norm.track_running_stats and norm.running_mean is not None:
-            with torch.no_grad():  # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
-                cnt = raw.numel() / c
-                norm.num_batches_tracked += 1
-                m = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked)
-                norm.running_mean.mul_(1 - m).add_(mean[0], alpha=m)
-                norm.running_var.mul_(1 - m).add_(var[0] * (cnt / max(cnt - 1, 1)), alpha=m)
+        _bn_track(norm, mean, var, raw.numel() / c)      # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
         return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=out), scale, shift, mean, var, False
     raise NotImplementedError(f"norm layer {type(norm).__name__} is not on the path")
 
@@ -189,13 +183,7 @@ def _norm_forward(layer, norm, plan, x, residual, flags, out, keep_raw, exact=Fa
         return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=dst), raw, scale, shift, mean, var, True
     if isinstance(norm, nn.BatchNorm3d):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, c, False, norm.eps)
-        if norm.training and norm.track_running_stats and norm.running_mean is not None:
-            with torch.no_grad():  # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
-                cnt = raw.numel() / c
-                norm.num_batches_tracked += 1
-                m = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked)
-                norm.running_mean.mul_(1 - m).add_(mean[0], alpha=m)
-                norm.running_var.mul_(1 - m).add_(var[0] * (cnt / max(cnt - 1, 1)), alpha=m)
+        _bn_track(norm, mean, var, raw.numel() / c)      # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
         return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst), raw, scale, shift, mean, var, False
     raise NotImplementedError(f"norm layer {type(norm).__name__} is not on the path")
 
@@ -535,8 +523,8 @@ def _bn_track(norm, mean, var, cnt):
         with torch.no_grad():
             norm.num_batches_tracked += 1
             m = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked)
-            norm.running_mean.mul_(1 - m).add_(mean[0], alpha=m)
-            norm.running_var.mul_(1 - m).add_(var[0] * (cnt / max(cnt - 1, 1)), alpha=m)
+            norm.running_mean.lerp_(mean[0], m)                                   # (1 - m) * running + m * batch, one launch each
+            norm.running_var.lerp_(var[0] * (cnt / max(cnt - 1, 1)), m)
 
 
 class _ShearedFirstConvFn(torch.autograd.Function):
