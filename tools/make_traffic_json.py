@@ -20,6 +20,7 @@ KERNEL = {  # layer -> substring of the kernel whose LAST dispatch is reported
     # r3
     "conv2_side": "conv3d_wino_dma_kernel", "hg_s2": "conv3d_winos2_pipe_kernel", "sheared": "sheared_expand_kernel",
     "gather_cfg3": "voxel_gather_fwd_lds", "f16_k7_32": "conv3d_f16_kernel",
+    "general": "warped_expand_kernel", "sheared_bwd": "sheared_bwd_kernel",
 }
 ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     "conv1_factored": 1472200704, "cost_volume": 1479869184, "cost_volume_right": 739934976, "cost_volume_bwd": 1479869184 + 2 * 3833856,
@@ -30,6 +31,8 @@ ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     # writes 64 at half resolution; the expand pass writes one 32-channel volume; 8 crops of 96^3
     "conv2_side": 2 * 735902208 + 22996944, "hg_s2": 735902208 + 183975552, "sheared": 735902208,
     "gather_cfg3": 8 * (884736 * 272 + 2 * 32 * 4096 * 4), "f16_k7_32": 2 * 786432 * 2 * (64 + 32),
+    # the warp-after-convolution expand writes one 32-channel volume; the sheared layer's fused backward reads one (gy)
+    "general": 735902208, "sheared_bwd": 735902208,
 }
 F32_MFMA_LAYERS = ("conv1_factored", "conv2_side", "hg_s2")
 

@@ -89,6 +89,15 @@ with torch.no_grad():
     elif args.layer == "hg_s2":             # hourglass conv1: k3 / stride 2, 32 -> 64 (slice-pipelined refill)
         v2 = torch.randn(1, bench.C, bench.D, bench.H, bench.W, device=dev)
         fn = lambda: model.hg_conv3d.conv1(v2)  # noqa: E731
+    elif args.layer == "general":           # any shift array: warp after convolution (three depth-1 convs + warped_expand)
+        fn = lambda: model.forward_pair(left, right, shift, 1, sheared=False)  # noqa: E731
+    elif args.layer == "sheared_bwd":       # cfg4's first layer: forward + backward of the sheared function with folded BatchNorm
+        model.train()
+        lt, rt = left.clone().requires_grad_(), right.clone().requires_grad_()
+        def fn():
+            with torch.enable_grad():
+                v = model.forward_pair(lt, rt, shift, 1)
+                v.mean().backward()
     elif args.layer == "sheared":           # the sheared first convolution: Rq, G | G', edge slab, expand, copies
         fn = lambda: model.forward_pair(left, right, shift, 1)  # noqa: E731
     elif args.layer == "f16_k7_32":         # released shape, fp16 storage, MI = 1 form (64 -> 32)
