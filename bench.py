@@ -19,11 +19,13 @@ One JSON line on stdout (rank 0):
   value / ms_per_step  the step through the fused entry point GlobalStack.forward_pair (factored first
                        convolution); `materialized` repeats it through the reference's own operator API
                        (build_cost_volume(...) then the modules) -- config.entry_points says which is which
-  roofline             dominant kernel (first 3x3x3 convolution), events on the launch stream inside the
-                       timed loop.  `frac` = EXECUTED MFMA flops / launch time / fp32-MFMA peak (<= 1: the
+  roofline             dominant kernel (the second 3x3x3 convolution + side head on the headline path), events on the
+                       launch stream inside the timed loop.  `frac` = EXECUTED MFMA flops / launch time / fp32-MFMA peak (<= 1: the
                        Winograd F(4,3) kernel issues 6 of the direct form's 12 multiplies);
                        `algorithmic_over_peak` prices the convolution's algorithmic flops instead
-  roofline_hbm         the cost-volume builders (HBM-write bound), same event timing
+  roofline_hbm         the headline path's HBM-bound kernel (sheared expand: the first layer's 0.74 GB write stream);
+                       sub-entries: the any-shift expand, the cost-volume builders, the gather.  Same event timing
+  parity_vs_cpu_baseline  every timed leg's output against the CPU oracle's on the same inputs and weights
   configs              the other BASELINE configs on this GPU (N=1 only): cfg3 96^3 crops, the released
                        local shape, cfg5 high-res, cfg4 training step; each with its dominant kernel's
                        executed pipe fraction; gather bandwidth on projected and on uniform coordinates
@@ -92,9 +94,10 @@ def seeded_state(model, seed=2024):
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(d_sample=D):
+def cpu_baseline(d_sample=D, outputs=None):
     """CPU oracle on ONE FULL cfg2 pair (all 192 planes, measured, not scaled): C/OpenMP cost volume +
-    torch-CPU 3D stack, every host core."""
+    torch-CPU 3D stack, every host core.  The inputs and weights are rank 0's (make_inputs(0), seeded_state), so the
+    oracle's result (left in ``outputs["cost"]``) is what every timed leg of the GPU line has to reproduce."""
     from oracle import native as O
     from oracle import torch_ref as T
     cores = os.cpu_count() or 1
@@ -108,15 +111,30 @@ def cpu_baseline(d_sample=D):
     vol = O.cost_volume_forward(ln, rn, sn, 1)
     t1 = time.perf_counter()
     with torch.no_grad():
-        ref(torch.from_numpy(vol))
+        cost = ref(torch.from_numpy(vol))
     t2 = time.perf_counter()
     scale = D / float(d_sample)
+    if outputs is not None:
+        outputs["cost"] = cost.numpy()
     return {
         "value": 1.0 / ((t2 - t0) * scale), "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
         "sample": f"1 pair, {d_sample} of {D} disparity planes{'' if d_sample == D else ' (scaled)'}: {t2 - t0:.2f}s = "
                   f"cost volume (C oracle, OpenMP, {cores} threads) {t1 - t0:.2f}s + 3D stack (torch-CPU {torch.__version__}, "
                   f"{cores} threads) {t2 - t1:.2f}s",
     }
+
+
+def parity_vs(got, exp, rel=1e-3):
+    """The timed path's output against the CPU oracle's on the same inputs and weights: max|err| / max|ref| and north_star's
+    1e-3 criterion element by element (|err| <= rel*|ref| + rel*rms(ref); the same rule as tests/test_gpu_parity.py::check)."""
+    a = np.asarray(got, dtype=np.float64).ravel()
+    b = np.asarray(exp, dtype=np.float64).ravel()
+    if a.shape != b.shape:
+        return {"error": f"shape {a.shape} vs {b.shape}"}
+    err = np.abs(a - b)
+    bound = rel * np.abs(b) + rel * max(float(np.sqrt(np.mean(b * b))), 1e-30)
+    return {"rel_err": float(err.max() / max(np.abs(b).max(), 1e-30)), "elementwise_fail_frac": float((err > bound).mean()),
+            "elementwise_worst_over_bound": float((err / bound).max()), "elements": int(b.size)}
 
 
 # ------------------------------------------------------------------------------------------ helpers
@@ -499,7 +517,9 @@ def main():
     model.eval().to(device)
     left, right, shift = make_inputs(rank, device)
 
-    def run(factored, sheared=True, commuted=True):
+    outs = {}
+
+    def run(factored, sheared=True, commuted=True, tag="value"):
         """W warm-up + K timed steps; returns (seconds for the K steps, mean ms of the "conv1" bracket, of the "volume"
         bracket and of the "conv2" bracket).  sheared path: volume = Rq + the 2D convolution G + the 4-plane edge slab,
         conv1 = the expand pass (0.74 GB write) + edge-plane copies; general path: volume = the right-half cost-volume
@@ -532,6 +552,7 @@ def main():
                 return float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in ev]))
             except (RuntimeError, ValueError):      # a bracket this path does not record
                 return float("nan")
+        outs[tag] = out.cpu().numpy() if rank == 0 and world == 1 else None    # 23 MB, compared with the CPU oracle below
         return elapsed, mean("conv1"), mean("volume"), mean("conv2")
 
     # Headline: GlobalStack.forward_pair.  cfg2's disparity planes are uniformly spaced (linspace(0, 95.5, 192): half-pixel
@@ -542,9 +563,9 @@ def main():
     routes0 = S_._ROUTES["sheared_first_conv"]
     elapsed, expand_ms, shear_prep_ms, conv2_ms = run(True)
     sheared_taken = S_._ROUTES["sheared_first_conv"] > routes0
-    elapsed_gen, warp_expand_ms, warp_prep_ms, _ = run(True, sheared=False)                  # any shift array: warp after convolution
-    elapsed_built, conv_ms, cvr_ms, _ = run(True, sheared=False, commuted=False)              # right half built + 3D convolution over it
-    elapsed_mat, conv_ms_mat, cv_ms, _ = run(False)
+    elapsed_gen, warp_expand_ms, warp_prep_ms, _ = run(True, sheared=False, tag="general_shift")      # any shift array: warp after convolution
+    elapsed_built, conv_ms, cvr_ms, _ = run(True, sheared=False, commuted=False, tag="built_right_half")   # right half built + 3D convolution over it
+    elapsed_mat, conv_ms_mat, cv_ms, _ = run(False, tag="materialized")
 
     def run_reference_api():
         """the reference's call sequence, verbatim: volume = build_cost_volume(l, r, s, 1); cost = model(volume)"""
@@ -561,6 +582,7 @@ def main():
             dt = time.perf_counter() - t0
             gc.enable()
         assert torch.isfinite(out).all()
+        outs["reference_api"] = out.cpu().numpy() if rank == 0 and world == 1 else None
         return dt
     elapsed_api = run_reference_api()
     dom_flop = CONV1_FLOP / 2                       # a 32 -> 32 channel 3x3x3 layer on the full grid (conv2; conv1's right half)
@@ -651,15 +673,22 @@ def main():
                 "traffic_source": traffic_src,
             },
             "roofline_hbm": {
-                "kernel": "cost_volume_fwd_rows: right (warped) half only, as the general path builds it",
-                "bound": "hbm", "achieved": CV_RIGHT_BYTES / (cvr_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": CV_RIGHT_BYTES / (cvr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": CV_RIGHT_BYTES,
-                "avg_launch_ms": cvr_ms,
-                "sheared_expand": {"kernel": "sheared_expand_kernel + 2 edge-plane copies: conv1's result written along the shear "
-                                             "(the headline path's first layer: one 0.74 GB write stream)",
-                                   "achieved": V1_BYTES / (expand_ms * 1e-3) / 1e9, "frac": V1_BYTES / (expand_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                   "bytes_per_launch": V1_BYTES, "avg_launch_ms": expand_ms,
-                                   "prep_ms": shear_prep_ms, "prep": "Rq on two grids + the depth-1 3x7 convolutions G (all columns) and G' (last column), 3 depth classes each"},
+                # the headline path's own HBM-bound kernel: conv1's result written along the shear (one 0.74 GB write stream)
+                "kernel": "sheared_expand_kernel + 2 edge-plane copies: the first layer's output of the headline path, "
+                          "written along the shear",
+                "bound": "hbm", "achieved": V1_BYTES / (expand_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": V1_BYTES / (expand_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "bytes_per_launch": V1_BYTES,
+                "avg_launch_ms": expand_ms, "prep_ms": shear_prep_ms,
+                "prep": "Rq on two grids + the depth-1 3x7 convolutions G (all columns) and G' (last column), 3 depth classes each",
+                "warped_expand": {"kernel": "warped_expand_kernel: the same layer for ANY shift array (general_shift leg): three "
+                                            "interpolations of three 2D convolutions per voxel, same 0.74 GB write stream",
+                                  "achieved": V1_BYTES / (warp_expand_ms * 1e-3) / 1e9,
+                                  "frac": V1_BYTES / (warp_expand_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                  "bytes_per_launch": V1_BYTES, "avg_launch_ms": warp_expand_ms, "prep_ms": warp_prep_ms},
+                "right_half_builder": {"kernel": "cost_volume_fwd_rows: right (warped) half only (built_right_half leg; on no default path)",
+                                       "achieved": CV_RIGHT_BYTES / (cvr_ms * 1e-3) / 1e9,
+                                       "frac": CV_RIGHT_BYTES / (cvr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                       "bytes_per_launch": CV_RIGHT_BYTES, "avg_launch_ms": cvr_ms},
                 "full_volume": {"kernel": "cost_volume_fwd_rows: build_cost_volume, both halves (materialized leg)",
                                 "achieved": CV_BYTES / (cv_ms * 1e-3) / 1e9, "frac": CV_BYTES / (cv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "bytes_per_launch": CV_BYTES, "avg_launch_ms": cv_ms},
@@ -749,7 +778,12 @@ def main():
                 line["train"]["rccl"] = rccl_note
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            oracle_out = {}
+            line["cpu_baseline"] = cpu_baseline(outputs=oracle_out)
+            # the oracle ran on exactly the timed legs' inputs and weights: every leg's last output against it, all 5.75 M values
+            par = {k: parity_vs(v, oracle_out["cost"]) for k, v in outs.items() if v is not None}
+            line["parity_vs_cpu_baseline"] = dict(par.get("value", {}), legs=par, tolerance="north_star: 1e-3 relative fp32; "
+                                                  "tests/test_gpu_fullsize_oracle.py asserts rel_err <= 1e-4 and the elementwise rule")
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -520,6 +520,31 @@ SNVC_API int snvc_points_in_boxes_gpu(const float *boxes, const float *pts, int3
 SNVC_API int snvc_points_in_boxes_cpu(const float *boxes_host, const float *pts_host,
                                       int32_t *out_host, int T, int M);
 
+/* ------------------------------------------------------------------------------------
+ * N4  KITTI object AP / AOS evaluator core (HOST function: every pointer is a host pointer, no device work, no stream)
+ * replaces: tools/kitti-eval/evaluate_object_3d_offline.cpp / evaluate_object_3d_offline_r40.cpp -- imageBoxOverlap,
+ *   groundBoxOverlap, box3DOverlap (:227-344; the rotated-box overlaps without Boost.Geometry), getThresholds (:346-379),
+ *   cleanData (:381-454), computeStatistics (:456-616), eval_class (:622-706) and the class / metric loop of eval
+ *   (:853-911).  File parsing, the "which tables" flags of loadDetections (:159-170) and the AP read-out (:719-723,
+ *   R40: mean of recall points 1..40; R11: points 0,4,..,40) live in snvc_amd/evaluate.py.
+ *   gt  [G][14] doubles: truncation, occlusion, alpha, x1, y1, x2, y2, h, w, l, x, y, z, ry   (label_2 columns 2..15)
+ *   det [M][13] doubles: alpha, x1, y1, x2, y2, h, w, l, x, y, z, ry, score                    (result columns 4..16)
+ *   gt_type / det_type: SNVC_KITTI_* codes; gt_offsets / det_offsets [frames + 1]: rows of frame k are [off[k], off[k+1])
+ *   min_overlap [3 metrics: image, ground, 3D][3 classes: car, pedestrian, cyclist]   (the tool's MIN_OVERLAP, :55)
+ *   evaluate    [3 metrics][3 classes] != 0: fill that table (the tool's eval_image / eval_ground / eval_3d)
+ *   precision   [3 metrics][3 classes][3 difficulties: easy, moderate, hard][41 recall points]   (tables not asked for: 0)
+ *   aos         [3 classes][3 difficulties][41] or NULL; written when compute_aos != 0 (image metric only, :876-877)
+ *   threads     worker threads (0: one per hardware thread, at most 32).
+ * ---------------------------------------------------------------------------------- */
+enum {
+    SNVC_KITTI_CAR = 0, SNVC_KITTI_PEDESTRIAN = 1, SNVC_KITTI_CYCLIST = 2, SNVC_KITTI_VAN = 3,
+    SNVC_KITTI_PERSON_SITTING = 4, SNVC_KITTI_DONTCARE = 5, SNVC_KITTI_OTHER = 6
+};
+SNVC_API int snvc_kitti_eval(const double *gt, const int32_t *gt_type, const int64_t *gt_offsets, const double *det,
+                             const int32_t *det_type, const int64_t *det_offsets, int64_t frames,
+                             const double *min_overlap, const int32_t *evaluate, int compute_aos, double *precision,
+                             double *aos, int threads);
+
 #ifdef __cplusplus
 }
 #endif

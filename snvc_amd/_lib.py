@@ -101,6 +101,7 @@ SIGNATURES = {
     "snvc_roiaware_pool3d_backward": (c_int, [c_p, c_p, c_p, c_p] + [c_int] * 7 + [c_p]),
     "snvc_points_in_boxes_gpu": (c_int, [c_p, c_p, c_p, c_int, c_int, c_int, c_p]),
     "snvc_points_in_boxes_cpu": (c_int, [c_p, c_p, c_p, c_int, c_int]),
+    "snvc_kitti_eval": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_int, c_p, c_p, c_int]),
 }
 
 
@@ -132,7 +133,12 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+class Unsupported(RuntimeError):
+    """SNVC_ERR_UNSUPPORTED (status 2): the arguments are valid but this kernel form does not cover the shape (row too wide,
+    rows that do not fit the LDS, ...).  Callers that have a more general path catch it and take that path."""
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         msg = lib().snvc_last_error_string().decode("utf-8", "replace")
-        raise RuntimeError(f"{what or 'snvc_hip'} failed (status {rc}): {msg}")
+        raise (Unsupported if rc == 2 else RuntimeError)(f"{what or 'snvc_hip'} failed (status {rc}): {msg}")

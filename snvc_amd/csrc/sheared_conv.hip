@@ -747,10 +747,11 @@ int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, 
 }
 
 // Launch geometry of sheared_expand_kernel, shared by the forward statistics pass
-static int sheared_expand_rows(int64_t N, int64_t C, int64_t H, int quads) {
+static int sheared_expand_rows(int64_t N, int64_t C, int64_t H, int quads, size_t lds_floats_per_row) {
     int RB = 512 / quads;                       // rows per workgroup: as many as 512 threads cover ...
     if (RB > 8) RB = 8;
     while (RB > 1 && snvc::ceil_div<int64_t>(H, RB) * C * N < 4 * 256) RB = (RB + 1) / 2;      // ... while the chip stays covered
+    while (RB > 1 && sizeof(float) * RB * lds_floats_per_row > 150 * 1024) --RB;              // ... and the rows fit the LDS
     return RB;
 }
 
@@ -769,9 +770,9 @@ int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, 
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: y and planes must be 16-byte aligned");
     const int quads = (int)(W / 4);
     if (quads > 512 || C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand: row too wide or too many channels");
-    const int RB = sheared_expand_rows(N, C, H, quads);
-    const int threads = ceil_div(RB * quads, 64) * 64;
     const int LW = (int)((WG + q - 1) / q) + 4;
+    const int RB = sheared_expand_rows(N, C, H, quads, (size_t)q * LW + (size_t)D);
+    const int threads = ceil_div(RB * quads, 64) * 64;
     const size_t lds = sizeof(float) * ((size_t)RB * q * LW + (size_t)RB * D);
     if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand: rows do not fit the LDS");
     const dim3 grid((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N);
@@ -804,9 +805,9 @@ int snvc_sheared_expand_stats(const float *g, const float *gcol, const float *pl
     if (reinterpret_cast<uintptr_t>(planes) & 15) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_stats: planes must be 16-byte aligned");
     const int quads = (int)(W / 4);
     if (quads > 512 || C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_stats: row too wide or too many channels");
-    const int RB = sheared_expand_rows(N, C, H, quads);
-    const int threads = ceil_div(RB * quads, 64) * 64;
     const int LW = (int)((WG + q - 1) / q) + 4;
+    const int RB = sheared_expand_rows(N, C, H, quads, (size_t)q * LW + (size_t)D);
+    const int threads = ceil_div(RB * quads, 64) * 64;
     const size_t lds = sizeof(float) * ((size_t)RB * q * LW + (size_t)RB * D);
     if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_stats: rows do not fit the LDS");
     const dim3 grid((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N);
@@ -881,6 +882,7 @@ int snvc_warped_expand(const float *p, const float *q, const float *e, const flo
     int RB = 512 / quads;
     if (RB > 8) RB = 8;
     while (RB > 1 && ceil_div<int64_t>(H, RB) * C * N < 4 * 256) RB = (RB + 1) / 2;
+    while (RB > 1 && sizeof(float) * (2 * 3 * (size_t)RB * (2 * W + 8) + 3 * (size_t)RB * D) > 150 * 1024) --RB;
     const int threads = ceil_div(RB * quads, 64) * 64;
     const size_t lds = sizeof(float) * (2 * 3 * (size_t)RB * (2 * W + 8) + 3 * (size_t)RB * D);
     if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand: rows do not fit the LDS");

@@ -110,6 +110,23 @@ class GlobalStack(nn.Module):
     def _shift_structure_end(ticket, d):
         return ops.shift_spacing_result(ticket, d)     # one launch (r3 first form: 12 torch kernels, 60 us)
 
+    @staticmethod
+    def _sheared_fits(q, m0, d, w, training):
+        """The limits of csrc/sheared_conv.hip's launchers (they return SNVC_ERR_UNSUPPORTED beyond them), mirrored so that
+        such shapes take the general path instead of aborting the step: rows of at most 512 float4 pieces, and per workgroup
+        one row block's window of G plus D plane offsets in <= 150 KB of LDS (inference: at least one row; the training
+        kernels' own formulas: snvc_sheared_expand_stats like the forward, snvc_sheared_backward_reduce 4 rows of G, G',
+        their sums and D)."""
+        if w % 4 or w // 4 > 512:
+            return False
+        _, wu, _, wu_col = sheared_geometry(q, m0, d, w)
+        lw = (wu + q - 1) // q + 4
+        if 4 * (q * lw + d) > 150 * 1024:
+            return False
+        if training and 4 * 4 * (q * lw + d + 2 * wu + 2 * wu_col) > 150 * 1024:
+            return False
+        return True
+
     def _sheared_layers(self, plans, wr, q):
         """The depth-1 3 x 7 layers that compute G and G' (csrc/sheared_conv.hip): K[kh][t] = sum over (kd, kw) with
         q*kw - kd = t of the right-half weights, folded in fp64; G' is the kernel without its kw = +1 taps."""
@@ -189,6 +206,8 @@ class GlobalStack(nn.Module):
             else:
                 assert torch.all(shift >= 0.)
             plan = conv.__dict__.setdefault("_snvc_plans", {}).setdefault(left.device, _Plan())
+            if structure is not None and not self._sheared_fits(structure[0], structure[1], shift.size(1), left.size(3), True):
+                structure = None           # rows the sheared kernels do not cover (csrc/sheared_conv.hip's LDS limits): general path
             if (structure is not None and isinstance(bn, nn.BatchNorm3d) and bn.training and left.size(3) % 8 == 0
                     and left.size(3) <= 512 and fused_bn):
                 # ... with train-mode BatchNorm + ReLU folded around it: neither the raw result nor its gradient is ever stored
@@ -263,6 +282,8 @@ class GlobalStack(nn.Module):
             nonneg, structure = self._shift_structure_end(ticket, shift.size(1))
             assert nonneg                        # same contract as build_cost_volume (reference __init__.py:12)
             plans["spacing_seen"] = structure + (shift.size(1), left.size(3)) if structure is not None else None
+        if structure is not None and not self._sheared_fits(structure[0], structure[1], shift.size(1), left.size(3), False):
+            structure = None                     # rows the sheared kernels do not cover: the paths below
         if structure is not None:
             q, m0 = structure
             if ready is None or guess[:2] != structure:
@@ -272,10 +293,14 @@ class GlobalStack(nn.Module):
             mark("volume", 1)
             mark("conv1", 0)
             v = self._buffer("v1", shape, left.device)
-            ops.sheared_expand(g, gcol, planes, scale, bias, v, q, m0, off, off_col, ops.EPI_RELU)
-            mark("conv1", 1)
-            _ROUTES["sheared_first_conv"] += 1
-            return self._conv2_tail(v, shape, timing)
+            try:
+                ops.sheared_expand(g, gcol, planes, scale, bias, v, q, m0, off, off_col, ops.EPI_RELU)
+            except ops.Unsupported:              # a limit _sheared_fits does not mirror: same answer on the general paths
+                structure = None
+            else:
+                mark("conv1", 1)
+                _ROUTES["sheared_first_conv"] += 1
+                return self._conv2_tail(v, shape, timing)
         if commuted and shift.dtype == torch.float32 and left.size(3) <= 2048:
             # any other shift array: interpolation along w commutes with the convolution -- three 2D convolutions of the right
             # feature, three interpolations per output voxel, the warped volume is not built either (csrc/sheared_conv.hip)
@@ -287,12 +312,19 @@ class GlobalStack(nn.Module):
             mark("volume", 1)
             mark("conv1", 0)
             v = self._buffer("v1", shape, left.device)
-            ops.warped_expand(p_, q_, e_, planes, shift, scale, bias, v, ops.EPI_RELU)
-            mark("conv1", 1)
-            _ROUTES["commuted_first_conv"] += 1
-            return self._conv2_tail(v, shape, timing)
+            try:
+                ops.warped_expand(p_, q_, e_, planes, shift, scale, bias, v, ops.EPI_RELU)
+            except ops.Unsupported:              # rows that do not fit the LDS (grows with D): build the right half instead
+                pass
+            else:
+                mark("conv1", 1)
+                _ROUTES["commuted_first_conv"] += 1
+                return self._conv2_tail(v, shape, timing)
         mark("volume", 0)
-        vol_r = ops.cost_volume_forward_right(right, shift, out=self._buffer("vol_r", shape, left.device))   # [N,C,D,H,W]
+        try:
+            vol_r = ops.cost_volume_forward_right(right, shift, out=self._buffer("vol_r", shape, left.device))   # [N,C,D,H,W]
+        except ops.Unsupported:                  # rows beyond the row builder's width: the materialised volume, as the reference
+            return self.forward_pair(left, right, shift, downsample, factored=False, timing=timing)
         mark("volume", 1)
         mark("conv1", 0)
         v = plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, self._buffer("v1", shape, left.device), depth_planes=planes)

@@ -212,10 +212,10 @@ def _dgrad_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
 
 class _GradBox:
     """Where a skip connection's gradient waits for the layer whose data gradient it is added to (see _SkipTap)."""
-    __slots__ = ("grad", "consumed")
+    __slots__ = ("grad", "consumed", "took")
 
     def __init__(self):
-        self.grad, self.consumed = None, False
+        self.grad, self.consumed, self.took = None, False, False
 
 
 class _SkipTap(torch.autograd.Function):
@@ -234,7 +234,12 @@ class _SkipTap(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         if ctx.box.consumed:
-            raise RuntimeError("_SkipTap: the convolution's backward ran before the skip connection's")
+            # the convolution's backward has run since the last time this tap fired.  If it TOOK a parked gradient then, that
+            # was the previous pass over a retained graph (retain_graph=True, torch.autograd.grad twice): start a new pass.
+            # If it took nothing, it ran before this tap in the same pass and this gradient would be lost.
+            if not ctx.box.took:
+                raise RuntimeError("_SkipTap: the convolution's backward ran before the skip connection's")
+            ctx.box.consumed = ctx.box.took = False
         ctx.box.grad = g if ctx.box.grad is None else ctx.box.grad + g
         return None, None
 
@@ -286,6 +291,7 @@ class _ConvNormActFn(torch.autograd.Function):
         extra = None
         if ctx.grad_box is not None:        # the gradient of x's other use (a skip connection): added by the dgrad kernel's epilogue
             extra, ctx.grad_box.grad, ctx.grad_box.consumed = ctx.grad_box.grad, None, True
+            ctx.grad_box.took = extra is not None
             if extra is not None and not needs[0]:
                 raise RuntimeError("a skip connection's gradient was parked for a layer whose input needs no gradient")
             if extra is not None:
@@ -655,7 +661,9 @@ class _ShearedFirstConvBNFn(torch.autograd.Function):
         y = torch.empty(shape, dtype=torch.float32, device=left.device)
         ops.sheared_expand(g, gcol, planes, scale, shift, y, q, m0, off, off_col, EPI_RELU)
         ctx.conv, ctx.norm, ctx.q, ctx.m0 = conv, norm, q, m0
-        ctx.save_for_backward(left3, rd, g, gcol, planes, scale, shift, mean, var)
+        # gamma is saved as the autograd input it is: an in-place update between forward and backward (an interleaved
+        # optimizer step, an EMA swap) then trips autograd's version check instead of pairing a new gamma with old scale / shift
+        ctx.save_for_backward(left3, rd, g, gcol, planes, scale, shift, mean, var, gamma)
         _ROUTES["sheared_first_conv_train"] += 1
         _ROUTES["sheared_first_conv_train_fused_bn"] += 1
         return y
@@ -663,17 +671,17 @@ class _ShearedFirstConvBNFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gy):
-        left3, right, g, gcol, planes, scale, shift, mean, var = ctx.saved_tensors
+        left3, right, g, gcol, planes, scale, shift, mean, var, gamma = ctx.saved_tensors
         conv, norm, q, m0 = ctx.conv, ctx.norm, ctx.q, ctx.m0
         needs = ctx.needs_input_grad
         gy = gy.contiguous()
         n, c, depth, h, w = gy.shape
         off, wu, off_col, wu_col = sheared_geometry(q, m0, depth, w)
         line, colsum, lastc, sums = ops.sheared_backward_reduce(g, gcol, planes, scale, shift, gy, q, m0, off, off_col)
-        gw_ = norm.weight.detach().float().contiguous() if norm.weight is not None else None
+        gw_ = gamma.detach().float().contiguous() if gamma is not None else None
         a_, b_, c_, dgamma, dbeta = ops.bn_backward_coefs(sums, mean[0].contiguous(), var[0].contiguous(), gw_,
                                                           float(n * depth * h * w), float(norm.eps))
-        if norm.weight is None:
+        if gamma is None:
             dgamma = dbeta = None
         cnt_line, cnt_col, cnt_cls = _sheared_term_counts(q, m0, depth, w, gy.device)
         ch = lambda t: t.view(1, 1, c, 1, 1)                                       # noqa: E731  [N,3,C,H,*] layouts

@@ -10,13 +10,14 @@ PyTorch is plumbing here: it owns device memory and the HIP stream.  Every funct
 import contextlib
 import ctypes
 import math
+import threading
 from typing import Optional, Tuple
 
 import torch
 
 from . import _lib
 from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, Conv3dDesc,
-                   check)
+                   Unsupported, check)
 
 __all__ = [
     "cost_volume_forward", "cost_volume_forward_right", "cost_volume_backward", "cost_volume_backward_right", "depth_class_sums", "voxel_gather_forward", "voxel_gather_backward",
@@ -440,6 +441,7 @@ def shift_structure(shift):
 
 
 _PINNED4 = {}
+_PINNED4_LOCK = threading.Lock()
 
 
 def shift_structure_begin(shift):
@@ -451,10 +453,13 @@ def shift_structure_begin(shift):
         raise RuntimeError("shift_structure needs a non-empty float32 [N, D] tensor")
     shift = shift.contiguous()
     out = torch.empty(4, dtype=torch.float32, device=shift.device)
-    key = (shift.device, torch.cuda.current_stream(shift.device).cuda_stream)
-    host = _PINNED4.get(key)
+    # a ticket of its own per outstanding call (two unresolved tickets, or two threads on one stream, must not share the
+    # 16-byte result and its event); resolved tickets go back to a per-device free list
+    with _PINNED4_LOCK:
+        free = _PINNED4.setdefault(shift.device, [])
+        host = free.pop() if free else None
     if host is None:
-        host = _PINNED4[key] = (torch.empty(4, dtype=torch.float32).pin_memory(), torch.cuda.Event())
+        host = (torch.empty(4, dtype=torch.float32).pin_memory(), torch.cuda.Event(), shift.device)
     with torch.cuda.device(shift.device):
         check(_lib.lib().snvc_shift_structure(_ptr(shift), _ptr(out), shift.size(0), shift.size(1), _stream(shift)),
               "snvc_shift_structure")
@@ -466,6 +471,10 @@ def shift_structure_begin(shift):
 def shift_structure_result(ticket):
     ticket[1].synchronize()
     nonneg, u1, u2, first = ticket[0].tolist()
+    with _PINNED4_LOCK:
+        free = _PINNED4.setdefault(ticket[2], [])
+        if len(free) < 8 and not any(t is ticket for t in free):
+            free.append(ticket)
     return bool(nonneg), bool(u1), bool(u2), first
 
 
@@ -474,8 +483,10 @@ def shift_spacing_result(ticket, d: int):
     {1, 2} -- uniformly spaced whole- or half-pixel disparity planes -- exactly, in fp32 (the sheared first convolution)."""
     nonneg, u1, u2, first = shift_structure_result(ticket)
     q = 1 if u1 else (2 if u2 else 0)
+    if q == 0 or d < 4 or not math.isfinite(first):     # an all-+inf array is "non-negative" and "uniform": not a spacing
+        return nonneg, None
     m0 = first * q
-    if q == 0 or d < 4 or m0 != int(m0) or not (0 <= m0 < 1 << 20):
+    if m0 != int(m0) or not (0 <= m0 < 1 << 20):
         return nonneg, None
     return nonneg, (q, int(m0))
 

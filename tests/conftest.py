@@ -20,6 +20,9 @@ def _start_rccl_child(config):
     expr = config.getoption("-m", default="") or ""
     if "gpu" not in expr or "not gpu" in expr or os.environ.get("SNVC_NO_RCCL_CHILD"):
         return
+    # nothing that will not reach tests/test_gpu_rccl.py starts a rank: a listing, an xdist worker (one child EACH otherwise)
+    if config.getoption("collectonly", default=False) or hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return
     try:
         import torch
         if torch.cuda.device_count() < 1:
@@ -35,9 +38,29 @@ def _start_rccl_child(config):
     s.close()
     path = os.path.join(tempfile.mkdtemp(prefix="snvc_rccl_"), "report.json")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    log = open(os.path.join(os.path.dirname(path), "child.log"), "wb")      # beside report.json: a crash of the child is readable
     proc = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "helpers", "rccl_child.py"), path, str(port)], env=env,
-                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                            stdout=log, stderr=subprocess.STDOUT)
+    log.close()
     config._snvc_rccl_child = (proc, path)
+
+
+def pytest_unconfigure(config):
+    """The RCCL child must not outlive the session (-x on an earlier failure, -k / --deselect of the test that waits for it):
+    wait briefly, then kill exactly that process."""
+    child = getattr(config, "_snvc_rccl_child", None)
+    if child is None:
+        return
+    proc = child[0]
+    if proc.poll() is None:
+        try:
+            proc.wait(timeout=20)
+        except Exception:
+            proc.kill()
+            try:
+                proc.wait(timeout=10)
+            except Exception:
+                pass
 
 
 def _has_gpu():

@@ -1,0 +1,156 @@
+"""The BENCHMARKED step against the CPU oracle at the size it is benchmarked at.
+
+cfg2 (BASELINE.json configs[1]: features [1,32,96,312], 192 disparity planes) and cfg1 (configs[0]: 64 planes,
+SURVEY 8(d)'s mixed whole / half-pixel shifts) run ONCE through the oracle on the host -- C restatement of
+BuildCostVolume_cuda.cu:63-98 + the torch-CPU restatement of submodule.py:85-168 that tests/golden pins bit-equal to
+the imported reference -- with every intermediate of the stack kept.  Then:
+
+  * every entry point of the HIP path (sheared, any-shift, built right half, materialised, the reference's own call
+    sequence) against the oracle's cost on ALL 5.75 M (1.9 M) outputs: max-normalised error <= 1e-4 and north_star's
+    1e-3 relative criterion element by element (``check``);
+  * every layer of the stack on the ORACLE's input of that layer against the oracle's output of it, whole tensors
+    at the exact-fp32 tolerance: conv2 + its side head, the hourglass's stride-2 / stride-1 / transposed layers and
+    the folded one-channel tail -- so no layer's error can hide behind the next one's.
+
+bench.py uses the same inputs and weights (make_inputs(0), seeded_state): its ``parity_vs_cpu_baseline`` field is this
+comparison repeated on the timed run's own output.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import TIGHT, check
+
+pytestmark = pytest.mark.gpu
+C, H, W = 32, 96, 312
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _oracle_run(d, shift_np):
+    """One pair through the oracle, every intermediate kept (host tensors)."""
+    import bench
+    from oracle import native as O
+    from oracle import torch_ref as T
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    left, right, _ = bench.make_inputs(0, "cpu", d)
+    ref = T.GlobalStack(C)
+    ref.load_state_dict(bench.seeded_state(ref))
+    ref.eval()
+    o = {"left": left, "right": right, "shift": torch.from_numpy(shift_np), "ref": ref}
+    with torch.no_grad():
+        vol = torch.from_numpy(O.cost_volume_forward(left.numpy(), right.numpy(), shift_np, 1))
+        o["v1"] = ref.conv1(vol)
+        del vol
+        o["v2"] = ref.conv2(o["v1"])
+        hg = ref.hg_conv3d
+        o["h1"] = hg.conv1(o["v2"])
+        o["pre"] = torch.relu(hg.conv2(o["h1"]))
+        o["h3"] = hg.conv3(o["pre"])
+        o["h4"] = hg.conv4(o["h3"])
+        o["post"] = torch.relu(hg.conv5(o["h4"]) + o["pre"])
+        o["hv"] = ref.classifier(o["v2"])
+        o["cost"] = ref.classifier(o["v2"] + hg.conv6(o["post"]))
+    return o
+
+
+def _model():
+    import bench
+    from snvc_amd.models.stereo_volume import GlobalStack
+    m = GlobalStack(C)
+    m.load_state_dict(bench.seeded_state(m))
+    return m.eval().to(dev())
+
+
+@pytest.fixture(scope="module")
+def cfg2():
+    import bench
+    shift = np.linspace(0.0, (bench.D - 1) / 2.0, bench.D, dtype=np.float32)[None].copy()    # == bench.make_inputs
+    return _oracle_run(bench.D, shift)
+
+
+@pytest.fixture(scope="module")
+def cfg1():
+    d = 64
+    shift = (np.linspace(0, 63, d) + 0.5 * (np.arange(d) % 2)).astype(np.float32)[None]
+    return _oracle_run(d, shift)
+
+
+def _entry_points(o, expect_route):
+    """Every way into the step, against the oracle's cost: all outputs, check()'s three criteria."""
+    from snvc_amd.extension.build_cost_volume import build_cost_volume
+    from snvc_amd.models import submodule as S
+    m = _model()
+    dl, dr, ds = o["left"].to(dev()), o["right"].to(dev()), o["shift"].to(dev())
+    exp = o["cost"].numpy()
+    with torch.no_grad():
+        before = S._ROUTES[expect_route]
+        got = m.forward_pair(dl, dr, ds, 1).cpu().numpy()
+        assert S._ROUTES[expect_route] == before + 1, f"forward_pair did not take the {expect_route} route"
+        check(got, exp, 1e-4, f"forward_pair ({expect_route}) vs oracle, full size")
+        v1 = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+        check(v1.cpu().numpy(), o["v1"].numpy(), TIGHT, f"first layer ({expect_route}) vs oracle, full size")
+        if expect_route != "commuted_first_conv":
+            before = S._ROUTES["commuted_first_conv"]
+            got = m.forward_pair(dl, dr, ds, 1, sheared=False).cpu().numpy()
+            assert S._ROUTES["commuted_first_conv"] == before + 1
+            check(got, exp, 1e-4, "forward_pair (any shift array: warp after convolution) vs oracle, full size")
+            v1 = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+            check(v1.cpu().numpy(), o["v1"].numpy(), TIGHT, "first layer (warp after convolution) vs oracle, full size")
+        got = m.forward_pair(dl, dr, ds, 1, sheared=False, commuted=False).cpu().numpy()
+        check(got, exp, 1e-4, "forward_pair (right half built) vs oracle, full size")
+        got = m.forward_pair(dl, dr, ds, 1, factored=False).cpu().numpy()
+        check(got, exp, 1e-4, "forward_pair (materialised volume) vs oracle, full size")
+        got = m(build_cost_volume(dl, dr, ds, 1)).cpu().numpy()            # the reference's call sequence (lazy volume)
+        check(got, exp, 1e-4, "model(build_cost_volume(...)) vs oracle, full size")
+        vol = build_cost_volume(dl, dr, ds, 1)
+        vol.data_ptr()                                                       # somebody looked: the real volume
+        got = m(vol).cpu().numpy()
+        check(got, exp, 1e-4, "model(materialised lazy volume) vs oracle, full size")
+
+
+def test_cfg2_every_entry_point_vs_oracle_full_size(cfg2):
+    _entry_points(cfg2, "sheared_first_conv")
+
+
+def test_cfg1_every_entry_point_vs_oracle_full_size(cfg1):
+    """cfg1's shifts (linspace(0,63,64) + 0.5 on odd planes) are not uniformly spaced: the warp-after-convolution path."""
+    _entry_points(cfg1, "commuted_first_conv")
+
+
+def test_cfg2_every_layer_on_the_oracles_input_full_size(cfg2):
+    """conv2 + side head, hourglass conv1 (stride 2 on 192x96x312), conv2-conv5, and the folded one-channel tail
+    (deconv3d_cout1): each fed the oracle's input of that layer, whole output tensors at the exact-fp32 tolerance."""
+    from snvc_amd.models import submodule as S
+    o = cfg2
+    m = _model()
+    hg = m.hg_conv3d
+    g = lambda k: o[k].to(dev())                                                                     # noqa: E731
+    with torch.no_grad():
+        b_s = S._ROUTES["side_head"]
+        v2, hv = m.conv2.fused(g("v1"), side_head=m.classifier)
+        assert S._ROUTES["side_head"] == b_s + 1
+        check(v2.cpu().numpy(), o["v2"].numpy(), TIGHT, "conv2 (Winograd F(4,3), 32->32 on 192x96x312)")
+        check(hv.cpu().numpy(), o["hv"].numpy(), TIGHT, "conv2's side head = classifier(v2)")
+        del v2, hv
+        h1 = hg.conv1.fused(g("v2"))
+        check(h1.cpu().numpy(), o["h1"].numpy(), TIGHT, "hourglass conv1 (k3 stride 2, 32->64)")
+        del h1
+        pre = hg.conv2.fused(g("h1"), relu=True)
+        check(pre.cpu().numpy(), o["pre"].numpy(), TIGHT, "hourglass conv2 (64->64 on 96x48x156)")
+        del pre
+        h3 = hg.conv3.fused(g("pre"))
+        check(h3.cpu().numpy(), o["h3"].numpy(), TIGHT, "hourglass conv3 (k3 stride 2, 64->64)")
+        del h3
+        h4 = hg.conv4(g("h3"))
+        check(h4.cpu().numpy(), o["h4"].numpy(), TIGHT, "hourglass conv4 (64->64 on 48x24x78)")
+        del h4
+        post = hg.conv5.fused(g("h4"), relu=True, residual=g("pre"))
+        check(post.cpu().numpy(), o["post"].numpy(), TIGHT, "hourglass conv5 (transposed 64->64 + pre, ReLU)")
+        del post
+        b_f = S._ROUTES["folded_head"]
+        cost = hg.conv6.fused(g("post"), residual=g("v2"), head=m.classifier, head_residual=g("hv"))
+        assert S._ROUTES["folded_head"] == b_f + 1
+        check(cost.cpu().numpy(), o["cost"].numpy(), TIGHT, "folded tail: classifier(bn(deconv(post)) + v2) as one transposed layer to one channel")

@@ -1151,6 +1151,61 @@ def test_shift_structure_flags():
     assert ops.shift_structure(mk([np.linspace(0, 5, D)]))[:3] == (True, False, False)
 
 
+def test_shift_structure_tickets_and_non_finite():
+    """two unresolved tickets do not share their 16-byte result; an all-+inf shift array is "non-negative" and
+    "uniform" but is not a spacing (no OverflowError); resolved tickets are reused."""
+    from snvc_amd import ops
+    ar = np.arange(16, dtype=np.float32)
+    a = torch.from_numpy((ar / 2)[None].copy()).to(dev())
+    b = torch.from_numpy((5 + ar)[None].copy()).to(dev())
+    ta, tb = ops.shift_structure_begin(a), ops.shift_structure_begin(b)
+    assert ta is not tb and ta[0].data_ptr() != tb[0].data_ptr()
+    assert ops.shift_spacing_result(tb, 16) == (True, (1, 5))
+    assert ops.shift_spacing_result(ta, 16) == (True, (2, 0))
+    tc = ops.shift_structure_begin(a)
+    assert tc is ta or tc is tb                                     # back from the free list
+    assert ops.shift_spacing_result(tc, 16) == (True, (2, 0))
+    inf = torch.full((1, 16), float("inf"), device=dev())
+    nonneg, spacing = ops.shift_spacing_result(ops.shift_structure_begin(inf), 16)
+    assert spacing is None
+
+
+def test_first_conv_shapes_outside_the_special_kernels_take_the_general_path():
+    """rows wider than the sheared / warp-after-convolution kernels cover (W / 4 > 512) must not abort the step:
+    forward_pair lands on the built-right-half path and returns the oracle's answer."""
+    from oracle import native as O
+    from oracle import torch_ref as T
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    r = np.random.default_rng(5)
+    C, H, W, D = 32, 4, 2052, 4
+    L = r.standard_normal((1, C, H, W)).astype(np.float32)
+    R = r.standard_normal((1, C, H, W)).astype(np.float32)
+    ref = seeded(T.GlobalStack(C), 7)
+    ours = seeded(GlobalStack(C), 7).to(dev())
+    for s in (np.arange(D, dtype=np.float32)[None] / 2, np.array([[0.0, 0.7, 3.0, 4.25]], dtype=np.float32)):
+        with torch.no_grad():
+            exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, 1))).numpy()
+            before = (S._ROUTES["sheared_first_conv"], S._ROUTES["commuted_first_conv"])
+            got = ours.forward_pair(*(torch.from_numpy(a).to(dev()) for a in (L, R, s)), 1).cpu().numpy()
+            assert (S._ROUTES["sheared_first_conv"], S._ROUTES["commuted_first_conv"]) == before
+        check(got, exp, 1e-4, "pair, W = 2052")
+
+
+def test_hourglass_training_twice_over_a_retained_graph():
+    """the skip-connection taps (_SkipTap / _GradBox) survive a second backward over a retained graph."""
+    from snvc_amd.models.submodule import hourglass
+    torch.manual_seed(3)
+    hg = hourglass(32).to(dev()).train()
+    x = torch.randn(1, 32, 8, 8, 32, device=dev(), requires_grad=True)
+    out = hg(x, None, None, residual=x)[0]
+    loss = out.pow(2).mean()
+    g1 = torch.autograd.grad(loss, [x] + list(hg.parameters()), retain_graph=True)
+    g2 = torch.autograd.grad(loss, [x] + list(hg.parameters()))
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("q,m0", [(2, 0), (2, 3), (1, 0), (1, 2)])
 def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
     """Uniformly spaced disparity planes, shift[d] = (m0 + d) / q: forward_pair takes the sheared first convolution
