@@ -167,7 +167,10 @@ enum {
      * result never written (snvc/models/vernier.py:289,436: the pool between the trunk's conv4 and the BEV reshape).
      * Built for 3x3x3 / stride-1 Conv3d layers on the default Winograd form with Dout % 4 == 0 and no residual;
      * SNVC_ERR_UNSUPPORTED otherwise (the caller then pools in a launch of its own: snvc_avgpool_depth4). */
-    SNVC_EPI_AVGPOOL_D4 = 16
+    SNVC_EPI_AVGPOOL_D4 = 16,
+    /* snvc_warped_expand only: the r3 kernel form (four 16-byte LDS reads per kd and plane) instead of the register-window
+     * form; same values up to fp32 rounding, kept selectable for the parity tests and A/B timing. */
+    SNVC_WARPED_EXPAND_R3 = 256
 };
 
 /* desc.algo: which arithmetic / kernel form a layer may use.  Low byte = the arithmetic:

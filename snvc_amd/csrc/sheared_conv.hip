@@ -330,6 +330,193 @@ warped_expand_kernel(const float *__restrict__ p, const float *__restrict__ q, c
     }
 }
 
+// r4 form of the same layer: the interpolation windows live in REGISTERS across the walk over d.
+// Output plane d adds, for kd = 0..2, the interpolation of row P_kd at the shift of plane e = d + kd - 1; as d advances every kd
+// sees the same sequence of shifts (one plane apart), so the five floats F_kd[w0 - m - 1 .. w0 - m + 3] a quad needs move only when
+// m = floor(s_e) moves -- in a plane sweep by 0, +-1 or +-2 columns per plane.  The window (one for the F rows, one for the G rows,
+// per kd) is then shifted in registers and refilled with |dm| 4-byte LDS reads; only a jump re-reads it (two aligned 16-byte
+// pieces per row and the wave-uniform alignment pick of the r3 form).  r3 read four 16-byte pieces per kd and plane (192 B of
+// LDS per 16 B stored: 0.288 ms at cfg2, LDS-bound); on cfg2's half-pixel steps this form reads 3 x 2 x 4 B every other plane.
+// A whole-pixel shift s = m is evaluated as (m - 1, f = 1, g = 0): F[w - m] with nothing gated, which is what the reference
+// computes there, so the choice "G rows or F rows for the g-term" disappears from the loop.
+// Rows are staged with 12 zeros in front and >= 4 behind (LW = W + 16 instead of 2 W + 8: 26 KB per workgroup at cfg2, every
+// workgroup of the launch resident at once); a window that starts left of them is all zeros and reads the zero pad (clamped address).
+// tas[r][d] = the last column's zero-padding term of output plane d, summed over kd once per workgroup.
+__global__ void __launch_bounds__(512)
+warped_expand_win_kernel(const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
+                         const float *__restrict__ planes, const float *__restrict__ shift, const float *__restrict__ scale,
+                         const float *__restrict__ bias, float *__restrict__ y, int C, int D, int H, int W, int RB, int flags) {
+    extern __shared__ float lds[];
+    constexpr int FP = 12;                               // zero columns in front of column 0 (column -1 is staged, not zero)
+    constexpr int kInvalid = (int)0x80000001, kNone = (int)0x80000000;
+    const int quads = W >> 2, LW = W + 16;
+    const int tid = threadIdx.x;
+    const int co = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int h0 = blockIdx.x * RB;
+    const int rows = (H - h0) < RB ? (H - h0) : RB;
+    const int64_t hw = (int64_t)H * W;
+    float *const rowsG = lds + 3 * RB * LW;
+    float *const tas = rowsG + 3 * RB * LW;              // [RB][D]
+    f32x4 *const ptab = reinterpret_cast<f32x4 *>(tas + RB * D + ((4 - ((RB * D) & 3)) & 3));    // [D + 2]: {m, f, g, valid} of plane d
+    const float *sh = shift + n * D;
+    // plane parameters, once per workgroup (the walk reads them back as broadcast LDS reads: no scalar memory load inside the
+    // loop, whose out-of-order return would force every LDS wait in it down to lgkmcnt(0))
+    for (int i = tid; i < D + 2; i += blockDim.x) {
+        f32x4 t = {__builtin_bit_cast(float, kInvalid), 0.0f, 0.0f, 0.0f};      // no such plane / every sample left of the image: adds 0
+        if (i < D) {
+            const float s = sh[i];
+            if (s <= (float)W) {
+                const float mf = __builtin_floorf(s);
+                float ff = s - mf;
+                int mm = (int)mf;
+                if (ff == 0.0f) { mm -= 1; ff = 1.0f; }      // whole pixel: F[w - m], nothing gated
+                t = f32x4{__builtin_bit_cast(float, mm), ff, 1.0f - ff, 0.0f};
+            }
+        }
+        ptab[i] = t;
+    }
+    for (int i = tid; i < 3 * rows * (LW >> 2); i += blockDim.x) {
+        const int row = i / (LW >> 2), pc = i - row * (LW >> 2);
+        const int kd = row / rows, r = row - kd * rows, col = 4 * pc - FP;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (col >= 0 && col < W) v = *reinterpret_cast<const f32x4 *>(p + (((n * 3 + kd) * C + co) * (int64_t)H + h0 + r) * W + col);
+        f32x4 g4 = v;
+        const float *er = e + (((n * 3 + kd) * 3) * C + co) * (int64_t)H * 4 + (int64_t)(h0 + r) * 4;
+        const int64_t kws = (int64_t)C * H * 4;
+        if (col == -4) { v[3] = er[2 * kws]; g4[3] = 0.0f; }              // column -1: F = E2, G = 0
+        if (col == 0) { g4[0] = v[0] - er[kws]; g4[1] = v[1] - er[0]; }   // columns 0, 1 of G: the gated sample's share removed
+        *reinterpret_cast<f32x4 *>(lds + (kd * RB + r) * LW + 4 * pc) = v;
+        *reinterpret_cast<f32x4 *>(rowsG + (kd * RB + r) * LW + 4 * pc) = g4;
+    }
+    __syncthreads();                                     // ptab is complete
+    for (int i = tid; i < rows * D; i += blockDim.x) {
+        const int r = i / D, d = i - r * D;
+        // the three kd terms' plane parameters from ptab (no dependent global load), their six q values requested together
+        float fk[3], gk[3], a0[3], a1[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const int ee = d + kd - 1;
+            const f32x4 t = ptab[ee < 0 ? D : ee];       // entry D: "no such plane"
+            const int mm = __builtin_bit_cast(int, t[0]);
+            const bool valid = mm != kInvalid;
+            // ptab holds a whole-pixel shift s = m as (m - 1, f = 1, g = 0): Q0[W - m - 1] = Q[W - (m - 1) - 2]: same element
+            const int i0 = W - mm - 1;                   // f * Q[i0] + g * Q[i0 + 1]
+            const float *qr = q + (((n * 3 + kd) * C + co) * (int64_t)H + h0 + r) * W;
+            fk[kd] = t[1]; gk[kd] = t[2];
+            a0[kd] = (valid && (unsigned)i0 < (unsigned)W) ? qr[i0] : 0.0f;
+            a1[kd] = (valid && (unsigned)(i0 + 1) < (unsigned)W) ? qr[i0 + 1] : 0.0f;
+            if (i0 + 1 == 0) a1[kd] = 0.0f;              // Qg[0]: the gated sample's share (only reached with g > 0, i.e. a fractional shift)
+        }
+        tas[r * D + d] = (fk[0] * a0[0] + gk[0] * a1[0]) + (fk[1] * a0[1] + gk[1] * a1[1]) + (fk[2] * a0[2] + gk[2] * a1[2]);
+    }
+    __syncthreads();
+    if (tid >= rows * quads) return;
+    const int r = tid / quads, qd = tid - r * quads, w0 = 4 * qd, h = h0 + r;
+    const bool last = qd == quads - 1;
+    const float sc = scale ? scale[co] : 1.0f, bi = scale ? bias[co] : 0.0f;
+    const bool relu = (flags & SNVC_EPI_RELU) != 0;
+    f32x4 pl[3];
+#pragma unroll
+    for (int cls = 0; cls < 3; ++cls) {
+        pl[cls] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (planes) pl[cls] = *reinterpret_cast<const f32x4 *>(planes + (((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w0);
+    }
+    float *yp = y + ((n * C + co) * (int64_t)D) * hw + (int64_t)h * W + w0;
+    const float *tar = tas + r * D;
+    const int lane_idx = r * LW + FP + w0 - 1;          // index of window element 0 in an LDS row set, before "- m" and "+ kd * RB * LW"
+    const int row_lo = r * LW;                           // clamp: a window that starts left of the row's zero pad reads the pad
+    auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni_f = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    auto at = [&](const float *rows_, int idx) { return rows_[idx < row_lo ? row_lo : idx]; };
+
+    // The walk is bound by the VALU instructions a wave issues per plane (~120 at 65 % of HBM: a 1 KB store per wave and plane),
+    // so everything wave-uniform lives in scalar registers and the per-plane vector work is 12 packed FMAs + the epilogue:
+    //   * plane parameters {m, f, g} come from ptab (one broadcast LDS read a step ahead, three v_readfirstlane); a plane that
+    //     does not exist or lies wholly left of the image has f = g = 0 and m = kInvalid: it adds 0 and moves no window
+    //   * window kd = F[kd] at columns w0 - mw - 1 .. w0 - mw + 2 (the f-term's four) and G[kd] one column further (the g-term's
+    //     four): two aligned register quads that the packed FMAs read in place
+    int pm[3];
+    float pf[3], pg[3];
+    auto take = [&](const f32x4 &t, int &m, float &f, float &g) {
+        m = uni_i(__builtin_bit_cast(int, t[0])); f = uni_f(t[1]); g = uni_f(t[2]);
+    };
+    pm[0] = kInvalid; pf[0] = pg[0] = 0.0f;
+    take(ptab[0], pm[1], pf[1], pg[1]);
+    take(ptab[1], pm[2], pf[2], pg[2]);                  // ptab has D + 2 entries, the last two invalid
+    f32x4 nxt = ptab[2];
+    f32x4 wf[3], wg[3];
+    int mw[3] = {kNone, kNone, kNone};
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) wf[kd] = wg[kd] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // move window kd to column offset m (wave-uniform; only called when m != mw[kd])
+    auto refill = [&](int kd, int m) {
+        const float *fr = lds + kd * RB * LW, *gr = rowsG + kd * RB * LW;
+        const int idx0 = lane_idx - m;
+        const int dm = m - mw[kd];
+        f32x4 &F = wf[kd], &G = wg[kd];
+        if (mw[kd] != kNone && dm == 1) {
+            F = f32x4{at(fr, idx0), F[0], F[1], F[2]};
+            G = f32x4{at(gr, idx0 + 1), G[0], G[1], G[2]};
+        } else if (mw[kd] != kNone && dm == 2) {
+            F = f32x4{at(fr, idx0), at(fr, idx0 + 1), F[0], F[1]};
+            G = f32x4{at(gr, idx0 + 1), at(gr, idx0 + 2), G[0], G[1]};
+        } else if (dm == -1) {
+            F = f32x4{F[1], F[2], F[3], at(fr, idx0 + 3)};
+            G = f32x4{G[1], G[2], G[3], at(gr, idx0 + 4)};
+        } else if (dm == -2) {
+            F = f32x4{F[2], F[3], at(fr, idx0 + 2), at(fr, idx0 + 3)};
+            G = f32x4{G[2], G[3], at(gr, idx0 + 3), at(gr, idx0 + 4)};
+        } else {
+            // a jump: two aligned 16-byte pieces per row; window column i sits at position a + i of the eight floats
+            // (a = (3 - m) & 3 is the same for every lane: FP and w0 are multiples of 4)
+            const int a = (3 - m) & 3;
+            int base = idx0 - a;
+            base = base < row_lo ? row_lo : base;        // left of the pad: eight zeros
+            const f32x4 FA = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(fr + base, 16));
+            const f32x4 FB = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(fr + base + 4, 16));
+            const f32x4 GA = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(gr + base, 16));
+            const f32x4 GB = *reinterpret_cast<const f32x4 *>(__builtin_assume_aligned(gr + base + 4, 16));
+            if (a == 0) { F = FA; G = f32x4{GA[1], GA[2], GA[3], GB[0]}; }
+            else if (a == 1) { F = f32x4{FA[1], FA[2], FA[3], FB[0]}; G = f32x4{GA[2], GA[3], GB[0], GB[1]}; }
+            else if (a == 2) { F = f32x4{FA[2], FA[3], FB[0], FB[1]}; G = f32x4{GA[3], GB[0], GB[1], GB[2]}; }
+            else { F = f32x4{FA[3], FB[0], FB[1], FB[2]}; G = GB; }
+        }
+        mw[kd] = m;
+    };
+
+    for (int d = 0; d < D; ++d) {
+        // (requesting the refills a step ahead, so that their LDS latency hides behind the arithmetic, was measured and is
+        // SLOWER: the walk is bound by instruction issue, not by LDS latency; profiles/r4/kernel_experiments_r4.txt)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+            if (pm[kd] != mw[kd] && pm[kd] != kInvalid) refill(kd, pm[kd]);
+        int nm;
+        float nff, ngg;
+        take(nxt, nm, nff, ngg);                         // plane d + 2: kd = 2 of the next step
+        nxt = ptab[d + 3 < D + 2 ? d + 3 : D + 1];
+        const float tl = tar[d];
+        f32x4 o = d == 0 ? pl[0] : (d == D - 1 ? pl[2] : pl[1]);
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const f32x4 f4 = {pf[kd], pf[kd], pf[kd], pf[kd]}, g4 = {pg[kd], pg[kd], pg[kd], pg[kd]};
+            o = __builtin_elementwise_fma(g4, wg[kd], __builtin_elementwise_fma(f4, wf[kd], o));
+        }
+        o[3] -= last ? tl : 0.0f;                        // the kw = +1 taps of the last column read the zero padding
+        const f32x4 sc4 = {sc, sc, sc, sc}, bi4 = {bi, bi, bi, bi};
+        o = __builtin_elementwise_fma(o, sc4, bi4);
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaxf(o[k], 0.0f);      // NaN -> 0, as the generic epilogues (v > 0 ? v : 0)
+        }
+        *reinterpret_cast<f32x4 *>(yp + (int64_t)d * hw) = o;
+        pm[0] = pm[1]; pf[0] = pf[1]; pg[0] = pg[1];
+        pm[1] = pm[2]; pf[1] = pf[2]; pg[1] = pg[2];
+        pm[2] = nm; pf[2] = nff; pg[2] = ngg;
+    }
+}
+
 // ------------------------------------------------------------------------------------ backward (training, cfg4)
 // Adjoint of sheared_expand_kernel w.r.t. G and G' (scale = 1: the caller applies the norm's backward first):
 //     dG[n][cls][co][h][i]  = sum over (d in class cls, w <= W-2) with Q*w - d - m0 + off  == i of dy[n][co][d][h][w]
@@ -872,7 +1059,7 @@ int snvc_warped_expand(const float *p, const float *q, const float *e, const flo
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand: bad sizes (W % 4 == 0)");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand: scale and bias must both be given or both be NULL");
-    if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand: only SNVC_EPI_RELU");
+    if (flags & ~(SNVC_EPI_RELU | SNVC_WARPED_EXPAND_R3)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand: only SNVC_EPI_RELU");
     if (N == 0) return SNVC_OK;
     if (!p || !q || !e || !shift || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand: null pointer");
     if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(p)) & 15)
@@ -882,13 +1069,25 @@ int snvc_warped_expand(const float *p, const float *q, const float *e, const flo
     int RB = 512 / quads;
     if (RB > 8) RB = 8;
     while (RB > 1 && ceil_div<int64_t>(H, RB) * C * N < 4 * 256) RB = (RB + 1) / 2;
-    while (RB > 1 && sizeof(float) * (2 * 3 * (size_t)RB * (2 * W + 8) + 3 * (size_t)RB * D) > 150 * 1024) --RB;
+    if (flags & SNVC_WARPED_EXPAND_R3) {        // the r3 form (four 16-byte LDS reads per kd and plane): kept for A/B tests
+        while (RB > 1 && sizeof(float) * (2 * 3 * (size_t)RB * (2 * W + 8) + 3 * (size_t)RB * D) > 150 * 1024) --RB;
+        const int threads = ceil_div(RB * quads, 64) * 64;
+        const size_t lds = sizeof(float) * (2 * 3 * (size_t)RB * (2 * W + 8) + 3 * (size_t)RB * D);
+        if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand: rows do not fit the LDS");
+        static std::atomic<unsigned> attr{0};
+        if (!allow_large_lds(reinterpret_cast<const void *>(&warped_expand_kernel), (int)lds, attr)) return check_launch("snvc_warped_expand");
+        warped_expand_kernel<<<dim3((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N), threads, lds, as_stream(stream)>>>(
+            p, q, e, planes, shift, scale, bias, y, (int)C, (int)D, (int)H, (int)W, RB, flags & SNVC_EPI_RELU);
+        return check_launch("snvc_warped_expand");
+    }
+    auto lds_of = [&](int rb) { return sizeof(float) * (2 * 3 * (size_t)rb * (W + 16) + (size_t)rb * D + 4 + 4 * (size_t)(D + 2)); };
+    while (RB > 1 && lds_of(RB) > 150 * 1024) --RB;
     const int threads = ceil_div(RB * quads, 64) * 64;
-    const size_t lds = sizeof(float) * (2 * 3 * (size_t)RB * (2 * W + 8) + 3 * (size_t)RB * D);
+    const size_t lds = lds_of(RB);
     if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand: rows do not fit the LDS");
-    static std::atomic<unsigned> attr{0};
-    if (!allow_large_lds(reinterpret_cast<const void *>(&warped_expand_kernel), (int)lds, attr)) return check_launch("snvc_warped_expand");
-    warped_expand_kernel<<<dim3((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N), threads, lds, as_stream(stream)>>>(
+    static std::atomic<unsigned> attr_w{0};
+    if (!allow_large_lds(reinterpret_cast<const void *>(&warped_expand_win_kernel), (int)lds, attr_w)) return check_launch("snvc_warped_expand");
+    warped_expand_win_kernel<<<dim3((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N), threads, lds, as_stream(stream)>>>(
         p, q, e, planes, shift, scale, bias, y, (int)C, (int)D, (int)H, (int)W, RB, flags);
     return check_launch("snvc_warped_expand");
 }

@@ -408,6 +408,10 @@ class Conv3dLayer:
         return out, scale, shift, mean, var
 
 
+WARPED_EXPAND_R3 = 256           # include/snvc_hip.h SNVC_WARPED_EXPAND_R3
+WARPED_EXPAND_FORM = [0]         # tests / A-B timing: [WARPED_EXPAND_R3] selects the r3 kernel form
+
+
 def warped_expand(p, q, e, planes, shift, scale, bias, out, flags: int = 0):
     """First convolution over the warped half for ANY shift array, warp after convolution (snvc_warped_expand):
     p, q [N,3C,H,W] (kd-major stacks of the depth-1 convolutions of the right feature: all taps | the kw = +1 taps alone),
@@ -427,7 +431,7 @@ def warped_expand(p, q, e, planes, shift, scale, bias, out, flags: int = 0):
     shift = shift.contiguous()
     with torch.cuda.device(out.device):
         check(_lib.lib().snvc_warped_expand(_ptr(p), _ptr(q), _ptr(e), _ptr(planes), _ptr(shift), _ptr(scale), _ptr(bias), _ptr(out),
-                                            n, c, d, h, w, int(flags), _stream(out)), "snvc_warped_expand")
+                                            n, c, d, h, w, int(flags) | WARPED_EXPAND_FORM[0], _stream(out)), "snvc_warped_expand")
     return out
 
 

@@ -1090,7 +1090,8 @@ def test_global_pair_end_to_end_vs_oracle(tile):
     check(full1, exp1, 2e-5, "conv1")
 
 
-@pytest.mark.parametrize("case", ["random", "whole_pixels", "beyond_the_image", "ragged_rows"])
+@pytest.mark.parametrize("case", ["random", "whole_pixels", "beyond_the_image", "ragged_rows", "sweep_up", "sweep_down", "sweep_cfg1",
+                                  "sweep_quarter"])
 def test_commuted_first_conv_any_shift_vs_oracle_and_built_volume(case):
     """Any shift array (inference): the first convolution over the warped half as three interpolations of three 2D convolutions
     (snvc_warped_expand, csrc/sheared_conv.hip) -- against the C oracle's cost volume + the torch-CPU stack and against the path
@@ -1108,6 +1109,11 @@ def test_commuted_first_conv_any_shift_vs_oracle_and_built_volume(case):
     s = r.uniform(0, 20, (2, D))
     if case == "whole_pixels":
         s = np.floor(s)
+    elif case.startswith("sweep"):       # monotone plane sweeps: the register windows move by 0, +-1, +-2 columns per plane
+        d_ = np.arange(D, dtype=np.float64)
+        s = {"sweep_up": np.stack([0.7 * d_ + 0.3, 1.9 * d_]), "sweep_down": np.stack([30.0 - 1.3 * d_, 25.5 - 2.0 * d_]),
+             "sweep_cfg1": np.stack([d_ + 0.5 * (d_ % 2), 3.0 + d_ + 0.5 * (d_ % 2)]),
+             "sweep_quarter": np.stack([0.25 * d_, 40.0 + 0.25 * d_])}[case]
     elif case == "beyond_the_image":
         s[:, ::2] = r.uniform(W - 2, W + 3, (2, (D + 1) // 2))
         s[0, 1], s[1, 3] = float(W), float(W - 1)
@@ -1129,6 +1135,16 @@ def test_commuted_first_conv_any_shift_vs_oracle_and_built_volume(case):
     check(v1c.cpu().numpy(), v1b.cpu().numpy(), TIGHT, f"first layer, warp after convolution vs built volume ({case})")
     check(got, exp, 1e-4, f"pair vs oracle ({case})")
     check(got, built, 2e-5, f"pair, warp after convolution vs built volume ({case})")
+    # the r3 kernel form (SNVC_WARPED_EXPAND_R3) and the register-window form agree to fp32 rounding
+    from snvc_amd import ops
+    ops.WARPED_EXPAND_FORM[0] = ops.WARPED_EXPAND_R3
+    try:
+        with torch.no_grad():
+            ours.forward_pair(dl, dr, dsh, 1)
+            v1r = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+    finally:
+        ops.WARPED_EXPAND_FORM[0] = 0
+    check(v1c.cpu().numpy(), v1r.cpu().numpy(), 2e-6, f"first layer, register-window form vs r3 form ({case})")
 
 
 def test_shift_structure_flags():
