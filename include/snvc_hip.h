@@ -470,6 +470,32 @@ SNVC_API int snvc_f16_conv3d_pack_weights(const snvc_conv3d_desc *desc_host, con
 SNVC_API int snvc_f16_conv3d_forward(const snvc_conv3d_desc *desc_host, const void *x_c8, const void *packed_weight,
                                      const float *scale, const float *bias, const void *residual_c8, void *y_c8,
                                      float *y_f32, void *stream);
+/* ------------------------------------------------------------------------------------
+ * r4 split mode ("f16x3"): the fp32 layers' contraction at fp32 accuracy on the half-precision matrix pipe.
+ * A value travels as a PAIR of C8 half tensors, v * 2^e = hi + lo (hi = half(v * 2^e), lo = half(v * 2^e - hi): 22
+ * significant bits; the exponent e is the caller's, a power of two keeps the split exact), weights likewise, and a
+ * product is evaluated as hi_w*hi_x + lo_w*hi_x + hi_w*lo_x on three v_mfma_f32_32x32x16_f16 with fp32 accumulation
+ * (the dropped lo*lo term is 2^-22 of the product: measured 5e-7 of the output range on an 864-term contraction, the
+ * fp32 FMA chain's own figure).  Same layers, same epilogue and flags as snvc_conv3d_forward for
+ * nn.Conv3d(k3, stride 1, pad 1) (+ folded eval BatchNorm) (+ residual) (+ ReLU) -- snvc/models/submodule.py:32-50 --
+ * with Cin % 8 == 0 and Cout % 32 == 0.  The caller folds 2^-(e_x + e_w) (and 2^e_y for a split output) into
+ * scale / bias.  Output: a split C8 pair (y_hi, y_lo; residual then a split pair too), or, with y_f32 != NULL, a plain
+ * fp32 NCDHW tensor [N][Cout][D][H][W] (no residual) for a consumer on the fp32 kernels.
+ * Values beyond half's range after scaling (|v * 2^e| > 65504) overflow: the caller picks e from what it knows of the
+ * tensor (folded BatchNorm statistics) -- see snvc_amd/ops.py.
+ * ---------------------------------------------------------------------------------- */
+SNVC_API int snvc_f16x3_from_ncdhw(const float *x, void *y_hi, void *y_lo, int64_t N, int64_t C, int64_t S,
+                                   int64_t x_batch_stride, int64_t y_batch_stride, float mul, void *stream);
+SNVC_API int snvc_f16x3_to_ncdhw(const void *x_hi, const void *x_lo, float *y, int64_t N, int64_t C, int64_t S,
+                                 int64_t x_batch_stride, int64_t y_batch_stride, float mul, void *stream);
+SNVC_API int64_t snvc_f16x3_conv3d_packed_weight_bytes(const snvc_conv3d_desc *desc_host);
+/* weight: the fp32 nn.Conv3d [Cout,Cin,3,3,3] parameter; packed as (hi, lo) of weight * wmul (wmul a power of two). */
+SNVC_API int snvc_f16x3_conv3d_pack_weights(const snvc_conv3d_desc *desc_host, const float *weight, void *packed,
+                                            float wmul, void *stream);
+SNVC_API int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,
+                                       const void *packed_weight, const float *scale, const float *bias,
+                                       const void *res_hi, const void *res_lo, void *y_hi, void *y_lo, float *y_f32,
+                                       void *stream);
 /* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half (vernier.py:433) on C8 tensors:
  *   out[n,c,s] = half(float(feat[n,c,s]) * occ[n,0,s]), occ an fp32 plane [N][S]; C % 8 == 0. */
 SNVC_API int snvc_f16_mul_broadcast(const void *feat_c8, const float *occ, void *out_c8, int64_t N, int64_t C,

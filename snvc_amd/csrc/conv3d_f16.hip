@@ -42,7 +42,10 @@ struct F16Args {
     const float *scale, *bias;
     const _Float16 *res;
     _Float16 *y;
-    float *y_f32;        // EPI 1: [N][1][Dout][Hout][Wout] fp32 plane of output channel 0
+    float *y_f32;        // EPI 1: [N][1][Dout][Hout][Wout] fp32 plane of output channel 0; EPI 2: [N][Cout][Dout][Hout][Wout] fp32
+    // split mode (PL = 2, "f16x3"): every tensor is a pair of C8 half planes, value = hi + lo; x / res / y are the hi planes
+    const _Float16 *x_lo, *res_lo;
+    _Float16 *y_lo;
     int CGin;            // input channel groups (Cin / 8, rounded up)
     int Cout;
     int Din, Hin, Win;
@@ -61,11 +64,15 @@ struct F16Args {
 
 // A-fragment register ring depth (k-steps ahead).  Measured on cfg5 (k7 / k5 / k3 ms): 2: 9.70 / 1.92 / 0.91;
 // 4: 9.38 / 2.00 / 0.91; 6: 8.99 / 1.82 / 0.85 (242-246 VGPRs, no spills); 8: 8.89 / 1.83 / 0.86 with spills.
-constexpr int F16_PF = 6;
 
 template <int KD_, int KH_, int KW_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KCG_, int MODE_, bool DB_, int OCC_,
-          int DILW_ = DIL_>
+          int DILW_ = DIL_, int PL_ = 1>
 struct F16Cfg {
+    // PL = 2: split mode.  Activations and weights are (hi, lo) pairs of halves, value = hi + lo (22 significant bits), and a
+    // product is evaluated as hi*hi + lo_w*hi_x + hi_w*lo_x on three v_mfma_f32_32x32x16_f16 with fp32 accumulation: the fp32
+    // layers' contraction at fp32 accuracy (the dropped lo*lo term is 2^-22 of the product) on the 16x faster half pipe.
+    static constexpr int PL = PL_;
+    static constexpr int PF = PL_ == 2 ? 3 : 6;             // A-fragment ring depth (k-steps ahead)
     // DIL applies to D and H, DILW to W (they differ only for the sub-grid form of a dilated layer, see F16K5D2)
     static constexpr int KD = KD_, KH = KH_, KW = KW_, STRIDE = STRIDE_, DIL = DIL_, DILW = DILW_, MI = MI_, TD = TD_, TH = TH_;
     static constexpr int KCG = KCG_, MODE = MODE_, OCC = OCC_;
@@ -75,7 +82,8 @@ struct F16Cfg {
     static constexpr int IN_W = 31 * STRIDE + (KW - 1) * DILW + 1;
     static constexpr int VOX = IN_D * IN_H * IN_W;          // pieces per channel-group image
     static constexpr int GB = VOX * 16;                     // bytes per channel-group image
-    static constexpr int ITEMS = KCG * VOX;
+    static constexpr int ITEMS = PL * KCG * VOX;            // image = [plane][channel group][voxel] pieces
+    static constexpr int PLANE_BYTES = KCG * GB;
     static constexpr int NIT = (ITEMS + 255) / 256;
     static constexpr int IMG_BYTES = NIT * 256 * 16;        // whole DMA rounds
     static constexpr int LDS_BYTES = IMG_BYTES * (DB ? 2 : 1);
@@ -122,7 +130,7 @@ conv3d_f16_kernel(const F16Args a_) {
     }
     constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, NB = Cfg::NB, KCG = Cfg::KCG;
     constexpr int IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, GB = Cfg::GB, NIT = Cfg::NIT, ITEMS = Cfg::ITEMS;
-    constexpr int PF = F16_PF;
+    constexpr int PF = Cfg::PF, PL = Cfg::PL;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -147,11 +155,14 @@ conv3d_f16_kernel(const F16Args a_) {
     // the chunk's first channel group) and validity do not depend on the chunk
     const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     unsigned off[NIT];
-    unsigned vmask = 0;
+    unsigned vmask = 0, gmask = 0, pmask = 0;           // per piece: valid, its channel group (KCG <= 2), its plane
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = it * 256 + tid;
-        const int g = i / VOX, r = i - g * VOX;
+        const int pg = i / VOX, r = i - pg * VOX;
+        const int plane = pg / KCG, g = pg - plane * KCG;
+        gmask |= (unsigned)(g & 1) << it;
+        pmask |= (unsigned)(plane & 1) << it;
         const int dd = r / (IN_H * IN_W), r2 = r - dd * (IN_H * IN_W);
         const int hh = r2 / IN_W, ww = r2 - hh * IN_W;
         const int gd = (id0 + dd) * a.isd + a.iod, gh = (ih0 + hh) * a.ish + a.ioh, gw = iw0 + ww;
@@ -160,16 +171,18 @@ conv3d_f16_kernel(const F16Args a_) {
         off[it] = ok ? (unsigned)(g * in_dhw + gd * in_hw + gh * a.Win + gw) : 0u;
         vmask |= (ok ? 1u : 0u) << it;
     }
-    const _Float16 *xn = a.x + n * a.x_bs;
+    static_assert(KCG <= 2, "gmask holds one bit per piece");
+    const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = PL == 2 ? a.x_lo + n * a.x_bs : nullptr;
     const int wbase = tid & ~63;
     auto issue = [&](int chunk, int buf) {
-        const _Float16 *xc = xn + (int64_t)chunk * KCG * in_dhw * 8;
+        const int64_t coff = (int64_t)chunk * KCG * in_dhw * 8;
         const int cg_left = a.CGin - chunk * KCG;
         char *const ibuf = lds + buf * Cfg::IMG_BYTES;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = it * 256 + tid;
-            const bool ok = ((vmask >> it) & 1u) && (KCG == 1 || i / VOX < cg_left);
+            const bool ok = ((vmask >> it) & 1u) && (KCG == 1 || (int)((gmask >> it) & 1u) < cg_left);
+            const _Float16 *xc = (PL == 2 && ((pmask >> it) & 1u) ? xn_lo : xn) + coff;
             const void *src = ok ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
             if (ITEMS % 256 == 0 || i < ITEMS)
                 __builtin_amdgcn_global_load_lds(static_cast<const float *>(src),
@@ -196,14 +209,16 @@ conv3d_f16_kernel(const F16Args a_) {
     const int b_none = lanebase;
 
     // ---- A fragments: [cout block][chunk][segment][k-step][m][lane] pieces, consumed in exactly that order
+    // (split mode: [..][k-step][m][hi | lo][lane])
+    constexpr int MA = MI * PL;
     const int64_t steps_total = (int64_t)a.nchunks * Cfg::STEPS;
-    const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * MI) * 64 + lane;
-    h8 q[PF][MI];
+    const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * MA) * 64 + lane;
+    h8 q[PF][MA];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
 #pragma unroll
-        for (int m = 0; m < MI; ++m) q[i][m] = wq[m * 64];
-        wq += MI * 64;     // the packed buffer carries PF steps of zero padding behind the last block
+        for (int m = 0; m < MA; ++m) q[i][m] = wq[m * 64];
+        wq += MA * 64;     // the packed buffer carries PF steps of zero padding behind the last block
     }
 
     auto compute = [&](const char *img) {
@@ -227,22 +242,32 @@ conv3d_f16_kernel(const F16Args a_) {
                         base = delta == D_SAME ? b_same : (delta == D_ROW ? b_row : b_slice);
                     }
                 }
-                h8 af[MI];
+                h8 af[MA];
 #pragma unroll
-                for (int m = 0; m < MI; ++m) af[m] = q[0][m];
+                for (int m = 0; m < MA; ++m) af[m] = q[0][m];
 #pragma unroll
                 for (int i = 0; i + 1 < PF; ++i)
 #pragma unroll
-                    for (int m = 0; m < MI; ++m) q[i][m] = q[i + 1][m];
+                    for (int m = 0; m < MA; ++m) q[i][m] = q[i + 1][m];
 #pragma unroll
-                for (int m = 0; m < MI; ++m) q[PF - 1][m] = wq[m * 64];
-                wq += MI * 64;
+                for (int m = 0; m < MA; ++m) q[PF - 1][m] = wq[m * 64];
+                wq += MA * 64;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const h8 bf = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
+                    if constexpr (PL == 2) {
+                        const h8 bl = *reinterpret_cast<const h8 *>(simg + Cfg::PLANE_BYTES + base + toff + rowoff[nb]);
 #pragma unroll
-                    for (int m = 0; m < MI; ++m)
-                        acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf, acc[nb][m], 0, 0, 0);
+                        for (int m = 0; m < MI; ++m) {      // the two correction terms first, then the leading one
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf, acc[nb][m], 0, 0, 0);
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bl, acc[nb][m], 0, 0, 0);
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf, acc[nb][m], 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int m = 0; m < MI; ++m)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf, acc[nb][m], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -291,9 +316,30 @@ conv3d_f16_kernel(const F16Args a_) {
             if (a.flags & SNVC_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
             if (okv[nb] && half == 0) yp[sp[nb]] = v;
         }
+    } else if constexpr (EPI == 2) {
+        // fp32 NCDHW output (a split-mode layer handing its result to the fp32 kernels): register r of a lane is channel
+        // c0 + r of voxel (lane & 31): per store instruction two 128-byte runs (one per half-wave)
+        float *yp = a.y_f32 + n * a.yf_bs;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+            if ((cb * MI + m) * 32 >= a.Cout) break;
+            const int c0 = (cb * MI + m) * 32 + 16 * half;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float sc = a.scale ? a.scale[c0 + r] : 1.0f, bi = a.scale ? a.bias[c0 + r] : 0.0f;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    float v = acc[nb][m][r] * sc + bi;
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    if (okv[nb]) yp[(int64_t)(c0 + r) * out_dhw + sp[nb]] = v;
+                }
+            }
+        }
     } else {
         const _Float16 *rn = a.res ? a.res + n * a.r_bs : nullptr;
+        const _Float16 *rn_lo = (PL == 2 && a.res) ? a.res_lo + n * a.r_bs : nullptr;
         _Float16 *yn = a.y + n * a.y_bs;
+        _Float16 *yn_lo = PL == 2 ? a.y_lo + n * a.y_bs : nullptr;
 #pragma unroll
         for (int m = 0; m < MI; ++m) {
             if ((cb * MI + m) * 32 >= a.Cout) break;                // Cout = 32 * odd: the last block is half empty
@@ -307,24 +353,30 @@ conv3d_f16_kernel(const F16Args a_) {
             const int64_t g0 = (int64_t)(c0 >> 3) * out_dhw;        // channel group of registers 0..7; 8..15 is the next
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                h8 rv[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    rv[j] = rn ? *reinterpret_cast<const h8 *>(rn + ((g0 + j * out_dhw) + sp[nb]) * 8) : h8((_Float16)0.0f);
+                h8 rv[2], rl[2];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    h8 o;
+                    rv[j] = rn ? *reinterpret_cast<const h8 *>(rn + ((g0 + j * out_dhw) + sp[nb]) * 8) : h8((_Float16)0.0f);
+                    rl[j] = rn_lo ? *reinterpret_cast<const h8 *>(rn_lo + ((g0 + j * out_dhw) + sp[nb]) * 8) : h8((_Float16)0.0f);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    h8 o, ol;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int r = 8 * j + e;
                         float v = acc[nb][m][r] * sc[r >> 2][r & 3] + bi[r >> 2][r & 3];
-                        const float rr = (float)rv[j][e];
+                        const float rr = (float)rv[j][e] + (float)rl[j][e];
                         if (add_pre) v += rr;
                         if (relu) v = v > 0.0f ? v : 0.0f;
                         if (add_post) v += rr;
                         o[e] = (_Float16)v;
+                        if constexpr (PL == 2) ol[e] = (_Float16)(v - (float)o[e]);
                     }
-                    if (okv[nb]) *reinterpret_cast<h8 *>(yn + ((g0 + j * out_dhw) + sp[nb]) * 8) = o;
+                    if (okv[nb]) {
+                        *reinterpret_cast<h8 *>(yn + ((g0 + j * out_dhw) + sp[nb]) * 8) = o;
+                        if constexpr (PL == 2) *reinterpret_cast<h8 *>(yn_lo + ((g0 + j * out_dhw) + sp[nb]) * 8) = ol;
+                    }
                 }
             }
         }
@@ -339,6 +391,8 @@ struct PackArgs {
     int transposed, pd, ph, pw;  // transposed: parity class of this packing ([Cin][Cout][3][3][3] source)
     int KD, KH, KW, KCG, MODE, MI, SEGS, TSEG, NPS, NS, unroll_d;
     int nchunks, cblocks;
+    int PL;                    // 2: split mode, [..][m][hi | lo][lane][8]; values are w * wmul (a power of two) split as hi + lo
+    float wmul;
     int64_t total;             // elements (halves)
 };
 
@@ -348,6 +402,7 @@ __global__ void pack_f16_weights_kernel(const PackArgs p) {
     int64_t r = i;
     const int e = (int)(r % 8); r /= 8;
     const int lane = (int)(r % 64); r /= 64;
+    const int pl = (int)(r % p.PL); r /= p.PL;
     const int m = (int)(r % p.MI); r /= p.MI;
     const int s = (int)(r % p.NS); r /= p.NS;
     const int seg = (int)(r % p.SEGS); r /= p.SEGS;
@@ -377,7 +432,13 @@ __global__ void pack_f16_weights_kernel(const PackArgs p) {
             if (ok) v = p.w[((((int64_t)ci * p.Cout + co) * 3 + k3[0]) * 3 + k3[1]) * 3 + k3[2]];
         }
     }
-    p.out[i] = (_Float16)v;
+    if (p.PL == 2) {
+        v *= p.wmul;
+        const _Float16 hi = (_Float16)v;
+        p.out[i] = pl ? (_Float16)(v - (float)hi) : hi;
+    } else {
+        p.out[i] = (_Float16)v;
+    }
 }
 
 // ------------------------------------------------------------------------------------ configurations
@@ -404,10 +465,17 @@ using F16K5D2N = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2>;
 using F16K7N   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2>;
 using F16DCN   = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 0, true, 2>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FNONE };
+// r4 split mode ("f16x3": fp32-accurate layers on the half pipe, see F16Cfg::PL): one channel group per chunk, two taps per MFMA
+// (MODE 1), hi and lo planes of the image side by side in LDS (2 x 19.6 KB), single-buffered at three (MI = 1) / two (MI = 2)
+// workgroups per CU.
+//                         KD KH KW S  D  MI TD TH KCG MODE DB    OCC DILW PL
+using F16K3X  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, false, 3, 1, 2>;
+using F16K3X2 = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 1, 1, false, 2, 1, 2>;
+
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FNONE };
 
 struct F16Plan {
-    int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d;
+    int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF;
     int nchunks, cblocks;
     int64_t block_halves;      // packed halves of one class (without padding)
 };
@@ -418,13 +486,27 @@ F16Plan plan_from(int kind) {
     p.kind = kind; p.MI = Cfg::MI; p.KCG = Cfg::KCG; p.MODE = Cfg::MODE; p.TD = Cfg::TD; p.TH = Cfg::TH;
     p.STEPS = Cfg::STEPS; p.SEGS = Cfg::SEGS; p.TSEG = Cfg::TSEG; p.NPS = Cfg::NPS; p.NS = Cfg::NS;
     p.KD = Cfg::KD; p.KH = Cfg::KH; p.KW = Cfg::KW; p.unroll_d = Cfg::UNROLL_D ? 1 : 0;
+    p.PL = Cfg::PL; p.PF = Cfg::PF;
     return p;
 }
 
-int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p) {
+int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
     if (d.N < 0 || d.Cin <= 0 || d.Cout <= 0 || d.Din <= 0 || d.Hin <= 0 || d.Win <= 0)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d: sizes must be positive");
     if (d.Cin % 8 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: Cin must be a multiple of 8 (C8 layout)");
+    if (split) {
+        const int eff = d.dilation * (d.ksize - 1) + 1;
+        if (d.transposed || d.ksize != 3 || d.stride != 1 || d.dilation != 1 || d.pad != 1 || d.Cout % 32 != 0)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: built for Conv3d(k3, s1, p1) with Cout % 32 == 0");
+        if (d.Dout != d.Din + 2 - eff + 1 || d.Hout != d.Hin + 2 - eff + 1 || d.Wout != d.Win + 2 - eff + 1)
+            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d: output size does not match the convolution arithmetic");
+        p = d.Cout == 32 ? plan_from<F16K3X>(FK3X) : plan_from<F16K3X2>(FK3X2);
+        p.nchunks = ceil_div(d.Cin / 8, p.KCG);
+        p.cblocks = ceil_div(d.Cout, 32 * p.MI);
+        p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * p.MI * p.PL * 64 * 8;
+        if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: too many channel blocks or samples");
+        return SNVC_OK;
+    }
     if (d.Cout != 1 && d.Cout % 32 != 0)
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: Cout must be a multiple of 32, or 1 (fp32 plane output)");
     if (d.transposed) {
@@ -462,12 +544,12 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p) {
     }
     p.nchunks = ceil_div(d.Cin / 8, p.KCG);
     p.cblocks = ceil_div(d.Cout, 32 * p.MI);
-    p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * p.MI * 64 * 8;
+    p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * p.MI * p.PL * 64 * 8;
     if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: too many channel blocks or samples");
     return SNVC_OK;
 }
 
-inline int64_t f16_class_stride(const F16Plan &p) { return p.block_halves + (int64_t)F16_PF * p.MI * 64 * 8; }
+inline int64_t f16_class_stride(const F16Plan &p) { return p.block_halves + (int64_t)p.PF * p.MI * p.PL * 64 * 8; }
 
 template <class Cfg, int EPI>
 void launch_f16(const F16Args &a, dim3 grid, hipStream_t st) {
@@ -488,17 +570,18 @@ int64_t snvc_f16_conv3d_packed_weight_bytes(const snvc_conv3d_desc *d) {
     return 2 * f16_class_stride(p) * (d->transposed ? 8 : 1);
 }
 
-int snvc_f16_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, void *packed, void *stream) {
+static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void *packed, bool split, float wmul, void *stream,
+                           const char *who) {
     using namespace snvc;
     F16Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_pack_weights: null desc");
-    int rc = make_f16_plan(*d, p);
+    int rc = make_f16_plan(*d, p, split);
     if (rc) return rc;
     if (!weight || !packed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_pack_weights: null pointer");
-    const int64_t bytes = snvc_f16_conv3d_packed_weight_bytes(d);
+    const int classes = d->transposed ? 8 : 1;
+    const int64_t bytes = 2 * f16_class_stride(p) * classes;
     if (hipMemsetAsync(packed, 0, (size_t)bytes, as_stream(stream)) != hipSuccess)   // the ring's read-ahead padding
         return fail(SNVC_ERR_HIP, "snvc_f16_conv3d_pack_weights: hipMemsetAsync failed");
-    const int classes = d->transposed ? 8 : 1;
     for (int c = 0; c < classes; ++c) {
         PackArgs a;
         a.w = weight;
@@ -508,9 +591,25 @@ int snvc_f16_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight,
         a.KD = p.KD; a.KH = p.KH; a.KW = p.KW; a.KCG = p.KCG; a.MODE = p.MODE; a.MI = p.MI; a.SEGS = p.SEGS;
         a.TSEG = p.TSEG; a.NPS = p.NPS; a.NS = p.NS; a.unroll_d = p.unroll_d;
         a.nchunks = p.nchunks; a.cblocks = p.cblocks; a.total = p.block_halves;
+        a.PL = p.PL; a.wmul = wmul;
         pack_f16_weights_kernel<<<(unsigned)ceil_div<int64_t>(a.total, 256), 256, 0, as_stream(stream)>>>(a);
     }
-    return check_launch("snvc_f16_conv3d_pack_weights");
+    return check_launch(who);
+}
+
+int snvc_f16_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, void *packed, void *stream) {
+    return f16_pack_common(d, weight, packed, false, 1.0f, stream, "snvc_f16_conv3d_pack_weights");
+}
+
+int64_t snvc_f16x3_conv3d_packed_weight_bytes(const snvc_conv3d_desc *d) {
+    using namespace snvc;
+    F16Plan p;
+    if (!d || make_f16_plan(*d, p, true) != SNVC_OK) return -1;
+    return 2 * f16_class_stride(p);
+}
+
+int snvc_f16x3_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, void *packed, float wmul, void *stream) {
+    return f16_pack_common(d, weight, packed, true, wmul, stream, "snvc_f16x3_conv3d_pack_weights");
 }
 
 int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void *packed_weight, const float *scale,
@@ -542,7 +641,7 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     if ((d->x_batch_stride | d->y_batch_stride | d->res_batch_stride) % 8)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d_forward: batch strides must be multiples of 8 elements");
 
-    F16Args a;
+    F16Args a{};
     a.x = reinterpret_cast<const _Float16 *>(x);
     a.scale = scale; a.bias = bias;
     a.res = resflags ? reinterpret_cast<const _Float16 *>(residual) : nullptr;
@@ -600,6 +699,66 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
         default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: no kernel");
     }
     return check_launch("snvc_f16_conv3d_forward");
+}
+
+int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
+                              const float *scale, const float *bias, const void *res_hi, const void *res_lo, void *y_hi,
+                              void *y_lo, float *y_f32, void *stream) {
+    using namespace snvc;
+    F16Plan p;
+    if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null desc");
+    int rc = make_f16_plan(*d, p, true);
+    if (rc) return rc;
+    if (d->N == 0) return SNVC_OK;
+    const bool to_f32 = y_f32 != nullptr;
+    if (!x_hi || !x_lo || !packed_weight || (!to_f32 && (!y_hi || !y_lo)))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null pointer");
+    if ((scale == nullptr) != (bias == nullptr))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: scale and bias must both be given or both be NULL");
+    const int resflags = d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST);
+    if (resflags && (!res_hi || !res_lo || to_f32))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: residual flag without a split residual (C8 output only)");
+    if (resflags == (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: ADD_PRE and ADD_POST are exclusive");
+    if (d->flags & ~(SNVC_EPI_RELU | SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: RELU / ADD_PRE / ADD_POST only");
+    const int64_t in_sp = (int64_t)d->Din * d->Hin * d->Win, out_sp = (int64_t)d->Dout * d->Hout * d->Wout;
+    if ((int64_t)(d->Cin / 8 + 2) * in_sp >= ((int64_t)1 << 31) || (int64_t)d->Cout * out_sp >= ((int64_t)1 << 40) || out_sp >= ((int64_t)1 << 31))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: one sample must stay below 2^31 pieces");
+    if ((reinterpret_cast<uintptr_t>(x_hi) | reinterpret_cast<uintptr_t>(x_lo) | reinterpret_cast<uintptr_t>(y_hi) |
+         reinterpret_cast<uintptr_t>(y_lo) | reinterpret_cast<uintptr_t>(res_hi) | reinterpret_cast<uintptr_t>(res_lo) |
+         reinterpret_cast<uintptr_t>(packed_weight)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: C8 tensors must be 16-byte aligned");
+    if ((d->x_batch_stride | d->y_batch_stride | d->res_batch_stride) % 8)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: batch strides must be multiples of 8 elements");
+    F16Args a{};
+    a.x = reinterpret_cast<const _Float16 *>(x_hi); a.x_lo = reinterpret_cast<const _Float16 *>(x_lo);
+    a.scale = scale; a.bias = bias;
+    a.res = resflags ? reinterpret_cast<const _Float16 *>(res_hi) : nullptr;
+    a.res_lo = resflags ? reinterpret_cast<const _Float16 *>(res_lo) : nullptr;
+    a.y = reinterpret_cast<_Float16 *>(y_hi); a.y_lo = reinterpret_cast<_Float16 *>(y_lo); a.y_f32 = y_f32;
+    a.CGin = d->Cin / 8; a.Cout = d->Cout;
+    a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
+    a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;
+    a.nchunks = p.nchunks; a.flags = d->flags;
+    a.x_bs = d->x_batch_stride ? d->x_batch_stride : (int64_t)d->Cin * in_sp;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->Cout * out_sp;
+    a.r_bs = d->res_batch_stride ? d->res_batch_stride : (int64_t)d->Cout * out_sp;
+    a.yf_bs = to_f32 ? a.y_bs : out_sp;
+    a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
+    a.N = d->N; a.cls_mode = 0; a.cls_wstride = f16_class_stride(p);
+    a.isd = a.ish = 1; a.iod = a.ioh = 0; a.offd = a.offh = a.offw = 0;
+    a.nd = d->Dout; a.nh = d->Hout; a.nw = d->Wout;
+    a.osd = a.osh = a.osw = 1;
+    a.pad_d = a.pad_h = a.pad_w = d->pad;
+    a.tiles_d = ceil_div(a.nd, p.TD); a.tiles_h = ceil_div(a.nh, p.TH); a.tiles_w = ceil_div(a.nw, 32);
+    const int64_t ntiles = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
+    if (ntiles >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles");
+    dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)d->N);
+    hipStream_t st = as_stream(stream);
+    if (p.kind == FK3X) { if (to_f32) launch_f16<F16K3X, 2>(a, grid, st); else launch_f16<F16K3X, 0>(a, grid, st); }
+    else { if (to_f32) launch_f16<F16K3X2, 2>(a, grid, st); else launch_f16<F16K3X2, 0>(a, grid, st); }
+    return check_launch("snvc_f16x3_conv3d_forward");
 }
 
 }  // extern "C"

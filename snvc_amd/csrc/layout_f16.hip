@@ -36,6 +36,41 @@ c8_to_ncdhw_f32_kernel(const _Float16 *__restrict__ x, float *__restrict__ y, in
         if (g * 8 + e < C) yp[(int64_t)e * S] = (float)v[e];
 }
 
+// split mode (conv3d_f16.hip, F16Cfg::PL == 2): value * mul (a power of two) = hi + lo, two C8 half planes
+__global__ void __launch_bounds__(256)
+ncdhw_f32_to_c8_split_kernel(const float *__restrict__ x, _Float16 *__restrict__ yh, _Float16 *__restrict__ yl, int C, int64_t S,
+                             int64_t x_bs, int64_t y_bs, float mul) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int g = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const float *xp = x + n * x_bs + (int64_t)g * 8 * S + s;
+    h8 o, ol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = (g * 8 + e < C) ? xp[(int64_t)e * S] * mul : 0.0f;
+        o[e] = (_Float16)v;
+        ol[e] = (_Float16)(v - (float)o[e]);
+    }
+    *reinterpret_cast<h8 *>(yh + n * y_bs + ((int64_t)g * S + s) * 8) = o;
+    *reinterpret_cast<h8 *>(yl + n * y_bs + ((int64_t)g * S + s) * 8) = ol;
+}
+
+__global__ void __launch_bounds__(256)
+c8_split_to_ncdhw_f32_kernel(const _Float16 *__restrict__ xh, const _Float16 *__restrict__ xl, float *__restrict__ y, int C, int64_t S,
+                             int64_t x_bs, int64_t y_bs, float mul) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int g = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const h8 v = *reinterpret_cast<const h8 *>(xh + n * x_bs + ((int64_t)g * S + s) * 8);
+    const h8 l = *reinterpret_cast<const h8 *>(xl + n * x_bs + ((int64_t)g * S + s) * 8);
+    float *yp = y + n * y_bs + (int64_t)g * 8 * S + s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (g * 8 + e < C) yp[(int64_t)e * S] = ((float)v[e] + (float)l[e]) * mul;
+}
+
 // out[n][g][s][:] = feat[n][g][s][:] * occ[n][s]   (occ: fp32 plane; product in fp32, rounded once)
 __global__ void __launch_bounds__(256)
 mul_broadcast_c8_kernel(const _Float16 *__restrict__ feat, const float *__restrict__ occ, _Float16 *__restrict__ out,
@@ -113,6 +148,38 @@ int snvc_f16_to_ncdhw(const void *x, float *y, int64_t N, int64_t C, int64_t S, 
                                                                x_batch_stride ? x_batch_stride : G * 8 * S,
                                                                y_batch_stride ? y_batch_stride : C * S);
     return check_launch("snvc_f16_to_ncdhw");
+}
+
+int snvc_f16x3_from_ncdhw(const float *x, void *y_hi, void *y_lo, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                          int64_t y_batch_stride, float mul, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_from_ncdhw: bad sizes");
+    if (N == 0 || S == 0) return SNVC_OK;
+    const int64_t G = ceil_div<int64_t>(C, 8);
+    if (!x || !y_hi || !y_lo || ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_from_ncdhw: null or unaligned pointer");
+    if (!grid_ok(S, G, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_from_ncdhw: tensor too large");
+    dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)G, (unsigned)N);
+    ncdhw_f32_to_c8_split_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, reinterpret_cast<_Float16 *>(y_hi), reinterpret_cast<_Float16 *>(y_lo),
+                                                                     (int)C, S, x_batch_stride ? x_batch_stride : C * S,
+                                                                     y_batch_stride ? y_batch_stride : G * 8 * S, mul);
+    return check_launch("snvc_f16x3_from_ncdhw");
+}
+
+int snvc_f16x3_to_ncdhw(const void *x_hi, const void *x_lo, float *y, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                        int64_t y_batch_stride, float mul, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_to_ncdhw: bad sizes");
+    if (N == 0 || S == 0) return SNVC_OK;
+    const int64_t G = ceil_div<int64_t>(C, 8);
+    if (!x_hi || !x_lo || !y || ((reinterpret_cast<uintptr_t>(x_hi) | reinterpret_cast<uintptr_t>(x_lo)) & 15))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_to_ncdhw: null or unaligned pointer");
+    if (!grid_ok(S, G, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_to_ncdhw: tensor too large");
+    dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)G, (unsigned)N);
+    c8_split_to_ncdhw_f32_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const _Float16 *>(x_hi), reinterpret_cast<const _Float16 *>(x_lo),
+                                                                     y, (int)C, S, x_batch_stride ? x_batch_stride : G * 8 * S,
+                                                                     y_batch_stride ? y_batch_stride : C * S, mul);
+    return check_launch("snvc_f16x3_to_ncdhw");
 }
 
 int snvc_f16_mul_broadcast(const void *feat, const float *occ, void *out, int64_t N, int64_t C, int64_t S,

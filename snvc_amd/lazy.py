@@ -22,7 +22,9 @@ class LazyCostVolume(torch.Tensor):
         r._sources = (left, right, shift, downsample)
         r._build = build
         r._real = None
+        r._real_version = None
         r._spacing = spacing
+        r._source_versions = (left._version, right._version, shift._version)
         return r
 
     @property
@@ -41,10 +43,30 @@ class LazyCostVolume(torch.Tensor):
         """(left, right, shift, downsample) as given to build_cost_volume."""
         return self._sources
 
+    @property
+    def sources_unchanged(self):
+        """No in-place write to left / right / shift since build_cost_volume was called."""
+        left, right, shift, _ = self._sources
+        return (left._version, right._version, shift._version) == self._source_versions
+
+    @property
+    def is_pristine(self):
+        """The volume still equals build_cost_volume(*sources): never built, or built and only LOOKED at since (its version
+        counter has not moved; nobody wrote through an aten operator) -- and the sources themselves are untouched.  Then
+        GlobalStack.forward may take the fused path from the sources: same values as the eager volume would give."""
+        if not self.sources_unchanged:
+            return False
+        return self._real is None or self._real._version == self._real_version
+
     def materialize(self) -> torch.Tensor:
         if self._real is None:
+            if not self.sources_unchanged:
+                raise RuntimeError("LazyCostVolume: left / right / shift were modified in place after build_cost_volume(...) and "
+                                   "before the volume was first used; the volume the call described can no longer be built "
+                                   "(clone the inputs, or call build_cost_volume with autograd enabled for the eager tensor)")
             left, right, shift, ds = self._sources
             self._real = self._build(left, right, shift, ds)
+            self._real_version = self._real._version
         return self._real
 
     # ---- everything else sees the real tensor

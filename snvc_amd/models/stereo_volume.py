@@ -87,7 +87,8 @@ class GlobalStack(nn.Module):
         from ..lazy import LazyCostVolume
         if isinstance(volume, LazyCostVolume):
             # build_cost_volume's result that nobody has looked at yet: the reference's call sequence on the fused path
-            if not volume.is_materialized and not torch.is_grad_enabled() and not self.training:
+            # ... or that somebody only PEEKED at (materialised, never written to: same values, so the fused path still applies)
+            if volume.is_pristine and not torch.is_grad_enabled() and not self.training:
                 left, right, shift, ds = volume.sources
                 if left.shape[1] * 2 == self.conv1[0][0].in_channels and left.shape[3] % 4 == 0:
                     return self.forward_pair(left, right, shift, ds, shift_checked=True, spacing=volume.spacing)

@@ -1049,6 +1049,123 @@ class Conv3dLayerF16:
         return y32 if plane else out
 
 
+# ------------------------------------------------------------------------------------ split mode ("f16x3")
+def _split_check(t: torch.Tensor, name: str):
+    _gpu(t, name)
+    if t.dtype != torch.float16 or t.dim() != 7 or t.size(1) != 2 or t.size(6) != 8:
+        raise RuntimeError(f"{name} must be a split C8 tensor: float16 [N, 2 (hi | lo), C/8, D, H, W, 8], got {tuple(t.shape)} {t.dtype}")
+    if not _dense_inner(t) or t.data_ptr() % 16:
+        raise RuntimeError(f"{name} must be dense below dim 0 and 16-byte aligned")
+
+
+def _lo_ptr(t: torch.Tensor):
+    return ctypes.c_void_p(t.data_ptr() + 2 * t.stride(1)) if t.numel() else ctypes.c_void_p(0)
+
+
+def to_split(x: torch.Tensor, exp: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 [N,C,D,H,W] -> split C8 [N, 2, ceil(C/8), D, H, W, 8] half with  x * 2**exp = hi + lo  (snvc_f16x3_from_ncdhw)."""
+    _gpu(x, "x")
+    if x.dtype != torch.float32 or x.dim() != 5:
+        raise RuntimeError("to_split needs a float32 [N,C,D,H,W] tensor")
+    if not _dense_inner(x):
+        x = x.contiguous()
+    n, c = x.shape[0], x.shape[1]
+    sp = tuple(x.shape[2:])
+    if out is None:
+        out = torch.empty((n, 2, (c + 7) // 8) + sp + (8,), dtype=torch.float16, device=x.device)
+    else:
+        _split_check(out, "out")
+    if x.numel() == 0:
+        return out
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_f16x3_from_ncdhw(_ptr(x), _ptr(out), _lo_ptr(out), n, c, math.prod(sp), _batch_stride(x), _batch_stride(out),
+                                               float(2.0 ** exp), _stream(x)), "snvc_f16x3_from_ncdhw")
+    return out
+
+
+def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) -> torch.Tensor:
+    """split C8 -> float32 [N,C,D,H,W]: (hi + lo) * 2**-exp."""
+    _split_check(x, "x")
+    n, g = x.shape[0], x.shape[2]
+    sp = tuple(x.shape[3:6])
+    c = channels if channels is not None else 8 * g
+    y = torch.empty((n, c) + sp, dtype=torch.float32, device=x.device)
+    if y.numel() == 0:
+        return y
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_f16x3_to_ncdhw(_ptr(x), _lo_ptr(x), _ptr(y), n, c, math.prod(sp), _batch_stride(x), 0, float(2.0 ** -exp),
+                                             _stream(x)), "snvc_f16x3_to_ncdhw")
+    return y
+
+
+class Conv3dLayerX3:
+    """nn.Conv3d(k3, s1, p1) prepared for the split-mode kernels (snvc_f16x3_conv3d_*): fp32-accurate contraction on the half
+    pipe.  The weights are packed as (hi, lo) of  w * 2**w_exp  with w_exp chosen so that max|w| lands in [2^13, 2^14): both
+    parts then keep their full 11 bits."""
+
+    def __init__(self, weight: torch.Tensor, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1, transposed: bool = False):
+        _gpu(weight, "weight")
+        if weight.dtype != torch.float32:
+            raise RuntimeError("conv3d weights must be float32")
+        self.transposed = bool(transposed)
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
+        wmax = float(weight.detach().abs().max().item()) if weight.numel() else 1.0
+        self.w_exp = 13 - math.frexp(wmax)[1] + 1 if wmax > 0 and math.isfinite(wmax) else 0      # wmax * 2^w_exp in [2^13, 2^14)
+        probe = self._desc(1, (16, 16, 32), 0)
+        nbytes = _lib.lib().snvc_f16x3_conv3d_packed_weight_bytes(ctypes.byref(probe))
+        if nbytes < 0:
+            check(2, "snvc_f16x3_conv3d_packed_weight_bytes")
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        with torch.cuda.device(weight.device):
+            check(_lib.lib().snvc_f16x3_conv3d_pack_weights(ctypes.byref(probe), _ptr(weight.detach().contiguous()), _ptr(self.packed),
+                                                            float(2.0 ** self.w_exp), _stream(weight)), "snvc_f16x3_conv3d_pack_weights")
+
+    out_spatial = Conv3dLayer.out_spatial
+    _desc = Conv3dLayer._desc
+
+    def __call__(self, x, x_exp: int = 0, scale=None, bias=None, residual=None, flags: int = 0, out=None, out_exp: int = 0,
+                 out_f32=None, to_f32: bool = False):
+        """y = epilogue(conv(x)).  x: split C8 tensor holding values * 2**x_exp.  Result: a split C8 tensor holding
+        y * 2**out_exp (``residual``: a split tensor with the same exponent), or -- ``to_f32`` / ``out_f32`` -- float32 NCDHW."""
+        _split_check(x, "x")
+        if x.size(2) * 8 != self.cin:
+            raise RuntimeError(f"conv3d input must have {self.cin} channels (split C8), got {x.size(2) * 8}")
+        n = x.size(0)
+        in_sp = tuple(x.shape[3:6])
+        out_sp = self.out_spatial(in_sp)
+        f32 = to_f32 or out_f32 is not None
+        if f32:
+            if residual is not None:
+                raise RuntimeError("the float32 output form takes no residual")
+            if out_f32 is None:
+                out_f32 = torch.empty((n, self.cout) + out_sp, dtype=torch.float32, device=x.device)
+            elif tuple(out_f32.shape) != (n, self.cout) + out_sp or out_f32.dtype != torch.float32 or not _dense_inner(out_f32):
+                raise RuntimeError("out_f32 must be a float32 [N,Cout,D,H,W] tensor, dense below dim 0")
+            out_exp = 0
+        elif out is None:
+            out = torch.empty((n, 2, self.cout // 8) + out_sp + (8,), dtype=torch.float16, device=x.device)
+        else:
+            _split_check(out, "out")
+        if residual is not None:
+            _split_check(residual, "residual")
+        # the exponents ride in the epilogue's affine: conv sums are in units of 2^(x_exp + w_exp)
+        dev = x.device
+        fold = 2.0 ** (out_exp - x_exp - self.w_exp)
+        sc = (scale.float() if scale is not None else torch.ones(self.cout, device=dev)) * fold
+        bi = (bias.float() if bias is not None else torch.zeros(self.cout, device=dev)) * (2.0 ** out_exp)
+        if n == 0:
+            return out_f32 if f32 else out
+        d = self._desc(n, in_sp, flags, _batch_stride(x), _batch_stride(out_f32 if f32 else out),
+                       _batch_stride(residual) if residual is not None else 0)
+        with torch.cuda.device(dev):
+            check(_lib.lib().snvc_f16x3_conv3d_forward(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(self.packed), _ptr(sc.contiguous()),
+                                                       _ptr(bi.contiguous()), _ptr(residual), _lo_ptr(residual) if residual is not None else None,
+                                                       _ptr(out) if not f32 else None, _lo_ptr(out) if not f32 else None,
+                                                       _ptr(out_f32) if f32 else None, _stream(x)), "snvc_f16x3_conv3d_forward")
+        return out_f32 if f32 else out
+
+
 def mul_broadcast_c8(feat, occ, out=None):
     """out[n,c,...] = feat[n,c,...] * occ[n,0,...] on C8 tensors (occ: float32 [N,1,D,H,W])."""
     _c8_check(feat, "feat")

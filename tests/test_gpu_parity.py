@@ -1031,8 +1031,21 @@ def test_lazy_cost_volume_reference_call_sequence():
         vol4 = build_cost_volume(L, R, S_, 1)
         y4 = m.conv1.fused(vol4)                         # a kernel of this library asking for the pointer
         assert vol4.is_materialized and torch.equal(y4, m.conv1.fused(eager))
-        y5 = m(vol4)                                     # a materialised lazy volume: the materialised path
-        assert torch.equal(y5, y_mat)
+        y5 = m(vol4)                                     # materialised but only LOOKED at: still the fused path (r4)
+        assert vol4.is_pristine and torch.equal(y5, y_pair)
+        vol7 = build_cost_volume(L, R, S_, 1)
+        vol7.add_(1.0)                                   # written to through an aten operator: the values are the tensor's own now
+        assert vol7.is_materialized and not vol7.is_pristine
+        assert torch.equal(m(vol7), m(eager + 1.0))
+        L2 = L.clone()
+        vol8 = build_cost_volume(L2, R, S_, 1)
+        L2.add_(1.0)                                     # a source modified before the volume was ever built: it cannot be any more
+        with pytest.raises(RuntimeError, match="modified in place"):
+            m(vol8)
+        vol9 = build_cost_volume(L2, R, S_, 1)
+        peek = vol9[:, :1].clone()                       # built, then a source changes: the BUILT values stay the volume's values
+        L2.add_(1.0)
+        assert not vol9.is_pristine and torch.equal(m(vol9), m(vol9.materialize())) and torch.equal(peek, vol9.materialize()[:, :1])
         m.train()
         vol6 = build_cost_volume(L, R, S_, 1)            # train-mode BatchNorm: not the fused path
         y6 = m(vol6)
