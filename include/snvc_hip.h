@@ -341,6 +341,14 @@ SNVC_API int snvc_sheared_upsample(const float *right, float *out, int64_t N, in
 SNVC_API int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale,
                                  const float *bias, float *y, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q,
                                  int m0, int64_t WG, int off, int64_t WG2, int off2, int flags, void *stream);
+/* snvc_sheared_expand with the result written as a split C8 pair (y_hi, y_lo: half [N][2][C/8][D][H][W][8] planes, see the
+ * split-mode section below) for a consumer on the snvc_f16x3_* kernels; scale / bias carry the tensor's exponent (the host
+ * folds 2^e in: exact).  y_batch_stride in halves (0: dense pair).  overflow (device int, may be NULL): set to 1 if a value had
+ * to be clamped to half's range. */
+SNVC_API int snvc_sheared_expand_split(const float *g, const float *gcol, const float *planes, const float *scale,
+                                       const float *bias, void *y_hi, void *y_lo, int *overflow, int64_t N, int64_t C,
+                                       int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2,
+                                       int off2, int64_t y_batch_stride, int flags, void *stream);
 /* Backward of the sheared first convolution (training, BASELINE.json configs[3]); dy = the gradient of the layer's RAW
  * result (the caller applies the norm / activation backward first, snvc_act_backward_*).
  *   snvc_sheared_reduce            : adjoint of snvc_sheared_expand: dg [N][3][C][H][WG] / dgcol [N][3][C][H][WG2] = the
@@ -477,10 +485,10 @@ SNVC_API int snvc_f16_conv3d_forward(const snvc_conv3d_desc *desc_host, const vo
  * product is evaluated as hi_w*hi_x + lo_w*hi_x + hi_w*lo_x on three v_mfma_f32_32x32x16_f16 with fp32 accumulation
  * (the dropped lo*lo term is 2^-22 of the product: measured 5e-7 of the output range on an 864-term contraction, the
  * fp32 FMA chain's own figure).  Same layers, same epilogue and flags as snvc_conv3d_forward for
- * nn.Conv3d(k3, stride 1, pad 1) (+ folded eval BatchNorm) (+ residual) (+ ReLU) -- snvc/models/submodule.py:32-50 --
- * with Cin % 8 == 0 and Cout % 32 == 0.  The caller folds 2^-(e_x + e_w) (and 2^e_y for a split output) into
+ * nn.Conv3d(k3, pad 1, stride 1 or 2) and nn.ConvTranspose3d(k3, s2, p1, op1) (+ folded eval BatchNorm) (+ residual) (+ ReLU)
+ * -- snvc/models/submodule.py:32-50,127-146,170-208 -- with Cin % 8 == 0 and Cout % 32 == 0 (stride 2 / transposed: % 64).  The caller folds 2^-(e_x + e_w) (and 2^e_y for a split output) into
  * scale / bias.  Output: a split C8 pair (y_hi, y_lo; residual then a split pair too), or, with y_f32 != NULL, a plain
- * fp32 NCDHW tensor [N][Cout][D][H][W] (no residual) for a consumer on the fp32 kernels.
+ * fp32 NCDHW tensor [N][Cout][D][H][W] for a consumer on the fp32 kernels (a residual stays a split pair).
  * Values beyond half's range after scaling (|v * 2^e| > 65504) overflow: the caller picks e from what it knows of the
  * tensor (folded BatchNorm statistics) -- see snvc_amd/ops.py.
  * ---------------------------------------------------------------------------------- */
@@ -492,10 +500,15 @@ SNVC_API int64_t snvc_f16x3_conv3d_packed_weight_bytes(const snvc_conv3d_desc *d
 /* weight: the fp32 nn.Conv3d [Cout,Cin,3,3,3] parameter; packed as (hi, lo) of weight * wmul (wmul a power of two). */
 SNVC_API int snvc_f16x3_conv3d_pack_weights(const snvc_conv3d_desc *desc_host, const float *weight, void *packed,
                                             float wmul, void *stream);
+/* head / y_head (both or neither; 32-channel stride-1 layers with a split output): y_head[n][voxel] = head_mul * sum_c head[c] *
+ * (the value stored for channel c) -- the classifier's projection of the layer's own result (the r3 side head of
+ * snvc_conv3d_forward_side_head); head_mul = 2^-e_y (with y_f32 the stored result is multiplied by head_mul as well: the epilogue
+ * then works in the residual's units 2^e_y).  overflow (device int, may be NULL): set to 1 if a value had to be
+ * clamped to half's range on the way out (the exponent the caller chose was too large for this input). */
 SNVC_API int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,
                                        const void *packed_weight, const float *scale, const float *bias,
                                        const void *res_hi, const void *res_lo, void *y_hi, void *y_lo, float *y_f32,
-                                       void *stream);
+                                       const float *head, float *y_head, float head_mul, int *overflow, void *stream);
 /* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half (vernier.py:433) on C8 tensors:
  *   out[n,c,s] = half(float(feat[n,c,s]) * occ[n,0,s]), occ an fp32 plane [N][S]; C % 8 == 0. */
 SNVC_API int snvc_f16_mul_broadcast(const void *feat_c8, const float *occ, void *out_c8, int64_t N, int64_t C,

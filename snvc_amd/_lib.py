@@ -73,6 +73,8 @@ SIGNATURES = {
     "snvc_sheared_upsample_backward": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_p]),
     "snvc_sheared_expand": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_i64, c_int,
                                     c_int, c_p]),
+    "snvc_sheared_expand_split": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int,
+                                          c_i64, c_int, c_i64, c_int, c_p]),
     "snvc_norm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "snvc_norm_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_p]),
     "snvc_affine_act": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
@@ -97,7 +99,7 @@ SIGNATURES = {
     "snvc_f16x3_to_ncdhw": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_p]),
     "snvc_f16x3_conv3d_packed_weight_bytes": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
     "snvc_f16x3_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_f32, c_p]),
-    "snvc_f16x3_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "snvc_f16x3_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p]),
     "snvc_f16_mul_broadcast": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_f16_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_volume_resample": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_i64, c_p]),

@@ -46,6 +46,10 @@ struct F16Args {
     // split mode (PL = 2, "f16x3"): every tensor is a pair of C8 half planes, value = hi + lo; x / res / y are the hi planes
     const _Float16 *x_lo, *res_lo;
     _Float16 *y_lo;
+    const float *head;   // split EPI 0, Cout == 32: y_head[n][voxel] = sum_c head[c] * (the value written for channel c, unscaled: * head_mul)
+    float *y_head;       //   fp32 plane [N][Dout][Hout][Wout] (the classifier's projection of the layer's own result, r3 side head)
+    float head_mul;      //   2^-out_exp (EPI 2: applied to the fp32 result, which the epilogue forms in the residual's units)
+    int *overflow;       // split output: set to 1 if a value had to be clamped to half's range (the caller's exponent was too large)
     int CGin;            // input channel groups (Cin / 8, rounded up)
     int Cout;
     int Din, Hin, Win;
@@ -71,8 +75,13 @@ struct F16Cfg {
     // PL = 2: split mode.  Activations and weights are (hi, lo) pairs of halves, value = hi + lo (22 significant bits), and a
     // product is evaluated as hi*hi + lo_w*hi_x + hi_w*lo_x on three v_mfma_f32_32x32x16_f16 with fp32 accumulation: the fp32
     // layers' contraction at fp32 accuracy (the dropped lo*lo term is 2^-22 of the product) on the 16x faster half pipe.
+    // PL = 3: split mode with the two planes of the image taken one after the other (a pass over the hi plane: lo_w*hi_x +
+    // hi_w*hi_x; a pass over the lo plane: hi_w*lo_x) -- half the LDS for the layers whose image is large (stride 2).
     static constexpr int PL = PL_;
-    static constexpr int PF = PL_ == 2 ? 3 : 6;             // A-fragment ring depth (k-steps ahead)
+    static constexpr bool SPLIT = PL_ >= 2, SERIAL = PL_ == 3;
+    static constexpr int RES_PL = PL_ == 2 ? 2 : 1;         // planes resident in LDS
+    static constexpr int PASSES = SERIAL ? 2 : 1;           // image passes per channel chunk
+    static constexpr int PF = SPLIT ? 3 : 6;                // A-fragment ring depth (k-steps ahead)
     // DIL applies to D and H, DILW to W (they differ only for the sub-grid form of a dilated layer, see F16K5D2)
     static constexpr int KD = KD_, KH = KH_, KW = KW_, STRIDE = STRIDE_, DIL = DIL_, DILW = DILW_, MI = MI_, TD = TD_, TH = TH_;
     static constexpr int KCG = KCG_, MODE = MODE_, OCC = OCC_;
@@ -82,7 +91,7 @@ struct F16Cfg {
     static constexpr int IN_W = 31 * STRIDE + (KW - 1) * DILW + 1;
     static constexpr int VOX = IN_D * IN_H * IN_W;          // pieces per channel-group image
     static constexpr int GB = VOX * 16;                     // bytes per channel-group image
-    static constexpr int ITEMS = PL * KCG * VOX;            // image = [plane][channel group][voxel] pieces
+    static constexpr int ITEMS = RES_PL * KCG * VOX;        // image = [plane][channel group][voxel] pieces
     static constexpr int PLANE_BYTES = KCG * GB;
     static constexpr int NIT = (ITEMS + 255) / 256;
     static constexpr int IMG_BYTES = NIT * 256 * 16;        // whole DMA rounds
@@ -115,7 +124,9 @@ __device__ __forceinline__ int xcd_remap16(int b, int n) {
     return base + k;
 }
 
-template <class Cfg, int EPI>   // EPI 0: C8 half output (+affine, residual, ReLU); 1: fp32 plane of channel 0 (+Sigmoid)
+// EPI 0: C8 half output (+affine, residual, ReLU); 1: fp32 plane of channel 0 (+Sigmoid); 2: fp32 NCDHW output (split mode);
+// 3: EPI 0 + the side head (split mode, one 32-channel block)
+template <class Cfg, int EPI>
 __global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_f16_kernel(const F16Args a_) {
     F16Args a = a_;
@@ -131,6 +142,7 @@ conv3d_f16_kernel(const F16Args a_) {
     constexpr int S = Cfg::STRIDE, MI = Cfg::MI, TD = Cfg::TD, TH = Cfg::TH, NB = Cfg::NB, KCG = Cfg::KCG;
     constexpr int IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, GB = Cfg::GB, NIT = Cfg::NIT, ITEMS = Cfg::ITEMS;
     constexpr int PF = Cfg::PF, PL = Cfg::PL;
+    constexpr bool SPLIT = Cfg::SPLIT, SERIAL = Cfg::SERIAL;
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -172,9 +184,11 @@ conv3d_f16_kernel(const F16Args a_) {
         vmask |= (ok ? 1u : 0u) << it;
     }
     static_assert(KCG <= 2, "gmask holds one bit per piece");
-    const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = PL == 2 ? a.x_lo + n * a.x_bs : nullptr;
+    const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = SPLIT ? a.x_lo + n * a.x_bs : nullptr;
     const int wbase = tid & ~63;
-    auto issue = [&](int chunk, int buf) {
+    auto issue = [&](int pass, int buf) {           // pass = chunk (* 2 + plane when the planes are taken serially)
+        const int chunk = SERIAL ? pass >> 1 : pass;
+        const bool lo_pass = SERIAL && (pass & 1);
         const int64_t coff = (int64_t)chunk * KCG * in_dhw * 8;
         const int cg_left = a.CGin - chunk * KCG;
         char *const ibuf = lds + buf * Cfg::IMG_BYTES;
@@ -182,7 +196,7 @@ conv3d_f16_kernel(const F16Args a_) {
         for (int it = 0; it < NIT; ++it) {
             const int i = it * 256 + tid;
             const bool ok = ((vmask >> it) & 1u) && (KCG == 1 || (int)((gmask >> it) & 1u) < cg_left);
-            const _Float16 *xc = (PL == 2 && ((pmask >> it) & 1u) ? xn_lo : xn) + coff;
+            const _Float16 *xc = (((PL == 2 && ((pmask >> it) & 1u)) || lo_pass) ? xn_lo : xn) + coff;
             const void *src = ok ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
             if (ITEMS % 256 == 0 || i < ITEMS)
                 __builtin_amdgcn_global_load_lds(static_cast<const float *>(src),
@@ -210,8 +224,8 @@ conv3d_f16_kernel(const F16Args a_) {
 
     // ---- A fragments: [cout block][chunk][segment][k-step][m][lane] pieces, consumed in exactly that order
     // (split mode: [..][k-step][m][hi | lo][lane])
-    constexpr int MA = MI * PL;
-    const int64_t steps_total = (int64_t)a.nchunks * Cfg::STEPS;
+    constexpr int MA = MI * (SPLIT ? 2 : 1);
+    const int64_t steps_total = (int64_t)a.nchunks * Cfg::PASSES * Cfg::STEPS;
     const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * MA) * 64 + lane;
     h8 q[PF][MA];
 #pragma unroll
@@ -221,7 +235,7 @@ conv3d_f16_kernel(const F16Args a_) {
         wq += MA * 64;     // the packed buffer carries PF steps of zero padding behind the last block
     }
 
-    auto compute = [&](const char *img) {
+    auto compute = [&](const char *img, bool lo_pass) {
 #pragma unroll 1
         for (int seg = 0; seg < Cfg::SEGS; ++seg) {
             const char *simg = img + seg * Cfg::SEG_BYTES;
@@ -255,7 +269,13 @@ conv3d_f16_kernel(const F16Args a_) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     const h8 bf = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
-                    if constexpr (PL == 2) {
+                    if constexpr (SERIAL) {
+#pragma unroll
+                        for (int m = 0; m < MI; ++m) {
+                            if (!lo_pass) acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf, acc[nb][m], 0, 0, 0);
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf, acc[nb][m], 0, 0, 0);
+                        }
+                    } else if constexpr (PL == 2) {
                         const h8 bl = *reinterpret_cast<const h8 *>(simg + Cfg::PLANE_BYTES + base + toff + rowoff[nb]);
 #pragma unroll
                         for (int m = 0; m < MI; ++m) {      // the two correction terms first, then the leading one
@@ -273,19 +293,20 @@ conv3d_f16_kernel(const F16Args a_) {
         }
     };
 
+    const int npass = a.nchunks * Cfg::PASSES;
     if constexpr (Cfg::DB) {
         issue(0, 0);
         __syncthreads();
-        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-            if (chunk + 1 < a.nchunks) issue(chunk + 1, (chunk + 1) & 1);
-            compute(lds + (chunk & 1) * Cfg::IMG_BYTES);
-            __syncthreads();     // drains the DMA of chunk+1 and retires every read of this chunk's buffer
+        for (int ps = 0; ps < npass; ++ps) {
+            if (ps + 1 < npass) issue(ps + 1, (ps + 1) & 1);
+            compute(lds + (ps & 1) * Cfg::IMG_BYTES, SERIAL && (ps & 1));
+            __syncthreads();     // drains the DMA of the next pass and retires every read of this pass's buffer
         }
     } else {
-        for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-            issue(chunk, 0);
+        for (int ps = 0; ps < npass; ++ps) {
+            issue(ps, 0);
             __syncthreads();
-            compute(lds);
+            compute(lds, SERIAL && (ps & 1));
             __syncthreads();
         }
     }
@@ -316,39 +337,27 @@ conv3d_f16_kernel(const F16Args a_) {
             if (a.flags & SNVC_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
             if (okv[nb] && half == 0) yp[sp[nb]] = v;
         }
-    } else if constexpr (EPI == 2) {
-        // fp32 NCDHW output (a split-mode layer handing its result to the fp32 kernels): register r of a lane is channel
-        // c0 + r of voxel (lane & 31): per store instruction two 128-byte runs (one per half-wave)
-        float *yp = a.y_f32 + n * a.yf_bs;
-#pragma unroll
-        for (int m = 0; m < MI; ++m) {
-            if ((cb * MI + m) * 32 >= a.Cout) break;
-            const int c0 = (cb * MI + m) * 32 + 16 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float sc = a.scale ? a.scale[c0 + r] : 1.0f, bi = a.scale ? a.bias[c0 + r] : 0.0f;
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    float v = acc[nb][m][r] * sc + bi;
-                    if (relu) v = v > 0.0f ? v : 0.0f;
-                    if (okv[nb]) yp[(int64_t)(c0 + r) * out_dhw + sp[nb]] = v;
-                }
-            }
-        }
     } else {
+        // EPI 0: C8 half output (split mode: a (hi, lo) pair); EPI 2: fp32 NCDHW output (a split-mode layer handing its result
+        // to the fp32 kernels).  Residual: C8 (split mode: a pair).
         const _Float16 *rn = a.res ? a.res + n * a.r_bs : nullptr;
-        const _Float16 *rn_lo = (PL == 2 && a.res) ? a.res_lo + n * a.r_bs : nullptr;
-        _Float16 *yn = a.y + n * a.y_bs;
-        _Float16 *yn_lo = PL == 2 ? a.y_lo + n * a.y_bs : nullptr;
+        const _Float16 *rn_lo = (SPLIT && a.res) ? a.res_lo + n * a.r_bs : nullptr;
+        constexpr bool C8OUT = EPI == 0 || EPI == 3, side = EPI == 3 && SPLIT && MI == 1;
+        _Float16 *yn = C8OUT ? a.y + n * a.y_bs : nullptr;
+        _Float16 *yn_lo = (C8OUT && SPLIT) ? a.y_lo + n * a.y_bs : nullptr;
+        float *yf = EPI == 2 ? a.y_f32 + n * a.yf_bs : nullptr;
+        constexpr float kHalfMax = 65504.0f;
+        bool clamped = false;
 #pragma unroll
         for (int m = 0; m < MI; ++m) {
             if ((cb * MI + m) * 32 >= a.Cout) break;                // Cout = 32 * odd: the last block is half empty
             const int c0 = (cb * MI + m) * 32 + 16 * half;          // first of this lane's 16 channels
-            f32x4 sc[4], bi[4];
+            f32x4 sc[4], bi[4], hw4[side ? 4 : 1];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 sc[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + c0 + 4 * k) : f32x4(1.0f);
                 bi[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.bias + c0 + 4 * k) : f32x4(0.0f);
+                if constexpr (side) hw4[k] = *reinterpret_cast<const f32x4 *>(a.head + c0 + 4 * k);
             }
             const int64_t g0 = (int64_t)(c0 >> 3) * out_dhw;        // channel group of registers 0..7; 8..15 is the next
 #pragma unroll
@@ -359,6 +368,7 @@ conv3d_f16_kernel(const F16Args a_) {
                     rv[j] = rn ? *reinterpret_cast<const h8 *>(rn + ((g0 + j * out_dhw) + sp[nb]) * 8) : h8((_Float16)0.0f);
                     rl[j] = rn_lo ? *reinterpret_cast<const h8 *>(rn_lo + ((g0 + j * out_dhw) + sp[nb]) * 8) : h8((_Float16)0.0f);
                 }
+                float hsum = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     h8 o, ol;
@@ -370,15 +380,34 @@ conv3d_f16_kernel(const F16Args a_) {
                         if (add_pre) v += rr;
                         if (relu) v = v > 0.0f ? v : 0.0f;
                         if (add_post) v += rr;
-                        o[e] = (_Float16)v;
-                        if constexpr (PL == 2) ol[e] = (_Float16)(v - (float)o[e]);
+                        if constexpr (EPI == 2) {
+                            if (okv[nb]) yf[(int64_t)(c0 + r) * out_dhw + sp[nb]] = v * a.head_mul;     // 2^-e_y: exact
+                        } else {
+                            if constexpr (SPLIT) {      // keep the pair finite: beyond half's range the value is clamped and flagged
+                                const float vc = __builtin_fminf(__builtin_fmaxf(v, -kHalfMax), kHalfMax);
+                                clamped = clamped || (vc != v && v == v);
+                                v = vc;
+                            }
+                            if constexpr (side) hsum += hw4[r >> 2][r & 3] * v;
+                            o[e] = (_Float16)v;
+                            if constexpr (SPLIT) ol[e] = (_Float16)(v - (float)o[e]);
+                        }
                     }
-                    if (okv[nb]) {
-                        *reinterpret_cast<h8 *>(yn + ((g0 + j * out_dhw) + sp[nb]) * 8) = o;
-                        if constexpr (PL == 2) *reinterpret_cast<h8 *>(yn_lo + ((g0 + j * out_dhw) + sp[nb]) * 8) = ol;
+                    if constexpr (C8OUT) {
+                        if (okv[nb]) {
+                            *reinterpret_cast<h8 *>(yn + ((g0 + j * out_dhw) + sp[nb]) * 8) = o;
+                            if constexpr (SPLIT) *reinterpret_cast<h8 *>(yn_lo + ((g0 + j * out_dhw) + sp[nb]) * 8) = ol;
+                        }
                     }
                 }
+                if constexpr (side) {     // the two half-waves hold channels 0..15 / 16..31 of the same 32 voxels
+                    hsum += __shfl_xor(hsum, 32, 64);
+                    if (okv[nb] && half == 0) a.y_head[n * out_dhw + sp[nb]] = hsum * a.head_mul;
+                }
             }
+        }
+        if constexpr (C8OUT && SPLIT) {
+            if (clamped && a.overflow) atomicOr(a.overflow, 1);
         }
     }
 }
@@ -391,7 +420,8 @@ struct PackArgs {
     int transposed, pd, ph, pw;  // transposed: parity class of this packing ([Cin][Cout][3][3][3] source)
     int KD, KH, KW, KCG, MODE, MI, SEGS, TSEG, NPS, NS, unroll_d;
     int nchunks, cblocks;
-    int PL;                    // 2: split mode, [..][m][hi | lo][lane][8]; values are w * wmul (a power of two) split as hi + lo
+    int PL;                    // >= 2: split mode, [..][m][hi | lo][lane][8]; values are w * wmul (a power of two) split as hi + lo
+    int PASSES;                // 2: planes taken serially, the k-steps of a chunk are stored once per pass
     float wmul;
     int64_t total;             // elements (halves)
 };
@@ -402,10 +432,12 @@ __global__ void pack_f16_weights_kernel(const PackArgs p) {
     int64_t r = i;
     const int e = (int)(r % 8); r /= 8;
     const int lane = (int)(r % 64); r /= 64;
-    const int pl = (int)(r % p.PL); r /= p.PL;
+    const int npl = p.PL >= 2 ? 2 : 1;
+    const int pl = (int)(r % npl); r /= npl;
     const int m = (int)(r % p.MI); r /= p.MI;
     const int s = (int)(r % p.NS); r /= p.NS;
     const int seg = (int)(r % p.SEGS); r /= p.SEGS;
+    r /= p.PASSES;                                             // both passes of a chunk see the same weights
     const int chunk = (int)(r % p.nchunks); r /= p.nchunks;
     const int cb = (int)r;
     const int half = lane >> 5;
@@ -432,7 +464,7 @@ __global__ void pack_f16_weights_kernel(const PackArgs p) {
             if (ok) v = p.w[((((int64_t)ci * p.Cout + co) * 3 + k3[0]) * 3 + k3[1]) * 3 + k3[2]];
         }
     }
-    if (p.PL == 2) {
+    if (p.PL >= 2) {
         v *= p.wmul;
         const _Float16 hi = (_Float16)v;
         p.out[i] = pl ? (_Float16)(v - (float)hi) : hi;
@@ -471,11 +503,15 @@ using F16DCN   = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 0, true, 2>;
 //                         KD KH KW S  D  MI TD TH KCG MODE DB    OCC DILW PL
 using F16K3X  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, false, 3, 1, 2>;
 using F16K3X2 = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 1, 1, false, 2, 1, 2>;
+// stride 2: the image of a 2x4x32 tile is 5 x 9 x 65 pieces (46.8 KB per plane): the planes are taken serially (PL = 3)
+using F16K3S2X = F16Cfg<3, 3, 3, 2, 1, 2, 2, 4, 1, 1, false, 2, 1, 3>;
+// one parity class of ConvTranspose3d(k3,s2,p1,op1): 2x2x2 box taps, both planes resident, double-buffered
+using F16DCX  = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 1, 1, true, 2, 1, 2>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FNONE };
 
 struct F16Plan {
-    int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF;
+    int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES;
     int nchunks, cblocks;
     int64_t block_halves;      // packed halves of one class (without padding)
 };
@@ -486,7 +522,7 @@ F16Plan plan_from(int kind) {
     p.kind = kind; p.MI = Cfg::MI; p.KCG = Cfg::KCG; p.MODE = Cfg::MODE; p.TD = Cfg::TD; p.TH = Cfg::TH;
     p.STEPS = Cfg::STEPS; p.SEGS = Cfg::SEGS; p.TSEG = Cfg::TSEG; p.NPS = Cfg::NPS; p.NS = Cfg::NS;
     p.KD = Cfg::KD; p.KH = Cfg::KH; p.KW = Cfg::KW; p.unroll_d = Cfg::UNROLL_D ? 1 : 0;
-    p.PL = Cfg::PL; p.PF = Cfg::PF;
+    p.PL = Cfg::PL; p.PF = Cfg::PF; p.PASSES = Cfg::PASSES;
     return p;
 }
 
@@ -495,15 +531,28 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d: sizes must be positive");
     if (d.Cin % 8 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: Cin must be a multiple of 8 (C8 layout)");
     if (split) {
-        const int eff = d.dilation * (d.ksize - 1) + 1;
-        if (d.transposed || d.ksize != 3 || d.stride != 1 || d.dilation != 1 || d.pad != 1 || d.Cout % 32 != 0)
-            return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: built for Conv3d(k3, s1, p1) with Cout % 32 == 0");
-        if (d.Dout != d.Din + 2 - eff + 1 || d.Hout != d.Hin + 2 - eff + 1 || d.Wout != d.Win + 2 - eff + 1)
-            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d: output size does not match the convolution arithmetic");
-        p = d.Cout == 32 ? plan_from<F16K3X>(FK3X) : plan_from<F16K3X2>(FK3X2);
+        if (d.ksize != 3 || d.dilation != 1 || d.pad != 1)
+            return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: built for k3 layers (stride 1 / stride 2 / transposed)");
+        if (d.transposed) {
+            if (d.stride != 2 || d.Cout % 64 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: transposed layers: k3,s2,p1,op1 with Cout % 64 == 0");
+            if (d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win)
+                return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d: transposed output must be 2x the input");
+            p = plan_from<F16DCX>(FDCX);
+        } else {
+            if (d.stride != 1 && d.stride != 2) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: stride 1 or 2");
+            if (d.Dout != (d.Din - 1) / d.stride + 1 || d.Hout != (d.Hin - 1) / d.stride + 1 || d.Wout != (d.Win - 1) / d.stride + 1)
+                return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d: output size does not match the convolution arithmetic");
+            if (d.stride == 2) {
+                if (d.Cout % 64 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: stride-2 layers need Cout % 64 == 0");
+                p = plan_from<F16K3S2X>(FK3S2X);
+            } else {
+                if (d.Cout % 32 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: Cout % 32 == 0");
+                p = d.Cout == 32 ? plan_from<F16K3X>(FK3X) : plan_from<F16K3X2>(FK3X2);
+            }
+        }
         p.nchunks = ceil_div(d.Cin / 8, p.KCG);
         p.cblocks = ceil_div(d.Cout, 32 * p.MI);
-        p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * p.MI * p.PL * 64 * 8;
+        p.block_halves = (int64_t)p.cblocks * p.nchunks * p.PASSES * p.STEPS * p.MI * 2 * 64 * 8;
         if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: too many channel blocks or samples");
         return SNVC_OK;
     }
@@ -544,12 +593,12 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
     }
     p.nchunks = ceil_div(d.Cin / 8, p.KCG);
     p.cblocks = ceil_div(d.Cout, 32 * p.MI);
-    p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * p.MI * p.PL * 64 * 8;
+    p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * p.MI * 64 * 8;
     if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: too many channel blocks or samples");
     return SNVC_OK;
 }
 
-inline int64_t f16_class_stride(const F16Plan &p) { return p.block_halves + (int64_t)p.PF * p.MI * p.PL * 64 * 8; }
+inline int64_t f16_class_stride(const F16Plan &p) { return p.block_halves + (int64_t)p.PF * p.MI * (p.PL >= 2 ? 2 : 1) * 64 * 8; }
 
 template <class Cfg, int EPI>
 void launch_f16(const F16Args &a, dim3 grid, hipStream_t st) {
@@ -591,7 +640,7 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
         a.KD = p.KD; a.KH = p.KH; a.KW = p.KW; a.KCG = p.KCG; a.MODE = p.MODE; a.MI = p.MI; a.SEGS = p.SEGS;
         a.TSEG = p.TSEG; a.NPS = p.NPS; a.NS = p.NS; a.unroll_d = p.unroll_d;
         a.nchunks = p.nchunks; a.cblocks = p.cblocks; a.total = p.block_halves;
-        a.PL = p.PL; a.wmul = wmul;
+        a.PL = p.PL; a.PASSES = p.PASSES; a.wmul = wmul;
         pack_f16_weights_kernel<<<(unsigned)ceil_div<int64_t>(a.total, 256), 256, 0, as_stream(stream)>>>(a);
     }
     return check_launch(who);
@@ -605,7 +654,7 @@ int64_t snvc_f16x3_conv3d_packed_weight_bytes(const snvc_conv3d_desc *d) {
     using namespace snvc;
     F16Plan p;
     if (!d || make_f16_plan(*d, p, true) != SNVC_OK) return -1;
-    return 2 * f16_class_stride(p);
+    return 2 * f16_class_stride(p) * (d->transposed ? 8 : 1);
 }
 
 int snvc_f16x3_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, void *packed, float wmul, void *stream) {
@@ -703,7 +752,8 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
 
 int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
                               const float *scale, const float *bias, const void *res_hi, const void *res_lo, void *y_hi,
-                              void *y_lo, float *y_f32, void *stream) {
+                              void *y_lo, float *y_f32, const float *head, float *y_head, float head_mul, int *overflow,
+                              void *stream) {
     using namespace snvc;
     F16Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null desc");
@@ -716,20 +766,25 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: scale and bias must both be given or both be NULL");
     const int resflags = d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST);
-    if (resflags && (!res_hi || !res_lo || to_f32))
-        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: residual flag without a split residual (C8 output only)");
+    if (resflags && (!res_hi || !res_lo))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: residual flag without a split residual");
     if (resflags == (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: ADD_PRE and ADD_POST are exclusive");
     if (d->flags & ~(SNVC_EPI_RELU | SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: RELU / ADD_PRE / ADD_POST only");
+    if ((head != nullptr) != (y_head != nullptr))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: head and y_head go together");
+    if (head && (p.kind != FK3X || to_f32))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the side head is built for 32-channel stride-1 layers with a split output");
     const int64_t in_sp = (int64_t)d->Din * d->Hin * d->Win, out_sp = (int64_t)d->Dout * d->Hout * d->Wout;
-    if ((int64_t)(d->Cin / 8 + 2) * in_sp >= ((int64_t)1 << 31) || (int64_t)d->Cout * out_sp >= ((int64_t)1 << 40) || out_sp >= ((int64_t)1 << 31))
+    if ((int64_t)(d->Cin / 8 + 2) * in_sp >= ((int64_t)1 << 31) || out_sp >= ((int64_t)1 << 31))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: one sample must stay below 2^31 pieces");
     if ((reinterpret_cast<uintptr_t>(x_hi) | reinterpret_cast<uintptr_t>(x_lo) | reinterpret_cast<uintptr_t>(y_hi) |
          reinterpret_cast<uintptr_t>(y_lo) | reinterpret_cast<uintptr_t>(res_hi) | reinterpret_cast<uintptr_t>(res_lo) |
-         reinterpret_cast<uintptr_t>(packed_weight)) & 15)
-        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: C8 tensors must be 16-byte aligned");
-    if ((d->x_batch_stride | d->y_batch_stride | d->res_batch_stride) % 8)
+         reinterpret_cast<uintptr_t>(packed_weight) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) |
+         reinterpret_cast<uintptr_t>(head)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: C8 tensors and the per-channel vectors must be 16-byte aligned");
+    if ((d->x_batch_stride | d->res_batch_stride) % 8 || (!to_f32 && d->y_batch_stride % 8))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: batch strides must be multiples of 8 elements");
     F16Args a{};
     a.x = reinterpret_cast<const _Float16 *>(x_hi); a.x_lo = reinterpret_cast<const _Float16 *>(x_lo);
@@ -737,27 +792,45 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     a.res = resflags ? reinterpret_cast<const _Float16 *>(res_hi) : nullptr;
     a.res_lo = resflags ? reinterpret_cast<const _Float16 *>(res_lo) : nullptr;
     a.y = reinterpret_cast<_Float16 *>(y_hi); a.y_lo = reinterpret_cast<_Float16 *>(y_lo); a.y_f32 = y_f32;
+    a.head = head; a.y_head = y_head; a.head_mul = head_mul; a.overflow = overflow;
     a.CGin = d->Cin / 8; a.Cout = d->Cout;
     a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
     a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;
     a.nchunks = p.nchunks; a.flags = d->flags;
-    a.x_bs = d->x_batch_stride ? d->x_batch_stride : (int64_t)d->Cin * in_sp;
-    a.y_bs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->Cout * out_sp;
-    a.r_bs = d->res_batch_stride ? d->res_batch_stride : (int64_t)d->Cout * out_sp;
-    a.yf_bs = to_f32 ? a.y_bs : out_sp;
+    a.x_bs = d->x_batch_stride ? d->x_batch_stride : 2 * (int64_t)d->Cin * in_sp;
+    a.y_bs = d->y_batch_stride ? d->y_batch_stride : 2 * (int64_t)d->Cout * out_sp;
+    a.r_bs = d->res_batch_stride ? d->res_batch_stride : 2 * (int64_t)d->Cout * out_sp;
+    a.yf_bs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->Cout * out_sp;
     a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
-    a.N = d->N; a.cls_mode = 0; a.cls_wstride = f16_class_stride(p);
+    const int classes = d->transposed ? 8 : 1;
+    a.N = d->N; a.cls_mode = d->transposed ? 1 : 0; a.cls_wstride = f16_class_stride(p);
     a.isd = a.ish = 1; a.iod = a.ioh = 0; a.offd = a.offh = a.offw = 0;
-    a.nd = d->Dout; a.nh = d->Hout; a.nw = d->Wout;
-    a.osd = a.osh = a.osw = 1;
-    a.pad_d = a.pad_h = a.pad_w = d->pad;
+    if (d->transposed) {
+        a.nd = d->Din; a.nh = d->Hin; a.nw = d->Win;
+        a.osd = a.osh = a.osw = 2;
+        a.pad_d = a.pad_h = a.pad_w = 0;
+    } else {
+        a.nd = d->Dout; a.nh = d->Hout; a.nw = d->Wout;
+        a.osd = a.osh = a.osw = 1;
+        a.pad_d = a.pad_h = a.pad_w = d->pad;
+    }
     a.tiles_d = ceil_div(a.nd, p.TD); a.tiles_h = ceil_div(a.nh, p.TH); a.tiles_w = ceil_div(a.nw, 32);
     const int64_t ntiles = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
-    if (ntiles >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles");
-    dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)d->N);
+    if (ntiles >= ((int64_t)1 << 31) || (int64_t)d->N * classes > 65535)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles or samples");
+    dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)(d->N * classes));
     hipStream_t st = as_stream(stream);
-    if (p.kind == FK3X) { if (to_f32) launch_f16<F16K3X, 2>(a, grid, st); else launch_f16<F16K3X, 0>(a, grid, st); }
-    else { if (to_f32) launch_f16<F16K3X2, 2>(a, grid, st); else launch_f16<F16K3X2, 0>(a, grid, st); }
+    switch (p.kind) {
+        case FK3X:
+            if (to_f32) launch_f16<F16K3X, 2>(a, grid, st);
+            else if (head) launch_f16<F16K3X, 3>(a, grid, st);
+            else launch_f16<F16K3X, 0>(a, grid, st);
+            break;
+        case FK3X2: if (to_f32) launch_f16<F16K3X2, 2>(a, grid, st); else launch_f16<F16K3X2, 0>(a, grid, st); break;
+        case FK3S2X: if (to_f32) launch_f16<F16K3S2X, 2>(a, grid, st); else launch_f16<F16K3S2X, 0>(a, grid, st); break;
+        case FDCX: if (to_f32) launch_f16<F16DCX, 2>(a, grid, st); else launch_f16<F16DCX, 0>(a, grid, st); break;
+        default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: no kernel");
+    }
     return check_launch("snvc_f16x3_conv3d_forward");
 }
 

@@ -25,6 +25,7 @@ class LazyCostVolume(torch.Tensor):
         r._real_version = None
         r._spacing = spacing
         r._source_versions = (left._version, right._version, shift._version)
+        r._own_version = r._version      # in-place aten operators on the wrapper bump ITS counter (above __torch_dispatch__)
         return r
 
     @property
@@ -55,6 +56,8 @@ class LazyCostVolume(torch.Tensor):
         counter has not moved; nobody wrote through an aten operator) -- and the sources themselves are untouched.  Then
         GlobalStack.forward may take the fused path from the sources: same values as the eager volume would give."""
         if not self.sources_unchanged:
+            return False
+        if self._version != self._own_version:
             return False
         return self._real is None or self._real._version == self._real_version
 

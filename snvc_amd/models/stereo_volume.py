@@ -13,13 +13,17 @@ blocks (``convbn_3d``, ``hourglass``) and the composition pattern of VernierScal
     v = v + hourglass(v)[0]                                      hg_conv3d
     cost = conv1x1x1(v)           C  -> 1                        classifier
 """
+import math
+import warnings
+
 import torch
 import torch.nn as nn
 
 from ..extension.build_cost_volume import _BuildCostVolume, build_cost_volume  # noqa: F401  (re-exported)
 from .. import ops
 from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _ShearedFirstConvBNFn,
-                        _ShearedFirstConvFn, _folded_bn, _Plan, convbn_3d, hourglass, sheared_geometry, sheared_kernels, EPI_RELU)
+                        _ShearedFirstConvFn, _folded_bn, _is_channel_head as _is_head_conv, _Plan, convbn_3d, hourglass,
+                        sheared_geometry, sheared_kernels, EPI_RELU)
 
 
 class GlobalStack(nn.Module):
@@ -36,7 +40,7 @@ class GlobalStack(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
-    def _buffer(self, name, shape, device):
+    def _buffer(self, name, shape, device, dtype=torch.float32):
         """Inference workspace: the three full-resolution intermediates (warped half-volume, conv1 / conv2 outputs,
         0.74 GB each at cfg2) are kept across calls instead of going through the caching allocator every step -- with
         GB-sized blocks that are split and re-merged, a steady-state step can land on a fresh hipMalloc (tens of ms).
@@ -50,8 +54,18 @@ class GlobalStack(nn.Module):
         if buf is None:
             for k in [k for k in ws if k[0] == name and k[2] == device]:
                 del ws[k]
-            buf = ws[key] = torch.empty(shape, dtype=torch.float32, device=device)
+            buf = ws[key] = torch.empty(shape, dtype=dtype, device=device)
         return buf
+
+    def last_first_layer(self) -> torch.Tensor:
+        """The first layer's result of the most recent inference call as a float32 [N,C,D,H,W] tensor (a copy when the call ran
+        in split mode and the workspace holds the (hi, lo) pair) -- for tests and debugging."""
+        ws = self.__dict__.get("_snvc_ws", {})
+        which = self.__dict__.get("_snvc_last_v1", "v1")
+        for k, v in ws.items():
+            if k[0] == which:
+                return ops.from_split(v, self.__dict__["_snvc_x3"]["exp"]["v1"]) if which == "v1s" else v
+        raise RuntimeError("no first-layer result in the workspace")
 
     def release_workspace(self):
         """Drop the persistent inference workspace (2.2 GB at cfg2)."""
@@ -65,7 +79,117 @@ class GlobalStack(nn.Module):
     def __getstate__(self):          # copy.deepcopy / torch.save(model): the workspace is scratch, not state
         state = self.__dict__.copy()
         state.pop("_snvc_ws", None)
+        state.pop("_snvc_x3", None)      # packed split-mode layers, a pinned flag buffer and an event: rebuilt on first use
         return state
+
+    # ------------------------------------------------------------------------------------------ split mode ("f16x3", r4)
+    # Inference with frozen statistics: conv2 and the hourglass's five MFMA layers run on the split-mode kernels
+    # (csrc/conv3d_f16.hip, F16Cfg::PL): the SAME fp32 layers -- values travel as (hi, lo) pairs of halves (22 bits), a product
+    # is three v_mfma_f32_32x32x16_f16 with fp32 accumulation, measured 5e-7 of the range against float64 where the fp32
+    # Winograd kernels measure 2e-6 -- on a matrix pipe 16 times faster than the fp32 one.  ``arithmetic``: "auto" (default:
+    # split mode when the stack qualifies), "fp32" (the fp32-MFMA kernels everywhere), "x3" (split mode or an error).
+    arithmetic = "auto"
+    X3_SIGMAS = 64.0     # a tensor's exponent is chosen so that |beta| + X3_SIGMAS * |gamma| of its BatchNorm stays below 2^15
+
+    @staticmethod
+    def _x3_exponent(bound: float) -> int:
+        """e with bound * 2^e <= 2^15 (half overflows at 65504; a value beyond the bound is clamped and FLAGGED)."""
+        if not (bound > 0.0) or not math.isfinite(bound):
+            return 0
+        return max(-14, min(14, 15 - math.frexp(bound)[1]))
+
+    def _x3_state(self, device):
+        """Packed split-mode layers, folded affines and per-tensor exponents of conv2 + the hourglass, or None when the stack
+        does not qualify (channels, norm kind, train mode).  Cached on the parameters' versions."""
+        hg = self.hg_conv3d
+        seqs = {"conv2": self.conv2[0], "h1": hg.conv1[0], "h2": hg.conv2, "h3": hg.conv3[0], "h4": hg.conv4[0], "h5": hg.conv5}
+        c = self.conv2[0][0].out_channels
+        if c != 32 or self.conv2[0][0].in_channels != 32 or not _is_head_conv(self.classifier, c):
+            return None
+        norms = [self.conv1[0][1]] + [sq[1] for sq in seqs.values()]
+        for nm in norms:
+            if not isinstance(nm, nn.BatchNorm3d) or nm.training or nm.running_mean is None:
+                return None
+        tensors = [t for sq in seqs.values() for t in (sq[0].weight, sq[1].weight, sq[1].bias, sq[1].running_mean, sq[1].running_var)]
+        tensors += [self.conv1[0][1].weight, self.conv1[0][1].bias]
+        key = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (device, _GENERATION[0])
+        st = self.__dict__.get("_snvc_x3")
+        if st is not None and st["key"] == key:
+            return st
+
+        def bound(nm):
+            g = nm.weight.detach().abs() if nm.weight is not None else torch.ones(1, device=device)
+            b = nm.bias.detach().abs() if nm.bias is not None else torch.zeros(1, device=device)
+            return float((b + self.X3_SIGMAS * g).max().item())
+        b = {k: bound(sq[1]) for k, sq in seqs.items()}
+        st = {"key": key, "exp": {"v1": self._x3_exponent(bound(self.conv1[0][1]))}, "layers": {}, "affine": {}}
+        st["exp"].update({k: self._x3_exponent(v) for k, v in b.items()})
+        geo = {"conv2": (1, False), "h1": (2, False), "h2": (1, False), "h3": (2, False), "h4": (1, False), "h5": (2, True)}
+        for k, sq in seqs.items():
+            w = sq[0].weight.detach().to(device)
+            st["layers"][k] = ops.Conv3dLayerX3(w, 3, geo[k][0], 1, 1, geo[k][1])
+            st["affine"][k] = _folded_bn(sq[1], sq[0].__dict__.setdefault("_snvc_plans", {}).setdefault(device, _Plan()))
+        st["flag"] = torch.zeros(1, dtype=torch.int32, device=device)
+        st["flag_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        st["flag_event"] = None
+        self.__dict__["_snvc_x3"] = st
+        return st
+
+    def _x3_select(self, device, arithmetic=None):
+        """The split-mode state if this call runs in split mode, else None."""
+        mode = arithmetic or self.arithmetic
+        if mode == "fp32" or torch.is_grad_enabled() or self.training or self.__dict__.get("_snvc_x3_off"):
+            if mode == "x3":
+                raise RuntimeError("arithmetic='x3' needs inference (no autograd, eval mode) and no earlier overflow")
+            return None
+        st = self._x3_state(device)
+        if st is None:
+            if mode == "x3":
+                raise RuntimeError("arithmetic='x3': the stack does not qualify (32 channels, eval-mode BatchNorm3d everywhere)")
+            return None
+        ev = st["flag_event"]
+        if ev is not None and ev.query():        # the previous call's overflow flag has arrived (no sync)
+            st["flag_event"] = None
+            if int(st["flag_host"].item()) != 0:
+                # a value exceeded the range its BatchNorm statistics promised (X3_SIGMAS standard deviations): the previous
+                # result had it clamped.  Split mode stays off for this model from here on.
+                self.__dict__["_snvc_x3_off"] = True
+                warnings.warn("snvc_amd: split-mode (f16x3) overflow -- an activation exceeded |beta| + %g |gamma| of its BatchNorm; "
+                              "the previous result clamped it.  This model now runs on the fp32-MFMA kernels." % self.X3_SIGMAS)
+                if mode == "x3":
+                    raise RuntimeError("arithmetic='x3': overflow flagged by the previous call")
+                return None
+        return st
+
+    def _tail_x3(self, st, v1s, timing=None):
+        """conv2 (+ side head) -> hourglass -> folded one-channel tail on a split-C8 first-layer result ``v1s`` (exponent
+        st['exp']['v1']).  Full-resolution intermediates: v1s, v2s (0.74 GB each at cfg2, like their fp32 counterparts)."""
+        L, A, E, flag = st["layers"], st["affine"], st["exp"], st["flag"]
+        n, dev = v1s.size(0), v1s.device
+        d, h, w = v1s.shape[3:6]
+        hg = self.hg_conv3d
+        if timing is not None and "conv2" in timing:
+            timing["conv2"][0].record()
+        v2s, hv = L["conv2"](v1s, E["v1"], *A["conv2"], flags=EPI_RELU, out_exp=E["conv2"], head=self.classifier.weight, overflow=flag,
+                             out=self._buffer("v2s", (n, 2, 4, d, h, w, 8), dev, torch.float16))
+        if timing is not None and "conv2" in timing:
+            timing["conv2"][1].record()
+        _ROUTES["side_head"] += 1
+        o = L["h1"](v2s, E["conv2"], *A["h1"], flags=EPI_RELU, out_exp=E["h1"], overflow=flag)                  # 1/2 res, 2C channels
+        pre = L["h2"](o, E["h1"], *A["h2"], flags=EPI_RELU, out_exp=E["h2"], overflow=flag)                     # relu(bn(conv))   :153-156
+        o = L["h3"](pre, E["h2"], *A["h3"], flags=EPI_RELU, out_exp=E["h3"], overflow=flag)                     # 1/4 res
+        o = L["h4"](o, E["h3"], *A["h4"], flags=EPI_RELU, out_exp=E["h4"], overflow=flag)
+        # post = relu(bn(deconv(o)) + pre): the result leaves as fp32 NCDHW for the one-channel transposed tail (VALU kernel)
+        post = L["h5"](o, E["h4"], *A["h5"], residual=pre, flags=EPI_RELU | ops.EPI_ADD_PRE, out_exp=E["h2"], to_f32=True)
+        cost = hg.conv6.fused(post, residual=None, head=self.classifier, head_residual=hv)    # deconv'(post) + b' + classifier(v2)
+        _ROUTES["x3_tail"] += 1
+        # the overflow flag travels to the host behind the step (no sync); the next call looks at it
+        if st["flag_event"] is None:
+            st["flag_host"].copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["flag_event"] = ev
+        return cost
 
     def _tail(self, v, hv=None):
         """v + hourglass(v)[0] -> classifier.  The hourglass's last transposed layer has no activation
@@ -75,7 +199,14 @@ class GlobalStack(nn.Module):
         cost, _, _ = self.hg_conv3d(v, None, None, residual=v, head=self.classifier, head_residual=hv)
         return cost
 
-    def _conv2_tail(self, v1, shape, timing=None):
+    def _conv2_tail(self, v1, shape, timing=None, arithmetic=None):
+        st = self._x3_select(v1.device, arithmetic) if (v1.is_cuda and v1.dtype == torch.float32) else None
+        if st is not None:      # split mode from an fp32 first-layer result: one layout pass (the sheared path writes the pair itself)
+            n, c = v1.size(0), v1.size(1)
+            v1s = ops.to_split(v1, st["exp"]["v1"], out=self._buffer("v1s", (n, 2, c // 8) + tuple(v1.shape[2:]) + (8,), v1.device, torch.float16))
+            self.__dict__["_snvc_last_v1"] = "v1"       # the fp32 first-layer result is in the workspace too
+            return self._tail_x3(st, v1s, timing)
+        self.__dict__["_snvc_last_v1"] = "v1"
         if timing is not None and "conv2" in timing:
             timing["conv2"][0].record()
         v, hv = self.conv2.fused(v1, out=self._buffer("v2", shape, v1.device), side_head=self.classifier)
@@ -170,7 +301,7 @@ class GlobalStack(nn.Module):
         return plans["commuted"]
 
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True,
-                     fused_bn=True, spacing="unknown", commuted=True):
+                     fused_bn=True, spacing="unknown", commuted=True, arithmetic=None):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
 
         ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT
@@ -188,6 +319,8 @@ class GlobalStack(nn.Module):
         evaluated along the shear (csrc/sheared_conv.hip): the warped volume is not built at all and conv1's 318 GFLOP
         become 3.4.  Any other shift array (checked on the device, same sync as the reference's assert) takes the
         general factored path.
+        ``arithmetic``: None (the model's ``arithmetic`` attribute, default "auto"), "fp32" or "x3": whether conv2 and the
+        hourglass run on the split-mode kernels (see ``_x3_state``).
         ``timing``: optional dict ``{"volume": (start, end), "conv1": (start, end)}`` of events recorded on the
         current stream around the cost-volume launch and the first 3D convolution (the dominant kernel); used by
         bench.py for the roofline figures."""
@@ -240,7 +373,7 @@ class GlobalStack(nn.Module):
             v = self.conv1.fused(vol, out=self._buffer("v1", shape, device))
             mark("conv1", 1)
             del vol
-            return self._conv2_tail(v, shape, timing)
+            return self._conv2_tail(v, shape, timing, arithmetic)
         # The one device -> host sync of the step (the wrapper's `assert shift >= 0`, here also the shift array's spacing) is
         # STARTED first and awaited only after everything that does not need its answer has been queued: the left half's
         # planes, and -- speculatively, for the spacing the previous call saw -- the sheared layer's two small 2D convolutions.
@@ -293,6 +426,24 @@ class GlobalStack(nn.Module):
             g, gcol, off, off_col = ready
             mark("volume", 1)
             mark("conv1", 0)
+            st = self._x3_select(left.device, arithmetic)
+            if st is not None and c % 8 == 0:
+                # split mode: the expand pass writes the (hi, lo) pair conv2 reads (same bytes as the fp32 tensor, no layout pass)
+                e1 = st["exp"]["v1"]
+                if st.get("v1_affine_key") != (scale.data_ptr(), bias.data_ptr(), e1):
+                    st["v1_affine"] = ((scale * 2.0 ** e1).contiguous(), (bias * 2.0 ** e1).contiguous())
+                    st["v1_affine_key"] = (scale.data_ptr(), bias.data_ptr(), e1)
+                v1s = self._buffer("v1s", (shape[0], 2, c // 8) + tuple(shape[2:]) + (8,), left.device, torch.float16)
+                try:
+                    ops.sheared_expand_split(g, gcol, planes, st["v1_affine"][0], st["v1_affine"][1], v1s, q, m0, off, off_col,
+                                             ops.EPI_RELU, st["flag"])
+                except ops.Unsupported:
+                    st = None
+                else:
+                    mark("conv1", 1)
+                    _ROUTES["sheared_first_conv"] += 1
+                    self.__dict__["_snvc_last_v1"] = "v1s"
+                    return self._tail_x3(st, v1s, timing)
             v = self._buffer("v1", shape, left.device)
             try:
                 ops.sheared_expand(g, gcol, planes, scale, bias, v, q, m0, off, off_col, ops.EPI_RELU)
@@ -301,7 +452,7 @@ class GlobalStack(nn.Module):
             else:
                 mark("conv1", 1)
                 _ROUTES["sheared_first_conv"] += 1
-                return self._conv2_tail(v, shape, timing)
+                return self._conv2_tail(v, shape, timing, arithmetic)
         if commuted and shift.dtype == torch.float32 and left.size(3) <= 2048:
             # any other shift array: interpolation along w commutes with the convolution -- three 2D convolutions of the right
             # feature, three interpolations per output voxel, the warped volume is not built either (csrc/sheared_conv.hip)
@@ -320,14 +471,14 @@ class GlobalStack(nn.Module):
             else:
                 mark("conv1", 1)
                 _ROUTES["commuted_first_conv"] += 1
-                return self._conv2_tail(v, shape, timing)
+                return self._conv2_tail(v, shape, timing, arithmetic)
         mark("volume", 0)
         try:
             vol_r = ops.cost_volume_forward_right(right, shift, out=self._buffer("vol_r", shape, left.device))   # [N,C,D,H,W]
         except ops.Unsupported:                  # rows beyond the row builder's width: the materialised volume, as the reference
-            return self.forward_pair(left, right, shift, downsample, factored=False, timing=timing)
+            return self.forward_pair(left, right, shift, downsample, factored=False, timing=timing, arithmetic=arithmetic)
         mark("volume", 1)
         mark("conv1", 0)
         v = plans["right"](vol_r, scale, bias, None, ops.EPI_RELU, self._buffer("v1", shape, left.device), depth_planes=planes)
         mark("conv1", 1)
-        return self._conv2_tail(v, shape, timing)
+        return self._conv2_tail(v, shape, timing, arithmetic)

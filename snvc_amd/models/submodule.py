@@ -73,7 +73,7 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
 # coordinate maps).  invalidate_plans() drops exactly these; tests/test_host_cpu.py checks that no other `_snvc_*`
 # name is written anywhere in the package.
 CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans2d", "_snvc_plans2d_t", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
-               "_snvc_coor_maps")
+               "_snvc_coor_maps", "_snvc_x3", "_snvc_x3_off")
 
 
 class _Plan:
@@ -796,7 +796,7 @@ def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *,
         if fusable and not (flags & (EPI_RELU | EPI_SIGMOID)):
             fl, one, fbias = _folded_head_layer(conv, norm, head, plan)
             hres = None
-            if residual is not None:
+            if residual is not None or head_residual is not None:      # head_residual alone: the caller only has head(residual)
                 hres = head_residual if head_residual is not None else head(residual)
             _ROUTES["folded_head"] += 1
             return fl(x, one, fbias, hres, EPI_ADD_PRE if hres is not None else 0)

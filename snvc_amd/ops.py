@@ -529,6 +529,27 @@ def sheared_expand(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int,
     return out
 
 
+def sheared_expand_split(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int, off_col: int, flags: int = 0, overflow=None):
+    """``sheared_expand`` with the result written as a split C8 pair (snvc_sheared_expand_split): ``out`` = float16
+    [N, 2, C/8, D, H, W, 8] holding the layer's result times the power of two the caller folded into scale / bias."""
+    _gpu(g, "g"); _gpu(gcol, "gcol")
+    _split_check(out, "out")
+    n, _, grp, d, h, w, _ = out.shape
+    c = g.size(1) // 3
+    if (c + 7) // 8 != grp:
+        raise RuntimeError("sheared_expand_split: out has the wrong number of channel groups")
+    for t in (g, gcol):
+        if t.dtype != torch.float32 or tuple(t.shape[:3]) != (n, 3 * c, h) or not t.is_contiguous():
+            raise RuntimeError("sheared_expand_split needs contiguous float32 g / gcol [N,3C,H,*] (depth classes stacked class-major)")
+    if planes is not None and (tuple(planes.shape) != (n, c, 3, h, w) or not planes.is_contiguous()):
+        raise RuntimeError("planes must be a contiguous [N,C,3,H,W] tensor")
+    with torch.cuda.device(out.device):
+        check(_lib.lib().snvc_sheared_expand_split(_ptr(g), _ptr(gcol), _ptr(planes), _ptr(scale), _ptr(bias), _ptr(out), _lo_ptr(out),
+                                                   _ptr(overflow), n, c, d, h, w, int(q), int(m0), g.size(3), int(off), gcol.size(3),
+                                                   int(off_col), _batch_stride(out), int(flags), _stream(out)), "snvc_sheared_expand_split")
+    return out
+
+
 def sheared_expand_stats(g, gcol, planes, gamma, beta, shape, q: int, m0: int, off: int, off_col: int, eps: float):
     """Batch statistics of the sheared layer's raw result without storing it (snvc_sheared_expand_stats): returns
     (scale, shift, mean, var), each [1, C], for ``y = relu(scale * raw + shift)``; ``shape`` = (N, C, D, H, W) of the result."""
@@ -1099,19 +1120,22 @@ def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) ->
 
 
 class Conv3dLayerX3:
-    """nn.Conv3d(k3, s1, p1) prepared for the split-mode kernels (snvc_f16x3_conv3d_*): fp32-accurate contraction on the half
-    pipe.  The weights are packed as (hi, lo) of  w * 2**w_exp  with w_exp chosen so that max|w| lands in [2^13, 2^14): both
-    parts then keep their full 11 bits."""
+    """nn.Conv3d(k3, p1, stride 1 | 2) / nn.ConvTranspose3d(k3, s2, p1, op1) prepared for the split-mode kernels
+    (snvc_f16x3_conv3d_*): the fp32 contraction at fp32 accuracy on the half pipe.  The weights are packed as (hi, lo) of
+    w * 2**w_exp  with w_exp chosen so that max|w| lands in [2^13, 2^14): both parts then keep their full 11 bits."""
 
     def __init__(self, weight: torch.Tensor, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1, transposed: bool = False):
         _gpu(weight, "weight")
         if weight.dtype != torch.float32:
             raise RuntimeError("conv3d weights must be float32")
         self.transposed = bool(transposed)
-        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        if transposed:
+            self.cin, self.cout = weight.shape[0], weight.shape[1]
+        else:
+            self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
         wmax = float(weight.detach().abs().max().item()) if weight.numel() else 1.0
-        self.w_exp = 13 - math.frexp(wmax)[1] + 1 if wmax > 0 and math.isfinite(wmax) else 0      # wmax * 2^w_exp in [2^13, 2^14)
+        self.w_exp = 14 - math.frexp(wmax)[1] if wmax > 0 and math.isfinite(wmax) else 0      # wmax * 2^w_exp in [2^13, 2^14)
         probe = self._desc(1, (16, 16, 32), 0)
         nbytes = _lib.lib().snvc_f16x3_conv3d_packed_weight_bytes(ctypes.byref(probe))
         if nbytes < 0:
@@ -1120,14 +1144,33 @@ class Conv3dLayerX3:
         with torch.cuda.device(weight.device):
             check(_lib.lib().snvc_f16x3_conv3d_pack_weights(ctypes.byref(probe), _ptr(weight.detach().contiguous()), _ptr(self.packed),
                                                             float(2.0 ** self.w_exp), _stream(weight)), "snvc_f16x3_conv3d_pack_weights")
+        self._affine = {}
 
     out_spatial = Conv3dLayer.out_spatial
     _desc = Conv3dLayer._desc
 
+    def folded(self, scale, bias, x_exp: int, out_exp: int):
+        """(scale', bias') of the epilogue with the exponents folded in: conv sums are in units of 2^(x_exp + w_exp), the
+        stored result in units of 2^out_exp.  Cached per (scale, bias, exponents)."""
+        key = (None if scale is None else (scale.data_ptr(), scale._version), None if bias is None else (bias.data_ptr(), bias._version),
+               x_exp, out_exp)
+        hit = self._affine.get(key)
+        if hit is None:
+            dev = self.packed.device
+            sc = (scale.detach().float() if scale is not None else torch.ones(self.cout, device=dev)) * (2.0 ** (out_exp - x_exp - self.w_exp))
+            bi = (bias.detach().float() if bias is not None else torch.zeros(self.cout, device=dev)) * (2.0 ** out_exp)
+            if len(self._affine) > 8:
+                self._affine.clear()
+            hit = self._affine[key] = (sc.contiguous(), bi.contiguous())
+        return hit
+
     def __call__(self, x, x_exp: int = 0, scale=None, bias=None, residual=None, flags: int = 0, out=None, out_exp: int = 0,
-                 out_f32=None, to_f32: bool = False):
+                 out_f32=None, to_f32: bool = False, head=None, overflow=None):
         """y = epilogue(conv(x)).  x: split C8 tensor holding values * 2**x_exp.  Result: a split C8 tensor holding
-        y * 2**out_exp (``residual``: a split tensor with the same exponent), or -- ``to_f32`` / ``out_f32`` -- float32 NCDHW."""
+        y * 2**out_exp, or -- ``to_f32`` / ``out_f32`` -- float32 NCDHW (out_exp is then the residual's exponent).  ``residual``:
+        a split tensor holding values * 2**out_exp.  ``head`` [Cout = 32] weights: returns ``(y, y_head)`` with ``y_head`` the
+        float32 [N,1,D,H,W] projection sum_c head[c] * y[:, c] written by the same launch.  ``overflow``: an int32 device
+        tensor that is set to 1 if a value had to be clamped to half's range."""
         _split_check(x, "x")
         if x.size(2) * 8 != self.cin:
             raise RuntimeError(f"conv3d input must have {self.cin} channels (split C8), got {x.size(2) * 8}")
@@ -1136,34 +1179,40 @@ class Conv3dLayerX3:
         out_sp = self.out_spatial(in_sp)
         f32 = to_f32 or out_f32 is not None
         if f32:
-            if residual is not None:
-                raise RuntimeError("the float32 output form takes no residual")
             if out_f32 is None:
                 out_f32 = torch.empty((n, self.cout) + out_sp, dtype=torch.float32, device=x.device)
             elif tuple(out_f32.shape) != (n, self.cout) + out_sp or out_f32.dtype != torch.float32 or not _dense_inner(out_f32):
                 raise RuntimeError("out_f32 must be a float32 [N,Cout,D,H,W] tensor, dense below dim 0")
-            out_exp = 0
         elif out is None:
             out = torch.empty((n, 2, self.cout // 8) + out_sp + (8,), dtype=torch.float16, device=x.device)
         else:
             _split_check(out, "out")
+            if tuple(out.shape) != (n, 2, self.cout // 8) + out_sp + (8,):
+                raise RuntimeError("conv3d `out` must be a split C8 tensor of the output shape")
         if residual is not None:
             _split_check(residual, "residual")
-        # the exponents ride in the epilogue's affine: conv sums are in units of 2^(x_exp + w_exp)
-        dev = x.device
-        fold = 2.0 ** (out_exp - x_exp - self.w_exp)
-        sc = (scale.float() if scale is not None else torch.ones(self.cout, device=dev)) * fold
-        bi = (bias.float() if bias is not None else torch.zeros(self.cout, device=dev)) * (2.0 ** out_exp)
+            if tuple(residual.shape) != (n, 2, self.cout // 8) + out_sp + (8,):
+                raise RuntimeError("residual must have the output's shape (split C8)")
+        y_head = None
+        if head is not None:
+            head = head.detach().reshape(-1).float().contiguous()
+            y_head = torch.empty((n, 1) + out_sp, dtype=torch.float32, device=x.device)
+        # with a float32 result the epilogue works in units of 2^out_exp too (the residual's) and scales back on the way out: exact
+        sc, bi = self.folded(scale, bias, x_exp, out_exp)
         if n == 0:
-            return out_f32 if f32 else out
+            return out_f32 if f32 else ((out, y_head) if head is not None else out)
         d = self._desc(n, in_sp, flags, _batch_stride(x), _batch_stride(out_f32 if f32 else out),
                        _batch_stride(residual) if residual is not None else 0)
-        with torch.cuda.device(dev):
-            check(_lib.lib().snvc_f16x3_conv3d_forward(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(self.packed), _ptr(sc.contiguous()),
-                                                       _ptr(bi.contiguous()), _ptr(residual), _lo_ptr(residual) if residual is not None else None,
-                                                       _ptr(out) if not f32 else None, _lo_ptr(out) if not f32 else None,
-                                                       _ptr(out_f32) if f32 else None, _stream(x)), "snvc_f16x3_conv3d_forward")
-        return out_f32 if f32 else out
+        null = ctypes.c_void_p(0)
+        with torch.cuda.device(x.device):
+            check(_lib.lib().snvc_f16x3_conv3d_forward(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(self.packed), _ptr(sc), _ptr(bi),
+                                                       _ptr(residual), _lo_ptr(residual) if residual is not None else null,
+                                                       null if f32 else _ptr(out), null if f32 else _lo_ptr(out),
+                                                       _ptr(out_f32) if f32 else null, _ptr(head), _ptr(y_head), float(2.0 ** -out_exp),
+                                                       _ptr(overflow), _stream(x)), "snvc_f16x3_conv3d_forward")
+        if f32:
+            return out_f32          # the kernel multiplied by 2^-out_exp on the way out
+        return (out, y_head) if head is not None else out
 
 
 def mul_broadcast_c8(feat, occ, out=None):

@@ -330,3 +330,85 @@ def test_f16_released_shape_full_size_forward():
         e = (out[k] - ref[k]).abs().max().item() / max(ref[k].abs().max().item(), 1e-30)
         print(f"released shape, fp16-storage vs fp32 forward, {k}: max|err|/max = {e:.2e}")
         assert e <= tol, (k, e)
+
+
+# ================================================================================================
+# r4 split mode ("f16x3", conv3d_f16.hip F16Cfg::PL >= 2): the fp32 layers' contraction on three half-precision MFMAs per
+# product.  These are fp32 layers: they are held to the fp32 path's own tolerances (TIGHT = 2e-5 of the range per layer)
+# against torch's fp32 / fp64 convolution -- not to the fp16-storage mode's.
+# ================================================================================================
+def _x3_reference(x, w, scale, bias, stride, transposed, relu, residual=None, pre=True):
+    xd, wd = x.double().cpu(), w.double().cpu()
+    if transposed:
+        y = F.conv_transpose3d(xd, wd, None, 2, 1, 1)
+    else:
+        y = F.conv3d(xd, wd, None, stride, 1)
+    y = y * scale.double().cpu().view(1, -1, 1, 1, 1) + bias.double().cpu().view(1, -1, 1, 1, 1)
+    if residual is not None and pre:
+        y = y + residual.double().cpu()
+    if relu:
+        y = torch.relu(y)
+    if residual is not None and not pre:
+        y = y + residual.double().cpu()
+    return y
+
+
+@pytest.mark.parametrize("case", ["k3_32_32", "k3_64_64", "k3_32_64", "k3s2_32_64", "k3s2_64_64", "deconv_64_64", "k3_32_32_odd"])
+def test_split_mode_layers_vs_float64(case):
+    from snvc_amd import ops
+    from test_gpu_parity import TIGHT, check
+    torch.manual_seed(hash(case) % 1000)
+    cin, cout, stride, transposed, shape = {
+        "k3_32_32": (32, 32, 1, False, (8, 12, 40)), "k3_64_64": (64, 64, 1, False, (8, 8, 36)), "k3_32_64": (32, 64, 1, False, (5, 9, 33)),
+        "k3s2_32_64": (32, 64, 2, False, (8, 12, 72)), "k3s2_64_64": (64, 64, 2, False, (6, 10, 42)),
+        "deconv_64_64": (64, 64, 2, True, (4, 6, 20)), "k3_32_32_odd": (32, 32, 1, False, (3, 5, 31))}[case]
+    x = torch.relu(torch.randn(2, cin, *shape, device=dev())) * 2.0 + 0.01 * torch.randn(2, cin, *shape, device=dev())
+    w = torch.randn((cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3), device=dev()) * np.sqrt(2.0 / (cin * 27))
+    scale, bias = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.3
+    layer = ops.Conv3dLayerX3(w, 3, stride, 1, 1, transposed)
+    for x_exp, out_exp in ((0, 0), (5, 3)):
+        xs = ops.to_split(x, x_exp)
+        assert torch.allclose(ops.from_split(xs, x_exp), x, rtol=0, atol=2e-6 * x.abs().max().item())       # 22 bits
+        ref = _x3_reference(x, w, scale, bias, stride, transposed, True)
+        y32 = layer(xs, x_exp, scale, bias, flags=ops.EPI_RELU, to_f32=True)
+        check(y32.cpu().numpy(), ref.numpy(), TIGHT, f"{case}: split -> float32, exponents {x_exp}/{out_exp}")
+        flag = torch.zeros(1, dtype=torch.int32, device=dev())
+        ys = layer(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out_exp=out_exp, overflow=flag)
+        check(ops.from_split(ys, out_exp).cpu().numpy(), ref.numpy(), TIGHT, f"{case}: split -> split")
+        assert flag.item() == 0
+        # residual before / after the activation, split residual, both output forms
+        res = torch.randn_like(y32)
+        rs = ops.to_split(res, out_exp)
+        for pre, fl in ((True, ops.EPI_ADD_PRE), (False, ops.EPI_ADD_POST)):
+            ref_r = _x3_reference(x, w, scale, bias, stride, transposed, True, res, pre)
+            yr = layer(xs, x_exp, scale, bias, residual=rs, flags=ops.EPI_RELU | fl, out_exp=out_exp)
+            check(ops.from_split(yr, out_exp).cpu().numpy(), ref_r.numpy(), TIGHT, f"{case}: residual pre={pre}")
+            yr32 = layer(xs, x_exp, scale, bias, residual=rs, flags=ops.EPI_RELU | fl, out_exp=out_exp, to_f32=True)
+            check(yr32.cpu().numpy(), ref_r.numpy(), TIGHT, f"{case}: residual pre={pre}, float32 out")
+    # no affine, no activation
+    y0 = layer(ops.to_split(x, 2), 2, to_f32=True)
+    ref0 = (F.conv_transpose3d(x.double().cpu(), w.double().cpu(), None, 2, 1, 1) if transposed else
+            F.conv3d(x.double().cpu(), w.double().cpu(), None, stride, 1))
+    check(y0.cpu().numpy(), ref0.numpy(), TIGHT, f"{case}: bare convolution")
+
+
+def test_split_mode_side_head_and_overflow_flag():
+    from snvc_amd import ops
+    from test_gpu_parity import TIGHT, check
+    torch.manual_seed(5)
+    x = torch.relu(torch.randn(1, 32, 6, 8, 40, device=dev()))
+    w = torch.randn(32, 32, 3, 3, 3, device=dev()) * 0.05
+    scale, bias = torch.rand(32, device=dev()) + 0.5, torch.randn(32, device=dev()) * 0.2
+    head = torch.randn(32, device=dev())
+    layer = ops.Conv3dLayerX3(w)
+    xs = ops.to_split(x, 4)
+    ys, yh = layer(xs, 4, scale, bias, flags=ops.EPI_RELU, out_exp=6, head=head)
+    ref = _x3_reference(x, w, scale, bias, 1, False, True)
+    check(ops.from_split(ys, 6).cpu().numpy(), ref.numpy(), TIGHT, "side head: the layer itself")
+    check(yh.cpu().numpy(), (ref * head.double().cpu().view(1, -1, 1, 1, 1)).sum(1, keepdim=True).numpy(), TIGHT, "side head: the projection")
+    # an exponent that pushes the result beyond half's range: finite (clamped) and flagged
+    flag = torch.zeros(1, dtype=torch.int32, device=dev())
+    big = layer(xs, 4, scale, bias, flags=ops.EPI_RELU, out_exp=16, overflow=flag)
+    assert flag.item() == 1 and torch.isfinite(big.float()).all()
+    with pytest.raises(RuntimeError):
+        ops.Conv3dLayerX3(torch.randn(32, 32, 5, 5, 5, device=dev()), 5, 1, 2, 1, False)       # k5: not built

@@ -97,11 +97,11 @@ def test_global_pair_full_size_factored_equals_materialised(pair):
         before = S._ROUTES["sheared_first_conv"]
         s = m.forward_pair(dl, dr, ds, 1)                           # cfg2's shifts are d / 2: the sheared first convolution
         assert S._ROUTES["sheared_first_conv"] == before + 1
-        v1s = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+        v1s = m.last_first_layer()
         probe_s = v1s[0, ::7, ::5, ::9, ::11].clone()               # the first layer itself, strided over the whole volume,
         edge_s = [v1s[0, :, 0].clone(), v1s[0, :, D - 1].clone(), v1s[0, :, :, :, W - 1].clone(), v1s[0, :, :, :, 0].clone()]
         a = m.forward_pair(dl, dr, ds, 1, factored=True, sheared=False, commuted=False)
-        v1g = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+        v1g = m.last_first_layer()
         assert torch.allclose(probe_s, v1g[0, ::7, ::5, ::9, ::11], rtol=1e-4, atol=1e-4)
         for e, g in zip(edge_s, (v1g[0, :, 0], v1g[0, :, D - 1], v1g[0, :, :, :, W - 1], v1g[0, :, :, :, 0])):   # and its four borders whole
             assert torch.allclose(e, g, rtol=1e-4, atol=1e-4), (e - g).abs().max()   # 864-term fp32 sums in two orders, values up to ~5
@@ -111,7 +111,7 @@ def test_global_pair_full_size_factored_equals_materialised(pair):
         before_c = S._ROUTES["commuted_first_conv"]
         cmt = m.forward_pair(dl, dr, ds, 1, sheared=False)
         assert S._ROUTES["commuted_first_conv"] == before_c + 1
-        v1c = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+        v1c = m.last_first_layer()
         assert torch.allclose(probe_g, v1c[0, ::7, ::5, ::9, ::11], rtol=1e-4, atol=1e-4)
         for e, g in zip(edge_g, (v1c[0, :, 0], v1c[0, :, D - 1], v1c[0, :, :, :, W - 1], v1c[0, :, :, :, 0])):
             assert torch.allclose(e, g, rtol=1e-4, atol=1e-4), (e - g).abs().max()

@@ -78,26 +78,29 @@ def cfg1():
     return _oracle_run(d, shift)
 
 
-def _entry_points(o, expect_route):
-    """Every way into the step, against the oracle's cost: all outputs, check()'s three criteria."""
+def _entry_points(o, expect_route, arithmetic):
+    """Every way into the step, against the oracle's cost: all outputs, check()'s three criteria.  ``arithmetic``: "fp32" (the
+    fp32-MFMA kernels) or "x3" (conv2 + hourglass on the split-mode kernels: three half-precision MFMAs per product)."""
     from snvc_amd.extension.build_cost_volume import build_cost_volume
     from snvc_amd.models import submodule as S
     m = _model()
+    m.arithmetic = arithmetic
     dl, dr, ds = o["left"].to(dev()), o["right"].to(dev()), o["shift"].to(dev())
     exp = o["cost"].numpy()
     with torch.no_grad():
-        before = S._ROUTES[expect_route]
+        before, before_x3 = S._ROUTES[expect_route], S._ROUTES["x3_tail"]
         got = m.forward_pair(dl, dr, ds, 1).cpu().numpy()
         assert S._ROUTES[expect_route] == before + 1, f"forward_pair did not take the {expect_route} route"
+        assert S._ROUTES["x3_tail"] == before_x3 + (1 if arithmetic == "x3" else 0)
         check(got, exp, 1e-4, f"forward_pair ({expect_route}) vs oracle, full size")
-        v1 = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+        v1 = m.last_first_layer()
         check(v1.cpu().numpy(), o["v1"].numpy(), TIGHT, f"first layer ({expect_route}) vs oracle, full size")
         if expect_route != "commuted_first_conv":
             before = S._ROUTES["commuted_first_conv"]
             got = m.forward_pair(dl, dr, ds, 1, sheared=False).cpu().numpy()
             assert S._ROUTES["commuted_first_conv"] == before + 1
             check(got, exp, 1e-4, "forward_pair (any shift array: warp after convolution) vs oracle, full size")
-            v1 = [v for k, v in m.__dict__["_snvc_ws"].items() if k[0] == "v1"][0]
+            v1 = m.last_first_layer()
             check(v1.cpu().numpy(), o["v1"].numpy(), TIGHT, "first layer (warp after convolution) vs oracle, full size")
         got = m.forward_pair(dl, dr, ds, 1, sheared=False, commuted=False).cpu().numpy()
         check(got, exp, 1e-4, "forward_pair (right half built) vs oracle, full size")
@@ -111,13 +114,15 @@ def _entry_points(o, expect_route):
         check(got, exp, 1e-4, "model(materialised lazy volume) vs oracle, full size")
 
 
-def test_cfg2_every_entry_point_vs_oracle_full_size(cfg2):
-    _entry_points(cfg2, "sheared_first_conv")
+@pytest.mark.parametrize("arithmetic", ["fp32", "x3"])
+def test_cfg2_every_entry_point_vs_oracle_full_size(cfg2, arithmetic):
+    _entry_points(cfg2, "sheared_first_conv", arithmetic)
 
 
-def test_cfg1_every_entry_point_vs_oracle_full_size(cfg1):
+@pytest.mark.parametrize("arithmetic", ["fp32", "x3"])
+def test_cfg1_every_entry_point_vs_oracle_full_size(cfg1, arithmetic):
     """cfg1's shifts (linspace(0,63,64) + 0.5 on odd planes) are not uniformly spaced: the warp-after-convolution path."""
-    _entry_points(cfg1, "commuted_first_conv")
+    _entry_points(cfg1, "commuted_first_conv", arithmetic)
 
 
 def test_cfg2_every_layer_on_the_oracles_input_full_size(cfg2):
@@ -126,6 +131,7 @@ def test_cfg2_every_layer_on_the_oracles_input_full_size(cfg2):
     from snvc_amd.models import submodule as S
     o = cfg2
     m = _model()
+    m.arithmetic = "fp32"
     hg = m.hg_conv3d
     g = lambda k: o[k].to(dev())                                                                     # noqa: E731
     with torch.no_grad():
@@ -154,3 +160,39 @@ def test_cfg2_every_layer_on_the_oracles_input_full_size(cfg2):
         cost = hg.conv6.fused(g("post"), residual=g("v2"), head=m.classifier, head_residual=g("hv"))
         assert S._ROUTES["folded_head"] == b_f + 1
         check(cost.cpu().numpy(), o["cost"].numpy(), TIGHT, "folded tail: classifier(bn(deconv(post)) + v2) as one transposed layer to one channel")
+
+
+def test_cfg2_every_split_mode_layer_on_the_oracles_input_full_size(cfg2):
+    """The same layer-by-layer comparison for the split-mode (f16x3) kernels the default inference path runs conv2 and the
+    hourglass on: each layer fed the oracle's input of that layer (split with the exponent the model chose), whole output
+    tensors against the oracle's at the SAME exact-fp32 tolerance as the fp32 kernels."""
+    from snvc_amd import ops
+    o = cfg2
+    m = _model()
+    st = m._x3_state(dev())
+    assert st is not None
+    L, A, E = st["layers"], st["affine"], st["exp"]
+    sp = lambda k, e: ops.to_split(o[k].to(dev()), e)                                               # noqa: E731
+    with torch.no_grad():
+        flag = torch.zeros(1, dtype=torch.int32, device=dev())
+        v2s, hv = L["conv2"](sp("v1", E["v1"]), E["v1"], *A["conv2"], flags=ops.EPI_RELU, out_exp=E["conv2"], head=m.classifier.weight,
+                             overflow=flag)
+        check(ops.from_split(v2s, E["conv2"]).cpu().numpy(), o["v2"].numpy(), TIGHT, "split conv2 (32->32 on 192x96x312)")
+        check(hv.cpu().numpy(), o["hv"].numpy(), TIGHT, "split conv2's side head = classifier(v2)")
+        del v2s, hv
+        h1 = L["h1"](sp("v2", E["conv2"]), E["conv2"], *A["h1"], flags=ops.EPI_RELU, out_exp=E["h1"], overflow=flag)
+        check(ops.from_split(h1, E["h1"]).cpu().numpy(), o["h1"].numpy(), TIGHT, "split hourglass conv1 (k3 stride 2, 32->64)")
+        del h1
+        pre = L["h2"](sp("h1", E["h1"]), E["h1"], *A["h2"], flags=ops.EPI_RELU, out_exp=E["h2"], overflow=flag)
+        check(ops.from_split(pre, E["h2"]).cpu().numpy(), o["pre"].numpy(), TIGHT, "split hourglass conv2 (64->64 on 96x48x156)")
+        del pre
+        h3 = L["h3"](sp("pre", E["h2"]), E["h2"], *A["h3"], flags=ops.EPI_RELU, out_exp=E["h3"], overflow=flag)
+        check(ops.from_split(h3, E["h3"]).cpu().numpy(), o["h3"].numpy(), TIGHT, "split hourglass conv3 (k3 stride 2, 64->64)")
+        del h3
+        h4 = L["h4"](sp("h3", E["h3"]), E["h3"], *A["h4"], flags=ops.EPI_RELU, out_exp=E["h4"], overflow=flag)
+        check(ops.from_split(h4, E["h4"]).cpu().numpy(), o["h4"].numpy(), TIGHT, "split hourglass conv4 (64->64 on 48x24x78)")
+        del h4
+        post = L["h5"](sp("h4", E["h4"]), E["h4"], *A["h5"], residual=sp("pre", E["h2"]), flags=ops.EPI_RELU | ops.EPI_ADD_PRE,
+                       out_exp=E["h2"], to_f32=True)
+        check(post.cpu().numpy(), o["post"].numpy(), TIGHT, "split hourglass conv5 (transposed 64->64 + pre, ReLU) -> fp32")
+        assert flag.item() == 0, "a value was clamped to half's range"

@@ -1141,10 +1141,10 @@ def test_commuted_first_conv_any_shift_vs_oracle_and_built_volume(case):
         before = S._ROUTES["commuted_first_conv"]
         got = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()
         assert S._ROUTES["commuted_first_conv"] == before + 1
-        v1c = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+        v1c = ours.last_first_layer().clone()
         built = ours.forward_pair(dl, dr, dsh, 1, commuted=False).cpu().numpy()
         assert S._ROUTES["commuted_first_conv"] == before + 1
-        v1b = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+        v1b = ours.last_first_layer().clone()
     check(v1c.cpu().numpy(), v1b.cpu().numpy(), TIGHT, f"first layer, warp after convolution vs built volume ({case})")
     check(got, exp, 1e-4, f"pair vs oracle ({case})")
     check(got, built, 2e-5, f"pair, warp after convolution vs built volume ({case})")
@@ -1154,7 +1154,7 @@ def test_commuted_first_conv_any_shift_vs_oracle_and_built_volume(case):
     try:
         with torch.no_grad():
             ours.forward_pair(dl, dr, dsh, 1)
-            v1r = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+            v1r = ours.last_first_layer().clone()
     finally:
         ops.WARPED_EXPAND_FORM[0] = 0
     check(v1c.cpu().numpy(), v1r.cpu().numpy(), 2e-6, f"first layer, register-window form vs r3 form ({case})")
@@ -1264,9 +1264,9 @@ def test_sheared_first_conv_vs_oracle_and_general_path(q, m0):
         # first layer alone (before conv2 / the hourglass smooth anything over): the sheared planes against the general ones
         v_sheared = ours.__dict__["_snvc_ws"]
         ours.forward_pair(dl, dr, dsh, 1)
-        v1s = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+        v1s = ours.last_first_layer().clone()
         ours.forward_pair(dl, dr, dsh, 1, sheared=False, commuted=False)
-        v1g = [v for k, v in ours.__dict__["_snvc_ws"].items() if k[0] == "v1"][0].clone()
+        v1g = ours.last_first_layer().clone()
         # a shift array that is not uniformly spaced: general path
         dsh2 = dsh.clone()
         dsh2[0, 5] += 0.25
