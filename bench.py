@@ -519,7 +519,7 @@ def main():
 
     outs = {}
 
-    def run(factored, sheared=True, commuted=True, tag="value"):
+    def run(factored, sheared=True, commuted=True, tag="value", arithmetic=None):
         """W warm-up + K timed steps; returns (seconds for the K steps, mean ms of the "conv1" bracket, of the "volume"
         bracket and of the "conv2" bracket).  sheared path: volume = Rq + the 2D convolution G + the 4-plane edge slab,
         conv1 = the expand pass (0.74 GB write) + edge-plane copies; general path: volume = the right-half cost-volume
@@ -529,7 +529,7 @@ def main():
               for _ in range(args.steps)]
         with torch.no_grad():
             for _ in range(args.warmup):
-                model.forward_pair(left, right, shift, 1, factored=factored, sheared=sheared)
+                model.forward_pair(left, right, shift, 1, factored=factored, sheared=sheared, commuted=commuted, arithmetic=arithmetic)
             # the cyclic garbage collector stays out of the timed region (as timeit does): a generation-2 pass over the
             # ~1e6 objects torch keeps alive costs ~35 ms, i.e. six steps, whenever its counter happens to trip
             gc.collect()
@@ -538,7 +538,8 @@ def main():
             t0 = time.perf_counter()
             for i in range(args.steps):
                 # events go to torch's current stream == the stream the kernels are launched on
-                out = model.forward_pair(left, right, shift, 1, factored=factored, timing=ev[i], sheared=sheared, commuted=commuted)
+                out = model.forward_pair(left, right, shift, 1, factored=factored, timing=ev[i], sheared=sheared, commuted=commuted,
+                                         arithmetic=arithmetic)
             barrier()
             elapsed = time.perf_counter() - t0
             gc.enable()
@@ -560,9 +561,12 @@ def main():
     # The same step on the general path (any shift array: factored first convolution over the built right half) and
     # through the reference's operator API (build_cost_volume + conv1 over all 64 channels) is timed in the same process.
     from snvc_amd.models import submodule as S_
-    routes0 = S_._ROUTES["sheared_first_conv"]
+    routes0, routes_x3 = S_._ROUTES["sheared_first_conv"], S_._ROUTES["x3_tail"]
     elapsed, expand_ms, shear_prep_ms, conv2_ms = run(True)
     sheared_taken = S_._ROUTES["sheared_first_conv"] > routes0
+    x3_taken = S_._ROUTES["x3_tail"] > routes_x3          # conv2 + hourglass on the split-mode (f16x3) kernels
+    # the same step with conv2 and the hourglass on the fp32-MFMA kernels (r1-r3's arithmetic: Winograd F(4,3), v_mfma_f32_32x32x2_f32)
+    elapsed_f32, expand_ms_f32, _, conv2_ms_f32 = run(True, tag="fp32_mfma", arithmetic="fp32")
     elapsed_gen, warp_expand_ms, warp_prep_ms, _ = run(True, sheared=False, tag="general_shift")      # any shift array: warp after convolution
     elapsed_built, conv_ms, cvr_ms, _ = run(True, sheared=False, commuted=False, tag="built_right_half")   # right half built + 3D convolution over it
     elapsed_mat, conv_ms_mat, cv_ms, _ = run(False, tag="materialized")
@@ -587,18 +591,25 @@ def main():
     elapsed_api = run_reference_api()
     dom_flop = CONV1_FLOP / 2                       # a 32 -> 32 channel 3x3x3 layer on the full grid (conv2; conv1's right half)
     share = wino_executed_share(3, W)               # F(4,3): 6 of 12 multiplies x padding of W=312 to 320
+    # split mode: three half-precision MFMAs per product, 28 tap slots for 27 taps (two taps per MFMA), W = 312 on 32-wide tiles
+    share_x3 = 3.0 * (28.0 / 27.0) * ((-(-W // 32) * 32) / float(W))
     dom_ms = conv2_ms if sheared_taken else conv_ms
-    exec_tflops = dom_flop * share / (dom_ms * 1e-3) / 1e12
+    exec_tflops = dom_flop * (share_x3 if x3_taken else share) / (dom_ms * 1e-3) / 1e12
     alg_tflops = dom_flop / (dom_ms * 1e-3) / 1e12
+    dom_peak = PEAK_F16_MFMA_TFLOPS if x3_taken else PEAK_F32_MFMA_TFLOPS
+    exec_tflops_f32 = dom_flop * share / (conv2_ms_f32 * 1e-3) / 1e12
     V1_BYTES = 4.0 * C * D * H * W                  # the first layer's output, written once by the expand pass
     alg_tflops_mat = CONV1_FLOP / (conv_ms_mat * 1e-3) / 1e12
     # HBM bytes per launch: PMC counters cannot be read from inside this process; separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE, gfx950 correction) are committed under profiles/
     traffic, traffic_src, traffic_conv2 = None, None, None
-    for rel in ("profiles/r3/traffic.json", "profiles/r2/traffic.json", "profiles/r1/traffic.json"):
+    traffic_x3 = None
+    for rel in ("profiles/r4/traffic.json", "profiles/r3/traffic.json", "profiles/r2/traffic.json", "profiles/r1/traffic.json"):
         try:
             with open(os.path.join(ROOT, rel)) as fh:
                 tj = json.load(fh)
+            if traffic_x3 is None:
+                traffic_x3 = tj.get("layers", {}).get("x3_conv2", {}).get("hbm_bytes_corrected")
             if traffic_conv2 is None:
                 traffic_conv2 = tj.get("layers", {}).get("conv2_side", {}).get("hbm_bytes_corrected")
             if traffic is None:
@@ -609,6 +620,10 @@ def main():
             pass
     if sheared_taken and traffic_conv2 is not None:
         traffic_src = "profiles/r3/traffic.json, layer conv2_side (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    if x3_taken:
+        traffic_conv2 = traffic_x3
+        traffic_src = ("profiles/r4/traffic.json, layer x3_conv2 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+                       if traffic_x3 is not None else None)
 
     if args.breakdown and rank == 0:
         _breakdown(model, left, right, shift, build_cost_volume)
@@ -633,6 +648,11 @@ def main():
             "config": {
                 "workload": "cfg2 global scene model: 1 pair/GPU, features [1,32,96,312] (1242x375 /4), "
                             "192 disparities -> concat volume [1,64,192,96,312] -> conv3d x2 + hourglass(32) + classifier",
+                "arithmetic": ("fp32 tensors in and out; conv2 + hourglass in SPLIT MODE (" + ("taken" if x3_taken else "NOT taken") + "): activations / weights "
+                               "travel as (hi, lo) pairs of halves (22 significant bits), each fp32 product = three half-precision MFMAs with fp32 "
+                               "accumulation -- the fp32 layers at fp32 accuracy (5e-7 of the range vs float64 per layer; the fp32 Winograd "
+                               "kernels: 2e-6), held to the SAME per-layer 2e-5 / stack 1e-4 tolerances as the fp32 kernels "
+                               "(tests/test_gpu_fullsize_oracle.py, parity_vs_cpu_baseline below); `fp32_mfma` repeats the step on the fp32-MFMA kernels"),
                 "entry_points": {
                     "value": "GlobalStack.forward_pair(left, right, shift): fused entry point.  Left half of the concat volume: "
                              "d-invariant -> 3 depth-class planes.  Warped right half: the disparity planes are uniformly "
@@ -652,25 +672,32 @@ def main():
                 "step_cost_volume_mb_algorithmic": CV_BYTES / 1e6,
             },
             "roofline": {
-                "kernel": ("conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, side head>: second 3D convolution, 32->32 on 192x96x312 "
+                "kernel": ("conv3d_f16_kernel<k3, split mode (f16x3), 4x4x32 tile, 3 WG/CU, side head>: second 3D convolution, 32->32 on "
+                           "192x96x312 + the classifier's projection of its own result; every fp32 product = three v_mfma_f32_32x32x16_f16 "
+                           "on (hi, lo) half pairs, fp32 accumulate (csrc/conv3d_f16.hip, F16Cfg::PL)" if x3_taken else
+                           "conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, side head>: second 3D convolution, 32->32 on 192x96x312 "
                            "+ the classifier's projection of its own result (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)"
                            if sheared_taken else
                            "conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, planes>: first conv over the right half of the volume, "
                            "32->32 on 192x96x312, + depth-class planes (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)"),
                 "bound": "mfma",
-                # `achieved` = flops the kernel EXECUTES on the matrix pipe per second (F(4,3) issues 6 MFMAs where
-                # the direct form needs 12; W = 312 is padded to 320) -> frac <= 1 is the pipe's utilisation.
+                # `achieved` = flops the kernel EXECUTES on the matrix pipe per second.  Split mode: 3 half-precision MFMAs per
+                # fp32 product (x 28/27 tap slots x 320/312 columns), priced against the dense f16 MFMA peak.  fp32 kernels:
+                # F(4,3) issues 6 MFMAs where the direct form needs 12, priced against the fp32 MFMA peak.  frac <= 1 either way.
                 "achieved": exec_tflops,
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": dom_peak,
                 "unit": "TFLOP/s",
-                "frac": exec_tflops / PEAK_F32_MFMA_TFLOPS,
+                "frac": exec_tflops / dom_peak,
                 "algorithmic_tflops": alg_tflops,
-                "algorithmic_over_peak": alg_tflops / PEAK_F32_MFMA_TFLOPS,
+                "algorithmic_over_fp32_mfma_peak": alg_tflops / PEAK_F32_MFMA_TFLOPS,
                 "flop_per_launch_algorithmic": dom_flop,
-                "flop_per_launch_executed": dom_flop * share,
+                "flop_per_launch_executed": dom_flop * (share_x3 if x3_taken else share),
                 "avg_launch_ms": dom_ms,
                 "traffic": traffic if not sheared_taken else traffic_conv2,
                 "traffic_source": traffic_src,
+                "fp32_mfma_form": {"kernel": "conv3d_wino_dma_kernel<4x4x32, side head> (the fp32_mfma leg's conv2: Winograd F(4,3), v_mfma_f32_32x32x2_f32)",
+                                   "avg_launch_ms": conv2_ms_f32, "achieved": exec_tflops_f32, "peak": PEAK_F32_MFMA_TFLOPS,
+                                   "frac": exec_tflops_f32 / PEAK_F32_MFMA_TFLOPS},
             },
             "roofline_hbm": {
                 # the headline path's own HBM-bound kernel: conv1's result written along the shear (one 0.74 GB write stream)
@@ -692,6 +719,12 @@ def main():
                 "full_volume": {"kernel": "cost_volume_fwd_rows: build_cost_volume, both halves (materialized leg)",
                                 "achieved": CV_BYTES / (cv_ms * 1e-3) / 1e9, "frac": CV_BYTES / (cv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "bytes_per_launch": CV_BYTES, "avg_launch_ms": cv_ms},
+            },
+            "fp32_mfma": {
+                "note": "same step, same entry point, with conv2 and the hourglass on the fp32-MFMA kernels (forward_pair(..., arithmetic='fp32'): "
+                        "Winograd F(4,3) / polyphase kernels on v_mfma_f32_32x32x2_f32 -- rounds 1-3's arithmetic)",
+                "value": world * args.steps / elapsed_f32, "ms_per_step": 1e3 * elapsed_f32 / args.steps,
+                "conv2_ms": conv2_ms_f32, "expand_ms": expand_ms_f32,
             },
             "reference_api": {
                 "note": "the reference's call sequence verbatim -- volume = build_cost_volume(left, right, shift, 1); "

@@ -197,7 +197,11 @@ enum {
     SNVC_ALGO_WINO_TILE_NARROW_REG = 0x300,
     SNVC_ALGO_WINO_TILE_MASK = 0x300,
     SNVC_ALGO_GENERIC_EPILOGUE = 0x400,
-    SNVC_ALGO_SCALAR_STAGING = 0x800
+    SNVC_ALGO_SCALAR_STAGING = 0x800,
+    /* snvc_f16x3_* stride-1 layers only: the image's hi / lo planes taken one after the other (double-buffered 19.6 KB image)
+     * instead of side by side (single-buffered 39 KB image); same values, kept selectable for A/B timing.  Pack and forward
+     * must agree on it. */
+    SNVC_ALGO_X3_SERIAL = 0x1000
 };
 
 typedef struct {

@@ -25,6 +25,8 @@
 // A fragments (weights) are NOT staged in LDS: a chunk of a 7^3 layer needs 343 KB of them.  Each wave streams
 // them from L2 in consumption order through a small register ring (they are packed exactly in that order), so
 // the chunk loop has no barrier besides the image hand-over and the LDS holds images only.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace snvc {
@@ -107,6 +109,7 @@ struct F16Cfg {
     static_assert(TD * TH % 4 == 0, "rows split over 4 waves");
     static_assert(MODE == 1 || KCG % 2 == 0, "MODE 0 pairs channel groups");
     static_assert(NIT <= 32, "validity mask is one register");
+    static_assert((TD * TH / 4) * 4 == TD * TH, "whole rows per wave");
     // voxel offset of tap t of a segment (kd = 0 for looped segments)
     static constexpr int tapoff(int t) {
         const int kd = UNROLL_D ? t / (KH * KW) : 0, kh = (t / KW) % KH, kw = t % KW;
@@ -266,27 +269,42 @@ conv3d_f16_kernel(const F16Args a_) {
 #pragma unroll
                 for (int m = 0; m < MA; ++m) q[PF - 1][m] = wq[m * 64];
                 wq += MA * 64;
+                if constexpr (PL == 2) {
+                    // all eight B fragments of the step first, then the three product terms row by row: consecutive MFMAs
+                    // write different accumulators (no back-to-back dependence), the two correction terms before the leading one
+                    h8 bf[NB], bl[NB];
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const h8 bf = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
-                    if constexpr (SERIAL) {
+                    for (int nb = 0; nb < NB; ++nb) {
+                        bf[nb] = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
+                        bl[nb] = *reinterpret_cast<const h8 *>(simg + Cfg::PLANE_BYTES + base + toff + rowoff[nb]);
+                    }
 #pragma unroll
-                        for (int m = 0; m < MI; ++m) {
-                            if (!lo_pass) acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf, acc[nb][m], 0, 0, 0);
-                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf, acc[nb][m], 0, 0, 0);
+                    for (int m = 0; m < MI; ++m) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf[nb], acc[nb][m], 0, 0, 0);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bl[nb], acc[nb][m], 0, 0, 0);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf[nb], acc[nb][m], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const h8 bf = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
+                        if constexpr (SERIAL) {
+#pragma unroll
+                            for (int m = 0; m < MI; ++m) {
+                                if (!lo_pass) acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf, acc[nb][m], 0, 0, 0);
+                                acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf, acc[nb][m], 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < MI; ++m)
+                                acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf, acc[nb][m], 0, 0, 0);
                         }
-                    } else if constexpr (PL == 2) {
-                        const h8 bl = *reinterpret_cast<const h8 *>(simg + Cfg::PLANE_BYTES + base + toff + rowoff[nb]);
-#pragma unroll
-                        for (int m = 0; m < MI; ++m) {      // the two correction terms first, then the leading one
-                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf, acc[nb][m], 0, 0, 0);
-                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bl, acc[nb][m], 0, 0, 0);
-                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf, acc[nb][m], 0, 0, 0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int m = 0; m < MI; ++m)
-                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf, acc[nb][m], 0, 0, 0);
                     }
                 }
             }
@@ -347,65 +365,85 @@ conv3d_f16_kernel(const F16Args a_) {
         _Float16 *yn_lo = (C8OUT && SPLIT) ? a.y_lo + n * a.y_bs : nullptr;
         float *yf = EPI == 2 ? a.y_f32 + n * a.yf_bs : nullptr;
         constexpr float kHalfMax = 65504.0f;
-        bool clamped = false;
+        // Epilogue arithmetic is counted in VALU instructions (every one costs matrix-pipe time of the co-resident waves): the
+        // affine is one FMA, ReLU and the clamp to half's range are ONE v_med3 (lower bound 0 or -65504), the overflow flag is a
+        // running max of |v| compared once at the end, and the residual's conversions exist only in the with-residual instance.
+        const float lo_bound = relu ? 0.0f : -kHalfMax;
+        float vmax = 0.0f;
+        auto run = [&](auto has_res_tag) {
+            constexpr bool HAS_RES = decltype(has_res_tag)::value;
 #pragma unroll
-        for (int m = 0; m < MI; ++m) {
-            if ((cb * MI + m) * 32 >= a.Cout) break;                // Cout = 32 * odd: the last block is half empty
-            const int c0 = (cb * MI + m) * 32 + 16 * half;          // first of this lane's 16 channels
-            f32x4 sc[4], bi[4], hw4[side ? 4 : 1];
+            for (int m = 0; m < MI; ++m) {
+                if ((cb * MI + m) * 32 >= a.Cout) break;                // Cout = 32 * odd: the last block is half empty
+                const int c0 = (cb * MI + m) * 32 + 16 * half;          // first of this lane's 16 channels
+                float hsum[NB];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                sc[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + c0 + 4 * k) : f32x4(1.0f);
-                bi[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.bias + c0 + 4 * k) : f32x4(0.0f);
-                if constexpr (side) hw4[k] = *reinterpret_cast<const f32x4 *>(a.head + c0 + 4 * k);
-            }
-            const int64_t g0 = (int64_t)(c0 >> 3) * out_dhw;        // channel group of registers 0..7; 8..15 is the next
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-                h8 rv[2], rl[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    rv[j] = rn ? *reinterpret_cast<const h8 *>(rn + ((g0 + j * out_dhw) + sp[nb]) * 8) : h8((_Float16)0.0f);
-                    rl[j] = rn_lo ? *reinterpret_cast<const h8 *>(rn_lo + ((g0 + j * out_dhw) + sp[nb]) * 8) : h8((_Float16)0.0f);
-                }
-                float hsum = 0.0f;
+                for (int nb = 0; nb < NB; ++nb) hsum[nb] = 0.0f;
+                // one 8-channel group (a C8 piece) at a time: its affine / head weights are live only while its pieces are formed
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    h8 o, ol;
+                    const int cj = c0 + 8 * j;
+                    f32x4 sc[2], bi[2], hw4[2];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int r = 8 * j + e;
-                        float v = acc[nb][m][r] * sc[r >> 2][r & 3] + bi[r >> 2][r & 3];
-                        const float rr = (float)rv[j][e] + (float)rl[j][e];
-                        if (add_pre) v += rr;
-                        if (relu) v = v > 0.0f ? v : 0.0f;
-                        if (add_post) v += rr;
-                        if constexpr (EPI == 2) {
-                            if (okv[nb]) yf[(int64_t)(c0 + r) * out_dhw + sp[nb]] = v * a.head_mul;     // 2^-e_y: exact
-                        } else {
-                            if constexpr (SPLIT) {      // keep the pair finite: beyond half's range the value is clamped and flagged
-                                const float vc = __builtin_fminf(__builtin_fmaxf(v, -kHalfMax), kHalfMax);
-                                clamped = clamped || (vc != v && v == v);
-                                v = vc;
-                            }
-                            if constexpr (side) hsum += hw4[r >> 2][r & 3] * v;
-                            o[e] = (_Float16)v;
-                            if constexpr (SPLIT) ol[e] = (_Float16)(v - (float)o[e]);
-                        }
+                    for (int k = 0; k < 2; ++k) {
+                        sc[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + cj + 4 * k) : f32x4(1.0f);
+                        bi[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.bias + cj + 4 * k) : f32x4(0.0f);
+                        if constexpr (side) hw4[k] = *reinterpret_cast<const f32x4 *>(a.head + cj + 4 * k);
                     }
-                    if constexpr (C8OUT) {
-                        if (okv[nb]) {
-                            *reinterpret_cast<h8 *>(yn + ((g0 + j * out_dhw) + sp[nb]) * 8) = o;
-                            if constexpr (SPLIT) *reinterpret_cast<h8 *>(yn_lo + ((g0 + j * out_dhw) + sp[nb]) * 8) = ol;
+                    const int64_t gj = (int64_t)(cj >> 3) * out_dhw;        // this group's plane of pieces
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        h8 rv = h8((_Float16)0.0f), rl = h8((_Float16)0.0f);
+                        if constexpr (HAS_RES) {
+                            rv = *reinterpret_cast<const h8 *>(rn + (gj + sp[nb]) * 8);
+                            if (rn_lo) rl = *reinterpret_cast<const h8 *>(rn_lo + (gj + sp[nb]) * 8);
+                        }
+                        h8 o, ol;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float v = __builtin_fmaf(acc[nb][m][8 * j + e], sc[e >> 2][e & 3], bi[e >> 2][e & 3]);
+                            if constexpr (HAS_RES) {
+                                const float rr = (float)rv[e] + (float)rl[e];
+                                if (add_pre) v += rr;
+                                if (relu) v = __builtin_fmaxf(v, 0.0f);
+                                if (add_post) v += rr;
+                            }
+                            if constexpr (EPI == 2) {
+                                if constexpr (!HAS_RES) { if (relu) v = __builtin_fmaxf(v, 0.0f); }
+                                if (okv[nb]) yf[(int64_t)(cj + e) * out_dhw + sp[nb]] = v * a.head_mul;     // 2^-e_y: exact
+                            } else {
+                                if constexpr (SPLIT) {
+                                    vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
+                                    // ReLU (when no residual follows it) and the clamp that keeps the pair finite, in one v_med3
+                                    v = __builtin_amdgcn_fmed3f(v, HAS_RES ? -kHalfMax : lo_bound, kHalfMax);
+                                } else if constexpr (!HAS_RES) {
+                                    if (relu) v = __builtin_fmaxf(v, 0.0f);
+                                }
+                                if constexpr (side) hsum[nb] += hw4[e >> 2][e & 3] * v;
+                                o[e] = (_Float16)v;
+                                if constexpr (SPLIT) ol[e] = (_Float16)(v - (float)o[e]);
+                            }
+                        }
+                        if constexpr (C8OUT) {
+                            if (okv[nb]) {
+                                *reinterpret_cast<h8 *>(yn + (gj + sp[nb]) * 8) = o;
+                                if constexpr (SPLIT) *reinterpret_cast<h8 *>(yn_lo + (gj + sp[nb]) * 8) = ol;
+                            }
                         }
                     }
                 }
                 if constexpr (side) {     // the two half-waves hold channels 0..15 / 16..31 of the same 32 voxels
-                    hsum += __shfl_xor(hsum, 32, 64);
-                    if (okv[nb] && half == 0) a.y_head[n * out_dhw + sp[nb]] = hsum * a.head_mul;
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const float tot = hsum[nb] + __shfl_xor(hsum[nb], 32, 64);
+                        if (okv[nb] && half == 0) a.y_head[n * out_dhw + sp[nb]] = tot * a.head_mul;
+                    }
                 }
             }
-        }
+        };
+        if (rn) run(std::true_type{});
+        else run(std::false_type{});
+        const bool clamped = vmax >= kHalfMax;      // a NaN never raises the flag (fmaxf drops it)
         if constexpr (C8OUT && SPLIT) {
             if (clamped && a.overflow) atomicOr(a.overflow, 1);
         }
@@ -503,12 +541,17 @@ using F16DCN   = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 0, true, 2>;
 //                         KD KH KW S  D  MI TD TH KCG MODE DB    OCC DILW PL
 using F16K3X  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, false, 3, 1, 2>;
 using F16K3X2 = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 1, 1, false, 2, 1, 2>;
+// experiment (desc.algo & SNVC_ALGO_X3_SERIAL): planes taken serially, the 19.6 KB image double-buffered
+using F16K3XS  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, true, 3, 1, 3>;
+using F16K3XD  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, true, 2, 1, 2>;      // experiment 0x2000: resident planes, double-buffered, 2 WG/CU
+using F16K3XB  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 8, 1, 1, false, 2, 1, 2>;     // experiment 0x4000: 4x8x32 tile (NB = 8), 2 WG/CU
+using F16K3X2S = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 1, 1, true, 2, 1, 3>;
 // stride 2: the image of a 2x4x32 tile is 5 x 9 x 65 pieces (46.8 KB per plane): the planes are taken serially (PL = 3)
 using F16K3S2X = F16Cfg<3, 3, 3, 2, 1, 2, 2, 4, 1, 1, false, 2, 1, 3>;
 // one parity class of ConvTranspose3d(k3,s2,p1,op1): 2x2x2 box taps, both planes resident, double-buffered
 using F16DCX  = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 1, 1, true, 2, 1, 2>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XD, FK3XB, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES;
@@ -547,7 +590,10 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                 p = plan_from<F16K3S2X>(FK3S2X);
             } else {
                 if (d.Cout % 32 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: Cout % 32 == 0");
-                p = d.Cout == 32 ? plan_from<F16K3X>(FK3X) : plan_from<F16K3X2>(FK3X2);
+                if ((d.algo & 0x2000) && d.Cout == 32) p = plan_from<F16K3XD>(FK3XD);
+                else if ((d.algo & 0x4000) && d.Cout == 32) p = plan_from<F16K3XB>(FK3XB);
+                else if (d.algo & SNVC_ALGO_X3_SERIAL) p = d.Cout == 32 ? plan_from<F16K3XS>(FK3XS) : plan_from<F16K3X2S>(FK3X2S);
+                else p = d.Cout == 32 ? plan_from<F16K3X>(FK3X) : plan_from<F16K3X2>(FK3X2);
             }
         }
         p.nchunks = ceil_div(d.Cin / 8, p.KCG);
@@ -774,7 +820,7 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: RELU / ADD_PRE / ADD_POST only");
     if ((head != nullptr) != (y_head != nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: head and y_head go together");
-    if (head && (p.kind != FK3X || to_f32))
+    if (head && ((p.kind != FK3X && p.kind != FK3XS) || to_f32))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the side head is built for 32-channel stride-1 layers with a split output");
     const int64_t in_sp = (int64_t)d->Din * d->Hin * d->Win, out_sp = (int64_t)d->Dout * d->Hout * d->Wout;
     if ((int64_t)(d->Cin / 8 + 2) * in_sp >= ((int64_t)1 << 31) || out_sp >= ((int64_t)1 << 31))
@@ -827,6 +873,14 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
             else launch_f16<F16K3X, 0>(a, grid, st);
             break;
         case FK3X2: if (to_f32) launch_f16<F16K3X2, 2>(a, grid, st); else launch_f16<F16K3X2, 0>(a, grid, st); break;
+        case FK3XS:
+            if (to_f32) launch_f16<F16K3XS, 2>(a, grid, st);
+            else if (head) launch_f16<F16K3XS, 3>(a, grid, st);
+            else launch_f16<F16K3XS, 0>(a, grid, st);
+            break;
+        case FK3X2S: if (to_f32) launch_f16<F16K3X2S, 2>(a, grid, st); else launch_f16<F16K3X2S, 0>(a, grid, st); break;
+        case FK3XD: launch_f16<F16K3XD, 0>(a, grid, st); break;
+        case FK3XB: launch_f16<F16K3XB, 0>(a, grid, st); break;
         case FK3S2X: if (to_f32) launch_f16<F16K3S2X, 2>(a, grid, st); else launch_f16<F16K3S2X, 0>(a, grid, st); break;
         case FDCX: if (to_f32) launch_f16<F16DCX, 2>(a, grid, st); else launch_f16<F16DCX, 0>(a, grid, st); break;
         default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: no kernel");

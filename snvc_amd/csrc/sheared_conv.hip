@@ -917,141 +917,103 @@ sheared_upsample_bwd_kernel(const float *__restrict__ drq, float *__restrict__ d
 // ------------------------------------------------------------------------------------ split-mode output (r4, "f16x3")
 // sheared_expand_kernel with the result written as a split C8 pair (conv3d_f16.hip, F16Cfg::PL: v = hi + lo, two half planes
 // [C/8][D][H][W][8]) for a consumer on the split-mode kernels: the SAME bytes as the fp32 tensor.  A C8 piece holds the 8 channels
-// of one voxel, so a workgroup owns a channel GROUP (8 channels x RB rows; a thread = (row, quad of 4 columns) walks its planes
-// with 8 x Q register windows) and, to keep the launch at >= 1024 workgroups, a CHUNK of the depth range (blockIdx.y = group * DCH +
-// chunk; the windows simply start at the chunk's first plane).  scale / bias carry the tensor's exponent (v * 2^e, folded by the
-// host: exact).  Values beyond half's range are clamped and flagged (`overflow`).
+// of one voxel, so here a THREAD is one voxel column of one image row and owns its 8 channels: per plane it reads the 8 values
+// G[c][h][q*w - d - m0] from LDS (the index drops by one per plane), forms the 8 results and stores ONE 16-byte piece to each
+// plane of the pair -- consecutive lanes = consecutive voxels, 1 KB contiguous per store instruction.  (First form: a thread = 4
+// columns x 8 channels with register windows, four pieces per store at a 64-byte lane stride: 0.345 ms; this form: see DESIGN.)
+// A workgroup = one row x one channel group x a CHUNK of the depth range (blockIdx.y = group * DCH + chunk), so that the launch
+// has >= 1024 workgroups.  scale / bias carry the tensor's exponent (v * 2^e, folded by the host: exact).  Values beyond half's
+// range are clamped and flagged (`overflow`).
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 
 template <int Q>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 sheared_expand_split_kernel(const float *__restrict__ g, const float *__restrict__ gcol, const float *__restrict__ planes,
                             const float *__restrict__ scale, const float *__restrict__ bias, _Float16 *__restrict__ yh,
                             _Float16 *__restrict__ yl, int *__restrict__ overflow, int C, int D, int H, int W, int m0, int WG, int off,
-                            int WG2, int off2, int RB, int DCH, int DC, int64_t y_bs, int flags) {
+                            int WG2, int off2, int DCH, int DC, int64_t y_bs, int flags) {
     extern __shared__ float lds[];
-    const int quads = W >> 2;
     const int tid = threadIdx.x;
     const int cg = blockIdx.y / DCH, dch = blockIdx.y - cg * DCH;
     const int64_t n = blockIdx.z;
-    const int h0 = blockIdx.x * RB;
-    const int rows = (H - h0) < RB ? (H - h0) : RB;
+    const int h = blockIdx.x;
     const int d_lo = dch * DC, d_hi = (d_lo + DC) < D ? (d_lo + DC) : D;
     const int LW = (WG + Q - 1) / Q + 4;
-    float *const phase = lds;                            // [8][RB][Q][LW]
-    float *const lastcol = lds + 8 * RB * Q * LW;        // [8][RB][DC]: G' at the last column, per plane of this chunk
-    for (int e = tid; e < 8 * rows * WG; e += blockDim.x) {
-        const int c = e / (rows * WG), e2 = e - c * rows * WG;
-        const int r = e2 / WG, i = e2 - r * WG;
+    float *const phase = lds;                            // [8][Q][LW]: G (interior class) of this row, even / odd elements apart
+    float *const lastcol = lds + 8 * Q * LW;             // [8][DC]: G' at the last column, per plane of this chunk
+    for (int e = tid; e < 8 * WG; e += blockDim.x) {
+        const int c = e / WG, i = e - c * WG;
         const int co = cg * 8 + c;
-        const float v = co < C ? g[(((n * 3 + 1) * C + co) * (int64_t)H + h0 + r) * WG + i] : 0.0f;
-        phase[((c * RB + r) * Q + (i % Q)) * LW + i / Q] = v;
+        phase[(c * Q + (i % Q)) * LW + i / Q] = co < C ? g[(((n * 3 + 1) * C + co) * (int64_t)H + h) * WG + i] : 0.0f;
     }
-    for (int e = tid; e < 8 * rows * DC; e += blockDim.x) {
-        const int c = e / (rows * DC), e2 = e - c * rows * DC;
-        const int r = e2 / DC, dd = e2 - r * DC;
+    for (int e = tid; e < 8 * DC; e += blockDim.x) {
+        const int c = e / DC, dd = e - c * DC;
         const int co = cg * 8 + c, d = d_lo + dd;
         const int i = Q * (W - 1) - d - m0 + off2;
-        lastcol[(c * RB + r) * DC + dd] = (co < C && d < D && i >= 0 && i < WG2)
-            ? gcol[(((n * 3 + 1) * C + co) * (int64_t)H + h0 + r) * WG2 + i] : 0.0f;
+        lastcol[c * DC + dd] = (co < C && d < D && i >= 0 && i < WG2) ? gcol[(((n * 3 + 1) * C + co) * (int64_t)H + h) * WG2 + i] : 0.0f;
     }
     __syncthreads();
-    if (tid >= rows * quads) return;
-    const int r = tid / quads, qd = tid - r * quads, w0 = 4 * qd, h = h0 + r;
-    const bool relu = (flags & SNVC_EPI_RELU) != 0, last = qd == quads - 1;
+    const int w = tid;
+    if (w >= W) return;
+    const bool relu = (flags & SNVC_EPI_RELU) != 0, last = w == W - 1;
     const int64_t plane_sz = (int64_t)H * W;
-    _Float16 *yhp = yh + n * y_bs + (((int64_t)cg * D) * plane_sz + (int64_t)h * W + w0) * 8;
-    _Float16 *ylp = yl + n * y_bs + (((int64_t)cg * D) * plane_sz + (int64_t)h * W + w0) * 8;
-    float sc[8], bi[8];
+    _Float16 *yhp = yh + n * y_bs + (((int64_t)cg * D) * plane_sz + (int64_t)h * W + w) * 8;
+    _Float16 *ylp = yl + n * y_bs + (((int64_t)cg * D) * plane_sz + (int64_t)h * W + w) * 8;
+    float sc[8], bi[8], pl[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int co = cg * 8 + c;
-        sc[c] = (scale && co < C) ? scale[co] : (co < C ? 1.0f : 0.0f);
+        sc[c] = co < C ? (scale ? scale[co] : 1.0f) : 0.0f;
         bi[c] = (scale && co < C) ? bias[co] : 0.0f;
+        pl[c] = (planes && co < C) ? planes[(((n * C + co) * 3 + 1) * (int64_t)H + h) * W + w] : 0.0f;      // interior class
     }
     bool clamped = false;
-    // one plane: out[c][k] (raw G-part of channel c, column w0 + k) + planes class `cls` -> epilogue -> 4 split pieces
-    auto emit = [&](int d, int cls, const float (&raw)[8][4]) {
-        float v[8][4];
+    auto emit = [&](int d, const float (&raw)[8], const float (&pe)[8]) {
+        h8v hi, lo;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const int co = cg * 8 + c;
-            f32x4 pe = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (planes && co < C) pe = *reinterpret_cast<const f32x4 *>(planes + (((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float t = (raw[c][k] + pe[k]) * sc[c] + bi[c];
-                if (relu) t = t > 0.0f ? t : 0.0f;
-                const float tc = __builtin_fminf(__builtin_fmaxf(t, -65504.0f), 65504.0f);
-                clamped = clamped || (tc != t && t == t);
-                v[c][k] = tc;
-            }
+            float t = (raw[c] + pe[c]) * sc[c] + bi[c];
+            if (relu) t = __builtin_fmaxf(t, 0.0f);
+            const float tc = __builtin_fminf(__builtin_fmaxf(t, -65504.0f), 65504.0f);
+            clamped = clamped || (tc != t && t == t);
+            hi[c] = (_Float16)tc;
+            lo[c] = (_Float16)(tc - (float)hi[c]);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            h8v hi, lo;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                hi[c] = (_Float16)v[c][k];
-                lo[c] = (_Float16)(v[c][k] - (float)hi[c]);
-            }
-            *reinterpret_cast<h8v *>(yhp + ((int64_t)d * plane_sz + k) * 8) = hi;
-            *reinterpret_cast<h8v *>(ylp + ((int64_t)d * plane_sz + k) * 8) = lo;
-        }
+        *reinterpret_cast<h8v *>(yhp + (int64_t)d * plane_sz * 8) = hi;
+        *reinterpret_cast<h8v *>(ylp + (int64_t)d * plane_sz * 8) = lo;
     };
-    // the two end planes (depth classes 0 and 2): their own G / G', read straight from L2 by the chunk that holds them
+    // the two end planes (depth classes 0 and 2): their own G / G' and planes, read straight from L2 by the chunk that holds them
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const int d = e ? D - 1 : 0, cls = e ? 2 : 0;
         if (d < d_lo || d >= d_hi) continue;
-        float raw[8][4];
+        float raw[8], pe[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int co = cg * 8 + c;
-            const float *ge = g + (((n * 3 + cls) * C + (co < C ? co : 0)) * (int64_t)H + h) * WG;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = Q * (w0 + k) - d - m0 + off;
-                raw[c][k] = (co < C && i >= 0 && i < WG) ? ge[i] : 0.0f;
-            }
-            if (last) {
-                const int i = Q * (W - 1) - d - m0 + off2;
-                raw[c][3] = (co < C && i >= 0 && i < WG2) ? gcol[(((n * 3 + cls) * C + co) * (int64_t)H + h) * WG2 + i] : 0.0f;
+            const int i = Q * w - d - m0 + off, i2 = Q * (W - 1) - d - m0 + off2;
+            raw[c] = 0.0f;
+            pe[c] = 0.0f;
+            if (co < C) {
+                if (last) raw[c] = (i2 >= 0 && i2 < WG2) ? gcol[(((n * 3 + cls) * C + co) * (int64_t)H + h) * WG2 + i2] : 0.0f;
+                else raw[c] = (i >= 0 && i < WG) ? g[(((n * 3 + cls) * C + co) * (int64_t)H + h) * WG + i] : 0.0f;
+                if (planes) pe[c] = planes[(((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w];
             }
         }
-        emit(d, cls, raw);
+        emit(d, raw, pe);
     }
-    // interior planes of this chunk: chain p = planes dstart + p, dstart + p + Q, ...; a chain's window moves down by one element per step
     const int dstart = d_lo < 1 ? 1 : d_lo, dend = d_hi < D - 1 ? d_hi : D - 1;
-    auto load = [&](int c, int i) -> float {
-        return (i >= 0 && i < WG) ? phase[((c * RB + r) * Q + (i % Q)) * LW + i / Q] : 0.0f;
-    };
-    float win[8][Q][4];
+    for (int d = dstart; d < dend; ++d) {
+        const int i = Q * w - d - m0 + off;                  // drops by one per plane: alternates between the Q phase arrays
+        const bool in = i >= 0 && i < WG;
+        const int ph = in ? (i % Q) * LW + i / Q : 0;
+        float raw[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int p = 0; p < Q; ++p)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) win[c][p][k] = load(c, Q * (w0 + k) - (dstart + p) - m0 + off);
-    for (int d0 = dstart; d0 < dend; d0 += Q) {
-#pragma unroll
-        for (int p = 0; p < Q; ++p) {
-            const int d = d0 + p;
-            if (d >= dend) break;
-            float raw[8][4];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) raw[c][k] = win[c][p][k];
-                if (last) raw[c][3] = lastcol[(c * RB + r) * DC + (d - d_lo)];
-            }
-            emit(d, 1, raw);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                win[c][p][3] = win[c][p][2]; win[c][p][2] = win[c][p][1]; win[c][p][1] = win[c][p][0];
-                win[c][p][0] = load(c, Q * w0 - (d + Q) - m0 + off);
-            }
+        for (int c = 0; c < 8; ++c) {
+            const float v = phase[c * Q * LW + ph];
+            raw[c] = last ? lastcol[c * DC + (d - d_lo)] : (in ? v : 0.0f);
         }
+        emit(d, raw, pl);
     }
     if (clamped && overflow) atomicOr(overflow, 1);
 }
@@ -1122,42 +1084,38 @@ int snvc_sheared_expand_split(const float *g, const float *gcol, const float *pl
                               void *y_lo, int *overflow, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG,
                               int off, int64_t WG2, int off2, int64_t y_batch_stride, int flags, void *stream) {
     using namespace snvc;
-    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || W % 4 != 0 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || WG2 <= 0)
-        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: bad sizes (W % 4 == 0, q in {1,2}, D >= 2)");
+    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || WG2 <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: bad sizes (q in {1,2}, D >= 2)");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: scale and bias must both be given or both be NULL");
     if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: only SNVC_EPI_RELU");
     if (N == 0) return SNVC_OK;
     if (!g || !gcol || !y_hi || !y_lo) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: null pointer");
-    if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo) | reinterpret_cast<uintptr_t>(planes)) & 15)
-        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: y and planes must be 16-byte aligned");
-    const int quads = (int)(W / 4);
+    if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: y must be 16-byte aligned");
     const int64_t G = ceil_div<int64_t>(C, 8);
-    if (quads > 256 || G > 8191 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: row too wide or too many channels");
+    if (W > 512 || G > 4095 || N > 65535 || H >= ((int64_t)1 << 31))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: row too wide (W <= 512) or too many channels");
     const int LW = (int)((WG + q - 1) / q) + 4;
-    int RB = 256 / quads;
-    if (RB > 4) RB = 4;
     // depth chunks: enough workgroups to cover the chip four times over, at least 8 planes each
     int DCH = 1;
-    while (DCH < 8 && ceil_div<int64_t>(H, RB) * G * N * DCH < 4 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
+    while (DCH < 16 && H * G * N * DCH < 4 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
     const int DC = (int)ceil_div<int64_t>(D, DCH);
-    auto lds_of = [&](int rb) { return sizeof(float) * (8 * (size_t)rb * q * LW + 8 * (size_t)rb * DC); };
-    while (RB > 1 && lds_of(RB) > 64 * 1024) --RB;
-    const size_t lds = lds_of(RB);
-    if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: rows do not fit the LDS");
-    const int threads = ceil_div(RB * quads, 64) * 64;
-    const dim3 grid((unsigned)ceil_div<int64_t>(H, RB), (unsigned)(G * DCH), (unsigned)N);
+    const size_t lds = sizeof(float) * (8 * (size_t)q * LW + 8 * (size_t)DC);
+    if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: the row does not fit the LDS");
+    const int threads = ceil_div((int)W, 64) * 64;
+    const dim3 grid((unsigned)H, (unsigned)(G * DCH), (unsigned)N);
     const int64_t y_bs = y_batch_stride ? y_batch_stride : 2 * G * 8 * D * H * W;
     static std::atomic<unsigned> attr1{0}, attr2{0};
     _Float16 *yh = reinterpret_cast<_Float16 *>(y_hi), *yl = reinterpret_cast<_Float16 *>(y_lo);
     if (q == 1) {
         if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_split_kernel<1>), (int)lds, attr1)) return check_launch("snvc_sheared_expand_split");
         sheared_expand_split_kernel<1><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, yh, yl, overflow, (int)C, (int)D, (int)H,
-                                                                              (int)W, m0, (int)WG, off, (int)WG2, off2, RB, DCH, DC, y_bs, flags);
+                                                                              (int)W, m0, (int)WG, off, (int)WG2, off2, DCH, DC, y_bs, flags);
     } else {
         if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_split_kernel<2>), (int)lds, attr2)) return check_launch("snvc_sheared_expand_split");
         sheared_expand_split_kernel<2><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, yh, yl, overflow, (int)C, (int)D, (int)H,
-                                                                              (int)W, m0, (int)WG, off, (int)WG2, off2, RB, DCH, DC, y_bs, flags);
+                                                                              (int)W, m0, (int)WG, off, (int)WG2, off2, DCH, DC, y_bs, flags);
     }
     return check_launch("snvc_sheared_expand_split");
 }

@@ -1124,7 +1124,8 @@ class Conv3dLayerX3:
     (snvc_f16x3_conv3d_*): the fp32 contraction at fp32 accuracy on the half pipe.  The weights are packed as (hi, lo) of
     w * 2**w_exp  with w_exp chosen so that max|w| lands in [2^13, 2^14): both parts then keep their full 11 bits."""
 
-    def __init__(self, weight: torch.Tensor, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1, transposed: bool = False):
+    def __init__(self, weight: torch.Tensor, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1, transposed: bool = False,
+                 algo: int = 0):
         _gpu(weight, "weight")
         if weight.dtype != torch.float32:
             raise RuntimeError("conv3d weights must be float32")
@@ -1134,6 +1135,7 @@ class Conv3dLayerX3:
         else:
             self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
+        self.algo = int(algo)           # _lib.ALGO_X3_SERIAL: kernel-form selector, fixed at packing time
         wmax = float(weight.detach().abs().max().item()) if weight.numel() else 1.0
         self.w_exp = 14 - math.frexp(wmax)[1] if wmax > 0 and math.isfinite(wmax) else 0      # wmax * 2^w_exp in [2^13, 2^14)
         probe = self._desc(1, (16, 16, 32), 0)
@@ -1147,7 +1149,11 @@ class Conv3dLayerX3:
         self._affine = {}
 
     out_spatial = Conv3dLayer.out_spatial
-    _desc = Conv3dLayer._desc
+
+    def _desc(self, *a, **k):
+        d = Conv3dLayer._desc(self, *a, **k)
+        d.algo = self.algo
+        return d
 
     def folded(self, scale, bias, x_exp: int, out_exp: int):
         """(scale', bias') of the epilogue with the exponents folded in: conv sums are in units of 2^(x_exp + w_exp), the

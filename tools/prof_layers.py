@@ -89,6 +89,16 @@ with torch.no_grad():
     elif args.layer == "hg_s2":             # hourglass conv1: k3 / stride 2, 32 -> 64 (slice-pipelined refill)
         v2 = torch.randn(1, bench.C, bench.D, bench.H, bench.W, device=dev)
         fn = lambda: model.hg_conv3d.conv1(v2)  # noqa: E731
+    elif args.layer in ("x3_conv2", "x3_hg2"):      # split-mode (f16x3) layers: conv2 32->32 full size, hg conv2 64->64 half size
+        from snvc_amd import ops
+        cin, shp = (32, (bench.D, bench.H, bench.W)) if args.layer == "x3_conv2" else (64, (bench.D // 2, bench.H // 2, bench.W // 2))
+        xin = torch.relu(torch.randn(1, cin, *shp, device=dev))
+        wt = torch.randn(cin, cin, 3, 3, 3, device=dev) * 0.05
+        lay = ops.Conv3dLayerX3(wt)
+        xs_ = ops.to_split(xin, 4)
+        del xin
+        ys_ = torch.empty_like(xs_)
+        fn = lambda: lay(xs_, 4, flags=ops.EPI_RELU, out=ys_, out_exp=4)  # noqa: E731
     elif args.layer == "general":           # any shift array: warp after convolution (three depth-1 convs + warped_expand)
         fn = lambda: model.forward_pair(left, right, shift, 1, sheared=False)  # noqa: E731
     elif args.layer == "sheared_bwd":       # cfg4's first layer: forward + backward of the sheared function with folded BatchNorm

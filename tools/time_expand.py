@@ -36,6 +36,10 @@ for q_, m0 in ((2, 0), (1, 0)):
     gcol = torch.randn(1, 3 * C, H, wu_col, device=dev)
     ms, _ = bench.timed_ms(lambda: ops.sheared_expand(g, gcol, planes, scale, bias, out, q_, m0, off, off_col, ops.EPI_RELU), args.reps, 5)
     print(f"sheared q={q_}        {ms * 1e3:7.1f} us {nbytes / ms / 1e9:6.2f} TB/s ({nbytes / ms / 1e9 / 8 * 100:4.1f} %)", flush=True)
+    outs = torch.empty(1, 2, C // 8, D, H, W, 8, device=dev, dtype=torch.float16)
+    ms, _ = bench.timed_ms(lambda: ops.sheared_expand_split(g, gcol, planes, scale, bias, outs, q_, m0, off, off_col, ops.EPI_RELU), args.reps, 5)
+    print(f"sheared q={q_} split  {ms * 1e3:7.1f} us {nbytes / ms / 1e9:6.2f} TB/s ({nbytes / ms / 1e9 / 8 * 100:4.1f} %)", flush=True)
+    del outs
 ms, _ = bench.timed_ms(lambda: out.fill_(1.0), args.reps, 5)
 print(f"torch fill_         {ms * 1e3:7.1f} us {nbytes / ms / 1e9:6.2f} TB/s ({nbytes / ms / 1e9 / 8 * 100:4.1f} %)", flush=True)
 for name, s in patterns.items():

@@ -25,6 +25,8 @@ for name, cin, cout, shape in (("conv2 32->32 192x96x312", 32, 32, (192, 96, 312
     ref_layer = ops.Conv3dLayer(w, 3, 1, 1, 1, False)
     x3 = ops.Conv3dLayerX3(w)
     x_exp = 4
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    head = torch.randn(cout, device=dev)
     xs = ops.to_split(x, x_exp)
     y_ref = ref_layer(x, scale, bias, None, ops.EPI_RELU)
     y_x3 = x3(xs, x_exp, scale, bias, flags=ops.EPI_RELU, to_f32=True)
@@ -40,9 +42,26 @@ for name, cin, cout, shape in (("conv2 32->32 192x96x312", 32, 32, (192, 96, 312
     print(f"{name}: max|err| / max|ref| vs float64 on a crop: fp32 Winograd {e(y_ref):.2e}   split -> f32 {e(y_x3):.2e}   split -> split {e(y_rt):.2e}")
     print(f"   whole tensor, split vs fp32 path: {(y_x3 - y_ref).abs().max().item() / y_ref.abs().max().item():.2e}")
     flop = 2.0 * np.prod(shape) * cin * cout * 27
-    for label, fn in (("fp32 Winograd F(4,3)", lambda: ref_layer(x, scale, bias, None, ops.EPI_RELU, y_ref)),
+    from snvc_amd import _lib
+    x3s = ops.Conv3dLayerX3(w, algo=_lib.ALGO_X3_SERIAL)
+    ysr = x3s(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out_exp=4)
+    print(f"   serial form vs resident form: {(ops.from_split(ysr, 4) - y_rt).abs().max().item() / y_rt.abs().max().item():.2e}")
+    extra = []
+    if cout == 32:
+        for bit, nm in ((0x2000, "resident + double buffer"), (0x4000, "4x8x32 tile")):
+            lx = ops.Conv3dLayerX3(w, algo=bit)
+            yx = lx(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out_exp=4)
+            print(f"   {nm} vs default form: {(ops.from_split(yx, 4) - y_rt).abs().max().item() / y_rt.abs().max().item():.2e}")
+            extra.append((nm, (lambda l_: (lambda: l_(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out=ys, out_exp=4, overflow=flag)))(lx)))
+    for label, fn in tuple(extra) + (("serial: split -> split", lambda: x3s(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out=ys, out_exp=4, overflow=flag)),
+                      ("fp32 Winograd F(4,3)", lambda: ref_layer(x, scale, bias, None, ops.EPI_RELU, y_ref)),
                       ("split -> f32 NCDHW", lambda: x3(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out_f32=y_x3)),
                       ("split -> split C8", lambda: x3(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out=ys, out_exp=4)),
+                      ("split -> split C8 + flag", lambda: x3(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out=ys, out_exp=4, overflow=flag)),
+                      ("split -> split + head", (lambda: x3(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out=ys, out_exp=4, head=head, overflow=flag))
+                       if cout == 32 else None),
                       ("to_split (layout pass)", lambda: ops.to_split(x, x_exp, xs))):
+        if fn is None:
+            continue
         ms, _ = bench.timed_ms(fn, args.reps, 3)
         print(f"   {label:24s} {ms:7.3f} ms   {flop / ms / 1e9:7.1f} TFLOP/s algorithmic", flush=True)
