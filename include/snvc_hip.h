@@ -201,7 +201,11 @@ enum {
     /* snvc_f16x3_* stride-1 layers only: the image's hi / lo planes taken one after the other (double-buffered 19.6 KB image)
      * instead of side by side (single-buffered 39 KB image); same values, kept selectable for A/B timing.  Pack and forward
      * must agree on it. */
-    SNVC_ALGO_X3_SERIAL = 0x1000
+    SNVC_ALGO_X3_SERIAL = 0x1000,
+    /* snvc_f16x3_* stride-1 layers: one 32-channel block per workgroup even for Cout = 64 (NARROW), and additionally 2x4x32
+     * tiles (SMALL) -- more, smaller workgroups for layers that would not fill the chip otherwise.  Pack and forward must agree. */
+    SNVC_ALGO_X3_NARROW = 0x2000,
+    SNVC_ALGO_X3_SMALL = 0x4000
 };
 
 typedef struct {

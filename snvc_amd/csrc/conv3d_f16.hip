@@ -543,15 +543,18 @@ using F16K3X  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, false, 3, 1, 2>;
 using F16K3X2 = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 1, 1, false, 2, 1, 2>;
 // experiment (desc.algo & SNVC_ALGO_X3_SERIAL): planes taken serially, the 19.6 KB image double-buffered
 using F16K3XS  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, true, 3, 1, 3>;
-using F16K3XD  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, true, 2, 1, 2>;      // experiment 0x2000: resident planes, double-buffered, 2 WG/CU
-using F16K3XB  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 8, 1, 1, false, 2, 1, 2>;     // experiment 0x4000: 4x8x32 tile (NB = 8), 2 WG/CU
+// (measured and not kept, conv2 at cfg2: resident planes double-buffered at 2 WG/CU 1.03 ms, a 4x8x32 tile 0.94 ms, the serial
+// form above 0.91-1.07 ms, against 0.89-0.92 ms for the single-buffered 4x4x32 tile at 3 WG/CU)
+// small layers (SNVC_ALGO_X3_SMALL, chosen by the caller when a launch would not fill the chip): 2x4x32 tiles, one 32-channel
+// block per workgroup -- four times the workgroups of F16K3X2 (the hourglass's 48x24x78 level: 216 -> 864)
+using F16K3XT  = F16Cfg<3, 3, 3, 1, 1, 1, 2, 4, 1, 1, false, 4, 1, 2>;
 using F16K3X2S = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 1, 1, true, 2, 1, 3>;
 // stride 2: the image of a 2x4x32 tile is 5 x 9 x 65 pieces (46.8 KB per plane): the planes are taken serially (PL = 3)
 using F16K3S2X = F16Cfg<3, 3, 3, 2, 1, 2, 2, 4, 1, 1, false, 2, 1, 3>;
 // one parity class of ConvTranspose3d(k3,s2,p1,op1): 2x2x2 box taps, both planes resident, double-buffered
-using F16DCX  = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 1, 1, true, 2, 1, 2>;
+using F16DCX  = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 1, false, 2, 1, 2>;      // (KCG = 1, double-buffered: 0.255 ms on hg conv5; 8 k-steps per barrier pair now)
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XD, FK3XB, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES;
@@ -590,8 +593,8 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                 p = plan_from<F16K3S2X>(FK3S2X);
             } else {
                 if (d.Cout % 32 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: Cout % 32 == 0");
-                if ((d.algo & 0x2000) && d.Cout == 32) p = plan_from<F16K3XD>(FK3XD);
-                else if ((d.algo & 0x4000) && d.Cout == 32) p = plan_from<F16K3XB>(FK3XB);
+                if (d.algo & SNVC_ALGO_X3_SMALL) p = plan_from<F16K3XT>(FK3XT);
+                else if (d.algo & SNVC_ALGO_X3_NARROW) p = plan_from<F16K3X>(FK3X);
                 else if (d.algo & SNVC_ALGO_X3_SERIAL) p = d.Cout == 32 ? plan_from<F16K3XS>(FK3XS) : plan_from<F16K3X2S>(FK3X2S);
                 else p = d.Cout == 32 ? plan_from<F16K3X>(FK3X) : plan_from<F16K3X2>(FK3X2);
             }
@@ -820,7 +823,7 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: RELU / ADD_PRE / ADD_POST only");
     if ((head != nullptr) != (y_head != nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: head and y_head go together");
-    if (head && ((p.kind != FK3X && p.kind != FK3XS) || to_f32))
+    if (head && ((p.kind != FK3X && p.kind != FK3XS && p.kind != FK3XT) || d->Cout != 32 || to_f32))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the side head is built for 32-channel stride-1 layers with a split output");
     const int64_t in_sp = (int64_t)d->Din * d->Hin * d->Win, out_sp = (int64_t)d->Dout * d->Hout * d->Wout;
     if ((int64_t)(d->Cin / 8 + 2) * in_sp >= ((int64_t)1 << 31) || out_sp >= ((int64_t)1 << 31))
@@ -879,8 +882,11 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
             else launch_f16<F16K3XS, 0>(a, grid, st);
             break;
         case FK3X2S: if (to_f32) launch_f16<F16K3X2S, 2>(a, grid, st); else launch_f16<F16K3X2S, 0>(a, grid, st); break;
-        case FK3XD: launch_f16<F16K3XD, 0>(a, grid, st); break;
-        case FK3XB: launch_f16<F16K3XB, 0>(a, grid, st); break;
+        case FK3XT:
+            if (to_f32) launch_f16<F16K3XT, 2>(a, grid, st);
+            else if (head) launch_f16<F16K3XT, 3>(a, grid, st);
+            else launch_f16<F16K3XT, 0>(a, grid, st);
+            break;
         case FK3S2X: if (to_f32) launch_f16<F16K3S2X, 2>(a, grid, st); else launch_f16<F16K3S2X, 0>(a, grid, st); break;
         case FDCX: if (to_f32) launch_f16<F16DCX, 2>(a, grid, st); else launch_f16<F16DCX, 0>(a, grid, st); break;
         default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: no kernel");

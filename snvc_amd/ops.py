@@ -1122,10 +1122,13 @@ def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) ->
 class Conv3dLayerX3:
     """nn.Conv3d(k3, p1, stride 1 | 2) / nn.ConvTranspose3d(k3, s2, p1, op1) prepared for the split-mode kernels
     (snvc_f16x3_conv3d_*): the fp32 contraction at fp32 accuracy on the half pipe.  The weights are packed as (hi, lo) of
-    w * 2**w_exp  with w_exp chosen so that max|w| lands in [2^13, 2^14): both parts then keep their full 11 bits."""
+    w * 2**w_exp  with w_exp chosen so that max|w| lands in [2^13, 2^14): both parts then keep their full 11 bits.
+    Stride-1 layers have three kernel forms (64-channel blocks on 4x4x32 tiles; 32-channel blocks; 32-channel blocks on 2x4x32
+    tiles) whose packed weights differ: the form is picked per call from the number of workgroups the launch would have
+    (``algo`` forces one), its weights packed on first use."""
 
     def __init__(self, weight: torch.Tensor, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1, transposed: bool = False,
-                 algo: int = 0):
+                 algo: Optional[int] = None):
         _gpu(weight, "weight")
         if weight.dtype != torch.float32:
             raise RuntimeError("conv3d weights must be float32")
@@ -1135,18 +1138,40 @@ class Conv3dLayerX3:
         else:
             self.cout, self.cin = weight.shape[0], weight.shape[1]
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
-        self.algo = int(algo)           # _lib.ALGO_X3_SERIAL: kernel-form selector, fixed at packing time
-        wmax = float(weight.detach().abs().max().item()) if weight.numel() else 1.0
+        self.forced_algo = algo         # None: chosen per call
+        self.algo = int(algo or 0)
+        self.weight = weight.detach().contiguous()
+        wmax = float(self.weight.abs().max().item()) if weight.numel() else 1.0
         self.w_exp = 14 - math.frexp(wmax)[1] if wmax > 0 and math.isfinite(wmax) else 0      # wmax * 2^w_exp in [2^13, 2^14)
-        probe = self._desc(1, (16, 16, 32), 0)
-        nbytes = _lib.lib().snvc_f16x3_conv3d_packed_weight_bytes(ctypes.byref(probe))
-        if nbytes < 0:
-            check(2, "snvc_f16x3_conv3d_packed_weight_bytes")
-        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-        with torch.cuda.device(weight.device):
-            check(_lib.lib().snvc_f16x3_conv3d_pack_weights(ctypes.byref(probe), _ptr(weight.detach().contiguous()), _ptr(self.packed),
-                                                            float(2.0 ** self.w_exp), _stream(weight)), "snvc_f16x3_conv3d_pack_weights")
+        self._packed = {}
+        self.packed = self._pack(self.algo)
         self._affine = {}
+
+    def _pack(self, algo: int):
+        hit = self._packed.get(algo)
+        if hit is None:
+            self.algo = algo
+            probe = self._desc(1, (16, 16, 32), 0)
+            nbytes = _lib.lib().snvc_f16x3_conv3d_packed_weight_bytes(ctypes.byref(probe))
+            if nbytes < 0:
+                check(2, "snvc_f16x3_conv3d_packed_weight_bytes")
+            hit = torch.empty(nbytes, dtype=torch.uint8, device=self.weight.device)
+            with torch.cuda.device(self.weight.device):
+                check(_lib.lib().snvc_f16x3_conv3d_pack_weights(ctypes.byref(probe), _ptr(self.weight), _ptr(hit), float(2.0 ** self.w_exp),
+                                                                _stream(self.weight)), "snvc_f16x3_conv3d_pack_weights")
+            self._packed[algo] = hit
+        return hit
+
+    def _pick_form(self, n: int, out_sp):
+        """Kernel form of a stride-1 layer for this launch: enough workgroups to cover the 256 CUs about four times."""
+        if self.forced_algo is not None or self.stride != 1 or self.transposed:
+            return self.algo
+        tiles = n * -(-out_sp[0] // 4) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32)
+        if self.cout % 64 == 0 and tiles * (self.cout // 64) >= 1024:
+            return 0
+        if tiles * (self.cout // 32) >= 1024 or self.cout == 32 and tiles >= 512:
+            return _lib.ALGO_X3_NARROW if self.cout != 32 else 0
+        return _lib.ALGO_X3_SMALL
 
     out_spatial = Conv3dLayer.out_spatial
 
@@ -1162,7 +1187,7 @@ class Conv3dLayerX3:
                x_exp, out_exp)
         hit = self._affine.get(key)
         if hit is None:
-            dev = self.packed.device
+            dev = self.weight.device
             sc = (scale.detach().float() if scale is not None else torch.ones(self.cout, device=dev)) * (2.0 ** (out_exp - x_exp - self.w_exp))
             bi = (bias.detach().float() if bias is not None else torch.zeros(self.cout, device=dev)) * (2.0 ** out_exp)
             if len(self._affine) > 8:
@@ -1205,13 +1230,15 @@ class Conv3dLayerX3:
             y_head = torch.empty((n, 1) + out_sp, dtype=torch.float32, device=x.device)
         # with a float32 result the epilogue works in units of 2^out_exp too (the residual's) and scales back on the way out: exact
         sc, bi = self.folded(scale, bias, x_exp, out_exp)
+        self.algo = self._pick_form(n, out_sp)
+        packed = self._pack(self.algo)
         if n == 0:
             return out_f32 if f32 else ((out, y_head) if head is not None else out)
         d = self._desc(n, in_sp, flags, _batch_stride(x), _batch_stride(out_f32 if f32 else out),
                        _batch_stride(residual) if residual is not None else 0)
         null = ctypes.c_void_p(0)
         with torch.cuda.device(x.device):
-            check(_lib.lib().snvc_f16x3_conv3d_forward(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(self.packed), _ptr(sc), _ptr(bi),
+            check(_lib.lib().snvc_f16x3_conv3d_forward(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(packed), _ptr(sc), _ptr(bi),
                                                        _ptr(residual), _lo_ptr(residual) if residual is not None else null,
                                                        null if f32 else _ptr(out), null if f32 else _lo_ptr(out),
                                                        _ptr(out_f32) if f32 else null, _ptr(head), _ptr(y_head), float(2.0 ** -out_exp),

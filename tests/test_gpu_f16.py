@@ -366,6 +366,14 @@ def test_split_mode_layers_vs_float64(case):
     w = torch.randn((cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3), device=dev()) * np.sqrt(2.0 / (cin * 27))
     scale, bias = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.3
     layer = ops.Conv3dLayerX3(w, 3, stride, 1, 1, transposed)
+    if stride == 1 and not transposed:      # every kernel form of a stride-1 layer gives the same values (same MFMA order per output)
+        from snvc_amd import _lib
+        xs0 = ops.to_split(x, 2)
+        forms = [ops.Conv3dLayerX3(w, algo=a)(xs0, 2, scale, bias, flags=ops.EPI_RELU, to_f32=True)
+                 for a in (0, _lib.ALGO_X3_NARROW, _lib.ALGO_X3_SMALL, _lib.ALGO_X3_SERIAL)]
+        ref0 = _x3_reference(x, w, scale, bias, 1, False, True)
+        for k, f in enumerate(forms):
+            check(f.cpu().numpy(), ref0.numpy(), TIGHT, f"{case}: kernel form {k}")
     for x_exp, out_exp in ((0, 0), (5, 3)):
         xs = ops.to_split(x, x_exp)
         assert torch.allclose(ops.from_split(xs, x_exp), x, rtol=0, atol=2e-6 * x.abs().max().item())       # 22 bits
