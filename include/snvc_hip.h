@@ -339,6 +339,11 @@ SNVC_API int snvc_conv3d_forward_stats(const snvc_conv3d_desc *desc_host, const 
 SNVC_API int snvc_warped_expand(const float *p, const float *q, const float *e, const float *planes, const float *shift,
                                 const float *scale, const float *bias, float *y, int64_t N, int64_t C, int64_t D, int64_t H,
                                 int64_t W, int flags, void *stream);
+/* snvc_warped_expand with the result written as a split C8 pair (y_hi, y_lo), like snvc_sheared_expand_split. */
+SNVC_API int snvc_warped_expand_split(const float *p, const float *q, const float *e, const float *planes, const float *shift,
+                                      const float *scale, const float *bias, void *y_hi, void *y_lo, int *overflow,
+                                      int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int64_t y_batch_stride, int flags,
+                                      void *stream);
 /* Structure of a float32 shift array [N][D] in one launch: out4 = { all >= 0, every row == shift[0][0] + d (q = 1),
  * every row == shift[0][0] + d/2 (q = 2), shift[0][0] } (flags as 1.0 / 0.0, exact fp32 comparisons).  The caller reads the four
  * floats back: the same single device -> host sync as the reference wrapper's `assert torch.all(shift >= 0)`

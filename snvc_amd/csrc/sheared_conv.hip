@@ -1018,6 +1018,157 @@ sheared_expand_split_kernel(const float *__restrict__ g, const float *__restrict
     if (clamped && overflow) atomicOr(overflow, 1);
 }
 
+// warped_expand_win_kernel with the result written as a split C8 pair (see sheared_expand_split_kernel): a thread = one voxel
+// column of one image row, 8 channels; a workgroup = one row x one channel group x a chunk of the depth range.  Per plane and kd
+// the thread needs F_kd[c][w - m - 1] and G_kd[c][w - m] of its 8 channels: 16 LDS reads, kept in registers while m stands (every
+// other plane on half-pixel steps).  Same plane parameters (ptab), same whole-pixel remap, same last-column table as the fp32 form.
+__global__ void __launch_bounds__(512)
+warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
+                           const float *__restrict__ planes, const float *__restrict__ shift, const float *__restrict__ scale,
+                           const float *__restrict__ bias, _Float16 *__restrict__ yh, _Float16 *__restrict__ yl, int *__restrict__ overflow,
+                           int C, int D, int H, int W, int DCH, int DC, int64_t y_bs, int flags) {
+    extern __shared__ float lds[];
+    constexpr int FP = 12;
+    constexpr int kInvalid = (int)0x80000001, kNone = (int)0x80000000;
+    const int LW = W + 16;
+    const int tid = threadIdx.x;
+    const int cg = blockIdx.y / DCH, dch = blockIdx.y - cg * DCH;
+    const int64_t n = blockIdx.z;
+    const int h = blockIdx.x;
+    const int d_lo = dch * DC, d_hi = (d_lo + DC) < D ? (d_lo + DC) : D;
+    const int64_t hw = (int64_t)H * W;
+    float *const rowsF = lds;                            // [3 kd][8][LW]
+    float *const rowsG = lds + 24 * LW;
+    float *const tas = rowsG + 24 * LW;                  // [8][DC]
+    f32x4 *const ptab = reinterpret_cast<f32x4 *>(tas + 8 * DC + ((4 - ((8 * DC) & 3)) & 3));       // [D + 2]
+    const float *sh = shift + n * D;
+    for (int i = tid; i < D + 2; i += blockDim.x) {
+        f32x4 t = {__builtin_bit_cast(float, kInvalid), 0.0f, 0.0f, 0.0f};
+        if (i < D) {
+            const float s = sh[i];
+            if (s <= (float)W) {
+                const float mf = __builtin_floorf(s);
+                float ff = s - mf;
+                int mm = (int)mf;
+                if (ff == 0.0f) { mm -= 1; ff = 1.0f; }      // whole pixel: F[w - m], nothing gated
+                t = f32x4{__builtin_bit_cast(float, mm), ff, 1.0f - ff, 0.0f};
+            }
+        }
+        ptab[i] = t;
+    }
+    for (int i = tid; i < 24 * (LW >> 2); i += blockDim.x) {
+        const int row = i / (LW >> 2), pc = i - row * (LW >> 2);      // row = kd * 8 + c
+        const int kd = row >> 3, c = row & 7, co = cg * 8 + c, col = 4 * pc - FP;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 g4 = v;
+        if (co < C) {
+            if (col >= 0 && col < W) v = *reinterpret_cast<const f32x4 *>(p + (((n * 3 + kd) * C + co) * (int64_t)H + h) * W + col);
+            g4 = v;
+            const float *er = e + (((n * 3 + kd) * 3) * C + co) * (int64_t)H * 4 + (int64_t)h * 4;
+            const int64_t kws = (int64_t)C * H * 4;
+            if (col == -4) { v[3] = er[2 * kws]; g4[3] = 0.0f; }              // column -1: F = E2, G = 0
+            if (col == 0) { g4[0] = v[0] - er[kws]; g4[1] = v[1] - er[0]; }   // columns 0, 1 of G: the gated sample's share removed
+        }
+        *reinterpret_cast<f32x4 *>(rowsF + row * LW + 4 * pc) = v;
+        *reinterpret_cast<f32x4 *>(rowsG + row * LW + 4 * pc) = g4;
+    }
+    __syncthreads();
+    for (int i = tid; i < 8 * DC; i += blockDim.x) {
+        const int c = i / DC, dd = i - c * DC, d = d_lo + dd, co = cg * 8 + c;
+        float t = 0.0f;
+        if (co < C && d < D) {
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const int ee = d + kd - 1;
+                const f32x4 pt = ptab[ee < 0 ? D : ee];
+                const int mm = __builtin_bit_cast(int, pt[0]);
+                if (mm == kInvalid) continue;
+                const int i0 = W - mm - 1;
+                const float *qr = q + (((n * 3 + kd) * C + co) * (int64_t)H + h) * W;
+                const float a0 = (unsigned)i0 < (unsigned)W ? qr[i0] : 0.0f;
+                float a1 = (unsigned)(i0 + 1) < (unsigned)W ? qr[i0 + 1] : 0.0f;
+                if (i0 + 1 == 0) a1 = 0.0f;
+                t += pt[1] * a0 + pt[2] * a1;
+            }
+        }
+        tas[c * DC + dd] = t;
+    }
+    __syncthreads();
+    const int w = tid;
+    if (w >= W) return;
+    const bool last = w == W - 1, relu = (flags & SNVC_EPI_RELU) != 0;
+    float sc[8], bi[8], pl[3][8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int co = cg * 8 + c;
+        sc[c] = co < C ? (scale ? scale[co] : 1.0f) : 0.0f;
+        bi[c] = (scale && co < C) ? bias[co] : 0.0f;
+#pragma unroll
+        for (int cls = 0; cls < 3; ++cls)
+            pl[cls][c] = (planes && co < C) ? planes[(((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w] : 0.0f;
+    }
+    _Float16 *yhp = yh + n * y_bs + (((int64_t)cg * D) * hw + (int64_t)h * W + w) * 8;
+    _Float16 *ylp = yl + n * y_bs + (((int64_t)cg * D) * hw + (int64_t)h * W + w) * 8;
+    auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni_f = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+    int pm[3];
+    float pf[3], pg[3];
+    auto take = [&](const f32x4 &t, int &m, float &f, float &g) {
+        m = uni_i(__builtin_bit_cast(int, t[0])); f = uni_f(t[1]); g = uni_f(t[2]);
+    };
+    take(ptab[d_lo - 1 < 0 ? D : d_lo - 1], pm[0], pf[0], pg[0]);
+    take(ptab[d_lo], pm[1], pf[1], pg[1]);
+    take(ptab[d_lo + 1], pm[2], pf[2], pg[2]);            // ptab has D + 2 entries, the last two invalid
+    f32x4 nxt = ptab[d_lo + 2 < D + 2 ? d_lo + 2 : D + 1];
+    float wf[3][8], wg[3][8];
+    int mw[3] = {kNone, kNone, kNone};
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) wf[kd][c] = wg[kd][c] = 0.0f;
+    float vmax = 0.0f;
+    const float lo_bound = relu ? 0.0f : -65504.0f;
+    for (int d = d_lo; d < d_hi; ++d) {
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            if (pm[kd] != mw[kd] && pm[kd] != kInvalid) {      // wave-uniform: the window of this kd moves
+                int idx = FP + w - pm[kd] - 1;                   // column w - m - 1 of the staged rows; left of the pad: zeros
+                const int fi = idx < 0 ? 0 : idx, gi = idx + 1 < 0 ? 0 : idx + 1;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    wf[kd][c] = rowsF[(kd * 8 + c) * LW + fi];
+                    wg[kd][c] = rowsG[(kd * 8 + c) * LW + gi];
+                }
+                mw[kd] = pm[kd];
+            }
+        }
+        int nm;
+        float nff, ngg;
+        take(nxt, nm, nff, ngg);
+        nxt = ptab[d + 3 < D + 2 ? d + 3 : D + 1];
+        const int cls = d == 0 ? 0 : (d == D - 1 ? 2 : 1);
+        h8v hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float o = cls == 0 ? pl[0][c] : (cls == 2 ? pl[2][c] : pl[1][c]);
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) o = __builtin_fmaf(pg[kd], wg[kd][c], __builtin_fmaf(pf[kd], wf[kd][c], o));
+            if (last) o -= tas[c * DC + (d - d_lo)];
+            float t = __builtin_fmaf(o, sc[c], bi[c]);
+            vmax = __builtin_fmaxf(vmax, __builtin_fabsf(t));
+            t = __builtin_amdgcn_fmed3f(t, lo_bound, 65504.0f);      // ReLU and the clamp to half's range in one
+            hi[c] = (_Float16)t;
+            lo[c] = (_Float16)(t - (float)hi[c]);
+        }
+        *reinterpret_cast<h8v *>(yhp + (int64_t)d * hw * 8) = hi;
+        *reinterpret_cast<h8v *>(ylp + (int64_t)d * hw * 8) = lo;
+        pm[0] = pm[1]; pf[0] = pf[1]; pg[0] = pg[1];
+        pm[1] = pm[2]; pf[1] = pf[2]; pg[1] = pg[2];
+        pm[2] = nm; pf[2] = nff; pg[2] = ngg;
+    }
+    if (vmax >= 65504.0f && overflow) atomicOr(overflow, 1);
+}
+
 }  // namespace
 }  // namespace snvc
 
@@ -1234,6 +1385,38 @@ int snvc_warped_expand(const float *p, const float *q, const float *e, const flo
     warped_expand_win_kernel<<<dim3((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N), threads, lds, as_stream(stream)>>>(
         p, q, e, planes, shift, scale, bias, y, (int)C, (int)D, (int)H, (int)W, RB, flags);
     return check_launch("snvc_warped_expand");
+}
+
+int snvc_warped_expand_split(const float *p, const float *q, const float *e, const float *planes, const float *shift, const float *scale,
+                             const float *bias, void *y_hi, void *y_lo, int *overflow, int64_t N, int64_t C, int64_t D, int64_t H,
+                             int64_t W, int64_t y_batch_stride, int flags, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || D < 1 || H <= 0 || W <= 0 || W % 4 != 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_split: bad sizes (W % 4 == 0)");
+    if ((scale == nullptr) != (bias == nullptr))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_split: scale and bias must both be given or both be NULL");
+    if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_split: only SNVC_EPI_RELU");
+    if (N == 0) return SNVC_OK;
+    if (!p || !q || !e || !shift || !y_hi || !y_lo) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_split: null pointer");
+    if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo) | reinterpret_cast<uintptr_t>(p)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_split: p and y must be 16-byte aligned");
+    const int64_t G = ceil_div<int64_t>(C, 8);
+    if (W > 512 || G > 4095 || N > 65535 || H >= ((int64_t)1 << 31))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_split: row too wide (W <= 512) or too many channels");
+    int DCH = 1;
+    while (DCH < 16 && H * G * N * DCH < 4 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
+    const int DC = (int)ceil_div<int64_t>(D, DCH);
+    const size_t lds = sizeof(float) * (2 * 24 * (size_t)(W + 16) + 8 * (size_t)DC + 4 + 4 * (size_t)(D + 2));
+    if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_split: the row does not fit the LDS");
+    const int threads = ceil_div((int)W, 64) * 64;
+    const dim3 grid((unsigned)H, (unsigned)(G * DCH), (unsigned)N);
+    const int64_t y_bs = y_batch_stride ? y_batch_stride : 2 * G * 8 * D * H * W;
+    static std::atomic<unsigned> attr{0};
+    if (!allow_large_lds(reinterpret_cast<const void *>(&warped_expand_split_kernel), (int)lds, attr)) return check_launch("snvc_warped_expand_split");
+    warped_expand_split_kernel<<<grid, threads, lds, as_stream(stream)>>>(p, q, e, planes, shift, scale, bias, reinterpret_cast<_Float16 *>(y_hi),
+                                                                          reinterpret_cast<_Float16 *>(y_lo), overflow, (int)C, (int)D, (int)H,
+                                                                          (int)W, DCH, DC, y_bs, flags);
+    return check_launch("snvc_warped_expand_split");
 }
 
 int snvc_shift_structure(const float *shift, float *out4, int64_t N, int64_t D, void *stream) {

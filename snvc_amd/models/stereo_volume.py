@@ -135,6 +135,15 @@ class GlobalStack(nn.Module):
         self.__dict__["_snvc_x3"] = st
         return st
 
+    @staticmethod
+    def _x3_v1_affine(st, scale, bias):
+        """The first layer's folded BatchNorm with the exponent of the split first-layer tensor folded in (exact: a power of two)."""
+        e1 = st["exp"]["v1"]
+        if st.get("v1_affine_key") != (scale.data_ptr(), bias.data_ptr(), e1):
+            st["v1_affine"] = ((scale * 2.0 ** e1).contiguous(), (bias * 2.0 ** e1).contiguous())
+            st["v1_affine_key"] = (scale.data_ptr(), bias.data_ptr(), e1)
+        return st["v1_affine"]
+
     def _x3_select(self, device, arithmetic=None):
         """The split-mode state if this call runs in split mode, else None."""
         mode = arithmetic or self.arithmetic
@@ -429,13 +438,9 @@ class GlobalStack(nn.Module):
             st = self._x3_select(left.device, arithmetic)
             if st is not None and c % 8 == 0:
                 # split mode: the expand pass writes the (hi, lo) pair conv2 reads (same bytes as the fp32 tensor, no layout pass)
-                e1 = st["exp"]["v1"]
-                if st.get("v1_affine_key") != (scale.data_ptr(), bias.data_ptr(), e1):
-                    st["v1_affine"] = ((scale * 2.0 ** e1).contiguous(), (bias * 2.0 ** e1).contiguous())
-                    st["v1_affine_key"] = (scale.data_ptr(), bias.data_ptr(), e1)
                 v1s = self._buffer("v1s", (shape[0], 2, c // 8) + tuple(shape[2:]) + (8,), left.device, torch.float16)
                 try:
-                    ops.sheared_expand_split(g, gcol, planes, st["v1_affine"][0], st["v1_affine"][1], v1s, q, m0, off, off_col,
+                    ops.sheared_expand_split(g, gcol, planes, *self._x3_v1_affine(st, scale, bias), v1s, q, m0, off, off_col,
                                              ops.EPI_RELU, st["flag"])
                 except ops.Unsupported:
                     st = None
@@ -463,6 +468,18 @@ class GlobalStack(nn.Module):
             e_ = lay_e(right[:, :, :, :4].contiguous().unsqueeze(2)).squeeze(2)
             mark("volume", 1)
             mark("conv1", 0)
+            st = self._x3_select(left.device, arithmetic)
+            if st is not None and c % 8 == 0:       # split mode: the expand pass writes the (hi, lo) pair conv2 reads
+                v1s = self._buffer("v1s", (shape[0], 2, c // 8) + tuple(shape[2:]) + (8,), left.device, torch.float16)
+                try:
+                    ops.warped_expand_split(p_, q_, e_, planes, shift, *self._x3_v1_affine(st, scale, bias), v1s, ops.EPI_RELU, st["flag"])
+                except ops.Unsupported:
+                    pass
+                else:
+                    mark("conv1", 1)
+                    _ROUTES["commuted_first_conv"] += 1
+                    self.__dict__["_snvc_last_v1"] = "v1s"
+                    return self._tail_x3(st, v1s, timing)
             v = self._buffer("v1", shape, left.device)
             try:
                 ops.warped_expand(p_, q_, e_, planes, shift, scale, bias, v, ops.EPI_RELU)

@@ -435,6 +435,30 @@ def warped_expand(p, q, e, planes, shift, scale, bias, out, flags: int = 0):
     return out
 
 
+def warped_expand_split(p, q, e, planes, shift, scale, bias, out, flags: int = 0, overflow=None):
+    """``warped_expand`` with the result written as a split C8 pair (snvc_warped_expand_split): ``out`` = float16
+    [N, 2, C/8, D, H, W, 8] holding the layer's result times the power of two the caller folded into scale / bias."""
+    _gpu(p, "p"); _gpu(q, "q"); _gpu(e, "e")
+    _split_check(out, "out")
+    n, _, grp, d, h, w, _ = out.shape
+    c = p.size(1) // 3
+    for t, shp in ((p, (n, 3 * c, h, w)), (q, (n, 3 * c, h, w)), (e, (n, 9 * c, h, 4))):
+        if t.dtype != torch.float32 or tuple(t.shape) != shp or not t.is_contiguous():
+            raise RuntimeError("warped_expand_split needs contiguous float32 p / q [N,3C,H,W] and e [N,9C,H,4]")
+    if (c + 7) // 8 != grp:
+        raise RuntimeError("warped_expand_split: out has the wrong number of channel groups")
+    if shift.dtype != torch.float32 or tuple(shift.shape) != (n, d):
+        raise RuntimeError("warped_expand_split needs a float32 shift [N,D]")
+    if planes is not None and (tuple(planes.shape) != (n, c, 3, h, w) or not planes.is_contiguous()):
+        raise RuntimeError("planes must be a contiguous [N,C,3,H,W] tensor")
+    shift = shift.contiguous()
+    with torch.cuda.device(out.device):
+        check(_lib.lib().snvc_warped_expand_split(_ptr(p), _ptr(q), _ptr(e), _ptr(planes), _ptr(shift), _ptr(scale), _ptr(bias), _ptr(out),
+                                                  _lo_ptr(out), _ptr(overflow), n, c, d, h, w, _batch_stride(out), int(flags), _stream(out)),
+              "snvc_warped_expand_split")
+    return out
+
+
 def shift_structure(shift):
     """(all shifts >= 0, rows == s0 + d, rows == s0 + d/2, s0) of a float32 [N, D] shift array: one launch and one 16-byte
     device -> host copy (snvc_shift_structure)."""
