@@ -21,7 +21,12 @@ KERNEL = {  # layer -> substring of the kernel whose LAST dispatch is reported
     "conv2_side": "conv3d_wino_dma_kernel", "hg_s2": "conv3d_winos2_pipe_kernel", "sheared": "sheared_expand_kernel",
     "gather_cfg3": "voxel_gather_fwd_lds", "f16_k7_32": "conv3d_f16_kernel",
     "general": "warped_expand_kernel", "sheared_bwd": "sheared_bwd_kernel",
+    # r4: split-mode (f16x3) layers and the split-output expand passes; the fp32 any-shift expand in its register-window form
+    "x3_conv2": "conv3d_f16_kernel", "x3_hg2": "conv3d_f16_kernel", "sheared_split": "sheared_expand_split_kernel",
+    "general_split": "warped_expand_split_kernel", "general_f32": "warped_expand_win_kernel",
 }
+if ROUND >= "r4":
+    KERNEL = {k: v for k, v in KERNEL.items() if k in ("x3_conv2", "x3_hg2", "sheared_split", "general_split", "general_f32", "conv2_side")}
 ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     "conv1_factored": 1472200704, "cost_volume": 1479869184, "cost_volume_right": 739934976, "cost_volume_bwd": 1479869184 + 2 * 3833856,
     "gather_proj": 2 * (786432 * 272 + 2 * 32 * 4096 * 4), "gather_uniform": 2 * (786432 * 272 + 2 * 32 * 4096 * 4),
@@ -33,6 +38,10 @@ ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     "gather_cfg3": 8 * (884736 * 272 + 2 * 32 * 4096 * 4), "f16_k7_32": 2 * 786432 * 2 * (64 + 32),
     # the warp-after-convolution expand writes one 32-channel volume; the sheared layer's fused backward reads one (gy)
     "general": 735902208, "sheared_bwd": 735902208,
+    # r4: a split pair is two half planes = the fp32 tensor's bytes; conv2 reads one 32-channel pair, writes one and the 1-channel
+    # fp32 projection; hg conv2 reads and writes a 64-channel pair at half resolution
+    "x3_conv2": 2 * 735902208 + 22996944, "x3_hg2": 2 * 183975552, "sheared_split": 735902208, "general_split": 735902208,
+    "general_f32": 735902208,
 }
 F32_MFMA_LAYERS = ("conv1_factored", "conv2_side", "hg_s2")
 

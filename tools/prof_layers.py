@@ -19,6 +19,7 @@ import bench  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("layer")
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--arithmetic", default=None, help="GlobalStack.arithmetic for the layers that run forward_pair: fp32 | x3")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 
@@ -28,6 +29,8 @@ from snvc_amd.models.stereo_volume import GlobalStack  # noqa: E402
 model = GlobalStack(bench.C)
 model.load_state_dict(bench.seeded_state(model))
 model.eval().to(dev)
+if args.arithmetic:
+    model.arithmetic = args.arithmetic
 left, right, shift = bench.make_inputs(0, dev)
 with torch.no_grad():
     if args.layer in ("gather", "trunk", "trunk_f16"):
@@ -98,7 +101,12 @@ with torch.no_grad():
         xs_ = ops.to_split(xin, 4)
         del xin
         ys_ = torch.empty_like(xs_)
-        fn = lambda: lay(xs_, 4, flags=ops.EPI_RELU, out=ys_, out_exp=4)  # noqa: E731
+        flag_ = torch.zeros(1, dtype=torch.int32, device=dev)
+        head_ = torch.randn(cin, device=dev) if cin == 32 else None      # conv2 carries the classifier's side head
+        fn = lambda: lay(xs_, 4, flags=ops.EPI_RELU, out=ys_, out_exp=4, head=head_, overflow=flag_)  # noqa: E731
+    elif args.layer in ("general_f32", "sheared_f32"):     # the fp32 expand kernels (arithmetic = fp32)
+        model.arithmetic = "fp32"
+        fn = lambda: model.forward_pair(left, right, shift, 1, sheared=args.layer == "sheared_f32")  # noqa: E731
     elif args.layer == "general":           # any shift array: warp after convolution (three depth-1 convs + warped_expand)
         fn = lambda: model.forward_pair(left, right, shift, 1, sheared=False)  # noqa: E731
     elif args.layer == "sheared_bwd":       # cfg4's first layer: forward + backward of the sheared function with folded BatchNorm

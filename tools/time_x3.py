@@ -11,7 +11,7 @@ import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
 
 import bench  # noqa: E402
-from snvc_amd import ops  # noqa: E402
+from snvc_amd import _lib, ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=10)
@@ -23,7 +23,7 @@ for name, cin, cout, shape in (("conv2 32->32 192x96x312", 32, 32, (192, 96, 312
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * np.sqrt(2.0 / (cin * 27))
     scale, bias = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev) * 0.2
     ref_layer = ops.Conv3dLayer(w, 3, 1, 1, 1, False)
-    x3 = ops.Conv3dLayerX3(w)
+    x3 = ops.Conv3dLayerX3(w, algo=0)
     x_exp = 4
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
     head = torch.randn(cout, device=dev)
@@ -42,13 +42,12 @@ for name, cin, cout, shape in (("conv2 32->32 192x96x312", 32, 32, (192, 96, 312
     print(f"{name}: max|err| / max|ref| vs float64 on a crop: fp32 Winograd {e(y_ref):.2e}   split -> f32 {e(y_x3):.2e}   split -> split {e(y_rt):.2e}")
     print(f"   whole tensor, split vs fp32 path: {(y_x3 - y_ref).abs().max().item() / y_ref.abs().max().item():.2e}")
     flop = 2.0 * np.prod(shape) * cin * cout * 27
-    from snvc_amd import _lib
     x3s = ops.Conv3dLayerX3(w, algo=_lib.ALGO_X3_SERIAL)
     ysr = x3s(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out_exp=4)
     print(f"   serial form vs resident form: {(ops.from_split(ysr, 4) - y_rt).abs().max().item() / y_rt.abs().max().item():.2e}")
     extra = []
-    if cout == 32:
-        for bit, nm in ((0x2000, "resident + double buffer"), (0x4000, "4x8x32 tile")):
+    if cout == 64:
+        for bit, nm in ((_lib.ALGO_X3_NARROW, "32-channel blocks"), (_lib.ALGO_X3_SMALL, "32-channel blocks, 2x4x32 tiles")):
             lx = ops.Conv3dLayerX3(w, algo=bit)
             yx = lx(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out_exp=4)
             print(f"   {nm} vs default form: {(ops.from_split(yx, 4) - y_rt).abs().max().item() / y_rt.abs().max().item():.2e}")
