@@ -72,8 +72,11 @@ struct F16Args {
 // 4: 9.38 / 2.00 / 0.91; 6: 8.99 / 1.82 / 0.85 (242-246 VGPRs, no spills); 8: 8.89 / 1.83 / 0.86 with spills.
 
 template <int KD_, int KH_, int KW_, int STRIDE_, int DIL_, int MI_, int TD_, int TH_, int KCG_, int MODE_, bool DB_, int OCC_,
-          int DILW_ = DIL_, int PL_ = 1>
+          int DILW_ = DIL_, int PL_ = 1, bool DYN_ = false>
 struct F16Cfg {
+    // DYN (split transposed layers): the 2x2x2 box of a parity class is walked over its REAL taps only -- (1+pd)(1+ph)(1+pw) of
+    // them, 27 over the eight classes instead of 64 -- in pairs (two taps per MFMA), their offsets held in scalar registers.
+    static constexpr bool DYN = DYN_;
     // PL = 2: split mode.  Activations and weights are (hi, lo) pairs of halves, value = hi + lo (22 significant bits), and a
     // product is evaluated as hi*hi + lo_w*hi_x + hi_w*lo_x on three v_mfma_f32_32x32x16_f16 with fp32 accumulation: the fp32
     // layers' contraction at fp32 accuracy (the dropped lo*lo term is 2^-22 of the product) on the 16x faster half pipe.
@@ -83,7 +86,7 @@ struct F16Cfg {
     static constexpr bool SPLIT = PL_ >= 2, SERIAL = PL_ == 3;
     static constexpr int RES_PL = PL_ == 2 ? 2 : 1;         // planes resident in LDS
     static constexpr int PASSES = SERIAL ? 2 : 1;           // image passes per channel chunk
-    static constexpr int PF = SPLIT ? 3 : 6;                // A-fragment ring depth (k-steps ahead)
+    static constexpr int PF = DYN_ ? 2 : (SPLIT ? 3 : 6);   // A-fragment ring depth (k-steps ahead)
     // DIL applies to D and H, DILW to W (they differ only for the sub-grid form of a dilated layer, see F16K5D2)
     static constexpr int KD = KD_, KH = KH_, KW = KW_, STRIDE = STRIDE_, DIL = DIL_, DILW = DILW_, MI = MI_, TD = TD_, TH = TH_;
     static constexpr int KCG = KCG_, MODE = MODE_, OCC = OCC_;
@@ -228,7 +231,21 @@ conv3d_f16_kernel(const F16Args a_) {
     // ---- A fragments: [cout block][chunk][segment][k-step][m][lane] pieces, consumed in exactly that order
     // (split mode: [..][k-step][m][hi | lo][lane])
     constexpr int MA = MI * (SPLIT ? 2 : 1);
-    const int64_t steps_total = (int64_t)a.nchunks * Cfg::PASSES * Cfg::STEPS;
+    // DYN: this class's real taps, in (kd, kh, kw) order with kw fastest; pair p = taps (2p, 2p + 1)
+    int dyn_np = 0, dyn_toff[4] = {0, 0, 0, 0}, dyn_base[4] = {0, 0, 0, 0};
+    if constexpr (Cfg::DYN) {
+        const int nw = 1 + (cls & 1), nh = 1 + ((cls >> 1) & 1), ndp = 1 + ((cls >> 2) & 1);
+        const int T = nw * nh * ndp;
+        dyn_np = T > 1 ? T / 2 : 1;
+        auto vox = [&](int t) { return (((t / (nw * nh)) * IN_H) + (t / nw) % nh) * IN_W + t % nw; };
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int ta = 2 * p, tb = 2 * p + 1;
+            dyn_toff[p] = vox(ta) * 16;
+            dyn_base[p] = lanebase + half * ((tb < T ? vox(tb) - vox(ta) : 0) * 16);
+        }
+    }
+    const int64_t steps_total = Cfg::DYN ? (int64_t)a.nchunks * 2 * dyn_np : (int64_t)a.nchunks * Cfg::PASSES * Cfg::STEPS;
     const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * MA) * 64 + lane;
     h8 q[PF][MA];
 #pragma unroll
@@ -239,6 +256,40 @@ conv3d_f16_kernel(const F16Args a_) {
     }
 
     auto compute = [&](const char *img, bool lo_pass) {
+        if constexpr (Cfg::DYN) {
+            static_assert(!Cfg::DYN || (PL == 2 && KCG == 2 && Cfg::MODE == 1 && PF == 2), "DYN: resident split planes, two groups, tap pairs");
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                if (p >= dyn_np) break;                  // block-uniform
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {            // k-step (p, g): ring slot g, refilled with the step two ahead
+                    h8 af[MA];
+#pragma unroll
+                    for (int m = 0; m < MA; ++m) { af[m] = q[g][m]; q[g][m] = wq[m * 64]; }
+                    wq += MA * 64;
+                    h8 bf[NB], bl[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb) {
+                        const char *src = img + g * GB + dyn_toff[p] + dyn_base[p] + rowoff[nb];
+                        bf[nb] = *reinterpret_cast<const h8 *>(src);
+                        bl[nb] = *reinterpret_cast<const h8 *>(src + Cfg::PLANE_BYTES);
+                    }
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) {
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf[nb], acc[nb][m], 0, 0, 0);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bl[nb], acc[nb][m], 0, 0, 0);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf[nb], acc[nb][m], 0, 0, 0);
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll 1
         for (int seg = 0; seg < Cfg::SEGS; ++seg) {
             const char *simg = img + seg * Cfg::SEG_BYTES;
@@ -460,6 +511,7 @@ struct PackArgs {
     int nchunks, cblocks;
     int PL;                    // >= 2: split mode, [..][m][hi | lo][lane][8]; values are w * wmul (a power of two) split as hi + lo
     int PASSES;                // 2: planes taken serially, the k-steps of a chunk are stored once per pass
+    int dyn;                   // 1: transposed class packed over its real taps only (F16Cfg::DYN): NS = 2 * pairs of this class
     float wmul;
     int64_t total;             // elements (halves)
 };
@@ -481,11 +533,20 @@ __global__ void pack_f16_weights_kernel(const PackArgs p) {
     const int half = lane >> 5;
     const int co = (cb * p.MI + m) * 32 + f16_row_channel(lane & 31);
     int tap, g;
-    if (p.MODE == 0) { tap = s / (p.KCG / 2); g = 2 * (s % (p.KCG / 2)) + half; }
+    if (p.dyn) { g = s % p.KCG; tap = 2 * (s / p.KCG) + half; }
+    else if (p.MODE == 0) { tap = s / (p.KCG / 2); g = 2 * (s % (p.KCG / 2)) + half; }
     else { g = s / p.NPS; tap = 2 * (s % p.NPS) + half; }
     const int ci = (chunk * p.KCG + g) * 8 + e;
     float v = 0.0f;
-    if (tap < p.TSEG && co < p.Cout && ci < p.Cin) {
+    if (p.dyn) {
+        const int nw = 1 + p.pw, nh = 1 + p.ph, ndp = 1 + p.pd;
+        if (tap < nw * nh * ndp && co < p.Cout && ci < p.Cin) {
+            const int b[3] = {tap / (nw * nh), (tap / nw) % nh, tap % nw}, par[3] = {p.pd, p.ph, p.pw};
+            int k3[3];
+            for (int d = 0; d < 3; ++d) k3[d] = par[d] == 0 ? 1 : (b[d] == 0 ? 2 : 0);      // parity 1: box tap 0 = kernel index 2, tap 1 = index 0
+            v = p.w[((((int64_t)ci * p.Cout + co) * 3 + k3[0]) * 3 + k3[1]) * 3 + k3[2]];
+        }
+    } else if (tap < p.TSEG && co < p.Cout && ci < p.Cin) {
         const int kd = p.unroll_d ? tap / (p.KH * p.KW) : seg, kh = (tap / p.KW) % p.KH, kw = tap % p.KW;
         if (!p.transposed) {
             v = p.w[((((int64_t)co * p.Cin + ci) * p.K + kd) * p.K + kh) * p.K + kw];
@@ -552,12 +613,13 @@ using F16K3X2S = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 1, 1, true, 2, 1, 3>;
 // stride 2: the image of a 2x4x32 tile is 5 x 9 x 65 pieces (46.8 KB per plane): the planes are taken serially (PL = 3)
 using F16K3S2X = F16Cfg<3, 3, 3, 2, 1, 2, 2, 4, 1, 1, false, 2, 1, 3>;
 // one parity class of ConvTranspose3d(k3,s2,p1,op1): 2x2x2 box taps, both planes resident, double-buffered
-using F16DCX  = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 1, false, 2, 1, 2>;      // (KCG = 1, double-buffered: 0.255 ms on hg conv5; 8 k-steps per barrier pair now)
+// (first forms, all 8 box taps with zero weights where a class has none: KCG = 1 double-buffered 0.255 ms, KCG = 2 0.284 ms on hg conv5)
+using F16DCX  = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 1, false, 2, 1, 2, true>;
 
 enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FNONE };
 
 struct F16Plan {
-    int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES;
+    int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
     int nchunks, cblocks;
     int64_t block_halves;      // packed halves of one class (without padding)
 };
@@ -568,7 +630,7 @@ F16Plan plan_from(int kind) {
     p.kind = kind; p.MI = Cfg::MI; p.KCG = Cfg::KCG; p.MODE = Cfg::MODE; p.TD = Cfg::TD; p.TH = Cfg::TH;
     p.STEPS = Cfg::STEPS; p.SEGS = Cfg::SEGS; p.TSEG = Cfg::TSEG; p.NPS = Cfg::NPS; p.NS = Cfg::NS;
     p.KD = Cfg::KD; p.KH = Cfg::KH; p.KW = Cfg::KW; p.unroll_d = Cfg::UNROLL_D ? 1 : 0;
-    p.PL = Cfg::PL; p.PF = Cfg::PF; p.PASSES = Cfg::PASSES;
+    p.PL = Cfg::PL; p.PF = Cfg::PF; p.PASSES = Cfg::PASSES; p.dyn = Cfg::DYN ? 1 : 0;
     return p;
 }
 
@@ -690,6 +752,12 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
         a.TSEG = p.TSEG; a.NPS = p.NPS; a.NS = p.NS; a.unroll_d = p.unroll_d;
         a.nchunks = p.nchunks; a.cblocks = p.cblocks; a.total = p.block_halves;
         a.PL = p.PL; a.PASSES = p.PASSES; a.wmul = wmul;
+        a.dyn = p.dyn;
+        if (p.dyn) {        // compact per class: 2 * pairs k-steps per chunk
+            const int T = (1 + a.pd) * (1 + a.ph) * (1 + a.pw);
+            a.NS = 2 * (T > 1 ? T / 2 : 1);
+            a.total = (int64_t)p.cblocks * p.nchunks * a.NS * p.MI * 2 * 64 * 8;
+        }
         pack_f16_weights_kernel<<<(unsigned)ceil_div<int64_t>(a.total, 256), 256, 0, as_stream(stream)>>>(a);
     }
     return check_launch(who);
