@@ -49,6 +49,7 @@ _GENERATION = [0]   # bumped by invalidate_plans(): part of every cache key
 # How often each fused route was taken (tests assert on it: a silent regression to a slower or to a torch route shows)
 import collections
 _ROUTES = collections.Counter()
+TRAIN_EXACT_K57 = [False]     # True: k5 / k7 layers under autograd on the direct kernels (exact fp32 FMA chains) instead of Winograd
 
 
 def invalidate_plans(module: Optional[nn.Module] = None) -> None:
@@ -261,15 +262,12 @@ class _ConvNormActFn(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, residual, conv, norm, flags, plan, grad_box=None):
         ctx.grad_box = grad_box
         layer = _get_layer(conv, plan)
-        if layer.stride == 2 and not layer.transposed and any(int(s) % 2 for s in x.shape[2:]):
-            # the data gradient of Conv3d(k3,s2,p1) runs on the ConvTranspose3d(k3,s2,p1,op1) kernel, whose
-            # output is exactly 2x its input: an odd extent would come back one element too large
-            raise NotImplementedError("training through a stride-2 3D convolution needs even input extents "
-                                      f"(got {tuple(x.shape[2:])}); the reference's hourglasses require it too")
-        # training keeps the k5 / k7 layers on the direct kernel (exact fp32 FMA chain): the F(4,7) forward is
-        # 1e-4 off, inside the 1e-3 contract but enough to flip ReLU masks and blur gradient comparisons
+        # k5 / k7 layers under autograd: Winograd F(4,5) / F(4,7) forward and data gradient like at inference (r4; the local
+        # trunk's conv1 3.7 instead of 7.5 ms) unless TRAIN_EXACT_K57 asks for the direct kernels' exact fp32 FMA chain -- the
+        # F(4,7) forward is 1e-4 of the range off, inside the 1e-3 contract, but it moves a few ReLU masks, which gradient
+        # comparisons against another implementation see as isolated differences
         y, raw, scale, shift, mean, var, per_sample = _norm_forward(layer, norm, plan, x, residual, flags, None, True,
-                                                                    exact=layer.ksize >= 5)
+                                                                    exact=layer.ksize >= 5 and TRAIN_EXACT_K57[0])
         ctx.conv, ctx.norm, ctx.flags, ctx.plan, ctx.per_sample = conv, norm, flags, plan, per_sample
         ctx.has_res = residual is not None
         ctx.train_stats = mean is not None
@@ -296,13 +294,25 @@ class _ConvNormActFn(torch.autograd.Function):
                 raise RuntimeError("a skip connection's gradient was parked for a layer whose input needs no gradient")
             if extra is not None:
                 extra = extra.contiguous()
+        # Conv3d(k3,s2,p1) takes any extent (reference submodule.py:170-181); its data gradient runs on the
+        # ConvTranspose3d(k3,s2,p1,op1) kernel, whose result is exactly twice the size of draw: for an odd input extent that is
+        # one plane / row / column more than x has -- the gradient of the zero padding -- which is cropped off; the weight
+        # gradient sees x with that padding position made explicit (a zero plane contributes nothing)
+        odd = (st == 2 and not transposed) and any(int(e) % 2 for e in x.shape[2:])
         gx = None
         if needs[0]:
-            gx = dl(draw, None, None, extra, EPI_ADD_POST if extra is not None else 0, None, exact=dl.ksize >= 5)
+            if odd:
+                gx = dl(draw, None, None, None, 0, None)[:, :, :x.size(2), :x.size(3), :x.size(4)].contiguous()
+                if extra is not None:
+                    gx = gx + extra
+            else:
+                gx = dl(draw, None, None, extra, EPI_ADD_POST if extra is not None else 0, None, exact=dl.ksize >= 5 and TRAIN_EXACT_K57[0])
         gw = None
         if needs[1]:
             if transposed:   # roles swapped, see snvc_conv3d_wgrad
                 gw = ops.conv3d_wgrad(draw, x, 3, 2, 1, 1)
+            elif odd:
+                gw = ops.conv3d_wgrad(F.pad(x, (0, x.size(4) % 2, 0, x.size(3) % 2, 0, x.size(2) % 2)), draw, k, st, p, d)
             else:
                 gw = ops.conv3d_wgrad(x, draw, k, st, p, d)
         return gx, gw, dg, db, gres, None, None, None, None, None

@@ -756,7 +756,8 @@ def test_conv3d_wgrad_vs_float64(case, variant):
     check(dw.cpu().numpy(), w.grad.float().numpy(), 2e-5 if variant == "auto" else 5e-6, f"wgrad {case} ({variant})")
 
 
-@pytest.mark.parametrize("case", ["k3_bn_train", "k3_bn_eval", "k3s2_bn_train", "deconv_bn_train", "k3_gn", "k1_plain"])
+@pytest.mark.parametrize("case", ["k3_bn_train", "k3_bn_eval", "k3s2_bn_train", "k3s2_odd_bn_train", "k3s2_odd_w_bn_eval", "deconv_bn_train",
+                                  "k3_gn", "k1_plain"])
 def test_layer_backward_vs_torch_autograd(case):
     """fwd+bwd of one fused layer (conv/deconv + norm + residual + ReLU) against torch autograd on
     the CPU restatement: dx, dW, dgamma, dbeta, dresidual."""
@@ -770,7 +771,8 @@ def test_layer_backward_vs_torch_autograd(case):
         xs = (2, 64, 3, 4, 20)
     elif case.startswith("k3s2"):
         ours, ref = S.convbn_3d(32, 64, 3, 2, 1, gn=gn), T.convbn_3d(32, 64, 3, 2, 1, gn=gn)
-        xs = (2, 32, 4, 6, 40)
+        # r4: odd extents under autograd (nn.Conv3d(k3,s2,p1) takes any, reference submodule.py:170-181)
+        xs = {"k3s2_odd_bn_train": (2, 32, 5, 7, 41), "k3s2_odd_w_bn_eval": (1, 32, 4, 6, 37)}.get(case, (2, 32, 4, 6, 40))
     elif case.startswith("k1"):
         ours, ref = S.convbn_3d(40, 32, 1, 1, 0, gn=gn), T.convbn_3d(40, 32, 1, 1, 0, gn=gn)
         xs = (1, 40, 3, 5, 36)
@@ -1474,13 +1476,17 @@ def test_sheared_backward_entry_points_vs_numpy(q, m0):
     assert abs((up * G).sum() - (back.astype(np.float64) * R).sum()) < 1e-3
 
 
-@pytest.mark.parametrize("gn", [False, True])
-def test_training_step_vernier_trunk_vs_torch_autograd(gn):
+@pytest.mark.parametrize("gn,exact_k57", [(False, False), (True, False), (False, True)])
+def test_training_step_vernier_trunk_vs_torch_autograd(gn, exact_k57, request):
     """Local (V-A) model: gather + 3D trunk (7^3, 5^3, dilated 5^3 convs, hourglass, heads' inputs)
     forward+backward in train mode against torch-CPU autograd: every 3D-trunk parameter gradient and
-    the gradients w.r.t. the two feature maps."""
+    the gradients w.r.t. the two feature maps.  The k5 / k7 layers on their Winograd forms (the default under autograd since
+    r4) and on the direct kernels (TRAIN_EXACT_K57)."""
     from oracle import torch_ref as T
+    from snvc_amd.models import submodule as S_
     from snvc_amd.models.vernier import VernierScale
+    S_.TRAIN_EXACT_K57[0] = exact_k57
+    request.addfinalizer(lambda: S_.TRAIN_EXACT_K57.__setitem__(0, False))
     grid = (16, 16, 24)
     ref = T.VernierTrunk(32, grid, gn)
     ours = VernierScale(_cfg(grid, gn))
@@ -1506,12 +1512,17 @@ def test_training_step_vernier_trunk_vs_torch_autograd(gn):
 
     def l2(a, b):
         return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
-    assert l2(gl_o.numpy(), gl_r.numpy()) < 2e-3 and l2(gr_o.numpy(), gr_r.numpy()) < 2e-3
+    # direct kernels: 2e-3.  Winograd F(4,5) / F(4,7) forward (1e-4 of the range off, inside the 1e-3 contract): a handful of
+    # ReLU masks differ from torch's, each an isolated O(1) difference in the gradient behind it -- bounded, not matched
+    tol = 2e-3 if exact_k57 else 2e-2
+    errs = {"left": l2(gl_o.numpy(), gl_r.numpy()), "right": l2(gr_o.numpy(), gr_r.numpy())}
     trunk = [k for k in gp_r if gp_r[k] is not None and k.split(".")[0] in
              ("vimg_feat", "conv1", "conv2", "conv3", "conv4", "hg_conv3d", "fg_cls_head")]
     assert len(trunk) >= 30
-    for k in trunk:
-        assert l2(gp_o[k].numpy(), gp_r[k].numpy()) < 2e-3, (k, l2(gp_o[k].numpy(), gp_r[k].numpy()))
+    errs.update({k: l2(gp_o[k].numpy(), gp_r[k].numpy()) for k in trunk})
+    worst = max(errs, key=errs.get)
+    print(f"gn={gn} exact={exact_k57}: worst l2 {errs[worst]:.2e} ({worst}), left {errs['left']:.2e}, right {errs['right']:.2e}")
+    assert errs[worst] < tol, (worst, errs[worst])
 
 
 def test_empty_and_ragged_inputs():
