@@ -625,6 +625,9 @@ def main():
         traffic_src = ("profiles/r4/traffic.json, layer x3_conv2 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
                        if traffic_x3 is not None else None)
 
+    x3_state = model.__dict__.get("_snvc_x3")
+    x3_overflow = int(x3_state["flag"].item()) if x3_state is not None else None       # 0: no value was clamped to half's range
+    x3_exponents = dict(x3_state["exp"]) if x3_state is not None else None
     if args.breakdown and rank == 0:
         _breakdown(model, left, right, shift, build_cost_volume)
     del model
@@ -653,6 +656,9 @@ def main():
                                "accumulation -- the fp32 layers at fp32 accuracy (5e-7 of the range vs float64 per layer; the fp32 Winograd "
                                "kernels: 2e-6), held to the SAME per-layer 2e-5 / stack 1e-4 tolerances as the fp32 kernels "
                                "(tests/test_gpu_fullsize_oracle.py, parity_vs_cpu_baseline below); `fp32_mfma` repeats the step on the fp32-MFMA kernels"),
+                "split_mode": {"taken": bool(x3_taken), "overflow_flag": x3_overflow, "tensor_exponents": x3_exponents,
+                               "rule": "2^e * (|beta| + 64 |gamma|) <= 2^15 per tensor (folded eval BatchNorm); a value beyond it is clamped "
+                                       "and flagged, the model then falls back to the fp32-MFMA kernels"},
                 "entry_points": {
                     "value": "GlobalStack.forward_pair(left, right, shift): fused entry point.  Left half of the concat volume: "
                              "d-invariant -> 3 depth-class planes.  Warped right half: the disparity planes are uniformly "

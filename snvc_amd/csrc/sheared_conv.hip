@@ -1037,9 +1037,11 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
     const int h = blockIdx.x;
     const int d_lo = dch * DC, d_hi = (d_lo + DC) < D ? (d_lo + DC) : D;
     const int64_t hw = (int64_t)H * W;
+    // Only the F rows are staged (31.5 KB instead of 63: four workgroups per CU): the G rows differ from them at columns -1, 0, 1
+    // alone (G = F - {E2, E1, E0}: the gated sample's share), which the lanes that sit there subtract when their window moves.
     float *const rowsF = lds;                            // [3 kd][8][LW]
-    float *const rowsG = lds + 24 * LW;
-    float *const tas = rowsG + 24 * LW;                  // [8][DC]
+    float *const corr = lds + 24 * LW;                   // [3 kd][8][4]: {E2, E1, E0, 0}
+    float *const tas = corr + 24 * 4;                    // [8][DC]
     f32x4 *const ptab = reinterpret_cast<f32x4 *>(tas + 8 * DC + ((4 - ((8 * DC) & 3)) & 3));       // [D + 2]
     const float *sh = shift + n * D;
     for (int i = tid; i < D + 2; i += blockDim.x) {
@@ -1060,17 +1062,18 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
         const int row = i / (LW >> 2), pc = i - row * (LW >> 2);      // row = kd * 8 + c
         const int kd = row >> 3, c = row & 7, co = cg * 8 + c, col = 4 * pc - FP;
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        f32x4 g4 = v;
         if (co < C) {
             if (col >= 0 && col < W) v = *reinterpret_cast<const f32x4 *>(p + (((n * 3 + kd) * C + co) * (int64_t)H + h) * W + col);
-            g4 = v;
             const float *er = e + (((n * 3 + kd) * 3) * C + co) * (int64_t)H * 4 + (int64_t)h * 4;
             const int64_t kws = (int64_t)C * H * 4;
-            if (col == -4) { v[3] = er[2 * kws]; g4[3] = 0.0f; }              // column -1: F = E2, G = 0
-            if (col == 0) { g4[0] = v[0] - er[kws]; g4[1] = v[1] - er[0]; }   // columns 0, 1 of G: the gated sample's share removed
+            if (col == -4) {                                                    // column -1: F = E2
+                v[3] = er[2 * kws];
+                *reinterpret_cast<f32x4 *>(corr + row * 4) = f32x4{er[2 * kws], er[kws], er[0], 0.0f};
+            }
+        } else if (col == -4) {
+            *reinterpret_cast<f32x4 *>(corr + row * 4) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
         *reinterpret_cast<f32x4 *>(rowsF + row * LW + 4 * pc) = v;
-        *reinterpret_cast<f32x4 *>(rowsG + row * LW + 4 * pc) = g4;
     }
     __syncthreads();
     for (int i = tid; i < 8 * DC; i += blockDim.x) {
@@ -1134,10 +1137,15 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
             if (pm[kd] != mw[kd] && pm[kd] != kInvalid) {      // wave-uniform: the window of this kd moves
                 int idx = FP + w - pm[kd] - 1;                   // column w - m - 1 of the staged rows; left of the pad: zeros
                 const int fi = idx < 0 ? 0 : idx, gi = idx + 1 < 0 ? 0 : idx + 1;
+                const int gcol = w - pm[kd];                     // the G-term's column: -1, 0, 1 carry the gate's correction
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     wf[kd][c] = rowsF[(kd * 8 + c) * LW + fi];
-                    wg[kd][c] = rowsG[(kd * 8 + c) * LW + gi];
+                    wg[kd][c] = rowsF[(kd * 8 + c) * LW + gi];
+                }
+                if ((unsigned)(gcol + 1) <= 2u) {                // at most three lanes of the row
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) wg[kd][c] -= corr[(kd * 8 + c) * 4 + gcol + 1];
                 }
                 mw[kd] = pm[kd];
             }
@@ -1403,10 +1411,10 @@ int snvc_warped_expand_split(const float *p, const float *q, const float *e, con
     const int64_t G = ceil_div<int64_t>(C, 8);
     if (W > 512 || G > 4095 || N > 65535 || H >= ((int64_t)1 << 31))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_split: row too wide (W <= 512) or too many channels");
-    int DCH = 1;
-    while (DCH < 16 && H * G * N * DCH < 4 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
+    int DCH = 1;         // depth chunks: about three workgroups per CU (four fit; every workgroup re-stages its 24 rows)
+    while (DCH < 16 && H * G * N * DCH < 3 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
     const int DC = (int)ceil_div<int64_t>(D, DCH);
-    const size_t lds = sizeof(float) * (2 * 24 * (size_t)(W + 16) + 8 * (size_t)DC + 4 + 4 * (size_t)(D + 2));
+    const size_t lds = sizeof(float) * (24 * (size_t)(W + 16) + 96 + 8 * (size_t)DC + 4 + 4 * (size_t)(D + 2));
     if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_split: the row does not fit the LDS");
     const int threads = ceil_div((int)W, 64) * 64;
     const dim3 grid((unsigned)H, (unsigned)(G * DCH), (unsigned)N);

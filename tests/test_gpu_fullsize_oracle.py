@@ -112,6 +112,8 @@ def _entry_points(o, expect_route, arithmetic):
         vol.data_ptr()                                                       # somebody looked: the real volume
         got = m(vol).cpu().numpy()
         check(got, exp, 1e-4, "model(materialised lazy volume) vs oracle, full size")
+    if arithmetic == "x3":      # no value left the range its BatchNorm statistics promised (nothing was clamped)
+        assert int(m.__dict__["_snvc_x3"]["flag"].item()) == 0 and not m.__dict__.get("_snvc_x3_off")
 
 
 @pytest.mark.parametrize("arithmetic", ["fp32", "x3"])
