@@ -616,7 +616,17 @@ using F16K3S2X = F16Cfg<3, 3, 3, 2, 1, 2, 2, 4, 1, 1, false, 2, 1, 3>;
 // (first forms, all 8 box taps with zero weights where a class has none: KCG = 1 double-buffered 0.255 ms, KCG = 2 0.284 ms on hg conv5)
 using F16DCX  = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 1, false, 2, 1, 2, true>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FNONE };
+// split forms of the local trunk's other layer kinds (snvc/models/vernier.py:249-278): 1x1x1 (two channel groups per MFMA, both
+// planes resident), 5^3 / dilated 5^3 (sub-grid classes) / 7^3 (planes serial: their single-plane images are 37 / 41 / 61 KB),
+// the 32-output-channel transposed layer (hourglass_downsample_16's conv12), and the one-channel occupancy head (EPI 1 on F16K3X)
+//                         KD KH KW S  D  MI TD TH KCG MODE DB    OCC DILW PL
+using F16K1X   = F16Cfg<1, 1, 1, 1, 1, 1, 4, 4, 2, 0, true, 3, 1, 2>;
+using F16K5X   = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 3, 1, 3>;
+using F16K5D2X = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2, 3>;
+using F16K7X   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 3>;
+using F16DCXN  = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 1, false, 3, 1, 2, true>;
+
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
@@ -639,26 +649,43 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16_conv3d: sizes must be positive");
     if (d.Cin % 8 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: Cin must be a multiple of 8 (C8 layout)");
     if (split) {
-        if (d.ksize != 3 || d.dilation != 1 || d.pad != 1)
-            return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: built for k3 layers (stride 1 / stride 2 / transposed)");
         if (d.transposed) {
-            if (d.stride != 2 || d.Cout % 64 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: transposed layers: k3,s2,p1,op1 with Cout % 64 == 0");
+            if (d.ksize != 3 || d.stride != 2 || d.pad != 1 || d.dilation != 1 || d.Cout % 32 != 0)
+                return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: transposed layers: k3,s2,p1,op1 with Cout % 32 == 0");
             if (d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win)
                 return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d: transposed output must be 2x the input");
-            p = plan_from<F16DCX>(FDCX);
+            p = d.Cout % 64 == 0 ? plan_from<F16DCX>(FDCX) : plan_from<F16DCXN>(FDCXN);
         } else {
-            if (d.stride != 1 && d.stride != 2) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: stride 1 or 2");
-            if (d.Dout != (d.Din - 1) / d.stride + 1 || d.Hout != (d.Hin - 1) / d.stride + 1 || d.Wout != (d.Win - 1) / d.stride + 1)
+            if (d.pad != d.dilation * (d.ksize - 1) / 2)
+                return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: pad must equal dilation*(ksize-1)/2");
+            const int eff = d.dilation * (d.ksize - 1) + 1;
+            if (d.Dout != (d.Din + 2 * d.pad - eff) / d.stride + 1 || d.Hout != (d.Hin + 2 * d.pad - eff) / d.stride + 1 ||
+                d.Wout != (d.Win + 2 * d.pad - eff) / d.stride + 1)
                 return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d: output size does not match the convolution arithmetic");
-            if (d.stride == 2) {
+            const int key = d.ksize * 100 + d.stride * 10 + d.dilation;
+            if (d.Cout == 1) {
+                if (key != 311) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: one-channel output is built for k3/s1 only");
+                p = plan_from<F16K3X>(FK3XH);
+            } else if (key == 321) {
                 if (d.Cout % 64 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: stride-2 layers need Cout % 64 == 0");
                 p = plan_from<F16K3S2X>(FK3S2X);
             } else {
                 if (d.Cout % 32 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: Cout % 32 == 0");
-                if (d.algo & SNVC_ALGO_X3_SMALL) p = plan_from<F16K3XT>(FK3XT);
-                else if (d.algo & SNVC_ALGO_X3_NARROW) p = plan_from<F16K3X>(FK3X);
-                else if (d.algo & SNVC_ALGO_X3_SERIAL) p = d.Cout == 32 ? plan_from<F16K3XS>(FK3XS) : plan_from<F16K3X2S>(FK3X2S);
-                else p = d.Cout == 32 ? plan_from<F16K3X>(FK3X) : plan_from<F16K3X2>(FK3X2);
+                switch (key) {
+                    case 111: p = plan_from<F16K1X>(FK1X); break;
+                    case 511: p = plan_from<F16K5X>(FK5X); break;
+                    case 512: p = plan_from<F16K5D2X>(FK5D2X); break;
+                    case 711: p = plan_from<F16K7X>(FK7X); break;
+                    case 311:
+                        if (d.algo & SNVC_ALGO_X3_SMALL) p = plan_from<F16K3XT>(FK3XT);
+                        else if (d.algo & SNVC_ALGO_X3_NARROW) p = plan_from<F16K3X>(FK3X);
+                        else if (d.algo & SNVC_ALGO_X3_SERIAL) p = d.Cout == 32 ? plan_from<F16K3XS>(FK3XS) : plan_from<F16K3X2S>(FK3X2S);
+                        else p = d.Cout == 32 ? plan_from<F16K3X>(FK3X) : plan_from<F16K3X2>(FK3X2);
+                        break;
+                    default:
+                        return fail(SNVC_ERR_UNSUPPORTED,
+                                    "snvc_f16x3_conv3d: (ksize,stride,dilation) not in {(1,1,1),(3,1,1),(3,2,1),(5,1,1),(5,1,2),(7,1,1)}");
+                }
             }
         }
         p.nchunks = ceil_div(d.Cin / 8, p.KCG);
@@ -877,18 +904,20 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     int rc = make_f16_plan(*d, p, true);
     if (rc) return rc;
     if (d->N == 0) return SNVC_OK;
+    const bool plane = d->Cout == 1;              // the occupancy head: y_f32 is then the fp32 plane [N][1][D][H][W] (Sigmoid honoured)
     const bool to_f32 = y_f32 != nullptr;
+    if (plane && !to_f32) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: a one-channel layer writes y_f32");
     if (!x_hi || !x_lo || !packed_weight || (!to_f32 && (!y_hi || !y_lo)))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null pointer");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: scale and bias must both be given or both be NULL");
     const int resflags = d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST);
-    if (resflags && (!res_hi || !res_lo))
+    if (resflags && (!res_hi || !res_lo || plane))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: residual flag without a split residual");
     if (resflags == (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: ADD_PRE and ADD_POST are exclusive");
-    if (d->flags & ~(SNVC_EPI_RELU | SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))
-        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: RELU / ADD_PRE / ADD_POST only");
+    if (d->flags & ~(SNVC_EPI_RELU | SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST | (plane ? SNVC_EPI_SIGMOID : 0)))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: RELU / ADD_PRE / ADD_POST only (SIGMOID with the one-channel output)");
     if ((head != nullptr) != (y_head != nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: head and y_head go together");
     if (head && ((p.kind != FK3X && p.kind != FK3XS && p.kind != FK3XT) || d->Cout != 32 || to_f32))
@@ -917,15 +946,21 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     a.x_bs = d->x_batch_stride ? d->x_batch_stride : 2 * (int64_t)d->Cin * in_sp;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : 2 * (int64_t)d->Cout * out_sp;
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : 2 * (int64_t)d->Cout * out_sp;
-    a.yf_bs = d->y_batch_stride ? d->y_batch_stride : (int64_t)d->Cout * out_sp;
+    a.yf_bs = plane ? out_sp : (d->y_batch_stride ? d->y_batch_stride : (int64_t)d->Cout * out_sp);
     a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
-    const int classes = d->transposed ? 8 : 1;
-    a.N = d->N; a.cls_mode = d->transposed ? 1 : 0; a.cls_wstride = f16_class_stride(p);
+    const bool subgrid = p.kind == FK5D2X;        // (depth, height) parity classes share ONE packed weight block
+    const int classes = d->transposed ? 8 : (subgrid ? 4 : 1);
+    a.N = d->N; a.cls_mode = d->transposed ? 1 : (subgrid ? 2 : 0); a.cls_wstride = f16_class_stride(p);
     a.isd = a.ish = 1; a.iod = a.ioh = 0; a.offd = a.offh = a.offw = 0;
     if (d->transposed) {
         a.nd = d->Din; a.nh = d->Hin; a.nw = d->Win;
         a.osd = a.osh = a.osw = 2;
         a.pad_d = a.pad_h = a.pad_w = 0;
+    } else if (subgrid) {
+        a.nd = (d->Dout + 1) / 2; a.nh = (d->Hout + 1) / 2; a.nw = d->Wout;     // the largest class; the kernel trims the others
+        a.osd = a.osh = 2; a.osw = 1;
+        a.isd = a.ish = 2;
+        a.pad_d = a.pad_h = d->pad / 2; a.pad_w = d->pad;
     } else {
         a.nd = d->Dout; a.nh = d->Hout; a.nw = d->Wout;
         a.osd = a.osh = a.osw = 1;
@@ -937,28 +972,36 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles or samples");
     dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)(d->N * classes));
     hipStream_t st = as_stream(stream);
+#define SNVC_X3_LAUNCH(CFG) do { if (to_f32) launch_f16<CFG, 2>(a, grid, st); else launch_f16<CFG, 0>(a, grid, st); } while (0)
     switch (p.kind) {
         case FK3X:
             if (to_f32) launch_f16<F16K3X, 2>(a, grid, st);
             else if (head) launch_f16<F16K3X, 3>(a, grid, st);
             else launch_f16<F16K3X, 0>(a, grid, st);
             break;
-        case FK3X2: if (to_f32) launch_f16<F16K3X2, 2>(a, grid, st); else launch_f16<F16K3X2, 0>(a, grid, st); break;
+        case FK3X2: SNVC_X3_LAUNCH(F16K3X2); break;
         case FK3XS:
             if (to_f32) launch_f16<F16K3XS, 2>(a, grid, st);
             else if (head) launch_f16<F16K3XS, 3>(a, grid, st);
             else launch_f16<F16K3XS, 0>(a, grid, st);
             break;
-        case FK3X2S: if (to_f32) launch_f16<F16K3X2S, 2>(a, grid, st); else launch_f16<F16K3X2S, 0>(a, grid, st); break;
+        case FK3X2S: SNVC_X3_LAUNCH(F16K3X2S); break;
         case FK3XT:
             if (to_f32) launch_f16<F16K3XT, 2>(a, grid, st);
             else if (head) launch_f16<F16K3XT, 3>(a, grid, st);
             else launch_f16<F16K3XT, 0>(a, grid, st);
             break;
-        case FK3S2X: if (to_f32) launch_f16<F16K3S2X, 2>(a, grid, st); else launch_f16<F16K3S2X, 0>(a, grid, st); break;
-        case FDCX: if (to_f32) launch_f16<F16DCX, 2>(a, grid, st); else launch_f16<F16DCX, 0>(a, grid, st); break;
+        case FK3S2X: SNVC_X3_LAUNCH(F16K3S2X); break;
+        case FDCX: SNVC_X3_LAUNCH(F16DCX); break;
+        case FDCXN: SNVC_X3_LAUNCH(F16DCXN); break;
+        case FK1X: SNVC_X3_LAUNCH(F16K1X); break;
+        case FK5X: SNVC_X3_LAUNCH(F16K5X); break;
+        case FK5D2X: SNVC_X3_LAUNCH(F16K5D2X); break;
+        case FK7X: SNVC_X3_LAUNCH(F16K7X); break;
+        case FK3XH: launch_f16<F16K3X, 1>(a, grid, st); break;
         default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: no kernel");
     }
+#undef SNVC_X3_LAUNCH
     return check_launch("snvc_f16x3_conv3d_forward");
 }
 

@@ -1188,7 +1188,7 @@ class Conv3dLayerX3:
 
     def _pick_form(self, n: int, out_sp):
         """Kernel form of a stride-1 layer for this launch: enough workgroups to cover the 256 CUs about four times."""
-        if self.forced_algo is not None or self.stride != 1 or self.transposed:
+        if self.forced_algo is not None or self.stride != 1 or self.transposed or self.ksize != 3 or self.cout == 1:
             return self.algo
         tiles = n * -(-out_sp[0] // 4) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32)
         if self.cout % 64 == 0 and tiles * (self.cout // 64) >= 1024:
@@ -1232,7 +1232,7 @@ class Conv3dLayerX3:
         n = x.size(0)
         in_sp = tuple(x.shape[3:6])
         out_sp = self.out_spatial(in_sp)
-        f32 = to_f32 or out_f32 is not None
+        f32 = to_f32 or out_f32 is not None or self.cout == 1        # a one-channel layer (the occupancy head) writes an fp32 plane
         if f32:
             if out_f32 is None:
                 out_f32 = torch.empty((n, self.cout) + out_sp, dtype=torch.float32, device=x.device)
