@@ -184,6 +184,7 @@ def projected_coordinates(n, grid, device, res=256.0):
 def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="f32"):
     """gather + 3D trunk of the local (V-A) model on `crops` RoI crops; returns the `configs` entry.
     precision "f16": the fp16-storage mode (C8 half activations / weights, fp32 accumulate; BASELINE configs[4])."""
+    from snvc_amd import ops as ops_
     m = local_model(grid, F, device)
     r = np.random.default_rng(5)
     v = grid[0] * grid[1] * grid[2]
@@ -194,18 +195,29 @@ def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="
     gr = torch.from_numpy(r.uniform(-8, 264, (crops, 2, v)).astype(np.float32)).to(device)
     pl, pr = projected_coordinates(crops, grid, device)
     f16 = precision == "f16"
+    m.precision = "f16" if f16 else "auto"      # auto: the fp32 trunk in split mode (f16x3) when it qualifies; f16: fp16 STORAGE
     gather_bytes = crops * (v * (16 + (4 if f16 else 8) * F) + 2 * F * 64 * 64 * 4)
     conv1_flop = 2.0 * crops * v * (2 * F) * F * 343
     out = {"grid": list(grid), "F": F, "crops_per_call": crops, "dtype": precision}
     gather = m.construct_voxel_f16 if f16 else m.construct_voxel
     trunk = m.trunk_3d_f16 if f16 else m.trunk_3d
     conv1 = m.conv1.fused_f16 if f16 else m.conv1
+    from snvc_amd.models import submodule as S_
     with torch.no_grad():
         ms_u, vox = timed_ms(lambda: gather(lf, rf, gl, gr), reps)
         ms_p, _ = timed_ms(lambda: gather(lf, rf, pl, pr), reps)
-        ms_c1, _ = timed_ms(lambda: conv1(vox), reps)
-        del vox
+        x3_before = S_._ROUTES["x3_local_trunk"]
         ms, res = timed_ms(lambda: trunk(gather(lf, rf, pl, pr)), reps)
+        x3 = S_._ROUTES["x3_local_trunk"] > x3_before         # the trunk ran in split mode
+        if x3:      # its dominant layer: conv1 (k7) in split mode, on the split pair of the same voxel tensor
+            mul_ = ops_.split_scale_for(vox)
+            vs_ = S_.SplitT(ops_.to_split(vox, mul_dev=mul_), 0, None, mul_)
+            ms_c1, _ = timed_ms(lambda: m.conv1.fused_x3(vs_), reps)
+            ms_c1_f32, _ = timed_ms(lambda: m.conv1(vox), 5, 2)
+            del vs_
+        else:
+            ms_c1, _ = timed_ms(lambda: conv1(vox), reps)
+        del vox
         assert torch.isfinite(res[0]).all()
         if heads:
             ms_h, _ = timed_ms(lambda: m.heads_2d(res[0]), reps)
@@ -218,12 +230,18 @@ def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="
             del bev8
             # everything after the backbone (gather + trunk + 2D neck + heads) through VernierScale.forward
             del res
-            m.precision = precision
             ms_e, _ = timed_ms(lambda: m(lf, rf, pl, pr), reps)
             out["forward_ms_per_crop"] = ms_e / crops
+    out["arithmetic"] = ("fp16 storage (C8 half activations / weights, fp32 accumulate)" if f16 else
+                         "fp32 tensors; 3D trunk in split mode (f16x3: three half-precision MFMAs per fp32 product, fp32 accuracy)" if x3 else
+                         "fp32 (Winograd F(4,k) on fp32 MFMA)")
     if f16:     # direct form: every algorithmic multiply-add is executed (+ the 50th tap of the 25 tap pairs per slice)
         kernel = f"conv3d_f16_kernel<k7> {2 * F}->{F} (direct, v_mfma_f32_32x32x16_f16, C8 half storage)"
         frac = conv1_flop / (ms_c1 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
+    elif x3:    # 3 MFMAs per product, 50 tap slots per 49-tap depth slice
+        kernel = f"conv3d_f16_kernel<k7, split mode, planes serial> {2 * F}->{F} (three v_mfma_f32_32x32x16_f16 per fp32 product)"
+        frac = 3.0 * (50.0 / 49.0) * conv1_flop / (ms_c1 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
+        out["dominant_fp32_winograd_ms"] = ms_c1_f32
     else:
         kernel = f"conv3d_winok_kernel<k7> {2 * F}->{F} (Winograd F(4,7) along W, fp32 MFMA)"
         frac = conv1_flop * wino_executed_share(7, grid[2]) / (ms_c1 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
@@ -231,7 +249,7 @@ def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="
         "ms_per_crop": ms / crops, "crops_per_s": 1e3 * crops / ms,
         "dominant_kernel": kernel,
         "dominant_ms": ms_c1, "dominant_gflop_algorithmic": conv1_flop / 1e9,
-        "dominant_pipe_frac": frac, "dominant_peak_tflops": PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS,
+        "dominant_pipe_frac": frac, "dominant_peak_tflops": PEAK_F16_MFMA_TFLOPS if (f16 or x3) else PEAK_F32_MFMA_TFLOPS,
         "gather_projected": {"ms": ms_p, "GBps": gather_bytes / (ms_p * 1e-3) / 1e9,
                              "frac_hbm": gather_bytes / (ms_p * 1e-3) / 1e9 / PEAK_HBM_GBS,
                              "coords": "GridProjector on KITTI-like calibration, car-sized boxes"},

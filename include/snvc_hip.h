@@ -505,8 +505,17 @@ SNVC_API int snvc_f16_conv3d_forward(const snvc_conv3d_desc *desc_host, const vo
  * Values beyond half's range after scaling (|v * 2^e| > 65504) overflow: the caller picks e from what it knows of the
  * tensor (folded BatchNorm statistics) -- see snvc_amd/ops.py.
  * ---------------------------------------------------------------------------------- */
+/* mul_dev (device pointer, may be NULL): when given, the scale is read from device memory instead of `mul` -- a caller that
+ * derives the exponent from the data (max |x| of a small tensor) does so without a host round trip.  Batch strides in elements
+ * (0: dense; a dense split tensor is [N][2][C/8][S][8] halves, i.e. 2*C*S per sample). */
 SNVC_API int snvc_f16x3_from_ncdhw(const float *x, void *y_hi, void *y_lo, int64_t N, int64_t C, int64_t S,
-                                   int64_t x_batch_stride, int64_t y_batch_stride, float mul, void *stream);
+                                   int64_t x_batch_stride, int64_t y_batch_stride, float mul, const float *mul_dev,
+                                   void *stream);
+/* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half (vernier.py:433) on split pairs:
+ *   out = split((hi + lo) * occ), occ an fp32 plane [N][S]; C % 8 == 0; the pair's exponent is unchanged. */
+SNVC_API int snvc_f16x3_mul_broadcast(const void *feat_hi, const void *feat_lo, const float *occ, void *out_hi, void *out_lo,
+                                      int64_t N, int64_t C, int64_t S, int64_t feat_batch_stride, int64_t out_batch_stride,
+                                      void *stream);
 SNVC_API int snvc_f16x3_to_ncdhw(const void *x_hi, const void *x_lo, float *y, int64_t N, int64_t C, int64_t S,
                                  int64_t x_batch_stride, int64_t y_batch_stride, float mul, void *stream);
 SNVC_API int64_t snvc_f16x3_conv3d_packed_weight_bytes(const snvc_conv3d_desc *desc_host);
@@ -516,12 +525,14 @@ SNVC_API int snvc_f16x3_conv3d_pack_weights(const snvc_conv3d_desc *desc_host, c
 /* head / y_head (both or neither; 32-channel stride-1 layers with a split output): y_head[n][voxel] = head_mul * sum_c head[c] *
  * (the value stored for channel c) -- the classifier's projection of the layer's own result (the r3 side head of
  * snvc_conv3d_forward_side_head); head_mul = 2^-e_y (with y_f32 the stored result is multiplied by head_mul as well: the epilogue
- * then works in the residual's units 2^e_y).  overflow (device int, may be NULL): set to 1 if a value had to be
+ * then works in the residual's units 2^e_y).  res_mul = 2^(e_y - e_res): the residual pair's stored units relative to the result's (1 if they
+ * share an exponent).  overflow (device int, may be NULL): set to 1 if a value had to be
  * clamped to half's range on the way out (the exponent the caller chose was too large for this input). */
 SNVC_API int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,
                                        const void *packed_weight, const float *scale, const float *bias,
                                        const void *res_hi, const void *res_lo, void *y_hi, void *y_lo, float *y_f32,
-                                       const float *head, float *y_head, float head_mul, int *overflow, void *stream);
+                                       const float *head, float *y_head, float head_mul, float res_mul, int *overflow,
+                                       void *stream);
 /* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half (vernier.py:433) on C8 tensors:
  *   out[n,c,s] = half(float(feat[n,c,s]) * occ[n,0,s]), occ an fp32 plane [N][S]; C % 8 == 0. */
 SNVC_API int snvc_f16_mul_broadcast(const void *feat_c8, const float *occ, void *out_c8, int64_t N, int64_t C,

@@ -51,6 +51,7 @@ struct F16Args {
     const float *head;   // split EPI 0, Cout == 32: y_head[n][voxel] = sum_c head[c] * (the value written for channel c, unscaled: * head_mul)
     float *y_head;       //   fp32 plane [N][Dout][Hout][Wout] (the classifier's projection of the layer's own result, r3 side head)
     float head_mul;      //   2^-out_exp (EPI 2: applied to the fp32 result, which the epilogue forms in the residual's units)
+    float res_mul;       // split residual: its stored units relative to the result's, 2^(e_y - e_res) (exact)
     int *overflow;       // split output: set to 1 if a value had to be clamped to half's range (the caller's exponent was too large)
     int CGin;            // input channel groups (Cin / 8, rounded up)
     int Cout;
@@ -454,7 +455,7 @@ conv3d_f16_kernel(const F16Args a_) {
                         for (int e = 0; e < 8; ++e) {
                             float v = __builtin_fmaf(acc[nb][m][8 * j + e], sc[e >> 2][e & 3], bi[e >> 2][e & 3]);
                             if constexpr (HAS_RES) {
-                                const float rr = (float)rv[e] + (float)rl[e];
+                                const float rr = ((float)rv[e] + (float)rl[e]) * a.res_mul;
                                 if (add_pre) v += rr;
                                 if (relu) v = __builtin_fmaxf(v, 0.0f);
                                 if (add_post) v += rr;
@@ -839,6 +840,7 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     a.scale = scale; a.bias = bias;
     a.res = resflags ? reinterpret_cast<const _Float16 *>(residual) : nullptr;
     a.y = reinterpret_cast<_Float16 *>(y); a.y_f32 = y_f32;
+    a.res_mul = 1.0f;
     a.CGin = d->Cin / 8;
     a.Cout = d->Cout;
     a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
@@ -896,8 +898,8 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
 
 int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
                               const float *scale, const float *bias, const void *res_hi, const void *res_lo, void *y_hi,
-                              void *y_lo, float *y_f32, const float *head, float *y_head, float head_mul, int *overflow,
-                              void *stream) {
+                              void *y_lo, float *y_f32, const float *head, float *y_head, float head_mul, float res_mul,
+                              int *overflow, void *stream) {
     using namespace snvc;
     F16Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null desc");
@@ -938,7 +940,7 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     a.res = resflags ? reinterpret_cast<const _Float16 *>(res_hi) : nullptr;
     a.res_lo = resflags ? reinterpret_cast<const _Float16 *>(res_lo) : nullptr;
     a.y = reinterpret_cast<_Float16 *>(y_hi); a.y_lo = reinterpret_cast<_Float16 *>(y_lo); a.y_f32 = y_f32;
-    a.head = head; a.y_head = y_head; a.head_mul = head_mul; a.overflow = overflow;
+    a.head = head; a.y_head = y_head; a.head_mul = head_mul; a.res_mul = res_mul; a.overflow = overflow;
     a.CGin = d->Cin / 8; a.Cout = d->Cout;
     a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
     a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;

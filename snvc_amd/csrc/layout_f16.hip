@@ -39,9 +39,10 @@ c8_to_ncdhw_f32_kernel(const _Float16 *__restrict__ x, float *__restrict__ y, in
 // split mode (conv3d_f16.hip, F16Cfg::PL == 2): value * mul (a power of two) = hi + lo, two C8 half planes
 __global__ void __launch_bounds__(256)
 ncdhw_f32_to_c8_split_kernel(const float *__restrict__ x, _Float16 *__restrict__ yh, _Float16 *__restrict__ yl, int C, int64_t S,
-                             int64_t x_bs, int64_t y_bs, float mul) {
+                             int64_t x_bs, int64_t y_bs, float mul, const float *__restrict__ mul_dev) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
+    if (mul_dev) mul = *mul_dev;             // the scale chosen on the device (no host round trip): a power of two
     const int g = blockIdx.y;
     const int64_t n = blockIdx.z;
     const float *xp = x + n * x_bs + (int64_t)g * 8 * S + s;
@@ -85,6 +86,28 @@ mul_broadcast_c8_kernel(const _Float16 *__restrict__ feat, const float *__restri
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)v[e] * w);
     *reinterpret_cast<h8 *>(out + n * o_bs + ((int64_t)g * S + s) * 8) = o;
+}
+
+// split mode: out = (hi + lo) * occ, re-split (the product of the pair's VALUE with the occupancy, not of its halves)
+__global__ void __launch_bounds__(256)
+mul_broadcast_c8_split_kernel(const _Float16 *__restrict__ fh, const _Float16 *__restrict__ fl, const float *__restrict__ occ,
+                              _Float16 *__restrict__ oh, _Float16 *__restrict__ ol, int64_t S, int64_t f_bs, int64_t o_bs) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int g = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const h8 a = *reinterpret_cast<const h8 *>(fh + n * f_bs + ((int64_t)g * S + s) * 8);
+    const h8 b = *reinterpret_cast<const h8 *>(fl + n * f_bs + ((int64_t)g * S + s) * 8);
+    const float w = occ[n * S + s];
+    h8 o, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = ((float)a[e] + (float)b[e]) * w;
+        o[e] = (_Float16)v;
+        l[e] = (_Float16)(v - (float)o[e]);
+    }
+    *reinterpret_cast<h8 *>(oh + n * o_bs + ((int64_t)g * S + s) * 8) = o;
+    *reinterpret_cast<h8 *>(ol + n * o_bs + ((int64_t)g * S + s) * 8) = l;
 }
 
 // AvgPool3d((4,1,1)) of a C8 tensor [N][G][D][HW][8] into the fp32 NCDHW tensor [N][C][D/4][HW] the 2D neck reads
@@ -151,7 +174,7 @@ int snvc_f16_to_ncdhw(const void *x, float *y, int64_t N, int64_t C, int64_t S, 
 }
 
 int snvc_f16x3_from_ncdhw(const float *x, void *y_hi, void *y_lo, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
-                          int64_t y_batch_stride, float mul, void *stream) {
+                          int64_t y_batch_stride, float mul, const float *mul_dev, void *stream) {
     using namespace snvc;
     if (N < 0 || C <= 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_from_ncdhw: bad sizes");
     if (N == 0 || S == 0) return SNVC_OK;
@@ -162,7 +185,7 @@ int snvc_f16x3_from_ncdhw(const float *x, void *y_hi, void *y_lo, int64_t N, int
     dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)G, (unsigned)N);
     ncdhw_f32_to_c8_split_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, reinterpret_cast<_Float16 *>(y_hi), reinterpret_cast<_Float16 *>(y_lo),
                                                                      (int)C, S, x_batch_stride ? x_batch_stride : C * S,
-                                                                     y_batch_stride ? y_batch_stride : G * 8 * S, mul);
+                                                                     y_batch_stride ? y_batch_stride : 2 * G * 8 * S, mul, mul_dev);
     return check_launch("snvc_f16x3_from_ncdhw");
 }
 
@@ -177,7 +200,7 @@ int snvc_f16x3_to_ncdhw(const void *x_hi, const void *x_lo, float *y, int64_t N,
     if (!grid_ok(S, G, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_to_ncdhw: tensor too large");
     dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)G, (unsigned)N);
     c8_split_to_ncdhw_f32_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const _Float16 *>(x_hi), reinterpret_cast<const _Float16 *>(x_lo),
-                                                                     y, (int)C, S, x_batch_stride ? x_batch_stride : G * 8 * S,
+                                                                     y, (int)C, S, x_batch_stride ? x_batch_stride : 2 * G * 8 * S,
                                                                      y_batch_stride ? y_batch_stride : C * S, mul);
     return check_launch("snvc_f16x3_to_ncdhw");
 }
@@ -196,6 +219,23 @@ int snvc_f16_mul_broadcast(const void *feat, const float *occ, void *out, int64_
                                                                 feat_batch_stride ? feat_batch_stride : C * S,
                                                                 out_batch_stride ? out_batch_stride : C * S);
     return check_launch("snvc_f16_mul_broadcast");
+}
+
+int snvc_f16x3_mul_broadcast(const void *feat_hi, const void *feat_lo, const float *occ, void *out_hi, void *out_lo, int64_t N,
+                             int64_t C, int64_t S, int64_t feat_batch_stride, int64_t out_batch_stride, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || C % 8 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_mul_broadcast: bad sizes (C % 8 == 0)");
+    if (N == 0 || S == 0) return SNVC_OK;
+    if (!feat_hi || !feat_lo || !occ || !out_hi || !out_lo ||
+        ((reinterpret_cast<uintptr_t>(feat_hi) | reinterpret_cast<uintptr_t>(feat_lo) | reinterpret_cast<uintptr_t>(out_hi) |
+          reinterpret_cast<uintptr_t>(out_lo)) & 15))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_mul_broadcast: null or unaligned pointer");
+    if (!grid_ok(S, C / 8, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_mul_broadcast: tensor too large");
+    dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)(C / 8), (unsigned)N);
+    mul_broadcast_c8_split_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+        reinterpret_cast<const _Float16 *>(feat_hi), reinterpret_cast<const _Float16 *>(feat_lo), occ, reinterpret_cast<_Float16 *>(out_hi),
+        reinterpret_cast<_Float16 *>(out_lo), S, feat_batch_stride ? feat_batch_stride : 2 * C * S, out_batch_stride ? out_batch_stride : 2 * C * S);
+    return check_launch("snvc_f16x3_mul_broadcast");
 }
 
 int snvc_f16_avgpool_depth4(const void *x, float *y, int64_t N, int64_t C, int64_t D, int64_t HW, int64_t x_batch_stride,

@@ -48,6 +48,7 @@ _GENERATION = [0]   # bumped by invalidate_plans(): part of every cache key
 
 # How often each fused route was taken (tests assert on it: a silent regression to a slower or to a torch route shows)
 import collections
+import math
 _ROUTES = collections.Counter()
 TRAIN_EXACT_K57 = [False]     # True: k5 / k7 layers under autograd on the direct kernels (exact fp32 FMA chains) instead of Winograd
 
@@ -73,7 +74,7 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
 # convolution's split weights for inference and training, the persistent inference workspace, the device copy of the
 # coordinate maps).  invalidate_plans() drops exactly these; tests/test_host_cpu.py checks that no other `_snvc_*`
 # name is written anywhere in the package.
-CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans2d", "_snvc_plans2d_t", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
+CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans_x3", "_snvc_plans2d", "_snvc_plans2d_t", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
                "_snvc_coor_maps", "_snvc_x3", "_snvc_x3_off", "_snvc_last_v1")
 
 
@@ -867,6 +868,93 @@ def fused_conv3d_f16(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor
     return plan.layer(x, scale, bias, residual, flags, out)
 
 
+# ------------------------------------------------------------------------------------------
+# split mode ("f16x3", r4): inference with frozen statistics on the snvc_f16x3_* kernels -- the fp32 layers at fp32 accuracy on
+# the half-precision matrix pipe (csrc/conv3d_f16.hip, F16Cfg::PL).  A tensor travels as SplitT: the (hi, lo) pair,
+# the power of two its values are stored times (an int exponent, or a one-element device tensor when the range is only known
+# from the data), and the bound |value| is promised to stay below (None for data-scaled tensors: they cannot overflow).
+# ------------------------------------------------------------------------------------------
+X3_SIGMAS = 64.0     # a BatchNorm output is promised to stay below |beta| + X3_SIGMAS * |gamma|
+
+
+class SplitT:
+    __slots__ = ("t", "exp", "mul_dev", "bound")
+
+    def __init__(self, t, exp=0, bound=None, mul_dev=None):
+        self.t, self.exp, self.bound, self.mul_dev = t, exp, bound, mul_dev
+
+    def slice_groups(self, lo: int, hi: int):
+        """Channel groups [lo, hi) of the pair (a view: split tensors are [N, 2, C/8, D, H, W, 8])."""
+        return SplitT(self.t[:, :, lo:hi], self.exp, self.bound, self.mul_dev)
+
+
+def x3_exponent(bound: float) -> int:
+    """e with bound * 2^e <= 2^15 (half overflows at 65504; a value beyond the bound is clamped and FLAGGED)."""
+    if not (bound > 0.0) or not math.isfinite(bound):
+        return 0
+    return max(-14, min(14, 15 - math.frexp(bound)[1]))
+
+
+def x3_norm_bound(norm, plan) -> float:
+    """|beta| + X3_SIGMAS * |gamma| of a frozen BatchNorm3d, maximised over channels (cached with the folded affine)."""
+    key = getattr(plan, "bn_key", None)
+    hit = getattr(plan, "x3_bound", None)
+    if hit is None or hit[0] != key or key is None:
+        _folded_bn(norm, plan)
+        g = norm.weight.detach().abs() if norm.weight is not None else torch.ones(1, device=norm.running_mean.device)
+        b = norm.bias.detach().abs() if norm.bias is not None else torch.zeros(1, device=norm.running_mean.device)
+        hit = plan.x3_bound = (plan.bn_key, float((b + X3_SIGMAS * g).max().item()))
+    return hit[1]
+
+
+def x3_ok(*modules) -> bool:
+    """Every norm a frozen BatchNorm3d (eval mode, running statistics), nothing to differentiate."""
+    if torch.is_grad_enabled():
+        return False
+    for m in modules:
+        for n in m.modules():
+            if isinstance(n, nn.GroupNorm) or (isinstance(n, nn.modules.batchnorm._BatchNorm) and (n.training or n.running_mean is None)):
+                return False
+    return True
+
+
+def fused_conv3d_x3(conv: nn.Module, norm: Optional[nn.Module], x: SplitT, *, relu=False, sigmoid=False, residual: Optional[SplitT] = None,
+                    residual_after_act=False, out=None, out_exp: Optional[int] = None, to_f32=False, flag=None):
+    """``fused_conv3d`` in split mode: returns a SplitT (or, ``to_f32`` / a one-channel layer, a float32 tensor).  The result's
+    exponent is ``out_exp`` if given (a slice of a larger pair must share the pair's), else chosen from the bound
+    |beta| + X3_SIGMAS |gamma| (+ the residual's bound)."""
+    plan = conv.__dict__.setdefault("_snvc_plans_x3", {}).setdefault(x.t.device, _Plan())
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
+    if plan.layer is None or plan.key != key:
+        k, s_, p_, d_, transposed = _conv_geometry(conv)
+        plan.layer = ops.Conv3dLayerX3(w.detach(), k, s_, p_, d_, transposed)
+        plan.key = key
+    scale = bias = None
+    bound = None
+    if norm is not None:
+        scale, bias = _folded_bn(norm, plan)
+        bound = x3_norm_bound(norm, plan)
+    flags = (EPI_RELU if relu else 0) | (EPI_SIGMOID if sigmoid else 0)
+    f32 = to_f32 or plan.layer.cout == 1
+    res_t = None
+    if residual is not None:
+        flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
+        if residual.bound is None or bound is None:
+            raise RuntimeError("split mode: a residual add needs bounds on both summands")
+        bound = bound + residual.bound
+        res_t = residual.t
+    if not f32:
+        if bound is None:
+            raise RuntimeError("split mode: a layer without a frozen norm has no a-priori bound; ask for a float32 result")
+        e = x3_exponent(bound) if out_exp is None else out_exp
+    else:
+        e = residual.exp if residual is not None else 0
+    y = plan.layer(x.t, 0 if x.mul_dev is not None else x.exp, scale, bias, residual=res_t, flags=flags, out=out, out_exp=e,
+                   to_f32=f32, overflow=flag, x_mul_dev=x.mul_dev, res_exp=residual.exp if residual is not None else None)
+    return y if f32 else SplitT(y, e, bound)
+
+
 class ConvBN3d(nn.Sequential):
     """``Sequential(Conv3d | ConvTranspose3d, BatchNorm3d | GroupNorm)`` -- the object convbn_3d
     returns in the reference (keys ``0.weight``, ``1.weight``, ``1.bias``, ``1.running_mean``, ...)."""
@@ -880,6 +968,9 @@ class ConvBN3d(nn.Sequential):
     def fused_f16(self, x, **kw):
         return fused_conv3d_f16(self[0], self[1], x, **kw)
 
+    def fused_x3(self, x, **kw):
+        return fused_conv3d_x3(self[0], self[1], x, **kw)
+
 
 class HipConv3d(nn.Conv3d):
     """A bare nn.Conv3d(bias=False) (classifier, fg_cls_head[2], part_reg_head[2]) on the HIP kernel."""
@@ -892,6 +983,9 @@ class HipConv3d(nn.Conv3d):
 
     def fused_f16(self, x, **kw):
         return fused_conv3d_f16(self, None, x, **kw)
+
+    def fused_x3(self, x, **kw):
+        return fused_conv3d_x3(self, None, x, **kw)
 
 
 def convbn_3d(in_planes, out_planes, kernel_size, stride, pad, dilation=1, gn=False, groups=32):
@@ -919,6 +1013,10 @@ class ConvBNReLU3d(nn.Sequential):
     def fused_f16(self, x, **kw):
         kw.setdefault("relu", True)
         return self[0].fused_f16(x, **kw)
+
+    def fused_x3(self, x, **kw):
+        kw.setdefault("relu", True)
+        return self[0].fused_x3(x, **kw)
 
 
 class disparityregression(nn.Module):
@@ -964,6 +1062,15 @@ class hourglass(nn.Module):
         o = self.conv4(o)                                                   # 1/4 res
         post = self.conv5.fused(o, relu=True, residual=presqu if presqu is not None else pre_skip)  # :161-164
         o = self.conv6.fused(post, residual=residual, out=out, head=head, head_residual=head_residual)   # :166
+        return o, pre, post
+
+    def forward_x3(self, x, residual=None, out=None, out_exp=None, flag=None):
+        """The same graph in split mode (SplitT in / out; presqu / postsqu = None as the callers on the path use it)."""
+        o = self.conv1.fused_x3(x, flag=flag)
+        pre = self.conv2.fused_x3(o, relu=True, flag=flag)
+        o = self.conv4.fused_x3(self.conv3.fused_x3(pre, flag=flag), flag=flag)
+        post = self.conv5.fused_x3(o, relu=True, residual=pre, flag=flag)
+        o = self.conv6.fused_x3(post, residual=residual, out=out, out_exp=out_exp, flag=flag)
         return o, pre, post
 
     def forward_f16(self, x, presqu=None, postsqu=None, residual=None, out=None):
@@ -1015,6 +1122,18 @@ class hourglass_downsample_16(nn.Module):
         i11 = self.conv10.fused(i10, residual=o4)   # out_conv10 + out_conv4  :261-262
         i12 = self.conv11.fused(i11, residual=o2)   # out_conv11 + out_conv2  :264-266
         return self.conv12.fused(i12, residual=residual, out=out)
+
+    def forward_x3(self, x, residual=None, out=None, out_exp=None, flag=None):
+        """The same graph in split mode (SplitT in / out)."""
+        f = lambda seq, t, **kw: seq.fused_x3(t, flag=flag, **kw)                              # noqa: E731
+        o2 = f(self.conv2, f(self.conv1, x))
+        o4 = f(self.conv4, f(self.conv3, o2))
+        o6 = f(self.conv6, f(self.conv5, o4))
+        o8 = f(self.conv8, f(self.conv7, o6))
+        i10 = f(self.conv9, o8, residual=o6)
+        i11 = f(self.conv10, i10, residual=o4)
+        i12 = f(self.conv11, i11, residual=o2)
+        return f(self.conv12, i12, residual=residual, out=out, out_exp=out_exp)
 
     def forward_f16(self, x, residual=None, out=None):
         """The same graph on C8 half tensors (fp16-storage mode)."""

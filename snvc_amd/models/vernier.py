@@ -151,8 +151,92 @@ class VernierScale(nn.Module):
         return self._sample_2d_feat(left, right, grid_proj_left, grid_proj_right)
 
     # ------------------------------------------------------------------ a7: 3D trunk
+    # precision: "auto" (default: the 3D trunk in split mode at inference when it qualifies), "f32" (fp32-MFMA kernels only),
+    # "x3" (split mode or an error), "f16" (the fp16-STORAGE mode of BASELINE configs[4]: forward() gathers into C8 halves)
+    precision = "auto"
+
+    def _x3_local(self, voxel):
+        """The split-mode bookkeeping of this model (overflow flag + its pinned host copy) if this call runs the trunk in split
+        mode, else None: inference only, frozen BatchNorm3d everywhere, channels a multiple of 32, no part_reg_head."""
+        from .submodule import x3_ok
+        mode = getattr(self, "precision", "auto")
+        want = mode == "x3"
+        if mode in ("f32", "f16") or self.__dict__.get("_snvc_x3_off"):
+            return None
+        ok = (voxel.is_cuda and voxel.dtype == torch.float32 and voxel.dim() == 5 and not hasattr(self, "part_reg_head")
+              and voxel.size(1) % 64 == 0 and not self.training
+              and x3_ok(self.vimg_feat, self.conv1, self.conv2, self.conv3, self.conv4, self.hg_conv3d, self.fg_cls_head))
+        if not ok:
+            if want:
+                raise RuntimeError("precision='x3': the trunk does not qualify (inference, eval-mode BatchNorm3d, 2F % 64 == 0)")
+            return None
+        st = self.__dict__.get("_snvc_x3")
+        if st is None or st["flag"].device != voxel.device:
+            st = self.__dict__["_snvc_x3"] = {"flag": torch.zeros(1, dtype=torch.int32, device=voxel.device),
+                                              "flag_host": torch.zeros(1, dtype=torch.int32).pin_memory(), "flag_event": None}
+        ev = st["flag_event"]
+        if ev is not None and ev.query():        # the previous call's overflow flag has arrived (no sync)
+            st["flag_event"] = None
+            if int(st["flag_host"].item()) != 0:
+                import warnings
+                from .submodule import X3_SIGMAS
+                self.__dict__["_snvc_x3_off"] = True
+                warnings.warn("snvc_amd: split-mode (f16x3) overflow in the local trunk -- an activation exceeded |beta| + %g |gamma| of "
+                              "its BatchNorm; the previous result clamped it.  This model now runs on the fp32-MFMA kernels." % X3_SIGMAS)
+                if want:
+                    raise RuntimeError("precision='x3': overflow flagged by the previous call")
+                return None
+        return st
+
+    def trunk_3d_x3(self, voxel, st):
+        """``trunk_3d`` (reference vernier.py:415-438) in split mode: the same fp32 layers, every product three
+        half-precision MFMAs on (hi, lo) pairs with fp32 accumulation.  ``voxel`` is the fp32 gather result; it is scaled by a
+        power of two derived from its own maximum on the device (no host round trip) and split once; every later tensor's
+        exponent comes from its folded BatchNorm.  Returns the same float32 tensors as ``trunk_3d``."""
+        from .submodule import SplitT, x3_exponent, x3_norm_bound, _Plan
+        n, c2 = voxel.size(0), voxel.size(1)
+        g = c2 // 16                                                             # channel groups of F channels
+        flag = st["flag"]
+        mul = ops.split_scale_for(voxel)
+        vs = SplitT(ops.to_split(voxel, mul_dev=mul), 0, None, mul)
+
+        def nb(seq):        # the bound of a ConvBN3d's result
+            conv, norm = seq[0], seq[1]
+            return x3_norm_bound(norm, conv.__dict__.setdefault("_snvc_plans_x3", {}).setdefault(voxel.device, _Plan()))
+        # the two halves of the concat of :433 share one exponent: both bounds are known from the parameters alone
+        b_v3 = nb(self.conv1[0]) + nb(self.conv2[0]) + nb(self.conv3[0])
+        last = self.hg_conv3d.conv6 if self.small else self.hg_conv3d.conv12
+        e_cat = x3_exponent(max(nb(last) + b_v3, nb(self.vimg_feat[0])))
+        img = self.vimg_feat.fused_x3(vs, out_exp=e_cat, flag=flag)             # :415
+        v = self.conv1.fused_x3(vs, flag=flag)                                   # :417
+        v = self.conv2.fused_x3(v, residual=v, residual_after_act=True, flag=flag)      # conv2(v) + v   :418
+        v = self.conv3.fused_x3(v, residual=v, residual_after_act=True, flag=flag)      # conv3(v) + v   :419
+        cat = torch.empty((n, 2, 2 * g) + tuple(v.t.shape[3:]), dtype=torch.float16, device=voxel.device)
+        dst = cat[:, :, :g]
+        if self.small:                                                           # :420-423
+            vh, _, _ = self.hg_conv3d.forward_x3(v, residual=v, out=dst, out_exp=e_cat, flag=flag)
+        else:
+            vh = self.hg_conv3d.forward_x3(v, residual=v, out=dst, out_exp=e_cat, flag=flag)
+        t = self.fg_cls_head[0].fused_x3(vh, relu=True, flag=flag)               # :427
+        occ = self.fg_cls_head[2].fused_x3(t, sigmoid=True)                      # float32 [N,1,nh,nw,nl]
+        ops.mul_broadcast_split(img.t, occ, out=cat[:, :, g:])                   # cat([v, img * occ])  :433
+        v = self.conv4.fused_x3(SplitT(cat, e_cat, max(vh.bound, img.bound)), to_f32=True)      # :435, float32 NCDHW
+        v = ops.avgpool_depth4(v)                                                # :436
+        if st["flag_event"] is None:     # the overflow flag travels to the host behind the call; the next call looks at it
+            st["flag_host"].copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["flag_event"] = ev
+        from .submodule import _ROUTES
+        _ROUTES["x3_local_trunk"] += 1
+        return v.reshape(n, -1, v.size(3), v.size(4)), occ, None                 # :437-438
+
     def trunk_3d(self, voxel):
         """reference vernier.py:415-438 -> (voxel_BEV [N, F*nh/4, nw, nl], occupancy [N,1,nh,nw,nl], offset)."""
+        if not torch.is_grad_enabled():
+            st = self._x3_local(voxel)
+            if st is not None:
+                return self.trunk_3d_x3(voxel, st)
         n, c2 = voxel.size(0), voxel.size(1)
         f = c2 // 2
         training_graph = torch.is_grad_enabled() and (voxel.requires_grad or any(p.requires_grad for p in self.parameters()))

@@ -1099,16 +1099,25 @@ def _split_check(t: torch.Tensor, name: str):
     _gpu(t, name)
     if t.dtype != torch.float16 or t.dim() != 7 or t.size(1) != 2 or t.size(6) != 8:
         raise RuntimeError(f"{name} must be a split C8 tensor: float16 [N, 2 (hi | lo), C/8, D, H, W, 8], got {tuple(t.shape)} {t.dtype}")
-    if not _dense_inner(t) or t.data_ptr() % 16:
-        raise RuntimeError(f"{name} must be dense below dim 0 and 16-byte aligned")
+    # dense from the channel-group axis down (a slice of channel groups of a larger pair qualifies: the plane and batch strides
+    # are passed to the kernels), 16-byte aligned pieces
+    exp = 1
+    for size, stride in zip(reversed(t.shape[2:]), reversed(t.stride()[2:])):
+        if size != 1 and stride != exp:
+            raise RuntimeError(f"{name} must be dense below its channel-group axis")
+        exp *= size
+    if t.data_ptr() % 16 or t.stride(1) % 8 or t.stride(0) % 8:
+        raise RuntimeError(f"{name} must be 16-byte aligned with plane / batch strides that are multiples of 8")
 
 
 def _lo_ptr(t: torch.Tensor):
     return ctypes.c_void_p(t.data_ptr() + 2 * t.stride(1)) if t.numel() else ctypes.c_void_p(0)
 
 
-def to_split(x: torch.Tensor, exp: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """float32 [N,C,D,H,W] -> split C8 [N, 2, ceil(C/8), D, H, W, 8] half with  x * 2**exp = hi + lo  (snvc_f16x3_from_ncdhw)."""
+def to_split(x: torch.Tensor, exp: int = 0, out: Optional[torch.Tensor] = None, mul_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 [N,C,D,H,W] -> split C8 [N, 2, ceil(C/8), D, H, W, 8] half with  x * 2**exp = hi + lo  (snvc_f16x3_from_ncdhw).
+    ``mul_dev``: a one-element float32 device tensor holding the scale (a power of two) instead of ``2**exp`` -- for an exponent
+    derived from the data on the device (``split_scale_for``) without a host round trip."""
     _gpu(x, "x")
     if x.dtype != torch.float32 or x.dim() != 5:
         raise RuntimeError("to_split needs a float32 [N,C,D,H,W] tensor")
@@ -1124,8 +1133,21 @@ def to_split(x: torch.Tensor, exp: int = 0, out: Optional[torch.Tensor] = None) 
         return out
     with torch.cuda.device(x.device):
         check(_lib.lib().snvc_f16x3_from_ncdhw(_ptr(x), _ptr(out), _lo_ptr(out), n, c, math.prod(sp), _batch_stride(x), _batch_stride(out),
-                                               float(2.0 ** exp), _stream(x)), "snvc_f16x3_from_ncdhw")
+                                               float(2.0 ** exp), _ptr(mul_dev), _stream(x)), "snvc_f16x3_from_ncdhw")
     return out
+
+
+def split_scale_for(*tensors) -> torch.Tensor:
+    """A one-element device tensor holding the power of two that puts max|t| over the given tensors into [2^13, 2^14) (1 for an
+    all-zero or non-finite input): the scale of a split pair whose range is only known from the data.  Device-side, no sync."""
+    amax = None
+    for t in tensors:
+        a = t.detach().abs().amax()
+        amax = a if amax is None else torch.maximum(amax, a)
+    amax = amax.float().reshape(1)
+    e = torch.floor(torch.log2(16384.0 / amax))
+    e = torch.where(torch.isfinite(e), e, torch.zeros_like(e)).clamp_(-24, 40)
+    return torch.exp2(e)
 
 
 def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) -> torch.Tensor:
@@ -1220,10 +1242,10 @@ class Conv3dLayerX3:
         return hit
 
     def __call__(self, x, x_exp: int = 0, scale=None, bias=None, residual=None, flags: int = 0, out=None, out_exp: int = 0,
-                 out_f32=None, to_f32: bool = False, head=None, overflow=None):
+                 out_f32=None, to_f32: bool = False, head=None, overflow=None, x_mul_dev=None, res_exp: Optional[int] = None):
         """y = epilogue(conv(x)).  x: split C8 tensor holding values * 2**x_exp.  Result: a split C8 tensor holding
-        y * 2**out_exp, or -- ``to_f32`` / ``out_f32`` -- float32 NCDHW (out_exp is then the residual's exponent).  ``residual``:
-        a split tensor holding values * 2**out_exp.  ``head`` [Cout = 32] weights: returns ``(y, y_head)`` with ``y_head`` the
+        y * 2**out_exp, or -- ``to_f32`` / ``out_f32`` -- float32 NCDHW.  ``residual``: a split tensor holding values *
+        2**res_exp (default: out_exp).  ``head`` [Cout = 32] weights: returns ``(y, y_head)`` with ``y_head`` the
         float32 [N,1,D,H,W] projection sum_c head[c] * y[:, c] written by the same launch.  ``overflow``: an int32 device
         tensor that is set to 1 if a value had to be clamped to half's range."""
         _split_check(x, "x")
@@ -1254,6 +1276,8 @@ class Conv3dLayerX3:
             y_head = torch.empty((n, 1) + out_sp, dtype=torch.float32, device=x.device)
         # with a float32 result the epilogue works in units of 2^out_exp too (the residual's) and scales back on the way out: exact
         sc, bi = self.folded(scale, bias, x_exp, out_exp)
+        if x_mul_dev is not None:           # x holds values * x_mul_dev (a device-side power of two, see split_scale_for); x_exp is 0
+            sc = (sc / x_mul_dev).contiguous()
         self.algo = self._pick_form(n, out_sp)
         packed = self._pack(self.algo)
         if n == 0:
@@ -1266,10 +1290,34 @@ class Conv3dLayerX3:
                                                        _ptr(residual), _lo_ptr(residual) if residual is not None else null,
                                                        null if f32 else _ptr(out), null if f32 else _lo_ptr(out),
                                                        _ptr(out_f32) if f32 else null, _ptr(head), _ptr(y_head), float(2.0 ** -out_exp),
+                                                       float(2.0 ** (out_exp - (out_exp if res_exp is None else res_exp))),
                                                        _ptr(overflow), _stream(x)), "snvc_f16x3_conv3d_forward")
         if f32:
             return out_f32          # the kernel multiplied by 2^-out_exp on the way out
         return (out, y_head) if head is not None else out
+
+
+def mul_broadcast_split(feat, occ, out=None):
+    """out = split((hi + lo) * occ[n, 0]) on split pairs (snvc_f16x3_mul_broadcast); occ: float32 [N,1,D,H,W]."""
+    _split_check(feat, "feat")
+    _gpu(occ, "occ")
+    occ = occ.contiguous()
+    n, g = feat.shape[0], feat.shape[2]
+    s_ = math.prod(feat.shape[3:6])
+    if occ.dtype != torch.float32 or occ.numel() != n * s_:
+        raise RuntimeError("occupancy must be float32 [N,1,D,H,W] matching the feature volume")
+    if out is None:
+        out = torch.empty(feat.shape, dtype=torch.float16, device=feat.device)
+    else:
+        _split_check(out, "out")
+        if tuple(out.shape) != tuple(feat.shape):
+            raise RuntimeError("mul_broadcast_split `out` must have feat's shape")
+    if feat.numel() == 0:
+        return out
+    with torch.cuda.device(feat.device):
+        check(_lib.lib().snvc_f16x3_mul_broadcast(_ptr(feat), _lo_ptr(feat), _ptr(occ), _ptr(out), _lo_ptr(out), n, 8 * g, s_,
+                                                  _batch_stride(feat), _batch_stride(out), _stream(feat)), "snvc_f16x3_mul_broadcast")
+    return out
 
 
 def mul_broadcast_c8(feat, occ, out=None):

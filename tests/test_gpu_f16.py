@@ -353,6 +353,44 @@ def _x3_reference(x, w, scale, bias, stride, transposed, relu, residual=None, pr
     return y
 
 
+@pytest.mark.parametrize("case", ["k1_64_32", "k5_32_32", "k5d2_32_32", "k7_64_32", "k7_128_64", "deconv_64_32", "k3_32_1"])
+def test_split_mode_local_trunk_layer_kinds_vs_float64(case):
+    """The other layer kinds of the local trunk in split mode (vernier.py:249-278: 1^3, 5^3, dilated 5^3, 7^3, the 32-channel
+    transposed layer, the one-channel occupancy head with its Sigmoid) against float64 at the exact-fp32 tolerance."""
+    from snvc_amd import ops
+    from test_gpu_parity import TIGHT, check
+    torch.manual_seed(len(case))
+    cin, cout, k, dil, transposed, shape = {
+        "k1_64_32": (64, 32, 1, 1, False, (5, 9, 40)), "k5_32_32": (32, 32, 5, 1, False, (7, 9, 37)),
+        "k5d2_32_32": (32, 32, 5, 2, False, (9, 10, 36)), "k7_64_32": (64, 32, 7, 1, False, (8, 9, 35)),
+        "k7_128_64": (128, 64, 7, 1, False, (5, 8, 33)), "deconv_64_32": (64, 32, 3, 1, True, (3, 5, 18)),
+        "k3_32_1": (32, 1, 3, 1, False, (6, 7, 38))}[case]
+    pad = 1 if transposed else dil * (k - 1) // 2
+    x = torch.relu(torch.randn(2, cin, *shape, device=dev())) * 2.0 + 0.01 * torch.randn(2, cin, *shape, device=dev())
+    w = torch.randn((cin, cout, 3, 3, 3) if transposed else (cout, cin, k, k, k), device=dev()) * np.sqrt(2.0 / (cin * k ** 3))
+    scale, bias = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.3
+    layer = ops.Conv3dLayerX3(w, k, 2 if transposed else 1, pad, dil, transposed)
+    xd, wd = x.double().cpu(), w.double().cpu()
+    raw = F.conv_transpose3d(xd, wd, None, 2, 1, 1) if transposed else F.conv3d(xd, wd, None, 1, pad, dil)
+    aff = raw * scale.double().cpu().view(1, -1, 1, 1, 1) + bias.double().cpu().view(1, -1, 1, 1, 1)
+    mul = ops.split_scale_for(x)                                    # the data-derived scale, as the trunk's first layers get it
+    xs = ops.to_split(x, mul_dev=mul)
+    if cout == 1:
+        y = layer(xs, 0, scale, bias, flags=ops.EPI_SIGMOID, x_mul_dev=mul)
+        assert y.dtype == torch.float32 and tuple(y.shape) == (2, 1) + shape
+        check(y.cpu().numpy(), torch.sigmoid(aff).numpy(), TIGHT, f"{case}: occupancy head")
+        return
+    ref = torch.relu(aff)
+    ys = layer(xs, 0, scale, bias, flags=ops.EPI_RELU, out_exp=3, x_mul_dev=mul)
+    check(ops.from_split(ys, 3).cpu().numpy(), ref.numpy(), TIGHT, f"{case}: split -> split, data-scaled input")
+    y32 = layer(ops.to_split(x, 2), 2, scale, bias, flags=ops.EPI_RELU, to_f32=True)
+    check(y32.cpu().numpy(), ref.numpy(), TIGHT, f"{case}: split -> float32")
+    # a residual stored with another exponent than the result (res_mul), after the activation: the trunk's conv2(v) + v
+    res = torch.randn_like(y32)
+    yr = layer(xs, 0, scale, bias, residual=ops.to_split(res, 5), res_exp=5, flags=ops.EPI_RELU | ops.EPI_ADD_POST, out_exp=2, x_mul_dev=mul)
+    check(ops.from_split(yr, 2).cpu().numpy(), (ref + res.double().cpu()).numpy(), TIGHT, f"{case}: residual with its own exponent")
+
+
 @pytest.mark.parametrize("case", ["k3_32_32", "k3_64_64", "k3_32_64", "k3s2_32_64", "k3s2_64_64", "deconv_64_64", "k3_32_32_odd"])
 def test_split_mode_layers_vs_float64(case):
     from snvc_amd import ops
@@ -419,4 +457,4 @@ def test_split_mode_side_head_and_overflow_flag():
     big = layer(xs, 4, scale, bias, flags=ops.EPI_RELU, out_exp=16, overflow=flag)
     assert flag.item() == 1 and torch.isfinite(big.float()).all()
     with pytest.raises(RuntimeError):
-        ops.Conv3dLayerX3(torch.randn(32, 32, 5, 5, 5, device=dev()), 5, 1, 2, 1, False)       # k5: not built
+        ops.Conv3dLayerX3(torch.randn(32, 32, 5, 5, 5, device=dev()), 5, 2, 2, 1, False)       # a stride-2 k5 layer: not on the path

@@ -197,6 +197,7 @@ def test_local_trunk_full_size(grid):
     from snvc_amd import ops
     from snvc_amd.models.submodule import _folded_bn, _get_layer, _Plan
     m = _local_model(grid)
+    m.precision = "f32"          # this test walks the fp32-MFMA kernels layer by layer; the split-mode trunk has its own test below
     f = 32
     r = np.random.default_rng(7)
     lf = torch.from_numpy(r.standard_normal((1, f, 64, 64)).astype(np.float32)).to(dev())
@@ -266,6 +267,48 @@ def test_local_trunk_full_size(grid):
         assert bev.shape == bev_ref.shape and torch.isfinite(bev).all()
         assert (bev - bev_ref).abs().max().item() <= 1e-5 * bev_ref.abs().max().item()
         assert (occ2 - occ).abs().max().item() <= 1e-6
+
+
+@pytest.mark.parametrize("grid", [(32, 128, 192), (96, 96, 96)], ids=["released_32x128x192", "cfg3_crop_96"])
+def test_local_trunk_split_mode_full_size(grid):
+    """The local trunk in split mode (the default at inference) at full size: the 7^3 / 5^3 / dilated 5^3 / 1^3 layers
+    on the gather's own output against torch-CPU on crops at the EXACT-fp32 tolerance (2e-5: the fp32 Winograd F(4,7) form needs
+    4e-4), and the whole trunk against the fp32-MFMA trunk (whose own error, F(4,7)'s 1e-4, bounds the comparison)."""
+    import bench
+    from snvc_amd import ops
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.submodule import SplitT
+    m = _local_model(grid)
+    f = 32
+    r = np.random.default_rng(7)
+    lf = torch.from_numpy(r.standard_normal((1, f, 64, 64)).astype(np.float32)).to(dev())
+    rf = torch.from_numpy(r.standard_normal((1, f, 64, 64)).astype(np.float32)).to(dev())
+    pl, pr = bench.projected_coordinates(1, grid, dev())
+    with torch.no_grad():
+        vox = m.construct_voxel(lf, rf, pl, pr)
+        before = S._ROUTES["x3_local_trunk"]
+        bev, occ, _ = m.trunk_3d(vox)                                   # precision "auto": split mode
+        assert S._ROUTES["x3_local_trunk"] == before + 1
+        assert int(m.__dict__["_snvc_x3"]["flag"].item()) == 0         # nothing was clamped
+        m.precision = "f32"
+        bev32, occ32, _ = m.trunk_3d(vox)
+        assert S._ROUTES["x3_local_trunk"] == before + 1
+        e = (bev - bev32).abs().max().item() / bev32.abs().max().item()
+        assert e < 3e-4, f"split-mode trunk vs fp32-MFMA trunk (BEV features): {e:.2e}"
+        assert (occ - occ32).abs().max().item() < 3e-4          # sigmoid outputs in [0, 1]; the fp32 trunk carries F(4,7)'s 1e-4
+        # layer by layer on the same input, against torch-CPU on crops
+        mul = ops.split_scale_for(vox)
+        vs = SplitT(ops.to_split(vox, mul_dev=mul), 0, None, mul)
+        img = m.vimg_feat.fused_x3(vs)
+        _check_layer_spots(m.vimg_feat[0], vox, ops.from_split(img.t, img.exp), tol=2e-5, what="split vimg_feat k1")
+        v1 = m.conv1.fused_x3(vs)
+        v1f = ops.from_split(v1.t, v1.exp)
+        _check_layer_spots(m.conv1[0], vox, v1f, tol=2e-5, what="split conv1 k7")
+        v2 = m.conv2.fused_x3(v1, residual=v1, residual_after_act=True)
+        v2f = ops.from_split(v2.t, v2.exp)
+        _check_layer_spots(m.conv2[0], v1f, v2f, residual=v1f, after_act=True, tol=2e-5, what="split conv2 k5")
+        v3 = m.conv3.fused_x3(v2, residual=v2, residual_after_act=True)
+        _check_layer_spots(m.conv3[0], v2f, ops.from_split(v3.t, v3.exp), residual=v2f, after_act=True, tol=2e-5, what="split conv3 k5 dil2")
 
 
 def test_training_step_full_size_properties():
