@@ -775,13 +775,16 @@ def main():
             },
             "materialized": {
                 "note": "same step with the full concat volume built in HBM (what the reference does, and what this library "
-                        "does whenever the volume is looked at): build_cost_volume_cuda.build_cost_volume_forward, "
+                        "does whenever the volume is written to): build_cost_volume_cuda.build_cost_volume_forward, "
                         "conv1 runs over all 64 channels",
                 "value": world * args.steps / elapsed_mat,
                 "ms_per_step": 1e3 * elapsed_mat / args.steps,
                 "conv1_ms": conv_ms_mat,
                 "conv1_tflops_algorithmic": alg_tflops_mat,
-                "conv1_pipe_frac": alg_tflops_mat * share / PEAK_F32_MFMA_TFLOPS,
+                # split mode: three half-precision MFMAs per product against the f16 peak; fp32 form: Winograd's 6/12 against the fp32 peak
+                "conv1_pipe_frac": (alg_tflops_mat * share_x3 / PEAK_F16_MFMA_TFLOPS if x3_taken else alg_tflops_mat * share / PEAK_F32_MFMA_TFLOPS),
+                "conv1_kernel": ("conv3d_f16_kernel<k3, split mode> 64->32 after a layout pass of the 1.47 GB volume (snvc_f16x3_from_ncdhw)"
+                                 if x3_taken else "conv3d_wino_dma_kernel 64->32 (fp32 Winograd F(4,3))"),
                 "conv1_flop_per_launch": CONV1_FLOP,
             },
             "step_tflops_algorithmic": STEP_FLOP / (elapsed / args.steps) / 1e12,

@@ -232,13 +232,40 @@ class GlobalStack(nn.Module):
                 left, right, shift, ds = volume.sources
                 if left.shape[1] * 2 == self.conv1[0][0].in_channels and left.shape[3] % 4 == 0:
                     return self.forward_pair(left, right, shift, ds, shift_checked=True, spacing=volume.spacing)
-            volume = volume.materialize()
+            # built from these two features: its maximum is theirs (interpolation weights are in [0, 1]), if they are untouched
+            scale_from = tuple(volume.sources[:2]) if volume.sources_unchanged else None
+            return self._forward_volume(volume.materialize(), scale_from=scale_from)
+        return self._forward_volume(volume)
+
+    def _forward_volume(self, volume, timing=None, arithmetic=None, scale_from=None):
+        """conv1 over a materialised [N, 2C, D, H, W] volume, then the tail.  Split mode (r4): the volume is scaled by a power of
+        two derived on the device from its own maximum (or from the features it was built from, ``scale_from``: the volume holds
+        nothing but their values and interpolations) and split once, conv1 runs on the split-mode kernel and writes the pair
+        conv2 reads."""
         if torch.is_grad_enabled() or not volume.is_cuda:
             return self._tail(self.conv2(self.conv1(volume)))
         n, c2 = volume.size(0), volume.size(1)
         shape = (n, c2 // 2) + tuple(volume.shape[2:])
+        st = self._x3_select(volume.device, arithmetic) if (volume.dtype == torch.float32 and c2 % 16 == 0) else None
+        if st is not None:
+            from .submodule import SplitT
+            mul = ops.split_scale_for(*(scale_from if scale_from is not None else (volume,)))
+            vs = ops.to_split(volume, mul_dev=mul, out=self._buffer("vol_s", (n, 2, c2 // 8) + tuple(volume.shape[2:]) + (8,), volume.device,
+                                                                      torch.float16))
+            v1s = self._buffer("v1s", (n, 2, c2 // 16) + tuple(volume.shape[2:]) + (8,), volume.device, torch.float16)
+            if timing is not None and "conv1" in timing:
+                timing["conv1"][0].record()
+            self.conv1.fused_x3(SplitT(vs, 0, None, mul), out=v1s, out_exp=st["exp"]["v1"], flag=st["flag"])
+            if timing is not None and "conv1" in timing:
+                timing["conv1"][1].record()
+            self.__dict__["_snvc_last_v1"] = "v1s"
+            return self._tail_x3(st, v1s, timing)
+        if timing is not None and "conv1" in timing:
+            timing["conv1"][0].record()
         v = self.conv1.fused(volume, out=self._buffer("v1", shape, volume.device))
-        return self._conv2_tail(v, shape)
+        if timing is not None and "conv1" in timing:
+            timing["conv1"][1].record()
+        return self._conv2_tail(v, shape, timing, arithmetic)
 
     @staticmethod
     def _shift_structure(shift):
@@ -372,17 +399,13 @@ class GlobalStack(nn.Module):
             mark("volume", 0)
             vol = ops.cost_volume_forward(left, right, shift, downsample)
             mark("volume", 1)
-            mark("conv1", 0)
             if torch.is_grad_enabled():
+                mark("conv1", 0)
                 v = self.conv1(vol)
                 mark("conv1", 1)
                 del vol
                 return self._tail(self.conv2(v))
-            shape, device = (vol.size(0), vol.size(1) // 2) + tuple(vol.shape[2:]), vol.device
-            v = self.conv1.fused(vol, out=self._buffer("v1", shape, device))
-            mark("conv1", 1)
-            del vol
-            return self._conv2_tail(v, shape, timing, arithmetic)
+            return self._forward_volume(vol, timing, arithmetic, scale_from=(left, right))
         # The one device -> host sync of the step (the wrapper's `assert shift >= 0`, here also the shift array's spacing) is
         # STARTED first and awaited only after everything that does not need its answer has been queued: the left half's
         # planes, and -- speculatively, for the spacing the previous call saw -- the sheared layer's two small 2D convolutions.

@@ -1142,7 +1142,8 @@ def split_scale_for(*tensors) -> torch.Tensor:
     all-zero or non-finite input): the scale of a split pair whose range is only known from the data.  Device-side, no sync."""
     amax = None
     for t in tensors:
-        a = t.detach().abs().amax()
+        lo, hi = torch.aminmax(t.detach())                  # one read pass (abs().amax() would write a temporary of t's size)
+        a = torch.maximum(-lo, hi)
         amax = a if amax is None else torch.maximum(amax, a)
     amax = amax.float().reshape(1)
     e = torch.floor(torch.log2(16384.0 / amax))
