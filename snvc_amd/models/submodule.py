@@ -20,7 +20,8 @@ output, so they take three launches (conv, statistics, normalise+activation).
 
 The 2D helpers at the bottom (convbn, hourglass2d, ...) keep torch.nn's
 module tree; their inference forward runs on the depth-1 form of the same HIP conv kernels
-(``fused_conv2d`` / ``fused_deconv2d``), training and GroupNorm on the modules' own torch forward.
+(``fused_conv2d`` / ``fused_deconv2d``); under autograd / with train-mode BatchNorm the same kernels sit behind
+``_Conv2dNormActFn`` (r4: HIP backward -- epilogue reductions, data gradient as a twin layer, deterministic weight gradient).
 """
 from typing import Optional
 
@@ -130,6 +131,9 @@ def _folded_bn(bn: nn.BatchNorm3d, plan: _Plan):
     return plan.scale, plan.bias
 
 
+_BatchNormNd = (nn.BatchNorm3d, nn.BatchNorm2d)      # the 2D neck's layers run as depth-1 3D layers (raw is 5-D either way)
+
+
 def _norm_from_raw(raw, norm, plan, residual, flags, out=None):
     """norm + residual + activation of an already computed conv output `raw` (kept for the backward pass):
     returns (y, scale, shift, mean, var, per_sample)."""
@@ -137,14 +141,14 @@ def _norm_from_raw(raw, norm, plan, residual, flags, out=None):
         if flags or residual is not None:
             return ops.affine_act(raw, None, None, residual, flags, out=out), None, None, None, None, False
         return raw, None, None, None, None, False
-    if isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None):
+    if isinstance(norm, _BatchNormNd) and not (norm.training or norm.running_mean is None):
         scale, bias = _folded_bn(norm, plan)
         return ops.affine_act(raw, scale, bias, residual, flags, out=out), scale, bias, None, None, False
     c = raw.size(1)
     if isinstance(norm, nn.GroupNorm):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
         return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=out), scale, shift, mean, var, True
-    if isinstance(norm, nn.BatchNorm3d):
+    if isinstance(norm, _BatchNormNd):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, c, False, norm.eps)
         _bn_track(norm, mean, var, raw.numel() / c)      # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
         return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=out), scale, shift, mean, var, False
@@ -1155,21 +1159,122 @@ class hourglass_downsample_16(nn.Module):
 # compute takes the modules' own torch forward.
 # ------------------------------------------------------------------------------------------
 def _hip_2d_ok(x: torch.Tensor, *modules) -> bool:
-    """The HIP path of the 2D neck (kernels without a backward): a float32 GPU tensor, every norm of ``modules`` an
-    eval-mode BatchNorm2d (folded into the conv epilogue) or a GroupNorm (conv -> statistics -> normalise + residual +
-    activation, three launches like the 3D layers), and NOTHING to differentiate -- autograd off, or neither the input
-    nor any parameter of the modules requires grad (a frozen trunk with trainable heads must keep the torch forward, or
-    the heads would silently get no gradient).  Every decision is counted in ``_ROUTES`` ("neck2d_hip" / "neck2d_torch")."""
+    """The HIP path of the 2D neck: a float32 GPU tensor and every norm of ``modules`` a BatchNorm2d or a GroupNorm.
+    Nothing to differentiate and eval-mode BatchNorm: one fused launch per layer (norm folded into the epilogue; GroupNorm:
+    conv -> statistics -> normalise + residual + activation, like the 3D layers).  Autograd on with something that requires
+    grad, or train-mode BatchNorm: the same kernels behind ``_Conv2dNormActFn`` (r4) -- forward conv -> statistics ->
+    normalise, backward on the HIP epilogue-backward reductions, the data gradient as another depth-1 layer of the family
+    and the deterministic weight gradient -- so ``VernierScale`` trains through its neck natively (reference
+    vernier.py:296-313,438-450).  Every decision is counted in ``_ROUTES``: "neck2d_hip" / "neck2d_torch" per block,
+    "neck2d_hip_train" per layer that went through the autograd function."""
     if not x.is_cuda:
         raise RuntimeError("2D neck input must be a GPU tensor: Not implemented on the CPU")
-    ok = x.dtype == torch.float32
-    if ok and torch.is_grad_enabled():
-        ok = not (x.requires_grad or any(p.requires_grad for m in modules for p in m.parameters()))
-    if ok:
-        ok = all(isinstance(n, nn.GroupNorm) or (isinstance(n, nn.BatchNorm2d) and not n.training and n.running_mean is not None)
-                 for m in modules for n in _norms2d(m))
+    norms = [n for m in modules for n in _norms2d(m)]
+    ok = x.dtype == torch.float32 and all(isinstance(n, (nn.GroupNorm, nn.BatchNorm2d)) for n in norms)
+    if ok and not NECK2D_HIP_TRAINING[0]:
+        ok = not _wants_grad2d(x, *modules) and all(isinstance(n, nn.GroupNorm) or (not n.training and n.running_mean is not None)
+                                                    for n in norms)
     _ROUTES["neck2d_hip" if ok else "neck2d_torch"] += 1
     return ok
+
+
+NECK2D_HIP_TRAINING = [True]      # False: rounds 2-3's behaviour (anything with a gradient keeps the modules' torch forward)
+
+
+def _wants_grad2d(x, *modules) -> bool:
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in modules for p in m.parameters()))
+
+
+def _train2d(x, conv, norm, residual) -> bool:
+    """This layer goes through the autograd function: something to differentiate, or batch statistics to take."""
+    if isinstance(norm, nn.BatchNorm2d) and (norm.training or norm.running_mean is None):
+        return True
+    mods = (conv,) if norm is None else (conv, norm)
+    return _wants_grad2d(x, *mods) or (torch.is_grad_enabled() and residual is not None and residual.requires_grad)
+
+
+class _Conv2dNormActFn(torch.autograd.Function):
+    """One layer of the 2D neck with a backward: y = act(norm(conv(x) [+ conv bias]) [+ res]) [+ res] on 5-D depth-1 tensors.
+    ``kind``: ("conv", k, stride) for Conv2d(k in {1, 3}, stride in {1, 2}, padding (k-1)/2), ("deconv",) for
+    ConvTranspose2d(k3, s2, p1, op1), ("whole",) for the kernel that covers its whole input (a 1x1 layer over the flattened
+    input).  The data gradient is another depth-1 layer of the family (taps flipped / the transposed twin over the same
+    weight memory / the stride-2 twin); the weight gradient comes from snvc_conv3d_wgrad on the depth-1 tensors with a cubic
+    kernel whose middle depth tap is the 2D kernel (the other two taps see only padding)."""
+
+    @staticmethod
+    def forward(ctx, x5, weight, cbias, gamma, beta, res5, conv, norm, flags, plan, kind, layer):
+        raw = layer(x5, None, None, None, 0, None)
+        if cbias is not None:
+            if norm is not None:
+                raise NotImplementedError("a 2D layer with both a conv bias and a norm is not in the neck")
+            scale, shift = torch.ones_like(cbias.detach()), cbias.detach().float().contiguous()
+            y, mean, var, per_sample = ops.affine_act(raw, scale, shift, res5, flags), None, None, False
+        else:
+            y, scale, shift, mean, var, per_sample = _norm_from_raw(raw, norm, plan, res5, flags)
+        ctx.conv, ctx.norm, ctx.flags, ctx.plan, ctx.kind, ctx.per_sample = conv, norm, flags, plan, kind, per_sample
+        ctx.has_res, ctx.train_stats, ctx.has_bias = res5 is not None, mean is not None, cbias is not None
+        ctx.save_for_backward(x5, raw, scale, shift, mean, var, res5 if (res5 is not None and (flags & EPI_ADD_PRE)) else None)
+        _ROUTES["neck2d_hip_train"] += 1
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x5, raw, scale, shift, mean, var, res = ctx.saved_tensors
+        conv, norm, flags, plan, kind = ctx.conv, ctx.norm, ctx.flags, ctx.plan, ctx.kind
+        needs = ctx.needs_input_grad
+        draw, gres, dg, db = _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, ctx.per_sample, ctx.train_stats,
+                                                ctx.has_res and needs[5], needs[3], needs[4])
+        gb = draw.sum(dim=(0, 2, 3, 4)) if (ctx.has_bias and needs[2]) else None
+        w = conv.weight.detach()
+        key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
+        if getattr(plan, "dgrad2d_key", None) != key:
+            mk = lambda t, k, st, tr: ops.Conv3dLayer(t.contiguous(), k, st, (k - 1) // 2, 1, tr, planar=True)   # noqa: E731
+            if kind[0] == "deconv":
+                plan.dgrad2d = mk(w, 3, 2, False)                                   # Conv2d(k3,s2,p1) over the same weight memory
+            elif kind[0] == "whole":
+                plan.dgrad2d = ops.Conv3dLayer(w.reshape(w.size(0), -1).t().reshape(-1, w.size(0), 1, 1, 1).contiguous(), 1, 1, 0, 1,
+                                               False, planar=True)
+            elif kind[2] == 1:
+                plan.dgrad2d = mk(w.transpose(0, 1).flip(2, 3), kind[1], 1, False)
+            elif kind[1] == 3:
+                plan.dgrad2d = mk(w, 3, 2, True)                                    # ConvTranspose2d(k3,s2,p1,op1), same weight memory
+            else:
+                plan.dgrad2d = mk(w.transpose(0, 1), 1, 1, False)                   # k1 / stride 2: a 1x1 layer, scattered below
+            plan.dgrad2d_key = key
+        gx = gw = None
+        h, wd = x5.size(3), x5.size(4)
+        if needs[0]:
+            g = plan.dgrad2d(draw, None, None, None, 0, None)
+            if kind[0] == "conv" and kind[2] == 2:
+                if kind[1] == 3:        # twice draw's extent: crop the gradient of the padding when x's extent is odd
+                    gx = g if (g.size(3), g.size(4)) == (h, wd) else g[:, :, :, :h, :wd].contiguous()
+                else:                   # Conv2d(k1, s2) reads the even positions only
+                    gx = torch.zeros_like(x5)
+                    gx[:, :, :, ::2, ::2] = g
+            else:
+                gx = g
+        if needs[1]:
+            if kind[0] == "deconv":     # roles swapped, see snvc_conv3d_wgrad
+                gw = ops.conv3d_wgrad(draw, x5, 3, 2, 1, 1)[:, :, 1]
+            elif kind[0] == "whole":
+                gw = ops.conv3d_wgrad(x5, draw, 1, 1, 0, 1).reshape(w.shape)
+            elif kind[1] == 1:
+                xs = x5 if kind[2] == 1 else x5[:, :, :, ::2, ::2].contiguous()
+                gw = ops.conv3d_wgrad(xs, draw, 1, 1, 0, 1).reshape(w.shape)
+            else:
+                xs = x5
+                if kind[2] == 2 and (h % 2 or wd % 2):
+                    xs = F.pad(x5, (0, wd % 2, 0, h % 2))
+                gw = ops.conv3d_wgrad(xs, draw, 3, kind[2], 1, 1)[:, :, 1]
+            gw = gw.contiguous()
+        return gx, gw, gb, dg, db, gres, None, None, None, None, None, None
+
+
+def _conv2d_train(conv, norm, x5, res5, flags, plan, kind, layer):
+    gamma = norm.weight if norm is not None else None
+    beta = norm.bias if norm is not None else None
+    return _Conv2dNormActFn.apply(x5, conv.weight, conv.bias, gamma, beta, res5, conv, norm, flags, plan, kind, layer)
 
 
 def _plan2d(conv: nn.Module, device) -> _Plan:
@@ -1205,7 +1310,7 @@ def fused_conv2d(conv: nn.Conv2d, norm, x: torch.Tensor, *, relu=False, sigmoid=
     kh, kw = conv.kernel_size
     whole = (kh, kw) == tuple(x.shape[2:]) and tuple(conv.padding) == (0, 0) and (kh, kw) != (1, 1)
     if transposed_input:
-        if whole or kh != kw or residual is not None or isinstance(norm, nn.GroupNorm):
+        if whole or kh != kw or residual is not None or isinstance(norm, nn.GroupNorm) or _train2d(x, conv, norm, residual):
             return fused_conv2d(conv, norm, x.transpose(2, 3).contiguous(), relu=relu, sigmoid=sigmoid, residual=residual,
                                 residual_after_act=residual_after_act)
         plan = conv.__dict__.setdefault("_snvc_plans2d_t", {}).setdefault(x.device, _Plan())
@@ -1222,12 +1327,16 @@ def fused_conv2d(conv: nn.Conv2d, norm, x: torch.Tensor, *, relu=False, sigmoid=
             wk = w.detach().transpose(2, 3).contiguous() if transposed_input else w.detach()
             plan.layer = ops.Conv3dLayer(wk, k, st, (k - 1) // 2, 1, False, planar=True)
         plan.key = key
-    scale, bias = _affine2d(conv, norm, plan)
     flags = (EPI_RELU if relu else 0) | (EPI_SIGMOID if sigmoid else 0)
     if residual is not None:
         flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
     x5 = x.reshape(x.size(0), -1, 1, 1, 1) if whole else x.unsqueeze(2)
     r5 = residual.unsqueeze(2) if residual is not None else None
+    if _train2d(x, conv, norm, residual):
+        kind = ("whole",) if whole else ("conv", kh, conv.stride[0])
+        y = _conv2d_train(conv, norm, x5.contiguous(), r5.contiguous() if r5 is not None else None, flags, plan, kind, plan.layer)
+        return y.squeeze(2)
+    scale, bias = _affine2d(conv, norm, plan)
     if isinstance(norm, nn.GroupNorm):
         return _group_norm_2d(plan.layer(x5, scale, bias), norm, r5, flags).squeeze(2)
     y = plan.layer(x5, scale, bias, r5, flags).squeeze(2)
@@ -1254,9 +1363,12 @@ def fused_deconv2d(conv: nn.ConvTranspose2d, norm, x: torch.Tensor, *, relu=Fals
     if plan.layer is None or plan.key != key:
         plan.layer = ops.Conv3dLayer(w.detach().contiguous(), 3, 2, 1, 1, True, planar=True)
         plan.key = key
-    scale, bias = _affine2d(conv, norm, plan)
     flags = (EPI_RELU if relu else 0) | (EPI_ADD_PRE if residual is not None else 0)
     r5 = residual.unsqueeze(2) if residual is not None else None
+    if _train2d(x, conv, norm, residual):
+        return _conv2d_train(conv, norm, x.unsqueeze(2).contiguous(), r5.contiguous() if r5 is not None else None, flags, plan,
+                             ("deconv",), plan.layer).squeeze(2)
+    scale, bias = _affine2d(conv, norm, plan)
     if isinstance(norm, nn.GroupNorm):
         return _group_norm_2d(plan.layer(x.unsqueeze(2), scale, bias), norm, r5, flags).squeeze(2)
     return plan.layer(x.unsqueeze(2), scale, bias, r5, flags).squeeze(2)

@@ -3,7 +3,8 @@
 ``hourglass2d``, ``hourglass2d_downsample_16``; reference snvc/models/submodule.py:11-29,270-361, hrnet.py:25-69,
 vernier.py:68-93) against torch's fp32 operators on the CPU and the pinned oracle modules, at the tolerance an exact
 fp32 FMA chain in another summation order meets.  Every block test also asserts through ``_ROUTES`` that the HIP route
--- not the modules' torch forward -- is what ran, and that anything with a gradient to compute keeps torch's route.
+-- not the modules' torch forward -- is what ran; the backward tests compare the HIP autograd function with torch autograd
+through the same modules.
 """
 import numpy as np
 import pytest
@@ -190,25 +191,196 @@ def test_neck_blocks_vs_oracle_modules(block):
         check(g.cpu().numpy(), e.numpy(), 5e-5, f"{block} output {i}")
 
 
-def test_neck_keeps_torch_route_when_anything_needs_grad():
+def test_neck_head_only_fine_tuning_gets_its_gradients():
     """eval-mode BatchNorm + an input that does not require grad + trainable head weights (head-only
-    fine-tuning on a frozen trunk) must NOT take the kernels without a backward: the parameters get their gradients."""
+    fine-tuning on a frozen trunk): the parameters get their gradients -- on the HIP backward since r4, on the modules' own
+    torch forward with ``NECK2D_HIP_TRAINING`` off (rounds 2-3) -- and the two agree."""
     from snvc_amd.models import submodule as S
     r = np.random.default_rng(1400)
     blk = seeded(S.BasicBlock2d(16, 16), 3).to(dev())      # eval mode, parameters require grad
     x = _t(r, (1, 16, 8, 8)).to(dev())                      # detached input
+    S.NECK2D_HIP_TRAINING[0] = False
+    try:
+        hip0, torch0 = _routes()
+        y = blk(x)
+        assert _routes() == (hip0, torch0 + 1)
+        y.square().mean().backward()
+        ref = {k: p.grad.clone() for k, p in blk.named_parameters()}
+        blk.zero_grad(set_to_none=True)
+    finally:
+        S.NECK2D_HIP_TRAINING[0] = True
     hip0, torch0 = _routes()
-    y = blk(x)
-    hip1, torch1 = _routes()
-    assert (hip1, torch1) == (hip0, torch0 + 1)
-    y.square().mean().backward()
-    assert blk.conv1.weight.grad is not None and blk.conv2.weight.grad.abs().sum() > 0
-    with torch.no_grad():                                   # same module, nothing to differentiate: HIP route, same values
+    t0 = S._ROUTES["neck2d_hip_train"]
+    y1 = blk(x)
+    assert _routes() == (hip0 + 1, torch0) and S._ROUTES["neck2d_hip_train"] == t0 + 2
+    y1.square().mean().backward()
+    check(y1.detach().cpu().numpy(), y.detach().cpu().numpy(), 5e-5, "HIP training forward vs torch")
+    for k, p in blk.named_parameters():
+        assert p.grad is not None and ref[k].abs().sum() > 0, k
+        check(p.grad.cpu().numpy(), ref[k].cpu().numpy(), 2e-4, f"grad {k}")
+    with torch.no_grad():                                   # same module, nothing to differentiate: fused launches, same values
+        t1 = S._ROUTES["neck2d_hip_train"]
         y2 = blk(x)
-    assert _routes()[0] == hip1 + 1
-    check(y2.cpu().numpy(), y.detach().cpu().numpy(), 5e-5, "HIP route vs torch route")
-    for p in blk.parameters():                              # frozen parameters: HIP route even with autograd on
-        p.requires_grad_(False)
-    hip2 = _routes()[0]
-    blk(x)
-    assert _routes()[0] == hip2 + 1
+    assert S._ROUTES["neck2d_hip_train"] == t1
+    check(y2.cpu().numpy(), y.detach().cpu().numpy(), 5e-5, "fused route vs torch route")
+
+
+def _grads_vs_torch(ours, make_args, tol, what, train_bn):
+    """Forward + backward of a neck block on the HIP autograd function against the block's own torch forward (the reference's
+    modules: same module tree, NECK2D_HIP_TRAINING off) from the same parameters and inputs."""
+    from snvc_amd.models import submodule as S
+    ours = ours.to(dev())
+    ours.train(train_bn)
+    state = {k: v.clone() for k, v in ours.state_dict().items()}
+    outs = {}
+    for hip in (False, True):
+        ours.load_state_dict(state)
+        ours.zero_grad(set_to_none=True)
+        args = [a.clone().requires_grad_(True) if a is not None else None for a in make_args()]
+        S.NECK2D_HIP_TRAINING[0] = hip
+        try:
+            t0, r0 = S._ROUTES["neck2d_hip_train"], _routes()
+            y = ours(*args)
+            ys = y if isinstance(y, tuple) else (y,)
+            loss = sum((o * torch.linspace(0.5, 1.5, o.numel(), device=o.device).reshape(o.shape)).sum() for o in ys) * 1e-2
+            loss.backward()
+            if hip:
+                assert S._ROUTES["neck2d_hip_train"] > t0 and _routes()[1] == r0[1], "the HIP backward must be what ran"
+            else:
+                assert S._ROUTES["neck2d_hip_train"] == t0
+        finally:
+            S.NECK2D_HIP_TRAINING[0] = True
+        outs[hip] = ([o.detach().cpu().numpy() for o in ys], [a.grad.cpu().numpy() for a in args if a is not None],
+                     {k: p.grad.cpu().numpy() for k, p in ours.named_parameters() if p.grad is not None},
+                     {k: v.detach().cpu().numpy() for k, v in ours.state_dict().items() if "running" in k})
+    for i, (g, e) in enumerate(zip(outs[True][0], outs[False][0])):
+        check(g, e, 5e-5, f"{what}: output {i}")
+    for i, (g, e) in enumerate(zip(outs[True][1], outs[False][1])):
+        check(g, e, tol, f"{what}: input gradient {i}")
+    assert set(outs[True][2]) == set(outs[False][2]) and outs[False][2]
+    for k in outs[False][2]:
+        check(outs[True][2][k], outs[False][2][k], tol, f"{what}: grad {k}")
+    for k in outs[False][3]:
+        check(outs[True][3][k], outs[False][3][k], 1e-5, f"{what}: {k}")
+
+
+@pytest.mark.parametrize("train_bn", [False, True])
+@pytest.mark.parametrize("block", ["basic", "basic_down", "hg2d", "hg2d_skips", "hg2d_16", "hg2d_gn", "hg2d_16_odd", "convbn_k1s2", "head"])
+def test_neck_blocks_backward_vs_torch_autograd(block, train_bn):
+    """r4 (VERDICT r3 missing 3): the neck's layers have a HIP backward.  Every block kind, eval-mode (frozen statistics,
+    trainable affine) and train-mode BatchNorm / GroupNorm, odd extents through the stride-2 layers, the biased heads."""
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(1700)
+    if block == "basic":
+        ours, shapes = seeded(S.BasicBlock2d(32, 32), 5), [(2, 32, 12, 8)]
+    elif block == "basic_down":
+        ours, shapes = seeded(S.BasicBlock2d(16, 32, 2, S.basicdownsample(16, 32)), 6), [(2, 16, 12, 8)]
+    elif block == "hg2d":
+        ours, shapes = seeded(S.hourglass2d(32), 7), [(2, 32, 16, 24), None, None]
+    elif block == "hg2d_skips":
+        ours, shapes = seeded(S.hourglass2d(32), 8), [(1, 32, 8, 12), (1, 64, 4, 6), (1, 64, 4, 6)]
+    elif block == "hg2d_gn":
+        ours, shapes = seeded(S.hourglass2d(32, gn=True), 9), [(2, 32, 16, 24), None, None]
+    elif block == "hg2d_16":
+        ours, shapes = seeded(S.hourglass2d_downsample_16(32), 10), [(2, 32, 32, 48)]
+    elif block == "hg2d_16_odd":       # stride-2 layers over odd extents (13 x 9 -> 7 x 5): cropped data gradient, padded weight gradient
+        ours, shapes = seeded(torch.nn.Sequential(S.get_hg_down_sample_2d(16, 32, False), S.get_hg_down_sample_2d(32, 32, False, False)), 11), \
+            [(2, 16, 13, 9)]
+    elif block == "convbn_k1s2":
+        ours, shapes = seeded(S.basicdownsample(16, 32), 12), [(2, 16, 12, 8)]
+    else:
+        ours, shapes = None, [(2, 11, 6, 4)]
+    if block in ("hg2d_16_odd", "convbn_k1s2"):
+        seq = ours
+
+        class Wrap(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.seq = seq
+
+            def forward(self, x):
+                if not S._hip_2d_ok(x, self):
+                    return self.seq(x)
+                if block == "convbn_k1s2":
+                    return S.fused_conv2d(self.seq[0], self.seq[1], x)
+                return S._cbr2d(self.seq[1], S._cbr2d(self.seq[0], x))
+        ours = Wrap()
+    if block == "head":                # Conv2d with a bias: a 3x3 head, then the whole-extent layer + Sigmoid (vernier.py:87-88, 296-313)
+        class Head(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.hm = torch.nn.Conv2d(11, 8, 3, 1, 1, bias=True)
+                self.last = torch.nn.Conv2d(8, 6, (6, 4), bias=True)
+
+            def forward(self, x):
+                if not S._hip_2d_ok(x, self):
+                    return torch.sigmoid(self.last(F.relu(self.hm(x))))
+                return S.fused_conv2d(self.last, None, S.fused_conv2d(self.hm, None, x, relu=True), sigmoid=True)
+        ours = Head()
+        with torch.no_grad():
+            for p in ours.parameters():
+                p.copy_(_t(r, tuple(p.shape)) * 0.1)
+    args = [_t(r, s).to(dev()) if s is not None else None for s in shapes]
+    _grads_vs_torch(ours, lambda: args, 2e-4, block, train_bn)
+
+
+@pytest.mark.parametrize("gn", [False, True])
+def test_vernier_scale_trains_through_its_neck_natively(gn):
+    """VernierScale.predict_3d_heatmaps in train mode (reference vernier.py:362-458): no layer of the neck falls back to the
+    modules' torch forward, the gradients reach the 3D trunk and the feature maps, and every neck / head gradient is as close
+    to a float64 evaluation of the same modules as torch's own fp32 autograd is (train-mode BatchNorm over 48 values per
+    channel in the coordinate head makes fp32-against-fp32 comparisons of this model ill-conditioned: 2e-2 between two
+    summation orders; against float64 both sit at 1e-3 or better)."""
+    from oracle import torch_ref as T
+    import golden_cases as GC
+    from test_gpu_parity import _cfg
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.vernier import VernierScale
+    grid = (16, 16, 24)
+    ours = VernierScale(_cfg(grid, gn))
+    ours.load_state_dict(T.seeded_state_dict(T.VernierTrunk(32, grid, gn), 91))
+    ours = ours.to(dev()).train()
+    state = {k: v.clone() for k, v in ours.state_dict().items()}
+    lf, rf, gpl, gpr = GC.trunk_inputs(2, 32, 16, 16, grid, 92)
+
+    # 1. the whole model: one backward through neck + trunk + gather, all on the HIP autograd functions
+    r0, t0 = _routes(), S._ROUTES["neck2d_hip_train"]
+    lo, ro = lf.to(dev()).requires_grad_(), rf.to(dev()).requires_grad_()
+    hm, occ, _, coords, _ = ours.predict_3d_heatmaps(ours.construct_voxel(lo, ro, gpl.to(dev()), gpr.to(dev())))
+    (hm.pow(2).mean() + coords.pow(2).mean() + occ.mean()).backward()
+    assert _routes()[1] == r0[1] and S._ROUTES["neck2d_hip_train"] >= t0 + 12, "the whole neck on the HIP autograd function"
+    assert lo.grad.abs().sum() > 0 and ro.grad.abs().sum() > 0
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in ours.parameters())
+
+    # 2. the neck alone from the trunk's BEV tensor: HIP fp32 and torch fp32 against torch float64
+    with torch.no_grad():
+        bev = ours.trunk_3d(ours.construct_voxel(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev())))[0].clone()
+    res = {}
+    for tag, hip, dt in (("f64", False, torch.float64), ("torch", False, torch.float32), ("hip", True, torch.float32)):
+        ours.load_state_dict(state)
+        ours.to(dt)
+        ours.zero_grad(set_to_none=True)
+        S.NECK2D_HIP_TRAINING[0] = hip
+        try:
+            r0 = _routes()
+            b = bev.to(dt).clone().requires_grad_()
+            hm, coords = ours.heads_2d(b)
+            (hm.pow(2).mean() + coords.pow(2).mean()).backward()
+            assert (_routes()[1] == r0[1]) == hip
+        finally:
+            S.NECK2D_HIP_TRAINING[0] = True
+            ours.float()
+        g = {k: p.grad.double().cpu().numpy() for k, p in ours.named_parameters() if p.grad is not None}
+        g["bev"] = b.grad.double().cpu().numpy()
+        res[tag] = (hm.detach().double().cpu().numpy(), coords.detach().double().cpu().numpy(), g)
+    check(res["hip"][0], res["f64"][0], 5e-5, "heat maps")
+    check(res["hip"][1], res["f64"][1], 5e-5, "coordinates")
+    assert len(res["f64"][2]) >= 20 and set(res["hip"][2]) == set(res["f64"][2])
+
+    def l2(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+    e_hip = {k: l2(res["hip"][2][k], v) for k, v in res["f64"][2].items()}
+    e_torch = {k: l2(res["torch"][2][k], v) for k, v in res["f64"][2].items()}
+    wh, wt = max(e_hip, key=e_hip.get), max(e_torch, key=e_torch.get)
+    print(f"gn={gn}: against float64, HIP worst l2 {e_hip[wh]:.2e} ({wh}); torch fp32 worst {e_torch[wt]:.2e} ({wt})")
+    assert e_hip[wh] < max(3 * e_torch[wt], 1e-4), (wh, e_hip[wh], e_torch[wt])
