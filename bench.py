@@ -340,8 +340,9 @@ class TrainStep:
     """cfg4: build_cost_volume + GlobalStack forward (train-mode BatchNorm), loss = mean(cost^2), backward through
     the HIP kernels, then the flat-bucket gradient all-reduce (RCCL when world > 1)."""
 
-    def __init__(self, rank, device):
+    def __init__(self, rank, device, sheared=True):
         from snvc_amd.models.stereo_volume import GlobalStack
+        self.sheared = sheared
         self.model = GlobalStack(C)
         self.model.load_state_dict(seeded_state(self.model))
         self.model.train().to(device)
@@ -357,7 +358,7 @@ class TrainStep:
             p.grad = None
         self.left.grad = self.right.grad = None
         self.ev[0].record()
-        out = self.model.forward_pair(self.left, self.right, self.shift, 1)
+        out = self.model.forward_pair(self.left, self.right, self.shift, 1, sheared=self.sheared)
         loss = out.pow(2).mean()
         self.ev[1].record()
         loss.backward()
@@ -399,6 +400,34 @@ def run_train(rank, world, device, dist, steps, warmup, barrier):
         "fwd_ms": f, "bwd_ms": b, "allreduce_us": 1e3 * r, "allreduce_bytes": ts.moved, "params": ts.nparam,
         "step_tflops_algorithmic": 3 * STEP_FLOP / (elapsed / steps) / 1e12, "steps": steps,
     }
+    if rank == 0 and world == 1:
+        # the same step as ANY shift array takes it (sheared=False: warp after convolution, forward and -- r4 -- backward), and with
+        # rounds 1-3's backward of that layer (right half built; 3D data and weight gradients over it)
+        from snvc_amd.models import submodule as S
+        del ts
+        torch.cuda.empty_cache()
+        gen = {}
+        for tag, flag in (("ms_per_step", True), ("ms_per_step_built_volume_backward", False)):
+            S.COMMUTED_BACKWARD[0] = flag
+            try:
+                tg = TrainStep(rank, device, sheared=False)
+                for _ in range(3):
+                    tg()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                k = max(5, steps // 2)
+                for _ in range(k):
+                    tg()
+                    torch.cuda.synchronize()
+                gen[tag] = 1e3 * (time.perf_counter() - t1) / k
+                del tg
+                torch.cuda.empty_cache()
+            finally:
+                S.COMMUTED_BACKWARD[0] = True
+        gen["note"] = ("forward_pair(..., sheared=False): the first layer warps after the convolution in both directions "
+                       "(snvc_warped_expand / snvc_warped_expand_backward); second figure: its backward through the built right half")
+        res["general_shift"] = gen
+        ts = TrainStep(rank, device)
     if dist is not None:
         # the collective alone on synthetic buckets: the 3D stack's gradients and SURVEY.md 8(d)'s 133.5 MB full model,
         # as one all-reduce and as reduce-scatter + all-gather (what `algorithm="auto"` picks from 8 MB on)

@@ -339,6 +339,17 @@ SNVC_API int snvc_conv3d_forward_stats(const snvc_conv3d_desc *desc_host, const 
 SNVC_API int snvc_warped_expand(const float *p, const float *q, const float *e, const float *planes, const float *shift,
                                 const float *scale, const float *bias, float *y, int64_t N, int64_t C, int64_t D, int64_t H,
                                 int64_t W, int flags, void *stream);
+/* Adjoint of snvc_warped_expand w.r.t. the right feature and the weights, in one pass over the output gradient dy [N][C][D][H][W]
+ * (scale = 1, no activation: the caller applies the epilogue's backward first), replacing the reference's Conv3d backward over
+ * the built volume + BuildCostVolume_cuda.cu:152-205 for the right half:
+ *   a[n][kd][kw][co][h][j] = the gradient of plane e = d+kd-1's warp, taken back through tap (kd, kw):
+ *       sum_e f_e [j+m_e+1 <= W-1] dy[co][e-kd+1][h][j+m_e+2-kw] + g_e [j >= 1, j+m_e <= W-1] dy[co][e-kd+1][h][j+m_e+1-kw]
+ *   (shift[e] = m_e + f_e, g_e = 1 - f_e; a whole-pixel shift counts as (m-1, 1, 0); planes with a negative or NaN shift add 0),
+ *   so that dWt[co][c][kd][kh][kw] = sum_{n,h,j} a * right[n][c][h+kh-1][j] and dRight = the depth-1 transposed convolution of a.
+ *   dplanes [N][C][3][H][W] or NULL: the depth-class sums of dy (snvc_depth_class_sums) from the same pass.
+ * Deterministic.  W <= 1024. */
+SNVC_API int snvc_warped_expand_backward(const float *dy, const float *shift, float *a, float *dplanes, int64_t N, int64_t C,
+                                         int64_t D, int64_t H, int64_t W, void *stream);
 /* snvc_warped_expand with the result written as a split C8 pair (y_hi, y_lo), like snvc_sheared_expand_split. */
 SNVC_API int snvc_warped_expand_split(const float *p, const float *q, const float *e, const float *planes, const float *shift,
                                       const float *scale, const float *bias, void *y_hi, void *y_lo, int *overflow,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "snvc_conv3d_stats_workspace_bytes": (c_i64, [c_p]),
     "snvc_conv3d_forward_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_float, c_p]),
     "snvc_warped_expand": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
+    "snvc_warped_expand_backward": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_warped_expand_split": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_p]),
     "snvc_shift_structure": (c_int, [c_p, c_p, c_i64, c_i64, c_p]),
     "snvc_sheared_upsample": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_p]),

@@ -517,6 +517,137 @@ warped_expand_win_kernel(const float *__restrict__ p, const float *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------ adjoint of the any-shift layer (r4)
+// Backward of the first convolution over the warped half for an ARBITRARY shift array, without the warped volume, its
+// gradient or a 3D kernel.  With V_e[w'] = f_e R[w' - m_e - 1] + g_e R[w' - m_e] for m_e + 1 <= w' <= W-1 and 0 elsewhere
+// (BuildCostVolume_cuda.cu:63-98 for s_e = m_e + f_e >= 0: the gate x >= 0 is "w' > m_e", a whole-pixel shift is (m - 1, 1, 0))
+//     raw[co][d][h][w] = sum_{c,kd,kh,kw} Wt[co][c][kd][kh][kw] * V_{d+kd-1}[c][h+kh-1][w+kw-1]      (zero padding in d and w)
+// is linear in R through the nine shifted-and-warped-back gradients
+//     A[kd][kw][co][h][j] = sum_e  f_e [j + m_e + 1 <= W-1] dy[co][e-kd+1][h][j + m_e + 2 - kw]
+//                                + g_e [1 <= j, j + m_e <= W-1] dy[co][e-kd+1][h][j + m_e + 1 - kw]     (dy = 0 outside the tensor)
+// from which  dWt[co][c][kd][kh][kw] = sum_{h,j} A[kd][kw][co][h][j] R[c][h+kh-1][j]  and
+//             dR[c][y][j] = sum_{co,kd,kw,kh} Wt[co][c][kd][kh][kw] A[kd][kw][co][y-kh+1][j]
+// are depth-1 work on 9 C planes (the host runs them on the depth-1 conv / wgrad kernels).  This kernel is the one pass over dy
+// (0.74 GB at cfg4): a workgroup owns RB rows of one (n, co), thread = one column j; the rows of dy walk through an LDS ring of
+// 16 planes (8 loaded per step, each thread 8 independent 4-byte loads a step ahead of their use), plane e adds into the 9
+// register accumulators from planes d = e-1, e, e+1 of the ring: 4 conflict-free LDS reads and 6 FMAs per (e, kd).  Every sum runs
+// in ascending e: deterministic, no atomics.  The loading thread also owns column j of every plane, so the depth-class sums of dy
+// (the left half's gradient planes, snvc_depth_class_sums) come out of the same pass.
+__global__ void __launch_bounds__(1024)
+warped_expand_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ shift, float *__restrict__ a,
+                         float *__restrict__ dplanes, int C, int D, int H, int W, int RB, int TW) {
+    extern __shared__ float lds[];
+    constexpr int NS = 16, CH = 8;                       // ring slots, planes per step
+    constexpr int kInvalid = (int)0x80000001;
+    const int LWB = W + 4;                               // a staged row: columns -2 .. W+1 (zeros outside 0 .. W-1)
+    const int tid = threadIdx.x;
+    const int r = tid / TW, j = tid - r * TW;
+    const int co = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int h = blockIdx.x * RB + r;
+    const bool live = h < H && j < W;
+    const int64_t hw = (int64_t)H * W;
+    float *const ring = lds + (size_t)r * NS * LWB;      // [NS][LWB]
+    f32x4 *const ptab = reinterpret_cast<f32x4 *>(lds + (((size_t)RB * NS * LWB + 3) & ~(size_t)3));   // [D]: {m, f, g, -}
+    const float *sh = shift + n * D;
+    for (int i = tid; i < D; i += blockDim.x) {
+        f32x4 t = {__builtin_bit_cast(float, kInvalid), 0.0f, 0.0f, 0.0f};
+        const float s = sh[i];
+        if (s >= 0.0f && s <= (float)W) {
+            const float mf = __builtin_floorf(s);
+            float ff = s - mf;
+            int mm = (int)mf;
+            if (ff == 0.0f) { mm -= 1; ff = 1.0f; }
+            t = f32x4{__builtin_bit_cast(float, mm), ff, 1.0f - ff, 0.0f};
+        }
+        ptab[i] = t;
+    }
+    // the zero borders of every slot (columns -2, -1, W, W+1) are written once; the loads below only touch 0 .. W-1
+    if (j < 4 && r < RB) {
+        for (int sl = 0; sl < NS; ++sl) ring[sl * LWB + (j < 2 ? j : W + j)] = 0.0f;
+    }
+    const float *src = dy + ((n * C + co) * (int64_t)D) * hw + (int64_t)(live ? h : 0) * W + (live ? j : 0);
+    float acc[3][3];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc[kd][kw] = 0.0f;
+    float c_first = 0.0f, c_mid = 0.0f, c_last = 0.0f;
+    float nx[CH];
+    // prologue: planes 0 .. CH
+    {
+        const float v0 = live ? src[0] : 0.0f;
+        c_first = v0;
+        if (D == 1) c_last = v0;
+        if (live) ring[0 * LWB + j + 2] = v0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int d = 1 + i;
+            nx[i] = (live && d < D) ? src[(int64_t)d * hw] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int d = 1 + i;
+            if (d < D) {
+                if (live) ring[(d & (NS - 1)) * LWB + j + 2] = nx[i];
+                if (d == D - 1) c_last = nx[i]; else c_mid += nx[i];
+            }
+        }
+    }
+    __syncthreads();
+    for (int e0 = 0; e0 < D; e0 += CH) {
+        // planes e0 + CH + 1 .. e0 + 2 CH: requested now, stored after this step's arithmetic
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int d = e0 + CH + 1 + i;
+            nx[i] = (live && d < D) ? src[(int64_t)d * hw] : 0.0f;
+        }
+        if (live) {
+            const int e1 = e0 + CH < D ? e0 + CH : D;
+            for (int e = e0; e < e1; ++e) {
+                const f32x4 t = ptab[e];
+                const int m = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t[0]));
+                if (m == kInvalid) continue;
+                const int base = j + m;
+                const bool ok = base <= W - 1;
+                const float fe = (ok && base + 1 <= W - 1) ? t[1] : 0.0f;
+                const float ge = (ok && j >= 1) ? t[2] : 0.0f;
+                const int idx = (ok ? base : 0) + 2;
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) {
+                    const int d = e - kd + 1;
+                    if (d < 0 || d >= D) continue;
+                    const float *row = ring + (d & (NS - 1)) * LWB + idx;
+                    const float vm = row[-1], v0 = row[0], v1 = row[1], v2 = row[2];
+                    acc[kd][0] = __builtin_fmaf(ge, v1, __builtin_fmaf(fe, v2, acc[kd][0]));
+                    acc[kd][1] = __builtin_fmaf(ge, v0, __builtin_fmaf(fe, v1, acc[kd][1]));
+                    acc[kd][2] = __builtin_fmaf(ge, vm, __builtin_fmaf(fe, v0, acc[kd][2]));
+                }
+            }
+        }
+        __syncthreads();                                 // every wave is done with planes <= e0 + CH - 2 ... the slots written next
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int d = e0 + CH + 1 + i;
+            if (d < D) {
+                if (live) ring[(d & (NS - 1)) * LWB + j + 2] = nx[i];
+                if (d == D - 1) c_last = nx[i]; else c_mid += nx[i];
+            }
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            a[((((n * 3 + kd) * 3 + kw) * C + co) * (int64_t)H + h) * W + j] = acc[kd][kw];
+    if (dplanes) {
+        float *dp = dplanes + (((n * C + co) * 3) * (int64_t)H + h) * W + j;
+        dp[0] = c_first; dp[hw] = c_mid; dp[2 * hw] = c_last;
+    }
+}
+
 // ------------------------------------------------------------------------------------ backward (training, cfg4)
 // Adjoint of sheared_expand_kernel w.r.t. G and G' (scale = 1: the caller applies the norm's backward first):
 //     dG[n][cls][co][h][i]  = sum over (d in class cls, w <= W-2) with Q*w - d - m0 + off  == i of dy[n][co][d][h][w]
@@ -1393,6 +1524,30 @@ int snvc_warped_expand(const float *p, const float *q, const float *e, const flo
     warped_expand_win_kernel<<<dim3((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N), threads, lds, as_stream(stream)>>>(
         p, q, e, planes, shift, scale, bias, y, (int)C, (int)D, (int)H, (int)W, RB, flags);
     return check_launch("snvc_warped_expand");
+}
+
+int snvc_warped_expand_backward(const float *dy, const float *shift, float *a, float *dplanes, int64_t N, int64_t C, int64_t D,
+                                int64_t H, int64_t W, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_backward: bad sizes (D >= 2)");
+    if (N == 0) return SNVC_OK;
+    if (!dy || !shift || !a) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_backward: null pointer");
+    if (W > 1024 || C > 65535 || N > 65535 || H * W >= ((int64_t)1 << 31))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_backward: W <= 1024, C and N <= 65535");
+    const int TW = ceil_div((int)W, 64) * 64;
+    int RB = 512 / TW;
+    if (RB < 1) RB = 1;
+    if (RB > H) RB = (int)H;
+    auto lds_of = [&](int rb) { return sizeof(float) * ((((size_t)rb * 16 * (W + 4) + 3) & ~(size_t)3) + 4 * (size_t)D); };
+    while (RB > 1 && lds_of(RB) > 150 * 1024) --RB;
+    const size_t lds = lds_of(RB);
+    if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_backward: rows do not fit the LDS");
+    static std::atomic<unsigned> attr{0};
+    if (!allow_large_lds(reinterpret_cast<const void *>(&warped_expand_bwd_kernel), (int)lds, attr))
+        return check_launch("snvc_warped_expand_backward");
+    warped_expand_bwd_kernel<<<dim3((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N), RB * TW, lds, as_stream(stream)>>>(
+        dy, shift, a, dplanes, (int)C, (int)D, (int)H, (int)W, RB, TW);
+    return check_launch("snvc_warped_expand_backward");
 }
 
 int snvc_warped_expand_split(const float *p, const float *q, const float *e, const float *planes, const float *shift, const float *scale,

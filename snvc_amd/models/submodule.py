@@ -455,10 +455,14 @@ class _FactoredFirstConvFn(torch.autograd.Function):
             ops.warped_expand(lp(r5).squeeze(2), lq(r5).squeeze(2), le(rd[:, :, :, :4].contiguous().unsqueeze(2)).squeeze(2), planes,
                               shift.detach().float().contiguous(), None, None, raw, 0)
             _ROUTES["commuted_first_conv_train"] += 1
+            # the backward warps back BEFORE the (transposed) convolution too (snvc_warped_expand_backward, r4) -- it assumes what
+            # the reference's wrapper asserts, shift >= 0, which forward_pair has checked on the device by now
+            ctx.commuted_bwd = COMMUTED_BACKWARD[0] and rd.size(3) <= 1024 and shift.size(1) >= 2
         else:
             vol_r = ops.cost_volume_forward_right(rd, shift)
             raw = fac["fr"](vol_r, None, None, None, 0, None, depth_planes=planes)
             del vol_r
+            ctx.commuted_bwd = False
         y, scale, shf, mean, var, per_sample = _norm_from_raw(raw, norm, plan, None, flags)
         ctx.conv, ctx.norm, ctx.flags, ctx.per_sample, ctx.train_stats = conv, norm, flags, per_sample, mean is not None
         ctx.save_for_backward(left3, right.detach(), shift, raw, scale, shf, mean, var)
@@ -473,8 +477,29 @@ class _FactoredFirstConvFn(torch.autograd.Function):
         draw, _, dg, db = _epilogue_backward(raw, gy, None, scale, shf, mean, var, norm, flags, ctx.per_sample, ctx.train_stats,
                                              False, needs[4], needs[5])
         fac = conv.__dict__["_snvc_factored_train"]
-        dplanes = ops.depth_class_sums(draw)                                      # [N,Cout,3,H,W]
         g_left = g_right = gw = None
+        if ctx.commuted_bwd and (needs[1] or needs[3]):
+            # one pass over draw: its nine warped-back, tap-shifted sums a[kd][kw] (and the left half's depth-class sums);
+            # the right feature's and the right-half weights' gradients are depth-1 work on those 9 * Cout planes
+            a, dplanes = ops.warped_expand_backward(draw, shift.detach().float())
+            n, c, cout = right.size(0), right.size(1), draw.size(1)
+            a5 = a.view(n, 9 * cout, 1, a.size(4), a.size(5))
+            if needs[3]:
+                g9 = ops.conv3d_wgrad(right.unsqueeze(2), a5, 3, 1, 1, 1)         # [9 Cout, C, 3, 3, 3]: (kh, centre column) used
+                gw_r = g9[:, :, 1, :, 1].reshape(3, 3, cout, c, 3).permute(2, 3, 0, 4, 1)      # [Cout, C, kd, kh, kw]
+                gw = torch.cat([ops.conv3d_wgrad(left3, dplanes, 3, 1, 1, 1), gw_r], dim=1)
+            if needs[1]:
+                if "ba" not in fac:     # dRight[c][y][j] = sum Wt[co][c][kd][kh][kw] a[kd][kw][co][y - kh + 1][j]: a depth-1 k3 layer
+                    wr = conv.weight.detach()[:, c:]                              # [Cout, C, kd, kh, kw]
+                    wd = torch.zeros((c, 9 * cout, 3, 3), dtype=wr.dtype, device=wr.device)
+                    wd[:, :, :, 1] = wr.permute(1, 2, 4, 0, 3).flip(4).reshape(c, 9 * cout, 3)
+                    fac["ba"] = ops.Conv3dLayer(wd, 3, 1, 1, 1, False, planar=True)
+                g_right = fac["ba"](a5).squeeze(2)
+            if needs[0]:
+                g_left = fac["bl"](dplanes).sum(dim=2)
+            _ROUTES["commuted_first_conv_backward"] += 1
+            return g_left, g_right, None, gw, dg, db, None, None, None, None, None
+        dplanes = ops.depth_class_sums(draw)                                      # [N,Cout,3,H,W]
         if needs[3]:
             vol_r = ops.cost_volume_forward_right(right, shift)                   # recomputed (0.17 ms) rather than kept (0.74 GB)
             gw_r = ops.conv3d_wgrad(vol_r, draw, 3, 1, 1, 1)
@@ -486,6 +511,9 @@ class _FactoredFirstConvFn(torch.autograd.Function):
         if needs[1]:
             g_right = ops.cost_volume_backward_right(fac["br"](draw), shift)
         return g_left, g_right, None, gw, dg, db, None, None, None, None, None
+
+
+COMMUTED_BACKWARD = [True]       # False: rounds 1-3's backward of the any-shift first layer (right half built, 3D dgrad + wgrad)
 
 
 SHEAR_CLASS_KDS = ((0, 1), (-1, 0, 1), (-1, 0))     # kd taps the first plane / the interior planes / the last plane see

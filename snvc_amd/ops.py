@@ -435,6 +435,27 @@ def warped_expand(p, q, e, planes, shift, scale, bias, out, flags: int = 0):
     return out
 
 
+def warped_expand_backward(dy, shift, want_planes: bool = True):
+    """Adjoint of ``warped_expand`` in one pass over the output gradient dy [N,C,D,H,W] (snvc_warped_expand_backward):
+    returns (a [N,3,3,C,H,W], dplanes [N,C,3,H,W] or None) -- a[:, kd, kw] = dy taken back through the warp of plane d+kd-1 and
+    the (kd, kw) tap, from which the right feature's and the weights' gradients are depth-1 convolution work; dplanes = the
+    depth-class sums of dy (``depth_class_sums``) from the same pass.  Raises ``Unsupported`` for W > 1024."""
+    _gpu(dy, "dy"); _gpu(shift, "shift")
+    if dy.dtype != torch.float32 or dy.dim() != 5:
+        raise RuntimeError("warped_expand_backward needs a float32 dy [N,C,D,H,W]")
+    dy = dy.contiguous()
+    n, c, d, h, w = dy.shape
+    if shift.dtype != torch.float32 or tuple(shift.shape) != (n, d):
+        raise RuntimeError("warped_expand_backward needs a float32 shift [N,D]")
+    shift = shift.contiguous()
+    a = torch.empty((n, 3, 3, c, h, w), dtype=torch.float32, device=dy.device)
+    dpl = torch.empty((n, c, 3, h, w), dtype=torch.float32, device=dy.device) if want_planes else None
+    with torch.cuda.device(dy.device):
+        check(_lib.lib().snvc_warped_expand_backward(_ptr(dy), _ptr(shift), _ptr(a), _ptr(dpl), n, c, d, h, w, _stream(dy)),
+              "snvc_warped_expand_backward")
+    return a, dpl
+
+
 def warped_expand_split(p, q, e, planes, shift, scale, bias, out, flags: int = 0, overflow=None):
     """``warped_expand`` with the result written as a split C8 pair (snvc_warped_expand_split): ``out`` = float16
     [N, 2, C/8, D, H, W, 8] holding the layer's result times the power of two the caller folded into scale / bias."""

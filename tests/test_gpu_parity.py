@@ -848,6 +848,7 @@ def test_training_step_global_stack_vs_torch_autograd():
     before_c = S._ROUTES["commuted_first_conv_train"]
     (gl_o, gr_o), gp_o = _grads(ours, [lo, ro], lambda: ours.forward_pair(lo, ro, sh, 1).pow(2).mean())
     assert S._ROUTES["commuted_first_conv_train"] == before_c + 1      # non-uniform shifts: the first layer's forward warps after the convolution
+    assert S._ROUTES["commuted_first_conv_backward"] >= 1               # ... and so does its backward (r4)
     # feature gradients pass through ~10 ReLUs: a mask bit that flips on a pre-activation of ~1e-7
     # perturbs a small neighbourhood, so they are compared in the L2 sense
     def l2(a, b):
@@ -860,6 +861,18 @@ def test_training_step_global_stack_vs_torch_autograd():
     for (k, a), (_, b) in zip(ours.state_dict().items(), ref.state_dict().items()):
         if "running" in k:
             check(a.cpu().numpy(), b.numpy(), 1e-4, k)
+    # the same step with rounds 1-3's backward (right half built, 3D data and weight gradients over it)
+    S.COMMUTED_BACKWARD[0] = False
+    try:
+        lb, rb = torch.from_numpy(L).to(dev()).requires_grad_(), torch.from_numpy(R).to(dev()).requires_grad_()
+        nb = S._ROUTES["commuted_first_conv_backward"]
+        (gl_b, gr_b), gp_b = _grads(ours, [lb, rb], lambda: ours.forward_pair(lb, rb, sh, 1).pow(2).mean())
+        assert S._ROUTES["commuted_first_conv_backward"] == nb
+    finally:
+        S.COMMUTED_BACKWARD[0] = True
+    assert l2(gl_o.numpy(), gl_b.numpy()) < 1e-3 and l2(gr_o.numpy(), gr_b.numpy()) < 1e-3
+    for k in gp_r:
+        check(gp_o[k].numpy(), gp_b[k].numpy(), 1e-3, f"d {k} (vs the built-volume backward)")
 
 
 # =============================================================================== a5 / a6
@@ -1103,6 +1116,49 @@ def test_global_pair_end_to_end_vs_oracle(tile):
     check(got_fact, got_full, 2e-5, "factored vs materialised")
     exp1 = ref.conv1(torch.from_numpy(vol_ref)).detach().numpy()
     check(full1, exp1, 2e-5, "conv1")
+
+
+@pytest.mark.parametrize("case", ["random", "whole_pixels", "beyond_the_image", "odd_width", "deep"])
+def test_warped_expand_backward_vs_oracle(case):
+    """snvc_warped_expand_backward (r4: the adjoint of the any-shift first layer) against the C oracle's cost-volume backward
+    (BuildCostVolume_cuda.cu:152-205 restated): a[kd][kw] is the right-feature gradient of a volume gradient that holds dy moved
+    by the (kd, kw) tap -- plane e takes dy's plane e-kd+1, column w' takes column w'-kw+1, zero padding outside.  Fractional,
+    whole, zero shifts, shifts beyond the image, repeated and non-monotone rows; the depth-class sums bit-equal to
+    snvc_depth_class_sums."""
+    from oracle import native as O
+    from snvc_amd import ops
+    r = np.random.default_rng(171 + len(case))
+    N, C, D, H, W = {"odd_width": (1, 2, 7, 3, 37), "deep": (1, 1, 37, 2, 72)}.get(case, (2, 3, 9, 5, 40))
+    dy = r.standard_normal((N, C, D, H, W)).astype(np.float32)
+    s = r.uniform(0, 14, (N, D))
+    if case == "whole_pixels":
+        s = np.floor(s)
+        s[0, 0] = 0.0
+    elif case == "beyond_the_image":
+        s[:, ::2] = r.uniform(W - 2, W + 3, (N, (D + 1) // 2))
+        s[0, 1], s[-1, 3] = float(W), float(W - 1)
+    else:
+        s[0, 2], s[-1, 5], s[0, 4] = 0.0, 3.0, 0.25
+        s[0, 6] = s[0, 5]
+    s = s.astype(np.float32)
+    a, dpl = ops.warped_expand_backward(torch.from_numpy(dy).to(dev()), torch.from_numpy(s).to(dev()))
+    a = a.cpu().numpy()
+    for kd in range(3):
+        for kw in range(3):
+            g = np.zeros((N, 2 * C, D, H, W), np.float32)
+            for e in range(D):
+                d = e - kd + 1
+                if 0 <= d < D:
+                    lo, hi = max(0, kw - 1), min(W, W + kw - 1)          # w' with 0 <= w' - kw + 1 <= W-1
+                    g[:, C:, e, :, lo:hi] = dy[:, :, d, :, lo - kw + 1:hi - kw + 1]
+            _, exp = O.cost_volume_backward(g, s, 1)
+            check(a[:, kd, kw], exp, 1e-5, f"a[{kd}][{kw}] ({case})")
+    ref = ops.depth_class_sums(torch.from_numpy(dy).to(dev())) if (H * W) % 4 == 0 else None
+    if ref is not None:
+        assert torch.equal(dpl, ref)
+    else:
+        exp = np.stack([dy[:, :, 0], dy[:, :, 1:-1].sum(2), dy[:, :, -1]], axis=2)
+        check(dpl.cpu().numpy(), exp, 1e-5, "depth-class sums")
 
 
 @pytest.mark.parametrize("case", ["random", "whole_pixels", "beyond_the_image", "ragged_rows", "sweep_up", "sweep_down", "sweep_cfg1",
