@@ -291,26 +291,44 @@ conv3d_f16_kernel(const F16Args a_) {
             }
             return;
         }
+        // B fragments are double-buffered in registers: the LDS reads of k-step s + 1 are issued BEFORE the MFMAs of step s (r4;
+        // the compiler's own schedule sank every ds_read to just in front of its MFMA -- an exposed LDS round trip per fragment,
+        // hidden only by the other waves of the SIMD: 0.76 of the pipe on the bare loop at 3 waves per SIMD, 0.64 at 2)
+        constexpr int NBF = NB * (PL == 2 ? 2 : 1);
+        auto step_addr = [&](int s, int &base, int &toff) {      // s is a constant after unrolling
+            if constexpr (Cfg::MODE == 0) {
+                const int tp = s / (KCG / 2), j = s % (KCG / 2);
+                base = b_grp;
+                toff = 2 * j * GB + Cfg::tapoff(tp) * 16;
+            } else {
+                const int g = s / Cfg::NPS, p = s % Cfg::NPS;
+                const int ta = 2 * p, tb = 2 * p + 1;
+                toff = g * GB + Cfg::tapoff(ta) * 16;
+                if (tb >= Cfg::TSEG) base = b_none;              // odd tap count: the pair's second half has zero weights
+                else {
+                    const int delta = Cfg::tapoff(tb) - Cfg::tapoff(ta);
+                    base = delta == D_SAME ? b_same : (delta == D_ROW ? b_row : b_slice);
+                }
+            }
+        };
+        h8 bfr[2][NBF];
+        auto load_b = [&](int buf, const char *simg, int s) {
+            int base, toff;
+            step_addr(s, base, toff);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                bfr[buf][nb] = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
+                if constexpr (PL == 2)
+                    bfr[buf][NB + nb] = *reinterpret_cast<const h8 *>(simg + Cfg::PLANE_BYTES + base + toff + rowoff[nb]);
+            }
+        };
+        load_b(0, img, 0);
 #pragma unroll 1
         for (int seg = 0; seg < Cfg::SEGS; ++seg) {
             const char *simg = img + seg * Cfg::SEG_BYTES;
 #pragma unroll
             for (int s = 0; s < Cfg::NS; ++s) {
-                int base, toff;
-                if constexpr (Cfg::MODE == 0) {
-                    const int tp = s / (KCG / 2), j = s % (KCG / 2);
-                    base = b_grp;
-                    toff = 2 * j * GB + Cfg::tapoff(tp) * 16;
-                } else {
-                    const int g = s / Cfg::NPS, p = s % Cfg::NPS;
-                    const int ta = 2 * p, tb = 2 * p + 1;
-                    toff = g * GB + Cfg::tapoff(ta) * 16;
-                    if (tb >= Cfg::TSEG) base = b_none;          // odd tap count: the pair's second half has zero weights
-                    else {
-                        const int delta = Cfg::tapoff(tb) - Cfg::tapoff(ta);
-                        base = delta == D_SAME ? b_same : (delta == D_ROW ? b_row : b_slice);
-                    }
-                }
+                const int cur = s & 1, nxt = cur ^ 1;
                 h8 af[MA];
 #pragma unroll
                 for (int m = 0; m < MA; ++m) af[m] = q[0][m];
@@ -321,44 +339,49 @@ conv3d_f16_kernel(const F16Args a_) {
 #pragma unroll
                 for (int m = 0; m < MA; ++m) q[PF - 1][m] = wq[m * 64];
                 wq += MA * 64;
+                // the next step's fragments (behind a depth slice's last step: the first step of the next slice)
+                if (s + 1 < Cfg::NS) load_b(nxt, simg, s + 1);
+                else if (Cfg::SEGS > 1 && seg + 1 < Cfg::SEGS) load_b(nxt, simg + Cfg::SEG_BYTES, 0);
+                __builtin_amdgcn_sched_barrier(0);          // the loads stay up here: nothing of them sinks into the MFMA block
                 if constexpr (PL == 2) {
-                    // all eight B fragments of the step first, then the three product terms row by row: consecutive MFMAs
-                    // write different accumulators (no back-to-back dependence), the two correction terms before the leading one
-                    h8 bf[NB], bl[NB];
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        bf[nb] = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
-                        bl[nb] = *reinterpret_cast<const h8 *>(simg + Cfg::PLANE_BYTES + base + toff + rowoff[nb]);
-                    }
+                    // the three product terms row by row: consecutive MFMAs write different accumulators (no back-to-back
+                    // dependence), the two correction terms before the leading one
 #pragma unroll
                     for (int m = 0; m < MI; ++m) {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf[nb], acc[nb][m], 0, 0, 0);
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bfr[cur][nb], acc[nb][m], 0, 0, 0);
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bl[nb], acc[nb][m], 0, 0, 0);
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bfr[cur][NB + nb], acc[nb][m], 0, 0, 0);
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
-                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf[nb], acc[nb][m], 0, 0, 0);
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bfr[cur][nb], acc[nb][m], 0, 0, 0);
+                    }
+                } else if constexpr (SERIAL) {
+#pragma unroll
+                    for (int m = 0; m < MI; ++m) {
+                        if (!lo_pass) {
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb)
+                                acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bfr[cur][nb], acc[nb][m], 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bfr[cur][nb], acc[nb][m], 0, 0, 0);
                     }
                 } else {
 #pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        const h8 bf = *reinterpret_cast<const h8 *>(simg + base + toff + rowoff[nb]);
-                        if constexpr (SERIAL) {
+                    for (int m = 0; m < MI; ++m)
 #pragma unroll
-                            for (int m = 0; m < MI; ++m) {
-                                if (!lo_pass) acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m + 1], bf, acc[nb][m], 0, 0, 0);
-                                acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[2 * m], bf, acc[nb][m], 0, 0, 0);
-                            }
-                        } else {
-#pragma unroll
-                            for (int m = 0; m < MI; ++m)
-                                acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bf, acc[nb][m], 0, 0, 0);
-                        }
-                    }
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[m], bfr[cur][nb], acc[nb][m], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (Cfg::SEGS > 1 && Cfg::NS % 2 == 1) {      // an odd number of steps: the prefetched slice start sits in buffer 1
+#pragma unroll
+                for (int i = 0; i < NBF; ++i) bfr[0][i] = bfr[1][i];
             }
         }
     };
@@ -598,10 +621,13 @@ using F16K7N   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2>;
 using F16DCN   = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 0, true, 2>;
 
 // r4 split mode ("f16x3": fp32-accurate layers on the half pipe, see F16Cfg::PL): one channel group per chunk, two taps per MFMA
-// (MODE 1), hi and lo planes of the image side by side in LDS (2 x 19.6 KB), single-buffered at three (MI = 1) / two (MI = 2)
-// workgroups per CU.
+// (MODE 1), hi and lo planes of the image side by side in LDS (2 x 19.6 KB), single-buffered at two workgroups per CU (three
+// before the k-loop's B fragments were double-buffered in registers: 194-238 VGPRs now).  conv2 at cfg2 takes 0.88-0.90 ms in
+// every form tried since (2 or 3 WG/CU, image single- or double-buffered, loads sunk or hoisted): the SAME launch on all-zero
+// operands takes 0.76 ms -- the layer is bound by the chip's power limit (the clock under this kernel is 1.62 GHz of 2.4), not
+// by a stall a schedule could remove; profiles/r4/kernel_experiments_r4.txt item 10.
 //                         KD KH KW S  D  MI TD TH KCG MODE DB    OCC DILW PL
-using F16K3X  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, false, 3, 1, 2>;
+using F16K3X  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 2>;
 using F16K3X2 = F16Cfg<3, 3, 3, 1, 1, 2, 4, 4, 1, 1, false, 2, 1, 2>;
 // experiment (desc.algo & SNVC_ALGO_X3_SERIAL): planes taken serially, the 19.6 KB image double-buffered
 using F16K3XS  = F16Cfg<3, 3, 3, 1, 1, 1, 4, 4, 1, 1, true, 3, 1, 3>;
