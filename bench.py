@@ -138,6 +138,29 @@ def parity_vs(got, exp, rel=1e-3):
 
 
 # ------------------------------------------------------------------------------------------ helpers
+def x3_power_probe(device):
+    """The dominant kernel's launch (split-mode conv2, 32 -> 32 on 192 x 96 x 312, same instruction stream, addresses and bytes)
+    on dense random operands and on all-zero operands: the difference is clock the chip gives up to operand switching in the
+    matrix pipe under its power limit -- the part of `roofline.frac`'s distance from 1 that no schedule removes."""
+    from snvc_amd import ops
+    out = {}
+    for kind in ("random", "zeros"):
+        xin = torch.relu(torch.randn(1, C, D, H, W, device=device)) if kind == "random" else torch.zeros(1, C, D, H, W, device=device)
+        wt = (torch.randn(C, C, 3, 3, 3, device=device) * 0.05) if kind == "random" else torch.zeros(C, C, 3, 3, 3, device=device)
+        lay = ops.Conv3dLayerX3(wt)
+        xs = ops.to_split(xin, 4)
+        del xin
+        ys = torch.empty_like(xs)
+        flag = torch.zeros(1, dtype=torch.int32, device=device)
+        ms, _ = timed_ms(lambda: lay(xs, 4, flags=ops.EPI_RELU, out=ys, out_exp=4, overflow=flag), 30, 5)
+        out[kind + "_operands_ms"] = ms
+        del xs, ys
+    torch.cuda.empty_cache()
+    out["note"] = ("conv2's launch without the side head, back to back: all-zero activations and weights (no switching in the matrix "
+                   "pipe) against dense random ones -- the layer is limited by the chip's power budget, not by a stall")
+    return out
+
+
 def timed_ms(fn, reps=20, warm=10):
     for _ in range(warm):
         fn()
@@ -679,6 +702,9 @@ def main():
         _breakdown(model, left, right, shift, build_cost_volume)
     del model
     torch.cuda.empty_cache()
+    power_probe = None
+    if x3_taken and rank == 0 and not args.no_extras:
+        power_probe = x3_power_probe(device)
 
     line = None
     if rank == 0:
@@ -748,6 +774,7 @@ def main():
                 "avg_launch_ms": dom_ms,
                 "traffic": traffic if not sheared_taken else traffic_conv2,
                 "traffic_source": traffic_src,
+                "power_probe": power_probe,
                 "fp32_mfma_form": {"kernel": "conv3d_wino_dma_kernel<4x4x32, side head> (the fp32_mfma leg's conv2: Winograd F(4,3), v_mfma_f32_32x32x2_f32)",
                                    "avg_launch_ms": conv2_ms_f32, "achieved": exec_tflops_f32, "peak": PEAK_F32_MFMA_TFLOPS,
                                    "frac": exec_tflops_f32 / PEAK_F32_MFMA_TFLOPS},

@@ -557,36 +557,61 @@ conv3d_wgrad_wino_kernel(const WgradArgs a) {
         // 8 K-steps of two quads (lanes 0-31: quad 2kk, lanes 32-63: quad 2kk+1) over this wave's two rows; quad q = row q / 8,
         // quad t = q % 8 (q = 2kk + half: row kk >> 2 and quad 2 (kk & 3) + half, so everything but 4 * half is an immediate)
         const float *gq = lds + buf * Cfg::BUF_FLOATS + grow, *xq = lds + buf * Cfg::BUF_FLOATS + xrow;
+        // The three LDS reads of K-step kk + 1 are issued between the transforms and the MFMAs of step kk and pinned there (r4:
+        // the compiler had sunk every ds_read_b128 to just in front of its consumers, s_waitcnt lgkmcnt(0) per step -- one exposed
+        // LDS round trip per 3 MFMAs, hidden only by the SIMD's other two waves: pipe 0.50; the kernel is NOT power-limited, its
+        // time is the same on all-zero operands).  Behind the transforms, because the compiler waits with lgkmcnt(0) before a
+        // step's first VALU use: there nothing younger is in flight, the reads issued next have the step's 192 MFMA cycles.
+        // Both position halves read piece t+1 of the input row; ph == 0 adds the float before it, ph == 1 the float behind it.
+        // (the one float a step needs of its second input piece is read as 4 bytes: a ds_read_b128 whose other three lanes
+        // are dead gets a destination that overlaps the next read's, and a wait between the two)
+        f32x4 dyb[2], xmb[2];
+        float xsb[2];
+        auto fetch = [&](int kk, int b) {
+            dyb[b] = *reinterpret_cast<const f32x4 *>(gq + 8 * kk);                                           // r * 32 + 4 * t == 4 * q
+            const float *xp = xq + (kk >> 2) * IN_WV + 8 * (kk & 3);
+            xmb[b] = *reinterpret_cast<const f32x4 *>(xp + 4);          // piece t + 1: d1 .. d4
+            xsb[b] = xp[ph == 0 ? 3 : 8];                               // d0 (last float of piece t) or d5 (first of piece t + 2)
+        };
+        fetch(0, 0);
         if (ph == 0) {
 #pragma unroll
             for (int kk = 0; kk < Cfg::TH * 2; ++kk) {
+                const int b = kk & 1;
                 // the quad's inputs x[4t-1 .. 4t+4] are image columns 4t+3 .. 4t+8: last float of piece t, piece t+1, first of t+2
-                const f32x4 dy = *reinterpret_cast<const f32x4 *>(gq + 8 * kk);                               // r * 32 + 4 * t == 4 * q
-                const float *xp = xq + (kk >> 2) * IN_WV + 8 * (kk & 3);
-                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(xp), x1 = *reinterpret_cast<const f32x4 *>(xp + 4);
+                const f32x4 dy = dyb[b], x1 = xmb[b];
                 const float dy0 = dy[0], dy1 = dy[1], dy2 = dy[2], dy3 = dy[3];
-                const float d0 = x0[3], d1 = x1[0], d2 = x1[1], d3 = x1[2], d4 = x1[3];
+                const float d0 = xsb[b], d1 = x1[0], d2 = x1[1], d3 = x1[2], d4 = x1[3];
                 const float s02 = dy0 + dy2, s13 = dy1 + dy3;
                 const float e = __builtin_fmaf(-4.0f, d2, d4), f = __builtin_fmaf(-4.0f, d1, d3);
                 const float v0 = __builtin_fmaf(4.0f, d0, __builtin_fmaf(-5.0f, d2, d4));
+                const float a1 = s02 + s13, b1 = e + f, a2 = s02 - s13, b2 = e - f;
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < Cfg::TH * 2) fetch(kk + 1, b ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy0, v0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(s02 + s13, e + f, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(s02 - s13, e - f, acc[2], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, acc[2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
             for (int kk = 0; kk < Cfg::TH * 2; ++kk) {
-                const f32x4 dy = *reinterpret_cast<const f32x4 *>(gq + 8 * kk);
-                const float *xp = xq + (kk >> 2) * IN_WV + 8 * (kk & 3);
-                const f32x4 x1 = *reinterpret_cast<const f32x4 *>(xp + 4), x2 = *reinterpret_cast<const f32x4 *>(xp + 8);
+                const int b = kk & 1;
+                const f32x4 dy = dyb[b], x1 = xmb[b];
                 const float dy0 = dy[0], dy1 = dy[1], dy2 = dy[2], dy3 = dy[3];
-                const float d1 = x1[0], d2 = x1[1], d3 = x1[2], d4 = x1[3], d5 = x2[0];
+                const float d1 = x1[0], d2 = x1[1], d3 = x1[2], d4 = x1[3], d5 = xsb[b];
                 const float t02 = __builtin_fmaf(4.0f, dy2, dy0), t13 = __builtin_fmaf(8.0f, dy3, 2.0f * dy1);
                 const float c2 = d4 - d2, e2 = d3 - d1;
                 const float v5 = __builtin_fmaf(4.0f, d1, __builtin_fmaf(-5.0f, d3, d5));
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(t02 + t13, __builtin_fmaf(2.0f, e2, c2), acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(t02 - t13, __builtin_fmaf(-2.0f, e2, c2), acc[1], 0, 0, 0);
+                const float a0 = t02 + t13, b0 = __builtin_fmaf(2.0f, e2, c2), a1 = t02 - t13, b1 = __builtin_fmaf(-2.0f, e2, c2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk + 1 < Cfg::TH * 2) fetch(kk + 1, b ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(dy3, v5, acc[2], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // the other buffer was last read before the previous barrier: refill it, then start the loads of the tile after
