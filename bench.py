@@ -230,8 +230,20 @@ def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="
         ms_u, vox = timed_ms(lambda: gather(lf, rf, gl, gr), reps)
         ms_p, _ = timed_ms(lambda: gather(lf, rf, pl, pr), reps)
         x3_before = S_._ROUTES["x3_local_trunk"]
-        ms, res = timed_ms(lambda: trunk(gather(lf, rf, pl, pr)), reps)
+
+        def gather_for_trunk(l_, r_, a_, b_):       # what VernierScale.forward does: in split mode the gather writes the (hi, lo) pair
+            vs = None if f16 else m.construct_voxel_x3(l_, r_, a_, b_)
+            return vs if vs is not None else gather(l_, r_, a_, b_)
+        ms, res = timed_ms(lambda: trunk(gather_for_trunk(lf, rf, pl, pr)), reps)
         x3 = S_._ROUTES["x3_local_trunk"] > x3_before         # the trunk ran in split mode
+        if x3:
+            ms_ps, vsp = timed_ms(lambda: m.construct_voxel_x3(lf, rf, pl, pr), reps)
+            if vsp is not None:
+                out["gather_projected_split"] = {"ms": ms_ps, "GBps": gather_bytes / (ms_ps * 1e-3) / 1e9,
+                                                 "frac_hbm": gather_bytes / (ms_ps * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                 "note": "snvc_voxel_gather_forward_split: the same samples written as the split C8 pair the "
+                                                         "trunk starts from (same bytes as the fp32 tensor; incl. the scale from the features' maximum)"}
+            del vsp
         if x3:      # its dominant layer: conv1 (k7) in split mode, on the split pair of the same voxel tensor
             mul_ = ops_.split_scale_for(vox)
             vs_ = S_.SplitT(ops_.to_split(vox, mul_dev=mul_), 0, None, mul_)
@@ -323,7 +335,10 @@ def run_cfg3(rank, world, device, dist, steps, warmup, barrier, total=64, per_ca
         occ = []
         for a in range(0, hi - lo, per_call):
             b = min(a + per_call, hi - lo)
-            bev, oc = m.trunk_3d(m.construct_voxel(lf[a:b], rf[a:b], gl[a:b], gr[a:b]))[:2]
+            vox = m.construct_voxel_x3(lf[a:b], rf[a:b], gl[a:b], gr[a:b])      # split mode: the gather writes the (hi, lo) pair
+            if vox is None:
+                vox = m.construct_voxel(lf[a:b], rf[a:b], gl[a:b], gr[a:b])
+            bev, oc = m.trunk_3d(vox)[:2]
             occ.append(oc)
         occ = torch.cat(occ) if occ else torch.empty((0,) + grid, device=device)
         return P.gather_outputs(occ, total) if gather else occ

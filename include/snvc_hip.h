@@ -490,6 +490,15 @@ SNVC_API int snvc_f16_to_ncdhw(const void *x_c8, float *y, int64_t N, int64_t C,
 SNVC_API int snvc_voxel_gather_forward_f16(const float *left, const float *right, const float *l_pts,
                                            const float *r_pts, void *out_c8, float *workspace, int64_t N, int64_t F,
                                            int64_t Hf, int64_t Wf, int64_t V, float res_x, float res_y, void *stream);
+/* The same gather with the result written as a split C8 pair (out_hi, out_lo: [N][2F/8][V][8] half planes, batch stride in
+ * halves, 0 = a dense [N][2][2F/8][V][8] pair) for a consumer on the split-mode kernels (snvc_f16x3_*): value * *mul_dev = hi + lo,
+ * mul_dev a device scalar (a power of two with max|feature| * mul < 2^15: a bilinear sample never exceeds the features' maximum).
+ * Bit-identical to snvc_voxel_gather_forward_ws followed by snvc_f16x3_from_ncdhw(mul_dev) without the fp32 tensor in between.
+ * SNVC_ERR_UNSUPPORTED unless Hf * Wf <= 4608 and V >= 4096 (the LDS-staged form). */
+SNVC_API int snvc_voxel_gather_forward_split(const float *left, const float *right, const float *l_pts, const float *r_pts,
+                                             void *out_hi, void *out_lo, const float *mul_dev, float *workspace, int64_t N,
+                                             int64_t F, int64_t Hf, int64_t Wf, int64_t V, int64_t out_batch_stride, float res_x,
+                                             float res_y, void *stream);
 /* replaces: nn.Conv3d / nn.ConvTranspose3d (+ folded eval BatchNorm) (+ residual) (+ ReLU) as snvc_conv3d_forward
  * does, on C8 half tensors.  desc as for snvc_conv3d_forward (Cin % 8 == 0; Cout % 32 == 0; the SNVC_EPI_* flags
  * except SIGMOID; desc.algo ignored; batch strides in half elements).  scale / bias / the epilogue are fp32.

@@ -94,6 +94,7 @@ SIGNATURES = {
     "snvc_argmax_rows": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p]),
     "snvc_f16_from_ncdhw": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_f16_to_ncdhw": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_voxel_gather_forward_split": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
     "snvc_voxel_gather_forward_f16": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_f32, c_p]),
     "snvc_f16_conv3d_packed_weight_bytes": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
     "snvc_f16_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p]),

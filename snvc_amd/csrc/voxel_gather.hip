@@ -252,14 +252,18 @@ __device__ __forceinline__ TapsLds make_taps_lds(float px, float py, f2 res, f2 
 // normalisation multiplies by the reciprocal when the crop resolution is a power of two (make_taps<POW2>); and the
 // channel slices of one voxel run are dispatched back to back on ONE XCD (blocks b and b + 8 share an XCD), so that the
 // run's coordinates are read from HBM once and from that XCD's L2 by the other slices.
-template <int CS, bool HALF, int BS, bool POW2>
+// OUT: 0 = fp32 NCDHW; 1 = C8 half; 2 = a split C8 pair (r4, conv3d_f16.hip F16Cfg::PL: value * *mul_dev = hi + lo, the lo plane
+// `lo_off` halves behind the hi plane) -- the SAME separately rounded fp32 bilinear sum in all three.
+template <int CS, int OUT, int BS, bool POW2>
 __global__ void __launch_bounds__(BS)
 voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_pts, const float *__restrict__ r_pts,
                      void *__restrict__ out_, int F, int Hf, int Wf, int64_t V, int64_t vrun, int nruns, float res_x,
-                     float res_y) {
+                     float res_y, const float *__restrict__ mul_dev, int64_t lo_off, int64_t out_bs) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr bool HALF = OUT != 0;
     static_assert(HALF ? CS == 8 : CS == 4, "fp32 output: 4-channel slices; C8 half output: one 8-channel group");
+    const float mul = OUT == 2 ? *mul_dev : 1.0f;
     constexpr int U = HALF ? 1 : 4;          // voxels per thread and step
     extern __shared__ __attribute__((aligned(16))) float img[];
     const int tid = threadIdx.x;
@@ -320,7 +324,7 @@ voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_p
                 for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(res[j], reinterpret_cast<f4 *>(o + (int64_t)j * V));
             } else {
                 const TapsLds t = make_taps_lds<POW2, CS>(px[0], py[0], res2, half_size, Hf, Wf, zidx);
-                h8 res;
+                h8 res, res_lo;
 #pragma unroll
                 for (int hq = 0; hq < 2; ++hq) {
                     const f4 a4 = *reinterpret_cast<const f4 *>(img + t.a[0] + 4 * hq);
@@ -329,10 +333,20 @@ voxel_gather_fwd_lds(const float *__restrict__ ws, const float *__restrict__ l_p
                     const f4 d4 = *reinterpret_cast<const f4 *>(img + t.a[3] + 4 * hq);
                     const f4 r = a4 * t.wt[0] + b4 * t.wt[1] + c4 * t.wt[2] + d4 * t.wt[3];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) res[4 * hq + j] = (_Float16)r[j];
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (OUT == 2) {      // as snvc_f16x3_from_ncdhw: hi = rn(v * mul), lo = rn(v * mul - hi); a bilinear sample is
+                            const float vv = r[j] * mul;      // a convex combination: |v| <= max|feature|, which is what mul was chosen for
+                            const _Float16 hi = (_Float16)vv;
+                            res[4 * hq + j] = hi;
+                            res_lo[4 * hq + j] = (_Float16)(vv - (float)hi);
+                        } else {
+                            res[4 * hq + j] = (_Float16)r[j];
+                        }
+                    }
                 }
-                _Float16 *o = reinterpret_cast<_Float16 *>(out_) + ((n * 2 * (F / 8) + (int64_t)side * (F / 8) + cs) * V + v) * 8;
+                _Float16 *o = reinterpret_cast<_Float16 *>(out_) + n * out_bs + (((int64_t)side * (F / 8) + cs) * V + v) * 8;
                 __builtin_nontemporal_store(res, reinterpret_cast<h8 *>(o));
+                if constexpr (OUT == 2) __builtin_nontemporal_store(res_lo, reinterpret_cast<h8 *>(o + lo_off));
             }
         }
         __syncthreads();       // every tap of this camera is resolved before the slice is overwritten
@@ -347,9 +361,11 @@ inline bool pow2_res(float x, float &inv) {
     return true;
 }
 
-template <int CS, bool HALF, int BS>
+template <int CS, int OUT, int BS>
 int launch_gather_lds(const float *ws, const float *l_pts, const float *r_pts, void *out, int64_t N, int64_t F, int64_t Hf,
-                      int64_t Wf, int64_t V, int64_t run, float res_x, float res_y, hipStream_t st) {
+                      int64_t Wf, int64_t V, int64_t run, float res_x, float res_y, hipStream_t st, const float *mul_dev = nullptr,
+                      int64_t lo_off = 0, int64_t out_bs = -1) {
+    if (out_bs < 0) out_bs = 2 * F * V;        // dense C8: [N][2F/8][V][8] halves (unused by the fp32 form)
     const int plane = (int)(Hf * Wf);
     const size_t lds = (size_t)plane * CS * 4 + (CS / 4) * 16;     // the slice + the zero slot
     const int nruns = (int)ceil_div<int64_t>(V, run);
@@ -357,14 +373,14 @@ int launch_gather_lds(const float *ws, const float *l_pts, const float *r_pts, v
     float ix = 0.0f, iy = 0.0f;
     if (pow2_res(res_x, ix) && pow2_res(res_y, iy)) {
         static std::atomic<unsigned> attr_done{0};
-        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<CS, HALF, BS, true>), (int)lds, attr_done))
-            voxel_gather_fwd_lds<CS, HALF, BS, true><<<grid, BS, lds, st>>>(ws, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run,
-                                                                          nruns, ix, iy);
+        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<CS, OUT, BS, true>), (int)lds, attr_done))
+            voxel_gather_fwd_lds<CS, OUT, BS, true><<<grid, BS, lds, st>>>(ws, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run,
+                                                                         nruns, ix, iy, mul_dev, lo_off, out_bs);
     } else {
         static std::atomic<unsigned> attr_done{0};
-        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<CS, HALF, BS, false>), (int)lds, attr_done))
-            voxel_gather_fwd_lds<CS, HALF, BS, false><<<grid, BS, lds, st>>>(ws, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run,
-                                                                           nruns, res_x, res_y);
+        if (allow_large_lds(reinterpret_cast<const void *>(&voxel_gather_fwd_lds<CS, OUT, BS, false>), (int)lds, attr_done))
+            voxel_gather_fwd_lds<CS, OUT, BS, false><<<grid, BS, lds, st>>>(ws, l_pts, r_pts, out, (int)F, (int)Hf, (int)Wf, V, run,
+                                                                          nruns, res_x, res_y, mul_dev, lo_off, out_bs);
     }
     return 0;
 }
@@ -588,13 +604,39 @@ int snvc_voxel_gather_forward_f16(const float *left, const float *right, const f
                                                                                                     (int)F, plane);
     if ((int64_t)plane * 32 <= 144 * 1024 && V >= 4096) {      // LDS-staged 8-channel groups (one workgroup per CU)
         const int64_t run = gather_run_length(V, F / 8, N);
-        launch_gather_lds<8, true, 1024>(workspace, l_pts, r_pts, out, N, F, Hf, Wf, V, run, res_x, res_y, as_stream(stream));
+        launch_gather_lds<8, 1, 1024>(workspace, l_pts, r_pts, out, N, F, Hf, Wf, V, run, res_x, res_y, as_stream(stream));
     } else {
         dim3 grid((unsigned)ceil_div<int64_t>(V, 256), (unsigned)N);
         voxel_gather_fwd_cl_c8<<<grid, 256, 0, as_stream(stream)>>>(workspace, l_pts, r_pts, reinterpret_cast<_Float16 *>(out),
                                                                     (int)F, (int)Hf, (int)Wf, V, res_x, res_y);
     }
     return check_launch("snvc_voxel_gather_forward_f16");
+}
+
+int snvc_voxel_gather_forward_split(const float *left, const float *right, const float *l_pts, const float *r_pts, void *out_hi,
+                                    void *out_lo, const float *mul_dev, float *workspace, int64_t N, int64_t F, int64_t Hf, int64_t Wf,
+                                    int64_t V, int64_t out_batch_stride, float res_x, float res_y, void *stream) {
+    using namespace snvc;
+    if (N < 0 || F <= 0 || F % 8 != 0 || F > 256 || Hf <= 0 || Wf <= 0 || V < 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward_split: bad sizes (F % 8 == 0, F <= 256)");
+    if (N == 0 || V == 0) return SNVC_OK;
+    if (N > 65535 || Hf * Wf >= ((int64_t)1 << 24))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_voxel_gather_forward_split: feature plane or batch too large");
+    if (!left || !right || !l_pts || !r_pts || !out_hi || !out_lo || !mul_dev || !workspace)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward_split: null pointer");
+    if ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_voxel_gather_forward_split: workspace and outputs must be 16-byte aligned");
+    const int plane = (int)(Hf * Wf);
+    if (!((int64_t)plane * 32 <= 144 * 1024 && V >= 4096))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_voxel_gather_forward_split: needs the LDS-staged form (Hf * Wf <= 4608, V >= 4096)");
+    dim3 tg((unsigned)ceil_div(plane, 64), (unsigned)N, 2);
+    features_to_channels_last<<<tg, 256, (size_t)64 * (F + 1) * sizeof(float), as_stream(stream)>>>(left, right, workspace,
+                                                                                                    (int)F, plane);
+    const int64_t run = gather_run_length(V, F / 8, N);
+    const int64_t lo_off = static_cast<const _Float16 *>(out_lo) - static_cast<const _Float16 *>(out_hi);
+    launch_gather_lds<8, 2, 1024>(workspace, l_pts, r_pts, out_hi, N, F, Hf, Wf, V, run, res_x, res_y, as_stream(stream), mul_dev, lo_off,
+                                  out_batch_stride ? out_batch_stride : 4 * F * V);
+    return check_launch("snvc_voxel_gather_forward_split");
 }
 
 int snvc_voxel_atten_scale(float *vox, int64_t N, int64_t F, int64_t V, void *stream) {

@@ -155,24 +155,50 @@ class VernierScale(nn.Module):
     # "x3" (split mode or an error), "f16" (the fp16-STORAGE mode of BASELINE configs[4]: forward() gathers into C8 halves)
     precision = "auto"
 
-    def _x3_local(self, voxel):
+    def construct_voxel_x3(self, left, right, grid_proj_left, grid_proj_right):
+        """``construct_voxel`` written directly as the split C8 pair the split-mode trunk starts from (r4): the scale comes from
+        the two feature maps' own maximum (a bilinear sample is a convex combination of feature values), so the fp32 voxel tensor,
+        the pass that looked for its maximum and the layout pass are gone -- same bits as ``to_split(construct_voxel(...))`` with
+        that scale.  Returns a ``SplitT``, or None when this call does not run in split mode (``trunk_3d`` decides the same way)."""
+        from .submodule import SplitT
+        nh, nw, nl = self.cfg.n_sample_h, self.cfg.n_sample_w, self.cfg.n_sample_l
+        if (torch.is_grad_enabled() or not left.is_cuda or left.dtype != torch.float32 or grid_proj_left.size(2) != nh * nw * nl
+                or self._x3_local(None, left.device, 2 * left.size(1)) is None):
+            return None
+        mul = ops.split_scale_for(left, right)
+        try:
+            vox = ops.voxel_gather_forward_split(left, right, grid_proj_left, grid_proj_right, self.cfg.resolution, mul)
+        except ops.Unsupported:
+            return None
+        return SplitT(vox.view(left.size(0), 2, 2 * left.size(1) // 8, nh, nw, nl, 8), 0, None, mul)
+
+    def _x3_local(self, voxel, device=None, channels=None):
         """The split-mode bookkeeping of this model (overflow flag + its pinned host copy) if this call runs the trunk in split
-        mode, else None: inference only, frozen BatchNorm3d everywhere, channels a multiple of 32, no part_reg_head."""
-        from .submodule import x3_ok
+        mode, else None: inference only, frozen BatchNorm3d everywhere, channels a multiple of 32, no part_reg_head.
+        ``voxel``: the fp32 gather result, an already split ``SplitT`` (``construct_voxel_x3``), or None with ``device`` /
+        ``channels`` given (the question asked before the gather runs)."""
+        from .submodule import SplitT, x3_ok
         mode = getattr(self, "precision", "auto")
         want = mode == "x3"
         if mode in ("f32", "f16") or self.__dict__.get("_snvc_x3_off"):
             return None
-        ok = (voxel.is_cuda and voxel.dtype == torch.float32 and voxel.dim() == 5 and not hasattr(self, "part_reg_head")
-              and voxel.size(1) % 64 == 0 and not self.training
+        if isinstance(voxel, SplitT):
+            device, channels, shape_ok = voxel.t.device, 8 * voxel.t.size(2), voxel.t.dim() == 7
+        elif voxel is not None:
+            device, channels = voxel.device, voxel.size(1)
+            shape_ok = voxel.is_cuda and voxel.dtype == torch.float32 and voxel.dim() == 5
+        else:
+            shape_ok = device.type == "cuda"
+        ok = (shape_ok and not hasattr(self, "part_reg_head")
+              and channels % 64 == 0 and not self.training
               and x3_ok(self.vimg_feat, self.conv1, self.conv2, self.conv3, self.conv4, self.hg_conv3d, self.fg_cls_head))
         if not ok:
             if want:
                 raise RuntimeError("precision='x3': the trunk does not qualify (inference, eval-mode BatchNorm3d, 2F % 64 == 0)")
             return None
         st = self.__dict__.get("_snvc_x3")
-        if st is None or st["flag"].device != voxel.device:
-            st = self.__dict__["_snvc_x3"] = {"flag": torch.zeros(1, dtype=torch.int32, device=voxel.device),
+        if st is None or st["flag"].device != device:
+            st = self.__dict__["_snvc_x3"] = {"flag": torch.zeros(1, dtype=torch.int32, device=device),
                                               "flag_host": torch.zeros(1, dtype=torch.int32).pin_memory(), "flag_event": None}
         ev = st["flag_event"]
         if ev is not None and ev.query():        # the previous call's overflow flag has arrived (no sync)
@@ -194,11 +220,16 @@ class VernierScale(nn.Module):
         power of two derived from its own maximum on the device (no host round trip) and split once; every later tensor's
         exponent comes from its folded BatchNorm.  Returns the same float32 tensors as ``trunk_3d``."""
         from .submodule import SplitT, x3_exponent, x3_norm_bound, _Plan
-        n, c2 = voxel.size(0), voxel.size(1)
-        g = c2 // 16                                                             # channel groups of F channels
         flag = st["flag"]
-        mul = ops.split_scale_for(voxel)
-        vs = SplitT(ops.to_split(voxel, mul_dev=mul), 0, None, mul)
+        if isinstance(voxel, SplitT):            # construct_voxel_x3: the gather wrote the pair itself
+            vs = voxel
+            voxel = vs.t
+            n, c2 = voxel.size(0), 8 * voxel.size(2)
+        else:
+            n, c2 = voxel.size(0), voxel.size(1)
+            mul = ops.split_scale_for(voxel)
+            vs = SplitT(ops.to_split(voxel, mul_dev=mul), 0, None, mul)
+        g = c2 // 16                                                             # channel groups of F channels
 
         def nb(seq):        # the bound of a ConvBN3d's result
             conv, norm = seq[0], seq[1]
@@ -233,10 +264,13 @@ class VernierScale(nn.Module):
 
     def trunk_3d(self, voxel):
         """reference vernier.py:415-438 -> (voxel_BEV [N, F*nh/4, nw, nl], occupancy [N,1,nh,nw,nl], offset)."""
+        from .submodule import SplitT
         if not torch.is_grad_enabled():
             st = self._x3_local(voxel)
             if st is not None:
                 return self.trunk_3d_x3(voxel, st)
+        if isinstance(voxel, SplitT):            # split by construct_voxel_x3, but the trunk has left split mode since (overflow flag)
+            voxel = ops.from_split(voxel.t) / voxel.mul_dev
         n, c2 = voxel.size(0), voxel.size(1)
         f = c2 // 2
         training_graph = torch.is_grad_enabled() and (voxel.requires_grad or any(p.requires_grad for p in self.parameters()))
@@ -339,7 +373,8 @@ class VernierScale(nn.Module):
         """reference vernier.py:362-458 -> (heatmaps, occupancy, offset, coordinates, bbox)"""
         if depth is not None:
             raise NotImplementedError
-        if voxel.dtype == torch.float16:        # a C8 tensor from construct_voxel_f16: fp16-storage mode
+        from .submodule import SplitT
+        if not isinstance(voxel, SplitT) and voxel.dtype == torch.float16:        # a C8 tensor from construct_voxel_f16: fp16-storage mode
             voxel_BEV, occupancy, offset = self.trunk_3d_f16(voxel)
         else:
             voxel_BEV, occupancy, offset = self.trunk_3d(voxel)
@@ -355,7 +390,9 @@ class VernierScale(nn.Module):
         if getattr(self, "precision", "f32") == "f16" and not torch.is_grad_enabled():
             voxels = self.construct_voxel_f16(left_feat, right_feat, grid_proj_left, grid_proj_right)
         else:
-            voxels = self.construct_voxel(left_feat, right_feat, grid_proj_left, grid_proj_right)
+            voxels = self.construct_voxel_x3(left_feat, right_feat, grid_proj_left, grid_proj_right)    # split mode: a (hi, lo) pair
+            if voxels is None:
+                voxels = self.construct_voxel(left_feat, right_feat, grid_proj_left, grid_proj_right)
         ncf, occupancy, part_offsets, coordinates, bboxes = self.predict_3d_heatmaps(voxels)
         return {"ncf": ncf, "occupancy": occupancy, "coordinates": coordinates}
 

@@ -1051,6 +1051,32 @@ def voxel_gather_forward_f16(left, right, l_pts, r_pts, resolution) -> torch.Ten
     return out
 
 
+def voxel_gather_forward_split(left, right, l_pts, r_pts, resolution, mul_dev) -> torch.Tensor:
+    """_sample_2d_feat(aggregate='concat') (vernier.py:323-349) written as a split C8 pair [N, 2, 2F/8, V, 8] (``to_split``
+    layout) holding the gather's fp32 result times the device scalar ``mul_dev`` (``split_scale_for(left, right)``: a bilinear
+    sample never exceeds the features' maximum) -- bit-identical to ``to_split(voxel_gather_forward(...), mul_dev=mul_dev)``
+    without the fp32 tensor, its maximum pass and the layout pass.  Raises ``Unsupported`` for feature planes beyond the
+    LDS-staged form."""
+    _check_gather(left, right, l_pts, r_pts)
+    n, f, hf, wf = left.shape
+    if f % 8:
+        raise RuntimeError("the split gather needs F % 8 == 0")
+    if mul_dev.dtype != torch.float32 or mul_dev.numel() != 1 or mul_dev.device != left.device:
+        raise RuntimeError("mul_dev: a one-element float32 tensor on the features' device")
+    v = l_pts.size(2)
+    out = torch.empty((n, 2, 2 * f // 8, v, 8), dtype=torch.float16, device=left.device)
+    if out.numel() == 0:
+        return out
+    left, right, l_pts, r_pts = left.contiguous(), right.contiguous(), l_pts.contiguous(), r_pts.contiguous()
+    with torch.cuda.device(left.device):
+        ws = torch.empty(_lib.lib().snvc_voxel_gather_workspace_floats(n, f, hf, wf), dtype=torch.float32, device=left.device)
+        check(_lib.lib().snvc_voxel_gather_forward_split(_ptr(left), _ptr(right), _ptr(l_pts), _ptr(r_pts), _ptr(out), _ptr(out[:, 1]),
+                                                         _ptr(mul_dev), _ptr(ws), n, f, hf, wf, v, out.stride(0),
+                                                         float(resolution[1]), float(resolution[0]), _stream(left)),
+              "voxel_gather_forward_split")
+    return out
+
+
 class Conv3dLayerF16:
     """A Conv3d / ConvTranspose3d layer prepared for the fp16-storage kernels (snvc_f16_conv3d_*): same
     geometry rules as Conv3dLayer; the fp32 parameter is rounded to half when packed."""

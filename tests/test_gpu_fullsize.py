@@ -311,6 +311,46 @@ def test_local_trunk_split_mode_full_size(grid):
         _check_layer_spots(m.conv3[0], v2f, ops.from_split(v3.t, v3.exp), residual=v2f, after_act=True, tol=2e-5, what="split conv3 k5 dil2")
 
 
+@pytest.mark.parametrize("grid,n", [((32, 128, 192), 2), ((96, 96, 96), 1), ((32, 64, 96), 3)], ids=["released_2crops", "cfg3_crop_96", "small_3crops"])
+def test_split_gather_is_bitwise_the_fp32_gather_then_to_split(grid, n):
+    """r4: ``construct_voxel_x3`` (snvc_voxel_gather_forward_split) -- the gather writing the split C8 pair itself, scaled by the
+    features' own maximum -- equals ``to_split(construct_voxel(...), mul_dev=that scale)`` bit for bit (hi and lo planes), incl.
+    coordinates outside the image; the model's forward takes it in split mode and gives the same outputs as from the fp32 gather."""
+    import bench
+    from snvc_amd import ops
+    from snvc_amd.models import submodule as S
+    m = _local_model(grid)
+    f = 32
+    r = np.random.default_rng(17)
+    lf = torch.from_numpy((3.7 * r.standard_normal((n, f, 64, 64))).astype(np.float32)).to(dev())
+    rf = torch.from_numpy(r.standard_normal((n, f, 64, 64)).astype(np.float32)).to(dev())
+    pl, pr = bench.projected_coordinates(n, grid, dev())
+    pl[:, :, ::97] -= 300.0                                      # some samples outside the image: zero taps
+    with torch.no_grad():
+        vs = m.construct_voxel_x3(lf, rf, pl, pr)
+        assert vs is not None, "split mode qualifies: the gather writes the pair"
+        vox = m.construct_voxel(lf, rf, pl, pr)
+        mul = ops.split_scale_for(lf, rf)
+        assert torch.equal(mul, vs.mul_dev) and 8192.0 <= float(mul.item()) * max(lf.abs().max().item(), rf.abs().max().item()) < 16384.0
+        ref = ops.to_split(vox, mul_dev=mul)
+        assert tuple(ref.shape) == tuple(vs.t.shape)
+        assert torch.equal(ref, vs.t), "hi / lo planes of the fused gather differ from gather + layout pass"
+        before = S._ROUTES["x3_local_trunk"]
+        bev_a, occ_a, _ = m.trunk_3d(vs)
+        bev_b, occ_b, _ = m.trunk_3d(vox)
+        assert S._ROUTES["x3_local_trunk"] == before + 2
+        # the only difference: the scale (features' maximum vs the voxels' own maximum, both powers of two: exact rescaling
+        # unless the two exponents differ, then the lo parts round differently at 2^-22)
+        e = (bev_a - bev_b).abs().max().item() / bev_b.abs().max().item()
+        assert e < 2e-6, e
+        assert (occ_a - occ_b).abs().max().item() < 2e-6
+        m.precision = "f32"                                       # a pair handed to a trunk that left split mode: taken apart again
+        bev_c, _, _ = m.trunk_3d(vs)
+        bev_d, _, _ = m.trunk_3d(vox)
+        # (the pair carries 22 bits of the fp32 voxel: 2^-22 on the input, a few 1e-6 behind the fp32 trunk's Winograd layers)
+        assert (bev_c - bev_d).abs().max().item() / bev_d.abs().max().item() < 2e-5
+
+
 def test_training_step_full_size_properties():
     """cfg4 at full size (1 pair, cfg2 shapes, train-mode BatchNorm): finite gradients for every parameter and both
     feature maps, equality of the step with the Winograd forms off (desc.algo = DIRECT), and the bilinear adjoint
