@@ -137,8 +137,17 @@ template <class Cfg, int EPI>
 __global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_f16_kernel(const F16Args a_) {
     F16Args a = a_;
-    const int cls = blockIdx.z / a.N;
+    // cls_mode 1 (transposed layer): blockIdx.z = (pd, ph) * N + n and the WIDTH parity is the low bit of the tile index -- the two
+    // classes that write the even and the odd voxels of the same output lines (and read the same residual lines) are neighbours
+    // in launch order on one XCD, so their half-line stores meet in that L2 and leave it as whole lines (r4; with all eight
+    // classes on blockIdx.z the fp32-output layer of the cfg2 hourglass wrote and read every line twice: 0.223 ms)
+    int cls = blockIdx.z / a.N;
+    int tile_raw = blockIdx.x, tiles_launch = a.tiles_d * a.tiles_h * a.tiles_w;
     if (a.cls_mode == 1) {
+        tiles_launch *= 2;
+        tile_raw = xcd_remap16(blockIdx.x, tiles_launch);
+        cls = (cls << 1) | (tile_raw & 1);
+        tile_raw >>= 1;
         a.offd = (cls >> 2) & 1; a.offh = (cls >> 1) & 1; a.offw = cls & 1;
         a.wp += cls * a.cls_wstride;
     } else if (a.cls_mode == 2) {
@@ -154,10 +163,10 @@ conv3d_f16_kernel(const F16Args a_) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
-    const int t = xcd_remap16(blockIdx.x, ntiles);
+    const int t = a.cls_mode == 1 ? tile_raw : xcd_remap16(blockIdx.x, ntiles);
     const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
     const int cb = blockIdx.y;              // block of 32*MI output channels
-    const int64_t n = blockIdx.z - cls * a.N;
+    const int64_t n = blockIdx.z % a.N;
     const int od0 = td * TD, oh0 = th * TH, ow0 = tw * 32;
     if (od0 >= a.nd || oh0 >= a.nh) return;      // a smaller class of an odd extent: whole tile outside (block-uniform)
     const int id0 = od0 * S - a.pad_d, ih0 = oh0 * S - a.pad_h, iw0 = ow0 * S - a.pad_w;
@@ -898,9 +907,9 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     }
     a.tiles_d = ceil_div(a.nd, p.TD); a.tiles_h = ceil_div(a.nh, p.TH); a.tiles_w = ceil_div(a.nw, 32);
     const int64_t ntiles = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
-    if (ntiles >= ((int64_t)1 << 31) || (int64_t)d->N * classes > 65535)
+    if (ntiles >= ((int64_t)1 << 30) || (int64_t)d->N * classes > 65535)
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: too many tiles or samples");
-    dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)(d->N * classes));
+    dim3 grid((unsigned)(d->transposed ? 2 * ntiles : ntiles), (unsigned)p.cblocks, (unsigned)(d->N * (d->transposed ? 4 : classes)));
     switch (p.kind) {
         case FK1: launch_f16<F16K1, 0>(a, grid, st); break;
         case FK3: launch_f16<F16K3, 0>(a, grid, st); break;
@@ -996,9 +1005,9 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     }
     a.tiles_d = ceil_div(a.nd, p.TD); a.tiles_h = ceil_div(a.nh, p.TH); a.tiles_w = ceil_div(a.nw, 32);
     const int64_t ntiles = (int64_t)a.tiles_d * a.tiles_h * a.tiles_w;
-    if (ntiles >= ((int64_t)1 << 31) || (int64_t)d->N * classes > 65535)
+    if (ntiles >= ((int64_t)1 << 30) || (int64_t)d->N * classes > 65535)
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles or samples");
-    dim3 grid((unsigned)ntiles, (unsigned)p.cblocks, (unsigned)(d->N * classes));
+    dim3 grid((unsigned)(d->transposed ? 2 * ntiles : ntiles), (unsigned)p.cblocks, (unsigned)(d->N * (d->transposed ? 4 : classes)));
     hipStream_t st = as_stream(stream);
 #define SNVC_X3_LAUNCH(CFG) do { if (to_f32) launch_f16<CFG, 2>(a, grid, st); else launch_f16<CFG, 0>(a, grid, st); } while (0)
     switch (p.kind) {
