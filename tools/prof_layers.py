@@ -104,6 +104,16 @@ with torch.no_grad():
         flag_ = torch.zeros(1, dtype=torch.int32, device=dev)
         head_ = torch.randn(cin, device=dev) if cin == 32 else None      # conv2 carries the classifier's side head
         fn = lambda: lay(xs_, 4, flags=ops.EPI_RELU, out=ys_, out_exp=4, head=head_, overflow=flag_)  # noqa: E731
+    elif args.layer == "x3_s2":             # split-mode hourglass conv1: k3 / stride 2, 32 -> 64 on the full grid
+        from snvc_amd import ops
+        xin = torch.relu(torch.randn(1, bench.C, bench.D, bench.H, bench.W, device=dev))
+        wt = torch.randn(2 * bench.C, bench.C, 3, 3, 3, device=dev) * 0.05
+        lay = ops.Conv3dLayerX3(wt, 3, 2, 1)
+        xs_ = ops.to_split(xin, 4)
+        del xin
+        flag_ = torch.zeros(1, dtype=torch.int32, device=dev)
+        ys_ = lay(xs_, 4, flags=ops.EPI_RELU, out_exp=4, overflow=flag_)
+        fn = lambda: lay(xs_, 4, flags=ops.EPI_RELU, out=ys_, out_exp=4, overflow=flag_)  # noqa: E731
     elif args.layer in ("general_f32", "sheared_f32"):     # the fp32 expand kernels (arithmetic = fp32)
         model.arithmetic = "fp32"
         fn = lambda: model.forward_pair(left, right, shift, 1, sheared=args.layer == "sheared_f32")  # noqa: E731
