@@ -164,13 +164,18 @@ def x3_power_probe(device):
 PREWARM_S = 0.15
 
 
-def prewarm(fn, seconds=PREWARM_S):
+def prewarm(fn, seconds=PREWARM_S, fixed=None):
     """Runs `fn` for `seconds` before a leg's W warm-up steps.  After any idle stretch (model set-up, the host work between legs)
     the GPU needs ~50 ms of load to reach its sustained clocks: measured on the cfg2 step, the first 20-step window after an idle
     second reads 2.54-2.56 ms/step, every later one 2.42-2.45 (tools/clock_ramp.py).  W = 5 steps are 13 ms, so without this a
     20-step measurement sits inside that transient; what is reported is the sustained rate.  Untimed, disclosed in the line
     (`config.prewarm`)."""
     torch.cuda.synchronize()
+    if fixed is not None:       # a step with a collective in it: every rank must run the SAME number of steps
+        for _ in range(fixed):
+            fn()
+        torch.cuda.synchronize()
+        return
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(5):
@@ -363,7 +368,7 @@ def run_cfg3(rank, world, device, dist, steps, warmup, barrier, total=64, per_ca
     with torch.no_grad():
         gc.collect()
         gc.disable()
-        prewarm(step)
+        prewarm(step, fixed=1)   # one step (>= 0.04 s per rank); a fixed count: the step ends in an all-gather
         for _ in range(warmup):
             out = step()
         barrier()
@@ -431,7 +436,7 @@ def run_train(rank, world, device, dist, steps, warmup, barrier):
     ts = TrainStep(rank, device)
     gc.collect()
     gc.disable()
-    prewarm(ts)
+    prewarm(ts, fixed=8)         # ~0.17 s; a fixed count: the step ends in a collective
     for _ in range(warmup):
         ts()
     barrier()
