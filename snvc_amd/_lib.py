@@ -31,7 +31,7 @@ EPI_RELU, EPI_ADD_PRE, EPI_ADD_POST, EPI_SIGMOID, EPI_AVGPOOL_D4 = 1, 2, 4, 8, 1
 ALGO_AUTO, ALGO_DIRECT = 0, 1
 ALGO_WINO_TILE_BIG, ALGO_WINO_TILE_STD, ALGO_WINO_TILE_NARROW_REG = 0x100, 0x200, 0x300
 ALGO_GENERIC_EPILOGUE, ALGO_SCALAR_STAGING = 0x400, 0x800
-ALGO_X3_SERIAL, ALGO_X3_NARROW, ALGO_X3_SMALL = 0x1000, 0x2000, 0x4000
+ALGO_X3_SERIAL, ALGO_X3_NARROW, ALGO_X3_SMALL, ALGO_X3_Q16 = 0x1000, 0x2000, 0x4000, 0x8000
 F32, F64 = 0, 1
 
 # name -> (restype, argtypes); kept next to the header so the symbol test can walk it

@@ -534,6 +534,241 @@ conv3d_f16_kernel(const F16Args a_) {
     }
 }
 
+// ------------------------------------------------------------------------------------ 16x16x32 form (r4 prototype)
+// Split-mode 3x3x3 / stride-1 layer on v_mfma_f32_16x16x32_f16 instead of 32x32x16: under the chip's power limit the 16x16x32
+// shape sustains 18-26 % more flops on dense random operands (a quarter of the accumulator updates per flop; tools/micro/
+// mfma_power.hip).  Same tile (4 x 4 x 32 voxels x 32 output channels per workgroup), same LDS image ([plane][group][voxel]
+// pieces, two channel groups per chunk: 80 KB, two workgroups per CU), same staging as conv3d_f16_kernel.
+//   K = 32 per MFMA = 4 k-blocks of one C8 piece: k-block kb = lane >> 4 is (channel group kb & 1, tap of the pair kb >> 1);
+//   B fragment (rows = k, 16 voxels): lane (voxel lane & 15, kb) reads ONE piece -- 16 voxels of the row's left or right half;
+//   A fragment (16 output channels x 32 k): row i of co-half h is channel 8 * (i >> 2) + 4 * h + (i & 3) of the block, so that
+//   lane (kb, voxel) ends up with accumulator rows 4 kb .. 4 kb + 3 of both halves = the 8 channels of C8 group kb: one piece.
+//   Per k-step (a tap pair x a channel-group pair): 4 A fragments (2 halves x hi | lo), 16 B fragments (4 rows x 2 halves of the
+//   row x hi | lo, fetched in two half-steps of 8), 48 MFMAs (16 cycles each).
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+
+struct X3QCfg {
+    static constexpr int TD = 4, TH = 4, NB = 4, IN_D = 6, IN_H = 6, IN_W = 34, VOX = IN_D * IN_H * IN_W, GB = VOX * 16;
+    static constexpr int KCG = 2, ITEMS = 2 * KCG * VOX, PLANE_BYTES = KCG * GB, NIT = (ITEMS + 255) / 256;
+    static constexpr int IMG_BYTES = NIT * 256 * 16, LDS_BYTES = IMG_BYTES;
+    static constexpr int NS = 14, PF = 2;                  // tap pairs per chunk; A-fragment ring depth
+    static constexpr int tapoff(int t) { return ((t / 9) * IN_H + (t / 3) % 3) * IN_W + t % 3; }
+};
+
+template <int EPI>      // 0: split C8 output; 3: + the side head (Cout == 32)
+__global__ void __launch_bounds__(256, 2)
+conv3d_x3q_kernel(const F16Args a) {
+    using Cfg = X3QCfg;
+    constexpr int NB = Cfg::NB, TH = Cfg::TH, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, GB = Cfg::GB, NIT = Cfg::NIT;
+    constexpr int ITEMS = Cfg::ITEMS, KCG = Cfg::KCG, PF = Cfg::PF;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kb = lane >> 4, col = lane & 15;
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+    const int t = xcd_remap16(blockIdx.x, ntiles);
+    const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
+    const int cb = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const int od0 = td * Cfg::TD, oh0 = th * TH, ow0 = tw * 32;
+    const int id0 = od0 - a.pad_d, ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
+
+    f32x4q acc[NB][2][2];      // [row][half of the row: voxels 0-15 | 16-31][co half]
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[nb][ph][h] = f32x4q{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // ---- staging geometry (as conv3d_f16_kernel): piece i = (plane, group, dd, hh, ww)
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    unsigned off[NIT];
+    unsigned vmask = 0, gmask = 0, pmask = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        const int pg = i / VOX, r = i - pg * VOX;
+        const int plane = pg / KCG, g = pg - plane * KCG;
+        gmask |= (unsigned)(g & 1) << it;
+        pmask |= (unsigned)(plane & 1) << it;
+        const int dd = r / (IN_H * IN_W), r2 = r - dd * (IN_H * IN_W);
+        const int hh = r2 / IN_W, ww = r2 - hh * IN_W;
+        const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww;
+        const bool ok = i < ITEMS && (unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Hin && (unsigned)gw < (unsigned)a.Win;
+        off[it] = ok ? (unsigned)(g * in_dhw + gd * in_hw + gh * a.Win + gw) : 0u;
+        vmask |= (ok ? 1u : 0u) << it;
+    }
+    const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = a.x_lo + n * a.x_bs;
+    const int wbase = tid & ~63;
+    auto issue = [&](int chunk) {
+        const int64_t coff = (int64_t)chunk * KCG * in_dhw * 8;
+        const int cg_left = a.CGin - chunk * KCG;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            const bool ok = ((vmask >> it) & 1u) && (int)((gmask >> it) & 1u) < cg_left;
+            const _Float16 *xc = (((pmask >> it) & 1u) ? xn_lo : xn) + coff;
+            const void *src = ok ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
+            if (ITEMS % 256 == 0 || i < ITEMS)
+                __builtin_amdgcn_global_load_lds(static_cast<const float *>(src), reinterpret_cast<float *>(lds + (it * 256 + wbase) * 16), 16, 0, 0);
+        }
+    };
+
+    // ---- B addressing: lane (voxel col, k-block kb): + (kb & 1) channel groups, + (kb >> 1) taps of the pair
+    constexpr int D_SAME = 1, D_ROW = IN_W - 2, D_SLICE = IN_H * IN_W - 2 * IN_W - 2;
+    const int lb0 = col * 16 + (kb & 1) * GB;
+    const int b_same = lb0 + (kb >> 1) * D_SAME * 16, b_row = lb0 + (kb >> 1) * D_ROW * 16, b_slice = lb0 + (kb >> 1) * D_SLICE * 16;
+    int rowoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        rowoff[nb] = ((row / TH) * IN_H + (row % TH)) * IN_W * 16;
+    }
+    // ---- A fragments: [cout block][chunk][tap pair][co half][hi | lo][lane] pieces, in consumption order
+    const int64_t steps_total = (int64_t)a.nchunks * Cfg::NS;
+    const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * 4) * 64 + lane;
+    h8 q[PF][4];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) q[i][m] = wq[m * 64];
+        wq += 4 * 64;          // the packed buffer carries PF steps of zero padding behind the last block
+    }
+
+    auto step_addr = [&](int s, int &base, int &toff) {       // s is a constant after unrolling
+        const int ta = 2 * s, tb = 2 * s + 1;
+        toff = Cfg::tapoff(ta) * 16;
+        if (tb >= 27) { base = lb0; return; }                  // the 28th slot has zero weights: both taps of the pair read tap 26's piece
+                                                               // (a piece further on may lie outside the image: 0 x garbage)
+        const int delta = Cfg::tapoff(tb) - Cfg::tapoff(ta);
+        base = delta == D_SAME ? b_same : (delta == D_ROW ? b_row : b_slice);
+    };
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        issue(chunk);
+        __syncthreads();
+        // half-step hs = 2 s + j covers rows 2 j, 2 j + 1 of k-step s; its 8 B fragments are fetched one half-step ahead
+        h8 bfr[2][8];      // [buffer][(row of the half-step) * 4 + (row half) * 2 + plane]
+        auto load_b = [&](int buf, int hs) {
+            int base, toff;
+            step_addr(hs >> 1, base, toff);
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl)
+                        bfr[buf][rr * 4 + ph * 2 + pl] =
+                            *reinterpret_cast<const h8 *>(lds + pl * Cfg::PLANE_BYTES + base + toff + rowoff[2 * (hs & 1) + rr] + ph * 256);
+        };
+        load_b(0, 0);
+        h8 af[4];
+#pragma unroll
+        for (int hs = 0; hs < 2 * Cfg::NS; ++hs) {
+            const int cur = hs & 1, nxt = cur ^ 1;
+            if ((hs & 1) == 0) {           // a new k-step: its weights leave the ring, the step PF ahead is requested
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = q[0][m];
+#pragma unroll
+                for (int i = 0; i + 1 < PF; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) q[i][m] = q[i + 1][m];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) q[PF - 1][m] = wq[m * 64];
+                wq += 4 * 64;
+            }
+            if (hs + 1 < 2 * Cfg::NS) load_b(nxt, hs + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // af: [0] = half 0 hi, [1] = half 0 lo, [2] = half 1 hi, [3] = half 1 lo.  Per accumulator: lo_w * hi_x, hi_w * lo_x, hi_w * hi_x
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const h8 aw = term == 0 ? af[2 * h + 1] : af[2 * h];
+                            const h8 bx = bfr[cur][rr * 4 + ph * 2 + (term == 1 ? 1 : 0)];
+                            acc[2 * (hs & 1) + rr][ph][h] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_f16(aw, bx, acc[2 * (hs & 1) + rr][ph][h], 0, 0, 0);
+                        }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (kb, col) holds the 8 channels of C8 group cb * 4 + kb for voxel col (+16) of each of its rows
+    const int out_hw = a.Hout * a.Wout;
+    const int64_t out_dhw = (int64_t)out_hw * a.Dout;
+    const bool relu = (a.flags & SNVC_EPI_RELU) != 0;
+    const int c0 = cb * 32 + 8 * kb;
+    float sc[8], bi[8], hw8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = a.scale ? a.scale[c0 + e] : 1.0f;
+        bi[e] = a.scale ? a.bias[c0 + e] : 0.0f;
+        hw8[e] = (EPI == 3) ? a.head[c0 + e] : 0.0f;
+    }
+    _Float16 *yn = a.y + n * a.y_bs + (int64_t)(cb * 4 + kb) * out_dhw * 8;
+    _Float16 *yn_lo = a.y_lo + n * a.y_bs + (int64_t)(cb * 4 + kb) * out_dhw * 8;
+    constexpr float kHalfMax = 65504.0f;
+    const float lo_bound = relu ? 0.0f : -kHalfMax;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int pd = od0 + row / TH, phh = oh0 + row % TH;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int pw = ow0 + 16 * ph + col;
+            const bool ok = pd < a.nd && phh < a.nh && pw < a.nw;
+            const int64_t sp = ok ? ((int64_t)pd * out_hw + phh * a.Wout + pw) : 0;
+            h8 o, ol;
+            float hsum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = __builtin_fmaf(acc[nb][ph][e >> 2][e & 3], sc[e], bi[e]);
+                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
+                v = __builtin_amdgcn_fmed3f(v, lo_bound, kHalfMax);
+                if constexpr (EPI == 3) hsum += hw8[e] * v;
+                o[e] = (_Float16)v;
+                ol[e] = (_Float16)(v - (float)o[e]);
+            }
+            if (ok) {
+                *reinterpret_cast<h8 *>(yn + sp * 8) = o;
+                *reinterpret_cast<h8 *>(yn_lo + sp * 8) = ol;
+            }
+            if constexpr (EPI == 3) {      // the four k-block lanes of a voxel hold its 32 channels
+                float tot = hsum + __shfl_xor(hsum, 16, 64);
+                tot += __shfl_xor(tot, 32, 64);
+                if (ok && kb == 0) a.y_head[n * out_dhw + sp] = tot * a.head_mul;
+            }
+        }
+    }
+    if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
+}
+
+__global__ void pack_x3q_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Cin, int nchunks,
+                                        float wmul, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int pl = (int)(r % 2); r /= 2;
+    const int h = (int)(r % 2); r /= 2;
+    const int s = (int)(r % X3QCfg::NS); r /= X3QCfg::NS;
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int cb = (int)r;
+    const int row = lane & 15, kb = lane >> 4;
+    const int co = cb * 32 + 8 * (row >> 2) + 4 * h + (row & 3);
+    const int ci = (chunk * 2 + (kb & 1)) * 8 + e;
+    const int tap = 2 * s + (kb >> 1);
+    float v = 0.0f;
+    if (tap < 27 && co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * 27 + tap] * wmul;
+    const _Float16 hi = (_Float16)v;
+    out[i] = pl == 0 ? hi : (_Float16)(v - (float)hi);
+}
+
 // ------------------------------------------------------------------------------------ weight packing
 struct PackArgs {
     const float *w;
@@ -662,7 +897,7 @@ using F16K5D2X = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2, 3>;
 using F16K7X   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 3>;
 using F16DCXN  = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 1, false, 3, 1, 2, true>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
@@ -713,6 +948,15 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                     case 512: p = plan_from<F16K5D2X>(FK5D2X); break;
                     case 711: p = plan_from<F16K7X>(FK7X); break;
                     case 311:
+                        if ((d.algo & SNVC_ALGO_X3_Q16) && d.Cin % 16 == 0) {      // the 16x16x32 form: its own packing
+                            p = plan_from<F16K3X>(FK3XQ);
+                            p.KCG = 2; p.MI = 1; p.STEPS = X3QCfg::NS; p.NS = X3QCfg::NS; p.PF = X3QCfg::PF;
+                            p.nchunks = d.Cin / 16;
+                            p.cblocks = d.Cout / 32;
+                            p.block_halves = (int64_t)p.cblocks * p.nchunks * X3QCfg::NS * 4 * 64 * 8;
+                            if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: too many channel blocks or samples");
+                            return SNVC_OK;
+                        }
                         if (d.algo & SNVC_ALGO_X3_SMALL) p = plan_from<F16K3XT>(FK3XT);
                         else if (d.algo & SNVC_ALGO_X3_NARROW) p = plan_from<F16K3X>(FK3X);
                         else if (d.algo & SNVC_ALGO_X3_SERIAL) p = d.Cout == 32 ? plan_from<F16K3XS>(FK3XS) : plan_from<F16K3X2S>(FK3X2S);
@@ -772,7 +1016,10 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
     return SNVC_OK;
 }
 
-inline int64_t f16_class_stride(const F16Plan &p) { return p.block_halves + (int64_t)p.PF * p.MI * (p.PL >= 2 ? 2 : 1) * 64 * 8; }
+inline int64_t f16_class_stride(const F16Plan &p) {
+    if (p.kind == FK3XQ) return p.block_halves + (int64_t)p.PF * 4 * 64 * 8;
+    return p.block_halves + (int64_t)p.PF * p.MI * (p.PL >= 2 ? 2 : 1) * 64 * 8;
+}
 
 template <class Cfg, int EPI>
 void launch_f16(const F16Args &a, dim3 grid, hipStream_t st) {
@@ -805,6 +1052,11 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
     const int64_t bytes = 2 * f16_class_stride(p) * classes;
     if (hipMemsetAsync(packed, 0, (size_t)bytes, as_stream(stream)) != hipSuccess)   // the ring's read-ahead padding
         return fail(SNVC_ERR_HIP, "snvc_f16_conv3d_pack_weights: hipMemsetAsync failed");
+    if (p.kind == FK3XQ) {
+        pack_x3q_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, p.nchunks, wmul, p.block_halves);
+        return check_launch(who);
+    }
     for (int c = 0; c < classes; ++c) {
         PackArgs a;
         a.w = weight;
@@ -957,7 +1209,7 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: RELU / ADD_PRE / ADD_POST only (SIGMOID with the one-channel output)");
     if ((head != nullptr) != (y_head != nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: head and y_head go together");
-    if (head && ((p.kind != FK3X && p.kind != FK3XS && p.kind != FK3XT) || d->Cout != 32 || to_f32))
+    if (head && ((p.kind != FK3X && p.kind != FK3XS && p.kind != FK3XT && p.kind != FK3XQ) || d->Cout != 32 || to_f32))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the side head is built for 32-channel stride-1 layers with a split output");
     const int64_t in_sp = (int64_t)d->Din * d->Hin * d->Win, out_sp = (int64_t)d->Dout * d->Hout * d->Wout;
     if ((int64_t)(d->Cin / 8 + 2) * in_sp >= ((int64_t)1 << 31) || out_sp >= ((int64_t)1 << 31))
@@ -1036,6 +1288,18 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
         case FK5D2X: SNVC_X3_LAUNCH(F16K5D2X); break;
         case FK7X: SNVC_X3_LAUNCH(F16K7X); break;
         case FK3XH: launch_f16<F16K3X, 1>(a, grid, st); break;
+        case FK3XQ: {
+            if (to_f32 || resflags) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the 16x16x32 form has no residual / fp32 output");
+            static std::atomic<unsigned> attr_q0{0}, attr_q3{0};
+            if (head) {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<3>), X3QCfg::LDS_BYTES, attr_q3))
+                    conv3d_x3q_kernel<3><<<grid, 256, X3QCfg::LDS_BYTES, st>>>(a);
+            } else {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<0>), X3QCfg::LDS_BYTES, attr_q0))
+                    conv3d_x3q_kernel<0><<<grid, 256, X3QCfg::LDS_BYTES, st>>>(a);
+            }
+            break;
+        }
         default: return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: no kernel");
     }
 #undef SNVC_X3_LAUNCH
