@@ -1213,6 +1213,9 @@ def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) ->
     return y
 
 
+X3_Q16 = [True]        # False: the 32x32x16 forms everywhere (rounds up to mid r4)
+
+
 class Conv3dLayerX3:
     """nn.Conv3d(k3, p1, stride 1 | 2) / nn.ConvTranspose3d(k3, s2, p1, op1) prepared for the split-mode kernels
     (snvc_f16x3_conv3d_*): the fp32 contraction at fp32 accuracy on the half pipe.  The weights are packed as (hi, lo) of
@@ -1256,11 +1259,14 @@ class Conv3dLayerX3:
             self._packed[algo] = hit
         return hit
 
-    def _pick_form(self, n: int, out_sp):
-        """Kernel form of a stride-1 layer for this launch: enough workgroups to cover the 256 CUs about four times."""
+    def _pick_form(self, n: int, out_sp, plain: bool = False):
+        """Kernel form of a stride-1 layer for this launch: enough workgroups to cover the 256 CUs about four times.
+        ``plain``: no residual and a split output -- what the 16x16x32 form (r4) covers."""
         if self.forced_algo is not None or self.stride != 1 or self.transposed or self.ksize != 3 or self.cout == 1:
             return self.algo
         tiles = n * -(-out_sp[0] // 4) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32)
+        if plain and X3_Q16[0] and self.cin % 16 == 0 and self.cout % 32 == 0 and tiles * (self.cout // 32) >= 1024:
+            return _lib.ALGO_X3_Q16         # v_mfma_f32_16x16x32_f16: ~15 % faster under the chip's power limit (conv2 0.94 -> 0.81 ms)
         if self.cout % 64 == 0 and tiles * (self.cout // 64) >= 1024:
             return _lib.ALGO_X3_SERIAL      # 64-channel blocks: the serial-plane form measures 6 % faster (0.424 vs 0.453 ms, hg conv2)
         if tiles * (self.cout // 32) >= 1024 or self.cout == 32 and tiles >= 512:
@@ -1326,7 +1332,7 @@ class Conv3dLayerX3:
         sc, bi = self.folded(scale, bias, x_exp, out_exp)
         if x_mul_dev is not None:           # x holds values * x_mul_dev (a device-side power of two, see split_scale_for); x_exp is 0
             sc = (sc / x_mul_dev).contiguous()
-        self.algo = self._pick_form(n, out_sp)
+        self.algo = self._pick_form(n, out_sp, plain=residual is None and not f32)
         packed = self._pack(self.algo)
         if n == 0:
             return out_f32 if f32 else ((out, y_head) if head is not None else out)
