@@ -798,9 +798,10 @@ def main():
                 "step_cost_volume_mb_algorithmic": CV_BYTES / 1e6,
             },
             "roofline": {
-                "kernel": ("conv3d_f16_kernel<k3, split mode (f16x3), 4x4x32 tile, 3 WG/CU, side head>: second 3D convolution, 32->32 on "
-                           "192x96x312 + the classifier's projection of its own result; every fp32 product = three v_mfma_f32_32x32x16_f16 "
-                           "on (hi, lo) half pairs, fp32 accumulate (csrc/conv3d_f16.hip, F16Cfg::PL)" if x3_taken else
+                "kernel": ("conv3d_x3q_kernel<side head>: second 3D convolution, 32->32 on 192x96x312 + the classifier's projection of its own "
+                           "result, split mode (f16x3), 4x4x32 tile, 2 WG/CU; every fp32 product = three v_mfma_f32_16x16x32_f16 on (hi, lo) "
+                           "half pairs, fp32 accumulate (csrc/conv3d_f16.hip; the 16x16x32 shape sustains ~20 % more than 32x32x16 under the "
+                           "chip's power limit: tools/micro/mfma_power.hip)" if x3_taken else
                            "conv3d_wino_dma_kernel<4x4x32 tile, KC2, 3 WG/CU, side head>: second 3D convolution, 32->32 on 192x96x312 "
                            "+ the classifier's projection of its own result (Winograd F(4,3) along W, fp32 MFMA, LDS-DMA staged)"
                            if sheared_taken else
