@@ -769,6 +769,237 @@ __global__ void pack_x3q_weights_kernel(const float *__restrict__ w, _Float16 *_
     out[i] = pl == 0 ? hi : (_Float16)(v - (float)hi);
 }
 
+// 16x16x32 form of the split-mode 5^3 / dilated 5^3 / 7^3 layers (planes serial, one channel group per chunk, as F16K5X / F16K5D2X /
+// F16K7X): K = 32 = FOUR TAPS of one C8 piece -- k-block kb = lane >> 4 is tap 4 q + kb of the depth slice's (kh, kw) raster
+// (7^3: 13 quads for 49 taps; 5^3: 7 for 25; a slot beyond the last tap has zero weights and re-reads the last tap's piece).
+// A lane's byte offset inside a slice per quad sits in registers (qoff).  Same tile, image, staging, sub-grid classes and epilogue
+// contract as the 32x32x16 forms; residual (before / after the activation) supported; split C8 output only.
+template <int KS_, int DILW_>
+struct Q16SCfg {
+    static constexpr int KS = KS_, DILW = DILW_, TD = 4, TH = 4, NB = 4;
+    static constexpr int IN_D = TD + KS - 1, IN_H = TH + KS - 1, IN_W = 32 + (KS - 1) * DILW, VOX = IN_D * IN_H * IN_W;
+    static constexpr int ITEMS = VOX, NIT = (ITEMS + 255) / 256, IMG_BYTES = NIT * 256 * 16, LDS_BYTES = IMG_BYTES;
+    static constexpr int SEG_BYTES = IN_H * IN_W * 16, NT = KS * KS, NQ = (NT + 3) / 4, PF = 2;
+    static constexpr int STEPS = KS * NQ;                   // k-steps per pass
+    static_assert(NIT <= 32, "validity mask is one register");
+    static constexpr int qvox(int t) { return (t / KS) * IN_W + (t % KS) * DILW; }
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(256, 2)
+conv3d_q16s_kernel(const F16Args a_) {
+    F16Args a = a_;
+    const int cls = blockIdx.z / a.N;
+    if (a.cls_mode == 2) {
+        const int pd = (cls >> 1) & 1, ph = cls & 1;
+        a.offd = a.iod = pd; a.offh = a.ioh = ph;
+        a.nd = (a.Dout - pd + 1) / 2; a.nh = (a.Hout - ph + 1) / 2;
+    }
+    constexpr int NB = Cfg::NB, TH = Cfg::TH, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, NIT = Cfg::NIT, NQ = Cfg::NQ;
+    constexpr int ITEMS = Cfg::ITEMS, PF = Cfg::PF, KS = Cfg::KS;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kb = lane >> 4, col = lane & 15;
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
+    const int t = xcd_remap16(blockIdx.x, ntiles);
+    const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
+    const int cb = blockIdx.y;
+    const int64_t n = blockIdx.z - cls * a.N;
+    const int od0 = td * Cfg::TD, oh0 = th * TH, ow0 = tw * 32;
+    if (od0 >= a.nd || oh0 >= a.nh) return;      // a smaller class of an odd extent: whole tile outside (block-uniform)
+    const int id0 = od0 - a.pad_d, ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
+
+    f32x4q acc[NB][2][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[nb][ph][h] = f32x4q{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    unsigned off[NIT];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        const int dd = i / (IN_H * IN_W), r2 = i - dd * (IN_H * IN_W);
+        const int hh = r2 / IN_W, ww = r2 - hh * IN_W;
+        const int gd = (id0 + dd) * a.isd + a.iod, gh = (ih0 + hh) * a.ish + a.ioh, gw = iw0 + ww;
+        const bool ok = i < ITEMS && (unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Hin && (unsigned)gw < (unsigned)a.Win;
+        off[it] = ok ? (unsigned)(gd * in_hw + gh * a.Win + gw) : 0u;
+        vmask |= (ok ? 1u : 0u) << it;
+    }
+    const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = a.x_lo + n * a.x_bs;
+    const int wbase = tid & ~63;
+    auto issue = [&](int pass) {                    // pass = chunk * 2 + plane
+        const int chunk = pass >> 1;
+        const _Float16 *xc = ((pass & 1) ? xn_lo : xn) + (int64_t)chunk * in_dhw * 8;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 256 + tid;
+            const void *src = ((vmask >> it) & 1u) ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
+            if (ITEMS % 256 == 0 || i < ITEMS)
+                __builtin_amdgcn_global_load_lds(static_cast<const float *>(src), reinterpret_cast<float *>(lds + (it * 256 + wbase) * 16), 16, 0, 0);
+        }
+    };
+    // this lane's byte offset inside a depth slice for every quad of taps
+    int qoff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        int tp = 4 * q + kb;
+        tp = tp < Cfg::NT ? tp : Cfg::NT - 1;
+        qoff[q] = ((tp / KS) * IN_W + (tp % KS) * Cfg::DILW + col) * 16;
+    }
+    int rowoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        rowoff[nb] = ((row / TH) * IN_H + (row % TH)) * IN_W * 16;
+    }
+    // A fragments: [cout block][chunk][pass][slice][quad][co half][hi | lo][lane] pieces, in consumption order
+    const int npass = a.nchunks * 2;
+    const int64_t steps_total = (int64_t)npass * Cfg::STEPS;
+    const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * 4) * 64 + lane;
+    h8 q_[PF][4];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) q_[i][m] = wq[m * 64];
+        wq += 4 * 64;
+    }
+
+    for (int ps = 0; ps < npass; ++ps) {
+        issue(ps);
+        __syncthreads();
+        const bool lo_pass = ps & 1;
+        // half-step hs = 2 s + j: rows 2 j, 2 j + 1 of k-step s = (slice, quad); its 4 B fragments are fetched one half-step ahead
+        h8 bfr[2][4];
+        auto load_b = [&](int buf, const char *simg, int q, int j) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph)
+                    bfr[buf][rr * 2 + ph] = *reinterpret_cast<const h8 *>(simg + qoff[q] + rowoff[2 * j + rr] + ph * 256);
+        };
+        load_b(0, lds, 0, 0);
+        h8 af[4];
+#pragma unroll 1
+        for (int seg = 0; seg < KS; ++seg) {
+            const char *simg = lds + seg * Cfg::SEG_BYTES;
+#pragma unroll
+            for (int hs = 0; hs < 2 * NQ; ++hs) {
+                const int cur = hs & 1, nxt = cur ^ 1, j = hs & 1;
+                if (j == 0) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) af[m] = q_[0][m];
+#pragma unroll
+                    for (int i = 0; i + 1 < PF; ++i)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) q_[i][m] = q_[i + 1][m];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) q_[PF - 1][m] = wq[m * 64];
+                    wq += 4 * 64;
+                }
+                if (hs + 1 < 2 * NQ) load_b(nxt, simg, (hs + 1) >> 1, (hs + 1) & 1);
+                else if (seg + 1 < KS) load_b(nxt, simg + Cfg::SEG_BYTES, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!lo_pass) {
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                acc[2 * j + rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * h + 1], bfr[cur][rr * 2 + ph], acc[2 * j + rr][ph][h], 0, 0, 0);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            acc[2 * j + rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * h], bfr[cur][rr * 2 + ph], acc[2 * j + rr][ph][h], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // 2 NQ half-steps per slice: an even count, so the buffer roles repeat from slice to slice
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (kb, col) holds the 8 channels of C8 group cb * 4 + kb for voxel col (+16) of each of its rows
+    const int out_hw = a.Hout * a.Wout;
+    const int64_t out_dhw = (int64_t)out_hw * a.Dout;
+    const bool relu = (a.flags & SNVC_EPI_RELU) != 0, add_pre = (a.flags & SNVC_EPI_ADD_PRE) != 0, add_post = (a.flags & SNVC_EPI_ADD_POST) != 0;
+    const int c0 = cb * 32 + 8 * kb;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = a.scale ? a.scale[c0 + e] : 1.0f;
+        bi[e] = a.scale ? a.bias[c0 + e] : 0.0f;
+    }
+    const int64_t gplane = (int64_t)(cb * 4 + kb) * out_dhw * 8;
+    _Float16 *yn = a.y + n * a.y_bs + gplane, *yn_lo = a.y_lo + n * a.y_bs + gplane;
+    const _Float16 *rn = a.res ? a.res + n * a.r_bs + gplane : nullptr, *rn_lo = a.res ? a.res_lo + n * a.r_bs + gplane : nullptr;
+    constexpr float kHalfMax = 65504.0f;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        const int pd = od0 + row / TH, phh = oh0 + row % TH;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int pw = ow0 + 16 * ph + col;
+            const bool ok = pd < a.nd && phh < a.nh && pw < a.nw;
+            const int64_t sp = ok ? ((int64_t)(pd * a.osd + a.offd) * out_hw + (phh * a.osh + a.offh) * a.Wout + (pw * a.osw + a.offw)) : 0;
+            h8 rv = h8((_Float16)0.0f), rl = h8((_Float16)0.0f);
+            if (rn) { rv = *reinterpret_cast<const h8 *>(rn + sp * 8); rl = *reinterpret_cast<const h8 *>(rn_lo + sp * 8); }
+            h8 o, ol;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = __builtin_fmaf(acc[nb][ph][e >> 2][e & 3], sc[e], bi[e]);
+                const float rr = ((float)rv[e] + (float)rl[e]) * a.res_mul;
+                if (rn && add_pre) v += rr;
+                if (relu) v = __builtin_fmaxf(v, 0.0f);
+                if (rn && add_post) v += rr;
+                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
+                v = __builtin_amdgcn_fmed3f(v, -kHalfMax, kHalfMax);
+                o[e] = (_Float16)v;
+                ol[e] = (_Float16)(v - (float)o[e]);
+            }
+            if (ok) {
+                *reinterpret_cast<h8 *>(yn + sp * 8) = o;
+                *reinterpret_cast<h8 *>(yn_lo + sp * 8) = ol;
+            }
+        }
+    }
+    if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
+}
+
+// packed weights of conv3d_q16s_kernel: [cb][chunk][pass][slice kd][quad][co half][hi | lo][lane][8]
+__global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Cin, int KS, int NQ, int nchunks,
+                                         float wmul, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int e = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int pl = (int)(r % 2); r /= 2;
+    const int h = (int)(r % 2); r /= 2;
+    const int q = (int)(r % NQ); r /= NQ;
+    const int kd = (int)(r % KS); r /= KS;
+    r /= 2;                                                    // both passes of a chunk see the same weights
+    const int chunk = (int)(r % nchunks); r /= nchunks;
+    const int cb = (int)r;
+    const int row = lane & 15, kb = lane >> 4;
+    const int co = cb * 32 + 8 * (row >> 2) + 4 * h + (row & 3);
+    const int ci = chunk * 8 + e;
+    const int tp = 4 * q + kb;
+    float v = 0.0f;
+    if (tp < KS * KS && co < Cout && ci < Cin) v = w[(((int64_t)co * Cin + ci) * KS + kd) * KS * KS + tp] * wmul;
+    const _Float16 hi = (_Float16)v;
+    out[i] = pl == 0 ? hi : (_Float16)(v - (float)hi);
+}
+
 // ------------------------------------------------------------------------------------ weight packing
 struct PackArgs {
     const float *w;
@@ -897,7 +1128,7 @@ using F16K5D2X = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2, 3>;
 using F16K7X   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 3>;
 using F16DCXN  = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 1, false, 3, 1, 2, true>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
@@ -942,6 +1173,16 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                 p = plan_from<F16K3S2X>(FK3S2X);
             } else {
                 if (d.Cout % 32 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: Cout % 32 == 0");
+                if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 511 || key == 512 || key == 711)) {      // 16x16x32 form, planes serial
+                    const int ks = d.ksize, nq = (ks * ks + 3) / 4;
+                    p = key == 511 ? plan_from<F16K5X>(FK5XQ) : (key == 512 ? plan_from<F16K5D2X>(FK5D2XQ) : plan_from<F16K7X>(FK7XQ));
+                    p.KCG = 1; p.MI = 1; p.PF = 2; p.STEPS = ks * nq;
+                    p.nchunks = d.Cin / 8;
+                    p.cblocks = d.Cout / 32;
+                    p.block_halves = (int64_t)p.cblocks * p.nchunks * 2 * p.STEPS * 4 * 64 * 8;
+                    if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: too many channel blocks or samples");
+                    return SNVC_OK;
+                }
                 switch (key) {
                     case 111: p = plan_from<F16K1X>(FK1X); break;
                     case 511: p = plan_from<F16K5X>(FK5X); break;
@@ -1017,7 +1258,7 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
 }
 
 inline int64_t f16_class_stride(const F16Plan &p) {
-    if (p.kind == FK3XQ) return p.block_halves + (int64_t)p.PF * 4 * 64 * 8;
+    if (p.kind == FK3XQ || p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ) return p.block_halves + (int64_t)p.PF * 4 * 64 * 8;
     return p.block_halves + (int64_t)p.PF * p.MI * (p.PL >= 2 ? 2 : 1) * 64 * 8;
 }
 
@@ -1052,6 +1293,12 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
     const int64_t bytes = 2 * f16_class_stride(p) * classes;
     if (hipMemsetAsync(packed, 0, (size_t)bytes, as_stream(stream)) != hipSuccess)   // the ring's read-ahead padding
         return fail(SNVC_ERR_HIP, "snvc_f16_conv3d_pack_weights: hipMemsetAsync failed");
+    if (p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ) {
+        const int ks = d->ksize, nq = (ks * ks + 3) / 4;
+        pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, ks, nq, p.nchunks, wmul, p.block_halves);
+        return check_launch(who);
+    }
     if (p.kind == FK3XQ) {
         pack_x3q_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
             weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, p.nchunks, wmul, p.block_halves);
@@ -1237,7 +1484,7 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : 2 * (int64_t)d->Cout * out_sp;
     a.yf_bs = plane ? out_sp : (d->y_batch_stride ? d->y_batch_stride : (int64_t)d->Cout * out_sp);
     a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
-    const bool subgrid = p.kind == FK5D2X;        // (depth, height) parity classes share ONE packed weight block
+    const bool subgrid = p.kind == FK5D2X || p.kind == FK5D2XQ;        // (depth, height) parity classes share ONE packed weight block
     const int classes = d->transposed ? 8 : (subgrid ? 4 : 1);
     a.N = d->N; a.cls_mode = d->transposed ? 1 : (subgrid ? 2 : 0); a.cls_wstride = f16_class_stride(p);
     a.isd = a.ish = 1; a.iod = a.ioh = 0; a.offd = a.offh = a.offw = 0;
@@ -1288,6 +1535,16 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
         case FK5D2X: SNVC_X3_LAUNCH(F16K5D2X); break;
         case FK7X: SNVC_X3_LAUNCH(F16K7X); break;
         case FK3XH: launch_f16<F16K3X, 1>(a, grid, st); break;
+        case FK5XQ: case FK5D2XQ: case FK7XQ: {
+            if (to_f32 || head) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the 16x16x32 form writes a split C8 tensor, no side head");
+#define SNVC_Q16S(CFG) do { static std::atomic<unsigned> at_{0};                                                                    \
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<CFG>), CFG::LDS_BYTES, at_))                \
+                    conv3d_q16s_kernel<CFG><<<grid, 256, CFG::LDS_BYTES, st>>>(a); } while (0)
+            using C5 = Q16SCfg<5, 1>; using C5D = Q16SCfg<5, 2>; using C7 = Q16SCfg<7, 1>;
+            if (p.kind == FK5XQ) SNVC_Q16S(C5); else if (p.kind == FK5D2XQ) SNVC_Q16S(C5D); else SNVC_Q16S(C7);
+#undef SNVC_Q16S
+            break;
+        }
         case FK3XQ: {
             if (to_f32 || resflags) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the 16x16x32 form has no residual / fp32 output");
             static std::atomic<unsigned> attr_q0{0}, attr_q3{0};
