@@ -774,15 +774,20 @@ __global__ void pack_x3q_weights_kernel(const float *__restrict__ w, _Float16 *_
 // (7^3: 13 quads for 49 taps; 5^3: 7 for 25; a slot beyond the last tap has zero weights and re-reads the last tap's piece).
 // A lane's byte offset inside a slice per quad sits in registers (qoff).  Same tile, image, staging, sub-grid classes and epilogue
 // contract as the 32x32x16 forms; residual (before / after the activation) supported; split C8 output only.
-template <int KS_, int DILW_>
+template <int KS_, int DILW_, int PLQ_ = 3, int NHB_ = 1>
 struct Q16SCfg {
-    static constexpr int KS = KS_, DILW = DILW_, TD = 4, TH = 4, NB = 4;
+    // PLQ = 3: split mode, planes serial (a hi pass: lo_w * hi_x + hi_w * hi_x; a lo pass: hi_w * lo_x); PLQ = 1: the fp16-STORAGE family
+    // (one plane, one MFMA per product, C8 half output).  NHB: 32-channel blocks per workgroup (2: every B fragment feeds two
+    // blocks -- the fp16-storage form needs that: with one block its LDS reads alone saturate the LDS at the MFMA rate)
+    static constexpr int KS = KS_, DILW = DILW_, PLQ = PLQ_, NHB = NHB_, TD = 4, TH = 4, NB = 4;
+    static constexpr bool SPLIT = PLQ_ == 3;
+    static constexpr int NH = 2 * NHB, MA = NH * (SPLIT ? 2 : 1), PASSES = SPLIT ? 2 : 1;
     static constexpr int IN_D = TD + KS - 1, IN_H = TH + KS - 1, IN_W = 32 + (KS - 1) * DILW, VOX = IN_D * IN_H * IN_W;
     static constexpr int ITEMS = VOX, NIT = (ITEMS + 255) / 256, IMG_BYTES = NIT * 256 * 16, LDS_BYTES = IMG_BYTES;
     static constexpr int SEG_BYTES = IN_H * IN_W * 16, NT = KS * KS, NQ = (NT + 3) / 4, PF = 2;
     static constexpr int STEPS = KS * NQ;                   // k-steps per pass
     static_assert(NIT <= 32, "validity mask is one register");
-    static constexpr int qvox(int t) { return (t / KS) * IN_W + (t % KS) * DILW; }
+    static_assert(PLQ_ == 3 || PLQ_ == 1, "planes serial (split) or one plane (fp16 storage)");
 };
 
 template <class Cfg>
@@ -795,8 +800,9 @@ conv3d_q16s_kernel(const F16Args a_) {
         a.offd = a.iod = pd; a.offh = a.ioh = ph;
         a.nd = (a.Dout - pd + 1) / 2; a.nh = (a.Hout - ph + 1) / 2;
     }
-    constexpr int NB = Cfg::NB, TH = Cfg::TH, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, NIT = Cfg::NIT, NQ = Cfg::NQ;
-    constexpr int ITEMS = Cfg::ITEMS, PF = Cfg::PF, KS = Cfg::KS;
+    constexpr int NB = Cfg::NB, TH = Cfg::TH, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, NIT = Cfg::NIT, NQ = Cfg::NQ;
+    constexpr int ITEMS = Cfg::ITEMS, PF = Cfg::PF, KS = Cfg::KS, NH = Cfg::NH, MA = Cfg::MA;
+    constexpr bool SPLIT = Cfg::SPLIT;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kb = lane >> 4, col = lane & 15;
     const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
@@ -808,13 +814,13 @@ conv3d_q16s_kernel(const F16Args a_) {
     if (od0 >= a.nd || oh0 >= a.nh) return;      // a smaller class of an odd extent: whole tile outside (block-uniform)
     const int id0 = od0 - a.pad_d, ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
 
-    f32x4q acc[NB][2][2];
+    f32x4q acc[NB][2][NH];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) acc[nb][ph][h] = f32x4q{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int h = 0; h < NH; ++h) acc[nb][ph][h] = f32x4q{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     unsigned off[NIT];
@@ -829,11 +835,11 @@ conv3d_q16s_kernel(const F16Args a_) {
         off[it] = ok ? (unsigned)(gd * in_hw + gh * a.Win + gw) : 0u;
         vmask |= (ok ? 1u : 0u) << it;
     }
-    const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = a.x_lo + n * a.x_bs;
+    const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = SPLIT ? a.x_lo + n * a.x_bs : nullptr;
     const int wbase = tid & ~63;
-    auto issue = [&](int pass) {                    // pass = chunk * 2 + plane
-        const int chunk = pass >> 1;
-        const _Float16 *xc = ((pass & 1) ? xn_lo : xn) + (int64_t)chunk * in_dhw * 8;
+    auto issue = [&](int pass) {                    // split: pass = chunk * 2 + plane; fp16 storage: pass = chunk
+        const int chunk = SPLIT ? pass >> 1 : pass;
+        const _Float16 *xc = ((SPLIT && (pass & 1)) ? xn_lo : xn) + (int64_t)chunk * in_dhw * 8;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = it * 256 + tid;
@@ -856,22 +862,22 @@ conv3d_q16s_kernel(const F16Args a_) {
         const int row = wave * NB + nb;
         rowoff[nb] = ((row / TH) * IN_H + (row % TH)) * IN_W * 16;
     }
-    // A fragments: [cout block][chunk][pass][slice][quad][co half][hi | lo][lane] pieces, in consumption order
-    const int npass = a.nchunks * 2;
+    // A fragments: [cout block][chunk][pass][slice][quad][co half][hi | lo (split)][lane] pieces, in consumption order
+    const int npass = a.nchunks * Cfg::PASSES;
     const int64_t steps_total = (int64_t)npass * Cfg::STEPS;
-    const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * 4) * 64 + lane;
-    h8 q_[PF][4];
+    const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * MA) * 64 + lane;
+    h8 q_[PF][MA];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) q_[i][m] = wq[m * 64];
-        wq += 4 * 64;
+        for (int m = 0; m < MA; ++m) q_[i][m] = wq[m * 64];
+        wq += MA * 64;
     }
 
     for (int ps = 0; ps < npass; ++ps) {
         issue(ps);
         __syncthreads();
-        const bool lo_pass = ps & 1;
+        const bool lo_pass = SPLIT && (ps & 1);
         // half-step hs = 2 s + j: rows 2 j, 2 j + 1 of k-step s = (slice, quad); its 4 B fragments are fetched one half-step ahead
         h8 bfr[2][4];
         auto load_b = [&](int buf, const char *simg, int q, int j) {
@@ -882,7 +888,7 @@ conv3d_q16s_kernel(const F16Args a_) {
                     bfr[buf][rr * 2 + ph] = *reinterpret_cast<const h8 *>(simg + qoff[q] + rowoff[2 * j + rr] + ph * 256);
         };
         load_b(0, lds, 0, 0);
-        h8 af[4];
+        h8 af[MA];
 #pragma unroll 1
         for (int seg = 0; seg < KS; ++seg) {
             const char *simg = lds + seg * Cfg::SEG_BYTES;
@@ -891,34 +897,36 @@ conv3d_q16s_kernel(const F16Args a_) {
                 const int cur = hs & 1, nxt = cur ^ 1, j = hs & 1;
                 if (j == 0) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) af[m] = q_[0][m];
+                    for (int m = 0; m < MA; ++m) af[m] = q_[0][m];
 #pragma unroll
                     for (int i = 0; i + 1 < PF; ++i)
 #pragma unroll
-                        for (int m = 0; m < 4; ++m) q_[i][m] = q_[i + 1][m];
+                        for (int m = 0; m < MA; ++m) q_[i][m] = q_[i + 1][m];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) q_[PF - 1][m] = wq[m * 64];
-                    wq += 4 * 64;
+                    for (int m = 0; m < MA; ++m) q_[PF - 1][m] = wq[m * 64];
+                    wq += MA * 64;
                 }
                 if (hs + 1 < 2 * NQ) load_b(nxt, simg, (hs + 1) >> 1, (hs + 1) & 1);
                 else if (seg + 1 < KS) load_b(nxt, simg + Cfg::SEG_BYTES, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (!lo_pass) {
+                if constexpr (SPLIT) {
+                    if (!lo_pass) {
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr)
+                        for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-                        for (int ph = 0; ph < 2; ++ph)
+                            for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                            for (int h = 0; h < 2; ++h)
-                                acc[2 * j + rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * h + 1], bfr[cur][rr * 2 + ph], acc[2 * j + rr][ph][h], 0, 0, 0);
+                                for (int h = 0; h < NH; ++h)
+                                    acc[2 * j + rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * h + 1], bfr[cur][rr * 2 + ph], acc[2 * j + rr][ph][h], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                     for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            acc[2 * j + rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * h], bfr[cur][rr * 2 + ph], acc[2 * j + rr][ph][h], 0, 0, 0);
+                        for (int h = 0; h < NH; ++h)
+                            acc[2 * j + rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[SPLIT ? 2 * h : h], bfr[cur][rr * 2 + ph], acc[2 * j + rr][ph][h], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // 2 NQ half-steps per slice: an even count, so the buffer roles repeat from slice to slice
@@ -926,72 +934,84 @@ conv3d_q16s_kernel(const F16Args a_) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane (kb, col) holds the 8 channels of C8 group cb * 4 + kb for voxel col (+16) of each of its rows
+    // ---- epilogue: lane (kb, col) holds, per 32-channel block, the 8 channels of C8 group 4 * block + kb for voxel col (+16) of its rows
     const int out_hw = a.Hout * a.Wout;
     const int64_t out_dhw = (int64_t)out_hw * a.Dout;
     const bool relu = (a.flags & SNVC_EPI_RELU) != 0, add_pre = (a.flags & SNVC_EPI_ADD_PRE) != 0, add_post = (a.flags & SNVC_EPI_ADD_POST) != 0;
-    const int c0 = cb * 32 + 8 * kb;
-    float sc[8], bi[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        sc[e] = a.scale ? a.scale[c0 + e] : 1.0f;
-        bi[e] = a.scale ? a.bias[c0 + e] : 0.0f;
-    }
-    const int64_t gplane = (int64_t)(cb * 4 + kb) * out_dhw * 8;
-    _Float16 *yn = a.y + n * a.y_bs + gplane, *yn_lo = a.y_lo + n * a.y_bs + gplane;
-    const _Float16 *rn = a.res ? a.res + n * a.r_bs + gplane : nullptr, *rn_lo = a.res ? a.res_lo + n * a.r_bs + gplane : nullptr;
     constexpr float kHalfMax = 65504.0f;
     float vmax = 0.0f;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        const int row = wave * NB + nb;
-        const int pd = od0 + row / TH, phh = oh0 + row % TH;
+    for (int blk = 0; blk < Cfg::NHB; ++blk) {
+        const int cblk = cb * Cfg::NHB + blk;
+        if (cblk * 32 >= a.Cout) break;
+        const int c0 = cblk * 32 + 8 * kb;
+        float sc[8], bi[8];
 #pragma unroll
-        for (int ph = 0; ph < 2; ++ph) {
-            const int pw = ow0 + 16 * ph + col;
-            const bool ok = pd < a.nd && phh < a.nh && pw < a.nw;
-            const int64_t sp = ok ? ((int64_t)(pd * a.osd + a.offd) * out_hw + (phh * a.osh + a.offh) * a.Wout + (pw * a.osw + a.offw)) : 0;
-            h8 rv = h8((_Float16)0.0f), rl = h8((_Float16)0.0f);
-            if (rn) { rv = *reinterpret_cast<const h8 *>(rn + sp * 8); rl = *reinterpret_cast<const h8 *>(rn_lo + sp * 8); }
-            h8 o, ol;
+        for (int e = 0; e < 8; ++e) {
+            sc[e] = a.scale ? a.scale[c0 + e] : 1.0f;
+            bi[e] = a.scale ? a.bias[c0 + e] : 0.0f;
+        }
+        const int64_t gplane = (int64_t)(cblk * 4 + kb) * out_dhw * 8;
+        _Float16 *yn = a.y + n * a.y_bs + gplane, *yn_lo = SPLIT ? a.y_lo + n * a.y_bs + gplane : nullptr;
+        const _Float16 *rn = a.res ? a.res + n * a.r_bs + gplane : nullptr, *rn_lo = (SPLIT && a.res) ? a.res_lo + n * a.r_bs + gplane : nullptr;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float v = __builtin_fmaf(acc[nb][ph][e >> 2][e & 3], sc[e], bi[e]);
-                const float rr = ((float)rv[e] + (float)rl[e]) * a.res_mul;
-                if (rn && add_pre) v += rr;
-                if (relu) v = __builtin_fmaxf(v, 0.0f);
-                if (rn && add_post) v += rr;
-                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
-                v = __builtin_amdgcn_fmed3f(v, -kHalfMax, kHalfMax);
-                o[e] = (_Float16)v;
-                ol[e] = (_Float16)(v - (float)o[e]);
-            }
-            if (ok) {
-                *reinterpret_cast<h8 *>(yn + sp * 8) = o;
-                *reinterpret_cast<h8 *>(yn_lo + sp * 8) = ol;
+        for (int nb = 0; nb < NB; ++nb) {
+            const int row = wave * NB + nb;
+            const int pd = od0 + row / TH, phh = oh0 + row % TH;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int pw = ow0 + 16 * ph + col;
+                const bool ok = pd < a.nd && phh < a.nh && pw < a.nw;
+                const int64_t sp = ok ? ((int64_t)(pd * a.osd + a.offd) * out_hw + (phh * a.osh + a.offh) * a.Wout + (pw * a.osw + a.offw)) : 0;
+                h8 rv = h8((_Float16)0.0f), rl = h8((_Float16)0.0f);
+                if (rn) {
+                    rv = *reinterpret_cast<const h8 *>(rn + sp * 8);
+                    if constexpr (SPLIT) rl = *reinterpret_cast<const h8 *>(rn_lo + sp * 8);
+                }
+                h8 o, ol;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = __builtin_fmaf(acc[nb][ph][2 * blk + (e >> 2)][e & 3], sc[e], bi[e]);
+                    const float rr = SPLIT ? ((float)rv[e] + (float)rl[e]) * a.res_mul : (float)rv[e];
+                    if (rn && add_pre) v += rr;
+                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    if (rn && add_post) v += rr;
+                    if constexpr (SPLIT) {
+                        vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
+                        v = __builtin_amdgcn_fmed3f(v, -kHalfMax, kHalfMax);
+                    }
+                    o[e] = (_Float16)v;
+                    if constexpr (SPLIT) ol[e] = (_Float16)(v - (float)o[e]);
+                }
+                if (ok) {
+                    *reinterpret_cast<h8 *>(yn + sp * 8) = o;
+                    if constexpr (SPLIT) *reinterpret_cast<h8 *>(yn_lo + sp * 8) = ol;
+                }
             }
         }
     }
-    if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
+    if constexpr (SPLIT) {
+        if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
+    }
 }
 
-// packed weights of conv3d_q16s_kernel: [cb][chunk][pass][slice kd][quad][co half][hi | lo][lane][8]
+// packed weights of conv3d_q16s_kernel: [cb][chunk][pass][slice kd][quad][co half (NH)][hi | lo (NPL)][lane][8]
 __global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Cin, int KS, int NQ, int nchunks,
-                                         float wmul, int64_t total) {
+                                         int NH, int NPL, int PASSES, float wmul, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int64_t r = i;
     const int e = (int)(r % 8); r /= 8;
     const int lane = (int)(r % 64); r /= 64;
-    const int pl = (int)(r % 2); r /= 2;
-    const int h = (int)(r % 2); r /= 2;
+    const int pl = (int)(r % NPL); r /= NPL;
+    const int h = (int)(r % NH); r /= NH;
     const int q = (int)(r % NQ); r /= NQ;
     const int kd = (int)(r % KS); r /= KS;
-    r /= 2;                                                    // both passes of a chunk see the same weights
+    r /= PASSES;                                               // both passes of a chunk see the same weights
     const int chunk = (int)(r % nchunks); r /= nchunks;
     const int cb = (int)r;
     const int row = lane & 15, kb = lane >> 4;
-    const int co = cb * 32 + 8 * (row >> 2) + 4 * h + (row & 3);
+    const int co = (cb * (NH / 2) + (h >> 1)) * 32 + 8 * (row >> 2) + 4 * (h & 1) + (row & 3);
     const int ci = chunk * 8 + e;
     const int tp = 4 * q + kb;
     float v = 0.0f;
@@ -1128,7 +1148,7 @@ using F16K5D2X = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2, 3>;
 using F16K7X   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 3>;
 using F16DCXN  = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 1, false, 3, 1, 2, true>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
@@ -1237,6 +1257,16 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
             p = plan_from<F16K3H>(FK3H);
         } else {
             const bool narrow = d.Cout == 32;      // one 32-channel block: the MI = 1 forms
+            if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 711 || key == 512) && d.Cout % 64 == 0) {     // 16x16x32 form, two blocks per workgroup
+                const int ks = d.ksize, nq = (ks * ks + 3) / 4;
+                p = key == 711 ? plan_from<F16K7>(FK7Q) : plan_from<F16K5D2>(FK5D2Q);
+                p.KCG = 1; p.MI = 2; p.PF = 2; p.STEPS = ks * nq;
+                p.nchunks = d.Cin / 8;
+                p.cblocks = d.Cout / 64;
+                p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * 4 * 64 * 8;
+                if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: too many channel blocks or samples");
+                return SNVC_OK;
+            }
             switch (key) {
                 case 111: p = narrow ? plan_from<F16K1N>(FK1N) : plan_from<F16K1>(FK1); break;
                 case 311: p = narrow ? plan_from<F16K3H>(FK3N) : plan_from<F16K3>(FK3); break;
@@ -1258,7 +1288,8 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
 }
 
 inline int64_t f16_class_stride(const F16Plan &p) {
-    if (p.kind == FK3XQ || p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ) return p.block_halves + (int64_t)p.PF * 4 * 64 * 8;
+    if (p.kind == FK3XQ || p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q)
+        return p.block_halves + (int64_t)p.PF * 4 * 64 * 8;
     return p.block_halves + (int64_t)p.PF * p.MI * (p.PL >= 2 ? 2 : 1) * 64 * 8;
 }
 
@@ -1293,10 +1324,12 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
     const int64_t bytes = 2 * f16_class_stride(p) * classes;
     if (hipMemsetAsync(packed, 0, (size_t)bytes, as_stream(stream)) != hipSuccess)   // the ring's read-ahead padding
         return fail(SNVC_ERR_HIP, "snvc_f16_conv3d_pack_weights: hipMemsetAsync failed");
-    if (p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ) {
+    if (p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q) {
         const int ks = d->ksize, nq = (ks * ks + 3) / 4;
+        const bool sp_ = p.PL >= 2;
         pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
-            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, ks, nq, p.nchunks, wmul, p.block_halves);
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, ks, nq, p.nchunks, sp_ ? 2 : 4, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
+            p.block_halves);
         return check_launch(who);
     }
     if (p.kind == FK3XQ) {
@@ -1385,7 +1418,7 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : (int64_t)d->Cout * out_sp;
     a.yf_bs = out_sp;
     hipStream_t st = as_stream(stream);
-    const bool subgrid = p.kind == FK5D2 || p.kind == FK5D2N;      // (depth, height) parity classes share ONE packed weight block
+    const bool subgrid = p.kind == FK5D2 || p.kind == FK5D2N || p.kind == FK5D2Q;      // (depth, height) parity classes share ONE packed weight block
     const int classes = d->transposed ? 8 : (subgrid ? 4 : 1);
     a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
     a.N = d->N; a.cls_mode = d->transposed ? 1 : (subgrid ? 2 : 0); a.cls_wstride = f16_class_stride(p);
@@ -1410,6 +1443,19 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: too many tiles or samples");
     dim3 grid((unsigned)(d->transposed ? 2 * ntiles : ntiles), (unsigned)p.cblocks, (unsigned)(d->N * (d->transposed ? 4 : classes)));
     switch (p.kind) {
+        case FK7Q: case FK5D2Q: {
+            if (plane) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: the 16x16x32 form writes C8 tensors");
+            using C7 = Q16SCfg<7, 1, 1, 2>; using C5D = Q16SCfg<5, 2, 1, 2>;
+            static std::atomic<unsigned> at7{0}, at5{0};
+            if (p.kind == FK7Q) {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C7>), C7::LDS_BYTES, at7))
+                    conv3d_q16s_kernel<C7><<<grid, 256, C7::LDS_BYTES, st>>>(a);
+            } else {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C5D>), C5D::LDS_BYTES, at5))
+                    conv3d_q16s_kernel<C5D><<<grid, 256, C5D::LDS_BYTES, st>>>(a);
+            }
+            break;
+        }
         case FK1: launch_f16<F16K1, 0>(a, grid, st); break;
         case FK3: launch_f16<F16K3, 0>(a, grid, st); break;
         case FK3H: launch_f16<F16K3H, 1>(a, grid, st); break;

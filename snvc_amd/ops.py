@@ -1077,6 +1077,9 @@ def voxel_gather_forward_split(left, right, l_pts, r_pts, resolution, mul_dev) -
     return out
 
 
+X3_Q16 = [True]        # False: the 32x32x16 kernel forms everywhere (rounds up to mid r4)
+
+
 class Conv3dLayerF16:
     """A Conv3d / ConvTranspose3d layer prepared for the fp16-storage kernels (snvc_f16_conv3d_*): same
     geometry rules as Conv3dLayer; the fp32 parameter is rounded to half when packed."""
@@ -1093,6 +1096,10 @@ class Conv3dLayerF16:
         if tuple(weight.shape[2:]) != (ksize,) * 3:
             raise RuntimeError("only cubic kernels are on the path")
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
+        # r4: the 7^3 and dilated 5^3 layers with whole 64-channel blocks take the 16x16x32 kernel form (decided here: packing and
+        # launch must agree)
+        self.q16 = bool(X3_Q16[0] and not transposed and self.stride == 1 and self.cout % 64 == 0 and
+                        (self.ksize == 7 or (self.ksize == 5 and self.dilation == 2)))
         probe = self._desc(1, (16, 16, 32), 0)
         nbytes = _lib.lib().snvc_f16_conv3d_packed_weight_bytes(ctypes.byref(probe))
         if nbytes < 0:
@@ -1103,7 +1110,12 @@ class Conv3dLayerF16:
                                                           _ptr(self.packed), _stream(weight)), "snvc_f16_conv3d_pack_weights")
 
     out_spatial = Conv3dLayer.out_spatial
-    _desc = Conv3dLayer._desc
+
+    def _desc(self, *a, **k):
+        d = Conv3dLayer._desc(self, *a, **k)
+        if self.q16:
+            d.algo |= _lib.ALGO_X3_Q16
+        return d
 
     def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None):
         """y = epilogue(conv(x)) on C8 tensors.  Cout == 1: returns the fp32 plane [N,1,D,H,W] (Sigmoid allowed)."""
@@ -1211,9 +1223,6 @@ def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) ->
         check(_lib.lib().snvc_f16x3_to_ncdhw(_ptr(x), _lo_ptr(x), _ptr(y), n, c, math.prod(sp), _batch_stride(x), 0, float(2.0 ** -exp),
                                              _stream(x)), "snvc_f16x3_to_ncdhw")
     return y
-
-
-X3_Q16 = [True]        # False: the 32x32x16 forms everywhere (rounds up to mid r4)
 
 
 class Conv3dLayerX3:
