@@ -1148,7 +1148,7 @@ using F16K5D2X = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2, 3>;
 using F16K7X   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 3>;
 using F16DCXN  = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 1, false, 3, 1, 2, true>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FK5D2QN, FK7QN, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
@@ -1257,13 +1257,14 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
             p = plan_from<F16K3H>(FK3H);
         } else {
             const bool narrow = d.Cout == 32;      // one 32-channel block: the MI = 1 forms
-            if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 711 || key == 512) && d.Cout % 64 == 0) {     // 16x16x32 form, two blocks per workgroup
-                const int ks = d.ksize, nq = (ks * ks + 3) / 4;
-                p = key == 711 ? plan_from<F16K7>(FK7Q) : plan_from<F16K5D2>(FK5D2Q);
-                p.KCG = 1; p.MI = 2; p.PF = 2; p.STEPS = ks * nq;
+            if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 711 || key == 512) && d.Cout % 32 == 0) {     // 16x16x32 form, two blocks per workgroup
+                const int ks = d.ksize, nq = (ks * ks + 3) / 4;                                     // (one for Cout = 32 * odd)
+                const bool two = d.Cout % 64 == 0;
+                p = key == 711 ? plan_from<F16K7>(two ? FK7Q : FK7QN) : plan_from<F16K5D2>(two ? FK5D2Q : FK5D2QN);
+                p.KCG = 1; p.MI = two ? 2 : 1; p.PF = 2; p.STEPS = ks * nq;
                 p.nchunks = d.Cin / 8;
-                p.cblocks = d.Cout / 64;
-                p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * 4 * 64 * 8;
+                p.cblocks = d.Cout / (two ? 64 : 32);
+                p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * (two ? 4 : 2) * 64 * 8;
                 if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d: too many channel blocks or samples");
                 return SNVC_OK;
             }
@@ -1290,6 +1291,7 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
 inline int64_t f16_class_stride(const F16Plan &p) {
     if (p.kind == FK3XQ || p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q)
         return p.block_halves + (int64_t)p.PF * 4 * 64 * 8;
+    if (p.kind == FK5D2QN || p.kind == FK7QN) return p.block_halves + (int64_t)p.PF * 2 * 64 * 8;
     return p.block_halves + (int64_t)p.PF * p.MI * (p.PL >= 2 ? 2 : 1) * 64 * 8;
 }
 
@@ -1324,11 +1326,12 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
     const int64_t bytes = 2 * f16_class_stride(p) * classes;
     if (hipMemsetAsync(packed, 0, (size_t)bytes, as_stream(stream)) != hipSuccess)   // the ring's read-ahead padding
         return fail(SNVC_ERR_HIP, "snvc_f16_conv3d_pack_weights: hipMemsetAsync failed");
-    if (p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q) {
+    if (p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q || p.kind == FK5D2QN || p.kind == FK7QN) {
         const int ks = d->ksize, nq = (ks * ks + 3) / 4;
         const bool sp_ = p.PL >= 2;
+        const int nh_ = sp_ ? 2 : 2 * p.MI;
         pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
-            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, ks, nq, p.nchunks, sp_ ? 2 : 4, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, ks, nq, p.nchunks, nh_, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
             p.block_halves);
         return check_launch(who);
     }
@@ -1418,7 +1421,7 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : (int64_t)d->Cout * out_sp;
     a.yf_bs = out_sp;
     hipStream_t st = as_stream(stream);
-    const bool subgrid = p.kind == FK5D2 || p.kind == FK5D2N || p.kind == FK5D2Q;      // (depth, height) parity classes share ONE packed weight block
+    const bool subgrid = p.kind == FK5D2 || p.kind == FK5D2N || p.kind == FK5D2Q || p.kind == FK5D2QN;      // (depth, height) parity classes share ONE packed weight block
     const int classes = d->transposed ? 8 : (subgrid ? 4 : 1);
     a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
     a.N = d->N; a.cls_mode = d->transposed ? 1 : (subgrid ? 2 : 0); a.cls_wstride = f16_class_stride(p);
@@ -1443,6 +1446,18 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: too many tiles or samples");
     dim3 grid((unsigned)(d->transposed ? 2 * ntiles : ntiles), (unsigned)p.cblocks, (unsigned)(d->N * (d->transposed ? 4 : classes)));
     switch (p.kind) {
+        case FK7QN: case FK5D2QN: {
+            using C7 = Q16SCfg<7, 1, 1, 1>; using C5D = Q16SCfg<5, 2, 1, 1>;
+            static std::atomic<unsigned> at7{0}, at5{0};
+            if (p.kind == FK7QN) {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C7>), C7::LDS_BYTES, at7))
+                    conv3d_q16s_kernel<C7><<<grid, 256, C7::LDS_BYTES, st>>>(a);
+            } else {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C5D>), C5D::LDS_BYTES, at5))
+                    conv3d_q16s_kernel<C5D><<<grid, 256, C5D::LDS_BYTES, st>>>(a);
+            }
+            break;
+        }
         case FK7Q: case FK5D2Q: {
             if (plane) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: the 16x16x32 form writes C8 tensors");
             using C7 = Q16SCfg<7, 1, 1, 2>; using C5D = Q16SCfg<5, 2, 1, 2>;

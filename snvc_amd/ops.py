@@ -1096,9 +1096,8 @@ class Conv3dLayerF16:
         if tuple(weight.shape[2:]) != (ksize,) * 3:
             raise RuntimeError("only cubic kernels are on the path")
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
-        # r4: the 7^3 and dilated 5^3 layers with whole 64-channel blocks take the 16x16x32 kernel form (decided here: packing and
-        # launch must agree)
-        self.q16 = bool(X3_Q16[0] and not transposed and self.stride == 1 and self.cout % 64 == 0 and
+        # r4: the 7^3 and dilated 5^3 layers take the 16x16x32 kernel form (decided here: packing and launch must agree)
+        self.q16 = bool(X3_Q16[0] and not transposed and self.stride == 1 and self.cout % 32 == 0 and
                         (self.ksize == 7 or (self.ksize == 5 and self.dilation == 2)))
         probe = self._desc(1, (16, 16, 32), 0)
         nbytes = _lib.lib().snvc_f16_conv3d_packed_weight_bytes(ctypes.byref(probe))
