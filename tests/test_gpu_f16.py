@@ -458,3 +458,87 @@ def test_split_mode_side_head_and_overflow_flag():
     assert flag.item() == 1 and torch.isfinite(big.float()).all()
     with pytest.raises(RuntimeError):
         ops.Conv3dLayerX3(torch.randn(32, 32, 5, 5, 5, device=dev()), 5, 2, 2, 1, False)       # a stride-2 k5 layer: not on the path
+
+
+@pytest.mark.parametrize("case", ["k3_32_32", "k3_48_64", "k3_64_32_ragged", "k7_64_32", "k7_16_64", "k5d2_32_32", "k5d2_8_96"])
+def test_split_mode_16x16x32_forms_vs_float64(case):
+    """r4: the kernel forms on v_mfma_f32_16x16x32_f16 (SNVC_ALGO_X3_Q16; the default only from ~1000 workgroups on, forced here on
+    small and ragged shapes): 3x3x3 (two taps x two channel groups per MFMA, side head), 7^3 and dilated 5^3 (four taps per MFMA,
+    planes serial, sub-grid classes, residual before / after the activation with its own exponent) against float64 at the
+    exact-fp32 tolerance, and against the 32x32x16 forms."""
+    from snvc_amd import _lib, ops
+    from test_gpu_parity import TIGHT, check
+    torch.manual_seed(100 + len(case))
+    cin, cout, k, dil, shape = {
+        "k3_32_32": (32, 32, 3, 1, (8, 12, 40)), "k3_48_64": (48, 64, 3, 1, (5, 9, 33)), "k3_64_32_ragged": (64, 32, 3, 1, (10, 9, 70)),
+        "k7_64_32": (64, 32, 7, 1, (8, 9, 35)), "k7_16_64": (16, 64, 7, 1, (5, 6, 64)), "k5d2_32_32": (32, 32, 5, 2, (9, 10, 36)),
+        "k5d2_8_96": (8, 96, 5, 2, (7, 7, 50))}[case]
+    pad = dil * (k - 1) // 2
+    x = torch.relu(torch.randn(2, cin, *shape, device=dev())) * 2.0 + 0.01 * torch.randn(2, cin, *shape, device=dev())
+    w = torch.randn(cout, cin, k, k, k, device=dev()) * np.sqrt(2.0 / (cin * k ** 3))
+    scale, bias = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.3
+    q16 = ops.Conv3dLayerX3(w, k, 1, pad, dil, algo=_lib.ALGO_X3_Q16)
+    old = ops.Conv3dLayerX3(w, k, 1, pad, dil, algo=0)
+    raw = F.conv3d(x.double().cpu(), w.double().cpu(), None, 1, pad, dil)
+    aff = raw * scale.double().cpu().view(1, -1, 1, 1, 1) + bias.double().cpu().view(1, -1, 1, 1, 1)
+    ref = torch.relu(aff)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev())
+    xs = ops.to_split(x, 3)
+    ys = q16(xs, 3, scale, bias, flags=ops.EPI_RELU, out_exp=2, overflow=flag)
+    got = ops.from_split(ys, 2)
+    check(got.cpu().numpy(), ref.numpy(), TIGHT, f"{case}: 16x16x32 form vs float64")
+    yo = ops.from_split(old(xs, 3, scale, bias, flags=ops.EPI_RELU, out_exp=2, overflow=flag), 2)
+    assert (got - yo).abs().max().item() <= 2e-6 * yo.abs().max().item(), "the two instruction shapes differ by fp32 summation order only"
+    assert int(flag.item()) == 0
+    if k == 3:
+        if cout == 32:      # the side head: the classifier's projection of the layer's own result
+            head = torch.randn(cout, device=dev())
+            y2, hv = q16(xs, 3, scale, bias, flags=ops.EPI_RELU, out_exp=2, head=head, overflow=flag)
+            assert torch.equal(y2, ys)
+            check(hv.cpu().numpy(), (ref * head.double().cpu().view(1, -1, 1, 1, 1)).sum(1, keepdim=True).numpy(), TIGHT, f"{case}: side head")
+        with pytest.raises(ops.Unsupported):      # no residual / fp32 output in this form: the caller takes another one
+            q16(xs, 3, scale, bias, flags=ops.EPI_RELU, to_f32=True)
+    else:
+        res = torch.randn_like(got)
+        rs = ops.to_split(res, 5)
+        yb = q16(xs, 3, scale, bias, residual=rs, res_exp=5, flags=ops.EPI_RELU | ops.EPI_ADD_POST, out_exp=2, overflow=flag)
+        check(ops.from_split(yb, 2).cpu().numpy(), (ref + res.double().cpu()).numpy(), TIGHT, f"{case}: residual after the activation")
+        ya = q16(xs, 3, scale, bias, residual=rs, res_exp=5, flags=ops.EPI_RELU | ops.EPI_ADD_PRE, out_exp=2, overflow=flag)
+        check(ops.from_split(ya, 2).cpu().numpy(), torch.relu(aff + res.double().cpu()).numpy(), TIGHT, f"{case}: residual before the activation")
+    # an exponent too large for half: clamped and flagged, like every split-mode form
+    q16(xs, 3, scale * 4096.0, bias, flags=ops.EPI_RELU, out_exp=8, overflow=flag)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("case", ["k7_64_32", "k7_16_64", "k5d2_32_64", "k5d2_24_32"])
+def test_f16_storage_16x16x32_forms_vs_torch(case):
+    """r4: the fp16-STORAGE 7^3 / dilated 5^3 layers take the 16x16x32 form (one or two 32-channel blocks per workgroup) by
+    default; against torch on the half-rounded operands like every layer of the family, and against the 32x32x16 form."""
+    from snvc_amd import ops
+    torch.manual_seed(200 + len(case))
+    cin, cout, k, dil, shape = {"k7_64_32": (64, 32, 7, 1, (6, 9, 37)), "k7_16_64": (16, 64, 7, 1, (5, 6, 64)),
+                                "k5d2_32_64": (32, 64, 5, 2, (9, 10, 36)), "k5d2_24_32": (24, 32, 5, 2, (7, 7, 50))}[case]
+    pad = dil * (k - 1) // 2
+    x = torch.randn(2, cin, *shape, device=dev())
+    w = torch.randn(cout, cin, k, k, k, device=dev()) * np.sqrt(2.0 / (cin * k ** 3))
+    scale, bias = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.3
+    xc = ops.to_c8(x)
+    lay = ops.Conv3dLayerF16(w, k, 1, pad, dil, False)
+    assert lay.q16
+    ops.X3_Q16[0] = False
+    try:
+        old = ops.Conv3dLayerF16(w, k, 1, pad, dil, False)
+    finally:
+        ops.X3_Q16[0] = True
+    assert not old.q16
+    res = torch.randn(2, cout, *shape, device=dev())
+    rc = ops.to_c8(res)
+    ref = F.conv3d(h(x).double().cpu(), h(w).double().cpu(), None, 1, pad, dil) * scale.double().cpu().view(1, -1, 1, 1, 1) \
+        + bias.double().cpu().view(1, -1, 1, 1, 1)
+    for flags, exp in ((ops.EPI_RELU, torch.relu(ref)), (ops.EPI_RELU | ops.EPI_ADD_PRE, torch.relu(ref + h(res).double().cpu())),
+                       (ops.EPI_RELU | ops.EPI_ADD_POST, torch.relu(ref) + h(res).double().cpu())):
+        kw = dict(residual=rc) if flags != ops.EPI_RELU else {}
+        got = ops.from_c8(lay(xc, scale, bias, flags=flags, **kw), cout)
+        close_f16(got.cpu(), exp.float(), f"{case} flags={flags}")
+        was = ops.from_c8(old(xc, scale, bias, flags=flags, **kw), cout)
+        close_f16(got.cpu(), was.cpu(), f"{case} flags={flags}: 16x16x32 vs 32x32x16")
