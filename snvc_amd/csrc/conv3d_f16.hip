@@ -534,33 +534,60 @@ conv3d_f16_kernel(const F16Args a_) {
     }
 }
 
-// ------------------------------------------------------------------------------------ 16x16x32 form (r4 prototype)
+// ------------------------------------------------------------------------------------ 16x16x32 form of the 3x3x3 layer (r4)
 // Split-mode 3x3x3 / stride-1 layer on v_mfma_f32_16x16x32_f16 instead of 32x32x16: under the chip's power limit the 16x16x32
 // shape sustains 18-26 % more flops on dense random operands (a quarter of the accumulator updates per flop; tools/micro/
-// mfma_power.hip).  Same tile (4 x 4 x 32 voxels x 32 output channels per workgroup), same LDS image ([plane][group][voxel]
-// pieces, two channel groups per chunk: 80 KB, two workgroups per CU), same staging as conv3d_f16_kernel.
-//   K = 32 per MFMA = 4 k-blocks of one C8 piece: k-block kb = lane >> 4 is (channel group kb & 1, tap of the pair kb >> 1);
+// mfma_power.hip).  Same tile as conv3d_f16_kernel's F16K3X (4 x 4 x 32 voxels x 32 output channels per workgroup).
+//   K = 32 per MFMA = 4 k-blocks of one C8 piece: k-block kb = lane >> 4 is ONE OF FOUR TAPS of one channel group (tap 4 q + kb of the
+//   27 in (kd, kh, kw) raster order: 7 quads = 28 slots, the 28th with zero weights), so a chunk is one channel group and its image
+//   -- both planes, [plane][voxel] pieces, 39 KB -- is DOUBLE-BUFFERED at two workgroups per CU (2 x 78 KB);
 //   B fragment (rows = k, 16 voxels): lane (voxel lane & 15, kb) reads ONE piece -- 16 voxels of the row's left or right half;
 //   A fragment (16 output channels x 32 k): row i of co-half h is channel 8 * (i >> 2) + 4 * h + (i & 3) of the block, so that
 //   lane (kb, voxel) ends up with accumulator rows 4 kb .. 4 kb + 3 of both halves = the 8 channels of C8 group kb: one piece.
-//   Per k-step (a tap pair x a channel-group pair): 4 A fragments (2 halves x hi | lo), 16 B fragments (4 rows x 2 halves of the
-//   row x hi | lo, fetched in two half-steps of 8), 48 MFMAs (16 cycles each).
+//   Per k-step (a tap quad): 4 A fragments (2 halves x hi | lo), 16 B fragments (4 rows x 2 halves of the row x hi | lo, fetched
+//   in two half-steps of 8), 48 MFMAs (16 cycles each).
+// (First form, measured and replaced: two taps x two channel groups per MFMA -- an 80 KB image, single-buffered, whose refills cost
+// 10 % of conv2: 0.838 ms against 0.818 for this one; profiles/r4/kernel_experiments_r4.txt items 16-18.)
+// How the refill overlaps the MFMAs -- three facts about the toolchain and the hardware decide the shape of the loop:
+//   * the backend drains every LDS-DMA in flight (s_waitcnt vmcnt(0)) in front of the first ds_read that follows one: it cannot tell
+//     the two buffers apart (the DMA intrinsic carries no alias scope; __restrict__ does not reach it).  So the B-fragment reads are
+//     inline-asm ds_read_b128 with hand-counted lgkmcnt waits: the 8 reads of half-step hs + 1 are issued in front of the MFMAs of
+//     half-step hs, whose own 8 reads are then exactly what `lgkmcnt(8)` waits for; the wait names the registers as in/out operands
+//     so that no MFMA moves in front of it;
+//   * with an LDS-DMA in flight, every compiler-placed vmcnt wait is vmcnt(0) (the DMA is a FLAT-class access to two address spaces:
+//     "pending flat");
+//   * vmcnt retires in order anyway: waiting for a weight fragment issued after a DMA waits for that DMA.
+//   So the DMA of the next chunk is issued LATE -- in front of k-step FILL_STEP of 7, after a forced wait for the weight fragments
+//   still in flight -- and no register load issued after it is consumed before the barrier that ends the chunk (FILL_STEP = 7 - PF):
+//   the refill has the last PF k-steps of MFMAs to land in.
 typedef float f32x4q __attribute__((ext_vector_type(4)));
 
 struct X3QCfg {
     static constexpr int TD = 4, TH = 4, NB = 4, IN_D = 6, IN_H = 6, IN_W = 34, VOX = IN_D * IN_H * IN_W, GB = VOX * 16;
-    static constexpr int KCG = 2, ITEMS = 2 * KCG * VOX, PLANE_BYTES = KCG * GB, NIT = (ITEMS + 255) / 256;
-    static constexpr int IMG_BYTES = NIT * 256 * 16, LDS_BYTES = IMG_BYTES;
-    static constexpr int NS = 14, PF = 2;                  // tap pairs per chunk; A-fragment ring depth
-    static constexpr int tapoff(int t) { return ((t / 9) * IN_H + (t / 3) % 3) * IN_W + t % 3; }
+    static constexpr int ITEMS = 2 * VOX, PLANE_BYTES = GB, NIT = (ITEMS + 255) / 256;
+    static constexpr int IMG_BYTES = NIT * 256 * 16, LDS_BYTES = 2 * IMG_BYTES;
+    static constexpr int NQ = 7, PF = 2, FILL_STEP = NQ - PF;      // a fragment fetched at k-step s is consumed at s + PF
 };
+
+template <int IMM>
+__device__ __forceinline__ void lds_read_b128_to(h8 &v, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_lgkm_for(h8 (&b)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+                 : "n"(N)
+                 : "memory");
+}
 
 template <int EPI>      // 0: split C8 output; 3: + the side head (Cout == 32)
 __global__ void __launch_bounds__(256, 2)
 conv3d_x3q_kernel(const F16Args a) {
     using Cfg = X3QCfg;
-    constexpr int NB = Cfg::NB, TH = Cfg::TH, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, GB = Cfg::GB, NIT = Cfg::NIT;
-    constexpr int ITEMS = Cfg::ITEMS, KCG = Cfg::KCG, PF = Cfg::PF;
+    constexpr int NB = Cfg::NB, TH = Cfg::TH, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, NIT = Cfg::NIT, NQ = Cfg::NQ;
+    constexpr int ITEMS = Cfg::ITEMS, PF = Cfg::PF;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kb = lane >> 4, col = lane & 15;
     const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
@@ -571,7 +598,7 @@ conv3d_x3q_kernel(const F16Args a) {
     const int od0 = td * Cfg::TD, oh0 = th * TH, ow0 = tw * 32;
     const int id0 = od0 - a.pad_d, ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
 
-    f32x4q acc[NB][2][2];      // [row][half of the row: voxels 0-15 | 16-31][co half]
+    f32x4q acc[NB][2][2];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -579,105 +606,102 @@ conv3d_x3q_kernel(const F16Args a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) acc[nb][ph][h] = f32x4q{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // ---- staging geometry (as conv3d_f16_kernel): piece i = (plane, group, dd, hh, ww)
     const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
     unsigned off[NIT];
-    unsigned vmask = 0, gmask = 0, pmask = 0;
+    unsigned vmask = 0, pmask = 0;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = it * 256 + tid;
-        const int pg = i / VOX, r = i - pg * VOX;
-        const int plane = pg / KCG, g = pg - plane * KCG;
-        gmask |= (unsigned)(g & 1) << it;
+        const int plane = i / VOX, r = i - plane * VOX;
         pmask |= (unsigned)(plane & 1) << it;
         const int dd = r / (IN_H * IN_W), r2 = r - dd * (IN_H * IN_W);
         const int hh = r2 / IN_W, ww = r2 - hh * IN_W;
         const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww;
         const bool ok = i < ITEMS && (unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Hin && (unsigned)gw < (unsigned)a.Win;
-        off[it] = ok ? (unsigned)(g * in_dhw + gd * in_hw + gh * a.Win + gw) : 0u;
+        off[it] = ok ? (unsigned)(gd * in_hw + gh * a.Win + gw) : 0u;
         vmask |= (ok ? 1u : 0u) << it;
     }
     const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = a.x_lo + n * a.x_bs;
     const int wbase = tid & ~63;
-    auto issue = [&](int chunk) {
-        const int64_t coff = (int64_t)chunk * KCG * in_dhw * 8;
-        const int cg_left = a.CGin - chunk * KCG;
+    auto issue = [&](int chunk, int buf) {     // every wave issues all NIT instructions (pieces past the image land in the buffer's padding)
+        const int64_t coff = (int64_t)chunk * in_dhw * 8;
+        char *const ibuf = lds + buf * Cfg::IMG_BYTES;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = it * 256 + tid;
-            const bool ok = ((vmask >> it) & 1u) && (int)((gmask >> it) & 1u) < cg_left;
             const _Float16 *xc = (((pmask >> it) & 1u) ? xn_lo : xn) + coff;
-            const void *src = ok ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
-            if (ITEMS % 256 == 0 || i < ITEMS)
-                __builtin_amdgcn_global_load_lds(static_cast<const float *>(src), reinterpret_cast<float *>(lds + (it * 256 + wbase) * 16), 16, 0, 0);
+            const void *src = ((vmask >> it) & 1u) ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
+            __builtin_amdgcn_global_load_lds(static_cast<const float *>(src), reinterpret_cast<float *>(ibuf + (it * 256 + wbase) * 16), 16, 0, 0);
         }
     };
-
-    // ---- B addressing: lane (voxel col, k-block kb): + (kb & 1) channel groups, + (kb >> 1) taps of the pair
-    constexpr int D_SAME = 1, D_ROW = IN_W - 2, D_SLICE = IN_H * IN_W - 2 * IN_W - 2;
-    const int lb0 = col * 16 + (kb & 1) * GB;
-    const int b_same = lb0 + (kb >> 1) * D_SAME * 16, b_row = lb0 + (kb >> 1) * D_ROW * 16, b_slice = lb0 + (kb >> 1) * D_SLICE * 16;
+    int qoff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        int tp = 4 * q + kb;
+        tp = tp < 27 ? tp : 26;                     // the 28th slot: zero weights, tap 26's piece
+        qoff[q] = (((tp / 9) * IN_H + (tp / 3) % 3) * IN_W + tp % 3 + col) * 16;
+    }
     int rowoff[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int row = wave * NB + nb;
         rowoff[nb] = ((row / TH) * IN_H + (row % TH)) * IN_W * 16;
     }
-    // ---- A fragments: [cout block][chunk][tap pair][co half][hi | lo][lane] pieces, in consumption order
-    const int64_t steps_total = (int64_t)a.nchunks * Cfg::NS;
+    const int64_t steps_total = (int64_t)a.nchunks * NQ;
     const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * 4) * 64 + lane;
-    h8 q[PF][4];
+    h8 q_[PF][4];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) q[i][m] = wq[m * 64];
-        wq += 4 * 64;          // the packed buffer carries PF steps of zero padding behind the last block
+        for (int m = 0; m < 4; ++m) q_[i][m] = wq[m * 64];
+        wq += 4 * 64;
     }
 
-    auto step_addr = [&](int s, int &base, int &toff) {       // s is a constant after unrolling
-        const int ta = 2 * s, tb = 2 * s + 1;
-        toff = Cfg::tapoff(ta) * 16;
-        if (tb >= 27) { base = lb0; return; }                  // the 28th slot has zero weights: both taps of the pair read tap 26's piece
-                                                               // (a piece further on may lie outside the image: 0 x garbage)
-        const int delta = Cfg::tapoff(tb) - Cfg::tapoff(ta);
-        base = delta == D_SAME ? b_same : (delta == D_ROW ? b_row : b_slice);
-    };
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    issue(0, 0);
+    __syncthreads();
     for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-        issue(chunk);
-        __syncthreads();
-        // half-step hs = 2 s + j covers rows 2 j, 2 j + 1 of k-step s; its 8 B fragments are fetched one half-step ahead
+        const unsigned img = lds_base + (unsigned)((chunk & 1) * Cfg::IMG_BYTES);
+        const bool more = chunk + 1 < a.nchunks;
         h8 bfr[2][8];      // [buffer][(row of the half-step) * 4 + (row half) * 2 + plane]
         auto load_b = [&](int buf, int hs) {
-            int base, toff;
-            step_addr(hs >> 1, base, toff);
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                for (int ph = 0; ph < 2; ++ph)
-#pragma unroll
-                    for (int pl = 0; pl < 2; ++pl)
-                        bfr[buf][rr * 4 + ph * 2 + pl] =
-                            *reinterpret_cast<const h8 *>(lds + pl * Cfg::PLANE_BYTES + base + toff + rowoff[2 * (hs & 1) + rr] + ph * 256);
+            for (int rr = 0; rr < 2; ++rr) {
+                const unsigned addr = img + (unsigned)(qoff[hs >> 1] + rowoff[2 * (hs & 1) + rr]);
+                lds_read_b128_to<0>(bfr[buf][rr * 4 + 0], addr);
+                lds_read_b128_to<Cfg::PLANE_BYTES>(bfr[buf][rr * 4 + 1], addr);
+                lds_read_b128_to<256>(bfr[buf][rr * 4 + 2], addr);
+                lds_read_b128_to<Cfg::PLANE_BYTES + 256>(bfr[buf][rr * 4 + 3], addr);
+            }
         };
         load_b(0, 0);
         h8 af[4];
 #pragma unroll
-        for (int hs = 0; hs < 2 * Cfg::NS; ++hs) {
-            const int cur = hs & 1, nxt = cur ^ 1;
-            if ((hs & 1) == 0) {           // a new k-step: its weights leave the ring, the step PF ahead is requested
+        for (int hs = 0; hs < 2 * NQ; ++hs) {
+            const int cur = hs & 1, nx = cur ^ 1;
+            if ((hs & 1) == 0) {
+                if (hs == 2 * Cfg::FILL_STEP) {
+                    // every weight fragment in flight lands first: none is waited for between here and the barrier
 #pragma unroll
-                for (int m = 0; m < 4; ++m) af[m] = q[0][m];
+                    for (int i = 0; i < PF; ++i) asm volatile("" ::"v"(q_[i][0]), "v"(q_[i][1]), "v"(q_[i][2]), "v"(q_[i][3]));
+                    if (more) issue(chunk + 1, (chunk + 1) & 1);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = q_[0][m];
 #pragma unroll
                 for (int i = 0; i + 1 < PF; ++i)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) q[i][m] = q[i + 1][m];
+                    for (int m = 0; m < 4; ++m) q_[i][m] = q_[i + 1][m];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) q[PF - 1][m] = wq[m * 64];
+                for (int m = 0; m < 4; ++m) q_[PF - 1][m] = wq[m * 64];      // from k-step FILL_STEP on: fragments of the NEXT chunk
                 wq += 4 * 64;
             }
-            if (hs + 1 < 2 * Cfg::NS) load_b(nxt, hs + 1);
+            if (hs + 1 < 2 * NQ) {
+                load_b(nx, hs + 1);
+                wait_lgkm_for<8>(bfr[cur]);
+            } else {
+                wait_lgkm_for<0>(bfr[cur]);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            // af: [0] = half 0 hi, [1] = half 0 lo, [2] = half 1 hi, [3] = half 1 lo.  Per accumulator: lo_w * hi_x, hi_w * lo_x, hi_w * hi_x
 #pragma unroll
             for (int term = 0; term < 3; ++term)
 #pragma unroll
@@ -693,10 +717,9 @@ conv3d_x3q_kernel(const F16Args a) {
                         }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        __syncthreads();     // drains the DMA of the next chunk and retires every read of this chunk's buffer
     }
 
-    // ---- epilogue: lane (kb, col) holds the 8 channels of C8 group cb * 4 + kb for voxel col (+16) of each of its rows
     const int out_hw = a.Hout * a.Wout;
     const int64_t out_dhw = (int64_t)out_hw * a.Dout;
     const bool relu = (a.flags & SNVC_EPI_RELU) != 0;
@@ -737,7 +760,7 @@ conv3d_x3q_kernel(const F16Args a) {
                 *reinterpret_cast<h8 *>(yn + sp * 8) = o;
                 *reinterpret_cast<h8 *>(yn_lo + sp * 8) = ol;
             }
-            if constexpr (EPI == 3) {      // the four k-block lanes of a voxel hold its 32 channels
+            if constexpr (EPI == 3) {
                 float tot = hsum + __shfl_xor(hsum, 16, 64);
                 tot += __shfl_xor(tot, 32, 64);
                 if (ok && kb == 0) a.y_head[n * out_dhw + sp] = tot * a.head_mul;
@@ -745,28 +768,6 @@ conv3d_x3q_kernel(const F16Args a) {
         }
     }
     if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
-}
-
-__global__ void pack_x3q_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Cin, int nchunks,
-                                        float wmul, int64_t total) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    int64_t r = i;
-    const int e = (int)(r % 8); r /= 8;
-    const int lane = (int)(r % 64); r /= 64;
-    const int pl = (int)(r % 2); r /= 2;
-    const int h = (int)(r % 2); r /= 2;
-    const int s = (int)(r % X3QCfg::NS); r /= X3QCfg::NS;
-    const int chunk = (int)(r % nchunks); r /= nchunks;
-    const int cb = (int)r;
-    const int row = lane & 15, kb = lane >> 4;
-    const int co = cb * 32 + 8 * (row >> 2) + 4 * h + (row & 3);
-    const int ci = (chunk * 2 + (kb & 1)) * 8 + e;
-    const int tap = 2 * s + (kb >> 1);
-    float v = 0.0f;
-    if (tap < 27 && co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * 27 + tap] * wmul;
-    const _Float16 hi = (_Float16)v;
-    out[i] = pl == 0 ? hi : (_Float16)(v - (float)hi);
 }
 
 // 16x16x32 form of the split-mode 5^3 / dilated 5^3 / 7^3 layers (planes serial, one channel group per chunk, as F16K5X / F16K5D2X /
@@ -996,8 +997,8 @@ conv3d_q16s_kernel(const F16Args a_) {
 }
 
 // packed weights of conv3d_q16s_kernel: [cb][chunk][pass][slice kd][quad][co half (NH)][hi | lo (NPL)][lane][8]
-__global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Cin, int KS, int NQ, int nchunks,
-                                         int NH, int NPL, int PASSES, float wmul, int64_t total) {
+__global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Cin, int NSEG, int NT, int NQ,
+                                         int nchunks, int NH, int NPL, int PASSES, float wmul, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int64_t r = i;
@@ -1006,7 +1007,7 @@ __global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *
     const int pl = (int)(r % NPL); r /= NPL;
     const int h = (int)(r % NH); r /= NH;
     const int q = (int)(r % NQ); r /= NQ;
-    const int kd = (int)(r % KS); r /= KS;
+    const int kd = (int)(r % NSEG); r /= NSEG;                 // segment: a depth slice of NT = K * K taps, or all K^3 taps (3^3)
     r /= PASSES;                                               // both passes of a chunk see the same weights
     const int chunk = (int)(r % nchunks); r /= nchunks;
     const int cb = (int)r;
@@ -1015,7 +1016,7 @@ __global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *
     const int ci = chunk * 8 + e;
     const int tp = 4 * q + kb;
     float v = 0.0f;
-    if (tp < KS * KS && co < Cout && ci < Cin) v = w[(((int64_t)co * Cin + ci) * KS + kd) * KS * KS + tp] * wmul;
+    if (tp < NT && co < Cout && ci < Cin) v = w[(((int64_t)co * Cin + ci) * NSEG + kd) * NT + tp] * wmul;
     const _Float16 hi = (_Float16)v;
     out[i] = pl == 0 ? hi : (_Float16)(v - (float)hi);
 }
@@ -1209,12 +1210,12 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                     case 512: p = plan_from<F16K5D2X>(FK5D2X); break;
                     case 711: p = plan_from<F16K7X>(FK7X); break;
                     case 311:
-                        if ((d.algo & SNVC_ALGO_X3_Q16) && d.Cin % 16 == 0) {      // the 16x16x32 form: its own packing
+                        if (d.algo & SNVC_ALGO_X3_Q16) {      // the 16x16x32 form (four taps x one channel group per MFMA): its own packing
                             p = plan_from<F16K3X>(FK3XQ);
-                            p.KCG = 2; p.MI = 1; p.STEPS = X3QCfg::NS; p.NS = X3QCfg::NS; p.PF = X3QCfg::PF;
-                            p.nchunks = d.Cin / 16;
+                            p.KCG = 1; p.MI = 1; p.STEPS = X3QCfg::NQ; p.NS = X3QCfg::NQ; p.PF = X3QCfg::PF;
+                            p.nchunks = d.Cin / 8;
                             p.cblocks = d.Cout / 32;
-                            p.block_halves = (int64_t)p.cblocks * p.nchunks * X3QCfg::NS * 4 * 64 * 8;
+                            p.block_halves = (int64_t)p.cblocks * p.nchunks * X3QCfg::NQ * 4 * 64 * 8;
                             if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: too many channel blocks or samples");
                             return SNVC_OK;
                         }
@@ -1331,13 +1332,13 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
         const bool sp_ = p.PL >= 2;
         const int nh_ = sp_ ? 2 : 2 * p.MI;
         pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
-            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, ks, nq, p.nchunks, nh_, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, ks, ks * ks, nq, p.nchunks, nh_, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
             p.block_halves);
         return check_launch(who);
     }
-    if (p.kind == FK3XQ) {
-        pack_x3q_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
-            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, p.nchunks, wmul, p.block_halves);
+    if (p.kind == FK3XQ) {      // [cb][chunk][quad][co half][hi | lo][lane][8]: one segment of all 27 taps
+        pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, 1, 27, X3QCfg::NQ, p.nchunks, 2, 2, 1, wmul, p.block_halves);
         return check_launch(who);
     }
     for (int c = 0; c < classes; ++c) {
@@ -1608,12 +1609,12 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
         }
         case FK3XQ: {
             if (to_f32 || resflags) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the 16x16x32 form has no residual / fp32 output");
-            static std::atomic<unsigned> attr_q0{0}, attr_q3{0};
+            static std::atomic<unsigned> attr_40{0}, attr_43{0};
             if (head) {
-                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<3>), X3QCfg::LDS_BYTES, attr_q3))
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<3>), X3QCfg::LDS_BYTES, attr_43))
                     conv3d_x3q_kernel<3><<<grid, 256, X3QCfg::LDS_BYTES, st>>>(a);
             } else {
-                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<0>), X3QCfg::LDS_BYTES, attr_q0))
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<0>), X3QCfg::LDS_BYTES, attr_40))
                     conv3d_x3q_kernel<0><<<grid, 256, X3QCfg::LDS_BYTES, st>>>(a);
             }
             break;

@@ -1280,7 +1280,7 @@ class Conv3dLayerX3:
         if self.forced_algo is not None or self.stride != 1 or self.transposed or self.ksize != 3 or self.cout == 1:
             return self.algo
         tiles = n * -(-out_sp[0] // 4) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32)
-        if plain and X3_Q16[0] and self.cin % 16 == 0 and self.cout % 32 == 0 and tiles * (self.cout // 32) >= 1024:
+        if plain and X3_Q16[0] and self.cout % 32 == 0 and tiles * (self.cout // 32) >= 1024:
             return _lib.ALGO_X3_Q16         # v_mfma_f32_16x16x32_f16: ~15 % faster under the chip's power limit (conv2 0.94 -> 0.81 ms)
         if self.cout % 64 == 0 and tiles * (self.cout // 64) >= 1024:
             return _lib.ALGO_X3_SERIAL      # 64-channel blocks: the serial-plane form measures 6 % faster (0.424 vs 0.453 ms, hg conv2)
