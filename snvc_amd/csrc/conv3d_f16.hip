@@ -590,10 +590,12 @@ conv3d_x3q_kernel(const F16Args a) {
     constexpr int ITEMS = Cfg::ITEMS, PF = Cfg::PF;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kb = lane >> 4, col = lane & 15;
-    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w;
-    const int t = xcd_remap16(blockIdx.x, ntiles);
+    // the output-channel blocks of a tile are consecutive jobs of the same XCD: the second reads the tile's input from that XCD's L2
+    // (as separate grid rows -- blockIdx.y -- the 64 -> 64 hourglass layer fetched its input twice: 299 MB against 159)
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w, cblocks = a.Cout >> 5;
+    const int job = xcd_remap16(blockIdx.x, ntiles * cblocks);
+    const int t = job / cblocks, cb = job - t * cblocks;
     const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
-    const int cb = blockIdx.y;
     const int64_t n = blockIdx.z;
     const int od0 = td * Cfg::TD, oh0 = th * TH, ow0 = tw * 32;
     const int id0 = od0 - a.pad_d, ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
@@ -1609,6 +1611,8 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
         }
         case FK3XQ: {
             if (to_f32 || resflags) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the 16x16x32 form has no residual / fp32 output");
+            if (ntiles * p.cblocks >= ((int64_t)1 << 30)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles");
+            grid = dim3((unsigned)(ntiles * p.cblocks), 1, (unsigned)d->N);      // (tile, channel block) jobs, channel block fastest
             static std::atomic<unsigned> attr_40{0}, attr_43{0};
             if (head) {
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<3>), X3QCfg::LDS_BYTES, attr_43))

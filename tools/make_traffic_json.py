@@ -22,7 +22,7 @@ KERNEL = {  # layer -> substring of the kernel whose LAST dispatch is reported
     "gather_cfg3": "voxel_gather_fwd_lds", "f16_k7_32": "conv3d_f16_kernel",
     "general": "warped_expand_kernel", "sheared_bwd": "sheared_bwd_kernel",
     # r4: split-mode (f16x3) layers and the split-output expand passes; the fp32 any-shift expand in its register-window form
-    "x3_conv2": "conv3d_f16_kernel", "x3_hg2": "conv3d_f16_kernel", "sheared_split": "sheared_expand_split_kernel",
+    "x3_conv2": "conv3d_x3q_kernel", "x3_hg2": "conv3d_x3q_kernel", "sheared_split": "sheared_expand_split_kernel",
     "general_split": "warped_expand_split_kernel", "general_f32": "warped_expand_win_kernel",
 }
 if ROUND >= "r4":
@@ -75,7 +75,8 @@ for layer, needle in KERNEL.items():
         entry["algorithmic_bytes"] = ALGORITHMIC[layer]
         entry["traffic_over_algorithmic"] = entry["hbm_bytes_corrected"] / ALGORITHMIC[layer]
     if "SQ_INSTS_MFMA" in entry and "GRBM_GUI_ACTIVE" in entry:
-        cyc = 64 if layer in F32_MFMA_LAYERS else 32          # v_mfma_f32_32x32x2_f32: 64 cycles/SIMD; 32x32x16_f16: 32
+        # v_mfma_f32_32x32x2_f32: 64 cycles/SIMD; 32x32x16_f16: 32; 16x16x32_f16 (the split-mode 3x3x3 layers since late r4): 16
+        cyc = 64 if layer in F32_MFMA_LAYERS else 16 if layer.startswith("x3_") else 32
         entry["mfma_pipe_frac"] = entry["SQ_INSTS_MFMA"] * cyc / (1024 * entry["GRBM_GUI_ACTIVE"] / 8)
     if len(entry) > 1:
         out["layers"][layer] = entry

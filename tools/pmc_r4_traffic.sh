@@ -9,7 +9,8 @@ run() {  # layer (output name), prof_layers layer, tag, counters...
   timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $O/${L}_$T -o p -- python3 tools/prof_layers.py $P --reps 2 > $O/${L}_$T.log 2>&1
   echo "$L $T rc=$?"
 }
-for pair in x3_conv2:x3_conv2 x3_hg2:x3_hg2 sheared_split:sheared general_split:general general_f32:general_f32 conv2_side:conv2_side; do
+# PAIRS="x3_conv2:x3_conv2 x3_hg2:x3_hg2" re-collects the split-mode layers only (late r4: their 16x16x32 form)
+for pair in ${PAIRS:-x3_conv2:x3_conv2 x3_hg2:x3_hg2 sheared_split:sheared general_split:general general_f32:general_f32 conv2_side:conv2_side}; do
   L=${pair%%:*}; P=${pair##*:}
   run $L $P fetch FETCH_SIZE
   run $L $P write WRITE_SIZE
