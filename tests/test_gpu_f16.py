@@ -460,17 +460,19 @@ def test_split_mode_side_head_and_overflow_flag():
         ops.Conv3dLayerX3(torch.randn(32, 32, 5, 5, 5, device=dev()), 5, 2, 2, 1, False)       # a stride-2 k5 layer: not on the path
 
 
-@pytest.mark.parametrize("case", ["k3_32_32", "k3_48_64", "k3_64_32_ragged", "k7_64_32", "k7_16_64", "k5d2_32_32", "k5d2_8_96"])
+@pytest.mark.parametrize("case", ["k3_32_32", "k3_48_64", "k3_64_32_ragged", "k3_8_32", "k3_24_96", "k7_64_32", "k7_16_64", "k5d2_32_32", "k5d2_8_96"])
 def test_split_mode_16x16x32_forms_vs_float64(case):
     """r4: the kernel forms on v_mfma_f32_16x16x32_f16 (SNVC_ALGO_X3_Q16; the default only from ~1000 workgroups on, forced here on
-    small and ragged shapes): 3x3x3 (two taps x two channel groups per MFMA, side head), 7^3 and dilated 5^3 (four taps per MFMA,
-    planes serial, sub-grid classes, residual before / after the activation with its own exponent) against float64 at the
-    exact-fp32 tolerance, and against the 32x32x16 forms."""
+    small and ragged shapes): 3x3x3 (four taps of one channel group per MFMA, the image double-buffered and refilled under the last
+    k-steps of a chunk -- one chunk only, an odd number of chunks, one / two / three output-channel blocks; side head), 7^3 and
+    dilated 5^3 (four taps per MFMA, planes serial, sub-grid classes, residual before / after the activation with its own
+    exponent) against float64 at the exact-fp32 tolerance, and against the 32x32x16 forms."""
     from snvc_amd import _lib, ops
     from test_gpu_parity import TIGHT, check
     torch.manual_seed(100 + len(case))
     cin, cout, k, dil, shape = {
         "k3_32_32": (32, 32, 3, 1, (8, 12, 40)), "k3_48_64": (48, 64, 3, 1, (5, 9, 33)), "k3_64_32_ragged": (64, 32, 3, 1, (10, 9, 70)),
+        "k3_8_32": (8, 32, 3, 1, (6, 7, 34)), "k3_24_96": (24, 96, 3, 1, (7, 5, 65)),
         "k7_64_32": (64, 32, 7, 1, (8, 9, 35)), "k7_16_64": (16, 64, 7, 1, (5, 6, 64)), "k5d2_32_32": (32, 32, 5, 2, (9, 10, 36)),
         "k5d2_8_96": (8, 96, 5, 2, (7, 7, 50))}[case]
     pad = dil * (k - 1) // 2
