@@ -777,7 +777,10 @@ conv3d_x3q_kernel(const F16Args a) {
 // (7^3: 13 quads for 49 taps; 5^3: 7 for 25; a slot beyond the last tap has zero weights and re-reads the last tap's piece).
 // A lane's byte offset inside a slice per quad sits in registers (qoff).  Same tile, image, staging, sub-grid classes and epilogue
 // contract as the 32x32x16 forms; residual (before / after the activation) supported; split C8 output only.
-template <int KS_, int DILW_, int PLQ_ = 3, int NHB_ = 1>
+// FLAT (the plain 5^3 layer): the quads run over ALL K^3 taps in (kd, kh, kw) raster order -- 32 quads for 125 taps (2 % padding)
+// where slice by slice it is 5 x 7 quads for 5 x 25 (11 %: no gain over the 13 tap pairs of the 32x32x16 form); the lane's offset
+// per quad is computed on the fly (a table of 32 would not fit the registers).
+template <int KS_, int DILW_, int PLQ_ = 3, int NHB_ = 1, bool FLAT_ = false>
 struct Q16SCfg {
     // PLQ = 3: split mode, planes serial (a hi pass: lo_w * hi_x + hi_w * hi_x; a lo pass: hi_w * lo_x); PLQ = 1: the fp16-STORAGE family
     // (one plane, one MFMA per product, C8 half output).  NHB: 32-channel blocks per workgroup (2: every B fragment feeds two
@@ -787,8 +790,10 @@ struct Q16SCfg {
     static constexpr int NH = 2 * NHB, MA = NH * (SPLIT ? 2 : 1), PASSES = SPLIT ? 2 : 1;
     static constexpr int IN_D = TD + KS - 1, IN_H = TH + KS - 1, IN_W = 32 + (KS - 1) * DILW, VOX = IN_D * IN_H * IN_W;
     static constexpr int ITEMS = VOX, NIT = (ITEMS + 255) / 256, IMG_BYTES = NIT * 256 * 16, LDS_BYTES = IMG_BYTES;
-    static constexpr int SEG_BYTES = IN_H * IN_W * 16, NT = KS * KS, NQ = (NT + 3) / 4, PF = 2;
-    static constexpr int STEPS = KS * NQ;                   // k-steps per pass
+    static constexpr bool FLAT = FLAT_;
+    static constexpr int KSEG = FLAT ? 1 : KS;              // runtime-looped segments: depth slices, or one segment of all taps
+    static constexpr int SEG_BYTES = IN_H * IN_W * 16, NT = FLAT ? KS * KS * KS : KS * KS, NQ = (NT + 3) / 4, PF = 2;
+    static constexpr int STEPS = KSEG * NQ;                 // k-steps per pass
     static_assert(NIT <= 32, "validity mask is one register");
     static_assert(PLQ_ == 3 || PLQ_ == 1, "planes serial (split) or one plane (fp16 storage)");
 };
@@ -851,14 +856,26 @@ conv3d_q16s_kernel(const F16Args a_) {
                 __builtin_amdgcn_global_load_lds(static_cast<const float *>(src), reinterpret_cast<float *>(lds + (it * 256 + wbase) * 16), 16, 0, 0);
         }
     };
-    // this lane's byte offset inside a depth slice for every quad of taps
-    int qoff[NQ];
+    // this lane's byte offset inside a depth slice for every quad of taps (FLAT: inside the image, computed per use)
+    int qoff[Cfg::FLAT ? 1 : NQ];
+    if constexpr (!Cfg::FLAT) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        int tp = 4 * q + kb;
-        tp = tp < Cfg::NT ? tp : Cfg::NT - 1;
-        qoff[q] = ((tp / KS) * IN_W + (tp % KS) * Cfg::DILW + col) * 16;
+        for (int q = 0; q < NQ; ++q) {
+            int tp = 4 * q + kb;
+            tp = tp < Cfg::NT ? tp : Cfg::NT - 1;
+            qoff[q] = ((tp / KS) * IN_W + (tp % KS) * Cfg::DILW + col) * 16;
+        }
     }
+    auto quad_off = [&](int q) {      // q is a constant after unrolling
+        if constexpr (Cfg::FLAT) {
+            int tp = 4 * q + kb;
+            tp = tp < Cfg::NT ? tp : Cfg::NT - 1;
+            const int kd = tp / (KS * KS), r = tp - kd * (KS * KS), kh = r / KS, kw = r - kh * KS;
+            return ((kd * IN_H + kh) * IN_W + kw * Cfg::DILW + col) * 16;
+        } else {
+            return qoff[q];
+        }
+    };
     int rowoff[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -884,16 +901,17 @@ conv3d_q16s_kernel(const F16Args a_) {
         // half-step hs = 2 s + j: rows 2 j, 2 j + 1 of k-step s = (slice, quad); its 4 B fragments are fetched one half-step ahead
         h8 bfr[2][4];
         auto load_b = [&](int buf, const char *simg, int q, int j) {
+            const int qo = quad_off(q);
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph)
-                    bfr[buf][rr * 2 + ph] = *reinterpret_cast<const h8 *>(simg + qoff[q] + rowoff[2 * j + rr] + ph * 256);
+                    bfr[buf][rr * 2 + ph] = *reinterpret_cast<const h8 *>(simg + qo + rowoff[2 * j + rr] + ph * 256);
         };
         load_b(0, lds, 0, 0);
         h8 af[MA];
 #pragma unroll 1
-        for (int seg = 0; seg < KS; ++seg) {
+        for (int seg = 0; seg < Cfg::KSEG; ++seg) {
             const char *simg = lds + seg * Cfg::SEG_BYTES;
 #pragma unroll
             for (int hs = 0; hs < 2 * NQ; ++hs) {
@@ -910,7 +928,7 @@ conv3d_q16s_kernel(const F16Args a_) {
                     wq += MA * 64;
                 }
                 if (hs + 1 < 2 * NQ) load_b(nxt, simg, (hs + 1) >> 1, (hs + 1) & 1);
-                else if (seg + 1 < KS) load_b(nxt, simg + Cfg::SEG_BYTES, 0, 0);
+                else if (seg + 1 < Cfg::KSEG) load_b(nxt, simg + Cfg::SEG_BYTES, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (SPLIT) {
                     if (!lo_pass) {
@@ -1151,7 +1169,7 @@ using F16K5D2X = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2, 3>;
 using F16K7X   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 3>;
 using F16DCXN  = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 1, false, 3, 1, 2, true>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FK5D2QN, FK7QN, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FK5D2QN, FK7QN, FK5Q, FK5QN, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
@@ -1199,7 +1217,7 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                 if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 511 || key == 512 || key == 711)) {      // 16x16x32 form, planes serial
                     const int ks = d.ksize, nq = (ks * ks + 3) / 4;
                     p = key == 511 ? plan_from<F16K5X>(FK5XQ) : (key == 512 ? plan_from<F16K5D2X>(FK5D2XQ) : plan_from<F16K7X>(FK7XQ));
-                    p.KCG = 1; p.MI = 1; p.PF = 2; p.STEPS = ks * nq;
+                    p.KCG = 1; p.MI = 1; p.PF = 2; p.STEPS = key == 511 ? (ks * ks * ks + 3) / 4 : ks * nq;      // plain 5^3: quads over all 125 taps
                     p.nchunks = d.Cin / 8;
                     p.cblocks = d.Cout / 32;
                     p.block_halves = (int64_t)p.cblocks * p.nchunks * 2 * p.STEPS * 4 * 64 * 8;
@@ -1260,11 +1278,12 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
             p = plan_from<F16K3H>(FK3H);
         } else {
             const bool narrow = d.Cout == 32;      // one 32-channel block: the MI = 1 forms
-            if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 711 || key == 512) && d.Cout % 32 == 0) {     // 16x16x32 form, two blocks per workgroup
-                const int ks = d.ksize, nq = (ks * ks + 3) / 4;                                     // (one for Cout = 32 * odd)
+            if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 711 || key == 512 || key == 511) && d.Cout % 32 == 0) {     // 16x16x32 form, two blocks per
+                const int ks = d.ksize, nq = (ks * ks + 3) / 4;                                     // workgroup (one for Cout = 32 * odd)
                 const bool two = d.Cout % 64 == 0;
-                p = key == 711 ? plan_from<F16K7>(two ? FK7Q : FK7QN) : plan_from<F16K5D2>(two ? FK5D2Q : FK5D2QN);
-                p.KCG = 1; p.MI = two ? 2 : 1; p.PF = 2; p.STEPS = ks * nq;
+                p = key == 711 ? plan_from<F16K7>(two ? FK7Q : FK7QN) : key == 512 ? plan_from<F16K5D2>(two ? FK5D2Q : FK5D2QN)
+                                                                                   : plan_from<F16K5>(two ? FK5Q : FK5QN);
+                p.KCG = 1; p.MI = two ? 2 : 1; p.PF = 2; p.STEPS = key == 511 ? (ks * ks * ks + 3) / 4 : ks * nq;
                 p.nchunks = d.Cin / 8;
                 p.cblocks = d.Cout / (two ? 64 : 32);
                 p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * (two ? 4 : 2) * 64 * 8;
@@ -1292,9 +1311,9 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
 }
 
 inline int64_t f16_class_stride(const F16Plan &p) {
-    if (p.kind == FK3XQ || p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q)
+    if (p.kind == FK3XQ || p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q || p.kind == FK5Q)
         return p.block_halves + (int64_t)p.PF * 4 * 64 * 8;
-    if (p.kind == FK5D2QN || p.kind == FK7QN) return p.block_halves + (int64_t)p.PF * 2 * 64 * 8;
+    if (p.kind == FK5D2QN || p.kind == FK7QN || p.kind == FK5QN) return p.block_halves + (int64_t)p.PF * 2 * 64 * 8;
     return p.block_halves + (int64_t)p.PF * p.MI * (p.PL >= 2 ? 2 : 1) * 64 * 8;
 }
 
@@ -1329,12 +1348,15 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
     const int64_t bytes = 2 * f16_class_stride(p) * classes;
     if (hipMemsetAsync(packed, 0, (size_t)bytes, as_stream(stream)) != hipSuccess)   // the ring's read-ahead padding
         return fail(SNVC_ERR_HIP, "snvc_f16_conv3d_pack_weights: hipMemsetAsync failed");
-    if (p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q || p.kind == FK5D2QN || p.kind == FK7QN) {
-        const int ks = d->ksize, nq = (ks * ks + 3) / 4;
+    if (p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q || p.kind == FK5D2QN || p.kind == FK7QN ||
+        p.kind == FK5Q || p.kind == FK5QN) {
+        const int ks = d->ksize;
+        const bool flat = p.kind == FK5XQ || p.kind == FK5Q || p.kind == FK5QN;      // plain 5^3: one segment of all 125 taps
+        const int nseg = flat ? 1 : ks, nt = flat ? ks * ks * ks : ks * ks, nq = (nt + 3) / 4;
         const bool sp_ = p.PL >= 2;
         const int nh_ = sp_ ? 2 : 2 * p.MI;
         pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
-            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, ks, ks * ks, nq, p.nchunks, nh_, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, nseg, nt, nq, p.nchunks, nh_, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
             p.block_halves);
         return check_launch(who);
     }
@@ -1449,25 +1471,31 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: too many tiles or samples");
     dim3 grid((unsigned)(d->transposed ? 2 * ntiles : ntiles), (unsigned)p.cblocks, (unsigned)(d->N * (d->transposed ? 4 : classes)));
     switch (p.kind) {
-        case FK7QN: case FK5D2QN: {
-            using C7 = Q16SCfg<7, 1, 1, 1>; using C5D = Q16SCfg<5, 2, 1, 1>;
-            static std::atomic<unsigned> at7{0}, at5{0};
+        case FK7QN: case FK5D2QN: case FK5QN: {
+            using C7 = Q16SCfg<7, 1, 1, 1>; using C5D = Q16SCfg<5, 2, 1, 1>; using C5 = Q16SCfg<5, 1, 1, 1, true>;
+            static std::atomic<unsigned> at7{0}, at5{0}, at5p{0};
             if (p.kind == FK7QN) {
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C7>), C7::LDS_BYTES, at7))
                     conv3d_q16s_kernel<C7><<<grid, 256, C7::LDS_BYTES, st>>>(a);
+            } else if (p.kind == FK5QN) {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C5>), C5::LDS_BYTES, at5p))
+                    conv3d_q16s_kernel<C5><<<grid, 256, C5::LDS_BYTES, st>>>(a);
             } else {
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C5D>), C5D::LDS_BYTES, at5))
                     conv3d_q16s_kernel<C5D><<<grid, 256, C5D::LDS_BYTES, st>>>(a);
             }
             break;
         }
-        case FK7Q: case FK5D2Q: {
+        case FK7Q: case FK5D2Q: case FK5Q: {
             if (plane) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: the 16x16x32 form writes C8 tensors");
-            using C7 = Q16SCfg<7, 1, 1, 2>; using C5D = Q16SCfg<5, 2, 1, 2>;
-            static std::atomic<unsigned> at7{0}, at5{0};
+            using C7 = Q16SCfg<7, 1, 1, 2>; using C5D = Q16SCfg<5, 2, 1, 2>; using C5 = Q16SCfg<5, 1, 1, 2, true>;
+            static std::atomic<unsigned> at7{0}, at5{0}, at5p{0};
             if (p.kind == FK7Q) {
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C7>), C7::LDS_BYTES, at7))
                     conv3d_q16s_kernel<C7><<<grid, 256, C7::LDS_BYTES, st>>>(a);
+            } else if (p.kind == FK5Q) {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C5>), C5::LDS_BYTES, at5p))
+                    conv3d_q16s_kernel<C5><<<grid, 256, C5::LDS_BYTES, st>>>(a);
             } else {
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C5D>), C5D::LDS_BYTES, at5))
                     conv3d_q16s_kernel<C5D><<<grid, 256, C5D::LDS_BYTES, st>>>(a);
@@ -1604,7 +1632,7 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
 #define SNVC_Q16S(CFG) do { static std::atomic<unsigned> at_{0};                                                                    \
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<CFG>), CFG::LDS_BYTES, at_))                \
                     conv3d_q16s_kernel<CFG><<<grid, 256, CFG::LDS_BYTES, st>>>(a); } while (0)
-            using C5 = Q16SCfg<5, 1>; using C5D = Q16SCfg<5, 2>; using C7 = Q16SCfg<7, 1>;
+            using C5 = Q16SCfg<5, 1, 3, 1, true>; using C5D = Q16SCfg<5, 2>; using C7 = Q16SCfg<7, 1>;
             if (p.kind == FK5XQ) SNVC_Q16S(C5); else if (p.kind == FK5D2XQ) SNVC_Q16S(C5D); else SNVC_Q16S(C7);
 #undef SNVC_Q16S
             break;

@@ -1078,6 +1078,7 @@ def voxel_gather_forward_split(left, right, l_pts, r_pts, resolution, mul_dev) -
 
 
 X3_Q16 = [True]        # False: the 32x32x16 kernel forms everywhere (rounds up to mid r4)
+X3_Q16_K5 = [True]     # ... and the plain 5^3 layers (quads over all 125 taps)
 
 
 class Conv3dLayerF16:
@@ -1096,9 +1097,9 @@ class Conv3dLayerF16:
         if tuple(weight.shape[2:]) != (ksize,) * 3:
             raise RuntimeError("only cubic kernels are on the path")
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
-        # r4: the 7^3 and dilated 5^3 layers take the 16x16x32 kernel form (decided here: packing and launch must agree)
+        # r4: the 7^3, 5^3 and dilated 5^3 layers take the 16x16x32 kernel form (decided here: packing and launch must agree)
         self.q16 = bool(X3_Q16[0] and not transposed and self.stride == 1 and self.cout % 32 == 0 and
-                        (self.ksize == 7 or (self.ksize == 5 and self.dilation == 2)))
+                        (self.ksize == 7 or (self.ksize == 5 and (self.dilation == 2 or (self.dilation == 1 and X3_Q16_K5[0])))))
         probe = self._desc(1, (16, 16, 32), 0)
         nbytes = _lib.lib().snvc_f16_conv3d_packed_weight_bytes(ctypes.byref(probe))
         if nbytes < 0:
@@ -1271,11 +1272,11 @@ class Conv3dLayerX3:
         """Kernel form of a stride-1 layer for this launch: enough workgroups to cover the 256 CUs about four times.
         ``plain``: no residual and a split output -- what the 16x16x32 form (r4) covers."""
         if self.forced_algo is None and self.stride == 1 and not self.transposed and self.ksize in (5, 7) and self.cout % 32 == 0:
-            # 7^3 / dilated 5^3: the 16x16x32 form (four taps per MFMA, planes serial) when the output is a split tensor and the launch
-            # fills the chip (released conv1 2.47 -> 2.10 ms/crop, conv3 0.49 -> 0.42; the plain 5^3 layer gains nothing: 28 tap
-            # slots for 25 taps against 26)
+            # 7^3 / 5^3 / dilated 5^3: the 16x16x32 form (four taps per MFMA, planes serial) when the output is a split tensor and the
+            # launch fills the chip (released conv1 2.47 -> 2.10 ms/crop, conv3 0.49 -> 0.42; the plain 5^3 layer with its quads over
+            # all 125 taps 0.53 -> 0.48 -- slice by slice, 28 tap slots for 25 taps gained nothing over the 26 of 13 tap pairs)
             tiles5 = n * -(-out_sp[0] // 4) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32) * (self.cout // 32)
-            q16 = X3_Q16[0] and split_out and tiles5 >= 512 and (self.ksize == 7 or self.dilation == 2)
+            q16 = X3_Q16[0] and split_out and tiles5 >= 512 and (self.ksize == 7 or self.dilation == 2 or X3_Q16_K5[0])
             return _lib.ALGO_X3_Q16 if q16 else 0
         if self.forced_algo is not None or self.stride != 1 or self.transposed or self.ksize != 3 or self.cout == 1:
             return self.algo

@@ -460,13 +460,14 @@ def test_split_mode_side_head_and_overflow_flag():
         ops.Conv3dLayerX3(torch.randn(32, 32, 5, 5, 5, device=dev()), 5, 2, 2, 1, False)       # a stride-2 k5 layer: not on the path
 
 
-@pytest.mark.parametrize("case", ["k3_32_32", "k3_48_64", "k3_64_32_ragged", "k3_8_32", "k3_24_96", "k7_64_32", "k7_16_64", "k5d2_32_32", "k5d2_8_96"])
+@pytest.mark.parametrize("case", ["k3_32_32", "k3_48_64", "k3_64_32_ragged", "k3_8_32", "k3_24_96", "k7_64_32", "k7_16_64", "k5d2_32_32", "k5d2_8_96",
+                                  "k5_32_32", "k5_16_64"])
 def test_split_mode_16x16x32_forms_vs_float64(case):
     """r4: the kernel forms on v_mfma_f32_16x16x32_f16 (SNVC_ALGO_X3_Q16; the default only from ~1000 workgroups on, forced here on
     small and ragged shapes): 3x3x3 (four taps of one channel group per MFMA, the image double-buffered and refilled under the last
-    k-steps of a chunk -- one chunk only, an odd number of chunks, one / two / three output-channel blocks; side head), 7^3 and
-    dilated 5^3 (four taps per MFMA, planes serial, sub-grid classes, residual before / after the activation with its own
-    exponent) against float64 at the exact-fp32 tolerance, and against the 32x32x16 forms."""
+    k-steps of a chunk -- one chunk only, an odd number of chunks, one / two / three output-channel blocks; side head), 7^3,
+    dilated 5^3 and 5^3 (four taps per MFMA, planes serial, sub-grid classes, the plain 5^3 layer's quads over all 125 taps,
+    residual before / after the activation with its own exponent) against float64 at the exact-fp32 tolerance, and against the 32x32x16 forms."""
     from snvc_amd import _lib, ops
     from test_gpu_parity import TIGHT, check
     torch.manual_seed(100 + len(case))
@@ -474,7 +475,7 @@ def test_split_mode_16x16x32_forms_vs_float64(case):
         "k3_32_32": (32, 32, 3, 1, (8, 12, 40)), "k3_48_64": (48, 64, 3, 1, (5, 9, 33)), "k3_64_32_ragged": (64, 32, 3, 1, (10, 9, 70)),
         "k3_8_32": (8, 32, 3, 1, (6, 7, 34)), "k3_24_96": (24, 96, 3, 1, (7, 5, 65)),
         "k7_64_32": (64, 32, 7, 1, (8, 9, 35)), "k7_16_64": (16, 64, 7, 1, (5, 6, 64)), "k5d2_32_32": (32, 32, 5, 2, (9, 10, 36)),
-        "k5d2_8_96": (8, 96, 5, 2, (7, 7, 50))}[case]
+        "k5d2_8_96": (8, 96, 5, 2, (7, 7, 50)), "k5_32_32": (32, 32, 5, 1, (9, 10, 36)), "k5_16_64": (16, 64, 5, 1, (6, 7, 50))}[case]
     pad = dil * (k - 1) // 2
     x = torch.relu(torch.randn(2, cin, *shape, device=dev())) * 2.0 + 0.01 * torch.randn(2, cin, *shape, device=dev())
     w = torch.randn(cout, cin, k, k, k, device=dev()) * np.sqrt(2.0 / (cin * k ** 3))
@@ -512,14 +513,16 @@ def test_split_mode_16x16x32_forms_vs_float64(case):
     assert int(flag.item()) == 1
 
 
-@pytest.mark.parametrize("case", ["k7_64_32", "k7_16_64", "k5d2_32_64", "k5d2_24_32"])
+@pytest.mark.parametrize("case", ["k7_64_32", "k7_16_64", "k5d2_32_64", "k5d2_24_32", "k5_32_64", "k5_8_32"])
 def test_f16_storage_16x16x32_forms_vs_torch(case):
-    """r4: the fp16-STORAGE 7^3 / dilated 5^3 layers take the 16x16x32 form (one or two 32-channel blocks per workgroup) by
-    default; against torch on the half-rounded operands like every layer of the family, and against the 32x32x16 form."""
+    """r4: the fp16-STORAGE 7^3 / dilated 5^3 / 5^3 layers take the 16x16x32 form (one or two 32-channel blocks per workgroup; the
+    plain 5^3 layer with its quads over all 125 taps) by default; against torch on the half-rounded operands like every layer of
+    the family, and against the 32x32x16 form."""
     from snvc_amd import ops
     torch.manual_seed(200 + len(case))
     cin, cout, k, dil, shape = {"k7_64_32": (64, 32, 7, 1, (6, 9, 37)), "k7_16_64": (16, 64, 7, 1, (5, 6, 64)),
-                                "k5d2_32_64": (32, 64, 5, 2, (9, 10, 36)), "k5d2_24_32": (24, 32, 5, 2, (7, 7, 50))}[case]
+                                "k5d2_32_64": (32, 64, 5, 2, (9, 10, 36)), "k5d2_24_32": (24, 32, 5, 2, (7, 7, 50)),
+                                "k5_32_64": (32, 64, 5, 1, (9, 10, 36)), "k5_8_32": (8, 32, 5, 1, (6, 7, 50))}[case]
     pad = dil * (k - 1) // 2
     x = torch.randn(2, cin, *shape, device=dev())
     w = torch.randn(cout, cin, k, k, k, device=dev()) * np.sqrt(2.0 / (cin * k ** 3))
