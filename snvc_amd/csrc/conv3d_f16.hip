@@ -772,15 +772,24 @@ conv3d_x3q_kernel(const F16Args a) {
     if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
 }
 
-// 16x16x32 form of the split-mode 5^3 / dilated 5^3 / 7^3 layers (planes serial, one channel group per chunk, as F16K5X / F16K5D2X /
-// F16K7X): K = 32 = FOUR TAPS of one C8 piece -- k-block kb = lane >> 4 is tap 4 q + kb of the depth slice's (kh, kw) raster
-// (7^3: 13 quads for 49 taps; 5^3: 7 for 25; a slot beyond the last tap has zero weights and re-reads the last tap's piece).
-// A lane's byte offset inside a slice per quad sits in registers (qoff).  Same tile, image, staging, sub-grid classes and epilogue
-// contract as the 32x32x16 forms; residual (before / after the activation) supported; split C8 output only.
-// FLAT (the plain 5^3 layer): the quads run over ALL K^3 taps in (kd, kh, kw) raster order -- 32 quads for 125 taps (2 % padding)
-// where slice by slice it is 5 x 7 quads for 5 x 25 (11 %: no gain over the 13 tap pairs of the 32x32x16 form); the lane's offset
-// per quad is computed on the fly (a table of 32 would not fit the registers).
-template <int KS_, int DILW_, int PLQ_ = 3, int NHB_ = 1, bool FLAT_ = false>
+// 16x16x32 form of the 5^3 / dilated 5^3 / 7^3 layers (split mode with the planes serial, one channel group per chunk, as F16K5X /
+// F16K5D2X / F16K7X; and the fp16-storage family): K = 32 = FOUR TAPS of one C8 piece -- k-block kb = lane >> 4 is tap 4 q + kb of
+// the list of ALL K^3 taps in (kd, kh, kw) raster order, cut into equal runtime-looped segments (a segment is what gets unrolled):
+// 5^3: one segment of 32 quads for 125 taps (2 % padding; slice by slice -- 5 x 7 quads for 5 x 25 taps, the first form -- the
+// plain 5^3 layer gained nothing over the 13 tap pairs of the 32x32x16 form), 7^3: two segments of 43 quads for 343 taps (0.3 %
+// instead of 6 %).  A slot beyond the last tap has zero weights and re-reads the last tap's piece.  A lane's byte offset per quad
+// comes from a table in LDS behind the image, fetched one quad ahead (a register table of 32 or 43 does not fit; computed per quad
+// -- two divisions -- it ate the gain in the forms with 16 MFMAs per half-step).  Measured against the slice-by-slice form: 7^3
+// -2..3 %, dilated 5^3 -6..10 %, 5^3 -18..22 % against its 32x32x16 form.  Same tile, image, staging, sub-grid classes and epilogue
+// contract as the 32x32x16 forms; residual (before / after the activation) supported; C8 output only.
+// flat segments of the 16x16x32 forms (Q16SCfg::FSEG): 5^3 and dilated 5^3 one (125 taps = 32 quads), 7^3 two (343 taps = 2 x 43 quads)
+constexpr int q16s_flat_segments(int ks) { return ks == 7 ? 2 : 1; }
+constexpr int q16s_steps(int ks) {      // k-steps per pass
+    const int f = q16s_flat_segments(ks), k3 = ks * ks * ks;
+    return f * (((k3 + f - 1) / f + 3) / 4);
+}
+
+template <int KS_, int DILW_, int PLQ_ = 3, int NHB_ = 1>
 struct Q16SCfg {
     // PLQ = 3: split mode, planes serial (a hi pass: lo_w * hi_x + hi_w * hi_x; a lo pass: hi_w * lo_x); PLQ = 1: the fp16-STORAGE family
     // (one plane, one MFMA per product, C8 half output).  NHB: 32-channel blocks per workgroup (2: every B fragment feeds two
@@ -789,11 +798,13 @@ struct Q16SCfg {
     static constexpr bool SPLIT = PLQ_ == 3;
     static constexpr int NH = 2 * NHB, MA = NH * (SPLIT ? 2 : 1), PASSES = SPLIT ? 2 : 1;
     static constexpr int IN_D = TD + KS - 1, IN_H = TH + KS - 1, IN_W = 32 + (KS - 1) * DILW, VOX = IN_D * IN_H * IN_W;
-    static constexpr int ITEMS = VOX, NIT = (ITEMS + 255) / 256, IMG_BYTES = NIT * 256 * 16, LDS_BYTES = IMG_BYTES;
-    static constexpr bool FLAT = FLAT_;
-    static constexpr int KSEG = FLAT ? 1 : KS;              // runtime-looped segments: depth slices, or one segment of all taps
-    static constexpr int SEG_BYTES = IN_H * IN_W * 16, NT = FLAT ? KS * KS * KS : KS * KS, NQ = (NT + 3) / 4, PF = 2;
+    static constexpr int ITEMS = VOX, NIT = (ITEMS + 255) / 256, IMG_BYTES = NIT * 256 * 16;
+    static constexpr int K3 = KS * KS * KS, KSEG = q16s_flat_segments(KS);      // segments of the flat tap list
+    static constexpr int NQ = ((K3 + KSEG - 1) / KSEG + 3) / 4, NT = 4 * NQ, PF = 2;      // quads / tap slots per segment
     static constexpr int STEPS = KSEG * NQ;                 // k-steps per pass
+    static_assert(STEPS == q16s_steps(KS) && KSEG * NT >= K3 && (KSEG - 1) * NT < K3, "the segments cover the taps");
+    static constexpr int TAB_BYTES = KSEG * NT * 4;         // byte offset of every tap slot's piece inside the image
+    static constexpr int LDS_BYTES = IMG_BYTES + TAB_BYTES;
     static_assert(NIT <= 32, "validity mask is one register");
     static_assert(PLQ_ == 3 || PLQ_ == 1, "planes serial (split) or one plane (fp16 storage)");
 };
@@ -856,33 +867,26 @@ conv3d_q16s_kernel(const F16Args a_) {
                 __builtin_amdgcn_global_load_lds(static_cast<const float *>(src), reinterpret_cast<float *>(lds + (it * 256 + wbase) * 16), 16, 0, 0);
         }
     };
-    // this lane's byte offset inside a depth slice for every quad of taps (FLAT: inside the image, computed per use)
-    int qoff[Cfg::FLAT ? 1 : NQ];
-    if constexpr (!Cfg::FLAT) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            int tp = 4 * q + kb;
-            tp = tp < Cfg::NT ? tp : Cfg::NT - 1;
-            qoff[q] = ((tp / KS) * IN_W + (tp % KS) * Cfg::DILW + col) * 16;
+    // this lane's byte offset inside the image for every quad of taps: the LDS table (written here, visible behind the first pass's
+    // barrier), two quads of it in registers at a time
+    int qo2[2] = {0, 0};
+    const int *const qlane = reinterpret_cast<const int *>(lds + Cfg::IMG_BYTES) + kb;
+    {
+        int *const qtab = reinterpret_cast<int *>(lds + Cfg::IMG_BYTES);
+        for (int i = tid; i < Cfg::KSEG * Cfg::NT; i += 256) {
+            const int tp = i < Cfg::K3 ? i : Cfg::K3 - 1;          // a slot beyond the last tap: zero weights, the last tap's piece
+            const int kd = tp / (KS * KS), r = tp - kd * (KS * KS), kh = r / KS, kw = r - kh * KS;
+            qtab[i] = ((kd * IN_H + kh) * IN_W + kw * Cfg::DILW) * 16;
         }
     }
-    auto quad_off = [&](int q) {      // q is a constant after unrolling
-        if constexpr (Cfg::FLAT) {
-            int tp = 4 * q + kb;
-            tp = tp < Cfg::NT ? tp : Cfg::NT - 1;
-            const int kd = tp / (KS * KS), r = tp - kd * (KS * KS), kh = r / KS, kw = r - kh * KS;
-            return ((kd * IN_H + kh) * IN_W + kw * Cfg::DILW + col) * 16;
-        } else {
-            return qoff[q];
-        }
-    };
+    const int col16 = col * 16;
     int rowoff[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int row = wave * NB + nb;
         rowoff[nb] = ((row / TH) * IN_H + (row % TH)) * IN_W * 16;
     }
-    // A fragments: [cout block][chunk][pass][slice][quad][co half][hi | lo (split)][lane] pieces, in consumption order
+    // A fragments: [cout block][chunk][pass][segment][quad][co half][hi | lo (split)][lane] pieces, in consumption order
     const int npass = a.nchunks * Cfg::PASSES;
     const int64_t steps_total = (int64_t)npass * Cfg::STEPS;
     const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * MA) * 64 + lane;
@@ -898,21 +902,21 @@ conv3d_q16s_kernel(const F16Args a_) {
         issue(ps);
         __syncthreads();
         const bool lo_pass = SPLIT && (ps & 1);
-        // half-step hs = 2 s + j: rows 2 j, 2 j + 1 of k-step s = (slice, quad); its 4 B fragments are fetched one half-step ahead
+        // half-step hs = 2 s + j: rows 2 j, 2 j + 1 of k-step s = (segment, quad); its 4 B fragments are fetched one half-step ahead
         h8 bfr[2][4];
-        auto load_b = [&](int buf, const char *simg, int q, int j) {
-            const int qo = quad_off(q);
+        auto load_b = [&](int buf, int qo, int j) {
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int ph = 0; ph < 2; ++ph)
-                    bfr[buf][rr * 2 + ph] = *reinterpret_cast<const h8 *>(simg + qo + rowoff[2 * j + rr] + ph * 256);
+                    bfr[buf][rr * 2 + ph] = *reinterpret_cast<const h8 *>(lds + qo + rowoff[2 * j + rr] + ph * 256);
         };
-        load_b(0, lds, 0, 0);
+        qo2[0] = qlane[0] + col16;
+        load_b(0, qo2[0], 0);
         h8 af[MA];
 #pragma unroll 1
         for (int seg = 0; seg < Cfg::KSEG; ++seg) {
-            const char *simg = lds + seg * Cfg::SEG_BYTES;
+            const int *const qseg = qlane + seg * Cfg::NT;
 #pragma unroll
             for (int hs = 0; hs < 2 * NQ; ++hs) {
                 const int cur = hs & 1, nxt = cur ^ 1, j = hs & 1;
@@ -926,9 +930,13 @@ conv3d_q16s_kernel(const F16Args a_) {
 #pragma unroll
                     for (int m = 0; m < MA; ++m) q_[PF - 1][m] = wq[m * 64];
                     wq += MA * 64;
+                    // the next quad's offset (behind the segment's last quad: the next segment's first)
+                    const int qn = (hs >> 1) + 1;      // a constant after unrolling
+                    if (qn < NQ) qo2[qn & 1] = qseg[4 * qn] + col16;
+                    else if (seg + 1 < Cfg::KSEG) qo2[qn & 1] = qseg[Cfg::NT] + col16;
                 }
-                if (hs + 1 < 2 * NQ) load_b(nxt, simg, (hs + 1) >> 1, (hs + 1) & 1);
-                else if (seg + 1 < Cfg::KSEG) load_b(nxt, simg + Cfg::SEG_BYTES, 0, 0);
+                if (hs + 1 < 2 * NQ) load_b(nxt, qo2[((hs + 1) >> 1) & 1], (hs + 1) & 1);
+                else if (seg + 1 < Cfg::KSEG) load_b(nxt, qo2[NQ & 1], 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (SPLIT) {
                     if (!lo_pass) {
@@ -950,7 +958,8 @@ conv3d_q16s_kernel(const F16Args a_) {
                             acc[2 * j + rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[SPLIT ? 2 * h : h], bfr[cur][rr * 2 + ph], acc[2 * j + rr][ph][h], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // 2 NQ half-steps per slice: an even count, so the buffer roles repeat from slice to slice
+            // 2 NQ half-steps per segment: an even count, so the buffer roles repeat from segment to segment
+            if constexpr (NQ % 2 == 1) qo2[0] = qo2[1];      // the next segment's first quad looks in slot 0
         }
         __syncthreads();
     }
@@ -1017,8 +1026,8 @@ conv3d_q16s_kernel(const F16Args a_) {
 }
 
 // packed weights of conv3d_q16s_kernel: [cb][chunk][pass][slice kd][quad][co half (NH)][hi | lo (NPL)][lane][8]
-__global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Cin, int NSEG, int NT, int NQ,
-                                         int nchunks, int NH, int NPL, int PASSES, float wmul, int64_t total) {
+__global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cout, int Cin, int K3, int NSEG, int NT,
+                                         int NQ, int nchunks, int NH, int NPL, int PASSES, float wmul, int64_t total) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     int64_t r = i;
@@ -1036,7 +1045,8 @@ __global__ void pack_q16s_weights_kernel(const float *__restrict__ w, _Float16 *
     const int ci = chunk * 8 + e;
     const int tp = 4 * q + kb;
     float v = 0.0f;
-    if (tp < NT && co < Cout && ci < Cin) v = w[(((int64_t)co * Cin + ci) * NSEG + kd) * NT + tp] * wmul;
+    // segment kd holds taps kd * NT .. of the (kd, kh, kw) raster: a depth slice (NT = K * K) or a run of the flat list (NT = 4 NQ slots)
+    if (tp < NT && kd * NT + tp < K3 && co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * K3 + kd * NT + tp] * wmul;
     const _Float16 hi = (_Float16)v;
     out[i] = pl == 0 ? hi : (_Float16)(v - (float)hi);
 }
@@ -1215,9 +1225,9 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
             } else {
                 if (d.Cout % 32 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: Cout % 32 == 0");
                 if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 511 || key == 512 || key == 711)) {      // 16x16x32 form, planes serial
-                    const int ks = d.ksize, nq = (ks * ks + 3) / 4;
+                    const int ks = d.ksize;
                     p = key == 511 ? plan_from<F16K5X>(FK5XQ) : (key == 512 ? plan_from<F16K5D2X>(FK5D2XQ) : plan_from<F16K7X>(FK7XQ));
-                    p.KCG = 1; p.MI = 1; p.PF = 2; p.STEPS = key == 511 ? (ks * ks * ks + 3) / 4 : ks * nq;      // plain 5^3: quads over all 125 taps
+                    p.KCG = 1; p.MI = 1; p.PF = 2; p.STEPS = q16s_steps(ks);
                     p.nchunks = d.Cin / 8;
                     p.cblocks = d.Cout / 32;
                     p.block_halves = (int64_t)p.cblocks * p.nchunks * 2 * p.STEPS * 4 * 64 * 8;
@@ -1279,11 +1289,11 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
         } else {
             const bool narrow = d.Cout == 32;      // one 32-channel block: the MI = 1 forms
             if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 711 || key == 512 || key == 511) && d.Cout % 32 == 0) {     // 16x16x32 form, two blocks per
-                const int ks = d.ksize, nq = (ks * ks + 3) / 4;                                     // workgroup (one for Cout = 32 * odd)
+                const int ks = d.ksize;                                                             // workgroup (one for Cout = 32 * odd)
                 const bool two = d.Cout % 64 == 0;
                 p = key == 711 ? plan_from<F16K7>(two ? FK7Q : FK7QN) : key == 512 ? plan_from<F16K5D2>(two ? FK5D2Q : FK5D2QN)
                                                                                    : plan_from<F16K5>(two ? FK5Q : FK5QN);
-                p.KCG = 1; p.MI = two ? 2 : 1; p.PF = 2; p.STEPS = key == 511 ? (ks * ks * ks + 3) / 4 : ks * nq;
+                p.KCG = 1; p.MI = two ? 2 : 1; p.PF = 2; p.STEPS = q16s_steps(ks);
                 p.nchunks = d.Cin / 8;
                 p.cblocks = d.Cout / (two ? 64 : 32);
                 p.block_halves = (int64_t)p.cblocks * p.nchunks * p.STEPS * (two ? 4 : 2) * 64 * 8;
@@ -1350,19 +1360,19 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
         return fail(SNVC_ERR_HIP, "snvc_f16_conv3d_pack_weights: hipMemsetAsync failed");
     if (p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q || p.kind == FK5D2QN || p.kind == FK7QN ||
         p.kind == FK5Q || p.kind == FK5QN) {
-        const int ks = d->ksize;
-        const bool flat = p.kind == FK5XQ || p.kind == FK5Q || p.kind == FK5QN;      // plain 5^3: one segment of all 125 taps
-        const int nseg = flat ? 1 : ks, nt = flat ? ks * ks * ks : ks * ks, nq = (nt + 3) / 4;
+        const int ks = d->ksize, k3 = ks * ks * ks;
+        const int fseg = q16s_flat_segments(ks);      // 5^3: one segment of all 125 taps; 7^3: two of 172 slots
+        const int nseg = fseg, nq = ((k3 + fseg - 1) / fseg + 3) / 4, nt = 4 * nq;
         const bool sp_ = p.PL >= 2;
         const int nh_ = sp_ ? 2 : 2 * p.MI;
         pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
-            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, nseg, nt, nq, p.nchunks, nh_, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, k3, nseg, nt, nq, p.nchunks, nh_, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
             p.block_halves);
         return check_launch(who);
     }
     if (p.kind == FK3XQ) {      // [cb][chunk][quad][co half][hi | lo][lane][8]: one segment of all 27 taps
         pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
-            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, 1, 27, X3QCfg::NQ, p.nchunks, 2, 2, 1, wmul, p.block_halves);
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, 27, 1, 4 * X3QCfg::NQ, X3QCfg::NQ, p.nchunks, 2, 2, 1, wmul, p.block_halves);
         return check_launch(who);
     }
     for (int c = 0; c < classes; ++c) {
@@ -1472,7 +1482,7 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     dim3 grid((unsigned)(d->transposed ? 2 * ntiles : ntiles), (unsigned)p.cblocks, (unsigned)(d->N * (d->transposed ? 4 : classes)));
     switch (p.kind) {
         case FK7QN: case FK5D2QN: case FK5QN: {
-            using C7 = Q16SCfg<7, 1, 1, 1>; using C5D = Q16SCfg<5, 2, 1, 1>; using C5 = Q16SCfg<5, 1, 1, 1, true>;
+            using C7 = Q16SCfg<7, 1, 1, 1>; using C5D = Q16SCfg<5, 2, 1, 1>; using C5 = Q16SCfg<5, 1, 1, 1>;
             static std::atomic<unsigned> at7{0}, at5{0}, at5p{0};
             if (p.kind == FK7QN) {
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C7>), C7::LDS_BYTES, at7))
@@ -1488,7 +1498,7 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
         }
         case FK7Q: case FK5D2Q: case FK5Q: {
             if (plane) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16_conv3d_forward: the 16x16x32 form writes C8 tensors");
-            using C7 = Q16SCfg<7, 1, 1, 2>; using C5D = Q16SCfg<5, 2, 1, 2>; using C5 = Q16SCfg<5, 1, 1, 2, true>;
+            using C7 = Q16SCfg<7, 1, 1, 2>; using C5D = Q16SCfg<5, 2, 1, 2>; using C5 = Q16SCfg<5, 1, 1, 2>;
             static std::atomic<unsigned> at7{0}, at5{0}, at5p{0};
             if (p.kind == FK7Q) {
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<C7>), C7::LDS_BYTES, at7))
@@ -1632,7 +1642,7 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
 #define SNVC_Q16S(CFG) do { static std::atomic<unsigned> at_{0};                                                                    \
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_q16s_kernel<CFG>), CFG::LDS_BYTES, at_))                \
                     conv3d_q16s_kernel<CFG><<<grid, 256, CFG::LDS_BYTES, st>>>(a); } while (0)
-            using C5 = Q16SCfg<5, 1, 3, 1, true>; using C5D = Q16SCfg<5, 2>; using C7 = Q16SCfg<7, 1>;
+            using C5 = Q16SCfg<5, 1>; using C5D = Q16SCfg<5, 2>; using C7 = Q16SCfg<7, 1>;
             if (p.kind == FK5XQ) SNVC_Q16S(C5); else if (p.kind == FK5D2XQ) SNVC_Q16S(C5D); else SNVC_Q16S(C7);
 #undef SNVC_Q16S
             break;
