@@ -292,12 +292,13 @@ def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="
     out["arithmetic"] = ("fp16 storage (C8 half activations / weights, fp32 accumulate)" if f16 else
                          "fp32 tensors; 3D trunk in split mode (f16x3: three half-precision MFMAs per fp32 product, fp32 accuracy)" if x3 else
                          "fp32 (Winograd F(4,k) on fp32 MFMA)")
-    if f16:     # direct form: every algorithmic multiply-add is executed (+ the 50th tap of the 25 tap pairs per slice)
-        kernel = f"conv3d_f16_kernel<k7> {2 * F}->{F} (direct, v_mfma_f32_32x32x16_f16, C8 half storage)"
+    if f16:     # direct form: every algorithmic multiply-add is executed (+ one padding slot: 2 x 43 quads of taps for 343)
+        kernel = f"conv3d_q16s_kernel<k7> {2 * F}->{F} (direct, v_mfma_f32_16x16x32_f16: four taps per MFMA over the flat tap list, C8 half storage)"
         frac = conv1_flop / (ms_c1 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
-    elif x3:    # 3 MFMAs per product, 50 tap slots per 49-tap depth slice
-        kernel = f"conv3d_f16_kernel<k7, split mode, planes serial> {2 * F}->{F} (three v_mfma_f32_32x32x16_f16 per fp32 product)"
-        frac = 3.0 * (50.0 / 49.0) * conv1_flop / (ms_c1 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
+    elif x3:    # 3 MFMAs per product, 344 tap slots for 343 taps
+        kernel = (f"conv3d_q16s_kernel<k7, split mode, planes serial> {2 * F}->{F} (three v_mfma_f32_16x16x32_f16 per fp32 product, "
+                  "four taps per MFMA over the flat tap list)")
+        frac = 3.0 * (344.0 / 343.0) * conv1_flop / (ms_c1 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS
         out["dominant_fp32_winograd_ms"] = ms_c1_f32
     else:
         kernel = f"conv3d_winok_kernel<k7> {2 * F}->{F} (Winograd F(4,7) along W, fp32 MFMA)"
