@@ -513,6 +513,35 @@ def test_split_mode_16x16x32_forms_vs_float64(case):
     assert int(flag.item()) == 1
 
 
+def test_split_mode_16x16x32_k3_is_bitwise_repeatable():
+    """The 3x3x3 form reads its LDS image with inline-asm ds_read_b128 behind hand-counted waits while the LDS-DMA refill of the
+    next channel group is in flight (csrc/conv3d_f16.hip, conv3d_x3q_kernel): a wait that is one short, or a refill that lands in the
+    buffer still being read, shows up as a run-to-run difference.  Many workgroups per CU, four chunks, both buffers in use, with and
+    without the side head: every repetition is bit-identical to the first, and the first agrees with the 32x32x16 form."""
+    from snvc_amd import _lib, ops
+    torch.manual_seed(77)
+    x = torch.relu(torch.randn(1, 32, 48, 40, 160, device=dev())) + 0.01 * torch.randn(1, 32, 48, 40, 160, device=dev())
+    w = torch.randn(32, 32, 3, 3, 3, device=dev()) * 0.06
+    scale, bias = torch.rand(32, device=dev()) + 0.5, torch.randn(32, device=dev()) * 0.3
+    head = torch.randn(32, device=dev())
+    q16 = ops.Conv3dLayerX3(w, algo=_lib.ALGO_X3_Q16)
+    old = ops.Conv3dLayerX3(w, algo=0)
+    xs = ops.to_split(x, 3)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev())
+    first, first_head = q16(xs, 3, scale, bias, flags=ops.EPI_RELU, out_exp=2, head=head, overflow=flag)
+    first, first_head = first.clone(), first_head.clone()
+    for rep in range(12):
+        if rep % 2:
+            y = q16(xs, 3, scale, bias, flags=ops.EPI_RELU, out_exp=2, overflow=flag)
+            assert torch.equal(y, first), f"repetition {rep} differs"
+        else:
+            y, yh = q16(xs, 3, scale, bias, flags=ops.EPI_RELU, out_exp=2, head=head, overflow=flag)
+            assert torch.equal(y, first) and torch.equal(yh, first_head), f"repetition {rep} differs"
+    yo = ops.from_split(old(xs, 3, scale, bias, flags=ops.EPI_RELU, out_exp=2, overflow=flag), 2)
+    assert (ops.from_split(first, 2) - yo).abs().max().item() <= 2e-6 * yo.abs().max().item()
+    assert int(flag.item()) == 0
+
+
 @pytest.mark.parametrize("case", ["k7_64_32", "k7_16_64", "k5d2_32_64", "k5d2_24_32", "k5_32_64", "k5_8_32"])
 def test_f16_storage_16x16x32_forms_vs_torch(case):
     """r4: the fp16-STORAGE 7^3 / dilated 5^3 / 5^3 layers take the 16x16x32 form (one or two 32-channel blocks per workgroup; the
