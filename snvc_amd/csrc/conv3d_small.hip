@@ -33,7 +33,13 @@ deconv3d_cout1_kernel(const float *__restrict__ x, const float *__restrict__ w, 
                       int Din, int Hin, int Win, int64_t x_bs, int64_t y_bs, int64_t r_bs, int flags) {
     const int nq = Win >> 2;
     const int total = Din * Hin * nq;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    // workgroups in XCD-local order: workgroup b runs on XCD b % 8, and a thread reads the rows of depth id AND id + 1 -- dealt out
+    // round-robin, the 7 workgroups of a depth plane and those of the next plane sit on different XCDs and every input element is
+    // fetched into two L2s; with a contiguous range of planes per XCD only the range borders are (cfg2: 84 -> 82 us, not the
+    // kernel's limit)
+    const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, k8 = blockIdx.x >> 3;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+    const int i = wg * 256 + threadIdx.x;
     if (i >= total) return;
     const int q = i % nq, t = i / nq, ih = t % Hin, id = t / Hin;
     const int64_t n = blockIdx.y;
