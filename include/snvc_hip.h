@@ -206,9 +206,11 @@ enum {
      * tiles (SMALL) -- more, smaller workgroups for layers that would not fill the chip otherwise.  Pack and forward must agree. */
     SNVC_ALGO_X3_NARROW = 0x2000,
     SNVC_ALGO_X3_SMALL = 0x4000,
-    /* snvc_f16x3_* 3x3x3 / stride-1 layers with Cin % 16 == 0, Cout % 32 == 0, no residual, split C8 output: the kernel form on
-     * v_mfma_f32_16x16x32_f16 (r4 prototype; that instruction shape sustains ~20 % more under the chip's power limit).  Same
-     * values as the 32x32x16 forms up to fp32 summation order.  Pack and forward must agree; SNVC_ERR_UNSUPPORTED otherwise. */
+    /* snvc_f16x3_* / snvc_f16_* stride-1 layers with Cin % 8 == 0 (one channel group per k-block), Cout % 32 == 0 and a C8 output:
+     * the kernel forms on v_mfma_f32_16x16x32_f16 (that instruction shape sustains ~20 % more under the chip's power limit).
+     * 3x3x3: split mode only, no residual (an optional side head); 5^3, dilated 5^3, 7^3: split and fp16-storage mode, residual
+     * allowed.  Same values as the 32x32x16 forms up to fp32 summation order.  Pack and forward must agree;
+     * SNVC_ERR_UNSUPPORTED otherwise. */
     SNVC_ALGO_X3_Q16 = 0x8000
 };
 

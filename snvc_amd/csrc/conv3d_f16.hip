@@ -497,9 +497,10 @@ conv3d_f16_kernel(const F16Args a_) {
                                 if (okv[nb]) yf[(int64_t)(cj + e) * out_dhw + sp[nb]] = v * a.head_mul;     // 2^-e_y: exact
                             } else {
                                 if constexpr (SPLIT) {
-                                    vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
-                                    // ReLU (when no residual follows it) and the clamp that keeps the pair finite, in one v_med3
+                                    // ReLU (when no residual follows it) and the clamp that keeps the pair finite, in one v_med3;
+                                    // the flag looks at what is STORED (after the activation) and only at voxels of the tensor
                                     v = __builtin_amdgcn_fmed3f(v, HAS_RES ? -kHalfMax : lo_bound, kHalfMax);
+                                    vmax = __builtin_fmaxf(vmax, okv[nb] ? __builtin_fabsf(v) : 0.0f);
                                 } else if constexpr (!HAS_RES) {
                                     if (relu) v = __builtin_fmaxf(v, 0.0f);
                                 }
@@ -752,8 +753,8 @@ conv3d_x3q_kernel(const F16Args a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = __builtin_fmaf(acc[nb][ph][e >> 2][e & 3], sc[e], bi[e]);
-                vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
                 v = __builtin_amdgcn_fmed3f(v, lo_bound, kHalfMax);
+                vmax = __builtin_fmaxf(vmax, ok ? __builtin_fabsf(v) : 0.0f);      // what is stored (after the ReLU), inside the tensor
                 if constexpr (EPI == 3) hsum += hw8[e] * v;
                 o[e] = (_Float16)v;
                 ol[e] = (_Float16)(v - (float)o[e]);
@@ -1007,8 +1008,8 @@ conv3d_q16s_kernel(const F16Args a_) {
                     if (relu) v = v > 0.0f ? v : 0.0f;
                     if (rn && add_post) v += rr;
                     if constexpr (SPLIT) {
-                        vmax = __builtin_fmaxf(vmax, __builtin_fabsf(v));
                         v = __builtin_amdgcn_fmed3f(v, -kHalfMax, kHalfMax);
+                        vmax = __builtin_fmaxf(vmax, ok ? __builtin_fabsf(v) : 0.0f);
                     }
                     o[e] = (_Float16)v;
                     if constexpr (SPLIT) ol[e] = (_Float16)(v - (float)o[e]);

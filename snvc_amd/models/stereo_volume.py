@@ -21,9 +21,9 @@ import torch.nn as nn
 
 from ..extension.build_cost_volume import _BuildCostVolume, build_cost_volume  # noqa: F401  (re-exported)
 from .. import ops
-from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, _FactoredFirstConvFn, _ShearedFirstConvBNFn,
+from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, SplitOverflow, _FactoredFirstConvFn, _ShearedFirstConvBNFn,
                         _ShearedFirstConvFn, _folded_bn, _is_channel_head as _is_head_conv, _Plan, convbn_3d, hourglass,
-                        sheared_geometry, sheared_kernels, EPI_RELU)
+                        overflow_guard, sheared_geometry, sheared_kernels, EPI_RELU)
 
 
 class GlobalStack(nn.Module):
@@ -79,7 +79,8 @@ class GlobalStack(nn.Module):
     def __getstate__(self):          # copy.deepcopy / torch.save(model): the workspace is scratch, not state
         state = self.__dict__.copy()
         state.pop("_snvc_ws", None)
-        state.pop("_snvc_x3", None)      # packed split-mode layers, a pinned flag buffer and an event: rebuilt on first use
+        state.pop("_snvc_x3", None)      # packed split-mode layers: rebuilt on first use
+        state.pop("_snvc_x3_guard", None)    # the overflow flag, its pinned host copy and an event
         return state
 
     # ------------------------------------------------------------------------------------------ split mode ("f16x3", r4)
@@ -88,7 +89,14 @@ class GlobalStack(nn.Module):
     # is three v_mfma_f32_32x32x16_f16 with fp32 accumulation, measured 5e-7 of the range against float64 where the fp32
     # Winograd kernels measure 2e-6 -- on a matrix pipe 16 times faster than the fp32 one.  ``arithmetic``: "auto" (default:
     # split mode when the stack qualifies), "fp32" (the fp32-MFMA kernels everywhere), "x3" (split mode or an error).
+    # A split tensor's exponent is chosen from its BatchNorm's parameters; a value beyond that range is clamped by the epilogue
+    # and FLAGGED.  ``overflow_check`` = "call" (default, r5): the flag is read before the result leaves the call -- the copy is
+    # queued behind the last layer that can clamp, the host waits for it after queueing the rest, so the GPU never idles -- and
+    # a flagged call is REDONE on the fp32-MFMA kernels ("auto": with a warning, and split mode stays off for this model;
+    # "x3": RuntimeError).  No clamped result is ever returned.  "deferred" (r4's behaviour, for measuring what the check
+    # costs): the flag is only posted; ``check_overflow()`` or the next call looks at it.
     arithmetic = "auto"
+    overflow_check = "call"
     X3_SIGMAS = 64.0     # a tensor's exponent is chosen so that |beta| + X3_SIGMAS * |gamma| of its BatchNorm stays below 2^15
 
     @staticmethod
@@ -111,7 +119,7 @@ class GlobalStack(nn.Module):
             if not isinstance(nm, nn.BatchNorm3d) or nm.training or nm.running_mean is None:
                 return None
         tensors = [t for sq in seqs.values() for t in (sq[0].weight, sq[1].weight, sq[1].bias, sq[1].running_mean, sq[1].running_var)]
-        tensors += [self.conv1[0][1].weight, self.conv1[0][1].bias]
+        tensors += [self.conv1[0][1].weight, self.conv1[0][1].bias, self.conv1[0][1].running_mean, self.conv1[0][1].running_var]
         key = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (device, _GENERATION[0])
         st = self.__dict__.get("_snvc_x3")
         if st is not None and st["key"] == key:
@@ -129,9 +137,8 @@ class GlobalStack(nn.Module):
             w = sq[0].weight.detach().to(device)
             st["layers"][k] = ops.Conv3dLayerX3(w, 3, geo[k][0], 1, 1, geo[k][1])
             st["affine"][k] = _folded_bn(sq[1], sq[0].__dict__.setdefault("_snvc_plans", {}).setdefault(device, _Plan()))
-        st["flag"] = torch.zeros(1, dtype=torch.int32, device=device)
-        st["flag_host"] = torch.zeros(1, dtype=torch.int32).pin_memory()
-        st["flag_event"] = None
+        st["guard"] = overflow_guard(self, device)      # survives rebuilds of this state: a pending flag is never dropped
+        st["flag"] = st["guard"].flag
         self.__dict__["_snvc_x3"] = st
         return st
 
@@ -139,9 +146,10 @@ class GlobalStack(nn.Module):
     def _x3_v1_affine(st, scale, bias):
         """The first layer's folded BatchNorm with the exponent of the split first-layer tensor folded in (exact: a power of two)."""
         e1 = st["exp"]["v1"]
-        if st.get("v1_affine_key") != (scale.data_ptr(), bias.data_ptr(), e1):
+        src = st.get("v1_affine_src")      # the folded tensors themselves are kept: an address cannot come back as another tensor
+        if src is None or src[0] is not scale or src[1] is not bias or src[2] != (scale._version, bias._version, e1):
             st["v1_affine"] = ((scale * 2.0 ** e1).contiguous(), (bias * 2.0 ** e1).contiguous())
-            st["v1_affine_key"] = (scale.data_ptr(), bias.data_ptr(), e1)
+            st["v1_affine_src"] = (scale, bias, (scale._version, bias._version, e1))
         return st["v1_affine"]
 
     def _x3_select(self, device, arithmetic=None):
@@ -156,19 +164,36 @@ class GlobalStack(nn.Module):
             if mode == "x3":
                 raise RuntimeError("arithmetic='x3': the stack does not qualify (32 channels, eval-mode BatchNorm3d everywhere)")
             return None
-        ev = st["flag_event"]
-        if ev is not None and ev.query():        # the previous call's overflow flag has arrived (no sync)
-            st["flag_event"] = None
-            if int(st["flag_host"].item()) != 0:
-                # a value exceeded the range its BatchNorm statistics promised (X3_SIGMAS standard deviations): the previous
-                # result had it clamped.  Split mode stays off for this model from here on.
-                self.__dict__["_snvc_x3_off"] = True
-                warnings.warn("snvc_amd: split-mode (f16x3) overflow -- an activation exceeded |beta| + %g |gamma| of its BatchNorm; "
-                              "the previous result clamped it.  This model now runs on the fp32-MFMA kernels." % self.X3_SIGMAS)
-                if mode == "x3":
-                    raise RuntimeError("arithmetic='x3': overflow flagged by the previous call")
-                return None
+        if st["guard"].event is not None and self._overflowed(st["guard"], mode, "an earlier call's result clamped it"):
+            return None                           # overflow_check = "deferred": the previous call's flag
         return st
+
+    def _overflowed(self, guard, mode, what):
+        """Look at a posted flag (synchronous).  True: a value was clamped -- split mode is switched off for this model."""
+        if not guard.wait():
+            return False
+        return self._leave_split_mode(mode, what)
+
+    def _leave_split_mode(self, mode, what):
+        self.__dict__["_snvc_x3_off"] = True
+        msg = ("snvc_amd: split-mode (f16x3) overflow -- an activation exceeded |beta| + %g |gamma| of its BatchNorm; %s.  "
+               "This model now runs on the fp32-MFMA kernels (reset_split_mode() turns split mode back on)." % (self.X3_SIGMAS, what))
+        if mode == "x3":
+            raise RuntimeError("arithmetic='x3': " + msg)
+        warnings.warn(msg)
+        return True
+
+    def check_overflow(self) -> bool:
+        """With ``overflow_check = "deferred"``: wait for the last split-mode call's flag.  True if that call's result was
+        clamped (the model leaves split mode, as in the checked mode); always False in the default checked mode."""
+        hit = False
+        for guard in self.__dict__.get("_snvc_x3_guard", {}).values():
+            hit |= self._overflowed(guard, "auto", "the last result clamped it")
+        return hit
+
+    def reset_split_mode(self):
+        """Turn split mode back on after an overflow switched it off (e.g. after loading matching statistics)."""
+        self.__dict__.pop("_snvc_x3_off", None)
 
     def _tail_x3(self, st, v1s, timing=None):
         """conv2 (+ side head) -> hourglass -> folded one-channel tail on a split-C8 first-layer result ``v1s`` (exponent
@@ -188,16 +213,14 @@ class GlobalStack(nn.Module):
         pre = L["h2"](o, E["h1"], *A["h2"], flags=EPI_RELU, out_exp=E["h2"], overflow=flag)                     # relu(bn(conv))   :153-156
         o = L["h3"](pre, E["h2"], *A["h3"], flags=EPI_RELU, out_exp=E["h3"], overflow=flag)                     # 1/4 res
         o = L["h4"](o, E["h3"], *A["h4"], flags=EPI_RELU, out_exp=E["h4"], overflow=flag)
+        st["guard"].post()      # the last layer that can clamp: the two below write float32.  The flag leaves for the host here
         # post = relu(bn(deconv(o)) + pre): the result leaves as fp32 NCDHW for the one-channel transposed tail (VALU kernel)
         post = L["h5"](o, E["h4"], *A["h5"], residual=pre, flags=EPI_RELU | ops.EPI_ADD_PRE, out_exp=E["h2"], to_f32=True)
         cost = hg.conv6.fused(post, residual=None, head=self.classifier, head_residual=hv)    # deconv'(post) + b' + classifier(v2)
         _ROUTES["x3_tail"] += 1
-        # the overflow flag travels to the host behind the step (no sync); the next call looks at it
-        if st["flag_event"] is None:
-            st["flag_host"].copy_(flag, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            st["flag_event"] = ev
+        if self.overflow_check == "call" and st["guard"].wait():
+            # waited for while the transposed layer and the tail still run: this call's result is dropped and redone in fp32
+            raise SplitOverflow()
         return cost
 
     def _tail(self, v, hv=None):
@@ -233,11 +256,25 @@ class GlobalStack(nn.Module):
                 if left.shape[1] * 2 == self.conv1[0][0].in_channels and left.shape[3] % 4 == 0:
                     return self.forward_pair(left, right, shift, ds, shift_checked=True, spacing=volume.spacing)
             # built from these two features: its maximum is theirs (interpolation weights are in [0, 1]), if they are untouched
-            scale_from = tuple(volume.sources[:2]) if volume.sources_unchanged else None
+            # ... and the volume itself: one that was written to in place (vol.mul_(8)) no longer has their maximum
+            scale_from = tuple(volume.sources[:2]) if volume.is_pristine else None
             return self._forward_volume(volume.materialize(), scale_from=scale_from)
         return self._forward_volume(volume)
 
+    def _checked(self, fn, arithmetic, *args, **kw):
+        """Run a split-mode capable entry point; a call whose overflow flag came back set is redone on the fp32-MFMA kernels
+        (its clamped result never leaves).  One extra step, once per model: split mode stays off afterwards."""
+        try:
+            return fn(*args, arithmetic=arithmetic, **kw)
+        except SplitOverflow:
+            self._leave_split_mode(arithmetic or self.arithmetic, "this call was redone in fp32")
+            _ROUTES["x3_overflow_redo"] += 1
+            return fn(*args, arithmetic="fp32", **kw)
+
     def _forward_volume(self, volume, timing=None, arithmetic=None, scale_from=None):
+        return self._checked(self._forward_volume_unchecked, arithmetic, volume, timing=timing, scale_from=scale_from)
+
+    def _forward_volume_unchecked(self, volume, timing=None, arithmetic=None, scale_from=None):
         """conv1 over a materialised [N, 2C, D, H, W] volume, then the tail.  Split mode (r4): the volume is scaled by a power of
         two derived on the device from its own maximum (or from the features it was built from, ``scale_from``: the volume holds
         nothing but their values and interpolations) and split once, conv1 runs on the split-mode kernel and writes the pair
@@ -338,6 +375,12 @@ class GlobalStack(nn.Module):
 
     def forward_pair(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True,
                      fused_bn=True, spacing="unknown", commuted=True, arithmetic=None):
+        return self._checked(self._forward_pair_unchecked, arithmetic, left, right, shift, downsample, factored, timing, shift_checked,
+                             sheared, fused_bn, spacing, commuted)
+    forward_pair.__doc__ = "see _forward_pair_unchecked"
+
+    def _forward_pair_unchecked(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True,
+                                fused_bn=True, spacing="unknown", commuted=True, arithmetic=None):
         """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
 
         ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT

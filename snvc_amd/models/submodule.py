@@ -76,7 +76,7 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
 # coordinate maps).  invalidate_plans() drops exactly these; tests/test_host_cpu.py checks that no other `_snvc_*`
 # name is written anywhere in the package.
 CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans_x3", "_snvc_plans2d", "_snvc_plans2d_t", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
-               "_snvc_coor_maps", "_snvc_x3", "_snvc_x3_off", "_snvc_last_v1")
+               "_snvc_coor_maps", "_snvc_x3", "_snvc_x3_off", "_snvc_x3_guard", "_snvc_last_v1")
 
 
 class _Plan:
@@ -918,6 +918,54 @@ class SplitT:
     def slice_groups(self, lo: int, hi: int):
         """Channel groups [lo, hi) of the pair (a view: split tensors are [N, 2, C/8, D, H, W, 8])."""
         return SplitT(self.t[:, :, lo:hi], self.exp, self.bound, self.mul_dev)
+
+
+class SplitOverflow(RuntimeError):
+    """Raised INSIDE a split-mode call whose overflow flag came back set: the call's result (an activation clamped to half's
+    range) is dropped and the model's public entry point redoes the call on the fp32-MFMA kernels.  Never reaches the caller
+    unless split mode was demanded (arithmetic / precision = "x3")."""
+
+
+class OverflowGuard:
+    """The overflow flag of a model's split-mode calls: an int32 on the device that every clamping epilogue ORs into, its pinned
+    host copy and the event behind the copy.
+
+    ``post()`` is queued right after the LAST layer that can clamp (the layers behind it write float32); ``wait()`` is called
+    once the rest of the call has been queued: the host then waits for the flag while the GPU still has those last layers to
+    run, so the check costs no GPU idle time and the result never leaves the call unchecked (r4 looked at the flag one call
+    late).  ``check="deferred"`` models post without waiting; ``pending()`` is the synchronous look a caller can take then."""
+
+    def __init__(self, device):
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+
+    def post(self):
+        self.host.copy_(self.flag, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def wait(self) -> bool:
+        """True if a value was clamped since the last look (the device flag is cleared again then)."""
+        ev, self.event = self.event, None
+        if ev is None:
+            return False
+        ev.synchronize()
+        if int(self.host.item()) == 0:
+            return False
+        self.flag.zero_()
+        return True
+
+    pending = wait
+
+
+def overflow_guard(module, device) -> OverflowGuard:
+    """The module's guard for ``device`` (kept across rebuilds of the packed split-mode state: a pending flag is never dropped)."""
+    guards = module.__dict__.setdefault("_snvc_x3_guard", {})
+    g = guards.get(device)
+    if g is None:
+        g = guards[device] = OverflowGuard(device)
+    return g
 
 
 def x3_exponent(bound: float) -> int:

@@ -180,7 +180,11 @@ class VernierScale(nn.Module):
         from .submodule import SplitT, x3_ok
         mode = getattr(self, "precision", "auto")
         want = mode == "x3"
-        if mode in ("f32", "f16") or self.__dict__.get("_snvc_x3_off"):
+        if mode in ("f32", "f16"):
+            return None
+        if self.__dict__.get("_snvc_x3_off"):
+            if want:
+                raise RuntimeError("precision='x3': split mode was switched off by an earlier overflow (reset_split_mode())")
             return None
         if isinstance(voxel, SplitT):
             device, channels, shape_ok = voxel.t.device, 8 * voxel.t.size(2), voxel.t.dim() == 7
@@ -196,23 +200,42 @@ class VernierScale(nn.Module):
             if want:
                 raise RuntimeError("precision='x3': the trunk does not qualify (inference, eval-mode BatchNorm3d, 2F % 64 == 0)")
             return None
-        st = self.__dict__.get("_snvc_x3")
-        if st is None or st["flag"].device != device:
-            st = self.__dict__["_snvc_x3"] = {"flag": torch.zeros(1, dtype=torch.int32, device=device),
-                                              "flag_host": torch.zeros(1, dtype=torch.int32).pin_memory(), "flag_event": None}
-        ev = st["flag_event"]
-        if ev is not None and ev.query():        # the previous call's overflow flag has arrived (no sync)
-            st["flag_event"] = None
-            if int(st["flag_host"].item()) != 0:
-                import warnings
-                from .submodule import X3_SIGMAS
-                self.__dict__["_snvc_x3_off"] = True
-                warnings.warn("snvc_amd: split-mode (f16x3) overflow in the local trunk -- an activation exceeded |beta| + %g |gamma| of "
-                              "its BatchNorm; the previous result clamped it.  This model now runs on the fp32-MFMA kernels." % X3_SIGMAS)
-                if want:
-                    raise RuntimeError("precision='x3': overflow flagged by the previous call")
-                return None
-        return st
+        from .submodule import overflow_guard
+        guard = overflow_guard(self, device)
+        if guard.event is not None and self._x3_overflowed(guard, "an earlier call's result clamped it"):
+            return None                               # overflow_check = "deferred": the previous call's flag
+        return guard
+
+    # "call" (default, r5): the overflow flag is read before the trunk's results leave the call, and a flagged call is redone on
+    # the fp32-MFMA kernels; "deferred": the flag is only posted (check_overflow() or the next call looks) -- see GlobalStack
+    overflow_check = "call"
+
+    def _x3_overflowed(self, guard, what):
+        if not guard.wait():
+            return False
+        return self._leave_split_mode(what)
+
+    def _leave_split_mode(self, what):
+        import warnings
+        from .submodule import X3_SIGMAS
+        self.__dict__["_snvc_x3_off"] = True
+        msg = ("snvc_amd: split-mode (f16x3) overflow in the local trunk -- an activation exceeded |beta| + %g |gamma| of its "
+               "BatchNorm; %s.  This model now runs on the fp32-MFMA kernels (reset_split_mode() turns split mode back on)."
+               % (X3_SIGMAS, what))
+        if getattr(self, "precision", "auto") == "x3":
+            raise RuntimeError("precision='x3': " + msg)
+        warnings.warn(msg)
+        return True
+
+    def check_overflow(self) -> bool:
+        """With ``overflow_check = "deferred"``: wait for the last split-mode call's flag; True if its result was clamped."""
+        hit = False
+        for guard in self.__dict__.get("_snvc_x3_guard", {}).values():
+            hit |= self._x3_overflowed(guard, "the last result clamped it")
+        return hit
+
+    def reset_split_mode(self):
+        self.__dict__.pop("_snvc_x3_off", None)
 
     def trunk_3d_x3(self, voxel, st):
         """``trunk_3d`` (reference vernier.py:415-438) in split mode: the same fp32 layers, every product three
@@ -220,7 +243,7 @@ class VernierScale(nn.Module):
         power of two derived from its own maximum on the device (no host round trip) and split once; every later tensor's
         exponent comes from its folded BatchNorm.  Returns the same float32 tensors as ``trunk_3d``."""
         from .submodule import SplitT, x3_exponent, x3_norm_bound, _Plan
-        flag = st["flag"]
+        guard, flag = st, st.flag
         if isinstance(voxel, SplitT):            # construct_voxel_x3: the gather wrote the pair itself
             vs = voxel
             voxel = vs.t
@@ -249,16 +272,14 @@ class VernierScale(nn.Module):
         else:
             vh = self.hg_conv3d.forward_x3(v, residual=v, out=dst, out_exp=e_cat, flag=flag)
         t = self.fg_cls_head[0].fused_x3(vh, relu=True, flag=flag)               # :427
+        guard.post()        # the last layer that can clamp (the ones below write float32 / multiply by occ in [0, 1])
         occ = self.fg_cls_head[2].fused_x3(t, sigmoid=True)                      # float32 [N,1,nh,nw,nl]
         ops.mul_broadcast_split(img.t, occ, out=cat[:, :, g:])                   # cat([v, img * occ])  :433
         v = self.conv4.fused_x3(SplitT(cat, e_cat, max(vh.bound, img.bound)), to_f32=True)      # :435, float32 NCDHW
         v = ops.avgpool_depth4(v)                                                # :436
-        if st["flag_event"] is None:     # the overflow flag travels to the host behind the call; the next call looks at it
-            st["flag_host"].copy_(flag, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            st["flag_event"] = ev
-        from .submodule import _ROUTES
+        from .submodule import _ROUTES, SplitOverflow
+        if self.overflow_check == "call" and guard.wait():      # waited for while the last three layers still run
+            raise SplitOverflow()
         _ROUTES["x3_local_trunk"] += 1
         return v.reshape(n, -1, v.size(3), v.size(4)), occ, None                 # :437-438
 
@@ -268,7 +289,12 @@ class VernierScale(nn.Module):
         if not torch.is_grad_enabled():
             st = self._x3_local(voxel)
             if st is not None:
-                return self.trunk_3d_x3(voxel, st)
+                from .submodule import SplitOverflow, _ROUTES
+                try:
+                    return self.trunk_3d_x3(voxel, st)
+                except SplitOverflow:       # this call's clamped result is dropped; the fp32 layers below redo it
+                    self._leave_split_mode("this call was redone in fp32")
+                    _ROUTES["x3_overflow_redo"] += 1
         if isinstance(voxel, SplitT):            # split by construct_voxel_x3, but the trunk has left split mode since (overflow flag)
             voxel = ops.from_split(voxel.t) / voxel.mul_dev
         n, c2 = voxel.size(0), voxel.size(1)

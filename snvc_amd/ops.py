@@ -1302,14 +1302,16 @@ class Conv3dLayerX3:
         key = (None if scale is None else (scale.data_ptr(), scale._version), None if bias is None else (bias.data_ptr(), bias._version),
                x_exp, out_exp)
         hit = self._affine.get(key)
+        if hit is not None and (hit[2] is not scale or hit[3] is not bias):
+            hit = None      # another tensor at a recycled address (the entry keeps its sources alive, so this only follows a clear())
         if hit is None:
             dev = self.weight.device
             sc = (scale.detach().float() if scale is not None else torch.ones(self.cout, device=dev)) * (2.0 ** (out_exp - x_exp - self.w_exp))
             bi = (bias.detach().float() if bias is not None else torch.zeros(self.cout, device=dev)) * (2.0 ** out_exp)
             if len(self._affine) > 8:
                 self._affine.clear()
-            hit = self._affine[key] = (sc.contiguous(), bi.contiguous())
-        return hit
+            hit = self._affine[key] = (sc.contiguous(), bi.contiguous(), scale, bias)
+        return hit[:2]
 
     def __call__(self, x, x_exp: int = 0, scale=None, bias=None, residual=None, flags: int = 0, out=None, out_exp: int = 0,
                  out_f32=None, to_f32: bool = False, head=None, overflow=None, x_mul_dev=None, res_exp: Optional[int] = None):

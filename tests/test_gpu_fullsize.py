@@ -289,7 +289,7 @@ def test_local_trunk_split_mode_full_size(grid):
         before = S._ROUTES["x3_local_trunk"]
         bev, occ, _ = m.trunk_3d(vox)                                   # precision "auto": split mode
         assert S._ROUTES["x3_local_trunk"] == before + 1
-        assert int(m.__dict__["_snvc_x3"]["flag"].item()) == 0         # nothing was clamped
+        assert not m.__dict__.get("_snvc_x3_off") and all(int(g.flag.item()) == 0 for g in m.__dict__["_snvc_x3_guard"].values())
         m.precision = "f32"
         bev32, occ32, _ = m.trunk_3d(vox)
         assert S._ROUTES["x3_local_trunk"] == before + 1
