@@ -559,6 +559,26 @@ SNVC_API int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *desc_host, const 
                                        const void *res_hi, const void *res_lo, void *y_hi, void *y_lo, float *y_f32,
                                        const float *head, float *y_head, float head_mul, float res_mul, int *overflow,
                                        void *stream);
+/* The global stack's tail -- classifier(bn(conv6(post)) + v), reference snvc/models/submodule.py:127-146,166 with the composition
+ * of snvc/models/vernier.py:366-371 -- is linear in `post` (conv6 has no activation): a transposed layer (k3, s2, p1, op1) to ONE
+ * channel with folded weights W'[c][kd][kh][kw] (c over post's channels) and a scalar bias.  Three entry points (r5) evaluate it
+ * WITHOUT storing `post` = relu(bn(conv5(x)) + pre) (reference submodule.py:161-164):
+ *   snvc_f16x3_tail_pack_weights:      W' ([Cin][27] fp32, Cin % 32 == 0) as split MFMA A fragments, values * wmul (a power of two);
+ *   snvc_f16x3_deconv3d_tail_forward:  the split transposed layer conv5 (same arguments as snvc_f16x3_conv3d_forward: desc of a
+ *       ConvTranspose3d(k3,s2,p1,op1) with Cout = 32 or 64, folded scale / bias, residual pair, flags) whose epilogue forms the result in
+ *       units 2^e_y (clamped to half's range and flagged like every split output), splits it and contracts it per voxel with W':
+ *       t_out[n][tap = (kd*3+kh)*3+kw][class][pd][ph][pw] = tail_mul * sum_c W'[c][tap] * post[n][c][2pd+rd][2ph+rh][2pw+rw],
+ *       class = rd*4 + rh*2 + rw, (pd, ph, pw) over the layer's INPUT grid; fp32, dense; tail_mul = 2^-(e_y + w_exp);
+ *   snvc_deconv_tail_gather:           y[n][o] = bias[0] + residual[n][o] + sum over (i, k) with o = 2 i - 1 + k per dimension of
+ *       t[n][k][i]; (nd, nh, nw) = the grid of t's classes, y / residual [N][4nd][4nh][4nw] fp32 (residual, bias may be NULL). */
+SNVC_API int64_t snvc_f16x3_tail_packed_weight_bytes(int cin);
+SNVC_API int snvc_f16x3_tail_pack_weights(const float *weight, int cin, void *packed, float wmul, void *stream);
+SNVC_API int snvc_f16x3_deconv3d_tail_forward(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,
+                                              const void *packed_weight, const float *scale, const float *bias,
+                                              const void *res_hi, const void *res_lo, float res_mul, const void *tail_packed,
+                                              float *t_out, float tail_mul, int *overflow, void *stream);
+SNVC_API int snvc_deconv_tail_gather(const float *t, const float *bias, const float *residual, float *y, int64_t N,
+                                     int64_t nd, int64_t nh, int64_t nw, void *stream);
 /* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half (vernier.py:433) on C8 tensors:
  *   out[n,c,s] = half(float(feat[n,c,s]) * occ[n,0,s]), occ an fp32 plane [N][S]; C % 8 == 0. */
 SNVC_API int snvc_f16_mul_broadcast(const void *feat_c8, const float *occ, void *out_c8, int64_t N, int64_t C,

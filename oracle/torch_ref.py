@@ -228,7 +228,10 @@ class VernierTrunk(nn.Module):
     """
 
     def __init__(self, dim=32, grid=(32, 128, 192), gn=False, num_parts=9, part_reg_head=False,
-                 x_range=(-1.0, 1.0), z_range=(-1.0, 1.0)):
+                 x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), heads=True):
+        """``heads=False``: only the 3D trunk's layers (vernier.py:249-289) are built -- for grids whose BEV neck the reference
+        cannot instantiate (nh not in {16, 32}: BASELINE configs[2] 96^3 crops, configs[4] 80x160x160; vernier.py:290-295 raises);
+        ``trunk_3d`` is the same code either way, and the default construction is what tests/golden pins."""
         super().__init__()
         nh, nw, nl = grid
         self.grid = grid
@@ -246,6 +249,9 @@ class VernierTrunk(nn.Module):
             self.part_reg_head = nn.Sequential(convbn_3d(dim, dim, 3, 1, 1, gn=gn), nn.ReLU(inplace=True),
                                                nn.Conv3d(dim, 27, 1, 1, 0, bias=False))
         self.pool_3d = nn.AvgPool3d((4, 1, 1), stride=(4, 1, 1))
+        if not heads:
+            self._init_weights()
+            return
         if nh == 32:
             dim_height = 256
         elif nh == 16:
@@ -269,6 +275,9 @@ class VernierTrunk(nn.Module):
         x_map = np.tile(np.linspace(0, 1, mw), (mh, 1)).reshape(1, 1, mh, mw)
         z_map = np.tile(np.linspace(0, 1, mh).reshape(mh, 1), (1, mw)).reshape(1, 1, mh, mw)
         self.coor_maps = torch.from_numpy(np.concatenate([x_map, z_map], axis=1).astype(np.float32))
+        self._init_weights()
+
+    def _init_weights(self):
         # init, vernier.py:38-54
         for m in self.modules():
             if isinstance(m, (nn.Conv3d, nn.Conv2d)):

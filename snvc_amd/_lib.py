@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNVC_HIP_LIB") or os.path.join(_HERE, "libsnvc_hip.so")   # env: development override
 _lib = None
-_ABI = 3   # snvc_abi_version() this binding was written against
+_ABI = 4   # snvc_abi_version() this binding was written against
 
 c_i64 = ctypes.c_int64
 c_f32 = ctypes.c_float
@@ -105,6 +105,10 @@ SIGNATURES = {
     "snvc_f16x3_conv3d_packed_weight_bytes": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
     "snvc_f16x3_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_f32, c_p]),
     "snvc_f16x3_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_f32, c_p, c_p]),
+    "snvc_f16x3_tail_packed_weight_bytes": (c_i64, [c_int]),
+    "snvc_f16x3_tail_pack_weights": (c_int, [c_p, c_int, c_p, c_f32, c_p]),
+    "snvc_f16x3_deconv3d_tail_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_f32, c_p, c_p]),
+    "snvc_deconv_tail_gather": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_f16_mul_broadcast": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_f16_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_volume_resample": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_i64, c_p]),

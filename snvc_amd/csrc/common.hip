@@ -15,5 +15,5 @@ void set_error(const char *fmt, ...) {
 
 extern "C" {
 const char *snvc_last_error_string(void) { return snvc::g_err; }
-int snvc_abi_version(void) { return 3; }   // 2: snvc_conv3d_desc.ksize_d, fp16-storage mode, volume resampling; 3: side head, one-channel transposed layers
+int snvc_abi_version(void) { return 4; }   // 2: snvc_conv3d_desc.ksize_d, fp16-storage mode, volume resampling; 3: side head, one-channel transposed layers; 4: tail projection
 }

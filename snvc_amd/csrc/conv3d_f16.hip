@@ -53,6 +53,12 @@ struct F16Args {
     float head_mul;      //   2^-out_exp (EPI 2: applied to the fp32 result, which the epilogue forms in the residual's units)
     float res_mul;       // split residual: its stored units relative to the result's, 2^(e_y - e_res) (exact)
     int *overflow;       // split output: set to 1 if a value had to be clamped to half's range (the caller's exponent was too large)
+    // EPI 4 (r5, "tail projection"): the layer's result is not stored; its contraction with a one-channel transposed layer's
+    // weights W'[c][27 taps] is -- t_out[n][tap][class][pd][ph][pw] fp32 (see snvc_f16x3_deconv3d_tail_forward)
+    const _Float16 *tail_w;   // [block m][8-channel group j][hi | lo][lane][8]: A fragments (32 tap rows x 16 channels), values * 2^w_exp
+    float *t_out;
+    float tail_mul;           // 2^-(e_y + w_exp): exact
+    int64_t t_bs;             // floats between samples of t_out
     int CGin;            // input channel groups (Cin / 8, rounded up)
     int Cout;
     int Din, Hin, Win;
@@ -132,7 +138,8 @@ __device__ __forceinline__ int xcd_remap16(int b, int n) {
 }
 
 // EPI 0: C8 half output (+affine, residual, ReLU); 1: fp32 plane of channel 0 (+Sigmoid); 2: fp32 NCDHW output (split mode);
-// 3: EPI 0 + the side head (split mode, one 32-channel block)
+// 3: EPI 0 + the side head (split mode, one 32-channel block); 4: tail projection (split transposed layer whose ONLY consumer is a
+// transposed layer to one channel: the per-voxel contraction with that layer's 27 taps is done here, on the matrix pipe)
 template <class Cfg, int EPI>
 __global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_f16_kernel(const F16Args a_) {
@@ -439,6 +446,82 @@ conv3d_f16_kernel(const F16Args a_) {
             if (a.flags & SNVC_EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
             if (okv[nb] && half == 0) yp[sp[nb]] = v;
         }
+    } else if constexpr (EPI == 4) {
+        // The layer's result v = act(affine(acc) + residual) (64 channels per voxel, never stored) feeds ONLY a transposed layer to one
+        // channel (the global stack's folded tail: classifier(bn(deconv(v)) + ...) -- reference submodule.py:127-146,166 with
+        // vernier.py:366-371's composition).  That layer is out[o] = sum over (voxel i, tap k) with o = 2 i - 1 + k of T[k][i],
+        // T[k][i] = sum_c W'[c][k] v[c][i]: a 27 x C contraction PER VOXEL, independent of every other voxel -- done here as three
+        // half-precision MFMAs per 8-channel group on the (hi, lo) pair of v (the same split arithmetic as the layer itself; the B operand of
+        // v_mfma_f32_32x32x16_f16 is exactly what a lane holds: 8 channels of one voxel).  Written: 27 fp32 planes per class instead of
+        // C channels of fp32 (0.42 of the bytes at C = 64), contiguous along W inside a class (the NCDHW form stored 4 bytes at an 8-byte stride).
+        static_assert(EPI != 4 || SPLIT, "tail projection: split mode");
+        const _Float16 *rn = a.res ? a.res + n * a.r_bs : nullptr, *rn_lo = a.res ? a.res_lo + n * a.r_bs : nullptr;
+        h8 tw[MI][2][2];
+        {
+            const h8 *twp = reinterpret_cast<const h8 *>(a.tail_w) + lane;
+#pragma unroll
+            for (int m = 0; m < MI; ++m)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) tw[m][j][s2] = twp[((m * 2 + j) * 2 + s2) * 64];
+        }
+        constexpr float kHalfMax = 65504.0f;
+        float vmax = 0.0f;
+        const int64_t cls_vox = (int64_t)a.nd * a.nh * a.nw;
+        float *tn = a.t_out + n * a.t_bs + (int64_t)cls * cls_vox;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int row = wave * NB + nb;
+            const int pd = od0 + row / TH, ph = oh0 + row % TH;
+            f32x16 tacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tacc[r] = 0.0f;
+#pragma unroll
+            for (int m = 0; m < MI; ++m) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int cj = m * 32 + 16 * half + 8 * j;
+                    f32x4 sc[2], bi[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        sc[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + cj + 4 * k) : f32x4(1.0f);
+                        bi[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.bias + cj + 4 * k) : f32x4(0.0f);
+                    }
+                    h8 rv = h8((_Float16)0.0f), rl = h8((_Float16)0.0f);
+                    if (rn) {
+                        const int64_t gj = (int64_t)(cj >> 3) * out_dhw;
+                        rv = *reinterpret_cast<const h8 *>(rn + (gj + sp[nb]) * 8);
+                        rl = *reinterpret_cast<const h8 *>(rn_lo + (gj + sp[nb]) * 8);
+                    }
+                    h8 o, ol;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float v = __builtin_fmaf(acc[nb][m][8 * j + e], sc[e >> 2][e & 3], bi[e >> 2][e & 3]);
+                        const float rr = ((float)rv[e] + (float)rl[e]) * a.res_mul;
+                        if (add_pre) v += rr;
+                        if (relu) v = __builtin_fmaxf(v, 0.0f);
+                        if (add_post) v += rr;
+                        v = __builtin_amdgcn_fmed3f(v, -kHalfMax, kHalfMax);
+                        vmax = __builtin_fmaxf(vmax, okv[nb] ? __builtin_fabsf(v) : 0.0f);
+                        o[e] = (_Float16)v;
+                        ol[e] = (_Float16)(v - (float)o[e]);
+                    }
+                    tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tw[m][j][1], o, tacc, 0, 0, 0);
+                    tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tw[m][j][0], ol, tacc, 0, 0, 0);
+                    tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tw[m][j][0], o, tacc, 0, 0, 0);
+                }
+            }
+            if (okv[nb]) {
+                const int64_t spc = ((int64_t)pd * a.nh + ph) * a.nw + pw_;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int tap = (r & 3) + 8 * (r >> 2) + 4 * half;       // accumulator row of this register
+                    if (tap < 27) tn[(int64_t)tap * 8 * cls_vox + spc] = tacc[r] * a.tail_mul;
+                }
+            }
+        }
+        if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
     } else {
         // EPI 0: C8 half output (split mode: a (hi, lo) pair); EPI 2: fp32 NCDHW output (a split-mode layer handing its result
         // to the fp32 kernels).  Residual: C8 (split mode: a pair).
@@ -1328,6 +1411,71 @@ inline int64_t f16_class_stride(const F16Plan &p) {
     return p.block_halves + (int64_t)p.PF * p.MI * (p.PL >= 2 ? 2 : 1) * 64 * 8;
 }
 
+// A fragments of the tail projection (conv3d_f16_kernel EPI 4): [m][j][hi | lo][lane][8]; row (lane & 31) = tap, k = 8 * (lane >> 5) + e
+// is channel 32 m + 16 (lane >> 5) + 8 j + e -- the channel that accumulator register 8 j + e of lane (voxel, lane >> 5) holds
+__global__ void pack_tail_weights_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, int Cin, float wmul, int total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int r = i;
+    const int e = r % 8; r /= 8;
+    const int lane = r % 64; r /= 64;
+    const int pl = r % 2; r /= 2;
+    const int j = r % 2; r /= 2;
+    const int m = r;
+    const int tap = lane & 31, c = 32 * m + 16 * (lane >> 5) + 8 * j + e;
+    const float v = (tap < 27 && c < Cin) ? w[c * 27 + tap] * wmul : 0.0f;
+    const _Float16 hi = (_Float16)v;
+    out[i] = pl == 0 ? hi : (_Float16)(v - (float)hi);
+}
+
+// out[o] = bias + res[o] + sum over (i, k) with o = 2 i - 1 + k (per dimension) of T[k][i]: the scatter half of a transposed layer
+// (k3, s2, p1, op1) to one channel whose per-voxel contraction T was formed by the producing layer (EPI 4).  T is class-major:
+// [27][8 = (i_d & 1, i_h & 1, i_w & 1)][nd][nh][nw], i = 2 p + r.  A thread owns 4 consecutive outputs of one output row
+// (ow = 4 j .. 4 j + 3): every T element is read exactly once, 4-byte loads consecutive across the lanes, one 16-byte store.
+__global__ void __launch_bounds__(256)
+deconv_tail_gather_kernel(const float *__restrict__ t, const float *__restrict__ bias, const float *__restrict__ res, float *__restrict__ y,
+                          int nd, int nh, int nw, int64_t t_bs, int64_t y_bs, int64_t r_bs) {
+    const int OD = 4 * nd, OH = 4 * nh;
+    const int64_t total = (int64_t)OD * OH * nw;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i % nw);
+    const int64_t r0 = i / nw;
+    const int oh = (int)(r0 % OH), od = (int)(r0 / OH);
+    const int64_t n = blockIdx.y;
+    const int64_t cls_vox = (int64_t)nd * nh * nw, tap_stride = 8 * cls_vox;
+    const float *tn = t + n * t_bs;
+    const float b = bias ? bias[0] : 0.0f;
+    float o0 = b, o1 = b, o2 = b, o3 = b;
+    // per dimension: even output 2 a: (k = 1, i = a); odd output 2 a + 1: (k = 2, i = a) and (k = 0, i = a + 1)
+    const int ad = od >> 1, ah = oh >> 1;
+    const int ndd = (od & 1) ? 2 : 1, nhh = (oh & 1) ? 2 : 1;
+    const bool last_w = j + 1 >= nw;
+    for (int a_ = 0; a_ < ndd; ++a_) {
+        const int kd = (od & 1) ? (a_ ? 0 : 2) : 1, id = ad + a_;
+        if (id >= 2 * nd) continue;
+        for (int b_ = 0; b_ < nhh; ++b_) {
+            const int kh = (oh & 1) ? (b_ ? 0 : 2) : 1, ih = ah + b_;
+            if (ih >= 2 * nh) continue;
+            const int cdh = ((id & 1) << 2) | ((ih & 1) << 1);
+            const int64_t base = ((int64_t)(id >> 1) * nh + (ih >> 1)) * nw + j;
+            const float *t0 = tn + (int64_t)((kd * 3 + kh) * 3) * tap_stride + base;      // kw = 0
+            const float *c0 = t0 + (int64_t)cdh * cls_vox, *c1 = t0 + (int64_t)(cdh | 1) * cls_vox;      // i_w even / odd at p_w = j
+            // ow = 4j: (kw 1, i_w = 2j); 4j+1: (kw 2, 2j) + (kw 0, 2j+1); 4j+2: (kw 1, 2j+1); 4j+3: (kw 2, 2j+1) + (kw 0, 2j+2)
+            o0 += c0[tap_stride];
+            o1 += c0[2 * tap_stride] + c1[0];
+            o2 += c1[tap_stride];
+            o3 += c1[2 * tap_stride] + (last_w ? 0.0f : c0[1]);
+        }
+    }
+    const int64_t sp = ((int64_t)od * OH + oh) * (4 * nw) + 4 * j;
+    if (res) {
+        const f32x4 rv = *reinterpret_cast<const f32x4 *>(res + n * r_bs + sp);
+        o0 += rv[0]; o1 += rv[1]; o2 += rv[2]; o3 += rv[3];
+    }
+    *reinterpret_cast<f32x4 *>(y + n * y_bs + sp) = f32x4{o0, o1, o2, o3};
+}
+
 template <class Cfg, int EPI>
 void launch_f16(const F16Args &a, dim3 grid, hipStream_t st) {
     static std::atomic<unsigned> attr_done{0};
@@ -1533,20 +1681,23 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
     return check_launch("snvc_f16_conv3d_forward");
 }
 
-int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
-                              const float *scale, const float *bias, const void *res_hi, const void *res_lo, void *y_hi,
-                              void *y_lo, float *y_f32, const float *head, float *y_head, float head_mul, float res_mul,
-                              int *overflow, void *stream) {
+static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
+                         const float *scale, const float *bias, const void *res_hi, const void *res_lo, void *y_hi,
+                         void *y_lo, float *y_f32, const float *head, float *y_head, float head_mul, float res_mul,
+                         int *overflow, const void *tail_w, float *t_out, float tail_mul, void *stream) {
     using namespace snvc;
     F16Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null desc");
     int rc = make_f16_plan(*d, p, true);
     if (rc) return rc;
     if (d->N == 0) return SNVC_OK;
+    const bool tail = tail_w != nullptr;          // EPI 4: the result is contracted with a one-channel transposed layer's taps, not stored
+    if (tail && (!t_out || !d->transposed || p.cblocks != 1 || d->Cout != 32 * p.MI || (reinterpret_cast<uintptr_t>(tail_w) & 15)))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_deconv3d_tail_forward: a transposed split layer whose 32 or 64 output channels sit in one block");
     const bool plane = d->Cout == 1;              // the occupancy head: y_f32 is then the fp32 plane [N][1][D][H][W] (Sigmoid honoured)
     const bool to_f32 = y_f32 != nullptr;
     if (plane && !to_f32) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: a one-channel layer writes y_f32");
-    if (!x_hi || !x_lo || !packed_weight || (!to_f32 && (!y_hi || !y_lo)))
+    if (!x_hi || !x_lo || !packed_weight || (!tail && !to_f32 && (!y_hi || !y_lo)))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null pointer");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: scale and bias must both be given or both be NULL");
@@ -1578,6 +1729,8 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     a.res_lo = resflags ? reinterpret_cast<const _Float16 *>(res_lo) : nullptr;
     a.y = reinterpret_cast<_Float16 *>(y_hi); a.y_lo = reinterpret_cast<_Float16 *>(y_lo); a.y_f32 = y_f32;
     a.head = head; a.y_head = y_head; a.head_mul = head_mul; a.res_mul = res_mul; a.overflow = overflow;
+    a.tail_w = reinterpret_cast<const _Float16 *>(tail_w); a.t_out = t_out; a.tail_mul = tail_mul;
+    a.t_bs = (int64_t)27 * 8 * d->Din * d->Hin * d->Win;
     a.CGin = d->Cin / 8; a.Cout = d->Cout;
     a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
     a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;
@@ -1631,8 +1784,8 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
             else launch_f16<F16K3XT, 0>(a, grid, st);
             break;
         case FK3S2X: SNVC_X3_LAUNCH(F16K3S2X); break;
-        case FDCX: SNVC_X3_LAUNCH(F16DCX); break;
-        case FDCXN: SNVC_X3_LAUNCH(F16DCXN); break;
+        case FDCX: if (tail) launch_f16<F16DCX, 4>(a, grid, st); else SNVC_X3_LAUNCH(F16DCX); break;
+        case FDCXN: if (tail) launch_f16<F16DCXN, 4>(a, grid, st); else SNVC_X3_LAUNCH(F16DCXN); break;
         case FK1X: SNVC_X3_LAUNCH(F16K1X); break;
         case FK5X: SNVC_X3_LAUNCH(F16K5X); break;
         case FK5D2X: SNVC_X3_LAUNCH(F16K5D2X); break;
@@ -1666,6 +1819,53 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
     }
 #undef SNVC_X3_LAUNCH
     return check_launch("snvc_f16x3_conv3d_forward");
+}
+
+int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
+                              const float *scale, const float *bias, const void *res_hi, const void *res_lo, void *y_hi,
+                              void *y_lo, float *y_f32, const float *head, float *y_head, float head_mul, float res_mul,
+                              int *overflow, void *stream) {
+    return f16x3_forward(d, x_hi, x_lo, packed_weight, scale, bias, res_hi, res_lo, y_hi, y_lo, y_f32, head, y_head, head_mul, res_mul,
+                         overflow, nullptr, nullptr, 0.0f, stream);
+}
+
+int64_t snvc_f16x3_tail_packed_weight_bytes(int cin) {
+    return cin > 0 && cin % 32 == 0 ? (int64_t)(cin / 32) * 2 * 2 * 64 * 8 * 2 : -1;
+}
+
+int snvc_f16x3_tail_pack_weights(const float *weight, int cin, void *packed, float wmul, void *stream) {
+    using namespace snvc;
+    if (!weight || !packed || cin <= 0 || cin % 32 != 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_tail_pack_weights: weight [Cin][27] with Cin % 32 == 0");
+    const int total = (cin / 32) * 2 * 2 * 64 * 8;
+    pack_tail_weights_kernel<<<(unsigned)ceil_div(total, 256), 256, 0, as_stream(stream)>>>(weight, reinterpret_cast<_Float16 *>(packed), cin, wmul, total);
+    return check_launch("snvc_f16x3_tail_pack_weights");
+}
+
+int snvc_f16x3_deconv3d_tail_forward(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
+                                     const float *scale, const float *bias, const void *res_hi, const void *res_lo, float res_mul,
+                                     const void *tail_packed, float *t_out, float tail_mul, int *overflow, void *stream) {
+    using namespace snvc;
+    if (!tail_packed || !t_out) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_deconv3d_tail_forward: null pointer");
+    return f16x3_forward(d, x_hi, x_lo, packed_weight, scale, bias, res_hi, res_lo, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, res_mul,
+                         overflow, tail_packed, t_out, tail_mul, stream);
+}
+
+int snvc_deconv_tail_gather(const float *t, const float *bias, const float *residual, float *y, int64_t n, int64_t nd, int64_t nh,
+                            int64_t nw, void *stream) {
+    using namespace snvc;
+    if (n < 0 || nd <= 0 || nh <= 0 || nw <= 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_deconv_tail_gather: sizes must be positive");
+    if (n == 0) return SNVC_OK;
+    if (!t || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_deconv_tail_gather: null pointer");
+    if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_deconv_tail_gather: y / residual must be 16-byte aligned");
+    const int64_t threads = 16 * nd * nh * nw, out_vox = 64 * nd * nh * nw;
+    if (threads >= ((int64_t)1 << 31) * 255 || n > 65535 || 27 * 8 * nd * nh * nw >= ((int64_t)1 << 40))
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_deconv_tail_gather: tensor too large");
+    const dim3 grid((unsigned)ceil_div<int64_t>(threads, 256), (unsigned)n);
+    deconv_tail_gather_kernel<<<grid, 256, 0, as_stream(stream)>>>(t, bias, residual, y, (int)nd, (int)nh, (int)nw, 27 * 8 * nd * nh * nw,
+                                                                   out_vox, out_vox);
+    return check_launch("snvc_deconv_tail_gather");
 }
 
 }  // extern "C"

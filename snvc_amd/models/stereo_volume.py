@@ -22,8 +22,8 @@ import torch.nn as nn
 from ..extension.build_cost_volume import _BuildCostVolume, build_cost_volume  # noqa: F401  (re-exported)
 from .. import ops
 from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, SplitOverflow, _FactoredFirstConvFn, _ShearedFirstConvBNFn,
-                        _ShearedFirstConvFn, _folded_bn, _is_channel_head as _is_head_conv, _Plan, convbn_3d, hourglass,
-                        overflow_guard, sheared_geometry, sheared_kernels, EPI_RELU)
+                        _ShearedFirstConvFn, _folded_bn, _is_channel_head as _is_head_conv, _Plan, convbn_3d, folded_head_weights,
+                        hourglass, overflow_guard, sheared_geometry, sheared_kernels, EPI_RELU)
 
 
 class GlobalStack(nn.Module):
@@ -97,6 +97,7 @@ class GlobalStack(nn.Module):
     # costs): the flag is only posted; ``check_overflow()`` or the next call looks at it.
     arithmetic = "auto"
     overflow_check = "call"
+    fused_tail = True    # split mode: conv5's epilogue contracts its result with the folded one-channel tail (False: r4's two launches)
     X3_SIGMAS = 64.0     # a tensor's exponent is chosen so that |beta| + X3_SIGMAS * |gamma| of its BatchNorm stays below 2^15
 
     @staticmethod
@@ -118,7 +119,8 @@ class GlobalStack(nn.Module):
         for nm in norms:
             if not isinstance(nm, nn.BatchNorm3d) or nm.training or nm.running_mean is None:
                 return None
-        tensors = [t for sq in seqs.values() for t in (sq[0].weight, sq[1].weight, sq[1].bias, sq[1].running_mean, sq[1].running_var)]
+        tensors = [t for sq in list(seqs.values()) + [hg.conv6] for t in (sq[0].weight, sq[1].weight, sq[1].bias, sq[1].running_mean, sq[1].running_var)]
+        tensors.append(self.classifier.weight)
         tensors += [self.conv1[0][1].weight, self.conv1[0][1].bias, self.conv1[0][1].running_mean, self.conv1[0][1].running_var]
         key = tuple((t.data_ptr(), t._version) for t in tensors if t is not None) + (device, _GENERATION[0])
         st = self.__dict__.get("_snvc_x3")
@@ -137,6 +139,13 @@ class GlobalStack(nn.Module):
             w = sq[0].weight.detach().to(device)
             st["layers"][k] = ops.Conv3dLayerX3(w, 3, geo[k][0], 1, 1, geo[k][1])
             st["affine"][k] = _folded_bn(sq[1], sq[0].__dict__.setdefault("_snvc_plans", {}).setdefault(device, _Plan()))
+        # the folded tail classifier(bn(conv6(post)) + v): a transposed layer to one channel whose per-voxel tap contraction is part
+        # of conv5's epilogue (snvc_f16x3_deconv3d_tail_forward); `post` is never stored
+        st["tail"] = st["tail_bias"] = None
+        if isinstance(hg.conv6[1], nn.BatchNorm3d) and not hg.conv6[1].training and hg.conv6[0].in_channels % 32 == 0:
+            wf, fb = folded_head_weights(hg.conv6[0], hg.conv6[1], self.classifier)
+            st["tail"] = ops.TailWeightsX3(wf.float().to(device))
+            st["tail_bias"] = fb.float().reshape(1).to(device)
         st["guard"] = overflow_guard(self, device)      # survives rebuilds of this state: a pending flag is never dropped
         st["flag"] = st["guard"].flag
         self.__dict__["_snvc_x3"] = st
@@ -213,10 +222,19 @@ class GlobalStack(nn.Module):
         pre = L["h2"](o, E["h1"], *A["h2"], flags=EPI_RELU, out_exp=E["h2"], overflow=flag)                     # relu(bn(conv))   :153-156
         o = L["h3"](pre, E["h2"], *A["h3"], flags=EPI_RELU, out_exp=E["h3"], overflow=flag)                     # 1/4 res
         o = L["h4"](o, E["h3"], *A["h4"], flags=EPI_RELU, out_exp=E["h4"], overflow=flag)
-        st["guard"].post()      # the last layer that can clamp: the two below write float32.  The flag leaves for the host here
-        # post = relu(bn(deconv(o)) + pre): the result leaves as fp32 NCDHW for the one-channel transposed tail (VALU kernel)
-        post = L["h5"](o, E["h4"], *A["h5"], residual=pre, flags=EPI_RELU | ops.EPI_ADD_PRE, out_exp=E["h2"], to_f32=True)
-        cost = hg.conv6.fused(post, residual=None, head=self.classifier, head_residual=hv)    # deconv'(post) + b' + classifier(v2)
+        if st["tail"] is not None and self.fused_tail:
+            # post = relu(bn(deconv(o)) + pre) is formed, clamped / flagged and contracted with the folded tail's 27 taps inside conv5's
+            # launch (r5): 27 fp32 planes per parity class leave instead of 64 channels, and the last launch only sums them
+            t = L["h5"].forward_tail(o, E["h4"], *A["h5"], st["tail"], residual=pre, flags=EPI_RELU | ops.EPI_ADD_PRE, out_exp=E["h2"],
+                                     overflow=flag, out=self._buffer("tail_t", (n, 27, 8) + tuple(o.shape[3:6]), dev))
+            st["guard"].post()      # the last launch that can clamp; the flag leaves for the host here
+            cost = ops.deconv_tail_gather(t, st["tail_bias"], hv)                             # deconv'(post) + b' + classifier(v2)
+            _ROUTES["x3_fused_tail"] += 1
+        else:
+            st["guard"].post()      # the last layer that can clamp: the two below write float32
+            # post = relu(bn(deconv(o)) + pre): the result leaves as fp32 NCDHW for the one-channel transposed tail (VALU kernel)
+            post = L["h5"](o, E["h4"], *A["h5"], residual=pre, flags=EPI_RELU | ops.EPI_ADD_PRE, out_exp=E["h2"], to_f32=True)
+            cost = hg.conv6.fused(post, residual=None, head=self.classifier, head_residual=hv)    # deconv'(post) + b' + classifier(v2)
         _ROUTES["x3_tail"] += 1
         if self.overflow_check == "call" and st["guard"].wait():
             # waited for while the transposed layer and the tail still run: this call's result is dropped and redone in fp32

@@ -762,26 +762,33 @@ def _folded_head_layer(conv: nn.Module, norm: Optional[nn.Module], head: nn.Modu
     cached = getattr(plan, "folded_head", None)
     if cached is None or cached[0] != key:
         k, s, p, d, transposed = _conv_geometry(conv)
-        h = hw.detach().double().reshape(-1)
-        if norm is not None:
-            var, mean = norm.running_var.detach().double(), norm.running_mean.detach().double()
-            g = norm.weight.detach().double() if norm.weight is not None else torch.ones_like(var)
-            b = norm.bias.detach().double() if norm.bias is not None else torch.zeros_like(var)
-            sc = g / torch.sqrt(var + norm.eps)
-            sh = b - mean * sc
-        else:
-            sc, sh = torch.ones_like(h), torch.zeros_like(h)
-        hs = h * sc
-        wd = w.detach().double()
-        if transposed:      # [Cin, Cout, k, k, k] -> [Cin, 1, k, k, k]
-            wf = torch.einsum("iodhw,o->idhw", wd, hs).unsqueeze(1)
-        else:               # [Cout, Cin, k, k, k] -> [1, Cin, k, k, k]
-            wf = torch.einsum("oidhw,o->idhw", wd, hs).unsqueeze(0)
+        wf, fb = folded_head_weights(conv, norm, head)
         layer = ops.Conv3dLayer(wf.float().contiguous(), k, s, p, d, transposed)
         one = torch.ones(1, dtype=torch.float32, device=w.device)
-        bias = (h * sh).sum().float().reshape(1)
-        cached = plan.folded_head = (key, layer, one, bias)
+        cached = plan.folded_head = (key, layer, one, fb.float().reshape(1))
     return cached[1], cached[2], cached[3]
+
+
+def folded_head_weights(conv: nn.Module, norm: Optional[nn.Module], head: nn.Module):
+    """(W', b') of ``head(norm(conv(x)))`` as one layer to one channel, folded in fp64: W' has conv's weight layout with one output
+    channel ([Cin, 1, k, k, k] for a transposed layer, [1, Cin, k, k, k] otherwise), b' is a scalar tensor."""
+    w, hw = conv.weight, head.weight
+    h = hw.detach().double().reshape(-1)
+    if norm is not None:
+        var, mean = norm.running_var.detach().double(), norm.running_mean.detach().double()
+        g = norm.weight.detach().double() if norm.weight is not None else torch.ones_like(var)
+        b = norm.bias.detach().double() if norm.bias is not None else torch.zeros_like(var)
+        sc = g / torch.sqrt(var + norm.eps)
+        sh = b - mean * sc
+    else:
+        sc, sh = torch.ones_like(h), torch.zeros_like(h)
+    hs = h * sc
+    wd = w.detach().double()
+    if isinstance(conv, nn.ConvTranspose3d):      # [Cin, Cout, k, k, k] -> [Cin, 1, k, k, k]
+        wf = torch.einsum("iodhw,o->idhw", wd, hs).unsqueeze(1)
+    else:                                         # [Cout, Cin, k, k, k] -> [1, Cin, k, k, k]
+        wf = torch.einsum("oidhw,o->idhw", wd, hs).unsqueeze(0)
+    return wf, (h * sh).sum()
 
 
 def fused_conv3d(conv: nn.Module, norm: Optional[nn.Module], x: torch.Tensor, *, relu=False, sigmoid=False,

@@ -1368,6 +1368,85 @@ class Conv3dLayerX3:
             return out_f32          # the kernel multiplied by 2^-out_exp on the way out
         return (out, y_head) if head is not None else out
 
+    def forward_tail(self, x, x_exp: int, scale, bias, tail: "TailWeightsX3", residual=None, flags: int = 0, out_exp: int = 0,
+                     overflow=None, res_exp: Optional[int] = None, out=None):
+        """A transposed layer whose result y = epilogue(conv(x)) (held in units 2**out_exp, clamped to half's range and flagged like any
+        split output) feeds only a one-channel transposed layer with folded weights ``tail``: returns the per-voxel tap contractions
+        T [N, 27, 8, Din, Hin, Win] float32 (class-major over y's parity classes) -- y itself is never stored
+        (snvc_f16x3_deconv3d_tail_forward; ``deconv_tail_gather`` finishes the layer)."""
+        _split_check(x, "x")
+        if not self.transposed or self.stride != 2 or x.size(2) * 8 != self.cin or tail.cin != self.cout:
+            raise RuntimeError("forward_tail: a ConvTranspose3d(k3,s2,p1,op1) layer whose Cout equals the tail's Cin")
+        n = x.size(0)
+        in_sp = tuple(x.shape[3:6])
+        out_sp = self.out_spatial(in_sp)
+        shape = (n, 27, 8) + in_sp
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+            raise RuntimeError("forward_tail `out` must be a contiguous float32 [N, 27, 8, Din, Hin, Win] tensor")
+        if residual is not None:
+            _split_check(residual, "residual")
+            if tuple(residual.shape) != (n, 2, self.cout // 8) + out_sp + (8,):
+                raise RuntimeError("residual must have the layer's output shape (split C8)")
+        sc, bi = self.folded(scale, bias, x_exp, out_exp)
+        packed = self._pack(self.algo)
+        if n == 0:
+            return out
+        d = self._desc(n, in_sp, flags, _batch_stride(x), 0, _batch_stride(residual) if residual is not None else 0)
+        null = ctypes.c_void_p(0)
+        with torch.cuda.device(x.device):
+            check(_lib.lib().snvc_f16x3_deconv3d_tail_forward(
+                ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(packed), _ptr(sc), _ptr(bi), _ptr(residual),
+                _lo_ptr(residual) if residual is not None else null, float(2.0 ** (out_exp - (out_exp if res_exp is None else res_exp))),
+                _ptr(tail.packed), _ptr(out), float(2.0 ** -(out_exp + tail.w_exp)), _ptr(overflow), _stream(x)),
+                "snvc_f16x3_deconv3d_tail_forward")
+        return out
+
+
+class TailWeightsX3:
+    """The folded one-channel transposed layer behind a split transposed layer (``Conv3dLayerX3.forward_tail``): W' [Cin, 27]
+    (tap = (kd*3 + kh)*3 + kw) packed as split MFMA A fragments, values * 2**w_exp with max|W'| * 2**w_exp in [2^13, 2^14)."""
+
+    def __init__(self, weight: torch.Tensor):
+        _gpu(weight, "weight")
+        w = weight.detach().reshape(weight.shape[0], -1).float().contiguous()
+        if w.shape[1] != 27 or w.shape[0] % 32 != 0:
+            raise RuntimeError("tail weights must be [Cin, 27] (or [Cin, 1, 3, 3, 3]) with Cin % 32 == 0")
+        self.cin = int(w.shape[0])
+        wmax = float(w.abs().max().item()) if w.numel() else 1.0
+        self.w_exp = 14 - math.frexp(wmax)[1] if wmax > 0 and math.isfinite(wmax) else 0
+        nbytes = _lib.lib().snvc_f16x3_tail_packed_weight_bytes(self.cin)
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        with torch.cuda.device(w.device):
+            check(_lib.lib().snvc_f16x3_tail_pack_weights(_ptr(w), self.cin, _ptr(self.packed), float(2.0 ** self.w_exp), _stream(w)),
+                  "snvc_f16x3_tail_pack_weights")
+
+
+def deconv_tail_gather(t: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, out=None):
+    """The scatter half of a transposed layer (k3, s2, p1, op1) to one channel: ``t`` [N, 27, 8, nd, nh, nw] (per-voxel tap
+    contractions, class-major: ``Conv3dLayerX3.forward_tail``) -> float32 [N, 1, 4nd, 4nh, 4nw] = bias + residual + the sums over
+    (voxel, tap) pairs that land on each output (snvc_deconv_tail_gather)."""
+    _gpu(t, "t")
+    if t.dtype != torch.float32 or t.dim() != 6 or t.size(1) != 27 or t.size(2) != 8 or not t.is_contiguous():
+        raise RuntimeError("t must be a contiguous float32 [N, 27, 8, nd, nh, nw] tensor")
+    n, nd, nh, nw = t.size(0), t.size(3), t.size(4), t.size(5)
+    shape = (n, 1, 4 * nd, 4 * nh, 4 * nw)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=t.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("out must be a contiguous float32 tensor of the output shape")
+    if residual is not None:
+        _gpu(residual, "residual")
+        if residual.dtype != torch.float32 or residual.numel() != out.numel() or not residual.is_contiguous():
+            raise RuntimeError("residual must be a contiguous float32 tensor of the output shape")
+    if bias is not None:
+        bias = bias.detach().reshape(-1)[:1].float().contiguous()
+    with torch.cuda.device(t.device):
+        check(_lib.lib().snvc_deconv_tail_gather(_ptr(t), _ptr(bias), _ptr(residual), _ptr(out), n, nd, nh, nw, _stream(t)),
+              "snvc_deconv_tail_gather")
+    return out
+
 
 def mul_broadcast_split(feat, occ, out=None):
     """out = split((hi + lo) * occ[n, 0]) on split pairs (snvc_f16x3_mul_broadcast); occ: float32 [N,1,D,H,W]."""

@@ -197,4 +197,11 @@ def test_cfg2_every_split_mode_layer_on_the_oracles_input_full_size(cfg2):
         post = L["h5"](sp("h4", E["h4"]), E["h4"], *A["h5"], residual=sp("pre", E["h2"]), flags=ops.EPI_RELU | ops.EPI_ADD_PRE,
                        out_exp=E["h2"], to_f32=True)
         check(post.cpu().numpy(), o["post"].numpy(), TIGHT, "split hourglass conv5 (transposed 64->64 + pre, ReLU) -> fp32")
+        del post
+        # r5: the same layer with its result contracted with the folded tail's taps in the epilogue, then the gather -- on the oracle's
+        # h4 / pre / classifier(v2), against the oracle's COST (the stack's output), whole tensor
+        t = L["h5"].forward_tail(sp("h4", E["h4"]), E["h4"], *A["h5"], st["tail"], residual=sp("pre", E["h2"]),
+                                 flags=ops.EPI_RELU | ops.EPI_ADD_PRE, out_exp=E["h2"], overflow=flag)
+        cost = ops.deconv_tail_gather(t, st["tail_bias"], o["hv"].to(dev()))
+        check(cost.cpu().numpy(), o["cost"].numpy(), TIGHT, "conv5 with the tail projection + gather = classifier(v2 + conv6(post))")
         assert flag.item() == 0, "a value was clamped to half's range"

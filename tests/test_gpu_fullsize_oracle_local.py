@@ -1,0 +1,194 @@
+"""The LOCAL (V-A) model against the CPU oracle at BASELINE's sizes, whole tensors ("missing" item 1 / next item 3).
+
+Reference graph: ``VernierScale._sample_2d_feat`` (snvc/models/vernier.py:323-349) -> the BEV_type3 3D trunk
+(vernier.py:414-438; blocks snvc/models/submodule.py:32-50,223-268).  One crop each of
+  * cfg3     (BASELINE configs[2]):  96 x 96 x 96 voxels, F = 32;
+  * released (the shape the reference's constants force): 32 x 128 x 192, F = 32;
+  * cfg5     (BASELINE configs[4]):  80 x 160 x 160, F = 64
+runs ONCE through the oracle on the host -- numpy restatement of the gather + the torch-CPU restatement of the trunk that
+tests/golden pins bit-equal to the imported reference -- with every intermediate kept.  Then, on the GPU:
+  * the gather (fp32, and the split / fp16 forms through their own exact rules) BIT-EXACT against the oracle's voxel tensor;
+  * ``bev`` and ``occupancy`` of the fused trunk on ALL elements: split mode (the default) and the fp32-MFMA kernels at 1e-4
+    (check()'s three criteria incl. north_star's elementwise 1e-3 rule), the fp16-STORAGE mode at its stated tolerance;
+  * every layer of the trunk fed the ORACLE's input of that layer, whole output tensors: split-mode kernels at the exact-fp32
+    tolerance 2e-5, fp32-MFMA kernels at 2e-5 (Winograd F(4,7): 3e-4) -- no layer's error can hide behind the next one's.
+bench.py's ``configs.*.parity_vs_cpu_baseline`` repeats the first two comparisons on the timed runs' own outputs.
+"""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_parity import REL, TIGHT, WINO7
+
+pytestmark = pytest.mark.gpu
+
+CASES = {"cfg3_crop_96": ((96, 96, 96), 32), "released_32x128x192": ((32, 128, 192), 32), "cfg5_80x160x160": ((80, 160, 160), 64)}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def check_t(got, exp, tol, what):
+    """tests/test_gpu_parity.py::check on the device (these tensors have up to 1.3e8 elements): max-normalised error <= tol (and
+    <= 1e-3), and element by element |err| <= 1e-3 |ref| + 1e-3 rms(ref) for all but 0.01 % of the elements, none beyond 10x."""
+    exp = exp.to(got.device)
+    assert got.shape == exp.shape, (what, got.shape, exp.shape)
+    a, b = got.double().reshape(-1), exp.double().reshape(-1)
+    err = (a - b).abs()
+    e = err.max().item() / max(b.abs().max().item(), 1e-30)
+    assert e <= REL, f"{what}: rel err {e:.3e} breaks the 1e-3 contract"
+    assert e <= tol, f"{what}: rel err {e:.3e} above the expected {tol:.1e}"
+    bound = REL * b.abs() + REL * max(b.pow(2).mean().sqrt().item(), 1e-30)
+    frac, worst = (err > bound).double().mean().item(), (err / bound).max().item()
+    assert frac <= 1e-4 and worst <= 10.0, f"{what}: elementwise 1e-3 criterion: {100 * frac:.4f} % outside, worst {worst:.2f}x"
+    return e
+
+
+@pytest.fixture(scope="module", params=list(CASES))
+def case(request):
+    import bench
+    grid, f = CASES[request.param]
+    o = bench.local_oracle(grid, f, 1, keep_layers=True)
+    o["name"], o["grid"], o["F"] = request.param, grid, f
+    yield o
+    o.clear()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _model(o, precision):
+    import bench
+    m = bench.local_model(o["grid"], o["F"], dev())
+    m.precision = precision
+    return m
+
+
+def _inputs(o):
+    return tuple(torch.from_numpy(o[k]).to(dev()) for k in ("lf", "rf", "gl", "gr"))
+
+
+def test_gather_is_bit_exact_at_full_size(case):
+    """a3 at BASELINE's sizes: all 64 (128) channels of every voxel equal the oracle's, bit for bit -- the fp32 gather, the gather
+    that writes the split pair (== the oracle's values split with the features' scale) and the fp16 one (== rounded once)."""
+    from snvc_amd import ops
+    o = case
+    m = _model(o, "auto")
+    lf, rf, gl, gr = _inputs(o)
+    exp = o["voxel"].to(dev())
+    with torch.no_grad():
+        vox = m.construct_voxel(lf, rf, gl, gr)
+        assert torch.equal(vox, exp), f"{o['name']}: fp32 gather differs from oracle/numpy_ref.py"
+        del vox
+        vs = m.construct_voxel_x3(lf, rf, gl, gr)
+        assert vs is not None
+        assert torch.equal(vs.t, ops.to_split(exp, mul_dev=vs.mul_dev)), f"{o['name']}: split gather != split(oracle voxels)"
+        del vs
+        vh = m.construct_voxel_f16(lf, rf, gl, gr)
+        assert torch.equal(ops.from_c8(vh, exp.size(1)), exp.half().float()), f"{o['name']}: fp16 gather != half(oracle voxels)"
+
+
+@pytest.mark.parametrize("precision", ["auto", "f32", "f16"])
+def test_trunk_outputs_vs_oracle_all_elements(case, precision):
+    """gather + trunk through the model's own entry points (what bench.py times), bev and occupancy on every element."""
+    from snvc_amd.models import submodule as S
+    o = case
+    m = _model(o, precision)
+    lf, rf, gl, gr = _inputs(o)
+    with torch.no_grad():
+        before = S._ROUTES["x3_local_trunk"]
+        if precision == "f16":
+            bev, occ, _ = m.trunk_3d_f16(m.construct_voxel_f16(lf, rf, gl, gr))
+        else:
+            vox = m.construct_voxel_x3(lf, rf, gl, gr) if precision == "auto" else None
+            bev, occ, _ = m.trunk_3d(vox if vox is not None else m.construct_voxel(lf, rf, gl, gr))
+        assert (S._ROUTES["x3_local_trunk"] == before + 1) == (precision == "auto"), "split mode is the default, and only the default"
+        assert not m.__dict__.get("_snvc_x3_off")
+    if precision == "f16":      # fp16 STORAGE: 20+ layers each re-rounding activations to half (tests/test_gpu_f16.py's stated tolerance)
+        ref = o["bev"].to(dev())
+        e_bev = (bev - ref).abs().max().item() / ref.pow(2).mean().sqrt().item()
+        e_occ = (occ - o["occupancy"].to(dev())).abs().max().item()
+        print(f"{o['name']} fp16 storage vs oracle: bev max|err|/rms = {e_bev:.2e}, occupancy max|err| = {e_occ:.2e}")
+        assert e_bev <= 2e-2 and e_occ <= 5e-3, (e_bev, e_occ)
+        return
+    # the fp32-MFMA trunk carries Winograd F(4,7)'s 1e-4 on its first layer; split mode is exact-fp32 per layer
+    e1 = check_t(bev, o["bev"], 3e-4 if precision == "f32" else 1e-4, f"{o['name']} [{precision}] bev vs oracle")
+    e2 = check_t(occ, o["occupancy"], 3e-4 if precision == "f32" else 1e-4, f"{o['name']} [{precision}] occupancy vs oracle")
+    print(f"{o['name']} [{precision}] vs oracle, all elements: bev {e1:.2e}, occupancy {e2:.2e}")
+
+
+def test_every_split_mode_layer_on_the_oracles_input(case):
+    """The layers the default inference path runs (split mode, f16x3), each on the oracle's input of that layer."""
+    from snvc_amd import ops
+    from snvc_amd.models.submodule import SplitT, x3_exponent, x3_norm_bound, _Plan
+    o = case
+    m = _model(o, "auto")
+    g = lambda k: o[k].to(dev())                                                                                  # noqa: E731
+
+    def sp(k, bound_of=None):           # the oracle's tensor as the split pair the model would hold it in
+        t = g(k)
+        if bound_of is None:
+            mul = ops.split_scale_for(t)
+            return SplitT(ops.to_split(t, mul_dev=mul), 0, None, mul)
+        b = sum(x3_norm_bound(s[0][1], s[0][0].__dict__.setdefault("_snvc_plans_x3", {}).setdefault(dev(), _Plan())) for s in bound_of)
+        e = x3_exponent(b)
+        return SplitT(ops.to_split(t, e), e, b)
+
+    f32 = lambda s_: ops.from_split(s_.t, s_.exp)                                                                 # noqa: E731
+    with torch.no_grad():
+        flag = torch.zeros(1, dtype=torch.int32, device=dev())
+        vs = sp("voxel")
+        check_t(f32(m.vimg_feat.fused_x3(vs, flag=flag)), o["img"], TIGHT, "split vimg_feat k1")
+        check_t(f32(m.conv1.fused_x3(vs, flag=flag)), o["v1"], TIGHT, "split conv1 k7")
+        del vs
+        v1 = sp("v1", [m.conv1])
+        check_t(f32(m.conv2.fused_x3(v1, residual=v1, residual_after_act=True, flag=flag)), o["v2"], TIGHT, "split conv2 k5 + v")
+        del v1
+        v2 = sp("v2", [m.conv1, m.conv2])
+        check_t(f32(m.conv3.fused_x3(v2, residual=v2, residual_after_act=True, flag=flag)), o["v3"], TIGHT, "split conv3 k5 dil 2 + v")
+        del v2
+        v3 = sp("v3", [m.conv1, m.conv2, m.conv3])
+        vh = m.hg_conv3d.forward_x3(v3, residual=v3, flag=flag)
+        vh = vh[0] if m.small else vh
+        check_t(f32(vh), o["vh"], 1e-4, "split hourglass_downsample_16 + v (12 layers)")
+        del v3
+        t = m.fg_cls_head[0].fused_x3(SplitT(ops.to_split(g("vh"), vh.exp), vh.exp, vh.bound), relu=True, flag=flag)
+        check_t(f32(t), o["t"], TIGHT, "split fg_cls_head[0] k3")
+        tb = t.bound
+        e = x3_exponent(tb)
+        occ = m.fg_cls_head[2].fused_x3(SplitT(ops.to_split(g("t"), e), e, tb), sigmoid=True)
+        check_t(occ, o["occupancy"], TIGHT, "split occupancy head k3 -> 1 channel, sigmoid")
+        cat = sp("cat")
+        v4 = m.conv4.fused_x3(cat, to_f32=True)
+        check_t(ops.avgpool_depth4(v4).reshape(1, -1, o["grid"][1], o["grid"][2]), o["bev"], TIGHT, "split conv4 k3 + AvgPool3d(4,1,1) + reshape")
+        assert int(flag.item()) == 0, "a value was clamped to half's range"
+
+
+def test_every_fp32_layer_on_the_oracles_input(case):
+    """The fp32-MFMA kernels (precision 'f32', training, GroupNorm models), each layer on the oracle's input of that layer."""
+    from snvc_amd.models.submodule import fused_conv3d_avgpool_d4
+    o = case
+    m = _model(o, "f32")
+    g = lambda k: o[k].to(dev())                                                                                  # noqa: E731
+    with torch.no_grad():
+        vox = g("voxel")
+        check_t(m.vimg_feat(vox), o["img"], TIGHT, "vimg_feat k1")
+        check_t(m.conv1(vox), o["v1"], WINO7, "conv1 k7 (Winograd F(4,7))")
+        del vox
+        v1 = g("v1")
+        check_t(m.conv2.fused(v1, residual=v1, residual_after_act=True), o["v2"], TIGHT, "conv2 k5 + v")
+        del v1
+        v2 = g("v2")
+        check_t(m.conv3.fused(v2, residual=v2, residual_after_act=True), o["v3"], TIGHT, "conv3 k5 dil 2 + v")
+        del v2
+        v3 = g("v3")
+        vh = m.hg_conv3d(v3, None, None, residual=v3)[0] if m.small else m.hg_conv3d(v3, residual=v3)
+        check_t(vh, o["vh"], 1e-4, "hourglass_downsample_16 + v (12 layers)")
+        del v3, vh
+        t = m.fg_cls_head[0].fused(g("vh"), relu=True)
+        check_t(t, o["t"], TIGHT, "fg_cls_head[0] k3")
+        check_t(m.fg_cls_head[2].fused(g("t"), sigmoid=True), o["occupancy"], TIGHT, "occupancy head")
+        v4 = fused_conv3d_avgpool_d4(m.conv4[0][0], m.conv4[0][1], g("cat"), relu=True)
+        check_t(v4.reshape(1, -1, o["grid"][1], o["grid"][2]), o["bev"], TIGHT, "conv4 k3 + AvgPool3d(4,1,1) fused")
