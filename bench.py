@@ -176,6 +176,26 @@ def local_oracle(grid, F, crops=1, seed=7, keep_layers=False):
     return o
 
 
+def kernel_source_hash(rel_path, marker):
+    """sha256 of one kernel's source text: from the line containing `marker` to the first line that is just "}".  profiles/*/traffic.json
+    records it when the PMC passes are turned into a file; bench.py quotes those counters only while the kernel's text is unchanged."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, rel_path)) as fh:
+            lines = fh.read().split("\n")
+    except OSError:
+        return None
+    for i, ln in enumerate(lines):
+        if marker in ln:
+            for j in range(i, len(lines)):
+                if lines[j] == "}":
+                    return hashlib.sha256("\n".join(lines[i:j + 1]).encode()).hexdigest()[:16]
+    return None
+
+
+X3Q_SOURCE = ("snvc_amd/csrc/conv3d_f16.hip", "conv3d_x3q_kernel(const F16Args a) {")
+
+
 def parity_vs(got, exp, rel=1e-3):
     """The timed path's output against the CPU oracle's on the same inputs and weights: max|err| / max|ref| and north_star's
     1e-3 criterion element by element (|err| <= rel*|ref| + rel*rms(ref); the same rule as tests/test_gpu_parity.py::check)."""
@@ -211,6 +231,61 @@ def x3_power_probe(device):
     out["note"] = ("conv2's launch without the side head, back to back: all-zero activations and weights (no switching in the matrix "
                    "pipe) against dense random ones -- the layer is limited by the chip's power budget, not by a stall")
     return out
+
+
+def read_gpu_clock_mhz(index=0):
+    """The shader clock the driver reports right now (sysfs, no subprocess: a 20-us file read between steps), or None."""
+    import glob
+    for pat in (f"/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input",):
+        for path in sorted(glob.glob(pat)):
+            try:
+                with open(path) as fh:
+                    hz = float(fh.read().strip())
+                if hz > 0:
+                    return hz / 1e6
+            except (OSError, ValueError):
+                pass
+    for path in sorted(__import__("glob").glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+        try:
+            with open(path) as fh:
+                for ln in fh:
+                    if "*" in ln:
+                        return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
+    return None
+
+
+def sustained_leg(step, seconds=5.0, min_steps=2000, block=100):
+    """The headline step back to back for >= `seconds` AND >= `min_steps` steps, timed in blocks of `block` steps (one sync per
+    block): what a deployment that runs the step continuously sees, on a part that is already warm (this leg runs after the extras)."""
+    torch.cuda.synchronize()
+    blocks, clocks = [], []
+    t_start = time.perf_counter()
+    gc.collect()
+    gc.disable()
+    try:
+        while True:
+            t0 = time.perf_counter()
+            for _ in range(block):
+                step()
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / block)
+            c = read_gpu_clock_mhz()
+            if c is not None:
+                clocks.append(c)
+            if len(blocks) * block >= min_steps and time.perf_counter() - t_start >= seconds:
+                break
+    finally:
+        gc.enable()
+    total_s = time.perf_counter() - t_start
+    n = len(blocks) * block
+    ms = [1e3 * b for b in blocks]
+    return {"steps": n, "seconds": total_s, "pairs_per_s": n / sum(blocks), "ms_per_step": 1e3 * sum(blocks) / n,
+            "first_100_ms_per_step": ms[0], "last_100_ms_per_step": ms[-1], "first_100_vs_last_100": ms[0] / ms[-1],
+            "slowest_block_ms_per_step": max(ms), "fastest_block_ms_per_step": min(ms),
+            "sclk_mhz": ({"mean": float(np.mean(clocks)), "min": float(np.min(clocks)), "max": float(np.max(clocks)),
+                          "source": "sysfs hwmon freq1_input / pp_dpm_sclk, one reading per 100-step block"} if clocks else None)}
 
 
 PREWARM_S = 0.15
@@ -276,6 +351,48 @@ def projected_coordinates(n, grid, device, res=256.0):
             t[i, 0, 2], t[i, 1, 2] = 0.5 * res - ctr[0] * t[i, 0, 0], 0.5 * res - ctr[1] * t[i, 1, 1]
     cfg = types.SimpleNamespace(x_range=xr, y_range=yr, z_range=zr, grid_resolution=list(grid))
     return GridProjector(cfg).generate(samples, P2, P3, tl, tr, device)
+
+
+_ORACLES = {}
+
+
+def local_parity(grid, F, device, precision, sample_grid=None):
+    """``parity_vs_cpu_baseline`` + ``cpu_baseline`` of a local-model config: ONE crop through the CPU oracle (bench.local_oracle: numpy
+    gather + torch-CPU trunk, every host core) and through the HIP path (the config's own arithmetic) on the same inputs and
+    weights; bev and occupancy compared on all elements.  ``sample_grid``: a smaller grid of the same model when the full one would
+    take the oracle more than ~30 s (cfg5: 17.7 TFLOP per RoI); the crops/s figure is then scaled by the voxel ratio and says so."""
+    g = tuple(sample_grid or grid)
+    key = (g, F)
+    if key not in _ORACLES:
+        _ORACLES.clear()                                   # one oracle's tensors at a time
+        o = local_oracle(g, F, 1)
+        _ORACLES[key] = {k: o[k] for k in ("lf", "rf", "gl", "gr", "bev", "occupancy", "gather_s", "trunk_s", "cores")}
+    o = _ORACLES[key]
+    m = local_model(g, F, device)
+    m.precision = "f16" if precision == "f16" else "auto"
+    lf, rf, gl, gr = (torch.from_numpy(o[k]).to(device) for k in ("lf", "rf", "gl", "gr"))
+    with torch.no_grad():
+        if precision == "f16":
+            bev, occ, _ = m.trunk_3d_f16(m.construct_voxel_f16(lf, rf, gl, gr))
+        else:
+            vs = m.construct_voxel_x3(lf, rf, gl, gr)
+            bev, occ, _ = m.trunk_3d(vs if vs is not None else m.construct_voxel(lf, rf, gl, gr))
+    sec = o["gather_s"] + o["trunk_s"]
+    scale = float(np.prod(grid)) / float(np.prod(g))
+    res = {"parity_vs_cpu_baseline": {"bev": parity_vs(bev.cpu().numpy(), o["bev"].numpy()),
+                                      "occupancy": parity_vs(occ.cpu().numpy(), o["occupancy"].numpy()),
+                                      "sample": f"1 crop {g[0]}x{g[1]}x{g[2]}, F={F}, uniform coordinates in [-8, 264) px, all elements",
+                                      "tolerance": ("fp16 STORAGE: bev max|err| <= 2e-2 rms, occupancy <= 5e-3 (tests/test_gpu_f16.py)" if precision == "f16"
+                                                    else "north_star 1e-3 relative fp32; tests/test_gpu_fullsize_oracle_local.py asserts rel_err <= 1e-4")},
+           "cpu_baseline": {"value": 1.0 / (sec * scale), "unit": "RoI-crops/s", "cores": o["cores"], "kind": "port",
+                            "sample": f"1 crop {g[0]}x{g[1]}x{g[2]}" + (f" (x{scale:.0f} voxels to the config's grid)" if scale != 1.0 else "") +
+                                      f": gather (numpy, 1 thread) {o['gather_s']:.2f}s + trunk (torch-CPU {torch.__version__}, {o['cores']} threads) {o['trunk_s']:.2f}s"}}
+    if precision == "f16":
+        ref = o["bev"].numpy().astype(np.float64)
+        res["parity_vs_cpu_baseline"]["bev"]["max_err_over_rms"] = float(np.abs(bev.cpu().numpy() - ref).max() / np.sqrt((ref * ref).mean()))
+    del m
+    torch.cuda.empty_cache()
+    return res
 
 
 def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="f32"):
@@ -373,9 +490,69 @@ def local_config(name, grid, F, crops, device, reps=20, heads=False, precision="
     return out
 
 
-def local_model(grid, F, device):
+def off_fast_path(device, reps=10):
+    """What a caller pays OFF the default inference path (one-line entries): GroupNorm models
+    (``convbn_3d(..., gn=True)``, reference submodule.py:49) and ``downsample != 1`` run on the fp32-MFMA kernels / the
+    materialised volume, fp64 exists for the cost-volume op only (as in the reference: BuildCostVolume_cuda.cu dispatches float/double)."""
+    from snvc_amd.extension.build_cost_volume import build_cost_volume
+    from snvc_amd.models import submodule as S_
+    from snvc_amd.models.stereo_volume import GlobalStack
+    out = {}
+    with torch.no_grad():
+        # 1. the local trunk with GroupNorm (statistics of each conv result: no folded affine, no a-priori range -> fp32-MFMA kernels)
+        grid, F, crops = (32, 128, 192), 32, 2
+        pl, pr = projected_coordinates(crops, grid, device)
+        lf, rf = (torch.from_numpy(a).to(device) for a in local_inputs(grid, F, crops, 5)[:2])
+        for tag, gn in (("released_trunk_groupnorm", True), ("released_trunk_batchnorm_fp32_mfma", False)):
+            m = local_model(grid, F, device, gn=gn)
+            m.precision = "f32" if not gn else "auto"
+            b = S_._ROUTES["x3_local_trunk"]
+            ms, _ = timed_ms(lambda: m.trunk_3d(m.construct_voxel(lf, rf, pl, pr)), reps, 3)
+            out[tag] = {"ms_per_crop": ms / crops, "crops_per_s": 1e3 * crops / ms, "split_mode": S_._ROUTES["x3_local_trunk"] > b}
+            del m
+        # 2. the global stack with GroupNorm
+        left, right, shift = make_inputs(0, device)
+        g = GlobalStack(C, gn=True)
+        g.load_state_dict(seeded_state(g))
+        g.eval().to(device)
+        b = S_._ROUTES["x3_tail"]
+        ms, _ = timed_ms(lambda: g.forward_pair(left, right, shift, 1), reps, 3)
+        out["cfg2_groupnorm"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms, "split_mode": S_._ROUTES["x3_tail"] > b,
+                                 "note": "GlobalStack(gn=True): every norm needs its conv result's statistics (two passes over each activation)"}
+        del g
+        torch.cuda.empty_cache()
+        # 3. downsample = 2: features at twice the resolution, the volume sampled at every second pixel (materialised volume)
+        g = GlobalStack(C)
+        g.load_state_dict(seeded_state(g))
+        g.eval().to(device)
+        r = np.random.default_rng(3)
+        l2 = torch.from_numpy(r.standard_normal((1, C, 2 * H, 2 * W)).astype(np.float32)).to(device)
+        r2 = torch.from_numpy(r.standard_normal((1, C, 2 * H, 2 * W)).astype(np.float32)).to(device)
+        ms, _ = timed_ms(lambda: g(build_cost_volume(l2, r2, shift, 2)), reps, 3)
+        out["cfg2_downsample_2"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms,
+                                    "note": "model(build_cost_volume(left [1,32,192,624], right, shift, 2)): same volume shape as cfg2, "
+                                            "the eager op + conv1 over all 64 channels (the fused first layer is built for downsample 1)"}
+        del g, l2, r2
+        torch.cuda.empty_cache()
+        # 4. fp64: the cost-volume op (the 3D stack has no fp64 kernels; neither does a user of the reference get one from cuDNN at speed)
+        ld, rd = left.double(), right.double()
+        ms, vol = timed_ms(lambda: ops_cost_volume(ld, rd, shift.double()), 5, 2)
+        out["fp64_cost_volume"] = {"ms": ms, "GBps": 2 * CV_BYTES / (ms * 1e-3) / 1e9, "frac_hbm": 2 * CV_BYTES / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "note": "build_cost_volume in float64 (2.96 GB written); 3D convolutions are float32-only: a float64 volume "
+                                           "raises in the stack"}
+        del vol, ld, rd
+        torch.cuda.empty_cache()
+    return out
+
+
+def ops_cost_volume(left, right, shift):
+    from snvc_amd import ops
+    return ops.cost_volume_forward(left, right, shift, 1)
+
+
+def local_model(grid, F, device, gn=False):
     from snvc_amd.models.vernier import VernierScale
-    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False,
+    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=gn,
                                 grid_resolution=[32, grid[1], 192], resolution=(256, 256),
                                 x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
     cfg.hrfeat = types.SimpleNamespace(output_channel=F, name="identity")
@@ -383,6 +560,39 @@ def local_model(grid, F, device):
     m = VernierScale(cfg)
     m.load_state_dict(seeded_state(m))
     return m.eval().to(device)
+
+
+def cfg3_crop_inputs(i, grid, F, fh=64, fw=64):
+    """Crop i of the cfg3 job, seeded per crop: every rank could draw any crop, each draws only its own."""
+    v = grid[0] * grid[1] * grid[2]
+    r = np.random.default_rng(4321 + i)
+    return (r.standard_normal((F, fh, fw)).astype(np.float32), r.standard_normal((F, fh, fw)).astype(np.float32),
+            r.uniform(-8, 264, (2, v)).astype(np.float32), r.uniform(-8, 264, (2, v)).astype(np.float32))
+
+
+def cfg3_shard_inputs(lo, hi, grid, F, device, fh=64, fw=64):
+    """This rank's crops [lo, hi) as four stacked tensors (empty tensors of the right trailing shape for an empty shard)."""
+    v = grid[0] * grid[1] * grid[2]
+    mine = [cfg3_crop_inputs(i, grid, F, fh, fw) for i in range(lo, hi)]
+    return tuple(torch.from_numpy(np.stack([c[k] for c in mine])).to(device) if mine else torch.empty((0,) + s_, device=device)
+                 for k, s_ in enumerate(((F, fh, fw), (F, fh, fw), (2, v), (2, v))))
+
+
+def cfg3_shard_step(m, lf, rf, gl, gr, per_call, total, grid, gather=True):
+    """One step of a rank's shard: gather + trunk on its crops, `per_call` at a time, NO data-path collective; the per-crop occupancy
+    volumes are optionally all-gathered into dim-0 order at the end (DataParallel's gather).  `m`: anything with construct_voxel_x3 /
+    construct_voxel / trunk_3d (the model; a stub in tests/test_parallel_gloo.py)."""
+    from snvc_amd import parallel as P
+    occ = []
+    n = lf.shape[0]
+    for a in range(0, n, per_call):
+        b = min(a + per_call, n)
+        vox = m.construct_voxel_x3(lf[a:b], rf[a:b], gl[a:b], gr[a:b])      # split mode: the gather writes the (hi, lo) pair
+        if vox is None:
+            vox = m.construct_voxel(lf[a:b], rf[a:b], gl[a:b], gr[a:b])
+        occ.append(m.trunk_3d(vox)[1])
+    occ = torch.cat(occ) if occ else torch.empty((0, 1) + tuple(grid), device=lf.device)
+    return P.gather_outputs(occ, total) if gather else occ
 
 
 def run_cfg3(rank, world, device, dist, steps, warmup, barrier, total=64, per_call=8, gather=True):
@@ -394,29 +604,11 @@ def run_cfg3(rank, world, device, dist, steps, warmup, barrier, total=64, per_ca
     from snvc_amd import parallel as P
     grid, F = (96, 96, 96), 32
     m = local_model(grid, F, device)
-    v = grid[0] * grid[1] * grid[2]
     lo, hi = P.shard_range(total, rank, world)
-
-    def crop_inputs(i):     # seeded per crop: every rank could draw any crop, each draws only its own
-        r = np.random.default_rng(4321 + i)
-        return (r.standard_normal((F, 64, 64)).astype(np.float32), r.standard_normal((F, 64, 64)).astype(np.float32),
-                r.uniform(-8, 264, (2, v)).astype(np.float32), r.uniform(-8, 264, (2, v)).astype(np.float32))
-    mine = [crop_inputs(i) for i in range(lo, hi)]
-    lf, rf, gl, gr = (torch.from_numpy(np.stack([c[k] for c in mine])).to(device) if mine else
-                      torch.empty((0,) + s_, device=device) for k, s_ in enumerate(((F, 64, 64), (F, 64, 64), (2, v), (2, v))))
-    del mine
+    lf, rf, gl, gr = cfg3_shard_inputs(lo, hi, grid, F, device)
 
     def step():
-        occ = []
-        for a in range(0, hi - lo, per_call):
-            b = min(a + per_call, hi - lo)
-            vox = m.construct_voxel_x3(lf[a:b], rf[a:b], gl[a:b], gr[a:b])      # split mode: the gather writes the (hi, lo) pair
-            if vox is None:
-                vox = m.construct_voxel(lf[a:b], rf[a:b], gl[a:b], gr[a:b])
-            bev, oc = m.trunk_3d(vox)[:2]
-            occ.append(oc)
-        occ = torch.cat(occ) if occ else torch.empty((0,) + grid, device=device)
-        return P.gather_outputs(occ, total) if gather else occ
+        return cfg3_shard_step(m, lf, rf, gl, gr, per_call, total, grid, gather)
 
     with torch.no_grad():
         gc.collect()
@@ -445,6 +637,8 @@ def run_cfg3(rank, world, device, dist, steps, warmup, barrier, total=64, per_ca
            "step_tflops_algorithmic": total * 1907.3e9 / (elapsed / steps) / 1e12,
            "outputs_gathered": "occupancy [64,96,96,96] all-gathered per step" if (gather and world > 1) else "none (one rank)",
            "steps": steps}
+    print(json.dumps({"rank_record_cfg3": {"rank": rank, "device": str(device), "world": world, "crops_this_rank": hi - lo,
+                                           "steps": steps, "ms_per_step_max_over_ranks": res["ms_per_step"]}}), file=sys.stderr, flush=True)
     del m, lf, rf, gl, gr, out
     torch.cuda.empty_cache()
     return res
@@ -595,6 +789,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the `configs` / `train` legs")
     ap.add_argument("--breakdown", action="store_true", help="per-layer timing on stderr (extra untimed pass)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 5 s sustained-rate leg")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0)
+    ap.add_argument("--sustained-steps", type=int, default=2000)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -679,7 +876,7 @@ def main():
     model.eval().to(device)
     left, right, shift = make_inputs(rank, device)
 
-    outs = {}
+    outs, local_elapsed = {}, {}
 
     def run(factored, sheared=True, commuted=True, tag="value", arithmetic=None):
         """W warm-up + K timed steps; returns (seconds for the K steps, mean ms of the "conv1" bracket, of the "volume"
@@ -706,6 +903,8 @@ def main():
                 # events go to torch's current stream == the stream the kernels are launched on
                 out = model.forward_pair(left, right, shift, 1, factored=factored, timing=ev[i], sheared=sheared, commuted=commuted,
                                          arithmetic=arithmetic)
+            torch.cuda.synchronize()
+            local_elapsed[tag] = time.perf_counter() - t0     # this rank's own K steps (before it waits for the others)
             barrier()
             elapsed = time.perf_counter() - t0
             gc.enable()
@@ -731,6 +930,15 @@ def main():
     elapsed, expand_ms, shear_prep_ms, conv2_ms = run(True)
     sheared_taken = S_._ROUTES["sheared_first_conv"] > routes0
     x3_taken = S_._ROUTES["x3_tail"] > routes_x3          # conv2 + hourglass on the split-mode (f16x3) kernels
+    # what reading the split-mode overflow flag INSIDE the call costs (r5: the default): the same leg with the flag only posted
+    model.overflow_check = "deferred"
+    elapsed_deferred = run(True, tag="deferred_overflow_check")[0]
+    model.check_overflow()
+    model.overflow_check = "call"
+    # ... and r4's tail (conv5 -> fp32 `post` -> the one-channel transposed layer as its own VALU kernel) for comparison
+    model.fused_tail = False
+    elapsed_tail2 = run(True, tag="two_launch_tail")[0]
+    model.fused_tail = True
     # the same step with conv2 and the hourglass on the fp32-MFMA kernels (r1-r3's arithmetic: Winograd F(4,3), v_mfma_f32_32x32x2_f32)
     elapsed_f32, expand_ms_f32, _, conv2_ms_f32 = run(True, tag="fp32_mfma", arithmetic="fp32")
     elapsed_gen, warp_expand_ms, warp_prep_ms, _ = run(True, sheared=False, tag="general_shift")      # any shift array: warp after convolution
@@ -770,13 +978,21 @@ def main():
     # HBM bytes per launch: PMC counters cannot be read from inside this process; separate rocprofv3 --pmc
     # passes (FETCH_SIZE, WRITE_SIZE, gfx950 correction) are committed under profiles/
     traffic, traffic_src, traffic_conv2 = None, None, None
-    traffic_x3 = None
-    for rel in ("profiles/r4/traffic.json", "profiles/r3/traffic.json", "profiles/r2/traffic.json", "profiles/r1/traffic.json"):
+    traffic_x3, traffic_x3_rel, traffic_stale = None, None, None
+    for rel in ("profiles/r5/traffic.json", "profiles/r4/traffic.json", "profiles/r3/traffic.json", "profiles/r2/traffic.json", "profiles/r1/traffic.json"):
         try:
             with open(os.path.join(ROOT, rel)) as fh:
                 tj = json.load(fh)
             if traffic_x3 is None:
-                traffic_x3 = tj.get("layers", {}).get("x3_conv2", {}).get("hbm_bytes_corrected")
+                ent = tj.get("layers", {}).get("x3_conv2", {})
+                traffic_x3 = ent.get("hbm_bytes_corrected")
+                if traffic_x3 is not None:
+                    traffic_x3_rel = rel
+                    # the counters belong to the kernel text they were collected on: a changed kernel voids them
+                    then, now = ent.get("kernel_source_sha256_16"), kernel_source_hash(*X3Q_SOURCE)
+                    if then is None or then != now:
+                        traffic_stale = (f"{rel}: collected on kernel source {then}, the kernel is now {now}: re-run tools/pmc_r5_traffic.sh "
+                                         "+ tools/make_traffic_json.py r5")
             if traffic_conv2 is None:
                 traffic_conv2 = tj.get("layers", {}).get("conv2_side", {}).get("hbm_bytes_corrected")
             if traffic is None:
@@ -788,10 +1004,15 @@ def main():
     if sheared_taken and traffic_conv2 is not None:
         traffic_src = "profiles/r3/traffic.json, layer conv2_side (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
     if x3_taken:
-        traffic_conv2 = traffic_x3
-        traffic_src = ("profiles/r4/traffic.json, layer x3_conv2 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-                       if traffic_x3 is not None else None)
+        traffic_conv2 = traffic_x3 if traffic_stale is None else None
+        traffic_src = (f"{traffic_x3_rel}, layer x3_conv2 (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; kernel source hash checked)"
+                       if traffic_conv2 is not None else traffic_stale)
 
+    # every rank (not only rank 0) leaves one line on stderr: a multi-GPU run can be audited rank by rank
+    print(json.dumps({"rank_record": {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(device),
+                                      "world_joined": joined, "steps": args.steps, "ms_per_step_this_rank": 1e3 * local_elapsed["value"] / args.steps,
+                                      "ms_per_step_max_over_ranks": 1e3 * elapsed / args.steps,
+                                      "split_mode": bool(x3_taken), "sclk_mhz": read_gpu_clock_mhz()}}), file=sys.stderr, flush=True)
     x3_state = model.__dict__.get("_snvc_x3")
     x3_overflow = int(x3_state["flag"].item()) if x3_state is not None else None       # 0: no value was clamped to half's range
     x3_exponents = dict(x3_state["exp"]) if x3_state is not None else None
@@ -901,6 +1122,20 @@ def main():
                                 "achieved": CV_BYTES / (cv_ms * 1e-3) / 1e9, "frac": CV_BYTES / (cv_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "bytes_per_launch": CV_BYTES, "avg_launch_ms": cv_ms},
             },
+            "overflow_check": {
+                "note": "split mode clamps a value beyond the range its BatchNorm parameters promise and raises a device flag.  `value` reads "
+                        "that flag INSIDE the call (4-byte copy queued behind the last layer that can clamp, waited for after the rest "
+                        "of the call is queued) and redoes a flagged call on the fp32-MFMA kernels: no clamped result is ever returned "
+                        "(tests/test_gpu_overflow.py).  `deferred` = the same leg with the flag only posted (r4's behaviour)",
+                "checked_ms_per_step": 1e3 * elapsed / args.steps, "deferred_ms_per_step": 1e3 * elapsed_deferred / args.steps,
+                "cost_ms_per_step": 1e3 * (elapsed - elapsed_deferred) / args.steps,
+                "redone_calls": int(S_._ROUTES["x3_overflow_redo"]),
+            },
+            "two_launch_tail": {
+                "note": "same step with r4's tail: conv5 writes `post` (64 channels, fp32), deconv3d_cout1_kernel reads it; `value` contracts "
+                        "conv5's result with the folded tail's 27 taps in conv5's epilogue (snvc_f16x3_deconv3d_tail_forward) + snvc_deconv_tail_gather",
+                "value": world * args.steps / elapsed_tail2, "ms_per_step": 1e3 * elapsed_tail2 / args.steps,
+            },
             "fp32_mfma": {
                 "note": "same step, same entry point, with conv2 and the hourglass on the fp32-MFMA kernels (forward_pair(..., arithmetic='fp32'): "
                         "Winograd F(4,3) / polyphase kernels on v_mfma_f32_32x32x2_f32 -- rounds 1-3's arithmetic)",
@@ -963,6 +1198,12 @@ def main():
                     cfgs[name] = local_config(name, grid, F, crops, device, heads=heads, precision=prec)
                 except Exception as e:  # an extra must never take the headline down with it
                     cfgs[name] = {"error": f"{type(e).__name__}: {e}"}
+                if rank == 0 and not args.no_cpu_baseline and "error" not in cfgs[name]:
+                    try:        # the same model on the oracle's inputs: whole-tensor parity + the CPU rate beside the GPU rate
+                        cfgs[name].update(local_parity(grid, F, device, prec, sample_grid=(48, 80, 80) if grid == (80, 160, 160) else None))
+                    except Exception as e:
+                        cfgs[name]["parity_vs_cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+            _ORACLES.clear()
             try:        # BASELINE configs[2] as the N > 1 runs shard it (`--config cfg3`), here all 64 crops on one rank
                 cfgs["cfg3_64crops_sharded"] = run_cfg3(rank, world, device, dist, 2, 1, barrier)
             except Exception as e:
@@ -985,6 +1226,10 @@ def main():
             except Exception as e:
                 cfgs["cfg4_train_step"]["dominant_error"] = f"{type(e).__name__}: {e}"
             line["configs"] = cfgs
+            try:
+                line["off_fast_path"] = off_fast_path(device)
+            except Exception as e:
+                line["off_fast_path"] = {"error": f"{type(e).__name__}: {e}"}
             g3 = cfgs.get("cfg3_crops_96", {}).get("gather_projected")
             if g3:      # north_star's ">= 60 % HBM roofline on the warp/gather": the gather beside the cost-volume builders
                 line["roofline_hbm"]["gather"] = {
@@ -993,6 +1238,28 @@ def main():
                     "bytes_per_launch": cfgs["cfg3_crops_96"]["gather_bytes_algorithmic"]}
             if rccl_note:
                 line["train"]["rccl"] = rccl_note
+    if not args.no_sustained:
+        # the headline step again, back to back for >= 5 s and >= 2000 steps, AFTER the extras (a warm part): the sustained rate
+        model = GlobalStack(C)
+        model.load_state_dict(seeded_state(model))
+        model.eval().to(device)
+        with torch.no_grad():
+            for _ in range(3):
+                model.forward_pair(left, right, shift, 1)
+            sus = sustained_leg(lambda: model.forward_pair(left, right, shift, 1), args.sustained_seconds, args.sustained_steps)
+        del model
+        torch.cuda.empty_cache()
+        if dist is not None and world > 1:      # whole-job rate: the slowest rank's
+            t = torch.tensor([sus["pairs_per_s"]], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            sus["pairs_per_s_slowest_rank"] = float(t.item())
+            sus["pairs_per_s"] = world * float(t.item())
+        print(json.dumps({"rank_record_sustained": dict(sus, rank=rank)}), file=sys.stderr, flush=True)
+        if rank == 0:
+            sus["note"] = ("`value` is the driver's 20-step window after a 0.15 s pre-warm; this is the same step for >= 5 s on a part already "
+                           "warm from the other legs -- what a deployment running the step continuously sees")
+            sus["vs_value"] = sus["pairs_per_s"] / line["value"]
+            line["sustained"] = sus
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             oracle_out = {}

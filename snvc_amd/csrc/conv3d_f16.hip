@@ -352,6 +352,8 @@ conv3d_f16_kernel(const F16Args a_) {
                 for (int i = 0; i + 1 < PF; ++i)
 #pragma unroll
                     for (int m = 0; m < MA; ++m) q[i][m] = q[i + 1][m];
+                // (r5, measured and dropped: not fetching w_lo for the steps of a lo pass -- they multiply w_hi alone.  The branch
+                // around two of the four loads costs the counted vmcnt waits of the ring: hg conv1 0.345 -> 0.79 ms.)
 #pragma unroll
                 for (int m = 0; m < MA; ++m) q[PF - 1][m] = wq[m * 64];
                 wq += MA * 64;
@@ -1252,6 +1254,12 @@ using F16K3S2X = F16Cfg<3, 3, 3, 2, 1, 2, 2, 4, 1, 1, false, 2, 1, 3>;
 // one parity class of ConvTranspose3d(k3,s2,p1,op1): 2x2x2 box taps, both planes resident, double-buffered
 // (first forms, all 8 box taps with zero weights where a class has none: KCG = 1 double-buffered 0.255 ms, KCG = 2 0.284 ms on hg conv5)
 using F16DCX  = F16Cfg<2, 2, 2, 1, 1, 2, 4, 4, 2, 1, false, 2, 1, 2, true>;
+// r5, SNVC_ALGO_X3_SMALL on the stride-2 and transposed split layers: the hourglass's quarter-resolution level (cfg2: 48x24x78) gives
+// a 2x4x32 / 4x4x32 tiling 432 / 216 tiles -- fewer workgroups than the chip has slots, each one a serial chain of 16 / 4 single-
+// buffered fills whose latency nothing hides.  Half-height tiles: twice the workgroups, 64 accumulator registers instead of 128
+// (three workgroups per CU), images of 28 KB (stride 2, per plane) / 32 KB (transposed, both planes).
+using F16K3S2XT = F16Cfg<3, 3, 3, 2, 1, 2, 1, 4, 1, 1, false, 3, 1, 3>;
+using F16DCXT   = F16Cfg<2, 2, 2, 1, 1, 2, 2, 4, 2, 1, false, 3, 1, 2, true>;
 
 // split forms of the local trunk's other layer kinds (snvc/models/vernier.py:249-278): 1x1x1 (two channel groups per MFMA, both
 // planes resident), 5^3 / dilated 5^3 (sub-grid classes) / 7^3 (planes serial: their single-plane images are 37 / 41 / 61 KB),
@@ -1263,7 +1271,7 @@ using F16K5D2X = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2, 3>;
 using F16K7X   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 3>;
 using F16DCXN  = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 1, false, 3, 1, 2, true>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FK5D2QN, FK7QN, FK5Q, FK5QN, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FK5D2QN, FK7QN, FK5Q, FK5QN, FK3S2XT, FDCXT, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
@@ -1291,7 +1299,7 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                 return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: transposed layers: k3,s2,p1,op1 with Cout % 32 == 0");
             if (d.Dout != 2 * d.Din || d.Hout != 2 * d.Hin || d.Wout != 2 * d.Win)
                 return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d: transposed output must be 2x the input");
-            p = d.Cout % 64 == 0 ? plan_from<F16DCX>(FDCX) : plan_from<F16DCXN>(FDCXN);
+            p = d.Cout % 64 == 0 ? ((d.algo & SNVC_ALGO_X3_SMALL) ? plan_from<F16DCXT>(FDCXT) : plan_from<F16DCX>(FDCX)) : plan_from<F16DCXN>(FDCXN);
         } else {
             if (d.pad != d.dilation * (d.ksize - 1) / 2)
                 return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: pad must equal dilation*(ksize-1)/2");
@@ -1305,7 +1313,7 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                 p = plan_from<F16K3X>(FK3XH);
             } else if (key == 321) {
                 if (d.Cout % 64 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: stride-2 layers need Cout % 64 == 0");
-                p = plan_from<F16K3S2X>(FK3S2X);
+                p = (d.algo & SNVC_ALGO_X3_SMALL) ? plan_from<F16K3S2XT>(FK3S2XT) : plan_from<F16K3S2X>(FK3S2X);
             } else {
                 if (d.Cout % 32 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: Cout % 32 == 0");
                 if ((d.algo & SNVC_ALGO_X3_Q16) && (key == 511 || key == 512 || key == 711)) {      // 16x16x32 form, planes serial
@@ -1784,7 +1792,9 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
             else launch_f16<F16K3XT, 0>(a, grid, st);
             break;
         case FK3S2X: SNVC_X3_LAUNCH(F16K3S2X); break;
+        case FK3S2XT: SNVC_X3_LAUNCH(F16K3S2XT); break;
         case FDCX: if (tail) launch_f16<F16DCX, 4>(a, grid, st); else SNVC_X3_LAUNCH(F16DCX); break;
+        case FDCXT: if (tail) launch_f16<F16DCXT, 4>(a, grid, st); else SNVC_X3_LAUNCH(F16DCXT); break;
         case FDCXN: if (tail) launch_f16<F16DCXN, 4>(a, grid, st); else SNVC_X3_LAUNCH(F16DCXN); break;
         case FK1X: SNVC_X3_LAUNCH(F16K1X); break;
         case FK5X: SNVC_X3_LAUNCH(F16K5X); break;

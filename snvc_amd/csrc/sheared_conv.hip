@@ -1098,15 +1098,18 @@ sheared_expand_split_kernel(const float *__restrict__ g, const float *__restrict
         bi[c] = (scale && co < C) ? bias[co] : 0.0f;
         pl[c] = (planes && co < C) ? planes[(((n * C + co) * 3 + 1) * (int64_t)H + h) * W + w] : 0.0f;      // interior class
     }
-    bool clamped = false;
+    // per element: one add, one FMA, ONE v_med3 (ReLU and the clamp to half's range together), one running max for the overflow
+    // flag (compared once at the end), three conversions and a subtraction -- r4's form (max, min + max, a compare chain per
+    // element) spent ~13 VALU instructions where this spends 8; the pass is co-limited by them (54 % of HBM in the step)
+    float vmax = 0.0f;
+    const float lo_bound = relu ? 0.0f : -65504.0f;
     auto emit = [&](int d, const float (&raw)[8], const float (&pe)[8]) {
         h8v hi, lo;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            float t = (raw[c] + pe[c]) * sc[c] + bi[c];
-            if (relu) t = __builtin_fmaxf(t, 0.0f);
-            const float tc = __builtin_fminf(__builtin_fmaxf(t, -65504.0f), 65504.0f);
-            clamped = clamped || (tc != t && t == t);
+            const float t = __builtin_fmaf(raw[c] + pe[c], sc[c], bi[c]);
+            const float tc = __builtin_amdgcn_fmed3f(t, lo_bound, 65504.0f);
+            vmax = __builtin_fmaxf(vmax, __builtin_fabsf(tc));      // what is stored (|x| is a source modifier); a NaN never raises the flag
             hi[c] = (_Float16)tc;
             lo[c] = (_Float16)(tc - (float)hi[c]);
         }
@@ -1146,7 +1149,7 @@ sheared_expand_split_kernel(const float *__restrict__ g, const float *__restrict
         }
         emit(d, raw, pl);
     }
-    if (clamped && overflow) atomicOr(overflow, 1);
+    if (vmax >= 65504.0f && overflow) atomicOr(overflow, 1);
 }
 
 // warped_expand_win_kernel with the result written as a split C8 pair (see sheared_expand_split_kernel): a thread = one voxel

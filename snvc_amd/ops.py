@@ -1079,6 +1079,8 @@ def voxel_gather_forward_split(left, right, l_pts, r_pts, resolution, mul_dev) -
 
 X3_Q16 = [True]        # False: the 32x32x16 kernel forms everywhere (rounds up to mid r4)
 X3_Q16_K5 = [True]     # ... and the plain 5^3 layers (quads over all 125 taps)
+X3_Q16_MIN_JOBS = [256]   # 3x3x3 layers: (tile, 32-channel block) jobs from which the 16x16x32 form is picked (r4: 1024; hg conv4 at cfg2 --
+#                           432 jobs -- 61.6 us against 74.5 for the 2x4x32-tile 32x32x16 form, tools/time_hg.py)
 
 
 class Conv3dLayerF16:
@@ -1225,6 +1227,9 @@ def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) ->
     return y
 
 
+X3_SMALL_BELOW = {"stride2": 1024, "transposed": 4096}      # workgroups below which the half-height tile forms are picked (tools flip these)
+
+
 class Conv3dLayerX3:
     """nn.Conv3d(k3, p1, stride 1 | 2) / nn.ConvTranspose3d(k3, s2, p1, op1) prepared for the split-mode kernels
     (snvc_f16x3_conv3d_*): the fp32 contraction at fp32 accuracy on the half pipe.  The weights are packed as (hi, lo) of
@@ -1278,10 +1283,18 @@ class Conv3dLayerX3:
             tiles5 = n * -(-out_sp[0] // 4) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32) * (self.cout // 32)
             q16 = X3_Q16[0] and split_out and tiles5 >= 512 and (self.ksize == 7 or self.dilation == 2 or X3_Q16_K5[0])
             return _lib.ALGO_X3_Q16 if q16 else 0
+        if self.forced_algo is None and self.ksize == 3 and self.cout % 64 == 0 and (self.stride == 2 or self.transposed):
+            # half-height tiles when the launch would not fill the chip's 512 workgroup slots a few times over (r5; the hourglass's
+            # quarter-resolution level): stride 2 counts 2x4x32 output tiles, a transposed layer 8 classes of 4x4x32 input tiles
+            if self.transposed:
+                wgs = 8 * n * -(-out_sp[0] // 8) * -(-out_sp[1] // 8) * -(-out_sp[2] // 64)
+                return _lib.ALGO_X3_SMALL if wgs < X3_SMALL_BELOW["transposed"] else 0
+            wgs = n * -(-out_sp[0] // 2) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32)
+            return _lib.ALGO_X3_SMALL if wgs < X3_SMALL_BELOW["stride2"] else 0
         if self.forced_algo is not None or self.stride != 1 or self.transposed or self.ksize != 3 or self.cout == 1:
             return self.algo
         tiles = n * -(-out_sp[0] // 4) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32)
-        if plain and X3_Q16[0] and self.cout % 32 == 0 and tiles * (self.cout // 32) >= 1024:
+        if plain and X3_Q16[0] and self.cout % 32 == 0 and tiles * (self.cout // 32) >= X3_Q16_MIN_JOBS[0]:
             return _lib.ALGO_X3_Q16         # v_mfma_f32_16x16x32_f16: ~15 % faster under the chip's power limit (conv2 0.94 -> 0.81 ms)
         if self.cout % 64 == 0 and tiles * (self.cout // 64) >= 1024:
             return _lib.ALGO_X3_SERIAL      # 64-channel blocks: the serial-plane form measures 6 % faster (0.424 vs 0.453 ms, hg conv2)
@@ -1390,6 +1403,7 @@ class Conv3dLayerX3:
             if tuple(residual.shape) != (n, 2, self.cout // 8) + out_sp + (8,):
                 raise RuntimeError("residual must have the layer's output shape (split C8)")
         sc, bi = self.folded(scale, bias, x_exp, out_exp)
+        self.algo = self._pick_form(n, out_sp)
         packed = self._pack(self.algo)
         if n == 0:
             return out

@@ -120,7 +120,13 @@ def all_reduce_gradients(params: Iterable[torch.nn.Parameter], average: bool = T
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in plist] + [mask])
     nmask = len(plist)
     _reduce_flat(flat, w, False, algorithm)
-    has = flat[-nmask:].tolist()          # one small device -> host copy per step
+    # Who received a gradient matters only to a rank that is MISSING one (an unused head, a skipped branch): it has to learn
+    # whether some other rank had it.  A rank whose parameters all carry gradients -- every step of an ordinary training run --
+    # takes the reduced values as they are and never waits for the device (r4 read the flags back on every step: a sync).
+    if all(p.grad is not None for p in plist):
+        has = [1.0] * nmask
+    else:
+        has = flat[-nmask:].tolist()      # one small device -> host copy, only on ranks with a missing gradient
     if average:
         flat[:-nmask] /= w
     off = 0

@@ -391,19 +391,31 @@ def test_split_mode_local_trunk_layer_kinds_vs_float64(case):
     check(ops.from_split(yr, 2).cpu().numpy(), (ref + res.double().cpu()).numpy(), TIGHT, f"{case}: residual with its own exponent")
 
 
-@pytest.mark.parametrize("case", ["k3_32_32", "k3_64_64", "k3_32_64", "k3s2_32_64", "k3s2_64_64", "deconv_64_64", "k3_32_32_odd"])
+@pytest.mark.parametrize("case", ["k3_32_32", "k3_64_64", "k3_32_64", "k3s2_32_64", "k3s2_64_64", "deconv_64_64", "k3_32_32_odd",
+                                  "k3s2_32_64_small", "k3s2_64_64_small", "deconv_64_64_small", "k3s2_64_64_small_odd", "deconv_64_64_small_odd"])
 def test_split_mode_layers_vs_float64(case):
-    from snvc_amd import ops
+    from snvc_amd import _lib as L_, ops
     from test_gpu_parity import TIGHT, check
-    torch.manual_seed(hash(case) % 1000)
+    torch.manual_seed(len(case) * 7 + ord(case[-1]))
+    # "_small": the half-height tile forms of the stride-2 / transposed layers (SNVC_ALGO_X3_SMALL, r5: what a launch with few
+    # workgroups picks); the others force the full-height forms (algo 0), whatever the launch size
+    small = "_small" in case
     cin, cout, stride, transposed, shape = {
         "k3_32_32": (32, 32, 1, False, (8, 12, 40)), "k3_64_64": (64, 64, 1, False, (8, 8, 36)), "k3_32_64": (32, 64, 1, False, (5, 9, 33)),
         "k3s2_32_64": (32, 64, 2, False, (8, 12, 72)), "k3s2_64_64": (64, 64, 2, False, (6, 10, 42)),
-        "deconv_64_64": (64, 64, 2, True, (4, 6, 20)), "k3_32_32_odd": (32, 32, 1, False, (3, 5, 31))}[case]
+        "deconv_64_64": (64, 64, 2, True, (4, 6, 20)), "k3_32_32_odd": (32, 32, 1, False, (3, 5, 31)),
+        "k3s2_32_64_small": (32, 64, 2, False, (8, 12, 72)), "k3s2_64_64_small": (64, 64, 2, False, (6, 10, 42)),
+        "deconv_64_64_small": (64, 64, 2, True, (4, 6, 20)), "k3s2_64_64_small_odd": (64, 64, 2, False, (7, 9, 67)),
+        "deconv_64_64_small_odd": (64, 64, 2, True, (3, 5, 35))}[case]
+    forced = None if (stride == 1 and not transposed) else (L_.ALGO_X3_SMALL if small else 0)
     x = torch.relu(torch.randn(2, cin, *shape, device=dev())) * 2.0 + 0.01 * torch.randn(2, cin, *shape, device=dev())
     w = torch.randn((cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3), device=dev()) * np.sqrt(2.0 / (cin * 27))
     scale, bias = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.3
-    layer = ops.Conv3dLayerX3(w, 3, stride, 1, 1, transposed)
+    layer = ops.Conv3dLayerX3(w, 3, stride, 1, 1, transposed, algo=forced)
+    if forced is not None:      # ... and what the launch-size rule picks by itself at this size is the half-height form
+        auto = ops.Conv3dLayerX3(w, 3, stride, 1, 1, transposed)
+        auto(ops.to_split(x, 2), 2, scale, bias, flags=ops.EPI_RELU, to_f32=True)
+        assert auto.algo == L_.ALGO_X3_SMALL
     if stride == 1 and not transposed:      # every kernel form of a stride-1 layer gives the same values (same MFMA order per output)
         from snvc_amd import _lib
         xs0 = ops.to_split(x, 2)

@@ -42,8 +42,9 @@ def test_tail_gather_is_the_scatter_half_of_a_one_channel_transposed_layer(shape
     check(got.cpu().numpy(), (ref - b - res).astype(np.float32), 1e-6, f"tail gather {shape} x{n}, no bias / residual")
 
 
+@pytest.mark.parametrize("form", ["full", "small"])
 @pytest.mark.parametrize("case", ["64_64", "64_64_ragged", "64_32", "32_64_odd"])
-def test_split_transposed_layer_with_tail_projection_vs_float64(case):
+def test_split_transposed_layer_with_tail_projection_vs_float64(case, form):
     """conv5 (+ folded BatchNorm + pre, ReLU) with its result contracted in the epilogue, then the gather: against the float64
     evaluation of relu(bn(deconv(x)) + pre) followed by the float64 one-channel transposed layer, at the exact-fp32 tolerance;
     and T itself against the to_f32 form of the same layer (what r4 stored) contracted in float64."""
@@ -58,7 +59,8 @@ def test_split_transposed_layer_with_tail_projection_vs_float64(case):
     out_sp = tuple(2 * s for s in shape)
     pre = torch.relu(torch.randn(n, cout, *out_sp, device=dev()))
     wt = torch.randn(cout, 1, 3, 3, 3, device=dev()) * 0.2
-    layer = ops.Conv3dLayerX3(w, 3, 2, 1, 1, True)
+    from snvc_amd import _lib as L_
+    layer = ops.Conv3dLayerX3(w, 3, 2, 1, 1, True, algo=L_.ALGO_X3_SMALL if form == "small" else 0)      # 2x4x32 / 4x4x32 input tiles
     tail = ops.TailWeightsX3(wt)
     x_exp, e_y, e_res = 3, 2, 4
     xs, rs = ops.to_split(x, x_exp), ops.to_split(pre, e_res)

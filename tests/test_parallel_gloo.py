@@ -112,3 +112,71 @@ def test_shard_range_partitions_exactly():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] as bench.py shards it (run_cfg3 -> cfg3_shard_inputs / cfg3_shard_step), rehearsed at WORLD SIZE 8 on the CPU
+# with a stub in place of the HIP model: 64 crops (8 per rank) and an uneven 65 (rank 0 takes 9).  What is checked is the host logic
+# an 8-GPU run depends on and no 1-GPU box can show: every crop is evaluated exactly once, by the rank that owns it, the gathered
+# result is in dim-0 order and identical on all ranks, and a rank with per_call not dividing its shard still covers it.
+# ------------------------------------------------------------------------------------------------------------------------------
+class _StubModel:
+    """construct_voxel / trunk_3d with the model's shapes, computed on the CPU: occupancy[i] is a function of crop i's inputs alone."""
+
+    def __init__(self, grid, rank):
+        self.grid, self.rank, self.calls = grid, rank, []
+
+    def construct_voxel_x3(self, *a):
+        return None                                 # "split mode does not qualify": the fp32 gather is taken
+
+    def construct_voxel(self, lf, rf, gl, gr):
+        self.calls.append(lf.shape[0])
+        n = lf.shape[0]
+        v = gl.shape[2]
+        base = lf.mean(dim=(1, 2, 3)) + 2.0 * rf.mean(dim=(1, 2, 3))                     # [n]
+        return (base.view(n, 1) + 1e-3 * (gl[:, 0] - gr[:, 1])).view((n, 1) + self.grid) + 0.0 * v
+
+    def trunk_3d(self, vox):
+        return vox.mean(dim=(2, 3, 4)), torch.tanh(vox), None
+
+
+def _cfg3_worker(rank, world, port, total, per_call, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from snvc_amd import parallel as P
+        grid, F = (2, 3, 4), 2
+        lo, hi = P.shard_range(total, rank, world)
+        lf, rf, gl, gr = bench.cfg3_shard_inputs(lo, hi, grid, F, "cpu", fh=4, fw=4)
+        assert lf.shape[0] == hi - lo
+        m = _StubModel(grid, rank)
+        out = bench.cfg3_shard_step(m, lf, rf, gl, gr, per_call, total, grid, gather=True)
+        assert sum(m.calls) == hi - lo and max(m.calls, default=0) <= per_call        # this rank's crops, once, per_call at a time
+        # the single-process evaluation of ALL crops, in order
+        alf, arf, agl, agr = bench.cfg3_shard_inputs(0, total, grid, F, "cpu", fh=4, fw=4)
+        ref = bench.cfg3_shard_step(_StubModel(grid, -1), alf, arf, agl, agr, total, total, grid, gather=False)
+        assert out.shape == (total, 1) + grid and torch.equal(out, ref)
+        local = bench.cfg3_shard_step(_StubModel(grid, rank), lf, rf, gl, gr, per_call, total, grid, gather=False)
+        assert torch.equal(local, ref[lo:hi])                                           # no data-path collective was needed for it
+        q.put((rank, hi - lo))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,per_call", [(64, 8), (65, 8), (65, 4), (5, 8)])
+def test_cfg3_sharding_at_world_size_8(total, per_call):
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfg3_worker, args=(r, world, port, total, per_call, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    got = dict(q.get(timeout=5) for _ in range(world))
+    assert sum(got.values()) == total and max(got.values()) - min(got.values()) <= 1
+    assert got[0] == -(-total // world)                                                 # the first total % world ranks take one more

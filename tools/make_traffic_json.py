@@ -44,6 +44,8 @@ ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     "general_f32": 735902208,
 }
 F32_MFMA_LAYERS = ("conv1_factored", "conv2_side", "hg_s2")
+SOURCE_OF = {"x3_conv2": ("snvc_amd/csrc/conv3d_f16.hip", "conv3d_x3q_kernel(const F16Args a) {"),
+             "x3_hg2": ("snvc_amd/csrc/conv3d_f16.hip", "conv3d_x3q_kernel(const F16Args a) {")}
 
 
 def last_dispatch(path, needle):
@@ -78,6 +80,10 @@ for layer, needle in KERNEL.items():
         # v_mfma_f32_32x32x2_f32: 64 cycles/SIMD; 32x32x16_f16: 32; 16x16x32_f16 (the split-mode 3x3x3 layers since late r4): 16
         cyc = 64 if layer in F32_MFMA_LAYERS else 16 if layer.startswith("x3_") else 32
         entry["mfma_pipe_frac"] = entry["SQ_INSTS_MFMA"] * cyc / (1024 * entry["GRBM_GUI_ACTIVE"] / 8)
+    if layer in SOURCE_OF and len(entry) > 1:
+        sys.path.insert(0, ROOT)
+        import bench        # noqa: E402  (kernel_source_hash: the counters are tied to the kernel text they were collected on)
+        entry["kernel_source_sha256_16"] = bench.kernel_source_hash(*SOURCE_OF[layer])
     if len(entry) > 1:
         out["layers"][layer] = entry
 if "conv1_factored" in out["layers"]:
