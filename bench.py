@@ -233,25 +233,48 @@ def x3_power_probe(device):
     return out
 
 
+_SYSFS_DEV = {}
+
+
+def _sysfs_device_dir(index=0):
+    """/sys/bus/pci/devices/<address> of THIS process's GPU `index` (the host may expose the other GPUs of the node in sysfs too:
+    matched by PCI address, never by card number)."""
+    if index in _SYSFS_DEV:
+        return _SYSFS_DEV[index]
+    path = None
+    try:
+        p = torch.cuda.get_device_properties(index)
+        addr = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        cand = os.path.join("/sys/bus/pci/devices", addr)
+        if os.path.isdir(cand):
+            path = cand
+    except Exception:
+        path = None
+    _SYSFS_DEV[index] = path
+    return path
+
+
 def read_gpu_clock_mhz(index=0):
-    """The shader clock the driver reports right now (sysfs, no subprocess: a 20-us file read between steps), or None."""
+    """The shader clock the driver reports right now for this process's GPU (sysfs, no subprocess: a 20-us file read between
+    blocks of steps), or None when the node does not expose it."""
     import glob
-    for pat in (f"/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input",):
-        for path in sorted(glob.glob(pat)):
-            try:
-                with open(path) as fh:
-                    hz = float(fh.read().strip())
-                if hz > 0:
-                    return hz / 1e6
-            except (OSError, ValueError):
-                pass
-    for path in sorted(__import__("glob").glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+    d = _sysfs_device_dir(index)
+    if d is None:
+        return None
+    try:
+        with open(os.path.join(d, "pp_dpm_sclk")) as fh:
+            for ln in fh:
+                if "*" in ln:
+                    return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+    except (OSError, ValueError, IndexError):
+        pass
+    for path in sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*", "freq1_input"))):
         try:
             with open(path) as fh:
-                for ln in fh:
-                    if "*" in ln:
-                        return float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
-        except (OSError, ValueError, IndexError):
+                hz = float(fh.read().strip())
+            if hz > 0:
+                return hz / 1e6
+        except (OSError, ValueError):
             pass
     return None
 
@@ -280,12 +303,13 @@ def sustained_leg(step, seconds=5.0, min_steps=2000, block=100):
         gc.enable()
     total_s = time.perf_counter() - t_start
     n = len(blocks) * block
-    ms = [1e3 * b for b in blocks]
-    return {"steps": n, "seconds": total_s, "pairs_per_s": n / sum(blocks), "ms_per_step": 1e3 * sum(blocks) / n,
+    ms = [1e3 * b for b in blocks]                 # per-step time of each block
+    busy_s = block * sum(blocks)                   # seconds inside the blocks (the clock readings between them excluded)
+    return {"steps": n, "seconds": total_s, "pairs_per_s": n / busy_s, "ms_per_step": 1e3 * busy_s / n,
             "first_100_ms_per_step": ms[0], "last_100_ms_per_step": ms[-1], "first_100_vs_last_100": ms[0] / ms[-1],
             "slowest_block_ms_per_step": max(ms), "fastest_block_ms_per_step": min(ms),
             "sclk_mhz": ({"mean": float(np.mean(clocks)), "min": float(np.min(clocks)), "max": float(np.max(clocks)),
-                          "source": "sysfs hwmon freq1_input / pp_dpm_sclk, one reading per 100-step block"} if clocks else None)}
+                          "source": "sysfs pp_dpm_sclk (current level) / hwmon freq1_input of this GPU's PCI device, one reading per 100-step block"} if clocks else None)}
 
 
 PREWARM_S = 0.15

@@ -459,6 +459,10 @@ SNVC_API int snvc_mul_broadcast(const float *feat, const float *occ, float *out,
  *   x [N,C,D,H*W] -> y [N,C,D/4,H*W] (== [N, C*D/4, H, W] after a free reshape). */
 SNVC_API int snvc_avgpool_depth4(const float *x, float *y, int64_t N, int64_t C, int64_t D,
                                  int64_t HW, void *stream);
+/* its adjoint (training: the pool in front of the BEV reshape under autograd, vernier.py:436): grad_x[n,c,4q+j,i] = grad_y[n,c,q,i] / 4,
+ * zero on the depth planes AvgPool3d's floor drops.  grad_y [N,C,D/4,HW], grad_x [N,C,D,HW], both dense fp32. */
+SNVC_API int snvc_avgpool_depth4_backward(const float *grad_y, float *grad_x, int64_t N, int64_t C, int64_t D, int64_t HW,
+                                          void *stream);
 /* Zero-stuffing pass of the 2D up-sampling layers: x [R,H,W] -> y [R,2H,2W], y[r,2i,2j] = x[r,i,j], 0 elsewhere.
  * nn.ConvTranspose2d(k3,s2,p1,op1) of the BEV neck (snvc/models/submodule.py:291-314) == the depth-1 k3 / stride-1
  * convolution (desc.ksize_d = 1) of y with the flipped, channel-transposed kernel. */

@@ -89,6 +89,7 @@ SIGNATURES = {
     "snvc_act_backward_apply": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     "snvc_mul_broadcast": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
+    "snvc_avgpool_depth4_backward": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_zero_stuff2x": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p]),
     "snvc_disparity_regression": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_p]),
     "snvc_argmax_rows": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p]),

@@ -70,6 +70,18 @@ avgpool_depth4_kernel(const float *__restrict__ x, float *__restrict__ y, int64_
     }
 }
 
+// adjoint of avgpool_depth4_kernel: gx[p, 4 dq + j, i] = gy[p, dq, i] / 4 for j = 0..3; depth planes beyond 4 * (D / 4) (the floor of
+// AvgPool3d without ceil_mode drops them) get zero
+__global__ void __launch_bounds__(256)
+avgpool_depth4_bwd_kernel(const float *__restrict__ gy, float *__restrict__ gx, int64_t D, int64_t HW) {
+    const int64_t p = blockIdx.z, d = blockIdx.y, Dq = D / 4;
+    const bool live = d < 4 * Dq;
+    const float *a = gy + (p * Dq + (live ? d / 4 : 0)) * HW;
+    float *o = gx + (p * D + d) * HW;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += stride) o[i] = live ? a[i] / 4.0f : 0.0f;
+}
+
 // out[n,i] = sum_d x[n,d,i] * depth[d], d ascending (torch.sum over dim 1 of a product)
 __global__ void __launch_bounds__(256)
 disparity_regression_kernel(const float *__restrict__ x, const float *__restrict__ depth,
@@ -433,6 +445,17 @@ int snvc_avgpool_depth4(const float *x, float *y, int64_t N, int64_t C, int64_t 
     dim3 grid(stream_blocks(HW / 4 + 1, N * C * Dq), (unsigned)Dq, (unsigned)(N * C));
     avgpool_depth4_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, y, D, HW);
     return check_launch("snvc_avgpool_depth4");
+}
+
+int snvc_avgpool_depth4_backward(const float *grad_y, float *grad_x, int64_t N, int64_t C, int64_t D, int64_t HW, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C < 0 || D < 0 || HW < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_avgpool_depth4_backward: negative size");
+    if (N * C == 0 || D == 0 || HW == 0) return SNVC_OK;
+    if (!grad_x || (D / 4 > 0 && !grad_y)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_avgpool_depth4_backward: null pointer");
+    if (D > 65535 || N * C > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_avgpool_depth4_backward: grid too large");
+    dim3 grid(stream_blocks(HW, N * C * D), (unsigned)D, (unsigned)(N * C));
+    avgpool_depth4_bwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(grad_y, grad_x, D, HW);
+    return check_launch("snvc_avgpool_depth4_backward");
 }
 
 int snvc_disparity_regression(const float *x, const float *depth, float *out, int64_t N, int64_t D,

@@ -57,6 +57,14 @@ class GlobalStack(nn.Module):
             buf = ws[key] = torch.empty(shape, dtype=dtype, device=device)
         return buf
 
+    prep_streams = True      # the sheared first layer's two small 2D chains on side streams (False: all on the current stream, as r4)
+
+    def _side_streams(self, device):
+        st = self.__dict__.setdefault("_snvc_streams", {})
+        if device not in st:
+            st[device] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+        return st[device]
+
     def last_first_layer(self) -> torch.Tensor:
         """The first layer's result of the most recent inference call as a float32 [N,C,D,H,W] tensor (a copy when the call ran
         in split mode and the workspace holds the (hi, lo) pair) -- for tests and debugging."""
@@ -81,6 +89,7 @@ class GlobalStack(nn.Module):
         state.pop("_snvc_ws", None)
         state.pop("_snvc_x3", None)      # packed split-mode layers: rebuilt on first use
         state.pop("_snvc_x3_guard", None)    # the overflow flag, its pinned host copy and an event
+        state.pop("_snvc_streams", None)
         return state
 
     # ------------------------------------------------------------------------------------------ split mode ("f16x3", r4)
@@ -496,9 +505,29 @@ class GlobalStack(nn.Module):
         def sheared_inputs(q, m0):
             off, wu, off_col, wu_col = sheared_geometry(q, m0, shift.size(1), left.size(3))
             lay_g, lay_col = self._sheared_layers(plans, w.detach()[:, c:], q)
-            g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)             # [N,3C,H,WU]
-            gcol = lay_col(ops.sheared_upsample(right, q, wu_col, off_col).unsqueeze(2)).squeeze(2)   # [N,3C,H,WU2]
-            return g, gcol, off, off_col
+            if not self.prep_streams:
+                g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)             # [N,3C,H,WU]
+                gcol = lay_col(ops.sheared_upsample(right, q, wu_col, off_col).unsqueeze(2)).squeeze(2)   # [N,3C,H,WU2]
+                return g, gcol, off, off_col
+            # r5: G and G' are two independent chains of small launches (an upsample + a depth-1 convolution of ~100 workgroups each:
+            # their time is one workgroup's latency, not throughput) beside the left half's planes already queued on this stream.
+            # They run on two side streams and join before the expand pass: three chains side by side instead of end to end.
+            cur = torch.cuda.current_stream(left.device)
+            s1, s2 = self._side_streams(left.device)
+            start = torch.cuda.Event()
+            start.record(cur)            # `right` (and everything else queued so far) is ready behind this point
+            out = []
+            for st_, lay, wu_, off_ in ((s1, lay_g, wu, off), (s2, lay_col, wu_col, off_col)):
+                with torch.cuda.stream(st_):
+                    st_.wait_event(start)
+                    t = lay(ops.sheared_upsample(right, q, wu_, off_).unsqueeze(2)).squeeze(2)
+                    t.record_stream(cur)     # allocated in the side stream's pool, consumed by the expand pass on `cur`
+                    done = torch.cuda.Event()
+                    done.record(st_)
+                out.append((t, done))
+            for _, done in out:
+                cur.wait_event(done)
+            return out[0][0], out[1][0], off, off_col
 
         structure, guess, ready = (spacing if known else None), None, None
         if ticket is not None:

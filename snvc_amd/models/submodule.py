@@ -76,7 +76,7 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
 # coordinate maps).  invalidate_plans() drops exactly these; tests/test_host_cpu.py checks that no other `_snvc_*`
 # name is written anywhere in the package.
 CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans_x3", "_snvc_plans2d", "_snvc_plans2d_t", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
-               "_snvc_coor_maps", "_snvc_x3", "_snvc_x3_off", "_snvc_x3_guard", "_snvc_last_v1")
+               "_snvc_coor_maps", "_snvc_x3", "_snvc_x3_off", "_snvc_x3_guard", "_snvc_last_v1", "_snvc_streams")
 
 
 class _Plan:
@@ -874,7 +874,7 @@ def fused_conv3d_avgpool_d4(conv: nn.Module, norm: Optional[nn.Module], x: torch
             return y
     y = fused_conv3d(conv, norm, x, relu=relu)
     if torch.is_grad_enabled() and y.requires_grad:
-        return F.avg_pool3d(y, (4, 1, 1), (4, 1, 1))
+        return ops.AvgPoolDepth4Fn.apply(y) if (y.is_cuda and y.dtype == torch.float32) else F.avg_pool3d(y, (4, 1, 1), (4, 1, 1))
     _ROUTES["conv_avgpool_separate"] += 1
     return ops.avgpool_depth4(y)
 

@@ -320,7 +320,7 @@ class VernierScale(nn.Module):
         if training_graph:
             cat = torch.cat([v, img * occ], dim=1)                              # :433
             v = self.conv4(cat)                                                 # :435
-            v = torch.nn.functional.avg_pool3d(v, (4, 1, 1), (4, 1, 1))         # :436
+            v = ops.AvgPoolDepth4Fn.apply(v) if v.is_cuda and v.dtype == torch.float32 else torch.nn.functional.avg_pool3d(v, (4, 1, 1), (4, 1, 1))   # :436
         else:
             ops.mul_broadcast(img, occ, out=cat[:, f:])                         # cat([v, img*occ])  :433
             from .submodule import fused_conv3d_avgpool_d4

@@ -904,6 +904,33 @@ def avgpool_depth4(x):
     return y
 
 
+def avgpool_depth4_backward(gy, d):
+    """Adjoint of ``avgpool_depth4`` for an input of depth ``d``: [N,C,d//4,H,W] -> [N,C,d,H,W] (snvc_avgpool_depth4_backward)."""
+    _gpu(gy, "gy")
+    gy = gy.contiguous()
+    n, c, dq, h, w = gy.shape
+    if dq != d // 4 or gy.dtype != torch.float32:
+        raise RuntimeError("avgpool_depth4_backward: grad must be float32 [N,C,d//4,H,W]")
+    gx = torch.empty((n, c, d, h, w), dtype=torch.float32, device=gy.device)
+    if gx.numel():
+        with torch.cuda.device(gy.device):
+            check(_lib.lib().snvc_avgpool_depth4_backward(_ptr(gy), _ptr(gx), n, c, d, h * w, _stream(gy)), "snvc_avgpool_depth4_backward")
+    return gx
+
+
+class AvgPoolDepth4Fn(torch.autograd.Function):
+    """``F.avg_pool3d(x, (4,1,1), (4,1,1))`` (reference vernier.py:289,436) under autograd on the HIP kernels, both directions."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.depth = x.size(2)
+        return avgpool_depth4(x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return avgpool_depth4_backward(gy, ctx.depth)
+
+
 def zero_stuff2x(x):
     """[N,C,H,W] -> [N,C,2H,2W] with y[..., 2i, 2j] = x[..., i, j] and zeros elsewhere (see snvc_zero_stuff2x)."""
     _gpu(x, "x")
@@ -1227,7 +1254,10 @@ def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) ->
     return y
 
 
-X3_SMALL_BELOW = {"stride2": 1024, "transposed": 4096}      # workgroups below which the half-height tile forms are picked (tools flip these)
+# workgroups below which the half-height tile forms are picked (tools flip these).  Measured at cfg2 (tools/time_hg.py): the transposed
+# layer gains 3-8 % (hg conv5 141 -> 137 us); the stride-2 layers LOSE -- hg conv3 (432 workgroups) 91 -> 170 us, hg conv1 398 -> 473:
+# twice the workgroups stream twice the weights (17 TB/s of L1 -> register traffic at hg conv3's size), so that form is never picked by itself
+X3_SMALL_BELOW = {"stride2": 0, "transposed": 4096}
 
 
 class Conv3dLayerX3:

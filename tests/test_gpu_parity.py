@@ -1108,9 +1108,9 @@ def test_global_pair_end_to_end_vs_oracle(tile):
     from snvc_amd.models import submodule as S
     if tile == "default":   # the folded tail and conv2's side head are what forward_pair runs on
         with torch.no_grad():
-            b_f, b_s = S._ROUTES["folded_head"], S._ROUTES["side_head"]
-            ours.forward_pair(dl, dr, dsh, 1)
-            assert (S._ROUTES["folded_head"], S._ROUTES["side_head"]) == (b_f + 1, b_s + 1)
+            b_f, b_s = S._ROUTES["folded_head"] + S._ROUTES["x3_fused_tail"], S._ROUTES["side_head"]
+            ours.forward_pair(dl, dr, dsh, 1)      # split mode (r5): the tail's tap contraction sits in conv5's epilogue (x3_fused_tail)
+            assert (S._ROUTES["folded_head"] + S._ROUTES["x3_fused_tail"], S._ROUTES["side_head"]) == (b_f + 1, b_s + 1)
     check(got_full, exp, 1e-4, "pair (materialised)")
     check(got_fact, exp, 1e-4, "pair (factored)")
     check(got_fact, got_full, 2e-5, "factored vs materialised")
@@ -1780,3 +1780,22 @@ def test_sample_2d_feat_concat_atten_vs_torch():
         got = m._sample_2d_feat(lf.to(dev()), rf.to(dev()), gpl.to(dev()), gpr.to(dev()), aggregate="concat-atten").cpu()
     att = F.cosine_similarity(plain[:, :32], plain[:, 32:], dim=1).unsqueeze(1)
     check(got.numpy(), (plain * torch.clamp(att, 0.0)).numpy(), 2e-6, "concat-atten")
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 8, 3, 7), (1, 32, 32, 16, 24), (1, 3, 10, 4, 4), (2, 2, 3, 5, 6)])
+def test_avgpool_depth4_autograd_vs_torch(shape):
+    """r5: the pool in front of the BEV reshape under autograd (reference vernier.py:289,436) on the HIP kernels in both
+    directions -- forward bit-equal to F.avg_pool3d's fp32 sum order, backward = grad / 4 on the pooled planes and zero on the
+    planes the floor drops (depth 10 -> 2 windows, depth 3 -> none)."""
+    from snvc_amd import ops
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape, device=dev(), requires_grad=True)
+    xr = x.detach().clone().requires_grad_()
+    y = ops.AvgPoolDepth4Fn.apply(x)
+    yr = F.avg_pool3d(xr, (4, 1, 1), (4, 1, 1)) if shape[2] >= 4 else xr.new_zeros(shape[:2] + (0,) + shape[3:]) + 0.0 * xr.sum()
+    assert y.shape == yr.shape
+    g = torch.randn_like(y)
+    y.backward(g)
+    yr.backward(g)
+    assert torch.allclose(y, yr, rtol=0, atol=1e-6)
+    assert torch.equal(x.grad, xr.grad)
