@@ -858,6 +858,300 @@ conv3d_x3q_kernel(const F16Args a) {
     if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
 }
 
+// ------------------------------------------------------------------------- 16x16x32 form of the stride-2 3x3x3 split layer (r5)
+// The hourglass's stride-2 layers (snvc/models/submodule.py:88-94,170-181) were the layers furthest from any roof: the 2x4x32 output tile
+// of conv3d_f16_kernel<F16K3S2X> needs a 5 x 9 x 65-piece image PER PLANE (46.8 KB), so the planes were taken one after the other,
+// single-buffered at two workgroups per CU: every pass a fill with nothing under it but the other workgroup, the weights of a
+// chunk streamed twice (hi pass, lo pass), 14 k-steps of 32x32x16 MFMAs per fill.  hg conv1 at cfg2: 1.16 GB moved at 3.4 TB/s.
+// This form: ONE PERSISTENT workgroup of 8 waves per CU with THREE image slots (144 KB of the CU's 160 KB LDS),
+// v_mfma_f32_16x16x32_f16 (K = 32 = four taps of one C8 piece, as conv3d_x3q_kernel), 64 output channels per workgroup: wave =
+// (row pair of the 2x4 output rows) x (32-channel half), so a wave holds only ITS half's weights -- a step's w_hi and w_lo, 2 x 56
+// VGPRs: MFMA operands cannot sit in AGPRs, and vmcnt retires in order: a weight fetched behind an LDS-DMA would wait for it, so a
+// step's weights are all in registers before its refills are requested.  A step (one channel group of one tile, both planes):
+//   the NEXT step's hi plane is requested into the spare slot;
+//   phase L: acc += w_hi * x_lo   from the lo slot, 7 tap quads x 8 MFMAs per wave;
+//   barrier (LDS reads only); the next step's lo plane is requested into the lo slot just released;
+//   phase H: acc += w_lo * x_hi + w_hi * x_hi   from the hi slot, 7 quads x 16 MFMAs; as each quad retires its weight registers the
+//            next step's fragments are requested into them (first read behind the barrier below);
+//   barrier (drains everything); the hi slot becomes the spare one.
+// Steps run on across tile boundaries (the next tile's first planes are requested under this tile's last step, the epilogue's
+// stores drain under the next tile's MFMAs): with one workgroup per CU nothing else would hide a workgroup's first fill, last
+// wait and stores -- one workgroup per tile measured 397 us on hg conv1, of which 257 remained with MFMAs AND refills off.
+// Measured (tools/time_hg.py, back to back): hg conv1 395-407 -> 326 us, hg conv3 93 -> 85 us.  What still bounds it is the
+// refill itself: 1.08 GB through 94 KB-per-CU bursts reach 3.3 TB/s (a deeper queue needs a fourth slot the LDS does not have).
+// The image rows are stored POLYPHASE in blocks of 32 columns -- 16 even columns, then the 16 odd ones -- so that the 16 output columns of
+// a fragment read consecutive pieces for every tap (column 2c + kw: kw = 0 / 2 -> even piece c / c + 1, kw = 1 -> odd piece c):
+// conflict-free ds_read_b128 where the natural order reads at a 32-byte stride, while 32 consecutive LDS positions are still 32
+// consecutive columns, i.e. a DMA round fetches whole 128-byte lines.  Same values as the 32x32x16 form up to fp32 summation order.
+struct X3S2Cfg {
+    static constexpr int TD = 2, TH = 4, NB = 2, IN_D = 5, IN_H = 9, IN_W = 65, VOX = IN_D * IN_H * IN_W;
+    static constexpr int THREADS = 512, NIT = (VOX + THREADS - 1) / THREADS, SLOT_BYTES = NIT * THREADS * 16, LDS_BYTES = 3 * SLOT_BYTES;
+    static constexpr int NQ = 7;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_lgkm_for4(h8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
+__global__ void __launch_bounds__(512, 1)
+conv3d_x3s2q_kernel(const F16Args a, const int total_jobs) {
+    using Cfg = X3S2Cfg;
+    constexpr int NB = Cfg::NB, TH = Cfg::TH, IN_H = Cfg::IN_H, IN_W = Cfg::IN_W, VOX = Cfg::VOX, NIT = Cfg::NIT, NQ = Cfg::NQ;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // 8 waves: wave = (row pair 0..3) + 4 * (32-channel half of the 64 output channels).  Two waves per SIMD: each holds the weights of ITS
+    // 32 channels only (2 x 56 VGPRs for a step's w_hi and w_lo -- MFMA operands cannot sit in AGPRs, and all 64 channels' 224 do not
+    // fit beside the B fragments), every B fragment is read by the two waves that share its rows
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, chalf = tid >> 8, kb = lane >> 4, col = lane & 15;
+    // PERSISTENT: one workgroup per CU walks the jobs b, b + G, b + 2 G, ... (job = (sample, tile, 64-channel block); G a multiple of 8,
+    // so a workgroup stays inside its XCD's contiguous range of tiles).  With one workgroup per CU nothing else hides a workgroup's
+    // start-up (first fill: a whole HBM round trip), its last wait and its stores -- measured with the MFMAs AND the refills
+    // switched off, one workgroup per tile still took 257 of 397 us on hg conv1.  Here the chunk pipeline simply runs on across
+    // tile boundaries: the next tile's first planes are requested under the last phase H of this one, the epilogue's stores drain
+    // under the next tile's MFMAs.
+    const int ntiles = a.tiles_d * a.tiles_h * a.tiles_w, cblocks = a.Cout >> 6;
+    const int in_hw = a.Hin * a.Win, in_dhw = in_hw * a.Din;
+    const int wbase = tid & ~63;
+
+    struct Job { int od0, oh0, ow0, cb; int64_t n; };
+    auto decode = [&](int b) {
+        const int j = xcd_remap16(b, total_jobs);
+        const int cb = j % cblocks, r = j / cblocks, t = r % ntiles;
+        Job jb;
+        jb.n = r / ntiles; jb.cb = cb;
+        const int tw = t % a.tiles_w, th = (t / a.tiles_w) % a.tiles_h, td = t / (a.tiles_w * a.tiles_h);
+        jb.od0 = td * Cfg::TD; jb.oh0 = th * TH; jb.ow0 = tw * 32;
+        return jb;
+    };
+    // staging geometry of a tile: piece i of a slot = (dd, hh, position in the polyphase row)
+    unsigned off[NIT];
+    unsigned vmask = 0;
+    auto geometry = [&](const Job &jb) {
+        const int id0 = 2 * jb.od0 - a.pad_d, ih0 = 2 * jb.oh0 - a.pad_h, iw0 = 2 * jb.ow0 - a.pad_w;
+        vmask = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = it * 512 + tid;
+            const int dd = i / (IN_H * IN_W), r2 = i - dd * (IN_H * IN_W);
+            const int hh = r2 / IN_W, pp = r2 - hh * IN_W;
+            // row layout: [16 even columns][16 odd columns] twice, then column 64 -- 32 consecutive positions are 32 consecutive
+            // columns (permuted): a DMA round still fetches whole 128-byte lines
+            const int blk = pp >> 5, rr_ = pp & 31;
+            const int ww = pp == 64 ? 64 : (rr_ < 16 ? 2 * (16 * blk + rr_) : 2 * (16 * blk + rr_ - 16) + 1);
+            const int gd = id0 + dd, gh = ih0 + hh, gw = iw0 + ww;
+            const bool ok = i < VOX && (unsigned)gd < (unsigned)a.Din && (unsigned)gh < (unsigned)a.Hin && (unsigned)gw < (unsigned)a.Win;
+            off[it] = ok ? (unsigned)(gd * in_hw + gh * a.Win + gw) : 0u;
+            vmask |= (ok ? 1u : 0u) << it;
+        }
+    };
+    auto issue = [&](int64_t n, int chunk, bool lo_plane, int slot) {      // every wave issues all NIT rounds (pieces past the image land in the slot's padding)
+        const _Float16 *xc = (lo_plane ? a.x_lo : a.x) + n * a.x_bs + (int64_t)chunk * in_dhw * 8;
+        char *const ibuf = lds + slot * Cfg::SLOT_BYTES;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const void *src = ((vmask >> it) & 1u) ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
+            __builtin_amdgcn_global_load_lds(static_cast<const float *>(src), reinterpret_cast<float *>(ibuf + (it * 512 + wbase) * 16), 16, 0, 0);
+        }
+    };
+    // this lane's byte offset of tap 4 q + kb inside a slot (output column `col` of the tile's left half; + 256 B: the right half)
+    int qoff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        int tp = 4 * q + kb;
+        tp = tp < 27 ? tp : 26;                     // the 28th slot: zero weights, tap 26's piece
+        const int kd = tp / 9, kh = (tp / 3) % 3, kw = tp % 3;
+        // column 2 c + kw of output column c = col (+ 16 for the right half: + 32 positions): kw = 0 -> even piece c, kw = 1 -> odd piece c,
+        // kw = 2 -> even piece c + 1 (for c = 15 the first piece of the next block: position 32)
+        const int pos = kw == 0 ? col : (kw == 1 ? 16 + col : (col == 15 ? 32 : col + 1));
+        qoff[q] = ((kd * IN_H + kh) * IN_W + pos) * 16;
+    }
+    int rowoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int row = wave * NB + nb;
+        rowoff[nb] = ((2 * (row / TH)) * IN_H + 2 * (row % TH)) * IN_W * 16;
+    }
+    // weights: [cb][chunk][quad][co half (4)][hi | lo][lane] pieces (pack_q16s_weights_kernel with NH = 4)
+    // (the pointer stays wave-uniform and the lane is added in the index: the loads take the scalar-base form, one VGPR of offset
+    // for all 56 fragments of a step instead of a 64-bit address pair each)
+    const h8 *const wall = reinterpret_cast<const h8 *>(a.wp);
+    const int64_t wchunk = (int64_t)NQ * 8 * 64;     // pieces per (cb, chunk)
+
+    int b = blockIdx.x;
+    Job cur = decode(b);
+    geometry(cur);
+    h8 WH[NQ][2], WL[NQ][2];
+    {
+        const h8 *wc = wall + (int64_t)cur.cb * a.nchunks * wchunk;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                WH[q][h] = wc[(q * 8 + (2 * chalf + h) * 2) * 64 + lane];
+                WL[q][h] = wc[(q * 8 + (2 * chalf + h) * 2 + 1) * 64 + lane];
+            }
+    }
+    f32x4q acc[NB][2][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[nb][ph][h] = f32x4q{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    int s_hi = 0, s_sp = 2;                          // slots: hi plane, (1 = lo plane, fixed), spare
+    issue(cur.n, 0, false, 0);
+    issue(cur.n, 0, true, 1);
+    __syncthreads();
+    const int gstride = gridDim.x;
+    constexpr float kHalfMax = 65504.0f;
+    float vmax = 0.0f;
+    int chunk = 0;
+    while (true) {
+        const bool last_chunk = chunk + 1 == a.nchunks;
+        const bool next_job = last_chunk && b + gstride < total_jobs;
+        const bool more = !last_chunk || next_job;
+        // the next step's hi plane is requested FIRST (the spare slot is free): with the lo plane following behind phase L, a request
+        // is outstanding for all but the few hundred cycles around the two barriers (requested only behind phase L, every CU asked
+        // for its 94 KB at the same moment and then waited: hg conv1 moved 3.2 TB/s)
+        Job nxt = cur;
+        if (next_job) {                              // block-uniform: the tile behind this one (all of this tile's planes are requested already)
+            nxt = decode(b + gstride);
+            geometry(nxt);
+        }
+        const int nchunk = last_chunk ? 0 : chunk + 1;
+        if (more) issue(nxt.n, nchunk, false, s_sp);
+        h8 bfr[2][4];      // [buffer][row * 2 + row half]
+        auto load_b = [&](int buf, unsigned img, int q) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const unsigned addr = img + (unsigned)(qoff[q] + rowoff[rr]);
+                lds_read_b128_to<0>(bfr[buf][rr * 2 + 0], addr);
+                lds_read_b128_to<512>(bfr[buf][rr * 2 + 1], addr);
+            }
+        };
+        // ---- phase L: w_hi * x_lo
+        {
+            const unsigned img = lds_base + (unsigned)Cfg::SLOT_BYTES;
+            load_b(0, img, 0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int cb_ = q & 1, nx = cb_ ^ 1;
+                if (q + 1 < NQ) {
+                    load_b(nx, img, q + 1);
+                    wait_lgkm_for4<4>(bfr[cb_]);
+                } else {
+                    wait_lgkm_for4<0>(bfr[cb_]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            acc[rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WH[q][h], bfr[cb_][rr * 2 + ph], acc[rr][ph][h], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the lo slot is released by every wave (a bare s_barrier: no vector-memory wait -- the hi plane's refill stays in flight; this
+        // chunk's weights landed before the barrier that ended the previous step)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (more) issue(nxt.n, nchunk, true, 1);
+        // ---- phase H: (w_lo + w_hi) * x_hi
+        {
+            const h8 *wn = wall + ((int64_t)nxt.cb * a.nchunks + nchunk) * wchunk;
+            const unsigned img = lds_base + (unsigned)(s_hi * Cfg::SLOT_BYTES);
+            load_b(0, img, 0);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int cb_ = q & 1, nx = cb_ ^ 1;
+                if (q + 1 < NQ) {
+                    load_b(nx, img, q + 1);
+                    wait_lgkm_for4<4>(bfr[cb_]);
+                } else {
+                    wait_lgkm_for4<0>(bfr[cb_]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int term = 0; term < 2; ++term)
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                acc[rr][ph][h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(term == 0 ? WL[q][h] : WH[q][h], bfr[cb_][rr * 2 + ph],
+                                                                                        acc[rr][ph][h], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                // the next step's weights of this quad, into the registers the quad has just retired (first read behind the barrier below)
+                if (more) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        WH[q][h] = wn[(q * 8 + (2 * chalf + h) * 2) * 64 + lane];
+                        WL[q][h] = wn[(q * 8 + (2 * chalf + h) * 2 + 1) * 64 + lane];
+                    }
+                }
+            }
+        }
+        __syncthreads();                             // drains the refill and retires every read of the hi slot
+        { const int o = s_hi; s_hi = s_sp; s_sp = o; }
+        if (!last_chunk) { ++chunk; continue; }
+
+        // ---- epilogue of the finished tile: lane (kb, col) holds, per 32-channel block bb, the 8 channels of C8 group 4 bb + kb for
+        // voxel col (+16) of its rows.  Its stores drain under the next tile's first phase.
+        {
+            const int out_hw = a.Hout * a.Wout;
+            const int64_t out_dhw = (int64_t)out_hw * a.Dout;
+            const bool relu = (a.flags & SNVC_EPI_RELU) != 0;
+            const float lo_bound = relu ? 0.0f : -kHalfMax;
+            {
+                const int bb = chalf;
+                const int c0 = cur.cb * 64 + bb * 32 + 8 * kb;
+                float sc[8], bi[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sc[e] = a.scale ? a.scale[c0 + e] : 1.0f;
+                    bi[e] = a.scale ? a.bias[c0 + e] : 0.0f;
+                }
+                const int64_t gplane = (int64_t)(cur.cb * 8 + bb * 4 + kb) * out_dhw * 8;
+                _Float16 *yn = a.y + cur.n * a.y_bs + gplane, *yn_lo = a.y_lo + cur.n * a.y_bs + gplane;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const int row = wave * NB + nb;
+                    const int pd = cur.od0 + row / TH, phh = cur.oh0 + row % TH;
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        const int pw = cur.ow0 + 16 * ph + col;
+                        const bool ok = pd < a.nd && phh < a.nh && pw < a.nw;
+                        const int64_t sp = ok ? ((int64_t)pd * out_hw + phh * a.Wout + pw) : 0;
+                        h8 o, ol;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float v = __builtin_fmaf(acc[nb][ph][e >> 2][e & 3], sc[e], bi[e]);
+                            v = __builtin_amdgcn_fmed3f(v, lo_bound, kHalfMax);
+                            vmax = __builtin_fmaxf(vmax, ok ? __builtin_fabsf(v) : 0.0f);
+                            o[e] = (_Float16)v;
+                            ol[e] = (_Float16)(v - (float)o[e]);
+                            acc[nb][ph][e >> 2][e & 3] = 0.0f;
+                        }
+                        if (ok) {
+                            *reinterpret_cast<h8 *>(yn + sp * 8) = o;
+                            *reinterpret_cast<h8 *>(yn_lo + sp * 8) = ol;
+                        }
+                    }
+                }
+            }
+        }
+        if (!next_job) break;                        // block-uniform: every wave of the workgroup leaves here
+        b += gstride;
+        cur = nxt;
+        chunk = 0;
+    }
+    if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
+}
+
 // 16x16x32 form of the 5^3 / dilated 5^3 / 7^3 layers (split mode with the planes serial, one channel group per chunk, as F16K5X /
 // F16K5D2X / F16K7X; and the fp16-storage family): K = 32 = FOUR TAPS of one C8 piece -- k-block kb = lane >> 4 is tap 4 q + kb of
 // the list of ALL K^3 taps in (kd, kh, kw) raster order, cut into equal runtime-looped segments (a segment is what gets unrolled):
@@ -1271,7 +1565,7 @@ using F16K5D2X = F16Cfg<5, 5, 5, 1, 1, 1, 4, 4, 1, 1, false, 2, 2, 3>;
 using F16K7X   = F16Cfg<7, 7, 7, 1, 1, 1, 4, 4, 1, 1, false, 2, 1, 3>;
 using F16DCXN  = F16Cfg<2, 2, 2, 1, 1, 1, 4, 4, 2, 1, false, 3, 1, 2, true>;
 
-enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FK5D2QN, FK7QN, FK5Q, FK5QN, FK3S2XT, FDCXT, FNONE };
+enum F16Kind { FK1, FK3, FK3H, FK3S2, FK5, FK5D2, FK7, FDC, FK1N, FK3N, FK3S2N, FK5N, FK5D2N, FK7N, FDCN, FK3X, FK3X2, FK3S2X, FDCX, FK3XS, FK3X2S, FK3XT, FK1X, FK5X, FK5D2X, FK7X, FDCXN, FK3XH, FK3XQ, FK5XQ, FK5D2XQ, FK7XQ, FK5D2Q, FK7Q, FK5D2QN, FK7QN, FK5Q, FK5QN, FK3S2XT, FDCXT, FK3S2XQ, FNONE };
 
 struct F16Plan {
     int kind, MI, KCG, MODE, TD, TH, STEPS, SEGS, TSEG, NPS, NS, KD, KH, KW, unroll_d, PL, PF, PASSES, dyn;
@@ -1313,6 +1607,15 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
                 p = plan_from<F16K3X>(FK3XH);
             } else if (key == 321) {
                 if (d.Cout % 64 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: stride-2 layers need Cout % 64 == 0");
+                if (d.algo & SNVC_ALGO_X3_Q16) {      // the 16x16x32 form: both planes, three image slots, one workgroup per CU
+                    p = plan_from<F16K3S2X>(FK3S2XQ);
+                    p.KCG = 1; p.MI = 2; p.STEPS = X3S2Cfg::NQ; p.NS = X3S2Cfg::NQ; p.PF = 0; p.PASSES = 1;
+                    p.nchunks = d.Cin / 8;
+                    p.cblocks = d.Cout / 64;
+                    p.block_halves = (int64_t)p.cblocks * p.nchunks * X3S2Cfg::NQ * 8 * 64 * 8;
+                    if (p.cblocks > 65535 || d.N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: too many channel blocks or samples");
+                    return SNVC_OK;
+                }
                 p = (d.algo & SNVC_ALGO_X3_SMALL) ? plan_from<F16K3S2XT>(FK3S2XT) : plan_from<F16K3S2X>(FK3S2X);
             } else {
                 if (d.Cout % 32 != 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d: Cout % 32 == 0");
@@ -1413,6 +1716,7 @@ int make_f16_plan(const snvc_conv3d_desc &d, F16Plan &p, bool split = false) {
 }
 
 inline int64_t f16_class_stride(const F16Plan &p) {
+    if (p.kind == FK3S2XQ) return p.block_halves + (int64_t)X3S2Cfg::NQ * 8 * 64 * 8;      // the last chunk's phase H never reads ahead, but stays in bounds if it did
     if (p.kind == FK3XQ || p.kind == FK5XQ || p.kind == FK5D2XQ || p.kind == FK7XQ || p.kind == FK5D2Q || p.kind == FK7Q || p.kind == FK5Q)
         return p.block_halves + (int64_t)p.PF * 4 * 64 * 8;
     if (p.kind == FK5D2QN || p.kind == FK7QN || p.kind == FK5QN) return p.block_halves + (int64_t)p.PF * 2 * 64 * 8;
@@ -1525,6 +1829,11 @@ static int f16_pack_common(const snvc_conv3d_desc *d, const float *weight, void 
         pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
             weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, k3, nseg, nt, nq, p.nchunks, nh_, sp_ ? 2 : 1, sp_ ? 2 : 1, wmul,
             p.block_halves);
+        return check_launch(who);
+    }
+    if (p.kind == FK3S2XQ) {    // [cb (64 channels)][chunk][quad][co half (4)][hi | lo][lane][8]
+        pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(p.block_halves, 256), 256, 0, as_stream(stream)>>>(
+            weight, reinterpret_cast<_Float16 *>(packed), d->Cout, d->Cin, 27, 1, 4 * X3S2Cfg::NQ, X3S2Cfg::NQ, p.nchunks, 4, 2, 1, wmul, p.block_halves);
         return check_launch(who);
     }
     if (p.kind == FK3XQ) {      // [cb][chunk][quad][co half][hi | lo][lane][8]: one segment of all 27 taps
@@ -1809,6 +2118,19 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
             using C5 = Q16SCfg<5, 1>; using C5D = Q16SCfg<5, 2>; using C7 = Q16SCfg<7, 1>;
             if (p.kind == FK5XQ) SNVC_Q16S(C5); else if (p.kind == FK5D2XQ) SNVC_Q16S(C5D); else SNVC_Q16S(C7);
 #undef SNVC_Q16S
+            break;
+        }
+        case FK3S2XQ: {
+            if (to_f32 || resflags || head) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the stride-2 16x16x32 form writes a split C8 tensor, no residual / head");
+            // persistent: one workgroup per CU (144 KB of LDS each), a multiple of 8 so that a workgroup's jobs b, b + G, ... stay on its XCD
+            const int64_t total = ntiles * p.cblocks * d->N;
+            if (total >= ((int64_t)1 << 30)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles");
+            int g = device_cu_count();
+            if (g <= 0) g = 256;
+            if (total < g) g = total >= 8 ? (int)(total & ~(int64_t)7) : (int)total;
+            static std::atomic<unsigned> attr_s2{0};
+            if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3s2q_kernel), X3S2Cfg::LDS_BYTES, attr_s2))
+                conv3d_x3s2q_kernel<<<dim3((unsigned)g), X3S2Cfg::THREADS, X3S2Cfg::LDS_BYTES, st>>>(a, (int)total);
             break;
         }
         case FK3XQ: {

@@ -1106,6 +1106,7 @@ def voxel_gather_forward_split(left, right, l_pts, r_pts, resolution, mul_dev) -
 
 X3_Q16 = [True]        # False: the 32x32x16 kernel forms everywhere (rounds up to mid r4)
 X3_Q16_K5 = [True]     # ... and the plain 5^3 layers (quads over all 125 taps)
+X3_Q16_S2 = [True]     # stride-2 3x3x3 layers with a split output and no residual: the 16x16x32 form (False: the serial-plane 32x32x16 form)
 X3_Q16_MIN_JOBS = [256]   # 3x3x3 layers: (tile, 32-channel block) jobs from which the 16x16x32 form is picked (r4: 1024; hg conv4 at cfg2 --
 #                           432 jobs -- 61.6 us against 74.5 for the 2x4x32-tile 32x32x16 form, tools/time_hg.py)
 
@@ -1320,6 +1321,8 @@ class Conv3dLayerX3:
                 wgs = 8 * n * -(-out_sp[0] // 8) * -(-out_sp[1] // 8) * -(-out_sp[2] // 64)
                 return _lib.ALGO_X3_SMALL if wgs < X3_SMALL_BELOW["transposed"] else 0
             wgs = n * -(-out_sp[0] // 2) * -(-out_sp[1] // 4) * -(-out_sp[2] // 32)
+            if X3_Q16_S2[0] and plain and split_out:
+                return _lib.ALGO_X3_Q16      # r5: both planes, three image slots, one workgroup per CU (conv3d_x3s2q_kernel)
             return _lib.ALGO_X3_SMALL if wgs < X3_SMALL_BELOW["stride2"] else 0
         if self.forced_algo is not None or self.stride != 1 or self.transposed or self.ksize != 3 or self.cout == 1:
             return self.algo

@@ -392,7 +392,8 @@ def test_split_mode_local_trunk_layer_kinds_vs_float64(case):
 
 
 @pytest.mark.parametrize("case", ["k3_32_32", "k3_64_64", "k3_32_64", "k3s2_32_64", "k3s2_64_64", "deconv_64_64", "k3_32_32_odd",
-                                  "k3s2_32_64_small", "k3s2_64_64_small", "deconv_64_64_small", "k3s2_64_64_small_odd", "deconv_64_64_small_odd"])
+                                  "k3s2_32_64_small", "k3s2_64_64_small", "deconv_64_64_small", "k3s2_64_64_small_odd", "deconv_64_64_small_odd",
+                                  "k3s2_32_64_q16", "k3s2_64_64_q16", "k3s2_64_128_q16_odd", "k3s2_8_64_q16_tiny"])
 def test_split_mode_layers_vs_float64(case):
     from snvc_amd import _lib as L_, ops
     from test_gpu_parity import TIGHT, check
@@ -406,16 +407,46 @@ def test_split_mode_layers_vs_float64(case):
         "deconv_64_64": (64, 64, 2, True, (4, 6, 20)), "k3_32_32_odd": (32, 32, 1, False, (3, 5, 31)),
         "k3s2_32_64_small": (32, 64, 2, False, (8, 12, 72)), "k3s2_64_64_small": (64, 64, 2, False, (6, 10, 42)),
         "deconv_64_64_small": (64, 64, 2, True, (4, 6, 20)), "k3s2_64_64_small_odd": (64, 64, 2, False, (7, 9, 67)),
-        "deconv_64_64_small_odd": (64, 64, 2, True, (3, 5, 35))}[case]
-    forced = None if (stride == 1 and not transposed) else (L_.ALGO_X3_SMALL if small else 0)
+        "deconv_64_64_small_odd": (64, 64, 2, True, (3, 5, 35)),
+        # r5: conv3d_x3s2q_kernel (16x16x32, both planes, three image slots): one chunk, eight chunks, two output blocks, ragged extents
+        "k3s2_32_64_q16": (32, 64, 2, False, (8, 12, 72)), "k3s2_64_64_q16": (64, 64, 2, False, (6, 10, 42)),
+        "k3s2_64_128_q16_odd": (64, 128, 2, False, (7, 9, 67)), "k3s2_8_64_q16_tiny": (8, 64, 2, False, (2, 2, 3))}[case]
+    q16 = "_q16" in case
+    forced = None if (stride == 1 and not transposed) else (L_.ALGO_X3_Q16 if q16 else L_.ALGO_X3_SMALL if small else 0)
     x = torch.relu(torch.randn(2, cin, *shape, device=dev())) * 2.0 + 0.01 * torch.randn(2, cin, *shape, device=dev())
     w = torch.randn((cin, cout, 3, 3, 3) if transposed else (cout, cin, 3, 3, 3), device=dev()) * np.sqrt(2.0 / (cin * 27))
     scale, bias = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev()) * 0.3
     layer = ops.Conv3dLayerX3(w, 3, stride, 1, 1, transposed, algo=forced)
+    if q16:     # split -> split only (no residual, no fp32 output in this form: the caller's rule takes another one for those)
+        old = ops.Conv3dLayerX3(w, 3, stride, 1, 1, transposed, algo=0)
+        ref = _x3_reference(x, w, scale, bias, stride, transposed, True)
+        for x_exp, out_exp in ((0, 0), (5, 3)):
+            xs = ops.to_split(x, x_exp)
+            flag = torch.zeros(1, dtype=torch.int32, device=dev())
+            ys = layer(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out_exp=out_exp, overflow=flag)
+            got = ops.from_split(ys, out_exp)
+            check(got.cpu().numpy(), ref.numpy(), TIGHT, f"{case}: 16x16x32 stride-2 form vs float64, exponents {x_exp}/{out_exp}")
+            yo = ops.from_split(old(xs, x_exp, scale, bias, flags=ops.EPI_RELU, out_exp=out_exp, overflow=flag), out_exp)
+            assert (got - yo).abs().max().item() <= 2e-6 * yo.abs().max().item(), "the two instruction shapes differ by fp32 summation order only"
+            assert flag.item() == 0
+        y0 = ops.from_split(layer(ops.to_split(x, 2), 2, out_exp=1), 1)                   # no affine, no activation (negative values kept)
+        check(y0.cpu().numpy(), F.conv3d(x.double().cpu(), w.double().cpu(), None, 2, 1).numpy(), TIGHT, f"{case}: bare convolution")
+        with pytest.raises(ops.Unsupported):
+            layer(ops.to_split(x, 2), 2, scale, bias, flags=ops.EPI_RELU, to_f32=True)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev())
+        layer(ops.to_split(x, 2), 2, scale * 4096.0, bias, flags=ops.EPI_RELU, out_exp=8, overflow=flag)   # clamped and flagged
+        assert int(flag.item()) == 1
+        a_ = layer(ops.to_split(x, 2), 2, scale, bias, flags=ops.EPI_RELU, out_exp=1)
+        for _ in range(3):      # the refill / slot rotation is deterministic: bitwise repeatable
+            assert torch.equal(layer(ops.to_split(x, 2), 2, scale, bias, flags=ops.EPI_RELU, out_exp=1), a_)
+        return
     if forced is not None:      # what the launch-size rule picks by itself at this size: half-height tiles for a transposed layer only
         auto = ops.Conv3dLayerX3(w, 3, stride, 1, 1, transposed)
         auto(ops.to_split(x, 2), 2, scale, bias, flags=ops.EPI_RELU, to_f32=True)
         assert auto.algo == (L_.ALGO_X3_SMALL if transposed else 0)
+        if not transposed:      # ... a stride-2 layer with a split output and no residual: the 16x16x32 form
+            auto(ops.to_split(x, 2), 2, scale, bias, flags=ops.EPI_RELU, out_exp=1)
+            assert auto.algo == L_.ALGO_X3_Q16
     if stride == 1 and not transposed:      # every kernel form of a stride-1 layer gives the same values (same MFMA order per output)
         from snvc_amd import _lib
         xs0 = ops.to_split(x, 2)

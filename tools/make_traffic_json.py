@@ -25,8 +25,11 @@ KERNEL = {  # layer -> substring of the kernel whose LAST dispatch is reported
     "x3_conv2": "conv3d_x3q_kernel", "x3_hg2": "conv3d_x3q_kernel", "sheared_split": "sheared_expand_split_kernel",
     "general_split": "warped_expand_split_kernel", "general_f32": "warped_expand_win_kernel",
 }
-if ROUND >= "r4":
+KERNEL.update({"x3_s2": "conv3d_f16_kernel", "x3_hg5_tail": "conv3d_f16_kernel", "tail_gather": "deconv_tail_gather_kernel"})     # r5
+if ROUND == "r4":
     KERNEL = {k: v for k, v in KERNEL.items() if k in ("x3_conv2", "x3_hg2", "sheared_split", "general_split", "general_f32", "conv2_side")}
+if ROUND >= "r5":
+    KERNEL = {k: v for k, v in KERNEL.items() if k in ("x3_conv2", "x3_hg2", "x3_s2", "x3_hg5_tail", "tail_gather", "sheared_split", "general_split")}
 ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     "conv1_factored": 1472200704, "cost_volume": 1479869184, "cost_volume_right": 739934976, "cost_volume_bwd": 1479869184 + 2 * 3833856,
     "gather_proj": 2 * (786432 * 272 + 2 * 32 * 4096 * 4), "gather_uniform": 2 * (786432 * 272 + 2 * 32 * 4096 * 4),
@@ -42,6 +45,11 @@ ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     # fp32 projection; hg conv2 reads and writes a 64-channel pair at half resolution
     "x3_conv2": 2 * 735902208 + 22996944, "x3_hg2": 2 * 183975552, "sheared_split": 735902208, "general_split": 735902208,
     "general_f32": 735902208,
+    # r5: hg conv1 reads the 32-channel pair at full and writes the 64-channel pair at half resolution; conv5 + tail projection reads
+    # the 64-channel pair at quarter resolution and `pre` at half, writes 27 x 8 fp32 class planes; the gather reads those and
+    # classifier(v2), writes the cost
+    "x3_s2": 735902208 + 183975552, "x3_hg5_tail": 22996944 * 2 + 183975552 + 27 * 8 * 359424 * 4,
+    "tail_gather": 27 * 8 * 359424 * 4 + 2 * 22996944,
 }
 F32_MFMA_LAYERS = ("conv1_factored", "conv2_side", "hg_s2")
 SOURCE_OF = {"x3_conv2": ("snvc_amd/csrc/conv3d_f16.hip", "conv3d_x3q_kernel(const F16Args a) {"),
@@ -78,7 +86,7 @@ for layer, needle in KERNEL.items():
         entry["traffic_over_algorithmic"] = entry["hbm_bytes_corrected"] / ALGORITHMIC[layer]
     if "SQ_INSTS_MFMA" in entry and "GRBM_GUI_ACTIVE" in entry:
         # v_mfma_f32_32x32x2_f32: 64 cycles/SIMD; 32x32x16_f16: 32; 16x16x32_f16 (the split-mode 3x3x3 layers since late r4): 16
-        cyc = 64 if layer in F32_MFMA_LAYERS else 16 if layer.startswith("x3_") else 32
+        cyc = 64 if layer in F32_MFMA_LAYERS else 16 if layer in ("x3_conv2", "x3_hg2") else 32
         entry["mfma_pipe_frac"] = entry["SQ_INSTS_MFMA"] * cyc / (1024 * entry["GRBM_GUI_ACTIVE"] / 8)
     if layer in SOURCE_OF and len(entry) > 1:
         sys.path.insert(0, ROOT)

@@ -114,6 +114,22 @@ with torch.no_grad():
         flag_ = torch.zeros(1, dtype=torch.int32, device=dev)
         ys_ = lay(xs_, 4, flags=ops.EPI_RELU, out_exp=4, overflow=flag_)
         fn = lambda: lay(xs_, 4, flags=ops.EPI_RELU, out=ys_, out_exp=4, overflow=flag_)  # noqa: E731
+    elif args.layer in ("x3_hg5_tail", "tail_gather"):     # r5: hourglass conv5 (transposed 64->64 + pre, ReLU) with the tail projection; the gather
+        from snvc_amd import ops
+        q = (bench.D // 4, bench.H // 4, bench.W // 4)
+        xin = torch.relu(torch.randn(1, 64, *q, device=dev))
+        wt = torch.randn(64, 64, 3, 3, 3, device=dev) * 0.05
+        lay = ops.Conv3dLayerX3(wt, 3, 2, 1, 1, True)
+        tail = ops.TailWeightsX3(torch.randn(64, 27, device=dev) * 0.1)
+        xs_ = ops.to_split(xin, 4)
+        pre_ = ops.to_split(torch.relu(torch.randn(1, 64, *(2 * e for e in q), device=dev)), 3)
+        flag_ = torch.zeros(1, dtype=torch.int32, device=dev)
+        t_ = lay.forward_tail(xs_, 4, None, None, tail, residual=pre_, flags=ops.EPI_RELU | ops.EPI_ADD_PRE, out_exp=3, overflow=flag_)
+        hv_ = torch.randn(1, 1, bench.D, bench.H, bench.W, device=dev)
+        if args.layer == "x3_hg5_tail":
+            fn = lambda: lay.forward_tail(xs_, 4, None, None, tail, residual=pre_, flags=ops.EPI_RELU | ops.EPI_ADD_PRE, out_exp=3, overflow=flag_, out=t_)  # noqa: E731
+        else:
+            fn = lambda: ops.deconv_tail_gather(t_, None, hv_)  # noqa: E731
     elif args.layer in ("general_f32", "sheared_f32"):     # the fp32 expand kernels (arithmetic = fp32)
         model.arithmetic = "fp32"
         fn = lambda: model.forward_pair(left, right, shift, 1, sheared=args.layer == "sheared_f32")  # noqa: E731

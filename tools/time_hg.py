@@ -35,8 +35,8 @@ full, half, quarter = (192, 96, 312), (96, 48, 156), (48, 24, 78)
 flag = torch.zeros(1, dtype=torch.int32, device=dev)
 sc64, bi64 = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.2
 cases = [
-    ("hg conv1  s2 32->64  192x96x312 -> 96x48x156", 32, 64, 2, False, full, [("2x4x32", 0), ("1x4x32 (SMALL)", _lib.ALGO_X3_SMALL)]),
-    ("hg conv3  s2 64->64  96x48x156 -> 48x24x78", 64, 64, 2, False, half, [("2x4x32", 0), ("1x4x32 (SMALL)", _lib.ALGO_X3_SMALL)]),
+    ("hg conv1  s2 32->64  192x96x312 -> 96x48x156", 32, 64, 2, False, full, [("2x4x32", 0), ("q16 3 slots", _lib.ALGO_X3_Q16)]),
+    ("hg conv3  s2 64->64  96x48x156 -> 48x24x78", 64, 64, 2, False, half, [("2x4x32", 0), ("q16 3 slots", _lib.ALGO_X3_Q16)]),
     ("hg conv2  s1 64->64  96x48x156", 64, 64, 1, False, half, [("auto", None)]),
     ("hg conv4  s1 64->64  48x24x78", 64, 64, 1, False, quarter, [("auto", None), ("q16", _lib.ALGO_X3_Q16), ("serial 64", _lib.ALGO_X3_SERIAL),
                                                                ("narrow", _lib.ALGO_X3_NARROW)]),
