@@ -57,7 +57,9 @@ class GlobalStack(nn.Module):
             buf = ws[key] = torch.empty(shape, dtype=dtype, device=device)
         return buf
 
-    prep_streams = True      # the sheared first layer's two small 2D chains on side streams (False: all on the current stream, as r4)
+    # the sheared first layer's two small 2D chains on side streams: built and measured in r5 (tools/ab_step.py, interleaved legs):
+    # 2.185 ms/step against 2.130 on one stream -- the cross-stream event waits cost more than the chains' overlap buys.  Off.
+    prep_streams = False
 
     def _side_streams(self, device):
         st = self.__dict__.setdefault("_snvc_streams", {})

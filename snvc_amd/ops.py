@@ -1107,8 +1107,8 @@ def voxel_gather_forward_split(left, right, l_pts, r_pts, resolution, mul_dev) -
 X3_Q16 = [True]        # False: the 32x32x16 kernel forms everywhere (rounds up to mid r4)
 X3_Q16_K5 = [True]     # ... and the plain 5^3 layers (quads over all 125 taps)
 X3_Q16_S2 = [True]     # stride-2 3x3x3 layers with a split output and no residual: the 16x16x32 form (False: the serial-plane 32x32x16 form)
-X3_Q16_MIN_JOBS = [256]   # 3x3x3 layers: (tile, 32-channel block) jobs from which the 16x16x32 form is picked (r4: 1024; hg conv4 at cfg2 --
-#                           432 jobs -- 61.6 us against 74.5 for the 2x4x32-tile 32x32x16 form, tools/time_hg.py)
+X3_Q16_MIN_JOBS = [1024]  # 3x3x3 layers: (tile, 32-channel block) jobs from which the 16x16x32 form is picked (r5 tried 256 for hg conv4 at
+#                           cfg2, 432 jobs: 61.6 us against 62.2 for the 2x4x32-tile 32x32x16 form -- no difference in the step, tools/ab_step.py)
 
 
 class Conv3dLayerF16:
