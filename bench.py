@@ -101,6 +101,7 @@ def cpu_baseline(d_sample=D, outputs=None):
     from oracle import native as O
     from oracle import torch_ref as T
     cores = os.cpu_count() or 1
+    threads_before = torch.get_num_threads()
     torch.set_num_threads(cores)
     left, right, shift = make_inputs(0, "cpu", d_sample)
     ref = T.GlobalStack(C)
@@ -113,6 +114,7 @@ def cpu_baseline(d_sample=D, outputs=None):
     with torch.no_grad():
         cost = ref(torch.from_numpy(vol))
     t2 = time.perf_counter()
+    torch.set_num_threads(threads_before)
     scale = D / float(d_sample)
     if outputs is not None:
         outputs["cost"] = cost.numpy()
@@ -133,7 +135,7 @@ def local_inputs(grid, F, crops=1, seed=7):
             r.uniform(-8, 264, (crops, 2, v)).astype(np.float32), r.uniform(-8, 264, (crops, 2, v)).astype(np.float32))
 
 
-def local_oracle(grid, F, crops=1, seed=7, keep_layers=False):
+def local_oracle(grid, F, crops=1, seed=7, keep_layers=False, heads=False):
     """The CPU oracle of the local (V-A) model's path on `crops` crops: numpy restatement of _sample_2d_feat (vernier.py:323-349) +
     the torch-CPU restatement of the BEV_type3 3D trunk (vernier.py:414-438) that tests/golden pins bit-equal to the imported
     reference, with bench.seeded_state's weights of the product model.  Returns a dict: the inputs, "voxel", "bev", "occupancy" (host
@@ -141,14 +143,14 @@ def local_oracle(grid, F, crops=1, seed=7, keep_layers=False):
     from oracle import numpy_ref as NR
     from oracle import torch_ref as T
     from snvc_amd.models.vernier import VernierScale
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    cores = torch.get_num_threads()                    # torch's own default: the caller's process setting is left alone (a test
+    #                                                    process that is switched to os.cpu_count() threads on a 16-CPU share crawls)
     cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False, grid_resolution=[32, grid[1], 192],
                                 resolution=(256, 256), x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
     cfg.hrfeat = types.SimpleNamespace(output_channel=F, name="identity")
     cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
     sd = seeded_state(VernierScale(cfg))               # the product model's parameters (CPU construction: nothing runs)
-    ref = T.VernierTrunk(F, grid, heads=False)
+    ref = T.VernierTrunk(F, grid, heads=heads)      # heads: the 2D BEV neck + heat-map / coordinate heads too (grids with nh in {16, 32})
     ref.load_state_dict({k: sd[k] for k in ref.state_dict()})
     ref.eval()
     lf, rf, gl, gr = local_inputs(grid, F, crops, seed)
@@ -171,6 +173,8 @@ def local_oracle(grid, F, crops=1, seed=7, keep_layers=False):
             o["cat"] = torch.cat([o["vh"], o["img"] * occ], dim=1)
             v4 = ref.pool_3d(ref.conv4(o["cat"]))
             bev = v4.reshape(crops, -1, v4.shape[3], v4.shape[4])
+        if heads:                                    # vernier.py:440-450 (predict_3d_heatmaps' 2D half)
+            o["heat"], o["coords"] = ref.heads_2d(bev)
     t2 = time.perf_counter()
     o.update(voxel=vt, bev=bev, occupancy=occ, ref=ref, gather_s=t1 - t0, trunk_s=t2 - t1)
     return o
@@ -389,7 +393,12 @@ def local_parity(grid, F, device, precision, sample_grid=None):
     key = (g, F)
     if key not in _ORACLES:
         _ORACLES.clear()                                   # one oracle's tensors at a time
-        o = local_oracle(g, F, 1)
+        threads_before = torch.get_num_threads()
+        torch.set_num_threads(os.cpu_count() or 1)         # the CPU baseline runs on every host core (and says how many)
+        try:
+            o = local_oracle(g, F, 1)
+        finally:
+            torch.set_num_threads(threads_before)
         _ORACLES[key] = {k: o[k] for k in ("lf", "rf", "gl", "gr", "bev", "occupancy", "gather_s", "trunk_s", "cores")}
     o = _ORACLES[key]
     m = local_model(g, F, device)

@@ -192,3 +192,25 @@ def test_every_fp32_layer_on_the_oracles_input(case):
         check_t(m.fg_cls_head[2].fused(g("t"), sigmoid=True), o["occupancy"], TIGHT, "occupancy head")
         v4 = fused_conv3d_avgpool_d4(m.conv4[0][0], m.conv4[0][1], g("cat"), relu=True)
         check_t(v4.reshape(1, -1, o["grid"][1], o["grid"][2]), o["bev"], TIGHT, "conv4 k3 + AvgPool3d(4,1,1) fused")
+
+
+@pytest.mark.parametrize("precision", ["auto", "f32"])
+def test_whole_forward_at_the_released_shape_vs_oracle(precision):
+    """a8 at the size the reference's constants force (32 x 128 x 192, F = 32): ``VernierScale.forward`` -- gather, 3D trunk, the 2D BEV
+    neck and both heads -- against the oracle's ``predict_3d_heatmaps`` on the same crop: ``ncf`` [1,9,192,128], ``occupancy``,
+    ``coordinates`` on all elements, and the heat maps' arg-max indices (row a12: the integers the decode starts from)."""
+    import bench
+    grid, f = (32, 128, 192), 32
+    o = bench.local_oracle(grid, f, 1, heads=True)
+    m = bench.local_model(grid, f, dev())
+    m.precision = precision
+    lf, rf, gl, gr = (torch.from_numpy(o[k]).to(dev()) for k in ("lf", "rf", "gl", "gr"))
+    with torch.no_grad():
+        out = m(lf, rf, gl, gr)
+    tol = 3e-4 if precision == "f32" else 1e-4
+    check_t(out["ncf"], o["heat"], tol, f"released shape [{precision}]: ncf vs oracle")
+    check_t(out["occupancy"], o["occupancy"].squeeze(1), tol, f"released shape [{precision}]: occupancy vs oracle")
+    check_t(out["coordinates"], o["coords"], tol, f"released shape [{precision}]: coordinates vs oracle")
+    got_idx = out["ncf"].flatten(2).argmax(dim=2).cpu()
+    exp_idx = o["heat"].flatten(2).argmax(dim=2)
+    assert torch.equal(got_idx, exp_idx), "heat-map arg-max indices differ from the oracle's"
