@@ -100,9 +100,11 @@ def cpu_baseline(d_sample=D, outputs=None):
     oracle's result (left in ``outputs["cost"]``) is what every timed leg of the GPU line has to reproduce."""
     from oracle import native as O
     from oracle import torch_ref as T
-    cores = os.cpu_count() or 1
-    threads_before = torch.get_num_threads()
-    torch.set_num_threads(cores)
+    # torch's own default thread count: on the GPU box (256 logical CPUs, a 16-CPU share per GPU) forcing os.cpu_count() threads made
+    # the torch-CPU stack 2-4x SLOWER than the default (r5: the 96^3 trunk 15.9 s at 256 threads, 4.3 s at the default) -- the
+    # baseline is the faster setting, and `cores` says how many threads that was
+    cores = torch.get_num_threads()
+    threads_before = cores
     left, right, shift = make_inputs(0, "cpu", d_sample)
     ref = T.GlobalStack(C)
     ref.load_state_dict(seeded_state(ref))
@@ -121,8 +123,8 @@ def cpu_baseline(d_sample=D, outputs=None):
     return {
         "value": 1.0 / ((t2 - t0) * scale), "unit": "stereo-pairs/s", "cores": cores, "kind": "port",
         "sample": f"1 pair, {d_sample} of {D} disparity planes{'' if d_sample == D else ' (scaled)'}: {t2 - t0:.2f}s = "
-                  f"cost volume (C oracle, OpenMP, {cores} threads) {t1 - t0:.2f}s + 3D stack (torch-CPU {torch.__version__}, "
-                  f"{cores} threads) {t2 - t1:.2f}s",
+                  f"cost volume (C oracle, OpenMP, {os.cpu_count()} logical CPUs visible) {t1 - t0:.2f}s + 3D stack (torch-CPU {torch.__version__}, "
+                  f"{cores} threads = torch's default here) {t2 - t1:.2f}s",
     }
 
 
@@ -393,12 +395,7 @@ def local_parity(grid, F, device, precision, sample_grid=None):
     key = (g, F)
     if key not in _ORACLES:
         _ORACLES.clear()                                   # one oracle's tensors at a time
-        threads_before = torch.get_num_threads()
-        torch.set_num_threads(os.cpu_count() or 1)         # the CPU baseline runs on every host core (and says how many)
-        try:
-            o = local_oracle(g, F, 1)
-        finally:
-            torch.set_num_threads(threads_before)
+        o = local_oracle(g, F, 1)                           # torch's default thread count (see cpu_baseline)
         _ORACLES[key] = {k: o[k] for k in ("lf", "rf", "gl", "gr", "bev", "occupancy", "gather_s", "trunk_s", "cores")}
     o = _ORACLES[key]
     m = local_model(g, F, device)
