@@ -287,6 +287,16 @@ class GlobalStack(nn.Module):
             # built from these two features: its maximum is theirs (interpolation weights are in [0, 1]), if they are untouched
             # ... and the volume itself: one that was written to in place (vol.mul_(8)) no longer has their maximum
             scale_from = tuple(volume.sources[:2]) if volume.is_pristine else None
+            # the 1.47 GB volume is built and conv1 runs over all 64 channels (about half the pairs/s of the fused path): said once
+            # per model, with the reason, and counted ("documented, not reported per call")
+            _ROUTES["lazy_volume_materialized"] += 1
+            if not self.__dict__.get("_snvc_lazy_warned"):
+                self.__dict__["_snvc_lazy_warned"] = True
+                why = ("autograd is enabled" if torch.is_grad_enabled() else "the model is in training mode" if self.training else
+                       "the volume or its sources were written to after build_cost_volume" if not volume.is_pristine else
+                       "the feature shape is outside the fused first layer's (2C input channels, W % 4 == 0)")
+                warnings.warn("snvc_amd: model(build_cost_volume(...)) is taking the MATERIALISED route (the whole concat volume is built): "
+                              + why + ".  forward_pair(left, right, shift) is the fused entry point.")
             return self._forward_volume(volume.materialize(), scale_from=scale_from)
         return self._forward_volume(volume)
 

@@ -25,7 +25,7 @@ KERNEL = {  # layer -> substring of the kernel whose LAST dispatch is reported
     "x3_conv2": "conv3d_x3q_kernel", "x3_hg2": "conv3d_x3q_kernel", "sheared_split": "sheared_expand_split_kernel",
     "general_split": "warped_expand_split_kernel", "general_f32": "warped_expand_win_kernel",
 }
-KERNEL.update({"x3_s2": "conv3d_f16_kernel", "x3_hg5_tail": "conv3d_f16_kernel", "tail_gather": "deconv_tail_gather_kernel"})     # r5
+KERNEL.update({"x3_s2": "conv3d_x3s2q_kernel", "x3_hg5_tail": "conv3d_f16_kernel", "tail_gather": "deconv_tail_gather_kernel"})     # r5
 if ROUND == "r4":
     KERNEL = {k: v for k, v in KERNEL.items() if k in ("x3_conv2", "x3_hg2", "sheared_split", "general_split", "general_f32", "conv2_side")}
 if ROUND >= "r5":
@@ -52,7 +52,8 @@ ALGORITHMIC = {  # bytes per launch (SURVEY.md section 8d formulas)
     "tail_gather": 27 * 8 * 359424 * 4 + 2 * 22996944,
 }
 F32_MFMA_LAYERS = ("conv1_factored", "conv2_side", "hg_s2")
-SOURCE_OF = {"x3_conv2": ("snvc_amd/csrc/conv3d_f16.hip", "conv3d_x3q_kernel(const F16Args a) {"),
+SOURCE_OF = {"x3_s2": ("snvc_amd/csrc/conv3d_f16.hip", "conv3d_x3s2q_kernel(const F16Args a, const int total_jobs) {"),
+             "x3_conv2": ("snvc_amd/csrc/conv3d_f16.hip", "conv3d_x3q_kernel(const F16Args a) {"),
              "x3_hg2": ("snvc_amd/csrc/conv3d_f16.hip", "conv3d_x3q_kernel(const F16Args a) {")}
 
 
@@ -86,7 +87,7 @@ for layer, needle in KERNEL.items():
         entry["traffic_over_algorithmic"] = entry["hbm_bytes_corrected"] / ALGORITHMIC[layer]
     if "SQ_INSTS_MFMA" in entry and "GRBM_GUI_ACTIVE" in entry:
         # v_mfma_f32_32x32x2_f32: 64 cycles/SIMD; 32x32x16_f16: 32; 16x16x32_f16 (the split-mode 3x3x3 layers since late r4): 16
-        cyc = 64 if layer in F32_MFMA_LAYERS else 16 if layer in ("x3_conv2", "x3_hg2") else 32
+        cyc = 64 if layer in F32_MFMA_LAYERS else 16 if layer in ("x3_conv2", "x3_hg2", "x3_s2") else 32
         entry["mfma_pipe_frac"] = entry["SQ_INSTS_MFMA"] * cyc / (1024 * entry["GRBM_GUI_ACTIVE"] / 8)
     if layer in SOURCE_OF and len(entry) > 1:
         sys.path.insert(0, ROOT)
