@@ -575,6 +575,30 @@ SNVC_API int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *desc_host, const 
  *       class = rd*4 + rh*2 + rw, (pd, ph, pw) over the layer's INPUT grid; fp32, dense; tail_mul = 2^-(e_y + w_exp);
  *   snvc_deconv_tail_gather:           y[n][o] = bias[0] + residual[n][o] + sum over (i, k) with o = 2 i - 1 + k per dimension of
  *       t[n][k][i]; (nd, nh, nw) = the grid of t's classes, y / residual [N][4nd][4nh][4nw] fp32 (residual, bias may be NULL). */
+/* r5: the depth-1 (2D) layers of the sheared first convolution in split mode -- G / G' = a 3x7 convolution of the upsampled right
+ * feature, the left half's depth-class planes = a 3x3 one (reference: the composition BuildCostVolume_cuda.cu:63-98 +
+ * submodule.py:32-50) -- three v_mfma_f32_16x16x32_f16 per fp32 product instead of the fp32 matrix pipe.
+ *   snvc_sheared_upsample_split: snvc_sheared_upsample writing the split pair [N][2][C/8][H][WU][8], value * *mul_dev = hi + lo;
+ *   snvc_f16x3_conv2d_pack_weights: weight [Cout][Cin][kh][kw] fp32 ((kh, kw) in {(3,7), (3,3)}, Cin % 8 == 0, Cout % 32 == 0) * wmul;
+ *   snvc_f16x3_conv2d_forward: y[n][co][h][w] = act(scale[co] * out_mul / *x_mul_dev * conv(x)[..] + bias[co]), fp32, stride 1, "same"
+ *     zero padding; x = the split pair (hi, lo planes), x_mul_dev (device scalar, may be NULL = 1) what it was multiplied by. */
+/* out_mul[0] = the power of two that puts max|x| (n floats, 16-byte aligned) into [2^13, 2^14); 1 for an all-zero or non-finite tensor.
+ * One launch, no host round trip; scratch8 = 8 bytes of device memory, ZERO before the first call (the kernel leaves it zero). */
+SNVC_API int snvc_f16x3_split_scale(const float *x, int64_t n, void *scratch8, float *out_mul, void *stream);
+SNVC_API int snvc_sheared_upsample_split(const float *right, void *y_hi, void *y_lo, const float *mul_dev, int64_t N, int64_t C,
+                                         int64_t H, int64_t W, int q, int64_t WU, int off, void *stream);
+/* all of it in one host call (snvc_f16x3_split_scale, two snvc_sheared_upsample_split, two 3x7 snvc_f16x3_conv2d_forward): rq_split /
+ * rq2_split = workspaces of N*2*C*H*WU / N*2*C*H*WU2 halves, g / gcol [N][Cout3][H][WU | WU2] fp32, out_mul_* = 2^-w_exp of the packings */
+SNVC_API int snvc_sheared_prep_x3(const float *right, int64_t N, int64_t C, int64_t H, int64_t W, int q, int64_t WU, int off,
+                                  int64_t WU2, int off2, const void *packed_g, const void *packed_col, int64_t Cout3, float out_mul_g,
+                                  float out_mul_col, void *rq_split, void *rq2_split, void *scratch8, float *mul_dev, float *g,
+                                  float *gcol, void *stream);
+SNVC_API int64_t snvc_f16x3_conv2d_packed_weight_bytes(int cout, int cin, int kh, int kw);
+SNVC_API int snvc_f16x3_conv2d_pack_weights(const float *weight, int cout, int cin, int kh, int kw, void *packed, float wmul,
+                                            void *stream);
+SNVC_API int snvc_f16x3_conv2d_forward(const void *x_hi, const void *x_lo, const void *packed_weight, const float *scale,
+                                       const float *bias, float *y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W,
+                                       int kh, int kw, float out_mul, const float *x_mul_dev, int flags, void *stream);
 SNVC_API int64_t snvc_f16x3_tail_packed_weight_bytes(int cin);
 SNVC_API int snvc_f16x3_tail_pack_weights(const float *weight, int cin, void *packed, float wmul, void *stream);
 SNVC_API int snvc_f16x3_deconv3d_tail_forward(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,

@@ -59,6 +59,7 @@ struct F16Args {
     float *t_out;
     float tail_mul;           // 2^-(e_y + w_exp): exact
     int64_t t_bs;             // floats between samples of t_out
+    const float *x_mul;       // conv2d_x3q_kernel: device scalar the input pair was multiplied by (a power of two from its own maximum), or NULL
     int CGin;            // input channel groups (Cin / 8, rounded up)
     int Cout;
     int Din, Hin, Win;
@@ -856,6 +857,187 @@ conv3d_x3q_kernel(const F16Args a) {
         }
     }
     if (vmax >= kHalfMax && a.overflow) atomicOr(a.overflow, 1);
+}
+
+// ------------------------------------------------------------------------- depth-1 (2D) layers in split mode (r5)
+// The sheared first layer's prep -- G = a depth-1 3x7 convolution of the upsampled right feature, 32 -> 96 channels, and its small
+// relatives (G', the left half's 3x3 depth-class planes) -- ran on the fp32 matrix pipe: 7.8 GFLOP at 93 TFLOP/s = 84 us of a
+// 2.1 ms step whose other layers had all moved to the 16x faster half pipe.  Same scheme as conv3d_x3q_kernel (three
+// v_mfma_f32_16x16x32_f16 per fp32 product on (hi, lo) pairs, K = 32 = four taps of one C8 piece, image double-buffered and refilled
+// late under hand-counted waits), on a 2D tile: 16 rows x 32 columns x 32 output channels per workgroup, taps in (kh, kw) raster order
+// (3x7: 21 taps in 6 quads; 3x3: 9 in 3).  The result leaves as plain fp32 [N][Cout][H][W] times `head_mul` (the expand pass that
+// consumes G applies the layer's affine itself); the input's scale is read from the device (`x_mul`: the feature's own maximum).
+template <int KH_, int KW_>
+struct X2QCfg {
+    static constexpr int KH = KH_, KW = KW_, TH = 16, NB = 4, IN_H = TH + KH - 1, IN_W = 32 + KW - 1, VOX = IN_H * IN_W, GB = VOX * 16;
+    static constexpr int ITEMS = 2 * VOX, PLANE_BYTES = GB, NIT = (ITEMS + 255) / 256;
+    static constexpr int IMG_BYTES = NIT * 256 * 16, LDS_BYTES = 2 * IMG_BYTES;
+    static constexpr int TAPS = KH * KW, NQ = (TAPS + 3) / 4, PF = 2, FILL_STEP = NQ - PF;
+    static_assert(NQ > PF, "the refill is issued PF k-steps before the chunk ends");
+};
+
+template <class Cfg>
+__global__ void __launch_bounds__(256, 2)
+conv2d_x3q_kernel(const F16Args a) {
+    constexpr int NB = Cfg::NB, IN_W = Cfg::IN_W, VOX = Cfg::VOX, NIT = Cfg::NIT, NQ = Cfg::NQ;
+    constexpr int ITEMS = Cfg::ITEMS, PF = Cfg::PF;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kb = lane >> 4, col = lane & 15;
+    const int ntiles = a.tiles_h * a.tiles_w, cblocks = a.Cout >> 5;
+    const int job = xcd_remap16(blockIdx.x, ntiles * cblocks);
+    const int t = job / cblocks, cb = job - t * cblocks;
+    const int tw = t % a.tiles_w, th = t / a.tiles_w;
+    const int64_t n = blockIdx.z;
+    const int oh0 = th * Cfg::TH, ow0 = tw * 32;
+    const int ih0 = oh0 - a.pad_h, iw0 = ow0 - a.pad_w;
+
+    f32x4q acc[NB][2][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[nb][ph][h] = f32x4q{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int in_hw = a.Hin * a.Win;
+    unsigned off[NIT];
+    unsigned vmask = 0, pmask = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + tid;
+        const int plane = i / VOX, r = i - plane * VOX;
+        pmask |= (unsigned)(plane & 1) << it;
+        const int hh = r / IN_W, ww = r - hh * IN_W;
+        const int gh = ih0 + hh, gw = iw0 + ww;
+        const bool ok = i < ITEMS && (unsigned)gh < (unsigned)a.Hin && (unsigned)gw < (unsigned)a.Win;
+        off[it] = ok ? (unsigned)(gh * a.Win + gw) : 0u;
+        vmask |= (ok ? 1u : 0u) << it;
+    }
+    const _Float16 *xn = a.x + n * a.x_bs, *xn_lo = a.x_lo + n * a.x_bs;
+    const int wbase = tid & ~63;
+    auto issue = [&](int chunk, int buf) {
+        const int64_t coff = (int64_t)chunk * in_hw * 8;
+        char *const ibuf = lds + buf * Cfg::IMG_BYTES;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const _Float16 *xc = (((pmask >> it) & 1u) ? xn_lo : xn) + coff;
+            const void *src = ((vmask >> it) & 1u) ? static_cast<const void *>(xc + (size_t)off[it] * 8) : static_cast<const void *>(g_zero16h);
+            __builtin_amdgcn_global_load_lds(static_cast<const float *>(src), reinterpret_cast<float *>(ibuf + (it * 256 + wbase) * 16), 16, 0, 0);
+        }
+    };
+    int qoff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        int tp = 4 * q + kb;
+        tp = tp < Cfg::TAPS ? tp : Cfg::TAPS - 1;       // a slot beyond the last tap: zero weights, the last tap's piece
+        qoff[q] = ((tp / Cfg::KW) * IN_W + tp % Cfg::KW + col) * 16;
+    }
+    int rowoff[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) rowoff[nb] = (wave * NB + nb) * IN_W * 16;
+    const int64_t steps_total = (int64_t)a.nchunks * NQ;
+    const h8 *wq = reinterpret_cast<const h8 *>(a.wp) + ((int64_t)cb * steps_total * 4) * 64 + lane;
+    h8 q_[PF][4];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) q_[i][m] = wq[m * 64];
+        wq += 4 * 64;
+    }
+
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)lds;
+    issue(0, 0);
+    __syncthreads();
+    for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+        const unsigned img = lds_base + (unsigned)((chunk & 1) * Cfg::IMG_BYTES);
+        const bool more = chunk + 1 < a.nchunks;
+        h8 bfr[2][8];      // [buffer][(row of the half-step) * 4 + (row half) * 2 + plane]
+        auto load_b = [&](int buf, int hs) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const unsigned addr = img + (unsigned)(qoff[hs >> 1] + rowoff[2 * (hs & 1) + rr]);
+                lds_read_b128_to<0>(bfr[buf][rr * 4 + 0], addr);
+                lds_read_b128_to<Cfg::PLANE_BYTES>(bfr[buf][rr * 4 + 1], addr);
+                lds_read_b128_to<256>(bfr[buf][rr * 4 + 2], addr);
+                lds_read_b128_to<Cfg::PLANE_BYTES + 256>(bfr[buf][rr * 4 + 3], addr);
+            }
+        };
+        load_b(0, 0);
+        h8 af[4];
+#pragma unroll
+        for (int hs = 0; hs < 2 * NQ; ++hs) {
+            const int cur = hs & 1, nx = cur ^ 1;
+            if ((hs & 1) == 0) {
+                if (hs == 2 * Cfg::FILL_STEP) {
+                    // every weight fragment in flight lands first: none is waited for between here and the barrier
+#pragma unroll
+                    for (int i = 0; i < PF; ++i) asm volatile("" ::"v"(q_[i][0]), "v"(q_[i][1]), "v"(q_[i][2]), "v"(q_[i][3]));
+                    if (more) issue(chunk + 1, (chunk + 1) & 1);
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) af[m] = q_[0][m];
+#pragma unroll
+                for (int i = 0; i + 1 < PF; ++i)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) q_[i][m] = q_[i + 1][m];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) q_[PF - 1][m] = wq[m * 64];      // from k-step FILL_STEP on: fragments of the NEXT chunk
+                wq += 4 * 64;
+            }
+            if (hs + 1 < 2 * NQ) {
+                load_b(nx, hs + 1);
+                wait_lgkm_for<8>(bfr[cur]);
+            } else {
+                wait_lgkm_for<0>(bfr[cur]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const h8 aw = term == 0 ? af[2 * h + 1] : af[2 * h];
+                            const h8 bx = bfr[cur][rr * 4 + ph * 2 + (term == 1 ? 1 : 0)];
+                            acc[2 * (hs & 1) + rr][ph][h] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_f16(aw, bx, acc[2 * (hs & 1) + rr][ph][h], 0, 0, 0);
+                        }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();     // drains the DMA of the next chunk and retires every read of this chunk's buffer
+    }
+
+    // epilogue: lane (kb, col) holds channels cb * 32 + 8 kb + e of columns col / col + 16 of its four rows; fp32 [N][Cout][H][W]
+    const int64_t out_hw = (int64_t)a.Hout * a.Wout;
+    const bool relu = (a.flags & SNVC_EPI_RELU) != 0;
+    const int c0 = cb * 32 + 8 * kb;
+    const float xm = a.x_mul ? a.head_mul / a.x_mul[0] : a.head_mul;
+    float sc[8], bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = (a.scale ? a.scale[c0 + e] : 1.0f) * xm;
+        bi[e] = a.scale ? a.bias[c0 + e] : 0.0f;
+    }
+    float *yn = a.y_f32 + n * a.yf_bs + (int64_t)c0 * out_hw;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int phh = oh0 + wave * NB + nb;
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph) {
+            const int pw = ow0 + 16 * ph + col;
+            if (phh < a.nh && pw < a.nw) {
+                float *yp = yn + (int64_t)phh * a.Wout + pw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = __builtin_fmaf(acc[nb][ph][e >> 2][e & 3], sc[e], bi[e]);
+                    if (relu) v = __builtin_fmaxf(v, 0.0f);
+                    yp[e * out_hw] = v;
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------- 16x16x32 form of the stride-2 3x3x3 split layer (r5)
@@ -1788,6 +1970,40 @@ deconv_tail_gather_kernel(const float *__restrict__ t, const float *__restrict__
     *reinterpret_cast<f32x4 *>(y + n * y_bs + sp) = f32x4{o0, o1, o2, o3};
 }
 
+// The power of two that puts max|x| into [2^13, 2^14) (1 for an all-zero or non-finite tensor) -- the scale of a split pair whose range is
+// only known from the data -- in ONE launch (r5; the torch expression it replaces was ten small launches): every workgroup folds its
+// share into scratch[0] (float bits of a non-negative maximum order like unsigned integers), the last one to arrive (scratch[1]) turns
+// the maximum into the scale and leaves both words zero for the next call.  NaNs do not take part (fmaxf drops them), +-inf gives 1.
+__global__ void __launch_bounds__(256)
+split_scale_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict__ scratch, float *__restrict__ out) {
+    float m = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    const int64_t n4 = n & ~(int64_t)3;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n4; i += stride) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + i);
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
+                                               __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4)) m = __builtin_fmaxf(m, __builtin_fabsf(x[n4 + threadIdx.x]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = __builtin_fmaxf(__builtin_fmaxf(part[0], part[1]), __builtin_fmaxf(part[2], part[3]));
+        atomicMax(scratch, __builtin_bit_cast(unsigned, m));
+        __threadfence();
+        if (atomicAdd(scratch + 1, 1u) == gridDim.x - 1) {
+            const float amax = __builtin_bit_cast(float, atomicExch(scratch, 0u));
+            atomicExch(scratch + 1, 0u);
+            float e = floorf(log2f(16384.0f / amax));          // amax = 0 -> +inf, amax = inf -> -inf: "not finite" below
+            e = (e == e && __builtin_fabsf(e) < 3.0e38f) ? __builtin_fminf(__builtin_fmaxf(e, -24.0f), 40.0f) : 0.0f;
+            out[0] = exp2f(e);
+        }
+    }
+}
+
 template <class Cfg, int EPI>
 void launch_f16(const F16Args &a, dim3 grid, hipStream_t st) {
     static std::atomic<unsigned> attr_done{0};
@@ -2159,6 +2375,106 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
                               int *overflow, void *stream) {
     return f16x3_forward(d, x_hi, x_lo, packed_weight, scale, bias, res_hi, res_lo, y_hi, y_lo, y_f32, head, y_head, head_mul, res_mul,
                          overflow, nullptr, nullptr, 0.0f, stream);
+}
+
+int snvc_f16x3_split_scale(const float *x, int64_t n, void *scratch8, float *out_mul, void *stream) {
+    using namespace snvc;
+    if (n < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_split_scale: negative size");
+    if (!out_mul || !scratch8 || (n > 0 && !x)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_split_scale: null pointer");
+    if (reinterpret_cast<uintptr_t>(x) & 15) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_split_scale: x must be 16-byte aligned");
+    int blocks = (int)ceil_div<int64_t>(n > 0 ? n : 1, 256 * 4 * 4);
+    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    split_scale_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, n, reinterpret_cast<unsigned *>(scratch8), out_mul);
+    return check_launch("snvc_f16x3_split_scale");
+}
+
+// ---- depth-1 (2D) split layers: 3x7 and 3x3, stride 1, "same" padding, Cin % 8 == 0, Cout % 32 == 0
+static int x2q_nq(int kh, int kw) { return (kh * kw + 3) / 4; }
+
+int64_t snvc_f16x3_conv2d_packed_weight_bytes(int cout, int cin, int kh, int kw) {
+    if (cout <= 0 || cin <= 0 || cout % 32 || cin % 8 || kh != 3 || (kw != 3 && kw != 7)) return -1;
+    return 2 * ((int64_t)(cout / 32) * (cin / 8) * x2q_nq(kh, kw) + 2) * 4 * 64 * 8;      // + the weight ring's read-ahead
+}
+
+int snvc_f16x3_conv2d_pack_weights(const float *weight, int cout, int cin, int kh, int kw, void *packed, float wmul, void *stream) {
+    using namespace snvc;
+    const int64_t bytes = snvc_f16x3_conv2d_packed_weight_bytes(cout, cin, kh, kw);
+    if (bytes < 0) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv2d: 3x7 or 3x3 kernels, Cin % 8 == 0, Cout % 32 == 0");
+    if (!weight || !packed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv2d_pack_weights: null pointer");
+    if (hipMemsetAsync(packed, 0, (size_t)bytes, as_stream(stream)) != hipSuccess)
+        return fail(SNVC_ERR_HIP, "snvc_f16x3_conv2d_pack_weights: hipMemsetAsync failed");
+    const int nq = x2q_nq(kh, kw);
+    const int64_t total = (int64_t)(cout / 32) * (cin / 8) * nq * 4 * 64 * 8;
+    // [cb][chunk][quad][co half][hi | lo][lane][8] over the (kh, kw) raster: the 3x3x3 form's packer with K3 = kh * kw taps
+    pack_q16s_weights_kernel<<<(unsigned)ceil_div<int64_t>(total, 256), 256, 0, as_stream(stream)>>>(
+        weight, reinterpret_cast<_Float16 *>(packed), cout, cin, kh * kw, 1, 4 * nq, nq, cin / 8, 2, 2, 1, wmul, total);
+    return check_launch("snvc_f16x3_conv2d_pack_weights");
+}
+
+int snvc_f16x3_conv2d_forward(const void *x_hi, const void *x_lo, const void *packed_weight, const float *scale, const float *bias,
+                              float *y, int64_t N, int64_t Cin, int64_t Cout, int64_t H, int64_t W, int kh, int kw, float out_mul,
+                              const float *x_mul_dev, int flags, void *stream) {
+    using namespace snvc;
+    if (N < 0 || H <= 0 || W <= 0 || snvc_f16x3_conv2d_packed_weight_bytes((int)Cout, (int)Cin, kh, kw) < 0)
+        return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv2d_forward: 3x7 or 3x3 kernels, Cin % 8 == 0, Cout % 32 == 0");
+    if (N == 0) return SNVC_OK;
+    if (!x_hi || !x_lo || !packed_weight || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv2d_forward: null pointer");
+    if ((scale == nullptr) != (bias == nullptr))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv2d_forward: scale and bias must both be given or both be NULL");
+    if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv2d_forward: only SNVC_EPI_RELU");
+    if ((reinterpret_cast<uintptr_t>(x_hi) | reinterpret_cast<uintptr_t>(x_lo) | reinterpret_cast<uintptr_t>(packed_weight)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv2d_forward: C8 tensors must be 16-byte aligned");
+    const int64_t hw = H * W;
+    if ((Cin / 8 + 2) * hw >= ((int64_t)1 << 31) || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv2d_forward: tensor too large");
+    F16Args a{};
+    a.x = reinterpret_cast<const _Float16 *>(x_hi); a.x_lo = reinterpret_cast<const _Float16 *>(x_lo);
+    a.wp = reinterpret_cast<const _Float16 *>(packed_weight);
+    a.scale = scale; a.bias = bias; a.y_f32 = y; a.head_mul = out_mul; a.x_mul = x_mul_dev;
+    a.CGin = (int)(Cin / 8); a.Cout = (int)Cout; a.nchunks = (int)(Cin / 8); a.flags = flags;
+    a.Din = a.Dout = 1; a.Hin = a.Hout = (int)H; a.Win = a.Wout = (int)W;
+    a.nd = 1; a.nh = (int)H; a.nw = (int)W;
+    a.pad_d = 0; a.pad_h = (kh - 1) / 2; a.pad_w = (kw - 1) / 2;
+    a.tiles_d = 1; a.tiles_h = (int)ceil_div<int64_t>(H, 16); a.tiles_w = (int)ceil_div<int64_t>(W, 32);
+    a.x_bs = 2 * Cin * hw; a.yf_bs = Cout * hw; a.N = (int)N;
+    const int64_t jobs = (int64_t)a.tiles_h * a.tiles_w * (Cout / 32);
+    if (jobs >= ((int64_t)1 << 30)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv2d_forward: too many tiles");
+    const dim3 grid((unsigned)jobs, 1, (unsigned)N);
+    hipStream_t st = as_stream(stream);
+    if (kw == 7) {
+        using C = X2QCfg<3, 7>;
+        static std::atomic<unsigned> at{0};
+        if (allow_large_lds(reinterpret_cast<const void *>(&conv2d_x3q_kernel<C>), C::LDS_BYTES, at)) conv2d_x3q_kernel<C><<<grid, 256, C::LDS_BYTES, st>>>(a);
+    } else {
+        using C = X2QCfg<3, 3>;
+        static std::atomic<unsigned> at{0};
+        if (allow_large_lds(reinterpret_cast<const void *>(&conv2d_x3q_kernel<C>), C::LDS_BYTES, at)) conv2d_x3q_kernel<C><<<grid, 256, C::LDS_BYTES, st>>>(a);
+    }
+    return check_launch("snvc_f16x3_conv2d_forward");
+}
+
+// The sheared first layer's whole 2D prep in ONE host call (five launches: scale, Rq -> G, Rq' -> G'): behind the step's one host
+// sync the GPU is empty, and five Python-level launches of 5-20 us kernels starve it (measured: +0.08-0.14 ms per step against
+// the same kernels queued by a host that runs ahead).
+extern "C" int snvc_sheared_upsample_split(const float *, void *, void *, const float *, int64_t, int64_t, int64_t, int64_t, int, int64_t, int, void *);
+int snvc_sheared_prep_x3(const float *right, int64_t N, int64_t C, int64_t H, int64_t W, int q, int64_t WU, int off, int64_t WU2, int off2,
+                         const void *packed_g, const void *packed_col, int64_t Cout3, float out_mul_g, float out_mul_col, void *rq_split,
+                         void *rq2_split, void *scratch8, float *mul_dev, float *g, float *gcol, void *stream) {
+    using namespace snvc;
+    if (!right || !packed_g || !packed_col || !rq_split || !rq2_split || !scratch8 || !mul_dev || !g || !gcol)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_prep_x3: null pointer");
+    if (N <= 0 || C % 8 || Cout3 % 32) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_prep_x3: C % 8 == 0, 3 * Cout % 32 == 0");
+    int rc = snvc_f16x3_split_scale(right, N * C * H * W, scratch8, mul_dev, stream);
+    if (rc) return rc;
+    const int64_t G = C / 8;
+    _Float16 *a = reinterpret_cast<_Float16 *>(rq_split), *b = reinterpret_cast<_Float16 *>(rq2_split);
+    rc = snvc_sheared_upsample_split(right, a, a + G * H * WU * 8, mul_dev, N, C, H, W, q, WU, off, stream);
+    if (rc) return rc;
+    rc = snvc_f16x3_conv2d_forward(a, a + G * H * WU * 8, packed_g, nullptr, nullptr, g, N, C, Cout3, H, WU, 3, 7, out_mul_g, mul_dev, 0, stream);
+    if (rc) return rc;
+    rc = snvc_sheared_upsample_split(right, b, b + G * H * WU2 * 8, mul_dev, N, C, H, W, q, WU2, off2, stream);
+    if (rc) return rc;
+    return snvc_f16x3_conv2d_forward(b, b + G * H * WU2 * 8, packed_col, nullptr, nullptr, gcol, N, C, Cout3, H, WU2, 3, 7, out_mul_col, mul_dev, 0,
+                                     stream);
 }
 
 int64_t snvc_f16x3_tail_packed_weight_bytes(int cin) {

@@ -49,6 +49,43 @@ sheared_upsample_kernel(const float *__restrict__ r, float *__restrict__ out, in
     out[idx] = v;
 }
 
+// sheared_upsample_kernel with the result written as a split C8 pair [N][2][C/8][H][WU][8] (r5: the 3x7 layer that reads it runs in
+// split mode): value * *mul_dev = hi + lo.  A thread = one position of one 8-channel group.
+typedef _Float16 h8u __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(256)
+sheared_upsample_split_kernel(const float *__restrict__ r, _Float16 *__restrict__ yh, _Float16 *__restrict__ yl, const float *__restrict__ mul_dev,
+                              int C, int H, int W, int q, int WU, int off, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // ((n * G + g) * H + h) * WU + i
+    if (idx >= total) return;
+    const int i = (int)(idx % WU), u = i - off;
+    const int64_t t = idx / WU;
+    const int h = (int)(t % H);
+    const int64_t ng = t / H;
+    const int G = (C + 7) >> 3, g = (int)(ng % G);
+    const int64_t n = ng / G;
+    const float mul = mul_dev[0];
+    h8u hi, lo;
+    const bool in = u >= 0 && u <= q * (W - 1);
+    const int j = in ? u / q : 0;
+    const bool whole = u - j * q == 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float v = 0.0f;
+        const int co = g * 8 + c;
+        if (in && co < C) {
+            const float *rr = r + ((n * C + co) * (int64_t)H + h) * W;
+            v = whole ? rr[j] : 0.5f * rr[j] + 0.5f * rr[j + 1];
+        }
+        v *= mul;
+        hi[c] = (_Float16)v;
+        lo[c] = (_Float16)(v - (float)hi[c]);
+    }
+    // [N][2 (hi | lo)][G][H][WU] pieces: a sample's two planes sit next to each other
+    const int64_t pos = ((n * 2 * G + g) * (int64_t)H + h) * WU + i;
+    *reinterpret_cast<h8u *>(yh + pos * 8) = hi;
+    *reinterpret_cast<h8u *>(yl + pos * 8) = lo;
+}
+
 // One workgroup = RB rows of one (n, co) plane; thread = (row, quad of 4 columns) and walks d = 1 .. D-2.
 // Window: the thread's four values G[i0 + q*k], k = 0..3, with i0 = q*4*quad - d - m0 + off.  For q = 2 the even- and the
 // odd-indexed elements of a G row are kept as two LDS arrays, so a window is 4 CONSECUTIVE elements of one of them and
@@ -1315,6 +1352,22 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
 }  // namespace snvc
 
 extern "C" {
+
+int snvc_sheared_upsample_split(const float *right, void *y_hi, void *y_lo, const float *mul_dev, int64_t N, int64_t C, int64_t H, int64_t W,
+                                int q, int64_t WU, int off, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || (q != 1 && q != 2) || WU <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_upsample_split: bad sizes (q in {1,2})");
+    if (N == 0) return SNVC_OK;
+    if (!right || !y_hi || !y_lo || !mul_dev) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_upsample_split: null pointer");
+    if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_upsample_split: y must be 16-byte aligned");
+    const int64_t total = N * ((C + 7) / 8) * H * WU;
+    if (ceil_div<int64_t>(total, 256) >= ((int64_t)1 << 31)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_upsample_split: too large");
+    sheared_upsample_split_kernel<<<(unsigned)ceil_div<int64_t>(total, 256), 256, 0, as_stream(stream)>>>(
+        right, reinterpret_cast<_Float16 *>(y_hi), reinterpret_cast<_Float16 *>(y_lo), mul_dev, (int)C, (int)H, (int)W, q, (int)WU, off, total);
+    return check_launch("snvc_sheared_upsample_split");
+}
 
 int snvc_sheared_upsample(const float *right, float *out, int64_t N, int64_t C, int64_t H, int64_t W, int q, int64_t WU,
                           int off, void *stream) {

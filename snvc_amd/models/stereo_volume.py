@@ -80,6 +80,7 @@ class GlobalStack(nn.Module):
     def release_workspace(self):
         """Drop the persistent inference workspace (2.2 GB at cfg2)."""
         self.__dict__.pop("_snvc_ws", None)
+        self.__dict__.pop("_snvc_prep_ws", None)
 
     def train(self, mode: bool = True):
         if mode:
@@ -92,6 +93,7 @@ class GlobalStack(nn.Module):
         state.pop("_snvc_x3", None)      # packed split-mode layers: rebuilt on first use
         state.pop("_snvc_x3_guard", None)    # the overflow flag, its pinned host copy and an event
         state.pop("_snvc_streams", None)
+        state.pop("_snvc_prep_ws", None)
         return state
 
     # ------------------------------------------------------------------------------------------ split mode ("f16x3", r4)
@@ -108,6 +110,7 @@ class GlobalStack(nn.Module):
     # costs): the flag is only posted; ``check_overflow()`` or the next call looks at it.
     arithmetic = "auto"
     overflow_check = "call"
+    split_prep = True    # split mode: the sheared first layer's depth-1 3 x 7 layers (G, G') on the half pipe too (False: fp32 MFMA, as r4)
     fused_tail = True    # split mode: conv5's epilogue contracts its result with the folded one-channel tail (False: r4's two launches)
     X3_SIGMAS = 64.0     # a tensor's exponent is chosen so that |beta| + X3_SIGMAS * |gamma| of its BatchNorm stays below 2^15
 
@@ -150,6 +153,24 @@ class GlobalStack(nn.Module):
             w = sq[0].weight.detach().to(device)
             st["layers"][k] = ops.Conv3dLayerX3(w, 3, geo[k][0], 1, 1, geo[k][1])
             st["affine"][k] = _folded_bn(sq[1], sq[0].__dict__.setdefault("_snvc_plans", {}).setdefault(device, _Plan()))
+        # `post` = relu(bn(conv5(o)) + pre) exists only inside conv5's epilogue (below); its exponent comes from a HARD bound, not from
+        # the statistical one: |conv5(o)| <= (sum of |w| over a parity class's taps and all input channels) * max|o|, and o / pre cannot
+        # exceed what their own (checked) exponents allow.  conv5 then cannot clamp once the layers before it have not, so the overflow
+        # flag is final BEHIND hg conv4 and the host's look at it overlaps conv5 + the gather (0.17 ms of GPU work) instead of
+        # leaving the GPU empty for the next call's first launches (r5: 0.08 ms per step).  The price: ~3 bits of exponent headroom
+        # out of half's 30 -- nothing, for activations of ordinary magnitude.
+        w5 = hg.conv5[0].weight.detach().double().abs()                       # [Cin, Cout, 3, 3, 3]
+        sets = ([1], [0, 2])
+        l1 = None
+        for pd in range(2):
+            for ph in range(2):
+                for pw in range(2):
+                    t = w5[:, :, sets[pd]][:, :, :, sets[ph]][:, :, :, :, sets[pw]].sum(dim=(0, 2, 3, 4))
+                    l1 = t if l1 is None else torch.maximum(l1, t)
+        sc5, bi5 = st["affine"]["h5"]
+        hard = float(((sc5.double().abs() * l1.to(sc5.device) * (65504.0 / 2.0 ** st["exp"]["h4"]) + bi5.double().abs()).max()
+                      + 65504.0 / 2.0 ** st["exp"]["h2"]).item())
+        st["exp"]["post"] = min(self._x3_exponent(hard), st["exp"]["h2"])
         # the folded tail classifier(bn(conv6(post)) + v): a transposed layer to one channel whose per-voxel tap contraction is part
         # of conv5's epilogue (snvc_f16x3_deconv3d_tail_forward); `post` is never stored
         st["tail"] = st["tail_bias"] = None
@@ -233,16 +254,15 @@ class GlobalStack(nn.Module):
         pre = L["h2"](o, E["h1"], *A["h2"], flags=EPI_RELU, out_exp=E["h2"], overflow=flag)                     # relu(bn(conv))   :153-156
         o = L["h3"](pre, E["h2"], *A["h3"], flags=EPI_RELU, out_exp=E["h3"], overflow=flag)                     # 1/4 res
         o = L["h4"](o, E["h3"], *A["h4"], flags=EPI_RELU, out_exp=E["h4"], overflow=flag)
+        st["guard"].post()      # the last layer that can clamp (conv5's exponent is a hard bound, see _x3_state): the flag leaves for the host here
         if st["tail"] is not None and self.fused_tail:
-            # post = relu(bn(deconv(o)) + pre) is formed, clamped / flagged and contracted with the folded tail's 27 taps inside conv5's
-            # launch (r5): 27 fp32 planes per parity class leave instead of 64 channels, and the last launch only sums them
-            t = L["h5"].forward_tail(o, E["h4"], *A["h5"], st["tail"], residual=pre, flags=EPI_RELU | ops.EPI_ADD_PRE, out_exp=E["h2"],
-                                     overflow=flag, out=self._buffer("tail_t", (n, 27, 8) + tuple(o.shape[3:6]), dev))
-            st["guard"].post()      # the last launch that can clamp; the flag leaves for the host here
+            # post = relu(bn(deconv(o)) + pre) is formed and contracted with the folded tail's 27 taps inside conv5's launch (r5): 27
+            # fp32 planes per parity class leave instead of 64 channels, and the last launch only sums them
+            t = L["h5"].forward_tail(o, E["h4"], *A["h5"], st["tail"], residual=pre, res_exp=E["h2"], flags=EPI_RELU | ops.EPI_ADD_PRE,
+                                     out_exp=E["post"], overflow=flag, out=self._buffer("tail_t", (n, 27, 8) + tuple(o.shape[3:6]), dev))
             cost = ops.deconv_tail_gather(t, st["tail_bias"], hv)                             # deconv'(post) + b' + classifier(v2)
             _ROUTES["x3_fused_tail"] += 1
         else:
-            st["guard"].post()      # the last layer that can clamp: the two below write float32
             # post = relu(bn(deconv(o)) + pre): the result leaves as fp32 NCDHW for the one-channel transposed tail (VALU kernel)
             post = L["h5"](o, E["h4"], *A["h5"], residual=pre, flags=EPI_RELU | ops.EPI_ADD_PRE, out_exp=E["h2"], to_f32=True)
             cost = hg.conv6.fused(post, residual=None, head=self.classifier, head_residual=hv)    # deconv'(post) + b' + classifier(v2)
@@ -382,6 +402,15 @@ class GlobalStack(nn.Module):
                                              ksize_h=3) for i in range(2))
         return cache[q]
 
+    def _sheared_layers_x3(self, plans, wr, q):
+        """``_sheared_layers`` as split-mode depth-1 layers (ops.Conv2dLayerX3): same folded 3 x 7 kernels."""
+        cache = plans.setdefault("sheared_x3", {})
+        if q not in cache:
+            k = sheared_kernels(wr, q)                                     # [all | last column][depth class][Cout,C,3,7]
+            cout, c = k.shape[2], k.shape[3]
+            cache[q] = tuple(ops.Conv2dLayerX3(k[i].reshape(3 * cout, c, 3, 7).float().contiguous()) for i in range(2))
+        return cache[q]
+
     @staticmethod
     def _left_planes_layer(plans, wl):
         """The three depth-class planes of the LEFT half of conv1(volume) as ONE depth-1 3x3 convolution of the left feature
@@ -516,6 +545,15 @@ class GlobalStack(nn.Module):
 
         def sheared_inputs(q, m0):
             off, wu, off_col, wu_col = sheared_geometry(q, m0, shift.size(1), left.size(3))
+            if split_prep:
+                # r5: G and G' (depth-1 3 x 7 layers, 7.8 + 2.5 GFLOP: 84 + 31 us on the fp32 matrix pipe) in split mode like the layers behind
+                # them: Rq is written as a split pair scaled by the right feature's own maximum (one launch, no host round trip)
+                lx_g, lx_col = self._sheared_layers_x3(plans, w.detach()[:, c:], q)
+                # one host call for the five launches (behind the step's host sync the GPU is empty: five Python-level launches of
+                # 5-20 us kernels starve it); G / G' live in a per-model workspace until this call's expand pass has read them
+                g, gcol = ops.sheared_prep_x3(right, q, wu, off, wu_col, off_col, lx_g, lx_col, self.__dict__.setdefault("_snvc_prep_ws", {}))
+                _ROUTES["sheared_prep_x3"] += 1
+                return g, gcol, off, off_col
             lay_g, lay_col = self._sheared_layers(plans, w.detach()[:, c:], q)
             if not self.prep_streams:
                 g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)             # [N,3C,H,WU]
@@ -541,6 +579,10 @@ class GlobalStack(nn.Module):
                 cur.wait_event(done)
             return out[0][0], out[1][0], off, off_col
 
+        # the sheared layer's small 2D convolutions run in split mode whenever the stack behind them does (same arithmetic contract:
+        # fp32 accuracy on the half pipe); `arithmetic="fp32"` keeps every layer on the fp32-MFMA kernels
+        split_prep = bool(self.split_prep and c % 8 == 0 and (3 * conv.out_channels) % 32 == 0 and right.is_contiguous()
+                          and self._x3_select(left.device, arithmetic) is not None)
         structure, guess, ready = (spacing if known else None), None, None
         if ticket is not None:
             guess = plans.get("spacing_seen")    # (q, m0, D, W) of the previous call: a guess, checked below

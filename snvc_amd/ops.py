@@ -517,8 +517,18 @@ def shift_structure_begin(shift):
     return host
 
 
+def spin_wait(event, spins: int = 20000):
+    """Wait for a recorded event by polling it (hipEventQuery, ~1 us a look) before falling back to the blocking wait: the waits of a
+    step are for results that are a few microseconds away, and a sleeping wait costs tens of microseconds to wake (r5: 0.076 ms of
+    a 2.04 ms step between the overflow flag's arrival and the next launch)."""
+    for _ in range(spins):
+        if event.query():
+            return
+    event.synchronize()
+
+
 def shift_structure_result(ticket):
-    ticket[1].synchronize()
+    spin_wait(ticket[1])
     nonneg, u1, u2, first = ticket[0].tolist()
     with _PINNED4_LOCK:
         free = _PINNED4.setdefault(ticket[2], [])
@@ -1107,8 +1117,8 @@ def voxel_gather_forward_split(left, right, l_pts, r_pts, resolution, mul_dev) -
 X3_Q16 = [True]        # False: the 32x32x16 kernel forms everywhere (rounds up to mid r4)
 X3_Q16_K5 = [True]     # ... and the plain 5^3 layers (quads over all 125 taps)
 X3_Q16_S2 = [True]     # stride-2 3x3x3 layers with a split output and no residual: the 16x16x32 form (False: the serial-plane 32x32x16 form)
-X3_Q16_MIN_JOBS = [1024]  # 3x3x3 layers: (tile, 32-channel block) jobs from which the 16x16x32 form is picked (r5 tried 256 for hg conv4 at
-#                           cfg2, 432 jobs: 61.6 us against 62.2 for the 2x4x32-tile 32x32x16 form -- no difference in the step, tools/ab_step.py)
+X3_Q16_MIN_JOBS = [256]   # 3x3x3 layers: (tile, 32-channel block) jobs from which the 16x16x32 form is picked (r4: 1024).  hg conv4 at cfg2
+#                           (432 jobs): 0.008-0.023 ms per step in five interleaved A/B runs (tools/ab_step.py, profiles/r5/ab_step_*.txt)
 
 
 class Conv3dLayerF16:
@@ -1238,6 +1248,101 @@ def split_scale_for(*tensors) -> torch.Tensor:
     e = torch.floor(torch.log2(16384.0 / amax))
     e = torch.where(torch.isfinite(e), e, torch.zeros_like(e)).clamp_(-24, 40)
     return torch.exp2(e)
+
+
+_SCALE_SCRATCH = {}
+
+
+def split_scale_of(t: torch.Tensor) -> torch.Tensor:
+    """``split_scale_for(t)`` for ONE contiguous float32 tensor in one launch (snvc_f16x3_split_scale): the power of two that puts
+    max|t| into [2^13, 2^14), as a one-element device tensor; no sync."""
+    _gpu(t, "t")
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16:
+        return split_scale_for(t)
+    scratch = _SCALE_SCRATCH.get(t.device)
+    if scratch is None:
+        scratch = _SCALE_SCRATCH[t.device] = torch.zeros(2, dtype=torch.int32, device=t.device)
+    out = torch.empty(1, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        check(_lib.lib().snvc_f16x3_split_scale(_ptr(t), t.numel(), _ptr(scratch), _ptr(out), _stream(t)), "snvc_f16x3_split_scale")
+    return out
+
+
+def sheared_upsample_split(right, q: int, wu: int, off: int, mul_dev: torch.Tensor):
+    """``sheared_upsample`` written as the split pair [N, 2, C/8, 1, H, wu, 8] (value * mul_dev = hi + lo): what the split-mode 3 x 7
+    layer reads (snvc_sheared_upsample_split)."""
+    _gpu(right, "right")
+    if right.dtype != torch.float32 or right.dim() != 4:
+        raise RuntimeError("sheared_upsample_split needs a float32 [N,C,H,W] tensor")
+    right = right.contiguous()
+    n, c, h, w = right.shape
+    out = torch.empty((n, 2, (c + 7) // 8, 1, h, wu, 8), dtype=torch.float16, device=right.device)
+    if out.numel():
+        with torch.cuda.device(right.device):
+            check(_lib.lib().snvc_sheared_upsample_split(_ptr(right), _ptr(out), _lo_ptr(out), _ptr(mul_dev), n, c, h, w, int(q), int(wu), int(off),
+                                                         _stream(right)), "snvc_sheared_upsample_split")
+    return out
+
+
+class Conv2dLayerX3:
+    """A depth-1 convolution (3x7 or 3x3, stride 1, "same" zero padding, no bias) in split mode: x a split pair [N,2,Cin/8,1,H,W,8]
+    holding values * x_mul_dev, result float32 [N,Cout,H,W] = scale * conv(x) + bias (snvc_f16x3_conv2d_*; r5: the sheared first
+    layer's G / G' on the half pipe)."""
+
+    def __init__(self, weight: torch.Tensor):
+        _gpu(weight, "weight")
+        if weight.dtype != torch.float32 or weight.dim() != 4:
+            raise RuntimeError("Conv2dLayerX3 needs a float32 [Cout,Cin,kh,kw] weight")
+        self.cout, self.cin, self.kh, self.kw = (int(v) for v in weight.shape)
+        nbytes = _lib.lib().snvc_f16x3_conv2d_packed_weight_bytes(self.cout, self.cin, self.kh, self.kw)
+        if nbytes < 0:
+            raise Unsupported("Conv2dLayerX3: 3x7 or 3x3 kernels, Cin % 8 == 0, Cout % 32 == 0")
+        w = weight.detach().contiguous()
+        wmax = float(w.abs().max().item()) if w.numel() else 1.0
+        self.w_exp = 14 - math.frexp(wmax)[1] if wmax > 0 and math.isfinite(wmax) else 0
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        with torch.cuda.device(w.device):
+            check(_lib.lib().snvc_f16x3_conv2d_pack_weights(_ptr(w), self.cout, self.cin, self.kh, self.kw, _ptr(self.packed),
+                                                            float(2.0 ** self.w_exp), _stream(w)), "snvc_f16x3_conv2d_pack_weights")
+
+    def __call__(self, x, x_mul_dev=None, scale=None, bias=None, flags: int = 0, x_exp: int = 0):
+        _split_check(x, "x")
+        if x.size(2) * 8 != self.cin or x.size(3) != 1:
+            raise RuntimeError(f"Conv2dLayerX3 input must be a split pair [N,2,{self.cin // 8},1,H,W,8]")
+        n, h, w = x.size(0), x.size(4), x.size(5)
+        y = torch.empty((n, self.cout, h, w), dtype=torch.float32, device=x.device)
+        if y.numel():
+            with torch.cuda.device(x.device):
+                check(_lib.lib().snvc_f16x3_conv2d_forward(_ptr(x), _lo_ptr(x), _ptr(self.packed), _ptr(scale), _ptr(bias), _ptr(y), n, self.cin,
+                                                           self.cout, h, w, self.kh, self.kw, float(2.0 ** -(self.w_exp + x_exp)), _ptr(x_mul_dev),
+                                                           int(flags), _stream(x)), "snvc_f16x3_conv2d_forward")
+        return y
+
+
+def sheared_prep_x3(right, q: int, wu: int, off: int, wu_col: int, off_col: int, lay_g: "Conv2dLayerX3", lay_col: "Conv2dLayerX3", ws: dict):
+    """The sheared first layer's 2D prep in one host call (snvc_sheared_prep_x3): returns (G [N,3C,H,wu], G' [N,3C,H,wu_col]) float32.
+    ``ws``: a dict the caller keeps (workspaces and results are allocated once per shape and reused: the results are consumed by the
+    expand pass of the same call)."""
+    _gpu(right, "right")
+    right = right.contiguous()
+    n, c, h, w = right.shape
+    key = (n, c, h, w, wu, wu_col, right.device)
+    if ws.get("key") != key:
+        dev = right.device
+        ws.clear()
+        ws.update(key=key, rq=torch.empty(n * 2 * c * h * wu, dtype=torch.float16, device=dev),
+                  rq2=torch.empty(n * 2 * c * h * wu_col, dtype=torch.float16, device=dev), mul=torch.empty(1, dtype=torch.float32, device=dev),
+                  g=torch.empty((n, lay_g.cout, h, wu), dtype=torch.float32, device=dev),
+                  gcol=torch.empty((n, lay_col.cout, h, wu_col), dtype=torch.float32, device=dev))
+    scratch = _SCALE_SCRATCH.get(right.device)
+    if scratch is None:
+        scratch = _SCALE_SCRATCH[right.device] = torch.zeros(2, dtype=torch.int32, device=right.device)
+    with torch.cuda.device(right.device):
+        check(_lib.lib().snvc_sheared_prep_x3(_ptr(right), n, c, h, w, int(q), int(wu), int(off), int(wu_col), int(off_col), _ptr(lay_g.packed),
+                                              _ptr(lay_col.packed), lay_g.cout, float(2.0 ** -lay_g.w_exp), float(2.0 ** -lay_col.w_exp),
+                                              _ptr(ws["rq"]), _ptr(ws["rq2"]), _ptr(scratch), _ptr(ws["mul"]), _ptr(ws["g"]), _ptr(ws["gcol"]),
+                                              _stream(right)), "snvc_sheared_prep_x3")
+    return ws["g"], ws["gcol"]
 
 
 def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) -> torch.Tensor:

@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from test_gpu_parity import TIGHT, check
+from test_gpu_parity import TIGHT, check  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -109,3 +109,92 @@ def test_global_stack_fused_tail_equals_the_two_launch_tail():
         c = m.forward_pair(left, right, shift, 1, arithmetic="fp32")
     check(a.cpu().numpy(), b.cpu().numpy(), 2e-6, "fused tail vs conv5 -> fp32 post -> one-channel transposed layer")
     check(a.cpu().numpy(), c.cpu().numpy(), 1e-4, "fused tail vs the fp32-MFMA stack")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# r5: the sheared first layer's depth-1 layers in split mode (snvc_f16x3_split_scale, snvc_sheared_upsample_split, snvc_f16x3_conv2d_*)
+# ------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096 * 37 + 2, 3 * 1000 * 1000])
+def test_split_scale_in_one_launch_equals_the_torch_expression(n):
+    from snvc_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n)
+    for amp in (1.0, 3.7e-5, 9.1e6):
+        x = (torch.randn(n, generator=g) * amp).to(dev())
+        a, b = ops.split_scale_of(x), ops.split_scale_for(x)
+        assert torch.equal(a, b), (n, amp, a.item(), b.item())
+        m = float(a.item()) * x.abs().max().item()
+        assert 8192.0 <= m < 16384.0
+    z = torch.zeros(n, device=dev())
+    assert ops.split_scale_of(z).item() == 1.0                     # all zero: scale 1
+    z[n // 2] = float("inf")
+    assert ops.split_scale_of(z).item() == 1.0                     # non-finite maximum: scale 1
+    z[n // 2] = float("nan")
+    z[0] = -5.0
+    assert ops.split_scale_of(z).item() == 2048.0                  # a NaN does not take part: max|x| = 5 -> 5 * 2048 = 10240
+    # (an exact power of two lands ON 2^14: floor(log2(16384 / 2)) = 13, as in the torch expression); the scratch words were left zero
+    assert ops.split_scale_of(torch.full((n,), 2.0, device=dev())).item() == 8192.0
+
+
+@pytest.mark.parametrize("q", [1, 2])
+def test_sheared_upsample_split_equals_upsample_then_split(q):
+    from snvc_amd import ops
+    torch.manual_seed(q)
+    right = torch.randn(2, 32, 9, 40, device=dev()) * 3.0
+    mul = ops.split_scale_of(right)
+    for wu, off in ((q * 39 + 12, 4), (56, -11)):
+        a = ops.sheared_upsample_split(right, q, wu, off, mul)
+        b = ops.to_split(ops.sheared_upsample(right, q, wu, off).unsqueeze(2), mul_dev=mul)
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", ["3x7_32_96", "3x7_8_32_ragged", "3x3_32_96", "3x3_64_64_tiny"])
+def test_depth1_split_layer_vs_float64(case):
+    from snvc_amd import ops
+    torch.manual_seed(len(case))
+    kh, kw, cin, cout, shape = {"3x7_32_96": (3, 7, 32, 96, (96, 200)), "3x7_8_32_ragged": (3, 7, 8, 32, (17, 45)),
+                                "3x3_32_96": (3, 3, 32, 96, (40, 70)), "3x3_64_64_tiny": (3, 3, 64, 64, (2, 3))}[case]
+    n = 2
+    x = torch.randn(n, cin, *shape, device=dev()) * 2.5
+    w = torch.randn(cout, cin, kh, kw, device=dev()) * np.sqrt(2.0 / (cin * kh * kw))
+    lay = ops.Conv2dLayerX3(w)
+    mul = ops.split_scale_of(x)
+    xs = ops.to_split(x.unsqueeze(2), mul_dev=mul)
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), None, 1, (kh // 2, kw // 2))
+    got = lay(xs, mul)
+    check(got.cpu().numpy(), ref.numpy(), TIGHT, f"{case}: depth-1 split layer vs float64")
+    scale, bias = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev())
+    got = lay(xs, mul, scale, bias, flags=ops.EPI_RELU)
+    ref2 = torch.relu(ref * scale.double().cpu().view(1, -1, 1, 1) + bias.double().cpu().view(1, -1, 1, 1))
+    check(got.cpu().numpy(), ref2.numpy(), TIGHT, f"{case}: + affine + ReLU")
+    xs5 = ops.to_split(x.unsqueeze(2), 5)                              # a fixed exponent instead of the device scale
+    check(lay(xs5, None, x_exp=5).cpu().numpy(), ref.numpy(), TIGHT, f"{case}: fixed exponent")
+
+
+def test_global_stack_split_prep_equals_fp32_prep():
+    import bench
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    m = GlobalStack(32)
+    m.load_state_dict(bench.seeded_state(m, 9))
+    m.eval().to(dev())
+    g = np.random.default_rng(4)
+    left = torch.from_numpy(g.standard_normal((2, 32, 12, 44)).astype(np.float32)).to(dev())
+    right = torch.from_numpy((5.0 * g.standard_normal((2, 32, 12, 44))).astype(np.float32)).to(dev())
+    for q in (1, 2):
+        shift = torch.from_numpy(np.tile(np.arange(20, dtype=np.float32) / q, (2, 1))).to(dev())
+        with torch.no_grad():
+            before = S._ROUTES["sheared_prep_x3"]
+            a = m.forward_pair(left, right, shift, 1)
+            v1a = m.last_first_layer()
+            after = S._ROUTES["sheared_prep_x3"]
+            assert after >= before + 1          # (+2 when the spacing guessed from the previous call was wrong and the prep ran twice)
+            m.split_prep = False
+            b = m.forward_pair(left, right, shift, 1)
+            v1b = m.last_first_layer()
+            assert S._ROUTES["sheared_prep_x3"] == after
+            m.split_prep = True
+            c = m.forward_pair(left, right, shift, 1, arithmetic="fp32")      # fp32 arithmetic: the fp32-MFMA prep
+            assert S._ROUTES["sheared_prep_x3"] == after
+        check(v1a.cpu().numpy(), v1b.cpu().numpy(), TIGHT, f"q={q}: first layer, split prep vs fp32 prep")
+        check(a.cpu().numpy(), b.cpu().numpy(), 1e-5, f"q={q}: stack output, split prep vs fp32 prep")
+        check(a.cpu().numpy(), c.cpu().numpy(), 1e-4, f"q={q}: vs the fp32-MFMA stack")

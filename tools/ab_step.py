@@ -26,12 +26,13 @@ model.eval().to(dev)
 left, right, shift = bench.make_inputs(0, dev)
 
 
-def setup(prep_streams=False, check="call", s2q=True, fused_tail=True, q16_min=1024):
+def setup(prep_streams=False, check="call", s2q=True, fused_tail=True, q16_min=256, split_prep=True):
     model.prep_streams = prep_streams
     model.overflow_check = check
     model.fused_tail = fused_tail
     ops.X3_Q16_S2[0] = s2q
     ops.X3_Q16_MIN_JOBS[0] = q16_min
+    model.split_prep = split_prep
 
 
 LEGS = {
@@ -40,7 +41,8 @@ LEGS = {
     "overflow check deferred": {"check": "deferred"},
     "stride-2 layers: 32x32x16 serial-plane form": {"s2q": False},
     "two-launch tail (r4)": {"fused_tail": False},
-    "hg conv4 on the 16x16x32 form (from 256 jobs)": {"q16_min": 256},
+    "hg conv4 on the 2x4x32 32x32x16 form (r4 rule: 1024 jobs)": {"q16_min": 1024},
+    "sheared prep (G, G') on the fp32 matrix pipe (r4)": {"split_prep": False},
 }
 res = {k: [] for k in LEGS}
 with torch.no_grad():
