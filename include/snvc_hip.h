@@ -593,6 +593,11 @@ SNVC_API int snvc_sheared_prep_x3(const float *right, int64_t N, int64_t C, int6
                                   int64_t WU2, int off2, const void *packed_g, const void *packed_col, int64_t Cout3, float out_mul_g,
                                   float out_mul_col, void *rq_split, void *rq2_split, void *scratch8, float *mul_dev, float *g,
                                   float *gcol, void *stream);
+/* n_layers (1..8) depth-1 split layers of ONE fp32 [N][C][H][W] input in one host call: scale, split pair (ws_split: N*2*C*H*W halves),
+ * then layer i: y[i] [N][cout[i]][H][W] = out_mul[i] / *mul_dev * conv(x, packed[i]).  packed / cout / out_mul / y are HOST arrays. */
+SNVC_API int snvc_f16x3_conv2d_from_f32(const float *x, int64_t N, int64_t C, int64_t H, int64_t W, int kh, int kw, int n_layers,
+                                        const void *const *packed, const int64_t *cout, const float *out_mul, float *const *y,
+                                        void *ws_split, void *scratch8, float *mul_dev, void *stream);
 SNVC_API int64_t snvc_f16x3_conv2d_packed_weight_bytes(int cout, int cin, int kh, int kw);
 SNVC_API int snvc_f16x3_conv2d_pack_weights(const float *weight, int cout, int cin, int kh, int kw, void *packed, float wmul,
                                             void *stream);

@@ -110,6 +110,7 @@ SIGNATURES = {
     "snvc_sheared_upsample_split": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_p]),
     "snvc_sheared_prep_x3": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64, c_int, c_p, c_p, c_i64, c_f32, c_f32, c_p, c_p, c_p,
                                      c_p, c_p, c_p, c_p]),
+    "snvc_f16x3_conv2d_from_f32": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_f16x3_conv2d_packed_weight_bytes": (c_i64, [c_int, c_int, c_int, c_int]),
     "snvc_f16x3_conv2d_pack_weights": (c_int, [c_p, c_int, c_int, c_int, c_int, c_p, c_f32, c_p]),
     "snvc_f16x3_conv2d_forward": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_f32, c_p, c_int, c_p]),

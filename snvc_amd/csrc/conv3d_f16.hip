@@ -2477,6 +2477,29 @@ int snvc_sheared_prep_x3(const float *right, int64_t N, int64_t C, int64_t H, in
                                      stream);
 }
 
+// n_layers depth-1 split layers of ONE fp32 [N][C][H][W] input in one host call: its scale, its split pair (ws: N*2*C*H*W halves), then
+// the layers (same kernel size, their own packed weights / output channels / results).  The left half's depth-class planes (one
+// 3x3 layer) and the any-shift path's P / Q layers (two 3x3 layers of the right feature) go through here.
+extern "C" int snvc_f16x3_from_ncdhw(const float *, void *, void *, int64_t, int64_t, int64_t, int64_t, int64_t, float, const float *, void *);
+int snvc_f16x3_conv2d_from_f32(const float *x, int64_t N, int64_t C, int64_t H, int64_t W, int kh, int kw, int n_layers,
+                               const void *const *packed, const int64_t *cout, const float *out_mul, float *const *y, void *ws_split,
+                               void *scratch8, float *mul_dev, void *stream) {
+    using namespace snvc;
+    if (!x || !packed || !cout || !out_mul || !y || !ws_split || !scratch8 || !mul_dev || n_layers < 1 || n_layers > 8)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv2d_from_f32: null pointer or layer count outside 1..8");
+    if (N <= 0 || C % 8) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv2d_from_f32: C % 8 == 0");
+    int rc = snvc_f16x3_split_scale(x, N * C * H * W, scratch8, mul_dev, stream);
+    if (rc) return rc;
+    _Float16 *a = reinterpret_cast<_Float16 *>(ws_split);
+    rc = snvc_f16x3_from_ncdhw(x, a, a + C * H * W, N, C, H * W, 0, 0, 1.0f, mul_dev, stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_layers; ++i) {
+        rc = snvc_f16x3_conv2d_forward(a, a + C * H * W, packed[i], nullptr, nullptr, y[i], N, C, cout[i], H, W, kh, kw, out_mul[i], mul_dev, 0, stream);
+        if (rc) return rc;
+    }
+    return SNVC_OK;
+}
+
 int64_t snvc_f16x3_tail_packed_weight_bytes(int cin) {
     return cin > 0 && cin % 32 == 0 ? (int64_t)(cin / 32) * 2 * 2 * 64 * 8 * 2 : -1;
 }

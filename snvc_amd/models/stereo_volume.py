@@ -412,16 +412,40 @@ class GlobalStack(nn.Module):
         return cache[q]
 
     @staticmethod
+    def _left_planes_weight(wl):
+        """[3 * Cout, C, 3, 3]: channel co*3 + cls = the kd taps depth class cls sees, summed in fp64."""
+        w = wl.detach().double()                                           # [Cout, C, kd, kh, kw]
+        k = torch.stack([w[:, :, 1:].sum(2), w.sum(2), w[:, :, :2].sum(2)], dim=1)          # [Cout, 3, C, kh, kw]
+        return k.reshape(-1, w.shape[1], 3, 3).float().contiguous()
+
+    @staticmethod
     def _left_planes_layer(plans, wl):
         """The three depth-class planes of the LEFT half of conv1(volume) as ONE depth-1 3x3 convolution of the left feature
         with 3*Cout output channels (channel co*3 + cls = the kd taps that class sees, summed in fp64): [N,3C,1,H,W] is
         the [N,C,3,H,W] tensor snvc_conv3d_forward_ex takes.  (r1-r2 ran the 3D kernel on the feature stacked 3 deep: a
         one-tile-deep launch whose time is one workgroup's whole channel loop, 50 us.)"""
         if "left2d" not in plans:
-            w = wl.detach().double()                                       # [Cout, C, kd, kh, kw]
-            k = torch.stack([w[:, :, 1:].sum(2), w.sum(2), w[:, :, :2].sum(2)], dim=1)      # [Cout, 3, C, kh, kw]
-            plans["left2d"] = ops.Conv3dLayer(k.reshape(-1, w.shape[1], 3, 3).float().contiguous(), 3, 1, 1, 1, False, planar=True)
+            plans["left2d"] = ops.Conv3dLayer(GlobalStack._left_planes_weight(wl), 3, 1, 1, 1, False, planar=True)
         return plans["left2d"]
+
+    @staticmethod
+    def _commuted_weights(wr):
+        """(P, Q, E) weights of the warp-after-convolution first layer as [*, C, 3, 3] depth-1 kernels (see _commuted_layers)."""
+        w = wr.detach()                                                   # [Cout, C, kd, kh, kw]
+        cout, c = w.shape[0], w.shape[1]
+        wk = w.permute(2, 0, 1, 3, 4).contiguous()                        # [kd, Cout, C, kh, kw]
+        kq = torch.zeros_like(wk)
+        kq[..., 1] = wk[..., 2]
+        ke = torch.zeros((3, 3, cout, c, 3, 3), dtype=w.dtype, device=w.device)
+        for kw in range(3):
+            ke[:, kw, :, :, :, 1] = wk[..., kw]
+        return tuple(t.reshape(-1, c, 3, 3).contiguous() for t in (wk, kq, ke))
+
+    @staticmethod
+    def _commuted_layers_x3(plans, wr):
+        if "commuted_x3" not in plans:
+            plans["commuted_x3"] = tuple(ops.Conv2dLayerX3(t.float()) for t in GlobalStack._commuted_weights(wr))
+        return plans["commuted_x3"]
 
     @staticmethod
     def _commuted_layers(plans, wr):
@@ -539,7 +563,18 @@ class GlobalStack(nn.Module):
             plans.clear()
             plans.update(key=key, right=ops.Conv3dLayer(wr, 3, 1, 1, 1, False), plan=_Plan())
         scale, bias = _folded_bn(bn, plans["plan"])
-        planes = self._left_planes_layer(plans, w.detach()[:, :c])(left.unsqueeze(2))       # [N,3C,1,H,W] ...
+        # the first layer's small 2D convolutions run in split mode whenever the stack behind them does (same arithmetic contract:
+        # fp32 accuracy on the half pipe); `arithmetic="fp32"` keeps every layer on the fp32-MFMA kernels
+        split_prep = bool(self.split_prep and c % 8 == 0 and (3 * conv.out_channels) % 32 == 0 and right.is_contiguous()
+                          and self._x3_select(left.device, arithmetic) is not None)
+        prep_ws = self.__dict__.setdefault("_snvc_prep_ws", {})
+        if split_prep:      # one host call: the left feature's scale, its split pair, the 3x3 layer with 3 * Cout output channels
+            lx = plans.get("left2d_x3")
+            if lx is None:
+                lx = plans["left2d_x3"] = ops.Conv2dLayerX3(self._left_planes_weight(w.detach()[:, :c]))
+            planes = ops.conv2d_x3_from_f32(left, [lx], prep_ws.setdefault("planes", {}))[0]
+        else:
+            planes = self._left_planes_layer(plans, w.detach()[:, :c])(left.unsqueeze(2))   # [N,3C,1,H,W] ...
         planes = planes.view(left.size(0), c, 3, left.size(2), left.size(3))                 # ... = [N,C,3,H,W]: first / interior / last
         shape = (left.size(0), c, shift.size(1)) + tuple(left.shape[2:])
 
@@ -551,7 +586,7 @@ class GlobalStack(nn.Module):
                 lx_g, lx_col = self._sheared_layers_x3(plans, w.detach()[:, c:], q)
                 # one host call for the five launches (behind the step's host sync the GPU is empty: five Python-level launches of
                 # 5-20 us kernels starve it); G / G' live in a per-model workspace until this call's expand pass has read them
-                g, gcol = ops.sheared_prep_x3(right, q, wu, off, wu_col, off_col, lx_g, lx_col, self.__dict__.setdefault("_snvc_prep_ws", {}))
+                g, gcol = ops.sheared_prep_x3(right, q, wu, off, wu_col, off_col, lx_g, lx_col, prep_ws.setdefault("sheared", {}))
                 _ROUTES["sheared_prep_x3"] += 1
                 return g, gcol, off, off_col
             lay_g, lay_col = self._sheared_layers(plans, w.detach()[:, c:], q)
@@ -579,10 +614,6 @@ class GlobalStack(nn.Module):
                 cur.wait_event(done)
             return out[0][0], out[1][0], off, off_col
 
-        # the sheared layer's small 2D convolutions run in split mode whenever the stack behind them does (same arithmetic contract:
-        # fp32 accuracy on the half pipe); `arithmetic="fp32"` keeps every layer on the fp32-MFMA kernels
-        split_prep = bool(self.split_prep and c % 8 == 0 and (3 * conv.out_channels) % 32 == 0 and right.is_contiguous()
-                          and self._x3_select(left.device, arithmetic) is not None)
         structure, guess, ready = (spacing if known else None), None, None
         if ticket is not None:
             guess = plans.get("spacing_seen")    # (q, m0, D, W) of the previous call: a guess, checked below
@@ -628,11 +659,19 @@ class GlobalStack(nn.Module):
         if commuted and shift.dtype == torch.float32 and left.size(3) <= 2048:
             # any other shift array: interpolation along w commutes with the convolution -- three 2D convolutions of the right
             # feature, three interpolations per output voxel, the warped volume is not built either (csrc/sheared_conv.hip)
-            lay_p, lay_q, lay_e = self._commuted_layers(plans, w.detach()[:, c:])
             mark("volume", 0)
-            r5 = right.unsqueeze(2)
-            p_, q_ = lay_p(r5).squeeze(2), lay_q(r5).squeeze(2)
-            e_ = lay_e(right[:, :, :, :4].contiguous().unsqueeze(2)).squeeze(2)
+            if split_prep and (9 * conv.out_channels) % 32 == 0:
+                # the three depth-1 3x3 layers in split mode: P and Q share the right feature's split pair (one host call), E runs on its
+                # first four columns (another)
+                lx_p, lx_q, lx_e = self._commuted_layers_x3(plans, w.detach()[:, c:])
+                p_, q_ = ops.conv2d_x3_from_f32(right, [lx_p, lx_q], prep_ws.setdefault("commuted", {}))
+                e_ = ops.conv2d_x3_from_f32(right[:, :, :, :4], [lx_e], prep_ws.setdefault("commuted_e", {}))[0]
+                _ROUTES["commuted_prep_x3"] += 1
+            else:
+                lay_p, lay_q, lay_e = self._commuted_layers(plans, w.detach()[:, c:])
+                r5 = right.unsqueeze(2)
+                p_, q_ = lay_p(r5).squeeze(2), lay_q(r5).squeeze(2)
+                e_ = lay_e(right[:, :, :, :4].contiguous().unsqueeze(2)).squeeze(2)
             mark("volume", 1)
             mark("conv1", 0)
             st = self._x3_select(left.device, arithmetic)

@@ -1345,6 +1345,37 @@ def sheared_prep_x3(right, q: int, wu: int, off: int, wu_col: int, off_col: int,
     return ws["g"], ws["gcol"]
 
 
+def conv2d_x3_from_f32(x, layers, ws: dict):
+    """``[layer(split(x)) for layer in layers]`` for depth-1 split layers of one kernel size on a float32 [N,C,H,W] tensor, in ONE host call
+    (snvc_f16x3_conv2d_from_f32: the scale from x's own maximum, its split pair, the layers).  ``ws``: a dict the caller keeps
+    (workspace and results allocated once per shape; the results are valid until the next call with the same dict)."""
+    _gpu(x, "x")
+    x = x.contiguous()
+    if x.dtype != torch.float32 or x.dim() != 4:
+        raise RuntimeError("conv2d_x3_from_f32 needs a float32 [N,C,H,W] tensor")
+    n, c, h, w = x.shape
+    key = (n, c, h, w, tuple(id(l) for l in layers), x.device)
+    if ws.get("key") != key:
+        ws.clear()
+        ws.update(key=key, split=torch.empty(n * 2 * c * h * w, dtype=torch.float16, device=x.device),
+                  mul=torch.empty(1, dtype=torch.float32, device=x.device),
+                  y=[torch.empty((n, l.cout, h, w), dtype=torch.float32, device=x.device) for l in layers])
+        k = len(layers)
+        ws["c_packed"] = (ctypes.c_void_p * k)(*[l.packed.data_ptr() for l in layers])
+        ws["c_cout"] = (ctypes.c_int64 * k)(*[l.cout for l in layers])
+        ws["c_mul"] = (ctypes.c_float * k)(*[2.0 ** -l.w_exp for l in layers])
+        ws["c_y"] = (ctypes.c_void_p * k)(*[t.data_ptr() for t in ws["y"]])
+        ws["layers"] = list(layers)          # keeps the packed weights the pointer array refers to alive
+    scratch = _SCALE_SCRATCH.get(x.device)
+    if scratch is None:
+        scratch = _SCALE_SCRATCH[x.device] = torch.zeros(2, dtype=torch.int32, device=x.device)
+    with torch.cuda.device(x.device):
+        check(_lib.lib().snvc_f16x3_conv2d_from_f32(_ptr(x), n, c, h, w, layers[0].kh, layers[0].kw, len(layers), ws["c_packed"], ws["c_cout"],
+                                                    ws["c_mul"], ws["c_y"], _ptr(ws["split"]), _ptr(scratch), _ptr(ws["mul"]), _stream(x)),
+              "snvc_f16x3_conv2d_from_f32")
+    return ws["y"]
+
+
 def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) -> torch.Tensor:
     """split C8 -> float32 [N,C,D,H,W]: (hi + lo) * 2**-exp."""
     _split_check(x, "x")

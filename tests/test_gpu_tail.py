@@ -198,3 +198,17 @@ def test_global_stack_split_prep_equals_fp32_prep():
         check(v1a.cpu().numpy(), v1b.cpu().numpy(), TIGHT, f"q={q}: first layer, split prep vs fp32 prep")
         check(a.cpu().numpy(), b.cpu().numpy(), 1e-5, f"q={q}: stack output, split prep vs fp32 prep")
         check(a.cpu().numpy(), c.cpu().numpy(), 1e-4, f"q={q}: vs the fp32-MFMA stack")
+    # any shift array (warp after convolution): its three depth-1 3x3 layers P, Q, E and the left planes in split mode
+    shift = torch.from_numpy(np.tile(np.arange(20, dtype=np.float32) * 0.73 + 0.2, (2, 1))).to(dev())
+    with torch.no_grad():
+        before = S._ROUTES["commuted_prep_x3"]
+        a = m.forward_pair(left, right, shift, 1)
+        v1a = m.last_first_layer()
+        assert S._ROUTES["commuted_prep_x3"] == before + 1
+        m.split_prep = False
+        b = m.forward_pair(left, right, shift, 1)
+        v1b = m.last_first_layer()
+        assert S._ROUTES["commuted_prep_x3"] == before + 1
+        m.split_prep = True
+    check(v1a.cpu().numpy(), v1b.cpu().numpy(), TIGHT, "any shift: first layer, split prep vs fp32 prep")
+    check(a.cpu().numpy(), b.cpu().numpy(), 1e-5, "any shift: stack output, split prep vs fp32 prep")
