@@ -168,6 +168,9 @@ enum {
      * Built for 3x3x3 / stride-1 Conv3d layers on the default Winograd form with Dout % 4 == 0 and no residual;
      * SNVC_ERR_UNSUPPORTED otherwise (the caller then pools in a launch of its own: snvc_avgpool_depth4). */
     SNVC_EPI_AVGPOOL_D4 = 16,
+    /* snvc_sheared_expand_split / snvc_warped_expand_split: write the result with non-temporal stores (a 0.74 GB tensor that is read
+     * once, by the next layer, long after the L2 has turned over: 4.0 -> 4.5 TB/s at cfg2, r5) */
+    SNVC_EPI_STREAM_OUT = 32,
     /* snvc_warped_expand only: the r3 kernel form (four 16-byte LDS reads per kd and plane) instead of the register-window
      * form; same values up to fp32 rounding, kept selectable for the parity tests and A/B timing. */
     SNVC_WARPED_EXPAND_R3 = 256

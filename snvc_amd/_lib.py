@@ -26,7 +26,7 @@ class Conv3dDesc(ctypes.Structure):
         (n, ctypes.c_int64) for n in ("x_batch_stride", "y_batch_stride", "res_batch_stride")]
 
 
-EPI_RELU, EPI_ADD_PRE, EPI_ADD_POST, EPI_SIGMOID, EPI_AVGPOOL_D4 = 1, 2, 4, 8, 16
+EPI_RELU, EPI_ADD_PRE, EPI_ADD_POST, EPI_SIGMOID, EPI_AVGPOOL_D4, EPI_STREAM_OUT = 1, 2, 4, 8, 16, 32
 # snvc_conv3d_desc.algo (include/snvc_hip.h): arithmetic in the low byte, kernel-form selectors above it
 ALGO_AUTO, ALGO_DIRECT = 0, 1
 ALGO_WINO_TILE_BIG, ALGO_WINO_TILE_STD, ALGO_WINO_TILE_NARROW_REG = 0x100, 0x200, 0x300

@@ -1123,7 +1123,7 @@ sheared_expand_split_kernel(const float *__restrict__ g, const float *__restrict
     __syncthreads();
     const int w = tid;
     if (w >= W) return;
-    const bool relu = (flags & SNVC_EPI_RELU) != 0, last = w == W - 1;
+    const bool relu = (flags & SNVC_EPI_RELU) != 0, last = w == W - 1, nt = (flags & SNVC_EPI_STREAM_OUT) != 0;
     const int64_t plane_sz = (int64_t)H * W;
     _Float16 *yhp = yh + n * y_bs + (((int64_t)cg * D) * plane_sz + (int64_t)h * W + w) * 8;
     _Float16 *ylp = yl + n * y_bs + (((int64_t)cg * D) * plane_sz + (int64_t)h * W + w) * 8;
@@ -1150,8 +1150,13 @@ sheared_expand_split_kernel(const float *__restrict__ g, const float *__restrict
             hi[c] = (_Float16)tc;
             lo[c] = (_Float16)(tc - (float)hi[c]);
         }
-        *reinterpret_cast<h8v *>(yhp + (int64_t)d * plane_sz * 8) = hi;
-        *reinterpret_cast<h8v *>(ylp + (int64_t)d * plane_sz * 8) = lo;
+        if (nt) {       // block-uniform: a streamed-out tensor that is read once, much later than the L2 keeps it
+            __builtin_nontemporal_store(hi, reinterpret_cast<h8v *>(yhp + (int64_t)d * plane_sz * 8));
+            __builtin_nontemporal_store(lo, reinterpret_cast<h8v *>(ylp + (int64_t)d * plane_sz * 8));
+        } else {
+            *reinterpret_cast<h8v *>(yhp + (int64_t)d * plane_sz * 8) = hi;
+            *reinterpret_cast<h8v *>(ylp + (int64_t)d * plane_sz * 8) = lo;
+        }
     };
     // the two end planes (depth classes 0 and 2): their own G / G' and planes, read straight from L2 by the chunk that holds them
 #pragma unroll
@@ -1270,7 +1275,7 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
     __syncthreads();
     const int w = tid;
     if (w >= W) return;
-    const bool last = w == W - 1, relu = (flags & SNVC_EPI_RELU) != 0;
+    const bool last = w == W - 1, relu = (flags & SNVC_EPI_RELU) != 0, nt = (flags & SNVC_EPI_STREAM_OUT) != 0;
     float sc[8], bi[8], pl[3][8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -1339,8 +1344,13 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
             hi[c] = (_Float16)t;
             lo[c] = (_Float16)(t - (float)hi[c]);
         }
-        *reinterpret_cast<h8v *>(yhp + (int64_t)d * hw * 8) = hi;
-        *reinterpret_cast<h8v *>(ylp + (int64_t)d * hw * 8) = lo;
+        if (nt) {
+            __builtin_nontemporal_store(hi, reinterpret_cast<h8v *>(yhp + (int64_t)d * hw * 8));
+            __builtin_nontemporal_store(lo, reinterpret_cast<h8v *>(ylp + (int64_t)d * hw * 8));
+        } else {
+            *reinterpret_cast<h8v *>(yhp + (int64_t)d * hw * 8) = hi;
+            *reinterpret_cast<h8v *>(ylp + (int64_t)d * hw * 8) = lo;
+        }
         pm[0] = pm[1]; pf[0] = pf[1]; pg[0] = pg[1];
         pm[1] = pm[2]; pf[1] = pf[2]; pg[1] = pg[2];
         pm[2] = nm; pf[2] = nff; pg[2] = ngg;
@@ -1434,7 +1444,7 @@ int snvc_sheared_expand_split(const float *g, const float *gcol, const float *pl
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: bad sizes (q in {1,2}, D >= 2)");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: scale and bias must both be given or both be NULL");
-    if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: only SNVC_EPI_RELU");
+    if (flags & ~(SNVC_EPI_RELU | SNVC_EPI_STREAM_OUT)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: only SNVC_EPI_RELU | SNVC_EPI_STREAM_OUT");
     if (N == 0) return SNVC_OK;
     if (!g || !gcol || !y_hi || !y_lo) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: null pointer");
     if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15)
@@ -1614,7 +1624,7 @@ int snvc_warped_expand_split(const float *p, const float *q, const float *e, con
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_split: bad sizes (W % 4 == 0)");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_split: scale and bias must both be given or both be NULL");
-    if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_split: only SNVC_EPI_RELU");
+    if (flags & ~(SNVC_EPI_RELU | SNVC_EPI_STREAM_OUT)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_split: only SNVC_EPI_RELU | SNVC_EPI_STREAM_OUT");
     if (N == 0) return SNVC_OK;
     if (!p || !q || !e || !shift || !y_hi || !y_lo) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_warped_expand_split: null pointer");
     if ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo) | reinterpret_cast<uintptr_t>(p)) & 15)

@@ -110,6 +110,10 @@ class GlobalStack(nn.Module):
     # costs): the flag is only posted; ``check_overflow()`` or the next call looks at it.
     arithmetic = "auto"
     overflow_check = "call"
+    # the first layer's 0.74 GB split pair written with non-temporal stores (SNVC_EPI_STREAM_OUT): the expand pass alone gains 9 % (182 ->
+    # 165 us back to back) but the step LOSES 0.013 ms (tools/ab_step.py, profiles/r5/ab_step_v5.txt): conv2 reads the pair right
+    # behind it.  Off.
+    stream_out = False
     split_prep = True    # split mode: the sheared first layer's depth-1 3 x 7 layers (G, G') on the half pipe too (False: fp32 MFMA, as r4)
     fused_tail = True    # split mode: conv5's epilogue contracts its result with the folded one-channel tail (False: r4's two launches)
     X3_SIGMAS = 64.0     # a tensor's exponent is chosen so that |beta| + X3_SIGMAS * |gamma| of its BatchNorm stays below 2^15
@@ -639,7 +643,7 @@ class GlobalStack(nn.Module):
                 v1s = self._buffer("v1s", (shape[0], 2, c // 8) + tuple(shape[2:]) + (8,), left.device, torch.float16)
                 try:
                     ops.sheared_expand_split(g, gcol, planes, *self._x3_v1_affine(st, scale, bias), v1s, q, m0, off, off_col,
-                                             ops.EPI_RELU, st["flag"])
+                                             ops.EPI_RELU | (ops.EPI_STREAM_OUT if self.stream_out else 0), st["flag"])
                 except ops.Unsupported:
                     st = None
                 else:
@@ -678,7 +682,8 @@ class GlobalStack(nn.Module):
             if st is not None and c % 8 == 0:       # split mode: the expand pass writes the (hi, lo) pair conv2 reads
                 v1s = self._buffer("v1s", (shape[0], 2, c // 8) + tuple(shape[2:]) + (8,), left.device, torch.float16)
                 try:
-                    ops.warped_expand_split(p_, q_, e_, planes, shift, *self._x3_v1_affine(st, scale, bias), v1s, ops.EPI_RELU, st["flag"])
+                    ops.warped_expand_split(p_, q_, e_, planes, shift, *self._x3_v1_affine(st, scale, bias), v1s,
+                                            ops.EPI_RELU | (ops.EPI_STREAM_OUT if self.stream_out else 0), st["flag"])
                 except ops.Unsupported:
                     pass
                 else:

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, F32, F64, Conv3dDesc,
+from ._lib import (EPI_ADD_POST, EPI_ADD_PRE, EPI_RELU, EPI_SIGMOID, EPI_STREAM_OUT, F32, F64, Conv3dDesc,
                    Unsupported, check)
 
 __all__ = [
@@ -25,7 +25,7 @@ __all__ = [
     "mul_broadcast_c8", "avgpool_depth4_c8", "volume_resample", "rect_to_psv_grid", "act_backward_reduce", "act_backward_apply", "bn_backward_coefs", "norm_stats", "affine_act", "mul_broadcast", "avgpool_depth4", "zero_stuff2x",
     "disparity_regression", "argmax_rows", "roiaware_pool3d_forward", "roiaware_pool3d_backward",
     "points_in_boxes_gpu", "points_in_boxes_cpu",
-    "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID",
+    "EPI_RELU", "EPI_ADD_PRE", "EPI_ADD_POST", "EPI_SIGMOID", "EPI_STREAM_OUT",
 ]
 
 

@@ -26,13 +26,14 @@ model.eval().to(dev)
 left, right, shift = bench.make_inputs(0, dev)
 
 
-def setup(prep_streams=False, check="call", s2q=True, fused_tail=True, q16_min=256, split_prep=True):
+def setup(prep_streams=False, check="call", s2q=True, fused_tail=True, q16_min=256, split_prep=True, stream_out=False):
     model.prep_streams = prep_streams
     model.overflow_check = check
     model.fused_tail = fused_tail
     ops.X3_Q16_S2[0] = s2q
     ops.X3_Q16_MIN_JOBS[0] = q16_min
     model.split_prep = split_prep
+    model.stream_out = stream_out
 
 
 LEGS = {
@@ -43,6 +44,7 @@ LEGS = {
     "two-launch tail (r4)": {"fused_tail": False},
     "hg conv4 on the 2x4x32 32x32x16 form (r4 rule: 1024 jobs)": {"q16_min": 1024},
     "sheared prep (G, G') on the fp32 matrix pipe (r4)": {"split_prep": False},
+    "first layer written with non-temporal stores": {"stream_out": True},
 }
 res = {k: [] for k in LEGS}
 with torch.no_grad():
