@@ -18,6 +18,7 @@ from snvc_amd.models.stereo_volume import GlobalStack  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rounds", type=int, default=4)
 ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--only", default="", help="comma-separated substrings: only legs matching one (default is always run)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 model = GlobalStack(bench.C)
@@ -46,6 +47,8 @@ LEGS = {
     "sheared prep (G, G') on the fp32 matrix pipe (r4)": {"split_prep": False},
     "first layer written with non-temporal stores": {"stream_out": True},
 }
+if args.only:
+    LEGS = {k: v for k, v in LEGS.items() if k == "default" or any(t in k for t in args.only.split(","))}
 res = {k: [] for k in LEGS}
 with torch.no_grad():
     for _ in range(30):

@@ -35,6 +35,7 @@ full, half, quarter = (192, 96, 312), (96, 48, 156), (48, 24, 78)
 flag = torch.zeros(1, dtype=torch.int32, device=dev)
 sc64, bi64 = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.2
 cases = [
+    ("conv2  s1 32->32  192x96x312", 32, 32, 1, False, full, [("q16", _lib.ALGO_X3_Q16)]),
     ("hg conv1  s2 32->64  192x96x312 -> 96x48x156", 32, 64, 2, False, full, [("2x4x32", 0), ("q16 3 slots", _lib.ALGO_X3_Q16)]),
     ("hg conv3  s2 64->64  96x48x156 -> 48x24x78", 64, 64, 2, False, half, [("2x4x32", 0), ("q16 3 slots", _lib.ALGO_X3_Q16)]),
     ("hg conv2  s1 64->64  96x48x156", 64, 64, 1, False, half, [("auto", None)]),
@@ -61,7 +62,7 @@ for name, cin, cout, stride, tr, shape, forms in cases:
             del res
         else:
             y = torch.empty((1, 2, cout // 8) + out_sp + (8,), dtype=torch.float16, device=dev)
-            ms, _ = bench.timed_ms(lambda: lay(x, 3, sc64, bi64, flags=ops.EPI_RELU, out=y, out_exp=2, overflow=flag), args.reps, 3)
+            ms, _ = bench.timed_ms(lambda: lay(x, 3, sc64[:cout], bi64[:cout], flags=ops.EPI_RELU, out=y, out_exp=2, overflow=flag), args.reps, 3)
             flop = 2.0 * np.prod(out_sp) * cin * cout * 27
             print(f"   {label:18s} {ms * 1e3:7.1f} us   {flop / ms / 1e9:7.1f} TFLOP/s algorithmic", flush=True)
             del y
