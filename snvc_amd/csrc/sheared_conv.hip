@@ -1198,7 +1198,7 @@ sheared_expand_split_kernel(const float *__restrict__ g, const float *__restrict
 // column of one image row, 8 channels; a workgroup = one row x one channel group x a chunk of the depth range.  Per plane and kd
 // the thread needs F_kd[c][w - m - 1] and G_kd[c][w - m] of its 8 channels: 16 LDS reads, kept in registers while m stands (every
 // other plane on half-pixel steps).  Same plane parameters (ptab), same whole-pixel remap, same last-column table as the fp32 form.
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5)))      // <= 96 VGPRs: four 5-wave workgroups per CU
 warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict__ q, const float *__restrict__ e,
                            const float *__restrict__ planes, const float *__restrict__ shift, const float *__restrict__ scale,
                            const float *__restrict__ bias, _Float16 *__restrict__ yh, _Float16 *__restrict__ yl, int *__restrict__ overflow,
@@ -1276,16 +1276,14 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
     const int w = tid;
     if (w >= W) return;
     const bool last = w == W - 1, relu = (flags & SNVC_EPI_RELU) != 0, nt = (flags & SNVC_EPI_STREAM_OUT) != 0;
-    float sc[8], bi[8], pl[3][8];
+    float sc[8], bi[8], pl[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int co = cg * 8 + c;
         sc[c] = co < C ? (scale ? scale[co] : 1.0f) : 0.0f;
         bi[c] = (scale && co < C) ? bias[co] : 0.0f;
-#pragma unroll
-        for (int cls = 0; cls < 3; ++cls)
-            pl[cls][c] = (planes && co < C) ? planes[(((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w] : 0.0f;
-    }
+        pl[c] = (planes && co < C) ? planes[(((n * C + co) * 3 + 1) * (int64_t)H + h) * W + w] : 0.0f;      // interior class; the two end
+    }                                                                                                       // planes fetch their own
     _Float16 *yhp = yh + n * y_bs + (((int64_t)cg * D) * hw + (int64_t)h * W + w) * 8;
     _Float16 *ylp = yl + n * y_bs + (((int64_t)cg * D) * hw + (int64_t)h * W + w) * 8;
     auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
@@ -1299,29 +1297,32 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
     take(ptab[d_lo], pm[1], pf[1], pg[1]);
     take(ptab[d_lo + 1], pm[2], pf[2], pg[2]);            // ptab has D + 2 entries, the last two invalid
     f32x4 nxt = ptab[d_lo + 2 < D + 2 ? d_lo + 2 : D + 1];
-    float wf[3][8], wg[3][8];
+    // window kd of channel c = the PAIR {F_kd[c][w - m - 1], G_kd[c][w - m]}: two adjacent floats of the staged row (one ds_read2_b32,
+    // landing in the register pair the packed FMA reads), G's correction subtracted from the second by the <= 3 lanes it concerns.
+    // Per plane and channel: three v_pk_fma_f32 {f, g} * {F, G} into a pair of partial sums (the f-terms | the g-terms) and one add
+    // (r4's form: six v_fmac and the window in two separate registers, 16 ds_read_b32 per move)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 win[3][8];
     int mw[3] = {kNone, kNone, kNone};
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) wf[kd][c] = wg[kd][c] = 0.0f;
+        for (int c = 0; c < 8; ++c) win[kd][c] = f32x2{0.0f, 0.0f};
     float vmax = 0.0f;
     const float lo_bound = relu ? 0.0f : -65504.0f;
     for (int d = d_lo; d < d_hi; ++d) {
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
             if (pm[kd] != mw[kd] && pm[kd] != kInvalid) {      // wave-uniform: the window of this kd moves
-                int idx = FP + w - pm[kd] - 1;                   // column w - m - 1 of the staged rows; left of the pad: zeros
-                const int fi = idx < 0 ? 0 : idx, gi = idx + 1 < 0 ? 0 : idx + 1;
+                const int idx = FP + w - pm[kd] - 1;             // column w - m - 1 of the staged rows; left of the pad: zeros
+                const int fi = idx < 0 ? 0 : idx;                // (columns 0 .. FP - 2 of a staged row are zeros: fi = 0, fi + 1 = 1 read two of them)
                 const int gcol = w - pm[kd];                     // the G-term's column: -1, 0, 1 carry the gate's correction
+                const float *fr = rowsF + kd * 8 * LW + fi;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    wf[kd][c] = rowsF[(kd * 8 + c) * LW + fi];
-                    wg[kd][c] = rowsF[(kd * 8 + c) * LW + gi];
-                }
+                for (int c = 0; c < 8; ++c) win[kd][c] = f32x2{fr[c * LW], fr[c * LW + 1]};
                 if ((unsigned)(gcol + 1) <= 2u) {                // at most three lanes of the row
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) wg[kd][c] -= corr[(kd * 8 + c) * 4 + gcol + 1];
+                    for (int c = 0; c < 8; ++c) win[kd][c][1] -= corr[(kd * 8 + c) * 4 + gcol + 1];
                 }
                 mw[kd] = pm[kd];
             }
@@ -1331,12 +1332,25 @@ warped_expand_split_kernel(const float *__restrict__ p, const float *__restrict_
         take(nxt, nm, nff, ngg);
         nxt = ptab[d + 3 < D + 2 ? d + 3 : D + 1];
         const int cls = d == 0 ? 0 : (d == D - 1 ? 2 : 1);
+        const f32x2 fg0 = {pf[0], pg[0]}, fg1 = {pf[1], pg[1]}, fg2 = {pf[2], pg[2]};
+        float pe[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pe[c] = pl[c];
+        if (cls != 1) {                      // block-uniform, two planes of the whole walk
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int co = cg * 8 + c;
+                pe[c] = (planes && co < C) ? planes[(((n * C + co) * 3 + cls) * (int64_t)H + h) * W + w] : 0.0f;
+            }
+        }
         h8v hi, lo;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            float o = cls == 0 ? pl[0][c] : (cls == 2 ? pl[2][c] : pl[1][c]);
-#pragma unroll
-            for (int kd = 0; kd < 3; ++kd) o = __builtin_fmaf(pg[kd], wg[kd][c], __builtin_fmaf(pf[kd], wf[kd][c], o));
+            const float base = pe[c];
+            f32x2 a2 = __builtin_elementwise_fma(fg0, win[0][c], f32x2{base, 0.0f});
+            a2 = __builtin_elementwise_fma(fg1, win[1][c], a2);
+            a2 = __builtin_elementwise_fma(fg2, win[2][c], a2);
+            float o = a2[0] + a2[1];
             if (last) o -= tas[c * DC + (d - d_lo)];
             float t = __builtin_fmaf(o, sc[c], bi[c]);
             vmax = __builtin_fmaxf(vmax, __builtin_fabsf(t));
@@ -1453,9 +1467,10 @@ int snvc_sheared_expand_split(const float *g, const float *gcol, const float *pl
     if (W > 512 || G > 4095 || N > 65535 || H >= ((int64_t)1 << 31))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: row too wide (W <= 512) or too many channels");
     const int LW = (int)((WG + q - 1) / q) + 4;
-    // depth chunks: enough workgroups to cover the chip four times over, at least 8 planes each
+    // depth chunks: at least two workgroups per CU, at least 8 planes each -- and no more: all of the launch's workgroups resident at
+    // once (five fit a CU) and long walks measure best (r5, cfg2's 96 rows x 4 groups: 1 chunk 166 us, 2: 156, 4: 169, 8: 171, 16: 180)
     int DCH = 1;
-    while (DCH < 16 && H * G * N * DCH < 4 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
+    while (DCH < 16 && H * G * N * DCH < 2 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
     const int DC = (int)ceil_div<int64_t>(D, DCH);
     const size_t lds = sizeof(float) * (8 * (size_t)q * LW + 8 * (size_t)DC);
     if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: the row does not fit the LDS");
@@ -1632,7 +1647,8 @@ int snvc_warped_expand_split(const float *p, const float *q, const float *e, con
     const int64_t G = ceil_div<int64_t>(C, 8);
     if (W > 512 || G > 4095 || N > 65535 || H >= ((int64_t)1 << 31))
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_warped_expand_split: row too wide (W <= 512) or too many channels");
-    int DCH = 1;         // depth chunks: about three workgroups per CU (four fit; every workgroup re-stages its 24 rows)
+    int DCH = 1;         // depth chunks: about three workgroups per CU (four fit; every workgroup re-stages its 24 rows).  r5, cfg2: 1 chunk
+                         // 251 us, 2 chunks 185, 4 chunks 225
     while (DCH < 16 && H * G * N * DCH < 3 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
     const int DC = (int)ceil_div<int64_t>(D, DCH);
     const size_t lds = sizeof(float) * (24 * (size_t)(W + 16) + 96 + 8 * (size_t)DC + 4 + 4 * (size_t)(D + 2));
