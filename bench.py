@@ -1295,7 +1295,7 @@ def main():
             sus["pairs_per_s"] = world * float(t.item())
         print(json.dumps({"rank_record_sustained": dict(sus, rank=rank)}), file=sys.stderr, flush=True)
         if rank == 0:
-            sus["note"] = ("`value` is the driver's 20-step window after a 0.15 s pre-warm; this is the same step for >= 5 s on a part already "
+            sus["note"] = (f"`value` is the driver's 20-step window after a {PREWARM_S} s pre-warm; this is the same step for >= 5 s on a part already "
                            "warm from the other legs -- what a deployment running the step continuously sees")
             sus["vs_value"] = sus["pairs_per_s"] / line["value"]
             line["sustained"] = sus
