@@ -137,7 +137,7 @@ def local_inputs(grid, F, crops=1, seed=7):
             r.uniform(-8, 264, (crops, 2, v)).astype(np.float32), r.uniform(-8, 264, (crops, 2, v)).astype(np.float32))
 
 
-def local_oracle(grid, F, crops=1, seed=7, keep_layers=False, heads=False):
+def local_oracle(grid, F, crops=1, seed=7, keep_layers=False, heads=False, gn=False):
     """The CPU oracle of the local (V-A) model's path on `crops` crops: numpy restatement of _sample_2d_feat (vernier.py:323-349) +
     the torch-CPU restatement of the BEV_type3 3D trunk (vernier.py:414-438) that tests/golden pins bit-equal to the imported
     reference, with bench.seeded_state's weights of the product model.  Returns a dict: the inputs, "voxel", "bev", "occupancy" (host
@@ -147,12 +147,12 @@ def local_oracle(grid, F, crops=1, seed=7, keep_layers=False, heads=False):
     from snvc_amd.models.vernier import VernierScale
     cores = torch.get_num_threads()                    # torch's own default: the caller's process setting is left alone (a test
     #                                                    process that is switched to os.cpu_count() threads on a 16-CPU share crawls)
-    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=False, grid_resolution=[32, grid[1], 192],
+    cfg = types.SimpleNamespace(vernier_type="BEV_type3", backbone="hrfeat", gn=gn, grid_resolution=[32, grid[1], 192],
                                 resolution=(256, 256), x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), num_parts=9)
     cfg.hrfeat = types.SimpleNamespace(output_channel=F, name="identity")
     cfg.n_sample_h, cfg.n_sample_w, cfg.n_sample_l = grid
     sd = seeded_state(VernierScale(cfg))               # the product model's parameters (CPU construction: nothing runs)
-    ref = T.VernierTrunk(F, grid, heads=heads)      # heads: the 2D BEV neck + heat-map / coordinate heads too (grids with nh in {16, 32})
+    ref = T.VernierTrunk(F, grid, gn=gn, heads=heads)      # heads: the 2D BEV neck + heat-map / coordinate heads too (grids with nh in {16, 32})
     ref.load_state_dict({k: sd[k] for k in ref.state_dict()})
     ref.eval()
     lf, rf, gl, gr = local_inputs(grid, F, crops, seed)
@@ -535,11 +535,18 @@ def off_fast_path(device, reps=10):
         grid, F, crops = (32, 128, 192), 32, 2
         pl, pr = projected_coordinates(crops, grid, device)
         lf, rf = (torch.from_numpy(a).to(device) for a in local_inputs(grid, F, crops, 5)[:2])
-        for tag, gn in (("released_trunk_groupnorm", True), ("released_trunk_batchnorm_fp32_mfma", False)):
+        # (r5: a GroupNorm trunk runs in split mode too -- convolution in split mode with an fp32 result, statistics, one affine pass
+        # that writes the split pair; `released_trunk_groupnorm_fp32_mfma` is the same model with that switched off = r4's behaviour)
+        for tag, gn, prec, x3gn in (("released_trunk_groupnorm", True, "auto", True), ("released_trunk_groupnorm_fp32_mfma", True, "auto", False),
+                                    ("released_trunk_batchnorm_fp32_mfma", False, "f32", True)):
             m = local_model(grid, F, device, gn=gn)
-            m.precision = "f32" if not gn else "auto"
-            b = S_._ROUTES["x3_local_trunk"]
-            ms, _ = timed_ms(lambda: m.trunk_3d(m.construct_voxel(lf, rf, pl, pr)), reps, 3)
+            m.precision = prec
+            S_.X3_GROUP_NORM[0] = x3gn
+            try:
+                b = S_._ROUTES["x3_local_trunk"]
+                ms, _ = timed_ms(lambda: m.trunk_3d(m.construct_voxel(lf, rf, pl, pr)), reps, 3)
+            finally:
+                S_.X3_GROUP_NORM[0] = True
             out[tag] = {"ms_per_crop": ms / crops, "crops_per_s": 1e3 * crops / ms, "split_mode": S_._ROUTES["x3_local_trunk"] > b}
             del m
         # 2. the global stack with GroupNorm

@@ -544,6 +544,15 @@ SNVC_API int snvc_f16_conv3d_forward(const snvc_conv3d_desc *desc_host, const vo
 SNVC_API int snvc_f16x3_from_ncdhw(const float *x, void *y_hi, void *y_lo, int64_t N, int64_t C, int64_t S,
                                    int64_t x_batch_stride, int64_t y_batch_stride, float mul, const float *mul_dev,
                                    void *stream);
+/* replaces: the norm + residual + activation of a convbn_3d(..., gn=True) layer (submodule.py:41-49, GroupNorm(32, C)) behind a
+ * split-mode convolution with an fp32 result: x = the raw fp32 NCDHW conv result, scale / shift [N or 1][C] from its statistics
+ * (snvc_norm_stats; per_sample = 1 for GroupNorm), res a split pair in units 2^-e_res (res_mul = 2^-e_res) or NULL,
+ *   y = split( out_mul * ( act(scale * x + shift [+ res]) [+ res] ) ),   flags: SNVC_EPI_RELU, SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST.
+ * A value beyond half's range is clamped and sets *overflow (may be NULL).  Batch strides in elements, 0 = dense. */
+SNVC_API int snvc_f16x3_affine_from_ncdhw(const float *x, const float *scale, const float *shift, const void *res_hi,
+                                          const void *res_lo, void *y_hi, void *y_lo, int *overflow, int64_t N, int64_t C,
+                                          int64_t S, int64_t x_batch_stride, int64_t y_batch_stride, int64_t res_batch_stride,
+                                          int per_sample, int flags, float out_mul, float res_mul, void *stream);
 /* replaces: torch.cat([voxel, voxel_img_feat * occupancy], dim=1)'s second half (vernier.py:433) on split pairs:
  *   out = split((hi + lo) * occ), occ an fp32 plane [N][S]; C % 8 == 0; the pair's exponent is unchanged. */
 SNVC_API int snvc_f16x3_mul_broadcast(const void *feat_hi, const void *feat_lo, const float *occ, void *out_hi, void *out_lo,

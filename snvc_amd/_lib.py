@@ -101,6 +101,8 @@ SIGNATURES = {
     "snvc_f16_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p]),
     "snvc_f16_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_f16x3_from_ncdhw": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_p, c_p]),
+    "snvc_f16x3_affine_from_ncdhw": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int,
+                                             c_f32, c_f32, c_p]),
     "snvc_f16x3_mul_broadcast": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_f16x3_to_ncdhw": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_f32, c_p]),
     "snvc_f16x3_conv3d_packed_weight_bytes": (c_i64, [ctypes.POINTER(Conv3dDesc)]),

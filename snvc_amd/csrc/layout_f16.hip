@@ -57,6 +57,49 @@ ncdhw_f32_to_c8_split_kernel(const float *__restrict__ x, _Float16 *__restrict__
     *reinterpret_cast<h8 *>(yl + n * y_bs + ((int64_t)g * S + s) * 8) = ol;
 }
 
+// GroupNorm layers in split mode (r5): the layer's raw fp32 NCDHW result -> the split C8 pair of  act(scale * raw + shift [+ res]) [+ res],
+// scale / shift per (sample, channel) from the statistics of `raw` (snvc_norm_stats), the residual a split pair in its own units
+// (res_mul = 2^-e_res).  Result * out_mul (2^e) is clamped to half's range and flagged like every split-mode epilogue.
+__global__ void __launch_bounds__(256)
+ncdhw_affine_to_c8_split_kernel(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                                const _Float16 *__restrict__ rh, const _Float16 *__restrict__ rl, _Float16 *__restrict__ yh,
+                                _Float16 *__restrict__ yl, int *__restrict__ overflow, int C, int64_t S, int64_t x_bs, int64_t y_bs,
+                                int64_t r_bs, int per_sample, int flags, float out_mul, float res_mul) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int g = blockIdx.y;
+    const int64_t n = blockIdx.z;
+    const float *xp = x + n * x_bs + (int64_t)g * 8 * S + s;
+    const float *sc = scale + (per_sample ? n * C : 0) + g * 8, *sh = shift + (per_sample ? n * C : 0) + g * 8;
+    const bool relu = (flags & SNVC_EPI_RELU) != 0, pre = (flags & SNVC_EPI_ADD_PRE) != 0, post = (flags & SNVC_EPI_ADD_POST) != 0;
+    h8 rhi = {}, rlo = {};
+    if (rh) {
+        rhi = *reinterpret_cast<const h8 *>(rh + n * r_bs + ((int64_t)g * S + s) * 8);
+        rlo = *reinterpret_cast<const h8 *>(rl + n * r_bs + ((int64_t)g * S + s) * 8);
+    }
+    h8 o, ol;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float v = 0.0f;
+        if (g * 8 + e < C) {
+            v = __builtin_fmaf(xp[(int64_t)e * S], sc[e], sh[e]);
+            const float r = rh ? ((float)rhi[e] + (float)rlo[e]) * res_mul : 0.0f;
+            if (pre) v += r;
+            if (relu) v = v > 0.0f ? v : 0.0f;
+            if (post) v += r;
+            v *= out_mul;
+        }
+        const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+        vmax = __builtin_fmaxf(vmax, __builtin_fabsf(c));
+        o[e] = (_Float16)c;
+        ol[e] = (_Float16)(c - (float)o[e]);
+    }
+    *reinterpret_cast<h8 *>(yh + n * y_bs + ((int64_t)g * S + s) * 8) = o;
+    *reinterpret_cast<h8 *>(yl + n * y_bs + ((int64_t)g * S + s) * 8) = ol;
+    if (vmax >= 65504.0f && overflow) atomicOr(overflow, 1);
+}
+
 __global__ void __launch_bounds__(256)
 c8_split_to_ncdhw_f32_kernel(const _Float16 *__restrict__ xh, const _Float16 *__restrict__ xl, float *__restrict__ y, int C, int64_t S,
                              int64_t x_bs, int64_t y_bs, float mul) {
@@ -187,6 +230,32 @@ int snvc_f16x3_from_ncdhw(const float *x, void *y_hi, void *y_lo, int64_t N, int
                                                                      (int)C, S, x_batch_stride ? x_batch_stride : C * S,
                                                                      y_batch_stride ? y_batch_stride : 2 * G * 8 * S, mul, mul_dev);
     return check_launch("snvc_f16x3_from_ncdhw");
+}
+
+int snvc_f16x3_affine_from_ncdhw(const float *x, const float *scale, const float *shift, const void *res_hi, const void *res_lo,
+                                 void *y_hi, void *y_lo, int *overflow, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                                 int64_t y_batch_stride, int64_t res_batch_stride, int per_sample, int flags, float out_mul,
+                                 float res_mul, void *stream) {
+    using namespace snvc;
+    if (N < 0 || C <= 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_affine_from_ncdhw: bad sizes");
+    if (flags & ~(SNVC_EPI_RELU | SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_affine_from_ncdhw: RELU / ADD_PRE / ADD_POST only");
+    if ((flags & SNVC_EPI_ADD_PRE) && (flags & SNVC_EPI_ADD_POST)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_affine_from_ncdhw: one residual position");
+    if (N == 0 || S == 0) return SNVC_OK;
+    const int64_t G = ceil_div<int64_t>(C, 8);
+    if (!x || !scale || !shift || !y_hi || !y_lo || ((reinterpret_cast<uintptr_t>(y_hi) | reinterpret_cast<uintptr_t>(y_lo)) & 15))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_affine_from_ncdhw: null or unaligned pointer");
+    const bool want_res = (flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) != 0;
+    if (want_res != (res_hi != nullptr) || (res_hi == nullptr) != (res_lo == nullptr))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_affine_from_ncdhw: a residual pair exactly when ADD_PRE / ADD_POST is set");
+    if (res_hi && ((reinterpret_cast<uintptr_t>(res_hi) | reinterpret_cast<uintptr_t>(res_lo)) & 15))
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_affine_from_ncdhw: unaligned residual");
+    if (!grid_ok(S, G, N)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_affine_from_ncdhw: tensor too large");
+    dim3 grid((unsigned)ceil_div<int64_t>(S, 256), (unsigned)G, (unsigned)N);
+    ncdhw_affine_to_c8_split_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+        x, scale, shift, reinterpret_cast<const _Float16 *>(res_hi), reinterpret_cast<const _Float16 *>(res_lo), reinterpret_cast<_Float16 *>(y_hi),
+        reinterpret_cast<_Float16 *>(y_lo), overflow, (int)C, S, x_batch_stride ? x_batch_stride : C * S,
+        y_batch_stride ? y_batch_stride : 2 * G * 8 * S, res_batch_stride ? res_batch_stride : 2 * G * 8 * S, per_sample, flags, out_mul, res_mul);
+    return check_launch("snvc_f16x3_affine_from_ncdhw");
 }
 
 int snvc_f16x3_to_ncdhw(const void *x_hi, const void *x_lo, float *y, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,

@@ -983,7 +983,17 @@ def x3_exponent(bound: float) -> int:
 
 
 def x3_norm_bound(norm, plan) -> float:
-    """|beta| + X3_SIGMAS * |gamma| of a frozen BatchNorm3d, maximised over channels (cached with the folded affine)."""
+    """|beta| + X3_SIGMAS * |gamma| of a frozen BatchNorm3d, maximised over channels (cached with the folded affine); of a
+    GroupNorm likewise (its result is gamma * xhat + beta with xhat normalised per sample and group)."""
+    if isinstance(norm, nn.GroupNorm):
+        w, b = norm.weight, norm.bias
+        gkey = (None if w is None else (w.data_ptr(), w._version), None if b is None else (b.data_ptr(), b._version), _GENERATION[0])
+        hit = getattr(plan, "x3_gn_bound", None)
+        if hit is None or hit[0] != gkey:
+            g = w.detach().abs() if w is not None else torch.ones(1)
+            bb = b.detach().abs().to(g.device) if b is not None else torch.zeros(1, device=g.device)
+            hit = plan.x3_gn_bound = (gkey, float((bb + X3_SIGMAS * g).max().item()), w, b)      # w, b held: no address reuse
+        return hit[1]
     key = getattr(plan, "bn_key", None)
     hit = getattr(plan, "x3_bound", None)
     if hit is None or hit[0] != key or key is None:
@@ -994,15 +1004,21 @@ def x3_norm_bound(norm, plan) -> float:
     return hit[1]
 
 
-def x3_ok(*modules) -> bool:
-    """Every norm a frozen BatchNorm3d (eval mode, running statistics), nothing to differentiate."""
+def x3_ok(*modules, group_norm: bool = True) -> bool:
+    """Every norm a frozen BatchNorm3d (eval mode, running statistics) or -- r5, ``group_norm`` -- a GroupNorm (its statistics are
+    taken from the layer's fp32 result, see fused_conv3d_x3); nothing to differentiate."""
     if torch.is_grad_enabled():
         return False
     for m in modules:
         for n in m.modules():
-            if isinstance(n, nn.GroupNorm) or (isinstance(n, nn.modules.batchnorm._BatchNorm) and (n.training or n.running_mean is None)):
+            if isinstance(n, nn.GroupNorm) and not (group_norm and X3_GROUP_NORM[0]):
+                return False
+            if isinstance(n, nn.modules.batchnorm._BatchNorm) and (n.training or n.running_mean is None):
                 return False
     return True
+
+
+X3_GROUP_NORM = [True]      # False: GroupNorm models stay on the fp32-MFMA kernels (r4's behaviour; kept for measuring)
 
 
 def fused_conv3d_x3(conv: nn.Module, norm: Optional[nn.Module], x: SplitT, *, relu=False, sigmoid=False, residual: Optional[SplitT] = None,
@@ -1019,6 +1035,8 @@ def fused_conv3d_x3(conv: nn.Module, norm: Optional[nn.Module], x: SplitT, *, re
         plan.key = key
     scale = bias = None
     bound = None
+    if isinstance(norm, nn.GroupNorm):
+        return _fused_conv3d_x3_gn(plan, norm, x, relu, sigmoid, residual, residual_after_act, out, out_exp, to_f32, flag)
     if norm is not None:
         scale, bias = _folded_bn(norm, plan)
         bound = x3_norm_bound(norm, plan)
@@ -1040,6 +1058,37 @@ def fused_conv3d_x3(conv: nn.Module, norm: Optional[nn.Module], x: SplitT, *, re
     y = plan.layer(x.t, 0 if x.mul_dev is not None else x.exp, scale, bias, residual=res_t, flags=flags, out=out, out_exp=e,
                    to_f32=f32, overflow=flag, x_mul_dev=x.mul_dev, res_exp=residual.exp if residual is not None else None)
     return y if f32 else SplitT(y, e, bound)
+
+
+def _fused_conv3d_x3_gn(plan, norm, x: SplitT, relu, sigmoid, residual, residual_after_act, out, out_exp, to_f32, flag):
+    """A ``convbn_3d(..., gn=True)`` layer (reference submodule.py:41-49) in split mode (r5): GroupNorm needs the statistics of the
+    convolution's own result, so the layer is  split-mode convolution -> fp32 NCDHW raw result -> snvc_norm_stats (per sample and
+    group) -> one pass that applies scale / shift (+ residual, activation) and writes the split pair
+    (snvc_f16x3_affine_from_ncdhw) -- or, ``to_f32``, the fp32 tensor (snvc_affine_act).  The convolution is the same three-MFMA
+    arithmetic as every split layer; the statistics and the affine are the fp32 path's own kernels."""
+    if sigmoid:
+        raise NotImplementedError("split mode: GroupNorm + Sigmoid is not on the path")
+    raw = plan.layer(x.t, 0 if x.mul_dev is not None else x.exp, None, None, flags=0, out_exp=0, to_f32=True, x_mul_dev=x.mul_dev)
+    scale, shift, _, _ = ops.norm_stats(raw, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
+    flags = EPI_RELU if relu else 0
+    _ROUTES["x3_group_norm"] += 1
+    if to_f32:
+        res32 = None
+        if residual is not None:
+            flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
+            res32 = ops.from_split(residual.t, residual.exp)
+        return ops.affine_act(raw, scale, shift, res32, flags, per_sample=True, out=out if out is not None else raw)
+    bound = x3_norm_bound(norm, plan)
+    res_t, res_exp = None, 0
+    if residual is not None:
+        flags |= EPI_ADD_POST if residual_after_act else EPI_ADD_PRE
+        if residual.bound is None:
+            raise RuntimeError("split mode: a residual add needs bounds on both summands")
+        bound = bound + residual.bound
+        res_t, res_exp = residual.t, residual.exp
+    e = x3_exponent(bound) if out_exp is None else out_exp
+    y = ops.affine_act_split(raw, scale, shift, e, residual=res_t, res_exp=res_exp, flags=flags, per_sample=True, out=out, overflow=flag)
+    return SplitT(y, e, bound)
 
 
 class ConvBN3d(nn.Sequential):

@@ -174,7 +174,7 @@ class VernierScale(nn.Module):
 
     def _x3_local(self, voxel, device=None, channels=None):
         """The split-mode bookkeeping of this model (overflow flag + its pinned host copy) if this call runs the trunk in split
-        mode, else None: inference only, frozen BatchNorm3d everywhere, channels a multiple of 32, no part_reg_head.
+        mode, else None: inference only, every norm a frozen BatchNorm3d or (r5) a GroupNorm, channels a multiple of 32, no part_reg_head.
         ``voxel``: the fp32 gather result, an already split ``SplitT`` (``construct_voxel_x3``), or None with ``device`` /
         ``channels`` given (the question asked before the gather runs)."""
         from .submodule import SplitT, x3_ok
@@ -198,7 +198,7 @@ class VernierScale(nn.Module):
               and x3_ok(self.vimg_feat, self.conv1, self.conv2, self.conv3, self.conv4, self.hg_conv3d, self.fg_cls_head))
         if not ok:
             if want:
-                raise RuntimeError("precision='x3': the trunk does not qualify (inference, eval-mode BatchNorm3d, 2F % 64 == 0)")
+                raise RuntimeError("precision='x3': the trunk does not qualify (inference, eval-mode BatchNorm3d or GroupNorm, 2F % 64 == 0)")
             return None
         from .submodule import overflow_guard
         guard = overflow_guard(self, device)

@@ -1236,6 +1236,47 @@ def to_split(x: torch.Tensor, exp: int = 0, out: Optional[torch.Tensor] = None, 
     return out
 
 
+def affine_act_split(raw, scale, shift, out_exp: int, residual=None, res_exp: int = 0, flags: int = 0, per_sample: bool = True, out=None,
+                     overflow=None):
+    """The norm + residual + activation of a GroupNorm layer behind a split-mode convolution (snvc_f16x3_affine_from_ncdhw): ``raw`` the
+    float32 [N,C,D,H,W] conv result, ``scale`` / ``shift`` [N or 1, C] from ``norm_stats``, ``residual`` a split pair holding values *
+    2**res_exp; returns the split pair of ``act(scale * raw + shift [+ res]) [+ res]`` times 2**out_exp (clamped and flagged)."""
+    _gpu(raw, "raw")
+    if raw.dtype != torch.float32 or raw.dim() != 5:
+        raise RuntimeError("affine_act_split needs a float32 [N,C,D,H,W] tensor")
+    if not _dense_inner(raw):
+        raw = raw.contiguous()
+    n, c = raw.shape[0], raw.shape[1]
+    sp = tuple(raw.shape[2:])
+    shape = (n, 2, (c + 7) // 8) + sp + (8,)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float16, device=raw.device)
+    else:
+        _split_check(out, "out")
+        if tuple(out.shape) != shape:
+            raise RuntimeError("affine_act_split: out has the wrong shape")
+    want_res = bool(flags & (EPI_ADD_PRE | EPI_ADD_POST))
+    if want_res != (residual is not None):
+        raise RuntimeError("affine_act_split: a residual exactly when EPI_ADD_PRE / EPI_ADD_POST is set")
+    if residual is not None:
+        _split_check(residual, "residual")
+        if tuple(residual.shape) != shape:
+            raise RuntimeError("residual must have the result's shape (split C8)")
+    for t in (scale, shift):
+        if t.dtype != torch.float32 or tuple(t.shape) != ((n if per_sample else 1), c) or not t.is_contiguous():
+            raise RuntimeError("scale / shift must be contiguous float32 [N or 1, C]")
+    if raw.numel() == 0:
+        return out
+    null = ctypes.c_void_p(0)
+    with torch.cuda.device(raw.device):
+        check(_lib.lib().snvc_f16x3_affine_from_ncdhw(
+            _ptr(raw), _ptr(scale), _ptr(shift), _ptr(residual) if residual is not None else null,
+            _lo_ptr(residual) if residual is not None else null, _ptr(out), _lo_ptr(out), _ptr(overflow), n, c, math.prod(sp),
+            _batch_stride(raw), _batch_stride(out), _batch_stride(residual) if residual is not None else 0, 1 if per_sample else 0,
+            int(flags), float(2.0 ** out_exp), float(2.0 ** -res_exp), _stream(raw)), "snvc_f16x3_affine_from_ncdhw")
+    return out
+
+
 def split_scale_for(*tensors) -> torch.Tensor:
     """A one-element device tensor holding the power of two that puts max|t| over the given tensors into [2^13, 2^14) (1 for an
     all-zero or non-finite input): the scale of a split pair whose range is only known from the data.  Device-side, no sync."""

@@ -214,3 +214,31 @@ def test_whole_forward_at_the_released_shape_vs_oracle(precision):
     got_idx = out["ncf"].flatten(2).argmax(dim=2).cpu()
     exp_idx = o["heat"].flatten(2).argmax(dim=2)
     assert torch.equal(got_idx, exp_idx), "heat-map arg-max indices differ from the oracle's"
+
+
+def test_groupnorm_trunk_in_split_mode_vs_oracle():
+    """convbn_3d(..., gn=True) (reference submodule.py:41-49): a GroupNorm trunk takes split mode too (r5) -- split-mode convolution
+    with an fp32 result, snvc_norm_stats, one affine pass that writes the split pair.  Whole bev / occupancy against the oracle's
+    GroupNorm trunk, and against the same model on the fp32-MFMA kernels (X3_GROUP_NORM off = r4's behaviour)."""
+    import bench
+    from snvc_amd.models import submodule as S
+    grid, f = (32, 64, 96), 32
+    o = bench.local_oracle(grid, f, 2, seed=11, gn=True)
+    m = bench.local_model(grid, f, dev(), gn=True)
+    lf, rf, gl, gr = (torch.from_numpy(o[k]).to(dev()) for k in ("lf", "rf", "gl", "gr"))
+    with torch.no_grad():
+        b, bg = S._ROUTES["x3_local_trunk"], S._ROUTES["x3_group_norm"]
+        bev, occ, _ = m.trunk_3d(m.construct_voxel(lf, rf, gl, gr))
+        assert S._ROUTES["x3_local_trunk"] == b + 1 and S._ROUTES["x3_group_norm"] > bg + 10, "the GroupNorm trunk did not take split mode"
+        assert not m.__dict__.get("_snvc_x3_off")
+        S.X3_GROUP_NORM[0] = False
+        try:
+            bev32, occ32, _ = m.trunk_3d(m.construct_voxel(lf, rf, gl, gr))
+            assert S._ROUTES["x3_local_trunk"] == b + 1
+        finally:
+            S.X3_GROUP_NORM[0] = True
+    e1 = check_t(bev, o["bev"], 1e-4, "GroupNorm trunk [split] bev vs oracle")
+    e2 = check_t(occ, o["occupancy"], 1e-4, "GroupNorm trunk [split] occupancy vs oracle")
+    e3 = check_t(bev32, o["bev"], 3e-4, "GroupNorm trunk [fp32 MFMA] bev vs oracle")
+    print(f"GroupNorm trunk vs oracle: split bev {e1:.2e} occupancy {e2:.2e}; fp32-MFMA bev {e3:.2e}")
+    o.clear()

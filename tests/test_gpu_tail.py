@@ -212,3 +212,37 @@ def test_global_stack_split_prep_equals_fp32_prep():
         m.split_prep = True
     check(v1a.cpu().numpy(), v1b.cpu().numpy(), TIGHT, "any shift: first layer, split prep vs fp32 prep")
     check(a.cpu().numpy(), b.cpu().numpy(), 1e-5, "any shift: stack output, split prep vs fp32 prep")
+
+
+@pytest.mark.parametrize("res_mode", ["none", "pre", "post"])
+def test_affine_act_split_vs_torch(res_mode):
+    """snvc_f16x3_affine_from_ncdhw (the norm + residual + activation pass of a GroupNorm layer in split mode): per-(sample, channel)
+    affine of an fp32 NCDHW tensor, residual a split pair in its own units, ReLU, result as a split pair; clamp + flag."""
+    from snvc_amd import ops
+    d = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n, c, sp = 2, 44, (3, 5, 37)          # 44 channels: a ragged last group (channels 44..47 do not exist)
+    raw = torch.randn(n, c, *sp, generator=g).to(d) * 3
+    sc = (torch.rand(n, c, generator=g) + 0.5).to(d)
+    sh = torch.randn(n, c, generator=g).to(d)
+    res = torch.randn(n, c, *sp, generator=g).to(d) * 2
+    res_s = ops.to_split(res, 3)
+    res_v = ops.from_split(res_s, 3, c)                     # what the pair holds (22 bits)
+    flags = ops.EPI_RELU | {"none": 0, "pre": ops.EPI_ADD_PRE, "post": ops.EPI_ADD_POST}[res_mode]
+    flag = torch.zeros(1, dtype=torch.int32, device=d)
+    y = ops.affine_act_split(raw, sc, sh, 2, residual=None if res_mode == "none" else res_s, res_exp=3, flags=flags, overflow=flag)
+    v = raw * sc[:, :, None, None, None] + sh[:, :, None, None, None]
+    if res_mode == "pre":
+        v = v + res_v
+    v = torch.relu(v)
+    if res_mode == "post":
+        v = v + res_v
+    got = ops.from_split(y, 2, c)
+    err = (got - v).abs().max().item() / v.abs().max().item()
+    assert err < 2e-6, err
+    assert flag.item() == 0
+    assert torch.isfinite(y.float()).all()
+    assert torch.all(y[:, :, 5, ..., 4:8].float() == 0)      # channels 44..47 of the ragged group are zeros
+    # clamp + flag: a scale that pushes values out of half's range
+    y2 = ops.affine_act_split(raw * 1e4, sc, sh, 4, flags=0, overflow=flag)
+    assert flag.item() == 1 and torch.isfinite(y2.float()).all()
