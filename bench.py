@@ -554,10 +554,16 @@ def off_fast_path(device, reps=10):
         g = GlobalStack(C, gn=True)
         g.load_state_dict(seeded_state(g))
         g.eval().to(device)
-        b = S_._ROUTES["x3_tail"]
-        ms, _ = timed_ms(lambda: g.forward_pair(left, right, shift, 1), reps, 3)
-        out["cfg2_groupnorm"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms, "split_mode": S_._ROUTES["x3_tail"] > b,
-                                 "note": "GlobalStack(gn=True): every norm needs its conv result's statistics (two passes over each activation)"}
+        for tag, x3gn in (("cfg2_groupnorm", True), ("cfg2_groupnorm_fp32_mfma", False)):
+            S_.X3_GROUP_NORM[0] = x3gn
+            try:
+                b = S_._ROUTES["x3_gn_tail"]
+                ms, _ = timed_ms(lambda: g.forward_pair(left, right, shift, 1), reps, 3)
+            finally:
+                S_.X3_GROUP_NORM[0] = True
+            out[tag] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms, "split_mode": S_._ROUTES["x3_gn_tail"] > b,
+                        "note": "GlobalStack(gn=True): every norm needs its conv result's statistics -- the volume is built, each layer is "
+                                "convolution -> statistics -> affine pass (r5: the convolutions in split mode, nothing fused around them)"}
         del g
         torch.cuda.empty_cache()
         # 3. downsample = 2: features at twice the resolution, the volume sampled at every second pixel (materialised volume)

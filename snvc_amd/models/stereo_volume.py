@@ -284,7 +284,57 @@ class GlobalStack(nn.Module):
         cost, _, _ = self.hg_conv3d(v, None, None, residual=v, head=self.classifier, head_residual=hv)
         return cost
 
+    def _gn_qualifies(self, device, arithmetic=None):
+        """The overflow guard if this call can run a GroupNorm stack in split mode (see _gn_tail_x3), else None."""
+        from .submodule import X3_GROUP_NORM, overflow_guard
+        mode = arithmetic or self.arithmetic
+        norms = [m for m in self.modules() if isinstance(m, (nn.GroupNorm, nn.modules.batchnorm._BatchNorm))]
+        if (not norms or not all(isinstance(m, nn.GroupNorm) for m in norms) or not X3_GROUP_NORM[0] or mode == "fp32"
+                or torch.is_grad_enabled() or self.training or self.__dict__.get("_snvc_x3_off") or device.type != "cuda"
+                or self.conv1[0][0].out_channels % 32 != 0):
+            return None
+        guard = overflow_guard(self, device)
+        if guard.event is not None and self._overflowed(guard, mode, "an earlier call's result clamped it"):
+            return None
+        return guard
+
+    def _gn_tail_x3(self, v1, timing=None, arithmetic=None):
+        """A GroupNorm stack (``GlobalStack(gn=True)``) behind its fp32 first-layer result, in split mode (r5): nothing folds here
+        (every norm needs its own conv result's statistics), so the layers run one by one through ``fused_conv3d_x3``'s GroupNorm
+        form -- conv2, the hourglass, conv6 + cost0 -- and the 1x1x1 classifier on the fp32 kernel.  Returns None when the
+        call does not qualify.  A flagged call raises SplitOverflow (``_checked`` redoes it in fp32)."""
+        from .submodule import SplitT, x3_exponent, x3_norm_bound, _Plan
+        if isinstance(v1, SplitT):          # conv1 ran in split mode already (_forward_volume_unchecked): its guard is the caller's
+            v1s, guard = v1, self.__dict__["_snvc_x3_guard"][v1.t.device]
+        else:
+            if not (v1.is_cuda and v1.dtype == torch.float32):
+                return None
+            guard = self._gn_qualifies(v1.device, arithmetic)
+            if guard is None:
+                return None
+            norm1 = self.conv1[0][1]
+            b1 = x3_norm_bound(norm1, self.conv1[0][0].__dict__.setdefault("_snvc_plans_x3", {}).setdefault(v1.device, _Plan()))
+            e1 = x3_exponent(b1)
+            n, c = v1.size(0), v1.size(1)
+            v1s = SplitT(ops.to_split(v1, e1, out=self._buffer("v1s", (n, 2, c // 8) + tuple(v1.shape[2:]) + (8,), v1.device, torch.float16)), e1, b1)
+        if timing is not None and "conv2" in timing:
+            timing["conv2"][0].record()
+        v2 = self.conv2.fused_x3(v1s, flag=guard.flag)
+        if timing is not None and "conv2" in timing:
+            timing["conv2"][1].record()
+        out, _, _ = self.hg_conv3d.forward_x3(v2, residual=v2, flag=guard.flag)
+        guard.post()                      # nothing clamps behind this point
+        cost = self.classifier(ops.from_split(out.t, out.exp))      # Conv3d(C, 1, k1): the fp32 kernel (the split one-channel form is k3)
+        _ROUTES["x3_gn_tail"] += 1
+        if self.overflow_check == "call" and guard.wait():
+            raise SplitOverflow()
+        return cost
+
     def _conv2_tail(self, v1, shape, timing=None, arithmetic=None):
+        gn_cost = self._gn_tail_x3(v1, timing, arithmetic)
+        if gn_cost is not None:
+            self.__dict__["_snvc_last_v1"] = "v1"
+            return gn_cost
         st = self._x3_select(v1.device, arithmetic) if (v1.is_cuda and v1.dtype == torch.float32) else None
         if st is not None:      # split mode from an fp32 first-layer result: one layout pass (the sheared path writes the pair itself)
             n, c = v1.size(0), v1.size(1)
@@ -346,6 +396,18 @@ class GlobalStack(nn.Module):
             return self._tail(self.conv2(self.conv1(volume)))
         n, c2 = volume.size(0), volume.size(1)
         shape = (n, c2 // 2) + tuple(volume.shape[2:])
+        gguard = self._gn_qualifies(volume.device, arithmetic) if (volume.dtype == torch.float32 and c2 % 16 == 0) else None
+        if gguard is not None:      # GroupNorm stack (r5): the volume split once, conv1 and everything behind it in split mode
+            from .submodule import SplitT
+            mul = ops.split_scale_for(*(scale_from if scale_from is not None else (volume,)))
+            vs = ops.to_split(volume, mul_dev=mul, out=self._buffer("vol_s", (n, 2, c2 // 8) + tuple(volume.shape[2:]) + (8,), volume.device,
+                                                                      torch.float16))
+            if timing is not None and "conv1" in timing:
+                timing["conv1"][0].record()
+            v1s = self.conv1.fused_x3(SplitT(vs, 0, None, mul), flag=gguard.flag)
+            if timing is not None and "conv1" in timing:
+                timing["conv1"][1].record()
+            return self._gn_tail_x3(v1s, timing, arithmetic)
         st = self._x3_select(volume.device, arithmetic) if (volume.dtype == torch.float32 and c2 % 16 == 0) else None
         if st is not None:
             from .submodule import SplitT
@@ -533,7 +595,10 @@ class GlobalStack(nn.Module):
                   and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)
         if not usable:
             if timing is None:
-                return self.forward(_BuildCostVolume.apply(left, right, shift, downsample))      # the eager volume
+                vol = _BuildCostVolume.apply(left, right, shift, downsample)      # the eager volume
+                if torch.is_grad_enabled() or not vol.is_cuda:
+                    return self.forward(vol)
+                return self._forward_volume(vol, None, arithmetic, scale_from=(left, right) if downsample == 1 else None)
             assert torch.all(shift >= 0.)        # the wrapper's own check (a sync) stays outside the event pair
             mark("volume", 0)
             vol = ops.cost_volume_forward(left, right, shift, downsample)

@@ -1118,6 +1118,36 @@ def test_global_pair_end_to_end_vs_oracle(tile):
     check(full1, exp1, 2e-5, "conv1")
 
 
+def test_global_pair_groupnorm_split_tail_vs_oracle():
+    """GlobalStack(gn=True) (convbn_3d(..., gn=True), reference submodule.py:41-49): behind the fp32 first layer the stack runs in
+    split mode through fused_conv3d_x3's GroupNorm form (r5: conv -> fp32 raw -> statistics -> affine pass writing the pair);
+    against the oracle's GroupNorm stack on the C oracle's volume, and against the same model on the fp32-MFMA kernels."""
+    from oracle import native as O
+    from oracle import torch_ref as T
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    r = np.random.default_rng(43)
+    C, H, W, D = 32, 16, 40, 16
+    L = r.standard_normal((2, C, H, W)).astype(np.float32)
+    R = r.standard_normal((2, C, H, W)).astype(np.float32)
+    s = np.stack([np.linspace(0, (D - 1) / 2, D), np.linspace(0, D - 1, D)]).astype(np.float32)
+    ref = seeded(T.GlobalStack(C, gn=True), 44)
+    ours = seeded(GlobalStack(C, gn=True), 44).to(dev())
+    dl, dr, dsh = torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()), torch.from_numpy(s).to(dev())
+    with torch.no_grad():
+        exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, 1))).numpy()
+        b = S._ROUTES["x3_gn_tail"]
+        got = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()
+        assert S._ROUTES["x3_gn_tail"] == b + 1, "the GroupNorm stack did not take its split-mode tail"
+        from snvc_amd.extension.build_cost_volume import build_cost_volume
+        got_api = ours(build_cost_volume(dl, dr, dsh, 1)).cpu().numpy()
+        got32 = ours.forward_pair(dl, dr, dsh, 1, arithmetic="fp32").cpu().numpy()
+        assert S._ROUTES["x3_gn_tail"] == b + 2
+    check(got, exp, 1e-4, "GroupNorm pair (split tail)")
+    check(got_api, exp, 1e-4, "GroupNorm pair through model(build_cost_volume(...))")
+    check(got32, exp, 1e-4, "GroupNorm pair (fp32 MFMA)")
+
+
 @pytest.mark.parametrize("case", ["random", "whole_pixels", "beyond_the_image", "odd_width", "deep"])
 def test_warped_expand_backward_vs_oracle(case):
     """snvc_warped_expand_backward (r4: the adjoint of the any-shift first layer) against the C oracle's cost-volume backward
