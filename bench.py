@@ -318,7 +318,7 @@ def sustained_leg(step, seconds=5.0, min_steps=2000, block=100):
                           "source": "sysfs pp_dpm_sclk (current level) / hwmon freq1_input of this GPU's PCI device, one reading per 100-step block"} if clocks else None)}
 
 
-PREWARM_S = 0.5
+PREWARM_S = 1.5
 
 
 def prewarm(fn, seconds=PREWARM_S, fixed=None):
@@ -328,7 +328,8 @@ def prewarm(fn, seconds=PREWARM_S, fixed=None):
     20-step measurement sits inside that transient; what is reported is the sustained rate.  Untimed, disclosed in the line
     (`config.prewarm`).  r5: 0.15 -> 0.5 s -- the sustained leg's blocks of 100 steps show the first 0.22 s of load still 2 % slower
     than the steady state (2.168 against 2.114-2.13 ms/step), and the first leg of the process (`value`) read 3 % under the legs
-    behind it (2.189 against 2.116-2.16); the `sustained` entry (>= 5 s) is the number to hold `value` against."""
+    behind it (2.189 against 2.116-2.16); later r5: 0.5 -> 1.5 s -- box to box the ramp differs (one box: value 2.082 ms against a sustained
+    2.033 after 0.5 s; another: 1.976 against 1.972); the `sustained` entry (>= 5 s) is the number to hold `value` against."""
     torch.cuda.synchronize()
     if fixed is not None:       # a step with a collective in it: every rank must run the SAME number of steps
         for _ in range(fixed):
@@ -1097,7 +1098,7 @@ def main():
                                "(tests/test_gpu_fullsize_oracle.py, parity_vs_cpu_baseline below); `fp32_mfma` repeats the step on the fp32-MFMA kernels"),
                 "prewarm": (f"{PREWARM_S} s of the same step, untimed, in front of every leg's W warm-up steps: after an idle stretch the GPU "
                             "needs a few hundred ms of load to reach its sustained clocks (the `sustained` leg's first 100-step block "
-                            "reads ~2 % slower than its last; r4 used 0.15 s and its first leg read 3 % under the later ones); W = 5 "
+                            "reads 1-4 % slower than its last; r4 used 0.15 s and its first leg read 3 % under the later ones); W = 5 "
                             "steps are 11 ms.  `value` is meant to be the sustained rate: hold it against `sustained` (>= 5 s, >= 2000 steps)"),
                 "split_mode": {"taken": bool(x3_taken), "overflow_flag": x3_overflow, "tensor_exponents": x3_exponents,
                                "rule": "2^e * (|beta| + 64 |gamma|) <= 2^15 per tensor (folded eval BatchNorm); a value beyond it is clamped "
