@@ -1471,7 +1471,6 @@ int snvc_sheared_expand_split(const float *g, const float *gcol, const float *pl
     // once (five fit a CU) and long walks measure best (r5, cfg2's 96 rows x 4 groups: 1 chunk 166 us, 2: 156, 4: 169, 8: 171, 16: 180)
     int DCH = 1;
     while (DCH < 16 && H * G * N * DCH < 2 * 256 && D / (2 * DCH) >= 8) DCH *= 2;
-    if (const char *dbg = getenv("SNVC_DBG_DCH")) DCH = atoi(dbg);
     const int DC = (int)ceil_div<int64_t>(D, DCH);
     const size_t lds = sizeof(float) * (8 * (size_t)q * LW + 8 * (size_t)DC);
     if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: the row does not fit the LDS");

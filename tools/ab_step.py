@@ -27,7 +27,7 @@ model.eval().to(dev)
 left, right, shift = bench.make_inputs(0, dev)
 
 
-def setup(prep_streams=False, check="call", s2q=True, fused_tail=True, q16_min=256, split_prep=True, stream_out=False, dch=None):
+def setup(prep_streams=False, check="call", s2q=True, fused_tail=True, q16_min=256, split_prep=True, stream_out=False):
     model.prep_streams = prep_streams
     model.overflow_check = check
     model.fused_tail = fused_tail
@@ -35,10 +35,6 @@ def setup(prep_streams=False, check="call", s2q=True, fused_tail=True, q16_min=2
     ops.X3_Q16_MIN_JOBS[0] = q16_min
     model.split_prep = split_prep
     model.stream_out = stream_out
-    if dch is None:
-        os.environ.pop('SNVC_DBG_DCH', None)
-    else:
-        os.environ['SNVC_DBG_DCH'] = str(dch)
 
 
 LEGS = {
@@ -50,10 +46,6 @@ LEGS = {
     "hg conv4 on the 2x4x32 32x32x16 form (r4 rule: 1024 jobs)": {"q16_min": 1024},
     "sheared prep (G, G') on the fp32 matrix pipe (r4)": {"split_prep": False},
     "first layer written with non-temporal stores": {"stream_out": True},
-    "expand dch 4": {"dch": 4},
-    "expand dch 2": {"dch": 2},
-    "expand dch 1": {"dch": 1},
-    "expand dch 8": {"dch": 8},
 }
 if args.only:
     LEGS = {k: v for k, v in LEGS.items() if k == "default" or any(t in k for t in args.only.split(","))}
