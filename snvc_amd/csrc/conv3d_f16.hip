@@ -1979,11 +1979,18 @@ split_scale_kernel(const float *__restrict__ x, int64_t n, unsigned *__restrict_
     float m = 0.0f;
     const int64_t stride = (int64_t)gridDim.x * 256 * 4;
     const int64_t n4 = n & ~(int64_t)3;
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n4; i += stride) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + i);
-        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])),
-                                               __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))));
+    auto amax4 = [](const f32x4 v) {
+        return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+    };
+    // few workgroups, four independent 16-byte loads in flight per thread: the launch's time is the chain of same-address atomics
+    // at its end (r5: 234 workgroups 9.1 us for 3.8 MB; <= 48 workgroups: see profiles/r5)
+    int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4 *>(x + i), v1 = *reinterpret_cast<const f32x4 *>(x + i + stride);
+        const f32x4 v2 = *reinterpret_cast<const f32x4 *>(x + i + 2 * stride), v3 = *reinterpret_cast<const f32x4 *>(x + i + 3 * stride);
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fmaxf(amax4(v0), amax4(v1)), __builtin_fmaxf(amax4(v2), amax4(v3))));
     }
+    for (; i < n4; i += stride) m = __builtin_fmaxf(m, amax4(*reinterpret_cast<const f32x4 *>(x + i)));
     if (blockIdx.x == 0 && threadIdx.x < (int)(n - n4)) m = __builtin_fmaxf(m, __builtin_fabsf(x[n4 + threadIdx.x]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = __builtin_fmaxf(m, __shfl_xor(m, o, 64));
@@ -2382,8 +2389,8 @@ int snvc_f16x3_split_scale(const float *x, int64_t n, void *scratch8, float *out
     if (n < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_split_scale: negative size");
     if (!out_mul || !scratch8 || (n > 0 && !x)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_split_scale: null pointer");
     if (reinterpret_cast<uintptr_t>(x) & 15) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_split_scale: x must be 16-byte aligned");
-    int blocks = (int)ceil_div<int64_t>(n > 0 ? n : 1, 256 * 4 * 4);
-    blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
+    int blocks = (int)ceil_div<int64_t>(n > 0 ? n : 1, 256 * 4 * 16);
+    blocks = blocks < 1 ? 1 : (blocks > 48 ? 48 : blocks);
     split_scale_kernel<<<blocks, 256, 0, as_stream(stream)>>>(x, n, reinterpret_cast<unsigned *>(scratch8), out_mul);
     return check_launch("snvc_f16x3_split_scale");
 }
