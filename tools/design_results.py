@@ -25,7 +25,7 @@ def f(v, n=1):
 
 
 rows = [
-    ("**value** (driver form: 20 steps after 5 warm-up + 0.5 s pre-warm)", f"**{f(d['value'])} pairs/s**, {f(d['ms_per_step'], 3)} ms/step"),
+    ("**value** (driver form: 20 steps after 5 warm-up + the disclosed pre-warm)", f"**{f(d['value'])} pairs/s**, {f(d['ms_per_step'], 3)} ms/step"),
     ("`sustained` (≥ 5 s, ≥ 2000 steps, warm part)", f"{f(s.get('pairs_per_s'))} pairs/s; first / last 100 steps {f(s.get('first_100_ms_per_step'), 3)} / {f(s.get('last_100_ms_per_step'), 3)} ms; die clock {f(g(s, 'sclk_mhz', 'mean'), 0)} MHz"),
     ("`parity_vs_cpu_baseline` (all 5.75 M outputs of the timed run vs the oracle)", f"{g(d, 'parity_vs_cpu_baseline', 'rel_err'):.2e}"),
     ("`roofline` conv2 (`conv3d_x3q_kernel<side head>`)", f"{f(r['avg_launch_ms'], 3)} ms; necessary 3× flops {f(r['achieved'], 0)} TFLOP/s = **{f(r['frac'], 3)}** of 2.5 PF (executed {f(r.get('executed_frac'), 3)}); "
