@@ -222,3 +222,35 @@ def test_flag_looks_at_what_is_stored_after_the_relu(algo):
     flag.zero_()
     layer(xs, 3, scale, torch.full((32,), -1e6, device=dev()), flags=0, out_exp=2, overflow=flag)      # no activation: -1e6 IS stored
     assert int(flag.item()) == 1
+
+
+def test_groupnorm_trunk_extreme_input_stays_exact():
+    """A GroupNorm layer's result is gamma * xhat + beta with xhat normalised per sample and group: |xhat| <= sqrt(m) for a group of m
+    elements -- bounded by construction, unlike a frozen BatchNorm's.  The worst case for the 64-sigma exponent is one voxel carrying
+    the whole signal through the 1x1x1 layer (vimg_feat: xhat = sqrt(16 * 32 * 48) = 157 there): the split pass must either represent it
+    (the concat's shared exponent leaves room for 2 x (|beta| + 64 |gamma|) x 4 tensors) or flag and redo -- never return a clamped value.
+    (The clamp + flag of the pass itself: tests/test_gpu_tail.py::test_affine_act_split_vs_torch.)"""
+    import bench
+    from snvc_amd.models import submodule as S
+    grid = (16, 32, 48)
+    m = bench.local_model(grid, 32, dev(), gn=True)
+    ref = copy.deepcopy(m)
+    ref.precision = "f32"
+    vox = torch.zeros(1, 64, *grid, device=dev())
+    vox[0, :, 7, 13, 21] = torch.linspace(1.0, 3.0, 64, device=dev())
+    with torch.no_grad():
+        bev32, occ32, _ = ref.trunk_3d(vox)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            bev, occ, _ = m.trunk_3d(vox)
+        _close(bev, bev32, "GroupNorm trunk, one-voxel input: bev")
+        _close(occ, occ32, "GroupNorm trunk, one-voxel input: occupancy")
+        # ordinary data stays in split mode
+        m.reset_split_mode()
+        g = np.random.default_rng(9)
+        dense = torch.from_numpy(g.standard_normal((1, 64) + grid).astype(np.float32)).to(dev())
+        b = S._ROUTES["x3_local_trunk"]
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            m.trunk_3d(dense)
+        assert S._ROUTES["x3_local_trunk"] == b + 1 and not m.__dict__.get("_snvc_x3_off")
