@@ -228,7 +228,7 @@ class VernierTrunk(nn.Module):
     """
 
     def __init__(self, dim=32, grid=(32, 128, 192), gn=False, num_parts=9, part_reg_head=False,
-                 x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), heads=True):
+                 x_range=(-1.0, 1.0), z_range=(-1.0, 1.0), heads=True, vernier_type="BEV_type3"):
         """``heads=False``: only the 3D trunk's layers (vernier.py:249-289) are built -- for grids whose BEV neck the reference
         cannot instantiate (nh not in {16, 32}: BASELINE configs[2] 96^3 crops, configs[4] 80x160x160; vernier.py:290-295 raises);
         ``trunk_3d`` is the same code either way, and the default construction is what tests/golden pins."""
@@ -252,7 +252,10 @@ class VernierTrunk(nn.Module):
         if not heads:
             self._init_weights()
             return
-        if nh == 32:
+        self.vernier_type = vernier_type
+        if vernier_type == "BEV_type2":      # vernier.py:191-248: the same 3D trunk, conv5 over dim * 8 channels, no coordinate head
+            dim_height = dim * 8
+        elif nh == 32:
             dim_height = 256
         elif nh == 16:
             dim_height = 128
@@ -261,6 +264,9 @@ class VernierTrunk(nn.Module):
         self.conv5 = nn.Sequential(convbn(dim_height, 64, 3, 1, 1, 1, gn=gn), nn.ReLU(inplace=True))
         self.hm1 = hourglass2d(64, gn=gn) if self.small else hourglass2d_downsample_16(64, gn=gn)
         self.hm2 = nn.Conv2d(64, num_parts, 3, 1, 1, bias=False)
+        if vernier_type == "BEV_type2":
+            self._init_weights()
+            return
         # coord head, vernier.py:68-93
         mods = [BasicBlock2d(num_parts + 2, num_parts * 2, stride=2,
                              downsample=basicdownsample(num_parts + 2, num_parts * 2))]
@@ -305,6 +311,8 @@ class VernierTrunk(nn.Module):
         bev = self.conv5(bev)
         feats = (self.hm1(bev, None, None)[0] if self.small else self.hm1(bev)).permute(0, 1, 3, 2)
         heat = self.hm2(feats)
+        if self.vernier_type == "BEV_type2":      # vernier.py:409-410: heat maps only
+            return heat, None
         n = len(heat)
         aug = torch.cat([heat, self.coor_maps.repeat(n, 1, 1, 1).to(heat.device)], dim=1)
         return heat, self.coord_head(aug).view(n, -1, 2)

@@ -1,4 +1,4 @@
-"""Drop-in for the 3D trunk of ``snvc.models.vernier.VernierScale`` (``BEV_type3``).
+"""Drop-in for the 3D trunk of ``snvc.models.vernier.VernierScale`` (``BEV_type3``; r5: ``BEV_type2``, the same trunk without the coordinate head).
 
 Module tree, attribute names and state-dict keys equal the reference's (vernier.py:249-313), so a
 reference checkpoint loads with ``strict=True``.  What changes is how ``forward`` executes:
@@ -58,11 +58,13 @@ class VernierScale(nn.Module):
         super().__init__()
         self.cfg = cfg
         self.is_train = is_train
-        if cfg.vernier_type != "BEV_type3":
-            raise NotImplementedError("only vernier_type='BEV_type3' (the released V-A model) is on the path")
+        if cfg.vernier_type not in ("BEV_type3", "BEV_type2"):
+            # '3D' calls an attribute its constructor never makes (vernier.py:134 hg_conv, :369 hg_conv3d) and 'BEV' is a 2D model
+            raise NotImplementedError("vernier_type 'BEV_type3' (the released V-A model) and 'BEV_type2' are on the path")
         self._init_3d_net()
         self._init_grid()
-        self._init_coord_head()
+        if cfg.vernier_type == "BEV_type3":       # reference vernier.py:33-36
+            self._init_coord_head()
         if getattr(self.cfg, "use_bbox_head", False):
             raise NotImplementedError("use_bbox_head (FCmodel) is off by default and outside the path")
         for m in self.modules():  # reference vernier.py:38-54
@@ -117,7 +119,9 @@ class VernierScale(nn.Module):
             self.part_reg_head = nn.Sequential(convbn_3d(dim, dim, 3, 1, 1, gn=gn), relu(),
                                                HipConv3d(dim, 27, 1, 1, 0, bias=False))
         self.pool_3d = nn.AvgPool3d((4, 1, 1), stride=(4, 1, 1))
-        if self.cfg.grid_resolution[0] == 32:
+        if self.cfg.vernier_type == "BEV_type2":      # reference vernier.py:231: convbn(dim*8, 64, ...)
+            dim_height = dim * 8
+        elif self.cfg.grid_resolution[0] == 32:
             dim_height = 256
         elif self.cfg.grid_resolution[0] == 16:
             dim_height = 128
@@ -366,13 +370,18 @@ class VernierScale(nn.Module):
         (conv5, hm1, hm2, the coordinate head's blocks and its last full-extent layer) on the depth-1 HIP kernels
         with fused norm / bias / residual / ReLU / Sigmoid epilogues; otherwise the modules' torch forward."""
         from .submodule import _hip_2d_ok, _cbr2d, fused_conv2d
-        hip = _hip_2d_ok(voxel_BEV, self.conv5, self.hm1, self.hm2, self.coord_head)
+        type2 = self.cfg.vernier_type == "BEV_type2"
+        if type2 and self.small:      # reference vernier.py:394: `self.hg_conv3d(voxel) + voxel` -- the plain hourglass returns a tuple there
+            raise NotImplementedError("vernier_type='BEV_type2' with n_sample_w <= 16 fails in the reference too (vernier.py:394, :409)")
+        hip = _hip_2d_ok(voxel_BEV, self.conv5, self.hm1, self.hm2, *(() if type2 else (self.coord_head,)))
         voxel_BEV = _cbr2d(self.conv5, voxel_BEV) if hip else self.conv5(voxel_BEV)
         feats = self.hm1(voxel_BEV, None, None)[0] if self.small else self.hm1(voxel_BEV)
         if hip:      # hm2(feats.permute(0, 1, 3, 2)) without copying the 64-channel tensor: swapped kernel, transposed view out
             heatmaps = fused_conv2d(self.hm2, None, feats, transposed_input=True)
         else:
             heatmaps = self.hm2(feats.permute(0, 1, 3, 2))
+        if type2:                     # reference vernier.py:396-410: heat maps and occupancy only
+            return heatmaps, None
         num_sample = len(heatmaps)
         # the coordinate maps are a plain attribute in the reference (not in the state dict): one device copy is kept,
         # so that no host -> device copy sits in the middle of the neck (and of a captured graph)

@@ -44,6 +44,13 @@ TRUNK_CASES = {
     "G2_gn": ((16, 32, 48), True, 1, 16, 16, 430),
 }
 
+# vernier_type='BEV_type2' (reference vernier.py:191-248, :391-410): the same 3D trunk without the coordinate head; nw > 16 only (the
+# reference's own forward fails on the plain hourglass there)
+TYPE2_CASES = {
+    "T2": ((32, 32, 48), False, 1, 16, 16, 440),
+    "T2_gn": ((32, 32, 48), True, 1, 16, 16, 450),
+}
+
 # name: (C, spatial (D,H,W), seed)
 GLOBAL_CASES = {
     "c32_small": (32, (8, 12, 40), 500),

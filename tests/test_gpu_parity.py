@@ -954,6 +954,37 @@ def test_vernier_scale_vs_golden(name, G):
     assert safe.mean() > 0.5
 
 
+@pytest.mark.parametrize("name", list(GC.TYPE2_CASES))
+def test_vernier_scale_type2_vs_golden(name):
+    """vernier_type='BEV_type2' (reference vernier.py:191-248, :391-410: the BEV_type3 trunk without the coordinate head) against the
+    imported reference's own outputs (tests/golden/make_golden_type2.py): same state-dict keys, ncf / occupancy, coordinates None."""
+    import os
+    from oracle import torch_ref as T
+    from snvc_amd.models.vernier import VernierScale
+    G2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vernier_type2.npz"))
+    grid, gn, n, fh, fw, seed = GC.TYPE2_CASES[name]
+    cfg = _cfg(grid, gn)
+    cfg.vernier_type = "BEV_type2"
+    m = VernierScale(cfg)
+    ref_keys = [(k, tuple(v.shape)) for k, v in T.VernierTrunk(32, grid, gn, vernier_type="BEV_type2").state_dict().items()]
+    assert [(k, tuple(v.shape)) for k, v in m.state_dict().items()] == ref_keys
+    assert not hasattr(m, "coord_head")
+    seeded(m, seed).to(dev())
+    lf, rf, gpl, gpr = (t.to(dev()) for t in GC.trunk_inputs(n, 32, fh, fw, grid, seed + 1))
+    tol = 3e-4 if gn else 1e-4
+    for precision in ("auto", "f32"):
+        m.precision = precision
+        with torch.no_grad():
+            out = m(lf, rf, gpl.clone(), gpr.clone())
+        assert set(out) == {"ncf", "occupancy", "coordinates"} and out["coordinates"] is None
+        check(out["occupancy"].cpu().numpy(), G2[f"{name}/occupancy"], tol, f"type2 occupancy [{precision}]")
+        check(out["ncf"].cpu().numpy(), G2[f"{name}/ncf"], 5 * tol, f"type2 ncf [{precision}]")
+    cfg_bad = _cfg((16, 16, 24), False)
+    cfg_bad.vernier_type = "3D"
+    with pytest.raises(NotImplementedError):
+        VernierScale(cfg_bad)
+
+
 def test_vernier_forward_self_check():
     """forward(test=True): the numeric half of the reference's aggregation self-check (vernier.py:479-519).  A pinhole
     calibration stand-in projects the grid: the host re-projection of the checked voxel agrees with the projected grid that

@@ -81,6 +81,23 @@ def test_trunk(name):
     assert np.array_equal(idx, G[f"trunk/{name}/argmax"])
 
 
+@pytest.mark.parametrize("name", list(GC.TYPE2_CASES))
+def test_trunk_type2(name):
+    """vernier_type='BEV_type2' (vernier.py:191-248, :391-410): the restatement against the imported reference's outputs
+    (tests/golden/make_golden_type2.py required bit equality when it made them)."""
+    import os
+    g2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vernier_type2.npz"))
+    grid, gn, n, fh, fw, seed = GC.TYPE2_CASES[name]
+    m = load(T.VernierTrunk(dim=32, grid=grid, gn=gn, vernier_type="BEV_type2"), seed)
+    assert not hasattr(m, "coord_head")
+    lf, rf, gpl, gpr = GC.trunk_inputs(n, 32, fh, fw, grid, seed + 1)
+    with torch.no_grad():
+        heat, occ, _, coords, _ = m.predict_3d_heatmaps(T.sample_2d_feat(lf, rf, gpl, gpr, GC.RESOLUTION, grid))
+    assert coords is None
+    np.testing.assert_allclose(heat.numpy(), g2[f"{name}/ncf"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(occ.numpy(), g2[f"{name}/occupancy"], **TOL)
+
+
 def test_reference_gather_mutates_in_place_flag():
     assert bool(G["gather/inplace_normalised"][0])
 
