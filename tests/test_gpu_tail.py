@@ -120,8 +120,17 @@ def test_split_scale_in_one_launch_equals_the_torch_expression(n):
     g = torch.Generator(device="cpu").manual_seed(n)
     for amp in (1.0, 3.7e-5, 9.1e6):
         x = (torch.randn(n, generator=g) * amp).to(dev())
-        a, b = ops.split_scale_of(x), ops.split_scale_for(x)
+        a = ops.split_scale_of(x)
+        # r4's torch expression (split_scale_for's fallback path), spelled out: the one-launch kernel must agree bit for bit
+        lo, hi = torch.aminmax(x)
+        e = torch.floor(torch.log2(16384.0 / torch.maximum(-lo, hi).float().reshape(1)))
+        b = torch.exp2(torch.where(torch.isfinite(e), e, torch.zeros_like(e)).clamp_(-24, 40))
         assert torch.equal(a, b), (n, amp, a.item(), b.item())
+        assert torch.equal(ops.split_scale_for(x), a)                  # contiguous fp32: the same launch
+        y = (x * 0.25)[: max(n // 2, 1)]
+        assert torch.equal(ops.split_scale_for(x, y), a)               # several tensors: the minimum of their scales
+        xs = x[::2] if n > 1 else x                                     # not contiguous: the torch expression
+        assert ops.split_scale_for(xs).item() * xs.abs().max().item() < 16384.0
         m = float(a.item()) * x.abs().max().item()
         assert 8192.0 <= m < 16384.0
     z = torch.zeros(n, device=dev())
