@@ -963,7 +963,7 @@ def main():
         def mean(k):
             try:
                 return float(np.mean([e[k][0].elapsed_time(e[k][1]) for e in ev]))
-            except (RuntimeError, ValueError):      # a bracket this path does not record
+            except (RuntimeError, ValueError, KeyError):      # a bracket this path / this leg does not record
                 return float("nan")
         outs[tag] = out.cpu().numpy() if rank == 0 and world == 1 else None    # 23 MB, compared with the CPU oracle below
         return elapsed, mean("conv1"), mean("volume"), mean("conv2")
