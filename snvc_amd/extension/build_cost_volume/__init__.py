@@ -48,9 +48,22 @@ def build_cost_volume(left, right, shift, downsample):
                not (left.requires_grad or right.requires_grad))
     if not lazy_ok:
         return _BuildCostVolume.apply(left, right, shift, downsample)
-    from ...lazy import LazyCostVolume
+    from ...lazy import CONSUMER, LazyCostVolume
     from ... import ops
     spacing = "unknown"
+    model = CONSUMER[0]() if CONSUMER[0] is not None else None
+    if model is not None:
+        # r5: the model that consumed the previous lazy volume runs this call's step up to its one host sync -- the same check of
+        # `shift` as below (an AssertionError comes out of here, reference __init__.py:12) -- with its first-layer prep queued in
+        # front of the wait; model(volume) resumes it.  Without this the GPU idles through the wait and the host's way from here to
+        # the model's first launch (reference_api 0.076 ms/step behind forward_pair at cfg2).
+        gen = model.lazy_prefetch(left, right, shift)
+        if gen is not None:
+            w = model.conv1[0][0].weight
+            seen = model.conv1[0][0].__dict__["_snvc_factored"].get("spacing_seen")      # (q, m0, D, W) of THIS shift array, or None
+            return LazyCostVolume(left, right, shift, downsample, build_cost_volume_cuda.build_cost_volume_forward,
+                                  tuple(seen[:2]) if seen is not None else None,
+                                  prefetch=(CONSUMER[0], gen, (w.data_ptr(), w._version)))
     if shift.dtype == torch.float32 and shift.numel() > 0:
         # reference __init__.py:12, at the same point of the call sequence and with the same single sync; the launch also
         # classifies the array's spacing, which GlobalStack.forward_pair would otherwise sync for a second time

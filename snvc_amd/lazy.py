@@ -13,9 +13,14 @@ import torch
 from torch.utils._pytree import tree_map
 
 
+# weakref to the GlobalStack that consumed the last lazy volume on the fused path (set by GlobalStack.forward): the next
+# build_cost_volume(...) starts that model's first-layer prep in front of its own host sync (GlobalStack.lazy_prefetch)
+CONSUMER = [None]
+
+
 class LazyCostVolume(torch.Tensor):
     @staticmethod
-    def __new__(cls, left, right, shift, downsample, build, spacing="unknown"):
+    def __new__(cls, left, right, shift, downsample, build, spacing="unknown", prefetch=None):
         n, c, h, w = left.shape
         shape = (n, 2 * c, shift.shape[1], h // downsample, w // downsample)
         r = torch.Tensor._make_wrapper_subclass(cls, shape, dtype=left.dtype, device=left.device, requires_grad=False)
@@ -26,7 +31,21 @@ class LazyCostVolume(torch.Tensor):
         r._spacing = spacing
         r._source_versions = (left._version, right._version, shift._version)
         r._own_version = r._version      # in-place aten operators on the wrapper bump ITS counter (above __torch_dispatch__)
+        r._prefetch = prefetch           # (weakref to the model, its paused step, the weight version it was started with) or None
         return r
+
+    def take_prefetch(self, model):
+        """The paused step ``build_cost_volume`` started for ``model`` (GlobalStack.lazy_prefetch), once: None if there is none, it
+        belongs to another model, or the model's first-layer weights changed since."""
+        pre, self._prefetch = self._prefetch, None
+        if pre is None:
+            return None
+        ref, gen, wver = pre
+        w = model.conv1[0][0].weight
+        if ref() is not model or wver != (w.data_ptr(), w._version):
+            gen.close()
+            return None
+        return gen
 
     @property
     def spacing(self):
@@ -62,6 +81,9 @@ class LazyCostVolume(torch.Tensor):
         return self._real is None or self._real._version == self._real_version
 
     def materialize(self) -> torch.Tensor:
+        if self._prefetch is not None:       # somebody looks at the volume itself: the step started for its consumer is dropped
+            self._prefetch[1].close()
+            self._prefetch = None
         if self._real is None:
             if not self.sources_unchanged:
                 raise RuntimeError("LazyCostVolume: left / right / shift were modified in place after build_cost_volume(...) and "

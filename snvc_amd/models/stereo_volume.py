@@ -15,6 +15,7 @@ blocks (``convbn_3d``, ``hourglass``) and the composition pattern of VernierScal
 """
 import math
 import warnings
+import weakref
 
 import torch
 import torch.nn as nn
@@ -357,6 +358,22 @@ class GlobalStack(nn.Module):
             if volume.is_pristine and not torch.is_grad_enabled() and not self.training:
                 left, right, shift, ds = volume.sources
                 if left.shape[1] * 2 == self.conv1[0][0].in_channels and left.shape[3] % 4 == 0:
+                    from .. import lazy as _lazy
+                    _lazy.CONSUMER[0] = weakref.ref(self)      # the next build_cost_volume starts this model's first-layer prep
+                    pre = volume.take_prefetch(self)
+                    if pre is not None:                         # build_cost_volume already ran the step up to its host sync
+                        try:
+                            try:
+                                while True:
+                                    next(pre)
+                            except StopIteration as done:
+                                _ROUTES["lazy_prefetch_resumed"] += 1
+                                return done.value
+                        except SplitOverflow:
+                            self._leave_split_mode(self.arithmetic, "this call was redone in fp32")
+                            _ROUTES["x3_overflow_redo"] += 1
+                            return self._forward_pair_unchecked(left, right, shift, ds, shift_checked=True, spacing=volume.spacing,
+                                                                arithmetic="fp32")
                     return self.forward_pair(left, right, shift, ds, shift_checked=True, spacing=volume.spacing)
             # built from these two features: its maximum is theirs (interpolation weights are in [0, 1]), if they are untouched
             # ... and the volume itself: one that was written to in place (vol.mul_(8)) no longer has their maximum
@@ -373,6 +390,22 @@ class GlobalStack(nn.Module):
                               + why + ".  forward_pair(left, right, shift) is the fused entry point.")
             return self._forward_volume(volume.materialize(), scale_from=scale_from)
         return self._forward_volume(volume)
+
+    def lazy_prefetch(self, left, right, shift):
+        """Called by ``build_cost_volume`` (no_grad, fp32, downsample 1) for the model that consumed the previous lazy volume: runs
+        this call's step up to and including its one host sync -- the sign / spacing check of ``shift`` (reference __init__.py:12:
+        an AssertionError for a negative shift comes out of build_cost_volume exactly as before) -- with the left half's planes
+        and the speculative first-layer prep queued in front of the wait, and returns the paused generator (None if this model
+        would not take the fused path for these inputs)."""
+        conv, bn = self.conv1[0][0], self.conv1[0][1]
+        if (self.training or torch.is_grad_enabled() or not isinstance(bn, nn.BatchNorm3d) or bn.training or left.device != conv.weight.device
+                or left.shape[1] * 2 != conv.in_channels or left.shape[3] % 4 != 0 or shift.size(1) < 4 or shift.dtype != torch.float32
+                or left.size(0) == 0):
+            return None
+        gen = self._forward_pair_steps(left, right, shift, 1, pause=True)
+        if next(gen, None) is None:        # the path taken has no pause point (it ran to its end): nothing to resume
+            return None
+        return gen
 
     def _checked(self, fn, arithmetic, *args, **kw):
         """Run a split-mode capable entry point; a call whose overflow flag came back set is redone on the fp32-MFMA kernels
@@ -537,9 +570,24 @@ class GlobalStack(nn.Module):
                              sheared, fused_bn, spacing, commuted)
     forward_pair.__doc__ = "see _forward_pair_unchecked"
 
-    def _forward_pair_unchecked(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True,
-                                fused_bn=True, spacing="unknown", commuted=True, arithmetic=None):
-        """cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
+    def _forward_pair_unchecked(self, *args, **kw):
+        """``_forward_pair_steps`` run to its end."""
+        gen = self._forward_pair_steps(*args, **kw)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as done:
+            return done.value
+
+    def _forward_pair_steps(self, left, right, shift, downsample=1, factored=True, timing=None, shift_checked=False, sheared=True,
+                            fused_bn=True, spacing="unknown", commuted=True, arithmetic=None, pause=False):
+        """A GENERATOR: with ``pause`` it yields once, right after the step's host sync (the shift array's sign / spacing check) with
+        the left half's planes and the speculative first-layer prep already queued -- ``build_cost_volume`` runs it up to there for
+        the model that consumed the last lazy volume (the reference's `assert` fires at build time as before, and the GPU is
+        not left idle while the host waits), ``GlobalStack.forward`` resumes it.  Without ``pause`` it runs straight through
+        (``_forward_pair_unchecked``).  The generator's return value is the cost tensor.
+
+        cost-volume build + 3D CNN forward: the unit BASELINE.json's metric counts.
 
         ``factored=True`` (inference, eval BatchNorm, downsample 1) uses the structure of the CONCAT
         volume: its left half repeats the left feature on every disparity plane
@@ -692,6 +740,8 @@ class GlobalStack(nn.Module):
             nonneg, structure = self._shift_structure_end(ticket, shift.size(1))
             assert nonneg                        # same contract as build_cost_volume (reference __init__.py:12)
             plans["spacing_seen"] = structure + (shift.size(1), left.size(3)) if structure is not None else None
+        if pause:
+            yield "shift checked; planes and speculative prep queued"
         if structure is not None and not self._sheared_fits(structure[0], structure[1], shift.size(1), left.size(3), False):
             structure = None                     # rows the sheared kernels do not cover: the paths below
         if structure is not None:

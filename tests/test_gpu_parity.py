@@ -1149,6 +1149,59 @@ def test_global_pair_end_to_end_vs_oracle(tile):
     check(full1, exp1, 2e-5, "conv1")
 
 
+def test_lazy_cost_volume_prefetches_the_consumers_first_layer():
+    """r5: build_cost_volume runs the step of the model that consumed the previous lazy volume up to its host sync (the check of
+    `shift`, with that model's first-layer prep queued in front of the wait); model(volume) resumes it.  Same values as forward_pair
+    bit for bit; the reference's assert still fires AT build time; a volume that is looked at, given to another model, or whose
+    consumer's weights changed in between is handled as before."""
+    from snvc_amd import ops
+    from snvc_amd.extension.build_cost_volume import build_cost_volume
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    C, H, W, D = 32, 8, 40, 8
+    r = np.random.default_rng(12)
+    L = torch.from_numpy(r.standard_normal((1, C, H, W)).astype(np.float32)).to(dev())
+    R = torch.from_numpy(r.standard_normal((1, C, H, W)).astype(np.float32)).to(dev())
+    S_ = torch.from_numpy(np.linspace(0.0, 3.5, D, dtype=np.float32)[None]).to(dev())
+    S2 = (S_ * 0.77 + 0.05).contiguous()                 # not uniformly spaced by 1 or 1/2: the general path
+    m, other = seeded(GlobalStack(C), 3).to(dev()), seeded(GlobalStack(C), 4).to(dev())
+    with torch.no_grad():
+        ref1, ref2 = m.forward_pair(L, R, S_, 1).clone(), m.forward_pair(L, R, S2, 1).clone()
+        ref_other = other.forward_pair(L, R, S_, 1).clone()
+        m(build_cost_volume(L, R, S_, 1))                # m is now the registered consumer
+        n0 = S._ROUTES["lazy_prefetch_resumed"]
+        vol = build_cost_volume(L, R, S_, 1)
+        assert vol._prefetch is not None and vol.spacing == (2, 0) and not vol.is_materialized
+        assert torch.equal(m(vol), ref1) and S._ROUTES["lazy_prefetch_resumed"] == n0 + 1 and not vol.is_materialized
+        assert torch.equal(m(build_cost_volume(L, R, S2, 1)), ref2)              # the speculation was for another spacing: dropped inside
+        assert S._ROUTES["lazy_prefetch_resumed"] == n0 + 2
+        assert torch.equal(m(build_cost_volume(L, R, S_, 1)), ref1)              # ... and back
+        with pytest.raises(AssertionError):                                        # reference __init__.py:12, at build time
+            build_cost_volume(L, R, S_ - 1.0, 1)
+        # looked at before the model sees it: the paused step is dropped, the values are the eager builder's
+        vol = build_cost_volume(L, R, S_, 1)
+        assert torch.equal(vol.materialize(), ops.cost_volume_forward(L, R, S_, 1)) and vol._prefetch is None
+        assert torch.equal(m(vol), ref1)
+        # another model consumes the volume m's step was started for
+        vol = build_cost_volume(L, R, S_, 1)
+        n1 = S._ROUTES["lazy_prefetch_resumed"]
+        assert torch.equal(other(vol), ref_other) and S._ROUTES["lazy_prefetch_resumed"] == n1
+        assert torch.equal(other(build_cost_volume(L, R, S_, 1)), ref_other)     # `other` is the consumer now
+        assert S._ROUTES["lazy_prefetch_resumed"] == n1 + 1
+        # the consumer's weights change between build and forward: not resumed, new weights used
+        vol = build_cost_volume(L, R, S_, 1)
+        other.conv1[0][0].weight.mul_(1.5)
+        n2 = S._ROUTES["lazy_prefetch_resumed"]
+        got = other(vol)
+        assert S._ROUTES["lazy_prefetch_resumed"] == n2 and torch.equal(got, other.forward_pair(L, R, S_, 1))
+        # a source written to after build: the error of the lazy volume, as before
+        vol = build_cost_volume(L, R, S_, 1)
+        L.add_(1.0)
+        with pytest.raises(RuntimeError, match="modified in place"):
+            other(vol)
+        L.sub_(1.0)
+
+
 def test_global_pair_groupnorm_split_tail_vs_oracle():
     """GlobalStack(gn=True) (convbn_3d(..., gn=True), reference submodule.py:41-49): behind the fp32 first layer the stack runs in
     split mode through fused_conv3d_x3's GroupNorm form (r5: conv -> fp32 raw -> statistics -> affine pass writing the pair);
