@@ -60,9 +60,9 @@ def build_cost_volume(left, right, shift, downsample):
         gen = model.lazy_prefetch(left, right, shift)
         if gen is not None:
             w = model.conv1[0][0].weight
-            seen = model.conv1[0][0].__dict__["_snvc_factored"].get("spacing_seen")      # (q, m0, D, W) of THIS shift array, or None
+            seen = model.conv1[0][0].__dict__["_snvc_factored"].get("spacing_seen")      # (q, m0, D, W) of THIS shift array, or ("general", D, W)
             return LazyCostVolume(left, right, shift, downsample, build_cost_volume_cuda.build_cost_volume_forward,
-                                  tuple(seen[:2]) if seen is not None else None,
+                                  tuple(seen[:2]) if (seen is not None and seen[0] != "general") else None,
                                   prefetch=(CONSUMER[0], gen, (w.data_ptr(), w._version)))
     if shift.dtype == torch.float32 and shift.numel() > 0:
         # reference __init__.py:12, at the same point of the call sequence and with the same single sync; the launch also

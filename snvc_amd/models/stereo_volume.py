@@ -667,7 +667,9 @@ class GlobalStack(nn.Module):
         known = shift_checked and spacing != "unknown"       # build_cost_volume already looked (LazyCostVolume.spacing)
         if known and not sheared:
             spacing = None
-        if not known and sheared and left.size(0) > 0 and shift.size(1) >= 4 and shift.dtype == torch.float32:
+        if not known and left.size(0) > 0 and shift.size(1) >= 4 and shift.dtype == torch.float32:
+            # (r5: also with sheared=False -- the sign check rides on the same launch instead of a blocking torch.all in front of
+            # an empty queue: 93 us of idle GPU per step on the any-shift path)
             ticket = ops.shift_structure_begin(shift.detach())
         elif not shift_checked:                  # a LazyCostVolume was checked when build_cost_volume made it
             assert torch.all(shift >= 0.)
@@ -731,22 +733,45 @@ class GlobalStack(nn.Module):
                 cur.wait_event(done)
             return out[0][0], out[1][0], off, off_col
 
-        structure, guess, ready = (spacing if known else None), None, None
+        def commuted_inputs():
+            # any other shift array: three 2D convolutions of the right feature (P, Q) and of its first columns (E)
+            if split_prep and (9 * conv.out_channels) % 32 == 0:
+                # the three depth-1 3x3 layers in split mode: P and Q share the right feature's split pair (one host call), E runs on its
+                # first four columns (another)
+                lx_p, lx_q, lx_e = self._commuted_layers_x3(plans, w.detach()[:, c:])
+                p_, q_ = ops.conv2d_x3_from_f32(right, [lx_p, lx_q], prep_ws.setdefault("commuted", {}))
+                e_ = ops.conv2d_x3_from_f32(right[:, :, :, :4], [lx_e], prep_ws.setdefault("commuted_e", {}))[0]
+                _ROUTES["commuted_prep_x3"] += 1
+            else:
+                lay_p, lay_q, lay_e = self._commuted_layers(plans, w.detach()[:, c:])
+                r5 = right.unsqueeze(2)
+                p_, q_ = lay_p(r5).squeeze(2), lay_q(r5).squeeze(2)
+                e_ = lay_e(right[:, :, :, :4].contiguous().unsqueeze(2)).squeeze(2)
+            return p_, q_, e_
+
+        can_commute = commuted and shift.dtype == torch.float32 and left.size(3) <= 2048
+        structure, guess, ready, ready_general = (spacing if known else None), None, None, None
         if ticket is not None:
-            guess = plans.get("spacing_seen")    # (q, m0, D, W) of the previous call: a guess, checked below
+            guess = plans.get("spacing_seen")    # (q, m0, D, W) of the previous call, or ("general", D, W): a guess, checked below
             mark("volume", 0)
-            if guess is not None and guess[2:] == (shift.size(1), left.size(3)):
+            dims = (shift.size(1), left.size(3))
+            if sheared and guess is not None and guess[0] != "general" and guess[2:] == dims:
                 ready = sheared_inputs(guess[0], guess[1])
+            elif can_commute and (not sheared or (guess is not None and guess[0] == "general" and guess[1:] == dims)):
+                ready_general = commuted_inputs()
             nonneg, structure = self._shift_structure_end(ticket, shift.size(1))
             assert nonneg                        # same contract as build_cost_volume (reference __init__.py:12)
-            plans["spacing_seen"] = structure + (shift.size(1), left.size(3)) if structure is not None else None
+            if sheared:
+                plans["spacing_seen"] = structure + dims if structure is not None else ("general",) + dims
+            else:
+                structure = None                 # the caller asked for the general path
         if pause:
             yield "shift checked; planes and speculative prep queued"
         if structure is not None and not self._sheared_fits(structure[0], structure[1], shift.size(1), left.size(3), False):
             structure = None                     # rows the sheared kernels do not cover: the paths below
         if structure is not None:
             q, m0 = structure
-            if ready is None or guess[:2] != structure:
+            if ready is None or tuple(guess[:2]) != tuple(structure):
                 mark("volume", 0)
                 ready = sheared_inputs(q, m0)    # first call, or the spacing changed: the guess is dropped
             g, gcol, off, off_col = ready
@@ -775,22 +800,13 @@ class GlobalStack(nn.Module):
                 mark("conv1", 1)
                 _ROUTES["sheared_first_conv"] += 1
                 return self._conv2_tail(v, shape, timing, arithmetic)
-        if commuted and shift.dtype == torch.float32 and left.size(3) <= 2048:
+        if can_commute:
             # any other shift array: interpolation along w commutes with the convolution -- three 2D convolutions of the right
             # feature, three interpolations per output voxel, the warped volume is not built either (csrc/sheared_conv.hip)
-            mark("volume", 0)
-            if split_prep and (9 * conv.out_channels) % 32 == 0:
-                # the three depth-1 3x3 layers in split mode: P and Q share the right feature's split pair (one host call), E runs on its
-                # first four columns (another)
-                lx_p, lx_q, lx_e = self._commuted_layers_x3(plans, w.detach()[:, c:])
-                p_, q_ = ops.conv2d_x3_from_f32(right, [lx_p, lx_q], prep_ws.setdefault("commuted", {}))
-                e_ = ops.conv2d_x3_from_f32(right[:, :, :, :4], [lx_e], prep_ws.setdefault("commuted_e", {}))[0]
-                _ROUTES["commuted_prep_x3"] += 1
-            else:
-                lay_p, lay_q, lay_e = self._commuted_layers(plans, w.detach()[:, c:])
-                r5 = right.unsqueeze(2)
-                p_, q_ = lay_p(r5).squeeze(2), lay_q(r5).squeeze(2)
-                e_ = lay_e(right[:, :, :, :4].contiguous().unsqueeze(2)).squeeze(2)
+            if ready_general is None:
+                mark("volume", 0)
+                ready_general = commuted_inputs()
+            p_, q_, e_ = ready_general
             mark("volume", 1)
             mark("conv1", 0)
             st = self._x3_select(left.device, arithmetic)
