@@ -13,9 +13,25 @@ import torch
 from torch.utils._pytree import tree_map
 
 
-# weakref to the GlobalStack that consumed the last lazy volume on the fused path (set by GlobalStack.forward): the next
-# build_cost_volume(...) starts that model's first-layer prep in front of its own host sync (GlobalStack.lazy_prefetch)
-CONSUMER = [None]
+import threading
+
+
+class _Consumer(threading.local):
+    """Weakref to the GlobalStack that consumed the last lazy volume on the fused path IN THIS THREAD (set by GlobalStack.forward): the
+    next build_cost_volume(...) of the thread starts that model's first-layer prep in front of its own host sync
+    (GlobalStack.lazy_prefetch).  Thread-local (r6): the reference's op is stateless and is called from DataParallel worker threads, one
+    per device (tools/inference_agnostic.py:472) -- a worker must never start another worker's model."""
+    ref = None
+
+    # the r5 spelling CONSUMER[0] keeps working
+    def __getitem__(self, i):
+        return self.ref
+
+    def __setitem__(self, i, value):
+        self.ref = value
+
+
+CONSUMER = _Consumer()
 
 
 class LazyCostVolume(torch.Tensor):
@@ -36,13 +52,16 @@ class LazyCostVolume(torch.Tensor):
 
     def take_prefetch(self, model):
         """The paused step ``build_cost_volume`` started for ``model`` (GlobalStack.lazy_prefetch), once: None if there is none, it
-        belongs to another model, or the model's first-layer weights changed since."""
+        belongs to another model or stream, or the model's first-layer weights changed since.  (Whether the prep buffers the paused
+        step queued are still ITS OWN is the step's business: it re-checks the model's prep epoch when resumed and starts over if another
+        call used them in between -- GlobalStack._forward_pair_steps.)"""
         pre, self._prefetch = self._prefetch, None
         if pre is None:
             return None
         ref, gen, wver = pre
         w = model.conv1[0][0].weight
-        if ref() is not model or wver != (w.data_ptr(), w._version):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if ref() is not model or wver != (w.data_ptr(), w._version, stream):
             gen.close()
             return None
         return gen

@@ -13,6 +13,7 @@ blocks (``convbn_3d``, ``hourglass``) and the composition pattern of VernierScal
     v = v + hourglass(v)[0]                                      hg_conv3d
     cost = conv1x1x1(v)           C  -> 1                        classifier
 """
+import itertools
 import math
 import warnings
 import weakref
@@ -25,6 +26,8 @@ from .. import ops
 from .submodule import (_GENERATION, _ROUTES, ConvBNReLU3d, HipConv3d, SplitOverflow, _FactoredFirstConvFn, _ShearedFirstConvBNFn,
                         _ShearedFirstConvFn, _folded_bn, _is_channel_head as _is_head_conv, _Plan, convbn_3d, folded_head_weights,
                         hourglass, overflow_guard, sheared_geometry, sheared_kernels, EPI_RELU)
+
+_PREP_EPOCH = itertools.count(1)      # stamps of the per-model first-layer prep buffers (see _forward_pair_steps)
 
 
 class GlobalStack(nn.Module):
@@ -359,7 +362,7 @@ class GlobalStack(nn.Module):
                 left, right, shift, ds = volume.sources
                 if left.shape[1] * 2 == self.conv1[0][0].in_channels and left.shape[3] % 4 == 0:
                     from .. import lazy as _lazy
-                    _lazy.CONSUMER[0] = weakref.ref(self)      # the next build_cost_volume starts this model's first-layer prep
+                    _lazy.CONSUMER.ref = weakref.ref(self)      # the next build_cost_volume starts this model's first-layer prep
                     pre = volume.take_prefetch(self)
                     if pre is not None:                         # build_cost_volume already ran the step up to its host sync
                         try:
@@ -685,8 +688,13 @@ class GlobalStack(nn.Module):
         # the first layer's small 2D convolutions run in split mode whenever the stack behind them does (same arithmetic contract:
         # fp32 accuracy on the half pipe); `arithmetic="fp32"` keeps every layer on the fp32-MFMA kernels
         split_prep = bool(self.split_prep and c % 8 == 0 and (3 * conv.out_channels) % 32 == 0 and right.is_contiguous()
+                          and (not left.is_contiguous() or left.data_ptr() % 16 == 0) and right.data_ptr() % 16 == 0      # the scale launch reads float4
                           and self._x3_select(left.device, arithmetic) is not None)
         prep_ws = self.__dict__.setdefault("_snvc_prep_ws", {})
+        # r6: the prep results (planes, G / G', P / Q / E) live in per-model buffers that the NEXT call through here overwrites.  Every
+        # call takes a new epoch; a step that was paused (build_cost_volume's speculative start) compares it when it is resumed
+        # (a process-wide counter: invalidate_plans(model) drops the attribute, and a fresh count must not meet an old step's number)
+        epoch = self.__dict__["_snvc_prep_epoch"] = next(_PREP_EPOCH)
         if split_prep:      # one host call: the left feature's scale, its split pair, the 3x3 layer with 3 * Cout output channels
             lx = plans.get("left2d_x3")
             if lx is None:
@@ -767,6 +775,17 @@ class GlobalStack(nn.Module):
                 structure = None                 # the caller asked for the general path
         if pause:
             yield "shift checked; planes and speculative prep queued"
+            # resumed by GlobalStack.forward(volume).  Anything may have run on this model in between -- another build_cost_volume (two
+            # pending volumes), a forward_pair, a parameter update: if the prep buffers are no longer this step's own, or the folded
+            # first-layer parameters moved, the step starts over from its inputs (the shift array's answer stays: it was checked)
+            w_now = conv.weight
+            fresh = (self.__dict__.get("_snvc_prep_epoch") == epoch and plans.get("key") == key
+                     and (w_now.data_ptr(), w_now._version, w_now.device, _GENERATION[0]) == key
+                     and all(a is b for a, b in zip(_folded_bn(bn, plans["plan"]), (scale, bias))))
+            if not fresh:
+                _ROUTES["lazy_prefetch_stale"] += 1
+                return (yield from self._forward_pair_steps(left, right, shift, downsample, factored, timing, True, sheared, fused_bn,
+                                                            structure, commuted, arithmetic, pause=False))
         if structure is not None and not self._sheared_fits(structure[0], structure[1], shift.size(1), left.size(3), False):
             structure = None                     # rows the sheared kernels do not cover: the paths below
         if structure is not None:

@@ -76,7 +76,7 @@ def invalidate_plans(module: Optional[nn.Module] = None) -> None:
 # coordinate maps).  invalidate_plans() drops exactly these; tests/test_host_cpu.py checks that no other `_snvc_*`
 # name is written anywhere in the package.
 CACHE_ATTRS = ("_snvc_plans", "_snvc_plans_f16", "_snvc_plans_x3", "_snvc_plans2d", "_snvc_plans2d_t", "_snvc_factored", "_snvc_factored_train", "_snvc_ws",
-               "_snvc_coor_maps", "_snvc_x3", "_snvc_x3_off", "_snvc_x3_guard", "_snvc_last_v1", "_snvc_streams", "_snvc_lazy_warned", "_snvc_prep_ws")
+               "_snvc_coor_maps", "_snvc_x3", "_snvc_x3_off", "_snvc_x3_guard", "_snvc_last_v1", "_snvc_streams", "_snvc_lazy_warned", "_snvc_prep_ws", "_snvc_prep_epoch")
 
 
 class _Plan:

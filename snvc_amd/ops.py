@@ -11,6 +11,7 @@ import contextlib
 import ctypes
 import math
 import threading
+import time
 from typing import Optional, Tuple
 
 import torch
@@ -517,11 +518,16 @@ def shift_structure_begin(shift):
     return host
 
 
-def spin_wait(event, spins: int = 20000):
+def spin_wait(event, spin_us: float = 1000.0):
     """Wait for a recorded event by polling it (hipEventQuery, ~1 us a look) before falling back to the blocking wait: the waits of a
     step are for results that are a few microseconds away, and a sleeping wait costs tens of microseconds to wake (r5: 0.076 ms of
-    a 2.04 ms step between the overflow flag's arrival and the next launch)."""
-    for _ in range(spins):
+    a 2.04 ms step between the overflow flag's arrival and the next launch).  The poll is bounded by TIME (r6, ADVICE r5: an
+    iteration count let a deep queue or a shared device burn a core, and the GIL, for tens of milliseconds): 1 ms covers every
+    wait of a 2 ms step; anything further away sleeps."""
+    if event.query():
+        return
+    deadline = time.perf_counter() + spin_us * 1e-6
+    while time.perf_counter() < deadline:
         if event.query():
             return
     event.synchronize()
@@ -1301,6 +1307,21 @@ def split_scale_for(*tensors) -> torch.Tensor:
 
 
 _SCALE_SCRATCH = {}
+_SCALE_SCRATCH_LOCK = threading.Lock()
+
+
+def _scale_scratch(device) -> torch.Tensor:
+    """The 8-byte (running maximum, arrival counter) scratch of the scale launches, one per (device, STREAM): launches on one stream are
+    ordered and may share it (the kernels leave it zeroed); two streams -- or two threads, each on its own stream -- of one device
+    must not (a shared scratch races on the maximum and on the counter and yields a wrong scale)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    scratch = _SCALE_SCRATCH.get(key)
+    if scratch is None:
+        with _SCALE_SCRATCH_LOCK:
+            scratch = _SCALE_SCRATCH.get(key)
+            if scratch is None:
+                scratch = _SCALE_SCRATCH[key] = torch.zeros(2, dtype=torch.int32, device=device)
+    return scratch
 
 
 def split_scale_of(t: torch.Tensor) -> torch.Tensor:
@@ -1309,9 +1330,7 @@ def split_scale_of(t: torch.Tensor) -> torch.Tensor:
     _gpu(t, "t")
     if t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16:
         return split_scale_for(t)
-    scratch = _SCALE_SCRATCH.get(t.device)
-    if scratch is None:
-        scratch = _SCALE_SCRATCH[t.device] = torch.zeros(2, dtype=torch.int32, device=t.device)
+    scratch = _scale_scratch(t.device)
     out = torch.empty(1, dtype=torch.float32, device=t.device)
     with torch.cuda.device(t.device):
         check(_lib.lib().snvc_f16x3_split_scale(_ptr(t), t.numel(), _ptr(scratch), _ptr(out), _stream(t)), "snvc_f16x3_split_scale")
@@ -1384,9 +1403,7 @@ def sheared_prep_x3(right, q: int, wu: int, off: int, wu_col: int, off_col: int,
                   rq2=torch.empty(n * 2 * c * h * wu_col, dtype=torch.float16, device=dev), mul=torch.empty(1, dtype=torch.float32, device=dev),
                   g=torch.empty((n, lay_g.cout, h, wu), dtype=torch.float32, device=dev),
                   gcol=torch.empty((n, lay_col.cout, h, wu_col), dtype=torch.float32, device=dev))
-    scratch = _SCALE_SCRATCH.get(right.device)
-    if scratch is None:
-        scratch = _SCALE_SCRATCH[right.device] = torch.zeros(2, dtype=torch.int32, device=right.device)
+    scratch = _scale_scratch(right.device)
     with torch.cuda.device(right.device):
         check(_lib.lib().snvc_sheared_prep_x3(_ptr(right), n, c, h, w, int(q), int(wu), int(off), int(wu_col), int(off_col), _ptr(lay_g.packed),
                                               _ptr(lay_col.packed), lay_g.cout, float(2.0 ** -lay_g.w_exp), float(2.0 ** -lay_col.w_exp),
@@ -1416,9 +1433,7 @@ def conv2d_x3_from_f32(x, layers, ws: dict):
         ws["c_mul"] = (ctypes.c_float * k)(*[2.0 ** -l.w_exp for l in layers])
         ws["c_y"] = (ctypes.c_void_p * k)(*[t.data_ptr() for t in ws["y"]])
         ws["layers"] = list(layers)          # keeps the packed weights the pointer array refers to alive
-    scratch = _SCALE_SCRATCH.get(x.device)
-    if scratch is None:
-        scratch = _SCALE_SCRATCH[x.device] = torch.zeros(2, dtype=torch.int32, device=x.device)
+    scratch = _scale_scratch(x.device)
     with torch.cuda.device(x.device):
         check(_lib.lib().snvc_f16x3_conv2d_from_f32(_ptr(x), n, c, h, w, layers[0].kh, layers[0].kw, len(layers), ws["c_packed"], ws["c_cout"],
                                                     ws["c_mul"], ws["c_y"], _ptr(ws["split"]), _ptr(scratch), _ptr(ws["mul"]), _stream(x)),
