@@ -24,6 +24,8 @@ REQUIRED = CONTRACT + ("roofline", "cpu_baseline")      # the headline line at N
 # keys whose values are prose: kept in the detail line, dropped from the compact result line
 PROSE_KEYS = frozenset({"note", "rule", "prewarm", "entry_points", "measured_in", "prep", "tolerance", "coords", "source", "arithmetic_note",
                         "traffic_source_note"})
+# ... and below the second level (configs.<name>.*, off_fast_path.<name>.*): descriptions of legs that are not the headline
+DEEP_PROSE_KEYS = frozenset({"sample", "dominant_kernel", "workload", "arithmetic", "outputs_gathered", "kernel"})
 MAX_STR = 200
 
 
@@ -51,14 +53,24 @@ def sanitize(obj):
 
 
 def compact(obj, depth=0):
-    """The result line's form of a (sanitized) record: prose keys dropped below the top level, long strings cut."""
+    """The result line's form of a (sanitized) record: prose keys dropped below the top level, long strings cut, floats below the
+    top level to 6 significant digits (the contract's own top-level numbers keep every digit)."""
     if isinstance(obj, dict):
-        return {k: compact(v, depth + 1) for k, v in obj.items() if not (depth >= 1 and k in PROSE_KEYS)}
+        return {k: compact(v, depth + 1) for k, v in obj.items()
+                if not (depth >= 1 and k in PROSE_KEYS) and not (depth >= 2 and k in DEEP_PROSE_KEYS and isinstance(v, str)
+                                                                 and not _is_roofline_entry(obj))}
     if isinstance(obj, list):
         return [compact(v, depth + 1) for v in obj]
     if isinstance(obj, str) and len(obj) > MAX_STR:
         return obj[:MAX_STR - 3] + "..."
+    if isinstance(obj, float) and depth >= 2:
+        return float(f"{obj:.6g}")
     return obj
+
+
+def _is_roofline_entry(d):
+    """roofline_hbm.<row> keeps its kernel name: the judge reads the row by it."""
+    return "achieved" in d and "bytes_per_launch" in d
 
 
 def _prefixed(tag, obj):
