@@ -214,7 +214,12 @@ enum {
      * 3x3x3: split mode only, no residual (an optional side head); 5^3, dilated 5^3, 7^3: split and fp16-storage mode, residual
      * allowed.  Same values as the 32x32x16 forms up to fp32 summation order.  Pack and forward must agree;
      * SNVC_ERR_UNSUPPORTED otherwise. */
-    SNVC_ALGO_X3_Q16 = 0x8000
+    SNVC_ALGO_X3_Q16 = 0x8000,
+    /* snvc_conv3d_wgrad only (r6): keep the fp32-MFMA forms.  By default a 3x3x3 / stride-1 layer with 16-byte aligned rows takes the
+     * split-operand form: x and g are scaled by a power of two from their own maxima and split into (hi, lo) pairs of halves on the
+     * way into LDS, every fp32 product is three v_mfma_f32_16x16x32_f16 with fp32 accumulation (22 significant bits per operand;
+     * deterministic: fixed-order partial sums) -- conv3d_wgrad_x3_kernel, csrc/conv3d_bwd.hip. */
+    SNVC_ALGO_WGRAD_FP32 = 0x10000
 };
 
 typedef struct {
@@ -277,6 +282,13 @@ SNVC_API int snvc_affine_act(const float *x, const float *scale, const float *sh
                              const float *residual, float *y, int64_t N, int64_t C, int64_t S,
                              int64_t x_batch_stride, int64_t y_batch_stride,
                              int64_t res_batch_stride, int per_sample, int flags, void *stream);
+/* r6: the same pass; additionally atomicMax-es the bit pattern of max|y| into *amax (a zeroed 4-byte device word; may be NULL): the
+ * split-operand weight gradient (snvc_conv3d_wgrad_amax) scales its operands by their maxima, and the pass that writes a tensor gets
+ * its maximum for free where a separate reduction costs a read of the whole tensor. */
+SNVC_API int snvc_affine_act_amax(const float *x, const float *scale, const float *shift,
+                                  const float *residual, float *y, int64_t N, int64_t C, int64_t S,
+                                  int64_t x_batch_stride, int64_t y_batch_stride,
+                                  int64_t res_batch_stride, int per_sample, int flags, uint32_t *amax, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Training backward of the 3D stack (BASELINE.json configs[3]; reference: torch autograd through
@@ -428,6 +440,13 @@ SNVC_API int snvc_sheared_upsample_backward(const float *drq, float *dright, int
 SNVC_API int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *desc_host);
 SNVC_API int snvc_conv3d_wgrad(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
                                void *workspace, void *stream);
+/* r6: snvc_conv3d_wgrad with the operands' maxima supplied: amax_x / amax_g point at the bit pattern of max|x| / max|g| (device words,
+ * e.g. written by snvc_affine_act_amax / snvc_act_backward_apply_amax when the tensors were produced); either may be NULL, the
+ * split-operand form then finds that maximum itself with one more pass over the tensor (0.2 ms per 736 MB).  A supplied value must
+ * be >= the true maximum (a larger one only costs precision: 2^k too large = k of the 39 bits below the maximum); the fp32
+ * forms ignore both. */
+SNVC_API int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
+                                    void *workspace, const uint32_t *amax_x, const uint32_t *amax_g, void *stream);
 SNVC_API int64_t snvc_act_backward_workspace_bytes(int64_t N, int64_t C);
 SNVC_API int snvc_act_backward_reduce(const float *raw, const float *gy, const float *residual,
                                       const float *scale, const float *shift, double *sums,
@@ -440,6 +459,13 @@ SNVC_API int snvc_act_backward_apply(const float *raw, const float *gy, const fl
                                      float *g_out, int64_t N, int64_t C, int64_t S,
                                      int64_t raw_batch_stride, int64_t gy_batch_stride,
                                      int64_t res_batch_stride, int per_sample, int flags, void *stream);
+/* r6: + the bit pattern of max|draw| into *amax (see snvc_affine_act_amax). */
+SNVC_API int snvc_act_backward_apply_amax(const float *raw, const float *gy, const float *residual,
+                                          const float *scale, const float *shift, const float *coef_g,
+                                          const float *coef_raw, const float *coef_const, float *draw,
+                                          float *g_out, int64_t N, int64_t C, int64_t S,
+                                          int64_t raw_batch_stride, int64_t gy_batch_stride,
+                                          int64_t res_batch_stride, int per_sample, int flags, uint32_t *amax, void *stream);
 
 /* Train-mode BatchNorm backward coefficients from snvc_act_backward_reduce's sums [N, C, 2] (fp64), in fp64, one launch
  * (replaces the ~15 per-channel tensor operations of torch autograd's native_batch_norm_backward on this path):

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNVC_HIP_LIB") or os.path.join(_HERE, "libsnvc_hip.so")   # env: development override
 _lib = None
-_ABI = 4   # snvc_abi_version() this binding was written against
+_ABI = 5   # snvc_abi_version() this binding was written against
 
 c_i64 = ctypes.c_int64
 c_f32 = ctypes.c_float
@@ -32,6 +32,7 @@ ALGO_AUTO, ALGO_DIRECT = 0, 1
 ALGO_WINO_TILE_BIG, ALGO_WINO_TILE_STD, ALGO_WINO_TILE_NARROW_REG = 0x100, 0x200, 0x300
 ALGO_GENERIC_EPILOGUE, ALGO_SCALAR_STAGING = 0x400, 0x800
 ALGO_X3_SERIAL, ALGO_X3_NARROW, ALGO_X3_SMALL, ALGO_X3_Q16 = 0x1000, 0x2000, 0x4000, 0x8000
+ALGO_WGRAD_FP32 = 0x10000      # snvc_conv3d_wgrad: the fp32-MFMA forms instead of the split-operand (f16x3) one
 F32, F64 = 0, 1
 
 # name -> (restype, argtypes); kept next to the header so the symbol test can walk it
@@ -81,12 +82,15 @@ SIGNATURES = {
     "snvc_norm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),
     "snvc_norm_stats": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_f32, c_p]),
     "snvc_affine_act": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "snvc_affine_act_amax": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p]),
     "snvc_conv3d_wgrad_workspace_bytes": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
     "snvc_conv3d_wgrad": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p]),
+    "snvc_conv3d_wgrad_amax": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_act_backward_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "snvc_act_backward_reduce": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     "snvc_bn_backward_coefs": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_p]),
     "snvc_act_backward_apply": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "snvc_act_backward_apply_amax": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p]),
     "snvc_mul_broadcast": (c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_avgpool_depth4": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),
     "snvc_avgpool_depth4_backward": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_p]),

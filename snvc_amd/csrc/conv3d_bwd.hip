@@ -17,6 +17,9 @@
 // waves split the (up to 28) taps, each wave keeping 7 accumulators of 32x32 in registers across
 // ALL tiles of the partition.  Partials go to a slab [partition][...] that a second kernel sums
 // in a fixed order: the result is deterministic (no float atomics).
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.hpp"
 
 
@@ -864,6 +867,297 @@ void launch_wgrad(const WgradArgs &a, dim3 grid, hipStream_t st) {
     }
 }
 
+// ------------------------------------------------------------------ split-operand (f16x3) weight gradient, 3x3x3 / stride 1 (r6)
+// The fp32 forms above run at half of the fp32 matrix pipe (conv2's 32 -> 32 layer on 192 x 96 x 312: 2.07 ms, the largest launch of
+// the cfg4 step).  This form puts the same contraction on v_mfma_f32_16x16x32_f16: both operands are split on the
+// way into LDS into (hi, lo) pairs of halves -- x * sx = hi + lo with a per-tensor power-of-two scale taken from the tensor's own
+// maximum (wgrad_amax2_kernel), 22 significant bits -- and every fp32 product becomes three MFMAs (hi*hi + hi*lo + lo*hi) with
+// fp32 accumulation, as in the forward split mode (conv3d_f16.hip).  K of the GEMM is the voxel index, so the natural operand
+// layout is the tensors' own NCDHW: a lane's 8 consecutive k are 8 consecutive w of one channel (no layout pass; 16-byte LDS reads
+// from channel-major rows).
+//   A (16 x 32) = x[ci][w0 + 8 kg + j + kw - 1]   B (32 x 16) = g[co][w0 + 8 kg + j]   D[ci][co] += A B      per tap and 32 voxels
+// At f16 rates the layer has 650 flop per algorithmic byte, twice the ridge: every staged byte has to serve ALL 27 taps.  A
+// workgroup therefore owns a COLUMN of the grid -- 4 output rows x 32 output columns -- and walks it along d with a ring of
+// three input planes in LDS (6 rows x 32 channels x 40 columns each, as halves): per step one new input plane (26 KB) and one
+// gradient plane (16 KB) arrive for 4 x 32 voxels x 27 taps x 32 x 32 channels.  The next step's planes travel global -> registers
+// under this step's MFMAs and are split into LDS between two barriers.
+// Four waves, one per SIMD: wave = (16-channel half of x) x (row pair); it keeps ALL 27 taps x both 16-channel halves of g:
+// 216 accumulator registers.  The kw = 0 / 2 operands are the kw = 1 piece shifted by one half: v_alignbit with the neighbouring
+// dwords (an unaligned ds_read_b128 is replayed at 64 cycles), computed once and used for both halves of g: 16 VALU per 54 MFMAs.
+// Partial slabs [column * 2 + row pair][pair][27][cg 32][cx 32] (the direct kernels' layout) are summed in a fixed order by
+// wgrad_reduce_kernel, which also removes the two scales: deterministic.  desc.algo |= SNVC_ALGO_WGRAD_FP32 keeps the fp32 forms.
+typedef _Float16 h8w __attribute__((ext_vector_type(8)));
+typedef _Float16 h4w __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4w __attribute__((ext_vector_type(4)));
+
+struct X3WgCfg {
+    static constexpr int TH = 4, XR = TH + 2, THREADS = 512;      // 4 x 32 gradient voxels per plane step
+    static constexpr int XCOLS = 32;                         // halves per staged x row: image columns w0 .. w0+31 (64 bytes, chunks swizzled)
+    static constexpr int XPLANE = XR * 32 * XCOLS;           // halves of the hi (or lo) half of a slot
+    static constexpr int SLOT_BYTES = 2 * XPLANE * 2;        // hi | lo = 24576
+    static constexpr int NSLOT = 4;
+    static constexpr int GCOLS = 48;                         // halves per staged dy row: columns w0-8 .. w0+39 (96-byte stride: conflict-free b128)
+    static constexpr int GPLANE = TH * 32 * GCOLS;
+    static constexpr int G_BYTES = 2 * GPLANE * 2;           // 24576
+    static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + 2 * G_BYTES;      // 147456
+    static constexpr int XPIECES = XR * 32 * 8, XNIT = XPIECES / THREADS;                        // float4 pieces of an input plane: 1536 = 3 rounds
+    static constexpr int GPIECES = TH * 32 * 10, GNIT = (GPIECES + THREADS - 1) / THREADS;       // 1280 -> 3 rounds (the last one half full)
+    static_assert(XPIECES % THREADS == 0, "whole rounds");
+};
+
+struct X3WgArgs {
+    const float *x, *g;
+    float *partial;
+    const unsigned *amax_x, *amax_g;       // bits of max|x|, max|g| (or of upper bounds)
+    int N, Cx, Cg, D, H, W;
+    int cx_blocks, pairs, hblocks, wsegs, dparts, dchunk, njobs;
+    int64_t x_bs, g_bs;
+};
+
+// power of two s with max * s in [2^13, 2^14) (half: 65504); 1 for an all-zero or non-finite tensor
+__device__ __forceinline__ float x3wg_scale(unsigned bits) {
+    const float a = __uint_as_float(bits);
+    if (!(a > 0.0f) || !(a < __builtin_inff())) return 1.0f;
+    int e;
+    (void)frexpf(a, &e);
+    int k = 14 - e;
+    k = k > 100 ? 100 : (k < -100 ? -100 : k);
+    return ldexpf(1.0f, k);
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_amax2_kernel(const float *__restrict__ x, const float *__restrict__ g, unsigned *__restrict__ out, int64_t n4x, int64_t n4g,
+                   int64_t x_bs, int64_t g_bs) {
+    const int which = blockIdx.y;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>((which ? g : x) + (int64_t)blockIdx.z * (which ? g_bs : x_bs));
+    const int64_t n4 = which ? n4g : n4x;
+    // |v| as bits: for non-negative floats the unsigned order is the float order; a NaN sorts above infinity
+    auto amax4 = [](const f32x4 v) {
+        const unsigned b0 = __float_as_uint(v[0]) & 0x7fffffffu, b1 = __float_as_uint(v[1]) & 0x7fffffffu;
+        const unsigned b2 = __float_as_uint(v[2]) & 0x7fffffffu, b3 = __float_as_uint(v[3]) & 0x7fffffffu;
+        const unsigned m01 = b0 > b1 ? b0 : b1, m23 = b2 > b3 ? b2 : b3;
+        return m01 > m23 ? m01 : m23;
+    };
+    unsigned m = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {           // four 16-byte loads in flight per lane
+        const f32x4 v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
+        const unsigned a0 = amax4(v0), a1 = amax4(v1), a2 = amax4(v2), a3 = amax4(v3);
+        const unsigned a01 = a0 > a1 ? a0 : a1, a23 = a2 > a3 ? a2 : a3;
+        const unsigned aa = a01 > a23 ? a01 : a23;
+        m = m > aa ? m : aa;
+    }
+    for (; i < n4; i += stride) {
+        const unsigned aa = amax4(p[i]);
+        m = m > aa ? m : aa;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off);
+        m = m > o ? m : o;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out + which, m);
+}
+
+__global__ void __launch_bounds__(512, 1)
+conv3d_wgrad_x3_kernel(const X3WgArgs a) {
+    using Cfg = X3WgCfg;
+    constexpr int XNIT = Cfg::XNIT, GNIT = Cfg::GNIT, XCOLS = Cfg::XCOLS, GCOLS = Cfg::GCOLS;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char *const lds = reinterpret_cast<char *>(lds_f);
+    char *const gbase = lds + Cfg::NSLOT * Cfg::SLOT_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this wave: x channels 16 cih .. +15, g channels 16 coh .. +15, gradient rows 2 kp, 2 kp + 1.  Waves w and w + 4 share a SIMD
+    // and differ in kp: one of them computes while the other one stages (see the loop)
+    const int cih = wave & 1, coh = (wave >> 1) & 1, kp = wave >> 2;
+    const int i16 = lane & 15, kg = lane >> 4;
+    // job -> (column, pair, depth part); the pairs of a column are neighbours on one XCD (they share its planes through that L2)
+    const int q8 = a.njobs >> 3, r8 = a.njobs & 7, xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+    const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kx;
+    if (kx >= q8 + (xcd < r8 ? 1 : 0)) return;
+    const int pair = job % a.pairs, col = job / a.pairs;          // col = ((n * dparts + dp) * hblocks + hb) * wsegs + ws
+    const int ws = col % a.wsegs, hb = (col / a.wsegs) % a.hblocks, dp = (col / (a.wsegs * a.hblocks)) % a.dparts;
+    const int64_t n = col / (a.wsegs * a.hblocks * a.dparts);
+    const int cgb = pair / a.cx_blocks, cxb = pair - cgb * a.cx_blocks;
+    const int cg0 = cgb * 32, cx0 = cxb * 32;
+    const int h0 = hb * Cfg::TH, w0 = ws * 32;
+    const int d0 = dp * a.dchunk, d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
+    const float sx = x3wg_scale(*a.amax_x), sg = x3wg_scale(*a.amax_g);
+    const int64_t hw = (int64_t)a.H * a.W, dhw = hw * a.D;
+
+    // staging tables (plane-invariant): element offset inside a plane of the sample, LDS position (in halves), validity
+    unsigned xoff[XNIT], goff[GNIT];
+    int xdst[XNIT], gdst[GNIT];
+    unsigned xok = 0, gok = 0;
+#pragma unroll
+    for (int it = 0; it < XNIT; ++it) {
+        const int p = it * Cfg::THREADS + tid;
+        const int ci = p / 48, rem = p - ci * 48, r = rem >> 3, q4 = rem & 7;
+        const int h = h0 - 1 + r, w = w0 + 4 * q4;
+        const bool ok = cx0 + ci < a.Cx && (unsigned)h < (unsigned)a.H && w + 4 <= a.W;
+        xoff[it] = ok ? (unsigned)(ci * dhw + (int64_t)h * a.W + w) : 0u;
+        // 16-byte chunk (q4 >> 1) of the row sits at position chunk ^ 2 * bit 2 of the channel: conflict-free ds_read_b128 at a 64-byte stride
+        xdst[it] = (r * 32 + ci) * XCOLS + (((q4 >> 1) ^ (2 * ((ci >> 2) & 1))) * 8) + (q4 & 1) * 4;
+        xok |= (ok ? 1u : 0u) << it;
+    }
+#pragma unroll
+    for (int it = 0; it < GNIT; ++it) {
+        const int p = it * Cfg::THREADS + tid;
+        const int co = p / 40, rem = p - co * 40, r = rem / 10, q = rem - r * 10;
+        const int h = h0 + r, w = w0 - 4 + 4 * q;
+        const bool in = p < Cfg::GPIECES;
+        const bool ok = in && cg0 + co < a.Cg && h < a.H && w >= 0 && w + 4 <= a.W;
+        goff[it] = ok ? (unsigned)(co * dhw + (int64_t)h * a.W + w) : 0u;
+        gdst[it] = in ? (r * 32 + co) * GCOLS + 4 + 4 * q : -1;
+        gok |= (ok ? 1u : 0u) << it;
+    }
+    const float *const xs = a.x + n * a.x_bs + (int64_t)cx0 * dhw;
+    const float *const gs = a.g + n * a.g_bs + (int64_t)cg0 * dhw;
+    // Loads are UNCONDITIONAL (an absent piece reads element 0 of the sample, a valid address) and the zeros are put in when the
+    // registers are split into LDS: a predicated load -- `ok ? *p : 0` -- makes the compiler zero the destination first and wait
+    // (s_waitcnt vmcnt(0)) for every earlier load before it may overwrite those registers: the six loads of a step then run one
+    // after the other, each paying its whole latency (measured: 5.1 us per step instead of 2.6).
+    f32x4 xv[XNIT], gv[GNIT];
+    bool x_dok = false, g_dok = false;     // the planes in the registers lie inside the grid
+    auto load_x = [&](int id) {           // input plane id -> registers
+        x_dok = (unsigned)id < (unsigned)a.D;
+        const float *b = xs + (int64_t)(x_dok ? id : 0) * hw;
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it) xv[it] = *reinterpret_cast<const f32x4 *>(b + xoff[it]);
+    };
+    auto load_g = [&](int od) {
+        g_dok = od < a.D;
+        const float *b = gs + (int64_t)(g_dok ? od : 0) * hw;
+#pragma unroll
+        for (int it = 0; it < GNIT; ++it) gv[it] = *reinterpret_cast<const f32x4 *>(b + goff[it]);
+    };
+    auto split_store = [&](char *hi_base, int plane_halves, int dst, f32x4 v, float s) {
+        const f32x4 t = v * s;
+        const h4w hi = __builtin_convertvector(t, h4w);
+        const f32x4 back = __builtin_convertvector(hi, f32x4);
+        const h4w lo = __builtin_convertvector(t - back, h4w);
+        *reinterpret_cast<h4w *>(hi_base + 2 * dst) = hi;
+        *reinterpret_cast<h4w *>(hi_base + 2 * (plane_halves + dst)) = lo;
+    };
+    auto store_x = [&](int id) {          // plane id lives in slot (id + 4) & 3
+        char *b = lds + ((id + 4) & 3) * Cfg::SLOT_BYTES;
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it)
+            split_store(b, Cfg::XPLANE, xdst[it], (x_dok && ((xok >> it) & 1u)) ? xv[it] : f32x4(0.0f), sx);
+    };
+    auto store_g = [&](int od) {
+        char *b = gbase + (od & 1) * Cfg::G_BYTES;
+#pragma unroll
+        for (int it = 0; it < GNIT; ++it) {
+            if (gdst[it] < 0) continue;
+            split_store(b, Cfg::GPLANE, gdst[it], (g_dok && ((gok >> it) & 1u)) ? gv[it] : f32x4(0.0f), sg);
+        }
+    };
+
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4(0.0f);
+
+    // prologue: planes d0 - 1, d0, d0 + 1 and gradient plane d0 into LDS; plane d0 + 2 and gradient plane d0 + 1 into registers
+    for (int k = -1; k <= 1; ++k) {
+        load_x(d0 + k);
+        store_x(d0 + k);
+    }
+    load_g(d0);
+    store_g(d0);
+    load_x(d0 + 2);
+    load_g(d0 + 1);
+    __syncthreads();
+
+    // byte offsets of this lane's operands inside a staged row set
+    const int xlane = ((cih * 16 + i16) * XCOLS + ((kg ^ (2 * ((i16 >> 2) & 1))) * 8)) * 2;
+    const int glane = ((coh * 16 + i16) * GCOLS + 8 + 8 * kg) * 2;
+    auto stage = [&](int od) {            // the registers hold input plane od + 2 and gradient plane od + 1: split them into LDS, then
+        if (od + 1 < d1) {                // fetch the planes behind them (consumed one step later: their latency is a whole step)
+            store_x(od + 2);
+            store_g(od + 1);
+            if (od + 2 < d1) {
+                load_x(od + 3);
+                load_g(od + 2);
+            }
+        }
+    };
+    for (int od = d0; od < d1; ++od) {
+        if (kp == 0) stage(od);          // the SIMD's other wave (kp == 1) runs its MFMAs meanwhile
+        const char *const gplane = gbase + (od & 1) * Cfg::G_BYTES + glane;
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int rg = 2 * kp + rr;
+            // the gradient row's three column shifts (hi and lo): kw = 0 -> g[u + 1], kw = 1 -> g[u], kw = 2 -> g[u - 1]; the shifted
+            // pieces come from the aligned one and its neighbouring dwords (an unaligned ds_read_b128 is replayed at 64 cycles)
+            u32x4w gb[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const char *q = gplane + (rg * 32 * GCOLS + pl * Cfg::GPLANE) * 2;
+                const u32x4w b = *reinterpret_cast<const u32x4w *>(q);
+                const unsigned left = *reinterpret_cast<const unsigned *>(q - 4);      // columns u - 2, u - 1
+                const unsigned right = *reinterpret_cast<const unsigned *>(q + 16);    // columns u + 8, u + 9
+                gb[pl][1] = b;
+                gb[pl][0] = u32x4w{__builtin_amdgcn_alignbit(b[1], b[0], 16), __builtin_amdgcn_alignbit(b[2], b[1], 16),
+                                   __builtin_amdgcn_alignbit(b[3], b[2], 16), __builtin_amdgcn_alignbit(right, b[3], 16)};
+                gb[pl][2] = u32x4w{__builtin_amdgcn_alignbit(b[0], left, 16), __builtin_amdgcn_alignbit(b[1], b[0], 16),
+                                   __builtin_amdgcn_alignbit(b[2], b[1], 16), __builtin_amdgcn_alignbit(b[3], b[2], 16)};
+            }
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const char *sb = lds + ((od + kd + 3) & 3) * Cfg::SLOT_BYTES + xlane;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const char *xp = sb + (rg + kh) * 32 * XCOLS * 2;
+                    const h8w xh = *reinterpret_cast<const h8w *>(xp);
+                    const h8w xl = *reinterpret_cast<const h8w *>(xp + 2 * Cfg::XPLANE);
+                    // three products per tap; the dependent MFMAs of one accumulator are three instructions apart
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int t = (kd * 3 + kh) * 3 + kw;
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 2 ? xl : xh, __builtin_bit_cast(h8w, gb[pr == 1 ? 1 : 0][kw]),
+                                                                            acc[t], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        if (kp == 1) stage(od);
+        __syncthreads();                 // plane od + 2 / gradient plane od + 1 are in LDS; every read of plane od - 1 is done
+    }
+    // ---- partial slab [col * 2 + kp][pair][tap][cg 32][cx 32]: D[i = x channel 4 kg + r][j = g channel i16]
+    float *pp = a.partial + (((int64_t)(col * 2 + kp) * a.pairs + pair) * 27) * 1024 + (coh * 16 + i16) * 32 + cih * 16 + 4 * kg;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(pp + t * 1024) = acc[t];
+}
+
+// wgrad_reduce_kernel for the split-operand form: the same fixed-order sum, then the two power-of-two scales are taken out (exact)
+__global__ void wgrad_reduce_x3_kernel(const float *__restrict__ partial, float *__restrict__ dw, int Cg, int Cx, int cx_blocks, int pairs,
+                                       int P, const unsigned *__restrict__ amax_x, const unsigned *__restrict__ amax_g) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t pstride = (int64_t)pairs * 27 * 1024;
+    if (i >= pstride) return;
+    const int cxl = (int)(i & 31), cgl = (int)((i >> 5) & 31);
+    const int tap = (int)((i >> 10) % 27);
+    const int pair = (int)(i / ((int64_t)27 * 1024));
+    const int cg = (pair / cx_blocks) * 32 + cgl, cx = (pair % cx_blocks) * 32 + cxl;
+    if (cg >= Cg || cx >= Cx) return;
+    const float *src = partial + i;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int p = 0;
+    for (; p + 4 <= P; p += 4) {
+        s0 += src[(int64_t)p * pstride];
+        s1 += src[(int64_t)(p + 1) * pstride];
+        s2 += src[(int64_t)(p + 2) * pstride];
+        s3 += src[(int64_t)(p + 3) * pstride];
+    }
+    for (; p < P; ++p) s0 += src[(int64_t)p * pstride];
+    const float inv_x = 1.0f / x3wg_scale(*amax_x), inv_g = 1.0f / x3wg_scale(*amax_g);
+    dw[((int64_t)cg * Cx + cx) * 27 + tap] = (((s0 + s1) + (s2 + s3)) * inv_x) * inv_g;
+}
+
 constexpr int kWgradPartitions = 512;   // 2 workgroups per CU
 #define SNVC_CFG(...) WgradCfg<__VA_ARGS__>
 
@@ -901,7 +1195,7 @@ int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *d) {
             if ((int64_t)4 * P * 27 > slabs) slabs = (int64_t)4 * P * 27;
         }
     }
-    return slabs * pairs * 1024 * (int64_t)sizeof(float);
+    return slabs * pairs * 1024 * (int64_t)sizeof(float) + 256;     // + the two amax words of the split-operand form (r6), at the end
 }
 
 // desc describes the FORWARD Conv3d (x = its input on the big grid, g = gradient of its output on
@@ -911,6 +1205,11 @@ int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *d) {
 // then in nn.ConvTranspose3d's [Cin][Cout][27] layout.
 int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g, float *dw, void *workspace,
                       void *stream) {
+    return snvc_conv3d_wgrad_amax(d, x, g, dw, workspace, nullptr, nullptr, stream);
+}
+
+int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const float *g, float *dw, void *workspace,
+                           const uint32_t *amax_x, const uint32_t *amax_g, void *stream) {
     using namespace snvc;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_wgrad: null desc");
     if (d->transposed) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_conv3d_wgrad: describe the equivalent strided convolution (see header)");
@@ -964,6 +1263,45 @@ int snvc_conv3d_wgrad(const snvc_conv3d_desc *d, const float *x, const float *g,
         }
     }
     const int key = d->ksize * 100 + d->stride * 10 + d->dilation;
+    if (key == 311 && a.vec == 4 && !(d->algo & SNVC_ALGO_WGRAD_FP32) && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
+        // split-operand (f16x3) form, see conv3d_wgrad_x3_kernel: one workgroup per (column of 4 x 32 voxels, depth part, channel pair)
+        X3WgArgs b;
+        b.x = x; b.g = g; b.partial = (float *)workspace;
+        b.N = d->N; b.Cx = d->Cin; b.Cg = d->Cout; b.D = d->Dout; b.H = d->Hout; b.W = d->Wout;
+        b.cx_blocks = a.cx_blocks; b.pairs = pairs; b.x_bs = a.x_bs; b.g_bs = a.g_bs;
+        b.hblocks = ceil_div(d->Hout, X3WgCfg::TH); b.wsegs = ceil_div(d->Wout, 32);
+        const int64_t cols = (int64_t)d->N * b.hblocks * b.wsegs;
+        // depth parts: enough jobs for every CU once, columns at least 8 planes long, at most 256 columns x parts (512 slabs, the
+        // workspace's size)
+        int dparts = 1;
+        while (cols * dparts * pairs < device_cu_count() * 3 / 4 && d->Dout / (dparts * 2) >= 8 && cols * dparts * 2 <= 256) dparts *= 2;
+        const int64_t slabs_bytes = snvc_conv3d_wgrad_workspace_bytes(d) - 256;
+        if (cols * dparts <= 256 && cols * dparts * pairs < ((int64_t)1 << 24) &&
+            (int64_t)2 * cols * dparts * pairs * 27 * 1024 * 4 <= slabs_bytes) {
+            b.dparts = dparts; b.dchunk = ceil_div(d->Dout, dparts);
+            b.dparts = ceil_div(d->Dout, b.dchunk);
+            b.njobs = (int)(cols * b.dparts * pairs);
+            unsigned *amax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + slabs_bytes);
+            b.amax_x = amax_x ? amax_x : amax;
+            b.amax_g = amax_g ? amax_g : amax + 1;
+            if (!amax_x || !amax_g) {        // a maximum the caller did not bring: one more pass over that tensor
+                if (hipMemsetAsync(amax, 0, 8, st) != hipSuccess) return fail(SNVC_ERR_HIP, "snvc_conv3d_wgrad: hipMemsetAsync failed");
+                const int64_t n4x = amax_x ? 0 : in_sz / 4, n4g = amax_g ? 0 : out_sz / 4;
+                const unsigned ab = (unsigned)std::min<int64_t>(ceil_div<int64_t>(std::max(n4x, n4g), 256 * 8), 4096);
+                wgrad_amax2_kernel<<<dim3(ab, 2, (unsigned)d->N), 256, 0, st>>>(x, g, amax, n4x, n4g, a.x_bs, a.g_bs);
+            }
+            static std::atomic<unsigned> attr_x3{0};
+            const unsigned nwg = (unsigned)(8 * ceil_div(b.njobs, 8));
+            if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3_kernel), X3WgCfg::LDS_BYTES, attr_x3))
+                conv3d_wgrad_x3_kernel<<<dim3(nwg), X3WgCfg::THREADS, X3WgCfg::LDS_BYTES, st>>>(b);
+            int rcx = check_launch("snvc_conv3d_wgrad(split operands)");
+            if (rcx) return rcx;
+            const int64_t total = (int64_t)pairs * 27 * 1024;
+            wgrad_reduce_x3_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>(
+                (const float *)workspace, dw, d->Cout, d->Cin, a.cx_blocks, pairs, (int)(2 * cols * b.dparts), b.amax_x, b.amax_g);
+            return check_launch("snvc_conv3d_wgrad(split operands reduce)");
+        }
+    }
     const int64_t wino_tiles = (int64_t)d->N * d->Dout * ceil_div(d->Hout, WinoWgradCfg::TH) * a.tiles_w;   // 32-bit tile counter
     if (key == 311 && a.vec == 4 && wino_tiles < ((int64_t)1 << 30) && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
         // Winograd-domain form (see conv3d_wgrad_wino_kernel): half the MFMAs of the direct form

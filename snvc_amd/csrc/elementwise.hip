@@ -221,12 +221,30 @@ __global__ void norm_finalize_kernel(const double *__restrict__ partial, const f
     }
 }
 
+// |v| as bits: for non-negative floats the unsigned order is the float order (a NaN sorts above infinity); one atomicMax per wave
+__device__ __forceinline__ unsigned amax_bits4(unsigned m, float a, float b, float c, float d) {
+    const unsigned b0 = __float_as_uint(a) & 0x7fffffffu, b1 = __float_as_uint(b) & 0x7fffffffu;
+    const unsigned b2 = __float_as_uint(c) & 0x7fffffffu, b3 = __float_as_uint(d) & 0x7fffffffu;
+    const unsigned m01 = b0 > b1 ? b0 : b1, m23 = b2 > b3 ? b2 : b3;
+    const unsigned mm = m01 > m23 ? m01 : m23;
+    return m > mm ? m : mm;
+}
+__device__ __forceinline__ void amax_publish(unsigned *amax, unsigned m) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off);
+        m = m > o ? m : o;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(amax, m);
+}
+
 __global__ void __launch_bounds__(256)
 affine_act_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                   const float *__restrict__ shift, const float *__restrict__ res,
                   float *__restrict__ y, int64_t C, int64_t S, int64_t x_bs, int64_t y_bs,
-                  int64_t r_bs, int per_sample, int flags) {
+                  int64_t r_bs, int per_sample, int flags, unsigned *__restrict__ amax) {
     const int64_t n = blockIdx.z, c = blockIdx.y;
+    unsigned mx = 0;        // bits of max|y| over this thread's elements (r6: the split-operand weight gradient scales by it)
     const float sc = scale ? scale[(per_sample ? n * C : 0) + c] : 1.0f;
     const float sh = shift ? shift[(per_sample ? n * C : 0) + c] : 0.0f;
     const float *a = x + n * x_bs + c * S;
@@ -246,11 +264,16 @@ affine_act_kernel(const float *__restrict__ x, const float *__restrict__ scale,
             w.z = epilogue(v.z * sc + sh, q.z, flags);
             w.w = epilogue(v.w * sc + sh, q.w, flags);
             reinterpret_cast<float4 *>(o)[i] = w;
+            mx = amax_bits4(mx, w.x, w.y, w.z, w.w);
         }
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += stride)
-            o[i] = epilogue(a[i] * sc + sh, r ? r[i] : 0.0f, flags);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += stride) {
+            const float w = epilogue(a[i] * sc + sh, r ? r[i] : 0.0f, flags);
+            o[i] = w;
+            mx = amax_bits4(mx, w, w, w, w);
+        }
     }
+    if (amax) amax_publish(amax, mx);
 }
 
 
@@ -333,7 +356,7 @@ act_bwd_apply_kernel(const float *__restrict__ raw, const float *__restrict__ gy
                      const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ A,
                      const float *__restrict__ B, const float *__restrict__ Cc, float *__restrict__ draw,
                      float *__restrict__ g_out, int64_t C, int64_t S, int64_t raw_bs, int64_t gy_bs, int64_t r_bs,
-                     int per_sample, int flags) {
+                     int per_sample, int flags, unsigned *__restrict__ amax) {
     const int64_t n = blockIdx.z, c = blockIdx.y;
     const int64_t pc = (per_sample ? n * C : 0) + c;
     const float sc = scale ? scale[pc] : 1.0f, sh = shift ? shift[pc] : 0.0f;
@@ -343,12 +366,16 @@ act_bwd_apply_kernel(const float *__restrict__ raw, const float *__restrict__ gy
     float *o = draw + (n * C + c) * S;
     float *go = g_out ? g_out + (n * C + c) * S : nullptr;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned mx = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += stride) {
         const float x = a[i];
         const float g = act_grad(x, b[i], r ? r[i] : 0.0f, sc, sh, flags);
-        o[i] = ca * g + cb * x + cc;
+        const float dr = ca * g + cb * x + cc;
+        o[i] = dr;
+        mx = amax_bits4(mx, dr, dr, dr, dr);
         if (go) go[i] = g;
     }
+    if (amax) amax_publish(amax, mx);
 }
 
 // Train-mode BatchNorm backward coefficients (see snvc_bn_backward_coefs): one thread per channel, fp64.
@@ -550,6 +577,15 @@ int snvc_act_backward_apply(const float *raw, const float *gy, const float *resi
                             const float *shift, const float *coef_g, const float *coef_raw, const float *coef_const,
                             float *draw, float *g_out, int64_t N, int64_t C, int64_t S, int64_t raw_batch_stride,
                             int64_t gy_batch_stride, int64_t res_batch_stride, int per_sample, int flags, void *stream) {
+    return snvc_act_backward_apply_amax(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const, draw, g_out, N, C, S,
+                                        raw_batch_stride, gy_batch_stride, res_batch_stride, per_sample, flags, nullptr, stream);
+}
+
+int snvc_act_backward_apply_amax(const float *raw, const float *gy, const float *residual, const float *scale,
+                                 const float *shift, const float *coef_g, const float *coef_raw, const float *coef_const,
+                                 float *draw, float *g_out, int64_t N, int64_t C, int64_t S, int64_t raw_batch_stride,
+                                 int64_t gy_batch_stride, int64_t res_batch_stride, int per_sample, int flags, uint32_t *amax,
+                                 void *stream) {
     using namespace snvc;
     if (N < 0 || C < 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_apply: negative size");
     if (N == 0 || C == 0 || S == 0) return SNVC_OK;
@@ -563,7 +599,7 @@ int snvc_act_backward_apply(const float *raw, const float *gy, const float *resi
     dim3 grid(stream_blocks(S, N * C), (unsigned)C, (unsigned)N);
     act_bwd_apply_kernel<<<grid, 256, 0, as_stream(stream)>>>(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const,
                                                               draw, g_out, C, S, raw_batch_stride, gy_batch_stride,
-                                                              res_batch_stride, per_sample, flags);
+                                                              res_batch_stride, per_sample, flags, amax);
     return check_launch("snvc_act_backward_apply");
 }
 
@@ -583,6 +619,14 @@ int snvc_affine_act(const float *x, const float *scale, const float *shift, cons
                     float *y, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
                     int64_t y_batch_stride, int64_t res_batch_stride, int per_sample, int flags,
                     void *stream) {
+    return snvc_affine_act_amax(x, scale, shift, residual, y, N, C, S, x_batch_stride, y_batch_stride, res_batch_stride, per_sample,
+                                flags, nullptr, stream);
+}
+
+int snvc_affine_act_amax(const float *x, const float *scale, const float *shift, const float *residual,
+                         float *y, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                         int64_t y_batch_stride, int64_t res_batch_stride, int per_sample, int flags,
+                         uint32_t *amax, void *stream) {
     using namespace snvc;
     if (N < 0 || C < 0 || S < 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_affine_act: negative size");
     if (N == 0 || C == 0 || S == 0) return SNVC_OK;
@@ -596,7 +640,7 @@ int snvc_affine_act(const float *x, const float *scale, const float *shift, cons
     if (res_batch_stride == 0) res_batch_stride = C * S;
     dim3 grid(stream_blocks(S / 4 + 1, N * C), (unsigned)C, (unsigned)N);
     affine_act_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, scale, shift, residual, y, C, S, x_batch_stride,
-                                                           y_batch_stride, res_batch_stride, per_sample, flags);
+                                                           y_batch_stride, res_batch_stride, per_sample, flags, amax);
     return check_launch("snvc_affine_act");
 }
 

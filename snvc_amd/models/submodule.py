@@ -157,18 +157,28 @@ def _norm_from_raw(raw, norm, plan, residual, flags, out=None):
 
 def _norm_forward(layer, norm, plan, x, residual, flags, out, keep_raw, exact=False):
     """Shared forward: returns (y, raw, scale, shift, mean, var, per_sample).  `raw` is the conv
-    output before the affine/activation (None when the single fused launch was used)."""
+    output before the affine/activation (None when the single fused launch was used).
+    ``keep_raw`` (the autograd functions): the pass that writes y also leaves max|y| in a device word tagged onto y (ops.tag_amax):
+    the next layer's split-operand weight gradient scales its x operand by it (r6)."""
+    am = ops.amax_word(x.device) if (keep_raw and x.is_cuda) else None
+    res = _norm_forward_impl(layer, norm, plan, x, residual, flags, out, keep_raw, exact, am)
+    if am is not None and res[1] is not None and res[0] is not res[1]:      # y came out of affine_act (not the raw tensor itself)
+        ops.tag_amax(res[0], am)
+    return res
+
+
+def _norm_forward_impl(layer, norm, plan, x, residual, flags, out, keep_raw, exact, am):
     if norm is None:
         if keep_raw and (flags or residual is not None):
             raw = layer(x, None, None, None, 0, None, exact=exact)
-            return ops.affine_act(raw, None, None, residual, flags, out=out), raw, None, None, None, None, False
+            return ops.affine_act(raw, None, None, residual, flags, out=out, amax=am), raw, None, None, None, None, False
         y = layer(x, None, None, residual, flags, out, exact=exact)
         return y, (y if keep_raw else None), None, None, None, None, False
     if isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None):
         scale, bias = _folded_bn(norm, plan)
         if keep_raw:
             raw = layer(x, None, None, None, 0, None, exact=exact)
-            return ops.affine_act(raw, scale, bias, residual, flags, out=out), raw, scale, bias, None, None, False
+            return ops.affine_act(raw, scale, bias, residual, flags, out=out, amax=am), raw, scale, bias, None, None, False
         return layer(x, scale, bias, residual, flags, out, exact=exact), None, scale, bias, None, None, False
     # statistics of the conv output are needed first: conv -> stats -> normalise (+res, +act)
     if isinstance(norm, nn.BatchNorm3d) and not exact:
@@ -180,17 +190,17 @@ def _norm_forward(layer, norm, plan, x, residual, flags, out, keep_raw, exact=Fa
             _ROUTES["conv_stats_epilogue"] += 1
             _bn_track(norm, mean, var, raw.numel() / raw.size(1))
             dst = out if out is not None else (None if keep_raw else raw)
-            return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst), raw, scale, shift, mean, var, False
+            return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst, amax=am), raw, scale, shift, mean, var, False
     raw = layer(x, None, None, None, 0, None, exact=exact)
     c = raw.size(1)
     dst = out if out is not None else (None if keep_raw else raw)
     if isinstance(norm, nn.GroupNorm):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
-        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=dst), raw, scale, shift, mean, var, True
+        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=dst, amax=am), raw, scale, shift, mean, var, True
     if isinstance(norm, nn.BatchNorm3d):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, c, False, norm.eps)
         _bn_track(norm, mean, var, raw.numel() / c)      # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
-        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst), raw, scale, shift, mean, var, False
+        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst, amax=am), raw, scale, shift, mean, var, False
     raise NotImplementedError(f"norm layer {type(norm).__name__} is not on the path")
 
 
@@ -274,6 +284,7 @@ class _ConvNormActFn(torch.autograd.Function):
         y, raw, scale, shift, mean, var, per_sample = _norm_forward(layer, norm, plan, x, residual, flags, None, True,
                                                                     exact=layer.ksize >= 5 and TRAIN_EXACT_K57[0])
         ctx.conv, ctx.norm, ctx.flags, ctx.plan, ctx.per_sample = conv, norm, flags, plan, per_sample
+        ctx.x_amax = ops.amax_of(x)          # max|x| left by the pass that wrote x (None: the weight gradient finds it itself)
         ctx.has_res = residual is not None
         ctx.train_stats = mean is not None
         res_saved = residual if (residual is not None and (flags & EPI_ADD_PRE)) else None
@@ -286,8 +297,11 @@ class _ConvNormActFn(torch.autograd.Function):
         x, raw, scale, shift, mean, var, res = ctx.saved_tensors
         conv, norm, flags, plan = ctx.conv, ctx.norm, ctx.flags, ctx.plan
         needs = ctx.needs_input_grad
+        g_amax = ops.amax_word(raw.device) if (needs[1] and raw.is_cuda) else None
         draw, gres, dg, db = _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, ctx.per_sample, ctx.train_stats,
-                                                ctx.has_res and needs[4], needs[2], needs[3])
+                                                ctx.has_res and needs[4], needs[2], needs[3], amax_out=g_amax)
+        if draw is gy:                       # no epilogue pass ran: nothing wrote the word
+            g_amax = None
         # data and weight gradients
         k, st, p, d, transposed = _conv_geometry(conv)
         dl = _dgrad_layer(conv, plan)
@@ -319,11 +333,12 @@ class _ConvNormActFn(torch.autograd.Function):
             elif odd:
                 gw = ops.conv3d_wgrad(F.pad(x, (0, x.size(4) % 2, 0, x.size(3) % 2, 0, x.size(2) % 2)), draw, k, st, p, d)
             else:
-                gw = ops.conv3d_wgrad(x, draw, k, st, p, d)
+                gw = ops.conv3d_wgrad(x, draw, k, st, p, d, amax_x=ctx.x_amax, amax_g=g_amax)
         return gx, gw, dg, db, gres, None, None, None, None, None
 
 
-def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_sample, train_stats, want_res, want_gamma, want_beta):
+def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_sample, train_stats, want_res, want_gamma, want_beta,
+                       amax_out=None):
     """Backward of  y = act(norm(raw) [+ res]) [+ res]  given gy: returns (draw, gres, dgamma, dbeta) on the HIP
     reduction / apply kernels (BatchNorm / GroupNorm backward coefficients in fp64)."""
     gy = gy.contiguous()
@@ -363,7 +378,7 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
                     dgamma = dbeta = None
                 want_g = want_res and bool(flags & EPI_ADD_PRE)
                 draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
-                                                     per_sample, want_g)
+                                                     per_sample, want_g, amax=amax_out)
                 gres = (g_out if (flags & EPI_ADD_PRE) else gy) if want_res else None
                 return draw, gres, (dgamma if want_gamma else None), (dbeta if want_beta else None)
             sg, sgr = sums[..., 0].sum(0), sums[..., 1].sum(0)                    # [c]
@@ -389,7 +404,7 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
         draw, g_out = gy, gy
     else:
         draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
-                                             per_sample, want_g)
+                                             per_sample, want_g, amax=amax_out)
     gres = None
     if want_res:
         gres = g_out if (flags & EPI_ADD_PRE) else gy

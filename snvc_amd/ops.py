@@ -775,10 +775,13 @@ def release_workspaces() -> None:
     _WORKSPACES.clear()
 
 
-def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: int) -> torch.Tensor:
+def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: int, amax_x: Optional[torch.Tensor] = None,
+                 amax_g: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW[cg][cx][k^3] = sum over batch and voxels of g_small[cg] * x_big[cx] (shifted by the tap):
     weight gradient of Conv3d(x_big -> g_small's shape); see snvc_conv3d_wgrad for the
-    ConvTranspose3d usage (roles swapped).  Deterministic."""
+    ConvTranspose3d usage (roles swapped).  Deterministic.  ``amax_x`` / ``amax_g``: int32 words holding the bit pattern of
+    max|x_big| / max|g_small| (amax_word, filled by the pass that wrote the tensor): the split-operand form (3x3x3, stride 1) then
+    skips its own reduction over that tensor."""
     _gpu(x_big, "x"); _gpu(g_small, "g")
     if not _dense_inner(x_big):
         x_big = x_big.contiguous()
@@ -795,8 +798,8 @@ def conv3d_wgrad(x_big, g_small, ksize: int, stride: int, pad: int, dilation: in
     ws = _workspace(_lib.lib().snvc_conv3d_wgrad_workspace_bytes(ctypes.byref(d)), x_big.device)
     dw = torch.empty((d.Cout, d.Cin, ksize, ksize, ksize), dtype=torch.float32, device=x_big.device)
     with torch.cuda.device(x_big.device):
-        check(_lib.lib().snvc_conv3d_wgrad(ctypes.byref(d), _ptr(x_big), _ptr(g_small), _ptr(dw), _ptr(ws),
-                                           _stream(x_big)), "snvc_conv3d_wgrad")
+        check(_lib.lib().snvc_conv3d_wgrad_amax(ctypes.byref(d), _ptr(x_big), _ptr(g_small), _ptr(dw), _ptr(ws), _ptr(amax_x),
+                                                _ptr(amax_g), _stream(x_big)), "snvc_conv3d_wgrad")
     return dw
 
 
@@ -828,19 +831,41 @@ def act_backward_reduce(raw, gy, residual, scale, shift, flags: int, per_sample:
     return sums
 
 
+def amax_word(device) -> torch.Tensor:
+    """A zeroed 4-byte device word for the bit pattern of a tensor's max|.| (snvc_*_amax entry points)."""
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def tag_amax(t: torch.Tensor, amax: Optional[torch.Tensor]) -> torch.Tensor:
+    """Remember the word that holds max|t| on the tensor object itself: the layer that consumes ``t`` hands it to its weight gradient
+    (split-operand form) instead of reading the whole tensor again.  Purely an optimisation: a tensor without the tag works."""
+    if amax is not None:
+        t.snvc_amax_tag = (amax, t._version)
+    return t
+
+
+def amax_of(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """The tagged word, if the tensor has not been written to since it was tagged (an in-place update bumps ``_version``)."""
+    tag = getattr(t, "snvc_amax_tag", None)
+    if tag is None or tag[1] != t._version or tag[0].device != t.device:
+        return None
+    return tag[0]
+
+
 def act_backward_apply(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const, flags: int, per_sample: bool,
-                       want_g: bool):
-    """draw = coef_g*g + coef_raw*raw + coef_const (per channel or per (n,c)); optionally also g."""
+                       want_g: bool, amax: Optional[torch.Tensor] = None):
+    """draw = coef_g*g + coef_raw*raw + coef_const (per channel or per (n,c)); optionally also g.  ``amax``: a zeroed int32 word
+    that receives the bit pattern of max|draw| (amax_word)."""
     n, c = raw.shape[0], raw.shape[1]
     s = raw[0, 0].numel()
     draw = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
     g_out = torch.empty(raw.shape, dtype=torch.float32, device=raw.device) if want_g else None
     with torch.cuda.device(raw.device):
-        check(_lib.lib().snvc_act_backward_apply(_ptr(raw), _ptr(gy), _ptr(residual), _ptr(scale), _ptr(shift),
-                                                 _ptr(coef_g), _ptr(coef_raw), _ptr(coef_const), _ptr(draw), _ptr(g_out),
-                                                 n, c, s, _batch_stride(raw), _batch_stride(gy),
-                                                 _batch_stride(residual) if residual is not None else 0,
-                                                 1 if per_sample else 0, flags, _stream(raw)), "snvc_act_backward_apply")
+        check(_lib.lib().snvc_act_backward_apply_amax(_ptr(raw), _ptr(gy), _ptr(residual), _ptr(scale), _ptr(shift),
+                                                      _ptr(coef_g), _ptr(coef_raw), _ptr(coef_const), _ptr(draw), _ptr(g_out),
+                                                      n, c, s, _batch_stride(raw), _batch_stride(gy),
+                                                      _batch_stride(residual) if residual is not None else 0,
+                                                      1 if per_sample else 0, flags, _ptr(amax), _stream(raw)), "snvc_act_backward_apply")
     return draw, g_out
 
 
@@ -865,7 +890,8 @@ def norm_stats(x, gamma, beta, groups: int, per_sample: bool, eps: float):
     return scale, shift, mean, var
 
 
-def affine_act(x, scale, shift, residual=None, flags=0, per_sample=False, out=None):
+def affine_act(x, scale, shift, residual=None, flags=0, per_sample=False, out=None, amax: Optional[torch.Tensor] = None):
+    """``amax``: a zeroed int32 word that receives the bit pattern of max|out| (amax_word)."""
     _gpu(x, "x")
     if not _dense_inner(x):
         x = x.contiguous()
@@ -880,10 +906,10 @@ def affine_act(x, scale, shift, residual=None, flags=0, per_sample=False, out=No
     if x.numel() == 0:
         return out
     with torch.cuda.device(x.device):
-        check(_lib.lib().snvc_affine_act(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, c, s,
-                                         _batch_stride(x), _batch_stride(out),
-                                         _batch_stride(residual) if residual is not None else 0,
-                                         1 if per_sample else 0, flags, _stream(x)), "snvc_affine_act")
+        check(_lib.lib().snvc_affine_act_amax(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, c, s,
+                                              _batch_stride(x), _batch_stride(out),
+                                              _batch_stride(residual) if residual is not None else 0,
+                                              1 if per_sample else 0, flags, _ptr(amax), _stream(x)), "snvc_affine_act")
     return out
 
 

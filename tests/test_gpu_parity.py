@@ -69,7 +69,7 @@ def seeded(mod, seed):
 def test_library_loads_and_reports_errors():
     from snvc_amd import _lib
     L = _lib.lib()
-    assert L.snvc_abi_version() == 4
+    assert L.snvc_abi_version() == 5
     rc = L.snvc_cost_volume_forward(None, None, None, None, 1, 1, 3, 4, 1, 2, 0, None)
     assert rc == 1 and b"multiples of downsample" in L.snvc_last_error_string()
 
@@ -735,10 +735,11 @@ _WGRAD_CASES = {
 }
 
 
-@pytest.mark.parametrize("variant", ["auto", "direct"])
+@pytest.mark.parametrize("variant", ["auto", "fp32", "direct"])
 @pytest.mark.parametrize("case", sorted(_WGRAD_CASES))
 def test_conv3d_wgrad_vs_float64(case, variant):
-    """snvc_conv3d_wgrad against the float64 weight gradient of F.conv3d on the CPU: the Winograd-domain form (auto, on
+    """snvc_conv3d_wgrad against the float64 weight gradient of F.conv3d on the CPU: the default form (r6: 3x3x3 / stride 1 on
+    16-byte rows = the split-operand f16x3 form; else the fp32 forms), the fp32 forms (ALGO_WGRAD_FP32: the Winograd-domain one on
     16-byte rows) and the direct form, on shapes that give a partition several tiles, none, and border tiles."""
     import torch.nn.functional as F
     from snvc_amd import _lib, ops
@@ -749,11 +750,11 @@ def test_conv3d_wgrad_vs_float64(case, variant):
     y = F.conv3d(x.double(), w, stride=st, padding=k // 2)
     g = torch.from_numpy(r.standard_normal(tuple(y.shape)).astype(np.float32))
     (y * g.double()).sum().backward()
-    with ops.conv_variant(0 if variant == "auto" else _lib.ALGO_DIRECT):
+    with ops.conv_variant({"auto": 0, "fp32": _lib.ALGO_WGRAD_FP32, "direct": _lib.ALGO_DIRECT}[variant]):
         dw = ops.conv3d_wgrad(x.to(dev()), g.to(dev()), k, st, k // 2, 1)
         dw2 = ops.conv3d_wgrad(x.to(dev()), g.to(dev()), k, st, k // 2, 1)
     assert torch.equal(dw, dw2), "the weight gradient is deterministic"
-    check(dw.cpu().numpy(), w.grad.float().numpy(), 2e-5 if variant == "auto" else 5e-6, f"wgrad {case} ({variant})")
+    check(dw.cpu().numpy(), w.grad.float().numpy(), 5e-6 if variant == "direct" else 2e-5, f"wgrad {case} ({variant})")
 
 
 @pytest.mark.parametrize("case", ["k3_bn_train", "k3_bn_eval", "k3s2_bn_train", "k3s2_odd_bn_train", "k3s2_odd_w_bn_eval", "deconv_bn_train",

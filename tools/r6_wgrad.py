@@ -1,0 +1,45 @@
+"""r6: the split-operand weight gradient (conv3d_wgrad_x3_kernel) against float64 and against the fp32 forms; timing at cfg2 sizes."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.nn.functional as F
+from snvc_amd import _lib, ops
+import bench
+dev = torch.device("cuda:0")
+
+def ref64(x, g, k=3):
+    w = torch.zeros(g.shape[1], x.shape[1], k, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x.double(), w, padding=k // 2)
+    (y * g.double()).sum().backward()
+    return w.grad
+
+cases = {"many tiles": (1, 32, 32, (10, 40, 96)), "ragged": (2, 40, 24, (5, 10, 44)), "one tile": (1, 32, 64, (2, 4, 32)),
+         "64x64": (1, 64, 64, (9, 12, 64)), "deep": (1, 32, 32, (40, 8, 32)), "tiny grads": (1, 32, 32, (6, 8, 64))}
+for name, (N, ci, co, shp) in cases.items():
+    r = np.random.default_rng(5)
+    x = torch.from_numpy(r.standard_normal((N, ci) + shp).astype(np.float32))
+    g = torch.from_numpy(r.standard_normal((N, co) + shp).astype(np.float32))
+    if name == "tiny grads":
+        g = g * 1e-9
+        x = x * 3e4
+    exp = ref64(x, g)
+    with ops.conv_variant(0):
+        a = ops.conv3d_wgrad(x.to(dev), g.to(dev), 3, 1, 1, 1)
+        a2 = ops.conv3d_wgrad(x.to(dev), g.to(dev), 3, 1, 1, 1)
+    with ops.conv_variant(_lib.ALGO_WGRAD_FP32):
+        b = ops.conv3d_wgrad(x.to(dev), g.to(dev), 3, 1, 1, 1)
+    ea = ((a.cpu().double() - exp).abs().max() / exp.abs().max()).item()
+    eb = ((b.cpu().double() - exp).abs().max() / exp.abs().max()).item()
+    print(f"{name:12s} x3 err {ea:.2e}  fp32 err {eb:.2e}  deterministic {torch.equal(a, a2)}  differs {not torch.equal(a, b)}", flush=True)
+
+if "time" in sys.argv:
+    for (ci, co, shp) in ((32, 32, (192, 96, 312)), (64, 64, (96, 48, 156)), (64, 64, (48, 24, 78))):
+        x = torch.relu(torch.randn(1, ci, *shp, device=dev)); g = torch.randn(1, co, *shp, device=dev) * 1e-4
+        for tag, bits in (("x3", 0), ("fp32", _lib.ALGO_WGRAD_FP32)):
+            with ops.conv_variant(bits):
+                ms, dw = bench.timed_ms(lambda: ops.conv3d_wgrad(x, g, 3, 1, 1, 1), 10, 3)
+            print(ci, co, shp, tag, round(ms, 3), "ms", flush=True)
+        with ops.conv_variant(0):
+            a = ops.conv3d_wgrad(x, g, 3, 1, 1, 1)
+        with ops.conv_variant(_lib.ALGO_WGRAD_FP32):
+            b = ops.conv3d_wgrad(x, g, 3, 1, 1, 1)
+        print("   x3 vs fp32 rel diff", ((a - b).abs().max() / b.abs().max()).item())
