@@ -282,7 +282,9 @@ SNVC_API int snvc_affine_act(const float *x, const float *scale, const float *sh
                              const float *residual, float *y, int64_t N, int64_t C, int64_t S,
                              int64_t x_batch_stride, int64_t y_batch_stride,
                              int64_t res_batch_stride, int per_sample, int flags, void *stream);
-/* r6: the same pass; additionally atomicMax-es the bit pattern of max|y| into *amax (a zeroed 4-byte device word; may be NULL): the
+#define SNVC_AMAX_SLOTS 64
+/* r6: the same pass; additionally atomicMax-es the bit pattern of max|y| into amax[0 .. SNVC_AMAX_SLOTS) (zeroed device words, a workgroup
+ * picks one slot -- same-address atomics serialise; the maximum over the slots is the tensor's; may be NULL): the
  * split-operand weight gradient (snvc_conv3d_wgrad_amax) scales its operands by their maxima, and the pass that writes a tensor gets
  * its maximum for free where a separate reduction costs a read of the whole tensor. */
 SNVC_API int snvc_affine_act_amax(const float *x, const float *scale, const float *shift,
@@ -440,7 +442,8 @@ SNVC_API int snvc_sheared_upsample_backward(const float *drq, float *dright, int
 SNVC_API int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *desc_host);
 SNVC_API int snvc_conv3d_wgrad(const snvc_conv3d_desc *desc_host, const float *x, const float *g, float *dw,
                                void *workspace, void *stream);
-/* r6: snvc_conv3d_wgrad with the operands' maxima supplied: amax_x / amax_g point at the bit pattern of max|x| / max|g| (device words,
+/* r6: snvc_conv3d_wgrad with the operands' maxima supplied: amax_x / amax_g point at SNVC_AMAX_SLOTS device words whose maximum is the
+ * bit pattern of max|x| / max|g| (
  * e.g. written by snvc_affine_act_amax / snvc_act_backward_apply_amax when the tensors were produced); either may be NULL, the
  * split-operand form then finds that maximum itself with one more pass over the tensor (0.2 ms per 736 MB).  A supplied value must
  * be >= the true maximum (a larger one only costs precision: 2^k too large = k of the 39 bits below the maximum); the fp32

@@ -911,8 +911,20 @@ struct X3WgArgs {
     const unsigned *amax_x, *amax_g;       // bits of max|x|, max|g| (or of upper bounds)
     int N, Cx, Cg, D, H, W;
     int cx_blocks, pairs, hblocks, wsegs, dparts, dchunk, njobs;
+    int pairs32;                // stride-2 form: 32 x 32 channel pairs of the slab layout (its jobs take 64 g channels)
     int64_t x_bs, g_bs;
 };
+
+// the maximum of the SNVC_AMAX_SLOTS words a producer pass left (snvc_affine_act_amax ...): every lane reads one, the wave reduces
+__device__ __forceinline__ unsigned x3wg_amax(const unsigned *__restrict__ p) {
+    unsigned m = p[threadIdx.x & (SNVC_AMAX_SLOTS - 1)];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off);
+        m = m > o ? m : o;
+    }
+    return m;
+}
 
 // power of two s with max * s in [2^13, 2^14) (half: 65504); 1 for an all-zero or non-finite tensor
 __device__ __forceinline__ float x3wg_scale(unsigned bits) {
@@ -957,7 +969,7 @@ wgrad_amax2_kernel(const float *__restrict__ x, const float *__restrict__ g, uns
         const unsigned o = (unsigned)__shfl_xor((int)m, off);
         m = m > o ? m : o;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out + which, m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out + which * SNVC_AMAX_SLOTS + (blockIdx.x & (SNVC_AMAX_SLOTS - 1)), m);
 }
 
 __global__ void __launch_bounds__(512, 1)
@@ -983,7 +995,7 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
     const int cg0 = cgb * 32, cx0 = cxb * 32;
     const int h0 = hb * Cfg::TH, w0 = ws * 32;
     const int d0 = dp * a.dchunk, d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
-    const float sx = x3wg_scale(*a.amax_x), sg = x3wg_scale(*a.amax_g);
+    const float sx = x3wg_scale(x3wg_amax(a.amax_x)), sg = x3wg_scale(x3wg_amax(a.amax_g));
     const int64_t hw = (int64_t)a.H * a.W, dhw = hw * a.D;
 
     // staging tables (plane-invariant): element offset inside a plane of the sample, LDS position (in halves), validity
@@ -1133,9 +1145,210 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
     for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(pp + t * 1024) = acc[t];
 }
 
+// ---- the same for 3x3x3 / stride-2 / pad-1 layers (and, roles swapped, the transposed layers): g on the small grid, x on the big one.
+//   dW[kw] = sum_u g[u - (kw == 0)  + 1 ... ]: with the input row de-interleaved into its even and odd columns E[c] = x[2c], O[c] = x[2c+1]
+//   kw = 1 -> E[u] * g[u],   kw = 2 -> O[u] * g[u],   kw = 0 -> x[2 ow - 1] * g[ow] = O[u] * g[u + 1]   (u = ow - 1)
+// so every x operand is an aligned piece of E or O and only g needs one shifted copy.  A stride-2 layer has an eighth of the
+// stride-1 layer's products per input byte: at f16 rates it is bound by the input stream, and the tile is chosen for that -- a
+// workgroup owns 2 x 32 gradient voxels per plane step (5 input rows x 64 input columns x 32 channels per input plane, two new
+// input planes per step into a ring of three), all 64 gradient channels: wave = (16-channel half of x) x (16-channel quarter of g),
+// 27 accumulators of 16 x 16.  Partial slabs in the direct kernels' layout, one per column.
+struct X3S2WgCfg {
+    static constexpr int TH = 2, XR = 2 * TH + 1, THREADS = 512;
+    static constexpr int XCOLS = 64;                         // halves per staged x row: E (32) then O (32), 16-byte chunks swizzled
+    static constexpr int XPLANE = XR * 32 * XCOLS;
+    static constexpr int SLOT_BYTES = 2 * XPLANE * 2;        // hi | lo = 40960
+    static constexpr int GCOLS = 48, GCH = 64;
+    static constexpr int GPLANE = TH * GCH * GCOLS;
+    static constexpr int G_BYTES = 2 * GPLANE * 2;           // 24576
+    static constexpr int LDS_BYTES = 3 * SLOT_BYTES + G_BYTES;      // 147456
+    static constexpr int XPIECES = XR * 32 * 16, XNIT = XPIECES / THREADS;                       // float4 pieces of an input plane: 2560 = 5 rounds
+    static constexpr int GPIECES = TH * GCH * 10, GNIT = (GPIECES + THREADS - 1) / THREADS;      // 1280 -> 3 rounds
+    static_assert(XPIECES % THREADS == 0, "whole rounds");
+};
+
+__global__ void __launch_bounds__(512, 1)
+conv3d_wgrad_x3s2_kernel(const X3WgArgs a) {      // a.D / H / W: the SMALL grid (g); x lives on 2D x 2H x 2W
+    using Cfg = X3S2WgCfg;
+    constexpr int XNIT = Cfg::XNIT, GNIT = Cfg::GNIT, XCOLS = Cfg::XCOLS, GCOLS = Cfg::GCOLS;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    char *const lds = reinterpret_cast<char *>(lds_f);
+    char *const gbase = lds + 3 * Cfg::SLOT_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cih = wave & 1, coq = wave >> 1;             // x channels 16 cih .. +15, g channels 16 coq .. +15 of the job's 64
+    const int i16 = lane & 15, kg = lane >> 4;
+    const int q8 = a.njobs >> 3, r8 = a.njobs & 7, xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+    const int job = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kx;
+    if (kx >= q8 + (xcd < r8 ? 1 : 0)) return;
+    // pairs here = (64-channel blocks of g) x (32-channel blocks of x)
+    const int pair = job % a.pairs, col = job / a.pairs;
+    const int ws = col % a.wsegs, hb = (col / a.wsegs) % a.hblocks, dp = (col / (a.wsegs * a.hblocks)) % a.dparts;
+    const int64_t n = col / (a.wsegs * a.hblocks * a.dparts);
+    const int cg64 = pair / a.cx_blocks, cxb = pair - cg64 * a.cx_blocks;
+    const int cg0 = cg64 * 64, cx0 = cxb * 32;
+    const int h0 = hb * Cfg::TH, w0 = ws * 32;             // small grid
+    const int d0 = dp * a.dchunk, d1 = d0 + a.dchunk < a.D ? d0 + a.dchunk : a.D;
+    const float sx = x3wg_scale(x3wg_amax(a.amax_x)), sg = x3wg_scale(x3wg_amax(a.amax_g));
+    const int Hi = 2 * a.H, Wi = 2 * a.W, Di = 2 * a.D;
+    const int64_t ghw = (int64_t)a.H * a.W, gdhw = ghw * a.D;
+    const int64_t xhw = (int64_t)Hi * Wi, xdhw = xhw * Di;
+
+    unsigned xoff[XNIT], goff[GNIT];
+    int xdst[XNIT], gdst[GNIT];
+    unsigned xok = 0, gok = 0;
+#pragma unroll
+    for (int it = 0; it < XNIT; ++it) {
+        const int p = it * Cfg::THREADS + tid;
+        const int ci = p / 80, rem = p - ci * 80, r = rem >> 4, q = rem & 15;       // 5 rows x 16 float4
+        const int h = 2 * h0 - 1 + r, w = 2 * w0 + 4 * q;
+        const bool ok = cx0 + ci < a.Cx && (unsigned)h < (unsigned)Hi && w + 4 <= Wi;
+        xoff[it] = ok ? (unsigned)(ci * xdhw + (int64_t)h * Wi + w) : 0u;
+        // the float4 holds E[2q], O[2q], E[2q+1], O[2q+1]: halves 2 (q & 3) .. +1 of E chunk q >> 2 and of O chunk 4 + (q >> 2); chunk c of
+        // the row sits at position c ^ ((ci >> 1) & 7): conflict-free ds_read_b128 at the 128-byte row stride
+        const int sw = (ci >> 1) & 7;
+        xdst[it] = (r * 32 + ci) * XCOLS + (((q >> 2) ^ sw) * 8) + 2 * (q & 3);    // E position; O: chunk + 4 -> position ^ 4 (see store_x)
+        xok |= (ok ? 1u : 0u) << it;
+    }
+#pragma unroll
+    for (int it = 0; it < GNIT; ++it) {
+        const int p = it * Cfg::THREADS + tid;
+        const int co = p / 20, rem = p - co * 20, r = rem / 10, q = rem - r * 10;
+        const int h = h0 + r, w = w0 - 4 + 4 * q;
+        const bool in = p < Cfg::GPIECES;
+        const bool ok = in && cg0 + co < a.Cg && h < a.H && w >= 0 && w + 4 <= a.W;
+        goff[it] = ok ? (unsigned)(co * gdhw + (int64_t)h * a.W + w) : 0u;
+        gdst[it] = in ? (r * Cfg::GCH + co) * GCOLS + 4 + 4 * q : -1;
+        gok |= (ok ? 1u : 0u) << it;
+    }
+    const float *const xs = a.x + n * a.x_bs + (int64_t)cx0 * xdhw;
+    const float *const gs = a.g + n * a.g_bs + (int64_t)cg0 * gdhw;
+    f32x4 xv[2][XNIT], gv[GNIT];
+    bool x_dok[2] = {false, false}, g_dok = false;
+    auto load_x = [&](int k, int id) {         // input plane id -> register set k (unconditional loads: see conv3d_wgrad_x3_kernel)
+        x_dok[k] = (unsigned)id < (unsigned)Di;
+        const float *b = xs + (int64_t)(x_dok[k] ? id : 0) * xhw;
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it) xv[k][it] = *reinterpret_cast<const f32x4 *>(b + xoff[it]);
+    };
+    auto load_g = [&](int od) {
+        g_dok = od < a.D;
+        const float *b = gs + (int64_t)(g_dok ? od : 0) * ghw;
+#pragma unroll
+        for (int it = 0; it < GNIT; ++it) gv[it] = *reinterpret_cast<const f32x4 *>(b + goff[it]);
+    };
+    typedef _Float16 h2w __attribute__((ext_vector_type(2)));
+    auto store_x = [&](int k, int id) {        // plane id lives in slot (id + 3) % 3
+        char *b = lds + ((id + 3) % 3) * Cfg::SLOT_BYTES;
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it) {
+            const f32x4 v = (x_dok[k] && ((xok >> it) & 1u)) ? xv[k][it] : f32x4(0.0f);
+            const f32x4 t = v * sx;
+            const h4w hi = __builtin_convertvector(t, h4w);
+            const f32x4 back = __builtin_convertvector(hi, f32x4);
+            const h4w lo = __builtin_convertvector(t - back, h4w);
+            char *e = b + 2 * xdst[it];
+            char *o = b + 2 * (xdst[it] ^ 32);                 // position ^ 4 in units of 8 halves
+            *reinterpret_cast<h2w *>(e) = h2w{hi[0], hi[2]};
+            *reinterpret_cast<h2w *>(o) = h2w{hi[1], hi[3]};
+            *reinterpret_cast<h2w *>(e + 2 * Cfg::XPLANE) = h2w{lo[0], lo[2]};
+            *reinterpret_cast<h2w *>(o + 2 * Cfg::XPLANE) = h2w{lo[1], lo[3]};
+        }
+    };
+    auto store_g = [&]() {
+#pragma unroll
+        for (int it = 0; it < GNIT; ++it) {
+            if (gdst[it] < 0) continue;
+            const f32x4 v = (g_dok && ((gok >> it) & 1u)) ? gv[it] : f32x4(0.0f);
+            const f32x4 t = v * sg;
+            const h4w hi = __builtin_convertvector(t, h4w);
+            const f32x4 back = __builtin_convertvector(hi, f32x4);
+            const h4w lo = __builtin_convertvector(t - back, h4w);
+            *reinterpret_cast<h4w *>(gbase + 2 * gdst[it]) = hi;
+            *reinterpret_cast<h4w *>(gbase + 2 * (Cfg::GPLANE + gdst[it])) = lo;
+        }
+    };
+
+    f32x4 acc[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) acc[t] = f32x4(0.0f);
+
+    // prologue: input planes 2 d0 - 1, 2 d0, 2 d0 + 1 and gradient plane d0 into LDS
+    load_x(0, 2 * d0 - 1);
+    store_x(0, 2 * d0 - 1);
+    load_x(0, 2 * d0);
+    load_x(1, 2 * d0 + 1);
+    store_x(0, 2 * d0);
+    store_x(1, 2 * d0 + 1);
+    load_g(d0);
+    store_g();
+    __syncthreads();
+
+    const int sw = (i16 >> 1) & 7;
+    const int xlaneE = ((cih * 16 + i16) * XCOLS + ((kg ^ sw) * 8)) * 2, xlaneO = ((cih * 16 + i16) * XCOLS + (((4 + kg) ^ sw) * 8)) * 2;
+    const int glane = ((coq * 16 + i16) * GCOLS + 8 + 8 * kg) * 2;
+    for (int od = d0; od < d1; ++od) {
+        const bool more = od + 1 < d1;
+        if (more) {                          // the next step's two new input planes and its gradient plane travel under this step's MFMAs
+            load_x(0, 2 * od + 2);
+            load_x(1, 2 * od + 3);
+            load_g(od + 1);
+        }
+        const int s0 = (2 * od - 1 + 3) % 3;     // slot of input plane 2 od - 1 (kd = 0)
+#pragma unroll 1
+        for (int r = 0; r < Cfg::TH; ++r) {
+            u32x4w gb[2][2];                 // [hi | lo][g[u] | g[u + 1]]
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const char *q = gbase + (r * Cfg::GCH * GCOLS + pl * Cfg::GPLANE) * 2 + glane;
+                const u32x4w b = *reinterpret_cast<const u32x4w *>(q);
+                const unsigned right = *reinterpret_cast<const unsigned *>(q + 16);
+                gb[pl][0] = b;
+                gb[pl][1] = u32x4w{__builtin_amdgcn_alignbit(b[1], b[0], 16), __builtin_amdgcn_alignbit(b[2], b[1], 16),
+                                   __builtin_amdgcn_alignbit(b[3], b[2], 16), __builtin_amdgcn_alignbit(right, b[3], 16)};
+            }
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                int slot = s0 + kd;
+                slot = slot >= 3 ? slot - 3 : slot;
+                const char *sb = lds + slot * Cfg::SLOT_BYTES;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const char *xp = sb + (2 * r + kh) * 32 * XCOLS * 2;
+                    const h8w eh = *reinterpret_cast<const h8w *>(xp + xlaneE), el = *reinterpret_cast<const h8w *>(xp + xlaneE + 2 * Cfg::XPLANE);
+                    const h8w oh = *reinterpret_cast<const h8w *>(xp + xlaneO), ol = *reinterpret_cast<const h8w *>(xp + xlaneO + 2 * Cfg::XPLANE);
+#pragma unroll
+                    for (int pr = 0; pr < 3; ++pr)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int t = (kd * 3 + kh) * 3 + kw;
+                            const h8w av = kw == 1 ? (pr == 2 ? el : eh) : (pr == 2 ? ol : oh);
+                            const h8w bv = __builtin_bit_cast(h8w, gb[pr == 1 ? 1 : 0][kw == 0 ? 1 : 0]);
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[t], 0, 0, 0);
+                        }
+                }
+            }
+        }
+        __syncthreads();                     // every read of planes 2 od - 1, 2 od and of the gradient plane is done
+        if (more) {
+            store_x(0, 2 * od + 2);          // into the slot of plane 2 od - 1
+            store_x(1, 2 * od + 3);          // into the slot of plane 2 od
+            store_g();
+        }
+        __syncthreads();
+    }
+    // ---- partial slab [col][pair32][tap][cg 32][cx 32] with pair32 = (2 cg64 + (coq >> 1)) * cx_blocks + cxb
+    const int cgb32 = 2 * cg64 + (coq >> 1);
+    if (cgb32 * a.cx_blocks >= a.pairs32) return;            // a 64-channel job over a layer with an odd number of 32-channel blocks
+    const int pair32 = cgb32 * a.cx_blocks + cxb;
+    float *pp = a.partial + (((int64_t)col * a.pairs32 + pair32) * 27) * 1024 + ((coq & 1) * 16 + i16) * 32 + cih * 16 + 4 * kg;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) *reinterpret_cast<f32x4 *>(pp + t * 1024) = acc[t];
+}
+
 // wgrad_reduce_kernel for the split-operand form: the same fixed-order sum, then the two power-of-two scales are taken out (exact)
 __global__ void wgrad_reduce_x3_kernel(const float *__restrict__ partial, float *__restrict__ dw, int Cg, int Cx, int cx_blocks, int pairs,
                                        int P, const unsigned *__restrict__ amax_x, const unsigned *__restrict__ amax_g) {
+    const unsigned ax = x3wg_amax(amax_x), ag = x3wg_amax(amax_g);        // (before any lane leaves: wave shuffles)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t pstride = (int64_t)pairs * 27 * 1024;
     if (i >= pstride) return;
@@ -1154,7 +1367,7 @@ __global__ void wgrad_reduce_x3_kernel(const float *__restrict__ partial, float 
         s3 += src[(int64_t)(p + 3) * pstride];
     }
     for (; p < P; ++p) s0 += src[(int64_t)p * pstride];
-    const float inv_x = 1.0f / x3wg_scale(*amax_x), inv_g = 1.0f / x3wg_scale(*amax_g);
+    const float inv_x = 1.0f / x3wg_scale(ax), inv_g = 1.0f / x3wg_scale(ag);
     dw[((int64_t)cg * Cx + cx) * 27 + tap] = (((s0 + s1) + (s2 + s3)) * inv_x) * inv_g;
 }
 
@@ -1195,7 +1408,7 @@ int64_t snvc_conv3d_wgrad_workspace_bytes(const snvc_conv3d_desc *d) {
             if ((int64_t)4 * P * 27 > slabs) slabs = (int64_t)4 * P * 27;
         }
     }
-    return slabs * pairs * 1024 * (int64_t)sizeof(float) + 256;     // + the two amax words of the split-operand form (r6), at the end
+    return slabs * pairs * 1024 * (int64_t)sizeof(float) + 1024;     // + the two amax words of the split-operand form (r6), at the end
 }
 
 // desc describes the FORWARD Conv3d (x = its input on the big grid, g = gradient of its output on
@@ -1268,14 +1481,14 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
         X3WgArgs b;
         b.x = x; b.g = g; b.partial = (float *)workspace;
         b.N = d->N; b.Cx = d->Cin; b.Cg = d->Cout; b.D = d->Dout; b.H = d->Hout; b.W = d->Wout;
-        b.cx_blocks = a.cx_blocks; b.pairs = pairs; b.x_bs = a.x_bs; b.g_bs = a.g_bs;
+        b.cx_blocks = a.cx_blocks; b.pairs = pairs; b.pairs32 = pairs; b.x_bs = a.x_bs; b.g_bs = a.g_bs;
         b.hblocks = ceil_div(d->Hout, X3WgCfg::TH); b.wsegs = ceil_div(d->Wout, 32);
         const int64_t cols = (int64_t)d->N * b.hblocks * b.wsegs;
         // depth parts: enough jobs for every CU once, columns at least 8 planes long, at most 256 columns x parts (512 slabs, the
         // workspace's size)
         int dparts = 1;
         while (cols * dparts * pairs < device_cu_count() * 3 / 4 && d->Dout / (dparts * 2) >= 8 && cols * dparts * 2 <= 256) dparts *= 2;
-        const int64_t slabs_bytes = snvc_conv3d_wgrad_workspace_bytes(d) - 256;
+        const int64_t slabs_bytes = snvc_conv3d_wgrad_workspace_bytes(d) - 1024;
         if (cols * dparts <= 256 && cols * dparts * pairs < ((int64_t)1 << 24) &&
             (int64_t)2 * cols * dparts * pairs * 27 * 1024 * 4 <= slabs_bytes) {
             b.dparts = dparts; b.dchunk = ceil_div(d->Dout, dparts);
@@ -1283,9 +1496,9 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
             b.njobs = (int)(cols * b.dparts * pairs);
             unsigned *amax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + slabs_bytes);
             b.amax_x = amax_x ? amax_x : amax;
-            b.amax_g = amax_g ? amax_g : amax + 1;
+            b.amax_g = amax_g ? amax_g : amax + SNVC_AMAX_SLOTS;
             if (!amax_x || !amax_g) {        // a maximum the caller did not bring: one more pass over that tensor
-                if (hipMemsetAsync(amax, 0, 8, st) != hipSuccess) return fail(SNVC_ERR_HIP, "snvc_conv3d_wgrad: hipMemsetAsync failed");
+                if (hipMemsetAsync(amax, 0, 2 * SNVC_AMAX_SLOTS * 4, st) != hipSuccess) return fail(SNVC_ERR_HIP, "snvc_conv3d_wgrad: hipMemsetAsync failed");
                 const int64_t n4x = amax_x ? 0 : in_sz / 4, n4g = amax_g ? 0 : out_sz / 4;
                 const unsigned ab = (unsigned)std::min<int64_t>(ceil_div<int64_t>(std::max(n4x, n4g), 256 * 8), 4096);
                 wgrad_amax2_kernel<<<dim3(ab, 2, (unsigned)d->N), 256, 0, st>>>(x, g, amax, n4x, n4g, a.x_bs, a.g_bs);
@@ -1321,6 +1534,44 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
         wgrad_wino_reduce_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>((const float *)workspace, dw, d->Cout,
                                                                                                  d->Cin, a.cx_blocks, pairs, 2 * a.P);
         return check_launch("snvc_conv3d_wgrad(winograd reduce)");
+    }
+    if (key == 321 && a.vec == 4 && !(d->algo & SNVC_ALGO_WGRAD_FP32) && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT &&
+        d->Din == 2 * d->Dout && d->Hin == 2 * d->Hout && d->Win == 2 * d->Wout) {
+        // split-operand (f16x3) form of the stride-2 layers, see conv3d_wgrad_x3s2_kernel
+        X3WgArgs b;
+        b.x = x; b.g = g; b.partial = (float *)workspace;
+        b.N = d->N; b.Cx = d->Cin; b.Cg = d->Cout; b.D = d->Dout; b.H = d->Hout; b.W = d->Wout;
+        b.cx_blocks = a.cx_blocks; b.pairs32 = pairs; b.pairs = ceil_div(d->Cout, 64) * a.cx_blocks; b.x_bs = a.x_bs; b.g_bs = a.g_bs;
+        b.hblocks = ceil_div(d->Hout, X3S2WgCfg::TH); b.wsegs = ceil_div(d->Wout, 32);
+        const int64_t cols = (int64_t)d->N * b.hblocks * b.wsegs;
+        int dparts = 1;
+        while (cols * dparts * b.pairs < device_cu_count() * 3 / 4 && d->Dout / (dparts * 2) >= 8 && cols * dparts * 2 <= 512) dparts *= 2;
+        const int64_t slabs_bytes = snvc_conv3d_wgrad_workspace_bytes(d) - 1024;
+        if (cols * dparts <= 512 && cols * dparts * b.pairs < ((int64_t)1 << 24) &&
+            cols * dparts * pairs * 27 * 1024 * 4 <= slabs_bytes) {
+            b.dchunk = ceil_div(d->Dout, dparts);
+            b.dparts = ceil_div(d->Dout, b.dchunk);
+            b.njobs = (int)(cols * b.dparts * b.pairs);
+            unsigned *amax = reinterpret_cast<unsigned *>(static_cast<char *>(workspace) + slabs_bytes);
+            b.amax_x = amax_x ? amax_x : amax;
+            b.amax_g = amax_g ? amax_g : amax + SNVC_AMAX_SLOTS;
+            if (!amax_x || !amax_g) {
+                if (hipMemsetAsync(amax, 0, 2 * SNVC_AMAX_SLOTS * 4, st) != hipSuccess) return fail(SNVC_ERR_HIP, "snvc_conv3d_wgrad: hipMemsetAsync failed");
+                const int64_t n4x = amax_x ? 0 : in_sz / 4, n4g = amax_g ? 0 : out_sz / 4;
+                const unsigned ab = (unsigned)std::min<int64_t>(ceil_div<int64_t>(std::max(n4x, n4g), 256 * 8), 4096);
+                wgrad_amax2_kernel<<<dim3(ab, 2, (unsigned)d->N), 256, 0, st>>>(x, g, amax, n4x, n4g, a.x_bs, a.g_bs);
+            }
+            static std::atomic<unsigned> attr_x3s2{0};
+            const unsigned nwg = (unsigned)(8 * ceil_div(b.njobs, 8));
+            if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3s2_kernel), X3S2WgCfg::LDS_BYTES, attr_x3s2))
+                conv3d_wgrad_x3s2_kernel<<<dim3(nwg), X3S2WgCfg::THREADS, X3S2WgCfg::LDS_BYTES, st>>>(b);
+            int rcx = check_launch("snvc_conv3d_wgrad(split operands, stride 2)");
+            if (rcx) return rcx;
+            const int64_t total = (int64_t)pairs * 27 * 1024;
+            wgrad_reduce_x3_kernel<<<dim3((unsigned)ceil_div<int64_t>(total, 256)), 256, 0, st>>>(
+                (const float *)workspace, dw, d->Cout, d->Cin, a.cx_blocks, pairs, (int)(cols * b.dparts), b.amax_x, b.amax_g);
+            return check_launch("snvc_conv3d_wgrad(split operands, stride 2, reduce)");
+        }
     }
     const int64_t s2_tiles = (int64_t)d->N * d->Dout * ceil_div(d->Hout, S2WgradCfg::TH) * a.tiles_w;
     if (key == 321 && (a.vec == 4 || a.vec == 2) && s2_tiles < ((int64_t)1 << 30) &&

@@ -329,7 +329,7 @@ class _ConvNormActFn(torch.autograd.Function):
         gw = None
         if needs[1]:
             if transposed:   # roles swapped, see snvc_conv3d_wgrad
-                gw = ops.conv3d_wgrad(draw, x, 3, 2, 1, 1)
+                gw = ops.conv3d_wgrad(draw, x, 3, 2, 1, 1, amax_x=g_amax, amax_g=ctx.x_amax)
             elif odd:
                 gw = ops.conv3d_wgrad(F.pad(x, (0, x.size(4) % 2, 0, x.size(3) % 2, 0, x.size(2) % 2)), draw, k, st, p, d)
             else:
@@ -718,6 +718,10 @@ class _ShearedFirstConvBNFn(torch.autograd.Function):
         _bn_track(norm, mean, var, float(n * depth * h * w))
         y = torch.empty(shape, dtype=torch.float32, device=left.device)
         ops.sheared_expand(g, gcol, planes, scale, shift, y, q, m0, off, off_col, EPI_RELU)
+        # an upper bound of max|y| for the next layer's split-operand weight gradient (r6): a voxel of the raw result is one element of
+        # G (+ one of G' in the last column) + one of the planes, so |y| <= max|scale| (max|G| + max|G'| + max|planes|) + max|shift|
+        ops.tag_amax(y, ops.amax_from_bound(scale.abs().max() * (g.abs().max() + gcol.abs().max() + planes.abs().max())
+                                            + shift.abs().max()))
         ctx.conv, ctx.norm, ctx.q, ctx.m0 = conv, norm, q, m0
         # gamma is saved as the autograd input it is: an in-place update between forward and backward (an interleaved
         # optimizer step, an EMA swap) then trips autograd's version check instead of pairing a new gamma with old scale / shift

@@ -831,9 +831,21 @@ def act_backward_reduce(raw, gy, residual, scale, shift, flags: int, per_sample:
     return sums
 
 
+AMAX_SLOTS = 64      # SNVC_AMAX_SLOTS
+
+
 def amax_word(device) -> torch.Tensor:
-    """A zeroed 4-byte device word for the bit pattern of a tensor's max|.| (snvc_*_amax entry points)."""
-    return torch.zeros(1, dtype=torch.int32, device=device)
+    """Zeroed device words for the bit pattern of a tensor's max|.| (snvc_*_amax entry points: SNVC_AMAX_SLOTS slots, the maximum over
+    them is the value; a single word would serialise the producers' atomics)."""
+    return torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=device)
+
+
+def amax_from_bound(bound: torch.Tensor) -> torch.Tensor:
+    """The words for an UPPER BOUND of max|t| given as a one-element float32 device tensor (no sync): a bound 2^k above the true
+    maximum costs the split-operand weight gradient k of the 39 bits it keeps below the maximum."""
+    w = torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=bound.device)
+    w[0:1] = bound.detach().float().reshape(1).abs().view(torch.int32)
+    return w
 
 
 def tag_amax(t: torch.Tensor, amax: Optional[torch.Tensor]) -> torch.Tensor:

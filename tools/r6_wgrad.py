@@ -43,3 +43,32 @@ if "time" in sys.argv:
         with ops.conv_variant(_lib.ALGO_WGRAD_FP32):
             b = ops.conv3d_wgrad(x, g, 3, 1, 1, 1)
         print("   x3 vs fp32 rel diff", ((a - b).abs().max() / b.abs().max()).item())
+
+# ---- stride 2
+def ref64_s2(x, g):
+    w = torch.zeros(g.shape[1], x.shape[1], 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x.double(), w, stride=2, padding=1)
+    assert y.shape == g.shape, (y.shape, g.shape)
+    (y * g.double()).sum().backward()
+    return w.grad
+cases2 = {"s2": (2, 32, 64, (6, 12, 40)), "s2 many": (1, 32, 32, (12, 40, 160)), "s2 64x64": (1, 64, 64, (8, 8, 72)), "s2 deep": (1, 32, 64, (40, 8, 64))}
+for name, (N, ci, co, shp) in cases2.items():
+    r = np.random.default_rng(6)
+    x = torch.from_numpy(r.standard_normal((N, ci) + shp).astype(np.float32))
+    g = torch.from_numpy(r.standard_normal((N, co) + tuple(s // 2 for s in shp)).astype(np.float32))
+    exp = ref64_s2(x, g)
+    with ops.conv_variant(0):
+        a = ops.conv3d_wgrad(x.to(dev), g.to(dev), 3, 2, 1, 1)
+        a2 = ops.conv3d_wgrad(x.to(dev), g.to(dev), 3, 2, 1, 1)
+    with ops.conv_variant(_lib.ALGO_WGRAD_FP32):
+        b = ops.conv3d_wgrad(x.to(dev), g.to(dev), 3, 2, 1, 1)
+    ea = ((a.cpu().double() - exp).abs().max() / exp.abs().max()).item()
+    eb = ((b.cpu().double() - exp).abs().max() / exp.abs().max()).item()
+    print(f"{name:12s} x3 err {ea:.2e}  fp32 err {eb:.2e}  deterministic {torch.equal(a, a2)}  differs {not torch.equal(a, b)}", flush=True)
+if "time" in sys.argv:
+    for (ci, co, shp) in ((32, 64, (192, 96, 312)), (64, 64, (96, 48, 156))):
+        x = torch.relu(torch.randn(1, ci, *shp, device=dev)); g = torch.randn(1, co, *(s // 2 for s in shp), device=dev) * 1e-4
+        for tag, bits in (("x3", 0), ("fp32", _lib.ALGO_WGRAD_FP32)):
+            with ops.conv_variant(bits):
+                ms, dw = bench.timed_ms(lambda: ops.conv3d_wgrad(x, g, 3, 2, 1, 1), 10, 3)
+            print("s2", ci, co, shp, tag, round(ms, 3), "ms", flush=True)
