@@ -905,6 +905,22 @@ struct X3WgCfg {
     static_assert(XPIECES % THREADS == 0, "whole rounds");
 };
 
+// a float4 piece of a row: one 16-byte load, or -- rows that are only 8-byte aligned (W % 4 == 2: the W = 78 level of the cfg2
+// hourglass) -- two 8-byte loads whose second half may lie beyond the row (then it reads element 0 and is zeroed by its own flag)
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+template <bool A16>
+__device__ __forceinline__ f32x4 x3wg_ld4(const float *__restrict__ b, unsigned off, unsigned off_hi) {
+    if constexpr (A16) {
+        return *reinterpret_cast<const f32x4 *>(b + off);
+    } else {
+        const f32x2w lo = *reinterpret_cast<const f32x2w *>(b + off), hi = *reinterpret_cast<const f32x2w *>(b + off_hi);
+        return f32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+}
+__device__ __forceinline__ f32x4 x3wg_mask(f32x4 v, bool lo_ok, bool hi_ok) {
+    return f32x4{lo_ok ? v[0] : 0.0f, lo_ok ? v[1] : 0.0f, hi_ok ? v[2] : 0.0f, hi_ok ? v[3] : 0.0f};
+}
+
 struct X3WgArgs {
     const float *x, *g;
     float *partial;
@@ -972,6 +988,7 @@ wgrad_amax2_kernel(const float *__restrict__ x, const float *__restrict__ g, uns
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out + which * SNVC_AMAX_SLOTS + (blockIdx.x & (SNVC_AMAX_SLOTS - 1)), m);
 }
 
+template <bool A16>      // rows 16-byte aligned (else 8-byte: W % 4 == 2)
 __global__ void __launch_bounds__(512, 1)
 conv3d_wgrad_x3_kernel(const X3WgArgs a) {
     using Cfg = X3WgCfg;
@@ -999,16 +1016,19 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
     const int64_t hw = (int64_t)a.H * a.W, dhw = hw * a.D;
 
     // staging tables (plane-invariant): element offset inside a plane of the sample, LDS position (in halves), validity
-    unsigned xoff[XNIT], goff[GNIT];
+    unsigned xoff[XNIT], goff[GNIT], xoffh[A16 ? 1 : XNIT], goffh[A16 ? 1 : GNIT];
     int xdst[XNIT], gdst[GNIT];
-    unsigned xok = 0, gok = 0;
+    unsigned xok = 0, gok = 0, xokh = 0, gokh = 0;        // piece (or its first half) / second half inside the grid
 #pragma unroll
     for (int it = 0; it < XNIT; ++it) {
         const int p = it * Cfg::THREADS + tid;
         const int ci = p / 48, rem = p - ci * 48, r = rem >> 3, q4 = rem & 7;
         const int h = h0 - 1 + r, w = w0 + 4 * q4;
-        const bool ok = cx0 + ci < a.Cx && (unsigned)h < (unsigned)a.H && w + 4 <= a.W;
+        const bool rowok = cx0 + ci < a.Cx && (unsigned)h < (unsigned)a.H;
+        const bool ok = rowok && w + (A16 ? 4 : 2) <= a.W, okh = rowok && w + 4 <= a.W;
         xoff[it] = ok ? (unsigned)(ci * dhw + (int64_t)h * a.W + w) : 0u;
+        if constexpr (!A16) xoffh[it] = okh ? xoff[it] + 2u : 0u;
+        xokh |= (okh ? 1u : 0u) << it;
         // 16-byte chunk (q4 >> 1) of the row sits at position chunk ^ 2 * bit 2 of the channel: conflict-free ds_read_b128 at a 64-byte stride
         xdst[it] = (r * 32 + ci) * XCOLS + (((q4 >> 1) ^ (2 * ((ci >> 2) & 1))) * 8) + (q4 & 1) * 4;
         xok |= (ok ? 1u : 0u) << it;
@@ -1019,8 +1039,11 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
         const int co = p / 40, rem = p - co * 40, r = rem / 10, q = rem - r * 10;
         const int h = h0 + r, w = w0 - 4 + 4 * q;
         const bool in = p < Cfg::GPIECES;
-        const bool ok = in && cg0 + co < a.Cg && h < a.H && w >= 0 && w + 4 <= a.W;
+        const bool rowok = in && cg0 + co < a.Cg && h < a.H && w >= 0;
+        const bool ok = rowok && w + (A16 ? 4 : 2) <= a.W, okh = rowok && w + 4 <= a.W;
         goff[it] = ok ? (unsigned)(co * dhw + (int64_t)h * a.W + w) : 0u;
+        if constexpr (!A16) goffh[it] = okh ? goff[it] + 2u : 0u;
+        gokh |= (okh ? 1u : 0u) << it;
         gdst[it] = in ? (r * 32 + co) * GCOLS + 4 + 4 * q : -1;
         gok |= (ok ? 1u : 0u) << it;
     }
@@ -1036,13 +1059,13 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
         x_dok = (unsigned)id < (unsigned)a.D;
         const float *b = xs + (int64_t)(x_dok ? id : 0) * hw;
 #pragma unroll
-        for (int it = 0; it < XNIT; ++it) xv[it] = *reinterpret_cast<const f32x4 *>(b + xoff[it]);
+        for (int it = 0; it < XNIT; ++it) xv[it] = x3wg_ld4<A16>(b, xoff[it], xoffh[A16 ? 0 : it]);
     };
     auto load_g = [&](int od) {
         g_dok = od < a.D;
         const float *b = gs + (int64_t)(g_dok ? od : 0) * hw;
 #pragma unroll
-        for (int it = 0; it < GNIT; ++it) gv[it] = *reinterpret_cast<const f32x4 *>(b + goff[it]);
+        for (int it = 0; it < GNIT; ++it) gv[it] = x3wg_ld4<A16>(b, goff[it], goffh[A16 ? 0 : it]);
     };
     auto split_store = [&](char *hi_base, int plane_halves, int dst, f32x4 v, float s) {
         const f32x4 t = v * s;
@@ -1056,14 +1079,14 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
         char *b = lds + ((id + 4) & 3) * Cfg::SLOT_BYTES;
 #pragma unroll
         for (int it = 0; it < XNIT; ++it)
-            split_store(b, Cfg::XPLANE, xdst[it], (x_dok && ((xok >> it) & 1u)) ? xv[it] : f32x4(0.0f), sx);
+            split_store(b, Cfg::XPLANE, xdst[it], x3wg_mask(xv[it], x_dok && ((xok >> it) & 1u), x_dok && ((xokh >> it) & 1u)), sx);
     };
     auto store_g = [&](int od) {
         char *b = gbase + (od & 1) * Cfg::G_BYTES;
 #pragma unroll
         for (int it = 0; it < GNIT; ++it) {
             if (gdst[it] < 0) continue;
-            split_store(b, Cfg::GPLANE, gdst[it], (g_dok && ((gok >> it) & 1u)) ? gv[it] : f32x4(0.0f), sg);
+            split_store(b, Cfg::GPLANE, gdst[it], x3wg_mask(gv[it], g_dok && ((gok >> it) & 1u), g_dok && ((gokh >> it) & 1u)), sg);
         }
     };
 
@@ -1167,6 +1190,7 @@ struct X3S2WgCfg {
     static_assert(XPIECES % THREADS == 0, "whole rounds");
 };
 
+template <bool G16>      // gradient rows 16-byte aligned (else 8-byte: Wout % 4 == 2); the input rows (2 Wout floats) always are
 __global__ void __launch_bounds__(512, 1)
 conv3d_wgrad_x3s2_kernel(const X3WgArgs a) {      // a.D / H / W: the SMALL grid (g); x lives on 2D x 2H x 2W
     using Cfg = X3S2WgCfg;
@@ -1193,9 +1217,9 @@ conv3d_wgrad_x3s2_kernel(const X3WgArgs a) {      // a.D / H / W: the SMALL grid
     const int64_t ghw = (int64_t)a.H * a.W, gdhw = ghw * a.D;
     const int64_t xhw = (int64_t)Hi * Wi, xdhw = xhw * Di;
 
-    unsigned xoff[XNIT], goff[GNIT];
+    unsigned xoff[XNIT], goff[GNIT], goffh[G16 ? 1 : GNIT];
     int xdst[XNIT], gdst[GNIT];
-    unsigned xok = 0, gok = 0;
+    unsigned xok = 0, gok = 0, gokh = 0;
 #pragma unroll
     for (int it = 0; it < XNIT; ++it) {
         const int p = it * Cfg::THREADS + tid;
@@ -1215,8 +1239,11 @@ conv3d_wgrad_x3s2_kernel(const X3WgArgs a) {      // a.D / H / W: the SMALL grid
         const int co = p / 20, rem = p - co * 20, r = rem / 10, q = rem - r * 10;
         const int h = h0 + r, w = w0 - 4 + 4 * q;
         const bool in = p < Cfg::GPIECES;
-        const bool ok = in && cg0 + co < a.Cg && h < a.H && w >= 0 && w + 4 <= a.W;
+        const bool rowok = in && cg0 + co < a.Cg && h < a.H && w >= 0;
+        const bool ok = rowok && w + (G16 ? 4 : 2) <= a.W, okh = rowok && w + 4 <= a.W;
         goff[it] = ok ? (unsigned)(co * gdhw + (int64_t)h * a.W + w) : 0u;
+        if constexpr (!G16) goffh[it] = okh ? goff[it] + 2u : 0u;
+        gokh |= (okh ? 1u : 0u) << it;
         gdst[it] = in ? (r * Cfg::GCH + co) * GCOLS + 4 + 4 * q : -1;
         gok |= (ok ? 1u : 0u) << it;
     }
@@ -1234,7 +1261,7 @@ conv3d_wgrad_x3s2_kernel(const X3WgArgs a) {      // a.D / H / W: the SMALL grid
         g_dok = od < a.D;
         const float *b = gs + (int64_t)(g_dok ? od : 0) * ghw;
 #pragma unroll
-        for (int it = 0; it < GNIT; ++it) gv[it] = *reinterpret_cast<const f32x4 *>(b + goff[it]);
+        for (int it = 0; it < GNIT; ++it) gv[it] = x3wg_ld4<G16>(b, goff[it], goffh[G16 ? 0 : it]);
     };
     typedef _Float16 h2w __attribute__((ext_vector_type(2)));
     auto store_x = [&](int k, int id) {        // plane id lives in slot (id + 3) % 3
@@ -1258,7 +1285,7 @@ conv3d_wgrad_x3s2_kernel(const X3WgArgs a) {      // a.D / H / W: the SMALL grid
 #pragma unroll
         for (int it = 0; it < GNIT; ++it) {
             if (gdst[it] < 0) continue;
-            const f32x4 v = (g_dok && ((gok >> it) & 1u)) ? gv[it] : f32x4(0.0f);
+            const f32x4 v = x3wg_mask(gv[it], g_dok && ((gok >> it) & 1u), g_dok && ((gokh >> it) & 1u));
             const f32x4 t = v * sg;
             const h4w hi = __builtin_convertvector(t, h4w);
             const f32x4 back = __builtin_convertvector(hi, f32x4);
@@ -1476,7 +1503,12 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
         }
     }
     const int key = d->ksize * 100 + d->stride * 10 + d->dilation;
-    if (key == 311 && a.vec == 4 && !(d->algo & SNVC_ALGO_WGRAD_FP32) && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
+    // rows of the split-operand forms: 16-byte aligned, or 8-byte (W % 4 == 2: float2 pieces)
+    const bool x8 = d->Win % 2 == 0 && a.x_bs % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7) == 0 && !(d->algo & SNVC_ALGO_SCALAR_STAGING);
+    // (their own amax pass reads the tensors as flat float4 streams)
+    const bool flat16 = in_sz % 4 == 0 && out_sz % 4 == 0 && a.x_bs % 4 == 0 && a.g_bs % 4 == 0 &&
+                        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    if (key == 311 && flat16 && (a.vec == 4 || (x8 && g2)) && !(d->algo & SNVC_ALGO_WGRAD_FP32) && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
         // split-operand (f16x3) form, see conv3d_wgrad_x3_kernel: one workgroup per (column of 4 x 32 voxels, depth part, channel pair)
         X3WgArgs b;
         b.x = x; b.g = g; b.partial = (float *)workspace;
@@ -1503,10 +1535,15 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
                 const unsigned ab = (unsigned)std::min<int64_t>(ceil_div<int64_t>(std::max(n4x, n4g), 256 * 8), 4096);
                 wgrad_amax2_kernel<<<dim3(ab, 2, (unsigned)d->N), 256, 0, st>>>(x, g, amax, n4x, n4g, a.x_bs, a.g_bs);
             }
-            static std::atomic<unsigned> attr_x3{0};
+            static std::atomic<unsigned> attr_x3{0}, attr_x3u{0};
             const unsigned nwg = (unsigned)(8 * ceil_div(b.njobs, 8));
-            if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3_kernel), X3WgCfg::LDS_BYTES, attr_x3))
-                conv3d_wgrad_x3_kernel<<<dim3(nwg), X3WgCfg::THREADS, X3WgCfg::LDS_BYTES, st>>>(b);
+            if (a.vec == 4) {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3_kernel<true>), X3WgCfg::LDS_BYTES, attr_x3))
+                    conv3d_wgrad_x3_kernel<true><<<dim3(nwg), X3WgCfg::THREADS, X3WgCfg::LDS_BYTES, st>>>(b);
+            } else {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3_kernel<false>), X3WgCfg::LDS_BYTES, attr_x3u))
+                    conv3d_wgrad_x3_kernel<false><<<dim3(nwg), X3WgCfg::THREADS, X3WgCfg::LDS_BYTES, st>>>(b);
+            }
             int rcx = check_launch("snvc_conv3d_wgrad(split operands)");
             if (rcx) return rcx;
             const int64_t total = (int64_t)pairs * 27 * 1024;
@@ -1535,7 +1572,7 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
                                                                                                  d->Cin, a.cx_blocks, pairs, 2 * a.P);
         return check_launch("snvc_conv3d_wgrad(winograd reduce)");
     }
-    if (key == 321 && a.vec == 4 && !(d->algo & SNVC_ALGO_WGRAD_FP32) && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT &&
+    if (key == 321 && flat16 && (a.vec == 4 || a.vec == 2) && !(d->algo & SNVC_ALGO_WGRAD_FP32) && (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT &&
         d->Din == 2 * d->Dout && d->Hin == 2 * d->Hout && d->Win == 2 * d->Wout) {
         // split-operand (f16x3) form of the stride-2 layers, see conv3d_wgrad_x3s2_kernel
         X3WgArgs b;
@@ -1561,10 +1598,15 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
                 const unsigned ab = (unsigned)std::min<int64_t>(ceil_div<int64_t>(std::max(n4x, n4g), 256 * 8), 4096);
                 wgrad_amax2_kernel<<<dim3(ab, 2, (unsigned)d->N), 256, 0, st>>>(x, g, amax, n4x, n4g, a.x_bs, a.g_bs);
             }
-            static std::atomic<unsigned> attr_x3s2{0};
+            static std::atomic<unsigned> attr_x3s2{0}, attr_x3s2u{0};
             const unsigned nwg = (unsigned)(8 * ceil_div(b.njobs, 8));
-            if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3s2_kernel), X3S2WgCfg::LDS_BYTES, attr_x3s2))
-                conv3d_wgrad_x3s2_kernel<<<dim3(nwg), X3S2WgCfg::THREADS, X3S2WgCfg::LDS_BYTES, st>>>(b);
+            if (a.vec == 4) {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3s2_kernel<true>), X3S2WgCfg::LDS_BYTES, attr_x3s2))
+                    conv3d_wgrad_x3s2_kernel<true><<<dim3(nwg), X3S2WgCfg::THREADS, X3S2WgCfg::LDS_BYTES, st>>>(b);
+            } else {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3s2_kernel<false>), X3S2WgCfg::LDS_BYTES, attr_x3s2u))
+                    conv3d_wgrad_x3s2_kernel<false><<<dim3(nwg), X3S2WgCfg::THREADS, X3S2WgCfg::LDS_BYTES, st>>>(b);
+            }
             int rcx = check_launch("snvc_conv3d_wgrad(split operands, stride 2)");
             if (rcx) return rcx;
             const int64_t total = (int64_t)pairs * 27 * 1024;
@@ -1574,7 +1616,7 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
         }
     }
     const int64_t s2_tiles = (int64_t)d->N * d->Dout * ceil_div(d->Hout, S2WgradCfg::TH) * a.tiles_w;
-    if (key == 321 && (a.vec == 4 || a.vec == 2) && s2_tiles < ((int64_t)1 << 30) &&
+    if (key == 321 && flat16 && (a.vec == 4 || a.vec == 2) && s2_tiles < ((int64_t)1 << 30) &&
         (d->algo & SNVC_ALGO_ARITH_MASK) != SNVC_ALGO_DIRECT) {
         // 12-wave form (see conv3d_wgrad_s2_kernel); SNVC_ALGO_DIRECT keeps the tap-split kernel below
         a.tiles_h = ceil_div(d->Hout, S2WgradCfg::TH);

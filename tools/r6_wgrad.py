@@ -13,7 +13,7 @@ def ref64(x, g, k=3):
     return w.grad
 
 cases = {"many tiles": (1, 32, 32, (10, 40, 96)), "ragged": (2, 40, 24, (5, 10, 44)), "one tile": (1, 32, 64, (2, 4, 32)),
-         "64x64": (1, 64, 64, (9, 12, 64)), "deep": (1, 32, 32, (40, 8, 32)), "tiny grads": (1, 32, 32, (6, 8, 64))}
+         "64x64": (1, 64, 64, (9, 12, 64)), "deep": (1, 32, 32, (40, 8, 32)), "tiny grads": (1, 32, 32, (6, 8, 64)), "w78": (1, 64, 64, (6, 10, 78)), "w38 ragged": (2, 40, 24, (5, 7, 38))}
 for name, (N, ci, co, shp) in cases.items():
     r = np.random.default_rng(5)
     x = torch.from_numpy(r.standard_normal((N, ci) + shp).astype(np.float32))
@@ -51,7 +51,7 @@ def ref64_s2(x, g):
     assert y.shape == g.shape, (y.shape, g.shape)
     (y * g.double()).sum().backward()
     return w.grad
-cases2 = {"s2": (2, 32, 64, (6, 12, 40)), "s2 many": (1, 32, 32, (12, 40, 160)), "s2 64x64": (1, 64, 64, (8, 8, 72)), "s2 deep": (1, 32, 64, (40, 8, 64))}
+cases2 = {"s2": (2, 32, 64, (6, 12, 40)), "s2 many": (1, 32, 32, (12, 40, 160)), "s2 64x64": (1, 64, 64, (8, 8, 72)), "s2 deep": (1, 32, 64, (40, 8, 64)), "s2 w76": (1, 32, 64, (4, 12, 76)), "s2 w156": (1, 64, 64, (8, 6, 156))}
 for name, (N, ci, co, shp) in cases2.items():
     r = np.random.default_rng(6)
     x = torch.from_numpy(r.standard_normal((N, ci) + shp).astype(np.float32))
