@@ -168,21 +168,30 @@ def run_extras(args, line, rank, world, device, dist, barrier, rccl_note):
     except Exception as e:
         cfgs["cfg3_64crops_sharded"] = {"error": f"{type(e).__name__}: {e}"}
     cfgs["cfg4_train_step"] = {k: tr[k] for k in ("ms_per_step", "fwd_ms", "bwd_ms", "step_tflops_algorithmic") if k in tr}
-    try:        # its dominant launch: the Winograd-domain weight gradient of a 32->32 layer on the full grid
-        from snvc_amd import ops                     # (conv1's right half, conv2, the classifier: 3 per step)
-        xg = torch.randn(1, C, D, H, W, device=device)
-        gg = torch.randn(1, C, D, H, W, device=device)
-        ms_w, _ = timed_ms(lambda: ops.conv3d_wgrad(xg, gg, 3, 1, 1, 1), 3)
+    try:        # the weight gradient of a 32->32 layer on the full grid (conv2's: the largest of the step's wgrad launches), both forms
+        from snvc_amd import _lib, ops
+        from benchlib.common import PEAK_F16_MFMA_TFLOPS
+        xg = torch.relu(torch.randn(1, C, D, H, W, device=device))
+        gg = torch.randn(1, C, D, H, W, device=device) * 1e-4
         flop = CONV1_FLOP / 2                          # 32 of conv1's 64 input channels
+        ax, ag = ops.amax_word(device), ops.amax_word(device)      # the maxima as the training step has them: left by the producer passes
+        ax[0:1] = xg.abs().max().reshape(1).view(torch.int32)
+        ag[0:1] = gg.abs().max().reshape(1).view(torch.int32)
+        ms_x3, _ = timed_ms(lambda: ops.conv3d_wgrad(xg, gg, 3, 1, 1, 1, amax_x=ax, amax_g=ag), 5, 3)
+        ms_x3_own, _ = timed_ms(lambda: ops.conv3d_wgrad(xg, gg, 3, 1, 1, 1), 5, 3)
+        with ops.conv_variant(_lib.ALGO_WGRAD_FP32):
+            ms_w, _ = timed_ms(lambda: ops.conv3d_wgrad(xg, gg, 3, 1, 1, 1), 3)
         cfgs["cfg4_train_step"].update({
-            "dominant_kernel": "conv3d_wgrad_wino_kernel 32->32 on 192x96x312 (Winograd-domain weight gradient, fp32 MFMA, deterministic) "
-                               "+ wgrad_wino_reduce_kernel",
-            "dominant_ms": ms_w, "dominant_gflop_algorithmic": flop / 1e9, "dominant_tflops_algorithmic": flop / (ms_w * 1e-3) / 1e12,
-            # executed on the matrix pipe: 6 of 12 multiply-adds, on 32-wide tiles (W = 312 -> 320)
-            "dominant_pipe_frac": wino_executed_share(3, W) * flop / (ms_w * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS})
+            "wgrad_kernel": "conv3d_wgrad_x3_kernel 32->32 on 192x96x312 (r6: operands split into (hi, lo) halves on the way into LDS, three "
+                            "v_mfma_f32_16x16x32_f16 per fp32 product, deterministic) + wgrad_reduce_x3_kernel",
+            "wgrad_ms": ms_x3, "wgrad_ms_finding_its_own_maxima": ms_x3_own, "wgrad_gflop_algorithmic": flop / 1e9,
+            # necessary matrix-pipe flops: three half-precision MFMA flops per algorithmic multiply-add, against the f16 peak
+            "wgrad_pipe_frac": 3.0 * flop / (ms_x3 * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+            "wgrad_fp32_form_ms": ms_w,
+            "wgrad_fp32_form_pipe_frac": wino_executed_share(3, W) * flop / (ms_w * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS})
         del xg, gg
     except Exception as e:
-        cfgs["cfg4_train_step"]["dominant_error"] = f"{type(e).__name__}: {e}"
+        cfgs["cfg4_train_step"]["wgrad_error"] = f"{type(e).__name__}: {e}"
     line["configs"] = cfgs
     try:
         line["off_fast_path"] = off_fast_path(device)

@@ -69,6 +69,8 @@ def run_train(rank, world, device, dist, steps, warmup, barrier):
     res = {
         "workload": "cfg4: 1 pair/GPU at cfg2 size, train-mode BatchNorm, loss = mean(cost^2), fwd + bwd on the HIP "
                     "kernels + flat-bucket gradient all-reduce",
+        "arithmetic": "f32 (forward / data gradients: fp32 MFMA, Winograd F(4,3); weight gradients of the 3x3x3 layers: split f16x3 operands, "
+                      "fp32 accumulate, r6)",
         "ms_per_step": 1e3 * elapsed / steps, "pairs_per_s": world * steps / elapsed,
         "fwd_ms": f, "bwd_ms": b, "allreduce_us": 1e3 * r, "allreduce_bytes": ts.moved, "params": ts.nparam,
         "step_tflops_algorithmic": 3 * STEP_FLOP / (elapsed / steps) / 1e12, "steps": steps,

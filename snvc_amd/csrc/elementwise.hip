@@ -369,13 +369,32 @@ act_bwd_apply_kernel(const float *__restrict__ raw, const float *__restrict__ gy
     float *go = g_out ? g_out + (n * C + c) * S : nullptr;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     unsigned mx = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += stride) {
-        const float x = a[i];
-        const float g = act_grad(x, b[i], r ? r[i] : 0.0f, sc, sh, flags);
-        const float dr = ca * g + cb * x + cc;
-        o[i] = dr;
-        mx = amax_bits4(mx, dr, dr, dr, dr);
-        if (go) go[i] = g;
+    // r6: 16-byte pieces when the rows allow it (the pass moved 3.7 TB/s with 4-byte accesses: 1.7 ms of the cfg4 step)
+    const bool vec = ((S & 3) == 0) && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)o | (uintptr_t)r | (uintptr_t)go) & 15) == 0);
+    if (vec) {
+        const int64_t S4 = S >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S4; i += stride) {
+            const float4 x = reinterpret_cast<const float4 *>(a)[i], gy4 = reinterpret_cast<const float4 *>(b)[i];
+            float4 q = make_float4(0, 0, 0, 0);
+            if (r) q = reinterpret_cast<const float4 *>(r)[i];
+            float4 g, dr;
+            g.x = act_grad(x.x, gy4.x, q.x, sc, sh, flags); g.y = act_grad(x.y, gy4.y, q.y, sc, sh, flags);
+            g.z = act_grad(x.z, gy4.z, q.z, sc, sh, flags); g.w = act_grad(x.w, gy4.w, q.w, sc, sh, flags);
+            dr.x = ca * g.x + cb * x.x + cc; dr.y = ca * g.y + cb * x.y + cc;
+            dr.z = ca * g.z + cb * x.z + cc; dr.w = ca * g.w + cb * x.w + cc;
+            reinterpret_cast<float4 *>(o)[i] = dr;
+            mx = amax_bits4(mx, dr.x, dr.y, dr.z, dr.w);
+            if (go) reinterpret_cast<float4 *>(go)[i] = g;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S; i += stride) {
+            const float x = a[i];
+            const float g = act_grad(x, b[i], r ? r[i] : 0.0f, sc, sh, flags);
+            const float dr = ca * g + cb * x + cc;
+            o[i] = dr;
+            mx = amax_bits4(mx, dr, dr, dr, dr);
+            if (go) go[i] = g;
+        }
     }
     if (amax) amax_publish(amax, mx);
 }
@@ -598,7 +617,7 @@ int snvc_act_backward_apply_amax(const float *raw, const float *gy, const float 
     if (raw_batch_stride == 0) raw_batch_stride = C * S;
     if (gy_batch_stride == 0) gy_batch_stride = C * S;
     if (res_batch_stride == 0) res_batch_stride = C * S;
-    dim3 grid(stream_blocks(S, N * C), (unsigned)C, (unsigned)N);
+    dim3 grid(stream_blocks(S / 4 + 1, N * C), (unsigned)C, (unsigned)N);
     act_bwd_apply_kernel<<<grid, 256, 0, as_stream(stream)>>>(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const,
                                                               draw, g_out, C, S, raw_batch_stride, gy_batch_stride,
                                                               res_batch_stride, per_sample, flags, amax);
