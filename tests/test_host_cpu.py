@@ -381,3 +381,19 @@ def test_warp_after_convolution_algebra_on_the_cpu(seed):
     ref = F.conv3d(vol_r, wr, padding=1)[0].numpy()
     got = _warped_first_conv_reference(R[0].astype(np.float64), wr, shift[0].astype(np.float64), D)
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)      # the oracle interpolates in fp32: ~1e-7 of the values
+
+
+def test_amax_tags_follow_the_tensor_version():
+    """ops.tag_amax / amax_of (r6): the word a producer pass left is handed on only while the tensor is unchanged."""
+    from snvc_amd import ops
+    t = torch.zeros(4)
+    w = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32)
+    assert ops.amax_of(t) is None
+    ops.tag_amax(t, w)
+    assert ops.amax_of(t) is w
+    t.add_(1.0)
+    assert ops.amax_of(t) is None
+    ops.tag_amax(t, None)
+    assert ops.amax_of(t) is None
+    b = ops.amax_from_bound(torch.tensor(-3.5))
+    assert b.shape == (ops.AMAX_SLOTS,) and b[0].item() == torch.tensor(3.5).view(torch.int32).item() and int(b[1:].abs().sum()) == 0
