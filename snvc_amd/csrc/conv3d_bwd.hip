@@ -1121,7 +1121,7 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
     for (int od = d0; od < d1; ++od) {
         if (kp == 0) stage(od);          // the SIMD's other wave (kp == 1) runs its MFMAs meanwhile
         const char *const gplane = gbase + (od & 1) * Cfg::G_BYTES + glane;
-#pragma unroll 1
+#pragma unroll 1      // (unrolled: spills, no gain)
         for (int rr = 0; rr < 2; ++rr) {
             const int rg = 2 * kp + rr;
             // the gradient row's three column shifts (hi and lo): kw = 0 -> g[u + 1], kw = 1 -> g[u], kw = 2 -> g[u - 1]; the shifted
@@ -1321,7 +1321,7 @@ conv3d_wgrad_x3s2_kernel(const X3WgArgs a) {      // a.D / H / W: the SMALL grid
             load_g(od + 1);
         }
         const int s0 = (2 * od - 1 + 3) % 3;     // slot of input plane 2 od - 1 (kd = 0)
-#pragma unroll 1
+#pragma unroll 1      // (unrolled: 60-84 bytes of scratch and 0.585 -> 0.66 ms)
         for (int r = 0; r < Cfg::TH; ++r) {
             u32x4w gb[2][2];                 // [hi | lo][g[u] | g[u + 1]]
 #pragma unroll

@@ -834,16 +834,29 @@ def act_backward_reduce(raw, gy, residual, scale, shift, flags: int, per_sample:
 AMAX_SLOTS = 64      # SNVC_AMAX_SLOTS
 
 
+_AMAX_POOL = threading.local()
+_AMAX_POOL_WORDS = 64
+
+
 def amax_word(device) -> torch.Tensor:
     """Zeroed device words for the bit pattern of a tensor's max|.| (snvc_*_amax entry points: SNVC_AMAX_SLOTS slots, the maximum over
-    them is the value; a single word would serialise the producers' atomics)."""
-    return torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=device)
+    them is the value; a single word would serialise the producers' atomics).  Handed out from a pool that is zeroed in ONE launch
+    per 64 words (a training step takes ~15): a word is a view of its pool and is never zeroed or handed out again, so a tag that
+    still refers to it stays valid; an exhausted pool is simply dropped (its views keep it alive as long as they live)."""
+    pools = _AMAX_POOL.__dict__.setdefault("pools", {})
+    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ent = pools.get(key)
+    if ent is None or ent[1] >= _AMAX_POOL_WORDS:
+        ent = pools[key] = [torch.zeros((_AMAX_POOL_WORDS, AMAX_SLOTS), dtype=torch.int32, device=device), 0]
+    w = ent[0][ent[1]]
+    ent[1] += 1
+    return w
 
 
 def amax_from_bound(bound: torch.Tensor) -> torch.Tensor:
     """The words for an UPPER BOUND of max|t| given as a one-element float32 device tensor (no sync): a bound 2^k above the true
     maximum costs the split-operand weight gradient k of the 39 bits it keeps below the maximum."""
-    w = torch.zeros(AMAX_SLOTS, dtype=torch.int32, device=bound.device)
+    w = amax_word(bound.device)
     w[0:1] = bound.detach().float().reshape(1).abs().view(torch.int32)
     return w
 
