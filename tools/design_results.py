@@ -36,7 +36,9 @@ rows = [
     ("`general_shift` (any shift array)", f"{f(g(d, 'general_shift', 'value'))} pairs/s, {f(g(d, 'general_shift', 'ms_per_step'), 3)} ms"),
     ("`reference_api` (the reference's two calls verbatim)", f"{f(g(d, 'reference_api', 'value'))} pairs/s"),
     ("`fp32_mfma` / `built_right_half` / `materialized`", f"{f(g(d, 'fp32_mfma', 'value'))} / {f(g(d, 'built_right_half', 'value'))} / {f(g(d, 'materialized', 'value'))} pairs/s"),
-    ("`train` (cfg4, fp32-MFMA kernels)", f"{f(g(d, 'train', 'ms_per_step'), 2)} ms/step (fwd {f(g(d, 'train', 'fwd_ms'), 2)}, bwd {f(g(d, 'train', 'bwd_ms'), 2)})"),
+    ("`train` (cfg4; r6: weight gradients of the 3x3x3 layers on split f16x3 operands)", f"{f(g(d, 'train', 'ms_per_step'), 2)} ms/step (fwd {f(g(d, 'train', 'fwd_ms'), 2)}, bwd {f(g(d, 'train', 'bwd_ms'), 2)})"),
+    ("`configs.cfg4_train_step` weight gradient 32->32 full grid", f"split-operand form {f(g(c, 'cfg4_train_step', 'wgrad_ms'), 3)} ms (finding its own maxima: {f(g(c, 'cfg4_train_step', 'wgrad_ms_finding_its_own_maxima'), 3)}), fp32 Winograd form {f(g(c, 'cfg4_train_step', 'wgrad_fp32_form_ms'), 3)} ms"),
+    ("`value_fp32_mfma` / `dtype`", f"{f(d.get('value_fp32_mfma'))} pairs/s on the fp32-MFMA kernels; dtype = {d.get('dtype')}"),
 ]
 for name, e in c.items():
     if not isinstance(e, dict):
@@ -50,11 +52,19 @@ for name, e in c.items():
         rate = 1e3 / e["ms_per_step"]
     cpu = g(e, "cpu_baseline", "value")
     extra = []
+    if name == "cfg4_train_step":
+        continue
     for k in ("crops_per_s_f16", "f16_crops_per_s", "rois_per_s_f32", "f32_rois_per_s"):
         if k in e:
             extra.append(f"{k} {f(e[k])}")
     rows.append((f"`configs.{name}`", f"{f(rate)} /s" + (f"; parity {par:.1e}" if par is not None else "") + (f"; CPU oracle {cpu:.3g} /s" if cpu is not None else "")
                  + ("; " + ", ".join(extra) if extra else "")))
+for key, label in (("warped_expand", "any-shift expand"), ("full_volume", "a1 cost-volume builder"), ("right_half_builder", "right-half builder"),
+                   ("gather", "a3 gather, projected coordinates"), ("gather_uniform", "a3 gather, uniform coordinates"),
+                   ("cost_volume_backward", "a2 cost-volume backward"), ("roiaware_pool3d", "a10 roiaware_pool3d")):
+    e = g(d, "roofline_hbm", key)
+    if isinstance(e, dict) and e.get("frac") is not None:
+        rows.append((f"`roofline_hbm.{key}` ({label})", f"{f(e.get('avg_launch_ms'), 3)} ms = {f(e.get('achieved'), 0)} GB/s = {f(e.get('frac'), 3)} of 8 TB/s"))
 cb = d["cpu_baseline"]
 rows.append(("`cpu_baseline`", f"{cb['value']:.3g} {cb['unit']} on {cb['cores']} threads ({cb['kind']}); {cb.get('sample', '')[:110]}"))
 off = d.get("off_fast_path", {})
@@ -66,7 +76,8 @@ if off:
             if v:
                 bits.append(f"{k} {f(v)} /s")
     rows.append(("`off_fast_path`", "; ".join(bits)))
-table = "| Entry of the line | r5 |\n|---|---|\n" + "\n".join(f"| {a} | {b} |" for a, b in rows)
+rnd = os.path.basename(os.path.dirname(os.path.abspath(sys.argv[1])))
+table = f"| Entry of the line | {rnd} |\n|---|---|\n" + "\n".join(f"| {a} | {b} |" for a, b in rows)
 path = os.path.join(ROOT, "DESIGN.md")
 text = open(path).read()
 block = f"<!-- RESULTS:BEGIN ({os.path.relpath(sys.argv[1], ROOT)}) -->\n{table}\n<!-- RESULTS:END -->"
