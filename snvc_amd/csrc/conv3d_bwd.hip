@@ -900,6 +900,7 @@ struct X3WgCfg {
     static constexpr int GPLANE = TH * 32 * GCOLS;
     static constexpr int G_BYTES = 2 * GPLANE * 2;           // 24576
     static constexpr int LDS_BYTES = NSLOT * SLOT_BYTES + 2 * G_BYTES;      // 147456
+    static constexpr int LDS_ALLOC = LDS_BYTES + 16384;                      // + a 16 KB sink for the last step's (dead) stores
     static constexpr int XPIECES = XR * 32 * 8, XNIT = XPIECES / THREADS;                        // float4 pieces of an input plane: 1536 = 3 rounds
     static constexpr int GPIECES = TH * 32 * 10, GNIT = (GPIECES + THREADS - 1) / THREADS;       // 1280 -> 3 rounds (the last one half full)
     static_assert(XPIECES % THREADS == 0, "whole rounds");
@@ -929,6 +930,7 @@ struct X3WgArgs {
     int cx_blocks, pairs, hblocks, wsegs, dparts, dchunk, njobs;
     int pairs32;                // stride-2 form: 32 x 32 channel pairs of the slab layout (its jobs take 64 g channels)
     int64_t x_bs, g_bs;
+    int dbg;
 };
 
 // the maximum of the SNVC_AMAX_SLOTS words a producer pass left (snvc_affine_act_amax ...): every lane reads one, the wave reduces
@@ -1067,28 +1069,32 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
 #pragma unroll
         for (int it = 0; it < GNIT; ++it) gv[it] = x3wg_ld4<A16>(b, goff[it], goffh[A16 ? 0 : it]);
     };
-    auto split_store = [&](char *hi_base, int plane_halves, int dst, f32x4 v, float s) {
+    auto split_store = [&](char *hi_base, int lo_bytes, int dst_bytes, f32x4 v, float s) {
         const f32x4 t = v * s;
         const h4w hi = __builtin_convertvector(t, h4w);
         const f32x4 back = __builtin_convertvector(hi, f32x4);
         const h4w lo = __builtin_convertvector(t - back, h4w);
-        *reinterpret_cast<h4w *>(hi_base + 2 * dst) = hi;
-        *reinterpret_cast<h4w *>(hi_base + 2 * (plane_halves + dst)) = lo;
+        *reinterpret_cast<h4w *>(hi_base + dst_bytes) = hi;
+        *reinterpret_cast<h4w *>(hi_base + dst_bytes + lo_bytes) = lo;
     };
-    auto store_x = [&](int id) {          // plane id lives in slot (id + 4) & 3
-        char *b = lds + ((id + 4) & 3) * Cfg::SLOT_BYTES;
-#pragma unroll
-        for (int it = 0; it < XNIT; ++it)
-            split_store(b, Cfg::XPLANE, xdst[it], x3wg_mask(xv[it], x_dok && ((xok >> it) & 1u), x_dok && ((xokh >> it) & 1u)), sx);
+    // one piece of the plane held in the registers -> LDS.  `live` false (the walk's last step: nothing behind it): the same
+    // instructions write into the 16 KB behind the image instead -- no branch, so that the whole step stays ONE basic block and the
+    // compiler can place these ~50 VALU instructions between the step's MFMAs (a wave's own VALU fits the 8 issue cycles an MFMA
+    // leaves free; staged as a separate phase they cost their full time: 0.31 ms of the layer's 0.93, measured with debug switches)
+    char *const dummy = lds + Cfg::LDS_BYTES;
+    auto store_x_piece = [&](int it, int id, bool live) {          // plane id lives in slot (id + 4) & 3
+        char *b = live ? lds + ((id + 4) & 3) * Cfg::SLOT_BYTES : dummy;
+        const int off = live ? 2 * xdst[it] : ((2 * xdst[it]) & 8191);
+        split_store(b, live ? 2 * Cfg::XPLANE : 8192, off, x3wg_mask(xv[it], x_dok && ((xok >> it) & 1u), x_dok && ((xokh >> it) & 1u)), sx);
     };
-    auto store_g = [&](int od) {
-        char *b = gbase + (od & 1) * Cfg::G_BYTES;
-#pragma unroll
-        for (int it = 0; it < GNIT; ++it) {
-            if (gdst[it] < 0) continue;
-            split_store(b, Cfg::GPLANE, gdst[it], x3wg_mask(gv[it], g_dok && ((gok >> it) & 1u), g_dok && ((gokh >> it) & 1u)), sg);
-        }
+    auto store_g_piece = [&](int it, int od, bool live) {
+        const bool in = gdst[it] >= 0 && live;
+        char *b = in ? gbase + (od & 1) * Cfg::G_BYTES : dummy;
+        const int off = in ? 2 * gdst[it] : ((2 * gdst[it]) & 8191);
+        split_store(b, in ? 2 * Cfg::GPLANE : 8192, off, x3wg_mask(gv[it], g_dok && ((gok >> it) & 1u), g_dok && ((gokh >> it) & 1u)), sg);
     };
+    auto load_x_piece = [&](int it, const float *b) { xv[it] = x3wg_ld4<A16>(b, xoff[it], xoffh[A16 ? 0 : it]); };
+    auto load_g_piece = [&](int it, const float *b) { gv[it] = x3wg_ld4<A16>(b, goff[it], goffh[A16 ? 0 : it]); };
 
     f32x4 acc[27];
 #pragma unroll
@@ -1097,10 +1103,12 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
     // prologue: planes d0 - 1, d0, d0 + 1 and gradient plane d0 into LDS; plane d0 + 2 and gradient plane d0 + 1 into registers
     for (int k = -1; k <= 1; ++k) {
         load_x(d0 + k);
-        store_x(d0 + k);
+#pragma unroll
+        for (int it = 0; it < XNIT; ++it) store_x_piece(it, d0 + k, true);
     }
     load_g(d0);
-    store_g(d0);
+#pragma unroll
+    for (int it = 0; it < GNIT; ++it) store_g_piece(it, d0, true);
     load_x(d0 + 2);
     load_g(d0 + 1);
     __syncthreads();
@@ -1108,20 +1116,15 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
     // byte offsets of this lane's operands inside a staged row set
     const int xlane = ((cih * 16 + i16) * XCOLS + ((kg ^ (2 * ((i16 >> 2) & 1))) * 8)) * 2;
     const int glane = ((coh * 16 + i16) * GCOLS + 8 + 8 * kg) * 2;
-    auto stage = [&](int od) {            // the registers hold input plane od + 2 and gradient plane od + 1: split them into LDS, then
-        if (od + 1 < d1) {                // fetch the planes behind them (consumed one step later: their latency is a whole step)
-            store_x(od + 2);
-            store_g(od + 1);
-            if (od + 2 < d1) {
-                load_x(od + 3);
-                load_g(od + 2);
-            }
-        }
-    };
+    static_assert(XNIT == 3 && GNIT == 3, "one piece per (row, kd) of a step: 3 x pieces behind the first row, 3 g pieces behind the second");
     for (int od = d0; od < d1; ++od) {
-        if (kp == 0) stage(od);          // the SIMD's other wave (kp == 1) runs its MFMAs meanwhile
+        const bool live = od + 1 < d1;       // the registers' planes (input od + 2, gradient od + 1) have a step that reads them
+        // where the registers are refilled from: input plane od + 3, gradient plane od + 2 (read by the step after next; beyond the
+        // walk or the grid the loads read a valid plane and the split writes zeros)
+        const bool nx = (unsigned)(od + 3) < (unsigned)a.D, ng = od + 2 < a.D;
+        const float *const xnext = xs + (int64_t)(nx ? od + 3 : 0) * hw, *const gnext = gs + (int64_t)(ng ? od + 2 : 0) * hw;
         const char *const gplane = gbase + (od & 1) * Cfg::G_BYTES + glane;
-#pragma unroll 1      // (unrolled: spills, no gain)
+#pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int rg = 2 * kp + rr;
             // the gradient row's three column shifts (hi and lo): kw = 0 -> g[u + 1], kw = 1 -> g[u], kw = 2 -> g[u - 1]; the shifted
@@ -1156,11 +1159,23 @@ conv3d_wgrad_x3_kernel(const X3WgArgs a) {
                             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pr == 2 ? xl : xh, __builtin_bit_cast(h8w, gb[pr == 1 ? 1 : 0][kw]),
                                                                             acc[t], 0, 0, 0);
                         }
+                    if (kh == 0) {           // one staged piece per (row, kd): split it into LDS, refill its registers for the step after next
+                        if (rr == 0) {
+                            store_x_piece(kd, od + 2, live);
+                            load_x_piece(kd, xnext);
+                        } else {
+                            store_g_piece(kd, od + 1, live);
+                            load_g_piece(kd, gnext);
+                        }
+                    }
                 }
             }
         }
-        if (kp == 1) stage(od);
-        __syncthreads();                 // plane od + 2 / gradient plane od + 1 are in LDS; every read of plane od - 1 is done
+        x_dok = nx;
+        g_dok = ng;
+        // plane od + 2 / gradient plane od + 1 are in LDS; every read of plane od - 1 is done.  A bare barrier (LDS traffic only:
+        // the refills stay in flight across it)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // ---- partial slab [col * 2 + kp][pair][tap][cg 32][cx 32]: D[i = x channel 4 kg + r][j = g channel i16]
     float *pp = a.partial + (((int64_t)(col * 2 + kp) * a.pairs + pair) * 27) * 1024 + (coh * 16 + i16) * 32 + cih * 16 + 4 * kg;
@@ -1514,6 +1529,7 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
         b.x = x; b.g = g; b.partial = (float *)workspace;
         b.N = d->N; b.Cx = d->Cin; b.Cg = d->Cout; b.D = d->Dout; b.H = d->Hout; b.W = d->Wout;
         b.cx_blocks = a.cx_blocks; b.pairs = pairs; b.pairs32 = pairs; b.x_bs = a.x_bs; b.g_bs = a.g_bs;
+        b.dbg = 0;
         b.hblocks = ceil_div(d->Hout, X3WgCfg::TH); b.wsegs = ceil_div(d->Wout, 32);
         const int64_t cols = (int64_t)d->N * b.hblocks * b.wsegs;
         // depth parts: enough jobs for every CU once, columns at least 8 planes long, at most 256 columns x parts (512 slabs, the
@@ -1538,11 +1554,11 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
             static std::atomic<unsigned> attr_x3{0}, attr_x3u{0};
             const unsigned nwg = (unsigned)(8 * ceil_div(b.njobs, 8));
             if (a.vec == 4) {
-                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3_kernel<true>), X3WgCfg::LDS_BYTES, attr_x3))
-                    conv3d_wgrad_x3_kernel<true><<<dim3(nwg), X3WgCfg::THREADS, X3WgCfg::LDS_BYTES, st>>>(b);
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3_kernel<true>), X3WgCfg::LDS_ALLOC, attr_x3))
+                    conv3d_wgrad_x3_kernel<true><<<dim3(nwg), X3WgCfg::THREADS, X3WgCfg::LDS_ALLOC, st>>>(b);
             } else {
-                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3_kernel<false>), X3WgCfg::LDS_BYTES, attr_x3u))
-                    conv3d_wgrad_x3_kernel<false><<<dim3(nwg), X3WgCfg::THREADS, X3WgCfg::LDS_BYTES, st>>>(b);
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_wgrad_x3_kernel<false>), X3WgCfg::LDS_ALLOC, attr_x3u))
+                    conv3d_wgrad_x3_kernel<false><<<dim3(nwg), X3WgCfg::THREADS, X3WgCfg::LDS_ALLOC, st>>>(b);
             }
             int rcx = check_launch("snvc_conv3d_wgrad(split operands)");
             if (rcx) return rcx;
@@ -1578,7 +1594,7 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
         X3WgArgs b;
         b.x = x; b.g = g; b.partial = (float *)workspace;
         b.N = d->N; b.Cx = d->Cin; b.Cg = d->Cout; b.D = d->Dout; b.H = d->Hout; b.W = d->Wout;
-        b.cx_blocks = a.cx_blocks; b.pairs32 = pairs; b.pairs = ceil_div(d->Cout, 64) * a.cx_blocks; b.x_bs = a.x_bs; b.g_bs = a.g_bs;
+        b.cx_blocks = a.cx_blocks; b.pairs32 = pairs; b.pairs = ceil_div(d->Cout, 64) * a.cx_blocks; b.x_bs = a.x_bs; b.g_bs = a.g_bs; b.dbg = 0;
         b.hblocks = ceil_div(d->Hout, X3S2WgCfg::TH); b.wsegs = ceil_div(d->Wout, 32);
         const int64_t cols = (int64_t)d->N * b.hblocks * b.wsegs;
         int dparts = 1;
