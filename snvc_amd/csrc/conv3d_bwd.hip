@@ -930,7 +930,6 @@ struct X3WgArgs {
     int cx_blocks, pairs, hblocks, wsegs, dparts, dchunk, njobs;
     int pairs32;                // stride-2 form: 32 x 32 channel pairs of the slab layout (its jobs take 64 g channels)
     int64_t x_bs, g_bs;
-    int dbg;
 };
 
 // the maximum of the SNVC_AMAX_SLOTS words a producer pass left (snvc_affine_act_amax ...): every lane reads one, the wave reduces
@@ -1529,7 +1528,6 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
         b.x = x; b.g = g; b.partial = (float *)workspace;
         b.N = d->N; b.Cx = d->Cin; b.Cg = d->Cout; b.D = d->Dout; b.H = d->Hout; b.W = d->Wout;
         b.cx_blocks = a.cx_blocks; b.pairs = pairs; b.pairs32 = pairs; b.x_bs = a.x_bs; b.g_bs = a.g_bs;
-        b.dbg = 0;
         b.hblocks = ceil_div(d->Hout, X3WgCfg::TH); b.wsegs = ceil_div(d->Wout, 32);
         const int64_t cols = (int64_t)d->N * b.hblocks * b.wsegs;
         // depth parts: enough jobs for every CU once, columns at least 8 planes long, at most 256 columns x parts (512 slabs, the
@@ -1594,7 +1592,7 @@ int snvc_conv3d_wgrad_amax(const snvc_conv3d_desc *d, const float *x, const floa
         X3WgArgs b;
         b.x = x; b.g = g; b.partial = (float *)workspace;
         b.N = d->N; b.Cx = d->Cin; b.Cg = d->Cout; b.D = d->Dout; b.H = d->Hout; b.W = d->Wout;
-        b.cx_blocks = a.cx_blocks; b.pairs32 = pairs; b.pairs = ceil_div(d->Cout, 64) * a.cx_blocks; b.x_bs = a.x_bs; b.g_bs = a.g_bs; b.dbg = 0;
+        b.cx_blocks = a.cx_blocks; b.pairs32 = pairs; b.pairs = ceil_div(d->Cout, 64) * a.cx_blocks; b.x_bs = a.x_bs; b.g_bs = a.g_bs;
         b.hblocks = ceil_div(d->Hout, X3S2WgCfg::TH); b.wsegs = ceil_div(d->Wout, 32);
         const int64_t cols = (int64_t)d->N * b.hblocks * b.wsegs;
         int dparts = 1;
