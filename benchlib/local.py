@@ -184,13 +184,15 @@ def off_fast_path(device, reps=10):
         for tag, x3gn in (("cfg2_groupnorm", True), ("cfg2_groupnorm_fp32_mfma", False)):
             S_.X3_GROUP_NORM[0] = x3gn
             try:
-                b = S_._ROUTES["x3_gn_tail"]
+                b, b_first = S_._ROUTES["x3_gn_tail"], S_._ROUTES["gn_sheared_first_conv"]
                 ms, _ = timed_ms(lambda: g.forward_pair(left, right, shift, 1), reps, 3)
             finally:
                 S_.X3_GROUP_NORM[0] = True
             out[tag] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms, "split_mode": S_._ROUTES["x3_gn_tail"] > b,
-                        "note": "GlobalStack(gn=True): every norm needs its conv result's statistics -- the volume is built, each layer is "
-                                "convolution -> statistics -> affine pass (r5: the convolutions in split mode, nothing fused around them)"}
+                        "sheared_first_layer": S_._ROUTES["gn_sheared_first_conv"] > b_first,
+                        "note": "GlobalStack(gn=True): every norm needs its conv result's statistics -- each layer is convolution -> "
+                                "statistics -> affine pass in split mode; r6: on uniformly spaced planes the first layer is the sheared one "
+                                "with its statistics from snvc_sheared_expand_stats (one channel per group), the 1.47 GB volume is not built"}
         del g
         torch.cuda.empty_cache()
         # 3. downsample = 2: features at twice the resolution, the volume sampled at every second pixel (materialised volume)

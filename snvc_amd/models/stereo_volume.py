@@ -334,6 +334,53 @@ class GlobalStack(nn.Module):
             raise SplitOverflow()
         return cost
 
+    def _gn_sheared_first_layer(self, left, right, shift, arithmetic=None):
+        """``GlobalStack(gn=True)`` on uniformly spaced disparity planes WITHOUT the 1.47 GB volume (r6): with one
+        channel per group -- GroupNorm(32, 32), what convbn_3d(..., gn=True) builds for 32 channels, reference submodule.py:41-49 --
+        the first layer's statistics are per (sample, channel) over the volume, which is what the sheared layer's statistics pass
+        computes for a train-mode BatchNorm at batch 1 (snvc_sheared_expand_stats: the raw result is never stored).  Per sample:
+        statistics, then the expand pass applies scale / shift + ReLU and writes the split pair the split-mode GroupNorm tail reads.
+        Returns None when the call does not qualify (another spacing, rows the sheared kernels do not cover, split mode off)."""
+        from .submodule import SplitT, x3_exponent, x3_norm_bound
+        conv, norm = self.conv1[0][0], self.conv1[0][1]
+        guard = self._gn_qualifies(left.device, arithmetic)
+        if guard is None:
+            return None
+        nonneg, structure = self._shift_structure(shift)
+        assert nonneg                              # reference __init__.py:12
+        n, c, h, w = left.shape
+        d = shift.size(1)
+        if structure is None or not self._sheared_fits(structure[0], structure[1], d, w, True):
+            return None
+        q, m0 = structure
+        wt = conv.weight
+        plans = conv.__dict__.setdefault("_snvc_factored", {})
+        key = (wt.data_ptr(), wt._version, wt.device, _GENERATION[0])
+        if plans.get("key") != key:
+            plans.clear()
+            plans.update(key=key, right=ops.Conv3dLayer(wt.detach()[:, c:].contiguous(), 3, 1, 1, 1, False), plan=_Plan())
+        planes = self._left_planes_layer(plans, wt.detach()[:, :c])(left.unsqueeze(2)).view(n, c, 3, h, w)
+        lay_g, lay_col = self._sheared_layers(plans, wt.detach()[:, c:], q)
+        off, wu, off_col, wu_col = sheared_geometry(q, m0, d, w)
+        g = lay_g(ops.sheared_upsample(right, q, wu, off).unsqueeze(2)).squeeze(2)
+        gcol = lay_col(ops.sheared_upsample(right, q, wu_col, off_col).unsqueeze(2)).squeeze(2)
+        b1 = x3_norm_bound(norm, conv.__dict__.setdefault("_snvc_plans_x3", {}).setdefault(left.device, _Plan()))
+        e1 = x3_exponent(b1)
+        v1s = self._buffer("v1s", (n, 2, c // 8, d, h, w, 8), left.device, torch.float16)
+        gam = norm.weight.detach() if norm.weight is not None else None
+        bet = norm.bias.detach() if norm.bias is not None else None
+        try:
+            for i in range(n):                     # GroupNorm statistics are per sample
+                sc, sh, _, _ = ops.sheared_expand_stats(g[i:i + 1], gcol[i:i + 1], planes[i:i + 1], gam, bet, (1, c, d, h, w), q, m0, off,
+                                                        off_col, norm.eps)
+                ops.sheared_expand_split(g[i:i + 1], gcol[i:i + 1], planes[i:i + 1], (sc * 2.0 ** e1).reshape(-1).contiguous(),
+                                         (sh * 2.0 ** e1).reshape(-1).contiguous(), v1s[i:i + 1], q, m0, off, off_col, ops.EPI_RELU, guard.flag)
+        except ops.Unsupported:
+            return None
+        _ROUTES["gn_sheared_first_conv"] += 1
+        self.__dict__["_snvc_last_v1"] = "v1s"
+        return self._gn_tail_x3(SplitT(v1s, e1, b1), None, arithmetic)
+
     def _conv2_tail(self, v1, shape, timing=None, arithmetic=None):
         gn_cost = self._gn_tail_x3(v1, timing, arithmetic)
         if gn_cost is not None:
@@ -644,6 +691,13 @@ class GlobalStack(nn.Module):
             return self._tail(self.conv2(v))
         usable = (factored and downsample == 1 and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
                   and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)
+        if (not usable and factored and sheared and downsample == 1 and timing is None and not torch.is_grad_enabled() and not self.training
+                and isinstance(bn, nn.GroupNorm) and bn.num_groups == conv.out_channels and left.is_cuda and left.dtype == torch.float32
+                and left.size(3) % 8 == 0 and left.size(3) <= 512 and shift.size(1) >= 4 and shift.dtype == torch.float32
+                and left.size(0) > 0 and left.size(1) % 8 == 0 and left.size(1) * 2 == conv.in_channels):
+            cost = self._gn_sheared_first_layer(left, right, shift, arithmetic)       # r6; None: the paths below
+            if cost is not None:
+                return cost
         if not usable:
             if timing is None:
                 vol = _BuildCostVolume.apply(left, right, shift, downsample)      # the eager volume

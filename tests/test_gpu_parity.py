@@ -1233,6 +1233,43 @@ def test_global_pair_groupnorm_split_tail_vs_oracle():
     check(got32, exp, 1e-4, "GroupNorm pair (fp32 MFMA)")
 
 
+@pytest.mark.parametrize("spacing", ["half_pixel", "whole_pixel"])
+def test_global_pair_groupnorm_sheared_first_layer_vs_oracle(spacing):
+    """r6: GlobalStack(gn=True) on uniformly spaced planes takes the sheared first layer with GroupNorm statistics from the sheared
+    statistics pass (one channel per group: per-sample, per-channel statistics; the concat volume and conv1's 64-channel
+    convolution over it are not built): against the oracle's GroupNorm stack (reference submodule.py:41-49 composed as
+    vernier.py:128-142) on the C oracle's volume, two samples with different statistics."""
+    from oracle import native as O
+    from oracle import torch_ref as T
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    r = np.random.default_rng(47)
+    C, H, W, D = 32, 16, 40, 16
+    L = r.standard_normal((2, C, H, W)).astype(np.float32)
+    R = r.standard_normal((2, C, H, W)).astype(np.float32)
+    R[1] *= 3.0                                   # the two samples' statistics differ
+    row = np.linspace(0, (D - 1) / 2, D) if spacing == "half_pixel" else np.linspace(2, D + 1, D)
+    s = np.stack([row, row]).astype(np.float32)
+    ref = seeded(T.GlobalStack(C, gn=True), 45)
+    ours = seeded(GlobalStack(C, gn=True), 45).to(dev())
+    dl, dr, dsh = torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()), torch.from_numpy(s).to(dev())
+    with torch.no_grad():
+        exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, 1))).numpy()
+        b = S._ROUTES["gn_sheared_first_conv"]
+        got = ours.forward_pair(dl, dr, dsh, 1).cpu().numpy()
+        assert S._ROUTES["gn_sheared_first_conv"] == b + 1, "the GroupNorm stack did not take the sheared first layer"
+        from snvc_amd.extension.build_cost_volume import build_cost_volume
+        got_api = ours(build_cost_volume(dl, dr, dsh, 1)).cpu().numpy()
+        assert S._ROUTES["gn_sheared_first_conv"] == b + 2
+        got_general = ours.forward_pair(dl, dr, dsh, 1, sheared=False).cpu().numpy()       # the materialised route, as r5
+        assert S._ROUTES["gn_sheared_first_conv"] == b + 2
+        with pytest.raises(AssertionError):
+            ours.forward_pair(dl, dr, dsh - 5.0, 1)
+    check(got, exp, 1e-4, "GroupNorm pair (sheared first layer)")
+    check(got_api, exp, 1e-4, "GroupNorm pair through model(build_cost_volume(...))")
+    check(got_general, exp, 1e-4, "GroupNorm pair (materialised volume)")
+
+
 @pytest.mark.parametrize("case", ["random", "whole_pixels", "beyond_the_image", "odd_width", "deep"])
 def test_warped_expand_backward_vs_oracle(case):
     """snvc_warped_expand_backward (r4: the adjoint of the any-shift first layer) against the C oracle's cost-volume backward
