@@ -254,3 +254,40 @@ def test_groupnorm_trunk_extreme_input_stays_exact():
             warnings.simplefilter("error")
             m.trunk_3d(dense)
         assert S._ROUTES["x3_local_trunk"] == b + 1 and not m.__dict__.get("_snvc_x3_off")
+
+
+def test_conv5_cannot_clamp_at_the_limit_its_inputs_allow():
+    """the overflow flag is posted BEFORE conv5 (the host's look at it overlaps conv5 + the tail gather) on the argument that
+    conv5's result carries a HARD exponent -- L1 norm of its folded weights x the largest value its input's exponent can hold + the
+    largest `pre` -- and so cannot clamp.  Driven to that limit here: every weight made non-negative, the BatchNorm scale positive,
+    `o` and `pre` at the largest split value (hi = 65504, lo = +16) everywhere, so that every term of every interior output adds up
+    to the bound itself: the flag must stay 0 and the tail finite."""
+    from snvc_amd import ops
+    m = _global_stack()
+    hg = m.hg_conv3d
+    with torch.no_grad():
+        hg.conv5[0].weight.abs_()
+        hg.conv5[1].weight.abs_().add_(0.5)
+        hg.conv5[1].running_mean.zero_()
+        hg.conv5[1].bias.abs_()
+    st = m._x3_state(dev())
+    assert st is not None and st["tail"] is not None
+    L, A, E = st["layers"], st["affine"], st["exp"]
+    n, d4, h4, w4 = 1, 4, 4, 20
+    hi = torch.full((n, 1, 8, d4, h4, w4, 8), 65504.0, dtype=torch.float16, device=dev())
+    lo = torch.full_like(hi, 16.0)
+    o = torch.cat([hi, lo], dim=1).contiguous()                                   # [n, 2, 64/8, D/4, H/4, W/4, 8] at exponent E["h4"]
+    pre = torch.cat([torch.full((n, 1, 8, 2 * d4, 2 * h4, 2 * w4, 8), 65504.0, dtype=torch.float16, device=dev()),
+                     torch.full((n, 1, 8, 2 * d4, 2 * h4, 2 * w4, 8), 16.0, dtype=torch.float16, device=dev())], dim=1).contiguous()
+    flag = torch.zeros(1, dtype=torch.int32, device=dev())
+    t = L["h5"].forward_tail(o, E["h4"], *A["h5"], st["tail"], residual=pre, res_exp=E["h2"], flags=ops.EPI_RELU | ops.EPI_ADD_PRE,
+                             out_exp=E["post"], overflow=flag, out=torch.empty((n, 27, 8, d4, h4, w4), device=dev()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0, "conv5 clamped inside the range its hard exponent promises"
+    assert torch.isfinite(t).all()
+    # and the bound is not vacuous: one exponent step less headroom does clamp on this input
+    flag.zero_()
+    L["h5"].forward_tail(o, E["h4"], *A["h5"], st["tail"], residual=pre, res_exp=E["h2"], flags=ops.EPI_RELU | ops.EPI_ADD_PRE,
+                         out_exp=E["post"] + 2, overflow=flag, out=torch.empty((n, 27, 8, d4, h4, w4), device=dev()))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
