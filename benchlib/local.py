@@ -7,7 +7,7 @@ import types
 import numpy as np
 import torch
 
-from .common import (C, CV_BYTES, H, PEAK_F16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS, W, make_inputs, parity_vs, prewarm,
+from .common import (C, CV_BYTES, D, H, PEAK_F16_MFMA_TFLOPS, PEAK_F32_MFMA_TFLOPS, PEAK_HBM_GBS, W, make_inputs, parity_vs, prewarm,
                      projected_coordinates, seeded_state, timed_ms, wino_executed_share)
 from .cpu import local_inputs, local_oracle
 from .emit import rank_note
@@ -204,8 +204,16 @@ def off_fast_path(device, reps=10):
         r2 = torch.from_numpy(r.standard_normal((1, C, 2 * H, 2 * W)).astype(np.float32)).to(device)
         ms, _ = timed_ms(lambda: g(build_cost_volume(l2, r2, shift, 2)), reps, 3)
         out["cfg2_downsample_2"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms,
-                                    "note": "model(build_cost_volume(left [1,32,192,624], right, shift, 2)): same volume shape as cfg2, "
-                                            "the eager op + conv1 over all 64 channels (the fused first layer is built for downsample 1)"}
+                                    "note": "model(build_cost_volume(left [1,32,192,624], right, shift, 2)) with cfg2's half-pixel shift "
+                                            "array (quarter-pixel planes of the volume: four phases): the eager op + conv1 over all 64 channels"}
+        # r6: the sweep that covers cfg2's disparity range at this resolution -- planes ONE input pixel apart -- takes the sheared first layer
+        shift1 = torch.arange(D, dtype=torch.float32, device=device)[None].contiguous()
+        b2 = S_._ROUTES["ds2_sheared_first_conv"]
+        ms, _ = timed_ms(lambda: g.forward_pair(l2, r2, shift1, 2), reps, 3)
+        out["cfg2_downsample_2_whole_pixel_planes"] = {
+            "ms_per_step": ms, "pairs_per_s": 1e3 / ms, "sheared_first_layer": S_._ROUTES["ds2_sheared_first_conv"] > b2,
+            "note": "forward_pair(left [1,32,192,624], right, shift = 0..191, 2): same volume as cfg2 (the same sampling positions), the "
+                    "row-subsampled right feature stands where the half-pixel upsampled one stands at downsample 1"}
         del g, l2, r2
         torch.cuda.empty_cache()
         # 4. fp64: the cost-volume op (the 3D stack has no fp64 kernels; neither does a user of the reference get one from cuDNN at speed)

@@ -39,20 +39,21 @@ class _BuildCostVolume(Function):
 
 
 def build_cost_volume(left, right, shift, downsample):
-    """Reference signature (__init__.py:26).  With autograd on, or for anything but the fp32 / downsample-1 case of the
+    """Reference signature (__init__.py:26).  With autograd on, or for anything but the fp32 / downsample 1 or 2 case of the
     global model, this is the eager autograd function.  Under ``torch.no_grad()`` the result is a ``LazyCostVolume``
     (snvc_amd/lazy.py): a tensor of the volume's shape that ``GlobalStack.forward`` consumes without building it and that
     turns into the real volume -- the same values -- on any other use."""
-    lazy_ok = (not torch.is_grad_enabled() and downsample == 1 and left.is_cuda and left.dtype == torch.float32 and
+    lazy_ok = (not torch.is_grad_enabled() and downsample in (1, 2) and left.is_cuda and left.dtype == torch.float32 and
                left.dim() == 4 and left.shape == right.shape and shift.dim() == 2 and shift.shape[0] == left.shape[0] and
-               not (left.requires_grad or right.requires_grad))
+               not (left.requires_grad or right.requires_grad) and
+               (downsample == 1 or (left.shape[2] % 2 == 0 and left.shape[3] % 2 == 0)))      # r6: downsample 2 has a fused route too
     if not lazy_ok:
         return _BuildCostVolume.apply(left, right, shift, downsample)
     from ...lazy import CONSUMER, LazyCostVolume
     from ... import ops
     spacing = "unknown"
     ref = CONSUMER.ref
-    model = ref() if ref is not None else None
+    model = ref() if (ref is not None and downsample == 1) else None
     if model is not None:
         # r5: the model that consumed the previous lazy volume runs this call's step up to its one host sync -- the same check of
         # `shift` as below (an AssertionError comes out of here, reference __init__.py:12) -- with its first-layer prep queued in

@@ -334,6 +334,53 @@ class GlobalStack(nn.Module):
             raise SplitOverflow()
         return cost
 
+    def _ds2_sheared_first_layer(self, left, right, shift, arithmetic=None):
+        """``downsample = 2`` (features at twice the volume's resolution, BuildCostVolume_cuda.cu:224-225: out[d,h,w] samples the right
+        feature on row 2h at x = 2w - shift[d]) with disparity planes one INPUT pixel apart -- shift[d] = m0 + d, the plane sweep that
+        covers the same range as cfg2's half-pixel sweep at full resolution -- is the sheared layer with two phases (r6; VERDICT r5
+        item 7): the row-subsampled right feature itself stands where the half-pixel upsampled one stands at downsample 1
+        (index 2w - m0 - d of a 2W-wide row either way), the left feature is subsampled in both directions.  Nothing else changes:
+        same 3 x 7 layers, same expand pass, same tail.  Any other spacing (q*ds > 2) returns None -> the materialised route."""
+        conv, bn = self.conv1[0][0], self.conv1[0][1]
+        nonneg, structure = self._shift_structure(shift)
+        assert nonneg                              # reference __init__.py:12
+        if structure is None or structure[0] != 1:
+            return None
+        m0 = structure[1]
+        n, c = left.size(0), left.size(1)
+        h, w, d = left.size(2) // 2, left.size(3) // 2, shift.size(1)
+        if not self._sheared_fits(2, m0, d, w, False):
+            return None
+        st = self._x3_select(left.device, arithmetic)
+        left_s = left[:, :, ::2, ::2].contiguous()
+        right_r = right[:, :, ::2, :].contiguous()           # rows 2h; every input column
+        wt = conv.weight
+        plans = conv.__dict__.setdefault("_snvc_factored", {})
+        key = (wt.data_ptr(), wt._version, wt.device, _GENERATION[0])
+        if plans.get("key") != key:
+            plans.clear()
+            plans.update(key=key, right=ops.Conv3dLayer(wt.detach()[:, c:].contiguous(), 3, 1, 1, 1, False), plan=_Plan())
+        scale, bias = _folded_bn(bn, plans["plan"])
+        planes = self._left_planes_layer(plans, wt.detach()[:, :c])(left_s.unsqueeze(2)).view(n, c, 3, h, w)
+        lay_g, lay_col = self._sheared_layers(plans, wt.detach()[:, c:], 2)
+        off, wu, off_col, wu_col = sheared_geometry(2, m0, d, w)
+        g = lay_g(ops.sheared_upsample(right_r, 1, wu, off).unsqueeze(2)).squeeze(2)
+        gcol = lay_col(ops.sheared_upsample(right_r, 1, wu_col, off_col).unsqueeze(2)).squeeze(2)
+        shape = (n, c, d, h, w)
+        try:
+            if st is not None:
+                v1s = self._buffer("v1s", (n, 2, c // 8, d, h, w, 8), left.device, torch.float16)
+                ops.sheared_expand_split(g, gcol, planes, *self._x3_v1_affine(st, scale, bias), v1s, 2, m0, off, off_col, ops.EPI_RELU, st["flag"])
+                _ROUTES["ds2_sheared_first_conv"] += 1
+                self.__dict__["_snvc_last_v1"] = "v1s"
+                return self._tail_x3(st, v1s, None)
+            v = self._buffer("v1", shape, left.device)
+            ops.sheared_expand(g, gcol, planes, scale, bias, v, 2, m0, off, off_col, ops.EPI_RELU)
+        except ops.Unsupported:
+            return None
+        _ROUTES["ds2_sheared_first_conv"] += 1
+        return self._conv2_tail(v, shape, None, arithmetic)
+
     def _gn_sheared_first_layer(self, left, right, shift, arithmetic=None):
         """``GlobalStack(gn=True)`` on uniformly spaced disparity planes WITHOUT the 1.47 GB volume (r6): with one
         channel per group -- GroupNorm(32, 32), what convbn_3d(..., gn=True) builds for 32 channels, reference submodule.py:41-49 --
@@ -691,6 +738,13 @@ class GlobalStack(nn.Module):
             return self._tail(self.conv2(v))
         usable = (factored and downsample == 1 and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
                   and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)
+        if (downsample == 2 and factored and sheared and timing is None and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
+                and not bn.training and left.is_cuda and left.dtype == torch.float32 and left.size(2) % 2 == 0 and left.size(3) % 8 == 0
+                and left.size(3) <= 1024 and shift.size(1) >= 4 and shift.dtype == torch.float32 and left.size(0) > 0
+                and left.size(1) % 8 == 0 and left.size(1) * 2 == conv.in_channels and left.shape == right.shape):
+            cost = self._ds2_sheared_first_layer(left, right, shift, arithmetic)      # r6; None: the materialised route below
+            if cost is not None:
+                return cost
         if (not usable and factored and sheared and downsample == 1 and timing is None and not torch.is_grad_enabled() and not self.training
                 and isinstance(bn, nn.GroupNorm) and bn.num_groups == conv.out_channels and left.is_cuda and left.dtype == torch.float32
                 and left.size(3) % 8 == 0 and left.size(3) <= 512 and shift.size(1) >= 4 and shift.dtype == torch.float32

@@ -1107,7 +1107,9 @@ def test_lazy_cost_volume_reference_call_sequence():
     # other dtypes / downsample: eager
     with torch.no_grad():
         assert not isinstance(build_cost_volume(L.double(), R.double(), S_.double(), 1), LazyCostVolume)
-        assert not isinstance(build_cost_volume(L, R, S_, 2), LazyCostVolume)
+        v2 = build_cost_volume(L, R, S_, 2)                  # r6: downsample 2 is lazy too (even extents); its values are the eager op's
+        assert isinstance(v2, LazyCostVolume) and torch.equal(v2.materialize(), ops.cost_volume_forward(L, R, S_, 2))
+        assert not isinstance(build_cost_volume(L, R, S_, 4), LazyCostVolume)
 
 
 @pytest.mark.parametrize("tile", ["default", "big", "narrow"])
@@ -1231,6 +1233,48 @@ def test_global_pair_groupnorm_split_tail_vs_oracle():
     check(got, exp, 1e-4, "GroupNorm pair (split tail)")
     check(got_api, exp, 1e-4, "GroupNorm pair through model(build_cost_volume(...))")
     check(got32, exp, 1e-4, "GroupNorm pair (fp32 MFMA)")
+
+
+@pytest.mark.parametrize("m0", [0, 3])
+@pytest.mark.parametrize("arith", ["auto", "fp32"])
+def test_global_pair_downsample_2_sheared_vs_oracle(m0, arith):
+    """r6: downsample = 2 with planes one input pixel apart takes the sheared first layer (the row-subsampled right feature in the
+    place of the half-pixel upsampled one): against the oracle -- the C restatement of BuildCostVolume_cuda.cu:63-98 at downsample 2
+    + the torch-CPU stack -- and against the materialised route; a half-pixel sweep at downsample 2 (four phases) still
+    materialises."""
+    from oracle import native as O
+    from oracle import torch_ref as T
+    from snvc_amd.extension.build_cost_volume import build_cost_volume
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    r = np.random.default_rng(51 + m0)
+    C, H, W, D = 32, 8, 40, 12
+    L = r.standard_normal((2, C, 2 * H, 2 * W)).astype(np.float32)
+    R = r.standard_normal((2, C, 2 * H, 2 * W)).astype(np.float32)
+    row = (m0 + np.arange(D)).astype(np.float32)
+    s = np.stack([row, row])
+    ref = seeded(T.GlobalStack(C), 52)
+    ours = seeded(GlobalStack(C), 52).to(dev())
+    dl, dr, dsh = torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()), torch.from_numpy(s).to(dev())
+    a = None if arith == "auto" else "fp32"
+    with torch.no_grad():
+        exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, 2))).numpy()
+        b = S._ROUTES["ds2_sheared_first_conv"]
+        got = ours.forward_pair(dl, dr, dsh, 2, arithmetic=a).cpu().numpy()
+        assert S._ROUTES["ds2_sheared_first_conv"] == b + 1, "downsample 2 did not take the sheared first layer"
+        got_mat = ours.forward_pair(dl, dr, dsh, 2, sheared=False, arithmetic=a).cpu().numpy()
+        assert S._ROUTES["ds2_sheared_first_conv"] == b + 1
+        ours.forward_pair(dl, dr, dsh * 0.5, 2)                                    # half-pixel planes at downsample 2: not this route
+        assert S._ROUTES["ds2_sheared_first_conv"] == b + 1
+        if arith == "auto":
+            vol = build_cost_volume(dl, dr, dsh, 2)                                  # r6: a lazy volume at downsample 2 as well
+            got_api = ours(vol).cpu().numpy()
+            assert S._ROUTES["ds2_sheared_first_conv"] == b + 2 and not vol.is_materialized
+            check(got_api, exp, 1e-4, "downsample 2 through model(build_cost_volume(...))")
+            assert np.array_equal(build_cost_volume(dl, dr, dsh, 2).cpu().numpy(), O.cost_volume_forward(L, R, s, 2))    # any other use: the volume
+    check(got, exp, 1e-4, "downsample 2 (sheared first layer)")
+    check(got_mat, exp, 1e-4, "downsample 2 (materialised)")
+    check(got, got_mat, 2e-5, "sheared vs materialised")
 
 
 @pytest.mark.parametrize("spacing", ["half_pixel", "whole_pixel"])
