@@ -195,23 +195,24 @@ def off_fast_path(device, reps=10):
                                 "with its statistics from snvc_sheared_expand_stats (one channel per group), the 1.47 GB volume is not built"}
         del g
         torch.cuda.empty_cache()
-        # 3. downsample = 2: features at twice the resolution, the volume sampled at every second pixel (materialised volume)
+        # 3. downsample = 2: features at twice the resolution, the volume sampled at every second pixel
         g = GlobalStack(C)
         g.load_state_dict(seeded_state(g))
         g.eval().to(device)
         r = np.random.default_rng(3)
         l2 = torch.from_numpy(r.standard_normal((1, C, 2 * H, 2 * W)).astype(np.float32)).to(device)
         r2 = torch.from_numpy(r.standard_normal((1, C, 2 * H, 2 * W)).astype(np.float32)).to(device)
+        b4 = S_._ROUTES["ds_sheared_first_conv"]
         ms, _ = timed_ms(lambda: g(build_cost_volume(l2, r2, shift, 2)), reps, 3)
-        out["cfg2_downsample_2"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms,
+        out["cfg2_downsample_2"] = {"ms_per_step": ms, "pairs_per_s": 1e3 / ms, "sheared_first_layer": S_._ROUTES["ds_sheared_first_conv"] > b4,
                                     "note": "model(build_cost_volume(left [1,32,192,624], right, shift, 2)) with cfg2's half-pixel shift "
                                             "array (quarter-pixel planes of the volume: four phases): the eager op + conv1 over all 64 channels"}
         # r6: the sweep that covers cfg2's disparity range at this resolution -- planes ONE input pixel apart -- takes the sheared first layer
         shift1 = torch.arange(D, dtype=torch.float32, device=device)[None].contiguous()
-        b2 = S_._ROUTES["ds2_sheared_first_conv"]
+        b2 = S_._ROUTES["ds_sheared_first_conv"]
         ms, _ = timed_ms(lambda: g.forward_pair(l2, r2, shift1, 2), reps, 3)
         out["cfg2_downsample_2_whole_pixel_planes"] = {
-            "ms_per_step": ms, "pairs_per_s": 1e3 / ms, "sheared_first_layer": S_._ROUTES["ds2_sheared_first_conv"] > b2,
+            "ms_per_step": ms, "pairs_per_s": 1e3 / ms, "sheared_first_layer": S_._ROUTES["ds_sheared_first_conv"] > b2,
             "note": "forward_pair(left [1,32,192,624], right, shift = 0..191, 2): same volume as cfg2 (the same sampling positions), the "
                     "row-subsampled right feature stands where the half-pixel upsampled one stands at downsample 1"}
         del g, l2, r2

@@ -350,7 +350,12 @@ SNVC_API int snvc_conv3d_forward_stats(const snvc_conv3d_desc *desc_host, const 
  *                           last plane d = D-1: without kd = +1), stacked class-major as 3*C output channels
  *   snvc_sheared_expand   : y[n][co][d][h][w] = epilogue(scale*G[n][cls(d)][co][h][q*w - d - m0 + off] + planes[n][co][cls(d)][h][w]),
  *                           G'[..][q*(W-1) - d - m0 + off2] in place of G at w = W-1; g [N][3][C][H][WG], gcol [N][3][C][H][WG2],
- *                           planes = the depth-class planes of snvc_conv3d_forward_ex (or NULL). */
+ *                           planes = the depth-class planes of snvc_conv3d_forward_ex (or NULL).
+ * r6: snvc_sheared_expand / snvc_sheared_expand_split also take q = 4 (index 4*w - d - m0: four phases): the layer at
+ * `downsample` ds > 1 (BuildCostVolume_cuda.cu:224-225: x = ds*w - shift on row ds*h) is the same shear with q*ds phases of the
+ * row-subsampled right feature, upsampled by q alone -- ds = 2 with whole-pixel planes = two phases (the q = 2 kernels, Rq = the
+ * feature itself), ds = 2 with half-pixel planes and ds = 4 with whole-pixel planes = four.  With four phases the 3 x 11 kernel of G
+ * splits into three 3 x 3 layers whose results are added 4 elements apart (host side: models/stereo_volume.py). */
 /* The same first convolution for an ARBITRARY shift array (shift >= 0): linear interpolation along w commutes with the
  * convolution, so conv3d(warped half)[co][d][h][w] = sum_kd lerp(P_kd[co][h][:], w - shift[d+kd-1]) with P_kd = the depth-1 3x3
  * convolution of the right feature with the layer's kd slice -- three 2D convolutions computed once and three

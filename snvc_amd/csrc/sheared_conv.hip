@@ -1420,8 +1420,8 @@ int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, 
                         int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2,
                         int off2, int flags, void *stream) {
     using namespace snvc;
-    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || W % 4 != 0 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || WG2 <= 0)
-        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: bad sizes (W % 4 == 0, q in {1,2}, D >= 2)");
+    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || W % 4 != 0 || (q != 1 && q != 2 && q != 4) || m0 < 0 || WG <= 0 || WG2 <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: bad sizes (W % 4 == 0, q in {1,2,4}, D >= 2)");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: scale and bias must both be given or both be NULL");
     if (flags & ~SNVC_EPI_RELU) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand: only SNVC_EPI_RELU");
@@ -1437,8 +1437,12 @@ int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, 
     const size_t lds = sizeof(float) * ((size_t)RB * q * LW + (size_t)RB * D);
     if (lds > 150 * 1024) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand: rows do not fit the LDS");
     const dim3 grid((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N);
-    static std::atomic<unsigned> attr1{0}, attr2{0};
-    if (q == 1) {
+    static std::atomic<unsigned> attr1{0}, attr2{0}, attr4{0};
+    if (q == 4) {      // r6: four phases (downsample 2 with half-pixel planes, downsample 4 with whole-pixel planes: index 4 w - m0 - d)
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<4, 0>), (int)lds, attr4)) return check_launch("snvc_sheared_expand");
+        sheared_expand_kernel<4, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
+                                                                             (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
+    } else if (q == 1) {
         if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<1, 0>), (int)lds, attr1)) return check_launch("snvc_sheared_expand");
         sheared_expand_kernel<1, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
                                                                              (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
@@ -1454,8 +1458,8 @@ int snvc_sheared_expand_split(const float *g, const float *gcol, const float *pl
                               void *y_lo, int *overflow, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG,
                               int off, int64_t WG2, int off2, int64_t y_batch_stride, int flags, void *stream) {
     using namespace snvc;
-    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || (q != 1 && q != 2) || m0 < 0 || WG <= 0 || WG2 <= 0)
-        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: bad sizes (q in {1,2}, D >= 2)");
+    if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || (q != 1 && q != 2 && q != 4) || m0 < 0 || WG <= 0 || WG2 <= 0)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: bad sizes (q in {1,2,4}, D >= 2)");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand_split: scale and bias must both be given or both be NULL");
     if (flags & ~(SNVC_EPI_RELU | SNVC_EPI_STREAM_OUT)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_sheared_expand_split: only SNVC_EPI_RELU | SNVC_EPI_STREAM_OUT");
@@ -1477,9 +1481,13 @@ int snvc_sheared_expand_split(const float *g, const float *gcol, const float *pl
     const int threads = ceil_div((int)W, 64) * 64;
     const dim3 grid((unsigned)H, (unsigned)(G * DCH), (unsigned)N);
     const int64_t y_bs = y_batch_stride ? y_batch_stride : 2 * G * 8 * D * H * W;
-    static std::atomic<unsigned> attr1{0}, attr2{0};
+    static std::atomic<unsigned> attr1{0}, attr2{0}, attr4{0};
     _Float16 *yh = reinterpret_cast<_Float16 *>(y_hi), *yl = reinterpret_cast<_Float16 *>(y_lo);
-    if (q == 1) {
+    if (q == 4) {
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_split_kernel<4>), (int)lds, attr4)) return check_launch("snvc_sheared_expand_split");
+        sheared_expand_split_kernel<4><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, yh, yl, overflow, (int)C, (int)D, (int)H,
+                                                                              (int)W, m0, (int)WG, off, (int)WG2, off2, DCH, DC, y_bs, flags);
+    } else if (q == 1) {
         if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_split_kernel<1>), (int)lds, attr1)) return check_launch("snvc_sheared_expand_split");
         sheared_expand_split_kernel<1><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, yh, yl, overflow, (int)C, (int)D, (int)H,
                                                                               (int)W, m0, (int)WG, off, (int)WG2, off2, DCH, DC, y_bs, flags);

@@ -39,14 +39,14 @@ class _BuildCostVolume(Function):
 
 
 def build_cost_volume(left, right, shift, downsample):
-    """Reference signature (__init__.py:26).  With autograd on, or for anything but the fp32 / downsample 1 or 2 case of the
+    """Reference signature (__init__.py:26).  With autograd on, or for anything but the fp32 / downsample 1, 2 or 4 case of the
     global model, this is the eager autograd function.  Under ``torch.no_grad()`` the result is a ``LazyCostVolume``
     (snvc_amd/lazy.py): a tensor of the volume's shape that ``GlobalStack.forward`` consumes without building it and that
     turns into the real volume -- the same values -- on any other use."""
-    lazy_ok = (not torch.is_grad_enabled() and downsample in (1, 2) and left.is_cuda and left.dtype == torch.float32 and
+    lazy_ok = (not torch.is_grad_enabled() and downsample in (1, 2, 4) and left.is_cuda and left.dtype == torch.float32 and
                left.dim() == 4 and left.shape == right.shape and shift.dim() == 2 and shift.shape[0] == left.shape[0] and
                not (left.requires_grad or right.requires_grad) and
-               (downsample == 1 or (left.shape[2] % 2 == 0 and left.shape[3] % 2 == 0)))      # r6: downsample 2 has a fused route too
+               (left.shape[2] % downsample == 0 and left.shape[3] % downsample == 0))      # r6: downsample 2 and 4 have fused routes too
     if not lazy_ok:
         return _BuildCostVolume.apply(left, right, shift, downsample)
     from ...lazy import CONSUMER, LazyCostVolume

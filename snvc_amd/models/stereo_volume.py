@@ -334,26 +334,78 @@ class GlobalStack(nn.Module):
             raise SplitOverflow()
         return cost
 
-    def _ds2_sheared_first_layer(self, left, right, shift, arithmetic=None):
-        """``downsample = 2`` (features at twice the volume's resolution, BuildCostVolume_cuda.cu:224-225: out[d,h,w] samples the right
-        feature on row 2h at x = 2w - shift[d]) with disparity planes one INPUT pixel apart -- shift[d] = m0 + d, the plane sweep that
-        covers the same range as cfg2's half-pixel sweep at full resolution -- is the sheared layer with two phases (r6; VERDICT r5
-        item 7): the row-subsampled right feature itself stands where the half-pixel upsampled one stands at downsample 1
-        (index 2w - m0 - d of a 2W-wide row either way), the left feature is subsampled in both directions.  Nothing else changes:
-        same 3 x 7 layers, same expand pass, same tail.  Any other spacing (q*ds > 2) returns None -> the materialised route."""
+    @staticmethod
+    def _sheared_geometry4(m0: int, d: int, w: int):
+        """sheared_geometry for four phases (index 4 w - d - m0): the kernel's taps reach 5 elements either side, so Rq sits 8 elements
+        into its padded grid and the last column's window carries 5 elements of context."""
+        off = 8
+        wu = (off + 4 * (w - 1) + 1 + 5 + 5 + 3) // 4 * 4
+        u_lo = 4 * (w - 1) - (d - 1) - m0 - 5
+        return off, wu, 8 - u_lo, (d + 10 + 8 + 3) // 4 * 4
+
+    @staticmethod
+    def _sheared_layer4(plans, wr):
+        """Four phases: G[u] = sum over (kd, kh, kw) of w[kd, kh, kw] Rq[row + kh - 1][u + 4 kw - kd] is a 3 x 11 kernel with nine non-zero
+        columns = three 3 x 3 layers P_kw[u] = sum_{kd, kh} w[kd, kh, kw] Rq[row + kh - 1][u - kd] added 4 elements apart:
+        G[u] = P_-1[u - 4] + P_0[u] + P_+1[u + 4], and G' (the last column: no kw = +1 taps) = P_-1[u - 4] + P_0[u].  One depth-1 3 x 3
+        layer with 3 (kw) x 3 (depth class) x Cout output channels, folded in fp64 like sheared_kernels."""
+        if "sheared4" not in plans:
+            from .submodule import SHEAR_CLASS_KDS
+            w = wr.detach().double()                                        # [Cout, C, kd, kh, kw]
+            cout, c = w.shape[0], w.shape[1]
+            k = torch.zeros((3, 3, cout, c, 3, 3), dtype=torch.float64, device=w.device)      # [kw][cls][co][c][kh][1 - kd]
+            for cls, kds in enumerate(SHEAR_CLASS_KDS):
+                for kd in kds:
+                    for kw in (-1, 0, 1):
+                        k[kw + 1, cls, :, :, :, 1 - kd] += w[:, :, kd + 1, :, kw + 1]
+            plans["sheared4"] = ops.Conv3dLayer(k.reshape(9 * cout, c, 3, 3).float().contiguous(), 3, 1, 1, 1, False, planar=True)
+        return plans["sheared4"]
+
+    def _sheared4_inputs(self, plans, wr, rq_src, q_up, m0, d, w):
+        """(g, gcol, off, off_col) of the four-phase sheared layer: ``rq_src`` upsampled by ``q_up`` (1 or 2) is Rq."""
+        lay = self._sheared_layer4(plans, wr)
+        off, wu, off_col, wu_col = self._sheared_geometry4(m0, d, w)
+        out = []
+        for width, o_, last in ((wu, off, False), (wu_col, off_col, True)):
+            p = lay(ops.sheared_upsample(rq_src, q_up, width, o_).unsqueeze(2)).squeeze(2)      # [N, 9 Cout, H, width]
+            n, c9, h, _ = p.shape
+            p = p.view(n, 3, c9 // 3, h, width)
+            g = p[:, 1].clone()
+            g[..., 4:] += p[:, 0][..., :-4]
+            if not last:
+                g[..., :-4] += p[:, 2][..., 4:]
+            out.append(g.contiguous())
+        return out[0], out[1], off, off_col
+
+    def _ds_sheared_first_layer(self, left, right, shift, ds, arithmetic=None):
+        """``downsample`` = ds > 1 (features at ds times the volume's resolution, BuildCostVolume_cuda.cu:224-225: out[d,h,w] samples the
+        right feature on row ds*h at x = ds*w - shift[d]) on uniformly spaced planes shift[d] = (m0 + d) / q is the sheared layer
+        with q*ds phases (r6): index q*ds*w - m0 - d of the row-subsampled right feature upsampled by q alone; the
+        left feature is subsampled in both directions.  Two phases (ds = 2, whole-pixel planes -- the sweep that covers cfg2's range
+        at twice the resolution): the existing 3 x 7 layers with the feature itself in the upsampled image's place.  Four phases
+        (ds = 2 with half-pixel planes, ds = 4 with whole-pixel planes): three 3 x 3 layers added 4 elements apart
+        (_sheared_layer4) and the expand kernels' q = 4 instantiation.  Anything else returns None -> the materialised route."""
         conv, bn = self.conv1[0][0], self.conv1[0][1]
         nonneg, structure = self._shift_structure(shift)
         assert nonneg                              # reference __init__.py:12
-        if structure is None or structure[0] != 1:
+        if structure is None or structure[0] * ds not in (2, 4):
             return None
-        m0 = structure[1]
+        q_up, m0 = structure
+        phases = q_up * ds
         n, c = left.size(0), left.size(1)
-        h, w, d = left.size(2) // 2, left.size(3) // 2, shift.size(1)
-        if not self._sheared_fits(2, m0, d, w, False):
+        h, w, d = left.size(2) // ds, left.size(3) // ds, shift.size(1)
+        if w % 8 or w > 512:
             return None
+        if phases == 2:
+            if not self._sheared_fits(2, m0, d, w, False):
+                return None
+        else:
+            _, wu4, _, _ = self._sheared_geometry4(m0, d, w)
+            if 4 * ((wu4 + 3) // 4 * 4 + 16 + d) > 150 * 1024:
+                return None
         st = self._x3_select(left.device, arithmetic)
-        left_s = left[:, :, ::2, ::2].contiguous()
-        right_r = right[:, :, ::2, :].contiguous()           # rows 2h; every input column
+        left_s = left[:, :, ::ds, ::ds].contiguous()
+        right_r = right[:, :, ::ds, :].contiguous()          # rows ds*h; every input column
         wt = conv.weight
         plans = conv.__dict__.setdefault("_snvc_factored", {})
         key = (wt.data_ptr(), wt._version, wt.device, _GENERATION[0])
@@ -362,23 +414,27 @@ class GlobalStack(nn.Module):
             plans.update(key=key, right=ops.Conv3dLayer(wt.detach()[:, c:].contiguous(), 3, 1, 1, 1, False), plan=_Plan())
         scale, bias = _folded_bn(bn, plans["plan"])
         planes = self._left_planes_layer(plans, wt.detach()[:, :c])(left_s.unsqueeze(2)).view(n, c, 3, h, w)
-        lay_g, lay_col = self._sheared_layers(plans, wt.detach()[:, c:], 2)
-        off, wu, off_col, wu_col = sheared_geometry(2, m0, d, w)
-        g = lay_g(ops.sheared_upsample(right_r, 1, wu, off).unsqueeze(2)).squeeze(2)
-        gcol = lay_col(ops.sheared_upsample(right_r, 1, wu_col, off_col).unsqueeze(2)).squeeze(2)
+        if phases == 2:
+            lay_g, lay_col = self._sheared_layers(plans, wt.detach()[:, c:], 2)
+            off, wu, off_col, wu_col = sheared_geometry(2, m0, d, w)
+            g = lay_g(ops.sheared_upsample(right_r, 1, wu, off).unsqueeze(2)).squeeze(2)
+            gcol = lay_col(ops.sheared_upsample(right_r, 1, wu_col, off_col).unsqueeze(2)).squeeze(2)
+        else:
+            g, gcol, off, off_col = self._sheared4_inputs(plans, wt.detach()[:, c:], right_r, q_up, m0, d, w)
         shape = (n, c, d, h, w)
         try:
             if st is not None:
                 v1s = self._buffer("v1s", (n, 2, c // 8, d, h, w, 8), left.device, torch.float16)
-                ops.sheared_expand_split(g, gcol, planes, *self._x3_v1_affine(st, scale, bias), v1s, 2, m0, off, off_col, ops.EPI_RELU, st["flag"])
-                _ROUTES["ds2_sheared_first_conv"] += 1
+                ops.sheared_expand_split(g, gcol, planes, *self._x3_v1_affine(st, scale, bias), v1s, phases, m0, off, off_col, ops.EPI_RELU,
+                                         st["flag"])
+                _ROUTES["ds_sheared_first_conv"] += 1
                 self.__dict__["_snvc_last_v1"] = "v1s"
                 return self._tail_x3(st, v1s, None)
             v = self._buffer("v1", shape, left.device)
-            ops.sheared_expand(g, gcol, planes, scale, bias, v, 2, m0, off, off_col, ops.EPI_RELU)
+            ops.sheared_expand(g, gcol, planes, scale, bias, v, phases, m0, off, off_col, ops.EPI_RELU)
         except ops.Unsupported:
             return None
-        _ROUTES["ds2_sheared_first_conv"] += 1
+        _ROUTES["ds_sheared_first_conv"] += 1
         return self._conv2_tail(v, shape, None, arithmetic)
 
     def _gn_sheared_first_layer(self, left, right, shift, arithmetic=None):
@@ -738,11 +794,11 @@ class GlobalStack(nn.Module):
             return self._tail(self.conv2(v))
         usable = (factored and downsample == 1 and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
                   and not bn.training and left.dtype == torch.float32 and left.size(3) % 4 == 0 and shift.size(1) >= 2)
-        if (downsample == 2 and factored and sheared and timing is None and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
-                and not bn.training and left.is_cuda and left.dtype == torch.float32 and left.size(2) % 2 == 0 and left.size(3) % 8 == 0
-                and left.size(3) <= 1024 and shift.size(1) >= 4 and shift.dtype == torch.float32 and left.size(0) > 0
+        if (downsample in (2, 4) and factored and sheared and timing is None and not torch.is_grad_enabled() and isinstance(bn, nn.BatchNorm3d)
+                and not bn.training and left.is_cuda and left.dtype == torch.float32 and left.size(2) % downsample == 0
+                and left.size(3) % downsample == 0 and shift.size(1) >= 4 and shift.dtype == torch.float32 and left.size(0) > 0
                 and left.size(1) % 8 == 0 and left.size(1) * 2 == conv.in_channels and left.shape == right.shape):
-            cost = self._ds2_sheared_first_layer(left, right, shift, arithmetic)      # r6; None: the materialised route below
+            cost = self._ds_sheared_first_layer(left, right, shift, downsample, arithmetic)      # r6; None: the materialised route below
             if cost is not None:
                 return cost
         if (not usable and factored and sheared and downsample == 1 and timing is None and not torch.is_grad_enabled() and not self.training

@@ -1109,7 +1109,7 @@ def test_lazy_cost_volume_reference_call_sequence():
         assert not isinstance(build_cost_volume(L.double(), R.double(), S_.double(), 1), LazyCostVolume)
         v2 = build_cost_volume(L, R, S_, 2)                  # r6: downsample 2 is lazy too (even extents); its values are the eager op's
         assert isinstance(v2, LazyCostVolume) and torch.equal(v2.materialize(), ops.cost_volume_forward(L, R, S_, 2))
-        assert not isinstance(build_cost_volume(L, R, S_, 4), LazyCostVolume)
+        assert not isinstance(build_cost_volume(L, R, S_, 8), LazyCostVolume)
 
 
 @pytest.mark.parametrize("tile", ["default", "big", "narrow"])
@@ -1235,45 +1235,52 @@ def test_global_pair_groupnorm_split_tail_vs_oracle():
     check(got32, exp, 1e-4, "GroupNorm pair (fp32 MFMA)")
 
 
-@pytest.mark.parametrize("m0", [0, 3])
+@pytest.mark.parametrize("case", ["ds2_whole", "ds2_whole_m3", "ds2_half", "ds2_half_m5", "ds4_whole", "ds4_whole_m2"])
 @pytest.mark.parametrize("arith", ["auto", "fp32"])
-def test_global_pair_downsample_2_sheared_vs_oracle(m0, arith):
-    """r6: downsample = 2 with planes one input pixel apart takes the sheared first layer (the row-subsampled right feature in the
-    place of the half-pixel upsampled one): against the oracle -- the C restatement of BuildCostVolume_cuda.cu:63-98 at downsample 2
-    + the torch-CPU stack -- and against the materialised route; a half-pixel sweep at downsample 2 (four phases) still
-    materialises."""
+def test_global_pair_downsample_sheared_vs_oracle(case, arith):
+    """r6: downsample = ds > 1 on uniformly spaced planes takes the sheared first layer with q*ds phases of the row-subsampled right
+    feature: two phases (ds 2, planes one input pixel apart: the existing 3 x 7 layers, the feature itself in the upsampled
+    image's place) or four (ds 2 with half-pixel planes, ds 4 with whole-pixel planes: three 3 x 3 layers added 4 elements apart,
+    the expand kernels' q = 4 form).  Against the oracle -- the C restatement of BuildCostVolume_cuda.cu:63-98 at that downsample + the
+    torch-CPU stack -- and against the materialised route; eight phases (ds 4, half-pixel planes) still materialise."""
     from oracle import native as O
     from oracle import torch_ref as T
     from snvc_amd.extension.build_cost_volume import build_cost_volume
+    from snvc_amd.lazy import LazyCostVolume
     from snvc_amd.models import submodule as S
     from snvc_amd.models.stereo_volume import GlobalStack
-    r = np.random.default_rng(51 + m0)
+    ds = 4 if case.startswith("ds4") else 2
+    q = 2 if "half" in case else 1
+    m0 = int(case.rsplit("_m", 1)[1]) if "_m" in case else 0
+    r = np.random.default_rng(51 + m0 + 7 * ds + q)
     C, H, W, D = 32, 8, 40, 12
-    L = r.standard_normal((2, C, 2 * H, 2 * W)).astype(np.float32)
-    R = r.standard_normal((2, C, 2 * H, 2 * W)).astype(np.float32)
-    row = (m0 + np.arange(D)).astype(np.float32)
+    L = r.standard_normal((2, C, ds * H, ds * W)).astype(np.float32)
+    R = r.standard_normal((2, C, ds * H, ds * W)).astype(np.float32)
+    row = ((m0 + np.arange(D)) / q).astype(np.float32)
     s = np.stack([row, row])
     ref = seeded(T.GlobalStack(C), 52)
     ours = seeded(GlobalStack(C), 52).to(dev())
     dl, dr, dsh = torch.from_numpy(L).to(dev()), torch.from_numpy(R).to(dev()), torch.from_numpy(s).to(dev())
     a = None if arith == "auto" else "fp32"
     with torch.no_grad():
-        exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, 2))).numpy()
-        b = S._ROUTES["ds2_sheared_first_conv"]
-        got = ours.forward_pair(dl, dr, dsh, 2, arithmetic=a).cpu().numpy()
-        assert S._ROUTES["ds2_sheared_first_conv"] == b + 1, "downsample 2 did not take the sheared first layer"
-        got_mat = ours.forward_pair(dl, dr, dsh, 2, sheared=False, arithmetic=a).cpu().numpy()
-        assert S._ROUTES["ds2_sheared_first_conv"] == b + 1
-        ours.forward_pair(dl, dr, dsh * 0.5, 2)                                    # half-pixel planes at downsample 2: not this route
-        assert S._ROUTES["ds2_sheared_first_conv"] == b + 1
+        exp = ref(torch.from_numpy(O.cost_volume_forward(L, R, s, ds))).numpy()
+        b = S._ROUTES["ds_sheared_first_conv"]
+        got = ours.forward_pair(dl, dr, dsh, ds, arithmetic=a).cpu().numpy()
+        assert S._ROUTES["ds_sheared_first_conv"] == b + 1, "the call did not take the sheared first layer"
+        got_mat = ours.forward_pair(dl, dr, dsh, ds, sheared=False, arithmetic=a).cpu().numpy()
+        assert S._ROUTES["ds_sheared_first_conv"] == b + 1
+        if ds == 4:
+            ours.forward_pair(dl, dr, dsh * 0.5, 4)                                # eight phases: not this route
+            assert S._ROUTES["ds_sheared_first_conv"] == b + 1
         if arith == "auto":
-            vol = build_cost_volume(dl, dr, dsh, 2)                                  # r6: a lazy volume at downsample 2 as well
+            vol = build_cost_volume(dl, dr, dsh, ds)                                 # the lazy volume covers downsample 2 and 4
+            assert isinstance(vol, LazyCostVolume)
             got_api = ours(vol).cpu().numpy()
-            assert S._ROUTES["ds2_sheared_first_conv"] == b + 2 and not vol.is_materialized
-            check(got_api, exp, 1e-4, "downsample 2 through model(build_cost_volume(...))")
-            assert np.array_equal(build_cost_volume(dl, dr, dsh, 2).cpu().numpy(), O.cost_volume_forward(L, R, s, 2))    # any other use: the volume
-    check(got, exp, 1e-4, "downsample 2 (sheared first layer)")
-    check(got_mat, exp, 1e-4, "downsample 2 (materialised)")
+            assert S._ROUTES["ds_sheared_first_conv"] == b + 2 and not vol.is_materialized
+            check(got_api, exp, 1e-4, "through model(build_cost_volume(...))")
+            assert np.array_equal(build_cost_volume(dl, dr, dsh, ds).cpu().numpy(), O.cost_volume_forward(L, R, s, ds))    # any other use: the volume
+    check(got, exp, 1e-4, f"{case} (sheared first layer)")
+    check(got_mat, exp, 1e-4, f"{case} (materialised)")
     check(got, got_mat, 2e-5, "sheared vs materialised")
 
 
