@@ -475,6 +475,37 @@ SNVC_API int snvc_act_backward_apply_amax(const float *raw, const float *gy, con
                                           int64_t raw_batch_stride, int64_t gy_batch_stride,
                                           int64_t res_batch_stride, int per_sample, int flags, uint32_t *amax, void *stream);
 
+/* r6 -- passes that also write the tensor's split C8 TWIN.  The training step's half- / quarter-resolution and transposed layers run
+ * their forward and data-gradient convolutions on the split kernels (snvc_f16x3_conv3d_forward with y_f32), which read
+ * [N][2 (hi | lo)][C/8][S][8] half pairs; the pass that produces the float32 NCDHW tensor (which the weight gradient, the statistics
+ * and autograd keep using) writes the pair too, +4 bytes per element instead of a layout pass (snvc_f16x3_from_ncdhw, 8 bytes per
+ * element).  twin value = v * twin_mul[0], hi = half(that), lo = half(that - hi); twin_mul: one device float, a power of two from
+ * snvc_split_scale_bound (so no clamp and no overflow flag); twin_lo is the lo plane's address, twin_batch_stride in halves
+ * (0 = 2*C*S).  C % 8 == 0, S % 4 == 0, 16-byte aligned tensors; everything else as snvc_affine_act_amax /
+ * snvc_act_backward_apply_amax / snvc_act_backward_reduce (+ amax_gy: the bit pattern of max|gy| into SNVC_AMAX_SLOTS words). */
+SNVC_API int snvc_affine_act_twin(const float *x, const float *scale, const float *shift, const float *residual, float *y,
+                                  void *twin_hi, void *twin_lo, const float *twin_mul, int64_t N, int64_t C, int64_t S,
+                                  int64_t x_batch_stride, int64_t y_batch_stride, int64_t res_batch_stride,
+                                  int64_t twin_batch_stride, int per_sample, int flags, uint32_t *amax, void *stream);
+SNVC_API int snvc_act_backward_apply_twin(const float *raw, const float *gy, const float *residual, const float *scale,
+                                          const float *shift, const float *coef_g, const float *coef_raw, const float *coef_const,
+                                          float *draw, float *g_out, void *twin_hi, void *twin_lo, const float *twin_mul, int64_t N,
+                                          int64_t C, int64_t S, int64_t raw_batch_stride, int64_t gy_batch_stride,
+                                          int64_t res_batch_stride, int64_t twin_batch_stride, int per_sample, int flags,
+                                          uint32_t *amax, void *stream);
+SNVC_API int snvc_act_backward_reduce_amax(const float *raw, const float *gy, const float *residual, const float *scale,
+                                           const float *shift, double *sums, void *workspace, int64_t N, int64_t C, int64_t S,
+                                           int64_t raw_batch_stride, int64_t gy_batch_stride, int64_t res_batch_stride,
+                                           int per_sample, int flags, uint32_t *amax_gy, void *stream);
+/* The scale of a twin from an upper bound of max|v| that is known BEFORE the pass runs (one small launch, no host round trip):
+ *   bound = max over rows r of ( |a[r]| * P + |b[r]| * l1[r % C] * X + |c[r]| ) + R,   mul_out[0] = 2^k with bound * 2^k in [2^13, 2^14)
+ * (1 for a zero or non-finite bound).  P / X / R: the maxima of the SNVC_AMAX_SLOTS-word arrays amax_p / amax_x / amax_r (NULL: 0; X: 1);
+ * a / c NULL count 0, b / l1 NULL count 1; a, b, c hold `rows` floats (C, or N*C per-sample), l1 holds C.
+ *   forward  y = act(scale*raw + shift [+res]) [+res]: b = scale, l1 = L1 norms of the layer's filters and X = max|x| (l1*X bounds |raw|),
+ *            c = shift, R = max|res|;     backward draw = A*g + B*raw + Cc: a = A, P = max|gy|, b = B, l1, X as forward, c = Cc. */
+SNVC_API int snvc_split_scale_bound(const float *a, const uint32_t *amax_p, const float *b, const float *l1, const uint32_t *amax_x,
+                                    const float *c, const uint32_t *amax_r, int64_t rows, int64_t C, float *mul_out, void *stream);
+
 /* Train-mode BatchNorm backward coefficients from snvc_act_backward_reduce's sums [N, C, 2] (fp64), in fp64, one launch
  * (replaces the ~15 per-channel tensor operations of torch autograd's native_batch_norm_backward on this path):
  *   sg = sum_n sums[n,c,0], sgr = sum_n sums[n,c,1], rstd = 1/sqrt(var[c] + eps), sgx = rstd * (sgr - mean[c] * sg)
@@ -603,7 +634,9 @@ SNVC_API int snvc_f16x3_conv3d_pack_weights(const snvc_conv3d_desc *desc_host, c
  * snvc_conv3d_forward_side_head); head_mul = 2^-e_y (with y_f32 the stored result is multiplied by head_mul as well: the epilogue
  * then works in the residual's units 2^e_y).  res_mul = 2^(e_y - e_res): the residual pair's stored units relative to the result's (1 if they
  * share an exponent).  overflow (device int, may be NULL): set to 1 if a value had to be
- * clamped to half's range on the way out (the exponent the caller chose was too large for this input). */
+ * clamped to half's range on the way out (the exponent the caller chose was too large for this input).
+ * r6: with y_f32 and SNVC_EPI_ADD_POST, res_hi may be a FLOAT32 NCDHW tensor of the result's shape and batch stride (res_lo = NULL):
+ * y_f32 = head_mul * act(scale * conv + bias) + res -- the training step's data gradients take a skip connection's gradient this way. */
 SNVC_API int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,
                                        const void *packed_weight, const float *scale, const float *bias,
                                        const void *res_hi, const void *res_lo, void *y_hi, void *y_lo, float *y_f32,

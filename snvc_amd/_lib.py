@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SNVC_HIP_LIB") or os.path.join(_HERE, "libsnvc_hip.so")   # env: development override
 _lib = None
-_ABI = 5   # snvc_abi_version() this binding was written against
+_ABI = 6   # snvc_abi_version() this binding was written against
 
 c_i64 = ctypes.c_int64
 c_f32 = ctypes.c_float
@@ -88,6 +88,11 @@ SIGNATURES = {
     "snvc_conv3d_wgrad_amax": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "snvc_act_backward_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "snvc_act_backward_reduce": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
+    "snvc_act_backward_reduce_amax": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p]),
+    "snvc_affine_act_twin": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p]),
+    "snvc_act_backward_apply_twin": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
+                                             c_i64, c_int, c_int, c_p, c_p]),
+    "snvc_split_scale_bound": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p]),
     "snvc_bn_backward_coefs": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_p]),
     "snvc_act_backward_apply": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),
     "snvc_act_backward_apply_amax": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p]),

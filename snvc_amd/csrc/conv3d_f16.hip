@@ -59,6 +59,8 @@ struct F16Args {
     float *t_out;
     float tail_mul;           // 2^-(e_y + w_exp): exact
     int64_t t_bs;             // floats between samples of t_out
+    const float *res_f32;     // EPI 2 (r6): a float32 NCDHW tensor of the result's shape added to the stored result (ADD_POST; the training
+                              //   step's data gradients take a skip connection's gradient this way), batch stride yf_bs; or NULL
     const float *x_mul;       // conv2d_x3q_kernel: device scalar the input pair was multiplied by (a power of two from its own maximum), or NULL
     int CGin;            // input channel groups (Cin / 8, rounded up)
     int Cout;
@@ -534,6 +536,7 @@ conv3d_f16_kernel(const F16Args a_) {
         _Float16 *yn = C8OUT ? a.y + n * a.y_bs : nullptr;
         _Float16 *yn_lo = (C8OUT && SPLIT) ? a.y_lo + n * a.y_bs : nullptr;
         float *yf = EPI == 2 ? a.y_f32 + n * a.yf_bs : nullptr;
+        const float *__restrict__ rf = (EPI == 2 && a.res_f32) ? a.res_f32 + n * a.yf_bs : nullptr;
         constexpr float kHalfMax = 65504.0f;
         // Epilogue arithmetic is counted in VALU instructions (every one costs matrix-pipe time of the co-resident waves): the
         // affine is one FMA, ReLU and the clamp to half's range are ONE v_med3 (lower bound 0 or -65504), the overflow flag is a
@@ -569,6 +572,15 @@ conv3d_f16_kernel(const F16Args a_) {
                             if (rn_lo) rl = *reinterpret_cast<const h8 *>(rn_lo + (gj + sp[nb]) * 8);
                         }
                         h8 o, ol;
+                        float rfv[8];
+                        if constexpr (EPI == 2) {
+                            // the float32 residual's eight values in flight together, ahead of the stores (which the compiler must
+                            // otherwise keep in order with them: one exposed HBM latency per channel, measured 2x on the whole kernel)
+                            if (rf && okv[nb]) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) rfv[e] = rf[(int64_t)(cj + e) * out_dhw + sp[nb]];
+                            }
+                        }
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             float v = __builtin_fmaf(acc[nb][m][8 * j + e], sc[e >> 2][e & 3], bi[e >> 2][e & 3]);
@@ -580,7 +592,10 @@ conv3d_f16_kernel(const F16Args a_) {
                             }
                             if constexpr (EPI == 2) {
                                 if constexpr (!HAS_RES) { if (relu) v = __builtin_fmaxf(v, 0.0f); }
-                                if (okv[nb]) yf[(int64_t)(cj + e) * out_dhw + sp[nb]] = v * a.head_mul;     // 2^-e_y: exact
+                                if (okv[nb]) {
+                                    const int64_t at = (int64_t)(cj + e) * out_dhw + sp[nb];
+                                    yf[at] = rf ? __builtin_fmaf(v, a.head_mul, rfv[e]) : v * a.head_mul;     // 2^-e_y: exact
+                                }
                             } else {
                                 if constexpr (SPLIT) {
                                     // ReLU (when no residual follows it) and the clamp that keeps the pair finite, in one v_med3;
@@ -2241,7 +2256,17 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null pointer");
     if ((scale == nullptr) != (bias == nullptr))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: scale and bias must both be given or both be NULL");
-    const int resflags = d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST);
+    int resflags = d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST);
+    // r6: a float32 result (y_f32) takes a float32 NCDHW residual of its own shape and batch stride: res_hi = that tensor, res_lo = NULL,
+    // ADD_POST only (the data gradients of the training step add a skip connection's gradient this way)
+    const float *res_f32 = nullptr;
+    if (resflags == SNVC_EPI_ADD_POST && to_f32 && !plane && res_hi && !res_lo && !tail_w) {
+        if (d->res_batch_stride && d->res_batch_stride != (d->y_batch_stride ? d->y_batch_stride : (int64_t)d->Cout * d->Dout * d->Hout * d->Wout))
+            return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: a float32 residual shares the result's batch stride");
+        res_f32 = reinterpret_cast<const float *>(res_hi);
+        res_hi = nullptr;
+        resflags = 0;
+    }
     if (resflags && (!res_hi || !res_lo || plane))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: residual flag without a split residual");
     if (resflags == (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))
@@ -2260,7 +2285,7 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
          reinterpret_cast<uintptr_t>(packed_weight) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(bias) |
          reinterpret_cast<uintptr_t>(head)) & 15)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: C8 tensors and the per-channel vectors must be 16-byte aligned");
-    if ((d->x_batch_stride | d->res_batch_stride) % 8 || (!to_f32 && d->y_batch_stride % 8))
+    if ((d->x_batch_stride | (res_f32 ? 0 : d->res_batch_stride)) % 8 || (!to_f32 && d->y_batch_stride % 8))
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: batch strides must be multiples of 8 elements");
     F16Args a{};
     a.x = reinterpret_cast<const _Float16 *>(x_hi); a.x_lo = reinterpret_cast<const _Float16 *>(x_lo);
@@ -2269,12 +2294,13 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
     a.res_lo = resflags ? reinterpret_cast<const _Float16 *>(res_lo) : nullptr;
     a.y = reinterpret_cast<_Float16 *>(y_hi); a.y_lo = reinterpret_cast<_Float16 *>(y_lo); a.y_f32 = y_f32;
     a.head = head; a.y_head = y_head; a.head_mul = head_mul; a.res_mul = res_mul; a.overflow = overflow;
+    a.res_f32 = res_f32;
     a.tail_w = reinterpret_cast<const _Float16 *>(tail_w); a.t_out = t_out; a.tail_mul = tail_mul;
     a.t_bs = (int64_t)27 * 8 * d->Din * d->Hin * d->Win;
     a.CGin = d->Cin / 8; a.Cout = d->Cout;
     a.Din = d->Din; a.Hin = d->Hin; a.Win = d->Win;
     a.Dout = d->Dout; a.Hout = d->Hout; a.Wout = d->Wout;
-    a.nchunks = p.nchunks; a.flags = d->flags;
+    a.nchunks = p.nchunks; a.flags = res_f32 ? (d->flags & ~SNVC_EPI_ADD_POST) : d->flags;
     a.x_bs = d->x_batch_stride ? d->x_batch_stride : 2 * (int64_t)d->Cin * in_sp;
     a.y_bs = d->y_batch_stride ? d->y_batch_stride : 2 * (int64_t)d->Cout * out_sp;
     a.r_bs = d->res_batch_stride ? d->res_batch_stride : 2 * (int64_t)d->Cout * out_sp;

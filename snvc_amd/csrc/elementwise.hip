@@ -6,6 +6,8 @@
 #include "elementwise_internal.hpp"
 
 #include <cfloat>
+#include <cstdlib>
+#include <initializer_list>
 
 namespace snvc {
 namespace {
@@ -159,7 +161,25 @@ norm_partial_kernel(const float *__restrict__ x, double *__restrict__ partial, i
     double sv[VEC], ssv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { sv[j] = 0.0; ssv[j] = 0.0; }
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    // r6: two loads in flight per thread (32 splits x rows workgroups = 16 waves per CU: with one 16-byte load each the pass moved
+    // 4.1 TB/s on cfg4's 736 MB layers); the order of the additions into each accumulator is unchanged
+    int64_t i = lo + threadIdx.x;
+    for (; i + blockDim.x < hi; i += 2 * blockDim.x) {
+        const fv q0 = p[i], q1 = p[i + blockDim.x];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const double v = (double)q0[j];
+            sv[j] += v;
+            ssv[j] += v * v;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const double v = (double)q1[j];
+            sv[j] += v;
+            ssv[j] += v * v;
+        }
+    }
+    for (; i < hi; i += blockDim.x) {
         const fv q = p[i];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -297,8 +317,9 @@ __global__ void __launch_bounds__(256)
 act_bwd_partial_kernel(const float *__restrict__ raw, const float *__restrict__ gy, const float *__restrict__ res,
                        const float *__restrict__ scale, const float *__restrict__ shift, double *__restrict__ partial,
                        int64_t C, int64_t S, int64_t raw_bs, int64_t gy_bs, int64_t r_bs, int per_sample, int flags,
-                       int splits) {
+                       int splits, unsigned *__restrict__ amax_gy) {
     typedef float fv __attribute__((ext_vector_type(VEC)));
+    unsigned mx = 0;                           // r6: bits of max|gy| (the split twin of draw is scaled by a bound built from it)
     const int64_t row = blockIdx.y;            // n*C + c
     const int split = blockIdx.x;
     const int64_t n = row / C, c = row % C;
@@ -312,10 +333,7 @@ act_bwd_partial_kernel(const float *__restrict__ raw, const float *__restrict__ 
     double s0v[VEC], s1v[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { s0v[j] = 0.0; s1v[j] = 0.0; }
-    for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const fv av = a[i], bv = b[i];
-        fv rv = av;
-        if (r) rv = r[i];
+    auto step = [&](const fv av, const fv bv, const fv rv) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float aj = av[j], bj = bv[j], rj = r ? rv[j] : 0.0f;
@@ -323,7 +341,27 @@ act_bwd_partial_kernel(const float *__restrict__ raw, const float *__restrict__ 
             s0v[j] += (double)g;
             s1v[j] += (double)g * (double)aj;
         }
+        if (amax_gy) {
+            if constexpr (VEC == 4) mx = amax_bits4(mx, bv[0], bv[1], bv[2], bv[3]);
+            else mx = amax_bits4(mx, bv[0], bv[0], bv[0], bv[0]);
+        }
+    };
+    // r6: two iterations' loads in flight (see norm_partial_kernel); accumulation order unchanged
+    int64_t i = lo + threadIdx.x;
+    for (; i + blockDim.x < hi; i += 2 * blockDim.x) {
+        const fv a0 = a[i], b0 = b[i], a1 = a[i + blockDim.x], b1 = b[i + blockDim.x];
+        fv r0 = a0, r1 = a1;
+        if (r) { r0 = r[i]; r1 = r[i + blockDim.x]; }
+        step(a0, b0, r0);
+        step(a1, b1, r1);
     }
+    for (; i < hi; i += blockDim.x) {
+        const fv av = a[i], bv = b[i];
+        fv rv = av;
+        if (r) rv = r[i];
+        step(av, bv, rv);
+    }
+    if (amax_gy) amax_publish(amax_gy, mx);
     double s0 = s0v[0], s1 = s1v[0];
     if constexpr (VEC == 4) { s0 = (s0v[0] + s0v[1]) + (s0v[2] + s0v[3]); s1 = (s1v[0] + s1v[1]) + (s1v[2] + s1v[3]); }
     for (int off = 32; off > 0; off >>= 1) {
@@ -397,6 +435,224 @@ act_bwd_apply_kernel(const float *__restrict__ raw, const float *__restrict__ gy
         }
     }
     if (amax) amax_publish(amax, mx);
+}
+
+// ---------------------------------------------------------------------------- r6: passes that also write a split C8 twin
+// The training step's half- / quarter-resolution and transposed layers run their forward and data-gradient convolutions on the split
+// kernels (csrc/conv3d_f16.hip), which read [N][2 (hi | lo)][C/8][S][8] half pairs.  The pass that produces the tensor in float32
+// NCDHW (for the weight gradient, the statistics and autograd) writes that pair as well: +4 bytes per element on a pass that moves 8
+// or 12, instead of a layout pass of its own (8 bytes per element, measured 0.22-0.25 ms at half resolution).  One thread = 4
+// consecutive voxels x the 8 channels of a group; twin value = v * mul[0] (a power of two from an upper bound of max|v|, see
+// split_scale_bound_kernel: no clamp needed), hi = half(v * mul), lo = half(v * mul - hi).
+typedef _Float16 tw_h8 __attribute__((ext_vector_type(8)));
+
+// A lane holds the 4 pieces (16 bytes each) of its 4 voxels: stored directly, every store instruction would touch 64 lanes x 16 bytes at
+// a 64-byte stride (measured: the full-resolution apply pass at 3.4 TB/s instead of 5.3).  The wave transposes through its own 8 KB of
+// LDS instead -- piece (4 lane + k) written, piece (64 j + lane) read back -- so that a store instruction covers 1 KB of consecutive
+// bytes.  `full`: all 64 lanes of the wave have voxels (the tail wave stores directly).
+__device__ __forceinline__ void twin_store(_Float16 *__restrict__ th, _Float16 *__restrict__ tl, int64_t piece, const float (&w)[8][4], float m,
+                                           tw_h8 *__restrict__ lds_wave, bool full) {
+    const int lane = threadIdx.x & 63;
+    tw_h8 hi[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = w[e][k] * m;
+            hi[k][e] = (_Float16)f;
+            lo[k][e] = (_Float16)(f - (float)hi[k][e]);
+        }
+    }
+    if (!full) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            *reinterpret_cast<tw_h8 *>(th + (piece + k) * 8) = hi[k];
+            *reinterpret_cast<tw_h8 *>(tl + (piece + k) * 8) = lo[k];
+        }
+        return;
+    }
+    // rotate the piece slot by the lane's quad so that the four 16-byte writes of four neighbouring lanes fall into different banks
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lds_wave[4 * lane + ((k + (lane >> 2)) & 3)] = hi[k];
+        lds_wave[256 + 4 * lane + ((k + (lane >> 2)) & 3)] = lo[k];
+    }
+    const int64_t base = piece - 4 * lane;          // the wave's first piece
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = 64 * j + lane;                // piece p = voxel-lane p >> 2, slot k = p & 3
+        const int src = (p & ~3) + (((p & 3) + ((p >> 2) >> 2)) & 3);
+        *reinterpret_cast<tw_h8 *>(th + (base + p) * 8) = lds_wave[src];
+        *reinterpret_cast<tw_h8 *>(tl + (base + p) * 8) = lds_wave[256 + src];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+affine_act_twin_kernel(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
+                       const float *__restrict__ res, float *__restrict__ y, _Float16 *__restrict__ t_hi, _Float16 *__restrict__ t_lo,
+                       const float *__restrict__ mul, int64_t C, int64_t S, int64_t x_bs, int64_t y_bs, int64_t r_bs, int64_t t_bs,
+                       int per_sample, int flags, unsigned *__restrict__ amax, int chunked) {
+    const int64_t n = blockIdx.z, g = blockIdx.y, c0 = 8 * g;
+    const float m = mul[0];
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = scale ? scale[(per_sample ? n * C : 0) + c0 + e] : 1.0f;
+        sh[e] = shift ? shift[(per_sample ? n * C : 0) + c0 + e] : 0.0f;
+    }
+    const float *a = x + n * x_bs + c0 * S;
+    const float *r = res ? res + n * r_bs + c0 * S : nullptr;
+    float *o = y + n * y_bs + c0 * S;
+    _Float16 *th = t_hi + n * t_bs + g * S * 8, *tl = t_lo + n * t_bs + g * S * 8;
+    const int64_t S4 = S >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned mx = 0;
+    __shared__ tw_h8 twin_lds[4][512];
+    tw_h8 *lds_wave = twin_lds[threadIdx.x >> 6];
+    int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, iend = S4, istep = stride;
+    if (chunked) {
+        const int64_t chunk = ((S4 + gridDim.x - 1) / gridDim.x + 255) & ~(int64_t)255;
+        i0 = blockIdx.x * chunk + threadIdx.x; iend = (blockIdx.x + 1) * chunk < S4 ? (blockIdx.x + 1) * chunk : S4; istep = 256;
+    }
+    for (int64_t i = i0; i < iend; i += istep) {
+        const bool full = (i - (threadIdx.x & 63)) + 64 <= iend;
+        float4 v[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = reinterpret_cast<const float4 *>(a + e * S)[i];
+        if (r) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = reinterpret_cast<const float4 *>(r + e * S)[i];
+        }
+        float w[8][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float4 qq = r ? q[e] : make_float4(0, 0, 0, 0);
+            w[e][0] = epilogue(v[e].x * sc[e] + sh[e], qq.x, flags);
+            w[e][1] = epilogue(v[e].y * sc[e] + sh[e], qq.y, flags);
+            w[e][2] = epilogue(v[e].z * sc[e] + sh[e], qq.z, flags);
+            w[e][3] = epilogue(v[e].w * sc[e] + sh[e], qq.w, flags);
+            reinterpret_cast<float4 *>(o + e * S)[i] = make_float4(w[e][0], w[e][1], w[e][2], w[e][3]);
+            mx = amax_bits4(mx, w[e][0], w[e][1], w[e][2], w[e][3]);
+        }
+        twin_store(th, tl, 4 * i, w, m, lds_wave, full);
+    }
+    if (amax) amax_publish(amax, mx);
+}
+
+// draw = A*g + B*raw + Cc per (n?, c) as act_bwd_apply_kernel, plus draw's split twin (what the data-gradient convolution reads)
+__global__ void __launch_bounds__(256)
+act_bwd_apply_twin_kernel(const float *__restrict__ raw, const float *__restrict__ gy, const float *__restrict__ res,
+                          const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ A,
+                          const float *__restrict__ B, const float *__restrict__ Cc, float *__restrict__ draw,
+                          float *__restrict__ g_out, _Float16 *__restrict__ t_hi, _Float16 *__restrict__ t_lo,
+                          const float *__restrict__ mul, int64_t C, int64_t S, int64_t raw_bs, int64_t gy_bs, int64_t r_bs, int64_t t_bs,
+                          int per_sample, int flags, unsigned *__restrict__ amax, int chunked) {
+    const int64_t n = blockIdx.z, g = blockIdx.y, c0 = 8 * g;
+    const int64_t pc = (per_sample ? n * C : 0) + c0;
+    const float m = mul[0];
+    float sc[8], sh[8], ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = scale ? scale[pc + e] : 1.0f;
+        sh[e] = shift ? shift[pc + e] : 0.0f;
+        ca[e] = A[pc + e];
+        cb[e] = B ? B[pc + e] : 0.0f;
+        cc[e] = Cc ? Cc[pc + e] : 0.0f;
+    }
+    const float *a = raw + n * raw_bs + c0 * S, *b = gy + n * gy_bs + c0 * S;
+    const float *r = res ? res + n * r_bs + c0 * S : nullptr;
+    float *o = draw + (n * C + c0) * S;
+    float *go = g_out ? g_out + (n * C + c0) * S : nullptr;
+    _Float16 *th = t_hi + n * t_bs + g * S * 8, *tl = t_lo + n * t_bs + g * S * 8;
+    const int64_t S4 = S >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned mx = 0;
+    __shared__ tw_h8 twin_lds[4][512];
+    tw_h8 *lds_wave = twin_lds[threadIdx.x >> 6];
+    int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, iend = S4, istep = stride;
+    if (chunked) {
+        const int64_t chunk = ((S4 + gridDim.x - 1) / gridDim.x + 255) & ~(int64_t)255;
+        i0 = blockIdx.x * chunk + threadIdx.x; iend = (blockIdx.x + 1) * chunk < S4 ? (blockIdx.x + 1) * chunk : S4; istep = 256;
+    }
+    for (int64_t i = i0; i < iend; i += istep) {
+        const bool full = (i - (threadIdx.x & 63)) + 64 <= iend;
+        float4 xv[8], gv[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xv[e] = reinterpret_cast<const float4 *>(a + e * S)[i];
+            gv[e] = reinterpret_cast<const float4 *>(b + e * S)[i];
+        }
+        if (r) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[e] = reinterpret_cast<const float4 *>(r + e * S)[i];
+        }
+        float w[8][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float4 qq = r ? q[e] : make_float4(0, 0, 0, 0);
+            float4 gg;
+            gg.x = act_grad(xv[e].x, gv[e].x, qq.x, sc[e], sh[e], flags); gg.y = act_grad(xv[e].y, gv[e].y, qq.y, sc[e], sh[e], flags);
+            gg.z = act_grad(xv[e].z, gv[e].z, qq.z, sc[e], sh[e], flags); gg.w = act_grad(xv[e].w, gv[e].w, qq.w, sc[e], sh[e], flags);
+            w[e][0] = ca[e] * gg.x + cb[e] * xv[e].x + cc[e]; w[e][1] = ca[e] * gg.y + cb[e] * xv[e].y + cc[e];
+            w[e][2] = ca[e] * gg.z + cb[e] * xv[e].z + cc[e]; w[e][3] = ca[e] * gg.w + cb[e] * xv[e].w + cc[e];
+            reinterpret_cast<float4 *>(o + e * S)[i] = make_float4(w[e][0], w[e][1], w[e][2], w[e][3]);
+            mx = amax_bits4(mx, w[e][0], w[e][1], w[e][2], w[e][3]);
+            if (go) reinterpret_cast<float4 *>(go + e * S)[i] = gg;
+        }
+        twin_store(th, tl, 4 * i, w, m, lds_wave, full);
+    }
+    if (amax) amax_publish(amax, mx);
+}
+
+// The scale of a twin from an UPPER BOUND of max|v| known before the pass runs (one workgroup):
+//   bound = max over rows r of ( |a[r]| * P + |b[r]| * L[r % C] * X + |c[r]| ) + R ,
+// P / X / R the maxima of SNVC_AMAX_SLOTS-word amax arrays (a NULL array counts 0; a NULL vector counts 0 for a, c and 1 for b, L),
+// mul = the power of two that puts bound into [2^13, 2^14) (1 for a zero or non-finite bound).
+//   forward  y = act(scale * raw + shift [+ res]) [+ res]:  b = scale, L = the L1 norms of the layer's filters, X = max|x| (so that
+//            L * X bounds |raw|), c = shift, R = max|res|;
+//   backward draw = A * g + B * raw + Cc:  a = A, P = max|gy|, b = B, L, X as forward, c = Cc.
+// A loose bound costs nothing until the pair's lo part leaves half's subnormal range: 2^-25 of the bound absolute, below float32's own
+// rounding for a bound up to 2^10 times the true maximum.
+__device__ __forceinline__ float slots_max(const unsigned *__restrict__ slots) {      // one wave: a slot per lane
+    if (!slots) return 0.0f;
+    unsigned m = slots[threadIdx.x & (SNVC_AMAX_SLOTS - 1)];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off);
+        m = m > o ? m : o;
+    }
+    return __uint_as_float(m);
+}
+
+__global__ void __launch_bounds__(256)
+split_scale_bound_kernel(const float *__restrict__ a, const unsigned *__restrict__ P, const float *__restrict__ b,
+                         const float *__restrict__ L, const unsigned *__restrict__ X, const float *__restrict__ c,
+                         const unsigned *__restrict__ R, int rows, int C, float *__restrict__ mul_out) {
+    const float Pv = slots_max(P), Xv = X ? slots_max(X) : 1.0f, Rv = slots_max(R);
+    float m = 0.0f;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        const float v = (a ? fabsf(a[r]) * Pv : 0.0f) + (b ? fabsf(b[r]) : 1.0f) * (L ? L[r % C] : 1.0f) * Xv + (c ? fabsf(c[r]) : 0.0f);
+        m = v > m || v != v ? v : m;          // a NaN sticks
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float o = __shfl_xor(m, off);
+        m = (o > m || o != o) ? o : m;
+    }
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) m = (sm[i] > m || sm[i] != sm[i]) ? sm[i] : m;
+        const float bound = m + Rv;
+        float mul = 1.0f;
+        if (bound > 0.0f && bound < INFINITY) {
+            int e;
+            frexpf(bound, &e);               // bound = f * 2^e, f in [0.5, 1)
+            int k = 14 - e;
+            k = k < -24 ? -24 : (k > 40 ? 40 : k);
+            mul = ldexpf(1.0f, k);
+        }
+        mul_out[0] = mul;
+    }
 }
 
 // Train-mode BatchNorm backward coefficients (see snvc_bn_backward_coefs): one thread per channel, fp64.
@@ -567,12 +823,21 @@ int snvc_act_backward_reduce(const float *raw, const float *gy, const float *res
                              const float *shift, double *sums, void *workspace, int64_t N, int64_t C, int64_t S,
                              int64_t raw_batch_stride, int64_t gy_batch_stride, int64_t res_batch_stride,
                              int per_sample, int flags, void *stream) {
+    return snvc_act_backward_reduce_amax(raw, gy, residual, scale, shift, sums, workspace, N, C, S, raw_batch_stride, gy_batch_stride,
+                                         res_batch_stride, per_sample, flags, nullptr, stream);
+}
+
+int snvc_act_backward_reduce_amax(const float *raw, const float *gy, const float *residual, const float *scale,
+                                  const float *shift, double *sums, void *workspace, int64_t N, int64_t C, int64_t S,
+                                  int64_t raw_batch_stride, int64_t gy_batch_stride, int64_t res_batch_stride,
+                                  int per_sample, int flags, uint32_t *amax_gy, void *stream) {
     using namespace snvc;
     if (N <= 0 || C <= 0 || S <= 0) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_reduce: sizes must be positive");
     if (!raw || !gy || !sums || !workspace) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_reduce: null pointer");
     if ((flags & SNVC_EPI_ADD_PRE) && !residual) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_reduce: ADD_PRE needs the residual");
     if (N * C > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_act_backward_reduce: N*C > 65535");
-    if (!(flags & SNVC_EPI_ADD_PRE)) residual = nullptr;
+    // the residual only enters through the activation's derivative: without one (conv6: bn(conv) + x) it is not read (r6: 736 MB per pass at cfg4)
+    if (!(flags & SNVC_EPI_ADD_PRE) || !(flags & (SNVC_EPI_RELU | SNVC_EPI_SIGMOID))) residual = nullptr;
     if (raw_batch_stride == 0) raw_batch_stride = C * S;
     if (gy_batch_stride == 0) gy_batch_stride = C * S;
     if (res_batch_stride == 0) res_batch_stride = C * S;
@@ -582,11 +847,11 @@ int snvc_act_backward_reduce(const float *raw, const float *gy, const float *res
     if (v4)
         act_bwd_partial_kernel<4><<<grid, 256, 0, as_stream(stream)>>>(raw, gy, residual, scale, shift, (double *)workspace, C, S,
                                                                        raw_batch_stride, gy_batch_stride, res_batch_stride,
-                                                                       per_sample, flags, kNormSplits);
+                                                                       per_sample, flags, kNormSplits, amax_gy);
     else
         act_bwd_partial_kernel<1><<<grid, 256, 0, as_stream(stream)>>>(raw, gy, residual, scale, shift, (double *)workspace, C, S,
                                                                        raw_batch_stride, gy_batch_stride, res_batch_stride,
-                                                                       per_sample, flags, kNormSplits);
+                                                                       per_sample, flags, kNormSplits, amax_gy);
     int rc = check_launch("snvc_act_backward_reduce(partial)");
     if (rc) return rc;
     act_bwd_fold_kernel<<<dim3((unsigned)ceil_div<int64_t>(N * C, 128)), 128, 0, as_stream(stream)>>>(
@@ -613,7 +878,8 @@ int snvc_act_backward_apply_amax(const float *raw, const float *gy, const float 
     if (!raw || !gy || !coef_g || !draw) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_apply: null pointer");
     if ((flags & SNVC_EPI_ADD_PRE) && !residual) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_apply: ADD_PRE needs the residual");
     if (C > 65535 || N > 65535) return fail(SNVC_ERR_UNSUPPORTED, "snvc_act_backward_apply: C or N > 65535");
-    if (!(flags & SNVC_EPI_ADD_PRE)) residual = nullptr;
+    // the residual only enters through the activation's derivative: without one (conv6: bn(conv) + x) it is not read (r6: 736 MB per pass at cfg4)
+    if (!(flags & SNVC_EPI_ADD_PRE) || !(flags & (SNVC_EPI_RELU | SNVC_EPI_SIGMOID))) residual = nullptr;
     if (raw_batch_stride == 0) raw_batch_stride = C * S;
     if (gy_batch_stride == 0) gy_batch_stride = C * S;
     if (res_batch_stride == 0) res_batch_stride = C * S;
@@ -663,6 +929,90 @@ int snvc_affine_act_amax(const float *x, const float *scale, const float *shift,
     affine_act_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, scale, shift, residual, y, C, S, x_batch_stride,
                                                            y_batch_stride, res_batch_stride, per_sample, flags, amax);
     return check_launch("snvc_affine_act");
+}
+
+// EXPERIMENT knobs (environment): SNVC_TWIN_CAP total workgroups, SNVC_TWIN_CHUNK 1 = a contiguous run of the row per workgroup
+static int twin_env(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
+static int twin_chunked() { static const int v = twin_env("SNVC_TWIN_CHUNK", 0); return v; }
+static unsigned twin_blocks(int64_t s4, int64_t outer) {
+    static const int cap_total = twin_env("SNVC_TWIN_CAP", 2048);
+    int64_t b = snvc::ceil_div<int64_t>(s4, 256);
+    const int64_t cap = snvc::ceil_div<int64_t>(cap_total, outer > 0 ? outer : 1);
+    if (b > cap) b = cap;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+static int twin_check(const char *who, int64_t N, int64_t C, int64_t S, const void *t_hi, const void *t_lo, const float *mul,
+                      int64_t twin_batch_stride, std::initializer_list<const void *> f32, std::initializer_list<int64_t> strides) {
+    using namespace snvc;
+    if (N <= 0 || C <= 0 || S <= 0) { set_error("%s: sizes must be positive", who); return SNVC_ERR_INVALID_ARGUMENT; }
+    if (C % 8 || S % 4) { set_error("%s: C must be a multiple of 8 and the voxel count of 4", who); return SNVC_ERR_UNSUPPORTED; }
+    if (!t_hi || !t_lo || !mul) { set_error("%s: null twin pointer", who); return SNVC_ERR_INVALID_ARGUMENT; }
+    if (C / 8 > 65535 || N > 65535) { set_error("%s: C/8 or N > 65535", who); return SNVC_ERR_UNSUPPORTED; }
+    uintptr_t bits = reinterpret_cast<uintptr_t>(t_hi) | reinterpret_cast<uintptr_t>(t_lo);
+    for (const void *q : f32) bits |= reinterpret_cast<uintptr_t>(q);
+    if (bits & 15) { set_error("%s: tensors must be 16-byte aligned", who); return SNVC_ERR_INVALID_ARGUMENT; }
+    for (int64_t st : strides)
+        if (st % 4) { set_error("%s: batch strides must be multiples of 4 elements", who); return SNVC_ERR_INVALID_ARGUMENT; }
+    if (twin_batch_stride % 8) { set_error("%s: the twin's batch stride must be a multiple of 8", who); return SNVC_ERR_INVALID_ARGUMENT; }
+    return SNVC_OK;
+}
+
+int snvc_affine_act_twin(const float *x, const float *scale, const float *shift, const float *residual, float *y, void *twin_hi,
+                         void *twin_lo, const float *twin_mul, int64_t N, int64_t C, int64_t S, int64_t x_batch_stride,
+                         int64_t y_batch_stride, int64_t res_batch_stride, int64_t twin_batch_stride, int per_sample, int flags,
+                         uint32_t *amax, void *stream) {
+    using namespace snvc;
+    if (!x || !y) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_affine_act_twin: null pointer");
+    if ((flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) && !residual)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_affine_act_twin: residual flag without residual pointer");
+    if (!(flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST))) residual = nullptr;
+    if (x_batch_stride == 0) x_batch_stride = C * S;
+    if (y_batch_stride == 0) y_batch_stride = C * S;
+    if (res_batch_stride == 0) res_batch_stride = C * S;
+    if (twin_batch_stride == 0) twin_batch_stride = 2 * C * S;
+    int rc = twin_check("snvc_affine_act_twin", N, C, S, twin_hi, twin_lo, twin_mul, twin_batch_stride, {x, y, residual},
+                        {x_batch_stride, y_batch_stride, res_batch_stride});
+    if (rc) return rc;
+    dim3 grid(twin_blocks(S / 4, N * C / 8), (unsigned)(C / 8), (unsigned)N);
+    affine_act_twin_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, scale, shift, residual, y, reinterpret_cast<_Float16 *>(twin_hi),
+                                                                reinterpret_cast<_Float16 *>(twin_lo), twin_mul, C, S, x_batch_stride,
+                                                                y_batch_stride, res_batch_stride, twin_batch_stride, per_sample, flags, amax, twin_chunked());
+    return check_launch("snvc_affine_act_twin");
+}
+
+int snvc_act_backward_apply_twin(const float *raw, const float *gy, const float *residual, const float *scale, const float *shift,
+                                 const float *coef_g, const float *coef_raw, const float *coef_const, float *draw, float *g_out,
+                                 void *twin_hi, void *twin_lo, const float *twin_mul, int64_t N, int64_t C, int64_t S,
+                                 int64_t raw_batch_stride, int64_t gy_batch_stride, int64_t res_batch_stride, int64_t twin_batch_stride,
+                                 int per_sample, int flags, uint32_t *amax, void *stream) {
+    using namespace snvc;
+    if (!raw || !gy || !coef_g || !draw) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_apply_twin: null pointer");
+    if ((flags & SNVC_EPI_ADD_PRE) && !residual) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_act_backward_apply_twin: ADD_PRE needs the residual");
+    // the residual only enters through the activation's derivative: without one (conv6: bn(conv) + x) it is not read (r6: 736 MB per pass at cfg4)
+    if (!(flags & SNVC_EPI_ADD_PRE) || !(flags & (SNVC_EPI_RELU | SNVC_EPI_SIGMOID))) residual = nullptr;
+    if (raw_batch_stride == 0) raw_batch_stride = C * S;
+    if (gy_batch_stride == 0) gy_batch_stride = C * S;
+    if (res_batch_stride == 0) res_batch_stride = C * S;
+    if (twin_batch_stride == 0) twin_batch_stride = 2 * C * S;
+    int rc = twin_check("snvc_act_backward_apply_twin", N, C, S, twin_hi, twin_lo, twin_mul, twin_batch_stride, {raw, gy, residual, draw, g_out},
+                        {raw_batch_stride, gy_batch_stride, res_batch_stride});
+    if (rc) return rc;
+    dim3 grid(twin_blocks(S / 4, N * C / 8), (unsigned)(C / 8), (unsigned)N);
+    act_bwd_apply_twin_kernel<<<grid, 256, 0, as_stream(stream)>>>(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const, draw, g_out,
+                                                                   reinterpret_cast<_Float16 *>(twin_hi), reinterpret_cast<_Float16 *>(twin_lo),
+                                                                   twin_mul, C, S, raw_batch_stride, gy_batch_stride, res_batch_stride,
+                                                                   twin_batch_stride, per_sample, flags, amax, twin_chunked());
+    return check_launch("snvc_act_backward_apply_twin");
+}
+
+int snvc_split_scale_bound(const float *a, const uint32_t *amax_p, const float *b, const float *l1, const uint32_t *amax_x, const float *c,
+                           const uint32_t *amax_r, int64_t rows, int64_t C, float *mul_out, void *stream) {
+    using namespace snvc;
+    if (rows <= 0 || C <= 0 || rows % C || rows > (1 << 24)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_split_scale_bound: rows must be a positive multiple of C");
+    if (!mul_out) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_split_scale_bound: null pointer");
+    split_scale_bound_kernel<<<1, 256, 0, as_stream(stream)>>>(a, amax_p, b, l1, amax_x, c, amax_r, (int)rows, (int)C, mul_out);
+    return check_launch("snvc_split_scale_bound");
 }
 
 }  // extern "C"

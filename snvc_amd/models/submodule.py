@@ -155,30 +155,52 @@ def _norm_from_raw(raw, norm, plan, residual, flags, out=None):
     raise NotImplementedError(f"norm layer {type(norm).__name__} is not on the path")
 
 
-def _norm_forward(layer, norm, plan, x, residual, flags, out, keep_raw, exact=False):
+def _norm_forward(layer, norm, plan, x, residual, flags, out, keep_raw, exact=False, twin=None):
     """Shared forward: returns (y, raw, scale, shift, mean, var, per_sample).  `raw` is the conv
     output before the affine/activation (None when the single fused launch was used).
     ``keep_raw`` (the autograd functions): the pass that writes y also leaves max|y| in a device word tagged onto y (ops.tag_amax):
-    the next layer's split-operand weight gradient scales its x operand by it (r6)."""
+    the next layer's split-operand weight gradient scales its x operand by it (r6).  ``twin`` (r6, see _twin_mul_forward): that pass
+    also writes y's split C8 twin for a consumer that runs on the split kernels."""
     am = ops.amax_word(x.device) if (keep_raw and x.is_cuda) else None
-    res = _norm_forward_impl(layer, norm, plan, x, residual, flags, out, keep_raw, exact, am)
+    res = _norm_forward_impl(layer, norm, plan, x, residual, flags, out, keep_raw, exact, am, twin)
     if am is not None and res[1] is not None and res[0] is not res[1]:      # y came out of affine_act (not the raw tensor itself)
         ops.tag_amax(res[0], am)
     return res
 
 
-def _norm_forward_impl(layer, norm, plan, x, residual, flags, out, keep_raw, exact, am):
+def _twin_mul_forward(twin, scale, shift, residual, c, device):
+    """The scale of y's split twin when the layer's consumer asked for one (``twin`` = (L1 norms of the filters per output channel,
+    the words of max|x|)): from the bound  max_c(|scale_c| * L1_c * max|x| + |shift_c|) + max|residual|  -- |raw_c| <= L1_c * max|x| --
+    in one small launch, or None when a maximum is not known on the device."""
+    if twin is None or twin[1] is None:
+        return None
+    ar = None
+    if residual is not None:
+        ar = ops.amax_of(residual)
+        if ar is None:
+            return None
+    rows = scale.numel() if scale is not None else c
+    return ops.split_scale_bound(rows, c, device, b=scale, l1=twin[0], amax_x=twin[1], cc=shift, amax_r=ar)
+
+
+def _norm_forward_impl(layer, norm, plan, x, residual, flags, out, keep_raw, exact, am, twin=None):
+    _affine_act = ops.affine_act
+    if twin is not None:
+        def _affine_act(raw, scale, shift, residual=None, flags=0, per_sample=False, out=None, amax=None):
+            ok = ops.twin_ok(raw) and not (flags & EPI_SIGMOID)           # a sigmoid's result is not bounded by its argument's bound
+            tm = _twin_mul_forward(twin, scale, shift, residual, raw.size(1), raw.device) if ok else None
+            return ops.affine_act(raw, scale, shift, residual, flags, per_sample=per_sample, out=out, amax=amax, twin_mul=tm)
     if norm is None:
         if keep_raw and (flags or residual is not None):
             raw = layer(x, None, None, None, 0, None, exact=exact)
-            return ops.affine_act(raw, None, None, residual, flags, out=out, amax=am), raw, None, None, None, None, False
+            return _affine_act(raw, None, None, residual, flags, out=out, amax=am), raw, None, None, None, None, False
         y = layer(x, None, None, residual, flags, out, exact=exact)
         return y, (y if keep_raw else None), None, None, None, None, False
     if isinstance(norm, nn.BatchNorm3d) and not (norm.training or norm.running_mean is None):
         scale, bias = _folded_bn(norm, plan)
         if keep_raw:
             raw = layer(x, None, None, None, 0, None, exact=exact)
-            return ops.affine_act(raw, scale, bias, residual, flags, out=out, amax=am), raw, scale, bias, None, None, False
+            return _affine_act(raw, scale, bias, residual, flags, out=out, amax=am), raw, scale, bias, None, None, False
         return layer(x, scale, bias, residual, flags, out, exact=exact), None, scale, bias, None, None, False
     # statistics of the conv output are needed first: conv -> stats -> normalise (+res, +act)
     if isinstance(norm, nn.BatchNorm3d) and not exact:
@@ -190,17 +212,17 @@ def _norm_forward_impl(layer, norm, plan, x, residual, flags, out, keep_raw, exa
             _ROUTES["conv_stats_epilogue"] += 1
             _bn_track(norm, mean, var, raw.numel() / raw.size(1))
             dst = out if out is not None else (None if keep_raw else raw)
-            return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst, amax=am), raw, scale, shift, mean, var, False
+            return _affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst, amax=am), raw, scale, shift, mean, var, False
     raw = layer(x, None, None, None, 0, None, exact=exact)
     c = raw.size(1)
     dst = out if out is not None else (None if keep_raw else raw)
     if isinstance(norm, nn.GroupNorm):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, norm.num_groups, True, norm.eps)
-        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=True, out=dst, amax=am), raw, scale, shift, mean, var, True
+        return _affine_act(raw, scale, shift, residual, flags, per_sample=True, out=dst, amax=am), raw, scale, shift, mean, var, True
     if isinstance(norm, nn.BatchNorm3d):
         scale, shift, mean, var = ops.norm_stats(raw, norm.weight, norm.bias, c, False, norm.eps)
         _bn_track(norm, mean, var, raw.numel() / c)      # nn.BatchNorm3d bookkeeping: momentum update with the unbiased variance
-        return ops.affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst, amax=am), raw, scale, shift, mean, var, False
+        return _affine_act(raw, scale, shift, residual, flags, per_sample=False, out=dst, amax=am), raw, scale, shift, mean, var, False
     raise NotImplementedError(f"norm layer {type(norm).__name__} is not on the path")
 
 
@@ -226,6 +248,111 @@ def _dgrad_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
     return plan.dgrad
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# r6: the training step's forward and data-gradient convolutions on the split kernels.
+# A convolution's MFMA operand is 8 channels of one voxel (split C8 pairs); training keeps float32 NCDHW for the weight gradients, the
+# statistics and autograd.  Both exist side by side: the pass that writes a tensor (affine_act forward, act_backward_apply backward)
+# also writes its split TWIN when the consumer runs on the split kernels (+4 bytes per element on a pass that moves 8-12, against a
+# layout pass of 8), scaled by a power of two from an upper bound of the tensor's maximum that is known before the pass runs
+# (_twin_mul_forward / _epilogue_backward); the split kernels write float32 NCDHW (y_f32).  Measured per layer in
+# profiles/r6/kernel_experiments_r6.txt.  Which layers: the half- / quarter-resolution, stride-2 and transposed 3x3x3 layers
+# (Cin * Cout >= 2048); the full-resolution 32 -> 32 layers stay on the fp32 Winograd kernels, which already halve the products.
+X3_TRAIN = [True]          # tools / tests flip this
+X3_TRAIN_MIN_CC = [2048]   # Cin * Cout from which a layer takes the route
+
+
+def _x3_train_route(conv: nn.Module, x: torch.Tensor) -> bool:
+    if not (X3_TRAIN[0] and x.is_cuda and x.dtype == torch.float32 and x.dim() == 5 and x.numel() > 0):
+        return False
+    if conv.bias is not None or conv.groups != 1:
+        return False
+    k, st, p, d, transposed = _conv_geometry(conv)
+    cin, cout = conv.in_channels, conv.out_channels
+    if k != 3 or p != 1 or d != 1 or st not in (1, 2) or (transposed and st != 2):
+        return False
+    if cin % 32 or cout % 32 or cin * cout < X3_TRAIN_MIN_CC[0]:
+        return False
+    if st == 2 and not transposed and any(int(e) % 2 for e in x.shape[2:]):
+        return False                                          # odd extents: the fp32 route crops / pads
+    out_vox = x[0, 0].numel() * (8 if transposed else 1) // (8 if (st == 2 and not transposed) else 1)
+    return x[0, 0].numel() % 4 == 0 and out_vox % 4 == 0
+
+
+def _l1_out(conv: nn.Module, plan: _Plan) -> torch.Tensor:
+    """sum |w| per OUTPUT channel (cached per weight version): |conv(x)[c]| <= l1[c] * max|x|."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
+    if getattr(plan, "l1", None) is None or plan.l1_key != key:
+        dims = (0, 2, 3, 4) if isinstance(conv, nn.ConvTranspose3d) else (1, 2, 3, 4)
+        plan.l1 = w.detach().abs().sum(dims).float().contiguous()
+        plan.l1_key = key
+    return plan.l1
+
+
+def _l1_in(conv: nn.Module, plan: _Plan) -> torch.Tensor:
+    """sum |w| per INPUT channel: the data gradient's filters (|dgrad(g)[c]| <= l1_in[c] * max|g|)."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
+    if getattr(plan, "l1_in", None) is None or plan.l1_in_key != key:
+        dims = (1, 2, 3, 4) if isinstance(conv, nn.ConvTranspose3d) else (0, 2, 3, 4)
+        plan.l1_in = w.detach().abs().sum(dims).float().contiguous()
+        plan.l1_in_key = key
+    return plan.l1_in
+
+
+def _x3_train_layers(conv: nn.Module, plan: _Plan):
+    """(forward layer, data-gradient layer) on the split kernels, weights scaled on the device; rebuilt when the weights change."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.device, _GENERATION[0])
+    if getattr(plan, "x3t", None) is None or plan.x3t_key != key:
+        k, s, p, d, transposed = _conv_geometry(conv)
+        wd = w.detach()
+        wm = ops.split_scale_of(wd.contiguous())
+        fwd = ops.Conv3dLayerX3(wd, 3, s, 1, 1, transposed, w_mul_dev=wm)
+        if transposed:
+            dg = ops.Conv3dLayerX3(wd, 3, 2, 1, 1, False, w_mul_dev=wm)
+        elif s == 1:
+            dg = ops.Conv3dLayerX3(_flip3d(wd), 3, 1, 1, 1, False, w_mul_dev=wm)
+        else:
+            dg = ops.Conv3dLayerX3(wd, 3, 2, 1, 1, True, w_mul_dev=wm)
+        plan.x3t, plan.x3t_key = (fwd, dg), key
+    return plan.x3t
+
+
+def _split_operand(t: torch.Tensor, amax: Optional[torch.Tensor]):
+    """(pair, mul) of a float32 tensor for the split kernels: the twin its producer wrote, else a layout pass of its own (and a note
+    to the producer, which writes the twin from the next step on)."""
+    tw = ops.twin_of(t)
+    if tw is not None:
+        _ROUTES["x3_train_twin"] += 1
+        return tw
+    src = getattr(t, "snvc_twin_src", None)
+    if src is not None:
+        src.want_twin = True
+    _ROUTES["x3_train_layout_pass"] += 1
+    tc = t if (ops._dense_inner(t) and t.data_ptr() % 16 == 0) else t.contiguous()
+    mul = ops.split_scale_bound(1, 1, t.device, amax_x=amax) if amax is not None else ops.split_scale_of(tc.contiguous())
+    return ops.to_split(tc, mul_dev=mul), mul
+
+
+class _X3TrainLayer:
+    """The plain convolution of a layer on the split kernels behind Conv3dLayer's calling convention (what _norm_forward_impl calls
+    with keep_raw): float32 NCDHW in (through its twin), float32 NCDHW out."""
+    ksize = 3
+
+    def __init__(self, layer: "ops.Conv3dLayerX3"):
+        self.layer = layer
+
+    def __call__(self, x, scale=None, bias=None, residual=None, flags=0, out=None, exact=False):
+        if scale is not None or bias is not None or residual is not None or flags or out is not None:
+            raise RuntimeError("_X3TrainLayer: the plain convolution only")
+        pair, mul = _split_operand(x, ops.amax_of(x))
+        return self.layer(pair, 0, None, None, flags=0, out_exp=0, to_f32=True, x_mul_dev=mul)
+
+    def forward_stats(self, *a, **k):
+        return None
+
+
 class _GradBox:
     """Where a skip connection's gradient waits for the layer whose data gradient it is added to (see _SkipTap)."""
     __slots__ = ("grad", "consumed", "took")
@@ -244,7 +371,11 @@ class _SkipTap(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, box):
         ctx.box = box
-        return x.view_as(x)
+        out = x.view_as(x)
+        am = ops.amax_of(x)               # the view is the same data: its consumer (a residual) may need max|x| for a twin's bound
+        if am is not None:
+            ops.tag_amax(out, am)
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -276,15 +407,19 @@ class _ConvNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, conv, norm, flags, plan, grad_box=None):
         ctx.grad_box = grad_box
-        layer = _get_layer(conv, plan)
+        ctx.x3 = _x3_train_route(conv, x)
+        layer = _X3TrainLayer(_x3_train_layers(conv, plan)[0]) if ctx.x3 else _get_layer(conv, plan)
         # k5 / k7 layers under autograd: Winograd F(4,5) / F(4,7) forward and data gradient like at inference (r4; the local
         # trunk's conv1 3.7 instead of 7.5 ms) unless TRAIN_EXACT_K57 asks for the direct kernels' exact fp32 FMA chain -- the
         # F(4,7) forward is 1e-4 of the range off, inside the 1e-3 contract, but it moves a few ReLU masks, which gradient
         # comparisons against another implementation see as isolated differences
-        y, raw, scale, shift, mean, var, per_sample = _norm_forward(layer, norm, plan, x, residual, flags, None, True,
-                                                                    exact=layer.ksize >= 5 and TRAIN_EXACT_K57[0])
-        ctx.conv, ctx.norm, ctx.flags, ctx.plan, ctx.per_sample = conv, norm, flags, plan, per_sample
         ctx.x_amax = ops.amax_of(x)          # max|x| left by the pass that wrote x (None: the weight gradient finds it itself)
+        twin = (_l1_out(conv, plan), ctx.x_amax) if (getattr(plan, "want_twin", False) and X3_TRAIN[0] and x.is_cuda) else None
+        y, raw, scale, shift, mean, var, per_sample = _norm_forward(layer, norm, plan, x, residual, flags, None, True,
+                                                                    exact=layer.ksize >= 5 and TRAIN_EXACT_K57[0], twin=twin)
+        if y is not raw:
+            y.snvc_twin_src = plan            # a consumer on the split kernels asks for the twin here (_split_operand)
+        ctx.conv, ctx.norm, ctx.flags, ctx.plan, ctx.per_sample = conv, norm, flags, plan, per_sample
         ctx.has_res = residual is not None
         ctx.train_stats = mean is not None
         res_saved = residual if (residual is not None and (flags & EPI_ADD_PRE)) else None
@@ -297,9 +432,11 @@ class _ConvNormActFn(torch.autograd.Function):
         x, raw, scale, shift, mean, var, res = ctx.saved_tensors
         conv, norm, flags, plan = ctx.conv, ctx.norm, ctx.flags, ctx.plan
         needs = ctx.needs_input_grad
-        g_amax = ops.amax_word(raw.device) if (needs[1] and raw.is_cuda) else None
+        x3 = ctx.x3 and needs[0]
+        g_amax = ops.amax_word(raw.device) if ((needs[1] or x3) and raw.is_cuda) else None
+        twin = (_l1_out(conv, plan), ctx.x_amax) if (x3 and ctx.x_amax is not None) else None
         draw, gres, dg, db = _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, ctx.per_sample, ctx.train_stats,
-                                                ctx.has_res and needs[4], needs[2], needs[3], amax_out=g_amax)
+                                                ctx.has_res and needs[4], needs[2], needs[3], amax_out=g_amax, twin=twin)
         if draw is gy:                       # no epilogue pass ran: nothing wrote the word
             g_amax = None
         # data and weight gradients
@@ -319,7 +456,11 @@ class _ConvNormActFn(torch.autograd.Function):
         # gradient sees x with that padding position made explicit (a zero plane contributes nothing)
         odd = (st == 2 and not transposed) and any(int(e) % 2 for e in x.shape[2:])
         gx = None
-        if needs[0]:
+        if x3:                               # r6: the data gradient on the split kernels, draw through its twin, the skip's gradient in the epilogue
+            pair, mul = _split_operand(draw, g_amax)
+            gx = _x3_train_layers(conv, plan)[1](pair, 0, None, None, flags=0, out_exp=0, to_f32=True, x_mul_dev=mul, residual_f32=extra)
+            _ROUTES["x3_train_dgrad"] += 1
+        elif needs[0]:
             if odd:
                 gx = dl(draw, None, None, None, 0, None)[:, :, :x.size(2), :x.size(3), :x.size(4)].contiguous()
                 if extra is not None:
@@ -338,10 +479,22 @@ class _ConvNormActFn(torch.autograd.Function):
 
 
 def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_sample, train_stats, want_res, want_gamma, want_beta,
-                       amax_out=None):
+                       amax_out=None, twin=None):
     """Backward of  y = act(norm(raw) [+ res]) [+ res]  given gy: returns (draw, gres, dgamma, dbeta) on the HIP
-    reduction / apply kernels (BatchNorm / GroupNorm backward coefficients in fp64)."""
+    reduction / apply kernels (BatchNorm / GroupNorm backward coefficients in fp64).  ``twin`` (r6) = (L1 norms of the layer's
+    filters per output channel, the words of max|x|): the apply pass also writes draw's split twin, scaled from the bound
+    max_c(|A_c| * max|gy| + |B_c| * L1_c * max|x| + |C_c|) with max|gy| taken by the reduction pass."""
     gy = gy.contiguous()
+    am_gy = ops.amax_word(raw.device) if (twin is not None and norm is not None and ops.twin_ok(raw) and not (flags & EPI_SIGMOID)) else None
+
+    def twin_mul(coef_g, coef_raw, coef_const):
+        if am_gy is None:
+            return None
+        if coef_raw is None:               # frozen statistics: draw = A * g
+            return ops.split_scale_bound(coef_g.numel(), raw.size(1), raw.device, a=coef_g, amax_p=am_gy, b=torch.zeros_like(coef_g))
+        return ops.split_scale_bound(coef_g.numel(), raw.size(1), raw.device, a=coef_g, amax_p=am_gy, b=coef_raw, l1=twin[0], amax_x=twin[1],
+                                     cc=coef_const)
+
     n, c = raw.shape[0], raw.shape[1]
     s = raw[0, 0].numel()
     dev = raw.device
@@ -352,7 +505,7 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
         coef_raw = coef_const = None
         per_sample = False
     else:
-        sums = ops.act_backward_reduce(raw, gy, res, scale, shift, act_flags, per_sample)   # [n, c, 2] fp64
+        sums = ops.act_backward_reduce(raw, gy, res, scale, shift, act_flags, per_sample, amax_gy=am_gy)   # [n, c, 2] fp64
         gam = norm.weight.detach().double() if norm.weight is not None else torch.ones(c, device=dev, dtype=torch.float64)
         if isinstance(norm, nn.GroupNorm):
             groups = norm.num_groups
@@ -378,7 +531,7 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
                     dgamma = dbeta = None
                 want_g = want_res and bool(flags & EPI_ADD_PRE)
                 draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
-                                                     per_sample, want_g, amax=amax_out)
+                                                     per_sample, want_g, amax=amax_out, twin_mul=twin_mul(coef_g, coef_raw, coef_const))
                 gres = (g_out if (flags & EPI_ADD_PRE) else gy) if want_res else None
                 return draw, gres, (dgamma if want_gamma else None), (dbeta if want_beta else None)
             sg, sgr = sums[..., 0].sum(0), sums[..., 1].sum(0)                    # [c]
@@ -404,7 +557,7 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
         draw, g_out = gy, gy
     else:
         draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
-                                             per_sample, want_g, amax=amax_out)
+                                             per_sample, want_g, amax=amax_out, twin_mul=twin_mul(coef_g, coef_raw, coef_const))
     gres = None
     if want_res:
         gres = g_out if (flags & EPI_ADD_PRE) else gy

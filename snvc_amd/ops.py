@@ -816,17 +816,18 @@ def bn_backward_coefs(sums, mean, var, gamma, count: float, eps: float):
     return out[0], out[1], out[2], out[3], out[4]
 
 
-def act_backward_reduce(raw, gy, residual, scale, shift, flags: int, per_sample: bool) -> torch.Tensor:
-    """Per (n, c): [sum(g), sum(g*raw)] in fp64, g = gy * act'(raw*scale + shift [+ residual])."""
+def act_backward_reduce(raw, gy, residual, scale, shift, flags: int, per_sample: bool, amax_gy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per (n, c): [sum(g), sum(g*raw)] in fp64, g = gy * act'(raw*scale + shift [+ residual]).  ``amax_gy``: zeroed words (amax_word)
+    that receive the bit pattern of max|gy| -- the pass reads all of gy anyway."""
     n, c = raw.shape[0], raw.shape[1]
     s = raw[0, 0].numel()
     sums = torch.empty((n, c, 2), dtype=torch.float64, device=raw.device)
     ws = torch.empty(_lib.lib().snvc_act_backward_workspace_bytes(n, c), dtype=torch.uint8, device=raw.device)
     with torch.cuda.device(raw.device):
-        check(_lib.lib().snvc_act_backward_reduce(_ptr(raw), _ptr(gy), _ptr(residual), _ptr(scale), _ptr(shift),
-                                                  _ptr(sums), _ptr(ws), n, c, s, _batch_stride(raw), _batch_stride(gy),
-                                                  _batch_stride(residual) if residual is not None else 0,
-                                                  1 if per_sample else 0, flags, _stream(raw)),
+        check(_lib.lib().snvc_act_backward_reduce_amax(_ptr(raw), _ptr(gy), _ptr(residual), _ptr(scale), _ptr(shift),
+                                                       _ptr(sums), _ptr(ws), n, c, s, _batch_stride(raw), _batch_stride(gy),
+                                                       _batch_stride(residual) if residual is not None else 0,
+                                                       1 if per_sample else 0, flags, _ptr(amax_gy), _stream(raw)),
               "snvc_act_backward_reduce")
     return sums
 
@@ -877,14 +878,69 @@ def amax_of(t: torch.Tensor) -> Optional[torch.Tensor]:
     return tag[0]
 
 
+def twin_ok(t: torch.Tensor) -> bool:
+    """Can the pass that writes ``t`` (float32 [N,C,D,H,W]) write its split C8 twin as well (snvc_*_twin)?"""
+    return (t.is_cuda and t.dtype == torch.float32 and t.dim() == 5 and t.size(1) % 8 == 0 and t[0, 0].numel() % 4 == 0
+            and t.numel() > 0 and t.size(1) // 8 <= 65535)
+
+
+def twin_empty(like: torch.Tensor) -> torch.Tensor:
+    n, c = like.shape[0], like.shape[1]
+    return torch.empty((n, 2, c // 8) + tuple(like.shape[2:]) + (8,), dtype=torch.float16, device=like.device)
+
+
+def tag_twin(t: torch.Tensor, pair: torch.Tensor, mul_dev: torch.Tensor) -> torch.Tensor:
+    """Remember ``t``'s split twin (``pair`` holds t * mul_dev) on the tensor object; void once t is written to (``_version``)."""
+    t.snvc_twin_tag = (pair, mul_dev, t._version)
+    return t
+
+
+def twin_of(t: torch.Tensor):
+    """(pair, mul_dev) tagged by the pass that wrote ``t``, or None."""
+    tag = getattr(t, "snvc_twin_tag", None)
+    if tag is None or tag[2] != t._version or tag[0].device != t.device:
+        return None
+    return tag[0], tag[1]
+
+
+def split_scale_bound(rows: int, c: int, device, a=None, amax_p=None, b=None, l1=None, amax_x=None, cc=None, amax_r=None) -> torch.Tensor:
+    """The scale of a twin from an upper bound of its tensor's maximum, on the device (snvc_split_scale_bound):
+    bound = max_r(|a[r]| * P + |b[r]| * l1[r % C] * X + |cc[r]|) + R with P / X / R the values of the amax words given."""
+    out = torch.empty(1, dtype=torch.float32, device=device)
+    for v in (a, b, cc):
+        if v is not None and (v.dtype != torch.float32 or v.numel() != rows or not v.is_contiguous()):
+            raise RuntimeError("split_scale_bound: a / b / c must be contiguous float32 vectors of `rows` elements")
+    if l1 is not None and (l1.dtype != torch.float32 or l1.numel() != c or not l1.is_contiguous()):
+        raise RuntimeError("split_scale_bound: l1 must be a contiguous float32 vector of C elements")
+    for w in (amax_p, amax_x, amax_r):
+        if w is not None and (w.dtype != torch.int32 or w.numel() != AMAX_SLOTS or not w.is_contiguous()):
+            raise RuntimeError("split_scale_bound: amax words come from amax_word()")
+    with torch.cuda.device(device):
+        check(_lib.lib().snvc_split_scale_bound(_ptr(a), _ptr(amax_p), _ptr(b), _ptr(l1), _ptr(amax_x), _ptr(cc), _ptr(amax_r), rows, c,
+                                                _ptr(out), ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)),
+              "snvc_split_scale_bound")
+    return out
+
+
 def act_backward_apply(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const, flags: int, per_sample: bool,
-                       want_g: bool, amax: Optional[torch.Tensor] = None):
+                       want_g: bool, amax: Optional[torch.Tensor] = None, twin_mul: Optional[torch.Tensor] = None):
     """draw = coef_g*g + coef_raw*raw + coef_const (per channel or per (n,c)); optionally also g.  ``amax``: a zeroed int32 word
-    that receives the bit pattern of max|draw| (amax_word)."""
+    that receives the bit pattern of max|draw| (amax_word).  ``twin_mul`` (r6): also write draw's split twin scaled by that device
+    float (split_scale_bound) and tag it onto draw (snvc_act_backward_apply_twin)."""
     n, c = raw.shape[0], raw.shape[1]
     s = raw[0, 0].numel()
     draw = torch.empty(raw.shape, dtype=torch.float32, device=raw.device)
     g_out = torch.empty(raw.shape, dtype=torch.float32, device=raw.device) if want_g else None
+    if twin_mul is not None and twin_ok(draw) and _dense_inner(raw) and _dense_inner(gy) and (residual is None or _dense_inner(residual)):
+        pair = twin_empty(draw)
+        with torch.cuda.device(raw.device):
+            check(_lib.lib().snvc_act_backward_apply_twin(
+                _ptr(raw), _ptr(gy), _ptr(residual), _ptr(scale), _ptr(shift), _ptr(coef_g), _ptr(coef_raw), _ptr(coef_const), _ptr(draw),
+                _ptr(g_out), _ptr(pair), _lo_ptr(pair), _ptr(twin_mul), n, c, s, _batch_stride(raw), _batch_stride(gy),
+                _batch_stride(residual) if residual is not None else 0, _batch_stride(pair), 1 if per_sample else 0, flags, _ptr(amax),
+                _stream(raw)), "snvc_act_backward_apply_twin")
+        tag_twin(draw, pair, twin_mul)
+        return draw, g_out
     with torch.cuda.device(raw.device):
         check(_lib.lib().snvc_act_backward_apply_amax(_ptr(raw), _ptr(gy), _ptr(residual), _ptr(scale), _ptr(shift),
                                                       _ptr(coef_g), _ptr(coef_raw), _ptr(coef_const), _ptr(draw), _ptr(g_out),
@@ -915,8 +971,10 @@ def norm_stats(x, gamma, beta, groups: int, per_sample: bool, eps: float):
     return scale, shift, mean, var
 
 
-def affine_act(x, scale, shift, residual=None, flags=0, per_sample=False, out=None, amax: Optional[torch.Tensor] = None):
-    """``amax``: a zeroed int32 word that receives the bit pattern of max|out| (amax_word)."""
+def affine_act(x, scale, shift, residual=None, flags=0, per_sample=False, out=None, amax: Optional[torch.Tensor] = None,
+               twin_mul: Optional[torch.Tensor] = None):
+    """``amax``: a zeroed int32 word that receives the bit pattern of max|out| (amax_word).  ``twin_mul`` (r6): also write out's split
+    twin scaled by that device float and tag it onto ``out`` (snvc_affine_act_twin)."""
     _gpu(x, "x")
     if not _dense_inner(x):
         x = x.contiguous()
@@ -929,6 +987,16 @@ def affine_act(x, scale, shift, residual=None, flags=0, per_sample=False, out=No
     n, c = x.shape[0], x.shape[1]
     s = x[0, 0].numel() if n else 0
     if x.numel() == 0:
+        return out
+    if twin_mul is not None and twin_ok(out) and x.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and (
+            residual is None or residual.data_ptr() % 16 == 0):
+        pair = twin_empty(out)
+        with torch.cuda.device(x.device):
+            check(_lib.lib().snvc_affine_act_twin(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), _ptr(pair), _lo_ptr(pair),
+                                                  _ptr(twin_mul), n, c, s, _batch_stride(x), _batch_stride(out),
+                                                  _batch_stride(residual) if residual is not None else 0, _batch_stride(pair),
+                                                  1 if per_sample else 0, flags, _ptr(amax), _stream(x)), "snvc_affine_act_twin")
+        tag_twin(out, pair, twin_mul)
         return out
     with torch.cuda.device(x.device):
         check(_lib.lib().snvc_affine_act_amax(_ptr(x), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n, c, s,
@@ -1522,7 +1590,9 @@ class Conv3dLayerX3:
     (``algo`` forces one), its weights packed on first use."""
 
     def __init__(self, weight: torch.Tensor, ksize: int = 3, stride: int = 1, pad: int = 1, dilation: int = 1, transposed: bool = False,
-                 algo: Optional[int] = None):
+                 algo: Optional[int] = None, w_mul_dev: Optional[torch.Tensor] = None):
+        """``w_mul_dev`` (r6, the training step): a one-element device float, the power of two ``split_scale_of(weight)`` -- the weights
+        are scaled by it ON THE DEVICE instead of by 2**w_exp from a host read of max|w| (weights change every step: no sync)."""
         _gpu(weight, "weight")
         if weight.dtype != torch.float32:
             raise RuntimeError("conv3d weights must be float32")
@@ -1534,9 +1604,15 @@ class Conv3dLayerX3:
         self.ksize, self.stride, self.pad, self.dilation = int(ksize), int(stride), int(pad), int(dilation)
         self.forced_algo = algo         # None: chosen per call
         self.algo = int(algo or 0)
-        self.weight = weight.detach().contiguous()
-        wmax = float(self.weight.abs().max().item()) if weight.numel() else 1.0
-        self.w_exp = 14 - math.frexp(wmax)[1] if wmax > 0 and math.isfinite(wmax) else 0      # wmax * 2^w_exp in [2^13, 2^14)
+        self.w_mul_dev = w_mul_dev
+        self._sc_w = self._bi_0 = None
+        if w_mul_dev is not None:
+            self.weight = (weight.detach() * w_mul_dev).contiguous()
+            self.w_exp = 0
+        else:
+            self.weight = weight.detach().contiguous()
+            wmax = float(self.weight.abs().max().item()) if weight.numel() else 1.0
+            self.w_exp = 14 - math.frexp(wmax)[1] if wmax > 0 and math.isfinite(wmax) else 0      # wmax * 2^w_exp in [2^13, 2^14)
         self._packed = {}
         self.packed = self._pack(self.algo)
         self._affine = {}
@@ -1612,12 +1688,14 @@ class Conv3dLayerX3:
         return hit[:2]
 
     def __call__(self, x, x_exp: int = 0, scale=None, bias=None, residual=None, flags: int = 0, out=None, out_exp: int = 0,
-                 out_f32=None, to_f32: bool = False, head=None, overflow=None, x_mul_dev=None, res_exp: Optional[int] = None):
+                 out_f32=None, to_f32: bool = False, head=None, overflow=None, x_mul_dev=None, res_exp: Optional[int] = None,
+                 residual_f32: Optional[torch.Tensor] = None):
         """y = epilogue(conv(x)).  x: split C8 tensor holding values * 2**x_exp.  Result: a split C8 tensor holding
         y * 2**out_exp, or -- ``to_f32`` / ``out_f32`` -- float32 NCDHW.  ``residual``: a split tensor holding values *
         2**res_exp (default: out_exp).  ``head`` [Cout = 32] weights: returns ``(y, y_head)`` with ``y_head`` the
         float32 [N,1,D,H,W] projection sum_c head[c] * y[:, c] written by the same launch.  ``overflow``: an int32 device
-        tensor that is set to 1 if a value had to be clamped to half's range."""
+        tensor that is set to 1 if a value had to be clamped to half's range.  ``residual_f32`` (r6, float32 result only): a float32
+        [N,Cout,D,H,W] tensor added to the stored result (EPI_ADD_POST implied)."""
         _split_check(x, "x")
         if x.size(2) * 8 != self.cin:
             raise RuntimeError(f"conv3d input must have {self.cin} channels (split C8), got {x.size(2) * 8}")
@@ -1640,14 +1718,30 @@ class Conv3dLayerX3:
             _split_check(residual, "residual")
             if tuple(residual.shape) != (n, 2, self.cout // 8) + out_sp + (8,):
                 raise RuntimeError("residual must have the output's shape (split C8)")
+        if residual_f32 is not None:
+            if not f32 or residual is not None or flags & (EPI_ADD_PRE | EPI_ADD_POST) or self.cout == 1:
+                raise RuntimeError("residual_f32 goes with a float32 result and no other residual")
+            if (residual_f32.dtype != torch.float32 or tuple(residual_f32.shape) != (n, self.cout) + out_sp or not _dense_inner(residual_f32)
+                    or _batch_stride(residual_f32) != _batch_stride(out_f32)):
+                raise RuntimeError("residual_f32 must be a float32 tensor of the result's shape and layout")
+            flags = flags | EPI_ADD_POST
         y_head = None
         if head is not None:
             head = head.detach().reshape(-1).float().contiguous()
             y_head = torch.empty((n, 1) + out_sp, dtype=torch.float32, device=x.device)
         # with a float32 result the epilogue works in units of 2^out_exp too (the residual's) and scales back on the way out: exact
-        sc, bi = self.folded(scale, bias, x_exp, out_exp)
-        if x_mul_dev is not None:           # x holds values * x_mul_dev (a device-side power of two, see split_scale_for); x_exp is 0
-            sc = (sc / x_mul_dev).contiguous()
+        if self.w_mul_dev is not None and scale is None and bias is None and x_exp == 0 and out_exp == 0:
+            # the training step's plain convolution: 1 / w_mul per channel is formed once per weight version, one small launch per call
+            if self._sc_w is None:
+                self._sc_w = (torch.ones(self.cout, device=x.device) / self.w_mul_dev).contiguous()
+                self._bi_0 = torch.zeros(self.cout, device=x.device)
+            sc, bi = (self._sc_w if x_mul_dev is None else (self._sc_w / x_mul_dev)), self._bi_0
+        else:
+            sc, bi = self.folded(scale, bias, x_exp, out_exp)
+            if x_mul_dev is not None:           # x holds values * x_mul_dev (a device-side power of two, see split_scale_for); x_exp is 0
+                sc = (sc / x_mul_dev).contiguous()
+            if self.w_mul_dev is not None:
+                sc = (sc / self.w_mul_dev).contiguous()
         self.algo = self._pick_form(n, out_sp, plain=residual is None and not f32, split_out=not f32 and head is None)
         packed = self._pack(self.algo)
         if n == 0:
@@ -1657,7 +1751,8 @@ class Conv3dLayerX3:
         null = ctypes.c_void_p(0)
         with torch.cuda.device(x.device):
             check(_lib.lib().snvc_f16x3_conv3d_forward(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(packed), _ptr(sc), _ptr(bi),
-                                                       _ptr(residual), _lo_ptr(residual) if residual is not None else null,
+                                                       _ptr(residual if residual_f32 is None else residual_f32),
+                                                       _lo_ptr(residual) if residual is not None else null,
                                                        null if f32 else _ptr(out), null if f32 else _lo_ptr(out),
                                                        _ptr(out_f32) if f32 else null, _ptr(head), _ptr(y_head), float(2.0 ** -out_exp),
                                                        float(2.0 ** (out_exp - (out_exp if res_exp is None else res_exp))),
