@@ -642,6 +642,16 @@ SNVC_API int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *desc_host, const 
                                        const void *res_hi, const void *res_lo, void *y_hi, void *y_lo, float *y_f32,
                                        const float *head, float *y_head, float head_mul, float res_mul, int *overflow,
                                        void *stream);
+/* r6: the split layer with a float32 result + the batch statistics of that result in the same launch (train-mode BatchNorm behind a
+ * layer of the training step that runs on the split kernels): as snvc_conv3d_forward_stats, for the kernel forms that write
+ * float32 through the shared epilogue (3x3x3 stride 1 / 2 and the transposed layer, 256-thread forms).  scale / bias / head_mul as
+ * snvc_f16x3_conv3d_forward (the statistics are those of the STORED values); desc.flags == 0, Cout % 32 == 0.
+ * SNVC_ERR_UNSUPPORTED (nothing launched) when the layer does not take such a form. */
+SNVC_API int64_t snvc_f16x3_conv3d_stats_workspace_bytes(const snvc_conv3d_desc *desc_host);
+SNVC_API int snvc_f16x3_conv3d_forward_stats(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,
+                                             const void *packed_weight, const float *scale, const float *bias, float *y_f32,
+                                             float head_mul, const float *gamma, const float *beta, float *bn_scale,
+                                             float *bn_shift, float *mean, float *var, void *workspace, float eps, void *stream);
 /* The global stack's tail -- classifier(bn(conv6(post)) + v), reference snvc/models/submodule.py:127-146,166 with the composition
  * of snvc/models/vernier.py:366-371 -- is linear in `post` (conv6 has no activation): a transposed layer (k3, s2, p1, op1) to ONE
  * channel with folded weights W'[c][kd][kh][kw] (c over post's channels) and a scalar bias.  Three entry points (r5) evaluate it

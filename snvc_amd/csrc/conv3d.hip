@@ -2494,6 +2494,42 @@ inline int64_t stats_tiles(const snvc_conv3d_desc &d) {
     return (int64_t)ceil_div(d.Dout, 4) * ceil_div(d.Hout, 4) * ceil_div(d.Wout, 32);
 }
 }  // namespace
+
+namespace {
+// The same fold for MANY slots (r6: the split kernels' statistics epilogue leaves one slot per wave, 46 k at cfg4's transposed layer; one
+// workgroup per channel walking them 512 bytes apart took 106 us): a first round of 64 -> 1 with consecutive threads on consecutive
+// doubles.  Row r' = sum of rows 64 r' .. 64 r' + 63 in ascending order (fixed order: deterministic), rows of `cols` doubles.
+__global__ void __launch_bounds__(256)
+conv_stats_fold_rows_kernel(const double *__restrict__ in, double *__restrict__ out, int64_t rows, int cols, int64_t in_ns, int64_t out_ns) {
+    const int64_t n = blockIdx.z;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    if (col >= cols) return;
+    const double *p = in + n * in_ns + r0 * cols + col;
+    const int64_t cnt = rows - r0 < 64 ? rows - r0 : 64;
+    double s = 0.0;
+#pragma unroll 8
+    for (int64_t r = 0; r < cnt; ++r) s += p[r * cols];
+    out[n * out_ns + (int64_t)blockIdx.y * cols + col] = s;
+}
+}  // namespace
+
+// `scratch` (N * ceil(tiles / 64) * groups * 64 doubles, conv_stats_fold_scratch_doubles) is used when tiles > 4096.
+int64_t conv_stats_fold_scratch_doubles(int64_t N, int groups, int64_t tiles) {
+    return tiles > 4096 ? N * ((tiles + 63) / 64) * groups * 64 : 0;
+}
+
+void launch_conv_stats_fold(const double *stats, double *scratch, double *partial, int64_t N, int C, int groups, int64_t tiles, hipStream_t st) {
+    const int cols = groups * 64;
+    if (tiles > 4096 && scratch) {
+        const int64_t out_rows = (tiles + 63) / 64;
+        conv_stats_fold_rows_kernel<<<dim3((unsigned)((cols + 255) / 256), (unsigned)out_rows, (unsigned)N), 256, 0, st>>>(
+            stats, scratch, tiles, cols, tiles * cols, out_rows * cols);
+        stats = scratch;
+        tiles = out_rows;
+    }
+    conv_stats_fold_kernel<<<dim3((unsigned)C, (unsigned)N), 256, 0, st>>>(stats, partial, C, groups, (int)tiles);
+}
 }
 
 extern "C" {

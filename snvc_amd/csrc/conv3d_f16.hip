@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "elementwise_internal.hpp"
 
 namespace snvc {
 namespace {
@@ -61,6 +62,8 @@ struct F16Args {
     int64_t t_bs;             // floats between samples of t_out
     const float *res_f32;     // EPI 2 (r6): a float32 NCDHW tensor of the result's shape added to the stored result (ADD_POST; the training
                               //   step's data gradients take a skip connection's gradient this way), batch stride yf_bs; or NULL
+    double *stats;            // EPI 2 (r6): per-(sample, slot, 32-channel group) fp64 (sum, sum of squares) of the stored float32 result, the layout
+                              //   conv_stats_fold_kernel folds: [((n * T + slot) * groups + cg)][32][2], slot = (z-class * gridDim.x + blockIdx.x) * 4 + wave
     const float *x_mul;       // conv2d_x3q_kernel: device scalar the input pair was multiplied by (a power of two from its own maximum), or NULL
     int CGin;            // input channel groups (Cin / 8, rounded up)
     int Cout;
@@ -543,6 +546,7 @@ conv3d_f16_kernel(const F16Args a_) {
         // running max of |v| compared once at the end, and the residual's conversions exist only in the with-residual instance.
         const float lo_bound = relu ? 0.0f : -kHalfMax;
         float vmax = 0.0f;
+        const bool want_stats = EPI == 2 && a.stats != nullptr;
         auto run = [&](auto has_res_tag) {
             constexpr bool HAS_RES = decltype(has_res_tag)::value;
 #pragma unroll
@@ -552,6 +556,13 @@ conv3d_f16_kernel(const F16Args a_) {
                 float hsum[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) hsum[nb] = 0.0f;
+                float st_s[2][8], st_q[2][8];          // EPI 2 with a.stats: this lane's sums over its voxels, per channel
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) st_s[j][e] = st_q[j][e] = 0.0f;
+                }
                 // one 8-channel group (a C8 piece) at a time: its affine / head weights are live only while its pieces are formed
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -595,6 +606,11 @@ conv3d_f16_kernel(const F16Args a_) {
                                 if (okv[nb]) {
                                     const int64_t at = (int64_t)(cj + e) * out_dhw + sp[nb];
                                     yf[at] = rf ? __builtin_fmaf(v, a.head_mul, rfv[e]) : v * a.head_mul;     // 2^-e_y: exact
+                                    if (want_stats) {
+                                        const float sv = v * a.head_mul;
+                                        st_s[j][e] += sv;
+                                        st_q[j][e] = __builtin_fmaf(sv, sv, st_q[j][e]);
+                                    }
                                 }
                             } else {
                                 if constexpr (SPLIT) {
@@ -616,6 +632,30 @@ conv3d_f16_kernel(const F16Args a_) {
                                 if constexpr (SPLIT) *reinterpret_cast<h8 *>(yn_lo + (gj + sp[nb]) * 8) = ol;
                             }
                         }
+                    }
+                }
+                if constexpr (EPI == 2) {
+                    if (want_stats) {
+                        // the 32 lanes of a half-wave hold the same 16 channels at 32 columns: fold them, lane 0 of the half writes its slot
+                        const int zc = blockIdx.z / a.N, groups = (a.Cout + 31) >> 5;
+                        const int64_t slots = (int64_t)(gridDim.z / a.N) * gridDim.x * 4;
+                        const int64_t slot = ((int64_t)zc * gridDim.x + blockIdx.x) * 4 + wave;
+                        double *dst = a.stats + ((((int64_t)n * slots + slot) * groups + (cb * MI + m)) * 32 + 16 * half) * 2;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                float s0 = st_s[j][e], s1 = st_q[j][e];
+#pragma unroll
+                                for (int o = 16; o >= 1; o >>= 1) {
+                                    s0 += __shfl_xor(s0, o, 64);
+                                    s1 += __shfl_xor(s1, o, 64);
+                                }
+                                if ((lane & 31) == 0) {
+                                    dst[(8 * j + e) * 2] = (double)s0;
+                                    dst[(8 * j + e) * 2 + 1] = (double)s1;
+                                }
+                            }
                     }
                 }
                 if constexpr (side) {     // the two half-waves hold channels 0..15 / 16..31 of the same 32 voxels
@@ -684,7 +724,7 @@ __device__ __forceinline__ void wait_lgkm_for(h8 (&b)[8]) {
                  : "memory");
 }
 
-template <int EPI>      // 0: split C8 output; 3: + the side head (Cout == 32)
+template <int EPI>      // 0: split C8 output; 3: + the side head (Cout == 32); 2 (r6): float32 NCDHW output (+ float32 residual, + statistics)
 __global__ void __launch_bounds__(256, 2)
 conv3d_x3q_kernel(const F16Args a) {
     using Cfg = X3QCfg;
@@ -834,6 +874,64 @@ conv3d_x3q_kernel(const F16Args a) {
         sc[e] = a.scale ? a.scale[c0 + e] : 1.0f;
         bi[e] = a.scale ? a.bias[c0 + e] : 0.0f;
         hw8[e] = (EPI == 3) ? a.head[c0 + e] : 0.0f;
+    }
+    if constexpr (EPI == 2) {
+        // the training step's layers (r6): lane (kb, col) stores its 8 channels of 16 consecutive voxels as float32 NCDHW (64-byte runs per
+        // channel), adds the float32 residual (a skip connection's gradient), and leaves the statistics of what it stored -- per wave and
+        // 32-channel group, the layout conv_stats_fold_kernel folds (slot = tile * 4 + wave)
+        float *yf = a.y_f32 + n * a.yf_bs + (int64_t)c0 * out_dhw;
+        const float *__restrict__ rf = a.res_f32 ? a.res_f32 + n * a.yf_bs + (int64_t)c0 * out_dhw : nullptr;
+        const bool want_stats = a.stats != nullptr;
+        float st_s[8], st_q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_s[e] = st_q[e] = 0.0f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int row = wave * NB + nb;
+            const int pd = od0 + row / TH, phh = oh0 + row % TH;
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const int pw = ow0 + 16 * ph + col;
+                const bool ok = pd < a.nd && phh < a.nh && pw < a.nw;
+                const int64_t sp = ok ? ((int64_t)pd * out_hw + phh * a.Wout + pw) : 0;
+                float rfv[8];
+                if (rf && ok) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rfv[e] = rf[(int64_t)e * out_dhw + sp];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float v = __builtin_fmaf(acc[nb][ph][e >> 2][e & 3], sc[e], bi[e]);
+                    if (relu) v = __builtin_fmaxf(v, 0.0f);
+                    const float sv = v * a.head_mul;
+                    if (ok) {
+                        yf[(int64_t)e * out_dhw + sp] = rf ? sv + rfv[e] : sv;
+                        if (want_stats) {
+                            st_s[e] += sv;
+                            st_q[e] = __builtin_fmaf(sv, sv, st_q[e]);
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            const int groups = a.Cout >> 5;
+            double *dst = a.stats + ((((int64_t)n * ntiles * 4 + (int64_t)t * 4 + wave) * groups + cb) * 32 + 8 * kb) * 2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s0 = st_s[e], s1 = st_q[e];
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) {
+                    s0 += __shfl_xor(s0, o, 64);
+                    s1 += __shfl_xor(s1, o, 64);
+                }
+                if (col == 0) {
+                    dst[e * 2] = (double)s0;
+                    dst[e * 2 + 1] = (double)s1;
+                }
+            }
+        }
+        return;
     }
     _Float16 *yn = a.y + n * a.y_bs + (int64_t)(cb * 4 + kb) * out_dhw * 8;
     _Float16 *yn_lo = a.y_lo + n * a.y_bs + (int64_t)(cb * 4 + kb) * out_dhw * 8;
@@ -2239,7 +2337,8 @@ int snvc_f16_conv3d_forward(const snvc_conv3d_desc *d, const void *x, const void
 static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
                          const float *scale, const float *bias, const void *res_hi, const void *res_lo, void *y_hi,
                          void *y_lo, float *y_f32, const float *head, float *y_head, float head_mul, float res_mul,
-                         int *overflow, const void *tail_w, float *t_out, float tail_mul, void *stream) {
+                         int *overflow, const void *tail_w, float *t_out, float tail_mul, void *stream, double *stats = nullptr,
+                         int64_t *stats_slots = nullptr) {
     using namespace snvc;
     F16Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null desc");
@@ -2295,6 +2394,7 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
     a.y = reinterpret_cast<_Float16 *>(y_hi); a.y_lo = reinterpret_cast<_Float16 *>(y_lo); a.y_f32 = y_f32;
     a.head = head; a.y_head = y_head; a.head_mul = head_mul; a.res_mul = res_mul; a.overflow = overflow;
     a.res_f32 = res_f32;
+    a.stats = stats;
     a.tail_w = reinterpret_cast<const _Float16 *>(tail_w); a.t_out = t_out; a.tail_mul = tail_mul;
     a.t_bs = (int64_t)27 * 8 * d->Din * d->Hin * d->Win;
     a.CGin = d->Cin / 8; a.Cout = d->Cout;
@@ -2330,6 +2430,16 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
         return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles or samples");
     dim3 grid((unsigned)(d->transposed ? 2 * ntiles : ntiles), (unsigned)p.cblocks, (unsigned)(d->N * (d->transposed ? 4 : classes)));
     hipStream_t st = as_stream(stream);
+    if (stats_slots) {          // the statistics epilogue (r6): only the forms that write float32 through the shared epilogue, 256 threads
+        const bool form_ok = to_f32 && !plane && !tail && (p.kind == FK3XQ || p.kind == FK3X || p.kind == FK3X2 || p.kind == FK3XS || p.kind == FK3X2S || p.kind == FK3XT ||
+                                                            p.kind == FK3S2X || p.kind == FK3S2XT || p.kind == FDCX || p.kind == FDCXT || p.kind == FDCXN);
+        if (!form_ok) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward_stats: this layer's kernel form has no statistics epilogue");
+        *stats_slots = p.kind == FK3XQ ? ntiles * 4 : (int64_t)(grid.z / d->N) * grid.x * 4;
+        if (!stats) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward_stats: null workspace");
+        // whole tiles outside a smaller parity class return early: their slots must read as zero
+        const hipError_t e = hipMemsetAsync(stats, 0, (size_t)d->N * *stats_slots * ((d->Cout + 31) / 32) * 64 * sizeof(double), st);
+        if (e != hipSuccess) return fail(SNVC_ERR_HIP, "snvc_f16x3_conv3d_forward_stats: hipMemsetAsync failed");
+    }
 #define SNVC_X3_LAUNCH(CFG) do { if (to_f32) launch_f16<CFG, 2>(a, grid, st); else launch_f16<CFG, 0>(a, grid, st); } while (0)
     switch (p.kind) {
         case FK3X:
@@ -2383,11 +2493,14 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
             break;
         }
         case FK3XQ: {
-            if (to_f32 || resflags) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the 16x16x32 form has no residual / fp32 output");
+            if (resflags || (to_f32 && head)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: the 16x16x32 form has no split residual, no side head beside a float32 result");
             if (ntiles * p.cblocks >= ((int64_t)1 << 30)) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward: too many tiles");
             grid = dim3((unsigned)(ntiles * p.cblocks), 1, (unsigned)d->N);      // (tile, channel block) jobs, channel block fastest
-            static std::atomic<unsigned> attr_40{0}, attr_43{0};
-            if (head) {
+            static std::atomic<unsigned> attr_40{0}, attr_43{0}, attr_42{0};
+            if (to_f32) {
+                if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<2>), X3QCfg::LDS_BYTES, attr_42))
+                    conv3d_x3q_kernel<2><<<grid, 256, X3QCfg::LDS_BYTES, st>>>(a);
+            } else if (head) {
                 if (allow_large_lds(reinterpret_cast<const void *>(&conv3d_x3q_kernel<3>), X3QCfg::LDS_BYTES, attr_43))
                     conv3d_x3q_kernel<3><<<grid, 256, X3QCfg::LDS_BYTES, st>>>(a);
             } else {
@@ -2408,6 +2521,52 @@ int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *d, const void *x_hi, const
                               int *overflow, void *stream) {
     return f16x3_forward(d, x_hi, x_lo, packed_weight, scale, bias, res_hi, res_lo, y_hi, y_lo, y_f32, head, y_head, head_mul, res_mul,
                          overflow, nullptr, nullptr, 0.0f, stream);
+}
+
+// slots per sample of the statistics epilogue = (z classes) * gridDim.x * 4 waves, as f16x3_forward lays its grid out
+static int64_t f16x3_stats_slots(const snvc_conv3d_desc &d, const snvc::F16Plan &p) {
+    using namespace snvc;
+    const bool subgrid = p.kind == FK5D2X || p.kind == FK5D2XQ;
+    int nd, nh, nw;
+    if (d.transposed) { nd = d.Din; nh = d.Hin; nw = d.Win; }
+    else if (subgrid) { nd = (d.Dout + 1) / 2; nh = (d.Hout + 1) / 2; nw = d.Wout; }
+    else { nd = d.Dout; nh = d.Hout; nw = d.Wout; }
+    const int64_t ntiles = (int64_t)ceil_div(nd, p.TD) * ceil_div(nh, p.TH) * ceil_div(nw, 32);
+    if (p.kind == FK3XQ) return ntiles * 4;              // (tile, channel block) jobs on gridDim.x: a slot per tile and wave
+    return (d.transposed ? 4 * 2 * ntiles : (subgrid ? 4 : 1) * ntiles) * 4;
+}
+
+int64_t snvc_f16x3_conv3d_stats_workspace_bytes(const snvc_conv3d_desc *d) {
+    using namespace snvc;
+    F16Plan p;
+    if (!d || d->N < 0 || make_f16_plan(*d, p, true)) return -1;
+    const int64_t groups = (d->Cout + 31) / 32;
+    const int64_t slots = f16x3_stats_slots(*d, p);
+    return (d->N * slots * groups * 64 + conv_stats_fold_scratch_doubles(d->N, (int)groups, slots) + d->N * (int64_t)d->Cout * 2) * (int64_t)sizeof(double);
+}
+
+int snvc_f16x3_conv3d_forward_stats(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
+                                    const float *scale, const float *bias, float *y_f32, float head_mul, const float *gamma,
+                                    const float *beta, float *bn_scale, float *bn_shift, float *mean, float *var, void *workspace,
+                                    float eps, void *stream) {
+    using namespace snvc;
+    if (!d || !y_f32 || !bn_scale || !bn_shift || !workspace)
+        return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward_stats: null pointer");
+    if (d->N <= 0 || d->flags || d->Cout % 32) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward_stats: whole 32-channel groups, no epilogue flags");
+    double *stats = static_cast<double *>(workspace);
+    int64_t slots = 0;
+    int rc = f16x3_forward(d, x_hi, x_lo, packed_weight, scale, bias, nullptr, nullptr, nullptr, nullptr, y_f32, nullptr, nullptr, head_mul, 1.0f,
+                           nullptr, nullptr, nullptr, 0.0f, stream, stats, &slots);
+    if (rc) return rc;
+    const int groups = d->Cout / 32;
+    double *scratch = stats + d->N * slots * groups * 64;
+    double *partial = scratch + conv_stats_fold_scratch_doubles(d->N, groups, slots);
+    launch_conv_stats_fold(stats, scratch, partial, d->N, d->Cout, groups, slots, as_stream(stream));
+    rc = check_launch("snvc_f16x3_conv3d_forward_stats(fold)");
+    if (rc) return rc;
+    launch_norm_finalize(partial, gamma, beta, bn_scale, bn_shift, mean, var, d->N, d->Cout, (int64_t)d->Dout * d->Hout * d->Wout, 1, eps,
+                         as_stream(stream));
+    return check_launch("snvc_f16x3_conv3d_forward_stats(finalize)");
 }
 
 int snvc_f16x3_split_scale(const float *x, int64_t n, void *scratch8, float *out_mul, void *stream) {

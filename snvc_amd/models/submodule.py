@@ -255,10 +255,10 @@ def _dgrad_layer(conv: nn.Module, plan: _Plan) -> ops.Conv3dLayer:
 # also writes its split TWIN when the consumer runs on the split kernels (+4 bytes per element on a pass that moves 8-12, against a
 # layout pass of 8), scaled by a power of two from an upper bound of the tensor's maximum that is known before the pass runs
 # (_twin_mul_forward / _epilogue_backward); the split kernels write float32 NCDHW (y_f32).  Measured per layer in
-# profiles/r6/kernel_experiments_r6.txt.  Which layers: the half- / quarter-resolution, stride-2 and transposed 3x3x3 layers
-# (Cin * Cout >= 2048); the full-resolution 32 -> 32 layers stay on the fp32 Winograd kernels, which already halve the products.
+# profiles/r6/kernel_experiments_r6.txt.  Which layers: every 3x3x3 layer with whole 32-channel blocks on both sides (conv2 and the
+# hourglass); the first layer has its own sheared route, the classifier (one output channel) stays on the fp32 kernels.
 X3_TRAIN = [True]          # tools / tests flip this
-X3_TRAIN_MIN_CC = [2048]   # Cin * Cout from which a layer takes the route
+X3_TRAIN_MIN_CC = [1024]   # Cin * Cout from which a layer takes the route (measured: 2048 -> 1024 = conv2 as well: 15.70 -> 15.25 ms)
 
 
 def _x3_train_route(conv: nn.Module, x: torch.Tensor) -> bool:
@@ -349,8 +349,9 @@ class _X3TrainLayer:
         pair, mul = _split_operand(x, ops.amax_of(x))
         return self.layer(pair, 0, None, None, flags=0, out_exp=0, to_f32=True, x_mul_dev=mul)
 
-    def forward_stats(self, *a, **k):
-        return None
+    def forward_stats(self, x, gamma, beta, eps):
+        pair, mul = _split_operand(x, ops.amax_of(x))
+        return self.layer.forward_stats(pair, mul, gamma, beta, eps)
 
 
 class _GradBox:
@@ -873,8 +874,16 @@ class _ShearedFirstConvBNFn(torch.autograd.Function):
         ops.sheared_expand(g, gcol, planes, scale, shift, y, q, m0, off, off_col, EPI_RELU)
         # an upper bound of max|y| for the next layer's split-operand weight gradient (r6): a voxel of the raw result is one element of
         # G (+ one of G' in the last column) + one of the planes, so |y| <= max|scale| (max|G| + max|G'| + max|planes|) + max|shift|
-        ops.tag_amax(y, ops.amax_from_bound(scale.abs().max() * (g.abs().max() + gcol.abs().max() + planes.abs().max())
-                                            + shift.abs().max()))
+        am = ops.amax_from_bound(scale.abs().max() * (g.abs().max() + gcol.abs().max() + planes.abs().max()) + shift.abs().max())
+        ops.tag_amax(y, am)
+        y.snvc_twin_src = plan
+        if getattr(plan, "want_twin", False) and X3_TRAIN[0] and ops.twin_ok(y):
+            # the next layer runs on the split kernels (r6): the expansion once more, written as the split pair (0.15 ms at cfg4 against a
+            # layout pass over the 736 MB result), scaled by the power of two of the same bound
+            mul = ops.split_scale_bound(1, 1, y.device, amax_x=am)
+            pair = ops.twin_empty(y)
+            ops.sheared_expand_split(g, gcol, planes, (scale * mul).contiguous(), (shift * mul).contiguous(), pair, q, m0, off, off_col, EPI_RELU)
+            ops.tag_twin(y, pair, mul)
         ctx.conv, ctx.norm, ctx.q, ctx.m0 = conv, norm, q, m0
         # gamma is saved as the autograd input it is: an in-place update between forward and backward (an interleaved
         # optimizer step, an EMA swap) then trips autograd's version check instead of pairing a new gamma with old scale / shift

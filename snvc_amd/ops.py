@@ -1742,7 +1742,9 @@ class Conv3dLayerX3:
                 sc = (sc / x_mul_dev).contiguous()
             if self.w_mul_dev is not None:
                 sc = (sc / self.w_mul_dev).contiguous()
-        self.algo = self._pick_form(n, out_sp, plain=residual is None and not f32, split_out=not f32 and head is None)
+        # r6: the training step's layers (device-scaled weights) take the 16x16x32 stride-1 form with a float32 result too
+        self.algo = self._pick_form(n, out_sp, plain=residual is None and (not f32 or (self.w_mul_dev is not None and head is None)),
+                                    split_out=not f32 and head is None)
         packed = self._pack(self.algo)
         if n == 0:
             return out_f32 if f32 else ((out, y_head) if head is not None else out)
@@ -1760,6 +1762,38 @@ class Conv3dLayerX3:
         if f32:
             return out_f32          # the kernel multiplied by 2^-out_exp on the way out
         return (out, y_head) if head is not None else out
+
+    def forward_stats(self, x, x_mul_dev, gamma, beta, eps: float):
+        """r6 (training): the plain convolution with a float32 result AND the batch statistics of that result from the same launch
+        (snvc_f16x3_conv3d_forward_stats): (raw, scale, shift, mean, var) as Conv3dLayer.forward_stats, or None when the layer's
+        kernel form carries no statistics epilogue.  Device-scaled weights only (``w_mul_dev``)."""
+        _split_check(x, "x")
+        if self.w_mul_dev is None or x.size(2) * 8 != self.cin or self.cout % 32:
+            return None
+        n = x.size(0)
+        in_sp = tuple(x.shape[3:6])
+        out_sp = self.out_spatial(in_sp)
+        if self._sc_w is None:
+            self._sc_w = (torch.ones(self.cout, device=x.device) / self.w_mul_dev).contiguous()
+            self._bi_0 = torch.zeros(self.cout, device=x.device)
+        sc = self._sc_w if x_mul_dev is None else (self._sc_w / x_mul_dev)
+        self.algo = self._pick_form(n, out_sp, plain=True, split_out=False)
+        packed = self._pack(self.algo)
+        raw = torch.empty((n, self.cout) + out_sp, dtype=torch.float32, device=x.device)
+        d = self._desc(n, in_sp, 0, _batch_stride(x), _batch_stride(raw), 0)
+        nbytes = _lib.lib().snvc_f16x3_conv3d_stats_workspace_bytes(ctypes.byref(d))
+        if nbytes < 0:
+            return None
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        out = torch.empty((4, self.cout), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().snvc_f16x3_conv3d_forward_stats(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(packed), _ptr(sc), _ptr(self._bi_0),
+                                                            _ptr(raw), 1.0, _ptr(gamma), _ptr(beta), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                                            _ptr(out[3]), _ptr(ws), float(eps), _stream(x))
+        if rc == 2:            # SNVC_ERR_UNSUPPORTED: the caller runs the convolution and the statistics pass separately
+            return None
+        check(rc, "snvc_f16x3_conv3d_forward_stats")
+        return raw, out[0:1], out[1:2], out[2:3], out[3:4]
 
     def forward_tail(self, x, x_exp: int, scale, bias, tail: "TailWeightsX3", residual=None, flags: int = 0, out_exp: int = 0,
                      overflow=None, res_exp: Optional[int] = None, out=None):

@@ -10,6 +10,9 @@ from snvc_amd.models import submodule as S
 
 dev = torch.device("cuda:0")
 what = sys.argv[1:] or ["unit", "hg", "step"]
+for w_ in what:
+    if w_.startswith("cc="):
+        S.X3_TRAIN_MIN_CC[0] = int(w_[3:])
 
 
 def rel(a, b):
@@ -87,11 +90,16 @@ if "hg" in what:
 if "step" in what:
     import bench
     from benchlib.train import TrainStep
-    combos = ((False, False), (True, False), (False, True), (True, True))
-    if "on" in what: combos = ((True, False),)
-    if "off" in what: combos = ((False, False),)
-    for on, touch in combos:
+    combos = ((False, False, None), (True, False, None), (False, True, None), (True, True, None))
+    if "on" in what: combos = ((True, False, None),)
+    if "off" in what: combos = ((False, False, None),)
+    for w_ in what:
+        if w_.startswith("ab="):            # ab=1024,2048,1024,2048: the route's channel threshold, alternating in one process
+            combos = tuple((True, False, int(v)) for v in w_[3:].split(","))
+    for on, touch, cc in combos:
         S.X3_TRAIN[0] = on
+        if cc is not None:
+            S.X3_TRAIN_MIN_CC[0] = cc
         ts = TrainStep(0, dev)
         for _ in range(4):
             ts()
@@ -99,7 +107,7 @@ if "step" in what:
         b = dict(S._ROUTES)
         import time
         t0 = time.perf_counter()
-        K = 15
+        K = 30
         acc = [0.0, 0.0, 0.0]
         for _ in range(K):
             if touch:
@@ -111,7 +119,7 @@ if "step" in what:
                 acc[i] += v
         ms = (time.perf_counter() - t0) / K * 1e3
         routes = {k: (v - b.get(k, 0)) // K for k, v in S._ROUTES.items() if v - b.get(k, 0) and k.startswith("x3_train")}
-        print(f"cfg4 step, split forward/dgrad {'ON ' if on else 'OFF'}{' (weights touched every step)' if touch else ''}: {ms:.2f} ms "
+        print(f"cfg4 step (min Cin*Cout {S.X3_TRAIN_MIN_CC[0]}), split forward/dgrad {'ON ' if on else 'OFF'}{' (weights touched every step)' if touch else ''}: {ms:.2f} ms "
               f"(fwd {acc[0] / K:.2f}, bwd {acc[1] / K:.2f}), loss {loss.item():.6e}, per step {routes}", flush=True)
         del ts
         torch.cuda.empty_cache()
