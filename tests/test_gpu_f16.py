@@ -542,8 +542,10 @@ def test_split_mode_16x16x32_forms_vs_float64(case):
             y2, hv = q16(xs, 3, scale, bias, flags=ops.EPI_RELU, out_exp=2, head=head, overflow=flag)
             assert torch.equal(y2, ys)
             check(hv.cpu().numpy(), (ref * head.double().cpu().view(1, -1, 1, 1, 1)).sum(1, keepdim=True).numpy(), TIGHT, f"{case}: side head")
-        with pytest.raises(ops.Unsupported):      # no residual / fp32 output in this form: the caller takes another one
-            q16(xs, 3, scale, bias, flags=ops.EPI_RELU, to_f32=True)
+        yf = q16(xs, 3, scale, bias, flags=ops.EPI_RELU, to_f32=True)      # r6: a float32 result in this form (the training step's layers)
+        check(yf.cpu().numpy(), ref.numpy(), TIGHT, f"{case}: 16x16x32 form, float32 result")
+        with pytest.raises(ops.Unsupported):      # no split residual in this form: the caller takes another one
+            q16(xs, 3, scale, bias, residual=ys, flags=ops.EPI_RELU | ops.EPI_ADD_POST, out_exp=2)
     else:
         res = torch.randn_like(got)
         rs = ops.to_split(res, 5)

@@ -69,7 +69,7 @@ def seeded(mod, seed):
 def test_library_loads_and_reports_errors():
     from snvc_amd import _lib
     L = _lib.lib()
-    assert L.snvc_abi_version() == 5
+    assert L.snvc_abi_version() == 6
     rc = L.snvc_cost_volume_forward(None, None, None, None, 1, 1, 3, 4, 1, 2, 0, None)
     assert rc == 1 and b"multiples of downsample" in L.snvc_last_error_string()
 

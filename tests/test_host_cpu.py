@@ -27,12 +27,12 @@ def test_every_declared_symbol_is_exported(L):
     from snvc_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "snvc_hip.h")).read()
     declared = set(re.findall(r"SNVC_API\s+[\w\s\*]+?\b(snvc_\w+)\s*\(", hdr))
-    assert len(declared) == 90, sorted(declared)
+    assert len(declared) == 96, sorted(declared)
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert L.snvc_abi_version() == 5
+    assert L.snvc_abi_version() == 6
 
 
 def test_struct_layout_matches_header():
