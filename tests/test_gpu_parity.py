@@ -1618,7 +1618,7 @@ def test_training_step_sheared_first_conv_vs_torch_autograd(q, m0, fused_bn):
     before_stats, before_x3 = S._ROUTES["conv_stats_epilogue"], S._ROUTES["x3_train_dgrad"]
     (gl_o, gr_o), gp_o = _grads(ours, [lo, ro], lambda: ours.forward_pair(lo, ro, sh, 1, fused_bn=fused_bn).pow(2).mean())
     assert S._ROUTES["conv_stats_epilogue"] >= before_stats + 1      # conv2 (fp32 Winograd, statistics in its epilogue)
-    assert S._ROUTES["x3_train_dgrad"] == before_x3 + 6              # r6: the hourglass's six layers on the split kernels, both directions
+    assert S._ROUTES["x3_train_dgrad"] == before_x3 + 7              # r6: conv2 and the hourglass's six layers on the split kernels, both directions
     assert S._ROUTES["sheared_first_conv_train"] == before + 1
     assert S._ROUTES["sheared_first_conv_train_fused_bn"] == before_bn + (1 if fused_bn else 0)
     for (k, a), (_, b) in zip(ours.state_dict().items(), ref.state_dict().items()):     # BatchNorm bookkeeping after ONE step
