@@ -69,8 +69,9 @@ def run_train(rank, world, device, dist, steps, warmup, barrier):
     res = {
         "workload": "cfg4: 1 pair/GPU at cfg2 size, train-mode BatchNorm, loss = mean(cost^2), fwd + bwd on the HIP "
                     "kernels + flat-bucket gradient all-reduce",
-        "arithmetic": "f32 (forward / data gradients: fp32 MFMA, Winograd F(4,3); weight gradients of the 3x3x3 layers: split f16x3 operands, "
-                      "fp32 accumulate, r6)",
+        "arithmetic": "f32 contract; conv2 and the hourglass (7 of the 9 layers): forward, data and weight gradients on split f16x3 operands "
+                      "(value = hi + lo halves, three f16 MFMAs per product, fp32 accumulate; twins / scales from device-side maxima, r6); first "
+                      "layer and classifier: fp32 MFMA; BatchNorm statistics and backward coefficients in fp64",
         "ms_per_step": 1e3 * elapsed / steps, "pairs_per_s": world * steps / elapsed,
         "fwd_ms": f, "bwd_ms": b, "allreduce_us": 1e3 * r, "allreduce_bytes": ts.moved, "params": ts.nparam,
         "step_tflops_algorithmic": 3 * STEP_FLOP / (elapsed / steps) / 1e12, "steps": steps,
@@ -99,6 +100,23 @@ def run_train(rank, world, device, dist, steps, warmup, barrier):
                 torch.cuda.empty_cache()
             finally:
                 S.COMMUTED_BACKWARD[0] = True
+        # r6: the same step with the 3x3x3 layers' forward / data gradients on the fp32 Winograd kernels (r5's route; weight gradients as above)
+        S.X3_TRAIN[0] = False
+        try:
+            tg = TrainStep(rank, device)
+            for _ in range(3):
+                tg()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            k = max(5, steps // 2)
+            for _ in range(k):
+                tg()
+                torch.cuda.synchronize()
+            res["ms_per_step_fp32_forward_dgrad"] = 1e3 * (time.perf_counter() - t1) / k
+            del tg
+            torch.cuda.empty_cache()
+        finally:
+            S.X3_TRAIN[0] = True
         gen["note"] = ("forward_pair(..., sheared=False): the first layer warps after the convolution in both directions "
                        "(snvc_warped_expand / snvc_warped_expand_backward); second figure: its backward through the built right half")
         res["general_shift"] = gen

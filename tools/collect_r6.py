@@ -45,9 +45,13 @@ for shape, (kern, alg_bytes, flop, what) in ALG.items():
     for name, r in stats.items():
         if kern in name and ("<true>" in name or "<" not in name):
             res[shape]["avg_ms_in_the_training_step"] = float(r["AverageNs"]) / 1e6
-prev = json.load(open(os.path.join(ROOT, "profiles", "r5", "traffic.json")))
+# layers.*: tools/pmc_r6_traffic.sh + `python tools/make_traffic_json.py r6` (moved to traffic_layers.json) -- re-collected in r6 because
+# conv3d_x3q_kernel gained its float32-output instance (bench.py ties `roofline.traffic` to the kernel's source hash)
+layers = os.path.join(DST, "traffic_layers.json")
+prev = json.load(open(layers if os.path.exists(layers) else os.path.join(ROOT, "profiles", "r5", "traffic.json")))
 prev["wgrad_x3"] = res
-prev["note_r6"] = ("layers.*: round 5's counters, still valid (bench.py checks the kernel source hash); wgrad_x3: round 6, tools/prof_r6.sh + "
-                   "tools/collect_r6.py, the weight-gradient launches with the maxima supplied as in the training step")
+prev["note_r6"] = ("layers.*: tools/pmc_r6_traffic.sh + tools/make_traffic_json.py r6 (round 6, after conv3d_x3q_kernel's float32-output instance was "
+                   "added; bench.py checks the kernel source hash); wgrad_x3: tools/prof_r6.sh + tools/collect_r6.py, the weight-gradient "
+                   "launches with the maxima supplied as in the training step")
 json.dump(prev, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
