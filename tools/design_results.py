@@ -36,7 +36,7 @@ rows = [
     ("`general_shift` (any shift array)", f"{f(g(d, 'general_shift', 'value'))} pairs/s, {f(g(d, 'general_shift', 'ms_per_step'), 3)} ms"),
     ("`reference_api` (the reference's two calls verbatim)", f"{f(g(d, 'reference_api', 'value'))} pairs/s"),
     ("`fp32_mfma` / `built_right_half` / `materialized`", f"{f(g(d, 'fp32_mfma', 'value'))} / {f(g(d, 'built_right_half', 'value'))} / {f(g(d, 'materialized', 'value'))} pairs/s"),
-    ("`train` (cfg4; r6: weight gradients of the 3x3x3 layers on split f16x3 operands)", f"{f(g(d, 'train', 'ms_per_step'), 2)} ms/step (fwd {f(g(d, 'train', 'fwd_ms'), 2)}, bwd {f(g(d, 'train', 'bwd_ms'), 2)})"),
+    ("`train` (cfg4; r6: forward, data and weight gradients of conv2 + hourglass on split f16x3 operands; the default run, other legs before it)", f"{f(g(d, 'train', 'ms_per_step'), 2)} ms/step (fwd {f(g(d, 'train', 'fwd_ms'), 2)}, bwd {f(g(d, 'train', 'bwd_ms'), 2)})"),
     ("`configs.cfg4_train_step` weight gradient 32->32 full grid", f"split-operand form {f(g(c, 'cfg4_train_step', 'wgrad_ms'), 3)} ms (finding its own maxima: {f(g(c, 'cfg4_train_step', 'wgrad_ms_finding_its_own_maxima'), 3)}), fp32 Winograd form {f(g(c, 'cfg4_train_step', 'wgrad_fp32_form_ms'), 3)} ms"),
     ("`value_fp32_mfma` / `dtype`", f"{f(d.get('value_fp32_mfma'))} pairs/s on the fp32-MFMA kernels; dtype = {d.get('dtype')}"),
 ]
