@@ -1581,6 +1581,19 @@ def from_split(x: torch.Tensor, exp: int = 0, channels: Optional[int] = None) ->
 X3_SMALL_BELOW = {"stride2": 0, "transposed": 4096}
 
 
+_ONES_ZEROS = {}
+
+
+def _ones_zeros(c: int, device):
+    """Read-only per-channel constants (ones, zeros) shared by every layer of that width on the device: the training step rebuilds its
+    split layers whenever the weights move, and two fill launches per layer and step add up."""
+    key = (c, device)
+    hit = _ONES_ZEROS.get(key)
+    if hit is None:
+        hit = _ONES_ZEROS[key] = (torch.ones(c, device=device), torch.zeros(c, device=device))
+    return hit
+
+
 class Conv3dLayerX3:
     """nn.Conv3d(k3, p1, stride 1 | 2) / nn.ConvTranspose3d(k3, s2, p1, op1) prepared for the split-mode kernels
     (snvc_f16x3_conv3d_*): the fp32 contraction at fp32 accuracy on the half pipe.  The weights are packed as (hi, lo) of
@@ -1614,7 +1627,9 @@ class Conv3dLayerX3:
             wmax = float(self.weight.abs().max().item()) if weight.numel() else 1.0
             self.w_exp = 14 - math.frexp(wmax)[1] if wmax > 0 and math.isfinite(wmax) else 0      # wmax * 2^w_exp in [2^13, 2^14)
         self._packed = {}
-        self.packed = self._pack(self.algo)
+        # device-scaled weights (the training step: rebuilt every time the weights move) are packed on first use, in the form that use
+        # picks -- not in a default form nobody may ask for
+        self.packed = self._pack(self.algo) if w_mul_dev is None else None
         self._affine = {}
 
     def _pack(self, algo: int):
@@ -1733,8 +1748,7 @@ class Conv3dLayerX3:
         if self.w_mul_dev is not None and scale is None and bias is None and x_exp == 0 and out_exp == 0:
             # the training step's plain convolution: 1 / w_mul per channel is formed once per weight version, one small launch per call
             if self._sc_w is None:
-                self._sc_w = (torch.ones(self.cout, device=x.device) / self.w_mul_dev).contiguous()
-                self._bi_0 = torch.zeros(self.cout, device=x.device)
+                self._sc_w, self._bi_0 = _ones_zeros(self.cout, x.device)[0] / self.w_mul_dev, _ones_zeros(self.cout, x.device)[1]
             sc, bi = (self._sc_w if x_mul_dev is None else (self._sc_w / x_mul_dev)), self._bi_0
         else:
             sc, bi = self.folded(scale, bias, x_exp, out_exp)
@@ -1774,8 +1788,7 @@ class Conv3dLayerX3:
         in_sp = tuple(x.shape[3:6])
         out_sp = self.out_spatial(in_sp)
         if self._sc_w is None:
-            self._sc_w = (torch.ones(self.cout, device=x.device) / self.w_mul_dev).contiguous()
-            self._bi_0 = torch.zeros(self.cout, device=x.device)
+            self._sc_w, self._bi_0 = _ones_zeros(self.cout, x.device)[0] / self.w_mul_dev, _ones_zeros(self.cout, x.device)[1]
         sc = self._sc_w if x_mul_dev is None else (self._sc_w / x_mul_dev)
         self.algo = self._pick_form(n, out_sp, plain=True, split_out=False)
         packed = self._pack(self.algo)

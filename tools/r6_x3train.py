@@ -93,6 +93,7 @@ if "step" in what:
     combos = ((False, False, None), (True, False, None), (False, True, None), (True, True, None))
     if "on" in what: combos = ((True, False, None),)
     if "off" in what: combos = ((False, False, None),)
+    if "touch" in what: combos = ((True, True, None),)
     for w_ in what:
         if w_.startswith("ab="):            # ab=1024,2048,1024,2048: the route's channel threshold, alternating in one process
             combos = tuple((True, False, int(v)) for v in w_[3:].split(","))
