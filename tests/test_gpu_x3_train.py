@@ -238,3 +238,21 @@ def test_global_stack_step_takes_no_layout_pass_from_the_second_step_on():
         assert outs[step][2] == {"x3_train_layout_pass": 0, "x3_train_twin": 14, "x3_train_dgrad": 7}, outs[step][2]
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
     check(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy(), 1e-5, "step with twins vs step with layout passes")
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 4, 12, 20), (2, 32, 8, 8, 36)])
+def test_hourglass_route_with_tensors_that_cannot_carry_a_twin(shape):
+    """voxel counts that are not a multiple of 4 at the quarter-resolution level (15 voxels; 36 at the second shape is one, its rows are
+    not): the producing passes skip the twin where ops.twin_ok says so, the consumer converts by itself -- same results as the fp32 kernels"""
+    from snvc_amd.models import submodule as S
+    hg = seeded(S.hourglass(32), 97).to(dev()).train()
+    x0 = torch.relu(_t(np.random.default_rng(98).standard_normal(shape)))
+    o0, gx0, gp0 = _hourglass_grads(hg, x0, False)
+    _hourglass_grads(hg, x0, True)
+    b = dict(S._ROUTES)
+    o1, gx1, gp1 = _hourglass_grads(hg, x0, True)
+    assert S._ROUTES["x3_train_dgrad"] - b.get("x3_train_dgrad", 0) == 6
+    check(o1.cpu().numpy(), o0.cpu().numpy(), 2e-5, "out")
+    check(gx1.cpu().numpy(), gx0.cpu().numpy(), 3e-5, "dx")
+    for k in gp0:
+        check(gp1[k].cpu().numpy(), gp0[k].cpu().numpy(), 1e-4, f"d{k}")

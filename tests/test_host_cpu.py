@@ -397,3 +397,29 @@ def test_amax_tags_follow_the_tensor_version():
     assert ops.amax_of(t) is None
     b = ops.amax_from_bound(torch.tensor(-3.5))
     assert b.shape == (ops.AMAX_SLOTS,) and b[0].item() == torch.tensor(3.5).view(torch.int32).item() and int(b[1:].abs().sum()) == 0
+
+
+def test_twin_tags_and_the_training_route_on_cpu_tensors():
+    """ops.tag_twin / twin_of (r6): a split twin is handed on only while its float32 tensor is unchanged; twin_ok / the route say no to
+    anything that is not a float32 CUDA tensor with whole channel groups (a CPU tensor keeps the reference's own torch path)."""
+    import torch.nn as nn
+    from snvc_amd import ops
+    from snvc_amd.models import submodule as S
+    t = torch.zeros(1, 8, 2, 2, 4)
+    pair, mul = torch.zeros(1, 2, 1, 2, 2, 4, 8, dtype=torch.float16), torch.ones(1)
+    assert ops.twin_of(t) is None
+    ops.tag_twin(t, pair, mul)
+    got = ops.twin_of(t)
+    assert got is not None and got[0] is pair and got[1] is mul
+    t.mul_(2.0)
+    assert ops.twin_of(t) is None
+    assert not ops.twin_ok(t)                                            # CPU
+    assert tuple(ops.twin_empty(t).shape) == (1, 2, 1, 2, 2, 4, 8)
+    assert not S._x3_train_route(nn.Conv3d(32, 32, 3, 1, 1, bias=False), torch.zeros(1, 32, 4, 4, 8))
+    assert S.X3_TRAIN == [True] and S.X3_TRAIN_MIN_CC == [1024]
+    # a skip connection's view keeps the maximum its source was tagged with (the consumer's twin bound needs it)
+    x = torch.zeros(2, 3, requires_grad=True) * 1.0
+    w = torch.zeros(ops.AMAX_SLOTS, dtype=torch.int32)
+    ops.tag_amax(x, w)
+    v = S._SkipTap.apply(x, S._GradBox())
+    assert ops.amax_of(v) is w
