@@ -256,3 +256,35 @@ def test_hourglass_route_with_tensors_that_cannot_carry_a_twin(shape):
     check(gx1.cpu().numpy(), gx0.cpu().numpy(), 3e-5, "dx")
     for k in gp0:
         check(gp1[k].cpu().numpy(), gp0[k].cpu().numpy(), 1e-4, f"d{k}")
+
+
+@pytest.mark.parametrize("norm", ["frozen_bn", "groupnorm", "none"])
+def test_single_layer_route_with_other_norms(norm):
+    """the route under a frozen (eval-mode) BatchNorm3d (draw = A * g: no raw term in the twin's bound), under GroupNorm (per-sample scale /
+    shift rows in the bound) and without a norm (draw is gy itself: no pass writes a twin, the data gradient converts): dx, dW and the
+    norm's gradients against the fp32 kernels"""
+    import torch.nn as nn
+    from snvc_amd.models import submodule as S
+    layer = seeded(S.ConvBNReLU3d(S.convbn_3d(64, 64, 3, 1, 1, gn=(norm == "groupnorm")), nn.ReLU(inplace=True)), 99).to(dev()).train()
+    if norm == "frozen_bn":
+        layer[0][1].eval()
+    if norm == "none":
+        layer = seeded(S.HipConv3d(64, 64, 3, 1, 1, bias=False), 99).to(dev()).train()
+    x0 = torch.relu(_t(np.random.default_rng(100).standard_normal((2, 64, 4, 8, 36))))
+    prev = seeded(S.ConvBNReLU3d(S.convbn_3d(64, 64, 3, 1, 1), nn.ReLU(inplace=True)), 101).to(dev()).train()      # a producer on the path
+    outs = {}
+    for on in (False, True, True):
+        S.X3_TRAIN[0] = on
+        try:
+            for p in list(layer.parameters()) + list(prev.parameters()):
+                p.grad = None
+            x = x0.clone().requires_grad_()
+            y = layer.fused(prev.fused(x)) if hasattr(layer, "fused") else layer(prev.fused(x))
+            y.pow(2).mean().backward()
+            outs[on] = (y.detach(), x.grad.clone(), [p.grad.clone() for p in layer.parameters()])
+        finally:
+            S.X3_TRAIN[0] = True
+    check(outs[True][0].cpu().numpy(), outs[False][0].cpu().numpy(), 2e-5, f"{norm}: out")
+    check(outs[True][1].cpu().numpy(), outs[False][1].cpu().numpy(), 3e-5, f"{norm}: dx")
+    for a, b in zip(outs[True][2], outs[False][2]):
+        check(a.cpu().numpy(), b.cpu().numpy(), 1e-4, f"{norm}: parameter gradient")
