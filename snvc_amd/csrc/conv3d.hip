@@ -1955,6 +1955,41 @@ pointwise_small_kernel(const float *__restrict__ x, const float *__restrict__ w,
     }
 }
 
+// 1x1x1 FROM <= 2 channels (r6): the data gradient of the classifier (1 -> C: gx[c] = w[c] * gy, an outer product) ran on the MFMA tile
+// kernel with 31/32 of its K empty (0.275 ms for the 736 MB it writes at cfg4); streamed instead: a lane owns 4 consecutive voxels,
+// reads its CIN values once and writes every output channel's 16 bytes.
+template <int CIN>
+__global__ void __launch_bounds__(256)
+pointwise_expand_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ scale,
+                        const float *__restrict__ bias, const float *__restrict__ res, float *__restrict__ y,
+                        int Cout, int64_t S, int64_t x_bs, int64_t y_bs, int64_t r_bs, int flags) {
+    const int64_t n = blockIdx.y;
+    const float *xn = x + n * x_bs;
+    float *yn = y + n * y_bs;
+    const float *rn = res ? res + n * r_bs : nullptr;
+    const int64_t S4 = S >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v[CIN];
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) v[ci] = reinterpret_cast<const f32x4 *>(xn + ci * S)[i];
+#pragma unroll 8
+        for (int co = 0; co < Cout; ++co) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) acc += v[ci] * w[co * CIN + ci];      // uniform -> scalar loads
+            const float sc = scale ? scale[co] : 1.0f, bi = scale ? bias[co] : 0.0f;
+            f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rn) r = reinterpret_cast<const f32x4 *>(rn + co * S)[i];
+            f32x4 o;
+            o.x = epilogue_f(acc.x * sc + bi, r.x, flags);
+            o.y = epilogue_f(acc.y * sc + bi, r.y, flags);
+            o.z = epilogue_f(acc.z * sc + bi, r.z, flags);
+            o.w = epilogue_f(acc.w * sc + bi, r.w, flags);
+            reinterpret_cast<f32x4 *>(yn + co * S)[i] = o;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ 3x3x3 to ONE channel
 // The occupancy head of the local model ends in Conv3d(32, 1, 3) + Sigmoid over the whole voxel grid
 // (vernier.py:262-270): 27 x Cin multiply-adds per voxel, far too little for a 32-channel MFMA tile (the MFMA
@@ -2544,7 +2579,7 @@ int64_t snvc_conv3d_packed_weight_count(const snvc_conv3d_desc *d) {
     if (planar) return count + wino_packed_count(*d);
     count += wino_packed_count(*d);   // k3/s1 layers also carry the Winograd-transformed weights
     // 1x1x1 layers with <= 2 output channels also keep their raw [Cout][Cin] weights (streaming kernel)
-    if (!d->transposed && d->ksize == 1 && d->Cout <= 2) count += (int64_t)d->Cout * d->Cin;
+    if (!d->transposed && d->ksize == 1 && (d->Cout <= 2 || d->Cin <= 2)) count += (int64_t)d->Cout * d->Cin;      // r6: or FROM <= 2 channels
     // 3x3x3 / stride-1 layers with ONE output channel too ([Cin][27], VALU kernel)
     if (!d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1) count += (int64_t)d->Cin * 27;
     // transposed layers to ONE channel as well ([Cin][1][27], VALU kernel of conv3d_small.hip)
@@ -2563,7 +2598,7 @@ int snvc_conv3d_pack_weights(const snvc_conv3d_desc *d, const float *weight, flo
     const bool planar = d->ksize_d == 1;
     const bool k3c1 = !planar && ((!d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1) ||
                                   (d->transposed && d->Cout == 1));
-    if (!planar && ((!d->transposed && d->ksize == 1 && d->Cout <= 2) || k3c1)) {   // raw copy behind the MFMA packing
+    if (!planar && ((!d->transposed && d->ksize == 1 && (d->Cout <= 2 || d->Cin <= 2)) || k3c1)) {   // raw copy behind the MFMA packing
         const int64_t nraw = k3c1 ? (int64_t)d->Cin * 27 : (int64_t)d->Cout * d->Cin;
         total -= nraw;
         if (hipMemcpyAsync(packed + total, weight, sizeof(float) * nraw, hipMemcpyDeviceToDevice,
@@ -2746,6 +2781,21 @@ int conv3d_forward_impl(const snvc_conv3d_desc *d, const float *x, const float *
         else
             pointwise_small_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cin, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
         return check_launch("snvc_conv3d_forward(pointwise)");
+    }
+    // 1x1x1 from <= 2 channels (the classifier's data gradient): streamed as well
+    if (!planar && !d->transposed && d->ksize == 1 && d->stride == 1 && d->Cin <= 2 && d->Cout > 2 && (S % 4) == 0 && !depth_planes &&
+        !head_w && !stats && (d->algo & SNVC_ALGO_ARITH_MASK) == 0 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(a.res)) & 15) == 0 &&
+        a.x_bs % 4 == 0 && a.y_bs % 4 == 0 && a.r_bs % 4 == 0) {
+        const float *wraw = packed_weight + snvc_conv3d_packed_weight_count(d) - (int64_t)d->Cout * d->Cin;
+        int64_t blocks = ceil_div<int64_t>(S / 4, 256);
+        if (blocks > 4096) blocks = 4096;
+        dim3 g((unsigned)blocks, (unsigned)d->N);
+        if (d->Cin == 1)
+            pointwise_expand_kernel<1><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cout, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
+        else
+            pointwise_expand_kernel<2><<<g, 256, 0, as_stream(stream)>>>(x, wraw, scale, bias, a.res, y, d->Cout, S, a.x_bs, a.y_bs, a.r_bs, d->flags);
+        return check_launch("snvc_conv3d_forward(pointwise expand)");
     }
     // 3x3x3 / stride 1 to ONE channel: VALU kernel (raw weights ride at the end of the packed buffer)
     if (!planar && !d->transposed && d->ksize == 3 && d->stride == 1 && d->dilation == 1 && d->Cout == 1 && !depth_planes) {

@@ -288,3 +288,28 @@ def test_single_layer_route_with_other_norms(norm):
     check(outs[True][1].cpu().numpy(), outs[False][1].cpu().numpy(), 3e-5, f"{norm}: dx")
     for a, b in zip(outs[True][2], outs[False][2]):
         check(a.cpu().numpy(), b.cpu().numpy(), 1e-4, f"{norm}: parameter gradient")
+
+
+@pytest.mark.parametrize("cin", [1, 2])
+@pytest.mark.parametrize("flags", ["none", "relu+post"])
+def test_pointwise_layer_from_one_or_two_channels(cin, flags):
+    """nn.Conv3d(k1) from <= 2 channels (r6: the classifier's data gradient, snvc/models/submodule.py classifier; gx[c] = w[c] * gy) on the
+    streaming kernel: against float64 torch, and equal to the MFMA tile form (ALGO_DIRECT keeps it) -- a one-term sum has one rounding"""
+    from snvc_amd import _lib, ops
+    r = np.random.default_rng(110 + cin)
+    x = _t(r.standard_normal((2, cin, 4, 6, 40)))
+    w = _t(r.standard_normal((32, cin, 1, 1, 1)))
+    res = _t(r.standard_normal((2, 32, 4, 6, 40))) if flags != "none" else None
+    fl = (ops.EPI_RELU | ops.EPI_ADD_POST) if res is not None else 0
+    lay = ops.Conv3dLayer(w, 1, 1, 0, 1, False)
+    y = lay(x, None, None, res, fl, None)
+    ref = F.conv3d(x.double().cpu(), w.double().cpu())
+    if res is not None:
+        ref = torch.relu(ref) + res.double().cpu()
+    check(y.cpu().numpy(), ref.float().numpy(), 1e-6, "pointwise expand")
+    with ops.conv_variant(_lib.ALGO_DIRECT):
+        y2 = ops.Conv3dLayer(w, 1, 1, 0, 1, False)(x, None, None, res, fl, None)
+    if cin == 1:
+        assert torch.equal(y, y2)
+    else:
+        check(y.cpu().numpy(), y2.cpu().numpy(), 1e-6, "streaming vs MFMA tile form")
