@@ -506,6 +506,12 @@ SNVC_API int snvc_act_backward_reduce_amax(const float *raw, const float *gy, co
 SNVC_API int snvc_split_scale_bound(const float *a, const uint32_t *amax_p, const float *b, const float *l1, const uint32_t *amax_x,
                                     const float *c, const uint32_t *amax_r, int64_t rows, int64_t C, float *mul_out, void *stream);
 
+/* replaces: nn.BatchNorm3d's train-mode bookkeeping (torch/nn/modules/batchnorm.py, reached from snvc/models/submodule.py:32-50's
+ * BatchNorm3d layers): num_batches_tracked += 1 (may be NULL), running_mean / running_var <- lerp(running, batch, momentum) with the batch
+ * variance multiplied by `unbias` = n / (n - 1) first -- one launch instead of four small ones per layer and step (r6).  float32 [C]. */
+SNVC_API int snvc_bn_track(float *running_mean, float *running_var, int64_t *num_batches_tracked, const float *mean, const float *var,
+                           int64_t C, float momentum, float unbias, void *stream);
+
 /* Train-mode BatchNorm backward coefficients from snvc_act_backward_reduce's sums [N, C, 2] (fp64), in fp64, one launch
  * (replaces the ~15 per-channel tensor operations of torch autograd's native_batch_norm_backward on this path):
  *   sg = sum_n sums[n,c,0], sgr = sum_n sums[n,c,1], rstd = 1/sqrt(var[c] + eps), sgx = rstd * (sgr - mean[c] * sg)

@@ -92,6 +92,7 @@ SIGNATURES = {
     "snvc_affine_act_twin": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p, c_p]),
     "snvc_act_backward_apply_twin": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64,
                                              c_i64, c_int, c_int, c_p, c_p]),
+    "snvc_bn_track": (c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_f32, c_f32, c_p]),
     "snvc_split_scale_bound": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p]),
     "snvc_bn_backward_coefs": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, ctypes.c_double, ctypes.c_double, c_p]),
     "snvc_act_backward_apply": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_p]),

@@ -674,6 +674,22 @@ __global__ void bn_bwd_coefs_kernel(const double *__restrict__ sums, const float
     if (dbeta) dbeta[c] = (float)sg;
 }
 
+// nn.BatchNorm's train-mode bookkeeping in ONE launch (r6: it was four small torch launches per layer and step -- the counter, two
+// lerp_ and the unbiasing product -- 36 launches of ~4.7 us in the cfg4 step): running <- lerp(running, batch, momentum) with the
+// batch variance unbiased first, num_batches_tracked += 1.  lerp as torch evaluates it (start + w * diff for |w| < 0.5, else end - diff * (1 - w)).
+__global__ void bn_track_kernel(float *__restrict__ running_mean, float *__restrict__ running_var, int64_t *__restrict__ nbt,
+                                const float *__restrict__ mean, const float *__restrict__ var, int C, float momentum, float unbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    auto lerp = [&](float a, float b) {
+        const float diff = b - a;
+        return fabsf(momentum) < 0.5f ? __builtin_fmaf(momentum, diff, a) : __builtin_fmaf(-diff, 1.0f - momentum, b);      // contracted, as torch's build
+    };
+    running_mean[c] = lerp(running_mean[c], mean[c]);
+    running_var[c] = lerp(running_var[c], var[c] * unbias);
+}
+
 constexpr int kNormSplits = 32;
 
 inline unsigned stream_blocks(int64_t items, int64_t outer) {
@@ -1004,6 +1020,15 @@ int snvc_act_backward_apply_twin(const float *raw, const float *gy, const float 
                                                                    twin_mul, C, S, raw_batch_stride, gy_batch_stride, res_batch_stride,
                                                                    twin_batch_stride, per_sample, flags, amax, twin_chunked());
     return check_launch("snvc_act_backward_apply_twin");
+}
+
+int snvc_bn_track(float *running_mean, float *running_var, int64_t *num_batches_tracked, const float *mean, const float *var, int64_t C,
+                  float momentum, float unbias, void *stream) {
+    using namespace snvc;
+    if (C <= 0 || !running_mean || !running_var || !mean || !var) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_bn_track: null pointer or empty");
+    bn_track_kernel<<<dim3((unsigned)ceil_div<int64_t>(C, 64)), 64, 0, as_stream(stream)>>>(running_mean, running_var, num_batches_tracked, mean, var,
+                                                                                      (int)C, momentum, unbias);
+    return check_launch("snvc_bn_track");
 }
 
 int snvc_split_scale_bound(const float *a, const uint32_t *amax_p, const float *b, const float *l1, const uint32_t *amax_x, const float *c,

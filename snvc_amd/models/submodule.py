@@ -737,6 +737,8 @@ def _sheared_train_layers(fac, weight, c, q):
 def _bn_track(norm, mean, var, cnt):
     """nn.BatchNorm3d's bookkeeping in train mode: momentum update of the running statistics with the unbiased variance."""
     if norm.training and norm.track_running_stats and norm.running_mean is not None:
+        if ops.bn_track(norm, mean[0] if mean.dim() == 2 else mean, var[0] if var.dim() == 2 else var, cnt):     # r6: one launch instead of four
+            return
         with torch.no_grad():
             norm.num_batches_tracked += 1
             m = norm.momentum if norm.momentum is not None else 1.0 / float(norm.num_batches_tracked)

@@ -816,6 +816,24 @@ def bn_backward_coefs(sums, mean, var, gamma, count: float, eps: float):
     return out[0], out[1], out[2], out[3], out[4]
 
 
+def bn_track(norm, mean, var, cnt: float) -> bool:
+    """nn.BatchNorm's train-mode bookkeeping in one launch (snvc_bn_track); False when this call is not the plain float32 CUDA case
+    (the caller then does it with torch ops)."""
+    rm, rv, nbt = norm.running_mean, norm.running_var, norm.num_batches_tracked
+    if (norm.momentum is None or not rm.is_cuda or rm.dtype != torch.float32 or rv.dtype != torch.float32 or not rm.is_contiguous()
+            or not rv.is_contiguous() or mean.dtype != torch.float32 or var.dtype != torch.float32 or not mean.is_contiguous()
+            or not var.is_contiguous() or mean.numel() != rm.numel() or var.numel() != rm.numel() or mean.device != rm.device
+            or (nbt is not None and (nbt.dtype != torch.int64 or nbt.device != rm.device))):
+        return False
+    with torch.cuda.device(rm.device):
+        check(_lib.lib().snvc_bn_track(_ptr(rm), _ptr(rv), _ptr(nbt), _ptr(mean), _ptr(var), rm.numel(), float(norm.momentum),
+                                       float(cnt / max(cnt - 1, 1)), _stream(rm)), "snvc_bn_track")
+    # the kernel wrote through raw pointers: tell the version counters (the folded eval-mode BatchNorm is cached on ._version)
+    for t in (rm, rv) + ((nbt,) if nbt is not None else ()):
+        torch.autograd.graph.increment_version(t)
+    return True
+
+
 def act_backward_reduce(raw, gy, residual, scale, shift, flags: int, per_sample: bool, amax_gy: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Per (n, c): [sum(g), sum(g*raw)] in fp64, g = gy * act'(raw*scale + shift [+ residual]).  ``amax_gy``: zeroed words (amax_word)
     that receive the bit pattern of max|gy| -- the pass reads all of gy anyway."""

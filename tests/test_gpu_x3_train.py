@@ -313,3 +313,43 @@ def test_pointwise_layer_from_one_or_two_channels(cin, flags):
         assert torch.equal(y, y2)
     else:
         check(y.cpu().numpy(), y2.cpu().numpy(), 1e-6, "streaming vs MFMA tile form")
+
+
+def test_bn_bookkeeping_in_one_launch():
+    """snvc_bn_track against nn.BatchNorm3d's own train-mode update (torch/nn/modules/batchnorm.py): the same running statistics bit for
+    bit, the counter advanced, and the tensors' version counters bumped (the folded eval-mode BatchNorm is cached on them)"""
+    import torch.nn as nn
+    from snvc_amd import ops
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(120)
+    x = _t(r.standard_normal((2, 32, 3, 4, 20)) * 2 + 0.5)
+    for momentum in (0.1, 0.7):
+        ref, ours = nn.BatchNorm3d(32, momentum=momentum).to(dev()).train(), nn.BatchNorm3d(32, momentum=momentum).to(dev()).train()
+        ref(x)
+        mean, var = x.mean((0, 2, 3, 4)), x.var((0, 2, 3, 4), unbiased=False)
+        v0 = ours.running_mean._version
+        assert ops.bn_track(ours, mean.contiguous(), var.contiguous(), x.numel() / 32)
+        assert ours.running_mean._version > v0 and int(ours.num_batches_tracked) == 1
+        check(ours.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), 1e-6, "running_mean")
+        check(ours.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), 1e-6, "running_var")
+        # torch's own two lerp_ on the same inputs: bit for bit
+        t = nn.BatchNorm3d(32, momentum=momentum).to(dev())
+        t.running_mean.lerp_(mean, momentum)
+        t.running_var.lerp_(var * (x.numel() / 32 / (x.numel() / 32 - 1)), momentum)
+        assert torch.equal(t.running_mean, ours.running_mean) and torch.equal(t.running_var, ours.running_var)
+    cum = nn.BatchNorm3d(32, momentum=None).to(dev()).train()
+    assert not ops.bn_track(cum, mean.contiguous(), var.contiguous(), 100.0)        # cumulative average: the torch path keeps it
+    # a layer trained one step, then evaluated: the folded BatchNorm sees the new statistics
+    layer = seeded(S.ConvBNReLU3d(S.convbn_3d(32, 32, 3, 1, 1), nn.ReLU(inplace=True)), 121).to(dev())
+    xin = torch.relu(_t(r.standard_normal((1, 32, 4, 6, 20))))
+    layer.eval()
+    with torch.no_grad():
+        y_before = layer.fused(xin).clone()
+    layer.train()
+    layer.fused(xin.clone().requires_grad_()).mean().backward()
+    layer.eval()
+    with torch.no_grad():
+        y_after = layer.fused(xin)
+        ref_after = torch.relu(layer[0][1](torch.nn.functional.conv3d(xin, layer[0][0].weight, padding=1)))
+    assert not torch.equal(y_before, y_after)
+    check(y_after.cpu().numpy(), ref_after.cpu().numpy(), 1e-5, "eval after one training step")
