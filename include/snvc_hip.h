@@ -393,6 +393,11 @@ SNVC_API int snvc_sheared_upsample(const float *right, float *out, int64_t N, in
 SNVC_API int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale,
                                  const float *bias, float *y, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q,
                                  int m0, int64_t WG, int off, int64_t WG2, int off2, int flags, void *stream);
+/* r6: + the bit pattern of max|y| into SNVC_AMAX_SLOTS zeroed words (see snvc_affine_act_amax): the training step's next layer scales its
+ * split operands by it -- exact, and without the dozen small launches a bound formed from max|G|, max|G'|, max|planes| took. */
+SNVC_API int snvc_sheared_expand_amax(const float *g, const float *gcol, const float *planes, const float *scale, const float *bias,
+                                      float *y, int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG,
+                                      int off, int64_t WG2, int off2, int flags, uint32_t *amax, void *stream);
 /* snvc_sheared_expand with the result written as a split C8 pair (y_hi, y_lo: half [N][2][C/8][D][H][W][8] planes, see the
  * split-mode section below) for a consumer on the snvc_f16x3_* kernels; scale / bias carry the tensor's exponent (the host
  * folds 2^e in: exact).  y_batch_stride in halves (0: dense pair).  overflow (device int, may be NULL): set to 1 if a value had

@@ -77,6 +77,8 @@ SIGNATURES = {
     "snvc_sheared_upsample_backward": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_p]),
     "snvc_sheared_expand": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_i64, c_int,
                                     c_int, c_p]),
+    "snvc_sheared_expand_amax": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int, c_i64, c_int,
+                                    c_int, c_p, c_p]),
     "snvc_sheared_expand_split": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_i64, c_int,
                                           c_i64, c_int, c_i64, c_int, c_p]),
     "snvc_norm_workspace_bytes": (c_i64, [c_i64, c_i64, c_i64]),

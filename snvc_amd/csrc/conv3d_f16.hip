@@ -2436,9 +2436,11 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
         if (!form_ok) return fail(SNVC_ERR_UNSUPPORTED, "snvc_f16x3_conv3d_forward_stats: this layer's kernel form has no statistics epilogue");
         *stats_slots = p.kind == FK3XQ ? ntiles * 4 : (int64_t)(grid.z / d->N) * grid.x * 4;
         if (!stats) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward_stats: null workspace");
-        // whole tiles outside a smaller parity class return early: their slots must read as zero
-        const hipError_t e = hipMemsetAsync(stats, 0, (size_t)d->N * *stats_slots * ((d->Cout + 31) / 32) * 64 * sizeof(double), st);
-        if (e != hipSuccess) return fail(SNVC_ERR_HIP, "snvc_f16x3_conv3d_forward_stats: hipMemsetAsync failed");
+        // whole tiles outside a smaller parity class return early: their slots must read as zero (one class: every workgroup writes its slots)
+        if (classes > 1) {
+            const hipError_t e = hipMemsetAsync(stats, 0, (size_t)d->N * *stats_slots * ((d->Cout + 31) / 32) * 64 * sizeof(double), st);
+            if (e != hipSuccess) return fail(SNVC_ERR_HIP, "snvc_f16x3_conv3d_forward_stats: hipMemsetAsync failed");
+        }
     }
 #define SNVC_X3_LAUNCH(CFG) do { if (to_f32) launch_f16<CFG, 2>(a, grid, st); else launch_f16<CFG, 0>(a, grid, st); } while (0)
     switch (p.kind) {

@@ -123,6 +123,14 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
     }
     __syncthreads();
     double st0 = 0.0, st1 = 0.0;
+    unsigned mxb = 0;            // MODE 2 (r6): bits of max|y| over what this thread stores, published into SNVC_AMAX_SLOTS words at `stats`
+    auto amax4 = [&](const f32x4 &o) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned b = __float_as_uint(o[k]) & 0x7fffffffu;
+            mxb = b > mxb ? b : mxb;
+        }
+    };
     if (tid < rows * quads) {
     const int r = tid / quads, qd = tid - r * quads, w0 = 4 * qd;
     const float sc = scale ? scale[co] : 1.0f, bi = scale ? bias[co] : 0.0f;
@@ -167,8 +175,9 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
             float v = (o[k] + pe[k]) * sc + bi;
             o[k] = relu ? (v > 0.0f ? v : 0.0f) : v;
         }
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 2) {
             *reinterpret_cast<f32x4 *>(yp + (int64_t)d * plane_sz) = o;
+            if (MODE == 2) amax4(o);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { st0 += (double)o[k]; st1 += (double)o[k] * (double)o[k]; }
@@ -188,8 +197,9 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
                 float v = (o[k] + pl[k]) * sc + bi;
                 o[k] = relu ? (v > 0.0f ? v : 0.0f) : v;
             }
-            if (MODE == 0) {
+            if (MODE == 0 || MODE == 2) {
                 *reinterpret_cast<f32x4 *>(yp + (int64_t)d * plane_sz) = o;      // plain store: conv2 reads the tail from the caches
+                if (MODE == 2) amax4(o);
             } else {
                 st0 += ((double)o[0] + (double)o[1]) + ((double)o[2] + (double)o[3]);
                 st1 += ((double)o[0] * (double)o[0] + (double)o[1] * (double)o[1]) + ((double)o[2] * (double)o[2] + (double)o[3] * (double)o[3]);
@@ -200,6 +210,15 @@ sheared_expand_kernel(const float *__restrict__ g, const float *__restrict__ gco
         }
     }
     }   // active threads
+    if (MODE == 2) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const unsigned v = (unsigned)__shfl_xor((int)mxb, o);
+            mxb = v > mxb ? v : mxb;
+        }
+        if ((tid & 63) == 0 && mxb)
+            atomicMax(reinterpret_cast<unsigned *>(stats) + ((blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & (SNVC_AMAX_SLOTS - 1)), mxb);
+    }
     if (MODE == 1) {
         for (int o = 32; o > 0; o >>= 1) { st0 += __shfl_down(st0, o, 64); st1 += __shfl_down(st1, o, 64); }
         __shared__ double red[16];
@@ -1419,6 +1438,12 @@ static int sheared_expand_rows(int64_t N, int64_t C, int64_t H, int quads, size_
 int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, const float *scale, const float *bias, float *y,
                         int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2,
                         int off2, int flags, void *stream) {
+    return snvc_sheared_expand_amax(g, gcol, planes, scale, bias, y, N, C, D, H, W, q, m0, WG, off, WG2, off2, flags, nullptr, stream);
+}
+
+int snvc_sheared_expand_amax(const float *g, const float *gcol, const float *planes, const float *scale, const float *bias, float *y,
+                             int64_t N, int64_t C, int64_t D, int64_t H, int64_t W, int q, int m0, int64_t WG, int off, int64_t WG2,
+                             int off2, int flags, uint32_t *amax, void *stream) {
     using namespace snvc;
     if (N < 0 || C <= 0 || D < 2 || H <= 0 || W <= 0 || W % 4 != 0 || (q != 1 && q != 2 && q != 4) || m0 < 0 || WG <= 0 || WG2 <= 0)
         return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_sheared_expand: bad sizes (W % 4 == 0, q in {1,2,4}, D >= 2)");
@@ -1439,17 +1464,38 @@ int snvc_sheared_expand(const float *g, const float *gcol, const float *planes, 
     const dim3 grid((unsigned)ceil_div<int64_t>(H, RB), (unsigned)C, (unsigned)N);
     static std::atomic<unsigned> attr1{0}, attr2{0}, attr4{0};
     if (q == 4) {      // r6: four phases (downsample 2 with half-pixel planes, downsample 4 with whole-pixel planes: index 4 w - m0 - d)
-        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<4, 0>), (int)lds, attr4)) return check_launch("snvc_sheared_expand");
-        sheared_expand_kernel<4, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
-                                                                             (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
+        static std::atomic<unsigned> attr_m2_4{0};
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<4, 0>), (int)lds, attr4) ||
+            (amax && !allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<4, 2>), (int)lds, attr_m2_4)))
+            return check_launch("snvc_sheared_expand");
+        if (amax)
+            sheared_expand_kernel<4, 2><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, reinterpret_cast<double *>(amax),
+                                                                                 (int)C, (int)D, (int)H, (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
+        else
+            sheared_expand_kernel<4, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
+                                                                                 (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
     } else if (q == 1) {
-        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<1, 0>), (int)lds, attr1)) return check_launch("snvc_sheared_expand");
-        sheared_expand_kernel<1, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
-                                                                             (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
+        static std::atomic<unsigned> attr_m2_1{0};
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<1, 0>), (int)lds, attr1) ||
+            (amax && !allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<1, 2>), (int)lds, attr_m2_1)))
+            return check_launch("snvc_sheared_expand");
+        if (amax)
+            sheared_expand_kernel<1, 2><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, reinterpret_cast<double *>(amax),
+                                                                                 (int)C, (int)D, (int)H, (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
+        else
+            sheared_expand_kernel<1, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
+                                                                                 (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
     } else {
-        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<2, 0>), (int)lds, attr2)) return check_launch("snvc_sheared_expand");
-        sheared_expand_kernel<2, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
-                                                                             (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
+        static std::atomic<unsigned> attr_m2_2{0};
+        if (!allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<2, 0>), (int)lds, attr2) ||
+            (amax && !allow_large_lds(reinterpret_cast<const void *>(&sheared_expand_kernel<2, 2>), (int)lds, attr_m2_2)))
+            return check_launch("snvc_sheared_expand");
+        if (amax)
+            sheared_expand_kernel<2, 2><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, reinterpret_cast<double *>(amax),
+                                                                                 (int)C, (int)D, (int)H, (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
+        else
+            sheared_expand_kernel<2, 0><<<grid, threads, lds, as_stream(stream)>>>(g, gcol, planes, scale, bias, y, nullptr, (int)C, (int)D, (int)H,
+                                                                                 (int)W, m0, (int)WG, off, (int)WG2, off2, RB, flags);
     }
     return check_launch("snvc_sheared_expand");
 }

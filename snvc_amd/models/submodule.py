@@ -872,10 +872,10 @@ class _ShearedFirstConvBNFn(torch.autograd.Function):
         scale, shift, mean, var = ops.sheared_expand_stats(g, gcol, planes, gam, bet, shape, q, m0, off, off_col, norm.eps)
         _bn_track(norm, mean, var, float(n * depth * h * w))
         y = torch.empty(shape, dtype=torch.float32, device=left.device)
-        ops.sheared_expand(g, gcol, planes, scale, shift, y, q, m0, off, off_col, EPI_RELU)
-        # an upper bound of max|y| for the next layer's split-operand weight gradient (r6): a voxel of the raw result is one element of
-        # G (+ one of G' in the last column) + one of the planes, so |y| <= max|scale| (max|G| + max|G'| + max|planes|) + max|shift|
-        am = ops.amax_from_bound(scale.abs().max() * (g.abs().max() + gcol.abs().max() + planes.abs().max()) + shift.abs().max())
+        # max|y| for the next layer's split operands (r6), left by the expansion itself (first form: an upper bound from max|G|, max|G'|,
+        # max|planes| -- sixteen small torch launches per step)
+        am = ops.amax_word(y.device)
+        ops.sheared_expand(g, gcol, planes, scale, shift, y, q, m0, off, off_col, EPI_RELU, amax=am)
         ops.tag_amax(y, am)
         y.snvc_twin_src = plan
         if getattr(plan, "want_twin", False) and X3_TRAIN[0] and ops.twin_ok(y):

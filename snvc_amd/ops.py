@@ -570,10 +570,12 @@ def sheared_upsample(right, q: int, wu: int, off: int):
     return out
 
 
-def sheared_expand(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int, off_col: int, flags: int = 0):
+def sheared_expand(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int, off_col: int, flags: int = 0,
+                   amax: Optional[torch.Tensor] = None):
     """out[n,co,d,h,w] = epilogue(scale*G[n,cls(d),co,h,q*w-d-m0+off] + planes[n,co,cls(d),h,w] + bias), with G' (``gcol``,
     indexed with ``off_col``) in place of G at w = W-1 (snvc_sheared_expand); g [N,3C,H,WG], gcol [N,3C,H,WG2] (depth classes
-    first / interior / last stacked class-major), planes [N,C,3,H,W] or None, out [N,C,D,H,W] (contiguous, written in place)."""
+    first / interior / last stacked class-major), planes [N,C,3,H,W] or None, out [N,C,D,H,W] (contiguous, written in place).
+    ``amax`` (r6): zeroed words (amax_word) that receive the bit pattern of max|out| (snvc_sheared_expand_amax)."""
     _gpu(g, "g"); _gpu(gcol, "gcol"); _gpu(out, "out")
     n, c, d, h, w = out.shape
     for t in (g, gcol):
@@ -584,9 +586,9 @@ def sheared_expand(g, gcol, planes, scale, bias, out, q: int, m0: int, off: int,
     if planes is not None and (tuple(planes.shape) != (n, c, 3, h, w) or not planes.is_contiguous()):
         raise RuntimeError("planes must be a contiguous [N,C,3,H,W] tensor")
     with torch.cuda.device(out.device):
-        check(_lib.lib().snvc_sheared_expand(_ptr(g), _ptr(gcol), _ptr(planes), _ptr(scale), _ptr(bias), _ptr(out), n, c, d, h, w,
-                                             int(q), int(m0), g.size(3), int(off), gcol.size(3), int(off_col), int(flags),
-                                             _stream(out)), "snvc_sheared_expand")
+        check(_lib.lib().snvc_sheared_expand_amax(_ptr(g), _ptr(gcol), _ptr(planes), _ptr(scale), _ptr(bias), _ptr(out), n, c, d, h, w,
+                                                  int(q), int(m0), g.size(3), int(off), gcol.size(3), int(off_col), int(flags),
+                                                  _ptr(amax), _stream(out)), "snvc_sheared_expand")
     return out
 
 

@@ -353,3 +353,23 @@ def test_bn_bookkeeping_in_one_launch():
         ref_after = torch.relu(layer[0][1](torch.nn.functional.conv3d(xin, layer[0][0].weight, padding=1)))
     assert not torch.equal(y_before, y_after)
     check(y_after.cpu().numpy(), ref_after.cpu().numpy(), 1e-5, "eval after one training step")
+
+
+@pytest.mark.parametrize("q", [1, 2, 4])
+def test_sheared_expand_leaves_the_maximum(q):
+    """snvc_sheared_expand_amax: the same tensor as snvc_sheared_expand bit for bit, and max|y| in the words, bit for bit"""
+    from snvc_amd import ops
+    from snvc_amd.models import submodule as S
+    r = np.random.default_rng(130 + q)
+    n, c, d, h, w, m0 = 2, 32, 12, 5, 40, 3
+    off, wu, off_col, wu_col = S.sheared_geometry(q, m0, d, w)      # any consistent geometry: the kernel reads zeros outside [0, WG)
+    g, gcol = _t(r.standard_normal((n, 3 * c, h, wu))), _t(r.standard_normal((n, 3 * c, h, wu_col)))
+    planes = _t(r.standard_normal((n, c, 3, h, w)))
+    scale, shift = _t(r.uniform(0.5, 2, c)), _t(r.standard_normal(c))
+    y0 = torch.empty((n, c, d, h, w), device=dev())
+    y1 = torch.empty_like(y0)
+    ops.sheared_expand(g, gcol, planes, scale, shift, y0, q, m0, off, off_col, ops.EPI_RELU)
+    am = ops.amax_word(dev())
+    ops.sheared_expand(g, gcol, planes, scale, shift, y1, q, m0, off, off_col, ops.EPI_RELU, amax=am)
+    assert torch.equal(y0, y1)
+    assert am.max().view(torch.float32).item() == y0.abs().max().item()
