@@ -657,12 +657,20 @@ SNVC_API int snvc_f16x3_conv3d_forward(const snvc_conv3d_desc *desc_host, const 
  * layer of the training step that runs on the split kernels): as snvc_conv3d_forward_stats, for the kernel forms that write
  * float32 through the shared epilogue (3x3x3 stride 1 / 2 and the transposed layer, 256-thread forms).  scale / bias / head_mul as
  * snvc_f16x3_conv3d_forward (the statistics are those of the STORED values); desc.flags == 0, Cout % 32 == 0.
- * SNVC_ERR_UNSUPPORTED (nothing launched) when the layer does not take such a form. */
+ * SNVC_ERR_UNSUPPORTED (nothing launched) when the layer does not take such a form.
+ * x_mul (may be NULL): ONE device float, the power of two the input pair was multiplied by (snvc_split_scale_bound /
+ * snvc_f16x3_split_scale); the epilogue takes it out of the channel scale exactly -- no host read, no launch to fold it into `scale`. */
 SNVC_API int64_t snvc_f16x3_conv3d_stats_workspace_bytes(const snvc_conv3d_desc *desc_host);
 SNVC_API int snvc_f16x3_conv3d_forward_stats(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,
-                                             const void *packed_weight, const float *scale, const float *bias, float *y_f32,
-                                             float head_mul, const float *gamma, const float *beta, float *bn_scale,
+                                             const void *packed_weight, const float *scale, const float *bias, const float *x_mul,
+                                             float *y_f32, float head_mul, const float *gamma, const float *beta, float *bn_scale,
                                              float *bn_shift, float *mean, float *var, void *workspace, float eps, void *stream);
+/* The same layer without the statistics: y_f32 = out_mul * act(scale / x_mul[0] * conv + bias) [+ res_f32] -- the float32-output form of
+ * snvc_f16x3_conv3d_forward with its arguments named (res_f32: a float32 NCDHW tensor of the result's shape and batch stride, or NULL;
+ * desc.flags: SNVC_EPI_RELU or 0).  The training step's data gradients run through this. */
+SNVC_API int snvc_f16x3_conv3d_forward_f32(const snvc_conv3d_desc *desc_host, const void *x_hi, const void *x_lo,
+                                           const void *packed_weight, const float *scale, const float *bias, const float *x_mul,
+                                           const float *res_f32, float *y_f32, float out_mul, void *stream);
 /* The global stack's tail -- classifier(bn(conv6(post)) + v), reference snvc/models/submodule.py:127-146,166 with the composition
  * of snvc/models/vernier.py:366-371 -- is linear in `post` (conv6 has no activation): a transposed layer (k3, s2, p1, op1) to ONE
  * channel with folded weights W'[c][kd][kh][kw] (c over post's channels) and a scalar bias.  Three entry points (r5) evaluate it

@@ -121,7 +121,8 @@ SIGNATURES = {
     "snvc_f16x3_conv3d_pack_weights": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_f32, c_p]),
     "snvc_f16x3_conv3d_forward": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_f32, c_p, c_p]),
     "snvc_f16x3_conv3d_stats_workspace_bytes": (c_i64, [ctypes.POINTER(Conv3dDesc)]),
-    "snvc_f16x3_conv3d_forward_stats": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p]),
+    "snvc_f16x3_conv3d_forward_stats": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p]),
+    "snvc_f16x3_conv3d_forward_f32": (c_int, [ctypes.POINTER(Conv3dDesc), c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f32, c_p]),
     "snvc_f16x3_split_scale": (c_int, [c_p, c_i64, c_p, c_p, c_p]),
     "snvc_sheared_upsample_split": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_p]),
     "snvc_sheared_prep_x3": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_int, c_i64, c_int, c_i64, c_int, c_p, c_p, c_i64, c_f32, c_f32, c_p, c_p, c_p,

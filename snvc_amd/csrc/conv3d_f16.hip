@@ -547,6 +547,8 @@ conv3d_f16_kernel(const F16Args a_) {
         const float lo_bound = relu ? 0.0f : -kHalfMax;
         float vmax = 0.0f;
         const bool want_stats = EPI == 2 && a.stats != nullptr;
+        // EPI 2 (r6): the input pair held x * x_mul[0] (a device-side power of two): taken out of the channel scale here, exactly
+        const float x_inv = (EPI == 2 && a.x_mul) ? 1.0f / a.x_mul[0] : 1.0f;
         auto run = [&](auto has_res_tag) {
             constexpr bool HAS_RES = decltype(has_res_tag)::value;
 #pragma unroll
@@ -570,7 +572,7 @@ conv3d_f16_kernel(const F16Args a_) {
                     f32x4 sc[2], bi[2], hw4[2];
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        sc[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + cj + 4 * k) : f32x4(1.0f);
+                        sc[k] = (a.scale ? *reinterpret_cast<const f32x4 *>(a.scale + cj + 4 * k) : f32x4(1.0f)) * x_inv;
                         bi[k] = a.scale ? *reinterpret_cast<const f32x4 *>(a.bias + cj + 4 * k) : f32x4(0.0f);
                         if constexpr (side) hw4[k] = *reinterpret_cast<const f32x4 *>(a.head + cj + 4 * k);
                     }
@@ -869,9 +871,10 @@ conv3d_x3q_kernel(const F16Args a) {
     const bool relu = (a.flags & SNVC_EPI_RELU) != 0;
     const int c0 = cb * 32 + 8 * kb;
     float sc[8], bi[8], hw8[8];
+    const float x_inv = (EPI == 2 && a.x_mul) ? 1.0f / a.x_mul[0] : 1.0f;      // see conv3d_f16_kernel's EPI 2
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        sc[e] = a.scale ? a.scale[c0 + e] : 1.0f;
+        sc[e] = (a.scale ? a.scale[c0 + e] : 1.0f) * x_inv;
         bi[e] = a.scale ? a.bias[c0 + e] : 0.0f;
         hw8[e] = (EPI == 3) ? a.head[c0 + e] : 0.0f;
     }
@@ -2338,7 +2341,7 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
                          const float *scale, const float *bias, const void *res_hi, const void *res_lo, void *y_hi,
                          void *y_lo, float *y_f32, const float *head, float *y_head, float head_mul, float res_mul,
                          int *overflow, const void *tail_w, float *t_out, float tail_mul, void *stream, double *stats = nullptr,
-                         int64_t *stats_slots = nullptr) {
+                         int64_t *stats_slots = nullptr, const float *x_mul = nullptr) {
     using namespace snvc;
     F16Plan p;
     if (!d) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward: null desc");
@@ -2395,6 +2398,7 @@ static int f16x3_forward(const snvc_conv3d_desc *d, const void *x_hi, const void
     a.head = head; a.y_head = y_head; a.head_mul = head_mul; a.res_mul = res_mul; a.overflow = overflow;
     a.res_f32 = res_f32;
     a.stats = stats;
+    a.x_mul = to_f32 ? x_mul : nullptr;
     a.tail_w = reinterpret_cast<const _Float16 *>(tail_w); a.t_out = t_out; a.tail_mul = tail_mul;
     a.t_bs = (int64_t)27 * 8 * d->Din * d->Hin * d->Win;
     a.CGin = d->Cin / 8; a.Cout = d->Cout;
@@ -2547,8 +2551,20 @@ int64_t snvc_f16x3_conv3d_stats_workspace_bytes(const snvc_conv3d_desc *d) {
     return (d->N * slots * groups * 64 + conv_stats_fold_scratch_doubles(d->N, (int)groups, slots) + d->N * (int64_t)d->Cout * 2) * (int64_t)sizeof(double);
 }
 
+int snvc_f16x3_conv3d_forward_f32(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
+                                  const float *scale, const float *bias, const float *x_mul, const float *res_f32, float *y_f32,
+                                  float out_mul, void *stream) {
+    using namespace snvc;
+    if (!d || !y_f32) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward_f32: null pointer");
+    if (d->flags & (SNVC_EPI_ADD_PRE | SNVC_EPI_ADD_POST)) return fail(SNVC_ERR_INVALID_ARGUMENT, "snvc_f16x3_conv3d_forward_f32: the residual is res_f32 (added after the activation), no flag");
+    snvc_conv3d_desc dd = *d;
+    if (res_f32) dd.flags |= SNVC_EPI_ADD_POST;
+    return f16x3_forward(&dd, x_hi, x_lo, packed_weight, scale, bias, res_f32, nullptr, nullptr, nullptr, y_f32, nullptr, nullptr, out_mul, 1.0f,
+                         nullptr, nullptr, nullptr, 0.0f, stream, nullptr, nullptr, x_mul);
+}
+
 int snvc_f16x3_conv3d_forward_stats(const snvc_conv3d_desc *d, const void *x_hi, const void *x_lo, const void *packed_weight,
-                                    const float *scale, const float *bias, float *y_f32, float head_mul, const float *gamma,
+                                    const float *scale, const float *bias, const float *x_mul, float *y_f32, float head_mul, const float *gamma,
                                     const float *beta, float *bn_scale, float *bn_shift, float *mean, float *var, void *workspace,
                                     float eps, void *stream) {
     using namespace snvc;
@@ -2558,7 +2574,7 @@ int snvc_f16x3_conv3d_forward_stats(const snvc_conv3d_desc *d, const void *x_hi,
     double *stats = static_cast<double *>(workspace);
     int64_t slots = 0;
     int rc = f16x3_forward(d, x_hi, x_lo, packed_weight, scale, bias, nullptr, nullptr, nullptr, nullptr, y_f32, nullptr, nullptr, head_mul, 1.0f,
-                           nullptr, nullptr, nullptr, 0.0f, stream, stats, &slots);
+                           nullptr, nullptr, nullptr, 0.0f, stream, stats, &slots, x_mul);
     if (rc) return rc;
     const int groups = d->Cout / 32;
     double *scratch = stats + d->N * slots * groups * 64;

@@ -346,7 +346,7 @@ class _X3TrainLayer:
         if scale is not None or bias is not None or residual is not None or flags or out is not None:
             raise RuntimeError("_X3TrainLayer: the plain convolution only")
         pair, mul = _split_operand(x, ops.amax_of(x))
-        return self.layer(pair, 0, None, None, flags=0, out_exp=0, to_f32=True, x_mul_dev=mul)
+        return self.layer.forward_f32(pair, mul)
 
     def forward_stats(self, x, gamma, beta, eps):
         pair, mul = _split_operand(x, ops.amax_of(x))
@@ -458,7 +458,7 @@ class _ConvNormActFn(torch.autograd.Function):
         gx = None
         if x3:                               # r6: the data gradient on the split kernels, draw through its twin, the skip's gradient in the epilogue
             pair, mul = _split_operand(draw, g_amax)
-            gx = _x3_train_layers(conv, plan)[1](pair, 0, None, None, flags=0, out_exp=0, to_f32=True, x_mul_dev=mul, residual_f32=extra)
+            gx = _x3_train_layers(conv, plan)[1].forward_f32(pair, mul, residual_f32=extra)
             _ROUTES["x3_train_dgrad"] += 1
         elif needs[0]:
             if odd:

@@ -1797,6 +1797,33 @@ class Conv3dLayerX3:
             return out_f32          # the kernel multiplied by 2^-out_exp on the way out
         return (out, y_head) if head is not None else out
 
+    def forward_f32(self, x, x_mul_dev, residual_f32: Optional[torch.Tensor] = None, relu: bool = False):
+        """r6 (training): the plain convolution of a device-scaled layer with a float32 NCDHW result (snvc_f16x3_conv3d_forward_f32):
+        ``x`` holds values * x_mul_dev (one device float, taken out by the kernel: no launch to fold it into the scale vector),
+        ``residual_f32`` is added to the stored result (a skip connection's gradient)."""
+        _split_check(x, "x")
+        if self.w_mul_dev is None or x.size(2) * 8 != self.cin:
+            raise RuntimeError("forward_f32: a device-scaled layer (w_mul_dev) and an input of its channel count")
+        n = x.size(0)
+        in_sp = tuple(x.shape[3:6])
+        out_sp = self.out_spatial(in_sp)
+        if self._sc_w is None:
+            self._sc_w, self._bi_0 = _ones_zeros(self.cout, x.device)[0] / self.w_mul_dev, _ones_zeros(self.cout, x.device)[1]
+        y = torch.empty((n, self.cout) + out_sp, dtype=torch.float32, device=x.device)
+        if residual_f32 is not None and (residual_f32.dtype != torch.float32 or tuple(residual_f32.shape) != tuple(y.shape)
+                                         or not _dense_inner(residual_f32) or _batch_stride(residual_f32) != _batch_stride(y)):
+            raise RuntimeError("residual_f32 must be a float32 tensor of the result's shape and layout")
+        self.algo = self._pick_form(n, out_sp, plain=True, split_out=False)
+        packed = self._pack(self.algo)
+        if n == 0:
+            return y
+        d = self._desc(n, in_sp, EPI_RELU if relu else 0, _batch_stride(x), _batch_stride(y), 0)
+        with torch.cuda.device(x.device):
+            check(_lib.lib().snvc_f16x3_conv3d_forward_f32(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(packed), _ptr(self._sc_w), _ptr(self._bi_0),
+                                                           _ptr(x_mul_dev), _ptr(residual_f32), _ptr(y), 1.0, _stream(x)),
+                  "snvc_f16x3_conv3d_forward_f32")
+        return y
+
     def forward_stats(self, x, x_mul_dev, gamma, beta, eps: float):
         """r6 (training): the plain convolution with a float32 result AND the batch statistics of that result from the same launch
         (snvc_f16x3_conv3d_forward_stats): (raw, scale, shift, mean, var) as Conv3dLayer.forward_stats, or None when the layer's
@@ -1809,7 +1836,7 @@ class Conv3dLayerX3:
         out_sp = self.out_spatial(in_sp)
         if self._sc_w is None:
             self._sc_w, self._bi_0 = _ones_zeros(self.cout, x.device)[0] / self.w_mul_dev, _ones_zeros(self.cout, x.device)[1]
-        sc = self._sc_w if x_mul_dev is None else (self._sc_w / x_mul_dev)
+        sc = self._sc_w                        # 1 / x_mul is applied by the kernel (x_mul: a device pointer)
         self.algo = self._pick_form(n, out_sp, plain=True, split_out=False)
         packed = self._pack(self.algo)
         raw = torch.empty((n, self.cout) + out_sp, dtype=torch.float32, device=x.device)
@@ -1821,7 +1848,7 @@ class Conv3dLayerX3:
         out = torch.empty((4, self.cout), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             rc = _lib.lib().snvc_f16x3_conv3d_forward_stats(ctypes.byref(d), _ptr(x), _lo_ptr(x), _ptr(packed), _ptr(sc), _ptr(self._bi_0),
-                                                            _ptr(raw), 1.0, _ptr(gamma), _ptr(beta), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
+                                                            _ptr(x_mul_dev), _ptr(raw), 1.0, _ptr(gamma), _ptr(beta), _ptr(out[0]), _ptr(out[1]), _ptr(out[2]),
                                                             _ptr(out[3]), _ptr(ws), float(eps), _stream(x))
         if rc == 2:            # SNVC_ERR_UNSUPPORTED: the caller runs the convolution and the statistics pass separately
             return None

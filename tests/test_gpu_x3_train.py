@@ -128,6 +128,9 @@ def test_split_layer_f32_output_residual_and_statistics(case):
     extra = _t(r.standard_normal(tuple(y.shape)))
     y2 = lay(xs, 0, None, None, to_f32=True, x_mul_dev=mul, residual_f32=extra)
     assert torch.equal(y2, y + extra)
+    # snvc_f16x3_conv3d_forward_f32: the input's scale taken out inside the kernel (a device pointer) instead of folded into the scale vector
+    assert torch.equal(lay.forward_f32(xs, mul), y) and torch.equal(lay.forward_f32(xs, mul, residual_f32=extra), y2)
+    assert torch.equal(lay.forward_f32(xs, mul, relu=True), torch.relu(y))
     gamma, beta = _t(r.uniform(0.5, 2, co)), _t(r.standard_normal(co))
     got = lay.forward_stats(xs, mul, gamma, beta, 1e-5)
     assert got is not None, "this kernel form carries the statistics epilogue"
