@@ -518,18 +518,26 @@ def shift_structure_begin(shift):
     return host
 
 
-def spin_wait(event, spin_us: float = 1000.0):
+def spin_wait(event, spin_us: float = 4000.0):
     """Wait for a recorded event by polling it (hipEventQuery, ~1 us a look) before falling back to the blocking wait: the waits of a
     step are for results that are a few microseconds away, and a sleeping wait costs tens of microseconds to wake (r5: 0.076 ms of
     a 2.04 ms step between the overflow flag's arrival and the next launch).  The poll is bounded by TIME (r6, ADVICE r5: an
-    iteration count let a deep queue or a shared device burn a core, and the GIL, for tens of milliseconds): 1 ms covers every
-    wait of a 2 ms step; anything further away sleeps."""
+    iteration count let a deep queue or a shared device burn a core, and the GIL, for tens of milliseconds) and hands the GIL over
+    every ~50 us (time.sleep(0): worker threads of a DataParallel caller keep running).  The bound is 4 ms: the flag's wait of a
+    2 ms step is ~1.5 ms long once the host runs ahead of the GPU, and on some hosts the blocking wait wakes up 0.8 ms late -- one
+    box measured the headline at 2.77 instead of 1.98 ms/step with a 1 ms bound (profiles/r6/kernel_experiments_r6.txt, item 26);
+    anything further away than 4 ms sleeps."""
     if event.query():
         return
-    deadline = time.perf_counter() + spin_us * 1e-6
-    while time.perf_counter() < deadline:
+    now = time.perf_counter()
+    deadline, nxt = now + spin_us * 1e-6, now + 50e-6
+    while now < deadline:
         if event.query():
             return
+        now = time.perf_counter()
+        if now >= nxt:
+            time.sleep(0)
+            nxt = now + 50e-6
     event.synchronize()
 
 
