@@ -376,3 +376,49 @@ def test_sheared_expand_leaves_the_maximum(q):
     ops.sheared_expand(g, gcol, planes, scale, shift, y1, q, m0, off, off_col, ops.EPI_RELU, amax=am)
     assert torch.equal(y0, y1)
     assert am.max().view(torch.float32).item() == y0.abs().max().item()
+
+
+def test_cfg4_full_size_step_split_route_vs_fp32_route():
+    """BASELINE.json configs[3] at its full size (features [1,32,96,312], 192 half-pixel planes: a 5.75 M-voxel grid, 736 MB per
+    32-channel tensor): the training step with conv2 + hourglass on the split kernels against the same step on the fp32 kernels --
+    the loss, every parameter gradient and both feature gradients; size-independent properties of the route: no layout pass and 14
+    twins from the second step on, the running statistics moved once per step either way."""
+    from snvc_amd.models import submodule as S
+    from snvc_amd.models.stereo_volume import GlobalStack
+    r = np.random.default_rng(140)
+    C, H, W, D = 32, 96, 312, 192
+    left, right = _t(r.standard_normal((1, C, H, W))).requires_grad_(), _t(r.standard_normal((1, C, H, W))).requires_grad_()
+    shift = torch.from_numpy(np.linspace(0.0, (D - 1) / 2.0, D, dtype=np.float32)[None].copy()).to(dev())
+    res = {}
+    for on in (False, True):
+        S.X3_TRAIN[0] = on
+        try:
+            model = seeded(GlobalStack(C), 141).to(dev()).train()
+            for step in range(2):
+                for p in model.parameters():
+                    p.grad = None
+                left.grad = right.grad = None
+                b = dict(S._ROUTES)
+                loss = model.forward_pair(left, right, shift, 1).pow(2).mean()
+                loss.backward()
+            d = {k: S._ROUTES[k] - b.get(k, 0) for k in ("x3_train_layout_pass", "x3_train_twin", "x3_train_dgrad")}
+            res[on] = (loss.item(), left.grad.clone(), right.grad.clone(), {k: p.grad.clone() for k, p in model.named_parameters()}, d,
+                       {k: v.clone() for k, v in model.state_dict().items() if "running_mean" in k})
+            del model
+            torch.cuda.empty_cache()
+        finally:
+            S.X3_TRAIN[0] = True
+    assert res[True][4] == {"x3_train_layout_pass": 0, "x3_train_twin": 14, "x3_train_dgrad": 7}, res[True][4]
+    assert res[False][4] == {"x3_train_layout_pass": 0, "x3_train_twin": 0, "x3_train_dgrad": 0}
+    assert np.isfinite(res[True][0]) and abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0])
+    # the bounds of tests/test_gpu_fullsize.py::test_training_step_full_size_properties (DIRECT vs Winograd fp32 forms of the same step): two
+    # arithmetics ~2e-6 of the range apart per layer flip ~1e-5 of the 1e9 ReLU masks; a parameter gradient sums over every voxel
+    # (flips average out), a feature-map gradient at one pixel sums ~1.7e5 terms (one flip moves it by a fraction of a percent)
+    def err(a, b):
+        return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+    e_l, e_r = err(res[True][1], res[False][1]), err(res[True][2], res[False][2])
+    assert e_l < 5e-2 and e_r < 5e-2, (e_l, e_r)
+    worst = max((err(res[True][3][k], res[False][3][k]), k) for k in res[False][3])
+    assert worst[0] < 5e-3, worst
+    for k in res[False][5]:
+        assert err(res[True][5][k], res[False][5][k]) < 1e-4, k           # BatchNorm bookkeeping moved the same way (two steps each)
