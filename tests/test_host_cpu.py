@@ -423,3 +423,12 @@ def test_twin_tags_and_the_training_route_on_cpu_tensors():
     ops.tag_amax(x, w)
     v = S._SkipTap.apply(x, S._GradBox())
     assert ops.amax_of(v) is w
+
+
+def test_build_entry_checks_the_abi_the_binding_was_written_against():
+    """__graft_entry__.build() compares the library's ABI with snvc_amd/_lib.py's _ABI, not with a literal that an ABI bump leaves behind
+    (r6: the literal said 5 after the bump to 6 -- the driver's build check would have failed on a library that was fine)"""
+    import os, re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "__graft_entry__.py")).read()
+    assert "snvc_abi_version() == _lib._ABI" in src
+    assert not re.search(r"snvc_abi_version\(\) == \d", src)
