@@ -529,10 +529,12 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
                     sums, mean[0].contiguous(), var[0].contiguous(), gw, float(n * s), float(norm.eps))
                 if norm.weight is None:
                     dgamma = dbeta = None
-                want_g = want_res and bool(flags & EPI_ADD_PRE)
+                # the residual's gradient is g = gy * act'(v): with no activation (conv6: bn(conv) + x) it IS gy -- nothing to write
+                # (r6: the pass wrote a 736 MB copy of gy at cfg4)
+                want_g = want_res and bool(flags & EPI_ADD_PRE) and bool(flags & (EPI_RELU | EPI_SIGMOID))
                 draw, g_out = ops.act_backward_apply(raw, gy, res, scale, shift, coef_g, coef_raw, coef_const, act_flags,
                                                      per_sample, want_g, amax=amax_out, twin_mul=twin_mul(coef_g, coef_raw, coef_const))
-                gres = (g_out if (flags & EPI_ADD_PRE) else gy) if want_res else None
+                gres = (g_out if want_g else gy) if want_res else None
                 return draw, gres, (dgamma if want_gamma else None), (dbeta if want_beta else None)
             sg, sgr = sums[..., 0].sum(0), sums[..., 1].sum(0)                    # [c]
             if train_stats:
@@ -552,7 +554,7 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
         coef_const = c_.float().contiguous() if c_ is not None else None
         if norm.weight is None:
             dgamma = dbeta = None
-    want_g = want_res and bool(flags & EPI_ADD_PRE)
+    want_g = want_res and bool(flags & EPI_ADD_PRE) and bool(flags & (EPI_RELU | EPI_SIGMOID))
     if norm is None and not act_flags:
         draw, g_out = gy, gy
     else:
@@ -560,7 +562,7 @@ def _epilogue_backward(raw, gy, res, scale, shift, mean, var, norm, flags, per_s
                                              per_sample, want_g, amax=amax_out, twin_mul=twin_mul(coef_g, coef_raw, coef_const))
     gres = None
     if want_res:
-        gres = g_out if (flags & EPI_ADD_PRE) else gy
+        gres = g_out if want_g else gy
     dg = dgamma.float() if (dgamma is not None and want_gamma) else None
     db = dbeta.float() if (dbeta is not None and want_beta) else None
     return draw, gres, dg, db
