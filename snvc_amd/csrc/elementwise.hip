@@ -491,7 +491,7 @@ __global__ void __launch_bounds__(256)
 affine_act_twin_kernel(const float *__restrict__ x, const float *__restrict__ scale, const float *__restrict__ shift,
                        const float *__restrict__ res, float *__restrict__ y, _Float16 *__restrict__ t_hi, _Float16 *__restrict__ t_lo,
                        const float *__restrict__ mul, int64_t C, int64_t S, int64_t x_bs, int64_t y_bs, int64_t r_bs, int64_t t_bs,
-                       int per_sample, int flags, unsigned *__restrict__ amax, int chunked) {
+                       int per_sample, int flags, unsigned *__restrict__ amax) {
     const int64_t n = blockIdx.z, g = blockIdx.y, c0 = 8 * g;
     const float m = mul[0];
     float sc[8], sh[8];
@@ -508,13 +508,8 @@ affine_act_twin_kernel(const float *__restrict__ x, const float *__restrict__ sc
     unsigned mx = 0;
     __shared__ tw_h8 twin_lds[4][512];
     tw_h8 *lds_wave = twin_lds[threadIdx.x >> 6];
-    int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, iend = S4, istep = stride;
-    if (chunked) {
-        const int64_t chunk = ((S4 + gridDim.x - 1) / gridDim.x + 255) & ~(int64_t)255;
-        i0 = blockIdx.x * chunk + threadIdx.x; iend = (blockIdx.x + 1) * chunk < S4 ? (blockIdx.x + 1) * chunk : S4; istep = 256;
-    }
-    for (int64_t i = i0; i < iend; i += istep) {
-        const bool full = (i - (threadIdx.x & 63)) + 64 <= iend;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S4; i += stride) {
+        const bool full = (i - (threadIdx.x & 63)) + 64 <= S4;
         float4 v[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = reinterpret_cast<const float4 *>(a + e * S)[i];
@@ -545,7 +540,7 @@ act_bwd_apply_twin_kernel(const float *__restrict__ raw, const float *__restrict
                           const float *__restrict__ B, const float *__restrict__ Cc, float *__restrict__ draw,
                           float *__restrict__ g_out, _Float16 *__restrict__ t_hi, _Float16 *__restrict__ t_lo,
                           const float *__restrict__ mul, int64_t C, int64_t S, int64_t raw_bs, int64_t gy_bs, int64_t r_bs, int64_t t_bs,
-                          int per_sample, int flags, unsigned *__restrict__ amax, int chunked) {
+                          int per_sample, int flags, unsigned *__restrict__ amax) {
     const int64_t n = blockIdx.z, g = blockIdx.y, c0 = 8 * g;
     const int64_t pc = (per_sample ? n * C : 0) + c0;
     const float m = mul[0];
@@ -567,13 +562,8 @@ act_bwd_apply_twin_kernel(const float *__restrict__ raw, const float *__restrict
     unsigned mx = 0;
     __shared__ tw_h8 twin_lds[4][512];
     tw_h8 *lds_wave = twin_lds[threadIdx.x >> 6];
-    int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, iend = S4, istep = stride;
-    if (chunked) {
-        const int64_t chunk = ((S4 + gridDim.x - 1) / gridDim.x + 255) & ~(int64_t)255;
-        i0 = blockIdx.x * chunk + threadIdx.x; iend = (blockIdx.x + 1) * chunk < S4 ? (blockIdx.x + 1) * chunk : S4; istep = 256;
-    }
-    for (int64_t i = i0; i < iend; i += istep) {
-        const bool full = (i - (threadIdx.x & 63)) + 64 <= iend;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < S4; i += stride) {
+        const bool full = (i - (threadIdx.x & 63)) + 64 <= S4;
         float4 xv[8], gv[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -947,13 +937,11 @@ int snvc_affine_act_amax(const float *x, const float *scale, const float *shift,
     return check_launch("snvc_affine_act");
 }
 
-// EXPERIMENT knobs (environment): SNVC_TWIN_CAP total workgroups, SNVC_TWIN_CHUNK 1 = a contiguous run of the row per workgroup
-static int twin_env(const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; }
-static int twin_chunked() { static const int v = twin_env("SNVC_TWIN_CHUNK", 0); return v; }
+// 2048 workgroups in all (measured at cfg4's layer sizes: 1024-8192 and contiguous chunks per workgroup instead of a grid stride make
+// no difference, profiles/r6/kernel_experiments_r6.txt item 19)
 static unsigned twin_blocks(int64_t s4, int64_t outer) {
-    static const int cap_total = twin_env("SNVC_TWIN_CAP", 2048);
     int64_t b = snvc::ceil_div<int64_t>(s4, 256);
-    const int64_t cap = snvc::ceil_div<int64_t>(cap_total, outer > 0 ? outer : 1);
+    const int64_t cap = snvc::ceil_div<int64_t>(2048, outer > 0 ? outer : 1);
     if (b > cap) b = cap;
     return (unsigned)(b < 1 ? 1 : b);
 }
@@ -993,7 +981,7 @@ int snvc_affine_act_twin(const float *x, const float *scale, const float *shift,
     dim3 grid(twin_blocks(S / 4, N * C / 8), (unsigned)(C / 8), (unsigned)N);
     affine_act_twin_kernel<<<grid, 256, 0, as_stream(stream)>>>(x, scale, shift, residual, y, reinterpret_cast<_Float16 *>(twin_hi),
                                                                 reinterpret_cast<_Float16 *>(twin_lo), twin_mul, C, S, x_batch_stride,
-                                                                y_batch_stride, res_batch_stride, twin_batch_stride, per_sample, flags, amax, twin_chunked());
+                                                                y_batch_stride, res_batch_stride, twin_batch_stride, per_sample, flags, amax);
     return check_launch("snvc_affine_act_twin");
 }
 
@@ -1018,7 +1006,7 @@ int snvc_act_backward_apply_twin(const float *raw, const float *gy, const float 
     act_bwd_apply_twin_kernel<<<grid, 256, 0, as_stream(stream)>>>(raw, gy, residual, scale, shift, coef_g, coef_raw, coef_const, draw, g_out,
                                                                    reinterpret_cast<_Float16 *>(twin_hi), reinterpret_cast<_Float16 *>(twin_lo),
                                                                    twin_mul, C, S, raw_batch_stride, gy_batch_stride, res_batch_stride,
-                                                                   twin_batch_stride, per_sample, flags, amax, twin_chunked());
+                                                                   twin_batch_stride, per_sample, flags, amax);
     return check_launch("snvc_act_backward_apply_twin");
 }
 

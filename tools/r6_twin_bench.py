@@ -1,4 +1,4 @@
-"""r6: the twin-writing passes at the cfg4 layer sizes (GB/s of algorithmic bytes); knobs through the environment (SNVC_TWIN_CAP, SNVC_TWIN_CHUNK)."""
+"""r6: the twin-writing passes at the cfg4 layer sizes (GB/s of algorithmic bytes).  (The workgroup-count / chunking knobs of item 19 were environment variables of an experimental build; the product has the defaults.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
